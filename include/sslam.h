@@ -1,0 +1,215 @@
+/*
+ * sslam.h — C-ABI of the MI355X-native semantic_slam hot path (libsslam_hip.so).
+ *
+ * Plain pointers and sizes only; no torch / g2o / PCL / ROS types.  Every entry point names the
+ * reference interface it replaces (paths relative to the reference repository root).
+ * The C++ shims that give these the reference's own method names live in
+ *   include/ps_graph_slam_amd/graph_slam.hpp              (ps_graph_slam::GraphSLAM)
+ *   include/planar_segmentation_amd/point_cloud_segmentation.hpp (point_cloud_segmentation)
+ * and INTEGRATION.md shows the binding a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - return value: >= 0 success (ids / counts where stated), < 0 error (sslam_last_error()).
+ *   - poses: 7 doubles  t(x,y,z) q(x,y,z,w)   (same order as g2o's VERTEX_SE3:QUAT row)
+ *   - information matrices: dense row-major d x d doubles (d = 6 or 3)
+ *   - handles are not re-entrant; different handles may be used from different threads.
+ *   - all compute runs on the GPU; there is NO CPU fallback: without a HIP device
+ *     sslam_graph_optimize()/sslam_seg_segment() fail with SSLAM_ERR_NO_DEVICE.
+ */
+#ifndef SSLAM_H
+#define SSLAM_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SSLAM_OK 0
+#define SSLAM_ERR_INVALID (-1)
+#define SSLAM_ERR_NO_DEVICE (-2)
+#define SSLAM_ERR_HIP (-3)
+#define SSLAM_ERR_NUMERIC (-4)      /* non-finite chi2 / factorisation breakdown */
+#define SSLAM_ERR_TOO_FEW_EDGES (-5) /* reference: graph_slam.cpp:184-186 returns false */
+#define SSLAM_ERR_UNSUPPORTED (-6)
+#define SSLAM_ERR_IO (-7)
+
+const char* sslam_last_error(void);
+/* number of visible HIP devices (0 on a CPU-only box; never fails) */
+int sslam_device_count(void);
+
+/* ============================================================================================
+ * Backend: ps_graph_slam::GraphSLAM  (reference include/ps_graph_slam/graph_slam.hpp:37-144)
+ * ==========================================================================================*/
+typedef struct sslam_graph sslam_graph;
+
+typedef struct sslam_opt_stats {
+  int iterations;        /* LM iterations performed (g2o SparseOptimizer::optimize return value) */
+  int trials;            /* linear solves (accepted + rejected LM trials) */
+  int status;            /* 0 = iteration cap reached, 1 = LM terminated (10 failed trials or rho == 0),
+                            <0 = SSLAM_ERR_* */
+  int reserved;
+  double chi2_before;    /* graph->chi2() before (graph_slam.cpp:202) */
+  double chi2_after;     /* graph->chi2() after  (graph_slam.cpp:211) */
+  double lambda;         /* final LM damping */
+  double seconds;        /* wall time of the call (graph_slam.cpp:204-215 "time:") */
+  int64_t solver_iterations; /* PCG iterations summed over trials (0 for the direct solver) */
+} sslam_opt_stats;
+
+/* GraphSLAM::GraphSLAM (graph_slam.cpp:40-97): LM over block-sparse normal equations, sensor
+ * offset parameter id 0 = identity.  device = HIP device ordinal. */
+sslam_graph* sslam_graph_create(int device);
+/* GraphSLAM::~GraphSLAM (graph_slam.cpp:102) */
+void sslam_graph_destroy(sslam_graph* g);
+
+/* add_se3_node (graph_slam.cpp:104-115).  The reference fixes the first vertex of the graph;
+ * pass fixed = -1 to get exactly that rule, 0/1 to force.  Returns the vertex id (= number of
+ * vertices before the call, graph_slam.cpp:106). */
+int sslam_graph_add_vertex_se3(sslam_graph* g, const double t_q[7], int fixed);
+/* add_point_xyz_node (graph_slam.cpp:127-134) */
+int sslam_graph_add_vertex_point(sslam_graph* g, const double p[3]);
+/* add_plane_node (commented out in the reference, graph_slam.cpp:117-125; g2o::VertexPlane) */
+int sslam_graph_add_vertex_plane(sslam_graph* g, const double n_d[4]);
+
+/* add_se3_edge (graph_slam.cpp:136-148): g2o::EdgeSE3 between SE3 vertices i and j. Returns edge id. */
+int sslam_graph_add_edge_se3(sslam_graph* g, int i, int j, const double z_tq[7], const double info[36]);
+/* add_se3_point_xyz_edge (graph_slam.cpp:150-166): g2o::EdgeSE3PointXYZ, offset parameter 0.
+ * The reference passes an uninitialised robust-kernel pointer (quirk B1); no kernel is applied. */
+int sslam_graph_add_edge_se3_point(sslam_graph* g, int i, int l, const double z[3], const double info[9]);
+/* add_se3_plane_edge (commented out, graph_slam.hpp:73-75) -> g2o::EdgeSE3Plane
+ * (reference include/g2o/edge_se3_plane.hpp:8-48; numeric Jacobian). */
+int sslam_graph_add_edge_se3_plane(sslam_graph* g, int i, int l, const double z[4], const double info[9]);
+
+int sslam_graph_num_vertices(const sslam_graph* g);
+int sslam_graph_num_edges(const sslam_graph* g);
+
+/* vertex->estimate() / setEstimate(); out has 7 (SE3), 3 (point) or 4 (plane) doubles */
+int sslam_graph_get_vertex(const sslam_graph* g, int id, double* out);
+int sslam_graph_set_vertex(sslam_graph* g, int id, const double* in);
+/* vertex->hessianIndex() after initializeOptimization (used at semantic_graph_slam.cpp:188-190):
+ * scalar offset in g2o's ordering (non-fixed vertices with edges, by id), or -1. */
+int sslam_graph_hessian_index(sslam_graph* g, int id);
+
+/* Options (doubles): "solver" 0 = PCG (block-Jacobi, matrix-free Schur optional), 1 = sparse block
+ * Cholesky; "pcg_tol" relative residual; "pcg_max_iters"; "schur" 0/1; "deterministic" 0/1 */
+int sslam_graph_set_option(sslam_graph* g, const char* key, double value);
+
+/* GraphSLAM::optimize (graph_slam.cpp:182-219) with the iteration cap as a parameter (the
+ * reference hard-codes 1024, graph_slam.cpp:205).  Fewer than 10 edges: returns
+ * SSLAM_ERR_TOO_FEW_EDGES and leaves the graph untouched (graph_slam.cpp:184-186). */
+int sslam_graph_optimize(sslam_graph* g, int max_iters, sslam_opt_stats* out);
+
+/* graph->chi2() at the current estimates */
+int sslam_graph_chi2(sslam_graph* g, double* chi2);
+
+/* computeLandmarkMarginals (graph_slam.cpp:221-234): diagonal blocks of H^-1 at the current
+ * linearisation for the listed vertex ids (the caller asks for (idx,idx) pairs only,
+ * semantic_graph_slam.cpp:186-191); out = packed row-major d x d blocks. */
+int sslam_graph_marginals(sslam_graph* g, const int* ids, int n, double* out_blocks);
+
+/* GraphSLAM::save (graph_slam.cpp:236-239): g2o text format */
+int sslam_graph_save_g2o(const sslam_graph* g, const char* path);
+/* inverse of save (the reference has no load path) */
+int sslam_graph_load_g2o(sslam_graph* g, const char* path);
+
+/* ---- parity / measurement hooks (no reference counterpart) ---------------------------------
+ * Linearise at the current estimates (BlockSolver::buildSystem) and copy the normal equations to
+ * the host as dense blocks in g2o hessian-index order.  Two-call protocol: pass NULL arrays to
+ * obtain counts.  H is returned as COO over scalar entries of the upper triangle. */
+int sslam_graph_linearize(sslam_graph* g, int* dim, int64_t* nnz_upper, int32_t* rows, int32_t* cols,
+                          double* vals, double* b);
+/* solve (H + lambda I) x = b for the current linearisation; x in g2o hessian-index order */
+int sslam_graph_solve(sslam_graph* g, double lambda, double* x, int64_t* solver_iterations);
+/* x <- x [+] dx for all active vertices (VertexSE3/PointXYZ/Plane::oplus) */
+int sslam_graph_oplus(sslam_graph* g, const double* dx);
+
+/* ---- batched, device-resident form (MI355X extension) ---------------------------------------
+ * B independent graphs laid out contiguously in HBM and optimised together: every kernel runs
+ * over the union, LM control (rho, lambda, accept/reject) is per graph on the device. */
+typedef struct sslam_batch sslam_batch;
+sslam_batch* sslam_batch_create(sslam_graph* const* graphs, int n);
+void sslam_batch_destroy(sslam_batch* b);
+/* re-upload the host graphs' current estimates (resets the device state) */
+int sslam_batch_upload(sslam_batch* b);
+/* copy optimised estimates back into the host graphs */
+int sslam_batch_download(sslam_batch* b);
+int sslam_batch_optimize(sslam_batch* b, int max_iters, sslam_opt_stats* out /* [n] */);
+/* run only the Jacobian build (linearise + assemble) `repeats` times; returns mean kernel
+ * milliseconds measured with hipEvents on the batch's stream */
+int sslam_batch_time_linearize(sslam_batch* b, int repeats, double* ms_per_build);
+/* algorithmic bytes of one Jacobian build over the whole batch (SURVEY §8d formula) */
+int64_t sslam_batch_linearize_bytes(const sslam_batch* b);
+/* per-kernel accumulated hipEvent time since the last reset (profiling must be enabled with
+ * sslam_batch_set_profiling); names: "linearize","chi2","spmv","pcg_update","precond","oplus","factor","solve" */
+int sslam_batch_set_profiling(sslam_batch* b, int enable);
+int sslam_batch_kernel_time(sslam_batch* b, const char* name, double* total_ms, int64_t* launches);
+
+/* ============================================================================================
+ * Frontend: point_cloud_segmentation::segmentallPointCloudData
+ *           (reference include/planar_segmentation/point_cloud_segmentation.h:105-181)
+ * ==========================================================================================*/
+typedef struct sslam_seg sslam_seg;
+
+typedef struct sslam_seg_params {
+  double num_point_seg;     /* ~num_point_seg   default 500  (plane_segmentation.cpp:7)  */
+  double norm_point_thres;  /* ~norm_point_thres default 5000 (plane_segmentation.cpp:8)  */
+  double planar_area;       /* ~planar_area     default 0.1  (plane_segmentation.cpp:9)  */
+  float max_depth_change_factor; /* 0.03  (plane_segmentation.cpp:99)  */
+  float normal_smoothing_size;   /* 20    (plane_segmentation.cpp:100) */
+  float angular_threshold;       /* 0.017453*2 rad (plane_segmentation.cpp:140) */
+  float distance_threshold;      /* 0.02 m (plane_segmentation.cpp:141) */
+  float maximum_curvature;       /* PCL default 0.001 */
+  int min_contour_points;        /* > 100 (plane_segmentation.cpp:169) */
+  int image_width, image_height; /* 640 x 480 crop bounds (plane_segmentation.cpp:34-35) */
+  int reference_quirks;          /* 1: reproduce tools.h:80-81 typo (quirk B2) */
+  int device;
+} sslam_seg_params;
+
+/* semantic_SLAM::ObjectInfo (msg/ObjectInfo.msg:1-6); class_id indexes SSLAM_CLASS_* below */
+typedef struct sslam_box {
+  int32_t tl_x, tl_y, width, height;
+  int32_t class_id;
+  float prob;
+} sslam_box;
+
+/* the class whitelist of point_cloud_segmentation.h:126-130 */
+enum { SSLAM_CLASS_OTHER = 0, SSLAM_CLASS_CHAIR, SSLAM_CLASS_TVMONITOR, SSLAM_CLASS_BOOK, SSLAM_CLASS_KEYBOARD,
+       SSLAM_CLASS_LAPTOP, SSLAM_CLASS_BUCKET, SSLAM_CLASS_CAR };
+
+/* detected_object (include/planar_segmentation/detected_object.h:14-24) */
+typedef struct sslam_plane {
+  float centroid_cam[3];  /* detected_object::pose */
+  float normal_d[4];      /* detected_object::normal_orientation (sign-normalised) */
+  float world_pose[3];    /* detected_object::world_pose */
+  float num_points;       /* contour point count (quirk B8) */
+  float prob;
+  int32_t plane_type;     /* 0 horizontal, 1 vertical */
+  int32_t class_id;
+  int32_t box_index;
+  int32_t inlier_count;   /* true inlier count (extension) */
+  float area;             /* polygon area of the contour */
+} sslam_plane;
+
+void sslam_seg_default_params(sslam_seg_params* p);
+sslam_seg* sslam_seg_create(const sslam_seg_params* p);
+void sslam_seg_destroy(sslam_seg* s);
+
+/* segmentallPointCloudData(robot_pose, cam_angle, object_info, point_cloud)
+ * cloud = sensor_msgs::PointCloud2::data of an organised width x height cloud; off_* = field
+ * offsets of x,y,z (plane_segmentation.cpp:48-61).  Returns the number of planes written. */
+int sslam_seg_segment(sslam_seg* s, const uint8_t* cloud, int width, int height, int point_step, int row_step,
+                      int off_x, int off_y, int off_z, const sslam_box* boxes, int n_boxes,
+                      const float robot_pose[6], float cam_angle, sslam_plane* out, int max_out);
+
+/* parity hooks: per-box products of the last sslam_seg_segment call.
+ * normals: w*h*4 floats (nx,ny,nz,curvature), labels: w*h int32 (-1 = no plane; otherwise the
+ * region index in output order of pcl::OrganizedMultiPlaneSegmentation::segmentAndRefine). */
+int sslam_seg_get_normals(sslam_seg* s, int box, float* out);
+int sslam_seg_get_labels(sslam_seg* s, int box, int32_t* out);
+/* semantic_tools::transformNormalsToWorld (include/tools.h:18-102): 4x4 row-major float */
+int sslam_seg_transform(const sslam_seg* s, const float robot_pose[6], float cam_angle, float out16[16]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SSLAM_H */

@@ -1,0 +1,737 @@
+/*
+ * TEST INFRASTRUCTURE — NOT PRODUCT CODE.
+ *
+ * Plain-C, single-threaded CPU restatement of the reference's graph-optimisation hot path
+ * (ps_graph_slam::GraphSLAM over g2o).  Only tests/, __graft_entry__.smoke() and bench.py's
+ * cpu_baseline leg may load this library; the product (semantic_slam_amd/csrc) never does.
+ *
+ * PARITY UNPINNED: the reference ships no tests / golden vectors for this path, and the
+ * arithmetic lives in un-vendored, un-pinned third-party code (g2o, "ros-$ROS_DISTRO-libg2o",
+ * reference README.md:41-43; CSparse) that is not installed here, so the reference cannot be
+ * built or run.  What is restated, and from where:
+ *
+ *   reference call sites (in tree)
+ *     - vertex/edge construction, first vertex fixed ....... src/ps_graph_slam/graph_slam.cpp:104-166
+ *     - optimize(): <10 edges -> false; initializeOptimization; optimize(1024)
+ *                                                            src/ps_graph_slam/graph_slam.cpp:182-219
+ *     - marginals of landmark diagonal blocks ............... src/ps_graph_slam/graph_slam.cpp:221-234,
+ *                                                            src/ps_graph_slam/semantic_graph_slam.cpp:181-205
+ *     - EdgeSE3Plane::computeError .......................... include/g2o/edge_se3_plane.hpp:15-24
+ *   published g2o algorithms (out of tree)
+ *     - VertexSE3 oplus / toVectorMQT / fromVectorMQT, EdgeSE3, EdgeSE3PointXYZ, Plane3D
+ *     - OptimizationAlgorithmLevenberg::solve (tau 1e-5, rho rule, 10 trials)
+ *     - BlockSolver::buildSystem  (H = sum J^T W J, b = -sum J^T W e, upper-triangular storage)
+ *     - LinearSolverCSparse: fill-reducing ordering on the BLOCK pattern, sparse Cholesky
+ *       (up-looking, elimination-tree based — T. Davis, "Direct Methods for Sparse Linear
+ *       Systems", ch. 4), triangular solves
+ *     - numeric Jacobian of BaseBinaryEdge (central differences, delta = 1e-9)
+ *
+ * Pinned instead by (tests/): finite differences, an independent numpy/scipy restatement
+ * (oracle/np_graph.py), scipy.optimize.least_squares, dense inverses, analytic invariants.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <stdio.h>
+#include <time.h>
+
+#define VT_SE3 0
+#define VT_POINT 1
+#define VT_PLANE 2
+#define ET_SE3 0
+#define ET_SE3_POINT 1
+#define ET_SE3_PLANE 2
+
+typedef struct {
+  int nv, ne;
+  const int *vtype;    /* [nv] */
+  const int *vfixed;   /* [nv] */
+  double *est;         /* [nv*7]  se3: t(3) q(xyzw); point: xyz; plane: n(3) d */
+  const int *etype;    /* [ne] */
+  const int *evi;      /* [ne] first vertex id (always the SE3 vertex) */
+  const int *evj;      /* [ne] */
+  const double *meas;  /* [ne*7] */
+  const double *info;  /* [ne*36] row-major dxd in the leading d*d entries */
+} og_problem;
+
+typedef struct {
+  int iterations;
+  int trials;
+  double chi2_before, chi2_after;
+  double lambda;
+  double seconds;
+  double seconds_linearize, seconds_solve;
+  int status; /* 0 ok, 1 terminated by trials/rho==0, -1 failure */
+} og_stats;
+
+/* ------------------------------------------------------------------ small math */
+static void q_mul(const double *a, const double *b, double *o) {
+  double ax = a[0], ay = a[1], az = a[2], aw = a[3];
+  double bx = b[0], by = b[1], bz = b[2], bw = b[3];
+  o[0] = aw * bx + ax * bw + ay * bz - az * by;
+  o[1] = aw * by - ax * bz + ay * bw + az * bx;
+  o[2] = aw * bz + ax * by - ay * bx + az * bw;
+  o[3] = aw * bw - ax * bx - ay * by - az * bz;
+}
+static void q_conj(const double *a, double *o) { o[0] = -a[0]; o[1] = -a[1]; o[2] = -a[2]; o[3] = a[3]; }
+static void q_to_R(const double *q, double R[9]) {
+  double x = q[0], y = q[1], z = q[2], w = q[3];
+  R[0] = 1 - 2 * (y * y + z * z); R[1] = 2 * (x * y - z * w); R[2] = 2 * (x * z + y * w);
+  R[3] = 2 * (x * y + z * w); R[4] = 1 - 2 * (x * x + z * z); R[5] = 2 * (y * z - x * w);
+  R[6] = 2 * (x * z - y * w); R[7] = 2 * (y * z + x * w); R[8] = 1 - 2 * (x * x + y * y);
+}
+static void R_mul_v(const double R[9], const double *v, double *o) {
+  double a = R[0] * v[0] + R[1] * v[1] + R[2] * v[2];
+  double b = R[3] * v[0] + R[4] * v[1] + R[5] * v[2];
+  double c = R[6] * v[0] + R[7] * v[1] + R[8] * v[2];
+  o[0] = a; o[1] = b; o[2] = c;
+}
+static void Rt_mul_v(const double R[9], const double *v, double *o) {
+  double a = R[0] * v[0] + R[3] * v[1] + R[6] * v[2];
+  double b = R[1] * v[0] + R[4] * v[1] + R[7] * v[2];
+  double c = R[2] * v[0] + R[5] * v[1] + R[8] * v[2];
+  o[0] = a; o[1] = b; o[2] = c;
+}
+static void q_rot(const double *q, const double *v, double *o) {
+  double R[9]; q_to_R(q, R); R_mul_v(R, v, o);
+}
+
+/* VertexSE3::oplus : X <- X * fromVectorMQT(d)    */
+static void se3_oplus(double *X, const double *d) {
+  double v2 = d[3] * d[3] + d[4] * d[4] + d[5] * d[5];
+  double w2 = 1.0 - v2;
+  double dq[4];
+  if (w2 < 0) { dq[0] = dq[1] = dq[2] = 0; dq[3] = 1; }
+  else { dq[0] = d[3]; dq[1] = d[4]; dq[2] = d[5]; dq[3] = sqrt(w2); }
+  double rt[3]; q_rot(X + 3, d, rt);
+  X[0] += rt[0]; X[1] += rt[1]; X[2] += rt[2];
+  double q[4]; q_mul(X + 3, dq, q);
+  double n = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+  X[3] = q[0] / n; X[4] = q[1] / n; X[5] = q[2] / n; X[6] = q[3] / n;
+}
+
+/* EdgeSE3: e = toVectorMQT(Z^-1 Xi^-1 Xj); Ji, Jj 6x6 row-major (NULL to skip) */
+static void se3_edge(const double *Xi, const double *Xj, const double *Z, double *e, double *Ji, double *Jj) {
+  double qzi[4], qii[4], d[3], tb[3], qb[4], tmp[3], te[3], qe[4];
+  q_conj(Z + 3, qzi); q_conj(Xi + 3, qii);
+  d[0] = Xj[0] - Xi[0]; d[1] = Xj[1] - Xi[1]; d[2] = Xj[2] - Xi[2];
+  q_rot(qii, d, tb);
+  q_mul(qii, Xj + 3, qb);
+  tmp[0] = tb[0] - Z[0]; tmp[1] = tb[1] - Z[1]; tmp[2] = tb[2] - Z[2];
+  q_rot(qzi, tmp, te);
+  q_mul(qzi, qb, qe);
+  double s = qe[3] < 0 ? -1.0 : 1.0;
+  e[0] = te[0]; e[1] = te[1]; e[2] = te[2];
+  e[3] = s * qe[0]; e[4] = s * qe[1]; e[5] = s * qe[2];
+  if (!Ji) return;
+  double Ra[9], Re[9];
+  q_to_R(qzi, Ra); q_to_R(qe, Re);
+  memset(Ji, 0, 36 * sizeof(double)); memset(Jj, 0, 36 * sizeof(double));
+  /* dte/ddt_i = -Ra ; dte/ddq_i = 2 Ra [tb]x */
+  double S[9] = {0, -tb[2], tb[1], tb[2], 0, -tb[0], -tb[1], tb[0], 0};
+  for (int r = 0; r < 3; ++r)
+    for (int c = 0; c < 3; ++c) {
+      Ji[r * 6 + c] = -Ra[r * 3 + c];
+      double a = 0;
+      for (int k = 0; k < 3; ++k) a += Ra[r * 3 + k] * S[k * 3 + c];
+      Ji[r * 6 + 3 + c] = 2.0 * a;
+      Jj[r * 6 + c] = Re[r * 3 + c];
+    }
+  /* dq_e/ddq_i: -s * xyz(qzi * (e_k,0) * qb) */
+  for (int k = 0; k < 3; ++k) {
+    double vk[4] = {0, 0, 0, 0}, t1[4], t2[4];
+    vk[k] = 1.0;
+    q_mul(qzi, vk, t1); q_mul(t1, qb, t2);
+    for (int r = 0; r < 3; ++r) Ji[(3 + r) * 6 + 3 + k] = -s * t2[r];
+  }
+  /* dq_e/ddq_j: s * (w I + [xyz]x) */
+  double w = qe[3], x = qe[0], y = qe[1], z = qe[2];
+  double M[9] = {w, -z, y, z, w, -x, -y, x, w};
+  for (int r = 0; r < 3; ++r)
+    for (int c = 0; c < 3; ++c) Jj[(3 + r) * 6 + 3 + c] = s * M[r * 3 + c];
+}
+
+/* EdgeSE3PointXYZ (offset = identity, graph_slam.cpp:75-83,162): e = Ri^T (p - ti) - z */
+static void point_edge(const double *Xi, const double *p, const double *z, double *e, double *Ji, double *Jl) {
+  double R[9]; q_to_R(Xi + 3, R);
+  double d[3] = {p[0] - Xi[0], p[1] - Xi[1], p[2] - Xi[2]}, pc[3];
+  Rt_mul_v(R, d, pc);
+  e[0] = pc[0] - z[0]; e[1] = pc[1] - z[1]; e[2] = pc[2] - z[2];
+  if (!Ji) return;
+  memset(Ji, 0, 18 * sizeof(double));
+  Ji[0] = -1; Ji[7] = -1; Ji[14] = -1;
+  Ji[0 * 6 + 4] = -2 * pc[2]; Ji[0 * 6 + 5] = 2 * pc[1];
+  Ji[1 * 6 + 3] = 2 * pc[2];  Ji[1 * 6 + 5] = -2 * pc[0];
+  Ji[2 * 6 + 3] = -2 * pc[1]; Ji[2 * 6 + 4] = 2 * pc[0];
+  for (int r = 0; r < 3; ++r)
+    for (int c = 0; c < 3; ++c) Jl[r * 3 + c] = R[c * 3 + r];
+}
+
+/* ---- Plane3D (g2o slam3d_addons) */
+static double pl_azimuth(const double *n) { return atan2(n[1], n[0]); }
+static double pl_elevation(const double *n) { return atan2(n[2], sqrt(n[0] * n[0] + n[1] * n[1])); }
+static void pl_rotation(const double *n, double R[9]) { /* Rz(az) * Ry(-el) */
+  double a = pl_azimuth(n), el = pl_elevation(n);
+  double ca = cos(a), sa = sin(a), cb = cos(-el), sb = sin(-el);
+  R[0] = ca * cb; R[1] = -sa; R[2] = ca * sb;
+  R[3] = sa * cb; R[4] = ca;  R[5] = sa * sb;
+  R[6] = -sb;     R[7] = 0;   R[8] = cb;
+}
+static void pl_normalize(double *p) {
+  double n = sqrt(p[0] * p[0] + p[1] * p[1] + p[2] * p[2]);
+  p[0] /= n; p[1] /= n; p[2] /= n; p[3] /= n;
+}
+static void pl_oplus(double *p, const double *v) {
+  double R[9]; pl_rotation(p, R);
+  double s[3] = {cos(v[1]) * cos(v[0]), cos(v[1]) * sin(v[0]), sin(v[1])}, n[3];
+  R_mul_v(R, s, n);
+  double d = -(-p[3] + v[2]);
+  p[0] = n[0]; p[1] = n[1]; p[2] = n[2]; p[3] = d;
+  pl_normalize(p);
+}
+/* e = (Xi^-1 ∘ pi_w) ⊖ z   (edge_se3_plane.hpp:21-23) */
+static void plane_err(const double *Xi, const double *pw, const double *z, double *e) {
+  double qi[4], ti[3], n[3], tmp[3];
+  q_conj(Xi + 3, qi);
+  q_rot(qi, Xi, tmp); ti[0] = -tmp[0]; ti[1] = -tmp[1]; ti[2] = -tmp[2];
+  q_rot(qi, pw, n);
+  double d = pw[3] - (ti[0] * n[0] + ti[1] * n[1] + ti[2] * n[2]);
+  double R[9], m[3]; pl_rotation(n, R); Rt_mul_v(R, z, m);
+  e[0] = pl_azimuth(m); e[1] = pl_elevation(m); e[2] = -d + z[3];
+}
+static void plane_edge(const double *Xi, const double *pw, const double *z, double *e, double *Ji, double *Jl) {
+  plane_err(Xi, pw, z, e);
+  if (!Ji) return;
+  const double delta = 1e-9, scalar = 1.0 / (2 * delta);
+  for (int d = 0; d < 6; ++d) {
+    double X[7], dv[6] = {0, 0, 0, 0, 0, 0}, ep[3], em[3];
+    memcpy(X, Xi, sizeof X); dv[d] = delta; se3_oplus(X, dv); plane_err(X, pw, z, ep);
+    memcpy(X, Xi, sizeof X); dv[d] = -delta; se3_oplus(X, dv); plane_err(X, pw, z, em);
+    for (int r = 0; r < 3; ++r) Ji[r * 6 + d] = scalar * (ep[r] - em[r]);
+  }
+  for (int d = 0; d < 3; ++d) {
+    double P[4], dv[3] = {0, 0, 0}, ep[3], em[3];
+    memcpy(P, pw, sizeof P); dv[d] = delta; pl_oplus(P, dv); plane_err(Xi, P, z, ep);
+    memcpy(P, pw, sizeof P); dv[d] = -delta; pl_oplus(P, dv); plane_err(Xi, P, z, em);
+    for (int r = 0; r < 3; ++r) Jl[r * 3 + d] = scalar * (ep[r] - em[r]);
+  }
+}
+
+static int vdim(int t) { return t == VT_SE3 ? 6 : 3; }
+static int edim(int t) { return t == ET_SE3 ? 6 : 3; }
+
+/* evaluate one edge: error e (dim d), Jacobians Ji (d x di), Jj (d x dj) */
+static void edge_eval(const og_problem *P, const double *est, int k, double *e, double *Ji, double *Jj) {
+  const double *Xi = est + 7 * (size_t)P->evi[k], *Xj = est + 7 * (size_t)P->evj[k];
+  const double *z = P->meas + 7 * (size_t)k;
+  switch (P->etype[k]) {
+    case ET_SE3: se3_edge(Xi, Xj, z, e, Ji, Jj); break;
+    case ET_SE3_POINT: point_edge(Xi, Xj, z, e, Ji, Jj); break;
+    default: plane_edge(Xi, Xj, z, e, Ji, Jj); break;
+  }
+}
+
+static double edge_chi2(const og_problem *P, const double *est, int k) {
+  double e[6];
+  edge_eval(P, est, k, e, NULL, NULL);
+  int d = edim(P->etype[k]);
+  const double *W = P->info + 36 * (size_t)k;
+  double c = 0;
+  for (int r = 0; r < d; ++r) {
+    double a = 0;
+    for (int s = 0; s < d; ++s) a += W[r * d + s] * e[s];
+    c += e[r] * a;
+  }
+  return c;
+}
+
+double og_chi2(const og_problem *P) {
+  double c = 0;
+  for (int k = 0; k < P->ne; ++k) c += edge_chi2(P, P->est, k);
+  return c;
+}
+
+void og_edge_eval(const og_problem *P, int k, double *e, double *Ji, double *Jj) { edge_eval(P, P->est, k, e, Ji, Jj); }
+
+void og_oplus(const og_problem *P, const int *hidx, const double *dx, double *est) {
+  for (int v = 0; v < P->nv; ++v) {
+    if (hidx[v] < 0) continue;
+    const double *d = dx + hidx[v];
+    double *x = est + 7 * (size_t)v;
+    if (P->vtype[v] == VT_SE3) se3_oplus(x, d);
+    else if (P->vtype[v] == VT_POINT) { x[0] += d[0]; x[1] += d[1]; x[2] += d[2]; }
+    else pl_oplus(x, d);
+  }
+}
+
+/* g2o initializeOptimization: non-fixed vertices that own at least one edge get consecutive
+ * hessian indices in id order (A.2). Returns total dimension. */
+int og_hessian_index(const og_problem *P, int *hidx) {
+  char *has = (char *)calloc(P->nv, 1);
+  for (int k = 0; k < P->ne; ++k) { has[P->evi[k]] = 1; has[P->evj[k]] = 1; }
+  int off = 0;
+  for (int v = 0; v < P->nv; ++v) {
+    if (P->vfixed[v] || !has[v]) hidx[v] = -1;
+    else { hidx[v] = off; off += vdim(P->vtype[v]); }
+  }
+  free(has);
+  return off;
+}
+
+/* ------------------------------------------------------------------ sparse system */
+typedef struct {
+  int n;        /* scalar dimension */
+  int nb;       /* number of block rows (active vertices) */
+  int *boff;    /* [nb+1] scalar offset of each block (hessian order) */
+  int *v2b;     /* [nv] vertex -> block or -1 */
+  /* upper-triangular CSC (incl. diagonal), sorted rows */
+  int *Ap, *Ai; double *Ax;
+  /* per-edge scatter map: for each edge, positions of the (up to) 3 blocks ii, ij, jj */
+  int *pos_ii, *pos_ij, *pos_jj; /* [ne] index into Ax of the block's (0,0) entry is not enough
+                                    for CSC; we store per-edge base into 'map' instead */
+  int *map;     /* concatenated entry positions */
+  int *map_off; /* [ne+1] */
+  double *b;
+  /* block pattern for ordering */
+  int *perm, *pinv; /* scalar permutation: perm[new] = old */
+  /* factor */
+  int *parent, *Lp, *Li; double *Lx;
+  int lnz;
+} og_system;
+
+static int cmp_i64(const void *a, const void *b) {
+  int64_t x = *(const int64_t *)a, y = *(const int64_t *)b;
+  return x < y ? -1 : (x > y);
+}
+
+static int find_pos(const og_system *S, int r, int c) { /* entry (r,c), r<=c, in upper CSC */
+  int lo = S->Ap[c], hi = S->Ap[c + 1] - 1;
+  while (lo <= hi) {
+    int mid = (lo + hi) >> 1;
+    if (S->Ai[mid] == r) return mid;
+    if (S->Ai[mid] < r) lo = mid + 1; else hi = mid - 1;
+  }
+  return -1;
+}
+
+static void sys_structure(const og_problem *P, const int *hidx, int n, og_system *S) {
+  memset(S, 0, sizeof *S);
+  S->n = n;
+  /* collect upper-triangular scalar coordinates from the block pattern */
+  size_t cap = 0;
+  for (int k = 0; k < P->ne; ++k) {
+    int di = vdim(P->vtype[P->evi[k]]), dj = vdim(P->vtype[P->evj[k]]);
+    cap += (size_t)di * di + (size_t)dj * dj + (size_t)di * dj;
+  }
+  int64_t *keys = (int64_t *)malloc((cap + 1) * sizeof(int64_t));
+  size_t nk = 0;
+  for (int k = 0; k < P->ne; ++k) {
+    int vi = P->evi[k], vj = P->evj[k];
+    int oi = hidx[vi], oj = hidx[vj];
+    int di = vdim(P->vtype[vi]), dj = vdim(P->vtype[vj]);
+    if (oi >= 0)
+      for (int r = 0; r < di; ++r) for (int c = r; c < di; ++c) keys[nk++] = (int64_t)(oi + c) * n + (oi + r);
+    if (oj >= 0)
+      for (int r = 0; r < dj; ++r) for (int c = r; c < dj; ++c) keys[nk++] = (int64_t)(oj + c) * n + (oj + r);
+    if (oi >= 0 && oj >= 0) {
+      for (int r = 0; r < di; ++r) for (int c = 0; c < dj; ++c) {
+        int R = oi + r, C = oj + c;
+        if (R > C) { int t = R; R = C; C = t; }
+        keys[nk++] = (int64_t)C * n + R;
+      }
+    }
+  }
+  qsort(keys, nk, sizeof(int64_t), cmp_i64);
+  size_t nu = 0;
+  for (size_t i = 0; i < nk; ++i) if (i == 0 || keys[i] != keys[i - 1]) keys[nu++] = keys[i];
+  S->Ap = (int *)calloc(n + 1, sizeof(int));
+  S->Ai = (int *)malloc(nu * sizeof(int));
+  S->Ax = (double *)calloc(nu, sizeof(double));
+  for (size_t i = 0; i < nu; ++i) { int c = (int)(keys[i] / n); S->Ap[c + 1]++; S->Ai[i] = (int)(keys[i] % n); }
+  for (int c = 0; c < n; ++c) S->Ap[c + 1] += S->Ap[c];
+  free(keys);
+  /* scatter map */
+  S->map_off = (int *)malloc((P->ne + 1) * sizeof(int));
+  S->map = (int *)malloc(cap * sizeof(int));
+  size_t m = 0;
+  for (int k = 0; k < P->ne; ++k) {
+    S->map_off[k] = (int)m;
+    int vi = P->evi[k], vj = P->evj[k];
+    int oi = hidx[vi], oj = hidx[vj];
+    int di = vdim(P->vtype[vi]), dj = vdim(P->vtype[vj]);
+    for (int r = 0; r < di; ++r) for (int c = 0; c < di; ++c)
+      S->map[m++] = (oi >= 0 && r <= c) ? find_pos(S, oi + r, oi + c) : -1;
+    for (int r = 0; r < dj; ++r) for (int c = 0; c < dj; ++c)
+      S->map[m++] = (oj >= 0 && r <= c) ? find_pos(S, oj + r, oj + c) : -1;
+    for (int r = 0; r < di; ++r) for (int c = 0; c < dj; ++c) {
+      if (oi >= 0 && oj >= 0) {
+        int R = oi + r, C = oj + c;
+        /* store H_ij entry (R,C) if R<C ; if the block lies below the diagonal (oj<oi) we store
+           its transpose entry (C,R) */
+        if (R > C) { int t = R; R = C; C = t; }
+        S->map[m++] = find_pos(S, R, C);
+      } else S->map[m++] = -1;
+    }
+  }
+  S->map_off[P->ne] = (int)m;
+  S->b = (double *)calloc(n, sizeof(double));
+}
+
+/* buildSystem: H = sum J^T W J (upper), b = -sum J^T W e   (A.3/A.4) */
+static void sys_build(const og_problem *P, const int *hidx, og_system *S) {
+  memset(S->Ax, 0, (size_t)S->Ap[S->n] * sizeof(double));
+  memset(S->b, 0, (size_t)S->n * sizeof(double));
+  for (int k = 0; k < P->ne; ++k) {
+    double e[6], Ji[36], Jj[36], WJi[36], WJj[36], We[6];
+    edge_eval(P, P->est, k, e, Ji, Jj);
+    int vi = P->evi[k], vj = P->evj[k];
+    int oi = hidx[vi], oj = hidx[vj];
+    int di = vdim(P->vtype[vi]), dj = vdim(P->vtype[vj]);
+    int d = edim(P->etype[k]);
+    const double *W = P->info + 36 * (size_t)k;
+    for (int r = 0; r < d; ++r) {
+      for (int c = 0; c < di; ++c) { double a = 0; for (int s = 0; s < d; ++s) a += W[r * d + s] * Ji[s * di + c]; WJi[r * di + c] = a; }
+      for (int c = 0; c < dj; ++c) { double a = 0; for (int s = 0; s < d; ++s) a += W[r * d + s] * Jj[s * dj + c]; WJj[r * dj + c] = a; }
+      double a = 0; for (int s = 0; s < d; ++s) a += W[r * d + s] * e[s]; We[r] = a;
+    }
+    const int *mp = S->map + S->map_off[k];
+    for (int r = 0; r < di; ++r) for (int c = 0; c < di; ++c, ++mp) if (*mp >= 0) {
+      double a = 0; for (int s = 0; s < d; ++s) a += Ji[s * di + r] * WJi[s * di + c]; S->Ax[*mp] += a; }
+    for (int r = 0; r < dj; ++r) for (int c = 0; c < dj; ++c, ++mp) if (*mp >= 0) {
+      double a = 0; for (int s = 0; s < d; ++s) a += Jj[s * dj + r] * WJj[s * dj + c]; S->Ax[*mp] += a; }
+    for (int r = 0; r < di; ++r) for (int c = 0; c < dj; ++c, ++mp) if (*mp >= 0) {
+      double a = 0; for (int s = 0; s < d; ++s) a += Ji[s * di + r] * WJj[s * dj + c]; S->Ax[*mp] += a; }
+    if (oi >= 0) for (int r = 0; r < di; ++r) { double a = 0; for (int s = 0; s < d; ++s) a += Ji[s * di + r] * We[s]; S->b[oi + r] -= a; }
+    if (oj >= 0) for (int r = 0; r < dj; ++r) { double a = 0; for (int s = 0; s < d; ++s) a += Jj[s * dj + r] * We[s]; S->b[oj + r] -= a; }
+  }
+}
+
+/* ---- fill-reducing ordering on the block pattern (minimum degree, explicit fill graph) */
+typedef struct { int *a; int n, cap; } ivec;
+static void iv_push(ivec *v, int x) {
+  if (v->n == v->cap) { v->cap = v->cap ? 2 * v->cap : 8; v->a = (int *)realloc(v->a, v->cap * sizeof(int)); }
+  v->a[v->n++] = x;
+}
+static int iv_has(const ivec *v, int x) { for (int i = 0; i < v->n; ++i) if (v->a[i] == x) return 1; return 0; }
+static void iv_remove(ivec *v, int x) { for (int i = 0; i < v->n; ++i) if (v->a[i] == x) { v->a[i] = v->a[--v->n]; return; } }
+
+static void block_min_degree(const og_problem *P, const int *hidx, int nb, const int *v2b, int *order) {
+  ivec *adj = (ivec *)calloc(nb, sizeof(ivec));
+  for (int k = 0; k < P->ne; ++k) {
+    int a = v2b[P->evi[k]], b = v2b[P->evj[k]];
+    if (a < 0 || b < 0 || a == b) continue;
+    if (!iv_has(&adj[a], b)) { iv_push(&adj[a], b); iv_push(&adj[b], a); }
+  }
+  (void)hidx;
+  char *done = (char *)calloc(nb, 1);
+  /* bucketed degree lists would be faster; nb <= ~10^4 so a heap-free scan with lazy minimum is fine */
+  int *deg = (int *)malloc(nb * sizeof(int));
+  for (int i = 0; i < nb; ++i) deg[i] = adj[i].n;
+  for (int step = 0; step < nb; ++step) {
+    int best = -1;
+    for (int i = 0; i < nb; ++i) if (!done[i] && (best < 0 || deg[i] < deg[best])) best = i;
+    order[step] = best; done[best] = 1;
+    ivec *nb_ = &adj[best];
+    for (int x = 0; x < nb_->n; ++x) iv_remove(&adj[nb_->a[x]], best);
+    for (int x = 0; x < nb_->n; ++x)
+      for (int y = x + 1; y < nb_->n; ++y) {
+        int u = nb_->a[x], w = nb_->a[y];
+        if (!iv_has(&adj[u], w)) { iv_push(&adj[u], w); iv_push(&adj[w], u); }
+      }
+    for (int x = 0; x < nb_->n; ++x) deg[nb_->a[x]] = adj[nb_->a[x]].n;
+  }
+  for (int i = 0; i < nb; ++i) free(adj[i].a);
+  free(adj); free(done); free(deg);
+}
+
+/* C = P A P^T (upper), standard symmetric permutation of an upper-triangular CSC */
+static void sym_perm(int n, const int *Ap, const int *Ai, const double *Ax, const int *pinv, int *Cp, int *Ci, double *Cx) {
+  int *w = (int *)calloc(n, sizeof(int));
+  for (int j = 0; j < n; ++j) {
+    int j2 = pinv[j];
+    for (int p = Ap[j]; p < Ap[j + 1]; ++p) {
+      int i = Ai[p]; if (i > j) continue;
+      int i2 = pinv[i];
+      w[i2 > j2 ? i2 : j2]++;
+    }
+  }
+  Cp[0] = 0; for (int j = 0; j < n; ++j) { Cp[j + 1] = Cp[j] + w[j]; w[j] = Cp[j]; }
+  for (int j = 0; j < n; ++j) {
+    int j2 = pinv[j];
+    for (int p = Ap[j]; p < Ap[j + 1]; ++p) {
+      int i = Ai[p]; if (i > j) continue;
+      int i2 = pinv[i];
+      int q = w[i2 > j2 ? i2 : j2]++;
+      Ci[q] = i2 < j2 ? i2 : j2;
+      if (Cx) Cx[q] = Ax[p];
+    }
+  }
+  free(w);
+}
+
+static void etree(int n, const int *Ap, const int *Ai, int *parent) {
+  int *anc = (int *)malloc(n * sizeof(int));
+  for (int k = 0; k < n; ++k) {
+    parent[k] = -1; anc[k] = -1;
+    for (int p = Ap[k]; p < Ap[k + 1]; ++p) {
+      int i = Ai[p];
+      while (i != -1 && i < k) {
+        int inext = anc[i]; anc[i] = k;
+        if (inext == -1) parent[i] = k;
+        i = inext;
+      }
+    }
+  }
+  free(anc);
+}
+
+/* nonzero pattern of row k of L: reach of A(0:k-1,k) in the etree; returns top, s[top..n-1] */
+static int ereach(int n, const int *Ap, const int *Ai, int k, const int *parent, int *s, int *w) {
+  int top = n;
+  w[k] = k;
+  for (int p = Ap[k]; p < Ap[k + 1]; ++p) {
+    int i = Ai[p];
+    if (i > k) continue;
+    int len = 0;
+    for (; w[i] != k; i = parent[i]) { s[len++] = i; w[i] = k; }
+    while (len > 0) s[--top] = s[--len];
+  }
+  return top;
+}
+
+typedef struct {
+  int n; int *perm, *pinv; int *Cp, *Ci; double *Cx; int *parent; int *Lp, *Li; double *Lx; int *cnt;
+} og_chol;
+
+static void chol_free(og_chol *C) {
+  free(C->perm); free(C->pinv); free(C->Cp); free(C->Ci); free(C->Cx); free(C->parent);
+  free(C->Lp); free(C->Li); free(C->Lx); free(C->cnt);
+  memset(C, 0, sizeof *C);
+}
+
+/* symbolic: ordering (given scalar perm), permuted pattern, etree, column counts */
+static void chol_symbolic(og_chol *C, int n, const int *Ap, const int *Ai, const int *perm) {
+  memset(C, 0, sizeof *C);
+  C->n = n;
+  C->perm = (int *)malloc(n * sizeof(int)); C->pinv = (int *)malloc(n * sizeof(int));
+  memcpy(C->perm, perm, n * sizeof(int));
+  for (int i = 0; i < n; ++i) C->pinv[perm[i]] = i;
+  int nnz = Ap[n];
+  C->Cp = (int *)malloc((n + 1) * sizeof(int)); C->Ci = (int *)malloc(nnz * sizeof(int)); C->Cx = (double *)malloc(nnz * sizeof(double));
+  sym_perm(n, Ap, Ai, NULL, C->pinv, C->Cp, C->Ci, NULL);
+  C->parent = (int *)malloc(n * sizeof(int));
+  etree(n, C->Cp, C->Ci, C->parent);
+  int *s = (int *)malloc(n * sizeof(int)), *w = (int *)malloc(n * sizeof(int));
+  C->cnt = (int *)calloc(n, sizeof(int));
+  for (int i = 0; i < n; ++i) w[i] = -1;
+  for (int k = 0; k < n; ++k) {
+    int top = ereach(n, C->Cp, C->Ci, k, C->parent, s, w);
+    for (int t = top; t < n; ++t) C->cnt[s[t]]++;  /* L(k, s[t]) != 0 */
+    C->cnt[k]++;                                   /* diagonal */
+  }
+  C->Lp = (int *)malloc((n + 1) * sizeof(int));
+  C->Lp[0] = 0; for (int k = 0; k < n; ++k) C->Lp[k + 1] = C->Lp[k] + C->cnt[k];
+  C->Li = (int *)malloc((size_t)C->Lp[n] * sizeof(int));
+  C->Lx = (double *)malloc((size_t)C->Lp[n] * sizeof(double));
+  free(s); free(w);
+}
+
+/* numeric up-looking Cholesky of (A + lambda I); returns 0 ok, -1 not positive definite */
+static int chol_numeric(og_chol *C, const int *Ap, const int *Ai, const double *Ax, double lambda) {
+  int n = C->n;
+  sym_perm(n, Ap, Ai, Ax, C->pinv, C->Cp, C->Ci, C->Cx);
+  int *c = (int *)malloc(n * sizeof(int)), *s = (int *)malloc(n * sizeof(int)), *w = (int *)malloc(n * sizeof(int));
+  double *x = (double *)calloc(n, sizeof(double));
+  for (int k = 0; k < n; ++k) { c[k] = C->Lp[k]; w[k] = -1; }
+  int ok = 0;
+  for (int k = 0; k < n; ++k) {
+    int top = ereach(n, C->Cp, C->Ci, k, C->parent, s, w);
+    x[k] = 0;
+    for (int p = C->Cp[k]; p < C->Cp[k + 1]; ++p) if (C->Ci[p] <= k) x[C->Ci[p]] = C->Cx[p];
+    double d = x[k] + lambda; x[k] = 0;
+    for (; top < n; ++top) {
+      int i = s[top];
+      double lki = x[i] / C->Lx[C->Lp[i]];
+      x[i] = 0;
+      for (int p = C->Lp[i] + 1; p < c[i]; ++p) x[C->Li[p]] -= C->Lx[p] * lki;
+      d -= lki * lki;
+      int p = c[i]++;
+      C->Li[p] = k; C->Lx[p] = lki;
+    }
+    if (!(d > 0) || !isfinite(d)) { ok = -1; break; }
+    int p = c[k]++;
+    C->Li[p] = k; C->Lx[p] = sqrt(d);
+  }
+  free(c); free(s); free(w); free(x);
+  return ok;
+}
+
+static void chol_solve(const og_chol *C, const double *b, double *x) {
+  int n = C->n;
+  double *y = (double *)malloc(n * sizeof(double));
+  for (int i = 0; i < n; ++i) y[i] = b[C->perm[i]];
+  for (int j = 0; j < n; ++j) {
+    y[j] /= C->Lx[C->Lp[j]];
+    for (int p = C->Lp[j] + 1; p < C->Lp[j + 1]; ++p) y[C->Li[p]] -= C->Lx[p] * y[j];
+  }
+  for (int j = n - 1; j >= 0; --j) {
+    for (int p = C->Lp[j] + 1; p < C->Lp[j + 1]; ++p) y[j] -= C->Lx[p] * y[C->Li[p]];
+    y[j] /= C->Lx[C->Lp[j]];
+  }
+  for (int i = 0; i < n; ++i) x[C->perm[i]] = y[i];
+  free(y);
+}
+
+static void sys_free(og_system *S) {
+  free(S->boff); free(S->v2b); free(S->Ap); free(S->Ai); free(S->Ax); free(S->map); free(S->map_off); free(S->b);
+  memset(S, 0, sizeof *S);
+}
+
+static void scalar_perm_from_blocks(const og_problem *P, const int *hidx, int n, int *perm) {
+  int nb = 0;
+  int *v2b = (int *)malloc(P->nv * sizeof(int));
+  for (int v = 0; v < P->nv; ++v) v2b[v] = hidx[v] >= 0 ? nb++ : -1;
+  int *b2v = (int *)malloc((nb + 1) * sizeof(int));
+  for (int v = 0; v < P->nv; ++v) if (v2b[v] >= 0) b2v[v2b[v]] = v;
+  int *order = (int *)malloc((nb + 1) * sizeof(int));
+  block_min_degree(P, hidx, nb, v2b, order);
+  int q = 0;
+  for (int s = 0; s < nb; ++s) {
+    int v = b2v[order[s]];
+    int d = vdim(P->vtype[v]);
+    for (int r = 0; r < d; ++r) perm[q++] = hidx[v] + r;
+  }
+  (void)n;
+  free(v2b); free(b2v); free(order);
+}
+
+static double now_s(void) {
+  struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts);
+  return ts.tv_sec + 1e-9 * ts.tv_nsec;
+}
+
+/* Export the linearised system at the current estimates: upper CSC + b. Two-call protocol:
+ * first with Ai==NULL to get nnz. */
+int og_linearize(const og_problem *P, int *n_out, int *Ap, int *Ai, double *Ax, double *b) {
+  int *hidx = (int *)malloc(P->nv * sizeof(int));
+  int n = og_hessian_index(P, hidx);
+  og_system S; sys_structure(P, hidx, n, &S);
+  int nnz = S.Ap[n];
+  *n_out = n;
+  if (Ai) {
+    sys_build(P, hidx, &S);
+    memcpy(Ap, S.Ap, (n + 1) * sizeof(int)); memcpy(Ai, S.Ai, nnz * sizeof(int));
+    memcpy(Ax, S.Ax, nnz * sizeof(double)); memcpy(b, S.b, n * sizeof(double));
+  }
+  sys_free(&S); free(hidx);
+  return nnz;
+}
+
+/* solve (H + lambda I) x = b at the current linearisation (for solver parity tests) */
+int og_solve(const og_problem *P, double lambda, double *x) {
+  int *hidx = (int *)malloc(P->nv * sizeof(int));
+  int n = og_hessian_index(P, hidx);
+  og_system S; sys_structure(P, hidx, n, &S); sys_build(P, hidx, &S);
+  int *perm = (int *)malloc(n * sizeof(int));
+  scalar_perm_from_blocks(P, hidx, n, perm);
+  og_chol C; chol_symbolic(&C, n, S.Ap, S.Ai, perm);
+  int rc = chol_numeric(&C, S.Ap, S.Ai, S.Ax, lambda);
+  if (rc == 0) chol_solve(&C, S.b, x);
+  chol_free(&C); free(perm); sys_free(&S); free(hidx);
+  return rc;
+}
+
+/* GraphSLAM::optimize (graph_slam.cpp:182-219) -> g2o LM. Updates P->est. */
+int og_optimize(og_problem *P, int max_iters, og_stats *st) {
+  memset(st, 0, sizeof *st);
+  if (P->ne < 10) { st->status = -2; return 0; }  /* graph_slam.cpp:184-186 */
+  double t0 = now_s();
+  int *hidx = (int *)malloc(P->nv * sizeof(int));
+  int n = og_hessian_index(P, hidx);
+  og_system S; sys_structure(P, hidx, n, &S);
+  int *perm = (int *)malloc(n * sizeof(int));
+  scalar_perm_from_blocks(P, hidx, n, perm);
+  og_chol C; chol_symbolic(&C, n, S.Ap, S.Ai, perm);
+  double *dx = (double *)malloc(n * sizeof(double));
+  double *backup = (double *)malloc((size_t)P->nv * 7 * sizeof(double));
+  double lambda = 0, nu = 2;
+  st->chi2_before = og_chi2(P);
+  int it;
+  int terminated = 0;
+  for (it = 0; it < max_iters && !terminated; ++it) {
+    double cur = og_chi2(P);
+    double t1 = now_s();
+    sys_build(P, hidx, &S);
+    st->seconds_linearize += now_s() - t1;
+    if (it == 0) {
+      double mx = 0;
+      for (int j = 0; j < n; ++j) { double d = fabs(S.Ax[S.Ap[j + 1] - 1]); if (d > mx) mx = d; }
+      lambda = 1e-5 * mx; nu = 2;
+    }
+    double rho = 0; int q = 0;
+    do {
+      memcpy(backup, P->est, (size_t)P->nv * 7 * sizeof(double));
+      double t2 = now_s();
+      int rc = chol_numeric(&C, S.Ap, S.Ai, S.Ax, lambda);
+      if (rc == 0) chol_solve(&C, S.b, dx);
+      st->seconds_solve += now_s() - t2;
+      double tmp = INFINITY, scale = 1.0;
+      if (rc == 0) {
+        og_oplus(P, hidx, dx, P->est);
+        tmp = og_chi2(P);
+        scale = 0;
+        for (int j = 0; j < n; ++j) scale += dx[j] * (lambda * dx[j] + S.b[j]);
+        scale += 1e-3;
+      }
+      rho = (cur - tmp) / scale;
+      st->trials++;
+      if (rho > 0 && isfinite(tmp)) {
+        double a = 1.0 - pow(2 * rho - 1, 3);
+        if (a > 2.0 / 3.0) a = 2.0 / 3.0;
+        double sf = a > 1.0 / 3.0 ? a : 1.0 / 3.0;
+        lambda *= sf; nu = 2; cur = tmp;
+      } else {
+        lambda *= nu; nu *= 2;
+        memcpy(P->est, backup, (size_t)P->nv * 7 * sizeof(double));
+      }
+      q++;
+    } while (rho < 0 && q < 10);
+    if (q == 10 || rho == 0) terminated = 1;
+  }
+  st->iterations = it;
+  st->chi2_after = og_chi2(P);
+  st->lambda = lambda;
+  st->status = terminated ? 1 : 0;
+  st->seconds = now_s() - t0;
+  chol_free(&C); free(perm); free(dx); free(backup); sys_free(&S); free(hidx);
+  return it;
+}
+
+/* computeLandmarkMarginals (graph_slam.cpp:221-234): diagonal blocks of H^-1 (undamped H of the
+ * current linearisation) for the given vertex ids; out = row-major d x d per vertex, packed. */
+int og_marginals(const og_problem *P, const int *ids, int nids, double *out) {
+  int *hidx = (int *)malloc(P->nv * sizeof(int));
+  int n = og_hessian_index(P, hidx);
+  og_system S; sys_structure(P, hidx, n, &S); sys_build(P, hidx, &S);
+  int *perm = (int *)malloc(n * sizeof(int));
+  scalar_perm_from_blocks(P, hidx, n, perm);
+  og_chol C; chol_symbolic(&C, n, S.Ap, S.Ai, perm);
+  int rc = chol_numeric(&C, S.Ap, S.Ai, S.Ax, 0.0);
+  if (rc == 0) {
+    double *rhs = (double *)calloc(n, sizeof(double)), *x = (double *)malloc(n * sizeof(double));
+    size_t o = 0;
+    for (int k = 0; k < nids; ++k) {
+      int v = ids[k]; int d = vdim(P->vtype[v]); int h = hidx[v];
+      if (h < 0) { for (int r = 0; r < d * d; ++r) out[o++] = 0; continue; }
+      for (int c = 0; c < d; ++c) {
+        rhs[h + c] = 1; chol_solve(&C, rhs, x); rhs[h + c] = 0;
+        for (int r = 0; r < d; ++r) out[o + r * d + c] = x[h + r];
+      }
+      o += (size_t)d * d;
+    }
+    free(rhs); free(x);
+  }
+  chol_free(&C); free(perm); sys_free(&S); free(hidx);
+  return rc;
+}

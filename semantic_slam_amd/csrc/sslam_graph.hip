@@ -1,0 +1,1500 @@
+// MI355X-native backend of ps_graph_slam::GraphSLAM — kernels, batch engine and C-ABI.
+// See include/sslam.h for the boundary and DESIGN.md for the data layout / roofline accounting.
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/sslam.h"
+#include "graph_host.hpp"
+#include "graph_kernels.hpp"
+#include "sslam_common.hpp"
+
+namespace sslam {
+
+// =============================================================================================
+// Kernels
+// =============================================================================================
+
+// ---- residual / chi2 (g2o computeActiveErrors): per-graph partial sums, deterministic ---------
+__global__ __launch_bounds__(kEdgeChunk) void k_chi2(BatchView V, const double* __restrict__ pose,
+                                                    const double* __restrict__ lmk, int mask_mode,
+                                                    double* __restrict__ part) {
+  __shared__ double red[kEdgeChunk / 64];
+  const int g = blockIdx.y;
+  const LmState& S = V.lm[g];
+  if (mask_mode == 1 && !S.in_trial) return;
+  if (mask_mode == 2 && !S.active) return;
+  const GraphSeg sg = V.seg[g];
+  const int e = blockIdx.x * kEdgeChunk + threadIdx.x;
+  if (blockIdx.x * kEdgeChunk >= sg.neo + sg.nel) return;
+  double c = 0;
+  if (e < sg.neo) {
+    const int k = sg.eo0 + e;
+    const Pose Xi = load_pose(pose, V.eo_i[k]), Xj = load_pose(pose, V.eo_j[k]);
+    const int n = V.nEo;
+    const Pose Z{{V.eo_z[0 * (size_t)n + k], V.eo_z[1 * (size_t)n + k], V.eo_z[2 * (size_t)n + k]},
+                 {V.eo_z[3 * (size_t)n + k], V.eo_z[4 * (size_t)n + k], V.eo_z[5 * (size_t)n + k], V.eo_z[6 * (size_t)n + k]}};
+    Se3Lin L;
+    se3_error(Xi, Xj, Z, L);
+    double W[36];
+    load_sym6(V.eo_w, n, k, W);
+    for (int r = 0; r < 6; ++r) {
+      double a = 0;
+      for (int s = 0; s < 6; ++s) a += W[r * 6 + s] * L.e[s];
+      c += L.e[r] * a;
+    }
+  } else if (e < sg.neo + sg.nel) {
+    const int k = sg.el0 + (e - sg.neo);
+    const int n = V.nEl;
+    const int li = V.el_l[k];
+    const Pose Xi = load_pose(pose, V.el_p[k]);
+    const double* lp = lmk + (size_t)li * 4;
+    double err[3];
+    if (V.lm_kind[li] == VT_POINT) {
+      PointLin L;
+      point_error(Xi, Vec3{lp[0], lp[1], lp[2]},
+                  Vec3{V.el_z[0 * (size_t)n + k], V.el_z[1 * (size_t)n + k], V.el_z[2 * (size_t)n + k]}, L);
+      err[0] = L.e[0]; err[1] = L.e[1]; err[2] = L.e[2];
+    } else {
+      plane_error(Xi, Plane{{lp[0], lp[1], lp[2]}, lp[3]},
+                  Plane{{V.el_z[0 * (size_t)n + k], V.el_z[1 * (size_t)n + k], V.el_z[2 * (size_t)n + k]}, V.el_z[3 * (size_t)n + k]}, err);
+    }
+    double W[9];
+    load_sym3(V.el_w, n, k, W);
+    for (int r = 0; r < 3; ++r) {
+      double a = 0;
+      for (int s = 0; s < 3; ++s) a += W[r * 3 + s] * err[s];
+      c += err[r] * a;
+    }
+  }
+  const double s = block_sum<kEdgeChunk>(c, red);
+  if (threadIdx.x == 0) part[(size_t)g * V.maxEdgeChunks + blockIdx.x] = s;
+}
+
+// ---- Jacobian build, variant A: edge-parallel, hardware FP64 atomics (global_atomic_add_f64) --
+__device__ __forceinline__ void atomic_add(double* p, double v) { unsafeAtomicAdd(p, v); }
+
+__global__ __launch_bounds__(kEdgeChunk) void k_linearize_atomic(BatchView V) {
+  const int g = blockIdx.y;
+  if (!V.lm[g].active) return;
+  const GraphSeg sg = V.seg[g];
+  const int e = blockIdx.x * kEdgeChunk + threadIdx.x;
+  if (e < sg.neo) {
+    const int k = sg.eo0 + e;
+    const int pi = V.eo_i[k], pj = V.eo_j[k];
+    const Pose Xi = load_pose(V.pose, pi), Xj = load_pose(V.pose, pj);
+    const int n = V.nEo;
+    const Pose Z{{V.eo_z[0 * (size_t)n + k], V.eo_z[1 * (size_t)n + k], V.eo_z[2 * (size_t)n + k]},
+                 {V.eo_z[3 * (size_t)n + k], V.eo_z[4 * (size_t)n + k], V.eo_z[5 * (size_t)n + k], V.eo_z[6 * (size_t)n + k]}};
+    Se3Lin L;
+    se3_error(Xi, Xj, Z, L);
+    double Ji[36], Jj[36], W[36];
+    se3_full_jacobians(L, Ji, Jj);
+    load_sym6(V.eo_w, n, k, W);
+    const int ri = V.pose_row[pi], rj = V.pose_row[pj];
+    const int blk = V.eo_blk[k];
+    double We[6];
+    for (int r = 0; r < 6; ++r) { double a = 0; for (int s = 0; s < 6; ++s) a += W[r * 6 + s] * L.e[s]; We[r] = a; }
+    // WJ = W * J  (one side at a time to bound live registers)
+    double WJ[36];
+    for (int r = 0; r < 6; ++r) for (int c = 0; c < 6; ++c) { double a = 0; for (int s = 0; s < 6; ++s) a += W[r * 6 + s] * Jj[s * 6 + c]; WJ[r * 6 + c] = a; }
+    if (rj >= 0) {
+      double* D = V.Hpp_diag + (size_t)rj * 36;
+      for (int r = 0; r < 6; ++r) for (int c = 0; c < 6; ++c) { double a = 0; for (int s = 0; s < 6; ++s) a += Jj[s * 6 + r] * WJ[s * 6 + c]; atomic_add(D + r * 6 + c, a); }
+      for (int r = 0; r < 6; ++r) { double a = 0; for (int s = 0; s < 6; ++s) a += Jj[s * 6 + r] * We[s]; atomic_add(V.bvec + 6 * (size_t)rj + r, -a); }
+    }
+    if (blk >= 0) {  // off-diagonal block (min row, max row): Ji^T W Jj or its transpose
+      double* O = V.Hpp_off + (size_t)(blk >> 1) * 36;
+      const int swap = blk & 1;
+      for (int r = 0; r < 6; ++r) for (int c = 0; c < 6; ++c) {
+        double a = 0; for (int s = 0; s < 6; ++s) a += Ji[s * 6 + r] * WJ[s * 6 + c];
+        atomic_add(O + (swap ? c * 6 + r : r * 6 + c), a);
+      }
+    }
+    if (ri >= 0) {
+      for (int r = 0; r < 6; ++r) for (int c = 0; c < 6; ++c) { double a = 0; for (int s = 0; s < 6; ++s) a += W[r * 6 + s] * Ji[s * 6 + c]; WJ[r * 6 + c] = a; }
+      double* D = V.Hpp_diag + (size_t)ri * 36;
+      for (int r = 0; r < 6; ++r) for (int c = 0; c < 6; ++c) { double a = 0; for (int s = 0; s < 6; ++s) a += Ji[s * 6 + r] * WJ[s * 6 + c]; atomic_add(D + r * 6 + c, a); }
+      for (int r = 0; r < 6; ++r) { double a = 0; for (int s = 0; s < 6; ++s) a += Ji[s * 6 + r] * We[s]; atomic_add(V.bvec + 6 * (size_t)ri + r, -a); }
+    }
+  } else if (e < sg.neo + sg.nel) {
+    const int k = sg.el0 + (e - sg.neo);
+    const int n = V.nEl;
+    const int pi = V.el_p[k], li = V.el_l[k];
+    const Pose Xi = load_pose(V.pose, pi);
+    const double* lp = V.lmk + (size_t)li * 4;
+    double err[3], Ji[18], Jl[9];
+    if (V.lm_kind[li] == VT_POINT) {
+      PointLin L;
+      point_error(Xi, Vec3{lp[0], lp[1], lp[2]},
+                  Vec3{V.el_z[0 * (size_t)n + k], V.el_z[1 * (size_t)n + k], V.el_z[2 * (size_t)n + k]}, L);
+      point_jacobians(L, Ji, Jl);
+      err[0] = L.e[0]; err[1] = L.e[1]; err[2] = L.e[2];
+    } else {
+      const Plane pw{{lp[0], lp[1], lp[2]}, lp[3]};
+      const Plane z{{V.el_z[0 * (size_t)n + k], V.el_z[1 * (size_t)n + k], V.el_z[2 * (size_t)n + k]}, V.el_z[3 * (size_t)n + k]};
+      plane_error(Xi, pw, z, err);
+      plane_jacobians(Xi, pw, z, Ji, Jl);
+    }
+    double W[9];
+    load_sym3(V.el_w, n, k, W);
+    double We[3], WJi[18], WJl[9];
+    for (int r = 0; r < 3; ++r) {
+      We[r] = W[r * 3 + 0] * err[0] + W[r * 3 + 1] * err[1] + W[r * 3 + 2] * err[2];
+      for (int c = 0; c < 6; ++c) WJi[r * 6 + c] = W[r * 3 + 0] * Ji[c] + W[r * 3 + 1] * Ji[6 + c] + W[r * 3 + 2] * Ji[12 + c];
+      for (int c = 0; c < 3; ++c) WJl[r * 3 + c] = W[r * 3 + 0] * Jl[c] + W[r * 3 + 1] * Jl[3 + c] + W[r * 3 + 2] * Jl[6 + c];
+    }
+    const int rp = V.pose_row[pi], rl = V.lm_row[li];
+    if (rp >= 0) {
+      double* D = V.Hpp_diag + (size_t)rp * 36;
+      for (int r = 0; r < 6; ++r) {
+        for (int c = 0; c < 6; ++c) atomic_add(D + r * 6 + c, Ji[r] * WJi[c] + Ji[6 + r] * WJi[6 + c] + Ji[12 + r] * WJi[12 + c]);
+        atomic_add(V.bvec + 6 * (size_t)rp + r, -(Ji[r] * We[0] + Ji[6 + r] * We[1] + Ji[12 + r] * We[2]));
+      }
+    }
+    if (rl >= 0) {
+      double* D = V.Hll_diag + (size_t)rl * 9;
+      for (int r = 0; r < 3; ++r) {
+        for (int c = 0; c < 3; ++c) atomic_add(D + r * 3 + c, Jl[r] * WJl[c] + Jl[3 + r] * WJl[3 + c] + Jl[6 + r] * WJl[6 + c]);
+        atomic_add(V.bvec + 6 * (size_t)V.nPr + 3 * (size_t)rl + r, -(Jl[r] * We[0] + Jl[3 + r] * We[1] + Jl[6 + r] * We[2]));
+      }
+    }
+    const int blk = V.el_blk[k];
+    if (blk >= 0) {
+      double* O = V.Hpl + (size_t)blk * 18;
+      for (int r = 0; r < 6; ++r)
+        for (int c = 0; c < 3; ++c) atomic_add(O + r * 3 + c, Ji[r] * WJl[c] + Ji[6 + r] * WJl[3 + c] + Ji[12 + r] * WJl[6 + c]);
+    }
+  }
+}
+
+// zero H and b of active graphs (variant A needs a cleared accumulator)
+__global__ void k_zero_active(BatchView V) {
+  const int g = blockIdx.y;
+  if (!V.lm[g].active) return;
+  // Whole-batch clear is done with hipMemsetAsync when every graph is active; this kernel handles
+  // the diagonal blocks + b of one graph (off-diagonal blocks are cleared via the edge lists).
+  const GraphSeg sg = V.seg[g];
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int np = sg.nprow * 36, nl = sg.nlrow * 9, nb = sg.nprow * 6 + sg.nlrow * 3;
+  if (t < np) V.Hpp_diag[(size_t)sg.prow0 * 36 + t] = 0;
+  else if (t < np + nl) V.Hll_diag[(size_t)sg.lrow0 * 9 + (t - np)] = 0;
+  else if (t < np + nl + nb) {
+    const int u = t - np - nl;
+    if (u < sg.nprow * 6) V.bvec[(size_t)sg.prow0 * 6 + u] = 0;
+    else V.bvec[(size_t)V.nPr * 6 + (size_t)sg.lrow0 * 3 + (u - sg.nprow * 6)] = 0;
+  }
+}
+__global__ void k_zero_offdiag(BatchView V) {
+  const int g = blockIdx.y;
+  if (!V.lm[g].active) return;
+  const GraphSeg sg = V.seg[g];
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e < sg.neo) {
+    const int blk = V.eo_blk[sg.eo0 + e];
+    if (blk >= 0) { double* O = V.Hpp_off + (size_t)(blk >> 1) * 36; for (int k = 0; k < 36; ++k) O[k] = 0; }
+  } else if (e < sg.neo + sg.nel) {
+    const int blk = V.el_blk[sg.el0 + e - sg.neo];
+    if (blk >= 0) { double* O = V.Hpl + (size_t)blk * 18; for (int k = 0; k < 18; ++k) O[k] = 0; }
+  }
+}
+
+// ---- scalar-row helpers -------------------------------------------------------------------------
+struct RowRef {
+  int valid;  // inside the graph's range
+  int is_pose;
+  int row;    // pose row or landmark row (global)
+  int r;      // component inside the block
+  int xoff;   // offset in the unknown vector
+  int base;   // xoff of component 0
+};
+__device__ __forceinline__ RowRef row_ref(const BatchView& V, const GraphSeg& sg, int e) {
+  RowRef R;
+  const int npd = sg.nprow * 6;
+  R.valid = e < npd + sg.nlrow * 3;
+  if (e < npd) {
+    R.is_pose = 1; R.row = sg.prow0 + e / 6; R.r = e % 6; R.base = 6 * R.row;
+  } else {
+    const int u = e - npd;
+    R.is_pose = 0; R.row = sg.lrow0 + u / 3; R.r = u % 3; R.base = 6 * V.nPr + 3 * R.row;
+  }
+  R.xoff = R.base + R.r;
+  return R;
+}
+
+// max diagonal entry per graph (lambda init = tau * max diag)
+__global__ __launch_bounds__(kRowChunk) void k_maxdiag(BatchView V, double* __restrict__ part) {
+  __shared__ double red[kRowChunk / 64];
+  const int g = blockIdx.y;
+  if (!V.lm[g].active) return;
+  const GraphSeg sg = V.seg[g];
+  if (blockIdx.x * kRowChunk >= sg.nprow * 6 + sg.nlrow * 3) return;
+  const RowRef R = row_ref(V, sg, blockIdx.x * kRowChunk + threadIdx.x);
+  double d = 0;
+  if (R.valid) d = fabs(R.is_pose ? V.Hpp_diag[(size_t)R.row * 36 + R.r * 7] : V.Hll_diag[(size_t)R.row * 9 + R.r * 4]);
+  const double m = block_max<kRowChunk>(d, red);
+  if (threadIdx.x == 0) part[(size_t)g * V.maxRowChunks + blockIdx.x] = m;
+}
+
+__device__ __forceinline__ int row_chunks(const GraphSeg& sg) { return (sg.nprow * 6 + sg.nlrow * 3 + kRowChunk - 1) / kRowChunk; }
+__device__ __forceinline__ int edge_chunks(const GraphSeg& sg) { return (sg.neo + sg.nel + kEdgeChunk - 1) / kEdgeChunk; }
+
+// one wave per graph: start of an LM iteration
+__global__ void k_lm_begin_iter(BatchView V, const double* __restrict__ part_maxdiag, int it) {
+  const int g = blockIdx.x;
+  LmState& S = V.lm[g];
+  if (!S.active) return;
+  if (it == 0) {
+    const int n = row_chunks(V.seg[g]);
+    double m = 0;
+    for (int k = threadIdx.x; k < n; k += 64) m = fmax(m, part_maxdiag[(size_t)g * V.maxRowChunks + k]);
+    for (int o = 32; o > 0; o >>= 1) m = fmax(m, __shfl_xor(m, o, 64));
+    if (threadIdx.x == 0) { S.max_diag = m; S.lambda = 1e-5 * m; S.nu = 2.0; }
+  }
+  if (threadIdx.x == 0) { S.q = 0; S.rho = 0; S.in_trial = 1; S.accept = 0; }
+}
+
+// initial chi2 -> cur_chi / chi_before
+__global__ void k_lm_init(BatchView V, const double* __restrict__ part_chi) {
+  const int g = blockIdx.x;
+  LmState& S = V.lm[g];
+  const double c = wave_sum_partials(part_chi + (size_t)g * V.maxEdgeChunks, edge_chunks(V.seg[g]));
+  if (threadIdx.x == 0) {
+    S.cur_chi = c; S.chi_before = c; S.iter = 0; S.trials = 0; S.pcg_iters = 0;
+    S.status = 0; S.active = 1; S.in_trial = 0; S.accept = 0; S.lambda = 0; S.nu = 2; S.rho = 0; S.q = 0; S.solve_failed = 0;
+  }
+}
+
+// invert (D + lambda I) per block row -> block-Jacobi preconditioner
+template <int N>
+__device__ __forceinline__ void spd_inverse(double* A /* N*N row-major, in-place */) {
+  // Cholesky A = L L^T (lower in place), then inverse via triangular inverse
+  double L[N * N];
+  for (int i = 0; i < N * N; ++i) L[i] = 0;
+  for (int j = 0; j < N; ++j) {
+    double d = A[j * N + j];
+    for (int k = 0; k < j; ++k) d -= L[j * N + k] * L[j * N + k];
+    d = sqrt(d);
+    L[j * N + j] = d;
+    for (int i = j + 1; i < N; ++i) {
+      double s = A[i * N + j];
+      for (int k = 0; k < j; ++k) s -= L[i * N + k] * L[j * N + k];
+      L[i * N + j] = s / d;
+    }
+  }
+  // Linv (lower)
+  double Li[N * N];
+  for (int i = 0; i < N * N; ++i) Li[i] = 0;
+  for (int j = 0; j < N; ++j) {
+    Li[j * N + j] = 1.0 / L[j * N + j];
+    for (int i = j + 1; i < N; ++i) {
+      double s = 0;
+      for (int k = j; k < i; ++k) s -= L[i * N + k] * Li[k * N + j];
+      Li[i * N + j] = s / L[i * N + i];
+    }
+  }
+  for (int r = 0; r < N; ++r)
+    for (int c = 0; c < N; ++c) {
+      double s = 0;
+      for (int k = (r > c ? r : c); k < N; ++k) s += Li[k * N + r] * Li[k * N + c];
+      A[r * N + c] = s;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_precond(BatchView V) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < V.nPr) {
+    const int g = V.prow_graph[t];
+    if (!V.lm[g].in_trial) return;
+    const double lam = V.lm[g].lambda;
+    double A[36];
+    for (int k = 0; k < 36; ++k) A[k] = V.Hpp_diag[(size_t)t * 36 + k];
+    for (int k = 0; k < 6; ++k) A[k * 7] += lam;
+    spd_inverse<6>(A);
+    for (int k = 0; k < 36; ++k) V.Minv[(size_t)t * 36 + k] = A[k];
+  } else if (t < V.nPr + V.nLr) {
+    const int l = t - V.nPr;
+    const int g = V.lrow_graph[l];
+    if (!V.lm[g].in_trial) return;
+    const double lam = V.lm[g].lambda;
+    double A[9];
+    for (int k = 0; k < 9; ++k) A[k] = V.Hll_diag[(size_t)l * 9 + k];
+    for (int k = 0; k < 3; ++k) A[k * 4] += lam;
+    spd_inverse<3>(A);
+    for (int k = 0; k < 9; ++k) V.Minv[(size_t)V.nPr * 36 + (size_t)l * 9 + k] = A[k];
+  }
+}
+
+// z = Minv * r for the block this scalar row belongs to (rvec staged in LDS by the caller)
+__device__ __forceinline__ double apply_minv(const BatchView& V, const RowRef& R, const double* lds_r, int lds_base) {
+  double z = 0;
+  if (R.is_pose) {
+    const double* M = V.Minv + (size_t)R.row * 36 + R.r * 6;
+#pragma unroll
+    for (int c = 0; c < 6; ++c) z += M[c] * lds_r[lds_base + c];
+  } else {
+    const double* M = V.Minv + (size_t)V.nPr * 36 + (size_t)R.row * 9 + R.r * 3;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) z += M[c] * lds_r[lds_base + c];
+  }
+  return z;
+}
+
+// PCG start: x = 0, r = b, z = Minv r, p = z; partials of r.z and b.b
+__global__ __launch_bounds__(kRowChunk) void k_pcg_init(BatchView V) {
+  __shared__ double red[kRowChunk / 64];
+  __shared__ double lr[kRowChunk];
+  const int g = blockIdx.y;
+  if (!V.lm[g].in_trial) return;
+  const GraphSeg sg = V.seg[g];
+  if (blockIdx.x * kRowChunk >= sg.nprow * 6 + sg.nlrow * 3) return;
+  const RowRef R = row_ref(V, sg, blockIdx.x * kRowChunk + threadIdx.x);
+  double rv = 0;
+  if (R.valid) rv = V.bvec[R.xoff];
+  lr[threadIdx.x] = rv;
+  __syncthreads();
+  double zv = 0;
+  if (R.valid) {
+    zv = apply_minv(V, R, lr, threadIdx.x - R.r);
+    V.x[R.xoff] = 0; V.r[R.xoff] = rv; V.z[R.xoff] = zv; V.p[R.xoff] = zv;
+  }
+  const double s1 = block_sum<kRowChunk>(rv * zv, red);
+  const double s2 = block_sum<kRowChunk>(rv * rv, red);
+  if (threadIdx.x == 0) {
+    V.part_a[(size_t)g * V.maxRowChunks + blockIdx.x] = s1;
+    V.part_b[(size_t)g * V.maxRowChunks + blockIdx.x] = s2;
+  }
+}
+__global__ void k_pcg_init2(BatchView V) {
+  const int g = blockIdx.x;
+  if (!V.lm[g].in_trial) { if (threadIdx.x == 0) { V.pcg_done[g] = 1; V.pcg_done[V.B + g] = 1; } return; }
+  const int n = row_chunks(V.seg[g]);
+  const double rz = wave_sum_partials(V.part_a + (size_t)g * V.maxRowChunks, n);
+  const double bb = wave_sum_partials(V.part_b + (size_t)g * V.maxRowChunks, n);
+  if (threadIdx.x == 0) {
+    V.rz[g] = rz; V.rz[V.B + g] = rz; V.bb[g] = bb;
+    V.pcg_fail[g] = 0;
+    const int d = (bb == 0.0 || !(rz > 0)) ? 1 : 0;
+    V.pcg_done[g] = d; V.pcg_done[V.B + g] = d;
+    if (!(bb == 0.0) && !(rz > 0)) V.pcg_fail[g] = 1;
+  }
+}
+
+// q = (H + lambda I) p, partial p.q      (block-sparse symmetric SpMV in gather form)
+__global__ __launch_bounds__(kRowChunk) void k_spmv(BatchView V, int parity) {
+  __shared__ double red[kRowChunk / 64];
+  const int g = blockIdx.y;
+  if (V.pcg_done[parity * V.B + g]) return;
+  const GraphSeg sg = V.seg[g];
+  if (blockIdx.x * kRowChunk >= sg.nprow * 6 + sg.nlrow * 3) return;
+  const RowRef R = row_ref(V, sg, blockIdx.x * kRowChunk + threadIdx.x);
+  double acc = 0, pv = 0;
+  if (R.valid) {
+    const double* __restrict__ p = V.p;
+    pv = p[R.xoff];
+    acc = V.lm[g].lambda * pv;
+    int arow;
+    if (R.is_pose) {
+      const double* D = V.Hpp_diag + (size_t)R.row * 36 + R.r * 6;
+#pragma unroll
+      for (int c = 0; c < 6; ++c) acc += D[c] * p[R.base + c];
+      arow = R.row;
+    } else {
+      const double* D = V.Hll_diag + (size_t)R.row * 9 + R.r * 3;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) acc += D[c] * p[R.base + c];
+      arow = V.nPr + R.row;
+    }
+    const int a0 = V.adj_ptr[arow], a1 = V.adj_ptr[arow + 1];
+    const double* Hbase = V.Hpp_diag;  // all H blocks live in one allocation; adj_blk is an offset from its start
+    for (int a = a0; a < a1; ++a) {
+      const double* Bk = Hbase + V.adj_blk[a];
+      const double* pn = p + V.adj_x[a];
+      const int fmt = V.adj_fmt[a];
+      if (fmt == 0) {
+#pragma unroll
+        for (int c = 0; c < 6; ++c) acc += Bk[R.r * 6 + c] * pn[c];
+      } else if (fmt == 1) {
+#pragma unroll
+        for (int c = 0; c < 6; ++c) acc += Bk[c * 6 + R.r] * pn[c];
+      } else if (fmt == 2) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) acc += Bk[R.r * 3 + c] * pn[c];
+      } else {
+#pragma unroll
+        for (int c = 0; c < 6; ++c) acc += Bk[c * 3 + R.r] * pn[c];
+      }
+    }
+    V.q[R.xoff] = acc;
+  }
+  const double s = block_sum<kRowChunk>(pv * acc, red);
+  if (threadIdx.x == 0) V.part_a[(size_t)g * V.maxRowChunks + blockIdx.x] = s;
+}
+
+// alpha = rz / pq ; x += alpha p ; r -= alpha q ; z = Minv r ; partials of r.z, r.r
+__global__ __launch_bounds__(kRowChunk) void k_pcg_update(BatchView V, int parity) {
+  __shared__ double red[kRowChunk / 64];
+  __shared__ double lr[kRowChunk];
+  __shared__ double s_alpha;
+  const int g = blockIdx.y;
+  if (V.pcg_done[parity * V.B + g]) return;
+  const GraphSeg sg = V.seg[g];
+  if (blockIdx.x * kRowChunk >= sg.nprow * 6 + sg.nlrow * 3) return;
+  if (threadIdx.x < 64) {
+    const double pq = wave_sum_partials(V.part_a + (size_t)g * V.maxRowChunks, row_chunks(sg));
+    if (threadIdx.x == 0) s_alpha = V.rz[parity * V.B + g] / pq;
+  }
+  __syncthreads();
+  const double alpha = s_alpha;
+  const RowRef R = row_ref(V, sg, blockIdx.x * kRowChunk + threadIdx.x);
+  double rv = 0;
+  if (R.valid) {
+    V.x[R.xoff] += alpha * V.p[R.xoff];
+    rv = V.r[R.xoff] - alpha * V.q[R.xoff];
+    V.r[R.xoff] = rv;
+  }
+  lr[threadIdx.x] = rv;
+  __syncthreads();
+  double zv = 0;
+  if (R.valid) { zv = apply_minv(V, R, lr, threadIdx.x - R.r); V.z[R.xoff] = zv; }
+  const double s1 = block_sum<kRowChunk>(rv * zv, red);
+  const double s2 = block_sum<kRowChunk>(rv * rv, red);
+  if (threadIdx.x == 0) {
+    V.part_b[(size_t)g * V.maxRowChunks + blockIdx.x] = s1;
+    V.part_c[(size_t)g * V.maxRowChunks + blockIdx.x] = s2;  // (part_a is still being read by other blocks)
+  }
+}
+
+// beta = rz_new / rz ; p = z + beta p ; convergence bookkeeping (flags double-buffered by parity so
+// that no block of a launch can observe a flag written by another block of the same launch)
+__global__ __launch_bounds__(kRowChunk) void k_pcg_pupdate(BatchView V, int parity, double tol2, int max_iters) {
+  __shared__ double s_beta;
+  const int g = blockIdx.y;
+  int* done_in = V.pcg_done + parity * V.B;
+  int* done_out = V.pcg_done + (parity ^ 1) * V.B;
+  if (done_in[g]) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) done_out[g] = 1;
+    return;
+  }
+  const GraphSeg sg = V.seg[g];
+  if (blockIdx.x * kRowChunk >= sg.nprow * 6 + sg.nlrow * 3) return;
+  if (threadIdx.x < 64) {
+    const int n = row_chunks(sg);
+    const double rzn = wave_sum_partials(V.part_b + (size_t)g * V.maxRowChunks, n);
+    const double rr = wave_sum_partials(V.part_c + (size_t)g * V.maxRowChunks, n);
+    if (threadIdx.x == 0) {
+      const double rzo = V.rz[parity * V.B + g];
+      s_beta = rzn / rzo;
+      if (blockIdx.x == 0) {
+        V.rz[(parity ^ 1) * V.B + g] = rzn;
+        LmState& S = V.lm[g];
+        S.pcg_iters += 1;
+        int d = 0;
+        if (!(rr > tol2 * V.bb[g])) d = 1;                 // converged (or NaN)
+        if (!isfinite(rr) || !isfinite(rzn) || !(rzn > 0)) { d = 1; if (!(rr <= tol2 * V.bb[g])) V.pcg_fail[g] = 1; }
+        done_out[g] = d;
+      }
+    }
+  }
+  __syncthreads();
+  const double beta = s_beta;
+  const RowRef R = row_ref(V, sg, blockIdx.x * kRowChunk + threadIdx.x);
+  if (R.valid) V.p[R.xoff] = V.z[R.xoff] + beta * V.p[R.xoff];
+}
+
+__global__ void k_pcg_alldone(BatchView V, int parity) {
+  // one workgroup; flags[1] = 1 iff every graph's PCG is finished
+  __shared__ int s_any;
+  if (threadIdx.x == 0) s_any = 0;
+  __syncthreads();
+  for (int g = threadIdx.x; g < V.B; g += blockDim.x)
+    if (!V.pcg_done[parity * V.B + g]) s_any = 1;
+  __syncthreads();
+  if (threadIdx.x == 0) V.flags[1] = s_any ? 0 : 1;
+}
+
+// trial estimate = current [+] dx  (VertexSE3 / VertexPointXYZ / VertexPlane oplus)
+__global__ __launch_bounds__(256) void k_oplus(BatchView V, const double* __restrict__ dx) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < V.nPr) {
+    const int g = V.prow_graph[t];
+    if (!V.lm[g].in_trial) return;
+    const int pi = V.prow_pose[t];
+    double d[6];
+    for (int k = 0; k < 6; ++k) d[k] = dx[6 * (size_t)t + k];
+    store_pose(V.pose_trial, pi, se3_oplus(load_pose(V.pose, pi), d));
+  } else if (t < V.nPr + V.nLr) {
+    const int l = t - V.nPr;
+    const int g = V.lrow_graph[l];
+    if (!V.lm[g].in_trial) return;
+    const int li = V.lrow_lm[l];
+    const double* d = dx + 6 * (size_t)V.nPr + 3 * (size_t)l;
+    const double* c = V.lmk + (size_t)li * 4;
+    double* o = V.lmk_trial + (size_t)li * 4;
+    if (V.lm_kind[li] == VT_POINT) {
+      o[0] = c[0] + d[0]; o[1] = c[1] + d[1]; o[2] = c[2] + d[2]; o[3] = 0;
+    } else {
+      const double dv[3] = {d[0], d[1], d[2]};
+      const Plane P = pl_oplus(Plane{{c[0], c[1], c[2]}, c[3]}, dv);
+      o[0] = P.n.x; o[1] = P.n.y; o[2] = P.n.z; o[3] = P.d;
+    }
+  }
+}
+
+// partial sums of dx . (lambda dx + b)   (denominator of the LM gain ratio)
+__global__ __launch_bounds__(kRowChunk) void k_scale(BatchView V, const double* __restrict__ dx) {
+  __shared__ double red[kRowChunk / 64];
+  const int g = blockIdx.y;
+  if (!V.lm[g].in_trial) return;
+  const GraphSeg sg = V.seg[g];
+  if (blockIdx.x * kRowChunk >= sg.nprow * 6 + sg.nlrow * 3) return;
+  const RowRef R = row_ref(V, sg, blockIdx.x * kRowChunk + threadIdx.x);
+  double v = 0;
+  if (R.valid) { const double d = dx[R.xoff]; v = d * (V.lm[g].lambda * d + V.bvec[R.xoff]); }
+  const double s = block_sum<kRowChunk>(v, red);
+  if (threadIdx.x == 0) V.part_a[(size_t)g * V.maxRowChunks + blockIdx.x] = s;
+}
+
+// g2o OptimizationAlgorithmLevenberg accept / reject, one wave per graph
+__global__ void k_lm_control(BatchView V, const double* __restrict__ part_chi, int max_iters) {
+  const int g = blockIdx.x;
+  LmState& S = V.lm[g];
+  if (!S.in_trial) return;
+  const double tchi = wave_sum_partials(part_chi + (size_t)g * V.maxEdgeChunks, edge_chunks(V.seg[g]));
+  const double sc = wave_sum_partials(V.part_a + (size_t)g * V.maxRowChunks, row_chunks(V.seg[g]));
+  if (threadIdx.x != 0) return;
+  double tmp = tchi;
+  double scale = sc + 1e-3;
+  if (V.pcg_fail[g]) { tmp = INFINITY; scale = 1.0; S.solve_failed += 1; }
+  const double rho = (S.cur_chi - tmp) / scale;
+  S.tmp_chi = tmp; S.scale = scale; S.rho = rho; S.trials += 1;
+  if (rho > 0 && isfinite(tmp)) {
+    double a = 2 * rho - 1;
+    double alpha = 1.0 - a * a * a;
+    alpha = fmin(alpha, 2.0 / 3.0);
+    const double sf = fmax(1.0 / 3.0, alpha);
+    S.lambda *= sf; S.nu = 2; S.cur_chi = tmp; S.accept = 1;
+  } else {
+    S.lambda *= S.nu; S.nu *= 2; S.accept = 0;
+  }
+  S.q += 1;
+  const int again = (rho < 0 && S.q < 10);
+  S.in_trial = again;
+  if (again) atomicOr(&V.flags[0], 1);
+  else {
+    S.iter += 1;
+    if (S.q == 10 || rho == 0) { S.status = 1; S.active = 0; }
+    else if (S.iter >= max_iters) { S.status = 0; S.active = 0; }
+  }
+}
+
+__global__ __launch_bounds__(256) void k_commit(BatchView V) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < V.nPr) {
+    const int g = V.prow_graph[t];
+    if (!V.lm[g].accept) return;
+    const int pi = V.prow_pose[t];
+    for (int k = 0; k < 7; ++k) V.pose[(size_t)pi * 8 + k] = V.pose_trial[(size_t)pi * 8 + k];
+  } else if (t < V.nPr + V.nLr) {
+    const int l = t - V.nPr;
+    const int g = V.lrow_graph[l];
+    if (!V.lm[g].accept) return;
+    const int li = V.lrow_lm[l];
+    for (int k = 0; k < 4; ++k) V.lmk[(size_t)li * 4 + k] = V.lmk_trial[(size_t)li * 4 + k];
+  }
+}
+__global__ void k_clear_accept(BatchView V) {
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g < V.B) V.lm[g].accept = 0;
+}
+__global__ void k_set_trial_all(BatchView V, double lambda) {  // used by the solve() hook
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g < V.B) { V.lm[g].in_trial = 1; V.lm[g].lambda = lambda; V.lm[g].active = 1; }
+}
+
+}  // namespace sslam
+
+// =============================================================================================
+// Host engine
+// =============================================================================================
+namespace sslam {
+
+std::string& last_error_ref() {
+  static thread_local std::string e;
+  return e;
+}
+
+struct KernelTimer {
+  double total_ms = 0;
+  int64_t launches = 0;
+};
+
+struct Batch {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::vector<HostGraph*> graphs;
+  std::vector<uint64_t> versions;
+  BatchView V{};
+  std::vector<void*> allocs;
+  // host-side metadata
+  std::vector<GraphSeg> seg;
+  std::vector<std::vector<int>> v2pose, v2lm;     // per graph: vertex id -> pose / landmark index (global), -1
+  std::vector<int> pose_row, lm_row;              // global
+  std::vector<int> prow_pose, lrow_lm;
+  std::vector<std::pair<int, int>> ppoff;         // unique pose-pose blocks (row a < row b)
+  std::vector<std::pair<int, int>> plblk;         // unique pose-landmark blocks (pose row, lm row)
+  std::vector<int> pose_vertex, lm_vertex;        // global pose/lm index -> vertex id in its graph
+  int64_t hpp_off_base = 0, hpl_base = 0, hll_base = 0;
+  double* d_part_e = nullptr;  // [B*maxEdgeChunks]
+  double* d_part_m = nullptr;  // [B*maxRowChunks] (max diag)
+  bool profiling = false;
+  std::map<std::string, KernelTimer> timers;
+  struct Pending { std::string name; hipEvent_t a, b; };
+  std::vector<Pending> pending;
+  std::vector<hipEvent_t> event_pool;
+  bool uploaded = false;
+
+  ~Batch() { release(); }
+  void release() {
+    if (stream) { hipSetDevice(device); hipStreamSynchronize(stream); }
+    for (auto& p : pending) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
+    pending.clear();
+    for (auto e : event_pool) hipEventDestroy(e);
+    event_pool.clear();
+    for (void* p : allocs) hipFree(p);
+    allocs.clear();
+    if (stream) { hipStreamDestroy(stream); stream = nullptr; }
+  }
+  hipEvent_t get_event() {
+    if (!event_pool.empty()) { hipEvent_t e = event_pool.back(); event_pool.pop_back(); return e; }
+    hipEvent_t e; hipEventCreate(&e); return e;
+  }
+  void harvest() {  // call after a stream sync
+    for (auto& p : pending) {
+      float ms = 0;
+      if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) { timers[p.name].total_ms += ms; timers[p.name].launches += 1; }
+      event_pool.push_back(p.a); event_pool.push_back(p.b);
+    }
+    pending.clear();
+  }
+};
+
+struct ScopedTimer {
+  Batch& b; const char* name; hipEvent_t a{}, e{}; bool on;
+  ScopedTimer(Batch& bb, const char* n) : b(bb), name(n), on(bb.profiling) {
+    if (on) { a = b.get_event(); e = b.get_event(); hipEventRecord(a, b.stream); }
+  }
+  ~ScopedTimer() {
+    if (on) { hipEventRecord(e, b.stream); b.pending.push_back({name, a, e}); }
+  }
+};
+
+template <typename T>
+static int dev_upload(Batch& b, const std::vector<T>& h, T** out, size_t min_elems = 1) {
+  const size_t n = std::max(h.size(), min_elems);
+  void* p = nullptr;
+  SSLAM_HIP_TRY(hipMalloc(&p, n * sizeof(T)));
+  b.allocs.push_back(p);
+  if (!h.empty()) SSLAM_HIP_TRY(hipMemcpyAsync(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, b.stream));
+  *out = (T*)p;
+  return 0;
+}
+template <typename T>
+static int dev_alloc(Batch& b, size_t n, T** out, bool zero = true) {
+  void* p = nullptr;
+  n = std::max<size_t>(n, 1);
+  SSLAM_HIP_TRY(hipMalloc(&p, n * sizeof(T)));
+  b.allocs.push_back(p);
+  if (zero) SSLAM_HIP_TRY(hipMemsetAsync(p, 0, n * sizeof(T), b.stream));
+  *out = (T*)p;
+  return 0;
+}
+
+static inline uint64_t pair_key(int a, int b) { return ((uint64_t)(uint32_t)a << 32) | (uint32_t)b; }
+
+// Compile host graphs into the device-resident batch layout (g2o initializeOptimization +
+// BlockSolver::buildStructure analogue; symbolic work only).
+static int batch_build(Batch& b) {
+  SSLAM_HIP_TRY(hipSetDevice(b.device));
+  if (!b.stream) SSLAM_HIP_TRY(hipStreamCreateWithFlags(&b.stream, hipStreamNonBlocking));
+  const int B = (int)b.graphs.size();
+  b.seg.assign(B, GraphSeg{});
+  b.v2pose.assign(B, {}); b.v2lm.assign(B, {});
+  b.pose_row.clear(); b.lm_row.clear(); b.prow_pose.clear(); b.lrow_lm.clear();
+  b.ppoff.clear(); b.plblk.clear(); b.pose_vertex.clear(); b.lm_vertex.clear();
+  std::vector<int> prow_graph, lrow_graph;
+  std::vector<unsigned char> lm_kind;
+  std::vector<int> eo_i, eo_j, eo_blk, el_p, el_l, el_blk;
+  std::vector<int> eo_src, el_src;  // (graph-local edge id) for SoA fill
+  std::vector<int> eo_g, el_g;
+  int maxRow = 1, maxEdge = 1;
+  for (int g = 0; g < B; ++g) {
+    const HostGraph& G = *b.graphs[g];
+    std::vector<int> hidx;
+    hessian_indices(G, hidx);
+    GraphSeg& sg = b.seg[g];
+    sg.pose0 = (int)b.pose_row.size(); sg.lm0 = (int)b.lm_row.size();
+    sg.prow0 = (int)b.prow_pose.size(); sg.lrow0 = (int)b.lrow_lm.size();
+    sg.eo0 = (int)eo_i.size(); sg.el0 = (int)el_p.size();
+    auto& vp = b.v2pose[g]; auto& vl = b.v2lm[g];
+    vp.assign(G.nv(), -1); vl.assign(G.nv(), -1);
+    for (int v = 0; v < G.nv(); ++v) {
+      if (G.vtype[v] == VT_SE3) {
+        vp[v] = (int)b.pose_row.size();
+        b.pose_vertex.push_back(v);
+        if (hidx[v] >= 0) { b.pose_row.push_back((int)b.prow_pose.size()); b.prow_pose.push_back(vp[v]); prow_graph.push_back(g); }
+        else b.pose_row.push_back(-1);
+      } else {
+        vl[v] = (int)b.lm_row.size();
+        b.lm_vertex.push_back(v);
+        lm_kind.push_back((unsigned char)G.vtype[v]);
+        if (hidx[v] >= 0) { b.lm_row.push_back((int)b.lrow_lm.size()); b.lrow_lm.push_back(vl[v]); lrow_graph.push_back(g); }
+        else b.lm_row.push_back(-1);
+      }
+    }
+    sg.npose = (int)b.pose_row.size() - sg.pose0; sg.nlm = (int)b.lm_row.size() - sg.lm0;
+    sg.nprow = (int)b.prow_pose.size() - sg.prow0; sg.nlrow = (int)b.lrow_lm.size() - sg.lrow0;
+    for (int k = 0; k < G.ne(); ++k) {
+      if (G.etype[k] == ET_SE3) { eo_i.push_back(vp[G.evi[k]]); eo_j.push_back(vp[G.evj[k]]); eo_src.push_back(k); eo_g.push_back(g); }
+      else { el_p.push_back(vp[G.evi[k]]); el_l.push_back(vl[G.evj[k]]); el_src.push_back(k); el_g.push_back(g); }
+    }
+    sg.neo = (int)eo_i.size() - sg.eo0; sg.nel = (int)el_p.size() - sg.el0;
+    maxRow = std::max(maxRow, (sg.nprow * 6 + sg.nlrow * 3 + kRowChunk - 1) / kRowChunk);
+    maxEdge = std::max(maxEdge, (sg.neo + sg.nel + kEdgeChunk - 1) / kEdgeChunk);
+  }
+  const int nPr = (int)b.prow_pose.size(), nLr = (int)b.lrow_lm.size();
+  const int nEo = (int)eo_i.size(), nEl = (int)el_p.size();
+  // unique off-diagonal blocks
+  std::unordered_map<uint64_t, int> ppmap, plmap;
+  eo_blk.assign(nEo, -1); el_blk.assign(nEl, -1);
+  for (int k = 0; k < nEo; ++k) {
+    const int ri = b.pose_row[eo_i[k]], rj = b.pose_row[eo_j[k]];
+    if (ri < 0 || rj < 0 || ri == rj) continue;
+    const int a = std::min(ri, rj), c = std::max(ri, rj);
+    auto it = ppmap.find(pair_key(a, c));
+    int idx;
+    if (it == ppmap.end()) { idx = (int)b.ppoff.size(); ppmap.emplace(pair_key(a, c), idx); b.ppoff.push_back({a, c}); }
+    else idx = it->second;
+    eo_blk[k] = idx * 2 + (ri > rj ? 1 : 0);
+  }
+  for (int k = 0; k < nEl; ++k) {
+    const int rp = b.pose_row[el_p[k]], rl = b.lm_row[el_l[k]];
+    if (rp < 0 || rl < 0) continue;
+    auto it = plmap.find(pair_key(rp, rl));
+    int idx;
+    if (it == plmap.end()) { idx = (int)b.plblk.size(); plmap.emplace(pair_key(rp, rl), idx); b.plblk.push_back({rp, rl}); }
+    else idx = it->second;
+    el_blk[k] = idx;
+  }
+  const int nPP = (int)b.ppoff.size(), nPL = (int)b.plblk.size();
+  b.hll_base = (int64_t)nPr * 36;
+  b.hpp_off_base = b.hll_base + (int64_t)nLr * 9;
+  b.hpl_base = b.hpp_off_base + (int64_t)nPP * 36;
+  const int64_t h_total = b.hpl_base + (int64_t)nPL * 18;
+  if (h_total >= (int64_t)1 << 31) return set_error(SSLAM_ERR_INVALID, "batch too large: H has %lld doubles (int32 block offsets)", (long long)h_total);
+  // adjacency (rows: pose rows then landmark rows)
+  std::vector<std::vector<std::array<int, 3>>> adj(nPr + nLr);
+  for (int i = 0; i < nPP; ++i) {
+    const int a = b.ppoff[i].first, c = b.ppoff[i].second;
+    const int off = (int)(b.hpp_off_base + (int64_t)i * 36);
+    adj[a].push_back({off, 6 * c, 0});
+    adj[c].push_back({off, 6 * a, 1});
+  }
+  for (int i = 0; i < nPL; ++i) {
+    const int rp = b.plblk[i].first, rl = b.plblk[i].second;
+    const int off = (int)(b.hpl_base + (int64_t)i * 18);
+    adj[rp].push_back({off, 6 * nPr + 3 * rl, 2});
+    adj[nPr + rl].push_back({off, 6 * rp, 3});
+  }
+  std::vector<int> adj_ptr(nPr + nLr + 1, 0), adj_blk, adj_x;
+  std::vector<unsigned char> adj_fmt;
+  for (int r = 0; r < nPr + nLr; ++r) {
+    std::sort(adj[r].begin(), adj[r].end(), [](const std::array<int, 3>& x, const std::array<int, 3>& y) { return x[1] < y[1]; });
+    for (auto& a : adj[r]) { adj_blk.push_back(a[0]); adj_x.push_back(a[1]); adj_fmt.push_back((unsigned char)a[2]); }
+    adj_ptr[r + 1] = (int)adj_blk.size();
+  }
+  // edge SoA payloads
+  std::vector<double> eo_z((size_t)7 * nEo), eo_w((size_t)21 * nEo), el_z((size_t)4 * nEl), el_w((size_t)6 * nEl);
+  for (int k = 0; k < nEo; ++k) {
+    const HostGraph& G = *b.graphs[eo_g[k]];
+    const int s = eo_src[k];
+    for (int c = 0; c < 7; ++c) eo_z[(size_t)c * nEo + k] = G.meas[(size_t)s * 7 + c];
+    int q = 0;
+    for (int r = 0; r < 6; ++r) for (int c = r; c < 6; ++c) eo_w[(size_t)(q++) * nEo + k] = G.info[(size_t)s * 36 + r * 6 + c];
+  }
+  for (int k = 0; k < nEl; ++k) {
+    const HostGraph& G = *b.graphs[el_g[k]];
+    const int s = el_src[k];
+    for (int c = 0; c < 4; ++c) el_z[(size_t)c * nEl + k] = G.meas[(size_t)s * 7 + c];
+    int q = 0;
+    for (int r = 0; r < 3; ++r) for (int c = r; c < 3; ++c) el_w[(size_t)(q++) * nEl + k] = G.info[(size_t)s * 36 + r * 3 + c];
+  }
+  // ---- device allocation
+  BatchView& V = b.V;
+  memset(&V, 0, sizeof V);
+  V.B = B; V.nPr = nPr; V.nLr = nLr; V.nPose = (int)b.pose_row.size(); V.nLm = (int)b.lm_row.size();
+  V.nEo = nEo; V.nEl = nEl; V.maxRowChunks = maxRow; V.maxEdgeChunks = maxEdge;
+  V.h_total = h_total;
+  int rc;
+#define UP(vec, field) if ((rc = dev_upload(b, vec, (std::remove_const<std::remove_pointer<decltype(V.field)>::type>::type**)&V.field)) != 0) return rc
+  UP(b.seg, seg); UP(b.pose_row, pose_row); UP(b.lm_row, lm_row); UP(b.prow_pose, prow_pose); UP(b.lrow_lm, lrow_lm);
+  UP(prow_graph, prow_graph); UP(lrow_graph, lrow_graph); UP(lm_kind, lm_kind);
+  UP(eo_i, eo_i); UP(eo_j, eo_j); UP(eo_z, eo_z); UP(eo_w, eo_w); UP(eo_blk, eo_blk);
+  UP(el_p, el_p); UP(el_l, el_l); UP(el_z, el_z); UP(el_w, el_w); UP(el_blk, el_blk);
+  UP(adj_ptr, adj_ptr); UP(adj_blk, adj_blk); UP(adj_x, adj_x); UP(adj_fmt, adj_fmt);
+#undef UP
+  double* H = nullptr;
+  if ((rc = dev_alloc(b, (size_t)h_total, &H))) return rc;
+  V.Hpp_diag = H; V.Hll_diag = H + b.hll_base; V.Hpp_off = H + b.hpp_off_base; V.Hpl = H + b.hpl_base;
+  const size_t dim = (size_t)6 * nPr + (size_t)3 * nLr;
+  if ((rc = dev_alloc(b, dim, &V.bvec))) return rc;
+  if ((rc = dev_alloc(b, (size_t)V.nPose * 8, &V.pose))) return rc;
+  if ((rc = dev_alloc(b, (size_t)V.nPose * 8, &V.pose_trial))) return rc;
+  if ((rc = dev_alloc(b, (size_t)V.nLm * 4, &V.lmk))) return rc;
+  if ((rc = dev_alloc(b, (size_t)V.nLm * 4, &V.lmk_trial))) return rc;
+  if ((rc = dev_alloc(b, dim, &V.x))) return rc;
+  if ((rc = dev_alloc(b, dim, &V.r))) return rc;
+  if ((rc = dev_alloc(b, dim, &V.z))) return rc;
+  if ((rc = dev_alloc(b, dim, &V.p))) return rc;
+  if ((rc = dev_alloc(b, dim, &V.q))) return rc;
+  if ((rc = dev_alloc(b, (size_t)nPr * 36 + (size_t)nLr * 9, &V.Minv))) return rc;
+  if ((rc = dev_alloc(b, (size_t)B * maxRow, &V.part_a))) return rc;
+  if ((rc = dev_alloc(b, (size_t)B * maxRow, &V.part_b))) return rc;
+  if ((rc = dev_alloc(b, (size_t)B * maxRow, &V.part_c))) return rc;
+  if ((rc = dev_alloc(b, (size_t)B * maxRow, &b.d_part_m))) return rc;
+  if ((rc = dev_alloc(b, (size_t)B * maxEdge, &b.d_part_e))) return rc;
+  if ((rc = dev_alloc(b, (size_t)2 * B, &V.rz))) return rc;
+  if ((rc = dev_alloc(b, (size_t)B, &V.bb))) return rc;
+  if ((rc = dev_alloc(b, (size_t)2 * B, &V.pcg_done))) return rc;
+  if ((rc = dev_alloc(b, (size_t)B, &V.pcg_fail))) return rc;
+  if ((rc = dev_alloc(b, (size_t)4, &V.flags))) return rc;
+  if ((rc = dev_alloc(b, (size_t)B, &V.lm))) return rc;
+  SSLAM_HIP_TRY(hipStreamSynchronize(b.stream));
+  b.versions.resize(B);
+  for (int g = 0; g < B; ++g) b.versions[g] = b.graphs[g]->structure_version;
+  b.uploaded = false;
+  return 0;
+}
+
+static int batch_upload_estimates(Batch& b) {
+  SSLAM_HIP_TRY(hipSetDevice(b.device));
+  std::vector<double> pose((size_t)b.V.nPose * 8, 0.0), lmk((size_t)b.V.nLm * 4, 0.0);
+  for (size_t g = 0; g < b.graphs.size(); ++g) {
+    const HostGraph& G = *b.graphs[g];
+    for (int v = 0; v < G.nv(); ++v) {
+      const double* e = &G.est[(size_t)v * 7];
+      if (G.vtype[v] == VT_SE3) { double* o = &pose[(size_t)b.v2pose[g][v] * 8]; for (int k = 0; k < 7; ++k) o[k] = e[k]; }
+      else { double* o = &lmk[(size_t)b.v2lm[g][v] * 4]; for (int k = 0; k < (G.vtype[v] == VT_POINT ? 3 : 4); ++k) o[k] = e[k]; }
+    }
+  }
+  if (!pose.empty()) {
+    SSLAM_HIP_TRY(hipMemcpyAsync(b.V.pose, pose.data(), pose.size() * 8, hipMemcpyHostToDevice, b.stream));
+    SSLAM_HIP_TRY(hipMemcpyAsync(b.V.pose_trial, pose.data(), pose.size() * 8, hipMemcpyHostToDevice, b.stream));
+  }
+  if (!lmk.empty()) {
+    SSLAM_HIP_TRY(hipMemcpyAsync(b.V.lmk, lmk.data(), lmk.size() * 8, hipMemcpyHostToDevice, b.stream));
+    SSLAM_HIP_TRY(hipMemcpyAsync(b.V.lmk_trial, lmk.data(), lmk.size() * 8, hipMemcpyHostToDevice, b.stream));
+  }
+  SSLAM_HIP_TRY(hipStreamSynchronize(b.stream));
+  b.uploaded = true;
+  return 0;
+}
+
+static int batch_download_estimates(Batch& b) {
+  SSLAM_HIP_TRY(hipSetDevice(b.device));
+  std::vector<double> pose((size_t)b.V.nPose * 8), lmk((size_t)b.V.nLm * 4);
+  if (!pose.empty()) SSLAM_HIP_TRY(hipMemcpyAsync(pose.data(), b.V.pose, pose.size() * 8, hipMemcpyDeviceToHost, b.stream));
+  if (!lmk.empty()) SSLAM_HIP_TRY(hipMemcpyAsync(lmk.data(), b.V.lmk, lmk.size() * 8, hipMemcpyDeviceToHost, b.stream));
+  SSLAM_HIP_TRY(hipStreamSynchronize(b.stream));
+  for (size_t g = 0; g < b.graphs.size(); ++g) {
+    HostGraph& G = *b.graphs[g];
+    for (int v = 0; v < G.nv(); ++v) {
+      double* e = &G.est[(size_t)v * 7];
+      if (G.vtype[v] == VT_SE3) { const double* o = &pose[(size_t)b.v2pose[g][v] * 8]; for (int k = 0; k < 7; ++k) e[k] = o[k]; }
+      else { const double* o = &lmk[(size_t)b.v2lm[g][v] * 4]; for (int k = 0; k < (G.vtype[v] == VT_POINT ? 3 : 4); ++k) e[k] = o[k]; }
+    }
+  }
+  return 0;
+}
+
+static inline dim3 row_grid(const Batch& b) { return dim3(b.V.maxRowChunks, b.V.B); }
+static inline dim3 edge_grid(const Batch& b) { return dim3(b.V.maxEdgeChunks, b.V.B); }
+static inline int vert_blocks(const Batch& b) { return std::max(1, (b.V.nPr + b.V.nLr + 255) / 256); }
+
+static int launch_check(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return set_error(SSLAM_ERR_HIP, "launch %s: %s", what, hipGetErrorString(e));
+  return 0;
+}
+
+// BlockSolver::buildSystem for the active graphs of the batch
+static int batch_linearize(Batch& b) {
+  ScopedTimer t(b, "linearize");
+  const BatchView& V = b.V;
+  const int per_graph_rows = V.maxRowChunks * kRowChunk;
+  // clear accumulators of the active graphs
+  hipLaunchKernelGGL(k_zero_active, dim3((per_graph_rows * 8 + 255) / 256, V.B), dim3(256), 0, b.stream, V);
+  hipLaunchKernelGGL(k_zero_offdiag, edge_grid(b), dim3(kEdgeChunk), 0, b.stream, V);
+  hipLaunchKernelGGL(k_linearize_atomic, edge_grid(b), dim3(kEdgeChunk), 0, b.stream, V);
+  return launch_check("linearize");
+}
+
+static int pcg_solve(Batch& b) {
+  const Options& opt = b.graphs[0]->opt;
+  const BatchView& V = b.V;
+  { ScopedTimer t(b, "precond");
+    hipLaunchKernelGGL(k_precond, dim3(vert_blocks(b)), dim3(256), 0, b.stream, V); }
+  hipLaunchKernelGGL(k_pcg_init, row_grid(b), dim3(kRowChunk), 0, b.stream, V);
+  hipLaunchKernelGGL(k_pcg_init2, dim3(V.B), dim3(64), 0, b.stream, V);
+  const double tol2 = opt.pcg_tol * opt.pcg_tol;
+  int it = 0;
+  const int check_every = 32;
+  while (it < opt.pcg_max_iters) {
+    for (int k = 0; k < check_every && it < opt.pcg_max_iters; ++k, ++it) {
+      const int parity = it & 1;
+      { ScopedTimer t(b, "spmv");
+        hipLaunchKernelGGL(k_spmv, row_grid(b), dim3(kRowChunk), 0, b.stream, V, parity); }
+      { ScopedTimer t(b, "pcg_update");
+        hipLaunchKernelGGL(k_pcg_update, row_grid(b), dim3(kRowChunk), 0, b.stream, V, parity);
+        hipLaunchKernelGGL(k_pcg_pupdate, row_grid(b), dim3(kRowChunk), 0, b.stream, V, parity, tol2, opt.pcg_max_iters); }
+    }
+    hipLaunchKernelGGL(k_pcg_alldone, dim3(1), dim3(256), 0, b.stream, V, it & 1);
+    int flag = 0;
+    SSLAM_HIP_TRY(hipMemcpyAsync(&flag, V.flags + 1, sizeof(int), hipMemcpyDeviceToHost, b.stream));
+    SSLAM_HIP_TRY(hipStreamSynchronize(b.stream));
+    b.harvest();
+    if (flag) break;
+  }
+  return launch_check("pcg");
+}
+
+static int batch_solve(Batch& b) {
+  // (H + lambda I) dx = b for every graph with in_trial set; result in V.x
+  return pcg_solve(b);
+}
+
+static int batch_chi2(Batch& b, const double* pose, const double* lmk, int mask_mode) {
+  ScopedTimer t(b, "chi2");
+  hipLaunchKernelGGL(k_chi2, edge_grid(b), dim3(kEdgeChunk), 0, b.stream, b.V, pose, lmk, mask_mode, b.d_part_e);
+  return launch_check("chi2");
+}
+
+static int batch_optimize(Batch& b, int max_iters, sslam_opt_stats* out) {
+  SSLAM_HIP_TRY(hipSetDevice(b.device));
+  const auto t0 = std::chrono::steady_clock::now();
+  const BatchView& V = b.V;
+  int rc;
+  if (!b.uploaded && (rc = batch_upload_estimates(b))) return rc;
+  if ((rc = batch_chi2(b, V.pose, V.lmk, 0))) return rc;
+  hipLaunchKernelGGL(k_lm_init, dim3(V.B), dim3(64), 0, b.stream, V, b.d_part_e);
+  std::vector<LmState> st(V.B);
+  for (int it = 0; it < max_iters; ++it) {
+    if ((rc = batch_linearize(b))) return rc;
+    if (it == 0) hipLaunchKernelGGL(k_maxdiag, row_grid(b), dim3(kRowChunk), 0, b.stream, V, b.d_part_m);
+    hipLaunchKernelGGL(k_lm_begin_iter, dim3(V.B), dim3(64), 0, b.stream, V, b.d_part_m, it);
+    for (int trial = 0; trial < 10; ++trial) {
+      SSLAM_HIP_TRY(hipMemsetAsync(V.flags, 0, sizeof(int), b.stream));
+      hipLaunchKernelGGL(k_clear_accept, dim3((V.B + 63) / 64), dim3(64), 0, b.stream, V);
+      if ((rc = batch_solve(b))) return rc;
+      { ScopedTimer t(b, "oplus");
+        hipLaunchKernelGGL(k_oplus, dim3(vert_blocks(b)), dim3(256), 0, b.stream, V, V.x); }
+      if ((rc = batch_chi2(b, V.pose_trial, V.lmk_trial, 1))) return rc;
+      hipLaunchKernelGGL(k_scale, row_grid(b), dim3(kRowChunk), 0, b.stream, V, V.x);
+      hipLaunchKernelGGL(k_lm_control, dim3(V.B), dim3(64), 0, b.stream, V, b.d_part_e, max_iters);
+      hipLaunchKernelGGL(k_commit, dim3(vert_blocks(b)), dim3(256), 0, b.stream, V);
+      int again = 0;
+      SSLAM_HIP_TRY(hipMemcpyAsync(&again, V.flags, sizeof(int), hipMemcpyDeviceToHost, b.stream));
+      SSLAM_HIP_TRY(hipStreamSynchronize(b.stream));
+      b.harvest();
+      if (!again) break;
+    }
+    SSLAM_HIP_TRY(hipMemcpyAsync(st.data(), V.lm, sizeof(LmState) * V.B, hipMemcpyDeviceToHost, b.stream));
+    SSLAM_HIP_TRY(hipStreamSynchronize(b.stream));
+    bool any = false;
+    for (auto& s : st) any |= (s.active != 0);
+    if (!any) break;
+  }
+  SSLAM_HIP_TRY(hipMemcpyAsync(st.data(), V.lm, sizeof(LmState) * V.B, hipMemcpyDeviceToHost, b.stream));
+  SSLAM_HIP_TRY(hipStreamSynchronize(b.stream));
+  b.harvest();
+  if ((rc = launch_check("optimize"))) return rc;
+  const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  int worst = 0;
+  for (int g = 0; g < V.B; ++g) {
+    sslam_opt_stats& o = out[g];
+    memset(&o, 0, sizeof o);
+    o.iterations = st[g].iter; o.trials = st[g].trials; o.status = st[g].status;
+    o.chi2_before = st[g].chi_before; o.chi2_after = st[g].cur_chi; o.lambda = st[g].lambda;
+    o.seconds = secs; o.solver_iterations = st[g].pcg_iters;
+    if (!std::isfinite(st[g].cur_chi)) { o.status = SSLAM_ERR_NUMERIC; worst = SSLAM_ERR_NUMERIC; }
+  }
+  if (worst) return set_error(worst, "non-finite chi2 after optimisation");
+  return 0;
+}
+
+}  // namespace sslam
+
+// =============================================================================================
+// C-ABI
+// =============================================================================================
+using namespace sslam;
+
+struct sslam_graph {
+  HostGraph g;
+  std::unique_ptr<Batch> batch;  // batch of one, rebuilt when the structure changes
+  bool linearized = false;
+};
+struct sslam_batch {
+  Batch b;
+};
+
+static int ensure_batch(sslam_graph* h) {
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0) return set_error(SSLAM_ERR_NO_DEVICE, "no HIP device visible (%s); the product has no CPU fallback", hipGetErrorString(e));
+  if (h->g.device < 0 || h->g.device >= n) return set_error(SSLAM_ERR_NO_DEVICE, "device %d out of range (%d visible)", h->g.device, n);
+  if (!h->batch || h->batch->versions.empty() || h->batch->versions[0] != h->g.structure_version) {
+    h->batch.reset(new Batch());
+    h->batch->device = h->g.device;
+    h->batch->graphs = {&h->g};
+    int rc = batch_build(*h->batch);
+    if (rc) { h->batch.reset(); return rc; }
+    h->linearized = false;
+  }
+  return 0;
+}
+
+extern "C" {
+
+const char* sslam_last_error(void) { return last_error_ref().c_str(); }
+
+int sslam_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+sslam_graph* sslam_graph_create(int device) {
+  sslam_graph* h = new sslam_graph();
+  h->g.device = device;
+  return h;
+}
+void sslam_graph_destroy(sslam_graph* g) { delete g; }
+
+static int add_vertex(sslam_graph* h, int type, const double* est, int n, int fixed) {
+  if (!h || !est) return set_error(SSLAM_ERR_INVALID, "null argument");
+  HostGraph& G = h->g;
+  const int id = G.nv();
+  G.vtype.push_back(type);
+  G.vfixed.push_back(fixed);
+  for (int k = 0; k < 7; ++k) G.est.push_back(k < n ? est[k] : 0.0);
+  G.structure_version++;
+  return id;
+}
+int sslam_graph_add_vertex_se3(sslam_graph* h, const double t_q[7], int fixed) {
+  if (!h) return set_error(SSLAM_ERR_INVALID, "null graph");
+  if (fixed < 0) fixed = (h->g.nv() == 0) ? 1 : 0;  // graph_slam.cpp:109-111
+  return add_vertex(h, VT_SE3, t_q, 7, fixed ? 1 : 0);
+}
+int sslam_graph_add_vertex_point(sslam_graph* h, const double p[3]) { return add_vertex(h, VT_POINT, p, 3, 0); }
+int sslam_graph_add_vertex_plane(sslam_graph* h, const double n_d[4]) {
+  if (!n_d) return set_error(SSLAM_ERR_INVALID, "null argument");
+  const double nn = std::sqrt(n_d[0] * n_d[0] + n_d[1] * n_d[1] + n_d[2] * n_d[2]);
+  if (!(nn > 0)) return set_error(SSLAM_ERR_INVALID, "plane normal has zero length");
+  const double p[4] = {n_d[0] / nn, n_d[1] / nn, n_d[2] / nn, n_d[3] / nn};  // Plane3D::fromVector normalises
+  return add_vertex(h, VT_PLANE, p, 4, 0);
+}
+
+static int add_edge(sslam_graph* h, int type, int i, int j, const double* z, int nz, const double* info, int d) {
+  if (!h || !z || !info) return set_error(SSLAM_ERR_INVALID, "null argument");
+  HostGraph& G = h->g;
+  if (i < 0 || j < 0 || i >= G.nv() || j >= G.nv() || i == j) return set_error(SSLAM_ERR_INVALID, "edge vertex ids (%d,%d) invalid", i, j);
+  if (G.vtype[i] != VT_SE3) return set_error(SSLAM_ERR_INVALID, "vertex %d is not an SE3 vertex", i);
+  const int want = type == ET_SE3 ? VT_SE3 : (type == ET_SE3_POINT ? VT_POINT : VT_PLANE);
+  if (G.vtype[j] != want) return set_error(SSLAM_ERR_INVALID, "vertex %d has the wrong type for this edge", j);
+  const int id = G.ne();
+  G.etype.push_back(type); G.evi.push_back(i); G.evj.push_back(j);
+  for (int k = 0; k < 7; ++k) G.meas.push_back(k < nz ? z[k] : 0.0);
+  for (int k = 0; k < 36; ++k) G.info.push_back(k < d * d ? info[k] : 0.0);
+  G.structure_version++;
+  return id;
+}
+int sslam_graph_add_edge_se3(sslam_graph* h, int i, int j, const double z[7], const double info[36]) {
+  return add_edge(h, ET_SE3, i, j, z, 7, info, 6);
+}
+int sslam_graph_add_edge_se3_point(sslam_graph* h, int i, int l, const double z[3], const double info[9]) {
+  return add_edge(h, ET_SE3_POINT, i, l, z, 3, info, 3);
+}
+int sslam_graph_add_edge_se3_plane(sslam_graph* h, int i, int l, const double z[4], const double info[9]) {
+  if (!z) return set_error(SSLAM_ERR_INVALID, "null argument");
+  const double nn = std::sqrt(z[0] * z[0] + z[1] * z[1] + z[2] * z[2]);
+  if (!(nn > 0)) return set_error(SSLAM_ERR_INVALID, "plane normal has zero length");
+  const double p[4] = {z[0] / nn, z[1] / nn, z[2] / nn, z[3] / nn};
+  return add_edge(h, ET_SE3_PLANE, i, l, p, 4, info, 3);
+}
+
+int sslam_graph_num_vertices(const sslam_graph* h) { return h ? h->g.nv() : SSLAM_ERR_INVALID; }
+int sslam_graph_num_edges(const sslam_graph* h) { return h ? h->g.ne() : SSLAM_ERR_INVALID; }
+
+int sslam_graph_get_vertex(const sslam_graph* h, int id, double* out) {
+  if (!h || !out || id < 0 || id >= h->g.nv()) return set_error(SSLAM_ERR_INVALID, "bad vertex id %d", id);
+  const int n = vertex_est_len(h->g.vtype[id]);
+  for (int k = 0; k < n; ++k) out[k] = h->g.est[(size_t)id * 7 + k];
+  return n;
+}
+int sslam_graph_set_vertex(sslam_graph* h, int id, const double* in) {
+  if (!h || !in || id < 0 || id >= h->g.nv()) return set_error(SSLAM_ERR_INVALID, "bad vertex id %d", id);
+  const int n = vertex_est_len(h->g.vtype[id]);
+  for (int k = 0; k < n; ++k) h->g.est[(size_t)id * 7 + k] = in[k];
+  if (h->batch) h->batch->uploaded = false;
+  h->linearized = false;
+  return n;
+}
+int sslam_graph_hessian_index(sslam_graph* h, int id) {
+  if (!h || id < 0 || id >= h->g.nv()) return set_error(SSLAM_ERR_INVALID, "bad vertex id %d", id);
+  std::vector<int> hidx;
+  hessian_indices(h->g, hidx);
+  return hidx[id];
+}
+
+int sslam_graph_set_option(sslam_graph* h, const char* key, double value) {
+  if (!h || !key) return set_error(SSLAM_ERR_INVALID, "null argument");
+  Options& o = h->g.opt;
+  const std::string k(key);
+  if (k == "solver") o.solver = (int)value;
+  else if (k == "pcg_tol") o.pcg_tol = value;
+  else if (k == "pcg_max_iters") o.pcg_max_iters = (int)value;
+  else if (k == "schur") o.schur = (int)value;
+  else if (k == "deterministic") o.deterministic = (int)value;
+  else return set_error(SSLAM_ERR_INVALID, "unknown option '%s'", key);
+  return 0;
+}
+
+int sslam_graph_optimize(sslam_graph* h, int max_iters, sslam_opt_stats* out) {
+  if (!h) return set_error(SSLAM_ERR_INVALID, "null graph");
+  sslam_opt_stats local;
+  if (!out) out = &local;
+  memset(out, 0, sizeof *out);
+  if (h->g.ne() < 10) {  // graph_slam.cpp:184-186
+    out->status = SSLAM_ERR_TOO_FEW_EDGES;
+    return set_error(SSLAM_ERR_TOO_FEW_EDGES, "graph has %d edges (< 10): not optimised", h->g.ne());
+  }
+  int rc = ensure_batch(h);
+  if (rc) { out->status = rc; return rc; }
+  if ((rc = batch_upload_estimates(*h->batch))) return rc;
+  if ((rc = batch_optimize(*h->batch, max_iters, out))) return rc;
+  h->linearized = false;
+  return batch_download_estimates(*h->batch);
+}
+
+int sslam_graph_chi2(sslam_graph* h, double* chi2) {
+  if (!h || !chi2) return set_error(SSLAM_ERR_INVALID, "null argument");
+  int rc = ensure_batch(h);
+  if (rc) return rc;
+  Batch& b = *h->batch;
+  if ((rc = batch_upload_estimates(b))) return rc;
+  if ((rc = batch_chi2(b, b.V.pose, b.V.lmk, 0))) return rc;
+  hipLaunchKernelGGL(k_lm_init, dim3(b.V.B), dim3(64), 0, b.stream, b.V, b.d_part_e);
+  LmState s;
+  SSLAM_HIP_TRY(hipMemcpyAsync(&s, b.V.lm, sizeof s, hipMemcpyDeviceToHost, b.stream));
+  SSLAM_HIP_TRY(hipStreamSynchronize(b.stream));
+  *chi2 = s.cur_chi;
+  return 0;
+}
+
+static int do_linearize(sslam_graph* h) {
+  int rc = ensure_batch(h);
+  if (rc) return rc;
+  Batch& b = *h->batch;
+  if ((rc = batch_upload_estimates(b))) return rc;
+  if ((rc = batch_chi2(b, b.V.pose, b.V.lmk, 0))) return rc;
+  hipLaunchKernelGGL(k_lm_init, dim3(b.V.B), dim3(64), 0, b.stream, b.V, b.d_part_e);
+  if ((rc = batch_linearize(b))) return rc;
+  SSLAM_HIP_TRY(hipStreamSynchronize(b.stream));
+  b.harvest();
+  h->linearized = true;
+  return 0;
+}
+
+int sslam_graph_linearize(sslam_graph* h, int* dim, int64_t* nnz_upper, int32_t* rows, int32_t* cols, double* vals, double* bout) {
+  if (!h || !dim || !nnz_upper) return set_error(SSLAM_ERR_INVALID, "null argument");
+  int rc = ensure_batch(h);
+  if (rc) return rc;
+  Batch& b = *h->batch;
+  std::vector<int> hidx;
+  const int n = hessian_indices(h->g, hidx);
+  *dim = n;
+  const int nPr = b.V.nPr, nLr = b.V.nLr;
+  const int64_t nnz = (int64_t)nPr * 21 + (int64_t)nLr * 6 + (int64_t)b.ppoff.size() * 36 + (int64_t)b.plblk.size() * 18;
+  *nnz_upper = nnz;
+  if (!rows || !cols || !vals || !bout) return 0;
+  if ((rc = do_linearize(h))) return rc;
+  std::vector<double> H((size_t)b.V.h_total), bv((size_t)6 * nPr + (size_t)3 * nLr);
+  SSLAM_HIP_TRY(hipMemcpy(H.data(), b.V.Hpp_diag, H.size() * 8, hipMemcpyDeviceToHost));
+  SSLAM_HIP_TRY(hipMemcpy(bv.data(), b.V.bvec, bv.size() * 8, hipMemcpyDeviceToHost));
+  auto prow_off = [&](int r) { return hidx[b.pose_vertex[b.prow_pose[r]]]; };
+  auto lrow_off = [&](int r) { return hidx[b.lm_vertex[b.lrow_lm[r]]]; };
+  int64_t q = 0;
+  auto emit = [&](int R, int C, double v) { if (R > C) std::swap(R, C); rows[q] = R; cols[q] = C; vals[q] = v; ++q; };
+  for (int r = 0; r < nPr; ++r) {
+    const int o = prow_off(r);
+    for (int a = 0; a < 6; ++a) { for (int c = a; c < 6; ++c) emit(o + a, o + c, H[(size_t)r * 36 + a * 6 + c]); bout[o + a] = bv[(size_t)6 * r + a]; }
+  }
+  for (int r = 0; r < nLr; ++r) {
+    const int o = lrow_off(r);
+    for (int a = 0; a < 3; ++a) { for (int c = a; c < 3; ++c) emit(o + a, o + c, H[(size_t)b.hll_base + (size_t)r * 9 + a * 3 + c]); bout[o + a] = bv[(size_t)6 * nPr + (size_t)3 * r + a]; }
+  }
+  for (size_t i = 0; i < b.ppoff.size(); ++i) {
+    const int oa = prow_off(b.ppoff[i].first), oc = prow_off(b.ppoff[i].second);
+    for (int a = 0; a < 6; ++a) for (int c = 0; c < 6; ++c) emit(oa + a, oc + c, H[(size_t)b.hpp_off_base + i * 36 + a * 6 + c]);
+  }
+  for (size_t i = 0; i < b.plblk.size(); ++i) {
+    const int op = prow_off(b.plblk[i].first), ol = lrow_off(b.plblk[i].second);
+    for (int a = 0; a < 6; ++a) for (int c = 0; c < 3; ++c) emit(op + a, ol + c, H[(size_t)b.hpl_base + i * 18 + a * 3 + c]);
+  }
+  return 0;
+}
+
+// internal <-> g2o ordering of the unknown vector
+static void to_g2o_order(const sslam_graph* h, const std::vector<double>& xin, double* xout) {
+  const Batch& b = *h->batch;
+  std::vector<int> hidx;
+  hessian_indices(h->g, hidx);
+  for (int r = 0; r < b.V.nPr; ++r) { const int o = hidx[b.pose_vertex[b.prow_pose[r]]]; for (int a = 0; a < 6; ++a) xout[o + a] = xin[(size_t)6 * r + a]; }
+  for (int r = 0; r < b.V.nLr; ++r) { const int o = hidx[b.lm_vertex[b.lrow_lm[r]]]; for (int a = 0; a < 3; ++a) xout[o + a] = xin[(size_t)6 * b.V.nPr + (size_t)3 * r + a]; }
+}
+static void from_g2o_order(const sslam_graph* h, const double* xin, std::vector<double>& xout) {
+  const Batch& b = *h->batch;
+  std::vector<int> hidx;
+  hessian_indices(h->g, hidx);
+  xout.assign((size_t)6 * b.V.nPr + (size_t)3 * b.V.nLr, 0.0);
+  for (int r = 0; r < b.V.nPr; ++r) { const int o = hidx[b.pose_vertex[b.prow_pose[r]]]; for (int a = 0; a < 6; ++a) xout[(size_t)6 * r + a] = xin[o + a]; }
+  for (int r = 0; r < b.V.nLr; ++r) { const int o = hidx[b.lm_vertex[b.lrow_lm[r]]]; for (int a = 0; a < 3; ++a) xout[(size_t)6 * b.V.nPr + (size_t)3 * r + a] = xin[o + a]; }
+}
+
+int sslam_graph_solve(sslam_graph* h, double lambda, double* x, int64_t* solver_iterations) {
+  if (!h || !x) return set_error(SSLAM_ERR_INVALID, "null argument");
+  int rc;
+  if (!h->linearized && (rc = do_linearize(h))) return rc;
+  Batch& b = *h->batch;
+  hipLaunchKernelGGL(k_set_trial_all, dim3((b.V.B + 63) / 64), dim3(64), 0, b.stream, b.V, lambda);
+  if ((rc = batch_solve(b))) return rc;
+  std::vector<double> xi((size_t)6 * b.V.nPr + (size_t)3 * b.V.nLr);
+  LmState s;
+  int fail = 0;
+  SSLAM_HIP_TRY(hipMemcpyAsync(xi.data(), b.V.x, xi.size() * 8, hipMemcpyDeviceToHost, b.stream));
+  SSLAM_HIP_TRY(hipMemcpyAsync(&s, b.V.lm, sizeof s, hipMemcpyDeviceToHost, b.stream));
+  SSLAM_HIP_TRY(hipMemcpyAsync(&fail, b.V.pcg_fail, sizeof fail, hipMemcpyDeviceToHost, b.stream));
+  SSLAM_HIP_TRY(hipStreamSynchronize(b.stream));
+  if (solver_iterations) *solver_iterations = s.pcg_iters;
+  to_g2o_order(h, xi, x);
+  if (fail) return set_error(SSLAM_ERR_NUMERIC, "linear solve broke down");
+  return 0;
+}
+
+int sslam_graph_oplus(sslam_graph* h, const double* dx) {
+  if (!h || !dx) return set_error(SSLAM_ERR_INVALID, "null argument");
+  int rc = ensure_batch(h);
+  if (rc) return rc;
+  Batch& b = *h->batch;
+  if ((rc = batch_upload_estimates(b))) return rc;
+  std::vector<double> xi;
+  from_g2o_order(h, dx, xi);
+  if (!xi.empty()) SSLAM_HIP_TRY(hipMemcpyAsync(b.V.x, xi.data(), xi.size() * 8, hipMemcpyHostToDevice, b.stream));
+  hipLaunchKernelGGL(k_set_trial_all, dim3((b.V.B + 63) / 64), dim3(64), 0, b.stream, b.V, 0.0);
+  hipLaunchKernelGGL(k_oplus, dim3(vert_blocks(b)), dim3(256), 0, b.stream, b.V, b.V.x);
+  if (b.V.nPose) SSLAM_HIP_TRY(hipMemcpyAsync(b.V.pose, b.V.pose_trial, (size_t)b.V.nPose * 64, hipMemcpyDeviceToDevice, b.stream));
+  if (b.V.nLm) SSLAM_HIP_TRY(hipMemcpyAsync(b.V.lmk, b.V.lmk_trial, (size_t)b.V.nLm * 32, hipMemcpyDeviceToDevice, b.stream));
+  SSLAM_HIP_TRY(hipStreamSynchronize(b.stream));
+  h->linearized = false;
+  return batch_download_estimates(b);
+}
+
+int sslam_graph_marginals(sslam_graph* h, const int* ids, int n, double* out) {
+  if (!h || !ids || !out || n < 0) return set_error(SSLAM_ERR_INVALID, "null argument");
+  int rc;
+  if ((rc = do_linearize(h))) return rc;  // undamped H at the current estimates
+  Batch& b = *h->batch;
+  std::vector<int> hidx;
+  const int dim = hessian_indices(h->g, hidx);
+  std::vector<double> rhs_g2o(dim, 0.0), rhs_int, xi((size_t)6 * b.V.nPr + (size_t)3 * b.V.nLr), xg(dim);
+  size_t o = 0;
+  for (int k = 0; k < n; ++k) {
+    const int v = ids[k];
+    if (v < 0 || v >= h->g.nv()) return set_error(SSLAM_ERR_INVALID, "bad vertex id %d", v);
+    const int d = vertex_dim(h->g.vtype[v]);
+    const int hi = hidx[v];
+    if (hi < 0) { for (int e = 0; e < d * d; ++e) out[o++] = 0; continue; }
+    for (int c = 0; c < d; ++c) {
+      rhs_g2o[hi + c] = 1.0;
+      from_g2o_order(h, rhs_g2o.data(), rhs_int);
+      rhs_g2o[hi + c] = 0.0;
+      SSLAM_HIP_TRY(hipMemcpyAsync(b.V.bvec, rhs_int.data(), rhs_int.size() * 8, hipMemcpyHostToDevice, b.stream));
+      hipLaunchKernelGGL(k_set_trial_all, dim3((b.V.B + 63) / 64), dim3(64), 0, b.stream, b.V, 0.0);
+      if ((rc = batch_solve(b))) return rc;
+      SSLAM_HIP_TRY(hipMemcpyAsync(xi.data(), b.V.x, xi.size() * 8, hipMemcpyDeviceToHost, b.stream));
+      SSLAM_HIP_TRY(hipStreamSynchronize(b.stream));
+      to_g2o_order(h, xi, xg.data());
+      for (int r = 0; r < d; ++r) out[o + r * d + c] = xg[hi + r];
+    }
+    o += (size_t)d * d;
+  }
+  h->linearized = false;  // b was overwritten
+  return 0;
+}
+
+// ---- g2o text format (GraphSLAM::save, graph_slam.cpp:236-239; SURVEY §5 checkpoint row) ------
+int sslam_graph_save_g2o(const sslam_graph* h, const char* path) {
+  if (!h || !path) return set_error(SSLAM_ERR_INVALID, "null argument");
+  FILE* f = fopen(path, "w");
+  if (!f) return set_error(SSLAM_ERR_IO, "cannot open %s for writing", path);
+  const HostGraph& G = h->g;
+  fprintf(f, "PARAMS_SE3OFFSET 0 0 0 0 0 0 0 1\n");
+  for (int v = 0; v < G.nv(); ++v) {
+    const double* e = &G.est[(size_t)v * 7];
+    if (G.vtype[v] == VT_SE3) fprintf(f, "VERTEX_SE3:QUAT %d %.17g %.17g %.17g %.17g %.17g %.17g %.17g\n", v, e[0], e[1], e[2], e[3], e[4], e[5], e[6]);
+    else if (G.vtype[v] == VT_POINT) fprintf(f, "VERTEX_TRACKXYZ %d %.17g %.17g %.17g\n", v, e[0], e[1], e[2]);
+    else fprintf(f, "VERTEX_PLANE %d %.17g %.17g %.17g %.17g\n", v, e[0], e[1], e[2], e[3]);
+    if (G.vfixed[v]) fprintf(f, "FIX %d\n", v);
+  }
+  for (int k = 0; k < G.ne(); ++k) {
+    const double* z = &G.meas[(size_t)k * 7];
+    const double* W = &G.info[(size_t)k * 36];
+    if (G.etype[k] == ET_SE3) {
+      fprintf(f, "EDGE_SE3:QUAT %d %d", G.evi[k], G.evj[k]);
+      for (int c = 0; c < 7; ++c) fprintf(f, " %.17g", z[c]);
+      for (int r = 0; r < 6; ++r) for (int c = r; c < 6; ++c) fprintf(f, " %.17g", W[r * 6 + c]);
+    } else if (G.etype[k] == ET_SE3_POINT) {
+      fprintf(f, "EDGE_SE3_TRACKXYZ %d %d 0", G.evi[k], G.evj[k]);
+      for (int c = 0; c < 3; ++c) fprintf(f, " %.17g", z[c]);
+      for (int r = 0; r < 3; ++r) for (int c = r; c < 3; ++c) fprintf(f, " %.17g", W[r * 3 + c]);
+    } else {  // row format of the in-tree EdgeSE3Plane::write (edge_se3_plane.hpp:40-47)
+      fprintf(f, "EDGE_SE3_PLANE %d %d", G.evi[k], G.evj[k]);
+      for (int c = 0; c < 4; ++c) fprintf(f, " %.17g", z[c]);
+      for (int r = 0; r < 3; ++r) for (int c = r; c < 3; ++c) fprintf(f, " %.17g", W[r * 3 + c]);
+    }
+    fprintf(f, "\n");
+  }
+  fclose(f);
+  return 0;
+}
+
+int sslam_graph_load_g2o(sslam_graph* h, const char* path) {
+  if (!h || !path) return set_error(SSLAM_ERR_INVALID, "null argument");
+  if (h->g.nv() != 0) return set_error(SSLAM_ERR_INVALID, "load requires an empty graph");
+  FILE* f = fopen(path, "r");
+  if (!f) return set_error(SSLAM_ERR_IO, "cannot open %s", path);
+  char tag[64];
+  std::unordered_map<int, int> idmap;  // file id -> vertex id (ids must be dense & ordered for exact round trips)
+  auto rd = [&](double* a, int n) { for (int k = 0; k < n; ++k) if (fscanf(f, "%lf", a + k) != 1) return false; return true; };
+  int rc = 0;
+  while (fscanf(f, "%63s", tag) == 1) {
+    const std::string t(tag);
+    if (t == "VERTEX_SE3:QUAT") { int id; double e[7]; if (fscanf(f, "%d", &id) != 1 || !rd(e, 7)) { rc = -1; break; } idmap[id] = add_vertex(h, VT_SE3, e, 7, 0); }
+    else if (t == "VERTEX_TRACKXYZ") { int id; double e[3]; if (fscanf(f, "%d", &id) != 1 || !rd(e, 3)) { rc = -1; break; } idmap[id] = add_vertex(h, VT_POINT, e, 3, 0); }
+    else if (t == "VERTEX_PLANE") { int id; double e[4]; if (fscanf(f, "%d", &id) != 1 || !rd(e, 4)) { rc = -1; break; } idmap[id] = add_vertex(h, VT_PLANE, e, 4, 0); }
+    else if (t == "FIX") { int id; if (fscanf(f, "%d", &id) != 1 || !idmap.count(id)) { rc = -1; break; } h->g.vfixed[idmap[id]] = 1; }
+    else if (t == "EDGE_SE3:QUAT") {
+      int i, j; double z[7], u[21], W[36];
+      if (fscanf(f, "%d %d", &i, &j) != 2 || !rd(z, 7) || !rd(u, 21) || !idmap.count(i) || !idmap.count(j)) { rc = -1; break; }
+      int q = 0; for (int r = 0; r < 6; ++r) for (int c = r; c < 6; ++c) { W[r * 6 + c] = u[q]; W[c * 6 + r] = u[q]; ++q; }
+      if (add_edge(h, ET_SE3, idmap[i], idmap[j], z, 7, W, 6) < 0) { rc = -1; break; }
+    } else if (t == "EDGE_SE3_TRACKXYZ") {
+      int i, j, pid; double z[3], u[6], W[9];
+      if (fscanf(f, "%d %d %d", &i, &j, &pid) != 3 || !rd(z, 3) || !rd(u, 6) || !idmap.count(i) || !idmap.count(j)) { rc = -1; break; }
+      int q = 0; for (int r = 0; r < 3; ++r) for (int c = r; c < 3; ++c) { W[r * 3 + c] = u[q]; W[c * 3 + r] = u[q]; ++q; }
+      if (add_edge(h, ET_SE3_POINT, idmap[i], idmap[j], z, 3, W, 3) < 0) { rc = -1; break; }
+    } else if (t == "EDGE_SE3_PLANE") {
+      int i, j; double z[4], u[6], W[9];
+      if (fscanf(f, "%d %d", &i, &j) != 2 || !rd(z, 4) || !rd(u, 6) || !idmap.count(i) || !idmap.count(j)) { rc = -1; break; }
+      int q = 0; for (int r = 0; r < 3; ++r) for (int c = r; c < 3; ++c) { W[r * 3 + c] = u[q]; W[c * 3 + r] = u[q]; ++q; }
+      if (add_edge(h, ET_SE3_PLANE, idmap[i], idmap[j], z, 4, W, 3) < 0) { rc = -1; break; }
+    } else {  // PARAMS_SE3OFFSET and unknown rows: skip to end of line
+      int ch; while ((ch = fgetc(f)) != EOF && ch != '\n') {}
+    }
+  }
+  fclose(f);
+  if (rc) return set_error(SSLAM_ERR_IO, "parse error in %s near tag %s", path, tag);
+  return 0;
+}
+
+// ---- batch API --------------------------------------------------------------------------------
+sslam_batch* sslam_batch_create(sslam_graph* const* graphs, int n) {
+  if (!graphs || n <= 0) { set_error(SSLAM_ERR_INVALID, "empty batch"); return nullptr; }
+  int nd = 0;
+  if (hipGetDeviceCount(&nd) != hipSuccess || nd <= 0) { set_error(SSLAM_ERR_NO_DEVICE, "no HIP device visible; the product has no CPU fallback"); return nullptr; }
+  sslam_batch* h = new sslam_batch();
+  h->b.device = graphs[0]->g.device;
+  for (int i = 0; i < n; ++i) {
+    if (!graphs[i] || graphs[i]->g.device != h->b.device) { set_error(SSLAM_ERR_INVALID, "batch graphs must share one device"); delete h; return nullptr; }
+    h->b.graphs.push_back(&graphs[i]->g);
+  }
+  if (batch_build(h->b) != 0) { delete h; return nullptr; }
+  return h;
+}
+void sslam_batch_destroy(sslam_batch* h) { delete h; }
+int sslam_batch_upload(sslam_batch* h) { return h ? batch_upload_estimates(h->b) : set_error(SSLAM_ERR_INVALID, "null batch"); }
+int sslam_batch_download(sslam_batch* h) { return h ? batch_download_estimates(h->b) : set_error(SSLAM_ERR_INVALID, "null batch"); }
+int sslam_batch_optimize(sslam_batch* h, int max_iters, sslam_opt_stats* out) {
+  if (!h || !out) return set_error(SSLAM_ERR_INVALID, "null argument");
+  return batch_optimize(h->b, max_iters, out);
+}
+int sslam_batch_time_linearize(sslam_batch* h, int repeats, double* ms_per_build) {
+  if (!h || !ms_per_build || repeats <= 0) return set_error(SSLAM_ERR_INVALID, "bad argument");
+  Batch& b = h->b;
+  SSLAM_HIP_TRY(hipSetDevice(b.device));
+  int rc;
+  if (!b.uploaded && (rc = batch_upload_estimates(b))) return rc;
+  if ((rc = batch_chi2(b, b.V.pose, b.V.lmk, 0))) return rc;
+  hipLaunchKernelGGL(k_lm_init, dim3(b.V.B), dim3(64), 0, b.stream, b.V, b.d_part_e);
+  const bool prof = b.profiling;
+  b.profiling = false;
+  if ((rc = batch_linearize(b))) return rc;  // warm-up
+  hipEvent_t e0, e1;
+  SSLAM_HIP_TRY(hipEventCreate(&e0)); SSLAM_HIP_TRY(hipEventCreate(&e1));
+  SSLAM_HIP_TRY(hipEventRecord(e0, b.stream));
+  for (int k = 0; k < repeats; ++k) if ((rc = batch_linearize(b))) return rc;
+  SSLAM_HIP_TRY(hipEventRecord(e1, b.stream));
+  SSLAM_HIP_TRY(hipEventSynchronize(e1));
+  float ms = 0;
+  SSLAM_HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+  hipEventDestroy(e0); hipEventDestroy(e1);
+  b.profiling = prof;
+  *ms_per_build = (double)ms / repeats;
+  return 0;
+}
+int64_t sslam_batch_linearize_bytes(const sslam_batch* h) {
+  if (!h) return 0;
+  const Batch& b = h->b;
+  // 344*Eo + 160*El(176 plane) + 288*Np + 72*Nl + 288*Eo + 144*El + 48*Np + 24*Nl
+  int64_t bytes = 0;
+  for (size_t g = 0; g < b.graphs.size(); ++g) {
+    const HostGraph& G = *b.graphs[g];
+    for (int k = 0; k < G.ne(); ++k) bytes += G.etype[k] == ET_SE3 ? 344 + 288 : (G.etype[k] == ET_SE3_POINT ? 160 + 144 : 176 + 144);
+  }
+  bytes += (int64_t)b.V.nPr * (288 + 48) + (int64_t)b.V.nLr * (72 + 24);
+  return bytes;
+}
+int sslam_batch_set_profiling(sslam_batch* h, int enable) {
+  if (!h) return set_error(SSLAM_ERR_INVALID, "null batch");
+  h->b.profiling = enable != 0;
+  h->b.timers.clear();
+  return 0;
+}
+int sslam_batch_kernel_time(sslam_batch* h, const char* name, double* total_ms, int64_t* launches) {
+  if (!h || !name) return set_error(SSLAM_ERR_INVALID, "null argument");
+  auto it = h->b.timers.find(name);
+  if (total_ms) *total_ms = it == h->b.timers.end() ? 0.0 : it->second.total_ms;
+  if (launches) *launches = it == h->b.timers.end() ? 0 : it->second.launches;
+  return 0;
+}
+
+}  // extern "C"
