@@ -1,0 +1,118 @@
+// Batch engine state shared by the backend translation units (LM driver, sparse Cholesky).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <array>
+#include <cstdint>
+#include <map>
+#include <string>
+#include <vector>
+#include "graph_host.hpp"
+#include "graph_kernels.hpp"
+#include "sslam_common.hpp"
+
+namespace sslam {
+
+struct CholPlan;
+void chol_plan_free(CholPlan*);
+
+struct KernelTimer {
+  double total_ms = 0;
+  int64_t launches = 0;
+};
+
+struct Batch {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::vector<HostGraph*> graphs;
+  std::vector<uint64_t> versions;
+  BatchView V{};
+  std::vector<void*> allocs;
+  // host-side metadata
+  std::vector<GraphSeg> seg;
+  std::vector<std::vector<int>> v2pose, v2lm;     // per graph: vertex id -> pose / landmark index (global), -1
+  std::vector<int> pose_row, lm_row;              // global
+  std::vector<int> prow_pose, lrow_lm;
+  std::vector<std::pair<int, int>> ppoff;         // unique pose-pose blocks (row a < row b)
+  std::vector<std::pair<int, int>> plblk;         // unique pose-landmark blocks (pose row, lm row)
+  std::vector<int> pose_vertex, lm_vertex;        // global pose/lm index -> vertex id in its graph
+  int64_t hpp_off_base = 0, hpl_base = 0, hll_base = 0;
+  double* d_part_e = nullptr;  // [B*maxEdgeChunks]
+  double* d_part_m = nullptr;  // [B*maxRowChunks] (max diag)
+  bool profiling = false;
+  std::map<std::string, KernelTimer> timers;
+  struct Pending { std::string name; hipEvent_t a, b; };
+  std::vector<Pending> pending;
+  std::vector<hipEvent_t> event_pool;
+  bool uploaded = false;
+  bool has_duplicate_blocks = false;
+  bool has_planes = false;
+  std::vector<int> dup_eo, dup_el;
+  int max_row_slots = 0;
+  CholPlan* chol = nullptr;
+
+  ~Batch() { release(); }
+  void release() {
+    if (chol) { chol_plan_free(chol); chol = nullptr; }
+    if (stream) { hipSetDevice(device); hipStreamSynchronize(stream); }
+    for (auto& p : pending) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
+    pending.clear();
+    for (auto e : event_pool) hipEventDestroy(e);
+    event_pool.clear();
+    for (void* p : allocs) hipFree(p);
+    allocs.clear();
+    if (stream) { hipStreamDestroy(stream); stream = nullptr; }
+  }
+  hipEvent_t get_event() {
+    if (!event_pool.empty()) { hipEvent_t e = event_pool.back(); event_pool.pop_back(); return e; }
+    hipEvent_t e; hipEventCreate(&e); return e;
+  }
+  void harvest() {  // call after a stream sync
+    for (auto& p : pending) {
+      float ms = 0;
+      if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) { timers[p.name].total_ms += ms; timers[p.name].launches += 1; }
+      event_pool.push_back(p.a); event_pool.push_back(p.b);
+    }
+    pending.clear();
+  }
+};
+
+struct ScopedTimer {
+  Batch& b; const char* name; hipEvent_t a{}, e{}; bool on;
+  ScopedTimer(Batch& bb, const char* n) : b(bb), name(n), on(bb.profiling) {
+    if (on) { a = b.get_event(); e = b.get_event(); hipEventRecord(a, b.stream); }
+  }
+  ~ScopedTimer() {
+    if (on) { hipEventRecord(e, b.stream); b.pending.push_back({name, a, e}); }
+  }
+};
+
+template <typename T>
+inline int dev_upload(Batch& b, const std::vector<T>& h, T** out, size_t min_elems = 1) {
+  const size_t n = std::max(h.size(), min_elems);
+  void* p = nullptr;
+  SSLAM_HIP_TRY(hipMalloc(&p, n * sizeof(T)));
+  b.allocs.push_back(p);
+  if (!h.empty()) SSLAM_HIP_TRY(hipMemcpyAsync(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, b.stream));
+  *out = (T*)p;
+  return 0;
+}
+template <typename T>
+inline int dev_alloc(Batch& b, size_t n, T** out, bool zero = true) {
+  void* p = nullptr;
+  n = std::max<size_t>(n, 1);
+  SSLAM_HIP_TRY(hipMalloc(&p, n * sizeof(T)));
+  b.allocs.push_back(p);
+  if (zero) SSLAM_HIP_TRY(hipMemsetAsync(p, 0, n * sizeof(T), b.stream));
+  *out = (T*)p;
+  return 0;
+}
+
+
+// sparse block Cholesky (sslam_chol.hip)
+int chol_plan_build(Batch& b);
+int chol_factor_and_forward(Batch& b);   // (H + lambda I) = L L^T for in_trial graphs, y = L^-1 b
+int chol_backward(Batch& b);             // x = L^-T y  -> V.x
+int chol_solve_multi(Batch& b, const double* rhs_host, int nrhs, double* x_host);  // uses the last factorisation
+
+}  // namespace sslam

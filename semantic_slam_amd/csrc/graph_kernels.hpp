@@ -16,7 +16,8 @@
 namespace sslam {
 
 constexpr int kEdgeChunk = 256;  // threads per workgroup in edge-parallel kernels
-constexpr int kRowChunk = 192;   // threads per workgroup in scalar-row kernels (multiple of 6 and 64)
+constexpr int kRowChunk = 192;
+constexpr int kTileSlots = 96;   // max (row, edge) slots per Jacobian-build tile (LDS budget)   // threads per workgroup in scalar-row kernels (multiple of 6 and 64)
 
 struct GraphSeg {
   int prow0, nprow;  // active pose rows  [prow0, prow0+nprow)
@@ -58,6 +59,14 @@ struct BatchView {
   int64_t h_total;  // doubles in the H allocation
   // row adjacency for SpMV (rows = pose rows then landmark rows)
   const int* adj_ptr; const int* adj_blk; const int* adj_x; const unsigned char* adj_fmt;
+  // gather-form Jacobian build: (row, incident edge) slots, pose rows tiled by slot count
+  int nTiles;
+  const int* tile_row0; const int* tile_row1;       // [nTiles] pose-row range of a tile (one graph each)
+  const int* pslot_ptr;                             // [nPr+1]
+  const int4* pslot_rec;                            // [slots] {edge, kind, pose i | pose, pose j | landmark}
+  const int* pslot_edge; const unsigned char* pslot_kind;  // kind 0: SE3 edge, self = i; 1: SE3, self = j; 2: landmark edge
+  const int* lslot_ptr; const int* lslot_edge;      // [nLr+1], landmark-side slots (edge index into el_*)
+  int nDupEo, nDupEl; const int* dup_eo; const int* dup_el;  // non-owner edges of shared off-diagonal blocks
   // PCG vectors
   double* x; double* r; double* z; double* p; double* q; double* Minv;  // Minv: [nPr*36 | nLr*9]
   double* part_a; double* part_b; double* part_c;  // [B*maxChunks] partial sums

@@ -16,6 +16,7 @@
 #include "graph_host.hpp"
 #include "graph_kernels.hpp"
 #include "sslam_common.hpp"
+#include "graph_engine.hpp"
 
 namespace sslam {
 
@@ -81,6 +82,8 @@ __global__ __launch_bounds__(kEdgeChunk) void k_chi2(BatchView V, const double* 
 
 // ---- Jacobian build, variant A: edge-parallel, hardware FP64 atomics (global_atomic_add_f64) --
 __device__ __forceinline__ void atomic_add(double* p, double v) { unsafeAtomicAdd(p, v); }
+// off-diagonal block codes: >= 0 owner edge, <= -2 a further edge on the same vertex pair, -1 none
+__device__ __forceinline__ int decode_blk(int code) { return code <= -2 ? -2 - code : code; }
 
 __global__ __launch_bounds__(kEdgeChunk) void k_linearize_atomic(BatchView V) {
   const int g = blockIdx.y;
@@ -100,7 +103,7 @@ __global__ __launch_bounds__(kEdgeChunk) void k_linearize_atomic(BatchView V) {
     se3_full_jacobians(L, Ji, Jj);
     load_sym6(V.eo_w, n, k, W);
     const int ri = V.pose_row[pi], rj = V.pose_row[pj];
-    const int blk = V.eo_blk[k];
+    const int blk = decode_blk(V.eo_blk[k]);
     double We[6];
     for (int r = 0; r < 6; ++r) { double a = 0; for (int s = 0; s < 6; ++s) a += W[r * 6 + s] * L.e[s]; We[r] = a; }
     // WJ = W * J  (one side at a time to bound live registers)
@@ -167,7 +170,7 @@ __global__ __launch_bounds__(kEdgeChunk) void k_linearize_atomic(BatchView V) {
         atomic_add(V.bvec + 6 * (size_t)V.nPr + 3 * (size_t)rl + r, -(Jl[r] * We[0] + Jl[3 + r] * We[1] + Jl[6 + r] * We[2]));
       }
     }
-    const int blk = V.el_blk[k];
+    const int blk = decode_blk(V.el_blk[k]);
     if (blk >= 0) {
       double* O = V.Hpl + (size_t)blk * 18;
       for (int r = 0; r < 6; ++r)
@@ -199,11 +202,459 @@ __global__ void k_zero_offdiag(BatchView V) {
   const GraphSeg sg = V.seg[g];
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e < sg.neo) {
-    const int blk = V.eo_blk[sg.eo0 + e];
+    const int blk = decode_blk(V.eo_blk[sg.eo0 + e]);
     if (blk >= 0) { double* O = V.Hpp_off + (size_t)(blk >> 1) * 36; for (int k = 0; k < 36; ++k) O[k] = 0; }
   } else if (e < sg.neo + sg.nel) {
-    const int blk = V.el_blk[sg.el0 + e - sg.neo];
+    const int blk = decode_blk(V.el_blk[sg.el0 + e - sg.neo]);
     if (blk >= 0) { double* O = V.Hpl + (size_t)blk * 18; for (int k = 0; k < 18; ++k) O[k] = 0; }
+  }
+}
+
+// ---- Jacobian build, variant B (default): gather form, deterministic, no atomics ----------------
+// One 256-thread workgroup per tile of consecutive pose rows (<= kTileSlots incident-edge slots).
+// Phase A: a group of 8 lanes evaluates one (row, edge) slot; lane r (< 6) owns column r of the
+//   Jacobians and row r of the products.  W*J is exchanged through a per-group LDS scratch; the
+//   off-diagonal block owned by the slot is written straight to HBM (288 / 144 contiguous bytes per
+//   group), the diagonal/b contribution goes to LDS.
+// Phase B: per output scalar, a fixed-order sum over the row's slots -> Hpp_diag, b.
+__device__ __forceinline__ Pose load_meas_pose(const double* z, int n, int k) {
+  return Pose{{z[0 * (size_t)n + k], z[1 * (size_t)n + k], z[2 * (size_t)n + k]},
+              {z[3 * (size_t)n + k], z[4 * (size_t)n + k], z[5 * (size_t)n + k], z[6 * (size_t)n + k]}};
+}
+
+template <bool PL>
+__global__ __launch_bounds__(256) void k_linearize_rows(BatchView V) {
+  __shared__ double contrib[kTileSlots * 42];   // [slot][r][7]: D row r (6) + b_r
+  __shared__ double scratch[32 * 72];           // per group: WJs[6][6], WJo[6][6]
+  const int tile = blockIdx.x;
+  const int row0 = V.tile_row0[tile], row1 = V.tile_row1[tile];
+  const int g = V.prow_graph[row0];
+  if (!V.lm[g].active) return;
+  const int slot0 = V.pslot_ptr[row0], slot1 = V.pslot_ptr[row1];
+  const int nslots = slot1 - slot0;
+  const int group = threadIdx.x >> 3, r = threadIdx.x & 7;
+  double* sc = scratch + group * 72;
+  const int rounds = (nslots + 31) >> 5;
+  for (int round = 0; round < rounds; ++round) {
+    const int sl = round * 32 + group;           // slot index inside the tile
+    const bool live = sl < nslots && r < 6;
+    int kind = 0, e = 0;
+    double self[6], other[6], We[6];
+    int blk = -1;
+    bool owner = false;
+#pragma unroll
+    for (int q = 0; q < 6; ++q) { self[q] = 0; other[q] = 0; We[q] = 0; }
+    if (live) {
+      kind = V.pslot_kind[slot0 + sl];
+      e = V.pslot_edge[slot0 + sl];
+      if (kind < 2) {
+        const int n = V.nEo;
+        Se3Lin L;
+        se3_error(load_pose(V.pose, V.eo_i[e]), load_pose(V.pose, V.eo_j[e]), load_meas_pose(V.eo_z, n, e), L);
+        L.Re = qmat(L.qe);
+        double ci[6], cj[6];
+        se3_Ji_col(L, r, ci);
+        se3_Jj_col(L, r, cj);
+        blk = V.eo_blk[e];
+        owner = (kind == 0) && blk >= 0;
+#pragma unroll
+        for (int q = 0; q < 6; ++q) { self[q] = kind == 0 ? ci[q] : cj[q]; other[q] = kind == 0 ? cj[q] : ci[q]; }
+        double W[36];
+        load_sym6(V.eo_w, n, e, W);
+#pragma unroll
+        for (int a = 0; a < 6; ++a) {
+          double ws = 0, wo = 0, we = 0;
+#pragma unroll
+          for (int q = 0; q < 6; ++q) { ws += W[a * 6 + q] * self[q]; wo += W[a * 6 + q] * other[q]; we += W[a * 6 + q] * L.e[q]; }
+          sc[a * 6 + r] = ws; sc[36 + a * 6 + r] = wo; We[a] = we;
+        }
+      } else {
+        const int n = V.nEl;
+        const int li = V.el_l[e];
+        const Pose Xi = load_pose(V.pose, V.el_p[e]);
+        const double* lp = V.lmk + (size_t)li * 4;
+        double err[3], jl[3];   // jl: column r of Jl (lanes r < 3)
+        jl[0] = jl[1] = jl[2] = 0;
+        if (!PL || V.lm_kind[li] == VT_POINT) {
+          PointLin L;
+          point_error(Xi, Vec3{lp[0], lp[1], lp[2]}, Vec3{V.el_z[0 * (size_t)n + e], V.el_z[1 * (size_t)n + e], V.el_z[2 * (size_t)n + e]}, L);
+          err[0] = L.e[0]; err[1] = L.e[1]; err[2] = L.e[2];
+          // Ji = [-I | 2[pc]x], column r
+          const double px = L.pc.x, py = L.pc.y, pz = L.pc.z;
+          if (r == 0) { self[0] = -1; } else if (r == 1) { self[1] = -1; } else if (r == 2) { self[2] = -1; }
+          else if (r == 3) { self[1] = 2 * pz; self[2] = -2 * py; }
+          else if (r == 4) { self[0] = -2 * pz; self[2] = 2 * px; }
+          else { self[0] = 2 * py; self[1] = -2 * px; }
+          if (r < 3) {  // Jl = R^T: column r = row r of R
+            jl[0] = pick3(r, L.R.m[0], L.R.m[3], L.R.m[6]); jl[1] = pick3(r, L.R.m[1], L.R.m[4], L.R.m[7]); jl[2] = pick3(r, L.R.m[2], L.R.m[5], L.R.m[8]);
+          }
+        } else {
+          const Plane pw{{lp[0], lp[1], lp[2]}, lp[3]};
+          const Plane z{{V.el_z[0 * (size_t)n + e], V.el_z[1 * (size_t)n + e], V.el_z[2 * (size_t)n + e]}, V.el_z[3 * (size_t)n + e]};
+          plane_error(Xi, pw, z, err);
+          const double delta = 1e-9, scalar = 1.0 / (2 * delta);
+          double dv[6], ep[3], em[3];
+#pragma unroll
+          for (int q = 0; q < 6; ++q) dv[q] = q == r ? delta : 0.0;
+          plane_error(se3_oplus(Xi, dv), pw, z, ep);
+#pragma unroll
+          for (int q = 0; q < 6; ++q) dv[q] = q == r ? -delta : 0.0;
+          plane_error(se3_oplus(Xi, dv), pw, z, em);
+          self[0] = scalar * (ep[0] - em[0]); self[1] = scalar * (ep[1] - em[1]); self[2] = scalar * (ep[2] - em[2]);
+          if (r < 3) {
+            double d3[3];
+#pragma unroll
+            for (int q = 0; q < 3; ++q) d3[q] = q == r ? delta : 0.0;
+            plane_error(Xi, pl_oplus(pw, d3), z, ep);
+#pragma unroll
+            for (int q = 0; q < 3; ++q) d3[q] = q == r ? -delta : 0.0;
+            plane_error(Xi, pl_oplus(pw, d3), z, em);
+            jl[0] = scalar * (ep[0] - em[0]); jl[1] = scalar * (ep[1] - em[1]); jl[2] = scalar * (ep[2] - em[2]);
+          }
+        }
+        blk = V.el_blk[e];
+        owner = blk >= 0;
+        double W[9];
+        load_sym3(V.el_w, n, e, W);
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+          sc[a * 6 + r] = W[a * 3 + 0] * self[0] + W[a * 3 + 1] * self[1] + W[a * 3 + 2] * self[2];       // (W Ji)[a][r]
+          if (r < 3) sc[36 + a * 3 + r] = W[a * 3 + 0] * jl[0] + W[a * 3 + 1] * jl[1] + W[a * 3 + 2] * jl[2];  // (W Jl)[a][r]
+          We[a] = W[a * 3 + 0] * err[0] + W[a * 3 + 1] * err[1] + W[a * 3 + 2] * err[2];
+        }
+      }
+    }
+    __syncthreads();
+    if (live) {
+      double* out = contrib + sl * 42 + r * 7;
+      if (kind < 2) {
+#pragma unroll
+        for (int c = 0; c < 6; ++c) {
+          double d = 0;
+#pragma unroll
+          for (int q = 0; q < 6; ++q) d += self[q] * sc[q * 6 + c];
+          out[c] = d;
+        }
+        double bb = 0;
+#pragma unroll
+        for (int q = 0; q < 6; ++q) bb += self[q] * We[q];
+        out[6] = -bb;
+        if (owner) {
+          double* O = V.Hpp_off + (size_t)(blk >> 1) * 36 + r * 6;
+          if (!(blk & 1)) {   // stored [row_i][row_j]: row r of Ji^T W Jj
+#pragma unroll
+            for (int c = 0; c < 6; ++c) { double d = 0;
+#pragma unroll
+              for (int q = 0; q < 6; ++q) d += self[q] * sc[36 + q * 6 + c];
+              O[c] = d; }
+          } else {            // stored [row_j][row_i]: row r of Jj^T W Ji
+#pragma unroll
+            for (int c = 0; c < 6; ++c) { double d = 0;
+#pragma unroll
+              for (int q = 0; q < 6; ++q) d += other[q] * sc[q * 6 + c];
+              O[c] = d; }
+          }
+        }
+      } else {
+#pragma unroll
+        for (int c = 0; c < 6; ++c) out[c] = self[0] * sc[0 * 6 + c] + self[1] * sc[1 * 6 + c] + self[2] * sc[2 * 6 + c];
+        out[6] = -(self[0] * We[0] + self[1] * We[1] + self[2] * We[2]);
+        if (owner) {
+          double* O = V.Hpl + (size_t)blk * 18 + r * 3;
+#pragma unroll
+          for (int c = 0; c < 3; ++c) O[c] = self[0] * sc[36 + 0 * 3 + c] + self[1] * sc[36 + 1 * 3 + c] + self[2] * sc[36 + 2 * 3 + c];
+        }
+      }
+    }
+    __syncthreads();
+  }
+  // phase B: fixed-order sums per output scalar
+  const int nrows = row1 - row0;
+  for (int t = threadIdx.x; t < nrows * 42; t += 256) {
+    const int lr = t / 42, rem = t - lr * 42;
+    const int rr = rem / 7, k = rem - rr * 7;
+    const int row = row0 + lr;
+    const int s0 = V.pslot_ptr[row] - slot0, s1 = V.pslot_ptr[row + 1] - slot0;
+    double acc = 0;
+    for (int s = s0; s < s1; ++s) acc += contrib[s * 42 + rr * 7 + k];
+    if (k < 6) V.Hpp_diag[(size_t)row * 36 + rr * 6 + k] = acc;
+    else V.bvec[(size_t)row * 6 + rr] = acc;
+  }
+}
+
+// ---- Jacobian build, variant C (default): one 8-lane group per pose row, registers only ---------
+// Lane r (< 6) of a group owns column r of the Jacobians and row r of every product of its row.
+// The group walks the row's (edge) slots; W*J columns are exchanged with wave shuffles (no LDS, no
+// barriers), the diagonal block / b accumulate in registers and are written once (288 + 48
+// contiguous bytes per row, rows of a wave are consecutive -> fully coalesced), off-diagonal blocks
+// are written by their owner slot.  Slot records are fetched lane-parallel (one latency per 8 slots).
+__device__ __forceinline__ double group_bcast(double v, int src_lane) { return __shfl(v, src_lane, 64); }
+
+template <bool PL>
+__global__ __launch_bounds__(256) void k_linearize_rows2(BatchView V) {
+  const int row = blockIdx.x * 32 + (threadIdx.x >> 3);
+  const int r = threadIdx.x & 7;
+  const int gbase = (threadIdx.x & 63) & ~7;   // first lane of this group inside the wave
+  const bool row_ok = row < V.nPr && V.lm[V.prow_graph[row < V.nPr ? row : 0]].active;
+  const bool lane_ok = row_ok && r < 6;
+  const int s0 = row_ok ? V.pslot_ptr[row] : 0, s1 = row_ok ? V.pslot_ptr[row + 1] : 0;
+  // all groups of a wave iterate to the longest slot list among them (shuffles need every lane)
+  int nmax = s1 - s0;
+#pragma unroll
+  for (int o = 8; o < 64; o <<= 1) nmax = max(nmax, __shfl_xor(nmax, o, 64));
+  double D[6] = {0, 0, 0, 0, 0, 0};
+  double bacc = 0;
+  int4 rec = make_int4(0, 0, 0, 0);
+  for (int t = 0; t < nmax; ++t) {
+    if ((t & 7) == 0) {  // lane-parallel fetch of the next 8 slot records
+      const int s = s0 + t + r;
+      rec = s < s1 ? V.pslot_rec[s] : make_int4(0, -1, 0, 0);
+    }
+    const int src = gbase + (t & 7);
+    const int e = __shfl(rec.x, src, 64), kind = __shfl(rec.y, src, 64), ia = __shfl(rec.z, src, 64), ib = __shfl(rec.w, src, 64);
+    const bool live = lane_ok && (s0 + t) < s1;
+    double self[6] = {0, 0, 0, 0, 0, 0}, other[6] = {0, 0, 0, 0, 0, 0}, We[6] = {0, 0, 0, 0, 0, 0};
+    double WJs[6] = {0, 0, 0, 0, 0, 0}, WJo[6] = {0, 0, 0, 0, 0, 0};
+    int blk = -1;
+    if (live) {
+      if (kind < 2) {
+        const int n = V.nEo;
+        Se3Lin L;
+        se3_error(load_pose(V.pose, ia), load_pose(V.pose, ib), load_meas_pose(V.eo_z, n, e), L);
+        L.Re = qmat(L.qe);
+        double ci[6], cj[6];
+        se3_Ji_col(L, r, ci);
+        se3_Jj_col(L, r, cj);
+        blk = V.eo_blk[e];
+#pragma unroll
+        for (int q = 0; q < 6; ++q) { self[q] = kind == 0 ? ci[q] : cj[q]; other[q] = kind == 0 ? cj[q] : ci[q]; }
+        if (kind != 0) blk = -1;
+        double W[36];
+        load_sym6(V.eo_w, n, e, W);
+#pragma unroll
+        for (int a = 0; a < 6; ++a) {
+          double ws = 0, wo = 0, we = 0;
+#pragma unroll
+          for (int q = 0; q < 6; ++q) { ws += W[a * 6 + q] * self[q]; wo += W[a * 6 + q] * other[q]; we += W[a * 6 + q] * L.e[q]; }
+          WJs[a] = ws; WJo[a] = wo; We[a] = we;
+        }
+      } else {
+        const int n = V.nEl;
+        const Pose Xi = load_pose(V.pose, ia);
+        const double* lp = V.lmk + (size_t)ib * 4;
+        double err[3], jl[3] = {0, 0, 0};
+        if (!PL || V.lm_kind[ib] == VT_POINT) {
+          PointLin L;
+          point_error(Xi, Vec3{lp[0], lp[1], lp[2]}, Vec3{V.el_z[0 * (size_t)n + e], V.el_z[1 * (size_t)n + e], V.el_z[2 * (size_t)n + e]}, L);
+          err[0] = L.e[0]; err[1] = L.e[1]; err[2] = L.e[2];
+          const double px = L.pc.x, py = L.pc.y, pz = L.pc.z;
+          if (r == 0) { self[0] = -1; } else if (r == 1) { self[1] = -1; } else if (r == 2) { self[2] = -1; }
+          else if (r == 3) { self[1] = 2 * pz; self[2] = -2 * py; }
+          else if (r == 4) { self[0] = -2 * pz; self[2] = 2 * px; }
+          else { self[0] = 2 * py; self[1] = -2 * px; }
+          if (r < 3) { jl[0] = pick3(r, L.R.m[0], L.R.m[3], L.R.m[6]); jl[1] = pick3(r, L.R.m[1], L.R.m[4], L.R.m[7]); jl[2] = pick3(r, L.R.m[2], L.R.m[5], L.R.m[8]); }
+        } else {
+          const Plane pw{{lp[0], lp[1], lp[2]}, lp[3]};
+          const Plane z{{V.el_z[0 * (size_t)n + e], V.el_z[1 * (size_t)n + e], V.el_z[2 * (size_t)n + e]}, V.el_z[3 * (size_t)n + e]};
+          plane_error(Xi, pw, z, err);
+          const double delta = 1e-9, scalar = 1.0 / (2 * delta);
+          double dv[6], ep[3], em[3];
+#pragma unroll
+          for (int q = 0; q < 6; ++q) dv[q] = q == r ? delta : 0.0;
+          plane_error(se3_oplus(Xi, dv), pw, z, ep);
+#pragma unroll
+          for (int q = 0; q < 6; ++q) dv[q] = q == r ? -delta : 0.0;
+          plane_error(se3_oplus(Xi, dv), pw, z, em);
+          self[0] = scalar * (ep[0] - em[0]); self[1] = scalar * (ep[1] - em[1]); self[2] = scalar * (ep[2] - em[2]);
+          if (r < 3) {
+            double d3[3];
+#pragma unroll
+            for (int q = 0; q < 3; ++q) d3[q] = q == r ? delta : 0.0;
+            plane_error(Xi, pl_oplus(pw, d3), z, ep);
+#pragma unroll
+            for (int q = 0; q < 3; ++q) d3[q] = q == r ? -delta : 0.0;
+            plane_error(Xi, pl_oplus(pw, d3), z, em);
+            jl[0] = scalar * (ep[0] - em[0]); jl[1] = scalar * (ep[1] - em[1]); jl[2] = scalar * (ep[2] - em[2]);
+          }
+        }
+        blk = V.el_blk[e];
+        double W[9];
+        load_sym3(V.el_w, n, e, W);
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+          WJs[a] = W[a * 3 + 0] * self[0] + W[a * 3 + 1] * self[1] + W[a * 3 + 2] * self[2];   // (W Ji)[a][r]
+          WJo[a] = W[a * 3 + 0] * jl[0] + W[a * 3 + 1] * jl[1] + W[a * 3 + 2] * jl[2];         // (W Jl)[a][r], r < 3
+          We[a] = W[a * 3 + 0] * err[0] + W[a * 3 + 1] * err[1] + W[a * 3 + 2] * err[2];
+        }
+      }
+    }
+    // exchange: column c of W*J lives in lane gbase + c
+    const bool se3 = kind < 2;
+    double O[6] = {0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int c = 0; c < 6; ++c) {
+      double d = 0, o2 = 0;
+#pragma unroll
+      for (int q = 0; q < 6; ++q) {
+        const double w = group_bcast(WJs[q], gbase + c);
+        d += self[q] * w;
+        o2 += other[q] * w;          // row r of Jj^T W Ji (swapped orientation)
+      }
+      D[c] += d;
+      O[c] = o2;
+    }
+    if (__any(live && blk >= 0 && !(se3 && (blk & 1)))) {   // somebody needs W*J_other columns
+#pragma unroll
+      for (int c = 0; c < 6; ++c) {
+        double o1 = 0;
+#pragma unroll
+        for (int q = 0; q < 6; ++q) o1 += self[q] * group_bcast(WJo[q], gbase + c);
+        if (!(se3 && (blk & 1))) O[c] = o1;
+      }
+    }
+    if (live) {
+      double bb = 0;
+#pragma unroll
+      for (int q = 0; q < 6; ++q) bb += self[q] * We[q];
+      bacc -= bb;
+      if (blk >= 0) {
+        if (se3) {
+          double* P = V.Hpp_off + (size_t)(blk >> 1) * 36 + r * 6;
+#pragma unroll
+          for (int c = 0; c < 6; ++c) P[c] = O[c];
+        } else {
+          double* P = V.Hpl + (size_t)blk * 18 + r * 3;
+          P[0] = O[0]; P[1] = O[1]; P[2] = O[2];
+        }
+      }
+    }
+  }
+  if (lane_ok) {
+    double* P = V.Hpp_diag + (size_t)row * 36 + r * 6;
+#pragma unroll
+    for (int c = 0; c < 6; ++c) P[c] = D[c];
+    V.bvec[(size_t)row * 6 + r] = bacc;
+  }
+}
+
+// landmark rows: 16 lanes per landmark, each lane walks a strided subset of the incident edges,
+// butterfly reduction in a fixed order.
+template <bool PL>
+__global__ __launch_bounds__(256) void k_linearize_lm_rows(BatchView V) {
+  const int l = blockIdx.x * 16 + (threadIdx.x >> 4);
+  const int lane = threadIdx.x & 15;
+  double acc[12];
+#pragma unroll
+  for (int q = 0; q < 12; ++q) acc[q] = 0;
+  bool live = l < V.nLr;
+  if (live && !V.lm[V.lrow_graph[l]].active) live = false;
+  if (live) {
+    const int li = V.lrow_lm[l];
+    const double* lp = V.lmk + (size_t)li * 4;
+    const int n = V.nEl;
+    const bool is_point = !PL || V.lm_kind[li] == VT_POINT;
+    for (int s = V.lslot_ptr[l] + lane; s < V.lslot_ptr[l + 1]; s += 16) {
+      const int e = V.lslot_edge[s];
+      const Pose Xi = load_pose(V.pose, V.el_p[e]);
+      double err[3], Jl[9];
+      if (is_point) {
+        PointLin L;
+        point_error(Xi, Vec3{lp[0], lp[1], lp[2]}, Vec3{V.el_z[0 * (size_t)n + e], V.el_z[1 * (size_t)n + e], V.el_z[2 * (size_t)n + e]}, L);
+        err[0] = L.e[0]; err[1] = L.e[1]; err[2] = L.e[2];
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+          for (int c = 0; c < 3; ++c) Jl[a * 3 + c] = L.R.m[c * 3 + a];
+      } else {
+        const Plane pw{{lp[0], lp[1], lp[2]}, lp[3]};
+        const Plane z{{V.el_z[0 * (size_t)n + e], V.el_z[1 * (size_t)n + e], V.el_z[2 * (size_t)n + e]}, V.el_z[3 * (size_t)n + e]};
+        plane_error(Xi, pw, z, err);
+        const double delta = 1e-9, scalar = 1.0 / (2 * delta);
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+          double d3[3], ep[3], em[3];
+#pragma unroll
+          for (int q = 0; q < 3; ++q) d3[q] = q == d ? delta : 0.0;
+          plane_error(Xi, pl_oplus(pw, d3), z, ep);
+#pragma unroll
+          for (int q = 0; q < 3; ++q) d3[q] = q == d ? -delta : 0.0;
+          plane_error(Xi, pl_oplus(pw, d3), z, em);
+          Jl[0 * 3 + d] = scalar * (ep[0] - em[0]); Jl[1 * 3 + d] = scalar * (ep[1] - em[1]); Jl[2 * 3 + d] = scalar * (ep[2] - em[2]);
+        }
+      }
+      double W[9];
+      load_sym3(V.el_w, n, e, W);
+      double WJ[9], We[3];
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        We[a] = W[a * 3 + 0] * err[0] + W[a * 3 + 1] * err[1] + W[a * 3 + 2] * err[2];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) WJ[a * 3 + c] = W[a * 3 + 0] * Jl[c] + W[a * 3 + 1] * Jl[3 + c] + W[a * 3 + 2] * Jl[6 + c];
+      }
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) acc[a * 3 + c] += Jl[a] * WJ[c] + Jl[3 + a] * WJ[3 + c] + Jl[6 + a] * WJ[6 + c];
+        acc[9 + a] -= Jl[a] * We[0] + Jl[3 + a] * We[1] + Jl[6 + a] * We[2];
+      }
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < 12; ++q) {
+    double v = acc[q];
+    v += __shfl_xor(v, 8, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 1, 64);
+    acc[q] = v;
+  }
+  if (live && lane == 0) {
+#pragma unroll
+    for (int q = 0; q < 9; ++q) V.Hll_diag[(size_t)l * 9 + q] = acc[q];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) V.bvec[(size_t)6 * V.nPr + (size_t)3 * l + q] = acc[9 + q];
+  }
+}
+
+// Further edges on an already-owned vertex pair (e.g. a repeated loop closure): their off-diagonal
+// contributions are added serially, in edge order, after the owners have written the blocks.
+__global__ void k_linearize_dups(BatchView V) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  for (int d = 0; d < V.nDupEo; ++d) {
+    const int k = V.dup_eo[d];
+    const int pi = V.eo_i[k], pj = V.eo_j[k];
+    if (!V.lm[V.prow_graph[V.pose_row[pi]]].active) continue;
+    Se3Lin L;
+    se3_error(load_pose(V.pose, pi), load_pose(V.pose, pj), load_meas_pose(V.eo_z, V.nEo, k), L);
+    double Ji[36], Jj[36], W[36], WJ[36];
+    se3_full_jacobians(L, Ji, Jj);
+    load_sym6(V.eo_w, V.nEo, k, W);
+    for (int r = 0; r < 6; ++r) for (int c = 0; c < 6; ++c) { double a = 0; for (int s = 0; s < 6; ++s) a += W[r * 6 + s] * Jj[s * 6 + c]; WJ[r * 6 + c] = a; }
+    const int blk = decode_blk(V.eo_blk[k]);
+    double* O = V.Hpp_off + (size_t)(blk >> 1) * 36;
+    for (int r = 0; r < 6; ++r) for (int c = 0; c < 6; ++c) {
+      double a = 0; for (int s = 0; s < 6; ++s) a += Ji[s * 6 + r] * WJ[s * 6 + c];
+      O[(blk & 1) ? c * 6 + r : r * 6 + c] += a;
+    }
+  }
+  for (int d = 0; d < V.nDupEl; ++d) {
+    const int k = V.dup_el[d];
+    const int pi = V.el_p[k], li = V.el_l[k];
+    if (!V.lm[V.prow_graph[V.pose_row[pi]]].active) continue;
+    const Pose Xi = load_pose(V.pose, pi);
+    const double* lp = V.lmk + (size_t)li * 4;
+    const int n = V.nEl;
+    double Ji[18], Jl[9], W[9];
+    if (V.lm_kind[li] == VT_POINT) {
+      PointLin L;
+      point_error(Xi, Vec3{lp[0], lp[1], lp[2]}, Vec3{V.el_z[0 * (size_t)n + k], V.el_z[1 * (size_t)n + k], V.el_z[2 * (size_t)n + k]}, L);
+      point_jacobians(L, Ji, Jl);
+    } else {
+      plane_jacobians(Xi, Plane{{lp[0], lp[1], lp[2]}, lp[3]},
+                      Plane{{V.el_z[0 * (size_t)n + k], V.el_z[1 * (size_t)n + k], V.el_z[2 * (size_t)n + k]}, V.el_z[3 * (size_t)n + k]}, Ji, Jl);
+    }
+    load_sym3(V.el_w, n, k, W);
+    double WJl[9];
+    for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) WJl[r * 3 + c] = W[r * 3 + 0] * Jl[c] + W[r * 3 + 1] * Jl[3 + c] + W[r * 3 + 2] * Jl[6 + c];
+    double* O = V.Hpl + (size_t)decode_blk(V.el_blk[k]) * 18;
+    for (int r = 0; r < 6; ++r) for (int c = 0; c < 3; ++c) O[r * 3 + c] += Ji[r] * WJl[c] + Ji[6 + r] * WJl[3 + c] + Ji[12 + r] * WJl[6 + c];
   }
 }
 
@@ -632,92 +1083,6 @@ std::string& last_error_ref() {
   return e;
 }
 
-struct KernelTimer {
-  double total_ms = 0;
-  int64_t launches = 0;
-};
-
-struct Batch {
-  int device = 0;
-  hipStream_t stream = nullptr;
-  std::vector<HostGraph*> graphs;
-  std::vector<uint64_t> versions;
-  BatchView V{};
-  std::vector<void*> allocs;
-  // host-side metadata
-  std::vector<GraphSeg> seg;
-  std::vector<std::vector<int>> v2pose, v2lm;     // per graph: vertex id -> pose / landmark index (global), -1
-  std::vector<int> pose_row, lm_row;              // global
-  std::vector<int> prow_pose, lrow_lm;
-  std::vector<std::pair<int, int>> ppoff;         // unique pose-pose blocks (row a < row b)
-  std::vector<std::pair<int, int>> plblk;         // unique pose-landmark blocks (pose row, lm row)
-  std::vector<int> pose_vertex, lm_vertex;        // global pose/lm index -> vertex id in its graph
-  int64_t hpp_off_base = 0, hpl_base = 0, hll_base = 0;
-  double* d_part_e = nullptr;  // [B*maxEdgeChunks]
-  double* d_part_m = nullptr;  // [B*maxRowChunks] (max diag)
-  bool profiling = false;
-  std::map<std::string, KernelTimer> timers;
-  struct Pending { std::string name; hipEvent_t a, b; };
-  std::vector<Pending> pending;
-  std::vector<hipEvent_t> event_pool;
-  bool uploaded = false;
-
-  ~Batch() { release(); }
-  void release() {
-    if (stream) { hipSetDevice(device); hipStreamSynchronize(stream); }
-    for (auto& p : pending) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
-    pending.clear();
-    for (auto e : event_pool) hipEventDestroy(e);
-    event_pool.clear();
-    for (void* p : allocs) hipFree(p);
-    allocs.clear();
-    if (stream) { hipStreamDestroy(stream); stream = nullptr; }
-  }
-  hipEvent_t get_event() {
-    if (!event_pool.empty()) { hipEvent_t e = event_pool.back(); event_pool.pop_back(); return e; }
-    hipEvent_t e; hipEventCreate(&e); return e;
-  }
-  void harvest() {  // call after a stream sync
-    for (auto& p : pending) {
-      float ms = 0;
-      if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) { timers[p.name].total_ms += ms; timers[p.name].launches += 1; }
-      event_pool.push_back(p.a); event_pool.push_back(p.b);
-    }
-    pending.clear();
-  }
-};
-
-struct ScopedTimer {
-  Batch& b; const char* name; hipEvent_t a{}, e{}; bool on;
-  ScopedTimer(Batch& bb, const char* n) : b(bb), name(n), on(bb.profiling) {
-    if (on) { a = b.get_event(); e = b.get_event(); hipEventRecord(a, b.stream); }
-  }
-  ~ScopedTimer() {
-    if (on) { hipEventRecord(e, b.stream); b.pending.push_back({name, a, e}); }
-  }
-};
-
-template <typename T>
-static int dev_upload(Batch& b, const std::vector<T>& h, T** out, size_t min_elems = 1) {
-  const size_t n = std::max(h.size(), min_elems);
-  void* p = nullptr;
-  SSLAM_HIP_TRY(hipMalloc(&p, n * sizeof(T)));
-  b.allocs.push_back(p);
-  if (!h.empty()) SSLAM_HIP_TRY(hipMemcpyAsync(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, b.stream));
-  *out = (T*)p;
-  return 0;
-}
-template <typename T>
-static int dev_alloc(Batch& b, size_t n, T** out, bool zero = true) {
-  void* p = nullptr;
-  n = std::max<size_t>(n, 1);
-  SSLAM_HIP_TRY(hipMalloc(&p, n * sizeof(T)));
-  b.allocs.push_back(p);
-  if (zero) SSLAM_HIP_TRY(hipMemsetAsync(p, 0, n * sizeof(T), b.stream));
-  *out = (T*)p;
-  return 0;
-}
-
 static inline uint64_t pair_key(int a, int b) { return ((uint64_t)(uint32_t)a << 32) | (uint32_t)b; }
 
 // Compile host graphs into the device-resident batch layout (g2o initializeOptimization +
@@ -794,6 +1159,64 @@ static int batch_build(Batch& b) {
     else idx = it->second;
     el_blk[k] = idx;
   }
+  // (row, incident edge) slots for the gather-form Jacobian build; duplicates of an off-diagonal
+  // block (two edges on the same vertex pair) force the atomic variant
+  std::vector<std::vector<std::pair<int, unsigned char>>> pslots(nPr);
+  std::vector<std::vector<int>> lslots(nLr);
+  {
+    std::vector<char> seen_pp(b.ppoff.size(), 0), seen_pl(b.plblk.size(), 0);
+    b.has_duplicate_blocks = false;
+    b.dup_eo.clear(); b.dup_el.clear();
+    b.has_planes = false;
+    for (unsigned char k : lm_kind) if (k == VT_PLANE) b.has_planes = true;
+    for (int k = 0; k < nEo; ++k) {
+      const int ri = b.pose_row[eo_i[k]], rj = b.pose_row[eo_j[k]];
+      if (ri >= 0) pslots[ri].push_back({k, 0});
+      if (rj >= 0) pslots[rj].push_back({k, 1});
+      if (eo_blk[k] >= 0) {   // a later edge on an already-owned block: not the owner (code <= -2)
+        if (seen_pp[eo_blk[k] >> 1]) { b.has_duplicate_blocks = true; b.dup_eo.push_back(k); eo_blk[k] = -2 - eo_blk[k]; }
+        else seen_pp[eo_blk[k] >> 1] = 1;
+      }
+    }
+    for (int k = 0; k < nEl; ++k) {
+      const int rp = b.pose_row[el_p[k]], rl = b.lm_row[el_l[k]];
+      if (rp >= 0) pslots[rp].push_back({k, 2});
+      if (rl >= 0) lslots[rl].push_back(k);
+      if (el_blk[k] >= 0) {
+        if (seen_pl[el_blk[k]]) { b.has_duplicate_blocks = true; b.dup_el.push_back(k); el_blk[k] = -2 - el_blk[k]; }
+        else seen_pl[el_blk[k]] = 1;
+      }
+    }
+  }
+  std::vector<int> pslot_ptr(nPr + 1, 0), pslot_edge, lslot_ptr(nLr + 1, 0), lslot_edge, tile_row0, tile_row1;
+  std::vector<unsigned char> pslot_kind;
+  b.max_row_slots = 0;
+  std::vector<int4> pslot_rec;
+  for (int r = 0; r < nPr; ++r) {
+    for (auto& s : pslots[r]) {
+      pslot_edge.push_back(s.first); pslot_kind.push_back(s.second);
+      if (s.second < 2) pslot_rec.push_back(make_int4(s.first, s.second, eo_i[s.first], eo_j[s.first]));
+      else pslot_rec.push_back(make_int4(s.first, 2, el_p[s.first], el_l[s.first]));
+    }
+    pslot_ptr[r + 1] = (int)pslot_edge.size();
+    b.max_row_slots = std::max(b.max_row_slots, (int)pslots[r].size());
+  }
+  for (int r = 0; r < nLr; ++r) {
+    for (int k : lslots[r]) lslot_edge.push_back(k);
+    lslot_ptr[r + 1] = (int)lslot_edge.size();
+  }
+  for (int g = 0; g < B; ++g) {   // tiles never span graphs
+    const GraphSeg& sg = b.seg[g];
+    int r = sg.prow0;
+    const int rend = sg.prow0 + sg.nprow;
+    while (r < rend) {
+      int r1 = r, ns = 0;
+      while (r1 < rend && r1 - r < 32 && ns + (pslot_ptr[r1 + 1] - pslot_ptr[r1]) <= kTileSlots) { ns += pslot_ptr[r1 + 1] - pslot_ptr[r1]; ++r1; }
+      if (r1 == r) ++r1;  // a single row with more than kTileSlots slots: atomic variant is used instead
+      tile_row0.push_back(r); tile_row1.push_back(r1);
+      r = r1;
+    }
+  }
   const int nPP = (int)b.ppoff.size(), nPL = (int)b.plblk.size();
   b.hll_base = (int64_t)nPr * 36;
   b.hpp_off_base = b.hll_base + (int64_t)nLr * 9;
@@ -850,6 +1273,11 @@ static int batch_build(Batch& b) {
   UP(eo_i, eo_i); UP(eo_j, eo_j); UP(eo_z, eo_z); UP(eo_w, eo_w); UP(eo_blk, eo_blk);
   UP(el_p, el_p); UP(el_l, el_l); UP(el_z, el_z); UP(el_w, el_w); UP(el_blk, el_blk);
   UP(adj_ptr, adj_ptr); UP(adj_blk, adj_blk); UP(adj_x, adj_x); UP(adj_fmt, adj_fmt);
+  UP(tile_row0, tile_row0); UP(tile_row1, tile_row1); UP(pslot_ptr, pslot_ptr); UP(pslot_edge, pslot_edge); UP(pslot_kind, pslot_kind);
+  UP(lslot_ptr, lslot_ptr); UP(lslot_edge, lslot_edge);
+  UP(b.dup_eo, dup_eo); UP(b.dup_el, dup_el); UP(pslot_rec, pslot_rec);
+  V.nDupEo = (int)b.dup_eo.size(); V.nDupEl = (int)b.dup_el.size();
+  V.nTiles = (int)tile_row0.size();
 #undef UP
   double* H = nullptr;
   if ((rc = dev_alloc(b, (size_t)h_total, &H))) return rc;
@@ -939,6 +1367,30 @@ static int launch_check(const char* what) {
 static int batch_linearize(Batch& b) {
   ScopedTimer t(b, "linearize");
   const BatchView& V = b.V;
+  const int mode = b.graphs[0]->opt.deterministic;   // 1: per-row groups (default), 2: LDS tiles, 0: atomics
+  const bool gather = mode == 1 || (mode == 2 && b.max_row_slots <= kTileSlots);
+  if (gather && mode == 2) {
+    if (b.has_planes) { if (V.nTiles > 0) hipLaunchKernelGGL(k_linearize_rows<true>, dim3(V.nTiles), dim3(256), 0, b.stream, V); }
+    else { if (V.nTiles > 0) hipLaunchKernelGGL(k_linearize_rows<false>, dim3(V.nTiles), dim3(256), 0, b.stream, V); }
+    if (V.nLr > 0) {
+      if (b.has_planes) hipLaunchKernelGGL(k_linearize_lm_rows<true>, dim3((V.nLr + 15) / 16), dim3(256), 0, b.stream, V);
+      else hipLaunchKernelGGL(k_linearize_lm_rows<false>, dim3((V.nLr + 15) / 16), dim3(256), 0, b.stream, V);
+    }
+    if (V.nDupEo + V.nDupEl > 0) hipLaunchKernelGGL(k_linearize_dups, dim3(1), dim3(64), 0, b.stream, V);
+    return launch_check("linearize");
+  }
+  if (gather) {
+    // every H block and b entry is written exactly once per build: no clearing pass needed
+    if (b.has_planes) {
+      if (V.nPr > 0) hipLaunchKernelGGL(k_linearize_rows2<true>, dim3((V.nPr + 31) / 32), dim3(256), 0, b.stream, V);
+      if (V.nLr > 0) hipLaunchKernelGGL(k_linearize_lm_rows<true>, dim3((V.nLr + 15) / 16), dim3(256), 0, b.stream, V);
+    } else {
+      if (V.nPr > 0) hipLaunchKernelGGL(k_linearize_rows2<false>, dim3((V.nPr + 31) / 32), dim3(256), 0, b.stream, V);
+      if (V.nLr > 0) hipLaunchKernelGGL(k_linearize_lm_rows<false>, dim3((V.nLr + 15) / 16), dim3(256), 0, b.stream, V);
+    }
+    if (V.nDupEo + V.nDupEl > 0) hipLaunchKernelGGL(k_linearize_dups, dim3(1), dim3(64), 0, b.stream, V);
+    return launch_check("linearize");
+  }
   const int per_graph_rows = V.maxRowChunks * kRowChunk;
   // clear accumulators of the active graphs
   hipLaunchKernelGGL(k_zero_active, dim3((per_graph_rows * 8 + 255) / 256, V.B), dim3(256), 0, b.stream, V);
@@ -978,7 +1430,11 @@ static int pcg_solve(Batch& b) {
 
 static int batch_solve(Batch& b) {
   // (H + lambda I) dx = b for every graph with in_trial set; result in V.x
-  return pcg_solve(b);
+  if (b.graphs[0]->opt.solver == 0) return pcg_solve(b);
+  int rc;
+  if (!b.chol && (rc = chol_plan_build(b))) return rc;
+  if ((rc = chol_factor_and_forward(b))) return rc;
+  return chol_backward(b);
 }
 
 static int batch_chi2(Batch& b, const double* pose, const double* lmk, int mask_mode) {
@@ -1327,6 +1783,46 @@ int sslam_graph_marginals(sslam_graph* h, const int* ids, int n, double* out) {
   const int dim = hessian_indices(h->g, hidx);
   std::vector<double> rhs_g2o(dim, 0.0), rhs_int, xi((size_t)6 * b.V.nPr + (size_t)3 * b.V.nLr), xg(dim);
   size_t o = 0;
+  if (h->g.opt.solver != 0) {
+    // factor the undamped H once, then solve all unit right-hand sides together
+    hipLaunchKernelGGL(k_set_trial_all, dim3((b.V.B + 63) / 64), dim3(64), 0, b.stream, b.V, 0.0);
+    if (!b.chol && (rc = chol_plan_build(b))) return rc;
+    if ((rc = chol_factor_and_forward(b))) return rc;
+    int fail = 0;
+    SSLAM_HIP_TRY(hipMemcpyAsync(&fail, b.V.pcg_fail, sizeof fail, hipMemcpyDeviceToHost, b.stream));
+    SSLAM_HIP_TRY(hipStreamSynchronize(b.stream));
+    if (fail) return set_error(SSLAM_ERR_NUMERIC, "H is not positive definite: no marginals");
+    const size_t idim = xi.size();
+    std::vector<int> col_v, col_c;
+    for (int k = 0; k < n; ++k) {
+      const int v = ids[k];
+      if (v < 0 || v >= h->g.nv()) return set_error(SSLAM_ERR_INVALID, "bad vertex id %d", v);
+      if (hidx[v] < 0) continue;
+      for (int c = 0; c < vertex_dim(h->g.vtype[v]); ++c) { col_v.push_back(v); col_c.push_back(c); }
+    }
+    const int nrhs = (int)col_v.size();
+    std::vector<double> R((size_t)nrhs * idim, 0.0), X((size_t)nrhs * idim);
+    for (int q = 0; q < nrhs; ++q) {
+      rhs_g2o[hidx[col_v[q]] + col_c[q]] = 1.0;
+      from_g2o_order(h, rhs_g2o.data(), rhs_int);
+      rhs_g2o[hidx[col_v[q]] + col_c[q]] = 0.0;
+      std::copy(rhs_int.begin(), rhs_int.end(), R.begin() + (size_t)q * idim);
+    }
+    if ((rc = chol_solve_multi(b, R.data(), nrhs, X.data()))) return rc;
+    int q = 0;
+    for (int k = 0; k < n; ++k) {
+      const int v = ids[k];
+      const int d = vertex_dim(h->g.vtype[v]);
+      if (hidx[v] < 0) { for (int e = 0; e < d * d; ++e) out[o++] = 0; continue; }
+      for (int c = 0; c < d; ++c, ++q) {
+        std::copy(X.begin() + (size_t)q * idim, X.begin() + (size_t)(q + 1) * idim, xi.begin());
+        to_g2o_order(h, xi, xg.data());
+        for (int r = 0; r < d; ++r) out[o + r * d + c] = xg[hidx[v] + r];
+      }
+      o += (size_t)d * d;
+    }
+    return 0;
+  }
   for (int k = 0; k < n; ++k) {
     const int v = ids[k];
     if (v < 0 || v >= h->g.nv()) return set_error(SSLAM_ERR_INVALID, "bad vertex id %d", v);

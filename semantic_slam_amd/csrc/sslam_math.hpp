@@ -105,9 +105,12 @@ SSLAM_HD void se3_error(const Pose& Xi, const Pose& Xj, const Pose& Z, Se3Lin& L
 
 // Column c (0..5) of d e / d delta_i, written to col[6].
 //   translation rows: [-Ra | 2 Ra [tb]x];  rotation rows: [0 | -s * xyz(qa (e_k,0) qb)]
+SSLAM_HD double pick3(int k, double a, double b, double c) { return k == 0 ? a : (k == 1 ? b : c); }
 SSLAM_HD void se3_Ji_col(const Se3Lin& L, int c, double col[6]) {
-  if (c < 3) {
-    col[0] = -L.Ra.m[0 + c]; col[1] = -L.Ra.m[3 + c]; col[2] = -L.Ra.m[6 + c];
+  if (c < 3) {  // (no dynamic indexing: keeps the matrices in registers)
+    col[0] = -pick3(c, L.Ra.m[0], L.Ra.m[1], L.Ra.m[2]);
+    col[1] = -pick3(c, L.Ra.m[3], L.Ra.m[4], L.Ra.m[5]);
+    col[2] = -pick3(c, L.Ra.m[6], L.Ra.m[7], L.Ra.m[8]);
     col[3] = col[4] = col[5] = 0;
   } else {
     const int k = c - 3;
@@ -123,7 +126,9 @@ SSLAM_HD void se3_Ji_col(const Se3Lin& L, int c, double col[6]) {
 // Column c of d e / d delta_j:  [[Re, 0], [0, s (w I + [q_xyz]x)]]
 SSLAM_HD void se3_Jj_col(const Se3Lin& L, int c, double col[6]) {
   if (c < 3) {
-    col[0] = L.Re.m[0 + c]; col[1] = L.Re.m[3 + c]; col[2] = L.Re.m[6 + c];
+    col[0] = pick3(c, L.Re.m[0], L.Re.m[1], L.Re.m[2]);
+    col[1] = pick3(c, L.Re.m[3], L.Re.m[4], L.Re.m[5]);
+    col[2] = pick3(c, L.Re.m[6], L.Re.m[7], L.Re.m[8]);
     col[3] = col[4] = col[5] = 0;
   } else {
     const int k = c - 3;

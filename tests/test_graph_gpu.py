@@ -35,6 +35,41 @@ def test_linearize_matches_oracle(gpu_lib, kind, interleave, tol):
     assert [G.hessian_index(v) for v in range(gp.nv)] == list(h)
 
 
+@pytest.mark.parametrize("deterministic", [1, 2, 0])
+def test_linearize_with_repeated_edges(gpu_lib, deterministic):
+    """Two edges on the same vertex pair (a repeated loop closure / a landmark matched twice in one
+    keyframe) share one off-diagonal block; gather-form and atomic Jacobian builds must both sum them."""
+    from semantic_slam_amd import GraphSLAM
+    g = make_graph(60, 12, seed=8)
+    gp0 = GraphProblem.from_synth(g, interleave=True)
+    Eo = len(g.odom_ij)
+    dup = [3, 17, Eo + 5, Eo + 40, 3]
+    rng = np.random.default_rng(1)
+    meas = np.concatenate([gp0.meas, gp0.meas[dup] + rng.normal(0, 1e-3, (len(dup), 7))])
+    meas[:, 3:7] /= np.where(np.linalg.norm(meas[:, 3:7], axis=1, keepdims=True) > 0.5, np.linalg.norm(meas[:, 3:7], axis=1, keepdims=True), 1.0)
+    gp = GraphProblem(gp0.vtype, gp0.vfixed, gp0.est, np.concatenate([gp0.etype, gp0.etype[dup]]),
+                      np.concatenate([gp0.evi, gp0.evi[dup]]), np.concatenate([gp0.evj, gp0.evj[dup]]),
+                      meas, np.concatenate([gp0.info, gp0.info[dup]]))
+    G = GraphSLAM.from_problem(gp)
+    G.set_option("deterministic", deterministic)
+    U, b = G.linearize()
+    Uo, bo = gp.linearize()
+    assert abs(_full(U) - _full(Uo)).max() <= 1e-11 * abs(Uo).max()
+    assert np.abs(b - bo).max() <= 1e-11 * np.abs(bo).max()
+    assert G.optimize(5)
+    st = gp.optimize(5)
+    assert G.last_stats.chi2_after == pytest.approx(st.chi2_after, rel=1e-6)
+
+
+def test_jacobian_build_is_bitwise_deterministic(gpu_lib):
+    from semantic_slam_amd import GraphSLAM
+    gp = GraphProblem.from_synth(make_graph(200, 40, seed=9))
+    G = GraphSLAM.from_problem(gp)
+    U1, b1 = G.linearize()
+    U2, b2 = G.linearize()
+    assert np.array_equal(U1.data, U2.data) and np.array_equal(b1, b2)
+
+
 def test_oplus_matches_oracle(gpu_lib):
     from semantic_slam_amd import GraphSLAM
     for kind in ("point", "plane"):
@@ -61,12 +96,30 @@ def test_pcg_solve_matches_oracle_cholesky(gpu_lib, lam):
     assert np.abs(x - xo).max() <= 1e-6 * np.abs(xo).max()
 
 
-@pytest.mark.parametrize("kind", ["point", "plane"])
-def test_optimize_small_graph_matches_oracle(gpu_lib, kind):
+@pytest.mark.parametrize("lam", [5.0, 1e-3, 0.0])
+def test_cholesky_solve_matches_oracle_cholesky(gpu_lib, lam):
+    from semantic_slam_amd import GraphSLAM
+    g = make_graph(150, 30, seed=7)
+    gp = GraphProblem.from_synth(g, interleave=True)
+    G = GraphSLAM.from_problem(gp)
+    G.set_option("solver", 1)
+    x, its = G.solve(lam)
+    xo = gp.solve(lam)
+    assert its == 0
+    assert np.abs(x - xo).max() <= 1e-9 * np.abs(xo).max()
+    # and the residual of the normal equations themselves
+    U, b = G.linearize()
+    H = _full(U) + lam * sp.identity(U.shape[0])
+    assert np.abs(H @ x - b).max() <= 1e-9 * np.abs(b).max()
+
+
+@pytest.mark.parametrize("kind,solver", [("point", 1), ("plane", 1), ("point", 0), ("plane", 0)])
+def test_optimize_small_graph_matches_oracle(gpu_lib, kind, solver):
     from semantic_slam_amd import GraphSLAM
     g = make_graph(100, 20, seed=2, landmark_kind=kind)
     gp = GraphProblem.from_synth(g, interleave=True)
     G = GraphSLAM.from_problem(gp)
+    G.set_option("solver", solver)
     assert G.optimize(12) is True
     st = gp.optimize(12)
     s = G.last_stats
@@ -76,12 +129,14 @@ def test_optimize_small_graph_matches_oracle(gpu_lib, kind):
     assert np.abs(E - Eo).max() <= 1e-4 * np.abs(Eo).max()
 
 
-def test_optimize_S_config_10_iterations(gpu_lib):
+@pytest.mark.parametrize("solver", [1, 0])
+def test_optimize_S_config_10_iterations(gpu_lib, solver):
     """BASELINE.json configs[1]: 500 poses / 100 landmarks, exactly 10 LM iterations."""
     from semantic_slam_amd import GraphSLAM
     g = make_graph(500, 100, seed=0)
     gp = GraphProblem.from_synth(g)
     G = GraphSLAM.from_problem(gp)
+    G.set_option("solver", solver)
     assert G.optimize(10)
     st = gp.optimize(10)
     s = G.last_stats
@@ -91,6 +146,26 @@ def test_optimize_S_config_10_iterations(gpu_lib):
     assert np.abs(E - Eo).max() <= 1e-4 * np.abs(Eo).max()
     # gauge: the fixed first vertex does not move (graph_slam.cpp:109-111)
     assert np.array_equal(E[0], g.poses_init[0])
+
+
+def test_optimize_L_config(gpu_lib):
+    """BASELINE.json configs[2]: 5000 poses / 1000 landmarks + loop closures; 10 iterations, then to termination."""
+    from semantic_slam_amd import GraphSLAM
+    g = make_graph(5000, 1000, seed=0)
+    gp = GraphProblem.from_synth(g)
+    G = GraphSLAM.from_problem(gp)
+    assert G.optimize(10)
+    st = gp.optimize(10)
+    s = G.last_stats
+    assert s.iterations == st.iterations == 10
+    assert s.chi2_after == pytest.approx(st.chi2_after, rel=1e-6)
+    assert np.abs(G.estimates() - gp.est).max() <= 1e-4 * np.abs(gp.est).max()
+    # run both to LM termination (cap 1024 as graph_slam.cpp:205): converged estimates must agree
+    assert G.optimize(1024)
+    st2 = gp.optimize(1024)
+    assert G.last_stats.status == 1 and st2.status == 1
+    assert G.last_stats.chi2_after == pytest.approx(st2.chi2_after, rel=1e-8)
+    assert np.abs(G.estimates() - gp.est).max() <= 1e-4 * np.abs(gp.est).max()
 
 
 def test_too_few_edges_returns_false(gpu_lib):
