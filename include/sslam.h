@@ -206,6 +206,8 @@ int sslam_seg_segment(sslam_seg* s, const uint8_t* cloud, int width, int height,
  * region index in output order of pcl::OrganizedMultiPlaneSegmentation::segmentAndRefine). */
 int sslam_seg_get_normals(sslam_seg* s, int box, float* out);
 int sslam_seg_get_labels(sslam_seg* s, int box, int32_t* out);
+/* GPU kernel time (hipEvents on the handle's stream, H2D/D2H excluded) and wall time of the last call */
+int sslam_seg_last_timing(const sslam_seg* s, double* kernel_ms, double* total_ms);
 /* semantic_tools::transformNormalsToWorld (include/tools.h:18-102): 4x4 row-major float */
 int sslam_seg_transform(const sslam_seg* s, const float robot_pose[6], float cam_angle, float out16[16]);
 

@@ -1,0 +1,944 @@
+// MI355X-native frontend: point_cloud_segmentation::segmentallPointCloudData
+// (reference include/planar_segmentation/point_cloud_segmentation.h:105-181,
+//  src/planar_segmentation/plane_segmentation.cpp:24-259) as hand-written HIP for gfx950.
+//
+// The two PCL calls of the reference (IntegralImageNormalEstimation::compute and
+// OrganizedMultiPlaneSegmentation::segmentAndRefine, plane_segmentation.cpp:97-104,136-156) are
+// restated kernel by kernel.  Parity rule: labels / inlier sets must be bit-identical with the CPU
+// oracle, so every float/double expression keeps PCL's operation order (this file is compiled with
+// -ffp-contract=off) and the inherently sequential raster recurrences of PCL (integral-image
+// recurrence, two-pass chamfer distance map, two-sweep label refinement) are executed as *skewed
+// wavefronts*: lane l of a wave owns image row r0+l and runs two columns behind lane l-1, which
+// reproduces the sequential order exactly while 64 rows progress in parallel.  Everything that is
+// order-free (crop, depth-change map, per-pixel covariance + eigen solve, comparator evaluation,
+// union-find connected components) is one thread per pixel.
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "../../include/sslam.h"
+#include "sslam_common.hpp"
+
+namespace sslam {
+namespace seg {
+
+constexpr int kMaxRegions = 64;
+constexpr int kBandFloats = 30720;  // LDS floats available to a band-staging kernel (120 KiB)
+
+struct BoxMeta {
+  int w, h, tlx, tly;
+  int pix0;   // offset into the packed per-pixel arrays
+  int ii0;    // offset into the packed integral-image arrays ((w+1)*(h+1) per box)
+  int box_index, pad;
+};
+
+struct Region {
+  float centroid[3];
+  float model[4];
+  int inliers, first_inlier, label, contour_n;
+  float area;
+  unsigned long long last_key;  // (pass << 60) | (order key << 24) | pixel index
+};
+
+struct View {
+  int nbox, npix_total, maxpix;
+  const BoxMeta* box;
+  const unsigned char* cloud;
+  int point_step, row_step, ox, oy, oz;
+  float* pts;    // [npix*3]
+  float* dm;     // [npix]
+  float* nrm;    // [npix*4]
+  float* pd;     // [npix]
+  int* lab;      // [npix] connected-component root (pixel index inside the box) or -1
+  int* cnt;      // [npix] pixels per root
+  int* l2m;      // [npix] root label -> region index, or -1
+  double* fo;    // [nii*3]
+  double* so;    // [nii*6]
+  unsigned* ic;  // [nii]
+  Region* reg;   // [nbox*kMaxRegions]
+  int* nreg;     // [nbox]
+  float mdcf, smoothing, ang_thr_cos, dist_thr, max_curv;
+  unsigned min_inliers;
+};
+
+// ---------------------------------------------------------------------------------------------
+// pcl::eigen33 (smallest eigenpair), float, same operation order as oracle/oracle_seg.c
+__device__ __forceinline__ void roots2(float b, float c, float r[3]) {
+  r[0] = 0.0f;
+  float d = b * b - 4.0f * c;
+  if (d < 0.0f) d = 0.0f;
+  const float sd = sqrtf(d);
+  r[2] = 0.5f * (b + sd);
+  r[1] = 0.5f * (b - sd);
+}
+__device__ __forceinline__ void compute_roots(const float m[9], float r[3]) {
+  const float m00 = m[0], m01 = m[1], m02 = m[2], m11 = m[4], m12 = m[5], m22 = m[8];
+  const float c0 = m00 * m11 * m22 + 2.0f * m01 * m02 * m12 - m00 * m12 * m12 - m11 * m02 * m02 - m22 * m01 * m01;
+  const float c1 = m00 * m11 - m01 * m01 + m00 * m22 - m02 * m02 + m11 * m22 - m12 * m12;
+  const float c2 = m00 + m11 + m22;
+  if (fabsf(c0) < 1.1920929e-07f) { roots2(c2, c1, r); return; }
+  const float s_inv3 = 1.0f / 3.0f;
+  const float s_sqrt3 = sqrtf(3.0f);
+  const float c2_over_3 = c2 * s_inv3;
+  float a_over_3 = (c1 - c2 * c2_over_3) * s_inv3;
+  if (a_over_3 > 0.0f) a_over_3 = 0.0f;
+  const float half_b = 0.5f * (c0 + c2_over_3 * (2.0f * c2_over_3 * c2_over_3 - c1));
+  float q = half_b * half_b + a_over_3 * a_over_3 * a_over_3;
+  if (q > 0.0f) q = 0.0f;
+  const float rho = sqrtf(-a_over_3);
+  // trigonometry in double, rounded to float: identical bits on glibc and ocml
+  const float theta = (float)atan2((double)sqrtf(-q), (double)half_b) * s_inv3;
+  const float cos_theta = (float)cos((double)theta);
+  const float sin_theta = (float)sin((double)theta);
+  r[0] = c2_over_3 + 2.0f * rho * cos_theta;
+  r[1] = c2_over_3 - rho * (cos_theta + s_sqrt3 * sin_theta);
+  r[2] = c2_over_3 - rho * (cos_theta - s_sqrt3 * sin_theta);
+  float t;
+  if (r[0] >= r[1]) { t = r[0]; r[0] = r[1]; r[1] = t; }
+  if (r[1] >= r[2]) {
+    t = r[1]; r[1] = r[2]; r[2] = t;
+    if (r[0] >= r[1]) { t = r[0]; r[0] = r[1]; r[1] = t; }
+  }
+  if (r[0] <= 0.0f) roots2(c2, c1, r);
+}
+__device__ __forceinline__ void cross3(const float* a, const float* b, float* o) {
+  o[0] = a[1] * b[2] - a[2] * b[1]; o[1] = a[2] * b[0] - a[0] * b[2]; o[2] = a[0] * b[1] - a[1] * b[0];
+}
+__device__ __forceinline__ void eigen33(const float mat[9], float& eigenvalue, float vec[3]) {
+  float scale = 0;
+#pragma unroll
+  for (int k = 0; k < 9; ++k) { const float a = fabsf(mat[k]); if (a > scale) scale = a; }
+  if (scale <= 1.17549435e-38f) scale = 1.0f;
+  float s[9];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) s[k] = mat[k] / scale;
+  float r[3];
+  compute_roots(s, r);
+  eigenvalue = r[0] * scale;
+  s[0] -= r[0]; s[4] -= r[0]; s[8] -= r[0];
+  float v1[3], v2[3], v3[3];
+  cross3(s + 0, s + 3, v1); cross3(s + 0, s + 6, v2); cross3(s + 3, s + 6, v3);
+  const float l1 = v1[0] * v1[0] + v1[1] * v1[1] + v1[2] * v1[2];
+  const float l2 = v2[0] * v2[0] + v2[1] * v2[1] + v2[2] * v2[2];
+  const float l3 = v3[0] * v3[0] + v3[1] * v3[1] + v3[2] * v3[2];
+  float v[3], l;
+  if (l1 >= l2 && l1 >= l3) { v[0] = v1[0]; v[1] = v1[1]; v[2] = v1[2]; l = l1; }
+  else if (l2 >= l1 && l2 >= l3) { v[0] = v2[0]; v[1] = v2[1]; v[2] = v2[2]; l = l2; }
+  else { v[0] = v3[0]; v[1] = v3[1]; v[2] = v3[2]; l = l3; }
+  const float n = sqrtf(l);
+  vec[0] = v[0] / n; vec[1] = v[1] / n; vec[2] = v[2] / n;
+}
+
+// ---------------------------------------------------------------------------------------------
+// crop (plane_segmentation.cpp:24-82): box pixels of the organised cloud -> packed xyz
+__global__ __launch_bounds__(256) void k_crop(View V) {
+  const BoxMeta b = V.box[blockIdx.y];
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= b.w * b.h) return;
+  const int v = i / b.w, u = i - v * b.w;
+  const size_t pos = (size_t)(b.tly + v) * V.row_step + (size_t)(b.tlx + u) * V.point_step;
+  float x, y, z;
+  memcpy(&x, V.cloud + pos + V.ox, 4); memcpy(&y, V.cloud + pos + V.oy, 4); memcpy(&z, V.cloud + pos + V.oz, 4);
+  float* o = V.pts + ((size_t)b.pix0 + i) * 3;
+  o[0] = x; o[1] = y; o[2] = z;
+}
+
+// depth-change map in gather form + distance-map initialisation
+__device__ __forceinline__ bool dc_right(const float* pts, int w, int r, int c, float f) {
+  const float d = pts[((size_t)r * w + c) * 3 + 2], dR = pts[((size_t)r * w + c + 1) * 3 + 2];
+  const float thr = f * (fabsf(d) + 1.0f) * 2.0f;
+  return fabsf(d - dR) > thr || !isfinite(d) || !isfinite(dR);
+}
+__device__ __forceinline__ bool dc_down(const float* pts, int w, int r, int c, float f) {
+  const float d = pts[((size_t)r * w + c) * 3 + 2], dD = pts[((size_t)(r + 1) * w + c) * 3 + 2];
+  const float thr = f * (fabsf(d) + 1.0f) * 2.0f;
+  return fabsf(d - dD) > thr || !isfinite(d) || !isfinite(dD);
+}
+__global__ __launch_bounds__(256) void k_depth_change(View V) {
+  const BoxMeta b = V.box[blockIdx.y];
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  const int w = b.w, h = b.h;
+  if (i >= w * h) return;
+  const int r = i / w, c = i - r * w;
+  const float* pts = V.pts + (size_t)b.pix0 * 3;
+  bool zero = false;
+  if (r < h - 1 && c < w - 1) zero = dc_right(pts, w, r, c, V.mdcf) || dc_down(pts, w, r, c, V.mdcf);
+  if (!zero && c >= 1 && r < h - 1) zero = dc_right(pts, w, r, c - 1, V.mdcf);
+  if (!zero && r >= 1 && c < w - 1) zero = dc_down(pts, w, r - 1, c, V.mdcf);
+  V.dm[(size_t)b.pix0 + i] = zero ? 0.0f : (float)(w + h);
+  // normals default to NaN; labels to "invalid"
+  float* nn = V.nrm + ((size_t)b.pix0 + i) * 4;
+  const float qnan = __int_as_float(0x7fc00000);
+  nn[0] = qnan; nn[1] = qnan; nn[2] = qnan; nn[3] = qnan;
+}
+
+// two-pass chamfer distance map: skewed wavefront over rows, band staged in LDS with the image's
+// own row stride (so PCL's wrap-around reads prev[w] == cur[0], next[-1] == cur[w-1] come for free)
+__global__ __launch_bounds__(256) void k_distance_map(View V) {
+  extern __shared__ float band[];
+  const BoxMeta b = V.box[blockIdx.x];
+  const int w = b.w, h = b.h;
+  float* dm = V.dm + b.pix0;
+  const int BH = min(64, kBandFloats / w - 1);
+  // ---- forward pass: rows 1 .. h-1
+  for (int r0 = 1; r0 < h; r0 += BH) {
+    const int nr = min(BH, h - r0);
+    for (int k = threadIdx.x; k < (nr + 1) * w; k += 256) band[k] = dm[(size_t)(r0 - 1) * w + k];
+    __syncthreads();
+    if (threadIdx.x < 64) {
+      const int l = threadIdx.x;
+      const int steps = (w - 1) + 2 * (nr - 1);
+      for (int t = 0; t < steps; ++t) {
+        const int c = t - 2 * l + 1;
+        if (l < nr && c >= 1 && c < w) {
+          const float* prev = band + l * w;
+          float* cur = band + (l + 1) * w;
+          const float upLeft = prev[c - 1] + 1.4f, up = prev[c] + 1.0f, upRight = prev[c + 1] + 1.4f, left = cur[c - 1] + 1.0f;
+          const float center = cur[c];
+          const float m = fminf(fminf(upLeft, up), fminf(left, upRight));
+          if (m < center) cur[c] = m;
+        }
+      }
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < nr * w; k += 256) dm[(size_t)r0 * w + k] = band[w + k];
+    __syncthreads();
+  }
+  // ---- backward pass: rows h-2 .. 0
+  for (int rhi = h - 2; rhi >= 0; rhi -= BH) {
+    const int nr = min(BH, rhi + 1);
+    const int rlo = rhi - nr + 1;
+    for (int k = threadIdx.x; k < (nr + 1) * w; k += 256) band[k] = dm[(size_t)rlo * w + k];
+    __syncthreads();
+    if (threadIdx.x < 64) {
+      const int l = threadIdx.x;  // lane l owns row rhi - l = band row (nr - 1 - l)
+      const int steps = (w - 1) + 2 * (nr - 1);
+      for (int t = 0; t < steps; ++t) {
+        const int c = (w - 2) - (t - 2 * l);
+        if (l < nr && c >= 0 && c <= w - 2) {
+          float* cur = band + (nr - 1 - l) * w;
+          const float* next = cur + w;
+          // (row 0, column 0 would read next[-1] = cur[w-1]; for band row 0 that is band[w-1]: in range)
+          const float lowerLeft = next[c - 1] + 1.4f, lower = next[c] + 1.0f, lowerRight = next[c + 1] + 1.4f, right = cur[c + 1] + 1.0f;
+          const float center = cur[c];
+          const float m = fminf(fminf(lowerLeft, lower), fminf(right, lowerRight));
+          if (m < center) cur[c] = m;
+        }
+      }
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < nr * w; k += 256) dm[(size_t)rlo * w + k] = band[k];
+    __syncthreads();
+  }
+}
+
+// integral images (IntegralImage2D<float,3>::computeIntegralImages, second order on): one wave per
+// box, lane l owns row r0+l, two columns behind lane l-1; the previous row's running values arrive by
+// wave shuffle.  Recurrence and operation order are PCL's:  cur[c+1] = prev[c+1] + cur[c] - prev[c] (+ element).
+__global__ __launch_bounds__(64) void k_integral(View V) {
+  extern __shared__ double prevrow[];  // (w+1) x 10: last row of the previous band (count stored as double)
+  const BoxMeta b = V.box[blockIdx.x];
+  const int w = b.w, h = b.h, W1 = w + 1;
+  const float* pts = V.pts + (size_t)b.pix0 * 3;
+  double* fo = V.fo + (size_t)b.ii0 * 3;
+  double* so = V.so + (size_t)b.ii0 * 6;
+  unsigned* ic = V.ic + b.ii0;
+  const int l = threadIdx.x;
+  // row 0 of the integral images is zero
+  for (int k = l; k < W1; k += 64) {
+    for (int q = 0; q < 3; ++q) fo[(size_t)k * 3 + q] = 0;
+    for (int q = 0; q < 6; ++q) so[(size_t)k * 6 + q] = 0;
+    ic[k] = 0;
+  }
+  for (int k = l; k < W1 * 10; k += 64) prevrow[k] = 0;
+  __syncthreads();
+  for (int r0 = 0; r0 < h; r0 += 64) {
+    const int nr = min(64, h - r0);
+    const int r = r0 + l;
+    double cur[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};   // cur[c] of the running column
+    unsigned curc = 0;
+    double h1[9], h2[9], p0[9];                       // own outputs one / two steps ago; prev[c]
+    unsigned h1c = 0, h2c = 0, p0c = 0;
+#pragma unroll
+    for (int q = 0; q < 9; ++q) { h1[q] = 0; h2[q] = 0; p0[q] = 0; }
+    const int steps = w + 2 * (nr - 1);
+    for (int t = 0; t < steps; ++t) {
+      const int c = t - 2 * l;
+      // prev[c+1]: lane l-1's output two steps ago; lane 0 reads the staged last row of the previous band
+      double p1[9];
+      unsigned p1c;
+#pragma unroll
+      for (int q = 0; q < 9; ++q) p1[q] = __shfl_up(h2[q], 1, 64);
+      p1c = __shfl_up(h2c, 1, 64);
+      const bool active = l < nr && c >= 0 && c < w;
+      if (l == 0 && active) {
+#pragma unroll
+        for (int q = 0; q < 9; ++q) p1[q] = prevrow[(c + 1) * 10 + q];
+        p1c = (unsigned)prevrow[(c + 1) * 10 + 9];
+      }
+      double out[9];
+      unsigned outc = h1c;
+#pragma unroll
+      for (int q = 0; q < 9; ++q) out[q] = h1[q];
+      if (active) {
+#pragma unroll
+        for (int q = 0; q < 9; ++q) out[q] = p1[q] + cur[q] - p0[q];
+        outc = p1c + curc - p0c;
+        const float ex = pts[((size_t)r * w + c) * 3 + 0], ey = pts[((size_t)r * w + c) * 3 + 1], ez = pts[((size_t)r * w + c) * 3 + 2];
+        if (isfinite(ex + ey + ez)) {
+          out[0] += (double)ex; out[1] += (double)ey; out[2] += (double)ez;
+          ++outc;
+          out[3] += (double)(ex * ex); out[4] += (double)(ex * ey); out[5] += (double)(ex * ez);
+          out[6] += (double)(ey * ey); out[7] += (double)(ey * ez); out[8] += (double)(ez * ez);
+        }
+        const size_t o = (size_t)(r + 1) * W1 + (c + 1);
+        fo[o * 3 + 0] = out[0]; fo[o * 3 + 1] = out[1]; fo[o * 3 + 2] = out[2];
+#pragma unroll
+        for (int q = 0; q < 6; ++q) so[o * 6 + q] = out[3 + q];
+        ic[o] = outc;
+        if (c == 0) {  // integral column 0 of this row is zero
+          const size_t o0 = (size_t)(r + 1) * W1;
+          fo[o0 * 3 + 0] = 0; fo[o0 * 3 + 1] = 0; fo[o0 * 3 + 2] = 0;
+#pragma unroll
+          for (int q = 0; q < 6; ++q) so[o0 * 6 + q] = 0;
+          ic[o0] = 0;
+        }
+#pragma unroll
+        for (int q = 0; q < 9; ++q) { cur[q] = out[q]; p0[q] = p1[q]; }
+        curc = outc; p0c = p1c;
+      }
+      // shift the output history (every lane, every step: the shuffle above reads h2)
+#pragma unroll
+      for (int q = 0; q < 9; ++q) { h2[q] = h1[q]; h1[q] = out[q]; }
+      h2c = h1c; h1c = outc;
+    }
+    // stage the last row of this band for the next band's lane 0
+    __syncthreads();
+    if (r0 + 64 < h) {
+      const size_t rowo = (size_t)(r0 + 64) * W1;
+      for (int k = l; k < W1; k += 64) {
+        prevrow[k * 10 + 0] = fo[(rowo + k) * 3 + 0]; prevrow[k * 10 + 1] = fo[(rowo + k) * 3 + 1]; prevrow[k * 10 + 2] = fo[(rowo + k) * 3 + 2];
+        for (int q = 0; q < 6; ++q) prevrow[k * 10 + 3 + q] = so[(rowo + k) * 6 + q];
+        prevrow[k * 10 + 9] = (double)ic[rowo + k];
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// per-pixel normal: IntegralImageNormalEstimation::computePointNormal (COVARIANCE_MATRIX),
+// BORDER_POLICY_IGNORE, fixed smoothing size
+__global__ __launch_bounds__(256) void k_normals(View V) {
+  const BoxMeta b = V.box[blockIdx.y];
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  const int w = b.w, h = b.h, W1 = w + 1;
+  if (i >= w * h) return;
+  const int r = i / w, c = i - r * w;
+  const int border = (int)V.smoothing;
+  if (r < border || r >= h - border || c < border || c >= w - border) return;
+  const float* pts = V.pts + (size_t)b.pix0 * 3;
+  const float depth = pts[(size_t)i * 3 + 2];
+  if (!isfinite(depth)) return;
+  const float smoothing = fminf(V.dm[(size_t)b.pix0 + i], V.smoothing);
+  if (!(smoothing > 2.0f)) return;
+  const int rw = (int)smoothing, rh = (int)smoothing;
+  const int sx = c - rw / 2, sy = r - rh / 2;
+  const size_t ul = (size_t)sy * W1 + sx, ur = ul + rw, ll = (size_t)(sy + rh) * W1 + sx, lr = ll + rw;
+  const unsigned* ic = V.ic + b.ii0;
+  const unsigned count = ic[lr] + ic[ul] - ic[ur] - ic[ll];
+  if (count == 0) return;
+  const double* fo = V.fo + (size_t)b.ii0 * 3;
+  const double* so = V.so + (size_t)b.ii0 * 6;
+  float cen[3], sov[6], cov[9];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) cen[k] = (float)(fo[lr * 3 + k] + fo[ul * 3 + k] - fo[ur * 3 + k] - fo[ll * 3 + k]);
+#pragma unroll
+  for (int k = 0; k < 6; ++k) sov[k] = (float)(so[lr * 6 + k] + so[ul * 6 + k] - so[ur * 6 + k] - so[ll * 6 + k]);
+  cov[0] = sov[0]; cov[1] = cov[3] = sov[1]; cov[2] = cov[6] = sov[2]; cov[4] = sov[3]; cov[5] = cov[7] = sov[4]; cov[8] = sov[5];
+  const float fc = (float)count;
+#pragma unroll
+  for (int a = 0; a < 3; ++a)
+#pragma unroll
+    for (int bb = 0; bb < 3; ++bb) cov[a * 3 + bb] -= (cen[a] * cen[bb]) / fc;
+  float ev, v[3];
+  eigen33(cov, ev, v);
+  const float vx = 0.0f - pts[(size_t)i * 3 + 0], vy = 0.0f - pts[(size_t)i * 3 + 1], vz = 0.0f - pts[(size_t)i * 3 + 2];
+  const float ct = vx * v[0] + vy * v[1] + vz * v[2];
+  if (ct < 0) { v[0] *= -1; v[1] *= -1; v[2] *= -1; }
+  float* nn = V.nrm + ((size_t)b.pix0 + i) * 4;
+  nn[0] = v[0]; nn[1] = v[1]; nn[2] = v[2];
+  nn[3] = ev > 0.0f ? fabsf(ev / (cov[0] + cov[4] + cov[8])) : 0.0f;
+}
+
+// ---------------------------------------------------------------------------------------------
+// OrganizedConnectedComponentSegmentation with the PlaneCoefficientComparator (depth dependent)
+__global__ __launch_bounds__(256) void k_cc_init(View V) {
+  const BoxMeta b = V.box[blockIdx.y];
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= b.w * b.h) return;
+  const size_t g = (size_t)b.pix0 + i;
+  const float* p = V.pts + g * 3;
+  const float* n = V.nrm + g * 4;
+  V.pd[g] = p[0] * n[0] + p[1] * n[1] + p[2] * n[2];
+  V.lab[g] = isfinite(p[0]) ? i : -1;
+  V.cnt[g] = 0;
+  V.l2m[g] = -1;
+}
+__device__ __forceinline__ bool coeff_compare(const View& V, size_t g1, size_t g2) {
+  const float z = V.pts[g1 * 3 + 2];
+  const float thr = V.dist_thr * (z * z);
+  const float* a = V.nrm + g1 * 4;
+  const float* b = V.nrm + g2 * 4;
+  const float dot = a[0] * b[0] + a[1] * b[1] + a[2] * b[2];
+  return (fabsf(V.pd[g1] - V.pd[g2]) < thr) && (dot > V.ang_thr_cos);
+}
+__device__ __forceinline__ int uf_find(int* L, int i) {
+  int p = L[i];
+  while (p != i) { i = p; p = L[i]; }
+  return i;
+}
+__device__ __forceinline__ void uf_union(int* L, int a, int b) {
+  while (true) {
+    a = uf_find(L, a); b = uf_find(L, b);
+    if (a == b) return;
+    if (a < b) { const int t = a; a = b; b = t; }   // attach the larger root to the smaller one
+    const int old = atomicMin(&L[a], b);
+    if (old == a) return;
+    a = old;
+  }
+}
+__global__ __launch_bounds__(256) void k_cc_merge(View V) {
+  const BoxMeta b = V.box[blockIdx.y];
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  const int w = b.w;
+  if (i >= w * b.h) return;
+  int* L = V.lab + b.pix0;
+  if (L[i] < 0) return;
+  const int r = i / w, c = i - r * w;
+  const size_t g = (size_t)b.pix0 + i;
+  if (c > 0 && L[i - 1] >= 0 && coeff_compare(V, g, g - 1)) uf_union(L, i, i - 1);
+  if (r > 0 && L[i - w] >= 0 && coeff_compare(V, g, g - w)) uf_union(L, i, i - w);
+}
+__global__ __launch_bounds__(256) void k_cc_flatten(View V) {
+  const BoxMeta b = V.box[blockIdx.y];
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= b.w * b.h) return;
+  int* L = V.lab + b.pix0;
+  if (L[i] < 0) return;
+  const int root = uf_find(L, i);
+  atomicAdd(&V.cnt[b.pix0 + root], 1);
+  // roots only ever point at themselves, so writing the flattened parent is race-free
+  if (root != i) L[i] = root;
+}
+__global__ __launch_bounds__(256) void k_cc_flatten2(View V) {  // second hop: every pixel points at its root
+  const BoxMeta b = V.box[blockIdx.y];
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= b.w * b.h) return;
+  int* L = V.lab + b.pix0;
+  if (L[i] >= 0) L[i] = uf_find(L, i);
+}
+
+// per-label plane fit (OrganizedMultiPlaneSegmentation::segment): labels with more than
+// min_inliers pixels, float accumulation in raster order (one thread per candidate label),
+// eigen33, flip towards the viewpoint, curvature gate; regions are numbered in label order
+__global__ __launch_bounds__(256) void k_regions(View V) {
+  __shared__ int cand[256];
+  __shared__ int ncand;
+  __shared__ int accepted[256];
+  const BoxMeta b = V.box[blockIdx.x];
+  const int n = b.w * b.h;
+  const int* L = V.lab + b.pix0;
+  const int* cnt = V.cnt + b.pix0;
+  const float* pts = V.pts + (size_t)b.pix0 * 3;
+  if (threadIdx.x == 0) ncand = 0;
+  __syncthreads();
+  // ordered candidate list (roots in increasing pixel index): thread 0 scans, the list is short
+  if (threadIdx.x == 0) {
+    int k = 0;
+    for (int i = 0; i < n && k < 256; ++i)
+      if (L[i] == i && (unsigned)cnt[i] > V.min_inliers) cand[k++] = i;
+    ncand = k;
+  }
+  __syncthreads();
+  const int k = threadIdx.x;
+  Region R;
+  bool ok = false;
+  if (k < ncand) {
+    const int label = cand[k];
+    float a[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    int first = -1, last = -1;
+    for (int i = 0; i < n; ++i) {
+      if (L[i] != label) continue;
+      const float x = pts[(size_t)i * 3], y = pts[(size_t)i * 3 + 1], z = pts[(size_t)i * 3 + 2];
+      a[0] += x * x; a[1] += x * y; a[2] += x * z; a[3] += y * y; a[4] += y * z; a[5] += z * z; a[6] += x; a[7] += y; a[8] += z;
+      if (first < 0) first = i;
+      last = i;
+    }
+    const float cntf = (float)cnt[label];
+#pragma unroll
+    for (int q = 0; q < 9; ++q) a[q] = a[q] / cntf;
+    float cov[9];
+    cov[0] = a[0] - a[6] * a[6]; cov[1] = a[1] - a[6] * a[7]; cov[2] = a[2] - a[6] * a[8];
+    cov[4] = a[3] - a[7] * a[7]; cov[5] = a[4] - a[7] * a[8]; cov[8] = a[5] - a[8] * a[8];
+    cov[3] = cov[1]; cov[6] = cov[2]; cov[7] = cov[5];
+    float ev, v[3];
+    eigen33(cov, ev, v);
+    float p[4] = {v[0], v[1], v[2], 0};
+    p[3] = -1 * (p[0] * a[6] + p[1] * a[7] + p[2] * a[8]);
+    const float ct = (0.0f - a[6]) * p[0] + (0.0f - a[7]) * p[1] + (0.0f - a[8]) * p[2];
+    if (ct < 0) {
+      p[0] *= -1; p[1] *= -1; p[2] *= -1;
+      p[3] = -1 * (p[0] * a[6] + p[1] * a[7] + p[2] * a[8]);
+    }
+    const float es = cov[0] + cov[4] + cov[8];
+    const float curv = es != 0 ? fabsf(ev / es) : 0;
+    ok = curv < V.max_curv;
+    R.centroid[0] = a[6]; R.centroid[1] = a[7]; R.centroid[2] = a[8];
+    R.model[0] = p[0]; R.model[1] = p[1]; R.model[2] = p[2]; R.model[3] = p[3];
+    R.inliers = cnt[label]; R.first_inlier = first; R.label = label; R.contour_n = 0; R.area = 0;
+    R.last_key = (unsigned long long)(unsigned)last;
+  }
+  accepted[threadIdx.x] = ok ? 1 : 0;
+  __syncthreads();
+  if (ok) {
+    int idx = 0;
+    for (int q = 0; q < k; ++q) idx += accepted[q];
+    if (idx < kMaxRegions) {
+      V.reg[(size_t)blockIdx.x * kMaxRegions + idx] = R;
+      V.l2m[b.pix0 + R.label] = idx;
+    }
+  }
+  if (threadIdx.x == 0) {
+    int tot = 0;
+    for (int q = 0; q < ncand; ++q) tot += accepted[q];
+    V.nreg[blockIdx.x] = min(tot, kMaxRegions);
+  }
+}
+
+// OrganizedMultiPlaneSegmentation::refine: two raster sweeps with the PlaneRefinementComparator,
+// executed as skewed wavefronts over a label band staged in LDS (image row stride preserved, so the
+// second sweep's colIdx-1 read at column 0 lands on the previous row's last pixel as in PCL).
+__device__ __forceinline__ bool refine_compare(const View& V, const BoxMeta& b, int cl, int nl, int i1, int i2, int& model_idx) {
+  const int m1 = V.l2m[b.pix0 + cl];
+  if (m1 < 0) return false;
+  if (V.l2m[b.pix0 + nl] >= 0) return false;
+  model_idx = m1;
+  const float* m = V.reg[(size_t)b.box_index * kMaxRegions + m1].model;
+  const float* p = V.pts + ((size_t)b.pix0 + i2) * 3;
+  const double d = fabs((double)(m[0] * p[0] + m[1] * p[1] + m[2] * p[2] + m[3]));
+  const float z = V.pts[((size_t)b.pix0 + i1) * 3 + 2];
+  const float t = V.dist_thr * (z * z);
+  return d < (double)t;
+}
+__device__ __forceinline__ void refine_record(const View& V, const BoxMeta& b, int model_idx, unsigned long long pass, unsigned long long key, int target) {
+  Region* R = &V.reg[(size_t)b.box_index * kMaxRegions + model_idx];
+  atomicAdd(&R->inliers, 1);
+  atomicMax(&R->last_key, (pass << 60) | (key << 24) | (unsigned long long)target);
+}
+__global__ __launch_bounds__(256) void k_refine(View V) {
+  extern __shared__ int lband[];
+  BoxMeta b = V.box[blockIdx.x];
+  b.box_index = blockIdx.x;  // (regions are stored per accepted box slot)
+  if (V.nreg[blockIdx.x] == 0) return;
+  const int w = b.w, h = b.h;
+  int* L = V.lab + b.pix0;
+  const int BH = min(64, kBandFloats / w - 1);
+  // ---- sweep 1: top-down, left-right; checks right then lower neighbour
+  for (int r0 = 0; r0 < h - 1; r0 += BH) {
+    const int nr = min(BH, h - 1 - r0);
+    for (int k = threadIdx.x; k < (nr + 1) * w; k += 256) lband[k] = L[(size_t)r0 * w + k];
+    __syncthreads();
+    if (threadIdx.x < 64) {
+      const int l = threadIdx.x;
+      const int steps = (w - 1) + 2 * (nr - 1);
+      for (int t = 0; t < steps; ++t) {
+        const int c = t - 2 * l;
+        if (l < nr && c >= 0 && c < w - 1) {
+          int* cur = lband + l * w;
+          const int r = r0 + l;
+          const int cl = cur[c], rl = cur[c + 1];
+          if (cl >= 0 && rl >= 0) {
+            int mi;
+            if (refine_compare(V, b, cl, rl, r * w + c, r * w + c + 1, mi)) {
+              cur[c + 1] = cl;
+              refine_record(V, b, mi, 1ull, (unsigned long long)(r * w + c) * 2ull, r * w + c + 1);
+            }
+            const int ll = cur[w + c];
+            if (ll >= 0 && refine_compare(V, b, cl, ll, r * w + c, (r + 1) * w + c, mi)) {
+              cur[w + c] = cl;
+              refine_record(V, b, mi, 1ull, (unsigned long long)(r * w + c) * 2ull + 1ull, (r + 1) * w + c);
+            }
+          }
+        }
+      }
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < (nr + 1) * w; k += 256) L[(size_t)r0 * w + k] = lband[k];
+    __syncthreads();
+  }
+  // ---- sweep 2: bottom-up, right-left; checks left then upper neighbour
+  for (int rhi = h - 1; rhi >= 1; rhi -= BH) {
+    const int nr = min(BH, rhi);
+    const int rlo = rhi - nr;  // staged rows rlo .. rhi (rlo is the upper halo of the topmost processed row)
+    for (int k = threadIdx.x; k < (nr + 1) * w; k += 256) lband[k] = L[(size_t)rlo * w + k];
+    __syncthreads();
+    if (threadIdx.x < 64) {
+      const int l = threadIdx.x;  // lane l owns row rhi - l
+      const int steps = w + 2 * (nr - 1);
+      for (int t = 0; t < steps; ++t) {
+        const int c = (w - 1) - (t - 2 * l);
+        if (l < nr && c >= 0 && c <= w - 1) {
+          const int r = rhi - l;
+          int* cur = lband + (r - rlo) * w;
+          // column 0 has no left neighbour here (PCL reads the previous row's last pixel)
+          const int cl = cur[c];
+          const int lf = c >= 1 ? cur[c - 1] : 0;
+          if (cl >= 0 && lf >= 0) {
+            const unsigned long long key = (unsigned long long)((h - 1 - r) * w + (w - 1 - c)) * 2ull;
+            int mi;
+            if (c >= 1 && refine_compare(V, b, cl, lf, r * w + c, r * w + c - 1, mi)) {
+              cur[c - 1] = cl;
+              refine_record(V, b, mi, 2ull, key, r * w + c - 1);
+            }
+            const int ul = cur[c - w];
+            if (ul >= 0 && refine_compare(V, b, cl, ul, r * w + c, (r - 1) * w + c, mi)) {
+              cur[c - w] = cl;
+              refine_record(V, b, mi, 2ull, key + 1ull, (r - 1) * w + c);
+            }
+          }
+        }
+      }
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < (nr + 1) * w; k += 256) L[(size_t)rlo * w + k] = lband[k];
+    __syncthreads();
+  }
+}
+
+// findLabeledRegionBoundary (Moore trace from the last inlier) + pcl::calculatePolygonArea, one
+// thread per region (sequential by nature; float accumulation in contour order)
+__global__ void k_contour(View V) {
+  const int bx = blockIdx.x;
+  const int k = threadIdx.x;
+  if (k >= V.nreg[bx]) return;
+  const BoxMeta b = V.box[bx];
+  const int w = b.w, h = b.h;
+  const int* L = V.lab + b.pix0;
+  const float* pts = V.pts + (size_t)b.pix0 * 3;
+  Region* R = &V.reg[(size_t)bx * kMaxRegions + k];
+  const int start = (int)(R->last_key & 0xffffffull);
+  const int label = L[start];
+  const int dxs[8] = {-1, -1, 0, 1, 1, 1, 0, -1}, dys[8] = {0, -1, -1, -1, 0, 1, 1, 1};
+  int dirn = -1, cx = start % w, cy = start / w, ci = start;
+  for (int d = 0; d < 8; ++d) {
+    const int x = cx + dxs[d], y = cy + dys[d], idx = ci + dys[d] * w + dxs[d];
+    if (x >= 0 && x < w && y >= 0 && y < h && L[idx] != label) { dirn = d; break; }
+  }
+  int count = 0;
+  float res[3] = {0, 0, 0};
+  if (dirn != -1) {
+    count = 1;
+    const long guard = 4L * (long)w * h + 8;
+    long steps = 0;
+    int prev = start;
+    do {
+      int nI = 0;
+      for (int d = 1; d <= 8; ++d) {
+        nI = (dirn + d) & 7;
+        const int x = cx + dxs[nI], y = cy + dys[nI], idx = ci + dys[nI] * w + dxs[nI];
+        if (x >= 0 && x < w && y >= 0 && y < h && L[idx] == label) break;
+      }
+      dirn = (nI + 4) & 7;
+      ci += dys[nI] * w + dxs[nI]; cx += dxs[nI]; cy += dys[nI];
+      // polygon edge prev -> ci   (calculatePolygonArea: res += va x vb over consecutive contour points)
+      float c3[3];
+      cross3(pts + (size_t)prev * 3, pts + (size_t)ci * 3, c3);
+      res[0] += c3[0]; res[1] += c3[1]; res[2] += c3[2];
+      prev = ci;
+      ++count;
+    } while (ci != start && ++steps < guard);
+    // closing edge: last contour point -> first (the trace ends on `start`, which PCL stores twice)
+    float c3[3];
+    cross3(pts + (size_t)prev * 3, pts + (size_t)start * 3, c3);
+    res[0] += c3[0]; res[1] += c3[1]; res[2] += c3[2];
+  }
+  R->contour_n = count;
+  R->area = sqrtf(res[0] * res[0] + res[1] * res[1] + res[2] * res[2]) * 0.5f;
+}
+
+// final label image for the parity hook: region index or -1
+__global__ __launch_bounds__(256) void k_label_image(View V, int box, int* out) {
+  const BoxMeta b = V.box[box];
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= b.w * b.h) return;
+  const int l = V.lab[b.pix0 + i];
+  out[i] = l >= 0 ? V.l2m[b.pix0 + l] : -1;
+}
+
+}  // namespace seg
+}  // namespace sslam
+
+// =================================================================================================
+// host side + C-ABI
+// =================================================================================================
+using namespace sslam;
+using namespace sslam::seg;
+
+struct sslam_seg {
+  sslam_seg_params P;
+  hipStream_t stream = nullptr;
+  View V{};
+  std::vector<BoxMeta> boxes;      // accepted boxes of the last call
+  std::vector<int> box_src;        // accepted slot -> index into the caller's box array
+  size_t cap_pix = 0, cap_ii = 0, cap_cloud = 0, cap_box = 0;
+  unsigned char* d_cloud = nullptr;
+  BoxMeta* d_box = nullptr;
+  double last_kernel_ms = 0, last_total_ms = 0;
+  std::vector<void*> allocs;
+  ~sslam_seg() {
+    if (stream) { (void)hipSetDevice(P.device); (void)hipStreamSynchronize(stream); }
+    free_all();
+    if (stream) (void)hipStreamDestroy(stream);
+  }
+  void free_all() {
+    for (void* p : allocs) (void)hipFree(p);
+    allocs.clear();
+  }
+};
+
+static void host_mat4_mul(const float* A, const float* B, float* C) {
+  float T[16];
+  for (int r = 0; r < 4; ++r)
+    for (int c = 0; c < 4; ++c) {
+      float s = 0;
+      for (int k = 0; k < 4; ++k) s += A[r * 4 + k] * B[k * 4 + c];
+      T[r * 4 + c] = s;
+    }
+  memcpy(C, T, sizeof T);
+}
+
+template <typename T>
+static int seg_alloc(sslam_seg* s, size_t n, T** out) {
+  void* p = nullptr;
+  SSLAM_HIP_TRY(hipMalloc(&p, std::max<size_t>(n, 1) * sizeof(T)));
+  s->allocs.push_back(p);
+  *out = (T*)p;
+  return 0;
+}
+
+extern "C" {
+
+void sslam_seg_default_params(sslam_seg_params* p) {
+  if (!p) return;
+  p->num_point_seg = 500; p->norm_point_thres = 5000; p->planar_area = 0.1;   // plane_segmentation.cpp:7-9
+  p->max_depth_change_factor = 0.03f; p->normal_smoothing_size = 20.0f;        // :99-100
+  p->angular_threshold = (float)(0.017453 * 2.0); p->distance_threshold = 0.02f;  // :140-141
+  p->maximum_curvature = 0.001f;
+  p->min_contour_points = 100;                                                 // :169
+  p->image_width = 640; p->image_height = 480;                                 // :34-35
+  p->reference_quirks = 1; p->device = 0;
+}
+
+sslam_seg* sslam_seg_create(const sslam_seg_params* p) {
+  sslam_seg* s = new sslam_seg();
+  if (p) s->P = *p; else sslam_seg_default_params(&s->P);
+  return s;
+}
+void sslam_seg_destroy(sslam_seg* s) { delete s; }
+
+// semantic_tools::transformNormalsToWorld (tools.h:18-102), float matrix chain as in the reference
+int sslam_seg_transform(const sslam_seg* s, const float pose[6], float cam_pitch, float out[16]) {
+  if (!pose || !out) return set_error(SSLAM_ERR_INVALID, "null argument");
+  const int quirks = s ? s->P.reference_quirks : 1;
+  float rxc[16] = {0}, rxr[16] = {0}, rzr[16] = {0}, T[16] = {0};
+  const double roll = pose[3], pitch = pose[4], yaw = pose[5];
+  const double a = -(double)cam_pitch;
+  rxc[0] = 1; rxc[5] = (float)cos(a); rxc[6] = (float)-sin(a); rxc[9] = (float)sin(a); rxc[10] = (float)cos(a); rxc[15] = 1;
+  rxr[0] = 1; rxr[5] = (float)cos(-1.5708); rxr[6] = (float)-sin(-1.5708); rxr[9] = (float)sin(-1.5708); rxr[10] = (float)cos(-1.5708); rxr[15] = 1;
+  rzr[0] = (float)cos(-1.5708); rzr[1] = (float)-sin(-1.5708); rzr[4] = (float)sin(-1.5708); rzr[5] = (float)cos(-1.5708); rzr[10] = 1; rzr[15] = 1;
+  T[0] = (float)(cos(yaw) * cos(pitch));
+  T[1] = (float)(cos(yaw) * sin(pitch) * sin(roll) - sin(yaw) * cos(roll));
+  T[2] = (float)(cos(yaw) * sin(pitch) * cos(roll) + sin(yaw) * (quirks ? sin(pitch) : sin(roll)));  // tools.h:80-81 (quirk B2)
+  T[4] = (float)(sin(yaw) * cos(pitch));
+  T[5] = (float)(sin(yaw) * sin(pitch) * sin(roll) + cos(yaw) * cos(roll));
+  T[6] = (float)(sin(yaw) * sin(pitch) * cos(roll) - cos(yaw) * sin(roll));
+  T[8] = (float)(-sin(pitch)); T[9] = (float)(cos(pitch) * sin(roll)); T[10] = (float)(cos(pitch) * cos(roll)); T[15] = 1;
+  float M[16];
+  host_mat4_mul(T, rzr, M); host_mat4_mul(M, rxr, M); host_mat4_mul(M, rxc, out);
+  return 0;
+}
+
+int sslam_seg_segment(sslam_seg* s, const uint8_t* cloud, int width, int height, int point_step, int row_step, int ox, int oy, int oz,
+                      const sslam_box* boxes, int n_boxes, const float robot_pose[6], float cam_angle, sslam_plane* out, int max_out) {
+  if (!s || !cloud || (!boxes && n_boxes > 0) || !robot_pose || (!out && max_out > 0)) return set_error(SSLAM_ERR_INVALID, "null argument");
+  int nd = 0;
+  if (hipGetDeviceCount(&nd) != hipSuccess || nd <= 0) return set_error(SSLAM_ERR_NO_DEVICE, "no HIP device visible; the product has no CPU fallback");
+  SSLAM_HIP_TRY(hipSetDevice(s->P.device));
+  if (!s->stream) SSLAM_HIP_TRY(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
+  const auto t0 = std::chrono::steady_clock::now();
+  const sslam_seg_params& P = s->P;
+  // ---- host-side box filter: class whitelist (point_cloud_segmentation.h:126-130), crop bounds
+  //      (plane_segmentation.cpp:34-38), minimum point count (:93-95)
+  s->boxes.clear(); s->box_src.clear();
+  size_t npix = 0, nii = 0;
+  int maxpix = 1;
+  for (int i = 0; i < n_boxes; ++i) {
+    const sslam_box& b = boxes[i];
+    if (b.class_id < SSLAM_CLASS_CHAIR || b.class_id > SSLAM_CLASS_CAR) continue;
+    if (b.height < 0 || b.width < 0 || b.tl_x < 0 || b.tl_y < 0 || (b.tl_x + b.width) > P.image_width || (b.tl_y + b.height) > P.image_height) continue;
+    if (b.tl_x + b.width > width || b.tl_y + b.height > height) continue;
+    const size_t n = (size_t)b.width * b.height;
+    if (n == 0 || (double)n < P.norm_point_thres) continue;
+    if (b.width > kBandFloats / 2 - 1) return set_error(SSLAM_ERR_UNSUPPORTED, "box wider than %d px", kBandFloats / 2 - 1);
+    BoxMeta m{b.width, b.height, b.tl_x, b.tl_y, (int)npix, (int)nii, (int)s->boxes.size(), 0};
+    s->boxes.push_back(m); s->box_src.push_back(i);
+    npix += n; nii += (size_t)(b.width + 1) * (b.height + 1);
+    maxpix = std::max(maxpix, (int)n);
+  }
+  const int nb = (int)s->boxes.size();
+  View& V = s->V;
+  const size_t cloud_bytes = (size_t)row_step * height;
+  if (cloud_bytes > s->cap_cloud || npix > s->cap_pix || nii > s->cap_ii || (size_t)nb > s->cap_box) {
+    SSLAM_HIP_TRY(hipStreamSynchronize(s->stream));
+    s->free_all();
+    s->cap_cloud = cloud_bytes; s->cap_pix = std::max<size_t>(npix, 1); s->cap_ii = std::max<size_t>(nii, 1); s->cap_box = std::max(nb, 1);
+    int rc;
+    if ((rc = seg_alloc(s, s->cap_cloud, &s->d_cloud))) return rc;
+    if ((rc = seg_alloc(s, s->cap_box, &s->d_box))) return rc;
+    if ((rc = seg_alloc(s, s->cap_pix * 3, &V.pts))) return rc;
+    if ((rc = seg_alloc(s, s->cap_pix, &V.dm))) return rc;
+    if ((rc = seg_alloc(s, s->cap_pix * 4, &V.nrm))) return rc;
+    if ((rc = seg_alloc(s, s->cap_pix, &V.pd))) return rc;
+    if ((rc = seg_alloc(s, s->cap_pix, &V.lab))) return rc;
+    if ((rc = seg_alloc(s, s->cap_pix, &V.cnt))) return rc;
+    if ((rc = seg_alloc(s, s->cap_pix, &V.l2m))) return rc;
+    if ((rc = seg_alloc(s, s->cap_ii * 3, &V.fo))) return rc;
+    if ((rc = seg_alloc(s, s->cap_ii * 6, &V.so))) return rc;
+    if ((rc = seg_alloc(s, s->cap_ii, &V.ic))) return rc;
+    if ((rc = seg_alloc(s, s->cap_box * kMaxRegions, &V.reg))) return rc;
+    if ((rc = seg_alloc(s, s->cap_box, &V.nreg))) return rc;
+  }
+  V.nbox = nb; V.npix_total = (int)npix; V.maxpix = maxpix;
+  V.box = s->d_box; V.cloud = s->d_cloud;
+  V.point_step = point_step; V.row_step = row_step; V.ox = ox; V.oy = oy; V.oz = oz;
+  V.mdcf = P.max_depth_change_factor; V.smoothing = P.normal_smoothing_size;
+  V.ang_thr_cos = cosf(P.angular_threshold); V.dist_thr = P.distance_threshold; V.max_curv = P.maximum_curvature;
+  V.min_inliers = (unsigned)P.num_point_seg;
+  std::vector<Region> regs;
+  std::vector<int> nreg(nb, 0);
+  float kernel_ms = 0;
+  if (nb > 0) {
+    SSLAM_HIP_TRY(hipMemcpyAsync(s->d_cloud, cloud, cloud_bytes, hipMemcpyHostToDevice, s->stream));
+    SSLAM_HIP_TRY(hipMemcpyAsync(s->d_box, s->boxes.data(), nb * sizeof(BoxMeta), hipMemcpyHostToDevice, s->stream));
+    hipEvent_t e0, e1;
+    SSLAM_HIP_TRY(hipEventCreate(&e0)); SSLAM_HIP_TRY(hipEventCreate(&e1));
+    SSLAM_HIP_TRY(hipEventRecord(e0, s->stream));
+    const dim3 pg((maxpix + 255) / 256, nb), pb(256);
+    int maxw = 1;
+    for (auto& b : s->boxes) maxw = std::max(maxw, b.w);
+    const int BH = std::min(64, kBandFloats / maxw - 1);
+    const size_t band_bytes = (size_t)(BH + 1) * maxw * sizeof(float);
+    if (band_bytes > 64 * 1024) {
+      SSLAM_HIP_TRY(hipFuncSetAttribute((const void*)k_distance_map, hipFuncAttributeMaxDynamicSharedMemorySize, (int)band_bytes));
+      SSLAM_HIP_TRY(hipFuncSetAttribute((const void*)k_refine, hipFuncAttributeMaxDynamicSharedMemorySize, (int)band_bytes));
+    }
+    hipLaunchKernelGGL(k_crop, pg, pb, 0, s->stream, V);
+    hipLaunchKernelGGL(k_depth_change, pg, pb, 0, s->stream, V);
+    hipLaunchKernelGGL(k_distance_map, dim3(nb), dim3(256), band_bytes, s->stream, V);
+    hipLaunchKernelGGL(k_integral, dim3(nb), dim3(64), (size_t)(maxw + 1) * 10 * sizeof(double), s->stream, V);
+    hipLaunchKernelGGL(k_normals, pg, pb, 0, s->stream, V);
+    hipLaunchKernelGGL(k_cc_init, pg, pb, 0, s->stream, V);
+    hipLaunchKernelGGL(k_cc_merge, pg, pb, 0, s->stream, V);
+    hipLaunchKernelGGL(k_cc_flatten, pg, pb, 0, s->stream, V);
+    hipLaunchKernelGGL(k_cc_flatten2, pg, pb, 0, s->stream, V);
+    hipLaunchKernelGGL(k_regions, dim3(nb), dim3(256), 0, s->stream, V);
+    hipLaunchKernelGGL(k_refine, dim3(nb), dim3(256), band_bytes, s->stream, V);
+    hipLaunchKernelGGL(k_contour, dim3(nb), dim3(kMaxRegions), 0, s->stream, V);
+    SSLAM_HIP_TRY(hipEventRecord(e1, s->stream));
+    regs.resize((size_t)nb * kMaxRegions);
+    SSLAM_HIP_TRY(hipMemcpyAsync(regs.data(), V.reg, regs.size() * sizeof(Region), hipMemcpyDeviceToHost, s->stream));
+    SSLAM_HIP_TRY(hipMemcpyAsync(nreg.data(), V.nreg, nb * sizeof(int), hipMemcpyDeviceToHost, s->stream));
+    SSLAM_HIP_TRY(hipStreamSynchronize(s->stream));
+    hipError_t le = hipGetLastError();
+    if (le != hipSuccess) return set_error(SSLAM_ERR_HIP, "frontend kernels: %s", hipGetErrorString(le));
+    SSLAM_HIP_TRY(hipEventElapsedTime(&kernel_ms, e0, e1));
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  }
+  // ---- plane_segmentation.cpp:158-256 + point_cloud_segmentation.h:43-99 (scalar post-processing)
+  float T[16];
+  sslam_seg_transform(s, robot_pose, cam_angle, T);
+  const float hz[3] = {T[8], T[9], T[10]};
+  int nout = 0;
+  for (int bi = 0; bi < nb; ++bi) {
+    const sslam_box& sb = boxes[s->box_src[bi]];
+    for (int k = 0; k < nreg[bi]; ++k) {
+      const Region& R = regs[(size_t)bi * kMaxRegions + k];
+      if (!(R.contour_n > P.min_contour_points)) continue;
+      const float* m = R.model;
+      const float dotp = hz[0] * m[0] + hz[1] * m[1] + hz[2] * m[2];
+      if (!((double)R.area >= P.planar_area)) continue;
+      int type = -1;
+      float sgn = 1.0f;
+      if ((float)(fabsf(m[0]) - fabsf(hz[0])) < 0.3 && (float)(fabsf(m[1]) - fabsf(hz[1])) < 0.3 && (float)(fabsf(m[2]) - fabsf(hz[2])) < 0.3) {
+        type = 0;
+        if (m[1] > 0) sgn = -1.0f;
+      } else if (dotp < 0.5) {
+        type = 1;
+        if (m[0] > 0) sgn = -1.0f;
+      }
+      if (type < 0 || nout >= max_out) continue;
+      sslam_plane& o = out[nout++];
+      memcpy(o.centroid_cam, R.centroid, 12);
+      for (int q = 0; q < 4; ++q) o.normal_d[q] = sgn < 0 ? -m[q] : m[q];
+      for (int r = 0; r < 3; ++r) {
+        float sacc = 0;
+        for (int q = 0; q < 3; ++q) sacc += T[r * 4 + q] * R.centroid[q];
+        sacc += T[r * 4 + 3] * 1.0f;
+        o.world_pose[r] = sacc + robot_pose[r];
+      }
+      o.num_points = (float)R.contour_n; o.prob = sb.prob; o.plane_type = type; o.class_id = sb.class_id;
+      o.box_index = s->box_src[bi]; o.inlier_count = R.inliers; o.area = R.area;
+    }
+  }
+  s->last_kernel_ms = kernel_ms;
+  s->last_total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  return nout;
+}
+
+static int seg_find_slot(sslam_seg* s, int box) {
+  for (size_t k = 0; k < s->box_src.size(); ++k) if (s->box_src[k] == box) return (int)k;
+  return -1;
+}
+int sslam_seg_get_normals(sslam_seg* s, int box, float* out) {
+  if (!s || !out) return set_error(SSLAM_ERR_INVALID, "null argument");
+  const int k = seg_find_slot(s, box);
+  if (k < 0) return set_error(SSLAM_ERR_INVALID, "box %d was rejected or skipped in the last call", box);
+  const BoxMeta& b = s->boxes[k];
+  SSLAM_HIP_TRY(hipMemcpy(out, s->V.nrm + (size_t)b.pix0 * 4, (size_t)b.w * b.h * 4 * sizeof(float), hipMemcpyDeviceToHost));
+  return b.w * b.h;
+}
+int sslam_seg_get_labels(sslam_seg* s, int box, int32_t* out) {
+  if (!s || !out) return set_error(SSLAM_ERR_INVALID, "null argument");
+  const int k = seg_find_slot(s, box);
+  if (k < 0) return set_error(SSLAM_ERR_INVALID, "box %d was rejected or skipped in the last call", box);
+  const BoxMeta& b = s->boxes[k];
+  const int n = b.w * b.h;
+  int* d = nullptr;
+  SSLAM_HIP_TRY(hipMalloc((void**)&d, (size_t)n * sizeof(int)));
+  hipLaunchKernelGGL(k_label_image, dim3((n + 255) / 256), dim3(256), 0, s->stream, s->V, k, d);
+  SSLAM_HIP_TRY(hipStreamSynchronize(s->stream));
+  SSLAM_HIP_TRY(hipMemcpy(out, d, (size_t)n * sizeof(int), hipMemcpyDeviceToHost));
+  (void)hipFree(d);
+  return n;
+}
+int sslam_seg_last_timing(const sslam_seg* s, double* kernel_ms, double* total_ms) {
+  if (!s) return set_error(SSLAM_ERR_INVALID, "null argument");
+  if (kernel_ms) *kernel_ms = s->last_kernel_ms;
+  if (total_ms) *total_ms = s->last_total_ms;
+  return 0;
+}
+
+}  // extern "C"

@@ -281,3 +281,86 @@ def make_graph(n_poses: int, n_landmarks: int, seed: int = 0, *, landmark_kind: 
 
 GRAPH_S = dict(n_poses=500, n_landmarks=100)     # BASELINE.json configs[1]
 GRAPH_L = dict(n_poses=5000, n_landmarks=1000)   # BASELINE.json configs[2]
+
+
+# ----------------------------------------------------------------------------
+# organised depth cloud generator
+# ----------------------------------------------------------------------------
+
+CAM_FX = CAM_FY = 525.0
+CAM_CX, CAM_CY = 319.5, 239.5
+CLASS_CHAIR = 1   # SSLAM_CLASS_CHAIR, whitelisted at point_cloud_segmentation.h:126-130
+
+
+@dataclasses.dataclass
+class SynthFrame:
+    cloud: np.ndarray        # uint8 [height*row_step]  sensor_msgs::PointCloud2::data
+    width: int
+    height: int
+    point_step: int
+    row_step: int
+    offsets: tuple           # (x, y, z) field offsets
+    boxes: np.ndarray        # structured: tl_x, tl_y, width, height, class_id, prob
+    robot_pose: np.ndarray   # float32 [6] x y z roll pitch yaw
+    cam_angle: float         # radians (config camera_angle 33.93 deg)
+
+    def xyz(self) -> np.ndarray:
+        a = self.cloud.view(np.float32).reshape(self.height, self.width, self.point_step // 4)
+        return a[:, :, :3]
+
+
+BOX_DTYPE = np.dtype([("tl_x", "<i4"), ("tl_y", "<i4"), ("width", "<i4"), ("height", "<i4"), ("class_id", "<i4"), ("prob", "<f4")])
+
+
+def make_frame(seed: int = 0, width: int = 640, height: int = 480, n_boxes: int = 32, box_w: int = 128, box_h: int = 96,
+               n_objects: int = 12, nan_fraction: float = 0.02, noise: float = 3e-5) -> SynthFrame:
+    """Piecewise-planar scene (floor + back wall + cuboids) seen by a pinhole camera pitched down
+    by 33.93 deg (config/bucket_detector.yaml camera_angle); depth noise N(0,(noise*z^2)^2) — the
+    default is 3e-5, not SURVEY §8d's 1.5e-3: under PCL's float covariance + 2 deg comparator the
+    latter fragments every connected component below num_point_seg and no plane is ever found —; a
+    fraction of pixels NaN; point_step 32 with x@0 y@4 z@8 rgb@16 as depth_image_proc emits."""
+    rng = np.random.default_rng(seed)
+    pitch = np.deg2rad(33.93)
+    # world: x right, y forward, z up.  camera axes in world: x_c = right, z_c = forward pitched down, y_c = down
+    zc = np.array([0.0, np.cos(pitch), -np.sin(pitch)])
+    xc = np.array([1.0, 0.0, 0.0])
+    yc = np.cross(zc, xc)
+    Rwc = np.stack([xc, yc, zc], axis=1)
+    cam = np.array([0.0, 0.0, 1.3])
+    u, v = np.meshgrid(np.arange(width), np.arange(height))
+    d_c = np.stack([(u - CAM_CX) / CAM_FX, (v - CAM_CY) / CAM_FY, np.ones_like(u, float)], axis=-1)
+    d_w = d_c @ Rwc.T
+    t_best = np.full((height, width), np.inf)
+    # floor z = 0 and back wall y = 7
+    with np.errstate(divide="ignore", invalid="ignore"):
+        t = -cam[2] / d_w[..., 2]
+        t_best = np.where((t > 0) & (t < t_best), t, t_best)
+        t = (7.0 - cam[1]) / d_w[..., 1]
+        t_best = np.where((t > 0) & (t < t_best), t, t_best)
+        for _ in range(n_objects):
+            c = np.array([rng.uniform(-2.5, 2.5), rng.uniform(1.5, 6.0), 0.0])
+            sz = np.array([rng.uniform(0.4, 1.2), rng.uniform(0.4, 1.2), rng.uniform(0.3, 1.0)])
+            lo = c - np.array([sz[0] / 2, sz[1] / 2, 0.0]); hi = c + np.array([sz[0] / 2, sz[1] / 2, sz[2]])
+            t0 = (lo - cam) / d_w; t1 = (hi - cam) / d_w
+            tn = np.minimum(t0, t1).max(-1); tf = np.maximum(t0, t1).min(-1)
+            hit = (tn <= tf) & (tn > 0)
+            t_best = np.where(hit & (tn < t_best), tn, t_best)
+    z = t_best.copy()
+    z[~np.isfinite(z)] = np.nan
+    z = z + rng.normal(0.0, 1.0, z.shape) * noise * z * z
+    z[rng.uniform(size=z.shape) < nan_fraction] = np.nan
+    z[z > 9.5] = np.nan
+    pts = np.stack([(u - CAM_CX) / CAM_FX * z, (v - CAM_CY) / CAM_FY * z, z], axis=-1).astype(np.float32)
+    point_step = 32
+    buf = np.zeros((height, width, point_step // 4), np.float32)
+    buf[:, :, :3] = pts
+    buf[:, :, 4] = rng.uniform(0, 1, (height, width)).astype(np.float32)  # packed rgb stand-in
+    boxes = np.zeros(n_boxes, BOX_DTYPE)
+    boxes["tl_x"] = rng.integers(0, width - box_w + 1, n_boxes)
+    boxes["tl_y"] = rng.integers(0, height - box_h + 1, n_boxes)
+    boxes["width"] = box_w; boxes["height"] = box_h
+    boxes["class_id"] = CLASS_CHAIR
+    boxes["prob"] = rng.uniform(0.5, 1.0, n_boxes).astype(np.float32)
+    pose = np.array([rng.uniform(-1, 1), rng.uniform(-1, 1), 1.3, 0.0, 0.0, rng.uniform(-np.pi, np.pi)], np.float32)
+    return SynthFrame(buf.reshape(-1).view(np.uint8).copy(), width, height, point_step, point_step * width, (0, 4, 8), boxes,
+                      pose, float(pitch))

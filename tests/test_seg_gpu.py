@@ -1,0 +1,113 @@
+"""GPU parity of the planar-segmentation frontend: HIP path (through the C-ABI) vs the CPU oracle.
+
+Bar (north_star): label / inlier sets bit-exact; normals and plane parameters are float pipelines
+with an identical operation order on both sides, so they are compared for exact equality too."""
+import numpy as np
+import pytest
+
+from semantic_slam_amd.synth import make_frame
+
+pytestmark = pytest.mark.gpu
+
+
+def _run_both(frame, params=None):
+    from semantic_slam_amd.segmentation import PointCloudSegmentation, _oracle_segment
+    seg = PointCloudSegmentation(params=params)
+    planes = seg.segmentallPointCloudData(frame.robot_pose, frame.cam_angle, frame.boxes, frame)
+    ref, nrm, lab = _oracle_segment(frame, seg.params, want_products=True)
+    return seg, planes, ref, nrm, lab
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_frame_matches_oracle_bit_exact(gpu_lib, seed):
+    f = make_frame(seed=seed)
+    seg, planes, ref, nrm, lab = _run_both(f)
+    off = 0
+    nvalid = 0
+    for bi, b in enumerate(f.boxes):
+        n = int(b["width"]) * int(b["height"])
+        gn = seg.normals(bi).reshape(n, 4)
+        on = nrm[off:off + n]
+        assert np.array_equal(np.isnan(gn), np.isnan(on)), f"box {bi}: NaN pattern of the normals differs"
+        m = ~np.isnan(on[:, 0])
+        nvalid += int(m.sum())
+        assert np.array_equal(gn[m], on[m]), f"box {bi}: normals differ"
+        gl = seg.labels(bi).reshape(n)
+        assert np.array_equal(gl, lab[off:off + n]), f"box {bi}: label image differs in {(gl != lab[off:off+n]).sum()} px"
+        off += n
+    assert nvalid > 10000
+    assert len(planes) == len(ref) and len(ref) > 0
+    for a, r in zip(planes, ref):
+        assert a.box_index == r.box_index and a.inlier_count == r.inlier_count
+        assert a.num_points == r.num_points and a.area == r.area
+        assert a.plane_type == ("horizontal" if r.plane_type == 0 else "vertical")
+        assert np.array_equal(a.pose, np.array(r.centroid_cam, np.float32))
+        assert np.array_equal(a.normal_orientation, np.array(r.normal_d, np.float32))
+        assert np.array_equal(a.world_pose, np.array(r.world_pose, np.float32))
+
+
+def test_noise_free_planes_are_recovered(gpu_lib):
+    """A noise-free piecewise-planar scene: every reported plane satisfies its own inliers to < 1 mm."""
+    f = make_frame(seed=5, noise=0.0, nan_fraction=0.0)
+    seg, planes, ref, _, _ = _run_both(f)
+    assert len(planes) == len(ref) and len(planes) > 0
+    xyz = f.xyz()
+    for p in planes:
+        b = f.boxes[p.box_index]
+        pts = xyz[b["tl_y"]:b["tl_y"] + b["height"], b["tl_x"]:b["tl_x"] + b["width"]].reshape(-1, 3)
+        lab = seg.labels(p.box_index).reshape(-1)
+        # region index of this plane inside its box = order of appearance among the box's planes
+        d = np.abs(pts @ p.normal_orientation[:3] + p.normal_orientation[3])
+        assert np.nanmin(d) < 1e-3
+
+
+def test_ragged_and_rejected_boxes(gpu_lib):
+    """Class filter (point_cloud_segmentation.h:126-130), out-of-bounds crop (plane_segmentation.cpp:34-38),
+    too few points (:93-95), an empty box list, mixed box sizes."""
+    from semantic_slam_amd.segmentation import PointCloudSegmentation, _oracle_segment
+    f = make_frame(seed=3, n_boxes=8)
+    f.boxes["class_id"][0] = 0                                  # not whitelisted
+    f.boxes["tl_x"][1] = 600; f.boxes["width"][1] = 128         # crosses the right border -> spurious
+    f.boxes["width"][2] = 40; f.boxes["height"][2] = 40          # 1600 px < norm_point_thres
+    f.boxes["width"][3] = 200; f.boxes["height"][3] = 150; f.boxes["tl_x"][3] = 100; f.boxes["tl_y"][3] = 200
+    f.boxes["width"][4] = 97; f.boxes["height"][4] = 131; f.boxes["tl_x"][4] = 301; f.boxes["tl_y"][4] = 17
+    f.boxes["height"][5] = -3
+    seg = PointCloudSegmentation()
+    planes = seg.segmentallPointCloudData(f.robot_pose, f.cam_angle, f.boxes, f)
+    ref, nrm, lab = _oracle_segment(f, seg.params, want_products=True)
+    assert len(planes) == len(ref)
+    for a, r in zip(planes, ref):
+        assert a.box_index == r.box_index and a.inlier_count == r.inlier_count and a.area == r.area
+        assert a.box_index not in (0, 1, 2, 5)
+    off = 0
+    for bi in (3, 4, 6, 7):
+        n = int(f.boxes[bi]["width"]) * int(f.boxes[bi]["height"])
+        assert np.array_equal(seg.labels(bi).reshape(n), lab[off:off + n])
+        off += n
+    assert seg.segmentallPointCloudData(f.robot_pose, f.cam_angle, f.boxes[:0], f) == []
+
+
+def test_full_frame_box(gpu_lib):
+    """Maximum box size the reference accepts: the whole 640x480 frame (plane_segmentation.cpp:34-38)."""
+    from semantic_slam_amd.segmentation import PointCloudSegmentation, _oracle_segment
+    f = make_frame(seed=4, n_boxes=1)
+    f.boxes["tl_x"][0] = 0; f.boxes["tl_y"][0] = 0; f.boxes["width"][0] = 640; f.boxes["height"][0] = 480
+    seg = PointCloudSegmentation()
+    planes = seg.segmentallPointCloudData(f.robot_pose, f.cam_angle, f.boxes, f)
+    ref, nrm, lab = _oracle_segment(f, seg.params, want_products=True)
+    assert np.array_equal(seg.labels(0).reshape(-1), lab)
+    assert len(planes) == len(ref)
+    for a, r in zip(planes, ref):
+        assert a.inlier_count == r.inlier_count and a.num_points == r.num_points and a.area == r.area
+
+
+def test_transform_matches_oracle(gpu_lib):
+    import ctypes as C
+    from oracle import oracle
+    from semantic_slam_amd.segmentation import PointCloudSegmentation
+    seg = PointCloudSegmentation()
+    pose = np.array([0.3, -1.2, 0.9, 0.05, -0.1, 2.1], np.float32)
+    T = seg.transform(pose, 0.59)
+    ref = np.zeros(16, np.float32)
+    oracle.lib().os_transform_normals_to_world(pose.ctypes.data_as(C.c_void_p), C.c_float(0.59), 1, ref.ctypes.data_as(C.c_void_p))
+    assert np.array_equal(T.reshape(-1), ref)
