@@ -616,8 +616,11 @@ __global__ __launch_bounds__(256) void k_linearize_lm_rows(BatchView V) {
 // Further edges on an already-owned vertex pair (e.g. a repeated loop closure): their off-diagonal
 // contributions are added serially, in edge order, after the owners have written the blocks.
 __global__ void k_linearize_dups(BatchView V) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  for (int d = 0; d < V.nDupEo; ++d) {
+  // the host orders the duplicate lists by block; thread t owns the run of entries that share its block
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  for (int d = t; d < V.nDupEo; d = V.nDupEo) {
+    if (d > 0 && (decode_blk(V.eo_blk[V.dup_eo[d - 1]]) >> 1) == (decode_blk(V.eo_blk[V.dup_eo[d]]) >> 1)) break;  // not a run head
+    for (; d < V.nDupEo && (d == t || (decode_blk(V.eo_blk[V.dup_eo[d]]) >> 1) == (decode_blk(V.eo_blk[V.dup_eo[t]]) >> 1)); ++d) {
     const int k = V.dup_eo[d];
     const int pi = V.eo_i[k], pj = V.eo_j[k];
     if (!V.lm[V.prow_graph[V.pose_row[pi]]].active) continue;
@@ -633,8 +636,11 @@ __global__ void k_linearize_dups(BatchView V) {
       double a = 0; for (int s = 0; s < 6; ++s) a += Ji[s * 6 + r] * WJ[s * 6 + c];
       O[(blk & 1) ? c * 6 + r : r * 6 + c] += a;
     }
+    }
   }
-  for (int d = 0; d < V.nDupEl; ++d) {
+  for (int d = t; d < V.nDupEl; d = V.nDupEl) {
+    if (d > 0 && decode_blk(V.el_blk[V.dup_el[d - 1]]) == decode_blk(V.el_blk[V.dup_el[d]])) break;
+    for (; d < V.nDupEl && (d == t || decode_blk(V.el_blk[V.dup_el[d]]) == decode_blk(V.el_blk[V.dup_el[t]])); ++d) {
     const int k = V.dup_el[d];
     const int pi = V.el_p[k], li = V.el_l[k];
     if (!V.lm[V.prow_graph[V.pose_row[pi]]].active) continue;
@@ -655,6 +661,7 @@ __global__ void k_linearize_dups(BatchView V) {
     for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) WJl[r * 3 + c] = W[r * 3 + 0] * Jl[c] + W[r * 3 + 1] * Jl[3 + c] + W[r * 3 + 2] * Jl[6 + c];
     double* O = V.Hpl + (size_t)decode_blk(V.el_blk[k]) * 18;
     for (int r = 0; r < 6; ++r) for (int c = 0; c < 3; ++c) O[r * 3 + c] += Ji[r] * WJl[c] + Ji[6 + r] * WJl[3 + c] + Ji[12 + r] * WJl[6 + c];
+    }
   }
 }
 
@@ -1188,6 +1195,8 @@ static int batch_build(Batch& b) {
       }
     }
   }
+  std::stable_sort(b.dup_eo.begin(), b.dup_eo.end(), [&](int x, int y) { return ((-2 - eo_blk[x]) >> 1) < ((-2 - eo_blk[y]) >> 1); });
+  std::stable_sort(b.dup_el.begin(), b.dup_el.end(), [&](int x, int y) { return (-2 - el_blk[x]) < (-2 - el_blk[y]); });
   std::vector<int> pslot_ptr(nPr + 1, 0), pslot_edge, lslot_ptr(nLr + 1, 0), lslot_edge, tile_row0, tile_row1;
   std::vector<unsigned char> pslot_kind;
   b.max_row_slots = 0;
@@ -1376,7 +1385,7 @@ static int batch_linearize(Batch& b) {
       if (b.has_planes) hipLaunchKernelGGL(k_linearize_lm_rows<true>, dim3((V.nLr + 15) / 16), dim3(256), 0, b.stream, V);
       else hipLaunchKernelGGL(k_linearize_lm_rows<false>, dim3((V.nLr + 15) / 16), dim3(256), 0, b.stream, V);
     }
-    if (V.nDupEo + V.nDupEl > 0) hipLaunchKernelGGL(k_linearize_dups, dim3(1), dim3(64), 0, b.stream, V);
+    if (V.nDupEo + V.nDupEl > 0) hipLaunchKernelGGL(k_linearize_dups, dim3((std::max(V.nDupEo, V.nDupEl) + 63) / 64), dim3(64), 0, b.stream, V);
     return launch_check("linearize");
   }
   if (gather) {
@@ -1388,7 +1397,7 @@ static int batch_linearize(Batch& b) {
       if (V.nPr > 0) hipLaunchKernelGGL(k_linearize_rows2<false>, dim3((V.nPr + 31) / 32), dim3(256), 0, b.stream, V);
       if (V.nLr > 0) hipLaunchKernelGGL(k_linearize_lm_rows<false>, dim3((V.nLr + 15) / 16), dim3(256), 0, b.stream, V);
     }
-    if (V.nDupEo + V.nDupEl > 0) hipLaunchKernelGGL(k_linearize_dups, dim3(1), dim3(64), 0, b.stream, V);
+    if (V.nDupEo + V.nDupEl > 0) hipLaunchKernelGGL(k_linearize_dups, dim3((std::max(V.nDupEo, V.nDupEl) + 63) / 64), dim3(64), 0, b.stream, V);
     return launch_check("linearize");
   }
   const int per_graph_rows = V.maxRowChunks * kRowChunk;

@@ -17,6 +17,8 @@
 #include <chrono>
 #include <cmath>
 #include <cstring>
+#include <cstdio>
+#include <cstdlib>
 #include <vector>
 
 #include "../../include/sslam.h"
@@ -55,6 +57,7 @@ struct View {
   int* lab;      // [npix] connected-component root (pixel index inside the box) or -1
   int* cnt;      // [npix] pixels per root
   int* l2m;      // [npix] root label -> region index, or -1
+  int* code;     // [npix] region index | kOther | -1  (labels as seen by refinement / contour)
   double* fo;    // [nii*3]
   double* so;    // [nii*6]
   unsigned* ic;  // [nii]
@@ -442,110 +445,143 @@ __global__ __launch_bounds__(256) void k_cc_flatten2(View V) {  // second hop: e
 }
 
 // per-label plane fit (OrganizedMultiPlaneSegmentation::segment): labels with more than
-// min_inliers pixels, float accumulation in raster order (one thread per candidate label),
-// eigen33, flip towards the viewpoint, curvature gate; regions are numbered in label order
-__global__ __launch_bounds__(256) void k_regions(View V) {
-  __shared__ int cand[256];
+// min_inliers pixels; PCL accumulates the 9 float sums in index (raster) order, so the additions stay
+// a serial chain, but everything around them is parallel: candidate roots are found by all threads,
+// each candidate gets a wave, pixels are loaded 64 at a time (coalesced), the 9 products are formed
+// lane-parallel and parked in LDS, and lanes 0..8 each run one component's chain over the chunk.
+constexpr int kMaxCand = 64;
+__global__ __launch_bounds__(1024) void k_regions(View V) {
+  __shared__ int cand[kMaxCand];
   __shared__ int ncand;
-  __shared__ int accepted[256];
+  __shared__ int accepted[kMaxCand];
+  __shared__ float prod[16][64][9];
+  __shared__ Region regs[kMaxCand];
   const BoxMeta b = V.box[blockIdx.x];
   const int n = b.w * b.h;
   const int* L = V.lab + b.pix0;
   const int* cnt = V.cnt + b.pix0;
   const float* pts = V.pts + (size_t)b.pix0 * 3;
   if (threadIdx.x == 0) ncand = 0;
+  if (threadIdx.x < kMaxCand) accepted[threadIdx.x] = 0;
   __syncthreads();
-  // ordered candidate list (roots in increasing pixel index): thread 0 scans, the list is short
-  if (threadIdx.x == 0) {
-    int k = 0;
-    for (int i = 0; i < n && k < 256; ++i)
-      if (L[i] == i && (unsigned)cnt[i] > V.min_inliers) cand[k++] = i;
-    ncand = k;
+  for (int i = threadIdx.x; i < n; i += 1024)
+    if (L[i] == i && (unsigned)cnt[i] > V.min_inliers) { const int k = atomicAdd(&ncand, 1); if (k < kMaxCand) cand[k] = i; }
+  __syncthreads();
+  const int nc = min(ncand, kMaxCand);
+  if (threadIdx.x == 0) {  // order by root pixel index = PCL's label order (insertion sort, short list)
+    for (int a = 1; a < nc; ++a) { const int v = cand[a]; int q = a - 1; while (q >= 0 && cand[q] > v) { cand[q + 1] = cand[q]; --q; } cand[q + 1] = v; }
   }
   __syncthreads();
-  const int k = threadIdx.x;
-  Region R;
-  bool ok = false;
-  if (k < ncand) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  for (int k = wave; k < nc; k += 16) {
     const int label = cand[k];
-    float a[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    float acc = 0;            // lanes 0..8: component `lane`
     int first = -1, last = -1;
-    for (int i = 0; i < n; ++i) {
-      if (L[i] != label) continue;
-      const float x = pts[(size_t)i * 3], y = pts[(size_t)i * 3 + 1], z = pts[(size_t)i * 3 + 2];
-      a[0] += x * x; a[1] += x * y; a[2] += x * z; a[3] += y * y; a[4] += y * z; a[5] += z * z; a[6] += x; a[7] += y; a[8] += z;
-      if (first < 0) first = i;
-      last = i;
+    for (int i0 = 0; i0 < n; i0 += 64) {
+      const int i = i0 + lane;
+      const bool m = i < n && L[i] == label;
+      if (m) {
+        const float x = pts[(size_t)i * 3], y = pts[(size_t)i * 3 + 1], z = pts[(size_t)i * 3 + 2];
+        float* p = prod[wave][lane];
+        p[0] = x * x; p[1] = x * y; p[2] = x * z; p[3] = y * y; p[4] = y * z; p[5] = z * z; p[6] = x; p[7] = y; p[8] = z;
+      }
+      const unsigned long long mask = __ballot(m);
+      if (mask) {
+        if (first < 0) first = i0 + __ffsll((long long)mask) - 1;
+        last = i0 + 63 - __clzll((long long)mask);
+        if (lane < 9) {
+          unsigned long long mm = mask;
+          while (mm) { const int bpos = __ffsll((long long)mm) - 1; mm &= mm - 1; acc += prod[wave][bpos][lane]; }
+        }
+      }
     }
-    const float cntf = (float)cnt[label];
+    float a[9];
 #pragma unroll
-    for (int q = 0; q < 9; ++q) a[q] = a[q] / cntf;
-    float cov[9];
-    cov[0] = a[0] - a[6] * a[6]; cov[1] = a[1] - a[6] * a[7]; cov[2] = a[2] - a[6] * a[8];
-    cov[4] = a[3] - a[7] * a[7]; cov[5] = a[4] - a[7] * a[8]; cov[8] = a[5] - a[8] * a[8];
-    cov[3] = cov[1]; cov[6] = cov[2]; cov[7] = cov[5];
-    float ev, v[3];
-    eigen33(cov, ev, v);
-    float p[4] = {v[0], v[1], v[2], 0};
-    p[3] = -1 * (p[0] * a[6] + p[1] * a[7] + p[2] * a[8]);
-    const float ct = (0.0f - a[6]) * p[0] + (0.0f - a[7]) * p[1] + (0.0f - a[8]) * p[2];
-    if (ct < 0) {
-      p[0] *= -1; p[1] *= -1; p[2] *= -1;
+    for (int q = 0; q < 9; ++q) a[q] = __shfl(acc, q, 64);
+    if (lane == 0) {
+      const float cntf = (float)cnt[label];
+#pragma unroll
+      for (int q = 0; q < 9; ++q) a[q] = a[q] / cntf;
+      float cov[9];
+      cov[0] = a[0] - a[6] * a[6]; cov[1] = a[1] - a[6] * a[7]; cov[2] = a[2] - a[6] * a[8];
+      cov[4] = a[3] - a[7] * a[7]; cov[5] = a[4] - a[7] * a[8]; cov[8] = a[5] - a[8] * a[8];
+      cov[3] = cov[1]; cov[6] = cov[2]; cov[7] = cov[5];
+      float ev, v[3];
+      eigen33(cov, ev, v);
+      float p[4] = {v[0], v[1], v[2], 0};
       p[3] = -1 * (p[0] * a[6] + p[1] * a[7] + p[2] * a[8]);
+      const float ct = (0.0f - a[6]) * p[0] + (0.0f - a[7]) * p[1] + (0.0f - a[8]) * p[2];
+      if (ct < 0) {
+        p[0] *= -1; p[1] *= -1; p[2] *= -1;
+        p[3] = -1 * (p[0] * a[6] + p[1] * a[7] + p[2] * a[8]);
+      }
+      const float es = cov[0] + cov[4] + cov[8];
+      const float curv = es != 0 ? fabsf(ev / es) : 0;
+      Region R;
+      R.centroid[0] = a[6]; R.centroid[1] = a[7]; R.centroid[2] = a[8];
+      R.model[0] = p[0]; R.model[1] = p[1]; R.model[2] = p[2]; R.model[3] = p[3];
+      R.inliers = cnt[label]; R.first_inlier = first; R.label = label; R.contour_n = 0; R.area = 0;
+      R.last_key = (unsigned long long)(unsigned)last;
+      regs[k] = R;
+      accepted[k] = curv < V.max_curv ? 1 : 0;
     }
-    const float es = cov[0] + cov[4] + cov[8];
-    const float curv = es != 0 ? fabsf(ev / es) : 0;
-    ok = curv < V.max_curv;
-    R.centroid[0] = a[6]; R.centroid[1] = a[7]; R.centroid[2] = a[8];
-    R.model[0] = p[0]; R.model[1] = p[1]; R.model[2] = p[2]; R.model[3] = p[3];
-    R.inliers = cnt[label]; R.first_inlier = first; R.label = label; R.contour_n = 0; R.area = 0;
-    R.last_key = (unsigned long long)(unsigned)last;
   }
-  accepted[threadIdx.x] = ok ? 1 : 0;
   __syncthreads();
-  if (ok) {
+  if (threadIdx.x < nc && accepted[threadIdx.x]) {
     int idx = 0;
-    for (int q = 0; q < k; ++q) idx += accepted[q];
+    for (int q = 0; q < (int)threadIdx.x; ++q) idx += accepted[q];
     if (idx < kMaxRegions) {
-      V.reg[(size_t)blockIdx.x * kMaxRegions + idx] = R;
-      V.l2m[b.pix0 + R.label] = idx;
+      V.reg[(size_t)blockIdx.x * kMaxRegions + idx] = regs[threadIdx.x];
+      V.l2m[b.pix0 + regs[threadIdx.x].label] = idx;
     }
   }
   if (threadIdx.x == 0) {
     int tot = 0;
-    for (int q = 0; q < ncand; ++q) tot += accepted[q];
+    for (int q = 0; q < nc; ++q) tot += accepted[q];
     V.nreg[blockIdx.x] = min(tot, kMaxRegions);
   }
+}
+
+// labels -> compact codes for refinement / contour / the label image:
+//   region index (0..63) for pixels of an accepted plane, kOther for any other valid pixel, -1 invalid
+constexpr int kOther = 1000;
+__global__ __launch_bounds__(256) void k_relabel(View V) {
+  const BoxMeta b = V.box[blockIdx.y];
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= b.w * b.h) return;
+  const int l = V.lab[b.pix0 + i];
+  V.code[b.pix0 + i] = l < 0 ? -1 : (V.l2m[b.pix0 + l] >= 0 ? V.l2m[b.pix0 + l] : kOther);
 }
 
 // OrganizedMultiPlaneSegmentation::refine: two raster sweeps with the PlaneRefinementComparator,
 // executed as skewed wavefronts over a label band staged in LDS (image row stride preserved, so the
 // second sweep's colIdx-1 read at column 0 lands on the previous row's last pixel as in PCL).
-__device__ __forceinline__ bool refine_compare(const View& V, const BoxMeta& b, int cl, int nl, int i1, int i2, int& model_idx) {
-  const int m1 = V.l2m[b.pix0 + cl];
-  if (m1 < 0) return false;
-  if (V.l2m[b.pix0 + nl] >= 0) return false;
-  model_idx = m1;
-  const float* m = V.reg[(size_t)b.box_index * kMaxRegions + m1].model;
+__device__ __forceinline__ bool refine_compare(const View& V, const BoxMeta& b, const float* models, int cl, int nl, int i1, int i2) {
+  if (!(cl < kMaxRegions && nl >= kMaxRegions)) return false;   // grow[current] && !grow[next]
+  const float* m = models + cl * 4;
   const float* p = V.pts + ((size_t)b.pix0 + i2) * 3;
   const double d = fabs((double)(m[0] * p[0] + m[1] * p[1] + m[2] * p[2] + m[3]));
   const float z = V.pts[((size_t)b.pix0 + i1) * 3 + 2];
   const float t = V.dist_thr * (z * z);
   return d < (double)t;
 }
-__device__ __forceinline__ void refine_record(const View& V, const BoxMeta& b, int model_idx, unsigned long long pass, unsigned long long key, int target) {
-  Region* R = &V.reg[(size_t)b.box_index * kMaxRegions + model_idx];
+__device__ __forceinline__ void refine_record(const View& V, int slot, int model_idx, unsigned long long pass, unsigned long long key, int target) {
+  Region* R = &V.reg[(size_t)slot * kMaxRegions + model_idx];
   atomicAdd(&R->inliers, 1);
   atomicMax(&R->last_key, (pass << 60) | (key << 24) | (unsigned long long)target);
 }
 __global__ __launch_bounds__(256) void k_refine(View V) {
   extern __shared__ int lband[];
-  BoxMeta b = V.box[blockIdx.x];
-  b.box_index = blockIdx.x;  // (regions are stored per accepted box slot)
-  if (V.nreg[blockIdx.x] == 0) return;
+  __shared__ float models[kMaxRegions * 4];
+  const BoxMeta b = V.box[blockIdx.x];
+  const int slot = blockIdx.x;
+  const int nregs = V.nreg[slot];
+  if (nregs == 0) return;
+  for (int k = threadIdx.x; k < nregs * 4; k += 256) models[k] = V.reg[(size_t)slot * kMaxRegions + (k >> 2)].model[k & 3];
   const int w = b.w, h = b.h;
-  int* L = V.lab + b.pix0;
+  int* L = V.code + b.pix0;
   const int BH = min(64, kBandFloats / w - 1);
+  __syncthreads();
   // ---- sweep 1: top-down, left-right; checks right then lower neighbour
   for (int r0 = 0; r0 < h - 1; r0 += BH) {
     const int nr = min(BH, h - 1 - r0);
@@ -561,15 +597,14 @@ __global__ __launch_bounds__(256) void k_refine(View V) {
           const int r = r0 + l;
           const int cl = cur[c], rl = cur[c + 1];
           if (cl >= 0 && rl >= 0) {
-            int mi;
-            if (refine_compare(V, b, cl, rl, r * w + c, r * w + c + 1, mi)) {
+            if (refine_compare(V, b, models, cl, rl, r * w + c, r * w + c + 1)) {
               cur[c + 1] = cl;
-              refine_record(V, b, mi, 1ull, (unsigned long long)(r * w + c) * 2ull, r * w + c + 1);
+              refine_record(V, slot, cl, 1ull, (unsigned long long)(r * w + c) * 2ull, r * w + c + 1);
             }
             const int ll = cur[w + c];
-            if (ll >= 0 && refine_compare(V, b, cl, ll, r * w + c, (r + 1) * w + c, mi)) {
+            if (ll >= 0 && refine_compare(V, b, models, cl, ll, r * w + c, (r + 1) * w + c)) {
               cur[w + c] = cl;
-              refine_record(V, b, mi, 1ull, (unsigned long long)(r * w + c) * 2ull + 1ull, (r + 1) * w + c);
+              refine_record(V, slot, cl, 1ull, (unsigned long long)(r * w + c) * 2ull + 1ull, (r + 1) * w + c);
             }
           }
         }
@@ -598,15 +633,14 @@ __global__ __launch_bounds__(256) void k_refine(View V) {
           const int lf = c >= 1 ? cur[c - 1] : 0;
           if (cl >= 0 && lf >= 0) {
             const unsigned long long key = (unsigned long long)((h - 1 - r) * w + (w - 1 - c)) * 2ull;
-            int mi;
-            if (c >= 1 && refine_compare(V, b, cl, lf, r * w + c, r * w + c - 1, mi)) {
+            if (c >= 1 && refine_compare(V, b, models, cl, lf, r * w + c, r * w + c - 1)) {
               cur[c - 1] = cl;
-              refine_record(V, b, mi, 2ull, key, r * w + c - 1);
+              refine_record(V, slot, cl, 2ull, key, r * w + c - 1);
             }
             const int ul = cur[c - w];
-            if (ul >= 0 && refine_compare(V, b, cl, ul, r * w + c, (r - 1) * w + c, mi)) {
+            if (ul >= 0 && refine_compare(V, b, models, cl, ul, r * w + c, (r - 1) * w + c)) {
               cur[c - w] = cl;
-              refine_record(V, b, mi, 2ull, key + 1ull, (r - 1) * w + c);
+              refine_record(V, slot, cl, 2ull, key + 1ull, (r - 1) * w + c);
             }
           }
         }
@@ -619,23 +653,33 @@ __global__ __launch_bounds__(256) void k_refine(View V) {
 }
 
 // findLabeledRegionBoundary (Moore trace from the last inlier) + pcl::calculatePolygonArea, one
-// thread per region (sequential by nature; float accumulation in contour order)
-__global__ void k_contour(View V) {
+// thread per region (sequential by nature; float accumulation in contour order).  The code image is
+// staged in LDS as bytes when it fits (<= 150k pixels), so the trace does not pay HBM/L2 latency.
+template <bool STAGED>
+__global__ __launch_bounds__(256) void k_contour(View V) {
+  extern __shared__ unsigned char cimg[];
   const int bx = blockIdx.x;
-  const int k = threadIdx.x;
-  if (k >= V.nreg[bx]) return;
   const BoxMeta b = V.box[bx];
   const int w = b.w, h = b.h;
-  const int* L = V.lab + b.pix0;
+  const int* L = V.code + b.pix0;
+  const int nregs = V.nreg[bx];
+  if (nregs == 0) return;
+  if (STAGED) {
+    for (int i = threadIdx.x; i < w * h; i += 256) { const int c = L[i]; cimg[i] = c < 0 ? 255 : (c >= kMaxRegions ? 254 : (unsigned char)c); }
+    __syncthreads();
+  }
+  const int k = threadIdx.x;
+  if (k >= nregs) return;
   const float* pts = V.pts + (size_t)b.pix0 * 3;
   Region* R = &V.reg[(size_t)bx * kMaxRegions + k];
   const int start = (int)(R->last_key & 0xffffffull);
-  const int label = L[start];
+#define code_at(idx) (STAGED ? (int)cimg[(idx)] : (L[(idx)] < 0 ? 255 : (L[(idx)] >= kMaxRegions ? 254 : L[(idx)])))
+  const int label = code_at(start);
   const int dxs[8] = {-1, -1, 0, 1, 1, 1, 0, -1}, dys[8] = {0, -1, -1, -1, 0, 1, 1, 1};
   int dirn = -1, cx = start % w, cy = start / w, ci = start;
   for (int d = 0; d < 8; ++d) {
     const int x = cx + dxs[d], y = cy + dys[d], idx = ci + dys[d] * w + dxs[d];
-    if (x >= 0 && x < w && y >= 0 && y < h && L[idx] != label) { dirn = d; break; }
+    if (x >= 0 && x < w && y >= 0 && y < h && code_at(idx) != label) { dirn = d; break; }
   }
   int count = 0;
   float res[3] = {0, 0, 0};
@@ -649,7 +693,7 @@ __global__ void k_contour(View V) {
       for (int d = 1; d <= 8; ++d) {
         nI = (dirn + d) & 7;
         const int x = cx + dxs[nI], y = cy + dys[nI], idx = ci + dys[nI] * w + dxs[nI];
-        if (x >= 0 && x < w && y >= 0 && y < h && L[idx] == label) break;
+        if (x >= 0 && x < w && y >= 0 && y < h && code_at(idx) == label) break;
       }
       dirn = (nI + 4) & 7;
       ci += dys[nI] * w + dxs[nI]; cx += dxs[nI]; cy += dys[nI];
@@ -667,6 +711,7 @@ __global__ void k_contour(View V) {
   }
   R->contour_n = count;
   R->area = sqrtf(res[0] * res[0] + res[1] * res[1] + res[2] * res[2]) * 0.5f;
+#undef code_at
 }
 
 // final label image for the parity hook: region index or -1
@@ -674,8 +719,8 @@ __global__ __launch_bounds__(256) void k_label_image(View V, int box, int* out) 
   const BoxMeta b = V.box[box];
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= b.w * b.h) return;
-  const int l = V.lab[b.pix0 + i];
-  out[i] = l >= 0 ? V.l2m[b.pix0 + l] : -1;
+  const int c = V.code[b.pix0 + i];
+  out[i] = (c >= 0 && c < kMaxRegions) ? c : -1;
 }
 
 }  // namespace seg
@@ -815,6 +860,7 @@ int sslam_seg_segment(sslam_seg* s, const uint8_t* cloud, int width, int height,
     if ((rc = seg_alloc(s, s->cap_pix, &V.lab))) return rc;
     if ((rc = seg_alloc(s, s->cap_pix, &V.cnt))) return rc;
     if ((rc = seg_alloc(s, s->cap_pix, &V.l2m))) return rc;
+    if ((rc = seg_alloc(s, s->cap_pix, &V.code))) return rc;
     if ((rc = seg_alloc(s, s->cap_ii * 3, &V.fo))) return rc;
     if ((rc = seg_alloc(s, s->cap_ii * 6, &V.so))) return rc;
     if ((rc = seg_alloc(s, s->cap_ii, &V.ic))) return rc;
@@ -845,18 +891,49 @@ int sslam_seg_segment(sslam_seg* s, const uint8_t* cloud, int width, int height,
       SSLAM_HIP_TRY(hipFuncSetAttribute((const void*)k_distance_map, hipFuncAttributeMaxDynamicSharedMemorySize, (int)band_bytes));
       SSLAM_HIP_TRY(hipFuncSetAttribute((const void*)k_refine, hipFuncAttributeMaxDynamicSharedMemorySize, (int)band_bytes));
     }
+    const bool dbg = getenv("SSLAM_SEG_DEBUG") != nullptr;
+#define DBG(name) do { if (dbg) { hipError_t e_ = hipStreamSynchronize(s->stream); fprintf(stderr, "[seg] %s: %s\n", name, hipGetErrorString(e_)); } } while (0)
     hipLaunchKernelGGL(k_crop, pg, pb, 0, s->stream, V);
+    DBG("k_crop");
     hipLaunchKernelGGL(k_depth_change, pg, pb, 0, s->stream, V);
+    DBG("k_depth_change");
     hipLaunchKernelGGL(k_distance_map, dim3(nb), dim3(256), band_bytes, s->stream, V);
+    DBG("k_distance_map");
     hipLaunchKernelGGL(k_integral, dim3(nb), dim3(64), (size_t)(maxw + 1) * 10 * sizeof(double), s->stream, V);
+    DBG("k_integral");
     hipLaunchKernelGGL(k_normals, pg, pb, 0, s->stream, V);
+    DBG("k_normals");
     hipLaunchKernelGGL(k_cc_init, pg, pb, 0, s->stream, V);
+    DBG("k_cc_init");
     hipLaunchKernelGGL(k_cc_merge, pg, pb, 0, s->stream, V);
+    DBG("k_cc_merge");
     hipLaunchKernelGGL(k_cc_flatten, pg, pb, 0, s->stream, V);
+    DBG("k_cc_flatten");
     hipLaunchKernelGGL(k_cc_flatten2, pg, pb, 0, s->stream, V);
-    hipLaunchKernelGGL(k_regions, dim3(nb), dim3(256), 0, s->stream, V);
+    DBG("k_cc_flatten2");
+    hipLaunchKernelGGL(k_regions, dim3(nb), dim3(1024), 0, s->stream, V);
+    DBG("k_regions");
+    hipLaunchKernelGGL(k_relabel, pg, pb, 0, s->stream, V);
+    DBG("k_relabel");
     hipLaunchKernelGGL(k_refine, dim3(nb), dim3(256), band_bytes, s->stream, V);
-    hipLaunchKernelGGL(k_contour, dim3(nb), dim3(kMaxRegions), 0, s->stream, V);
+    DBG("k_refine");
+    if (dbg) {
+      std::vector<Region> rr((size_t)nb * kMaxRegions); std::vector<int> nn(nb);
+      (void)hipMemcpy(rr.data(), V.reg, rr.size() * sizeof(Region), hipMemcpyDeviceToHost);
+      (void)hipMemcpy(nn.data(), V.nreg, nb * sizeof(int), hipMemcpyDeviceToHost);
+      for (int bi = 0; bi < nb; ++bi) for (int k = 0; k < nn[bi]; ++k) {
+        const Region& R = rr[(size_t)bi * kMaxRegions + k];
+        fprintf(stderr, "[seg] box %d reg %d: inl %d first %d label %d key %llx\n", bi, k, R.inliers, R.first_inlier, R.label, R.last_key);
+      }
+    }
+    if (maxpix <= 150 * 1024 && !getenv("SSLAM_SEG_NOSTAGE")) {
+      if (maxpix > 64 * 1024) SSLAM_HIP_TRY(hipFuncSetAttribute((const void*)k_contour<true>, hipFuncAttributeMaxDynamicSharedMemorySize, maxpix));
+      hipLaunchKernelGGL(k_contour<true>, dim3(nb), dim3(256), (size_t)maxpix, s->stream, V);
+    DBG("k_contour");
+    } else {
+      hipLaunchKernelGGL(k_contour<false>, dim3(nb), dim3(256), 0, s->stream, V);
+    DBG("k_contour");
+    }
     SSLAM_HIP_TRY(hipEventRecord(e1, s->stream));
     regs.resize((size_t)nb * kMaxRegions);
     SSLAM_HIP_TRY(hipMemcpyAsync(regs.data(), V.reg, regs.size() * sizeof(Region), hipMemcpyDeviceToHost, s->stream));
