@@ -50,6 +50,7 @@ def main():
         dist.init_process_group("nccl")
     import numpy as np
     from semantic_slam_amd import GraphSLAM, GraphBatch, load_library
+    from semantic_slam_amd import distributed as D
     from semantic_slam_amd.synth import make_graph
     from oracle.oracle import GraphProblem  # only for problem packing + the cpu_baseline leg
 
@@ -98,15 +99,11 @@ def main():
     stats = batch.optimize(args.steps)       # blocks until the stream is idle (hipStreamSynchronize)
     sync_all()
     dt = time.perf_counter() - t0
-    if dist is not None:
-        import torch
-        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+    dt = D.max_over_ranks(dt, device="cuda" if dist is not None else None)
     iters_done = [s.iterations for s in stats]
     assert min(iters_done) == args.steps, f"LM terminated early: {min(iters_done)} < {args.steps}"
-    total_graph_iters = args.batch * world * args.steps
-    value = total_graph_iters / dt
+    # whole-job value: graph-iterations of ALL ranks / max-over-ranks time (replicas: no data-path collective)
+    value = D.aggregate_throughput(float(args.batch * args.steps), dt, device="cuda" if dist is not None else None)
 
     # ---- kernel times (hipEvents on the batch's stream, inside the timed region) -------------------
     names = ["linearize", "chi2", "spmv", "pcg_update", "precond", "oplus", "factor", "solve"]

@@ -1,0 +1,136 @@
+"""CPU-side checks of the boundary: libsslam_hip.so loads, exports every symbol include/sslam.h declares,
+the host logic of the C-ABI behaves like the reference's GraphSLAM wrapper, and - on a box without a GPU -
+every compute entry point fails loudly (there is no CPU fallback)."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol(hip_lib):
+    hdr = open(os.path.join(ROOT, "include", "sslam.h")).read()
+    names = sorted(set(re.findall(r"\b(sslam_[a-z0-9_]+)\s*\(", hdr)))
+    assert len(names) >= 40
+    missing = [n for n in names if not hasattr(hip_lib, n)]
+    assert not missing, f"symbols declared in include/sslam.h but not exported: {missing}"
+
+
+def test_no_cuda_shims_or_oracle_in_the_product(hip_lib):
+    from semantic_slam_amd import library_path
+    out = subprocess.run(["nm", "-D", "--defined-only", library_path()], capture_output=True, text=True).stdout
+    assert "og_optimize" not in out and "os_segment" not in out      # oracle symbols never ship in the product
+    deps = subprocess.run(["readelf", "-d", library_path()], capture_output=True, text=True).stdout
+    assert "libamdhip64" in deps and "liboracle" not in deps
+
+
+def test_vertex_and_edge_bookkeeping(hip_lib):
+    from semantic_slam_amd import GraphSLAM, SslamError
+    G = GraphSLAM()
+    a = G.add_se3_node([0, 0, 0, 0, 0, 0, 1])
+    p = G.add_point_xyz_node([1.0, 2.0, 3.0])
+    b = G.add_se3_node(np.array([[0, -1, 0, 1.0], [1, 0, 0, 2.0], [0, 0, 1, 3.0], [0, 0, 0, 1]]))   # Isometry3d-style input
+    assert (a, p, b) == (0, 1, 2)                                    # id = vertex count (graph_slam.cpp:106)
+    assert np.allclose(G.estimate(b), [1, 2, 3, 0, 0, np.sqrt(0.5), np.sqrt(0.5)])
+    assert np.allclose(G.estimate(p), [1, 2, 3])
+    e0 = G.add_se3_edge(a, b, [1, 2, 3, 0, 0, 0, 1], np.eye(6))
+    e1 = G.add_se3_point_xyz_edge(a, p, [1, 2, 3], np.eye(3) * 2.5)
+    assert (e0, e1) == (0, 1) and G.num_edges() == 2 and G.num_vertices() == 3
+    # first vertex fixed (graph_slam.cpp:109-111) -> no hessian index; others in id order (point 3, pose 6)
+    assert [G.hessian_index(v) for v in (a, p, b)] == [-1, 0, 3]
+    with pytest.raises(SslamError):
+        G.add_se3_edge(a, 7, [0, 0, 0, 0, 0, 0, 1], np.eye(6))
+    with pytest.raises(SslamError):
+        G.add_se3_point_xyz_edge(a, b, [0, 0, 0], np.eye(3))          # b is not a point vertex
+    with pytest.raises(SslamError):
+        G.add_plane_node([0, 0, 0, 1.0])                             # zero normal
+    pl = G.add_plane_node([0, 0, 2.0, 4.0])
+    assert np.allclose(G.estimate(pl), [0, 0, 1, 2])                 # Plane3D normalises its vector
+
+
+def test_optimize_with_fewer_than_ten_edges_returns_false(hip_lib):
+    from semantic_slam_amd import GraphSLAM
+    G = GraphSLAM()
+    a = G.add_se3_node([0, 0, 0, 0, 0, 0, 1]); b = G.add_se3_node([1, 0, 0, 0, 0, 0, 1])
+    for _ in range(9):
+        G.add_se3_edge(a, b, [1, 0, 0, 0, 0, 0, 1], np.eye(6))
+    assert G.optimize() is False                                      # graph_slam.cpp:184-186
+    assert G.last_stats.status == -5
+
+
+def test_compute_entry_points_fail_loudly_without_a_gpu(hip_lib):
+    if hip_lib.sslam_device_count() > 0:
+        pytest.skip("a GPU is visible here; the loud-failure path is for CPU-only boxes")
+    from semantic_slam_amd import GraphSLAM, SslamError
+    from semantic_slam_amd.segmentation import PointCloudSegmentation
+    from semantic_slam_amd.synth import make_graph, make_frame
+    from oracle.oracle import GraphProblem
+    G = GraphSLAM.from_problem(GraphProblem.from_synth(make_graph(20, 5, seed=0)))
+    with pytest.raises(SslamError) as ei:
+        G.optimize(3)
+    assert ei.value.code == -2 and "no CPU fallback" in str(ei.value)
+    with pytest.raises(SslamError):
+        G.chi2()
+    f = make_frame(seed=0, n_boxes=2)
+    with pytest.raises(SslamError) as ei:
+        PointCloudSegmentation().segmentallPointCloudData(f.robot_pose, f.cam_angle, f.boxes, f)
+    assert ei.value.code == -2
+
+
+def test_g2o_text_round_trip(hip_lib, tmp_path):
+    from semantic_slam_amd import GraphSLAM
+    from semantic_slam_amd.synth import make_graph
+    from oracle.oracle import GraphProblem
+    for kind in ("point", "plane"):
+        gp = GraphProblem.from_synth(make_graph(15, 4, seed=3, landmark_kind=kind), interleave=True)
+        G = GraphSLAM.from_problem(gp)
+        path = str(tmp_path / f"g_{kind}.g2o")
+        G.save(path)                                                 # GraphSLAM::save, graph_slam.cpp:236-239
+        text = open(path).read()
+        assert text.startswith("PARAMS_SE3OFFSET 0 0 0 0 0 0 0 1")
+        assert "VERTEX_SE3:QUAT 0 " in text and "EDGE_SE3:QUAT" in text and "FIX 0" in text
+        assert ("EDGE_SE3_TRACKXYZ" in text) == (kind == "point") and ("EDGE_SE3_PLANE" in text) == (kind == "plane")
+        G2 = GraphSLAM(); G2.load(path)
+        assert G2.num_vertices() == G.num_vertices() and G2.num_edges() == G.num_edges()
+        assert np.array_equal(G2.estimates(), G.estimates())          # %.17g round-trips doubles exactly
+        assert [G2.hessian_index(v) for v in range(gp.nv)] == [G.hessian_index(v) for v in range(gp.nv)]
+        path2 = str(tmp_path / f"g2_{kind}.g2o")
+        G2.save(path2)
+        assert open(path2).read() == text
+    golden = os.path.join(ROOT, "tests", "golden", "graph20_point.g2o")
+    G3 = GraphSLAM(); G3.load(golden)
+    assert G3.num_vertices() == 25 and G3.num_edges() == 79
+
+
+def test_seg_defaults_and_transform_match_reference_constants(hip_lib):
+    from semantic_slam_amd.segmentation import PointCloudSegmentation, default_params
+    from oracle import oracle
+    p = default_params()
+    assert (p.num_point_seg, p.norm_point_thres, p.planar_area) == (500, 5000, pytest.approx(0.1))   # plane_segmentation.cpp:7-9
+    assert p.max_depth_change_factor == pytest.approx(0.03) and p.normal_smoothing_size == 20        # :99-100
+    assert p.angular_threshold == pytest.approx(0.017453 * 2) and p.distance_threshold == pytest.approx(0.02)  # :140-141
+    assert (p.image_width, p.image_height, p.min_contour_points) == (640, 480, 100)                   # :34-35, :169
+    seg = PointCloudSegmentation()
+    pose = np.array([0.3, -1.2, 0.9, 0.05, -0.1, 2.1], np.float32)
+    T = seg.transform(pose, 0.59)                                      # host-side scalar math: no GPU needed
+    ref = np.zeros(16, np.float32)
+    oracle.lib().os_transform_normals_to_world(pose.ctypes.data_as(C.c_void_p), C.c_float(0.59), 1, ref.ctypes.data_as(C.c_void_p))
+    assert np.array_equal(T.reshape(-1), ref)
+    # level robot, yaw 0: the camera's optical axis maps to world +x, its y axis (down) to world -z
+    T0 = seg.transform(np.zeros(6, np.float32), 0.0)
+    assert np.allclose(T0[:3, :3] @ [0, 0, 1], [1, 0, 0], atol=1e-5) and np.allclose(T0[:3, :3] @ [0, 1, 0], [0, 0, -1], atol=1e-5)
+
+
+def test_cpp_shims_compile_and_link(hip_lib, tmp_path):
+    from semantic_slam_amd import library_path
+    exe = str(tmp_path / "shim_check")
+    libdir = os.path.dirname(library_path())
+    subprocess.check_call(["g++", "-std=c++17", "-O1", os.path.join(ROOT, "tests", "shim_compile_check.cpp"), "-o", exe,
+                           "-L" + libdir, "-lsslam_hip", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"])
+    out = subprocess.run([exe], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "shim ok" in out.stdout
