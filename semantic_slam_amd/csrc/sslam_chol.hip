@@ -49,6 +49,7 @@ struct CholPlan {
   CholView C{};
   std::vector<int> lvl_ptr;
   std::vector<int> lvl_maxlist;  // longest update list among the level's blocks
+  std::vector<int> lvl_maxEt;    // largest column (entries + rhs) of the level
   std::vector<void*> allocs;
   int max_col_entries = 0;
   int64_t lnz = 0;
@@ -73,17 +74,83 @@ void chol_plan_free(CholPlan* p) {
 //                                                    are split over up to 4 waves and reduced in LDS
 //                                                    in a fixed order -> deterministic)
 //   L(j,j) = chol(S(j,j)),  L(i,j) = S(i,j) L(j,j)^-T,   y(j) = L(j,j)^-1 (b(j) - sum_k L(j,k) y(k))
-// NT = 256 for wide (bottom) levels, 1024 for the narrow top levels whose update lists are long:
-// lists are split over NT / wpad slices and the partial sums reduced through LDS in a fixed order.
+// tail of a column: in-register dense Cholesky of the D x D diagonal block, forward-substituted rhs,
+// triangular solves of the off-diagonal rows
+template <int D, int NT>
+__device__ __forceinline__ void chol_tail(const double* sm, int csize, double* Lw, double* yout, int* fail, int tid) {
+  double a[D * D], t[D];
+#pragma unroll
+  for (int q = 0; q < D * D; ++q) a[q] = sm[q];
+#pragma unroll
+  for (int q = 0; q < D; ++q) t[q] = sm[csize + q];
+  bool ok = true;
+#pragma unroll
+  for (int c = 0; c < D; ++c) {
+    double d = a[c * D + c];
+#pragma unroll
+    for (int s = 0; s < c; ++s) d -= a[c * D + s] * a[c * D + s];
+    if (!(d > 0)) { ok = false; d = 1.0; }
+    d = sqrt(d);
+    a[c * D + c] = d;
+#pragma unroll
+    for (int r = c + 1; r < D; ++r) {
+      double x = a[r * D + c];
+#pragma unroll
+      for (int s = 0; s < c; ++s) x -= a[r * D + s] * a[c * D + s];
+      a[r * D + c] = x / d;
+    }
+#pragma unroll
+    for (int s = c + 1; s < D; ++s) a[c * D + s] = 0.0;  // strict upper = 0
+  }
+  if (tid == 0) {
+    if (!ok) *fail = 1;
+#pragma unroll
+    for (int r = 0; r < D; ++r) {
+      double v = t[r];
+#pragma unroll
+      for (int s = 0; s < r; ++s) v -= a[r * D + s] * t[s];
+      t[r] = v / a[r * D + r];
+    }
+#pragma unroll
+    for (int q = 0; q < D * D; ++q) Lw[q] = a[q];
+#pragma unroll
+    for (int q = 0; q < D; ++q) yout[q] = t[q];
+  }
+  const int nrows_off = (csize - D * D) / D;
+  for (int row = tid; row < nrows_off; row += NT) {
+    const double* v = sm + D * D + row * D;
+    double x[D];
+#pragma unroll
+    for (int c = 0; c < D; ++c) {
+      double w = v[c];
+#pragma unroll
+      for (int s = 0; s < c; ++s) w -= x[s] * a[c * D + s];
+      x[c] = w / a[c * D + c];
+    }
+    double* o = Lw + D * D + row * D;
+#pragma unroll
+    for (int c = 0; c < D; ++c) o[c] = x[c];
+  }
+}
+
+// NT = 256 (4 waves) for wide levels, 1024 (16 waves) for the narrow top levels whose update lists
+// are long.  Work item of a wave = (target block, slice of its update list).  For every update the
+// wave loads the two source blocks once with contiguous 8-byte lanes (2 x <=288 B), parks them in its
+// LDS scratch and the di x dj entry lanes read rows from LDS (broadcast), instead of every entry lane
+// gathering 12 scalars from L2.  Slices are reduced through LDS in a fixed order -> deterministic.
+constexpr int kPartDoubles = 4096;  // LDS budget for the per-slice partial sums
 template <int NT>
 __global__ __launch_bounds__(NT) void k_chol_level(BatchView V, CholView C, int lvl_begin) {
-  extern __shared__ double sm[];  // [Et] column + rhs entries, then partial sums [nslice][Et]
+  extern __shared__ double sm[];  // [Et] column + rhs entries | [nslice][Et] partial sums | [NW][80] wave scratch
+  constexpr int NW = NT / 64;
   const int j = C.lvl_cols[lvl_begin + blockIdx.x];
   const int g = C.col_graph[j];
   if (!V.lm[g].in_trial) return;
   const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63;
   const int dj = C.col_dim[j];
   const int b0 = C.bp[j], b1 = C.bp[j + 1];
+  const int nb = b1 - b0;
   const int base = C.boff[b0];
   int csize;
   {
@@ -91,46 +158,62 @@ __global__ __launch_bounds__(NT) void k_chol_level(BatchView V, CholView C, int 
     csize = C.boff[last] - base + C.col_dim[C.brow[last]] * dj;
   }
   const int Et = csize + dj;  // the last dj "entries" are the forward-substitution rhs
-  const int wpad = Et <= 64 ? 64 : (Et <= 128 ? 128 : (Et <= 256 ? 256 : NT));
-  const int nslice = NT / wpad;
-  const int slice = tid / wpad;
-  const int estride = nslice == 1 ? NT : wpad;
+  int maxlen = 0;
+  for (int b = b0; b < b1; ++b) maxlen = max(maxlen, C.up[b + 1] - C.up[b]);
+  const int nslice = max(1, min(min(NW, (maxlen + 3) >> 2), kPartDoubles / Et));
   const double lambda = V.lm[g].lambda;
   const double* __restrict__ H = V.Hpp_diag;
   const double* __restrict__ L = C.Lval;
   const double* __restrict__ Y = C.y;
   double* part = sm + Et;
-  for (int e = tid % wpad; e < Et; e += estride) {
+  double* scr = sm + Et + nslice * Et + wave * 80;
+  const int nitems = nb * nslice;
+  for (int item = wave; item < nitems; item += NW) {
+    const int b = b0 + item / nslice, sl = item - (item / nslice) * nslice;
+    const int di = C.col_dim[C.brow[b]];
+    const int nE = di * dj;
+    const bool diag = (b == b0);
+    const int r = lane / dj, c = lane - r * dj;          // entry lanes: lane < nE
+    const int ry = lane - 40;                            // rhs lanes: 40 .. 40 + dj - 1 (diagonal block only)
     double acc = 0;
-    if (e < csize) {
-      int b = b0;
-      while (b + 1 < b1 && C.boff[b + 1] - base <= e) ++b;
-      const int le = e - (C.boff[b] - base);
-      const int r = le / dj, c = le - r * dj;
-      const int u1 = C.up[b + 1];
-#pragma unroll 2
-      for (int u = C.up[b] + slice; u < u1; u += nslice) {
-        const int dk = C.udk[u];
-        const double* pa = L + C.ua[u] + r * dk;
-        const double* pb = L + C.ub[u] + c * dk;
+    const int u1 = C.up[b + 1];
+    int u = C.up[b] + sl;
+    // software pipeline: registers hold the next update's elements while the current one is consumed from LDS
+    double v0 = 0, v1 = 0;
+    int dk = 0, nA = 0, nB = 0;
+    auto fetch = [&](int uu) {
+      dk = C.udk[uu];
+      nA = di * dk; nB = dj * dk;
+      const double* A = L + C.ua[uu];
+      const double* B = L + C.ub[uu];
+      const double* Yk = Y + C.ux[uu];
+      const int i0 = lane, i1 = lane + 64;
+      v0 = i0 < nA ? A[i0] : (i0 < nA + nB ? B[i0 - nA] : ((diag && i0 < nA + nB + dk) ? Yk[i0 - nA - nB] : 0.0));
+      v1 = i1 < nA ? A[i1] : (i1 < nA + nB ? B[i1 - nA] : ((diag && i1 < nA + nB + dk) ? Yk[i1 - nA - nB] : 0.0));
+    };
+    if (u < u1) fetch(u);
+    while (u < u1) {
+      const int cdk = dk, cnA = nA, cnB = nB;
+      scr[lane] = v0;
+      if (lane < 16) scr[64 + lane] = v1;
+      u += nslice;
+      if (u < u1) fetch(u);
+      if (lane < nE) {
+        const double* pa = scr + r * cdk;
+        const double* pb = scr + cnA + c * cdk;
         double s = pa[0] * pb[0] + pa[1] * pb[1] + pa[2] * pb[2];
-        if (dk == 6) s += pa[3] * pb[3] + pa[4] * pb[4] + pa[5] * pb[5];
+        if (cdk == 6) s += pa[3] * pb[3] + pa[4] * pb[4] + pa[5] * pb[5];
         acc += s;
-      }
-    } else {
-      const int r = e - csize;
-      const int u1 = C.up[b0 + 1];
-#pragma unroll 2
-      for (int u = C.up[b0] + slice; u < u1; u += nslice) {
-        const int dk = C.udk[u];
-        const double* pa = L + C.ua[u] + r * dk;
-        const double* yk = Y + C.ux[u];
+      } else if (diag && ry >= 0 && ry < dj) {
+        const double* pa = scr + ry * cdk;
+        const double* yk = scr + cnA + cnB;
         double s = pa[0] * yk[0] + pa[1] * yk[1] + pa[2] * yk[2];
-        if (dk == 6) s += pa[3] * yk[3] + pa[4] * yk[4] + pa[5] * yk[5];
+        if (cdk == 6) s += pa[3] * yk[3] + pa[4] * yk[4] + pa[5] * yk[5];
         acc += s;
       }
     }
-    part[slice * Et + e] = acc;
+    if (lane < nE) part[sl * Et + (C.boff[b] - base) + lane] = acc;
+    else if (diag && ry >= 0 && ry < dj) part[sl * Et + csize + ry] = acc;
   }
   __syncthreads();
   for (int e = tid; e < Et; e += NT) {
@@ -152,46 +235,11 @@ __global__ __launch_bounds__(NT) void k_chol_level(BatchView V, CholView C, int 
     sm[e] = v;
   }
   __syncthreads();
-  double* tvec = sm + csize;
-  if (tid == 0) {  // dense Cholesky of the dj x dj diagonal block, in place (lower), + y_j
-    bool ok = true;
-    for (int c = 0; c < dj; ++c) {
-      double d = sm[c * dj + c];
-      for (int s = 0; s < c; ++s) d -= sm[c * dj + s] * sm[c * dj + s];
-      if (!(d > 0)) { ok = false; d = 1.0; }
-      d = sqrt(d);
-      sm[c * dj + c] = d;
-      for (int r = c + 1; r < dj; ++r) {
-        double x = sm[r * dj + c];
-        for (int s = 0; s < c; ++s) x -= sm[r * dj + s] * sm[c * dj + s];
-        sm[r * dj + c] = x / d;
-      }
-      for (int s = c + 1; s < dj; ++s) sm[c * dj + s] = 0.0;  // strict upper = 0
-    }
-    if (!ok) C.fail[g] = 1;
-    for (int r = 0; r < dj; ++r) {
-      double t = tvec[r];
-      for (int s = 0; s < r; ++s) t -= sm[r * dj + s] * tvec[s];
-      tvec[r] = t / sm[r * dj + r];
-    }
-  }
-  __syncthreads();
-  // off-diagonal rows: x L_jj^T = v  (forward substitution along the row); one thread per row
-  const int nrows_off = (csize - dj * dj) / dj;
-  for (int row = tid; row < nrows_off; row += NT) {
-    double* v = sm + dj * dj + row * dj;
-    double x[6];
-    for (int c = 0; c < dj; ++c) {
-      double t = v[c];
-      for (int s = 0; s < c; ++s) t -= x[s] * sm[c * dj + s];
-      x[c] = t / sm[c * dj + c];
-    }
-    for (int c = 0; c < dj; ++c) v[c] = x[c];
-  }
-  __syncthreads();
+  // ---- diagonal block: every thread factors its own register copy (D^3/3 flops, no LDS latency chain,
+  //      no further barriers); then one thread per off-diagonal row solves x L_jj^T = v and stores to HBM
   double* Lw = C.Lval + base;
-  for (int e = tid; e < csize; e += NT) Lw[e] = sm[e];
-  if (tid < dj) C.y[C.col_xoff[j] + tid] = tvec[tid];
+  if (dj == 6) chol_tail<6, NT>(sm, csize, Lw, C.y + C.col_xoff[j], C.fail + g, tid);
+  else chol_tail<3, NT>(sm, csize, Lw, C.y + C.col_xoff[j], C.fail + g, tid);
 }
 
 // forward substitution only (multi right-hand-side form, used for marginals): y_j = L_jj^-1 (b_j - sum_k L_jk y_k)
@@ -441,6 +489,12 @@ int chol_plan_build(Batch& b) {
     if (bp[j + 1] - bp[j] > 1) { const int par = brow[bp[j] + 1]; level[par] = std::max(level[par], level[j] + 1); }
     nlev = std::max(nlev, level[j] + 1);
   }
+  P->lvl_maxEt.assign(nlev, 0);
+  for (int j = 0; j < ncol; ++j) {
+    const int last = bp[j + 1] - 1;
+    const int cs = boff[last] - boff[bp[j]] + col_dim[brow[last]] * col_dim[j];
+    P->lvl_maxEt[level[j]] = std::max(P->lvl_maxEt[level[j]], cs + col_dim[j]);
+  }
   P->lvl_maxlist.assign(nlev, 0);
   for (int j = 0; j < ncol; ++j)
     for (int t = bp[j]; t < bp[j + 1]; ++t) P->lvl_maxlist[level[j]] = std::max(P->lvl_maxlist[level[j]], up[t + 1] - up[t]);
@@ -483,18 +537,27 @@ int chol_factor_and_forward(Batch& b) {
   const CholView& C = P.C;
   ScopedTimer t(b, "factor");
   hipLaunchKernelGGL(k_chol_begin, dim3((b.V.B + 63) / 64), dim3(64), 0, b.stream, b.V, C);
-  // LDS: Et entries + nslice*Et partials, nslice*Et <= max(NT, Et)
-  const size_t lds = (size_t)(2 * (P.max_col_entries + 6) + 1024) * sizeof(double);
-  if (lds > 160 * 1024) return set_error(SSLAM_ERR_UNSUPPORTED, "a factor column needs %zu B of LDS (> 160 KiB)", lds);
-  if (lds > 64 * 1024) {
-    SSLAM_HIP_TRY(hipFuncSetAttribute((const void*)k_chol_level<256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    SSLAM_HIP_TRY(hipFuncSetAttribute((const void*)k_chol_level<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  // LDS per level: Et entries + partial sums (nslice*Et <= kPartDoubles, nslice <= NW) + NW wave scratch areas
+  auto lds_for = [&](int l, int nw) {
+    const int et = P.lvl_maxEt[l];
+    return (size_t)(et + std::max(et, std::min(kPartDoubles, nw * et)) + nw * 80) * sizeof(double);
+  };
+  size_t lds_max = 0;
+  for (int l = 0; l < C.nlevels; ++l) lds_max = std::max(lds_max, lds_for(l, 16));
+  if (lds_max > 160 * 1024) return set_error(SSLAM_ERR_UNSUPPORTED, "a factor column needs %zu B of LDS (> 160 KiB)", lds_max);
+  if (lds_max > 64 * 1024) {
+    SSLAM_HIP_TRY(hipFuncSetAttribute((const void*)k_chol_level<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
+    SSLAM_HIP_TRY(hipFuncSetAttribute((const void*)k_chol_level<256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
+    SSLAM_HIP_TRY(hipFuncSetAttribute((const void*)k_chol_level<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
   }
   for (int l = 0; l < C.nlevels; ++l) {
     const int n = P.lvl_ptr[l + 1] - P.lvl_ptr[l];
     if (n <= 0) continue;
-    if (P.lvl_maxlist[l] >= 32) hipLaunchKernelGGL(k_chol_level<1024>, dim3(n), dim3(1024), lds, b.stream, b.V, C, P.lvl_ptr[l]);
-    else hipLaunchKernelGGL(k_chol_level<256>, dim3(n), dim3(256), lds, b.stream, b.V, C, P.lvl_ptr[l]);
+    // narrow levels are latency-bound (long update lists -> 16 waves per column); wide levels have enough
+    // columns in flight to hide latency and run 4 waves per column
+    if (P.lvl_maxlist[l] >= 32 && n < 1024) hipLaunchKernelGGL(k_chol_level<1024>, dim3(n), dim3(1024), lds_for(l, 16), b.stream, b.V, C, P.lvl_ptr[l]);
+    else if ((P.lvl_maxlist[l] <= 6 && n >= 2048) || n >= 24576) hipLaunchKernelGGL(k_chol_level<64>, dim3(n), dim3(64), lds_for(l, 1), b.stream, b.V, C, P.lvl_ptr[l]);
+    else hipLaunchKernelGGL(k_chol_level<256>, dim3(n), dim3(256), lds_for(l, 4), b.stream, b.V, C, P.lvl_ptr[l]);
   }
   hipLaunchKernelGGL(k_chol_end, dim3((b.V.B + 63) / 64), dim3(64), 0, b.stream, b.V, C);
   hipError_t e = hipGetLastError();

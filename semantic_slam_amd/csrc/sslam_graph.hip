@@ -382,24 +382,57 @@ __global__ __launch_bounds__(256) void k_linearize_rows(BatchView V) {
   }
 }
 
-// ---- Jacobian build, variant C (default): one 8-lane group per pose row, registers only ---------
-// Lane r (< 6) of a group owns column r of the Jacobians and row r of every product of its row.
-// The group walks the row's (edge) slots; W*J columns are exchanged with wave shuffles (no LDS, no
-// barriers), the diagonal block / b accumulate in registers and are written once (288 + 48
-// contiguous bytes per row, rows of a wave are consecutive -> fully coalesced), off-diagonal blocks
-// are written by their owner slot.  Slot records are fetched lane-parallel (one latency per 8 slots).
-__device__ __forceinline__ double group_bcast(double v, int src_lane) { return __shfl(v, src_lane, 64); }
+// ---- Jacobian build, variant C (default): one 8-lane group per pose row ------------------------
+// Lane c (< 6) of a group owns column c of the Jacobians and column c of every product of its row:
+//   D[:,c] = Js^T (W Js[:,c]),   Off[:,c] = Js^T (W Jo[:,c]),   b_c = -Js[:,c] . (W e)
+// so the only data a lane needs from its neighbours is the 6x6 (3x6) block Js itself.  It is exchanged
+// through a 288-byte per-group LDS scratch with 16-byte accesses (3 stores + 9 broadcast loads per
+// lane, wave-synchronous, no barriers).  The diagonal block / b accumulate in registers and are
+// written once (rows of a wave are consecutive -> coalesced); off-diagonal blocks are written by the
+// owner slot.  Slot records are fetched lane-parallel (one latency per 8 slots).
+struct alignas(16) D2 { double a, b; };
+__device__ __forceinline__ void exch_store6(double* scr, int c, const double v[6]) {
+  D2* p = reinterpret_cast<D2*>(scr + c * 6);
+  p[0] = D2{v[0], v[1]}; p[1] = D2{v[2], v[3]}; p[2] = D2{v[4], v[5]};
+}
+__device__ __forceinline__ void exch_load_row(const double* scr, int a, double row[6]) {
+  const D2* p = reinterpret_cast<const D2*>(scr + a * 6);
+  const D2 v0 = p[0], v1 = p[1], v2 = p[2];
+  row[0] = v0.a; row[1] = v0.b; row[2] = v1.a; row[3] = v1.b; row[4] = v2.a; row[5] = v2.b;
+}
+// y = W x for the symmetric 6x6 W given by its 21 upper-triangular entries (row-major order)
+__device__ __forceinline__ void sym6_mul(const double u[21], const double x[6], double y[6]) {
+#pragma unroll
+  for (int a = 0; a < 6; ++a) y[a] = 0;
+  int k = 0;
+#pragma unroll
+  for (int r = 0; r < 6; ++r)
+#pragma unroll
+    for (int cc = r; cc < 6; ++cc) {
+      y[r] += u[k] * x[cc];
+      if (cc != r) y[cc] += u[k] * x[r];
+      ++k;
+    }
+}
+__device__ __forceinline__ void exch_load36(const double* scr, double Jt[36]) {
+  const D2* p = reinterpret_cast<const D2*>(scr);
+#pragma unroll
+  for (int k = 0; k < 18; ++k) { const D2 v = p[k]; Jt[2 * k] = v.a; Jt[2 * k + 1] = v.b; }
+}
 
 template <bool PL>
-__global__ __launch_bounds__(256) void k_linearize_rows2(BatchView V) {
+__global__ __launch_bounds__(256, 2) void k_linearize_rows2(BatchView V) {
+  __shared__ alignas(16) double scratch[32 * 36];
+  __shared__ double hand[32 * 6 * 7];   // j-side contribution handed over by the row above: [local row][c][D(6), b]
+  bool receives = false;
   const int row = blockIdx.x * 32 + (threadIdx.x >> 3);
-  const int r = threadIdx.x & 7;
+  const int c = threadIdx.x & 7;
   const int gbase = (threadIdx.x & 63) & ~7;   // first lane of this group inside the wave
+  double* scr = scratch + (threadIdx.x >> 3) * 36;
   const bool row_ok = row < V.nPr && V.lm[V.prow_graph[row < V.nPr ? row : 0]].active;
-  const bool lane_ok = row_ok && r < 6;
+  const bool lane_ok = row_ok && c < 6;
   const int s0 = row_ok ? V.pslot_ptr[row] : 0, s1 = row_ok ? V.pslot_ptr[row + 1] : 0;
-  // all groups of a wave iterate to the longest slot list among them (shuffles need every lane)
-  int nmax = s1 - s0;
+  int nmax = s1 - s0;   // all groups of a wave iterate to the longest slot list among them (record shuffles)
 #pragma unroll
   for (int o = 8; o < 64; o <<= 1) nmax = max(nmax, __shfl_xor(nmax, o, 64));
   double D[6] = {0, 0, 0, 0, 0, 0};
@@ -407,133 +440,146 @@ __global__ __launch_bounds__(256) void k_linearize_rows2(BatchView V) {
   int4 rec = make_int4(0, 0, 0, 0);
   for (int t = 0; t < nmax; ++t) {
     if ((t & 7) == 0) {  // lane-parallel fetch of the next 8 slot records
-      const int s = s0 + t + r;
+      const int s = s0 + t + c;
       rec = s < s1 ? V.pslot_rec[s] : make_int4(0, -1, 0, 0);
     }
     const int src = gbase + (t & 7);
-    const int e = __shfl(rec.x, src, 64), kind = __shfl(rec.y, src, 64), ia = __shfl(rec.z, src, 64), ib = __shfl(rec.w, src, 64);
+    const int e = __shfl(rec.x, src, 64), kflags = __shfl(rec.y, src, 64), ia = __shfl(rec.z, src, 64), ib = __shfl(rec.w, src, 64);
     const bool live = lane_ok && (s0 + t) < s1;
-    double self[6] = {0, 0, 0, 0, 0, 0}, other[6] = {0, 0, 0, 0, 0, 0}, We[6] = {0, 0, 0, 0, 0, 0};
-    double WJs[6] = {0, 0, 0, 0, 0, 0}, WJo[6] = {0, 0, 0, 0, 0, 0};
-    int blk = -1;
-    if (live) {
-      if (kind < 2) {
-        const int n = V.nEo;
-        Se3Lin L;
-        se3_error(load_pose(V.pose, ia), load_pose(V.pose, ib), load_meas_pose(V.eo_z, n, e), L);
+    if (!live) continue;
+    const int kind = kflags & 15;
+    const bool provide = (kflags >> 4) & 1;
+    if (kind == 3) { receives = true; continue; }
+    if (kind < 2) {
+      const int n = V.nEo;
+      Se3Lin L;
+      se3_error(load_pose(V.pose, ia), load_pose(V.pose, ib), load_meas_pose(V.eo_z, n, e), L);
+      const int blk = kind == 0 ? V.eo_blk[e] : -1;
+      double self[6], other[6] = {0, 0, 0, 0, 0, 0};
+      if (kind == 0) { se3_Ji_col(L, c, self); } else { L.Re = qmat(L.qe); se3_Jj_col(L, c, self); }
+      double U[21];
+#pragma unroll
+      for (int k = 0; k < 21; ++k) U[k] = V.eo_w[(size_t)k * n + e];
+      double vs[6], We[6], vo[6] = {0, 0, 0, 0, 0, 0};
+      sym6_mul(U, self, vs);
+      sym6_mul(U, L.e, We);
+      const bool owner = blk >= 0;
+      const bool swapped = owner && (blk & 1);
+      if (owner || provide) {
         L.Re = qmat(L.qe);
-        double ci[6], cj[6];
-        se3_Ji_col(L, r, ci);
-        se3_Jj_col(L, r, cj);
-        blk = V.eo_blk[e];
-#pragma unroll
-        for (int q = 0; q < 6; ++q) { self[q] = kind == 0 ? ci[q] : cj[q]; other[q] = kind == 0 ? cj[q] : ci[q]; }
-        if (kind != 0) blk = -1;
-        double W[36];
-        load_sym6(V.eo_w, n, e, W);
-#pragma unroll
-        for (int a = 0; a < 6; ++a) {
-          double ws = 0, wo = 0, we = 0;
-#pragma unroll
-          for (int q = 0; q < 6; ++q) { ws += W[a * 6 + q] * self[q]; wo += W[a * 6 + q] * other[q]; we += W[a * 6 + q] * L.e[q]; }
-          WJs[a] = ws; WJo[a] = wo; We[a] = we;
-        }
-      } else {
-        const int n = V.nEl;
-        const Pose Xi = load_pose(V.pose, ia);
-        const double* lp = V.lmk + (size_t)ib * 4;
-        double err[3], jl[3] = {0, 0, 0};
-        if (!PL || V.lm_kind[ib] == VT_POINT) {
-          PointLin L;
-          point_error(Xi, Vec3{lp[0], lp[1], lp[2]}, Vec3{V.el_z[0 * (size_t)n + e], V.el_z[1 * (size_t)n + e], V.el_z[2 * (size_t)n + e]}, L);
-          err[0] = L.e[0]; err[1] = L.e[1]; err[2] = L.e[2];
-          const double px = L.pc.x, py = L.pc.y, pz = L.pc.z;
-          if (r == 0) { self[0] = -1; } else if (r == 1) { self[1] = -1; } else if (r == 2) { self[2] = -1; }
-          else if (r == 3) { self[1] = 2 * pz; self[2] = -2 * py; }
-          else if (r == 4) { self[0] = -2 * pz; self[2] = 2 * px; }
-          else { self[0] = 2 * py; self[1] = -2 * px; }
-          if (r < 3) { jl[0] = pick3(r, L.R.m[0], L.R.m[3], L.R.m[6]); jl[1] = pick3(r, L.R.m[1], L.R.m[4], L.R.m[7]); jl[2] = pick3(r, L.R.m[2], L.R.m[5], L.R.m[8]); }
-        } else {
-          const Plane pw{{lp[0], lp[1], lp[2]}, lp[3]};
-          const Plane z{{V.el_z[0 * (size_t)n + e], V.el_z[1 * (size_t)n + e], V.el_z[2 * (size_t)n + e]}, V.el_z[3 * (size_t)n + e]};
-          plane_error(Xi, pw, z, err);
-          const double delta = 1e-9, scalar = 1.0 / (2 * delta);
-          double dv[6], ep[3], em[3];
-#pragma unroll
-          for (int q = 0; q < 6; ++q) dv[q] = q == r ? delta : 0.0;
-          plane_error(se3_oplus(Xi, dv), pw, z, ep);
-#pragma unroll
-          for (int q = 0; q < 6; ++q) dv[q] = q == r ? -delta : 0.0;
-          plane_error(se3_oplus(Xi, dv), pw, z, em);
-          self[0] = scalar * (ep[0] - em[0]); self[1] = scalar * (ep[1] - em[1]); self[2] = scalar * (ep[2] - em[2]);
-          if (r < 3) {
-            double d3[3];
-#pragma unroll
-            for (int q = 0; q < 3; ++q) d3[q] = q == r ? delta : 0.0;
-            plane_error(Xi, pl_oplus(pw, d3), z, ep);
-#pragma unroll
-            for (int q = 0; q < 3; ++q) d3[q] = q == r ? -delta : 0.0;
-            plane_error(Xi, pl_oplus(pw, d3), z, em);
-            jl[0] = scalar * (ep[0] - em[0]); jl[1] = scalar * (ep[1] - em[1]); jl[2] = scalar * (ep[2] - em[2]);
-          }
-        }
-        blk = V.el_blk[e];
-        double W[9];
-        load_sym3(V.el_w, n, e, W);
-#pragma unroll
-        for (int a = 0; a < 3; ++a) {
-          WJs[a] = W[a * 3 + 0] * self[0] + W[a * 3 + 1] * self[1] + W[a * 3 + 2] * self[2];   // (W Ji)[a][r]
-          WJo[a] = W[a * 3 + 0] * jl[0] + W[a * 3 + 1] * jl[1] + W[a * 3 + 2] * jl[2];         // (W Jl)[a][r], r < 3
-          We[a] = W[a * 3 + 0] * err[0] + W[a * 3 + 1] * err[1] + W[a * 3 + 2] * err[2];
-        }
+        se3_Jj_col(L, c, other);
+        if (!swapped || provide) sym6_mul(U, other, vo);
       }
-    }
-    // exchange: column c of W*J lives in lane gbase + c
-    const bool se3 = kind < 2;
-    double O[6] = {0, 0, 0, 0, 0, 0};
-#pragma unroll
-    for (int c = 0; c < 6; ++c) {
-      double d = 0, o2 = 0;
-#pragma unroll
-      for (int q = 0; q < 6; ++q) {
-        const double w = group_bcast(WJs[q], gbase + c);
-        d += self[q] * w;
-        o2 += other[q] * w;          // row r of Jj^T W Ji (swapped orientation)
-      }
-      D[c] += d;
-      O[c] = o2;
-    }
-    if (__any(live && blk >= 0 && !(se3 && (blk & 1)))) {   // somebody needs W*J_other columns
-#pragma unroll
-      for (int c = 0; c < 6; ++c) {
-        double o1 = 0;
-#pragma unroll
-        for (int q = 0; q < 6; ++q) o1 += self[q] * group_bcast(WJo[q], gbase + c);
-        if (!(se3 && (blk & 1))) O[c] = o1;
-      }
-    }
-    if (live) {
       double bb = 0;
 #pragma unroll
       for (int q = 0; q < 6; ++q) bb += self[q] * We[q];
       bacc -= bb;
-      if (blk >= 0) {
-        if (se3) {
-          double* P = V.Hpp_off + (size_t)(blk >> 1) * 36 + r * 6;
+      exch_store6(scr, c, self);
+      double* O = owner ? V.Hpp_off + (size_t)(blk >> 1) * 36 : nullptr;
 #pragma unroll
-          for (int c = 0; c < 6; ++c) P[c] = O[c];
-        } else {
-          double* P = V.Hpl + (size_t)blk * 18 + r * 3;
-          P[0] = O[0]; P[1] = O[1]; P[2] = O[2];
+      for (int a = 0; a < 6; ++a) {   // row a of Js^T = column a of Js
+        double jr[6];
+        exch_load_row(scr, a, jr);
+        double d = 0, o = 0;
+#pragma unroll
+        for (int q = 0; q < 6; ++q) { d += jr[q] * vs[q]; o += jr[q] * vo[q]; }
+        D[a] += d;
+        if (owner && !swapped) O[a * 6 + c] = o;   // stored [row_i][row_j] = Ji^T W Jj: column c = Ji^T (W Jj[:,c])
+      }
+      if (swapped || provide) {       // needs the columns of Jj
+        exch_store6(scr, c, other);
+        double* hd = hand + (((kflags >> 8) & 31) * 6 + c) * 7;
+#pragma unroll
+        for (int a = 0; a < 6; ++a) {
+          double jr[6];
+          exch_load_row(scr, a, jr);
+          double o = 0, dj = 0;
+#pragma unroll
+          for (int q = 0; q < 6; ++q) { o += jr[q] * vs[q]; dj += jr[q] * vo[q]; }
+          if (swapped) O[a * 6 + c] = o;   // stored [row_j][row_i] = Jj^T W Ji: column c = Jj^T (W Ji[:,c])
+          if (provide) hd[a] = dj;         // D_jj[:,c] = Jj^T (W Jj[:,c])
         }
+        if (provide) {
+          double bj = 0;
+#pragma unroll
+          for (int q = 0; q < 6; ++q) bj += other[q] * We[q];
+          hd[6] = -bj;
+        }
+      }
+    } else {
+      const int n = V.nEl;
+      const Pose Xi = load_pose(V.pose, ia);
+      const double* lp = V.lmk + (size_t)ib * 4;
+      const double zz[4] = {V.el_z[0 * (size_t)n + e], V.el_z[1 * (size_t)n + e], V.el_z[2 * (size_t)n + e], PL ? V.el_z[3 * (size_t)n + e] : 0.0};
+      double err[3], self[6] = {0, 0, 0, 0, 0, 0}, jl[3] = {0, 0, 0};
+      if (!PL || V.lm_kind[ib] == VT_POINT) {
+        PointLin L;
+        point_error(Xi, Vec3{lp[0], lp[1], lp[2]}, Vec3{zz[0], zz[1], zz[2]}, L);
+        err[0] = L.e[0]; err[1] = L.e[1]; err[2] = L.e[2];
+        const double px = L.pc.x, py = L.pc.y, pz = L.pc.z;
+        if (c == 0) { self[0] = -1; } else if (c == 1) { self[1] = -1; } else if (c == 2) { self[2] = -1; }
+        else if (c == 3) { self[1] = 2 * pz; self[2] = -2 * py; }
+        else if (c == 4) { self[0] = -2 * pz; self[2] = 2 * px; }
+        else { self[0] = 2 * py; self[1] = -2 * px; }
+        if (c < 3) { jl[0] = pick3(c, L.R.m[0], L.R.m[3], L.R.m[6]); jl[1] = pick3(c, L.R.m[1], L.R.m[4], L.R.m[7]); jl[2] = pick3(c, L.R.m[2], L.R.m[5], L.R.m[8]); }
+      } else {
+        const Plane pw{{lp[0], lp[1], lp[2]}, lp[3]};
+        const Plane z{{zz[0], zz[1], zz[2]}, zz[3]};
+        plane_error(Xi, pw, z, err);
+        const double delta = 1e-9, scalar = 1.0 / (2 * delta);
+        double dv[6], ep[3], em[3];
+#pragma unroll
+        for (int q = 0; q < 6; ++q) dv[q] = q == c ? delta : 0.0;
+        plane_error(se3_oplus(Xi, dv), pw, z, ep);
+#pragma unroll
+        for (int q = 0; q < 6; ++q) dv[q] = q == c ? -delta : 0.0;
+        plane_error(se3_oplus(Xi, dv), pw, z, em);
+        self[0] = scalar * (ep[0] - em[0]); self[1] = scalar * (ep[1] - em[1]); self[2] = scalar * (ep[2] - em[2]);
+        if (c < 3) {
+          double d3[3];
+#pragma unroll
+          for (int q = 0; q < 3; ++q) d3[q] = q == c ? delta : 0.0;
+          plane_error(Xi, pl_oplus(pw, d3), z, ep);
+#pragma unroll
+          for (int q = 0; q < 3; ++q) d3[q] = q == c ? -delta : 0.0;
+          plane_error(Xi, pl_oplus(pw, d3), z, em);
+          jl[0] = scalar * (ep[0] - em[0]); jl[1] = scalar * (ep[1] - em[1]); jl[2] = scalar * (ep[2] - em[2]);
+        }
+      }
+      double W[9];
+      load_sym3(V.el_w, n, e, W);
+      double vs[3], vl[3], We[3];
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        vs[a] = W[a * 3 + 0] * self[0] + W[a * 3 + 1] * self[1] + W[a * 3 + 2] * self[2];   // W Ji[:,c]
+        vl[a] = W[a * 3 + 0] * jl[0] + W[a * 3 + 1] * jl[1] + W[a * 3 + 2] * jl[2];         // W Jl[:,c], c < 3
+        We[a] = W[a * 3 + 0] * err[0] + W[a * 3 + 1] * err[1] + W[a * 3 + 2] * err[2];
+      }
+      exch_store6(scr, c, self);   // rows 3..5 of the padded column are zero
+      bacc -= self[0] * We[0] + self[1] * We[1] + self[2] * We[2];
+      const int blk = V.el_blk[e];
+      double* O = (blk >= 0 && c < 3) ? V.Hpl + (size_t)blk * 18 : nullptr;   // Hpl = Ji^T W Jl (6 x 3): column c
+#pragma unroll
+      for (int a = 0; a < 6; ++a) {
+        double jr[6];
+        exch_load_row(scr, a, jr);
+        D[a] += jr[0] * vs[0] + jr[1] * vs[1] + jr[2] * vs[2];
+        if (O) O[a * 3 + c] = jr[0] * vl[0] + jr[1] * vl[1] + jr[2] * vl[2];
       }
     }
   }
-  if (lane_ok) {
-    double* P = V.Hpp_diag + (size_t)row * 36 + r * 6;
+  __syncthreads();
+  if (receives) {  // contribution of the edge (row-1, row), evaluated once by the row above
+    const double* hd = hand + ((row & 31) * 6 + c) * 7;
 #pragma unroll
-    for (int c = 0; c < 6; ++c) P[c] = D[c];
-    V.bvec[(size_t)row * 6 + r] = bacc;
+    for (int a = 0; a < 6; ++a) D[a] += hd[a];
+    bacc += hd[6];
+  }
+  if (lane_ok) {   // D is symmetric: column c is stored as row c (48 contiguous bytes per lane)
+    double* P = V.Hpp_diag + (size_t)row * 36 + c * 6;
+#pragma unroll
+    for (int a = 0; a < 6; ++a) P[a] = D[a];
+    V.bvec[(size_t)row * 6 + c] = bacc;
   }
 }
 
@@ -1200,12 +1246,25 @@ static int batch_build(Batch& b) {
   std::vector<int> pslot_ptr(nPr + 1, 0), pslot_edge, lslot_ptr(nLr + 1, 0), lslot_edge, tile_row0, tile_row1;
   std::vector<unsigned char> pslot_kind;
   b.max_row_slots = 0;
+  // record.y = kind | (flags << 4) | (local target row << 8):  flag 1 on an i-side slot = also produce the
+  // j-side contribution (D_jj column, b_j) of this edge and hand it to local row (y >> 8) of the same
+  // 32-row workgroup; kind 3 = j-side slot whose contribution arrives that way (not evaluated again)
   std::vector<int4> pslot_rec;
+  std::vector<char> paired_edge(nEo, 0), row_taken(nPr, 0);   // at most one hand-over per receiving row
+  for (int k = 0; k < nEo; ++k) {
+    const int ri = b.pose_row[eo_i[k]], rj = b.pose_row[eo_j[k]];
+    if (ri >= 0 && rj == ri + 1 && (ri >> 5) == (rj >> 5) && prow_graph[ri] == prow_graph[rj] && !row_taken[rj]) { paired_edge[k] = 1; row_taken[rj] = 1; }
+  }
   for (int r = 0; r < nPr; ++r) {
     for (auto& s : pslots[r]) {
       pslot_edge.push_back(s.first); pslot_kind.push_back(s.second);
-      if (s.second < 2) pslot_rec.push_back(make_int4(s.first, s.second, eo_i[s.first], eo_j[s.first]));
-      else pslot_rec.push_back(make_int4(s.first, 2, el_p[s.first], el_l[s.first]));
+      if (s.second < 2) {
+        const int rj = b.pose_row[eo_j[s.first]];
+        const bool paired = paired_edge[s.first] != 0;
+        int kind = s.second;
+        if (paired) kind = s.second == 0 ? (0 | (1 << 4) | ((rj & 31) << 8)) : 3;
+        pslot_rec.push_back(make_int4(s.first, kind, eo_i[s.first], eo_j[s.first]));
+      } else pslot_rec.push_back(make_int4(s.first, 2, el_p[s.first], el_l[s.first]));
     }
     pslot_ptr[r + 1] = (int)pslot_edge.size();
     b.max_row_slots = std::max(b.max_row_slots, (int)pslots[r].size());
