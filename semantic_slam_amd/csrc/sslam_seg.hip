@@ -42,6 +42,8 @@ struct Region {
   float model[4];
   int inliers, first_inlier, label, contour_n;
   float area;
+  int contour_off;   // start of this region's boundary indices in the box's contour arena (-1: not stored)
+  int pad0;
   unsigned long long last_key;  // (pass << 60) | (order key << 24) | pixel index
 };
 
@@ -62,6 +64,8 @@ struct View {
   double* so;    // [nii*6]
   unsigned* ic;  // [nii]
   Region* reg;   // [nbox*kMaxRegions]
+  int* contour;  // [4*npix] boundary pixel indices, one arena of 4*w*h ints per box at 4*pix0
+  int* ccount;   // [nbox] ints used in each arena
   int* nreg;     // [nbox]
   float mdcf, smoothing, ang_thr_cos, dist_thr, max_curv;
   unsigned min_inliers;
@@ -241,25 +245,30 @@ __global__ __launch_bounds__(256) void k_distance_map(View V) {
 // integral images (IntegralImage2D<float,3>::computeIntegralImages, second order on): one wave per
 // box, lane l owns row r0+l, two columns behind lane l-1; the previous row's running values arrive by
 // wave shuffle.  Recurrence and operation order are PCL's:  cur[c+1] = prev[c+1] + cur[c] - prev[c] (+ element).
-__global__ __launch_bounds__(64) void k_integral(View V) {
-  extern __shared__ double prevrow[];  // (w+1) x 10: last row of the previous band (count stored as double)
+__global__ __launch_bounds__(256) void k_integral(View V, int band_rows) {
+  extern __shared__ double prevrow[];  // (w+1) x 10 doubles: last row of the previous band; then the band's points (floats)
   const BoxMeta b = V.box[blockIdx.x];
   const int w = b.w, h = b.h, W1 = w + 1;
   const float* pts = V.pts + (size_t)b.pix0 * 3;
+  float* bpts = reinterpret_cast<float*>(prevrow + (size_t)W1 * 10);
   double* fo = V.fo + (size_t)b.ii0 * 3;
   double* so = V.so + (size_t)b.ii0 * 6;
   unsigned* ic = V.ic + b.ii0;
-  const int l = threadIdx.x;
+  const int tid = threadIdx.x;
+  const int l = tid;   // lanes of wave 0 own rows; the other waves only help staging
   // row 0 of the integral images is zero
-  for (int k = l; k < W1; k += 64) {
+  for (int k = tid; k < W1; k += 256) {
     for (int q = 0; q < 3; ++q) fo[(size_t)k * 3 + q] = 0;
     for (int q = 0; q < 6; ++q) so[(size_t)k * 6 + q] = 0;
     ic[k] = 0;
   }
-  for (int k = l; k < W1 * 10; k += 64) prevrow[k] = 0;
+  for (int k = tid; k < W1 * 10; k += 256) prevrow[k] = 0;
   __syncthreads();
-  for (int r0 = 0; r0 < h; r0 += 64) {
-    const int nr = min(64, h - r0);
+  for (int r0 = 0; r0 < h; r0 += band_rows) {
+    const int nr = min(band_rows, h - r0);
+    for (int k = tid; k < nr * w * 3; k += 256) bpts[k] = pts[(size_t)r0 * w * 3 + k];   // coalesced
+    __syncthreads();
+    if (tid < 64) {
     const int r = r0 + l;
     double cur[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};   // cur[c] of the running column
     unsigned curc = 0;
@@ -290,7 +299,8 @@ __global__ __launch_bounds__(64) void k_integral(View V) {
 #pragma unroll
         for (int q = 0; q < 9; ++q) out[q] = p1[q] + cur[q] - p0[q];
         outc = p1c + curc - p0c;
-        const float ex = pts[((size_t)r * w + c) * 3 + 0], ey = pts[((size_t)r * w + c) * 3 + 1], ez = pts[((size_t)r * w + c) * 3 + 2];
+        const float* ep = bpts + ((size_t)l * w + c) * 3;
+        const float ex = ep[0], ey = ep[1], ez = ep[2];
         if (isfinite(ex + ey + ez)) {
           out[0] += (double)ex; out[1] += (double)ey; out[2] += (double)ez;
           ++outc;
@@ -318,11 +328,12 @@ __global__ __launch_bounds__(64) void k_integral(View V) {
       for (int q = 0; q < 9; ++q) { h2[q] = h1[q]; h1[q] = out[q]; }
       h2c = h1c; h1c = outc;
     }
+    }
     // stage the last row of this band for the next band's lane 0
     __syncthreads();
-    if (r0 + 64 < h) {
-      const size_t rowo = (size_t)(r0 + 64) * W1;
-      for (int k = l; k < W1; k += 64) {
+    if (r0 + band_rows < h) {
+      const size_t rowo = (size_t)(r0 + band_rows) * W1;
+      for (int k = tid; k < W1; k += 256) {
         prevrow[k * 10 + 0] = fo[(rowo + k) * 3 + 0]; prevrow[k * 10 + 1] = fo[(rowo + k) * 3 + 1]; prevrow[k * 10 + 2] = fo[(rowo + k) * 3 + 2];
         for (int q = 0; q < 6; ++q) prevrow[k * 10 + 3 + q] = so[(rowo + k) * 6 + q];
         prevrow[k * 10 + 9] = (double)ic[rowo + k];
@@ -556,13 +567,13 @@ __global__ __launch_bounds__(256) void k_relabel(View V) {
 // OrganizedMultiPlaneSegmentation::refine: two raster sweeps with the PlaneRefinementComparator,
 // executed as skewed wavefronts over a label band staged in LDS (image row stride preserved, so the
 // second sweep's colIdx-1 read at column 0 lands on the previous row's last pixel as in PCL).
-__device__ __forceinline__ bool refine_compare(const View& V, const BoxMeta& b, const float* models, int cl, int nl, int i1, int i2) {
+// PlaneRefinementComparator::compare; p1 / p2 point at the xyz of the current / neighbour pixel (LDS band)
+__device__ __forceinline__ bool refine_compare(float dist_thr, const float* models, int cl, int nl, const float* p1, const float* p2) {
   if (!(cl < kMaxRegions && nl >= kMaxRegions)) return false;   // grow[current] && !grow[next]
   const float* m = models + cl * 4;
-  const float* p = V.pts + ((size_t)b.pix0 + i2) * 3;
-  const double d = fabs((double)(m[0] * p[0] + m[1] * p[1] + m[2] * p[2] + m[3]));
-  const float z = V.pts[((size_t)b.pix0 + i1) * 3 + 2];
-  const float t = V.dist_thr * (z * z);
+  const double d = fabs((double)(m[0] * p2[0] + m[1] * p2[1] + m[2] * p2[2] + m[3]));
+  const float z = p1[2];
+  const float t = dist_thr * (z * z);
   return d < (double)t;
 }
 __device__ __forceinline__ void refine_record(const View& V, int slot, int model_idx, unsigned long long pass, unsigned long long key, int target) {
@@ -580,12 +591,16 @@ __global__ __launch_bounds__(256) void k_refine(View V) {
   for (int k = threadIdx.x; k < nregs * 4; k += 256) models[k] = V.reg[(size_t)slot * kMaxRegions + (k >> 2)].model[k & 3];
   const int w = b.w, h = b.h;
   int* L = V.code + b.pix0;
-  const int BH = min(64, kBandFloats / w - 1);
+  const float* gp = V.pts + (size_t)b.pix0 * 3;
+  const int BH = min(64, kBandFloats / (4 * w) - 1);     // labels (1 word) + xyz (3 words) per staged pixel
+  float* pband = reinterpret_cast<float*>(lband + (BH + 1) * w);
+  const float dthr = V.dist_thr;
   __syncthreads();
   // ---- sweep 1: top-down, left-right; checks right then lower neighbour
   for (int r0 = 0; r0 < h - 1; r0 += BH) {
     const int nr = min(BH, h - 1 - r0);
     for (int k = threadIdx.x; k < (nr + 1) * w; k += 256) lband[k] = L[(size_t)r0 * w + k];
+    for (int k = threadIdx.x; k < (nr + 1) * w * 3; k += 256) pband[k] = gp[(size_t)r0 * w * 3 + k];
     __syncthreads();
     if (threadIdx.x < 64) {
       const int l = threadIdx.x;
@@ -594,15 +609,16 @@ __global__ __launch_bounds__(256) void k_refine(View V) {
         const int c = t - 2 * l;
         if (l < nr && c >= 0 && c < w - 1) {
           int* cur = lband + l * w;
+          const float* pc = pband + ((size_t)l * w + c) * 3;
           const int r = r0 + l;
-          const int cl = cur[c], rl = cur[c + 1];
+          // independent LDS reads first (the right-neighbour write below never touches cur[w + c])
+          const int cl = cur[c], rl = cur[c + 1], ll = cur[w + c];
           if (cl >= 0 && rl >= 0) {
-            if (refine_compare(V, b, models, cl, rl, r * w + c, r * w + c + 1)) {
+            if (refine_compare(dthr, models, cl, rl, pc, pc + 3)) {
               cur[c + 1] = cl;
               refine_record(V, slot, cl, 1ull, (unsigned long long)(r * w + c) * 2ull, r * w + c + 1);
             }
-            const int ll = cur[w + c];
-            if (ll >= 0 && refine_compare(V, b, models, cl, ll, r * w + c, (r + 1) * w + c)) {
+            if (ll >= 0 && refine_compare(dthr, models, cl, ll, pc, pc + 3 * w)) {
               cur[w + c] = cl;
               refine_record(V, slot, cl, 1ull, (unsigned long long)(r * w + c) * 2ull + 1ull, (r + 1) * w + c);
             }
@@ -619,6 +635,7 @@ __global__ __launch_bounds__(256) void k_refine(View V) {
     const int nr = min(BH, rhi);
     const int rlo = rhi - nr;  // staged rows rlo .. rhi (rlo is the upper halo of the topmost processed row)
     for (int k = threadIdx.x; k < (nr + 1) * w; k += 256) lband[k] = L[(size_t)rlo * w + k];
+    for (int k = threadIdx.x; k < (nr + 1) * w * 3; k += 256) pband[k] = gp[(size_t)rlo * w * 3 + k];
     __syncthreads();
     if (threadIdx.x < 64) {
       const int l = threadIdx.x;  // lane l owns row rhi - l
@@ -628,17 +645,18 @@ __global__ __launch_bounds__(256) void k_refine(View V) {
         if (l < nr && c >= 0 && c <= w - 1) {
           const int r = rhi - l;
           int* cur = lband + (r - rlo) * w;
+          const float* pc = pband + ((size_t)(r - rlo) * w + c) * 3;
           // column 0 has no left neighbour here (PCL reads the previous row's last pixel)
           const int cl = cur[c];
           const int lf = c >= 1 ? cur[c - 1] : 0;
+          const int ul = cur[c - w];
           if (cl >= 0 && lf >= 0) {
             const unsigned long long key = (unsigned long long)((h - 1 - r) * w + (w - 1 - c)) * 2ull;
-            if (c >= 1 && refine_compare(V, b, models, cl, lf, r * w + c, r * w + c - 1)) {
+            if (c >= 1 && refine_compare(dthr, models, cl, lf, pc, pc - 3)) {
               cur[c - 1] = cl;
               refine_record(V, slot, cl, 2ull, key, r * w + c - 1);
             }
-            const int ul = cur[c - w];
-            if (ul >= 0 && refine_compare(V, b, models, cl, ul, r * w + c, (r - 1) * w + c)) {
+            if (ul >= 0 && refine_compare(dthr, models, cl, ul, pc, pc - 3 * w)) {
               cur[c - w] = cl;
               refine_record(V, slot, cl, 2ull, key + 1ull, (r - 1) * w + c);
             }
@@ -657,61 +675,110 @@ __global__ __launch_bounds__(256) void k_refine(View V) {
 // staged in LDS as bytes when it fits (<= 150k pixels), so the trace does not pay HBM/L2 latency.
 template <bool STAGED>
 __global__ __launch_bounds__(256) void k_contour(View V) {
-  extern __shared__ unsigned char cimg[];
+  extern __shared__ unsigned char cimg[];   // (w+2) x (h+2) code image with a border of "invalid" (no bounds tests)
   const int bx = blockIdx.x;
   const BoxMeta b = V.box[bx];
-  const int w = b.w, h = b.h;
+  const int w = b.w, h = b.h, W2 = w + 2;
   const int* L = V.code + b.pix0;
   const int nregs = V.nreg[bx];
   if (nregs == 0) return;
   if (STAGED) {
-    for (int i = threadIdx.x; i < w * h; i += 256) { const int c = L[i]; cimg[i] = c < 0 ? 255 : (c >= kMaxRegions ? 254 : (unsigned char)c); }
+    for (int i = threadIdx.x; i < W2 * (h + 2); i += 256) cimg[i] = 255;
+    __syncthreads();
+    for (int i = threadIdx.x; i < w * h; i += 256) {
+      const int c = L[i];
+      const int y = i / w, x = i - y * w;
+      cimg[(y + 1) * W2 + x + 1] = c < 0 ? 255 : (c >= kMaxRegions ? 254 : (unsigned char)c);
+    }
     __syncthreads();
   }
   const int k = threadIdx.x;
   if (k >= nregs) return;
-  const float* pts = V.pts + (size_t)b.pix0 * 3;
   Region* R = &V.reg[(size_t)bx * kMaxRegions + k];
   const int start = (int)(R->last_key & 0xffffffull);
-#define code_at(idx) (STAGED ? (int)cimg[(idx)] : (L[(idx)] < 0 ? 255 : (L[(idx)] >= kMaxRegions ? 254 : L[(idx)])))
-  const int label = code_at(start);
-  const int dxs[8] = {-1, -1, 0, 1, 1, 1, 0, -1}, dys[8] = {0, -1, -1, -1, 0, 1, 1, 1};
-  int dirn = -1, cx = start % w, cy = start / w, ci = start;
+  // code of pixel (x, y); out-of-image neighbours read as 255 ("not this label"), which is what PCL's
+  // bounds tests amount to in the trace loop; the *seed* test below keeps PCL's explicit bounds test
+#define CODE_XY(x, y) (STAGED ? (int)cimg[((y) + 1) * W2 + (x) + 1] \
+                              : (((x) < 0 || (x) >= w || (y) < 0 || (y) >= h) ? 255 : (L[(y) * w + (x)] < 0 ? 255 : (L[(y) * w + (x)] >= kMaxRegions ? 254 : L[(y) * w + (x)]))))
+  int cx = start % w, cy = start / w, ci = start;
+  const int label = CODE_XY(cx, cy);
+  int dirn = -1;
+#pragma unroll
   for (int d = 0; d < 8; ++d) {
-    const int x = cx + dxs[d], y = cy + dys[d], idx = ci + dys[d] * w + dxs[d];
-    if (x >= 0 && x < w && y >= 0 && y < h && code_at(idx) != label) { dirn = d; break; }
+    const int ddx = d == 0 || d == 1 || d == 7 ? -1 : (d == 2 || d == 6 ? 0 : 1);
+    const int ddy = d == 1 || d == 2 || d == 3 ? -1 : (d == 0 || d == 4 ? 0 : 1);
+    const int x = cx + ddx, y = cy + ddy;
+    if (dirn < 0 && x >= 0 && x < w && y >= 0 && y < h && CODE_XY(x, y) != label) dirn = d;
   }
-  int count = 0;
-  float res[3] = {0, 0, 0};
+  int count = 0, off = -1;
   if (dirn != -1) {
+    // each region owns an equal slice of the box's arena (4*w*h ints); boundaries are far shorter
+    const int slice = (4 * w * h) / nregs;
+    int* out = V.contour + (size_t)b.pix0 * 4 + (size_t)k * slice;
+    off = k * slice;
+    out[0] = start;
     count = 1;
     const long guard = 4L * (long)w * h + 8;
     long steps = 0;
-    int prev = start;
     do {
-      int nI = 0;
-      for (int d = 1; d <= 8; ++d) {
-        nI = (dirn + d) & 7;
-        const int x = cx + dxs[nI], y = cy + dys[nI], idx = ci + dys[nI] * w + dxs[nI];
-        if (x >= 0 && x < w && y >= 0 && y < h && code_at(idx) == label) break;
+      // 8 independent neighbour reads (no dependent LDS chain), then the first match in scan order dirn+1 .. dirn+8
+      unsigned match = 0;
+#pragma unroll
+      for (int d = 0; d < 8; ++d) {
+        const int ddx = d == 0 || d == 1 || d == 7 ? -1 : (d == 2 || d == 6 ? 0 : 1);
+        const int ddy = d == 1 || d == 2 || d == 3 ? -1 : (d == 0 || d == 4 ? 0 : 1);
+        match |= (CODE_XY(cx + ddx, cy + ddy) == label ? 1u : 0u) << d;
       }
+      // rotate so that bit 0 is direction dirn+1; no match at all -> PCL's loop ends on (dirn+8)&7 = dirn
+      const unsigned rot = ((match | (match << 8)) >> ((dirn + 1) & 7)) & 0xffu;
+      const int nI = rot ? ((dirn + 1 + (__ffs(rot) - 1)) & 7) : dirn;
+      const int mdx = nI == 0 || nI == 1 || nI == 7 ? -1 : (nI == 2 || nI == 6 ? 0 : 1);
+      const int mdy = nI == 1 || nI == 2 || nI == 3 ? -1 : (nI == 0 || nI == 4 ? 0 : 1);
       dirn = (nI + 4) & 7;
-      ci += dys[nI] * w + dxs[nI]; cx += dxs[nI]; cy += dys[nI];
-      // polygon edge prev -> ci   (calculatePolygonArea: res += va x vb over consecutive contour points)
-      float c3[3];
-      cross3(pts + (size_t)prev * 3, pts + (size_t)ci * 3, c3);
-      res[0] += c3[0]; res[1] += c3[1]; res[2] += c3[2];
-      prev = ci;
+      ci += mdy * w + mdx; cx += mdx; cy += mdy;
+      if (count < slice) out[count] = ci;
       ++count;
     } while (ci != start && ++steps < guard);
-    // closing edge: last contour point -> first (the trace ends on `start`, which PCL stores twice)
-    float c3[3];
-    cross3(pts + (size_t)prev * 3, pts + (size_t)start * 3, c3);
-    res[0] += c3[0]; res[1] += c3[1]; res[2] += c3[2];
+    if (count > slice) off = -1;   // pathological boundary longer than its slice: area stays 0, region is dropped
   }
   R->contour_n = count;
-  R->area = sqrtf(res[0] * res[0] + res[1] * res[1] + res[2] * res[2]) * 0.5f;
-#undef code_at
+  R->contour_off = off;
+  R->area = 0;
+#undef CODE_XY
+}
+
+// pcl::calculatePolygonArea over the stored boundary: res += p[i] x p[(i+1) % n] in contour order (float).
+// One wave per region: 64 cross products are formed in parallel (coalesced index loads, gathered
+// points) and parked in LDS; lanes 0..2 then run the three serial float chains of the chunk.
+__global__ __launch_bounds__(64) void k_area(View V) {
+  __shared__ float prod[3][64];
+  const int bx = blockIdx.x, k = blockIdx.y;
+  if (k >= V.nreg[bx]) return;
+  const BoxMeta b = V.box[bx];
+  Region* R = &V.reg[(size_t)bx * kMaxRegions + k];
+  const int n = R->contour_n, off = R->contour_off;
+  if (n <= 0 || off < 0) return;
+  const int* idx = V.contour + (size_t)b.pix0 * 4 + off;
+  const float* pts = V.pts + (size_t)b.pix0 * 3;
+  const int lane = threadIdx.x;
+  float acc = 0;
+  for (int i0 = 0; i0 < n; i0 += 64) {
+    const int i = i0 + lane;
+    if (i < n) {
+      const int a = idx[i], c = idx[(i + 1) % n];
+      float c3[3];
+      cross3(pts + (size_t)a * 3, pts + (size_t)c * 3, c3);
+      prod[0][lane] = c3[0]; prod[1][lane] = c3[1]; prod[2][lane] = c3[2];
+    }
+    __syncthreads();
+    if (lane < 3) {
+      const int m = min(64, n - i0);
+      for (int q = 0; q < m; ++q) acc += prod[lane][q];
+    }
+    __syncthreads();
+  }
+  const float rx = __shfl(acc, 0, 64), ry = __shfl(acc, 1, 64), rz = __shfl(acc, 2, 64);
+  if (lane == 0) R->area = sqrtf(rx * rx + ry * ry + rz * rz) * 0.5f;
 }
 
 // final label image for the parity hook: region index or -1
@@ -837,7 +904,7 @@ int sslam_seg_segment(sslam_seg* s, const uint8_t* cloud, int width, int height,
     if (b.tl_x + b.width > width || b.tl_y + b.height > height) continue;
     const size_t n = (size_t)b.width * b.height;
     if (n == 0 || (double)n < P.norm_point_thres) continue;
-    if (b.width > kBandFloats / 2 - 1) return set_error(SSLAM_ERR_UNSUPPORTED, "box wider than %d px", kBandFloats / 2 - 1);
+    if (b.width > kBandFloats / 8 - 1) return set_error(SSLAM_ERR_UNSUPPORTED, "box wider than %d px", kBandFloats / 8 - 1);
     BoxMeta m{b.width, b.height, b.tl_x, b.tl_y, (int)npix, (int)nii, (int)s->boxes.size(), 0};
     s->boxes.push_back(m); s->box_src.push_back(i);
     npix += n; nii += (size_t)(b.width + 1) * (b.height + 1);
@@ -866,6 +933,8 @@ int sslam_seg_segment(sslam_seg* s, const uint8_t* cloud, int width, int height,
     if ((rc = seg_alloc(s, s->cap_ii, &V.ic))) return rc;
     if ((rc = seg_alloc(s, s->cap_box * kMaxRegions, &V.reg))) return rc;
     if ((rc = seg_alloc(s, s->cap_box, &V.nreg))) return rc;
+    if ((rc = seg_alloc(s, s->cap_pix * 4, &V.contour))) return rc;
+    if ((rc = seg_alloc(s, s->cap_box, &V.ccount))) return rc;
   }
   V.nbox = nb; V.npix_total = (int)npix; V.maxpix = maxpix;
   V.box = s->d_box; V.cloud = s->d_cloud;
@@ -885,21 +954,33 @@ int sslam_seg_segment(sslam_seg* s, const uint8_t* cloud, int width, int height,
     const dim3 pg((maxpix + 255) / 256, nb), pb(256);
     int maxw = 1;
     for (auto& b : s->boxes) maxw = std::max(maxw, b.w);
-    const int BH = std::min(64, kBandFloats / maxw - 1);
-    const size_t band_bytes = (size_t)(BH + 1) * maxw * sizeof(float);
-    if (band_bytes > 64 * 1024) {
-      SSLAM_HIP_TRY(hipFuncSetAttribute((const void*)k_distance_map, hipFuncAttributeMaxDynamicSharedMemorySize, (int)band_bytes));
-      SSLAM_HIP_TRY(hipFuncSetAttribute((const void*)k_refine, hipFuncAttributeMaxDynamicSharedMemorySize, (int)band_bytes));
+    // dynamic LDS: the largest per-box band (the kernels size their bands from the box's own width)
+    size_t band_bytes = 0, rband_bytes = 0;
+    for (auto& b : s->boxes) {
+      const int bh = std::min(64, kBandFloats / b.w - 1);
+      band_bytes = std::max(band_bytes, (size_t)(bh + 1) * b.w * sizeof(float));
+      const int bhr = std::min(64, kBandFloats / (4 * b.w) - 1);
+      rband_bytes = std::max(rband_bytes, (size_t)(bhr + 1) * b.w * 4 * sizeof(float));
     }
+    if (band_bytes > 64 * 1024) SSLAM_HIP_TRY(hipFuncSetAttribute((const void*)k_distance_map, hipFuncAttributeMaxDynamicSharedMemorySize, (int)band_bytes));
+    if (rband_bytes > 64 * 1024) SSLAM_HIP_TRY(hipFuncSetAttribute((const void*)k_refine, hipFuncAttributeMaxDynamicSharedMemorySize, (int)rband_bytes));
     const bool dbg = getenv("SSLAM_SEG_DEBUG") != nullptr;
 #define DBG(name) do { if (dbg) { hipError_t e_ = hipStreamSynchronize(s->stream); fprintf(stderr, "[seg] %s: %s\n", name, hipGetErrorString(e_)); } } while (0)
+    SSLAM_HIP_TRY(hipMemsetAsync(V.ccount, 0, nb * sizeof(int), s->stream));
     hipLaunchKernelGGL(k_crop, pg, pb, 0, s->stream, V);
     DBG("k_crop");
     hipLaunchKernelGGL(k_depth_change, pg, pb, 0, s->stream, V);
     DBG("k_depth_change");
     hipLaunchKernelGGL(k_distance_map, dim3(nb), dim3(256), band_bytes, s->stream, V);
     DBG("k_distance_map");
-    hipLaunchKernelGGL(k_integral, dim3(nb), dim3(64), (size_t)(maxw + 1) * 10 * sizeof(double), s->stream, V);
+    {
+      // band rows: as many as fit next to the (w+1) x 10 double carry row in ~150 KiB of LDS (<= 64 lanes)
+      const size_t carry = (size_t)(maxw + 1) * 10 * sizeof(double);
+      const int ib_rows = (int)std::max<size_t>(1, std::min<size_t>(64, (150 * 1024 - carry) / ((size_t)maxw * 12)));
+      const size_t ilds = carry + (size_t)ib_rows * maxw * 12;
+      if (ilds > 64 * 1024) SSLAM_HIP_TRY(hipFuncSetAttribute((const void*)k_integral, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ilds));
+      hipLaunchKernelGGL(k_integral, dim3(nb), dim3(256), ilds, s->stream, V, ib_rows);
+    }
     DBG("k_integral");
     hipLaunchKernelGGL(k_normals, pg, pb, 0, s->stream, V);
     DBG("k_normals");
@@ -915,7 +996,7 @@ int sslam_seg_segment(sslam_seg* s, const uint8_t* cloud, int width, int height,
     DBG("k_regions");
     hipLaunchKernelGGL(k_relabel, pg, pb, 0, s->stream, V);
     DBG("k_relabel");
-    hipLaunchKernelGGL(k_refine, dim3(nb), dim3(256), band_bytes, s->stream, V);
+    hipLaunchKernelGGL(k_refine, dim3(nb), dim3(256), rband_bytes, s->stream, V);
     DBG("k_refine");
     if (dbg) {
       std::vector<Region> rr((size_t)nb * kMaxRegions); std::vector<int> nn(nb);
@@ -926,14 +1007,18 @@ int sslam_seg_segment(sslam_seg* s, const uint8_t* cloud, int width, int height,
         fprintf(stderr, "[seg] box %d reg %d: inl %d first %d label %d key %llx\n", bi, k, R.inliers, R.first_inlier, R.label, R.last_key);
       }
     }
-    if (maxpix <= 150 * 1024 && !getenv("SSLAM_SEG_NOSTAGE")) {
-      if (maxpix > 64 * 1024) SSLAM_HIP_TRY(hipFuncSetAttribute((const void*)k_contour<true>, hipFuncAttributeMaxDynamicSharedMemorySize, maxpix));
-      hipLaunchKernelGGL(k_contour<true>, dim3(nb), dim3(256), (size_t)maxpix, s->stream, V);
+    size_t cimg_bytes = 0;
+    for (auto& b : s->boxes) cimg_bytes = std::max(cimg_bytes, (size_t)(b.w + 2) * (b.h + 2));
+    if (cimg_bytes <= 150 * 1024 && !getenv("SSLAM_SEG_NOSTAGE")) {
+      if (cimg_bytes > 64 * 1024) SSLAM_HIP_TRY(hipFuncSetAttribute((const void*)k_contour<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cimg_bytes));
+      hipLaunchKernelGGL(k_contour<true>, dim3(nb), dim3(256), cimg_bytes, s->stream, V);
     DBG("k_contour");
     } else {
       hipLaunchKernelGGL(k_contour<false>, dim3(nb), dim3(256), 0, s->stream, V);
     DBG("k_contour");
     }
+    hipLaunchKernelGGL(k_area, dim3(nb, kMaxRegions), dim3(64), 0, s->stream, V);
+    DBG("k_area");
     SSLAM_HIP_TRY(hipEventRecord(e1, s->stream));
     regs.resize((size_t)nb * kMaxRegions);
     SSLAM_HIP_TRY(hipMemcpyAsync(regs.data(), V.reg, regs.size() * sizeof(Region), hipMemcpyDeviceToHost, s->stream));
@@ -944,6 +1029,7 @@ int sslam_seg_segment(sslam_seg* s, const uint8_t* cloud, int width, int height,
     SSLAM_HIP_TRY(hipEventElapsedTime(&kernel_ms, e0, e1));
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
   }
+  if (getenv("SSLAM_SEG_DEBUG")) for (int bi = 0; bi < nb; ++bi) for (int k = 0; k < nreg[bi]; ++k) { const Region& R = regs[(size_t)bi * kMaxRegions + k]; fprintf(stderr, "[seg] post box %d reg %d: inl %d contour %d off %d area %g\n", bi, k, R.inliers, R.contour_n, R.contour_off, R.area); }
   // ---- plane_segmentation.cpp:158-256 + point_cloud_segmentation.h:43-99 (scalar post-processing)
   float T[16];
   sslam_seg_transform(s, robot_pose, cam_angle, T);
