@@ -118,7 +118,26 @@ def main():
     roof_jac = {"bound": "hbm", "kernel": "jacobian_build", "achieved": round(jac_gbs, 2), "peak": 8000.0, "unit": "GB/s",
                 "frac": round(jac_gbs / 8000.0, 4), "traffic": None, "bytes_per_launch": jac_bytes,
                 "ms_per_launch": round(jac_ms, 5), "launches": lin_n}
+    # measured HBM traffic of the Jacobian build (PMC FETCH_SIZE / WRITE_SIZE, collected with rocprofv3 in separate
+    # passes, FETCH x2 per MI355X_MICROARCH.md; committed under profiles/).  Only valid for the profiled batch size.
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r1_pmc_jacobian_build.json")))
+        if pmc.get("algorithmic_bytes") == jac_bytes:
+            roof_jac["traffic"] = int(pmc["hbm_bytes_fetch_x2"])
+            roof_jac["traffic_raw_counters"] = int(pmc["hbm_bytes_raw"])
+    except (OSError, ValueError):
+        pass
     roofline = roof_jac
+    if dominant == "factor" and ktimes["factor"][1] > 0:
+        fbytes = batch.info("factor_bytes")
+        ms = ktimes["factor"][0] / ktimes["factor"][1]
+        gbs = fbytes / (ms * 1e-3) / 1e9
+        roofline = {"bound": "hbm", "kernel": "block_cholesky_factor (level-scheduled k_chol_level launches of one numeric factorisation)",
+                    "achieved": round(gbs, 2), "peak": 8000.0, "unit": "GB/s", "frac": round(gbs / 8000.0, 4), "traffic": None,
+                    "bytes_per_launch": int(fbytes), "ms_per_launch": round(ms, 4), "launches": ktimes["factor"][1],
+                    "levels": int(batch.info("factor_levels")), "factor_doubles": int(batch.info("factor_lnz")),
+                    "note": "one 'launch' = the dependent chain of per-level kernels of one factorisation; latency / L2-issue bound, "
+                            "algorithmic bytes = read H,b + write L,y once"}
     if dominant == "spmv" and ktimes["spmv"][1] > 0:
         # H bytes + 3 vectors x 8*dim per block-SpMV
         Np, Nl = args.poses - 1, args.landmarks

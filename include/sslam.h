@@ -139,6 +139,10 @@ int sslam_batch_optimize(sslam_batch* b, int max_iters, sslam_opt_stats* out /* 
 int sslam_batch_time_linearize(sslam_batch* b, int repeats, double* ms_per_build);
 /* algorithmic bytes of one Jacobian build over the whole batch (SURVEY §8d formula) */
 int64_t sslam_batch_linearize_bytes(const sslam_batch* b);
+/* structural facts of a batch (doubles): "factor_lnz" (doubles in the Cholesky factor), "factor_levels",
+ * "h_doubles" (doubles in H), "dim" (scalar unknowns), "factor_bytes" = algorithmic HBM bytes of one numeric
+ * factorisation + fused forward solve: read H and b once, write L and y once */
+int sslam_batch_info(sslam_batch* b, const char* key, double* value);
 /* per-kernel accumulated hipEvent time since the last reset (profiling must be enabled with
  * sslam_batch_set_profiling); names: "linearize","chi2","spmv","pcg_update","precond","oplus","factor","solve" */
 int sslam_batch_set_profiling(sslam_batch* b, int enable);

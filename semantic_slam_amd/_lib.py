@@ -80,6 +80,7 @@ def load_library():
         "sslam_batch_optimize": (ci, [vp, ci, C.POINTER(OptStats)]),
         "sslam_batch_time_linearize": (ci, [vp, ci, dp]),
         "sslam_batch_linearize_bytes": (i64, [vp]),
+        "sslam_batch_info": (ci, [vp, C.c_char_p, dp]),
         "sslam_batch_set_profiling": (ci, [vp, ci]),
         "sslam_batch_kernel_time": (ci, [vp, C.c_char_p, dp, C.POINTER(i64)]),
     }

@@ -113,6 +113,8 @@ inline int dev_alloc(Batch& b, size_t n, T** out, bool zero = true) {
 int chol_plan_build(Batch& b);
 int chol_factor_and_forward(Batch& b);   // (H + lambda I) = L L^T for in_trial graphs, y = L^-1 b
 int chol_backward(Batch& b);             // x = L^-T y  -> V.x
+int64_t chol_plan_lnz(const Batch& b);
+int chol_plan_levels(const Batch& b);
 int chol_solve_multi(Batch& b, const double* rhs_host, int nrhs, double* x_host);  // uses the last factorisation
 
 }  // namespace sslam

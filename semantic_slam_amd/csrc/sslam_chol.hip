@@ -532,6 +532,9 @@ int chol_plan_build(Batch& b) {
   return 0;
 }
 
+int64_t chol_plan_lnz(const Batch& b) { return b.chol ? b.chol->lnz : 0; }
+int chol_plan_levels(const Batch& b) { return b.chol ? b.chol->C.nlevels : 0; }
+
 int chol_factor_and_forward(Batch& b) {
   CholPlan& P = *b.chol;
   const CholView& C = P.C;

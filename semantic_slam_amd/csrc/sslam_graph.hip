@@ -583,6 +583,150 @@ __global__ __launch_bounds__(256, 2) void k_linearize_rows2(BatchView V) {
   }
 }
 
+// ---- Jacobian build, variant D: one THREAD per pose row ------------------------------------------
+// No redundancy across lanes: a thread evaluates each incident edge once, keeps the 6x6 Jacobian of
+// its own vertex in registers, streams the other vertex's columns for the off-diagonal block it
+// owns, and accumulates the symmetric diagonal block (21 values) + b (6) in a thread-private LDS
+// column (lane-contiguous layout -> conflict free), written to HBM once at the end.  All block stores
+// are 16-byte (two doubles): half the write requests of scalar stores at a 288-byte lane stride.
+constexpr int kRowThreads = 64;
+__device__ __forceinline__ int tri21(int a, int c) { return a * 6 - (a * (a - 1)) / 2 + (c - a); }   // a <= c
+__device__ __forceinline__ void store2(double* p, double a, double b) { *reinterpret_cast<D2*>(p) = D2{a, b}; }
+
+template <bool PL>
+__global__ __launch_bounds__(kRowThreads) void k_linearize_rowthread(BatchView V) {
+  __shared__ double accD[27][kRowThreads];
+  const int tid = threadIdx.x;
+  const int row = blockIdx.x * kRowThreads + tid;
+  if (row >= V.nPr) return;
+  if (!V.lm[V.prow_graph[row]].active) return;
+#pragma unroll
+  for (int k = 0; k < 27; ++k) accD[k][tid] = 0.0;
+  const int s0 = V.pslot_ptr[row], s1 = V.pslot_ptr[row + 1];
+  for (int s = s0; s < s1; ++s) {
+    const int4 rec = V.pslot_rec[s];
+    const int e = rec.x, kind = rec.y & 15, ia = rec.z, ib = rec.w;   // kind 3 (hand-over) is evaluated like kind 1 here
+    if (kind != 2) {
+      const int n = V.nEo;
+      const bool iside = (kind == 0);
+      Se3Lin L;
+      se3_error(load_pose(V.pose, ia), load_pose(V.pose, ib), load_meas_pose(V.eo_z, n, e), L);
+      L.Re = qmat(L.qe);
+      double Js[36];   // Js[c*6 + q] = J_self[q][c]
+#pragma unroll
+      for (int c = 0; c < 6; ++c) {
+        double col[6];
+        if (iside) se3_Ji_col(L, c, col); else se3_Jj_col(L, c, col);
+#pragma unroll
+        for (int q = 0; q < 6; ++q) Js[c * 6 + q] = col[q];
+      }
+      double U[21];
+#pragma unroll
+      for (int k = 0; k < 21; ++k) U[k] = V.eo_w[(size_t)k * n + e];
+      const int blk = iside ? V.eo_blk[e] : -1;
+      if (blk >= 0) {   // owner: stream the columns of the other vertex's Jacobian, two at a time
+        double* O = V.Hpp_off + (size_t)(blk >> 1) * 36;
+        const bool swapped = blk & 1;
+#pragma unroll
+        for (int c = 0; c < 6; c += 2) {
+          double cj0[6], cj1[6], v0[6], v1[6];
+          se3_Jj_col(L, c, cj0); se3_Jj_col(L, c + 1, cj1);
+          sym6_mul(U, cj0, v0); sym6_mul(U, cj1, v1);
+          double d0[6], d1[6];   // (Ji^T W Jj)[a][c], [a][c+1]
+#pragma unroll
+          for (int a = 0; a < 6; ++a) {
+            double x = 0, y = 0;
+#pragma unroll
+            for (int q = 0; q < 6; ++q) { x += Js[a * 6 + q] * v0[q]; y += Js[a * 6 + q] * v1[q]; }
+            d0[a] = x; d1[a] = y;
+          }
+          if (!swapped) {       // stored [row_i][row_j]: entries (a, c), (a, c+1) are adjacent
+#pragma unroll
+            for (int a = 0; a < 6; ++a) store2(O + a * 6 + c, d0[a], d1[a]);
+          } else {              // stored transposed: rows c and c+1, pairs of adjacent a
+#pragma unroll
+            for (int a = 0; a < 6; a += 2) { store2(O + c * 6 + a, d0[a], d0[a + 1]); store2(O + (c + 1) * 6 + a, d1[a], d1[a + 1]); }
+          }
+        }
+      }
+      double We[6];
+      sym6_mul(U, L.e, We);
+#pragma unroll
+      for (int c = 0; c < 6; ++c) {
+        double vs[6];
+        sym6_mul(U, Js + c * 6, vs);
+#pragma unroll
+        for (int a = 0; a <= c; ++a) {
+          double d = 0;
+#pragma unroll
+          for (int q = 0; q < 6; ++q) d += Js[a * 6 + q] * vs[q];
+          accD[tri21(a, c)][tid] += d;
+        }
+        double bb = 0;
+#pragma unroll
+        for (int q = 0; q < 6; ++q) bb += Js[c * 6 + q] * We[q];
+        accD[21 + c][tid] -= bb;
+      }
+    } else {
+      const int n = V.nEl;
+      const Pose Xi = load_pose(V.pose, ia);
+      const double* lp = V.lmk + (size_t)ib * 4;
+      double err[3], Ji[18], Jl[9];   // Ji row-major 3x6, Jl row-major 3x3
+      if (!PL || V.lm_kind[ib] == VT_POINT) {
+        PointLin L;
+        point_error(Xi, Vec3{lp[0], lp[1], lp[2]}, Vec3{V.el_z[0 * (size_t)n + e], V.el_z[1 * (size_t)n + e], V.el_z[2 * (size_t)n + e]}, L);
+        point_jacobians(L, Ji, Jl);
+        err[0] = L.e[0]; err[1] = L.e[1]; err[2] = L.e[2];
+      } else {
+        const Plane pw{{lp[0], lp[1], lp[2]}, lp[3]};
+        const Plane z{{V.el_z[0 * (size_t)n + e], V.el_z[1 * (size_t)n + e], V.el_z[2 * (size_t)n + e]}, V.el_z[3 * (size_t)n + e]};
+        plane_error(Xi, pw, z, err);
+        plane_jacobians(Xi, pw, z, Ji, Jl);
+      }
+      double W[9];
+      load_sym3(V.el_w, n, e, W);
+      double WJi[18], We[3];
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        We[a] = W[a * 3 + 0] * err[0] + W[a * 3 + 1] * err[1] + W[a * 3 + 2] * err[2];
+#pragma unroll
+        for (int c = 0; c < 6; ++c) WJi[a * 6 + c] = W[a * 3 + 0] * Ji[c] + W[a * 3 + 1] * Ji[6 + c] + W[a * 3 + 2] * Ji[12 + c];
+      }
+#pragma unroll
+      for (int c = 0; c < 6; ++c) {
+#pragma unroll
+        for (int a = 0; a <= c; ++a) accD[tri21(a, c)][tid] += Ji[a] * WJi[c] + Ji[6 + a] * WJi[6 + c] + Ji[12 + a] * WJi[12 + c];
+        accD[21 + c][tid] -= Ji[c] * We[0] + Ji[6 + c] * We[1] + Ji[12 + c] * We[2];
+      }
+      const int blk = V.el_blk[e];
+      if (blk >= 0) {
+        double WJl[9];
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+          for (int c = 0; c < 3; ++c) WJl[a * 3 + c] = W[a * 3 + 0] * Jl[c] + W[a * 3 + 1] * Jl[3 + c] + W[a * 3 + 2] * Jl[6 + c];
+        double o[18];
+#pragma unroll
+        for (int a = 0; a < 6; ++a)
+#pragma unroll
+          for (int c = 0; c < 3; ++c) o[a * 3 + c] = Ji[a] * WJl[c] + Ji[6 + a] * WJl[3 + c] + Ji[12 + a] * WJl[6 + c];
+        double* O = V.Hpl + (size_t)blk * 18;
+#pragma unroll
+        for (int k = 0; k < 18; k += 2) store2(O + k, o[k], o[k + 1]);
+      }
+    }
+  }
+  double* P = V.Hpp_diag + (size_t)row * 36;
+#pragma unroll
+  for (int a = 0; a < 6; ++a)
+#pragma unroll
+    for (int c = 0; c < 6; c += 2)
+      store2(P + a * 6 + c, accD[a <= c ? tri21(a, c) : tri21(c, a)][tid], accD[a <= c + 1 ? tri21(a, c + 1) : tri21(c + 1, a)][tid]);
+  double* Bv = V.bvec + (size_t)row * 6;
+#pragma unroll
+  for (int c = 0; c < 6; c += 2) store2(Bv + c, accD[21 + c][tid], accD[22 + c][tid]);
+}
+
 // landmark rows: 16 lanes per landmark, each lane walks a strided subset of the incident edges,
 // butterfly reduction in a fixed order.
 template <bool PL>
@@ -1435,8 +1579,21 @@ static int launch_check(const char* what) {
 static int batch_linearize(Batch& b) {
   ScopedTimer t(b, "linearize");
   const BatchView& V = b.V;
-  const int mode = b.graphs[0]->opt.deterministic;   // 1: per-row groups (default), 2: LDS tiles, 0: atomics
-  const bool gather = mode == 1 || (mode == 2 && b.max_row_slots <= kTileSlots);
+  const int mode = b.graphs[0]->opt.deterministic;   // 1: per-row groups, 2: LDS tiles, 3: thread per row, 0: atomics
+  const bool gather = mode == 1 || mode == 3 || (mode == 2 && b.max_row_slots <= kTileSlots);
+  if (mode == 3) {
+    const int nblk = (V.nPr + kRowThreads - 1) / kRowThreads;
+    if (V.nPr > 0) {
+      if (b.has_planes) hipLaunchKernelGGL(k_linearize_rowthread<true>, dim3(nblk), dim3(kRowThreads), 0, b.stream, V);
+      else hipLaunchKernelGGL(k_linearize_rowthread<false>, dim3(nblk), dim3(kRowThreads), 0, b.stream, V);
+    }
+    if (V.nLr > 0) {
+      if (b.has_planes) hipLaunchKernelGGL(k_linearize_lm_rows<true>, dim3((V.nLr + 15) / 16), dim3(256), 0, b.stream, V);
+      else hipLaunchKernelGGL(k_linearize_lm_rows<false>, dim3((V.nLr + 15) / 16), dim3(256), 0, b.stream, V);
+    }
+    if (V.nDupEo + V.nDupEl > 0) hipLaunchKernelGGL(k_linearize_dups, dim3((std::max(V.nDupEo, V.nDupEl) + 63) / 64), dim3(64), 0, b.stream, V);
+    return launch_check("linearize");
+  }
   if (gather && mode == 2) {
     if (b.has_planes) { if (V.nTiles > 0) hipLaunchKernelGGL(k_linearize_rows<true>, dim3(V.nTiles), dim3(256), 0, b.stream, V); }
     else { if (V.nTiles > 0) hipLaunchKernelGGL(k_linearize_rows<false>, dim3(V.nTiles), dim3(256), 0, b.stream, V); }
@@ -2046,6 +2203,21 @@ int64_t sslam_batch_linearize_bytes(const sslam_batch* h) {
   }
   bytes += (int64_t)b.V.nPr * (288 + 48) + (int64_t)b.V.nLr * (72 + 24);
   return bytes;
+}
+int sslam_batch_info(sslam_batch* h, const char* key, double* value) {
+  if (!h || !key || !value) return set_error(SSLAM_ERR_INVALID, "null argument");
+  Batch& b = h->b;
+  const std::string k(key);
+  int rc;
+  if ((k == "factor_lnz" || k == "factor_levels" || k == "factor_bytes") && !b.chol && (rc = chol_plan_build(b))) return rc;
+  const double dim = 6.0 * b.V.nPr + 3.0 * b.V.nLr;
+  if (k == "factor_lnz") *value = (double)chol_plan_lnz(b);
+  else if (k == "factor_levels") *value = (double)chol_plan_levels(b);
+  else if (k == "h_doubles") *value = (double)b.V.h_total;
+  else if (k == "dim") *value = dim;
+  else if (k == "factor_bytes") *value = 8.0 * ((double)b.V.h_total + dim + (double)chol_plan_lnz(b) + dim);
+  else return set_error(SSLAM_ERR_INVALID, "unknown info key '%s'", key);
+  return 0;
 }
 int sslam_batch_set_profiling(sslam_batch* h, int enable) {
   if (!h) return set_error(SSLAM_ERR_INVALID, "null batch");

@@ -249,6 +249,11 @@ class GraphBatch:
     def linearize_bytes(self) -> int:
         return int(self._lib.sslam_batch_linearize_bytes(self._h))
 
+    def info(self, key: str) -> float:
+        v = C.c_double(0)
+        _check(self._lib, self._lib.sslam_batch_info(self._h, key.encode(), C.byref(v)))
+        return v.value
+
     def set_profiling(self, on: bool):
         _check(self._lib, self._lib.sslam_batch_set_profiling(self._h, 1 if on else 0))
 

@@ -18,12 +18,14 @@ def _full(U):
     return (U + sp.triu(U, 1).T).tocsc()
 
 
+@pytest.mark.parametrize("mode", [1, 3])
 @pytest.mark.parametrize("kind,interleave,tol", [("point", False, 1e-11), ("point", True, 1e-11), ("plane", False, 2e-5)])
-def test_linearize_matches_oracle(gpu_lib, kind, interleave, tol):
+def test_linearize_matches_oracle(gpu_lib, kind, interleave, tol, mode):
     from semantic_slam_amd import GraphSLAM
     g = make_graph(60, 12, seed=3, landmark_kind=kind)
     gp = GraphProblem.from_synth(g, interleave=interleave)
     G = GraphSLAM.from_problem(gp)
+    G.set_option("deterministic", mode)
     U, b = G.linearize()
     Uo, bo = gp.linearize()
     assert U.shape == Uo.shape
@@ -35,7 +37,7 @@ def test_linearize_matches_oracle(gpu_lib, kind, interleave, tol):
     assert [G.hessian_index(v) for v in range(gp.nv)] == list(h)
 
 
-@pytest.mark.parametrize("deterministic", [1, 2, 0])
+@pytest.mark.parametrize("deterministic", [1, 2, 3, 0])
 def test_linearize_with_repeated_edges(gpu_lib, deterministic):
     """Two edges on the same vertex pair (a repeated loop closure / a landmark matched twice in one
     keyframe) share one off-diagonal block; gather-form and atomic Jacobian builds must both sum them."""
