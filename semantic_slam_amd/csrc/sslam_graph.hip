@@ -593,6 +593,12 @@ constexpr int kRowThreads = 64;
 __device__ __forceinline__ int tri21(int a, int c) { return a * 6 - (a * (a - 1)) / 2 + (c - a); }   // a <= c
 __device__ __forceinline__ void store2(double* p, double a, double b) { *reinterpret_cast<D2*>(p) = D2{a, b}; }
 
+__device__ __forceinline__ Pose load_pose16(const double* a, int idx) {   // four 16-byte loads of the 64-byte record
+  const D2* p = reinterpret_cast<const D2*>(a + (size_t)idx * 8);
+  const D2 v0 = p[0], v1 = p[1], v2 = p[2], v3 = p[3];
+  return Pose{{v0.a, v0.b, v1.a}, {v1.b, v2.a, v2.b, v3.a}};
+}
+
 template <bool PL>
 __global__ __launch_bounds__(kRowThreads) void k_linearize_rowthread(BatchView V) {
   __shared__ double accD[27][kRowThreads];
@@ -603,6 +609,8 @@ __global__ __launch_bounds__(kRowThreads) void k_linearize_rowthread(BatchView V
 #pragma unroll
   for (int k = 0; k < 27; ++k) accD[k][tid] = 0.0;
   const int s0 = V.pslot_ptr[row], s1 = V.pslot_ptr[row + 1];
+  const int own = V.prow_pose[row];
+  const Pose Xown = load_pose16(V.pose, own);   // this row's vertex: loaded once, reused by every slot
   for (int s = s0; s < s1; ++s) {
     const int4 rec = V.pslot_rec[s];
     const int e = rec.x, kind = rec.y & 15, ia = rec.z, ib = rec.w;   // kind 3 (hand-over) is evaluated like kind 1 here
@@ -610,7 +618,7 @@ __global__ __launch_bounds__(kRowThreads) void k_linearize_rowthread(BatchView V
       const int n = V.nEo;
       const bool iside = (kind == 0);
       Se3Lin L;
-      se3_error(load_pose(V.pose, ia), load_pose(V.pose, ib), load_meas_pose(V.eo_z, n, e), L);
+      se3_error(iside ? Xown : load_pose16(V.pose, ia), iside ? load_pose16(V.pose, ib) : Xown, load_meas_pose(V.eo_z, n, e), L);
       L.Re = qmat(L.qe);
       double Js[36];   // Js[c*6 + q] = J_self[q][c]
 #pragma unroll
@@ -669,7 +677,7 @@ __global__ __launch_bounds__(kRowThreads) void k_linearize_rowthread(BatchView V
       }
     } else {
       const int n = V.nEl;
-      const Pose Xi = load_pose(V.pose, ia);
+      const Pose Xi = Xown;
       const double* lp = V.lmk + (size_t)ib * 4;
       double err[3], Ji[18], Jl[9];   // Ji row-major 3x6, Jl row-major 3x3
       if (!PL || V.lm_kind[ib] == VT_POINT) {
