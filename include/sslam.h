@@ -205,6 +205,15 @@ int sslam_seg_segment(sslam_seg* s, const uint8_t* cloud, int width, int height,
                       int off_x, int off_y, int off_z, const sslam_box* boxes, int n_boxes,
                       const float robot_pose[6], float cam_angle, sslam_plane* out, int max_out);
 
+/* RANSAC plane fit: pcl::SACSegmentation(SACMODEL_PLANE, SAC_RANSAC, optimise coefficients)
+ * as configured at plane_segmentation.cpp:639-647 (threshold 0.01; PCL defaults max_iterations 50, probability 0.99)
+ * on an unorganised cloud of n xyz float points.  Every hypothesis is scored in parallel (one thread per point,
+ * LDS / ballot inlier counting); pcl::RandomSampleConsensus' adaptive-k loop is replayed over the counts.
+ * Samples come from a counter-based hash of (seed, iteration) instead of rand().  Returns the number of inliers of
+ * the refined model; coeff_out = (nx, ny, nz, d); inliers_out = ascending point indices. */
+int sslam_seg_ransac_plane(sslam_seg* s, const float* xyz, int n, float threshold, int max_iterations, double probability,
+                           uint64_t seed, float coeff_out[4], int32_t* inliers_out, int max_inliers);
+
 /* parity hooks: per-box products of the last sslam_seg_segment call.
  * normals: w*h*4 floats (nx,ny,nz,curvature), labels: w*h int32 (-1 = no plane; otherwise the
  * region index in output order of pcl::OrganizedMultiPlaneSegmentation::segmentAndRefine). */

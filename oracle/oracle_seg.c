@@ -550,3 +550,106 @@ int os_segment(const os_params *P, const uint8_t *cloud, int width, int height, 
   }
   return nout;
 }
+
+/* ---------------------------------------------------------------- RANSAC plane (row a15) */
+/* pcl::SACSegmentation (SACMODEL_PLANE, SAC_RANSAC, optimize coefficients) as called by the reference's
+ * dead code path plane_segmentation::compute2DConvexHull (src/planar_segmentation/plane_segmentation.cpp:639-647:
+ * distance threshold 0.01, default max_iterations 50, probability 0.99).  Restated from
+ * pcl/sample_consensus/{ransac.hpp, sac_model_plane.hpp} (from memory): adaptive iteration count k,
+ * 3-point plane, |n.p + d| < threshold, refit by mean/covariance + eigen33, inliers re-selected with
+ * the refined model.  DEVIATION: PCL draws its samples with rand(); here sample triples come from a
+ * counter-based hash (splitmix64 of seed / iteration / attempt) so that the CPU oracle and the GPU
+ * evaluate the very same hypotheses. */
+static uint64_t splitmix64(uint64_t x) {
+  x += 0x9E3779B97F4A7C15ull;
+  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+  x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+  return x ^ (x >> 31);
+}
+/* returns 1 and fills model[4] if a good (non-collinear, distinct) sample exists for this iteration */
+static int ransac_hypothesis(const float *pts, int n, uint64_t seed, int iter, float model[4]) {
+  for (int attempt = 0; attempt < 1000; ++attempt) {
+    int id[3];
+    for (int j = 0; j < 3; ++j) id[j] = (int)(splitmix64(seed ^ ((uint64_t)iter << 32) ^ ((uint64_t)attempt << 8) ^ (uint64_t)j) % (uint64_t)n);
+    if (id[0] == id[1] || id[0] == id[2] || id[1] == id[2]) continue;
+    const float *p0 = pts + (size_t)id[0] * 3, *p1 = pts + (size_t)id[1] * 3, *p2 = pts + (size_t)id[2] * 3;
+    const float a0 = p1[0] - p0[0], a1 = p1[1] - p0[1], a2 = p1[2] - p0[2];
+    const float b0 = p2[0] - p0[0], b1 = p2[1] - p0[1], b2 = p2[2] - p0[2];
+    const float r0 = a0 / b0, r1 = a1 / b1, r2 = a2 / b2;          /* isSampleGood: dy1dy2 */
+    if (!((r0 != r1) || (r2 != r1))) continue;
+    float m0 = a1 * b2 - a2 * b1, m1 = a2 * b0 - a0 * b2, m2 = a0 * b1 - a1 * b0;
+    const float nn = sqrtf(m0 * m0 + m1 * m1 + m2 * m2);
+    m0 /= nn; m1 /= nn; m2 /= nn;
+    model[0] = m0; model[1] = m1; model[2] = m2;
+    model[3] = -1 * (m0 * p0[0] + m1 * p0[1] + m2 * p0[2]);
+    return isfinite(model[0]) && isfinite(model[3]);
+  }
+  return 0;
+}
+static int plane_inlier(const float *m, const float *p, float thr) {
+  return fabsf(m[0] * p[0] + m[1] * p[1] + m[2] * p[2] + m[3]) < thr;
+}
+/* counts_out (optional): inlier count of every evaluated hypothesis (test hook). Returns #inliers. */
+int os_ransac_plane(const float *pts, int n, float threshold, int max_iterations, double probability, uint64_t seed,
+                    float coeff[4], int32_t *inliers, int max_inliers, int32_t *counts_out, int *best_iter_out) {
+  coeff[0] = coeff[1] = coeff[2] = coeff[3] = 0;
+  if (best_iter_out) *best_iter_out = -1;
+  if (n < 3) return 0;
+  int best = -1, best_it = -1;
+  float best_model[4] = {0, 0, 0, 0};
+  double k = 1.0;
+  const double log_probability = log(1.0 - probability), one_over = 1.0 / (double)n;
+  const double eps = 2.220446049250313e-16;
+  int iterations = 0, skipped = 0, it = 0;
+  const int max_skip = max_iterations * 10;
+  while ((double)iterations < k && skipped < max_skip) {
+    float m[4];
+    const int ok = ransac_hypothesis(pts, n, seed, it, m);
+    int cnt = 0;
+    if (ok) for (int i = 0; i < n; ++i) cnt += plane_inlier(m, pts + (size_t)i * 3, threshold);
+    if (counts_out && it < max_iterations + max_skip + 2) counts_out[it] = ok ? cnt : -1;
+    ++it;
+    if (!ok) { ++skipped; continue; }
+    if (cnt > best) {
+      best = cnt; best_it = it - 1; memcpy(best_model, m, sizeof m);
+      const double w = (double)best * one_over;
+      double p_no = 1.0 - pow(w, 3.0);
+      if (p_no < eps) p_no = eps;
+      if (p_no > 1.0 - eps) p_no = 1.0 - eps;
+      k = log_probability / log(p_no);
+    }
+    ++iterations;
+    if (iterations > max_iterations) break;
+  }
+  if (best_iter_out) *best_iter_out = best_it;
+  if (best <= 0) return 0;
+  /* optimizeModelCoefficients: mean/covariance of the inliers (float, index order) + eigen33 */
+  float model[4];
+  memcpy(model, best_model, sizeof model);
+  if (best > 3) {
+    float a[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    int cnt = 0;
+    for (int i = 0; i < n; ++i) {
+      const float *p = pts + (size_t)i * 3;
+      if (!plane_inlier(best_model, p, threshold)) continue;
+      a[0] += p[0] * p[0]; a[1] += p[0] * p[1]; a[2] += p[0] * p[2]; a[3] += p[1] * p[1]; a[4] += p[1] * p[2]; a[5] += p[2] * p[2];
+      a[6] += p[0]; a[7] += p[1]; a[8] += p[2];
+      ++cnt;
+    }
+    const float cf = (float)cnt;
+    for (int q = 0; q < 9; ++q) a[q] = a[q] / cf;
+    float cov[9];
+    cov[0] = a[0] - a[6] * a[6]; cov[1] = a[1] - a[6] * a[7]; cov[2] = a[2] - a[6] * a[8];
+    cov[4] = a[3] - a[7] * a[7]; cov[5] = a[4] - a[7] * a[8]; cov[8] = a[5] - a[8] * a[8];
+    cov[3] = cov[1]; cov[6] = cov[2]; cov[7] = cov[5];
+    float ev, v[3];
+    os_eigen33(cov, &ev, v);
+    model[0] = v[0]; model[1] = v[1]; model[2] = v[2];
+    model[3] = -1 * (v[0] * a[6] + v[1] * a[7] + v[2] * a[8]);
+  }
+  memcpy(coeff, model, sizeof model);
+  int ni = 0;
+  for (int i = 0; i < n; ++i)
+    if (plane_inlier(model, pts + (size_t)i * 3, threshold)) { if (ni < max_inliers) inliers[ni] = i; ++ni; }
+  return ni;
+}

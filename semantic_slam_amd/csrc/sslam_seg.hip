@@ -781,6 +781,137 @@ __global__ __launch_bounds__(64) void k_area(View V) {
   if (lane == 0) R->area = sqrtf(rx * rx + ry * ry + rz * rz) * 0.5f;
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// RANSAC plane fit: pcl::SACSegmentation(SACMODEL_PLANE, SAC_RANSAC) as used by the
+// reference's compute2DConvexHull (plane_segmentation.cpp:639-647).  All `max_iterations + slack`
+// hypotheses are scored in parallel — one workgroup per hypothesis, one thread per point with a
+// wave-ballot / LDS inlier count — and the sequential adaptive-k logic of pcl::RandomSampleConsensus is
+// replayed over the counts afterwards, which selects exactly the hypothesis the sequential loop would.
+// Sample triples come from a counter-based hash (see oracle/oracle_seg.c for the deviation note).
+__device__ __forceinline__ unsigned long long splitmix64(unsigned long long x) {
+  x += 0x9E3779B97F4A7C15ull;
+  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+  x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+  return x ^ (x >> 31);
+}
+__device__ __forceinline__ bool plane_inlier(const float* m, const float* p, float thr) {
+  return fabsf(m[0] * p[0] + m[1] * p[1] + m[2] * p[2] + m[3]) < thr;
+}
+__global__ __launch_bounds__(256) void k_ransac_score(const float* __restrict__ pts, int n, float thr, unsigned long long seed,
+                                                     float* __restrict__ models, int* __restrict__ counts) {
+  __shared__ float m[4];
+  __shared__ int ok;
+  __shared__ int wsum[4];
+  const int iter = blockIdx.x;
+  if (threadIdx.x == 0) {
+    int good = 0;
+    for (int attempt = 0; attempt < 1000 && !good; ++attempt) {
+      int id[3];
+      for (int j = 0; j < 3; ++j)
+        id[j] = (int)(splitmix64(seed ^ ((unsigned long long)iter << 32) ^ ((unsigned long long)attempt << 8) ^ (unsigned long long)j) % (unsigned long long)n);
+      if (id[0] == id[1] || id[0] == id[2] || id[1] == id[2]) continue;
+      const float* p0 = pts + (size_t)id[0] * 3; const float* p1 = pts + (size_t)id[1] * 3; const float* p2 = pts + (size_t)id[2] * 3;
+      const float a0 = p1[0] - p0[0], a1 = p1[1] - p0[1], a2 = p1[2] - p0[2];
+      const float b0 = p2[0] - p0[0], b1 = p2[1] - p0[1], b2 = p2[2] - p0[2];
+      const float r0 = a0 / b0, r1 = a1 / b1, r2 = a2 / b2;
+      if (!((r0 != r1) || (r2 != r1))) continue;
+      float m0 = a1 * b2 - a2 * b1, m1 = a2 * b0 - a0 * b2, m2 = a0 * b1 - a1 * b0;
+      const float nn = sqrtf(m0 * m0 + m1 * m1 + m2 * m2);
+      m0 /= nn; m1 /= nn; m2 /= nn;
+      m[0] = m0; m[1] = m1; m[2] = m2;
+      m[3] = -1 * (m0 * p0[0] + m1 * p0[1] + m2 * p0[2]);
+      good = 2;   // a sample was found (whether or not its model is finite)
+    }
+    ok = (good == 2) && isfinite(m[0]) && isfinite(m[3]);
+  }
+  __syncthreads();
+  int cnt = 0;
+  if (ok)
+    for (int i = threadIdx.x; i < n; i += 256) cnt += plane_inlier(m, pts + (size_t)i * 3, thr) ? 1 : 0;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) cnt += __shfl_down(cnt, o, 64);
+  if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = cnt;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    counts[iter] = ok ? wsum[0] + wsum[1] + wsum[2] + wsum[3] : -1;
+    models[iter * 4 + 0] = m[0]; models[iter * 4 + 1] = m[1]; models[iter * 4 + 2] = m[2]; models[iter * 4 + 3] = m[3];
+  }
+}
+// ordered inlier list of one model: per-block counts -> offsets -> indices (index order = PCL's)
+__global__ __launch_bounds__(256) void k_ransac_mark(const float* __restrict__ pts, int n, float thr, const float* __restrict__ model,
+                                                    int* __restrict__ block_counts) {
+  __shared__ int wsum[4];
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  const float m[4] = {model[0], model[1], model[2], model[3]};
+  int c = (i < n && plane_inlier(m, pts + (size_t)i * 3, thr)) ? 1 : 0;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o, 64);
+  if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) block_counts[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+__global__ void k_ransac_scan(int* block_counts, int nblocks, int* total) {   // exclusive scan by one thread (nblocks is small)
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  int acc = 0;
+  for (int b = 0; b < nblocks; ++b) { const int c = block_counts[b]; block_counts[b] = acc; acc += c; }
+  *total = acc;
+}
+__global__ __launch_bounds__(256) void k_ransac_write(const float* __restrict__ pts, int n, float thr, const float* __restrict__ model,
+                                                     const int* __restrict__ block_off, int* __restrict__ inliers, int max_inliers) {
+  __shared__ int woff[4];
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  const float m[4] = {model[0], model[1], model[2], model[3]};
+  const bool in = i < n && plane_inlier(m, pts + (size_t)i * 3, thr);
+  const unsigned long long mask = __ballot(in);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) woff[wave] = __popcll(mask);
+  __syncthreads();
+  int base = block_off[blockIdx.x];
+  for (int w = 0; w < wave; ++w) base += woff[w];
+  if (in) {
+    const int pos = base + __popcll(mask & ((1ull << lane) - 1ull));
+    if (pos < max_inliers) inliers[pos] = i;
+  }
+}
+// optimizeModelCoefficients: float mean / covariance of the inliers in index order + eigen33 (one wave)
+__global__ __launch_bounds__(64) void k_ransac_refit(const float* __restrict__ pts, const int* __restrict__ inliers, const int* __restrict__ total,
+                                                    float* __restrict__ model) {
+  __shared__ float prod[64][9];
+  const int cntN = *total;
+  if (cntN <= 3) return;   // PCL keeps the unrefined model
+  const int lane = threadIdx.x;
+  float acc = 0;
+  for (int i0 = 0; i0 < cntN; i0 += 64) {
+    const int i = i0 + lane;
+    if (i < cntN) {
+      const float* p = pts + (size_t)inliers[i] * 3;
+      float* q = prod[lane];
+      q[0] = p[0] * p[0]; q[1] = p[0] * p[1]; q[2] = p[0] * p[2]; q[3] = p[1] * p[1]; q[4] = p[1] * p[2]; q[5] = p[2] * p[2];
+      q[6] = p[0]; q[7] = p[1]; q[8] = p[2];
+    }
+    __syncthreads();
+    if (lane < 9) { const int mcount = min(64, cntN - i0); for (int q = 0; q < mcount; ++q) acc += prod[q][lane]; }
+    __syncthreads();
+  }
+  float a[9];
+#pragma unroll
+  for (int q = 0; q < 9; ++q) a[q] = __shfl(acc, q, 64);
+  if (lane == 0) {
+    const float cf = (float)cntN;
+#pragma unroll
+    for (int q = 0; q < 9; ++q) a[q] = a[q] / cf;
+    float cov[9];
+    cov[0] = a[0] - a[6] * a[6]; cov[1] = a[1] - a[6] * a[7]; cov[2] = a[2] - a[6] * a[8];
+    cov[4] = a[3] - a[7] * a[7]; cov[5] = a[4] - a[7] * a[8]; cov[8] = a[5] - a[8] * a[8];
+    cov[3] = cov[1]; cov[6] = cov[2]; cov[7] = cov[5];
+    float ev, v[3];
+    eigen33(cov, ev, v);
+    model[0] = v[0]; model[1] = v[1]; model[2] = v[2];
+    model[3] = -1 * (v[0] * a[6] + v[1] * a[7] + v[2] * a[8]);
+  }
+}
+
 // final label image for the parity hook: region index or -1
 __global__ __launch_bounds__(256) void k_label_image(View V, int box, int* out) {
   const BoxMeta b = V.box[box];
@@ -1069,6 +1200,75 @@ int sslam_seg_segment(sslam_seg* s, const uint8_t* cloud, int width, int height,
   s->last_kernel_ms = kernel_ms;
   s->last_total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   return nout;
+}
+
+
+int sslam_seg_ransac_plane(sslam_seg* s, const float* xyz, int n, float threshold, int max_iterations, double probability,
+                           uint64_t seed, float coeff_out[4], int32_t* inliers_out, int max_inliers) {
+  if (!s || !xyz || !coeff_out || (!inliers_out && max_inliers > 0) || n < 0 || max_iterations < 1)
+    return set_error(SSLAM_ERR_INVALID, "bad argument");
+  int nd = 0;
+  if (hipGetDeviceCount(&nd) != hipSuccess || nd <= 0) return set_error(SSLAM_ERR_NO_DEVICE, "no HIP device visible; the product has no CPU fallback");
+  coeff_out[0] = coeff_out[1] = coeff_out[2] = coeff_out[3] = 0;
+  if (n < 3) return 0;
+  SSLAM_HIP_TRY(hipSetDevice(s->P.device));
+  if (!s->stream) SSLAM_HIP_TRY(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
+  const int max_skip = max_iterations * 10;
+  const int H = max_iterations + 1 + max_skip;       // every hypothesis index the sequential loop can reach
+  const int nblk = (n + 255) / 256;
+  float *d_pts = nullptr, *d_models = nullptr;
+  int *d_counts = nullptr, *d_blk = nullptr, *d_inl = nullptr, *d_total = nullptr;
+  SSLAM_HIP_TRY(hipMalloc((void**)&d_pts, (size_t)n * 3 * sizeof(float)));
+  SSLAM_HIP_TRY(hipMalloc((void**)&d_models, (size_t)(H + 1) * 4 * sizeof(float)));
+  SSLAM_HIP_TRY(hipMalloc((void**)&d_counts, (size_t)H * sizeof(int)));
+  SSLAM_HIP_TRY(hipMalloc((void**)&d_blk, (size_t)nblk * sizeof(int)));
+  SSLAM_HIP_TRY(hipMalloc((void**)&d_inl, (size_t)std::max(n, 1) * sizeof(int)));
+  SSLAM_HIP_TRY(hipMalloc((void**)&d_total, sizeof(int)));
+  auto cleanup = [&]() { (void)hipFree(d_pts); (void)hipFree(d_models); (void)hipFree(d_counts); (void)hipFree(d_blk); (void)hipFree(d_inl); (void)hipFree(d_total); };
+  SSLAM_HIP_TRY(hipMemcpyAsync(d_pts, xyz, (size_t)n * 3 * sizeof(float), hipMemcpyHostToDevice, s->stream));
+  hipLaunchKernelGGL(k_ransac_score, dim3(H), dim3(256), 0, s->stream, d_pts, n, threshold, (unsigned long long)seed, d_models, d_counts);
+  std::vector<int> counts(H);
+  std::vector<float> models((size_t)H * 4);
+  SSLAM_HIP_TRY(hipMemcpyAsync(counts.data(), d_counts, (size_t)H * sizeof(int), hipMemcpyDeviceToHost, s->stream));
+  SSLAM_HIP_TRY(hipMemcpyAsync(models.data(), d_models, (size_t)H * 4 * sizeof(float), hipMemcpyDeviceToHost, s->stream));
+  SSLAM_HIP_TRY(hipStreamSynchronize(s->stream));
+  // replay of pcl::RandomSampleConsensus::computeModel over the precomputed counts
+  int best = -1, best_it = -1, iterations = 0, skipped = 0, it = 0;
+  double k = 1.0;
+  const double log_probability = std::log(1.0 - probability), one_over = 1.0 / (double)n, eps = 2.220446049250313e-16;
+  while ((double)iterations < k && skipped < max_skip && it < H) {
+    const int cnt = counts[it];
+    ++it;
+    if (cnt < 0) { ++skipped; continue; }
+    if (cnt > best) {
+      best = cnt; best_it = it - 1;
+      const double w = (double)best * one_over;
+      double p_no = 1.0 - std::pow(w, 3.0);
+      p_no = std::max(eps, p_no); p_no = std::min(1.0 - eps, p_no);
+      k = log_probability / std::log(p_no);
+    }
+    ++iterations;
+    if (iterations > max_iterations) break;
+  }
+  if (best <= 0) { cleanup(); return 0; }
+  float* d_model = d_models + (size_t)H * 4;   // working copy of the winning model
+  SSLAM_HIP_TRY(hipMemcpyAsync(d_model, d_models + (size_t)best_it * 4, 4 * sizeof(float), hipMemcpyDeviceToDevice, s->stream));
+  for (int pass = 0; pass < 2; ++pass) {   // inliers of the sampled model -> refit -> inliers of the refined model
+    hipLaunchKernelGGL(k_ransac_mark, dim3(nblk), dim3(256), 0, s->stream, d_pts, n, threshold, d_model, d_blk);
+    hipLaunchKernelGGL(k_ransac_scan, dim3(1), dim3(64), 0, s->stream, d_blk, nblk, d_total);
+    hipLaunchKernelGGL(k_ransac_write, dim3(nblk), dim3(256), 0, s->stream, d_pts, n, threshold, d_model, d_blk, d_inl, n);
+    if (pass == 0) hipLaunchKernelGGL(k_ransac_refit, dim3(1), dim3(64), 0, s->stream, d_pts, d_inl, d_total, d_model);
+  }
+  int total = 0;
+  SSLAM_HIP_TRY(hipMemcpyAsync(&total, d_total, sizeof(int), hipMemcpyDeviceToHost, s->stream));
+  SSLAM_HIP_TRY(hipMemcpyAsync(coeff_out, d_model, 4 * sizeof(float), hipMemcpyDeviceToHost, s->stream));
+  SSLAM_HIP_TRY(hipStreamSynchronize(s->stream));
+  if (total > 0 && max_inliers > 0)
+    SSLAM_HIP_TRY(hipMemcpy(inliers_out, d_inl, (size_t)std::min(total, max_inliers) * sizeof(int), hipMemcpyDeviceToHost));
+  hipError_t le = hipGetLastError();
+  cleanup();
+  if (le != hipSuccess) return set_error(SSLAM_ERR_HIP, "ransac kernels: %s", hipGetErrorString(le));
+  return total;
 }
 
 static int seg_find_slot(sslam_seg* s, int box) {

@@ -68,6 +68,8 @@ def _bind(lib):
     lib.sslam_seg_get_labels.restype = ci; lib.sslam_seg_get_labels.argtypes = [vp, ci, vp]
     lib.sslam_seg_last_timing.restype = ci; lib.sslam_seg_last_timing.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     lib.sslam_seg_transform.restype = ci; lib.sslam_seg_transform.argtypes = [vp, vp, C.c_float, vp]
+    lib.sslam_seg_ransac_plane.restype = ci
+    lib.sslam_seg_ransac_plane.argtypes = [vp, vp, ci, C.c_float, ci, C.c_double, C.c_uint64, vp, vp, ci]
     _BOUND = True
 
 
@@ -132,6 +134,16 @@ class PointCloudSegmentation:
                                       normal_orientation=np.array(p.normal_d, np.float32), box_index=p.box_index,
                                       inlier_count=p.inlier_count, area=p.area))
         return res
+
+    def ransac_plane(self, xyz, threshold: float = 0.01, max_iterations: int = 50, probability: float = 0.99, seed: int = 0):
+        """pcl::SACSegmentation plane RANSAC of plane_segmentation::compute2DConvexHull (plane_segmentation.cpp:639-647).
+        Returns (coefficients[4], ascending inlier indices)."""
+        pts = np.ascontiguousarray(xyz, np.float32).reshape(-1, 3)
+        coeff = np.zeros(4, np.float32)
+        inl = np.zeros(max(len(pts), 1), np.int32)
+        n = self._check(self._lib.sslam_seg_ransac_plane(self._h, pts.ctypes.data, len(pts), C.c_float(threshold), max_iterations,
+                                                          C.c_double(probability), C.c_uint64(seed), coeff.ctypes.data, inl.ctypes.data, len(inl)))
+        return coeff, inl[:n].copy()
 
     # parity hooks -----------------------------------------------------------------------------
     def normals(self, box: int) -> np.ndarray:

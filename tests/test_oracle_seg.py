@@ -152,3 +152,34 @@ def test_frame_level_outputs_are_consistent():
             assert pl.normal_d[1] <= 0
         else:
             assert pl.normal_d[0] <= 0
+
+
+def test_ransac_plane_recovers_a_noisy_plane_with_outliers():
+    """oracle RANSAC (row a15, plane_segmentation.cpp:639-647 parameters): analytic target + determinism in the seed"""
+    lib = oracle.lib()
+    rng = np.random.default_rng(3)
+    n = 6000
+    pts = np.zeros((n, 3), np.float32)
+    pts[:, :2] = rng.uniform(-1, 1, (n, 2))
+    pts[:, 2] = 0.3 * pts[:, 0] - 0.2 * pts[:, 1] + 1.5 + rng.normal(0, 0.002, n)
+    out = rng.choice(n, 2000, replace=False)
+    pts[out] += rng.uniform(-0.5, 0.5, (2000, 3)).astype(np.float32)
+
+    def run(seed):
+        coeff = np.zeros(4, np.float32); inl = np.zeros(n, np.int32); cnts = np.full(600, -7, np.int32); bi = C.c_int(0)
+        k = lib.os_ransac_plane(pts.ctypes.data_as(C.c_void_p), n, C.c_float(0.01), 50, C.c_double(0.99), C.c_uint64(seed),
+                                coeff.ctypes.data_as(C.c_void_p), inl.ctypes.data_as(C.c_void_p), n, cnts.ctypes.data_as(C.c_void_p), C.byref(bi))
+        return coeff, inl[:k].copy(), cnts, bi.value
+    c, inl, cnts, best = run(5)
+    nrm = np.array([0.3, -0.2, -1.0]); nrm /= np.linalg.norm(nrm)
+    assert abs(abs(c[:3] @ nrm) - 1) < 1e-4 and abs(abs(c[3]) - 1.5 / np.sqrt(1.13)) < 2e-3
+    truth = np.setdiff1d(np.arange(n), out)
+    assert len(np.intersect1d(inl, truth)) > 0.95 * len(truth)              # nearly all true inliers found
+    assert np.all(np.abs(pts[inl] @ c[:3] + c[3]) < 0.01)                    # every reported inlier satisfies the model
+    assert np.all(np.diff(inl) > 0)
+    evaluated = cnts[cnts != -7]
+    assert len(evaluated) < 50 and cnts[best] == evaluated.max()             # adaptive k stopped early, best hypothesis kept
+    c2, inl2, _, _ = run(5)
+    assert np.array_equal(c, c2) and np.array_equal(inl, inl2)
+    c3, inl3, _, best3 = run(6)
+    assert abs(abs(c3[:3] @ nrm) - 1) < 1e-4

@@ -111,3 +111,51 @@ def test_transform_matches_oracle(gpu_lib):
     ref = np.zeros(16, np.float32)
     oracle.lib().os_transform_normals_to_world(pose.ctypes.data_as(C.c_void_p), C.c_float(0.59), 1, ref.ctypes.data_as(C.c_void_p))
     assert np.array_equal(T.reshape(-1), ref)
+
+
+def _oracle_ransac(pts, thr, iters, prob, seed):
+    import ctypes as C
+    from oracle import oracle
+    lib = oracle.lib()
+    pts = np.ascontiguousarray(pts, np.float32).reshape(-1, 3)
+    coeff = np.zeros(4, np.float32); inl = np.zeros(max(len(pts), 1), np.int32); bi = C.c_int(0)
+    k = lib.os_ransac_plane(pts.ctypes.data_as(C.c_void_p), len(pts), C.c_float(thr), iters, C.c_double(prob), C.c_uint64(seed),
+                            coeff.ctypes.data_as(C.c_void_p), inl.ctypes.data_as(C.c_void_p), len(inl), None, C.byref(bi))
+    return coeff, inl[:k].copy()
+
+
+@pytest.mark.parametrize("seed", [0, 7, 42])
+def test_ransac_plane_inliers_bit_exact(gpu_lib, seed):
+    """SURVEY §8 a15 (plane_segmentation.cpp:639-647): inlier index set and refined coefficients vs the oracle."""
+    from semantic_slam_amd.segmentation import PointCloudSegmentation
+    rng = np.random.default_rng(seed)
+    n = 20000
+    pts = np.zeros((n, 3), np.float32)
+    pts[:, :2] = rng.uniform(-1, 1, (n, 2))
+    pts[:, 2] = 0.3 * pts[:, 0] - 0.2 * pts[:, 1] + 1.5 + rng.normal(0, 0.003, n)
+    out = rng.choice(n, n // 3, replace=False)
+    pts[out] += rng.uniform(-0.5, 0.5, (len(out), 3)).astype(np.float32)
+    seg = PointCloudSegmentation()
+    coeff, inl = seg.ransac_plane(pts, 0.01, 50, 0.99, seed)
+    rc, ri = _oracle_ransac(pts, 0.01, 50, 0.99, seed)
+    assert np.array_equal(inl, ri) and len(inl) > n // 2
+    assert np.array_equal(coeff, rc)
+    nrm = np.array([0.3, -0.2, -1.0]); nrm /= np.linalg.norm(nrm)
+    assert abs(abs(coeff[:3] @ nrm) - 1) < 1e-4
+
+
+def test_ransac_plane_edge_cases(gpu_lib):
+    from semantic_slam_amd.segmentation import PointCloudSegmentation
+    seg = PointCloudSegmentation()
+    coeff, inl = seg.ransac_plane(np.zeros((2, 3), np.float32))              # fewer than 3 points
+    assert len(inl) == 0 and not coeff.any()
+    line = np.stack([np.linspace(0, 1, 50), np.linspace(0, 2, 50), np.linspace(0, 3, 50)], 1).astype(np.float32)
+    c1, i1 = seg.ransac_plane(line, 0.01, 5, 0.99, 3)                        # collinear: every sample is rejected
+    c2, i2 = _oracle_ransac(line, 0.01, 5, 0.99, 3)
+    assert np.array_equal(i1, i2) and np.array_equal(c1, c2)
+    f = make_frame(seed=1, n_boxes=1)                                         # a real crop with NaN points
+    b = f.boxes[0]
+    crop = f.xyz()[b["tl_y"]:b["tl_y"] + b["height"], b["tl_x"]:b["tl_x"] + b["width"]].reshape(-1, 3)
+    c1, i1 = seg.ransac_plane(crop, 0.01, 50, 0.99, 11)
+    c2, i2 = _oracle_ransac(crop, 0.01, 50, 0.99, 11)
+    assert np.array_equal(i1, i2) and np.array_equal(c1, c2, equal_nan=True) and len(i1) > 1000
