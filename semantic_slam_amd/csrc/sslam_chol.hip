@@ -23,23 +23,25 @@
 
 namespace sslam {
 
+// Packed per-column / per-block / per-update records: one 16/32-byte load each instead of a chain of
+// dependent 4-byte loads (a narrow level is a single workgroup whose run time is that chain).
+struct ColMeta { int xoff, dim, graph, b0, nb, base, csize, ubase, ucount, pad; };  // base = Lval offset of the diagonal block;
+                                                                                    // [ubase, ubase + ucount) = the column's updates
+struct BlkMeta { int off, di, src, fmt, up0, up1, rowcol, xoff_row; };   // src: H offset or -1; rowcol: column id of the row
+struct UpdMeta { int ua, ub, ux, pk; };                                  // offsets of L_ik, L_jk, y_k; pk = target descriptor:
+constexpr int kUpdToffMask = 0xFFFFF;   // pk bits 0..19: offset of the target block inside its column
+constexpr int kUpdDi6 = 1 << 20;        // target block has 6 rows (else 3)
+constexpr int kUpdDk6 = 1 << 21;        // source column k is 6 wide (else 3)
+constexpr int kUpdDiag = 1 << 22;       // target is the diagonal block (carries the forward-substitution rhs too)
+
 struct CholView {
   int ncol, nlevels, dim;
-  const int* col_xoff;   // [ncol] offset in the unknown vector
-  const int* col_dim;    // [ncol] 6 | 3
-  const int* col_graph;  // [ncol]
-  const int* bp;         // [ncol+1] block range of each column (first = diagonal)
-  const int* boff;       // [nblk] offset into Lval
-  const int* brow;       // [nblk] column id of the block's row
-  const int* bsrc;       // [nblk] offset into H (doubles from Hpp_diag) or -1
-  const unsigned char* bfmt;  // [nblk] 0: H[r*dj+c], 1: H[c*di+r]
-  const int* up;         // [nblk+1] update list range
-  const int* ua;         // offset of L_ik
-  const int* ub;         // offset of L_jk
-  const int* uk;         // column id k
-  const int* ux;         // x offset of column k
-  const unsigned char* udk;  // dimension of column k
-  const int* lvl_cols;   // columns grouped by level
+  const ColMeta* col;    // [ncol]
+  const BlkMeta* blk;    // [nblk] (blocks of a column are consecutive, diagonal first)
+  const UpdMeta* upd;    // update lists, concatenated in block order
+  const int* lvl_cols;   // columns grouped by level (within a level: level-scheduled columns first, tail columns last)
+  const int* tail_ptr;   // [B + 1] per graph: its columns factored by k_chol_tail, in elimination order
+  const int* tail_cols;
   double* Lval;
   double* y;             // forward-substituted rhs [dim]
   int* fail;             // [B]
@@ -48,6 +50,8 @@ struct CholView {
 struct CholPlan {
   CholView C{};
   std::vector<int> lvl_ptr;
+  std::vector<int> lvl_nfactor;  // columns of the level that the level launches factor (the rest belong to a tail)
+  int tail_maxEt = 0, tail_total = 0;
   std::vector<int> lvl_maxlist;  // longest update list among the level's blocks
   std::vector<int> lvl_maxEt;    // largest column (entries + rhs) of the level
   std::vector<void*> allocs;
@@ -69,11 +73,6 @@ void chol_plan_free(CholPlan* p) {
 // ------------------------------------------------------------------------------------------------
 // kernels
 // ------------------------------------------------------------------------------------------------
-// One 256-thread workgroup per block column j of the current level:
-//   S = A(:,j) + lambda I - sum_k L(:,k) L(j,k)^T   (gather over precomputed update lists; long lists
-//                                                    are split over up to 4 waves and reduced in LDS
-//                                                    in a fixed order -> deterministic)
-//   L(j,j) = chol(S(j,j)),  L(i,j) = S(i,j) L(j,j)^-T,   y(j) = L(j,j)^-1 (b(j) - sum_k L(j,k) y(k))
 // tail of a column: in-register dense Cholesky of the D x D diagonal block, forward-substituted rhs,
 // triangular solves of the off-diagonal rows
 template <int D, int NT>
@@ -133,144 +132,202 @@ __device__ __forceinline__ void chol_tail(const double* sm, int csize, double* L
   }
 }
 
-// NT = 256 (4 waves) for wide levels, 1024 (16 waves) for the narrow top levels whose update lists
-// are long.  Work item of a wave = (target block, slice of its update list).  For every update the
-// wave loads the two source blocks once with contiguous 8-byte lanes (2 x <=288 B), parks them in its
-// LDS scratch and the di x dj entry lanes read rows from LDS (broadcast), instead of every entry lane
-// gathering 12 scalars from L2.  Slices are reduced through LDS in a fixed order -> deterministic.
-constexpr int kPartDoubles = 4096;  // LDS budget for the per-slice partial sums
+// One workgroup per block column j of the current level (NT = 64 leaf levels, 256 wide levels, 1024 narrow
+// top levels, which are a single column whose run time is a chain of dependent memory latencies):
+//   S = A(:,j) + lambda I - sum_k L(:,k) L(j,k)^T,   L(j,j) = chol(S(j,j)),   L(i,j) = S(i,j) L(j,j)^-T,
+//   y(j) = L(j,j)^-1 (b(j) - sum_k L(j,k) y(k))                      (forward substitution fused)
+// The column's updates form one flat list sorted by target block; wave w owns a contiguous range of it.
+// The range's records are fetched 64 at a time (one per lane) and broadcast with readlane, so the only
+// latency left on the per-update chain is the source-block load, which runs kRing updates ahead.  For every
+// update the wave parks the two source blocks in its LDS scratch and the di x dj entry lanes read rows from
+// LDS (broadcast).  When the target changes the wave flushes its partial block to its own LDS copy of the
+// column; the copies are reduced in wave order -> deterministic.
+constexpr int kPartDoubles = 12288;  // LDS budget for the per-wave partial columns
+constexpr int kScr = 104;             // doubles of LDS scratch per wave: L_ik at 0, L_jk at 36 (64 lanes written), y_k at 72
 template <int NT>
-__global__ __launch_bounds__(NT) void k_chol_level(BatchView V, CholView C, int lvl_begin) {
-  extern __shared__ double sm[];  // [Et] column + rhs entries | [nslice][Et] partial sums | [NW][80] wave scratch
+__device__ __forceinline__ void chol_column(const BatchView& V, const CholView& C, const int j, double* sm) {
+  // sm: [Et] column + rhs entries | [nparts][Et] partial columns | [NW][kScr] wave scratch
   constexpr int NW = NT / 64;
-  const int j = C.lvl_cols[lvl_begin + blockIdx.x];
-  const int g = C.col_graph[j];
-  if (!V.lm[g].in_trial) return;
+  const ColMeta cm = C.col[j];
+  const int g = cm.graph;
   const int tid = threadIdx.x;
-  const int wave = tid >> 6, lane = tid & 63;
-  const int dj = C.col_dim[j];
-  const int b0 = C.bp[j], b1 = C.bp[j + 1];
-  const int nb = b1 - b0;
-  const int base = C.boff[b0];
-  int csize;
-  {
-    const int last = b1 - 1;
-    csize = C.boff[last] - base + C.col_dim[C.brow[last]] * dj;
-  }
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;  // wave-uniform -> scalar metadata loads
+  const int dj = cm.dim, b0 = cm.b0, nb = cm.nb, base = cm.base, csize = cm.csize;
   const int Et = csize + dj;  // the last dj "entries" are the forward-substitution rhs
-  int maxlen = 0;
-  for (int b = b0; b < b1; ++b) maxlen = max(maxlen, C.up[b + 1] - C.up[b]);
-  const int nslice = max(1, min(min(NW, (maxlen + 3) >> 2), kPartDoubles / Et));
+  const int U = cm.ucount;
+  const int nparts = max(1, min(min(NW, (U + 7) >> 3), kPartDoubles / Et));
+  const int per = (U + nparts - 1) / nparts;
   const double lambda = V.lm[g].lambda;
   const double* __restrict__ H = V.Hpp_diag;
   const double* __restrict__ L = C.Lval;
   const double* __restrict__ Y = C.y;
   double* part = sm + Et;
-  double* scr = sm + Et + nslice * Et + wave * 80;
-  const int nitems = nb * nslice;
-  for (int item = wave; item < nitems; item += NW) {
-    const int b = b0 + item / nslice, sl = item - (item / nslice) * nslice;
-    const int di = C.col_dim[C.brow[b]];
-    const int nE = di * dj;
-    const bool diag = (b == b0);
-    const int r = lane / dj, c = lane - r * dj;          // entry lanes: lane < nE
-    const int ry = lane - 40;                            // rhs lanes: 40 .. 40 + dj - 1 (diagonal block only)
+  double* scr = sm + Et + nparts * Et + wave * kScr;
+  const int r = lane / dj, c = lane - r * dj;          // entry lanes: lane < di * dj
+  const int ry = lane - 40;                            // rhs lanes: 40 .. 40 + dj - 1 (diagonal block only)
+  if (wave < nparts && wave * per < U) {
+    // Per update the wave loads L_ik, L_jk and y_k with three uniform-base loads (idle lanes re-read the last
+    // element: no branches around loads, or the compiler waits for vmcnt(0) at every use and the ring
+    // serialises), parks them at fixed LDS offsets 0 / 36 / 72 and every lane forms one dot product
+    // row(A) . row(B or y).  Lane roles (rows, flush slot) only change when the target block changes.
+    const int lo = wave * per, hi = min(U, lo + per);
+    double* mypart = part + wave * Et;
+    const int lo36 = min(lane, 35), lo6 = min(lane, 5);
     double acc = 0;
-    const int u1 = C.up[b + 1];
-    int u = C.up[b] + sl;
-    // software pipeline: registers hold the next update's elements while the current one is consumed from LDS
-    double v0 = 0, v1 = 0;
-    int dk = 0, nA = 0, nB = 0;
-    auto fetch = [&](int uu) {
-      dk = C.udk[uu];
-      nA = di * dk; nB = dj * dk;
-      const double* A = L + C.ua[uu];
-      const double* B = L + C.ub[uu];
-      const double* Yk = Y + C.ux[uu];
-      const int i0 = lane, i1 = lane + 64;
-      v0 = i0 < nA ? A[i0] : (i0 < nA + nB ? B[i0 - nA] : ((diag && i0 < nA + nB + dk) ? Yk[i0 - nA - nB] : 0.0));
-      v1 = i1 < nA ? A[i1] : (i1 < nA + nB ? B[i1 - nA] : ((diag && i1 < nA + nB + dk) ? Yk[i1 - nA - nB] : 0.0));
-    };
-    if (u < u1) fetch(u);
-    while (u < u1) {
-      const int cdk = dk, cnA = nA, cnB = nB;
-      scr[lane] = v0;
-      if (lane < 16) scr[64 + lane] = v1;
-      u += nslice;
-      if (u < u1) fetch(u);
-      if (lane < nE) {
-        const double* pa = scr + r * cdk;
-        const double* pb = scr + cnA + c * cdk;
-        double s = pa[0] * pb[0] + pa[1] * pb[1] + pa[2] * pb[2];
-        if (cdk == 6) s += pa[3] * pb[3] + pa[4] * pb[4] + pa[5] * pb[5];
-        acc += s;
-      } else if (diag && ry >= 0 && ry < dj) {
-        const double* pa = scr + ry * cdk;
-        const double* yk = scr + cnA + cnB;
-        double s = pa[0] * yk[0] + pa[1] * yk[1] + pa[2] * yk[2];
-        if (cdk == 6) s += pa[3] * yk[3] + pa[4] * yk[4] + pa[5] * yk[5];
-        acc += s;
-      }
-    }
-    if (lane < nE) part[sl * Et + (C.boff[b] - base) + lane] = acc;
-    else if (diag && ry >= 0 && ry < dj) part[sl * Et + csize + ry] = acc;
+    int cur = -1;            // descriptor of the target being accumulated
+    bool active = false;     // lane owns an entry (or rhs component) of the target
+    int a3 = 0, a6 = 0, b3 = 0, b6 = 0, foff = 0;
+    for (int t0 = lo; t0 < hi; t0 += 64) {
+      const int nt = min(64, hi - t0);
+      const UpdMeta um = C.upd[cm.ubase + t0 + min(lane, nt - 1)];
+      const int mua = um.ua, mub = um.ub, mux = um.ux, mpk = um.pk;
+      constexpr int kRing = 4;
+      double va[kRing], vb[kRing], vy[kRing];
+      int pks[kRing];
+#define SSLAM_CHOL_ISSUE(q, t)                                                                        \
+  {                                                                                                   \
+    const int tt_ = min((t), nt - 1);                                                                 \
+    const double* A_ = L + __builtin_amdgcn_readlane(mua, tt_);                                       \
+    const double* B_ = L + __builtin_amdgcn_readlane(mub, tt_);                                       \
+    const double* Y_ = Y + __builtin_amdgcn_readlane(mux, tt_);                                       \
+    pks[q] = __builtin_amdgcn_readlane(mpk, tt_);                                                     \
+    va[q] = A_[lo36];                                                                                 \
+    vb[q] = B_[lo36];                                                                                 \
+    vy[q] = Y_[lo6];                                                                                  \
   }
-  __syncthreads();
-  for (int e = tid; e < Et; e += NT) {
-    double v;
-    if (e < csize) {
-      int b = b0;
-      while (b + 1 < b1 && C.boff[b + 1] - base <= e) ++b;
-      const int le = e - (C.boff[b] - base);
-      const int r = le / dj, c = le - r * dj;
-      const int di = C.col_dim[C.brow[b]];
-      const int src = C.bsrc[b];
-      v = 0;
-      if (src >= 0) v = C.bfmt[b] ? H[src + c * di + r] : H[src + r * dj + c];
-      if (b == b0 && r == c) v += lambda;
-    } else {
-      v = V.bvec[C.col_xoff[j] + (e - csize)];
+#pragma unroll
+      for (int q = 0; q < kRing; ++q) SSLAM_CHOL_ISSUE(q, q)
+      for (int t = 0; t < nt; t += kRing) {
+#pragma unroll
+        for (int q = 0; q < kRing; ++q) {
+          const bool live = t + q < nt;
+          const int pk = pks[q];
+          if (live) {
+            if ((pk & kUpdToffMask) != (cur & kUpdToffMask) || cur < 0) {
+              if (cur >= 0 && active) mypart[foff] = acc;
+              cur = pk; acc = 0;
+              const int nE = ((pk & kUpdDi6) ? 6 : 3) * dj;
+              const bool isrhs = lane >= nE;
+              active = !isrhs || ((pk & kUpdDiag) && ry >= 0 && ry < dj);
+              const int row = isrhs ? max(min(ry, 5), 0) : min(r, 5);
+              a3 = row * 3; a6 = row * 6;
+              b3 = isrhs ? 72 : 36 + c * 3; b6 = isrhs ? 72 : 36 + c * 6;
+              foff = isrhs ? csize + ry : (pk & kUpdToffMask) + lane;
+            }
+            scr[lane] = va[q];
+            scr[36 + lane] = vb[q];
+            if (lane < 6) scr[72 + lane] = vy[q];
+          }
+          SSLAM_CHOL_ISSUE(q, t + q + kRing)
+          if (live) {
+            if (pk & kUpdDk6) {
+              const double* pa = scr + a6;
+              const double* pb = scr + b6;
+              acc += pa[0] * pb[0] + pa[1] * pb[1] + pa[2] * pb[2] + pa[3] * pb[3] + pa[4] * pb[4] + pa[5] * pb[5];
+            } else {
+              const double* pa = scr + a3;
+              const double* pb = scr + b3;
+              acc += pa[0] * pb[0] + pa[1] * pb[1] + pa[2] * pb[2];
+            }
+          }
+        }
+      }
+#undef SSLAM_CHOL_ISSUE
     }
-    for (int s = 0; s < nslice; ++s) v -= part[s * Et + e];
-    sm[e] = v;
+    if (cur >= 0 && active) mypart[foff] = acc;
+  }
+  // A(:,j) + lambda I and the rhs, one wave per block (lanes as above).  The loads of the first two blocks
+  // of every wave are issued before the barrier so that their latency overlaps the update phase of the others.
+  auto gather = [&](const BlkMeta& bm, bool diag) -> double {
+    double v = 0;
+    if (lane < bm.di * dj) {
+      if (bm.src >= 0) v = bm.fmt ? H[bm.src + c * bm.di + r] : H[bm.src + r * dj + c];
+      if (diag && r == c) v += lambda;
+    } else if (diag && ry >= 0 && ry < dj) {
+      v = V.bvec[cm.xoff + ry];
+    }
+    return v;
+  };
+  double av0 = 0, av1 = 0;
+  if (wave < nb) av0 = gather(C.blk[b0 + wave], wave == 0);
+  if (wave + NW < nb) av1 = gather(C.blk[b0 + wave + NW], false);
+  __syncthreads();
+  for (int bi = wave, it = 0; bi < nb; bi += NW, ++it) {
+    const BlkMeta bm = C.blk[b0 + bi];
+    const bool diag = (bi == 0);
+    double v = it == 0 ? av0 : (it == 1 ? av1 : gather(bm, diag));
+    const bool ent = lane < bm.di * dj, rhs = diag && ry >= 0 && ry < dj;
+    const int e = ent ? (bm.off - base) + lane : csize + ry;
+    if (ent || rhs) {
+      if (bm.up1 > bm.up0) {
+        const int wf = (bm.up0 - cm.ubase) / per, wl = (bm.up1 - 1 - cm.ubase) / per;
+        for (int w = wf; w <= wl; ++w) v -= part[w * Et + e];
+      }
+      sm[e] = v;
+    }
   }
   __syncthreads();
   // ---- diagonal block: every thread factors its own register copy (D^3/3 flops, no LDS latency chain,
   //      no further barriers); then one thread per off-diagonal row solves x L_jj^T = v and stores to HBM
   double* Lw = C.Lval + base;
-  if (dj == 6) chol_tail<6, NT>(sm, csize, Lw, C.y + C.col_xoff[j], C.fail + g, tid);
-  else chol_tail<3, NT>(sm, csize, Lw, C.y + C.col_xoff[j], C.fail + g, tid);
+  if (dj == 6) chol_tail<6, NT>(sm, csize, Lw, C.y + cm.xoff, C.fail + g, tid);
+  else chol_tail<3, NT>(sm, csize, Lw, C.y + cm.xoff, C.fail + g, tid);
+}
+
+template <int NT>
+__global__ __launch_bounds__(NT) void k_chol_level(BatchView V, CholView C, int lvl_begin) {
+  extern __shared__ double sm[];
+  const int j = C.lvl_cols[lvl_begin + blockIdx.x];
+  if (!V.lm[C.col[j].graph].in_trial) return;
+  chol_column<NT>(V, C, j, sm);
+}
+
+// Top of the elimination tree: once a graph's levels are at most a couple of columns wide, a launch per level
+// only buys launch latency and cold caches.  One workgroup per graph walks those columns in elimination order;
+// the barrier between columns orders the L / y stores of one column before the loads of the next (same CU).
+template <int NT>
+__global__ __launch_bounds__(NT) void k_chol_tail(BatchView V, CholView C) {
+  extern __shared__ double sm[];
+  const int g = blockIdx.x;
+  if (!V.lm[g].in_trial) return;
+  const int q1 = C.tail_ptr[g + 1];
+  for (int q = C.tail_ptr[g]; q < q1; ++q) {
+    chol_column<NT>(V, C, C.tail_cols[q], sm);
+    __threadfence_block();
+    __syncthreads();
+  }
 }
 
 // forward substitution only (multi right-hand-side form, used for marginals): y_j = L_jj^-1 (b_j - sum_k L_jk y_k)
 __global__ __launch_bounds__(64) void k_chol_forward_level(CholView C, int lvl_begin, const double* __restrict__ rhs, double* __restrict__ y) {
   __shared__ double t[8];
   const int j = C.lvl_cols[lvl_begin + blockIdx.x];
+  const ColMeta cm = C.col[j];
   const size_t vo = (size_t)blockIdx.y * C.dim;
   const int lane = threadIdx.x;
-  const int dj = C.col_dim[j];
-  const int b0 = C.bp[j];
+  const int dj = cm.dim;
+  const BlkMeta bm = C.blk[cm.b0];
   const double* __restrict__ L = C.Lval;
   if (lane < dj) {
-    double a = rhs[vo + C.col_xoff[j] + lane];
-    for (int u = C.up[b0]; u < C.up[b0 + 1]; ++u) {
-      const int k = C.uk[u];
-      const int dk = C.col_dim[k];
-      const double* pa = L + C.ua[u] + lane * dk;
-      const double* yk = y + vo + C.col_xoff[k];
+    double a = rhs[vo + cm.xoff + lane];
+    for (int u = bm.up0; u < bm.up1; ++u) {
+      const UpdMeta um = C.upd[u];
+      const int dk = (um.pk & kUpdDk6) ? 6 : 3;
+      const double* pa = L + um.ua + lane * dk;
+      const double* yk = y + vo + um.ux;
       for (int q = 0; q < dk; ++q) a -= pa[q] * yk[q];
     }
     t[lane] = a;
   }
   __syncthreads();
   if (lane == 0) {
-    const double* D = L + C.boff[b0];
+    const double* D = L + cm.base;
     for (int r = 0; r < dj; ++r) {
       double a = t[r];
       for (int s = 0; s < r; ++s) a -= D[r * dj + s] * t[s];
       t[r] = a / D[r * dj + r];
     }
-    for (int r = 0; r < dj; ++r) y[vo + C.col_xoff[j] + r] = t[r];
+    for (int r = 0; r < dj; ++r) y[vo + cm.xoff + r] = t[r];
   }
 }
 
@@ -279,36 +336,35 @@ __global__ __launch_bounds__(64) void k_chol_backward_level(CholView C, int lvl_
                                                            const LmState* __restrict__ lm) {
   __shared__ double t[8];
   const int j = C.lvl_cols[lvl_begin + blockIdx.x];
-  if (lm && !lm[C.col_graph[j]].in_trial) return;
+  const ColMeta cm = C.col[j];
+  if (lm && !lm[cm.graph].in_trial) return;
   const size_t vo = (size_t)blockIdx.y * C.dim;
   const int lane = threadIdx.x;
-  const int dj = C.col_dim[j];
-  const int b0 = C.bp[j], b1 = C.bp[j + 1];
+  const int dj = cm.dim;
   const double* __restrict__ L = C.Lval;
   const int c = lane & 7, q = lane >> 3;
   double acc = 0;
   if (c < dj) {
-    for (int b = b0 + 1 + q; b < b1; b += 8) {
-      const int i = C.brow[b];
-      const int di = C.col_dim[i];
-      const double* Bk = L + C.boff[b];
-      const double* xi = x + vo + C.col_xoff[i];
-      for (int r = 0; r < di; ++r) acc += Bk[r * dj + c] * xi[r];
+    for (int bi = 1 + q; bi < cm.nb; bi += 8) {
+      const BlkMeta bm = C.blk[cm.b0 + bi];
+      const double* Bk = L + bm.off;
+      const double* xi = x + vo + bm.xoff_row;
+      for (int r = 0; r < bm.di; ++r) acc += Bk[r * dj + c] * xi[r];
     }
   }
   acc += __shfl_xor(acc, 8, 64);
   acc += __shfl_xor(acc, 16, 64);
   acc += __shfl_xor(acc, 32, 64);
-  if (q == 0 && c < dj) t[c] = y[vo + C.col_xoff[j] + c] - acc;
+  if (q == 0 && c < dj) t[c] = y[vo + cm.xoff + c] - acc;
   __syncthreads();
   if (lane == 0) {
-    const double* D = L + C.boff[b0];
+    const double* D = L + cm.base;
     for (int r = dj - 1; r >= 0; --r) {
       double a = t[r];
       for (int s = r + 1; s < dj; ++s) a -= D[s * dj + r] * t[s];
       t[r] = a / D[r * dj + r];
     }
-    for (int r = 0; r < dj; ++r) x[vo + C.col_xoff[j] + r] = t[r];
+    for (int r = 0; r < dj; ++r) x[vo + cm.xoff + r] = t[r];
   }
 }
 
@@ -489,43 +545,97 @@ int chol_plan_build(Batch& b) {
     if (bp[j + 1] - bp[j] > 1) { const int par = brow[bp[j] + 1]; level[par] = std::max(level[par], level[j] + 1); }
     nlev = std::max(nlev, level[j] + 1);
   }
+  // tail of every graph: the levels from which on the graph is at most `tail_width` columns wide
+  int tail_width = 2;
+  if (const char* e = getenv("SSLAM_CHOL_TAIL_WIDTH")) tail_width = atoi(e);
+  std::vector<char> is_tail(ncol, 0);
+  std::vector<int> tail_ptr(V.B + 1, 0), tail_cols;
+  {
+    int c0 = 0;
+    for (int g = 0; g < V.B; ++g) {
+      int c1 = c0;
+      while (c1 < ncol && col_graph[c1] == g) ++c1;
+      int gl = 0;
+      for (int j = c0; j < c1; ++j) gl = std::max(gl, level[j] + 1);
+      std::vector<int> width(gl, 0);
+      for (int j = c0; j < c1; ++j) width[level[j]]++;
+      int cut = gl;
+      while (cut > 0 && width[cut - 1] <= tail_width) --cut;
+      std::vector<std::pair<int, int>> tl;
+      for (int j = c0; j < c1; ++j) if (level[j] >= cut) { is_tail[j] = 1; tl.push_back({level[j], j}); }
+      std::sort(tl.begin(), tl.end());
+      for (auto& pr : tl) tail_cols.push_back(pr.second);
+      tail_ptr[g + 1] = (int)tail_cols.size();
+      c0 = c1;
+    }
+  }
+  P->tail_total = (int)tail_cols.size();
   P->lvl_maxEt.assign(nlev, 0);
+  P->tail_maxEt = 0;
   for (int j = 0; j < ncol; ++j) {
     const int last = bp[j + 1] - 1;
     const int cs = boff[last] - boff[bp[j]] + col_dim[brow[last]] * col_dim[j];
-    P->lvl_maxEt[level[j]] = std::max(P->lvl_maxEt[level[j]], cs + col_dim[j]);
+    if (is_tail[j]) P->tail_maxEt = std::max(P->tail_maxEt, cs + col_dim[j]);
+    else P->lvl_maxEt[level[j]] = std::max(P->lvl_maxEt[level[j]], cs + col_dim[j]);
   }
   P->lvl_maxlist.assign(nlev, 0);
   for (int j = 0; j < ncol; ++j)
-    for (int t = bp[j]; t < bp[j + 1]; ++t) P->lvl_maxlist[level[j]] = std::max(P->lvl_maxlist[level[j]], up[t + 1] - up[t]);
+    if (!is_tail[j])
+      for (int t = bp[j]; t < bp[j + 1]; ++t) P->lvl_maxlist[level[j]] = std::max(P->lvl_maxlist[level[j]], up[t + 1] - up[t]);
   P->lvl_ptr.assign(nlev + 1, 0);
-  for (int j = 0; j < ncol; ++j) P->lvl_ptr[level[j] + 1]++;
+  P->lvl_nfactor.assign(nlev, 0);
+  for (int j = 0; j < ncol; ++j) { P->lvl_ptr[level[j] + 1]++; if (!is_tail[j]) P->lvl_nfactor[level[j]]++; }
   for (int l = 0; l < nlev; ++l) P->lvl_ptr[l + 1] += P->lvl_ptr[l];
   std::vector<int> lvl_cols(ncol), cursor(P->lvl_ptr.begin(), P->lvl_ptr.end() - 1);
-  for (int j = 0; j < ncol; ++j) lvl_cols[cursor[level[j]]++] = j;
+  for (int pass = 0; pass < 2; ++pass)
+    for (int j = 0; j < ncol; ++j) if ((int)is_tail[j] == pass) lvl_cols[cursor[level[j]]++] = j;
 
+  if (getenv("SSLAM_CHOL_DUMP")) {
+    for (int l = 0; l < nlev; ++l) {
+      long nbs = 0, ups = 0; int mnb = 0;
+      for (int q = P->lvl_ptr[l]; q < P->lvl_ptr[l + 1]; ++q) {
+        const int j = lvl_cols[q];
+        nbs += bp[j + 1] - bp[j]; mnb = std::max(mnb, bp[j + 1] - bp[j]);
+        ups += up[bp[j + 1]] - up[bp[j]];
+      }
+      fprintf(stderr, "[chol-dump] level %d cols %d blocks %ld maxnb %d updates %ld maxlist %d\n", l, P->lvl_ptr[l + 1] - P->lvl_ptr[l], nbs, mnb, ups, P->lvl_maxlist[l]);
+    }
+  }
   CholView& C = P->C;
   C.ncol = ncol; C.nlevels = nlev; C.dim = 6 * nPr + 3 * nLr;
   P->max_col_entries = max_entries; P->lnz = lnz;
+  std::vector<ColMeta> colm(ncol);
+  std::vector<BlkMeta> blkm(nblk);
+  std::vector<UpdMeta> updm(ua.size());
+  for (int j = 0; j < ncol; ++j) {
+    const int last = bp[j + 1] - 1;
+    int maxlen = 0;
+    for (int t = bp[j]; t < bp[j + 1]; ++t) maxlen = std::max(maxlen, up[t + 1] - up[t]);
+    (void)maxlen;
+    colm[j] = ColMeta{col_xoff[j], col_dim[j], col_graph[j], bp[j], bp[j + 1] - bp[j], boff[bp[j]],
+                      boff[last] - boff[bp[j]] + col_dim[brow[last]] * col_dim[j], up[bp[j]], up[bp[j + 1]] - up[bp[j]], 0};
+    for (int t = bp[j]; t < bp[j + 1]; ++t)
+      blkm[t] = BlkMeta{boff[t], col_dim[brow[t]], bsrc[t], (int)bfmt[t], up[t], up[t + 1], brow[t], col_xoff[brow[t]]};
+  }
+  for (int j = 0; j < ncol; ++j)
+    for (int t = bp[j]; t < bp[j + 1]; ++t) {
+      const int toff = boff[t] - boff[bp[j]];
+      if (toff > kUpdToffMask) return set_error(SSLAM_ERR_UNSUPPORTED, "a factor column has more than 2^20 entries");
+      const int tpk = toff | (col_dim[brow[t]] == 6 ? kUpdDi6 : 0) | (t == bp[j] ? kUpdDiag : 0);
+      for (int u = up[t]; u < up[t + 1]; ++u) updm[u] = UpdMeta{ua[u], ub[u], ux[u], tpk | (udk[u] == 6 ? kUpdDk6 : 0)};
+    }
   int rc;
-  if ((rc = up_to_dev(*P, b.stream, col_xoff, &C.col_xoff))) return rc;
-  if ((rc = up_to_dev(*P, b.stream, col_dim, &C.col_dim))) return rc;
-  if ((rc = up_to_dev(*P, b.stream, col_graph, &C.col_graph))) return rc;
-  if ((rc = up_to_dev(*P, b.stream, bp, &C.bp))) return rc;
-  if ((rc = up_to_dev(*P, b.stream, boff, &C.boff))) return rc;
-  if ((rc = up_to_dev(*P, b.stream, brow, &C.brow))) return rc;
-  if ((rc = up_to_dev(*P, b.stream, bsrc, &C.bsrc))) return rc;
-  if ((rc = up_to_dev(*P, b.stream, bfmt, &C.bfmt))) return rc;
-  if ((rc = up_to_dev(*P, b.stream, up, &C.up))) return rc;
-  if ((rc = up_to_dev(*P, b.stream, ua, &C.ua))) return rc;
-  if ((rc = up_to_dev(*P, b.stream, ub, &C.ub))) return rc;
-  if ((rc = up_to_dev(*P, b.stream, uk, &C.uk))) return rc;
-  if ((rc = up_to_dev(*P, b.stream, ux, &C.ux))) return rc;
-  if ((rc = up_to_dev(*P, b.stream, udk, &C.udk))) return rc;
+  if ((rc = up_to_dev(*P, b.stream, colm, &C.col))) return rc;
+  if ((rc = up_to_dev(*P, b.stream, blkm, &C.blk))) return rc;
+  if ((rc = up_to_dev(*P, b.stream, updm, &C.upd))) return rc;
   if ((rc = up_to_dev(*P, b.stream, lvl_cols, &C.lvl_cols))) return rc;
+  if ((rc = up_to_dev(*P, b.stream, tail_ptr, &C.tail_ptr))) return rc;
+  if ((rc = up_to_dev(*P, b.stream, tail_cols, &C.tail_cols))) return rc;
   void* p = nullptr;
-  SSLAM_HIP_TRY(hipMalloc(&p, std::max<int64_t>(lnz, 1) * sizeof(double))); P->allocs.push_back(p); C.Lval = (double*)p;
-  SSLAM_HIP_TRY(hipMalloc(&p, std::max(C.dim, 1) * sizeof(double))); P->allocs.push_back(p); C.y = (double*)p;
+  SSLAM_HIP_TRY(hipMalloc(&p, (lnz + 64) * sizeof(double))); P->allocs.push_back(p); C.Lval = (double*)p;  // +64: clamped-lane over-reads
+  SSLAM_HIP_TRY(hipMemsetAsync(p, 0, (lnz + 64) * sizeof(double), b.stream));
+  SSLAM_HIP_TRY(hipMalloc(&p, (C.dim + 8) * sizeof(double))); P->allocs.push_back(p); C.y = (double*)p;
+  SSLAM_HIP_TRY(hipMemsetAsync(p, 0, (C.dim + 8) * sizeof(double), b.stream));
   SSLAM_HIP_TRY(hipMalloc(&p, std::max(V.B, 1) * sizeof(int))); P->allocs.push_back(p); C.fail = (int*)p;
   SSLAM_HIP_TRY(hipMemsetAsync(C.fail, 0, std::max(V.B, 1) * sizeof(int), b.stream));
   SSLAM_HIP_TRY(hipStreamSynchronize(b.stream));
@@ -541,20 +651,23 @@ int chol_factor_and_forward(Batch& b) {
   ScopedTimer t(b, "factor");
   hipLaunchKernelGGL(k_chol_begin, dim3((b.V.B + 63) / 64), dim3(64), 0, b.stream, b.V, C);
   // LDS per level: Et entries + partial sums (nslice*Et <= kPartDoubles, nslice <= NW) + NW wave scratch areas
-  auto lds_for = [&](int l, int nw) {
-    const int et = P.lvl_maxEt[l];
-    return (size_t)(et + std::max(et, std::min(kPartDoubles, nw * et)) + nw * 80) * sizeof(double);
+  auto lds_et = [&](int et, int nw) {
+    et = std::max(et, 1);
+    const int nparts = std::max(1, std::min(nw, kPartDoubles / et));
+    return (size_t)(et + nparts * et + nw * kScr) * sizeof(double);
   };
-  size_t lds_max = 0;
+  auto lds_for = [&](int l, int nw) { return lds_et(P.lvl_maxEt[l], nw); };
+  size_t lds_max = lds_et(P.tail_maxEt, 16);
   for (int l = 0; l < C.nlevels; ++l) lds_max = std::max(lds_max, lds_for(l, 16));
   if (lds_max > 160 * 1024) return set_error(SSLAM_ERR_UNSUPPORTED, "a factor column needs %zu B of LDS (> 160 KiB)", lds_max);
   if (lds_max > 64 * 1024) {
     SSLAM_HIP_TRY(hipFuncSetAttribute((const void*)k_chol_level<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
     SSLAM_HIP_TRY(hipFuncSetAttribute((const void*)k_chol_level<256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
     SSLAM_HIP_TRY(hipFuncSetAttribute((const void*)k_chol_level<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
+    SSLAM_HIP_TRY(hipFuncSetAttribute((const void*)k_chol_tail<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
   }
   for (int l = 0; l < C.nlevels; ++l) {
-    const int n = P.lvl_ptr[l + 1] - P.lvl_ptr[l];
+    const int n = P.lvl_nfactor[l];
     if (n <= 0) continue;
     // narrow levels are latency-bound (long update lists -> 16 waves per column); wide levels have enough
     // columns in flight to hide latency and run 4 waves per column
@@ -562,6 +675,7 @@ int chol_factor_and_forward(Batch& b) {
     else if ((P.lvl_maxlist[l] <= 6 && n >= 2048) || n >= 24576) hipLaunchKernelGGL(k_chol_level<64>, dim3(n), dim3(64), lds_for(l, 1), b.stream, b.V, C, P.lvl_ptr[l]);
     else hipLaunchKernelGGL(k_chol_level<256>, dim3(n), dim3(256), lds_for(l, 4), b.stream, b.V, C, P.lvl_ptr[l]);
   }
+  if (P.tail_total > 0) hipLaunchKernelGGL(k_chol_tail<1024>, dim3(b.V.B), dim3(1024), lds_et(P.tail_maxEt, 16), b.stream, b.V, C);
   hipLaunchKernelGGL(k_chol_end, dim3((b.V.B + 63) / 64), dim3(64), 0, b.stream, b.V, C);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return set_error(SSLAM_ERR_HIP, "cholesky factor launch: %s", hipGetErrorString(e));
