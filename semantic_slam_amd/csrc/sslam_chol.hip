@@ -73,49 +73,71 @@ void chol_plan_free(CholPlan* p) {
 // ------------------------------------------------------------------------------------------------
 // kernels
 // ------------------------------------------------------------------------------------------------
-// tail of a column: in-register dense Cholesky of the D x D diagonal block, forward-substituted rhs,
-// triangular solves of the off-diagonal rows
+// tail of a column: wave 0 factors the D x D diagonal block in registers (every lane the same copy) and
+// forward-substitutes the rhs; the other waves pick L_jj and the reciprocal pivots up from LDS and one thread
+// per off-diagonal row solves x L_jj^T = v.  Pivots are inverted once (rsqrt) and multiplied from then on:
+// FP64 sqrt / divide sequences are what the leaf levels of a batch are bound by.
 template <int D, int NT>
-__device__ __forceinline__ void chol_tail(const double* sm, int csize, double* Lw, double* yout, int* fail, int tid) {
-  double a[D * D], t[D];
+__device__ __forceinline__ void chol_tail(double* sm, int csize, double* fac, double* Lw, double* yout, int* fail, int tid) {
+  double a[D * D], inv[D];
+  if (tid < 64) {
+    double t[D];
 #pragma unroll
-  for (int q = 0; q < D * D; ++q) a[q] = sm[q];
+    for (int q = 0; q < D * D; ++q) a[q] = sm[q];
 #pragma unroll
-  for (int q = 0; q < D; ++q) t[q] = sm[csize + q];
-  bool ok = true;
+    for (int q = 0; q < D; ++q) t[q] = sm[csize + q];
+    bool ok = true;
 #pragma unroll
-  for (int c = 0; c < D; ++c) {
-    double d = a[c * D + c];
+    for (int c = 0; c < D; ++c) {
+      double d = a[c * D + c];
 #pragma unroll
-    for (int s = 0; s < c; ++s) d -= a[c * D + s] * a[c * D + s];
-    if (!(d > 0)) { ok = false; d = 1.0; }
-    d = sqrt(d);
-    a[c * D + c] = d;
+      for (int s = 0; s < c; ++s) d -= a[c * D + s] * a[c * D + s];
+      if (!(d > 0)) { ok = false; d = 1.0; }
+      const double id = rsqrt(d);
+      inv[c] = id;
+      a[c * D + c] = d * id;
 #pragma unroll
-    for (int r = c + 1; r < D; ++r) {
-      double x = a[r * D + c];
+      for (int r = c + 1; r < D; ++r) {
+        double x = a[r * D + c];
 #pragma unroll
-      for (int s = 0; s < c; ++s) x -= a[r * D + s] * a[c * D + s];
-      a[r * D + c] = x / d;
+        for (int s = 0; s < c; ++s) x -= a[r * D + s] * a[c * D + s];
+        a[r * D + c] = x * id;
+      }
+#pragma unroll
+      for (int s = c + 1; s < D; ++s) a[c * D + s] = 0.0;  // strict upper = 0
     }
+    if (tid == 0) {
+      if (!ok) *fail = 1;
 #pragma unroll
-    for (int s = c + 1; s < D; ++s) a[c * D + s] = 0.0;  // strict upper = 0
-  }
-  if (tid == 0) {
-    if (!ok) *fail = 1;
+      for (int r = 0; r < D; ++r) {
+        double v = t[r];
 #pragma unroll
-    for (int r = 0; r < D; ++r) {
-      double v = t[r];
+        for (int s = 0; s < r; ++s) v -= a[r * D + s] * t[s];
+        t[r] = v * inv[r];
+      }
 #pragma unroll
-      for (int s = 0; s < r; ++s) v -= a[r * D + s] * t[s];
-      t[r] = v / a[r * D + r];
+      for (int q = 0; q < D * D; ++q) Lw[q] = a[q];
+#pragma unroll
+      for (int q = 0; q < D; ++q) yout[q] = t[q];
+      if (NT > 64) {
+#pragma unroll
+        for (int q = 0; q < D * D; ++q) fac[q] = a[q];
+#pragma unroll
+        for (int q = 0; q < D; ++q) fac[D * D + q] = inv[q];
+      }
     }
-#pragma unroll
-    for (int q = 0; q < D * D; ++q) Lw[q] = a[q];
-#pragma unroll
-    for (int q = 0; q < D; ++q) yout[q] = t[q];
   }
   const int nrows_off = (csize - D * D) / D;
+  if (NT > 64) {
+    if (nrows_off <= 0) return;   // uniform per workgroup
+    __syncthreads();
+    if (tid >= 64 && tid < nrows_off) {
+#pragma unroll
+      for (int q = 0; q < D * D; ++q) a[q] = fac[q];
+#pragma unroll
+      for (int q = 0; q < D; ++q) inv[q] = fac[D * D + q];
+    }
+  }
   for (int row = tid; row < nrows_off; row += NT) {
     const double* v = sm + D * D + row * D;
     double x[D];
@@ -124,7 +146,7 @@ __device__ __forceinline__ void chol_tail(const double* sm, int csize, double* L
       double w = v[c];
 #pragma unroll
       for (int s = 0; s < c; ++s) w -= x[s] * a[c * D + s];
-      x[c] = w / a[c * D + c];
+      x[c] = w * inv[c];
     }
     double* o = Lw + D * D + row * D;
 #pragma unroll
@@ -270,8 +292,8 @@ __device__ __forceinline__ void chol_column(const BatchView& V, const CholView& 
   // ---- diagonal block: every thread factors its own register copy (D^3/3 flops, no LDS latency chain,
   //      no further barriers); then one thread per off-diagonal row solves x L_jj^T = v and stores to HBM
   double* Lw = C.Lval + base;
-  if (dj == 6) chol_tail<6, NT>(sm, csize, Lw, C.y + cm.xoff, C.fail + g, tid);
-  else chol_tail<3, NT>(sm, csize, Lw, C.y + cm.xoff, C.fail + g, tid);
+  if (dj == 6) chol_tail<6, NT>(sm, csize, part, Lw, C.y + cm.xoff, C.fail + g, tid);   // `part` is free again: reuse as L_jj staging
+  else chol_tail<3, NT>(sm, csize, part, Lw, C.y + cm.xoff, C.fail + g, tid);
 }
 
 template <int NT>

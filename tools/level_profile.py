@@ -1,5 +1,5 @@
 """Summarise a rocprofv3 --kernel-trace CSV: per-level durations of the last Cholesky factorisation.
-usage: python tools/level_profile.py <dir with *_kernel_trace.csv>"""
+usage: python tools/level_profile.py <dir with *_kernel_trace.csv> [last|largest]"""
 import csv, glob, sys
 from collections import defaultdict
 
@@ -15,9 +15,10 @@ for r in rows:
         facts.append(cur)
     elif "k_chol_end" in n:
         cur = None
-    elif cur is not None and "k_chol_level" in n:
+    elif cur is not None and ("k_chol_level" in n or "k_chol_tail" in n):
         cur.append((n, int(r["End_Timestamp"]) - int(r["Start_Timestamp"]), int(r["Grid_Size_X"]) if "Grid_Size_X" in r else int(r.get("Grid_Size", 0)), int(r["Workgroup_Size_X"]) if "Workgroup_Size_X" in r else 0, int(r["Start_Timestamp"]), int(r["End_Timestamp"])))
-f = facts[-1]
+which = sys.argv[2] if len(sys.argv) > 2 else 'last'
+f = max(facts, key=lambda x: sum(y[2] for y in x)) if which == 'largest' else facts[-1]
 tot = defaultdict(lambda: [0, 0])
 for n, d, gx, wx, s, e in f:
     k = n[n.find("<"):n.find(">") + 1]
