@@ -353,40 +353,67 @@ __global__ __launch_bounds__(64) void k_chol_forward_level(CholView C, int lvl_b
   }
 }
 
-// backward substitution, one wave per column, levels top-down: x_j = L_jj^-T (y_j - sum_i L_ij^T x_i)
-__global__ __launch_bounds__(64) void k_chol_backward_level(CholView C, int lvl_begin, const double* __restrict__ y, double* __restrict__ x,
-                                                           const LmState* __restrict__ lm) {
-  __shared__ double t[8];
-  const int j = C.lvl_cols[lvl_begin + blockIdx.x];
+// backward substitution of one column by a team of 8 * Q lanes:   x_j = L_jj^-T (y_j - sum_i L_ij^T x_i)
+// lane (c, q): component c of block slice q (blocks 1 + q, 1 + q + Q, ...); the slices are summed with xor
+// shuffles, the back-substitution runs across the 8 component lanes with shuffles; nothing goes through LDS.
+// Q = 8: one column per wave (long columns, latency-bound levels); Q = 1: eight columns per wave (leaf levels).
+template <int Q>
+__device__ __forceinline__ void chol_backward_column(const CholView& C, const int j, const double* __restrict__ y, double* x,
+                                                     const size_t vo, const int lt) {
+  const int c = lt & 7, q = lt >> 3;
   const ColMeta cm = C.col[j];
-  if (lm && !lm[cm.graph].in_trial) return;
-  const size_t vo = (size_t)blockIdx.y * C.dim;
-  const int lane = threadIdx.x;
   const int dj = cm.dim;
   const double* __restrict__ L = C.Lval;
-  const int c = lane & 7, q = lane >> 3;
+  const int cc = min(c, dj - 1);   // idle lanes of the team shadow the last component
+  const double* D = L + cm.base;
   double acc = 0;
-  if (c < dj) {
-    for (int bi = 1 + q; bi < cm.nb; bi += 8) {
-      const BlkMeta bm = C.blk[cm.b0 + bi];
-      const double* Bk = L + bm.off;
-      const double* xi = x + vo + bm.xoff_row;
-      for (int r = 0; r < bm.di; ++r) acc += Bk[r * dj + c] * xi[r];
+  for (int bi = 1 + q; bi < cm.nb; bi += Q) {
+    const BlkMeta bm = C.blk[cm.b0 + bi];
+    const double* Bk = L + bm.off + cc;
+    const double* xi = x + vo + bm.xoff_row;
+    double s = Bk[0] * xi[0] + Bk[dj] * xi[1] + Bk[2 * dj] * xi[2];
+    if (bm.di == 6) s += Bk[3 * dj] * xi[3] + Bk[4 * dj] * xi[4] + Bk[5 * dj] * xi[5];
+    acc += s;
+  }
+  if (Q > 1) acc += __shfl_xor(acc, 8, 64);
+  if (Q > 2) acc += __shfl_xor(acc, 16, 64);
+  if (Q > 4) acc += __shfl_xor(acc, 32, 64);
+  double t = y[vo + cm.xoff + cc] - acc;
+#pragma unroll
+  for (int r = 5; r >= 0; --r) {
+    const int rr = min(r, dj - 1);
+    const double drr = D[rr * dj + rr], drc = D[rr * dj + cc];
+    const double xr = __shfl(t, rr, 8) / drr;
+    if (r < dj) {
+      if (c == r) t = xr;
+      else if (c < r) t -= drc * xr;
     }
   }
-  acc += __shfl_xor(acc, 8, 64);
-  acc += __shfl_xor(acc, 16, 64);
-  acc += __shfl_xor(acc, 32, 64);
-  if (q == 0 && c < dj) t[c] = y[vo + cm.xoff + c] - acc;
-  __syncthreads();
-  if (lane == 0) {
-    const double* D = L + cm.base;
-    for (int r = dj - 1; r >= 0; --r) {
-      double a = t[r];
-      for (int s = r + 1; s < dj; ++s) a -= D[s * dj + r] * t[s];
-      t[r] = a / D[r * dj + r];
-    }
-    for (int r = 0; r < dj; ++r) x[vo + cm.xoff + r] = t[r];
+  if (q == 0 && c < dj) x[vo + cm.xoff + c] = t;
+}
+
+// levels top-down, 64 / (8 Q) columns per wave; blockIdx.y = right-hand side
+template <int Q>
+__global__ __launch_bounds__(64) void k_chol_backward_level(CholView C, int lvl_begin, int n, const double* __restrict__ y, double* x,
+                                                           const LmState* __restrict__ lm) {
+  constexpr int kCols = 8 / Q;
+  const int p = blockIdx.x * kCols + threadIdx.x / (8 * Q);
+  const int j = C.lvl_cols[lvl_begin + min(p, n - 1)];
+  const bool on = p < n && !(lm && !lm[C.col[j].graph].in_trial);
+  if (on) chol_backward_column<Q>(C, j, y, x, (size_t)blockIdx.y * C.dim, threadIdx.x % (8 * Q));
+}
+
+// The top of the elimination tree (the columns k_chol_tail factors) backwards in one launch: one wave per
+// graph walks its tail columns from the root down; a fence orders the x stores of a column before the loads
+// of the next.
+__global__ __launch_bounds__(64) void k_chol_backward_head(CholView C, const double* __restrict__ y, double* x, const LmState* __restrict__ lm) {
+  const int g = blockIdx.x;
+  if (lm && !lm[g].in_trial) return;
+  const size_t vo = (size_t)blockIdx.y * C.dim;
+  const int q0 = C.tail_ptr[g];
+  for (int q = C.tail_ptr[g + 1] - 1; q >= q0; --q) {
+    chol_backward_column<8>(C, C.tail_cols[q], y, x, vo, threadIdx.x);
+    __threadfence_block();   // same wave, same CU: workgroup scope is enough (an agent-scope fence writes back L2)
   }
 }
 
@@ -708,10 +735,12 @@ int chol_backward(Batch& b) {
   CholPlan& P = *b.chol;
   const CholView& C = P.C;
   ScopedTimer t(b, "solve");
+  if (P.tail_total > 0) hipLaunchKernelGGL(k_chol_backward_head, dim3(b.V.B, 1), dim3(64), 0, b.stream, C, (const double*)C.y, b.V.x, (const LmState*)b.V.lm);
   for (int l = C.nlevels - 1; l >= 0; --l) {
-    const int n = P.lvl_ptr[l + 1] - P.lvl_ptr[l];
+    const int n = P.lvl_nfactor[l];
     if (n <= 0) continue;
-    hipLaunchKernelGGL(k_chol_backward_level, dim3(n, 1), dim3(64), 0, b.stream, C, P.lvl_ptr[l], C.y, b.V.x, b.V.lm);
+    if (n >= 4096) hipLaunchKernelGGL(k_chol_backward_level<1>, dim3((n + 7) / 8, 1), dim3(64), 0, b.stream, C, P.lvl_ptr[l], n, (const double*)C.y, b.V.x, (const LmState*)b.V.lm);
+    else hipLaunchKernelGGL(k_chol_backward_level<8>, dim3(n, 1), dim3(64), 0, b.stream, C, P.lvl_ptr[l], n, (const double*)C.y, b.V.x, (const LmState*)b.V.lm);
   }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return set_error(SSLAM_ERR_HIP, "cholesky solve launch: %s", hipGetErrorString(e));
@@ -739,9 +768,10 @@ int chol_solve_multi(Batch& b, const double* rhs_host, int nrhs, double* x_host)
       const int n = P.lvl_ptr[l + 1] - P.lvl_ptr[l];
       if (n > 0) hipLaunchKernelGGL(k_chol_forward_level, dim3(n, nr), dim3(64), 0, b.stream, C, P.lvl_ptr[l], (const double*)P.d_multi_x, P.d_multi_y);
     }
+    if (P.tail_total > 0) hipLaunchKernelGGL(k_chol_backward_head, dim3(b.V.B, nr), dim3(64), 0, b.stream, C, (const double*)P.d_multi_y, P.d_multi_x, (const LmState*)nullptr);
     for (int l = C.nlevels - 1; l >= 0; --l) {
-      const int n = P.lvl_ptr[l + 1] - P.lvl_ptr[l];
-      if (n > 0) hipLaunchKernelGGL(k_chol_backward_level, dim3(n, nr), dim3(64), 0, b.stream, C, P.lvl_ptr[l], (const double*)P.d_multi_y, P.d_multi_x, (const LmState*)nullptr);
+      const int n = P.lvl_nfactor[l];
+      if (n > 0) hipLaunchKernelGGL(k_chol_backward_level<1>, dim3((n + 7) / 8, nr), dim3(64), 0, b.stream, C, P.lvl_ptr[l], n, (const double*)P.d_multi_y, P.d_multi_x, (const LmState*)nullptr);
     }
     SSLAM_HIP_TRY(hipMemcpyAsync(x_host + (size_t)r0 * C.dim, P.d_multi_x, bytes, hipMemcpyDeviceToHost, b.stream));
     SSLAM_HIP_TRY(hipStreamSynchronize(b.stream));
