@@ -40,6 +40,7 @@ struct CholView {
   const BlkMeta* blk;    // [nblk] (blocks of a column are consecutive, diagonal first)
   const UpdMeta* upd;    // update lists, concatenated in block order
   const int* lvl_cols;   // columns grouped by level (within a level: level-scheduled columns first, tail columns last)
+  const ColMeta* lcol;   // col[lvl_cols[.]]: the level kernels start from one load instead of two dependent ones
   const int* tail_ptr;   // [B + 1] per graph: its columns factored by k_chol_tail, in elimination order
   const int* tail_cols;
   double* Lval;
@@ -167,11 +168,11 @@ __device__ __forceinline__ void chol_tail(double* sm, int csize, double* fac, do
 constexpr int kPartDoubles = 12288;  // LDS budget for the per-wave partial columns
 constexpr int kScr = 104;             // doubles of LDS scratch per wave: L_ik at 0, L_jk at 36 (64 lanes written), y_k at 72
 template <int NT>
-__device__ __forceinline__ void chol_column(const BatchView& V, const CholView& C, const int j, double* sm) {
+__device__ __forceinline__ void chol_column(const BatchView& V, const CholView& C, const ColMeta& cm, double* sm) {
   // sm: [Et] column + rhs entries | [nparts][Et] partial columns | [NW][kScr] wave scratch
   constexpr int NW = NT / 64;
-  const ColMeta cm = C.col[j];
   const int g = cm.graph;
+  const int in_trial = V.lm[g].in_trial;   // checked after the update phase: its latency overlaps the source loads
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;  // wave-uniform -> scalar metadata loads
   const int dj = cm.dim, b0 = cm.b0, nb = cm.nb, base = cm.base, csize = cm.csize;
@@ -203,7 +204,7 @@ __device__ __forceinline__ void chol_column(const BatchView& V, const CholView& 
       const int nt = min(64, hi - t0);
       const UpdMeta um = C.upd[cm.ubase + t0 + min(lane, nt - 1)];
       const int mua = um.ua, mub = um.ub, mux = um.ux, mpk = um.pk;
-      constexpr int kRing = 4;
+      constexpr int kRing = NT >= 1024 ? 4 : 2;   // short lists on the wide levels: registers buy occupancy there
       double va[kRing], vb[kRing], vy[kRing];
       int pks[kRing];
 #define SSLAM_CHOL_ISSUE(q, t)                                                                        \
@@ -273,6 +274,7 @@ __device__ __forceinline__ void chol_column(const BatchView& V, const CholView& 
   double av0 = 0, av1 = 0;
   if (wave < nb) av0 = gather(C.blk[b0 + wave], wave == 0);
   if (wave + NW < nb) av1 = gather(C.blk[b0 + wave + NW], false);
+  if (!in_trial) return;   // uniform per workgroup; nothing has been written yet
   __syncthreads();
   for (int bi = wave, it = 0; bi < nb; bi += NW, ++it) {
     const BlkMeta bm = C.blk[b0 + bi];
@@ -299,9 +301,7 @@ __device__ __forceinline__ void chol_column(const BatchView& V, const CholView& 
 template <int NT>
 __global__ __launch_bounds__(NT) void k_chol_level(BatchView V, CholView C, int lvl_begin) {
   extern __shared__ double sm[];
-  const int j = C.lvl_cols[lvl_begin + blockIdx.x];
-  if (!V.lm[C.col[j].graph].in_trial) return;
-  chol_column<NT>(V, C, j, sm);
+  chol_column<NT>(V, C, C.lcol[lvl_begin + blockIdx.x], sm);
 }
 
 // Top of the elimination tree: once a graph's levels are at most a couple of columns wide, a launch per level
@@ -314,7 +314,7 @@ __global__ __launch_bounds__(NT) void k_chol_tail(BatchView V, CholView C) {
   if (!V.lm[g].in_trial) return;
   const int q1 = C.tail_ptr[g + 1];
   for (int q = C.tail_ptr[g]; q < q1; ++q) {
-    chol_column<NT>(V, C, C.tail_cols[q], sm);
+    chol_column<NT>(V, C, C.col[C.tail_cols[q]], sm);
     __threadfence_block();
     __syncthreads();
   }
@@ -678,6 +678,9 @@ int chol_plan_build(Batch& b) {
   if ((rc = up_to_dev(*P, b.stream, blkm, &C.blk))) return rc;
   if ((rc = up_to_dev(*P, b.stream, updm, &C.upd))) return rc;
   if ((rc = up_to_dev(*P, b.stream, lvl_cols, &C.lvl_cols))) return rc;
+  std::vector<ColMeta> lcolm(ncol);
+  for (int q = 0; q < ncol; ++q) lcolm[q] = colm[lvl_cols[q]];
+  if ((rc = up_to_dev(*P, b.stream, lcolm, &C.lcol))) return rc;
   if ((rc = up_to_dev(*P, b.stream, tail_ptr, &C.tail_ptr))) return rc;
   if ((rc = up_to_dev(*P, b.stream, tail_cols, &C.tail_cols))) return rc;
   void* p = nullptr;
