@@ -25,10 +25,14 @@ namespace sslam {
 
 // Packed per-column / per-block / per-update records: one 16/32-byte load each instead of a chain of
 // dependent 4-byte loads (a narrow level is a single workgroup whose run time is that chain).
-struct ColMeta { int xoff, dim, graph, b0, nb, base, csize, ubase, ucount, pad; };  // base = Lval offset of the diagonal block;
-                                                                                    // [ubase, ubase + ucount) = the column's updates
-struct BlkMeta { int off, di, src, fmt, up0, up1, rowcol, xoff_row; };   // src: H offset or -1; rowcol: column id of the row
+struct ColMeta { int xoff, dim, graph, b0, nb, base, csize, ubase, ucount, ibase, icount, chunk; };  // base = Lval offset of the diagonal block;
+                                                     // [ubase, ubase + ucount) = the column's updates,
+                                                     // [ibase, ibase + icount) = its work items of <= chunk updates each
+struct BlkMeta { int off, di, src, fmt, up0, up1, rowcol, xoff_row, it0, nit; };   // src: H offset or -1; rowcol: column id of the
+                                                                                   // row; [it0, it0 + nit) = items of this block
 struct UpdMeta { int ua, ub, ux, pk; };                                  // offsets of L_ik, L_jk, y_k; pk = target descriptor:
+struct ItemMeta { UpdMeta first; int u0, n, pad0, pad1; };               // <= chunk consecutive updates of ONE target block; the
+                                                                         // first update rides along (one dependent load less)
 constexpr int kUpdToffMask = 0xFFFFF;   // pk bits 0..19: offset of the target block inside its column
 constexpr int kUpdDi6 = 1 << 20;        // target block has 6 rows (else 3)
 constexpr int kUpdDk6 = 1 << 21;        // source column k is 6 wide (else 3)
@@ -39,6 +43,7 @@ struct CholView {
   const ColMeta* col;    // [ncol]
   const BlkMeta* blk;    // [nblk] (blocks of a column are consecutive, diagonal first)
   const UpdMeta* upd;    // update lists, concatenated in block order
+  const ItemMeta* item;  // work items, concatenated in block order
   const int* lvl_cols;   // columns grouped by level (within a level: level-scheduled columns first, tail columns last)
   const ColMeta* lcol;   // col[lvl_cols[.]]: the level kernels start from one load instead of two dependent ones
   const int* tail_ptr;   // [B + 1] per graph: its columns factored by k_chol_tail, in elimination order
@@ -55,6 +60,7 @@ struct CholPlan {
   int tail_maxEt = 0, tail_total = 0;
   std::vector<int> lvl_maxlist;  // longest update list among the level's blocks
   std::vector<int> lvl_maxEt;    // largest column (entries + rhs) of the level
+  std::vector<int> lvl_maxItemLds;  // most LDS doubles a column of the level needs under the item scheme; tail_maxEt likewise
   std::vector<void*> allocs;
   int max_col_entries = 0;
   int64_t lnz = 0;
@@ -159,105 +165,191 @@ __device__ __forceinline__ void chol_tail(double* sm, int csize, double* fac, do
 // top levels, which are a single column whose run time is a chain of dependent memory latencies):
 //   S = A(:,j) + lambda I - sum_k L(:,k) L(j,k)^T,   L(j,j) = chol(S(j,j)),   L(i,j) = S(i,j) L(j,j)^-T,
 //   y(j) = L(j,j)^-1 (b(j) - sum_k L(j,k) y(k))                      (forward substitution fused)
-// The column's updates form one flat list sorted by target block; wave w owns a contiguous range of it.
-// The range's records are fetched 64 at a time (one per lane) and broadcast with readlane, so the only
-// latency left on the per-update chain is the source-block load, which runs kRing updates ahead.  For every
-// update the wave parks the two source blocks in its LDS scratch and the di x dj entry lanes read rows from
-// LDS (broadcast).  When the target changes the wave flushes its partial block to its own LDS copy of the
-// column; the copies are reduced in wave order -> deterministic.
+// The updates of a column are cut (on the host) into work items of <= chunk consecutive updates of one target
+// block, so that a 1024-thread workgroup has an item for each of its 256 four-lane slots.  A slot keeps the
+// 3 x 3 tiles of the target in registers (lane = tile (tr, tc)): per update each lane reads its 3 rows of L_ik
+// and of L_jk straight from global memory (contiguous 3 dk doubles each) and does 9 dk FMAs -- no LDS staging,
+// no cross-lane traffic.  The item's tile goes to its own LDS slot; the slots of a block are summed in item
+// order -> deterministic.
+typedef double d2u __attribute__((ext_vector_type(2), aligned(8)));
+constexpr int kItemDoubles = 42;   // LDS doubles per item: 6 x 6 tile entries + 6 rhs components
+constexpr int kItemsPerColumn = 256;
+// Wide levels (NT < 1024: many columns in flight, short lists) use the other update scheme instead: the column's
+// updates form one flat list sorted by target block and wave w owns a contiguous range of it.  The range's
+// records are fetched 64 at a time (one per lane) and broadcast with readlane; per update the wave parks L_ik,
+// L_jk and y_k in its LDS scratch and the di x dj entry lanes read rows from LDS (broadcast).  When the target
+// changes the wave flushes its partial block to its own LDS copy of the column; the copies are reduced in wave
+// order.  Fewer registers (occupancy) and no redundant tile loads, but LDS-bandwidth bound on long lists.
 constexpr int kPartDoubles = 12288;  // LDS budget for the per-wave partial columns
 constexpr int kScr = 104;             // doubles of LDS scratch per wave: L_ik at 0, L_jk at 36 (64 lanes written), y_k at 72
 template <int NT>
 __device__ __forceinline__ void chol_column(const BatchView& V, const CholView& C, const ColMeta& cm, double* sm) {
-  // sm: [Et] column + rhs entries | [nparts][Et] partial columns | [NW][kScr] wave scratch
+  // ITEMS: sm = [Et] column + rhs entries | [icount][kItemDoubles] item partials (the first one doubles as L_jj staging)
+  // else:  sm = [Et] column + rhs entries | [nparts][Et] partial columns | [NW][kScr] wave scratch
   constexpr int NW = NT / 64;
+  constexpr bool ITEMS = NT >= 1024;
   const int g = cm.graph;
   const int in_trial = V.lm[g].in_trial;   // checked after the update phase: its latency overlaps the source loads
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;  // wave-uniform -> scalar metadata loads
   const int dj = cm.dim, b0 = cm.b0, nb = cm.nb, base = cm.base, csize = cm.csize;
   const int Et = csize + dj;  // the last dj "entries" are the forward-substitution rhs
-  const int U = cm.ucount;
-  const int nparts = max(1, min(min(NW, (U + 7) >> 3), kPartDoubles / Et));
-  const int per = (U + nparts - 1) / nparts;
   const double lambda = V.lm[g].lambda;
   const double* __restrict__ H = V.Hpp_diag;
   const double* __restrict__ L = C.Lval;
   const double* __restrict__ Y = C.y;
   double* part = sm + Et;
-  double* scr = sm + Et + nparts * Et + wave * kScr;
   const int r = lane / dj, c = lane - r * dj;          // entry lanes: lane < di * dj
   const int ry = lane - 40;                            // rhs lanes: 40 .. 40 + dj - 1 (diagonal block only)
-  if (wave < nparts && wave * per < U) {
-    // Per update the wave loads L_ik, L_jk and y_k with three uniform-base loads (idle lanes re-read the last
-    // element: no branches around loads, or the compiler waits for vmcnt(0) at every use and the ring
-    // serialises), parks them at fixed LDS offsets 0 / 36 / 72 and every lane forms one dot product
-    // row(A) . row(B or y).  Lane roles (rows, flush slot) only change when the target block changes.
-    const int lo = wave * per, hi = min(U, lo + per);
-    double* mypart = part + wave * Et;
-    const int lo36 = min(lane, 35), lo6 = min(lane, 5);
-    double acc = 0;
-    int cur = -1;            // descriptor of the target being accumulated
-    bool active = false;     // lane owns an entry (or rhs component) of the target
-    int a3 = 0, a6 = 0, b3 = 0, b6 = 0, foff = 0;
-    for (int t0 = lo; t0 < hi; t0 += 64) {
-      const int nt = min(64, hi - t0);
-      const UpdMeta um = C.upd[cm.ubase + t0 + min(lane, nt - 1)];
-      const int mua = um.ua, mub = um.ub, mux = um.ux, mpk = um.pk;
-      constexpr int kRing = NT >= 1024 ? 4 : 2;   // short lists on the wide levels: registers buy occupancy there
-      double va[kRing], vb[kRing], vy[kRing];
-      int pks[kRing];
-#define SSLAM_CHOL_ISSUE(q, t)                                                                        \
-  {                                                                                                   \
-    const int tt_ = min((t), nt - 1);                                                                 \
-    const double* A_ = L + __builtin_amdgcn_readlane(mua, tt_);                                       \
-    const double* B_ = L + __builtin_amdgcn_readlane(mub, tt_);                                       \
-    const double* Y_ = Y + __builtin_amdgcn_readlane(mux, tt_);                                       \
-    pks[q] = __builtin_amdgcn_readlane(mpk, tt_);                                                     \
-    va[q] = A_[lo36];                                                                                 \
-    vb[q] = B_[lo36];                                                                                 \
-    vy[q] = Y_[lo6];                                                                                  \
-  }
+  const int U = cm.ucount;
+  const int nparts = max(1, min(min(NW, (U + 7) >> 3), kPartDoubles / Et));
+  const int per = (U + nparts - 1) / nparts;
+  if (ITEMS) {
+    const int tr = (lane >> 1) & 1, tc = lane & 1;
+    const int icount = cm.icount, chunk = cm.chunk;
+    for (int it0 = wave * 16; it0 < icount; it0 += NT / 4) {     // wave-uniform bound
+      const int it = it0 + (lane >> 2);
+      const bool have = it < icount;
+      const ItemMeta im = C.item[cm.ibase + min(it, icount - 1)];
+      const int tpk = im.first.pk;
+      const int di = (tpk & kUpdDi6) ? 6 : 3;
+      const bool diag = tpk & kUpdDiag;
+      const bool tile = have && 3 * tr < di && 3 * tc < dj;
+      const int tre = 3 * tr < di ? tr : 0, tce = 3 * tc < dj ? tc : 0;   // idle lanes shadow tile (0, 0): valid addresses
+      double acc[9], accy[3];
 #pragma unroll
-      for (int q = 0; q < kRing; ++q) SSLAM_CHOL_ISSUE(q, q)
-      for (int t = 0; t < nt; t += kRing) {
+      for (int q = 0; q < 9; ++q) acc[q] = 0;
 #pragma unroll
-        for (int q = 0; q < kRing; ++q) {
-          const bool live = t + q < nt;
-          const int pk = pks[q];
-          if (live) {
-            if ((pk & kUpdToffMask) != (cur & kUpdToffMask) || cur < 0) {
-              if (cur >= 0 && active) mypart[foff] = acc;
-              cur = pk; acc = 0;
-              const int nE = ((pk & kUpdDi6) ? 6 : 3) * dj;
-              const bool isrhs = lane >= nE;
-              active = !isrhs || ((pk & kUpdDiag) && ry >= 0 && ry < dj);
-              const int row = isrhs ? max(min(ry, 5), 0) : min(r, 5);
-              a3 = row * 3; a6 = row * 6;
-              b3 = isrhs ? 72 : 36 + c * 3; b6 = isrhs ? 72 : 36 + c * 6;
-              foff = isrhs ? csize + ry : (pk & kUpdToffMask) + lane;
-            }
-            scr[lane] = va[q];
-            scr[36 + lane] = vb[q];
-            if (lane < 6) scr[72 + lane] = vy[q];
+      for (int q = 0; q < 3; ++q) accy[q] = 0;
+      UpdMeta um = im.first;
+      for (int k = 0; k < chunk; ++k) {
+        const bool live = k < im.n;
+        const UpdMeta nx = C.upd[im.u0 + min(k + 1, im.n - 1)];    // next update of the item (re-reads the last one at the end)
+        const int dk = (um.pk & kUpdDk6) ? 6 : 3;
+        const double* A = L + um.ua + 3 * tre * dk;
+        const double* B = L + um.ub + 3 * tce * dk;
+        const double* yk = Y + um.ux;
+        double a[18], bb[18], yv[6];
+        if (dk == 6) {
+#pragma unroll
+          for (int q = 0; q < 9; ++q) {
+            const d2u va = *(const d2u*)(A + 2 * q), vb = *(const d2u*)(B + 2 * q);
+            a[2 * q] = va.x; a[2 * q + 1] = va.y; bb[2 * q] = vb.x; bb[2 * q + 1] = vb.y;
           }
-          SSLAM_CHOL_ISSUE(q, t + q + kRing)
-          if (live) {
-            if (pk & kUpdDk6) {
-              const double* pa = scr + a6;
-              const double* pb = scr + b6;
-              acc += pa[0] * pb[0] + pa[1] * pb[1] + pa[2] * pb[2] + pa[3] * pb[3] + pa[4] * pb[4] + pa[5] * pb[5];
-            } else {
-              const double* pa = scr + a3;
-              const double* pb = scr + b3;
-              acc += pa[0] * pb[0] + pa[1] * pb[1] + pa[2] * pb[2];
+#pragma unroll
+          for (int q = 0; q < 6; ++q) yv[q] = yk[q];
+        } else {   // 3-wide source column: rows of 3, zero-padded to 6
+#pragma unroll
+          for (int rr = 0; rr < 3; ++rr)
+#pragma unroll
+            for (int q = 0; q < 6; ++q) {
+              a[rr * 6 + q] = q < 3 ? A[rr * 3 + q] : 0.0;
+              bb[rr * 6 + q] = q < 3 ? B[rr * 3 + q] : 0.0;
+            }
+#pragma unroll
+          for (int q = 0; q < 6; ++q) yv[q] = q < 3 ? yk[q] : 0.0;
+        }
+        if (live) {
+#pragma unroll
+          for (int rr = 0; rr < 3; ++rr) {
+#pragma unroll
+            for (int cc = 0; cc < 3; ++cc) {
+              double d = acc[rr * 3 + cc];
+#pragma unroll
+              for (int q = 0; q < 6; ++q) d += a[rr * 6 + q] * bb[cc * 6 + q];
+              acc[rr * 3 + cc] = d;
+            }
+            double d = accy[rr];
+#pragma unroll
+            for (int q = 0; q < 6; ++q) d += a[rr * 6 + q] * yv[q];
+            accy[rr] = d;
+          }
+        }
+        um = nx;
+      }
+      if (tile) {
+        double* o = part + it * kItemDoubles;
+#pragma unroll
+        for (int rr = 0; rr < 3; ++rr) {
+#pragma unroll
+          for (int cc = 0; cc < 3; ++cc) o[(3 * tr + rr) * dj + 3 * tc + cc] = acc[rr * 3 + cc];
+          if (diag && tc == 0) o[36 + 3 * tr + rr] = accy[rr];
+        }
+      }
+    }
+  } else {
+    double* scr = sm + Et + nparts * Et + wave * kScr;
+    if (wave < nparts && wave * per < U) {
+      // Per update the wave loads L_ik, L_jk and y_k with three uniform-base loads (idle lanes re-read the last
+      // element: no branches around loads, or the compiler waits for vmcnt(0) at every use and the ring
+      // serialises), parks them at fixed LDS offsets 0 / 36 / 72 and every lane forms one dot product
+      // row(A) . row(B or y).  Lane roles (rows, flush slot) only change when the target block changes.
+      const int lo = wave * per, hi = min(U, lo + per);
+      double* mypart = part + wave * Et;
+      const int lo36 = min(lane, 35), lo6 = min(lane, 5);
+      double acc = 0;
+      int cur = -1;            // descriptor of the target being accumulated
+      bool active = false;     // lane owns an entry (or rhs component) of the target
+      int a3 = 0, a6 = 0, b3 = 0, b6 = 0, foff = 0;
+      for (int t0 = lo; t0 < hi; t0 += 64) {
+        const int nt = min(64, hi - t0);
+        const UpdMeta um = C.upd[cm.ubase + t0 + min(lane, nt - 1)];
+        const int mua = um.ua, mub = um.ub, mux = um.ux, mpk = um.pk;
+        constexpr int kRing = NT >= 1024 ? 4 : 2;   // short lists on the wide levels: registers buy occupancy there
+        double va[kRing], vb[kRing], vy[kRing];
+        int pks[kRing];
+#define SSLAM_CHOL_ISSUE(q, t)                                                                        \
+    {                                                                                                   \
+      const int tt_ = min((t), nt - 1);                                                                 \
+      const double* A_ = L + __builtin_amdgcn_readlane(mua, tt_);                                       \
+      const double* B_ = L + __builtin_amdgcn_readlane(mub, tt_);                                       \
+      const double* Y_ = Y + __builtin_amdgcn_readlane(mux, tt_);                                       \
+      pks[q] = __builtin_amdgcn_readlane(mpk, tt_);                                                     \
+      va[q] = A_[lo36];                                                                                 \
+      vb[q] = B_[lo36];                                                                                 \
+      vy[q] = Y_[lo6];                                                                                  \
+    }
+#pragma unroll
+        for (int q = 0; q < kRing; ++q) SSLAM_CHOL_ISSUE(q, q)
+        for (int t = 0; t < nt; t += kRing) {
+#pragma unroll
+          for (int q = 0; q < kRing; ++q) {
+            const bool live = t + q < nt;
+            const int pk = pks[q];
+            if (live) {
+              if ((pk & kUpdToffMask) != (cur & kUpdToffMask) || cur < 0) {
+                if (cur >= 0 && active) mypart[foff] = acc;
+                cur = pk; acc = 0;
+                const int nE = ((pk & kUpdDi6) ? 6 : 3) * dj;
+                const bool isrhs = lane >= nE;
+                active = !isrhs || ((pk & kUpdDiag) && ry >= 0 && ry < dj);
+                const int row = isrhs ? max(min(ry, 5), 0) : min(r, 5);
+                a3 = row * 3; a6 = row * 6;
+                b3 = isrhs ? 72 : 36 + c * 3; b6 = isrhs ? 72 : 36 + c * 6;
+                foff = isrhs ? csize + ry : (pk & kUpdToffMask) + lane;
+              }
+              scr[lane] = va[q];
+              scr[36 + lane] = vb[q];
+              if (lane < 6) scr[72 + lane] = vy[q];
+            }
+            SSLAM_CHOL_ISSUE(q, t + q + kRing)
+            if (live) {
+              if (pk & kUpdDk6) {
+                const double* pa = scr + a6;
+                const double* pb = scr + b6;
+                acc += pa[0] * pb[0] + pa[1] * pb[1] + pa[2] * pb[2] + pa[3] * pb[3] + pa[4] * pb[4] + pa[5] * pb[5];
+              } else {
+                const double* pa = scr + a3;
+                const double* pb = scr + b3;
+                acc += pa[0] * pb[0] + pa[1] * pb[1] + pa[2] * pb[2];
+              }
             }
           }
         }
-      }
 #undef SSLAM_CHOL_ISSUE
+      }
+      if (cur >= 0 && active) mypart[foff] = acc;
     }
-    if (cur >= 0 && active) mypart[foff] = acc;
   }
   // A(:,j) + lambda I and the rhs, one wave per block (lanes as above).  The loads of the first two blocks
   // of every wave are issued before the barrier so that their latency overlaps the update phase of the others.
@@ -281,9 +373,12 @@ __device__ __forceinline__ void chol_column(const BatchView& V, const CholView& 
     const bool diag = (bi == 0);
     double v = it == 0 ? av0 : (it == 1 ? av1 : gather(bm, diag));
     const bool ent = lane < bm.di * dj, rhs = diag && ry >= 0 && ry < dj;
-    const int e = ent ? (bm.off - base) + lane : csize + ry;
     if (ent || rhs) {
-      if (bm.up1 > bm.up0) {
+      const int e = ent ? (bm.off - base) + lane : csize + ry;
+      if (ITEMS) {
+        const double* p = part + (bm.it0 - cm.ibase) * kItemDoubles + (ent ? lane : 36 + ry);
+        for (int q = 0; q < bm.nit; ++q) v -= p[q * kItemDoubles];
+      } else if (bm.up1 > bm.up0) {
         const int wf = (bm.up0 - cm.ubase) / per, wl = (bm.up1 - 1 - cm.ubase) / per;
         for (int w = wf; w <= wl; ++w) v -= part[w * Et + e];
       }
@@ -291,8 +386,8 @@ __device__ __forceinline__ void chol_column(const BatchView& V, const CholView& 
     }
   }
   __syncthreads();
-  // ---- diagonal block: every thread factors its own register copy (D^3/3 flops, no LDS latency chain,
-  //      no further barriers); then one thread per off-diagonal row solves x L_jj^T = v and stores to HBM
+  // ---- diagonal block: wave 0 factors it in registers; then one thread per off-diagonal row solves
+  //      x L_jj^T = v and stores to HBM
   double* Lw = C.Lval + base;
   if (dj == 6) chol_tail<6, NT>(sm, csize, part, Lw, C.y + cm.xoff, C.fail + g, tid);   // `part` is free again: reuse as L_jj staging
   else chol_tail<3, NT>(sm, csize, part, Lw, C.y + cm.xoff, C.fail + g, tid);
@@ -595,7 +690,8 @@ int chol_plan_build(Batch& b) {
     nlev = std::max(nlev, level[j] + 1);
   }
   // tail of every graph: the levels from which on the graph is at most `tail_width` columns wide
-  int tail_width = 2;
+  // (a batch keeps every level launch busy with other graphs' columns for longer, so its tails start lower)
+  int tail_width = V.B >= 32 ? 4 : 2;
   if (const char* e = getenv("SSLAM_CHOL_TAIL_WIDTH")) tail_width = atoi(e);
   std::vector<char> is_tail(ncol, 0);
   std::vector<int> tail_ptr(V.B + 1, 0), tail_cols;
@@ -619,14 +715,6 @@ int chol_plan_build(Batch& b) {
     }
   }
   P->tail_total = (int)tail_cols.size();
-  P->lvl_maxEt.assign(nlev, 0);
-  P->tail_maxEt = 0;
-  for (int j = 0; j < ncol; ++j) {
-    const int last = bp[j + 1] - 1;
-    const int cs = boff[last] - boff[bp[j]] + col_dim[brow[last]] * col_dim[j];
-    if (is_tail[j]) P->tail_maxEt = std::max(P->tail_maxEt, cs + col_dim[j]);
-    else P->lvl_maxEt[level[j]] = std::max(P->lvl_maxEt[level[j]], cs + col_dim[j]);
-  }
   P->lvl_maxlist.assign(nlev, 0);
   for (int j = 0; j < ncol; ++j)
     if (!is_tail[j])
@@ -656,16 +744,7 @@ int chol_plan_build(Batch& b) {
   std::vector<ColMeta> colm(ncol);
   std::vector<BlkMeta> blkm(nblk);
   std::vector<UpdMeta> updm(ua.size());
-  for (int j = 0; j < ncol; ++j) {
-    const int last = bp[j + 1] - 1;
-    int maxlen = 0;
-    for (int t = bp[j]; t < bp[j + 1]; ++t) maxlen = std::max(maxlen, up[t + 1] - up[t]);
-    (void)maxlen;
-    colm[j] = ColMeta{col_xoff[j], col_dim[j], col_graph[j], bp[j], bp[j + 1] - bp[j], boff[bp[j]],
-                      boff[last] - boff[bp[j]] + col_dim[brow[last]] * col_dim[j], up[bp[j]], up[bp[j + 1]] - up[bp[j]], 0};
-    for (int t = bp[j]; t < bp[j + 1]; ++t)
-      blkm[t] = BlkMeta{boff[t], col_dim[brow[t]], bsrc[t], (int)bfmt[t], up[t], up[t + 1], brow[t], col_xoff[brow[t]]};
-  }
+  std::vector<ItemMeta> itemm;
   for (int j = 0; j < ncol; ++j)
     for (int t = bp[j]; t < bp[j + 1]; ++t) {
       const int toff = boff[t] - boff[bp[j]];
@@ -673,10 +752,38 @@ int chol_plan_build(Batch& b) {
       const int tpk = toff | (col_dim[brow[t]] == 6 ? kUpdDi6 : 0) | (t == bp[j] ? kUpdDiag : 0);
       for (int u = up[t]; u < up[t + 1]; ++u) updm[u] = UpdMeta{ua[u], ub[u], ux[u], tpk | (udk[u] == 6 ? kUpdDk6 : 0)};
     }
+  std::vector<int> col_lds(ncol, 0), col_et(ncol, 0);   // LDS doubles the column needs with items; entries + rhs
+  for (int j = 0; j < ncol; ++j) {
+    const int last = bp[j + 1] - 1;
+    const int U = up[bp[j + 1]] - up[bp[j]];
+    const int chunk = std::max(1, (U + kItemsPerColumn - 1) / kItemsPerColumn);
+    const int ibase = (int)itemm.size();
+    for (int t = bp[j]; t < bp[j + 1]; ++t) {
+      const int it0 = (int)itemm.size();
+      for (int u = up[t]; u < up[t + 1]; u += chunk) itemm.push_back(ItemMeta{updm[u], u, std::min(chunk, up[t + 1] - u), 0, 0});
+      blkm[t] = BlkMeta{boff[t], col_dim[brow[t]], bsrc[t], (int)bfmt[t], up[t], up[t + 1], brow[t], col_xoff[brow[t]], it0, (int)itemm.size() - it0};
+    }
+    const int icount = (int)itemm.size() - ibase;
+    const int csize = boff[last] - boff[bp[j]] + col_dim[brow[last]] * col_dim[j];
+    colm[j] = ColMeta{col_xoff[j], col_dim[j], col_graph[j], bp[j], bp[j + 1] - bp[j], boff[bp[j]], csize, up[bp[j]], U, ibase, icount, chunk};
+    col_lds[j] = csize + col_dim[j] + std::max(icount, 1) * kItemDoubles;
+    col_et[j] = csize + col_dim[j];
+  }
+  P->lvl_maxEt.assign(nlev, 0);
+  P->lvl_maxItemLds.assign(nlev, 0);
+  P->tail_maxEt = 0;
+  for (int j = 0; j < ncol; ++j) {
+    if (is_tail[j]) P->tail_maxEt = std::max(P->tail_maxEt, col_lds[j]);
+    else {
+      P->lvl_maxEt[level[j]] = std::max(P->lvl_maxEt[level[j]], col_et[j]);
+      P->lvl_maxItemLds[level[j]] = std::max(P->lvl_maxItemLds[level[j]], col_lds[j]);
+    }
+  }
   int rc;
   if ((rc = up_to_dev(*P, b.stream, colm, &C.col))) return rc;
   if ((rc = up_to_dev(*P, b.stream, blkm, &C.blk))) return rc;
   if ((rc = up_to_dev(*P, b.stream, updm, &C.upd))) return rc;
+  if ((rc = up_to_dev(*P, b.stream, itemm, &C.item))) return rc;
   if ((rc = up_to_dev(*P, b.stream, lvl_cols, &C.lvl_cols))) return rc;
   std::vector<ColMeta> lcolm(ncol);
   for (int q = 0; q < ncol; ++q) lcolm[q] = colm[lvl_cols[q]];
@@ -702,15 +809,17 @@ int chol_factor_and_forward(Batch& b) {
   const CholView& C = P.C;
   ScopedTimer t(b, "factor");
   hipLaunchKernelGGL(k_chol_begin, dim3((b.V.B + 63) / 64), dim3(64), 0, b.stream, b.V, C);
-  // LDS per level: Et entries + partial sums (nslice*Et <= kPartDoubles, nslice <= NW) + NW wave scratch areas
+  // LDS per level: item scheme (16 waves): entries + rhs + item partials; flat scheme: Et entries + per-wave partial
+  // columns (nparts * Et <= kPartDoubles, nparts <= NW) + NW wave scratch areas
+  auto lds_items = [&](int doubles) { return (size_t)std::max(doubles, 64) * sizeof(double); };
   auto lds_et = [&](int et, int nw) {
     et = std::max(et, 1);
     const int nparts = std::max(1, std::min(nw, kPartDoubles / et));
     return (size_t)(et + nparts * et + nw * kScr) * sizeof(double);
   };
-  auto lds_for = [&](int l, int nw) { return lds_et(P.lvl_maxEt[l], nw); };
-  size_t lds_max = lds_et(P.tail_maxEt, 16);
-  for (int l = 0; l < C.nlevels; ++l) lds_max = std::max(lds_max, lds_for(l, 16));
+  auto lds_for = [&](int l, int nw) { return nw >= 16 ? lds_items(P.lvl_maxItemLds[l]) : lds_et(P.lvl_maxEt[l], nw); };
+  size_t lds_max = lds_items(P.tail_maxEt);
+  for (int l = 0; l < C.nlevels; ++l) lds_max = std::max(lds_max, std::max(lds_for(l, 16), lds_for(l, 4)));
   if (lds_max > 160 * 1024) return set_error(SSLAM_ERR_UNSUPPORTED, "a factor column needs %zu B of LDS (> 160 KiB)", lds_max);
   if (lds_max > 64 * 1024) {
     SSLAM_HIP_TRY(hipFuncSetAttribute((const void*)k_chol_level<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
@@ -727,7 +836,7 @@ int chol_factor_and_forward(Batch& b) {
     else if ((P.lvl_maxlist[l] <= 6 && n >= 2048) || n >= 24576) hipLaunchKernelGGL(k_chol_level<64>, dim3(n), dim3(64), lds_for(l, 1), b.stream, b.V, C, P.lvl_ptr[l]);
     else hipLaunchKernelGGL(k_chol_level<256>, dim3(n), dim3(256), lds_for(l, 4), b.stream, b.V, C, P.lvl_ptr[l]);
   }
-  if (P.tail_total > 0) hipLaunchKernelGGL(k_chol_tail<1024>, dim3(b.V.B), dim3(1024), lds_et(P.tail_maxEt, 16), b.stream, b.V, C);
+  if (P.tail_total > 0) hipLaunchKernelGGL(k_chol_tail<1024>, dim3(b.V.B), dim3(1024), lds_items(P.tail_maxEt), b.stream, b.V, C);
   hipLaunchKernelGGL(k_chol_end, dim3((b.V.B + 63) / 64), dim3(64), 0, b.stream, b.V, C);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return set_error(SSLAM_ERR_HIP, "cholesky factor launch: %s", hipGetErrorString(e));
