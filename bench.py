@@ -37,6 +37,7 @@ def main():
     ap.add_argument("--solver", type=int, default=-1, help="-1 library default, 0 PCG, 1 sparse Cholesky")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-frontend", action="store_true")
+    ap.add_argument("--no-single", action="store_true", help="skip the single-graph latency section (used under rocprofv3 --pmc)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -132,12 +133,20 @@ def main():
         fbytes = batch.info("factor_bytes")
         ms = ktimes["factor"][0] / ktimes["factor"][1]
         gbs = fbytes / (ms * 1e-3) / 1e9
-        roofline = {"bound": "hbm", "kernel": "block_cholesky_factor (level-scheduled k_chol_level launches of one numeric factorisation)",
+        roofline = {"bound": "hbm", "kernel": "block_cholesky_factor (k_chol_level launches per elimination-tree level + k_chol_tail "
+                                              "of one numeric factorisation)",
                     "achieved": round(gbs, 2), "peak": 8000.0, "unit": "GB/s", "frac": round(gbs / 8000.0, 4), "traffic": None,
                     "bytes_per_launch": int(fbytes), "ms_per_launch": round(ms, 4), "launches": ktimes["factor"][1],
                     "levels": int(batch.info("factor_levels")), "factor_doubles": int(batch.info("factor_lnz")),
-                    "note": "one 'launch' = the dependent chain of per-level kernels of one factorisation; latency / L2-issue bound, "
-                            "algorithmic bytes = read H,b + write L,y once"}
+                    "note": "one 'launch' = the dependent chain of kernels of one factorisation; latency / instruction-issue bound "
+                            "(6x6 blocks), algorithmic bytes = read H,b + write L,y once"}
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r1_pmc_factor.json")))
+            if pmc.get("algorithmic_bytes") == int(fbytes):
+                roofline["traffic"] = int(pmc["hbm_bytes_fetch_x2"])
+                roofline["traffic_raw_counters"] = int(pmc["hbm_bytes_raw"])
+        except (OSError, ValueError):
+            pass
     if dominant == "spmv" and ktimes["spmv"][1] > 0:
         # H bytes + 3 vectors x 8*dim per block-SpMV
         Np, Nl = args.poses - 1, args.landmarks
@@ -167,15 +176,16 @@ def main():
     }
 
     if rank == 0:
-        # ---- single-graph latency (same graph, batch of one) ---------------------------------------
-        one = GraphSLAM(False, dev); one.load(paths[0])
-        if args.solver >= 0:
-            one.set_option("solver", args.solver)
-        b1 = GraphBatch([one]); b1.upload(); b1.optimize(1); b1.upload()
-        t1 = time.perf_counter(); s1 = b1.optimize(args.steps); d1 = time.perf_counter() - t1
-        out["single_graph"] = {"iters_per_sec": round(args.steps / d1, 2), "ms_per_iter": round(1e3 * d1 / args.steps, 3),
-                               "regime": "latency-bound (working set < L2/MALL)", "chi2_after": s1[0].chi2_after}
-        del b1, one
+        if not args.no_single:
+            # ---- single-graph latency (same graph, batch of one) -----------------------------------
+            one = GraphSLAM(False, dev); one.load(paths[0])
+            if args.solver >= 0:
+                one.set_option("solver", args.solver)
+            b1 = GraphBatch([one]); b1.upload(); b1.optimize(1); b1.upload()
+            t1 = time.perf_counter(); s1 = b1.optimize(args.steps); d1 = time.perf_counter() - t1
+            out["single_graph"] = {"iters_per_sec": round(args.steps / d1, 2), "ms_per_iter": round(1e3 * d1 / args.steps, 3),
+                                   "regime": "latency-bound (working set < L2/MALL)", "chi2_after": s1[0].chi2_after}
+            del b1, one
         if not args.no_cpu_baseline and world == 1:
             # ---- CPU baseline: the oracle (restated reference algorithm), 1 core, bounded sample ----
             reps, cpu_t, budget = 0, 0.0, 15.0
