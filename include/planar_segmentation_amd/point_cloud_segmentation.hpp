@@ -9,6 +9,7 @@
 #define PLANAR_SEGMENTATION_AMD_POINT_CLOUD_SEGMENTATION_HPP
 
 #include <array>
+#include <cstdint>
 #include <iostream>
 #include <stdexcept>
 #include <string>
@@ -75,6 +76,24 @@ class point_cloud_segmentation {
       for (int q = 0; q < 3; ++q) { o.pose[q] = p.centroid_cam[q]; o.world_pose[q] = p.world_pose[q]; }
       for (int q = 0; q < 4; ++q) o.normal_orientation[q] = p.normal_d[q];
     }
+    return out;
+  }
+
+  /** plane_segmentation::compute2DConvexHull (plane_segmentation.cpp:631-665): RANSAC plane (threshold 0.01, refined
+   *  coefficients) -> pcl::ProjectInliers -> 2-D pcl::ConvexHull.  xyz = n x 3 floats; returns the hull points. */
+  std::vector<std::array<float, 3>> compute2DConvexHull(const float* xyz, int n, uint64_t seed = 0) {
+    float coeff[4];
+    std::vector<int32_t> inl(n > 0 ? n : 1);
+    const int ni = sslam_seg_ransac_plane(seg_, xyz, n, 0.01f, 50, 0.99, seed, coeff, inl.data(), (int)inl.size());
+    if (ni < 0) throw std::runtime_error(std::string("sslam_seg_ransac_plane: ") + sslam_last_error());
+    std::vector<std::array<float, 3>> out;
+    if (ni < 3) return out;
+    std::vector<float> proj((size_t)ni * 3);
+    std::vector<int32_t> hull(ni);
+    const int h = sslam_seg_convex_hull_2d(seg_, xyz, n, inl.data(), ni, coeff, proj.data(), hull.data(), ni, nullptr);
+    if (h < 0) throw std::runtime_error(std::string("sslam_seg_convex_hull_2d: ") + sslam_last_error());
+    out.resize(h);
+    for (int k = 0; k < h; ++k) out[k] = {proj[3 * (size_t)hull[k]], proj[3 * (size_t)hull[k] + 1], proj[3 * (size_t)hull[k] + 2]};
     return out;
   }
 

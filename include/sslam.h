@@ -214,6 +214,15 @@ int sslam_seg_segment(sslam_seg* s, const uint8_t* cloud, int width, int height,
 int sslam_seg_ransac_plane(sslam_seg* s, const float* xyz, int n, float threshold, int max_iterations, double probability,
                            uint64_t seed, float coeff_out[4], int32_t* inliers_out, int max_inliers);
 
+/* Second half of compute2DConvexHull: pcl::ProjectInliers(SACMODEL_PLANE) of the RANSAC inliers onto
+ * the model plane and the 2-D pcl::ConvexHull of the projected points (plane_segmentation.cpp:648-662).
+ * inliers = point indices (e.g. from sslam_seg_ransac_plane), coeff = (a, b, c, d).  projected_out (optional):
+ * n_inliers x 3 floats.  hull_out = POSITIONS in `inliers` of the hull vertices, counter-clockwise in the chosen coordinate
+ * plane (axes_out: 0 xy, 1 yz, 2 xz; picked from the plane normal as PCL does), starting at the vertex of smallest
+ * atan2 about the vertex centroid (PCL's comparePoints2D order).  Returns the number of hull vertices. */
+int sslam_seg_convex_hull_2d(sslam_seg* s, const float* xyz, int n, const int32_t* inliers, int n_inliers, const float coeff[4],
+                             float* projected_out, int32_t* hull_out, int max_hull, int* axes_out);
+
 /* parity hooks: per-box products of the last sslam_seg_segment call.
  * normals: w*h*4 floats (nx,ny,nz,curvature), labels: w*h int32 (-1 = no plane; otherwise the
  * region index in output order of pcl::OrganizedMultiPlaneSegmentation::segmentAndRefine). */

@@ -653,3 +653,110 @@ int os_ransac_plane(const float *pts, int n, float threshold, int max_iterations
     if (plane_inlier(model, pts + (size_t)i * 3, threshold)) { if (ni < max_inliers) inliers[ni] = i; ++ni; }
   return ni;
 }
+
+/* ---------------------------------------------------------------------------------------------------
+ * a15, second half: pcl::ProjectInliers (SACMODEL_PLANE) + pcl::ConvexHull (2-D) as compute2DConvexHull
+ * configures them (reference plane_segmentation.cpp:648-662).  PCL / qhull are not in /root/reference:
+ * restated from the published algorithms (PCL 1.7 sample_consensus/impl/sac_model_plane.hpp projectPoints,
+ * surface/impl/convex_hull.hpp performReconstruction2D).  PARITY UNPINNED (no reference vectors).
+ *   projectPoints : mc = (a,b,c,0) normalised in float; dist = mc.p + d (d NOT rescaled, as PCL);  p' = p - mc dist
+ *   hull          : the coordinate plane is picked from the normal of the first / last / middle projected
+ *                   points (|n.axis| > cos(10 deg) forbids the two planes containing that axis; order xy, yz, xz);
+ *                   strictly convex vertices of the 2-D point set (qhull drops collinear points), ordered by
+ *                   angle around the vertex centroid (comparePoints2D: atan2 ascending, -pi first) = the
+ *                   counter-clockwise polygon started at its vertex of smallest angle.
+ * Deviations (documented in DESIGN.md): if the three probe points are collinear PCL re-draws random points
+ * (rand()); here the middle index walks forward until the triple is not collinear.  The centroid is the
+ * double mean of the vertices in counter-clockwise chain order, rounded to float (qhull's vertex order is
+ * not reproducible); the angular order uses an exact half-plane / cross-product comparator instead of atan2.
+ * hull_out = positions in `inliers` order.  Returns the number of hull vertices (or -1: degenerate input). */
+typedef struct { float x, y; int32_t i; } os_p2;
+static int os_p2_cmp(const void *a, const void *b) {
+  const os_p2 *p = (const os_p2 *)a, *q = (const os_p2 *)b;
+  if (p->x != q->x) return p->x < q->x ? -1 : 1;
+  if (p->y != q->y) return p->y < q->y ? -1 : 1;
+  return p->i < q->i ? -1 : (p->i > q->i ? 1 : 0);
+}
+static double os_cross2(const os_p2 *o, const os_p2 *a, const os_p2 *b) {
+  return ((double)a->x - (double)o->x) * ((double)b->y - (double)o->y) - ((double)a->y - (double)o->y) * ((double)b->x - (double)o->x);
+}
+static int os_ang_half(float x, float y) { return y < 0 ? 0 : ((y == 0 && x > 0) ? 1 : (y > 0 ? 2 : 3)); }
+static float g_cx, g_cy;
+static int os_ang_cmp(const void *a, const void *b) {
+  const os_p2 *p = (const os_p2 *)a, *q = (const os_p2 *)b;
+  const float px = p->x - g_cx, py = p->y - g_cy, qx = q->x - g_cx, qy = q->y - g_cy;
+  const int hp = os_ang_half(px, py), hq = os_ang_half(qx, qy);
+  if (hp != hq) return hp < hq ? -1 : 1;
+  const double cr = (double)px * (double)qy - (double)py * (double)qx;
+  if (cr != 0) return cr > 0 ? -1 : 1;
+  return p->i < q->i ? -1 : (p->i > q->i ? 1 : 0);
+}
+
+void os_project_inliers(const float *pts, const int32_t *inliers, int n_in, const float coeff[4], float *proj) {
+  const float nrm = sqrtf(coeff[0] * coeff[0] + coeff[1] * coeff[1] + coeff[2] * coeff[2]);
+  const float mc[3] = {coeff[0] / nrm, coeff[1] / nrm, coeff[2] / nrm};
+  for (int k = 0; k < n_in; ++k) {
+    const float *p = pts + (size_t)inliers[k] * 3;
+    const float dist = mc[0] * p[0] + mc[1] * p[1] + mc[2] * p[2] + coeff[3];
+    proj[3 * k + 0] = p[0] - mc[0] * dist;
+    proj[3 * k + 1] = p[1] - mc[1] * dist;
+    proj[3 * k + 2] = p[2] - mc[2] * dist;
+  }
+}
+
+/* axes_out: 0 = xy, 1 = yz, 2 = xz */
+int os_hull_axes(const float *proj, int n_in) {
+  if (n_in < 3) return -1;
+  const float *p0 = proj, *p1 = proj + 3 * (size_t)(n_in - 1);
+  double nx = 0, ny = 0, nz = 0, nn = 0;
+  for (int m = n_in / 2, tries = 0; tries < n_in; ++tries, m = (m + 1) % n_in) {
+    const float *p2 = proj + 3 * (size_t)m;
+    const double ax = (double)p1[0] - p0[0], ay = (double)p1[1] - p0[1], az = (double)p1[2] - p0[2];
+    const double bx = (double)p2[0] - p0[0], by = (double)p2[1] - p0[1], bz = (double)p2[2] - p0[2];
+    nx = ay * bz - az * by; ny = az * bx - ax * bz; nz = ax * by - ay * bx;
+    nn = sqrt(nx * nx + ny * ny + nz * nz);
+    if (nn > 0) break;
+  }
+  if (!(nn > 0)) return -1;
+  const float thresh = cosf(0.174532925f);
+  const float tx = fabsf((float)(nx / nn)), ty = fabsf((float)(ny / nn)), tz = fabsf((float)(nz / nn));
+  int xy = 1, yz = 1, xz = 1;
+  if (tz > thresh) { xz = 0; yz = 0; }
+  if (tx > thresh) { xz = 0; xy = 0; }
+  if (ty > thresh) { xy = 0; yz = 0; }
+  return xy ? 0 : (yz ? 1 : (xz ? 2 : -1));
+}
+
+int os_convex_hull_2d(const float *proj, int n_in, int32_t *hull_out, int max_hull, int *axes_out) {
+  const int axes = os_hull_axes(proj, n_in);
+  if (axes_out) *axes_out = axes;
+  if (axes < 0) return -1;
+  const int ia = axes == 1 ? 1 : 0, ib = axes == 0 ? 1 : 2;
+  os_p2 *P = (os_p2 *)malloc(sizeof(os_p2) * (size_t)n_in), *Hh = (os_p2 *)malloc(sizeof(os_p2) * (size_t)(2 * n_in + 2));
+  for (int k = 0; k < n_in; ++k) { P[k].x = proj[3 * k + ia]; P[k].y = proj[3 * k + ib]; P[k].i = k; }
+  qsort(P, (size_t)n_in, sizeof(os_p2), os_p2_cmp);
+  int m = 0;
+  for (int k = 0; k < n_in; ++k) {              /* duplicates: the lowest index stays */
+    if (m > 0 && P[k].x == P[m - 1].x && P[k].y == P[m - 1].y) continue;
+    P[m++] = P[k];
+  }
+  int h = 0;
+  for (int k = 0; k < m; ++k) {                 /* lower chain */
+    while (h >= 2 && os_cross2(&Hh[h - 2], &Hh[h - 1], &P[k]) <= 0) --h;
+    Hh[h++] = P[k];
+  }
+  for (int k = m - 2, t = h + 1; k >= 0; --k) { /* upper chain */
+    while (h >= t && os_cross2(&Hh[h - 2], &Hh[h - 1], &P[k]) <= 0) --h;
+    Hh[h++] = P[k];
+  }
+  if (m > 1) --h;                               /* the first point closes the loop */
+  double sx = 0, sy = 0;
+  for (int k = 0; k < h; ++k) { sx += Hh[k].x; sy += Hh[k].y; }
+  g_cx = (float)(sx / h); g_cy = (float)(sy / h);
+  /* angular order = the counter-clockwise chain rotated to start at the vertex of smallest angle */
+  int first = 0;
+  for (int k = 1; k < h; ++k) if (os_ang_cmp(&Hh[k], &Hh[first]) < 0) first = k;
+  for (int k = 0; k < h && k < max_hull; ++k) hull_out[k] = Hh[(first + k) % h].i;
+  free(P); free(Hh);
+  return h;
+}

@@ -874,6 +874,238 @@ __global__ __launch_bounds__(256) void k_ransac_write(const float* __restrict__ 
     if (pos < max_inliers) inliers[pos] = i;
   }
 }
+// ---- a15, second half: pcl::ProjectInliers (plane) + 2-D pcl::ConvexHull (plane_segmentation.cpp:648-662) ---------
+// projectPoints: mc = (a, b, c, 0) normalised in float, dist = mc . p + d (d is not rescaled, as in PCL), p' = p - mc dist
+__global__ __launch_bounds__(256) void k_hull_project(const float* __restrict__ pts, const int* __restrict__ inliers, int n_in,
+                                                     float a, float b, float c, float d, float* __restrict__ proj) {
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  if (k >= n_in) return;
+  const float nrm = sqrtf(a * a + b * b + c * c);
+  const float m0 = a / nrm, m1 = b / nrm, m2 = c / nrm;
+  const float* p = pts + (size_t)inliers[k] * 3;
+  const float dist = m0 * p[0] + m1 * p[1] + m2 * p[2] + d;
+  proj[3 * (size_t)k + 0] = p[0] - m0 * dist;
+  proj[3 * (size_t)k + 1] = p[1] - m1 * dist;
+  proj[3 * (size_t)k + 2] = p[2] - m2 * dist;
+}
+// coordinate plane of the hull from the normal of the first / last / middle projected point (PCL performReconstruction2D);
+// collinear probes: the middle index walks forward.  meta[0] = 0 xy, 1 yz, 2 xz, -1 degenerate
+__global__ void k_hull_axes(const float* __restrict__ proj, int n_in, float thresh, int* __restrict__ meta) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const float* p0 = proj; const float* p1 = proj + 3 * (size_t)(n_in - 1);
+  double nx = 0, ny = 0, nz = 0, nn = 0;
+  for (int m = n_in / 2, tries = 0; tries < n_in; ++tries, m = (m + 1) % n_in) {
+    const float* p2 = proj + 3 * (size_t)m;
+    const double ax = (double)p1[0] - p0[0], ay = (double)p1[1] - p0[1], az = (double)p1[2] - p0[2];
+    const double bx = (double)p2[0] - p0[0], by = (double)p2[1] - p0[1], bz = (double)p2[2] - p0[2];
+    nx = ay * bz - az * by; ny = az * bx - ax * bz; nz = ax * by - ay * bx;
+    nn = sqrt(nx * nx + ny * ny + nz * nz);
+    if (nn > 0) break;
+  }
+  if (!(nn > 0)) { meta[0] = -1; return; }
+  const float tx = fabsf((float)(nx / nn)), ty = fabsf((float)(ny / nn)), tz = fabsf((float)(nz / nn));
+  bool xy = true, yz = true, xz = true;
+  if (tz > thresh) { xz = false; yz = false; }
+  if (tx > thresh) { xz = false; xy = false; }
+  if (ty > thresh) { xy = false; yz = false; }
+  meta[0] = xy ? 0 : (yz ? 1 : (xz ? 2 : -1));
+}
+__global__ __launch_bounds__(256) void k_hull_coords(const float* __restrict__ proj, int n_in, const int* __restrict__ meta,
+                                                    float* __restrict__ px, float* __restrict__ py) {
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  if (k >= n_in) return;
+  const int axes = meta[0];
+  px[k] = proj[3 * (size_t)k + (axes == 1 ? 1 : 0)];
+  py[k] = proj[3 * (size_t)k + (axes == 0 ? 1 : 2)];
+}
+// Akl-Toussaint pre-filter: the 8 extreme points (W, SW, S, SE, E, NE, N, NW; ties -> lowest index) span an octagon;
+// points strictly inside it (by a margin far above the rounding of the double cross products) cannot be hull vertices.
+__device__ __forceinline__ double hull_key(int dir, float x, float y) {
+  const double dx = x, dy = y;
+  switch (dir) { case 0: return -dx; case 1: return -(dx + dy); case 2: return -dy; case 3: return dx - dy;
+                 case 4: return dx; case 5: return dx + dy; case 6: return dy; default: return -(dx - dy); }
+}
+__global__ __launch_bounds__(256) void k_hull_extreme_partial(const float* __restrict__ px, const float* __restrict__ py, int n_in,
+                                                             double* __restrict__ bkey, int* __restrict__ bidx) {
+  __shared__ double wk[4][8];
+  __shared__ int wi[4][8];
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  const bool ok = k < n_in;
+  const float x = ok ? px[k] : 0.f, y = ok ? py[k] : 0.f;
+#pragma unroll
+  for (int dir = 0; dir < 8; ++dir) {
+    double key = ok ? hull_key(dir, x, y) : -1.0e300;
+    int idx = ok ? k : 0x7fffffff;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const double ok2 = __shfl_down(key, o, 64);
+      const int oi = __shfl_down(idx, o, 64);
+      if (ok2 > key || (ok2 == key && oi < idx)) { key = ok2; idx = oi; }
+    }
+    if ((threadIdx.x & 63) == 0) { wk[threadIdx.x >> 6][dir] = key; wi[threadIdx.x >> 6][dir] = idx; }
+  }
+  __syncthreads();
+  if (threadIdx.x < 8) {
+    const int dir = threadIdx.x;
+    double key = wk[0][dir]; int idx = wi[0][dir];
+    for (int w = 1; w < 4; ++w) if (wk[w][dir] > key || (wk[w][dir] == key && wi[w][dir] < idx)) { key = wk[w][dir]; idx = wi[w][dir]; }
+    bkey[(size_t)blockIdx.x * 8 + dir] = key; bidx[(size_t)blockIdx.x * 8 + dir] = idx;
+  }
+}
+// ext[dir] = (x, y) of the extreme point, eidx[dir] its index; ext[16] = margin
+__global__ void k_hull_extreme_final(const double* __restrict__ bkey, const int* __restrict__ bidx, int nblk, const float* __restrict__ px,
+                                     const float* __restrict__ py, double* __restrict__ ext, int* __restrict__ eidx) {
+  const int dir = threadIdx.x;
+  if (dir < 8) {
+    double key = bkey[dir]; int idx = bidx[dir];
+    for (int b = 1; b < nblk; ++b) {
+      const double k2 = bkey[(size_t)b * 8 + dir]; const int i2 = bidx[(size_t)b * 8 + dir];
+      if (k2 > key || (k2 == key && i2 < idx)) { key = k2; idx = i2; }
+    }
+    eidx[dir] = idx; ext[2 * dir] = px[idx]; ext[2 * dir + 1] = py[idx];
+  }
+  __syncthreads();
+  if (dir == 0) {
+    const double ex = ext[8] - ext[0], ey = ext[13] - ext[5];   // E.x - W.x, N.y - S.y
+    ext[16] = 1e-10 * (ex * ex + ey * ey);
+  }
+}
+__device__ __forceinline__ bool hull_keep(const double* __restrict__ ext, float x, float y) {
+  const double margin = ext[16];
+  int edges = 0;
+  bool inside = true;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const double ax = ext[2 * e], ay = ext[2 * e + 1], bx = ext[2 * ((e + 1) & 7)], by = ext[2 * ((e + 1) & 7) + 1];
+    if (ax == bx && ay == by) continue;
+    ++edges;
+    const double cr = (bx - ax) * ((double)y - ay) - (by - ay) * ((double)x - ax);
+    if (!(cr > margin)) inside = false;
+  }
+  return !(inside && edges >= 3);
+}
+__global__ __launch_bounds__(256) void k_hull_mark(const float* __restrict__ px, const float* __restrict__ py, int n_in, const double* __restrict__ ext,
+                                                  int* __restrict__ block_counts) {
+  __shared__ int wsum[4];
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  int c = (i < n_in && hull_keep(ext, px[i], py[i])) ? 1 : 0;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o, 64);
+  if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) block_counts[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+__global__ __launch_bounds__(256) void k_hull_write(const float* __restrict__ px, const float* __restrict__ py, int n_in, const double* __restrict__ ext,
+                                                   const int* __restrict__ block_off, float* __restrict__ cx, float* __restrict__ cy, int* __restrict__ ci) {
+  __shared__ int woff[4];
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  const bool in = i < n_in && hull_keep(ext, px[i], py[i]);
+  const unsigned long long mask = __ballot(in);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) woff[wave] = __popcll(mask);
+  __syncthreads();
+  int base = block_off[blockIdx.x];
+  for (int w = 0; w < wave; ++w) base += woff[w];
+  if (in) {
+    const int pos = base + __popcll(mask & ((1ull << lane) - 1ull));
+    cx[pos] = px[i]; cy[pos] = py[i]; ci[pos] = i;
+  }
+}
+// One workgroup per chunk of <= kHullCap candidates: bitonic sort by (x, y, index) in LDS, Andrew's monotone chain by
+// one thread (strict turns, duplicates keep the lowest index).  FINAL: counter-clockwise polygon rotated to start at the
+// vertex of smallest angle about the (double mean -> float) vertex centroid, indices only.  Otherwise the chunk's hull
+// vertices go back out as candidates of the next round (the hull of a union is the hull of the parts' hulls).
+constexpr int kHullCap = 4096;
+__device__ __forceinline__ bool hull_less(float ax, float ay, int ai, float bx, float by, int bi) {
+  if (ax != bx) return ax < bx;
+  if (ay != by) return ay < by;
+  return ai < bi;
+}
+__device__ __forceinline__ int hull_half(float x, float y) { return y < 0 ? 0 : ((y == 0 && x > 0) ? 1 : (y > 0 ? 2 : 3)); }
+// (plain functions over the LDS arrays: lambdas capturing __shared__ arrays by reference have miscompiled before)
+__device__ __forceinline__ double hull_cross(const float* sx, const float* sy, int o, int a, int b) {
+  return ((double)sx[a] - (double)sx[o]) * ((double)sy[b] - (double)sy[o]) - ((double)sy[a] - (double)sy[o]) * ((double)sx[b] - (double)sx[o]);
+}
+__device__ __forceinline__ bool hull_ang_less(const float* sx, const float* sy, const int* si, float gx, float gy, int p, int q) {
+  const float ax = sx[p] - gx, ay = sy[p] - gy, bx = sx[q] - gx, by = sy[q] - gy;
+  const int hp = hull_half(ax, ay), hq = hull_half(bx, by);
+  if (hp != hq) return hp < hq;
+  const double cr = (double)ax * (double)by - (double)ay * (double)bx;
+  if (cr != 0) return cr > 0;
+  return si[p] < si[q];
+}
+template <bool FINAL>
+__global__ __launch_bounds__(1024) void k_hull_core(const float* __restrict__ cx, const float* __restrict__ cy, const int* __restrict__ ci, int m,
+                                                   float* __restrict__ ox, float* __restrict__ oy, int* __restrict__ oi, int* __restrict__ counts) {
+  __shared__ float sx[kHullCap], sy[kHullCap];
+  __shared__ int si[kHullCap], st[kHullCap];
+  const int c0 = blockIdx.x * kHullCap, mc = min(kHullCap, m - c0), tid = threadIdx.x;
+  int N = 1;
+  while (N < mc) N <<= 1;
+  for (int t = tid; t < N; t += 1024) {
+    const bool ok = t < mc;
+    sx[t] = ok ? cx[c0 + t] : __int_as_float(0x7f800000); sy[t] = ok ? cy[c0 + t] : 0.f; si[t] = ok ? ci[c0 + t] : 0x7fffffff;
+  }
+  __syncthreads();
+  for (int k = 2; k <= N; k <<= 1)
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int t = tid; t < N; t += 1024) {
+        const int u = t ^ j;
+        if (u > t) {
+          const bool asc = (t & k) == 0;
+          const bool lt = hull_less(sx[u], sy[u], si[u], sx[t], sy[t], si[t]);   // element u sorts before element t
+          if (lt == asc) {
+            const float fx = sx[t], fy = sy[t]; const int fi = si[t];
+            sx[t] = sx[u]; sy[t] = sy[u]; si[t] = si[u]; sx[u] = fx; sy[u] = fy; si[u] = fi;
+          }
+        }
+      }
+      __syncthreads();
+    }
+  if (tid != 0) return;
+  // dedupe in place
+  int mu = 0;
+  for (int k = 0; k < mc; ++k) {
+    if (mu > 0 && sx[k] == sx[mu - 1] && sy[k] == sy[mu - 1]) continue;
+    sx[mu] = sx[k]; sy[mu] = sy[k]; si[mu] = si[k]; ++mu;
+  }
+  int h = 0;
+  for (int k = 0; k < mu; ++k) {
+    while (h >= 2 && hull_cross(sx, sy, st[h - 2], st[h - 1], k) <= 0) --h;
+    st[h++] = k;
+  }
+  for (int k = mu - 2, t = h + 1; k >= 0; --k) {
+    while (h >= t && hull_cross(sx, sy, st[h - 2], st[h - 1], k) <= 0) --h;
+    st[h++] = k;
+  }
+  if (mu > 1) --h;
+  if (!FINAL) {
+    for (int k = 0; k < h; ++k) { const int p = st[k]; ox[c0 + k] = sx[p]; oy[c0 + k] = sy[p]; oi[c0 + k] = si[p]; }
+    counts[blockIdx.x] = h;
+    return;
+  }
+  double sumx = 0, sumy = 0;
+  for (int k = 0; k < h; ++k) { sumx += sx[st[k]]; sumy += sy[st[k]]; }
+  const float gx = (float)(sumx / h), gy = (float)(sumy / h);
+  int first = 0;
+  for (int k = 1; k < h; ++k) if (hull_ang_less(sx, sy, si, gx, gy, st[k], st[first])) first = k;
+  for (int k = 0; k < h; ++k) oi[k] = si[st[(first + k) % h]];
+  counts[0] = h;
+}
+// compaction between rounds: chunk c's `counts[c]` vertices move to offset off[c]
+__global__ __launch_bounds__(256) void k_hull_compact(const float* __restrict__ ox, const float* __restrict__ oy, const int* __restrict__ oi,
+                                                     const int* __restrict__ counts, const int* __restrict__ off, float* __restrict__ cx,
+                                                     float* __restrict__ cy, int* __restrict__ ci) {
+  const int c = blockIdx.x, n = counts[c], o = off[c];
+  for (int k = threadIdx.x; k < n; k += 256) { cx[o + k] = ox[c * kHullCap + k]; cy[o + k] = oy[c * kHullCap + k]; ci[o + k] = oi[c * kHullCap + k]; }
+}
+__global__ void k_hull_scan(const int* __restrict__ counts, int nchunks, int* __restrict__ off, int* __restrict__ total) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  int acc = 0;
+  for (int c = 0; c < nchunks; ++c) { off[c] = acc; acc += counts[c]; }
+  *total = acc;
+}
+
 // optimizeModelCoefficients: float mean / covariance of the inliers in index order + eigen33 (one wave)
 __global__ __launch_bounds__(64) void k_ransac_refit(const float* __restrict__ pts, const int* __restrict__ inliers, const int* __restrict__ total,
                                                     float* __restrict__ model) {
@@ -1269,6 +1501,79 @@ int sslam_seg_ransac_plane(sslam_seg* s, const float* xyz, int n, float threshol
   cleanup();
   if (le != hipSuccess) return set_error(SSLAM_ERR_HIP, "ransac kernels: %s", hipGetErrorString(le));
   return total;
+}
+
+int sslam_seg_convex_hull_2d(sslam_seg* s, const float* xyz, int n, const int32_t* inliers, int n_inliers, const float coeff[4],
+                             float* projected_out, int32_t* hull_out, int max_hull, int* axes_out) {
+  if (!s || !xyz || !inliers || !coeff || (!hull_out && max_hull > 0) || n < 0 || n_inliers < 0)
+    return set_error(SSLAM_ERR_INVALID, "bad argument");
+  int nd = 0;
+  if (hipGetDeviceCount(&nd) != hipSuccess || nd <= 0) return set_error(SSLAM_ERR_NO_DEVICE, "no HIP device visible; the product has no CPU fallback");
+  if (axes_out) *axes_out = -1;
+  if (n_inliers < 3) return set_error(SSLAM_ERR_INVALID, "a 2-D hull needs at least 3 inliers");
+  for (int k = 0; k < n_inliers; ++k) if (inliers[k] < 0 || inliers[k] >= n) return set_error(SSLAM_ERR_INVALID, "inlier index out of range");
+  SSLAM_HIP_TRY(hipSetDevice(s->P.device));
+  if (!s->stream) SSLAM_HIP_TRY(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
+  const int m0 = n_inliers, nblk = (m0 + 255) / 256;
+  std::vector<void*> bufs;
+  auto alloc = [&](size_t bytes) -> void* { void* p = nullptr; if (hipMalloc(&p, std::max<size_t>(bytes, 16)) != hipSuccess) return nullptr; bufs.push_back(p); return p; };
+  auto cleanup = [&]() { for (void* p : bufs) (void)hipFree(p); };
+  float* d_pts = (float*)alloc((size_t)n * 3 * sizeof(float));
+  int* d_inl = (int*)alloc((size_t)m0 * sizeof(int));
+  float* d_proj = (float*)alloc((size_t)m0 * 3 * sizeof(float));
+  float* d_px = (float*)alloc((size_t)m0 * sizeof(float)); float* d_py = (float*)alloc((size_t)m0 * sizeof(float));
+  float* d_cx = (float*)alloc((size_t)m0 * sizeof(float)); float* d_cy = (float*)alloc((size_t)m0 * sizeof(float)); int* d_ci = (int*)alloc((size_t)m0 * sizeof(int));
+  const int max_chunks = (m0 + kHullCap - 1) / kHullCap;
+  float* d_ox = (float*)alloc((size_t)max_chunks * kHullCap * sizeof(float)); float* d_oy = (float*)alloc((size_t)max_chunks * kHullCap * sizeof(float));
+  int* d_oi = (int*)alloc((size_t)max_chunks * kHullCap * sizeof(int));
+  int* d_meta = (int*)alloc(4 * sizeof(int));
+  double* d_bkey = (double*)alloc((size_t)nblk * 8 * sizeof(double)); int* d_bidx = (int*)alloc((size_t)nblk * 8 * sizeof(int));
+  double* d_ext = (double*)alloc(17 * sizeof(double)); int* d_eidx = (int*)alloc(8 * sizeof(int));
+  int* d_blk = (int*)alloc((size_t)nblk * sizeof(int)); int* d_total = (int*)alloc(sizeof(int));
+  int* d_counts = (int*)alloc((size_t)max_chunks * sizeof(int)); int* d_off = (int*)alloc((size_t)max_chunks * sizeof(int));
+  if (!d_pts || !d_inl || !d_proj || !d_px || !d_py || !d_cx || !d_cy || !d_ci || !d_ox || !d_oy || !d_oi || !d_meta || !d_bkey || !d_bidx || !d_ext ||
+      !d_eidx || !d_blk || !d_total || !d_counts || !d_off) { cleanup(); return set_error(SSLAM_ERR_HIP, "hipMalloc failed (convex hull)"); }
+#define SSLAM_HULL_TRY(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { cleanup(); return set_error(SSLAM_ERR_HIP, "%s: %s", #x, hipGetErrorString(e_)); } } while (0)
+  SSLAM_HULL_TRY(hipMemcpyAsync(d_pts, xyz, (size_t)n * 3 * sizeof(float), hipMemcpyHostToDevice, s->stream));
+  SSLAM_HULL_TRY(hipMemcpyAsync(d_inl, inliers, (size_t)m0 * sizeof(int), hipMemcpyHostToDevice, s->stream));
+  hipLaunchKernelGGL(k_hull_project, dim3(nblk), dim3(256), 0, s->stream, d_pts, d_inl, m0, coeff[0], coeff[1], coeff[2], coeff[3], d_proj);
+  hipLaunchKernelGGL(k_hull_axes, dim3(1), dim3(1), 0, s->stream, d_proj, m0, cosf(0.174532925f), d_meta);
+  int axes = -1;
+  SSLAM_HULL_TRY(hipMemcpyAsync(&axes, d_meta, sizeof(int), hipMemcpyDeviceToHost, s->stream));
+  if (projected_out) SSLAM_HULL_TRY(hipMemcpyAsync(projected_out, d_proj, (size_t)m0 * 3 * sizeof(float), hipMemcpyDeviceToHost, s->stream));
+  SSLAM_HULL_TRY(hipStreamSynchronize(s->stream));
+  if (axes_out) *axes_out = axes;
+  if (axes < 0) { cleanup(); return set_error(SSLAM_ERR_NUMERIC, "convex hull: the projected inliers are collinear"); }
+  hipLaunchKernelGGL(k_hull_coords, dim3(nblk), dim3(256), 0, s->stream, d_proj, m0, d_meta, d_px, d_py);
+  hipLaunchKernelGGL(k_hull_extreme_partial, dim3(nblk), dim3(256), 0, s->stream, d_px, d_py, m0, d_bkey, d_bidx);
+  hipLaunchKernelGGL(k_hull_extreme_final, dim3(1), dim3(64), 0, s->stream, d_bkey, d_bidx, nblk, d_px, d_py, d_ext, d_eidx);
+  hipLaunchKernelGGL(k_hull_mark, dim3(nblk), dim3(256), 0, s->stream, d_px, d_py, m0, d_ext, d_blk);
+  hipLaunchKernelGGL(k_ransac_scan, dim3(1), dim3(64), 0, s->stream, d_blk, nblk, d_total);
+  hipLaunchKernelGGL(k_hull_write, dim3(nblk), dim3(256), 0, s->stream, d_px, d_py, m0, d_ext, d_blk, d_cx, d_cy, d_ci);
+  int m = 0;
+  SSLAM_HULL_TRY(hipMemcpyAsync(&m, d_total, sizeof(int), hipMemcpyDeviceToHost, s->stream));
+  SSLAM_HULL_TRY(hipStreamSynchronize(s->stream));
+  while (m > kHullCap) {   // hull of hulls until one workgroup holds every candidate
+    const int nchunks = (m + kHullCap - 1) / kHullCap;
+    hipLaunchKernelGGL(k_hull_core<false>, dim3(nchunks), dim3(1024), 0, s->stream, d_cx, d_cy, d_ci, m, d_ox, d_oy, d_oi, d_counts);
+    hipLaunchKernelGGL(k_hull_scan, dim3(1), dim3(64), 0, s->stream, d_counts, nchunks, d_off, d_total);
+    hipLaunchKernelGGL(k_hull_compact, dim3(nchunks), dim3(256), 0, s->stream, d_ox, d_oy, d_oi, d_counts, d_off, d_cx, d_cy, d_ci);
+    int m2 = 0;
+    SSLAM_HULL_TRY(hipMemcpyAsync(&m2, d_total, sizeof(int), hipMemcpyDeviceToHost, s->stream));
+    SSLAM_HULL_TRY(hipStreamSynchronize(s->stream));
+    if (m2 >= m) { cleanup(); return set_error(SSLAM_ERR_UNSUPPORTED, "convex hull with more than %d vertices", kHullCap); }
+    m = m2;
+  }
+  hipLaunchKernelGGL(k_hull_core<true>, dim3(1), dim3(1024), 0, s->stream, d_cx, d_cy, d_ci, m, d_ox, d_oy, d_oi, d_counts);
+  int h = 0;
+  SSLAM_HULL_TRY(hipMemcpyAsync(&h, d_counts, sizeof(int), hipMemcpyDeviceToHost, s->stream));
+  SSLAM_HULL_TRY(hipStreamSynchronize(s->stream));
+  if (h > 0 && max_hull > 0) SSLAM_HULL_TRY(hipMemcpy(hull_out, d_oi, (size_t)std::min(h, max_hull) * sizeof(int), hipMemcpyDeviceToHost));
+  hipError_t le = hipGetLastError();
+  cleanup();
+#undef SSLAM_HULL_TRY
+  if (le != hipSuccess) return set_error(SSLAM_ERR_HIP, "convex hull kernels: %s", hipGetErrorString(le));
+  return h;
 }
 
 static int seg_find_slot(sslam_seg* s, int box) {

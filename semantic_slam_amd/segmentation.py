@@ -70,6 +70,8 @@ def _bind(lib):
     lib.sslam_seg_transform.restype = ci; lib.sslam_seg_transform.argtypes = [vp, vp, C.c_float, vp]
     lib.sslam_seg_ransac_plane.restype = ci
     lib.sslam_seg_ransac_plane.argtypes = [vp, vp, ci, C.c_float, ci, C.c_double, C.c_uint64, vp, vp, ci]
+    lib.sslam_seg_convex_hull_2d.restype = ci
+    lib.sslam_seg_convex_hull_2d.argtypes = [vp, vp, ci, vp, ci, vp, vp, vp, ci, vp]
     _BOUND = True
 
 
@@ -144,6 +146,26 @@ class PointCloudSegmentation:
         n = self._check(self._lib.sslam_seg_ransac_plane(self._h, pts.ctypes.data, len(pts), C.c_float(threshold), max_iterations,
                                                           C.c_double(probability), C.c_uint64(seed), coeff.ctypes.data, inl.ctypes.data, len(inl)))
         return coeff, inl[:n].copy()
+
+    def convex_hull_2d(self, xyz, inliers, coeff):
+        """pcl::ProjectInliers + 2-D pcl::ConvexHull of plane_segmentation::compute2DConvexHull (plane_segmentation.cpp:648-662).
+        Returns (projected[n_inliers, 3], hull positions into `inliers` in angular order, axes)."""
+        pts = np.ascontiguousarray(xyz, np.float32).reshape(-1, 3)
+        inl = np.ascontiguousarray(inliers, np.int32)
+        co = np.ascontiguousarray(coeff, np.float32).reshape(4)
+        proj = np.zeros((len(inl), 3), np.float32)
+        hull = np.zeros(max(len(inl), 1), np.int32)
+        axes = C.c_int(-1)
+        h = self._check(self._lib.sslam_seg_convex_hull_2d(self._h, pts.ctypes.data, len(pts), inl.ctypes.data, len(inl), co.ctypes.data,
+                                                            proj.ctypes.data, hull.ctypes.data, len(hull), C.byref(axes)))
+        return proj, hull[:h].copy(), axes.value
+
+    def compute2DConvexHull(self, xyz, seed: int = 0):
+        """plane_segmentation::compute2DConvexHull (plane_segmentation.cpp:631-665): RANSAC plane (threshold 0.01, refined
+        coefficients) -> project the inliers -> 2-D convex hull.  Returns the hull points (h x 3, projected coordinates)."""
+        coeff, inl = self.ransac_plane(xyz, 0.01, 50, 0.99, seed)
+        proj, hull, _ = self.convex_hull_2d(xyz, inl, coeff)
+        return proj[hull]
 
     # parity hooks -----------------------------------------------------------------------------
     def normals(self, box: int) -> np.ndarray:

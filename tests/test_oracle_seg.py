@@ -183,3 +183,34 @@ def test_ransac_plane_recovers_a_noisy_plane_with_outliers():
     assert np.array_equal(c, c2) and np.array_equal(inl, inl2)
     c3, inl3, _, best3 = run(6)
     assert abs(abs(c3[:3] @ nrm) - 1) < 1e-4
+
+
+def test_oracle_projection_and_hull_against_scipy():
+    """a15 second half: the restated ProjectInliers + 2-D hull vs scipy.spatial.ConvexHull (qhull) and the order PCL sorts into"""
+    import ctypes as C
+    from scipy.spatial import ConvexHull
+    from oracle import oracle
+    lib = oracle.lib()
+    rng = np.random.default_rng(1)
+    for normal, want_axes in (((0.1, 0.2, -1.0), 0), ((1.0, 0.1, 0.05), 1), ((0.05, -1.0, 0.1), 2)):
+        n = 4000
+        nrm = np.array(normal); nrm /= np.linalg.norm(nrm)
+        u = np.cross(nrm, [0.3, 0.5, 0.8]); u /= np.linalg.norm(u); v = np.cross(nrm, u)
+        ab = rng.normal(0, 1, (n, 2))
+        pts = (ab[:, :1] * u + ab[:, 1:] * v + 2.0 * nrm + rng.normal(0, 0.004, (n, 1)) * nrm).astype(np.float32)
+        coeff = np.array([*nrm, -2.0], np.float32)
+        inl = np.arange(n, dtype=np.int32)
+        proj = np.zeros((n, 3), np.float32)
+        lib.os_project_inliers(pts.ctypes.data_as(C.c_void_p), inl.ctypes.data_as(C.c_void_p), n, coeff.ctypes.data_as(C.c_void_p),
+                               proj.ctypes.data_as(C.c_void_p))
+        assert np.abs(proj @ coeff[:3] + coeff[3]).max() < 1e-5
+        hull = np.zeros(n, np.int32); axes = C.c_int(-9)
+        h = lib.os_convex_hull_2d(proj.ctypes.data_as(C.c_void_p), n, hull.ctypes.data_as(C.c_void_p), n, C.byref(axes))
+        assert axes.value == want_axes
+        cols = {0: [0, 1], 1: [1, 2], 2: [0, 2]}[want_axes]
+        ref = ConvexHull(proj[:, cols].astype(np.float64))
+        assert set(ref.vertices.tolist()) == set(hull[:h].tolist())
+        hv = proj[hull[:h]][:, cols]
+        c = hv.mean(0)
+        a = np.arctan2(hv[:, 1] - c[1], hv[:, 0] - c[0])
+        assert np.all(np.diff(a) > 0)                       # comparePoints2D order: atan2 ascending

@@ -159,3 +159,65 @@ def test_ransac_plane_edge_cases(gpu_lib):
     c1, i1 = seg.ransac_plane(crop, 0.01, 50, 0.99, 11)
     c2, i2 = _oracle_ransac(crop, 0.01, 50, 0.99, 11)
     assert np.array_equal(i1, i2) and np.array_equal(c1, c2, equal_nan=True) and len(i1) > 1000
+
+
+def _oracle_hull(pts, inl, coeff):
+    import ctypes as C
+    from oracle import oracle
+    lib = oracle.lib()
+    pts = np.ascontiguousarray(pts, np.float32); inl = np.ascontiguousarray(inl, np.int32); coeff = np.ascontiguousarray(coeff, np.float32)
+    proj = np.zeros((len(inl), 3), np.float32)
+    lib.os_project_inliers(pts.ctypes.data_as(C.c_void_p), inl.ctypes.data_as(C.c_void_p), len(inl), coeff.ctypes.data_as(C.c_void_p),
+                           proj.ctypes.data_as(C.c_void_p))
+    hull = np.zeros(len(inl), np.int32); axes = C.c_int(-9)
+    h = lib.os_convex_hull_2d(proj.ctypes.data_as(C.c_void_p), len(inl), hull.ctypes.data_as(C.c_void_p), len(hull), C.byref(axes))
+    return proj, hull[:max(h, 0)].copy(), axes.value
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed,normal", [(0, (0.3, -0.2, -1.0)), (5, (1.0, 0.05, 0.1)), (9, (0.1, 1.0, -0.05))])
+def test_project_inliers_and_convex_hull_bit_exact(gpu_lib, seed, normal):
+    """SURVEY §8 a15 (plane_segmentation.cpp:648-662): projected points (float, bit-exact), coordinate-plane choice and hull
+    vertex sequence vs the oracle, for planes facing z, x and y (xy / yz / xz projections)."""
+    from semantic_slam_amd.segmentation import PointCloudSegmentation
+    rng = np.random.default_rng(seed)
+    n = 30000
+    nrm = np.array(normal, np.float64); nrm /= np.linalg.norm(nrm)
+    # two in-plane directions
+    u = np.cross(nrm, [0.3, 0.5, 0.8]); u /= np.linalg.norm(u); v = np.cross(nrm, u)
+    ab = rng.normal(0, 1, (n, 2))
+    pts = (ab[:, :1] * u + ab[:, 1:] * v + 1.5 * nrm + rng.normal(0, 0.003, (n, 1)) * nrm).astype(np.float32)
+    out = rng.choice(n, n // 4, replace=False)
+    pts[out] += rng.uniform(-0.5, 0.5, (len(out), 3)).astype(np.float32)
+    seg = PointCloudSegmentation()
+    coeff, inl = seg.ransac_plane(pts, 0.01, 50, 0.99, seed)
+    assert len(inl) > n // 2
+    proj, hull, axes = seg.convex_hull_2d(pts, inl, coeff)
+    rproj, rhull, raxes = _oracle_hull(pts, inl, coeff)
+    assert axes == raxes == {2: 0, 0: 1, 1: 2}[int(np.argmax(np.abs(nrm)))]
+    assert np.array_equal(proj, rproj)
+    assert np.array_equal(hull, rhull) and 3 <= len(hull) < 200
+    assert np.abs(proj @ coeff[:3] + coeff[3]).max() < 1e-5                 # the projected points lie on the plane
+    hp = seg.compute2DConvexHull(pts, seed)                                  # the composed reference entry point
+    assert np.array_equal(hp, proj[hull])
+
+
+@pytest.mark.gpu
+def test_convex_hull_many_candidates_and_duplicates(gpu_lib):
+    """more candidates than one workgroup holds (hull-of-hulls rounds), duplicated points, collinear input"""
+    from semantic_slam_amd.segmentation import PointCloudSegmentation
+    rng = np.random.default_rng(3)
+    n = 60000
+    ang = rng.uniform(0, 2 * np.pi, n); rad = rng.uniform(0.93, 1.0, n)          # annulus: the octagon filter keeps most points
+    pts = np.stack([rad * np.cos(ang), rad * np.sin(ang), np.zeros(n)], 1).astype(np.float32)
+    pts[1000:2000] = pts[0:1000]                                                  # exact duplicates
+    coeff = np.array([0, 0, 1, 0], np.float32)
+    inl = np.arange(n, dtype=np.int32)
+    seg = PointCloudSegmentation()
+    proj, hull, axes = seg.convex_hull_2d(pts, inl, coeff)
+    rproj, rhull, raxes = _oracle_hull(pts, inl, coeff)
+    assert axes == raxes == 0 and np.array_equal(proj, rproj)
+    assert np.array_equal(hull, rhull) and len(hull) > 100
+    line = np.stack([np.linspace(0, 1, 50), np.linspace(0, 2, 50), np.zeros(50)], 1).astype(np.float32)
+    with pytest.raises(RuntimeError):
+        seg.convex_hull_2d(line, np.arange(50, dtype=np.int32), coeff)            # collinear: no 2-D hull
