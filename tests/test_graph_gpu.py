@@ -212,6 +212,28 @@ def test_batch_matches_individual(gpu_lib):
         assert np.abs(G1.estimates() - G2.estimates()).max() < 1e-9
 
 
+def test_large_batch_of_unequal_graphs_matches_individual(gpu_lib):
+    """a batch of >= 32 graphs switches the factorisation to the wider per-graph tail (levels <= 4 columns wide);
+    every graph has its own structure, one is noise-free (fixed point from the first iteration)"""
+    from semantic_slam_amd import GraphSLAM, GraphBatch
+    gps = []
+    for i in range(34):
+        g = make_graph(40 + 3 * i, 8 + (i % 5), seed=100 + i, noise_scale=0.0 if i == 7 else 1.0)
+        gps.append(GraphProblem.from_synth(g, interleave=bool(i & 1)))
+    singles = [GraphSLAM.from_problem(gp) for gp in gps]
+    for G in singles:
+        G.optimize(6)
+    batch_graphs = [GraphSLAM.from_problem(gp) for gp in gps]
+    B = GraphBatch(batch_graphs)
+    B.upload()
+    stats = B.optimize(6)
+    B.download()
+    for G1, G2, st in zip(singles, batch_graphs, stats):
+        assert st.iterations == G1.last_stats.iterations
+        assert st.chi2_after == pytest.approx(G1.last_stats.chi2_after, rel=1e-9, abs=1e-18)
+        assert np.abs(G1.estimates() - G2.estimates()).max() < 1e-9
+
+
 def test_marginals_match_oracle(gpu_lib):
     from semantic_slam_amd import GraphSLAM
     g = make_graph(40, 8, seed=6)
