@@ -615,65 +615,122 @@ __global__ __launch_bounds__(kRowThreads) void k_linearize_rowthread(BatchView V
     const int4 rec = V.pslot_rec[s];
     const int e = rec.x, kind = rec.y & 15, ia = rec.z, ib = rec.w;   // kind 3 (hand-over) is evaluated like kind 1 here
     if (kind != 2) {
+      // EdgeSE3: both Jacobians are 2 x 2 block upper triangular in 3 x 3 blocks,
+      //   J_i = [[-Ra, 2 Ra [tb]x], [0, Ci]],   J_j = [[Re, 0], [0, Fj]],
+      // so J^T Omega J is formed from 3 x 3 products of the blocks (half the FMAs and a smaller live set than dense 6 x 6).
       const int n = V.nEo;
       const bool iside = (kind == 0);
       Se3Lin L;
       se3_error(iside ? Xown : load_pose16(V.pose, ia), iside ? load_pose16(V.pose, ib) : Xown, load_meas_pose(V.eo_z, n, e), L);
-      L.Re = qmat(L.qe);
-      double Js[36];   // Js[c*6 + q] = J_self[q][c]
+      double P[9], Q[9], R[9];   // Omega = [[P, Q], [Q^T, R]]
 #pragma unroll
-      for (int c = 0; c < 6; ++c) {
-        double col[6];
-        if (iside) se3_Ji_col(L, c, col); else se3_Jj_col(L, c, col);
+      for (int r = 0; r < 3; ++r)
 #pragma unroll
-        for (int q = 0; q < 6; ++q) Js[c * 6 + q] = col[q];
+        for (int c = 0; c < 3; ++c) {
+          P[r * 3 + c] = V.eo_w[(size_t)(r <= c ? tri21(r, c) : tri21(c, r)) * n + e];
+          Q[r * 3 + c] = V.eo_w[(size_t)tri21(r, 3 + c) * n + e];
+          R[r * 3 + c] = V.eo_w[(size_t)(r <= c ? tri21(3 + r, 3 + c) : tri21(3 + c, 3 + r)) * n + e];
+        }
+      double A[9], B[9], Cc[9];   // own Jacobian [[A, B], [0, Cc]]  (B = 0 on the j side)
+      if (iside) {
+        const Vec3 tb = L.tb;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+          const double r0 = L.Ra.m[r * 3], r1 = L.Ra.m[r * 3 + 1], r2 = L.Ra.m[r * 3 + 2];
+          A[r * 3] = -r0; A[r * 3 + 1] = -r1; A[r * 3 + 2] = -r2;
+          B[r * 3 + 0] = 2 * (r1 * tb.z - r2 * tb.y);     // Ra * (0, tz, -ty)
+          B[r * 3 + 1] = 2 * (-r0 * tb.z + r2 * tb.x);    // Ra * (-tz, 0, tx)
+          B[r * 3 + 2] = 2 * (r0 * tb.y - r1 * tb.x);     // Ra * (ty, -tx, 0)
+        }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          const Quat vk = {k == 0 ? 1.0 : 0.0, k == 1 ? 1.0 : 0.0, k == 2 ? 1.0 : 0.0, 0.0};
+          const Quat t = qmul(qmul(L.qa, vk), L.qb);
+          Cc[0 * 3 + k] = -L.s * t.x; Cc[1 * 3 + k] = -L.s * t.y; Cc[2 * 3 + k] = -L.s * t.z;
+        }
       }
-      double U[21];
+      double E[9], F[9];          // J_j = [[E, 0], [0, F]]
+      {
+        const Mat3 Re = qmat(L.qe);
+        const double w = L.s * L.qe.w, x = L.s * L.qe.x, y = L.s * L.qe.y, z = L.s * L.qe.z;
 #pragma unroll
-      for (int k = 0; k < 21; ++k) U[k] = V.eo_w[(size_t)k * n + e];
+        for (int q = 0; q < 9; ++q) E[q] = Re.m[q];
+        F[0] = w; F[1] = -z; F[2] = y; F[3] = z; F[4] = w; F[5] = -x; F[6] = -y; F[7] = x; F[8] = w;
+      }
+      if (!iside) {
+#pragma unroll
+        for (int q = 0; q < 9; ++q) { A[q] = E[q]; B[q] = 0.0; Cc[q] = F[q]; }
+      }
+      // M = J_self^T Omega = [[A^T P, A^T Q], [B^T P + C^T Q^T, B^T Q + C^T R]]
+      double M11[9], M12[9], M21[9], M22[9];
+#pragma unroll
+      for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          double m11 = 0, m12 = 0, m21 = 0, m22 = 0;
+#pragma unroll
+          for (int r = 0; r < 3; ++r) {
+            m11 += A[r * 3 + a] * P[r * 3 + c];
+            m12 += A[r * 3 + a] * Q[r * 3 + c];
+            m21 += Cc[r * 3 + a] * Q[c * 3 + r];
+            m22 += Cc[r * 3 + a] * R[r * 3 + c];
+          }
+          if (iside) {
+#pragma unroll
+            for (int r = 0; r < 3; ++r) { m21 += B[r * 3 + a] * P[r * 3 + c]; m22 += B[r * 3 + a] * Q[r * 3 + c]; }
+          }
+          M11[a * 3 + c] = m11; M12[a * 3 + c] = m12; M21[a * 3 + c] = m21; M22[a * 3 + c] = m22;
+        }
       const int blk = iside ? V.eo_blk[e] : -1;
-      if (blk >= 0) {   // owner: stream the columns of the other vertex's Jacobian, two at a time
+      if (blk >= 0) {   // owner of the off-diagonal block: J_i^T Omega J_j = [[M11 E, M12 F], [M21 E, M22 F]]
         double* O = V.Hpp_off + (size_t)(blk >> 1) * 36;
         const bool swapped = blk & 1;
+        double o[36];
 #pragma unroll
-        for (int c = 0; c < 6; c += 2) {
-          double cj0[6], cj1[6], v0[6], v1[6];
-          se3_Jj_col(L, c, cj0); se3_Jj_col(L, c + 1, cj1);
-          sym6_mul(U, cj0, v0); sym6_mul(U, cj1, v1);
-          double d0[6], d1[6];   // (Ji^T W Jj)[a][c], [a][c+1]
+        for (int a = 0; a < 3; ++a)
 #pragma unroll
-          for (int a = 0; a < 6; ++a) {
-            double x = 0, y = 0;
+          for (int c = 0; c < 3; ++c) {
+            double o11 = 0, o12 = 0, o21 = 0, o22 = 0;
 #pragma unroll
-            for (int q = 0; q < 6; ++q) { x += Js[a * 6 + q] * v0[q]; y += Js[a * 6 + q] * v1[q]; }
-            d0[a] = x; d1[a] = y;
+            for (int r = 0; r < 3; ++r) {
+              o11 += M11[a * 3 + r] * E[r * 3 + c]; o12 += M12[a * 3 + r] * F[r * 3 + c];
+              o21 += M21[a * 3 + r] * E[r * 3 + c]; o22 += M22[a * 3 + r] * F[r * 3 + c];
+            }
+            o[a * 6 + c] = o11; o[a * 6 + 3 + c] = o12; o[(3 + a) * 6 + c] = o21; o[(3 + a) * 6 + 3 + c] = o22;
           }
-          if (!swapped) {       // stored [row_i][row_j]: entries (a, c), (a, c+1) are adjacent
+        if (!swapped) {   // stored [row_i][row_j]
 #pragma unroll
-            for (int a = 0; a < 6; ++a) store2(O + a * 6 + c, d0[a], d1[a]);
-          } else {              // stored transposed: rows c and c+1, pairs of adjacent a
+          for (int k = 0; k < 36; k += 2) store2(O + k, o[k], o[k + 1]);
+        } else {          // stored transposed
 #pragma unroll
-            for (int a = 0; a < 6; a += 2) { store2(O + c * 6 + a, d0[a], d0[a + 1]); store2(O + (c + 1) * 6 + a, d1[a], d1[a + 1]); }
-          }
+          for (int c = 0; c < 6; ++c)
+#pragma unroll
+            for (int a = 0; a < 6; a += 2) store2(O + c * 6 + a, o[a * 6 + c], o[(a + 1) * 6 + c]);
         }
       }
-      double We[6];
-      sym6_mul(U, L.e, We);
+      // diagonal block J^T Omega J (upper triangle) and b -= J^T Omega e
 #pragma unroll
-      for (int c = 0; c < 6; ++c) {
-        double vs[6];
-        sym6_mul(U, Js + c * 6, vs);
+      for (int a = 0; a < 3; ++a) {
 #pragma unroll
-        for (int a = 0; a <= c; ++a) {
-          double d = 0;
+        for (int c = 0; c < 3; ++c) {
+          double d11 = 0, d12 = 0, d22 = 0;
 #pragma unroll
-          for (int q = 0; q < 6; ++q) d += Js[a * 6 + q] * vs[q];
-          accD[tri21(a, c)][tid] += d;
+          for (int r = 0; r < 3; ++r) {
+            d11 += M11[a * 3 + r] * A[r * 3 + c];
+            d12 += M12[a * 3 + r] * Cc[r * 3 + c];
+            d22 += M22[a * 3 + r] * Cc[r * 3 + c];
+          }
+          if (iside) {
+#pragma unroll
+            for (int r = 0; r < 3; ++r) { d12 += M11[a * 3 + r] * B[r * 3 + c]; d22 += M21[a * 3 + r] * B[r * 3 + c]; }
+          }
+          if (a <= c) { accD[tri21(a, c)][tid] += d11; accD[tri21(3 + a, 3 + c)][tid] += d22; }
+          accD[tri21(a, 3 + c)][tid] += d12;
         }
-        double bb = 0;
-#pragma unroll
-        for (int q = 0; q < 6; ++q) bb += Js[c * 6 + q] * We[q];
-        accD[21 + c][tid] -= bb;
+        accD[21 + a][tid] -= M11[a * 3] * L.e[0] + M11[a * 3 + 1] * L.e[1] + M11[a * 3 + 2] * L.e[2] +
+                             M12[a * 3] * L.e[3] + M12[a * 3 + 1] * L.e[4] + M12[a * 3 + 2] * L.e[5];
+        accD[24 + a][tid] -= M21[a * 3] * L.e[0] + M21[a * 3 + 1] * L.e[1] + M21[a * 3 + 2] * L.e[2] +
+                             M22[a * 3] * L.e[3] + M22[a * 3 + 1] * L.e[4] + M22[a * 3 + 2] * L.e[5];
       }
     } else {
       const int n = V.nEl;
