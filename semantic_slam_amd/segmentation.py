@@ -246,6 +246,25 @@ def bench_frontend(device: int = 0, frames: int = 8, cpu_baseline: bool = True) 
            "algorithmic_bytes_per_frame": 32 * npx,
            "achieved_GBps": round(32 * npx / (kms / frames * 1e-3) / 1e9, 3),
            "regime": "latency-bound: one frame (12.6 MB algorithmic) is far below the MALL; raster recurrences run as 64-row wavefronts"}
+    # throughput with several handles in flight (one stream each; a frame's 32 boxes occupy a fraction of the 256 CUs)
+    import threading
+    nh = 8
+    segs = [PointCloudSegmentation(device=device) for _ in range(nh)]
+    for sg in segs:
+        sg.segmentallPointCloudData(fs[0].robot_pose, fs[0].cam_angle, fs[0].boxes, fs[0])   # warm-up (allocation)
+    counts = [0] * nh
+    def work(i):
+        for k in range(frames):
+            f = fs[(i + k) % len(fs)]
+            counts[i] += len(segs[i].segmentallPointCloudData(f.robot_pose, f.cam_angle, f.boxes, f))
+    ths = [threading.Thread(target=work, args=(i,)) for i in range(nh)]
+    t2 = time.perf_counter()
+    for t in ths: t.start()
+    for t in ths: t.join()
+    wall_c = time.perf_counter() - t2
+    res["concurrent_handles"] = {"handles": nh, "frames": nh * frames, "planes_per_sec_incl_pcie_and_host": round(sum(counts) / wall_c, 1),
+                                 "frames_per_sec": round(nh * frames / wall_c, 1)}
+    del segs
     if cpu_baseline:
         t1 = time.perf_counter(); np_cpu = 0; nf = 0
         while time.perf_counter() - t1 < 6.0:
