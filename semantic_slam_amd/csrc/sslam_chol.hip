@@ -31,12 +31,17 @@ struct ColMeta { int xoff, dim, graph, b0, nb, base, csize, ubase, ucount, ibase
 struct BlkMeta { int off, di, src, fmt, up0, up1, rowcol, xoff_row, it0, nit; };   // src: H offset or -1; rowcol: column id of the
                                                                                    // row; [it0, it0 + nit) = items of this block
 struct UpdMeta { int ua, ub, ux, pk; };                                  // offsets of L_ik, L_jk, y_k; pk = target descriptor:
+constexpr int kMaxSn = 6;               // columns per supernode
+struct SnMeta { int q0, s, ibase, icount, chunk, lds, poff[kMaxSn + 2]; };   // supernode = tail columns [q0, q0 + s) (a chain with
+                                       // nested structure), its external-update items [ibase, ibase + icount), LDS doubles needed,
+                                       // LDS panel offset of every column (poff[s] = panel size)
 struct ItemMeta { UpdMeta first; int u0, n, pad0, pad1; };               // <= chunk consecutive updates of ONE target block; the
                                                                          // first update rides along (one dependent load less)
 constexpr int kUpdToffMask = 0xFFFFF;   // pk bits 0..19: offset of the target block inside its column
 constexpr int kUpdDi6 = 1 << 20;        // target block has 6 rows (else 3)
 constexpr int kUpdDk6 = 1 << 21;        // source column k is 6 wide (else 3)
 constexpr int kUpdDiag = 1 << 22;       // target is the diagonal block (carries the forward-substitution rhs too)
+constexpr int kUpdDj6 = 1 << 23;        // target column is 6 wide (else 3)
 
 struct CholView {
   int ncol, nlevels, dim;
@@ -48,6 +53,8 @@ struct CholView {
   const ColMeta* lcol;   // col[lvl_cols[.]]: the level kernels start from one load instead of two dependent ones
   const int* tail_ptr;   // [B + 1] per graph: its columns factored by k_chol_tail, in elimination order
   const int* tail_cols;
+  const int* sn_ptr;     // [B + 1] supernodes of each graph's tail, in elimination order
+  const SnMeta* sn;
   double* Lval;
   double* y;             // forward-substituted rhs [dim]
   int* fail;             // [B]
@@ -84,7 +91,8 @@ void chol_plan_free(CholPlan* p) {
 // forward-substitutes the rhs; the other waves pick L_jj and the reciprocal pivots up from LDS and one thread
 // per off-diagonal row solves x L_jj^T = v.  Pivots are inverted once (rsqrt) and multiplied from then on:
 // FP64 sqrt / divide sequences are what the leaf levels of a batch are bound by.
-template <int D, int NT>
+// KEEP: the factored column (L_jj, the solved rows, y_j) is also written back into `sm` for the in-LDS updates of a supernode
+template <int D, int NT, bool KEEP = false>
 __device__ __forceinline__ void chol_tail(double* sm, int csize, double* fac, double* Lw, double* yout, int* fail, int tid) {
   double a[D * D], inv[D];
   if (tid < 64) {
@@ -126,6 +134,12 @@ __device__ __forceinline__ void chol_tail(double* sm, int csize, double* fac, do
       for (int q = 0; q < D * D; ++q) Lw[q] = a[q];
 #pragma unroll
       for (int q = 0; q < D; ++q) yout[q] = t[q];
+      if (KEEP) {
+#pragma unroll
+        for (int q = 0; q < D * D; ++q) sm[q] = a[q];
+#pragma unroll
+        for (int q = 0; q < D; ++q) sm[csize + q] = t[q];
+      }
       if (NT > 64) {
 #pragma unroll
         for (int q = 0; q < D * D; ++q) fac[q] = a[q];
@@ -158,6 +172,11 @@ __device__ __forceinline__ void chol_tail(double* sm, int csize, double* fac, do
     double* o = Lw + D * D + row * D;
 #pragma unroll
     for (int c = 0; c < D; ++c) o[c] = x[c];
+    if (KEEP) {
+      double* w = sm + D * D + row * D;
+#pragma unroll
+      for (int c = 0; c < D; ++c) w[c] = x[c];
+    }
   }
 }
 
@@ -212,7 +231,7 @@ __device__ __forceinline__ void chol_column(const BatchView& V, const CholView& 
       const bool have = it < icount;
       const ItemMeta im = C.item[cm.ibase + min(it, icount - 1)];
       const int tpk = im.first.pk;
-      const int di = (tpk & kUpdDi6) ? 6 : 3;
+      const int di = (tpk & kUpdDi6) ? 6 : 3, dj = (tpk & kUpdDj6) ? 6 : 3;
       const bool diag = tpk & kUpdDiag;
       const bool tile = have && 3 * tr < di && 3 * tc < dj;
       const int tre = 3 * tr < di ? tr : 0, tce = 3 * tc < dj ? tc : 0;   // idle lanes shadow tile (0, 0): valid addresses
@@ -399,17 +418,234 @@ __global__ __launch_bounds__(NT) void k_chol_level(BatchView V, CholView C, int 
   chol_column<NT>(V, C, C.lcol[lvl_begin + blockIdx.x], sm);
 }
 
+// One step of the tail kernel: a *supernode* = s <= kMaxSn consecutive tail columns that form a chain of the elimination
+// tree with nested structure (column p+1 is the parent of column p and owns exactly its remaining rows; blocks 3 or 6 wide).
+//   1. external updates (sources outside the supernode) of all s columns at once: the item scheme of chol_column,
+//   2. A(:,j) + lambda I - item partials -> an LDS panel holding the s columns back to back,
+//   3. for p = 0 .. s-1: factor column p in the panel (diagonal block, row solves, forward substitution), then apply
+//      it to the later columns of the panel straight from LDS:  S(i, p') -= L(i, p) L(p', p)^T,  rhs(p') -= L(p', p) y_p.
+//      Block b' of column p' is block b' + (p' - p) of column p (nested, sorted row lists).
+// A chain of s columns costs one latency-bound update phase instead of s; singletons (s = 1) skip step 3's updates.
+template <int NT>
+__device__ __forceinline__ void chol_supernode(const BatchView& V, const CholView& C, const SnMeta sn, const int g, double* sm) {
+  constexpr int NW = NT / 64;
+  constexpr int kMaxRows = 192;                 // rows of the supernode's first column (LDS table; the host checks)
+  __shared__ int t_drow[kMaxRows];              // dim of row i of column 0 (row p = column p itself, then the common rows)
+  __shared__ int t_rpre[kMaxRows + 1];          // prefix sums of t_drow
+  __shared__ int t_col[kMaxSn][4];              // per column: Lval base, x offset, first block record, (unused)
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const int s = sn.s;
+  const ColMeta cm0 = C.col[C.tail_cols[sn.q0]];
+  const int nb0 = cm0.nb;                               // column p of the chain has nb0 - p blocks (nested row lists)
+  auto poff = [&](int p) {
+    int v = sn.poff[0];
+#pragma unroll
+    for (int q = 1; q <= kMaxSn; ++q) v = p == q ? sn.poff[q] : v;
+    return v;
+  };
+  const int panel = poff(s);
+  const double lambda = V.lm[g].lambda;
+  const double* __restrict__ H = V.Hpp_diag;
+  const double* __restrict__ L = C.Lval;
+  const double* __restrict__ Y = C.y;
+  double* part = sm + panel;
+  const int ry = lane - 40;
+  // table of the step (consumed after the barrier that ends phase 1)
+  if (tid < nb0) {   // block i of column 0 starts at (sum of the row dims before it) x dim(column 0)
+    const BlkMeta b0m = C.blk[cm0.b0 + tid];
+    t_drow[tid] = b0m.di;
+    t_rpre[tid] = (b0m.off - cm0.base) / cm0.dim;
+    if (tid == 0) t_rpre[nb0] = cm0.csize / cm0.dim;
+  }
+  if (tid >= 64 && tid < 64 + s) {
+    const ColMeta cp = C.col[C.tail_cols[sn.q0 + (tid - 64)]];
+    t_col[tid - 64][0] = cp.base; t_col[tid - 64][1] = cp.xoff; t_col[tid - 64][2] = cp.b0;
+  }
+  // ---- 1. external updates (item scheme of chol_column; the target's width rides in the item record)
+  {
+    const int tr = (lane >> 1) & 1, tc = lane & 1;
+    const int icount = sn.icount, chunk = sn.chunk;
+    for (int it0 = wave * 16; it0 < icount; it0 += NT / 4) {
+      const int it = it0 + (lane >> 2);
+      const bool have = it < icount;
+      const ItemMeta im = C.item[sn.ibase + min(it, icount - 1)];
+      const int tpk = im.first.pk;
+      const int di = (tpk & kUpdDi6) ? 6 : 3, dj = (tpk & kUpdDj6) ? 6 : 3;
+      const bool diag = tpk & kUpdDiag;
+      const bool tile = have && 3 * tr < di && 3 * tc < dj;
+      const int tre = 3 * tr < di ? tr : 0, tce = 3 * tc < dj ? tc : 0;
+      double acc[9], accy[3];
+#pragma unroll
+      for (int q = 0; q < 9; ++q) acc[q] = 0;
+#pragma unroll
+      for (int q = 0; q < 3; ++q) accy[q] = 0;
+      UpdMeta um = im.first;
+      for (int k = 0; k < chunk; ++k) {
+        const bool live = k < im.n;
+        const UpdMeta nx = C.upd[im.u0 + min(k + 1, im.n - 1)];
+        const int dk = (um.pk & kUpdDk6) ? 6 : 3;
+        const double* A = L + um.ua + 3 * tre * dk;
+        const double* B = L + um.ub + 3 * tce * dk;
+        const double* yk = Y + um.ux;
+        double a[18], bb[18], yv[6];
+        if (dk == 6) {
+#pragma unroll
+          for (int q = 0; q < 9; ++q) {
+            const d2u va = *(const d2u*)(A + 2 * q), vb = *(const d2u*)(B + 2 * q);
+            a[2 * q] = va.x; a[2 * q + 1] = va.y; bb[2 * q] = vb.x; bb[2 * q + 1] = vb.y;
+          }
+#pragma unroll
+          for (int q = 0; q < 6; ++q) yv[q] = yk[q];
+        } else {
+#pragma unroll
+          for (int rr = 0; rr < 3; ++rr)
+#pragma unroll
+            for (int q = 0; q < 6; ++q) {
+              a[rr * 6 + q] = q < 3 ? A[rr * 3 + q] : 0.0;
+              bb[rr * 6 + q] = q < 3 ? B[rr * 3 + q] : 0.0;
+            }
+#pragma unroll
+          for (int q = 0; q < 6; ++q) yv[q] = q < 3 ? yk[q] : 0.0;
+        }
+        if (live) {
+#pragma unroll
+          for (int rr = 0; rr < 3; ++rr) {
+#pragma unroll
+            for (int cc = 0; cc < 3; ++cc) {
+              double d = acc[rr * 3 + cc];
+#pragma unroll
+              for (int q = 0; q < 6; ++q) d += a[rr * 6 + q] * bb[cc * 6 + q];
+              acc[rr * 3 + cc] = d;
+            }
+            double d = accy[rr];
+#pragma unroll
+            for (int q = 0; q < 6; ++q) d += a[rr * 6 + q] * yv[q];
+            accy[rr] = d;
+          }
+        }
+        um = nx;
+      }
+      if (tile) {
+        double* o = part + it * kItemDoubles;
+#pragma unroll
+        for (int rr = 0; rr < 3; ++rr) {
+#pragma unroll
+          for (int cc = 0; cc < 3; ++cc) o[(3 * tr + rr) * dj + 3 * tc + cc] = acc[rr * 3 + cc];
+          if (diag && tc == 0) o[36 + 3 * tr + rr] = accy[rr];
+        }
+      }
+    }
+  }
+  __syncthreads();
+  // ---- 2. A(:,j) + lambda I - partials -> panel; one wave per (column, block) pair, four pairs in flight per wave
+  {
+    int total = 0;
+    for (int p = 0; p < s; ++p) total += nb0 - p;
+    constexpr int kPipe = 4;
+    for (int idx0 = wave; idx0 < total; idx0 += NW * kPipe) {
+      BlkMeta bm[kPipe];
+      int pp[kPipe], bb2[kPipe];
+#pragma unroll
+      for (int k = 0; k < kPipe; ++k) {
+        const int idx = min(idx0 + k * NW, total - 1);
+        int p = 0, bi = idx;
+        while (bi >= nb0 - p) { bi -= nb0 - p; ++p; }
+        pp[k] = p; bb2[k] = bi;
+        bm[k] = C.blk[__builtin_amdgcn_readfirstlane(t_col[p][2] + bi)];
+      }
+      double hv[kPipe];
+#pragma unroll
+      for (int k = 0; k < kPipe; ++k) {
+        const int p = pp[k], bi = bb2[k];
+        const int dj = t_drow[p];
+        const int r = lane / dj, c = lane - r * dj;
+        const bool diag = (bi == 0);
+        const bool ent = lane < bm[k].di * dj, rhs = diag && ry >= 0 && ry < dj;
+        double v = 0;
+        if (ent) {
+          if (bm[k].src >= 0) v = bm[k].fmt ? H[bm[k].src + c * bm[k].di + r] : H[bm[k].src + r * dj + c];
+          if (diag && r == c) v += lambda;
+        } else if (rhs) {
+          v = V.bvec[t_col[p][1] + ry];
+        }
+        hv[k] = v;
+      }
+#pragma unroll
+      for (int k = 0; k < kPipe; ++k) {
+        if (idx0 + k * NW >= total) continue;
+        const int p = pp[k], bi = bb2[k];
+        const int dj = t_drow[p];
+        const bool diag = (bi == 0);
+        const bool ent = lane < bm[k].di * dj, rhs = diag && ry >= 0 && ry < dj;
+        if (ent || rhs) {
+          double v = hv[k];
+          const double* q0 = part + (bm[k].it0 - sn.ibase) * kItemDoubles + (ent ? lane : 36 + ry);
+          for (int q = 0; q < bm[k].nit; ++q) v -= q0[q * kItemDoubles];
+          const int csz = (t_rpre[nb0] - t_rpre[p]) * dj;
+          sm[poff(p) + (ent ? (t_rpre[p + bi] - t_rpre[p]) * dj + lane : csz + ry)] = v;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  // ---- 3. factor the panel column by column; offsets come from the row table (no global metadata on this path)
+  for (int p = 0; p < s; ++p) {
+    const int dp = t_drow[p];
+    const int csz = (t_rpre[nb0] - t_rpre[p]) * dp;
+    double* col = sm + poff(p);
+    double* Lw = C.Lval + t_col[p][0];
+    double* yo = C.y + t_col[p][1];
+    if (s > 1) {
+      if (dp == 6) chol_tail<6, NT, true>(col, csz, part, Lw, yo, C.fail + g, tid);
+      else chol_tail<3, NT, true>(col, csz, part, Lw, yo, C.fail + g, tid);
+    } else {
+      if (dp == 6) chol_tail<6, NT>(col, csz, part, Lw, yo, C.fail + g, tid);
+      else chol_tail<3, NT>(col, csz, part, Lw, yo, C.fail + g, tid);
+    }
+    if (p + 1 < s) {
+      __syncthreads();
+      int total = 0;
+      for (int p2 = p + 1; p2 < s; ++p2) total += nb0 - p2;
+      for (int idx = wave; idx < total; idx += NW) {
+        int p2 = p + 1, b2 = idx;
+        while (b2 >= nb0 - p2) { b2 -= nb0 - p2; ++p2; }
+        const int d2 = t_drow[p2], di = t_drow[p2 + b2];
+        const double* Ab = col + (t_rpre[p2 + b2] - t_rpre[p]) * dp;     // L(row p2 + b2, p)
+        const double* Bb = col + (t_rpre[p2] - t_rpre[p]) * dp;          // L(p2, p)
+        double* tgt = sm + poff(p2);
+        if (lane < di * d2) {
+          const int r = lane / d2, c = lane - r * d2;
+          const double* pa = Ab + r * dp;
+          const double* pb = Bb + c * dp;
+          double d = pa[0] * pb[0] + pa[1] * pb[1] + pa[2] * pb[2];
+          if (dp == 6) d += pa[3] * pb[3] + pa[4] * pb[4] + pa[5] * pb[5];
+          tgt[(t_rpre[p2 + b2] - t_rpre[p2]) * d2 + lane] -= d;
+        } else if (b2 == 0 && ry >= 0 && ry < d2) {
+          const double* pb = Bb + ry * dp;
+          const double* yp = col + csz;                                  // y_p sits behind the column's entries
+          double d = pb[0] * yp[0] + pb[1] * yp[1] + pb[2] * yp[2];
+          if (dp == 6) d += pb[3] * yp[3] + pb[4] * yp[4] + pb[5] * yp[5];
+          tgt[(t_rpre[nb0] - t_rpre[p2]) * d2 + ry] -= d;
+        }
+      }
+      __syncthreads();
+    }
+  }
+}
+
 // Top of the elimination tree: once a graph's levels are at most a couple of columns wide, a launch per level
-// only buys launch latency and cold caches.  One workgroup per graph walks those columns in elimination order;
-// the barrier between columns orders the L / y stores of one column before the loads of the next (same CU).
+// only buys launch latency and cold caches.  One workgroup per graph walks those columns in elimination order,
+// a supernode at a time; the barrier between steps orders the L / y stores of one step before the loads of the next
+// (same CU).
 template <int NT>
 __global__ __launch_bounds__(NT) void k_chol_tail(BatchView V, CholView C) {
   extern __shared__ double sm[];
   const int g = blockIdx.x;
   if (!V.lm[g].in_trial) return;
-  const int q1 = C.tail_ptr[g + 1];
-  for (int q = C.tail_ptr[g]; q < q1; ++q) {
-    chol_column<NT>(V, C, C.col[C.tail_cols[q]], sm);
+  const int n1 = C.sn_ptr[g + 1];
+  for (int n = C.sn_ptr[g]; n < n1; ++n) {
+    chol_supernode<NT>(V, C, C.sn[n], g, sm);
     __threadfence_block();
     __syncthreads();
   }
@@ -706,10 +942,28 @@ int chol_plan_build(Batch& b) {
       for (int j = c0; j < c1; ++j) width[level[j]]++;
       int cut = gl;
       while (cut > 0 && width[cut - 1] <= tail_width) --cut;
-      std::vector<std::pair<int, int>> tl;
-      for (int j = c0; j < c1; ++j) if (level[j] >= cut) { is_tail[j] = 1; tl.push_back({level[j], j}); }
-      std::sort(tl.begin(), tl.end());
-      for (auto& pr : tl) tail_cols.push_back(pr.second);
+      // tail columns in post-order of their subtree (children before parents; any topological order is valid for the
+      // sequential tail kernel): chains of the elimination tree become contiguous, which is what supernodes need
+      for (int j = c0; j < c1; ++j)   // the tail kernel keeps a row table of 192 entries in LDS
+        if (level[j] >= cut && bp[j + 1] - bp[j] > 192) { cut = gl; break; }
+      std::vector<std::vector<int>> kids(c1 - c0);
+      std::vector<int> roots;
+      for (int j = c0; j < c1; ++j) {
+        if (level[j] < cut) continue;
+        is_tail[j] = 1;
+        const int par = bp[j + 1] - bp[j] > 1 ? brow[bp[j] + 1] : -1;
+        if (par >= 0) kids[par - c0].push_back(j); else roots.push_back(j);
+      }
+      std::vector<std::pair<int, size_t>> stack;   // (column, next child)
+      for (int rt : roots) {
+        stack.push_back({rt, 0});
+        while (!stack.empty()) {
+          auto& top = stack.back();
+          const std::vector<int>& ch = kids[top.first - c0];
+          if (top.second < ch.size()) { const int nx = ch[top.second++]; stack.push_back({nx, 0}); }
+          else { tail_cols.push_back(top.first); stack.pop_back(); }
+        }
+      }
       tail_ptr[g + 1] = (int)tail_cols.size();
       c0 = c1;
     }
@@ -749,41 +1003,109 @@ int chol_plan_build(Batch& b) {
     for (int t = bp[j]; t < bp[j + 1]; ++t) {
       const int toff = boff[t] - boff[bp[j]];
       if (toff > kUpdToffMask) return set_error(SSLAM_ERR_UNSUPPORTED, "a factor column has more than 2^20 entries");
-      const int tpk = toff | (col_dim[brow[t]] == 6 ? kUpdDi6 : 0) | (t == bp[j] ? kUpdDiag : 0);
+      const int tpk = toff | (col_dim[brow[t]] == 6 ? kUpdDi6 : 0) | (t == bp[j] ? kUpdDiag : 0) | (col_dim[j] == 6 ? kUpdDj6 : 0);
       for (int u = up[t]; u < up[t + 1]; ++u) updm[u] = UpdMeta{ua[u], ub[u], ux[u], tpk | (udk[u] == 6 ? kUpdDk6 : 0)};
     }
   std::vector<int> col_lds(ncol, 0), col_et(ncol, 0);   // LDS doubles the column needs with items; entries + rhs
-  for (int j = 0; j < ncol; ++j) {
-    const int last = bp[j + 1] - 1;
-    const int U = up[bp[j + 1]] - up[bp[j]];
-    const int chunk = std::max(1, (U + kItemsPerColumn - 1) / kItemsPerColumn);
+  auto col_csize = [&](int j) { const int last = bp[j + 1] - 1; return boff[last] - boff[bp[j]] + col_dim[brow[last]] * col_dim[j]; };
+  // items of one column; updates whose source column is flagged in `skip` (the column's own supernode) are left out
+  auto build_items = [&](int j, int chunk, const std::vector<char>* skip) {
     const int ibase = (int)itemm.size();
     for (int t = bp[j]; t < bp[j + 1]; ++t) {
       const int it0 = (int)itemm.size();
-      for (int u = up[t]; u < up[t + 1]; u += chunk) itemm.push_back(ItemMeta{updm[u], u, std::min(chunk, up[t + 1] - u), 0, 0});
+      int u = up[t];
+      while (u < up[t + 1]) {
+        if (skip && (*skip)[uk[u]]) { ++u; continue; }
+        int n = 1;
+        while (n < chunk && u + n < up[t + 1] && !(skip && (*skip)[uk[u + n]])) ++n;
+        itemm.push_back(ItemMeta{updm[u], u, n, 0, 0});
+        u += n;
+      }
       blkm[t] = BlkMeta{boff[t], col_dim[brow[t]], bsrc[t], (int)bfmt[t], up[t], up[t + 1], brow[t], col_xoff[brow[t]], it0, (int)itemm.size() - it0};
     }
     const int icount = (int)itemm.size() - ibase;
-    const int csize = boff[last] - boff[bp[j]] + col_dim[brow[last]] * col_dim[j];
-    colm[j] = ColMeta{col_xoff[j], col_dim[j], col_graph[j], bp[j], bp[j + 1] - bp[j], boff[bp[j]], csize, up[bp[j]], U, ibase, icount, chunk};
-    col_lds[j] = csize + col_dim[j] + std::max(icount, 1) * kItemDoubles;
-    col_et[j] = csize + col_dim[j];
+    const int U = up[bp[j + 1]] - up[bp[j]];
+    colm[j] = ColMeta{col_xoff[j], col_dim[j], col_graph[j], bp[j], bp[j + 1] - bp[j], boff[bp[j]], col_csize(j), up[bp[j]], U, ibase, icount, chunk};
+    col_et[j] = col_csize(j) + col_dim[j];
+    col_lds[j] = col_et[j] + std::max(icount, 1) * kItemDoubles;
+  };
+  for (int j = 0; j < ncol; ++j) {
+    if (is_tail[j]) continue;
+    const int U = up[bp[j + 1]] - up[bp[j]];
+    build_items(j, std::max(1, (U + kItemsPerColumn - 1) / kItemsPerColumn), nullptr);
+  }
+  // supernodes of every tail: maximal chains (next tail column = parent with exactly one row less, all blocks 6 x 6)
+  std::vector<SnMeta> snm;
+  std::vector<int> sn_ptr(V.B + 1, 0);
+  std::vector<char> in_sn(ncol, 0);
+  int sn_max = kMaxSn;
+  if (const char* e = getenv("SSLAM_CHOL_SUPERNODE")) sn_max = std::max(1, std::min(kMaxSn, atoi(e)));
+  P->tail_maxEt = 0;
+  for (int g = 0; g < V.B; ++g) {
+    int q = tail_ptr[g];
+    while (q < tail_ptr[g + 1]) {
+      int s_len = 1;
+      while (s_len < sn_max && q + s_len < tail_ptr[g + 1]) {
+        const int jl = tail_cols[q + s_len - 1], jn = tail_cols[q + s_len];
+        const int nbl = bp[jl + 1] - bp[jl], nbn = bp[jn + 1] - bp[jn];
+        if (nbl < 2 || brow[bp[jl] + 1] != jn || nbn != nbl - 1) break;
+        ++s_len;
+      }
+      for (;;) {   // shrink until the panel + item partials fit the LDS
+        for (int p = 0; p < s_len; ++p) in_sn[tail_cols[q + p]] = 1;
+        int Uext = 0, panel = 0;
+        for (int p = 0; p < s_len; ++p) {
+          const int j = tail_cols[q + p];
+          for (int u = up[bp[j]]; u < up[bp[j + 1]]; ++u) if (!(s_len > 1 && in_sn[uk[u]])) ++Uext;
+          panel += col_csize(j) + col_dim[j];
+        }
+        const int chunk = std::max(1, (Uext + kItemsPerColumn - 1) / kItemsPerColumn);
+        const size_t mark = itemm.size();
+        const int ibase = (int)mark;
+        for (int p = 0; p < s_len; ++p) build_items(tail_cols[q + p], chunk, s_len > 1 ? &in_sn : nullptr);
+        const int icount = (int)itemm.size() - ibase;
+        const int lds = panel + std::max(icount, 1) * kItemDoubles;
+        for (int p = 0; p < s_len; ++p) in_sn[tail_cols[q + p]] = 0;
+        if (s_len > 1 && (size_t)lds * sizeof(double) > 144 * 1024) { itemm.resize(mark); --s_len; continue; }
+        SnMeta rec{q, s_len, ibase, icount, chunk, lds, {0}};
+        for (int p = 0, acc = 0; p <= kMaxSn + 1; ++p) {
+          rec.poff[p] = acc;
+          if (p < s_len) acc += col_csize(tail_cols[q + p]) + col_dim[tail_cols[q + p]];
+        }
+        snm.push_back(rec);
+        P->tail_maxEt = std::max(P->tail_maxEt, lds);
+        break;
+      }
+      q += s_len;
+    }
+    sn_ptr[g + 1] = (int)snm.size();
+    if (g == 0 && getenv("SSLAM_CHOL_DUMP")) {
+      int hist[kMaxSn + 1] = {0}, n3 = 0, nrow3 = 0;
+      for (int n = sn_ptr[g]; n < sn_ptr[g + 1]; ++n) hist[snm[n].s]++;
+      for (int q2 = tail_ptr[g]; q2 < tail_ptr[g + 1]; ++q2) {
+        const int j = tail_cols[q2];
+        if (col_dim[j] != 6) ++n3;
+        for (int t = bp[j]; t < bp[j + 1]; ++t) if (col_dim[brow[t]] != 6) { ++nrow3; break; }
+      }
+      fprintf(stderr, "[chol-dump] graph 0 tail: %d columns, %d supernodes; sizes", tail_ptr[g + 1] - tail_ptr[g], sn_ptr[g + 1] - sn_ptr[g]);
+      for (int k = 1; k <= kMaxSn; ++k) fprintf(stderr, " %d:%d", k, hist[k]);
+      fprintf(stderr, "; 3-dim columns %d, columns with a 3-dim row %d\n", n3, nrow3);
+    }
   }
   P->lvl_maxEt.assign(nlev, 0);
   P->lvl_maxItemLds.assign(nlev, 0);
-  P->tail_maxEt = 0;
   for (int j = 0; j < ncol; ++j) {
-    if (is_tail[j]) P->tail_maxEt = std::max(P->tail_maxEt, col_lds[j]);
-    else {
-      P->lvl_maxEt[level[j]] = std::max(P->lvl_maxEt[level[j]], col_et[j]);
-      P->lvl_maxItemLds[level[j]] = std::max(P->lvl_maxItemLds[level[j]], col_lds[j]);
-    }
+    if (is_tail[j]) continue;
+    P->lvl_maxEt[level[j]] = std::max(P->lvl_maxEt[level[j]], col_et[j]);
+    P->lvl_maxItemLds[level[j]] = std::max(P->lvl_maxItemLds[level[j]], col_lds[j]);
   }
   int rc;
   if ((rc = up_to_dev(*P, b.stream, colm, &C.col))) return rc;
   if ((rc = up_to_dev(*P, b.stream, blkm, &C.blk))) return rc;
   if ((rc = up_to_dev(*P, b.stream, updm, &C.upd))) return rc;
   if ((rc = up_to_dev(*P, b.stream, itemm, &C.item))) return rc;
+  if ((rc = up_to_dev(*P, b.stream, sn_ptr, &C.sn_ptr))) return rc;
+  if ((rc = up_to_dev(*P, b.stream, snm, &C.sn))) return rc;
   if ((rc = up_to_dev(*P, b.stream, lvl_cols, &C.lvl_cols))) return rc;
   std::vector<ColMeta> lcolm(ncol);
   for (int q = 0; q < ncol; ++q) lcolm[q] = colm[lvl_cols[q]];
