@@ -581,7 +581,13 @@ __device__ __forceinline__ void chol_supernode(const BatchView& V, const CholVie
         if (ent || rhs) {
           double v = hv[k];
           const double* q0 = part + (bm[k].it0 - sn.ibase) * kItemDoubles + (ent ? lane : 36 + ry);
-          for (int q = 0; q < bm[k].nit; ++q) v -= q0[q * kItemDoubles];
+          double s0 = 0, s1 = 0, s2 = 0, s3 = 0;   // four independent chains (the LDS reads pipeline); fixed combination order
+          int q = 0;
+          for (; q + 4 <= bm[k].nit; q += 4) {
+            s0 += q0[q * kItemDoubles]; s1 += q0[(q + 1) * kItemDoubles]; s2 += q0[(q + 2) * kItemDoubles]; s3 += q0[(q + 3) * kItemDoubles];
+          }
+          for (; q < bm[k].nit; ++q) s0 += q0[q * kItemDoubles];
+          v -= (s0 + s1) + (s2 + s3);
           const int csz = (t_rpre[nb0] - t_rpre[p]) * dj;
           sm[poff(p) + (ent ? (t_rpre[p + bi] - t_rpre[p]) * dj + lane : csz + ry)] = v;
         }
@@ -927,7 +933,7 @@ int chol_plan_build(Batch& b) {
   }
   // tail of every graph: the levels from which on the graph is at most `tail_width` columns wide
   // (a batch keeps every level launch busy with other graphs' columns for longer, so its tails start lower)
-  int tail_width = V.B >= 32 ? 4 : 2;
+  int tail_width = V.B >= 32 ? 6 : 2;
   if (const char* e = getenv("SSLAM_CHOL_TAIL_WIDTH")) tail_width = atoi(e);
   std::vector<char> is_tail(ncol, 0);
   std::vector<int> tail_ptr(V.B + 1, 0), tail_cols;
