@@ -6,11 +6,20 @@
 // factorisation every LM trial, triangular solves.  MI355X design:
 //   * symbolic phase on the host (minimum degree with explicit fill on the 6x6/3x3 block graph,
 //     elimination tree levels, per-target-block update lists),
-//   * numeric phase level-scheduled on the device: one wave per block column, left-looking
-//     *gather* form (every L block is written by exactly one wave -> deterministic, no atomics),
-//     column staged in LDS, forward substitution fused into the factorisation (b is carried as
-//     an extra block row), backward substitution as a second top-down sweep,
-//   * all graphs of a batch share the level launches (levels are concatenated across graphs).
+//   * numeric phase on the device, left-looking *gather* form (every L block is written by exactly one
+//     workgroup -> deterministic, no atomics):
+//       - wide levels of the elimination tree: one launch per level, one workgroup (1 or 4 waves) per
+//         block column (k_chol_level<64/256>, flat update ranges staged through LDS),
+//       - narrow levels: 16 waves per column, update lists cut into <= 256 items of 4-lane register
+//         tiles (k_chol_level<1024>),
+//       - the top of the tree (levels a few columns wide): ONE launch, one workgroup per graph walking
+//         supernodes (chains with nested structure) through an LDS panel (k_chol_tail),
+//     forward substitution fused into the factorisation (b is carried as an extra block row),
+//     backward substitution as a top-down sweep with the same level / head split,
+//   * all graphs of a batch share the launches (levels are concatenated across graphs).
+// Tuning knobs read from the environment when a plan is built (defaults in parentheses):
+//   SSLAM_CHOL_TAIL_WIDTH (6 for batches of >= 32 graphs, else 2; 0 = no tail kernel),
+//   SSLAM_CHOL_SUPERNODE (6 = kMaxSn columns per supernode; 1 = singletons), SSLAM_CHOL_DUMP (level / supernode statistics).
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <cstring>
