@@ -72,6 +72,19 @@ def test_jacobian_build_is_bitwise_deterministic(gpu_lib):
     assert np.array_equal(U1.data, U2.data) and np.array_equal(b1, b2)
 
 
+def test_optimize_is_bitwise_repeatable(gpu_lib):
+    """no atomics anywhere on the default path (gather-form Jacobian build, left-looking Cholesky with ordered partial sums,
+    segmented reductions): two runs from the same state give identical bits"""
+    from semantic_slam_amd import GraphSLAM
+    gp = GraphProblem.from_synth(make_graph(300, 60, seed=21))
+    runs = []
+    for _ in range(2):
+        G = GraphSLAM.from_problem(gp)
+        assert G.optimize(6)
+        runs.append((G.estimates().copy(), G.last_stats.chi2_after))
+    assert np.array_equal(runs[0][0], runs[1][0]) and runs[0][1] == runs[1][1]
+
+
 def test_oplus_matches_oracle(gpu_lib):
     from semantic_slam_amd import GraphSLAM
     for kind in ("point", "plane"):
