@@ -199,7 +199,6 @@ __device__ __forceinline__ void chol_tail(double* sm, int csize, double* fac, do
 // and of L_jk straight from global memory (contiguous 3 dk doubles each) and does 9 dk FMAs -- no LDS staging,
 // no cross-lane traffic.  The item's tile goes to its own LDS slot; the slots of a block are summed in item
 // order -> deterministic.
-typedef double d2u __attribute__((ext_vector_type(2), aligned(8)));
 constexpr int kItemDoubles = 42;   // LDS doubles per item: 6 x 6 tile entries + 6 rhs components
 constexpr int kItemsPerColumn = 256;
 // Wide levels (NT < 1024: many columns in flight, short lists) use the other update scheme instead: the column's
@@ -257,40 +256,24 @@ __device__ __forceinline__ void chol_column(const BatchView& V, const CholView& 
         const double* A = L + um.ua + 3 * tre * dk;
         const double* B = L + um.ub + 3 * tce * dk;
         const double* yk = Y + um.ux;
-        double a[18], bb[18], yv[6];
-        if (dk == 6) {
 #pragma unroll
-          for (int q = 0; q < 9; ++q) {
-            const d2u va = *(const d2u*)(A + 2 * q), vb = *(const d2u*)(B + 2 * q);
-            a[2 * q] = va.x; a[2 * q + 1] = va.y; bb[2 * q] = vb.x; bb[2 * q + 1] = vb.y;
-          }
-#pragma unroll
-          for (int q = 0; q < 6; ++q) yv[q] = yk[q];
-        } else {   // 3-wide source column: rows of 3, zero-padded to 6
+        for (int h = 0; h < 2; ++h) {   // K in halves of 3 (one half when the source column is 3 wide): 21 live doubles, no spills
+          const bool on = live && 3 * h < dk;
+          const int ko = 3 * h < dk ? 3 * h : 0;
+          double a[9], bb[9], yv[3];
 #pragma unroll
           for (int rr = 0; rr < 3; ++rr)
 #pragma unroll
-            for (int q = 0; q < 6; ++q) {
-              a[rr * 6 + q] = q < 3 ? A[rr * 3 + q] : 0.0;
-              bb[rr * 6 + q] = q < 3 ? B[rr * 3 + q] : 0.0;
+            for (int q = 0; q < 3; ++q) { a[rr * 3 + q] = A[rr * dk + ko + q]; bb[rr * 3 + q] = B[rr * dk + ko + q]; }
+#pragma unroll
+          for (int q = 0; q < 3; ++q) yv[q] = yk[ko + q];
+          if (on) {
+#pragma unroll
+            for (int rr = 0; rr < 3; ++rr) {
+#pragma unroll
+              for (int cc = 0; cc < 3; ++cc) acc[rr * 3 + cc] += a[rr * 3] * bb[cc * 3] + a[rr * 3 + 1] * bb[cc * 3 + 1] + a[rr * 3 + 2] * bb[cc * 3 + 2];
+              accy[rr] += a[rr * 3] * yv[0] + a[rr * 3 + 1] * yv[1] + a[rr * 3 + 2] * yv[2];
             }
-#pragma unroll
-          for (int q = 0; q < 6; ++q) yv[q] = q < 3 ? yk[q] : 0.0;
-        }
-        if (live) {
-#pragma unroll
-          for (int rr = 0; rr < 3; ++rr) {
-#pragma unroll
-            for (int cc = 0; cc < 3; ++cc) {
-              double d = acc[rr * 3 + cc];
-#pragma unroll
-              for (int q = 0; q < 6; ++q) d += a[rr * 6 + q] * bb[cc * 6 + q];
-              acc[rr * 3 + cc] = d;
-            }
-            double d = accy[rr];
-#pragma unroll
-            for (int q = 0; q < 6; ++q) d += a[rr * 6 + q] * yv[q];
-            accy[rr] = d;
           }
         }
         um = nx;
@@ -497,40 +480,26 @@ __device__ __forceinline__ void chol_supernode(const BatchView& V, const CholVie
         const double* A = L + um.ua + 3 * tre * dk;
         const double* B = L + um.ub + 3 * tce * dk;
         const double* yk = Y + um.ux;
-        double a[18], bb[18], yv[6];
-        if (dk == 6) {
+        // K in halves of 3 (one half when the source column is 3 wide): 21 live doubles instead of 42 -- the 1024-thread
+        // workgroup caps a lane at 128 VGPRs and the full tile spilled
 #pragma unroll
-          for (int q = 0; q < 9; ++q) {
-            const d2u va = *(const d2u*)(A + 2 * q), vb = *(const d2u*)(B + 2 * q);
-            a[2 * q] = va.x; a[2 * q + 1] = va.y; bb[2 * q] = vb.x; bb[2 * q + 1] = vb.y;
-          }
-#pragma unroll
-          for (int q = 0; q < 6; ++q) yv[q] = yk[q];
-        } else {
+        for (int h = 0; h < 2; ++h) {
+          const bool on = live && 3 * h < dk;
+          const int ko = 3 * h < dk ? 3 * h : 0;
+          double a[9], bb[9], yv[3];
 #pragma unroll
           for (int rr = 0; rr < 3; ++rr)
 #pragma unroll
-            for (int q = 0; q < 6; ++q) {
-              a[rr * 6 + q] = q < 3 ? A[rr * 3 + q] : 0.0;
-              bb[rr * 6 + q] = q < 3 ? B[rr * 3 + q] : 0.0;
+            for (int q = 0; q < 3; ++q) { a[rr * 3 + q] = A[rr * dk + ko + q]; bb[rr * 3 + q] = B[rr * dk + ko + q]; }
+#pragma unroll
+          for (int q = 0; q < 3; ++q) yv[q] = yk[ko + q];
+          if (on) {
+#pragma unroll
+            for (int rr = 0; rr < 3; ++rr) {
+#pragma unroll
+              for (int cc = 0; cc < 3; ++cc) acc[rr * 3 + cc] += a[rr * 3] * bb[cc * 3] + a[rr * 3 + 1] * bb[cc * 3 + 1] + a[rr * 3 + 2] * bb[cc * 3 + 2];
+              accy[rr] += a[rr * 3] * yv[0] + a[rr * 3 + 1] * yv[1] + a[rr * 3 + 2] * yv[2];
             }
-#pragma unroll
-          for (int q = 0; q < 6; ++q) yv[q] = q < 3 ? yk[q] : 0.0;
-        }
-        if (live) {
-#pragma unroll
-          for (int rr = 0; rr < 3; ++rr) {
-#pragma unroll
-            for (int cc = 0; cc < 3; ++cc) {
-              double d = acc[rr * 3 + cc];
-#pragma unroll
-              for (int q = 0; q < 6; ++q) d += a[rr * 6 + q] * bb[cc * 6 + q];
-              acc[rr * 3 + cc] = d;
-            }
-            double d = accy[rr];
-#pragma unroll
-            for (int q = 0; q < 6; ++q) d += a[rr * 6 + q] * yv[q];
-            accy[rr] = d;
           }
         }
         um = nx;
