@@ -1016,7 +1016,12 @@ int chol_plan_build(Batch& b) {
   for (int j = 0; j < ncol; ++j) {
     if (is_tail[j]) continue;
     const int U = up[bp[j + 1]] - up[bp[j]];
-    build_items(j, std::max(1, (U + kItemsPerColumn - 1) / kItemsPerColumn), nullptr);
+    const size_t mark = itemm.size();
+    for (int chunk = std::max(1, (U + kItemsPerColumn - 1) / kItemsPerColumn);; ++chunk) {   // one pass of the slots (see the tail)
+      itemm.resize(mark);
+      build_items(j, chunk, nullptr);
+      if ((int)(itemm.size() - mark) <= kItemsPerColumn || chunk >= U) break;
+    }
   }
   // supernodes of every tail: maximal chains (next tail column = parent with exactly one row less, all blocks 6 x 6)
   std::vector<SnMeta> snm;
@@ -1043,11 +1048,16 @@ int chol_plan_build(Batch& b) {
           for (int u = up[bp[j]]; u < up[bp[j + 1]]; ++u) if (!(s_len > 1 && in_sn[uk[u]])) ++Uext;
           panel += col_csize(j) + col_dim[j];
         }
-        const int chunk = std::max(1, (Uext + kItemsPerColumn - 1) / kItemsPerColumn);
+        int chunk = std::max(1, (Uext + kItemsPerColumn - 1) / kItemsPerColumn);
         const size_t mark = itemm.size();
         const int ibase = (int)mark;
-        for (int p = 0; p < s_len; ++p) build_items(tail_cols[q + p], chunk, s_len > 1 ? &in_sn : nullptr);
-        const int icount = (int)itemm.size() - ibase;
+        int icount = 0;
+        for (;; ++chunk) {   // every target's list is cut separately: raise chunk until the items fit ONE pass of the 256 slots
+          itemm.resize(mark);
+          for (int p = 0; p < s_len; ++p) build_items(tail_cols[q + p], chunk, s_len > 1 ? &in_sn : nullptr);
+          icount = (int)itemm.size() - ibase;
+          if (icount <= kItemsPerColumn || chunk >= Uext) break;
+        }
         const int lds = panel + std::max(icount, 1) * kItemDoubles;
         for (int p = 0; p < s_len; ++p) in_sn[tail_cols[q + p]] = 0;
         if (s_len > 1 && (size_t)lds * sizeof(double) > 144 * 1024) { itemm.resize(mark); --s_len; continue; }
