@@ -16,4 +16,6 @@ for c in FETCH_SIZE WRITE_SIZE; do
 done
 python $R/tools/pmc_traffic.py $O/pmc_factor_FETCH_SIZE $O/pmc_factor_WRITE_SIZE $O/r1_pmc_factor.json $FB 1 k_chol_level k_chol_tail k_chol_begin k_chol_end
 python $R/tools/pmc_traffic.py $O/pmc_jac_FETCH_SIZE $O/pmc_jac_WRITE_SIZE $O/r1_pmc_jacobian_build.json $JB 0 k_linearize_rowthread k_linearize_lm_rows k_linearize_dups
+cp $O/r1_pmc_factor.json $O/r1_pmc_jacobian_build.json $R/profiles/   # so that the final bench line quotes this run's traffic
+python $R/bench.py > $O/bench_stdout.txt 2> $O/bench_stderr.txt; tail -1 $O/bench_stdout.txt > $O/r1_bench.json
 rm -rf $O/stats $O/pmc_*
