@@ -29,8 +29,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=int(os.environ.get("SSLAM_BENCH_BATCH", "256")),
-                    help="independent graphs resident per GPU (256 x ~10 MB of H + 7.5 MB of L each: far beyond the 256 MiB MALL)")
+    ap.add_argument("--batch", type=int, default=int(os.environ.get("SSLAM_BENCH_BATCH", "512")),
+                    help="independent graphs resident per GPU (512 x ~10 MB of H + 7.5 MB of L each: far beyond the 256 MiB MALL)")
     ap.add_argument("--poses", type=int, default=5000)
     ap.add_argument("--landmarks", type=int, default=1000)
     ap.add_argument("--distinct", type=int, default=4, help="distinct seeds generated per rank (tiled to --batch)")

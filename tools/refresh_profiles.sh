@@ -12,7 +12,7 @@ FB=$(python -c "import json;print(json.load(open('$O/r1_bench.json'))['roofline'
 JB=$(python -c "import json;print(json.load(open('$O/r1_bench.json'))['roofline_jacobian_build']['bytes_per_launch'])")
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --output-format csv -d $O/pmc_factor_$c -- python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-frontend --no-single > /dev/null 2>&1
-  rocprofv3 --pmc $c --output-format csv -d $O/pmc_jac_$c -- python $R/tools/lin_only.py 256 > /dev/null 2>&1
+  rocprofv3 --pmc $c --output-format csv -d $O/pmc_jac_$c -- python $R/tools/lin_only.py 512 > /dev/null 2>&1
 done
 python $R/tools/pmc_traffic.py $O/pmc_factor_FETCH_SIZE $O/pmc_factor_WRITE_SIZE $O/r1_pmc_factor.json $FB 1 k_chol_level k_chol_tail k_chol_begin k_chol_end
 python $R/tools/pmc_traffic.py $O/pmc_jac_FETCH_SIZE $O/pmc_jac_WRITE_SIZE $O/r1_pmc_jacobian_build.json $JB 0 k_linearize_rowthread k_linearize_lm_rows k_linearize_dups
