@@ -214,3 +214,29 @@ def test_oracle_projection_and_hull_against_scipy():
         c = hv.mean(0)
         a = np.arctan2(hv[:, 1] - c[1], hv[:, 0] - c[0])
         assert np.all(np.diff(a) > 0)                       # comparePoints2D order: atan2 ascending
+
+
+def test_oracle_hull_edge_cases():
+    """duplicates keep the lowest index, collinear points are not vertices, a collinear set has no 2-D hull"""
+    import ctypes as C
+    from oracle import oracle
+    lib = oracle.lib()
+
+    def hull(xy):
+        proj = np.zeros((len(xy), 3), np.float32); proj[:, :2] = xy
+        # three non-collinear probes (first / last / middle) are needed for the coordinate-plane choice
+        out = np.zeros(len(xy), np.int32); axes = C.c_int(-9)
+        h = lib.os_convex_hull_2d(proj.ctypes.data_as(C.c_void_p), len(xy), out.ctypes.data_as(C.c_void_p), len(out), C.byref(axes))
+        return h, out[:max(h, 0)].tolist(), axes.value
+
+    sq = np.array([[0, 0], [1, 0], [0.5, 0], [1, 1], [0, 1], [0, 0], [0.5, 0.5], [1, 1]], np.float32)   # edge midpoint, duplicates, interior
+    h, idx, axes = hull(sq)
+    assert axes == 0 and h == 4 and sorted(idx) == [0, 1, 3, 4]
+    v = sq[idx]; c = v.mean(0)
+    a = np.arctan2(v[:, 1] - c[1], v[:, 0] - c[0])
+    assert np.all(np.diff(a) > 0)
+    line = np.stack([np.linspace(0, 1, 9), np.linspace(0, 2, 9)], 1).astype(np.float32)
+    assert hull(line)[0] == -1
+    tri = np.array([[0, 0], [2, 0], [1, 3]], np.float32)
+    h, idx, _ = hull(tri)
+    assert h == 3 and sorted(idx) == [0, 1, 2]
