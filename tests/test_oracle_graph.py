@@ -194,3 +194,25 @@ def test_golden_vectors(kind):
     st = gp.optimize(25)
     assert st.chi2_after == pytest.approx(float(exp["chi2_after"]), rel=1e-9)
     assert np.abs(gp.est - exp["estimates"]).max() < 1e-7
+
+
+@pytest.mark.parametrize("kind", ["point", "plane"])
+def test_analytic_invariants(kind):
+    """H symmetric positive semi-definite (positive definite with the gauge fixed), chi2 non-increasing over the
+    accepted LM steps, the fixed first vertex never moves"""
+    gp = GraphProblem.from_synth(make_graph(40, 10, seed=4, landmark_kind=kind), interleave=True)
+    U, b = gp.linearize()
+    H = _full(U).toarray()
+    assert np.abs(H - H.T).max() <= 1e-12 * np.abs(H).max()
+    w = np.linalg.eigvalsh(H)
+    assert w.min() > 0 and np.isfinite(b).all()
+    est0 = gp.est.copy()
+    chis = [gp.chi2()]
+    for k in range(1, 7):
+        g2 = gp.copy()
+        st = g2.optimize(k)
+        assert st.iterations == k
+        chis.append(st.chi2_after)
+        assert np.array_equal(g2.est[0], est0[0])          # gauge: vertex 0 is fixed (graph_slam.cpp:109-111)
+    assert all(chis[i + 1] <= chis[i] * (1 + 1e-12) for i in range(len(chis) - 1))
+    assert chis[-1] < 0.5 * chis[0]
