@@ -88,5 +88,39 @@ def main():
     print("golden fixtures written to", HERE)
 
 
+def make_hull():
+    """row a15: RANSAC plane -> projected inliers -> 2-D hull on a noisy plane patch with outliers (oracle/oracle_seg.c);
+    the hull vertex set is cross-checked against scipy's qhull at generation time"""
+    from scipy.spatial import ConvexHull
+    lib = oracle.lib()
+    rng = np.random.default_rng(77)
+    n = 3000
+    nrm = np.array([0.25, -0.35, -1.0]); nrm /= np.linalg.norm(nrm)
+    u = np.cross(nrm, [0.3, 0.5, 0.8]); u /= np.linalg.norm(u); v = np.cross(nrm, u)
+    ab = rng.normal(0, 0.6, (n, 2))
+    pts = (ab[:, :1] * u + ab[:, 1:] * v + 1.2 * nrm + rng.normal(0, 0.003, (n, 1)) * nrm).astype(np.float32)
+    out = rng.choice(n, n // 5, replace=False)
+    pts[out] += rng.uniform(-0.4, 0.4, (len(out), 3)).astype(np.float32)
+    seed, thr, iters, prob = 5, 0.01, 50, 0.99
+    coeff = np.zeros(4, np.float32); inl = np.zeros(n, np.int32)
+    k = lib.os_ransac_plane(pts.ctypes.data_as(C.c_void_p), n, C.c_float(thr), iters, C.c_double(prob), C.c_uint64(seed),
+                            coeff.ctypes.data_as(C.c_void_p), inl.ctypes.data_as(C.c_void_p), n, None, None)
+    inl = inl[:k].copy()
+    proj = np.zeros((k, 3), np.float32)
+    lib.os_project_inliers(pts.ctypes.data_as(C.c_void_p), inl.ctypes.data_as(C.c_void_p), k, coeff.ctypes.data_as(C.c_void_p), proj.ctypes.data_as(C.c_void_p))
+    hull = np.zeros(k, np.int32); axes = C.c_int(-9)
+    h = lib.os_convex_hull_2d(proj.ctypes.data_as(C.c_void_p), k, hull.ctypes.data_as(C.c_void_p), k, C.byref(axes))
+    hull = hull[:h].copy()
+    cols = {0: [0, 1], 1: [1, 2], 2: [0, 2]}[axes.value]
+    assert set(ConvexHull(proj[:, cols].astype(np.float64)).vertices.tolist()) == set(hull.tolist())
+    np.savez_compressed(os.path.join(HERE, "hull3000.npz"), points=pts, seed=seed, threshold=thr, max_iterations=iters, probability=prob,
+                        coeff=coeff, inliers=inl, axes=axes.value, hull=hull, hull_points=proj[hull])
+    print("hull fixture:", k, "inliers,", h, "hull vertices, axes", axes.value)
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "hull":
+        make_hull()
+    else:
+        main()
+        make_hull()

@@ -240,3 +240,22 @@ def test_oracle_hull_edge_cases():
     tri = np.array([[0, 0], [2, 0], [1, 3]], np.float32)
     h, idx, _ = hull(tri)
     assert h == 3 and sorted(idx) == [0, 1, 2]
+
+
+def test_golden_hull():
+    """the committed a15 fixture (tests/golden/hull3000.npz): RANSAC inliers / coefficients, projected hull points, vertex order"""
+    import ctypes as C
+    from oracle import oracle
+    lib = oracle.lib()
+    g = np.load(os.path.join(GOLD, "hull3000.npz"))
+    pts = np.ascontiguousarray(g["points"]); n = len(pts)
+    coeff = np.zeros(4, np.float32); inl = np.zeros(n, np.int32)
+    k = lib.os_ransac_plane(pts.ctypes.data_as(C.c_void_p), n, C.c_float(float(g["threshold"])), int(g["max_iterations"]),
+                            C.c_double(float(g["probability"])), C.c_uint64(int(g["seed"])), coeff.ctypes.data_as(C.c_void_p),
+                            inl.ctypes.data_as(C.c_void_p), n, None, None)
+    assert np.array_equal(inl[:k], g["inliers"]) and np.array_equal(coeff, g["coeff"])
+    proj = np.zeros((k, 3), np.float32)
+    lib.os_project_inliers(pts.ctypes.data_as(C.c_void_p), inl.ctypes.data_as(C.c_void_p), k, coeff.ctypes.data_as(C.c_void_p), proj.ctypes.data_as(C.c_void_p))
+    hull = np.zeros(k, np.int32); axes = C.c_int(-9)
+    h = lib.os_convex_hull_2d(proj.ctypes.data_as(C.c_void_p), k, hull.ctypes.data_as(C.c_void_p), k, C.byref(axes))
+    assert axes.value == int(g["axes"]) and np.array_equal(hull[:h], g["hull"]) and np.array_equal(proj[hull[:h]], g["hull_points"])

@@ -221,3 +221,16 @@ def test_convex_hull_many_candidates_and_duplicates(gpu_lib):
     line = np.stack([np.linspace(0, 1, 50), np.linspace(0, 2, 50), np.zeros(50)], 1).astype(np.float32)
     with pytest.raises(RuntimeError):
         seg.convex_hull_2d(line, np.arange(50, dtype=np.int32), coeff)            # collinear: no 2-D hull
+
+
+@pytest.mark.gpu
+def test_golden_hull_fixture(gpu_lib):
+    """tests/golden/hull3000.npz (made by tests/golden/make_golden.py from the oracle, vertex set checked against qhull)"""
+    import os
+    from semantic_slam_amd.segmentation import PointCloudSegmentation
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "hull3000.npz"))
+    seg = PointCloudSegmentation()
+    coeff, inl = seg.ransac_plane(g["points"], float(g["threshold"]), int(g["max_iterations"]), float(g["probability"]), int(g["seed"]))
+    assert np.array_equal(inl, g["inliers"]) and np.array_equal(coeff, g["coeff"])
+    proj, hull, axes = seg.convex_hull_2d(g["points"], inl, coeff)
+    assert axes == int(g["axes"]) and np.array_equal(hull, g["hull"]) and np.array_equal(proj[hull], g["hull_points"])
