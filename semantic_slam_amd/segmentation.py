@@ -164,6 +164,8 @@ class PointCloudSegmentation:
         """plane_segmentation::compute2DConvexHull (plane_segmentation.cpp:631-665): RANSAC plane (threshold 0.01, refined
         coefficients) -> project the inliers -> 2-D convex hull.  Returns the hull points (h x 3, projected coordinates)."""
         coeff, inl = self.ransac_plane(xyz, 0.01, 50, 0.99, seed)
+        if len(inl) < 3:                      # no model: an empty hull, like the C++ shim
+            return np.zeros((0, 3), np.float32)
         proj, hull, _ = self.convex_hull_2d(xyz, inl, coeff)
         return proj[hull]
 
