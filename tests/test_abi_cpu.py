@@ -79,6 +79,13 @@ def test_compute_entry_points_fail_loudly_without_a_gpu(hip_lib):
     with pytest.raises(SslamError) as ei:
         PointCloudSegmentation().segmentallPointCloudData(f.robot_pose, f.cam_angle, f.boxes, f)
     assert ei.value.code == -2
+    pts = np.random.default_rng(0).normal(size=(100, 3)).astype(np.float32)
+    with pytest.raises(SslamError) as ei:                              # row a15 entry points
+        PointCloudSegmentation().ransac_plane(pts)
+    assert ei.value.code == -2
+    with pytest.raises(SslamError) as ei:
+        PointCloudSegmentation().convex_hull_2d(pts, np.arange(100, dtype=np.int32), [0, 0, 1, 0])
+    assert ei.value.code == -2
 
 
 def test_g2o_text_round_trip(hip_lib, tmp_path):
