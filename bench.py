@@ -3,17 +3,19 @@
 
   metric : graph-optimize LM iterations/sec on the synthetic 5000-pose / 1000-landmark graph with
            loop closures (BASELINE.json configs[2], the configuration the metric is quoted on).
+           The reference's own timer sits around graph->optimize (src/ps_graph_slam/graph_slam.cpp:204-215).
   step   : one Levenberg-Marquardt iteration (Jacobian build + linear solve(s) + update + chi2 +
            accept/reject) over one device-resident batch of `--batch` independent graphs.
-  value  : graphs-per-GPU x n_gpus x K / seconds  (graph-iterations per second, whole job),
-           inputs resident in HBM before the timed region.
+  value  : sum over graphs (and ranks) of the LM iterations they actually performed / seconds, inputs resident in HBM
+           before the timed region.  g2o's LM stops by itself when ten damping trials in a row fail (rho == 0 / q == 10):
+           a graph that converges before `--steps` iterations contributes only what it ran (`iters_min/max`,
+           `graphs_terminated` in the JSON line say how many did).
 
 One process per GPU; for N>1 launch with torch.distributed.run (RCCL): independent graphs shard
 across ranks with no data-path collective ("scaling": "weak"); the barrier + max-over-ranks timing
 uses torch.distributed.
 """
 import argparse
-import ctypes as C
 import json
 import os
 import sys
@@ -22,6 +24,104 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+
+PEAK_HBM_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E ~8 TB/s
+
+
+def pmc_traffic(name, algorithmic_bytes):
+    """HBM bytes per launch from the committed PMC passes (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs,
+    FETCH x2 on gfx950 per MI355X_MICROARCH.md); only quoted when the profiled workload had the same algorithmic bytes."""
+    for rnd in ("r2", "r1"):
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", f"{rnd}_pmc_{name}.json")))
+        except (OSError, ValueError):
+            continue
+        if int(pmc.get("algorithmic_bytes", -1)) == int(algorithmic_bytes):
+            return int(pmc["hbm_bytes_fetch_x2"]), int(pmc["hbm_bytes_raw"]), f"profiles/{rnd}_pmc_{name}.json"
+    return None, None, None
+
+
+def build_batch(paths, n, dev, solver):
+    from semantic_slam_amd import GraphSLAM, GraphBatch
+    graphs = []
+    for k in range(n):
+        G = GraphSLAM(False, dev)
+        G.load(paths[k % len(paths)])
+        if solver >= 0:
+            G.set_option("solver", solver)
+        graphs.append(G)
+    batch = GraphBatch(graphs)
+    batch.upload()
+    return batch
+
+
+def timed_optimize(batch, steps, warmup, sync_all):
+    """W untimed LM iterations, estimates reset, then K timed ones bracketed by barrier + device sync."""
+    if warmup > 0:
+        batch.optimize(warmup)
+    batch.upload()
+    sync_all()
+    t0 = time.perf_counter()
+    stats = batch.optimize(steps)       # returns after hipStreamSynchronize on the batch's stream
+    sync_all()
+    return stats, time.perf_counter() - t0
+
+
+def bench_frontend(device, frames=8, cpu_baseline=True):
+    """planes/sec on synthetic 640x480 clouds with 32 detection boxes of 128x96 px (BASELINE.json configs[3])."""
+    import numpy as np
+    from semantic_slam_amd.segmentation import PointCloudSegmentation
+    from semantic_slam_amd.synth import make_frame
+    fs = [make_frame(seed=s) for s in range(3)]
+    seg = PointCloudSegmentation(device=device)
+    for f in fs:
+        seg.segmentallPointCloudData(f.robot_pose, f.cam_angle, f.boxes, f)  # warm-up (allocation)
+    nplanes, kms = 0, 0.0
+    t0 = time.perf_counter()
+    for k in range(frames):
+        f = fs[k % len(fs)]
+        nplanes += len(seg.segmentallPointCloudData(f.robot_pose, f.cam_angle, f.boxes, f))
+        kms += seg.last_timing()[0]
+    wall = time.perf_counter() - t0
+    npx = int(sum(int(b["width"]) * int(b["height"]) for b in fs[0].boxes))
+    res = {"workload": "synthetic 640x480 organised cloud, 32 boxes of 128x96 px per frame (BASELINE.json configs[3])",
+           "frames": frames, "planes": nplanes, "planes_per_frame": round(nplanes / frames, 2),
+           "planes_per_sec_kernels": round(nplanes / (kms * 1e-3), 1), "frames_per_sec_kernels": round(frames / (kms * 1e-3), 1),
+           "planes_per_sec_incl_pcie_and_host": round(nplanes / wall, 1), "kernel_ms_per_frame": round(kms / frames, 4),
+           "algorithmic_bytes_per_frame": 32 * npx,
+           "achieved_GBps": round(32 * npx / (kms / frames * 1e-3) / 1e9, 3)}
+    import threading
+    nh = 8
+    segs = [PointCloudSegmentation(device=device) for _ in range(nh)]
+    for sg in segs:
+        sg.segmentallPointCloudData(fs[0].robot_pose, fs[0].cam_angle, fs[0].boxes, fs[0])
+    counts = [0] * nh
+
+    def work(i):
+        for k in range(frames):
+            f = fs[(i + k) % len(fs)]
+            counts[i] += len(segs[i].segmentallPointCloudData(f.robot_pose, f.cam_angle, f.boxes, f))
+    ths = [threading.Thread(target=work, args=(i,)) for i in range(nh)]
+    t2 = time.perf_counter()
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    wall_c = time.perf_counter() - t2
+    res["concurrent_handles"] = {"handles": nh, "frames": nh * frames,
+                                 "planes_per_sec_incl_pcie_and_host": round(sum(counts) / wall_c, 1),
+                                 "frames_per_sec": round(nh * frames / wall_c, 1)}
+    del segs
+    if cpu_baseline:
+        from oracle.oracle import segment_frame   # cpu_baseline leg only
+        t1 = time.perf_counter(); np_cpu = 0; nf = 0
+        while time.perf_counter() - t1 < 6.0:
+            ref, _, _ = segment_frame(fs[nf % len(fs)], seg.params)
+            np_cpu += len(ref); nf += 1
+        dt = time.perf_counter() - t1
+        res["cpu_baseline"] = {"value": round(np_cpu / dt, 2), "unit": "planes/s", "frames_per_sec": round(nf / dt, 3), "cores": 1,
+                               "kind": "port", "sample": f"{nf} frames of the same workload (oracle/oracle_seg.c)"}
+    return res
 
 
 def main():
@@ -35,6 +135,7 @@ def main():
     ap.add_argument("--landmarks", type=int, default=1000)
     ap.add_argument("--distinct", type=int, default=4, help="distinct seeds generated per rank (tiled to --batch)")
     ap.add_argument("--solver", type=int, default=-1, help="-1 library default, 0 PCG, 1 sparse Cholesky")
+    ap.add_argument("--plane-batch", type=int, default=64, help="graphs in the plane-landmark leg (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-frontend", action="store_true")
     ap.add_argument("--no-single", action="store_true", help="skip the single-graph latency section (used under rocprofv3 --pmc)")
@@ -49,7 +150,6 @@ def main():
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl")
-    import numpy as np
     from semantic_slam_amd import GraphSLAM, GraphBatch, load_library
     from semantic_slam_amd import distributed as D
     from semantic_slam_amd.synth import make_graph
@@ -59,30 +159,7 @@ def main():
     if lib.sslam_device_count() < 1:
         raise SystemExit("bench.py needs a GPU: the product has no CPU fallback")
     dev = local_rank if world > 1 else 0
-
-    # ---- synthetic workload, resident in HBM before timing -------------------------------------
-    t_setup = time.time()
-    tmpdir = tempfile.mkdtemp(prefix="sslam_bench_")
-    paths, problems = [], []
-    for d in range(max(1, min(args.distinct, args.batch))):
-        g = make_graph(args.poses, args.landmarks, seed=1000 * rank + d)
-        gp = GraphProblem.from_synth(g)
-        problems.append(gp)
-        G0 = GraphSLAM.from_problem(gp, device=dev)
-        p = os.path.join(tmpdir, f"g{d}.g2o")
-        G0.save(p)
-        paths.append(p)
-        del G0
-    graphs = []
-    for k in range(args.batch):
-        G = GraphSLAM(False, dev)
-        G.load(paths[k % len(paths)])
-        if args.solver >= 0:
-            G.set_option("solver", args.solver)
-        graphs.append(G)
-    batch = GraphBatch(graphs)
-    batch.upload()
-    setup_s = time.time() - t_setup
+    ddev = "cuda" if dist is not None else None
 
     def sync_all():
         if dist is not None:
@@ -90,7 +167,27 @@ def main():
             torch.cuda.synchronize()
             dist.barrier()
 
-    # ---- warmup (untimed), then reset to the initial estimates -----------------------------------
+    def write_graphs(kind, n_distinct, tmpdir):
+        paths, problems = [], []
+        for d in range(n_distinct):
+            g = make_graph(args.poses, args.landmarks, seed=1000 * rank + d, landmark_kind=kind)
+            gp = GraphProblem.from_synth(g)
+            problems.append(gp)
+            G0 = GraphSLAM.from_problem(gp, device=dev)
+            p = os.path.join(tmpdir, f"{kind}{d}.g2o")
+            G0.save(p)
+            paths.append(p)
+            del G0
+        return paths, problems
+
+    # ---- synthetic workload, resident in HBM before timing -------------------------------------
+    t_setup = time.time()
+    tmpdir = tempfile.mkdtemp(prefix="sslam_bench_")
+    paths, problems = write_graphs("point", max(1, min(args.distinct, args.batch)), tmpdir)
+    batch = build_batch(paths, args.batch, dev, args.solver)
+    setup_s = time.time() - t_setup
+
+    # ---- warmup (untimed), reset to the initial estimates, K timed steps ---------------------------
     if args.warmup > 0:
         batch.optimize(args.warmup)
     batch.upload()
@@ -100,11 +197,12 @@ def main():
     stats = batch.optimize(args.steps)       # blocks until the stream is idle (hipStreamSynchronize)
     sync_all()
     dt = time.perf_counter() - t0
-    dt = D.max_over_ranks(dt, device="cuda" if dist is not None else None)
-    iters_done = [s.iterations for s in stats]
-    assert min(iters_done) == args.steps, f"LM terminated early: {min(iters_done)} < {args.steps}"
-    # whole-job value: graph-iterations of ALL ranks / max-over-ranks time (replicas: no data-path collective)
-    value = D.aggregate_throughput(float(args.batch * args.steps), dt, device="cuda" if dist is not None else None)
+    dt = D.max_over_ranks(dt, device=ddev)
+    iters = [int(s.iterations) for s in stats]
+    iters_total = float(sum(iters))
+    steps_done = max(iters) if iters else 0
+    # whole-job value: graph-iterations actually performed by ALL ranks / max-over-ranks time (replicas: no data-path collective)
+    value = D.aggregate_throughput(iters_total, dt, device=ddev)
 
     # ---- kernel times (hipEvents on the batch's stream, inside the timed region) -------------------
     names = ["linearize", "chi2", "spmv", "pcg_update", "precond", "oplus", "factor", "solve"]
@@ -116,37 +214,28 @@ def main():
     lin_ms, lin_n = ktimes["linearize"]
     jac_ms = lin_ms / max(lin_n, 1)
     jac_gbs = jac_bytes / (jac_ms * 1e-3) / 1e9 if jac_ms > 0 else 0.0
-    roof_jac = {"bound": "hbm", "kernel": "jacobian_build", "achieved": round(jac_gbs, 2), "peak": 8000.0, "unit": "GB/s",
-                "frac": round(jac_gbs / 8000.0, 4), "traffic": None, "bytes_per_launch": jac_bytes,
+    roof_jac = {"bound": "hbm", "kernel": "jacobian_build", "achieved": round(jac_gbs, 2), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                "frac": round(jac_gbs / PEAK_HBM_GBS, 4), "traffic": None, "bytes_per_launch": jac_bytes,
                 "ms_per_launch": round(jac_ms, 5), "launches": lin_n}
-    # measured HBM traffic of the Jacobian build (PMC FETCH_SIZE / WRITE_SIZE, collected with rocprofv3 in separate
-    # passes, FETCH x2 per MI355X_MICROARCH.md; committed under profiles/).  Only valid for the profiled batch size.
-    try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r1_pmc_jacobian_build.json")))
-        if pmc.get("algorithmic_bytes") == jac_bytes:
-            roof_jac["traffic"] = int(pmc["hbm_bytes_fetch_x2"])
-            roof_jac["traffic_raw_counters"] = int(pmc["hbm_bytes_raw"])
-    except (OSError, ValueError):
-        pass
+    t, raw, src = pmc_traffic("jacobian_build", jac_bytes)
+    if t is not None:
+        roof_jac.update({"traffic": t, "traffic_raw_counters": raw, "traffic_source": src})
     roofline = roof_jac
-    if dominant == "factor" and ktimes["factor"][1] > 0:
-        fbytes = batch.info("factor_bytes")
+    roof_factor = None
+    if ktimes["factor"][1] > 0:
+        fbytes = int(batch.info("factor_bytes"))
         ms = ktimes["factor"][0] / ktimes["factor"][1]
         gbs = fbytes / (ms * 1e-3) / 1e9
-        roofline = {"bound": "hbm", "kernel": "block_cholesky_factor (k_chol_level launches per elimination-tree level + k_chol_tail "
-                                              "of one numeric factorisation)",
-                    "achieved": round(gbs, 2), "peak": 8000.0, "unit": "GB/s", "frac": round(gbs / 8000.0, 4), "traffic": None,
-                    "bytes_per_launch": int(fbytes), "ms_per_launch": round(ms, 4), "launches": ktimes["factor"][1],
-                    "levels": int(batch.info("factor_levels")), "factor_doubles": int(batch.info("factor_lnz")),
-                    "note": "one 'launch' = the dependent chain of kernels of one factorisation; latency / instruction-issue bound "
-                            "(6x6 blocks), algorithmic bytes = read H,b + write L,y once"}
-        try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r1_pmc_factor.json")))
-            if pmc.get("algorithmic_bytes") == int(fbytes):
-                roofline["traffic"] = int(pmc["hbm_bytes_fetch_x2"])
-                roofline["traffic_raw_counters"] = int(pmc["hbm_bytes_raw"])
-        except (OSError, ValueError):
-            pass
+        roof_factor = {"bound": "hbm", "kernel": "block_cholesky_factor (all kernels of one numeric factorisation + fused forward solve)",
+                       "achieved": round(gbs, 2), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4), "traffic": None,
+                       "bytes_per_launch": fbytes, "ms_per_launch": round(ms, 4), "launches": ktimes["factor"][1],
+                       "levels": int(batch.info("factor_levels")), "factor_doubles": int(batch.info("factor_lnz")),
+                       "note": "algorithmic bytes = read H, b once + write L, y once; one 'launch' = one factorisation of the whole batch"}
+        t, raw, src = pmc_traffic("factor", fbytes)
+        if t is not None:
+            roof_factor.update({"traffic": t, "traffic_raw_counters": raw, "traffic_source": src})
+        if dominant == "factor":
+            roofline = roof_factor
     if dominant == "spmv" and ktimes["spmv"][1] > 0:
         # H bytes + 3 vectors x 8*dim per block-SpMV
         Np, Nl = args.poses - 1, args.landmarks
@@ -154,75 +243,94 @@ def main():
         spmv_bytes = args.batch * (h_bytes + 3 * 8 * (6 * Np + 3 * Nl))
         ms = ktimes["spmv"][0] / ktimes["spmv"][1]
         gbs = spmv_bytes / (ms * 1e-3) / 1e9
-        roofline = {"bound": "hbm", "kernel": "pcg_block_spmv", "achieved": round(gbs, 2), "peak": 8000.0, "unit": "GB/s",
-                    "frac": round(gbs / 8000.0, 4), "traffic": None, "bytes_per_launch": spmv_bytes,
+        roofline = {"bound": "hbm", "kernel": "pcg_block_spmv", "achieved": round(gbs, 2), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                    "frac": round(gbs / PEAK_HBM_GBS, 4), "traffic": None, "bytes_per_launch": spmv_bytes,
                     "ms_per_launch": round(ms, 5), "launches": ktimes["spmv"][1],
                     "note": "bytes assume every still-active graph; converged graphs early-exit"}
 
     out = {
         "metric": "graph-optimize LM iters/sec (5k poses, 1k landmarks)",
         "value": round(value, 3), "unit": "iters/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(1e3 * dt / args.steps, 4), "higher_is_better": True, "scaling": "weak",
+        "ms_per_step": round(1e3 * dt / max(steps_done, 1), 4), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f64", "data": f"synthetic ({len(paths)} distinct seeds per GPU tiled to the batch)",
         "config": {"workload": f"synthetic {args.poses}-pose / {args.landmarks}-landmark graph with loop closures "
-                               f"(BASELINE.json configs[2]), batch of {args.batch} independent graphs per GPU",
+                               f"(BASELINE.json configs[2]), batch of {args.batch} independent graphs per GPU, point landmarks "
+                               f"(EdgeSE3PointXYZ, the reference's live landmark type)",
                    "graphs_per_gpu": args.batch, "se3_edges": Eo, "landmark_edges": El,
                    "solver": int(args.solver), "parallelism": f"replicas x{world}"},
+        "steps_done": steps_done, "iters_min": min(iters), "iters_max": max(iters),
+        "graphs_terminated": int(sum(1 for s in stats if s.status == 1)),
+        "timed_seconds": round(dt, 4),
         "keyframes_landmarks_per_sec": round(value * (args.poses + args.landmarks), 1),
         "chi2_after": stats[0].chi2_after, "lm_trials": stats[0].trials, "solver_iterations": stats[0].solver_iterations,
         "roofline": roofline, "roofline_jacobian_build": roof_jac,
         "kernel_ms": {n: [round(v[0], 3), v[1]] for n, v in ktimes.items() if v[1]},
         "setup_seconds": round(setup_s, 1),
     }
+    if roof_factor is not None:
+        out["roofline_factor"] = roof_factor
+    del batch
 
     if rank == 0:
         if not args.no_single:
             # ---- single-graph latency (same graph, batch of one) -----------------------------------
-            one = GraphSLAM(False, dev); one.load(paths[0])
-            if args.solver >= 0:
-                one.set_option("solver", args.solver)
-            b1 = GraphBatch([one]); b1.upload(); b1.optimize(1); b1.upload()
-            t1 = time.perf_counter(); s1 = b1.optimize(args.steps); d1 = time.perf_counter() - t1
-            out["single_graph"] = {"iters_per_sec": round(args.steps / d1, 2), "ms_per_iter": round(1e3 * d1 / args.steps, 3),
+            b1 = build_batch(paths[:1], 1, dev, args.solver)
+            s1, d1 = timed_optimize(b1, args.steps, 1, lambda: None)
+            n1 = max(int(s1[0].iterations), 1)
+            out["single_graph"] = {"iters_per_sec": round(n1 / d1, 2), "ms_per_iter": round(1e3 * d1 / n1, 3), "iterations": n1,
                                    "regime": "latency-bound (working set < L2/MALL)", "chi2_after": s1[0].chi2_after}
-            del b1, one
+            del b1
+        if args.plane_batch > 0 and world == 1:
+            # ---- plane landmarks (BASELINE.json metric: "5k poses, 1k planes"): VertexPlane + EdgeSE3Plane, numeric Jacobians
+            try:
+                ppaths, _ = write_graphs("plane", 1, tmpdir)
+                pb = build_batch(ppaths, args.plane_batch, dev, args.solver)
+                ps, pdt = timed_optimize(pb, args.steps, min(args.warmup, 2), lambda: None)
+                pit = [int(s.iterations) for s in ps]
+                out["plane_landmarks"] = {"value": round(sum(pit) / pdt, 3), "unit": "iters/s", "graphs": args.plane_batch,
+                                          "iters_min": min(pit), "iters_max": max(pit), "chi2_after": ps[0].chi2_after,
+                                          "workload": f"{args.poses} poses / {args.landmarks} plane landmarks (in-tree EdgeSE3Plane, "
+                                                      f"central-difference Jacobians), batch of {args.plane_batch}"}
+                del pb
+            except Exception as e:   # the headline line must still be printed
+                out["plane_landmarks"] = {"error": str(e)[:200]}
         if not args.no_cpu_baseline and world == 1:
             # ---- CPU baseline: the oracle (restated reference algorithm), 1 core, bounded sample ----
-            reps, cpu_t, budget = 0, 0.0, 15.0
+            reps, cpu_t, cpu_it, budget = 0, 0.0, 0, 15.0
             while cpu_t < budget:
                 gp = problems[reps % len(problems)].copy()
                 st = gp.optimize(args.steps)
                 cpu_t += st.seconds
+                cpu_it += int(st.iterations)
                 reps += 1
-            out["cpu_baseline"] = {"value": round(reps * args.steps / cpu_t, 3), "unit": "iters/s", "cores": 1, "kind": "port",
-                                   "sample": f"{reps} runs of {args.steps} LM iterations on the same {args.poses}/{args.landmarks} graphs "
-                                             f"(oracle/oracle_graph.c: LM + min-degree sparse Cholesky, gcc -O3 -march=native)",
+            out["cpu_baseline"] = {"value": round(cpu_it / cpu_t, 3), "unit": "iters/s", "cores": 1, "kind": "port",
+                                   "sample": f"{reps} runs of <= {args.steps} LM iterations ({cpu_it} performed) on the same {args.poses}/{args.landmarks} "
+                                             f"graphs (oracle/oracle_graph.c: LM + min-degree sparse Cholesky, gcc -O3 -march=native)",
                                    "host_cores_available": os.cpu_count()}
             # the same port on many host cores at once (independent graphs, one per thread; the C call releases the GIL)
             from concurrent.futures import ThreadPoolExecutor
             ncore = min(len(os.sched_getaffinity(0)), 64)
             work = [problems[k % len(problems)].copy() for k in range(ncore)]
             deadline = time.perf_counter() + 6.0
+
             def run(gp):
                 n = 0
                 while n == 0 or time.perf_counter() < deadline:
-                    gp.copy().optimize(args.steps)
-                    n += 1
+                    n += int(gp.copy().optimize(args.steps).iterations)
                 return n
             tA = time.perf_counter()
             with ThreadPoolExecutor(max_workers=ncore) as ex:
-                runs = sum(ex.map(run, work))
+                its = sum(ex.map(run, work))
             dA = time.perf_counter() - tA
-            out["cpu_baseline_multicore"] = {"value": round(runs * args.steps / dA, 3), "unit": "iters/s", "cores": ncore, "kind": "port",
-                                             "sample": f"{runs} runs of {args.steps} LM iterations over {ncore} threads in {dA:.1f} s, "
-                                                       f"independent graphs (same oracle)"}
+            out["cpu_baseline_multicore"] = {"value": round(its / dA, 3), "unit": "iters/s", "cores": ncore, "kind": "port",
+                                             "sample": f"{its} LM iterations over {ncore} threads in {dA:.1f} s, independent graphs (same oracle)"}
         if not args.no_frontend:
             try:
-                from semantic_slam_amd import segmentation
-                out["frontend"] = segmentation.bench_frontend(dev, cpu_baseline=(not args.no_cpu_baseline and world == 1))
-            except ImportError:
-                pass
+                out["frontend"] = bench_frontend(dev, cpu_baseline=(not args.no_cpu_baseline and world == 1))
+            except Exception as e:
+                out["frontend"] = {"error": str(e)[:200]}
         print(json.dumps(out))
+        sys.stdout.flush()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -192,87 +192,3 @@ class PointCloudSegmentation:
         out = np.zeros(16, np.float32)
         self._check(self._lib.sslam_seg_transform(self._h, pose.ctypes.data, C.c_float(cam_angle), out.ctypes.data))
         return out.reshape(4, 4)
-
-
-def _oracle_segment(frame, params: SegParams, want_products: bool = False):
-    """CPU oracle on the same frame (TEST / cpu_baseline use only)."""
-    from oracle import oracle
-    lib = oracle.lib()
-    out = (Plane * 512)()
-    npix = int(sum(int(b["width"]) * int(b["height"]) for b in frame.boxes))
-    nrm = np.zeros((npix, 4), np.float32) if want_products else None
-    lab = np.zeros(npix, np.int32) if want_products else None
-    lib.os_segment.restype = C.c_int
-    n = lib.os_segment(C.byref(params), frame.cloud.ctypes.data_as(C.c_void_p), frame.width, frame.height, frame.point_step,
-                       frame.row_step, frame.offsets[0], frame.offsets[1], frame.offsets[2],
-                       frame.boxes.ctypes.data_as(C.c_void_p), len(frame.boxes), frame.robot_pose.ctypes.data_as(C.c_void_p),
-                       C.c_float(frame.cam_angle), out, 512,
-                       nrm.ctypes.data_as(C.c_void_p) if want_products else None,
-                       lab.ctypes.data_as(C.c_void_p) if want_products else None)
-    return [out[k] for k in range(n)], nrm, lab
-
-
-def smoke_check():
-    """One small frontend invocation on cuda:0 checked against the oracle (used by __graft_entry__.smoke)."""
-    from .synth import make_frame
-    f = make_frame(seed=1, n_boxes=4)
-    seg = PointCloudSegmentation()
-    planes = seg.segmentallPointCloudData(f.robot_pose, f.cam_angle, f.boxes, f)
-    ref, _, _ = _oracle_segment(f, seg.params)
-    assert len(planes) == len(ref), (len(planes), len(ref))
-    for a, r in zip(planes, ref):
-        assert a.inlier_count == r.inlier_count and a.num_points == r.num_points
-        assert np.array_equal(a.normal_orientation, np.array(r.normal_d, np.float32))
-
-
-def bench_frontend(device: int = 0, frames: int = 8, cpu_baseline: bool = True) -> dict:
-    """planes/sec on synthetic 640x480 clouds with 32 detection boxes of 128x96 px (BASELINE.json configs[3])."""
-    import time
-    from .synth import make_frame
-    fs = [make_frame(seed=s) for s in range(3)]
-    seg = PointCloudSegmentation(device=device)
-    for f in fs:
-        seg.segmentallPointCloudData(f.robot_pose, f.cam_angle, f.boxes, f)  # warm-up (allocation)
-    nplanes, kms, tms = 0, 0.0, 0.0
-    t0 = time.perf_counter()
-    for k in range(frames):
-        f = fs[k % len(fs)]
-        nplanes += len(seg.segmentallPointCloudData(f.robot_pose, f.cam_angle, f.boxes, f))
-        a, b = seg.last_timing(); kms += a; tms += b
-    wall = time.perf_counter() - t0
-    npx = int(sum(int(b["width"]) * int(b["height"]) for b in fs[0].boxes))
-    res = {"workload": "synthetic 640x480 organised cloud, 32 boxes of 128x96 px per frame (BASELINE.json configs[3])",
-           "frames": frames, "planes": nplanes,
-           "planes_per_sec_kernels": round(nplanes / (kms * 1e-3), 1), "frames_per_sec_kernels": round(frames / (kms * 1e-3), 1),
-           "planes_per_sec_incl_pcie_and_host": round(nplanes / wall, 1), "kernel_ms_per_frame": round(kms / frames, 4),
-           "algorithmic_bytes_per_frame": 32 * npx,
-           "achieved_GBps": round(32 * npx / (kms / frames * 1e-3) / 1e9, 3),
-           "regime": "latency-bound: one frame (12.6 MB algorithmic) is far below the MALL; raster recurrences run as 64-row wavefronts"}
-    # throughput with several handles in flight (one stream each; a frame's 32 boxes occupy a fraction of the 256 CUs)
-    import threading
-    nh = 8
-    segs = [PointCloudSegmentation(device=device) for _ in range(nh)]
-    for sg in segs:
-        sg.segmentallPointCloudData(fs[0].robot_pose, fs[0].cam_angle, fs[0].boxes, fs[0])   # warm-up (allocation)
-    counts = [0] * nh
-    def work(i):
-        for k in range(frames):
-            f = fs[(i + k) % len(fs)]
-            counts[i] += len(segs[i].segmentallPointCloudData(f.robot_pose, f.cam_angle, f.boxes, f))
-    ths = [threading.Thread(target=work, args=(i,)) for i in range(nh)]
-    t2 = time.perf_counter()
-    for t in ths: t.start()
-    for t in ths: t.join()
-    wall_c = time.perf_counter() - t2
-    res["concurrent_handles"] = {"handles": nh, "frames": nh * frames, "planes_per_sec_incl_pcie_and_host": round(sum(counts) / wall_c, 1),
-                                 "frames_per_sec": round(nh * frames / wall_c, 1)}
-    del segs
-    if cpu_baseline:
-        t1 = time.perf_counter(); np_cpu = 0; nf = 0
-        while time.perf_counter() - t1 < 6.0:
-            ref, _, _ = _oracle_segment(fs[nf % len(fs)], seg.params)
-            np_cpu += len(ref); nf += 1
-        dt = time.perf_counter() - t1
-        res["cpu_baseline"] = {"value": round(np_cpu / dt, 2), "unit": "planes/s", "frames_per_sec": round(nf / dt, 3), "cores": 1,
-                               "kind": "port", "sample": f"{nf} frames of the same workload (oracle/oracle_seg.c)"}
-    return res

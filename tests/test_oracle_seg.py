@@ -138,7 +138,8 @@ def test_golden_patch():
 
 
 def test_frame_level_outputs_are_consistent():
-    from semantic_slam_amd.segmentation import _oracle_segment, SegParams
+    from semantic_slam_amd.segmentation import SegParams
+    from oracle.oracle import segment_frame as _oracle_segment
     f = make_frame(seed=2, n_boxes=6)
     p = SegParams(500, 5000, 0.1, 0.03, 20.0, 0.017453 * 2, 0.02, 0.001, 100, 640, 480, 1, 0)
     planes, nrm, lab = _oracle_segment(f, p, want_products=True)
