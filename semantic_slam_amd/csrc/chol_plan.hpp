@@ -1,0 +1,574 @@
+// Host-side symbolic phase of the sparse block Cholesky (no HIP types: also compiled into the CPU-only plan tests).
+//
+// Replaces the symbolic half of g2o's BlockSolverX + LinearSolverCSparse pair that the reference selects with "lm_var"
+// (reference src/ps_graph_slam/graph_slam.cpp:27,67-73).
+//
+// MI355X design.  The block elimination tree of a SLAM graph is bushy at the bottom and a long chain at the top
+// (151 levels for the 5000-pose / 1000-landmark graph), and one numeric factorisation is only ~25 MFLOP / 7.5 MB per
+// graph: a launch per level is all latency.  The tree is therefore cut into *pieces* -- connected sets of columns
+// (a subtree minus the pieces hanging below it) whose part of L fits in the LDS of one workgroup:
+//   * a piece is factored by ONE workgroup: its columns are gathered into LDS, the updates whose source columns lie
+//     in lower pieces ("external", already final in HBM) are applied in one massively parallel phase, and the
+//     levels *inside* the piece then run out of LDS with workgroup barriers between them -- no launch, no HBM latency;
+//   * pieces of equal depth in the piece tree share a launch (a handful of launches instead of 151); once a graph is
+//     down to a few pieces per depth, the rest ("tail") is walked by one workgroup per graph in a single launch;
+//   * L is laid out piece by piece, columns of a piece by internal level: a piece is one contiguous, coalesced
+//     stream in both directions, so HBM sees H read once and L written once;
+//   * updates are cut into work items of <= chunk consecutive updates of ONE target block; an item is executed by
+//     four lanes holding the 3x3 tiles of the target.  A target with a single item is subtracted in place ("sole"),
+//     longer lists go through per-item partial tiles that are summed in item order -> deterministic.
+// The backward substitution walks the same pieces top-down.
+#pragma once
+#include <algorithm>
+#include <array>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <functional>
+#include <queue>
+#include <string>
+#include <unordered_map>
+#include <utility>
+#include <vector>
+
+namespace sslam {
+
+struct ColMeta { int xoff, yoff, dim, graph, b0, nb, nbi, base, csize, piece, ilevel, pad; };
+// xoff: offset in the unknown vector (internal row order); yoff: offset in elimination order (the forward-substituted
+// rhs y lives in that order so that a piece's y is contiguous); blocks [b0, b0 + nb), diagonal first, the first nbi
+// (diagonal included) have their row inside the column's own piece; base = Lval offset of the diagonal block
+
+struct BlkMeta { int off, src, up0, up1, xoff_row, yoff_row, rowcol, eit0, enit, iit0, init, info; };
+// off: Lval offset; src: H offset or -1; [up0, up1) updates (external sources first); eit0/enit: external items (global item
+// index), iit0/init: internal items (piece-local index); info = di | dj << 4 | fmt << 8 | diag << 9 | row-in-piece << 10
+constexpr int kBlkFmt = 1 << 8, kBlkDiag = 1 << 9, kBlkRowIn = 1 << 10;
+
+struct UpdMeta { int ua, ub, ux, pk; };  // Lval offsets of L_ik, L_jk; y offset (elimination order) of y_k; flags below
+constexpr int kUpdDi6 = 1 << 20;         // target block has 6 rows (else 3)
+constexpr int kUpdDk6 = 1 << 21;         // source column k is 6 wide (else 3)
+constexpr int kUpdDiag = 1 << 22;        // target is the diagonal block (carries the forward-substitution rhs too)
+constexpr int kUpdDj6 = 1 << 23;         // target column is 6 wide (else 3)
+
+struct ItemMeta { int u0, n, tloff, flags; };   // updates [u0, u0 + n) of one target block at piece-local offset tloff
+constexpr int kItemSole = 1;                     // flags: bit 0 sole (subtract in place); bits 1..11 partial slot; bits 12.. local y offset
+constexpr int kItemSlotShift = 1, kItemSlotMask = 0x7FF, kItemYShift = 12;
+struct MbMeta { int tloff, ps0, n, info; };      // a target block with n > 1 items: partial slots [ps0, ps0 + n); info = di | dj << 4 | diag << 9 | ylocal << 12
+struct ILevel { int c0, c1, b0, b1, it0, it1, mb0, mb1; };   // one level inside a piece: columns, blocks (global ids), items (piece-local), multi-blocks
+struct PieceMeta { int graph, c0, nc, b0, nb, lbase, lsize, y0, ysize, eit0, enit, emb0, nemb, ilv0, nilv, iit0, nit_i, pad; };
+
+constexpr int kItemDoubles = 42;     // LDS doubles per partial tile: 6 x 6 entries + 6 rhs components
+constexpr int kMaxILevels = 64;      // internal levels per piece (LDS table in the kernels)
+constexpr int kMinChunk = 4;         // a list of <= kMinChunk updates is never split
+
+struct SymGraph { int prow0, nprow, lrow0, nlrow; };
+struct SymIn {
+  int B = 0, nPr = 0, nLr = 0;
+  std::vector<SymGraph> seg;
+  std::vector<std::pair<int, int>> ppoff, plblk;   // unique off-diagonal blocks: (pose row a < pose row b), (pose row, landmark row)
+  int64_t hll_base = 0, hpp_off_base = 0, hpl_base = 0;
+};
+struct CholOpts {
+  int cap_leaf = 3072;     // doubles of L per piece (pieces that share launches)
+  int cap_tail = 6144;     // doubles of L per piece of a tail
+  int max_blocks = 224;    // blocks per piece
+  int tail_width = -1;     // a graph's tail starts where it has <= tail_width pieces per depth; -1: 6 for batches >= 32, else 2; 0: no tail
+  int nt_leaf = 256, nt_tail = 512;   // workgroup sizes the items are cut for
+  bool dump = false;
+  static int env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
+  void from_env() {
+    cap_leaf = env_int("SSLAM_CHOL_CAP_LEAF", cap_leaf); cap_tail = env_int("SSLAM_CHOL_CAP_TAIL", cap_tail);
+    max_blocks = env_int("SSLAM_CHOL_MAX_BLOCKS", max_blocks); tail_width = env_int("SSLAM_CHOL_TAIL_WIDTH", tail_width);
+    nt_tail = env_int("SSLAM_CHOL_NT_TAIL", nt_tail);
+    dump = getenv("SSLAM_CHOL_DUMP") != nullptr;
+  }
+};
+
+struct CholHost {
+  int ncol = 0, nlevels = 0, dim = 0, B = 0, npiece = 0;
+  int64_t lnz = 0;           // doubles in Lval
+  std::vector<ColMeta> col; std::vector<BlkMeta> blk; std::vector<UpdMeta> upd; std::vector<ItemMeta> item; std::vector<MbMeta> mb;
+  std::vector<ILevel> ilv; std::vector<PieceMeta> piece;
+  std::vector<int> lvl_ptr, lvl_cols;       // column levels of the elimination tree (multi right-hand-side solves)
+  std::vector<int> plv_ptr, plv_pieces;     // pieces grouped by depth (one launch each)
+  std::vector<int> tail_ptr, tail_pieces;   // per graph: its tail pieces in elimination order
+  std::vector<int> plv_lds_f, plv_lds_b;    // LDS doubles per launch (factor / backward)
+  int tail_lds_f = 0, tail_lds_b = 0;
+  int nt_leaf = 256, nt_tail = 512;
+  std::string error;
+};
+
+namespace chol_detail {
+
+struct GraphSym {
+  std::vector<int> order;                  // elimination order (local node ids)
+  std::vector<std::vector<int>> cstruct;   // per node: higher-ordered neighbours at elimination time
+};
+
+// minimum degree with explicit fill (the block graphs here have ~1e4 nodes and fill ~1.7x)
+inline void min_degree(int n, std::vector<std::vector<int>>& adj, GraphSym& out) {
+  std::vector<char> done(n, 0);
+  using Item = std::pair<int, int>;  // (degree, node); lazy deletion
+  std::priority_queue<Item, std::vector<Item>, std::greater<Item>> pq;
+  for (int v = 0; v < n; ++v) { std::sort(adj[v].begin(), adj[v].end()); pq.push({(int)adj[v].size(), v}); }
+  out.order.clear(); out.order.reserve(n);
+  out.cstruct.assign(n, {});
+  std::vector<int> merged;
+  while (!pq.empty()) {
+    const Item it = pq.top(); pq.pop();
+    const int v = it.second;
+    if (done[v] || it.first != (int)adj[v].size()) continue;
+    done[v] = 1;
+    out.order.push_back(v);
+    std::vector<int>& nb = adj[v];
+    out.cstruct[v] = nb;
+    for (int u : nb) {
+      std::vector<int>& au = adj[u];
+      merged.clear();
+      merged.reserve(au.size() + nb.size());
+      std::set_union(au.begin(), au.end(), nb.begin(), nb.end(), std::back_inserter(merged));
+      au.clear();
+      for (int w : merged) if (w != u && w != v) au.push_back(w);
+      pq.push({(int)au.size(), u});
+    }
+    std::vector<int>().swap(adj[v]);
+  }
+}
+
+// Greedy bottom-up cut of an elimination tree (columns 0..n-1 in elimination order, parent[s] > s or -1) into pieces:
+// a column joins the still-open pieces of its children, largest first, while the caps hold; whatever does not fit is
+// closed.  fixed[s] >= 0 pins column s to an existing piece id (treated as closed).  Returns the piece id per column
+// (ids of new pieces start at first_new_id) and the number of ids used.
+inline int cut_pieces(int n, const std::vector<int>& parent, const std::vector<int>& colsz, const std::vector<int>& colnb,
+                      const std::vector<int>& fixed, int first_new_id, int cap, int max_blocks, std::vector<int>& pc) {
+  pc.assign(n, -1);
+  std::vector<std::vector<int>> kids(n);
+  for (int s = 0; s < n; ++s) if (parent[s] >= 0) kids[parent[s]].push_back(s);
+  std::vector<std::vector<int>> members;   // per new piece (index = id - first_new_id)
+  std::vector<int> psize, pblk;
+  std::vector<char> open;
+  std::vector<int> il(n, 0);               // level of a column inside its piece
+  for (int s = 0; s < n; ++s) {
+    if (fixed[s] >= 0) { pc[s] = fixed[s]; continue; }
+    std::vector<int> cand;                 // open pieces of the children
+    for (int c : kids[s]) {
+      const int p = pc[c];
+      if (fixed[c] >= 0) continue;
+      if (open[p - first_new_id] && std::find(cand.begin(), cand.end(), p) == cand.end()) cand.push_back(p);
+    }
+    std::sort(cand.begin(), cand.end(), [&](int a, int b) {
+      const int sa = psize[a - first_new_id], sb = psize[b - first_new_id];
+      return sa != sb ? sa > sb : a < b;
+    });
+    int size = colsz[s], nb = colnb[s], lev = 0;
+    std::vector<int> take;
+    for (int p : cand) {
+      const int q = p - first_new_id;
+      int l = 0;
+      for (int c : kids[s]) if (pc[c] == p) l = std::max(l, il[c] + 1);
+      if (size + psize[q] <= cap && nb + pblk[q] <= max_blocks && std::max(lev, l) < kMaxILevels) {
+        size += psize[q]; nb += pblk[q]; lev = std::max(lev, l); take.push_back(p);
+      }
+    }
+    for (int p : cand) open[p - first_new_id] = 0;   // merged or closed: either way no longer a candidate
+    int id;
+    if (take.empty()) {
+      id = first_new_id + (int)members.size();
+      members.push_back({}); psize.push_back(0); pblk.push_back(0); open.push_back(1);
+    } else {
+      id = take[0];                                   // the largest child keeps its id; the others are relabelled into it
+      for (size_t k = 1; k < take.size(); ++k) {
+        auto& mv = members[take[k] - first_new_id];
+        for (int c : mv) pc[c] = id;
+        auto& dst = members[id - first_new_id];
+        dst.insert(dst.end(), mv.begin(), mv.end());
+        std::vector<int>().swap(mv);
+      }
+    }
+    const int q = id - first_new_id;
+    members[q].push_back(s); pc[s] = id; psize[q] = size; pblk[q] = nb; open[q] = 1; il[s] = lev;
+  }
+  return first_new_id + (int)members.size();
+}
+
+}  // namespace chol_detail
+
+// Symbolic factorisation + piece plan of a whole batch.  Returns 0, or -1 with out.error set.
+inline int chol_symbolic(const SymIn& in, CholOpts opt, CholHost& out) {
+  using namespace chol_detail;
+  const int nPr = in.nPr, nLr = in.nLr, nrow = nPr + nLr, B = in.B;
+  if (opt.tail_width < 0) opt.tail_width = B >= 32 ? 6 : 2;
+  out = CholHost();
+  out.B = B; out.nt_leaf = opt.nt_leaf; out.nt_tail = opt.nt_tail;
+  auto row_dim = [&](int r) { return r < nPr ? 6 : 3; };
+  auto row_xoff = [&](int r) { return r < nPr ? 6 * r : 6 * nPr + 3 * (r - nPr); };
+  auto key = [](int a, int c) { return ((uint64_t)(uint32_t)a << 32) | (uint32_t)c; };
+  std::unordered_map<uint64_t, int> hoff;
+  hoff.reserve(in.ppoff.size() + in.plblk.size());
+  for (size_t i = 0; i < in.ppoff.size(); ++i) hoff[key(in.ppoff[i].first, in.ppoff[i].second)] = (int)(in.hpp_off_base + (int64_t)i * 36);
+  for (size_t i = 0; i < in.plblk.size(); ++i) hoff[key(in.plblk[i].first, nPr + in.plblk[i].second)] = (int)(in.hpl_base + (int64_t)i * 18);
+  std::vector<std::vector<int>> adj(nrow);
+  for (auto& pr : in.ppoff) { adj[pr.first].push_back(pr.second); adj[pr.second].push_back(pr.first); }
+  for (auto& pr : in.plblk) { adj[pr.first].push_back(nPr + pr.second); adj[nPr + pr.second].push_back(pr.first); }
+
+  // ---- per graph: ordering, elimination tree, pieces, final (piece-contiguous) elimination order ------------------
+  std::vector<int> col_row, col_graph, col_piece, col_tail;   // by final column id
+  std::vector<int> row_col(nrow, -1);
+  std::vector<std::vector<int>> cstruct_rows;                 // per column: rows of the off-diagonal blocks
+  int npiece = 0;
+  for (int g = 0; g < B; ++g) {
+    const SymGraph& sg = in.seg[g];
+    const int n = sg.nprow + sg.nlrow;
+    auto loc2row = [&](int v) { return v < sg.nprow ? sg.prow0 + v : nPr + sg.lrow0 + (v - sg.nprow); };
+    auto row2loc = [&](int r) { return r < nPr ? r - sg.prow0 : sg.nprow + (r - nPr - sg.lrow0); };
+    std::vector<std::vector<int>> ladj(n);
+    for (int v = 0; v < n; ++v) {
+      const int r = loc2row(v);
+      ladj[v].reserve(adj[r].size());
+      for (int w : adj[r]) ladj[v].push_back(row2loc(w));
+    }
+    GraphSym S;
+    min_degree(n, ladj, S);
+    std::vector<int> pos(n);
+    for (int s = 0; s < n; ++s) pos[S.order[s]] = s;
+    std::vector<int> parent(n, -1), colsz(n), colnb(n);
+    for (int s = 0; s < n; ++s) {
+      const int v = S.order[s];
+      const int d = row_dim(loc2row(v));
+      int rows = 0, par = n;
+      for (int w : S.cstruct[v]) { rows += row_dim(loc2row(w)); par = std::min(par, pos[w]); }
+      parent[s] = par == n ? -1 : par;
+      colsz[s] = d * d + d * rows;
+      colnb[s] = 1 + (int)S.cstruct[v].size();
+    }
+    // pass 1: leaf-sized pieces everywhere; depth of every piece in the piece tree
+    std::vector<int> pc, none(n, -1);
+    int np1 = cut_pieces(n, parent, colsz, colnb, none, 0, opt.cap_leaf, opt.max_blocks, pc);
+    std::vector<int> plev(np1, 0);
+    for (int s = 0; s < n; ++s)
+      if (parent[s] >= 0 && pc[parent[s]] != pc[s]) plev[pc[parent[s]]] = std::max(plev[pc[parent[s]]], plev[pc[s]] + 1);
+    // (a piece's depth must cover chains through several columns: iterate in elimination order, children first)
+    {
+      std::fill(plev.begin(), plev.end(), 0);
+      std::vector<int> colplev(n, 0);   // depth of the piece as known when the column is reached
+      bool changed = true;
+      while (changed) {
+        changed = false;
+        for (int s = 0; s < n; ++s)
+          if (parent[s] >= 0 && pc[parent[s]] != pc[s] && plev[pc[parent[s]]] < plev[pc[s]] + 1) { plev[pc[parent[s]]] = plev[pc[s]] + 1; changed = true; }
+      }
+    }
+    int nlev1 = 0;
+    for (int p = 0; p < np1; ++p) nlev1 = std::max(nlev1, plev[p] + 1);
+    std::vector<int> cnt(nlev1, 0);
+    for (int p = 0; p < np1; ++p) cnt[plev[p]]++;
+    int T = nlev1;
+    if (opt.tail_width > 0) while (T > 0 && cnt[T - 1] <= opt.tail_width) --T;
+    // pass 2: the tail columns are cut again with the tail cap (fewer external-update phases on the chain)
+    std::vector<int> fixed(n, -1);
+    bool any_tail = false;
+    for (int s = 0; s < n; ++s) { if (plev[pc[s]] < T) fixed[s] = pc[s]; else any_tail = true; }
+    std::vector<int> pc2 = pc;
+    int np2 = np1;
+    if (any_tail) np2 = cut_pieces(n, parent, colsz, colnb, fixed, np1, opt.cap_tail, opt.max_blocks, pc2);
+    std::vector<char> is_tail(np2, 0);
+    for (int s = 0; s < n; ++s) if (fixed[s] < 0) is_tail[pc2[s]] = 1;
+    // final order: pieces by root position, columns of a piece by (internal level, position)
+    std::vector<int> proot(np2, -1);
+    for (int s = 0; s < n; ++s) proot[pc2[s]] = std::max(proot[pc2[s]], s);
+    std::vector<int> il(n, 0);
+    for (int s = 0; s < n; ++s) if (parent[s] >= 0 && pc2[parent[s]] == pc2[s]) il[parent[s]] = std::max(il[parent[s]], il[s] + 1);
+    std::vector<int> ids;
+    for (int p = 0; p < np2; ++p) if (proot[p] >= 0) ids.push_back(p);
+    std::sort(ids.begin(), ids.end(), [&](int a, int b) { return proot[a] < proot[b]; });
+    std::vector<int> rank(np2, -1);
+    for (size_t k = 0; k < ids.size(); ++k) rank[ids[k]] = (int)k;
+    std::vector<int> perm(n);
+    for (int s = 0; s < n; ++s) perm[s] = s;
+    std::sort(perm.begin(), perm.end(), [&](int a, int b) {
+      if (pc2[a] != pc2[b]) return rank[pc2[a]] < rank[pc2[b]];
+      if (il[a] != il[b]) return il[a] < il[b];
+      return a < b;
+    });
+    const int c0 = (int)col_row.size();
+    for (int k = 0; k < n; ++k) {
+      const int s = perm[k];
+      const int r = loc2row(S.order[s]);
+      row_col[r] = c0 + k;
+      col_row.push_back(r); col_graph.push_back(g);
+      col_piece.push_back(npiece + rank[pc2[s]]); col_tail.push_back(is_tail[pc2[s]]);
+      std::vector<int> rows;
+      for (int w : S.cstruct[S.order[s]]) rows.push_back(loc2row(w));
+      cstruct_rows.push_back(std::move(rows));
+    }
+    npiece += (int)ids.size();
+  }
+  const int ncol = (int)col_row.size();
+  out.ncol = ncol; out.npiece = npiece; out.dim = 6 * nPr + 3 * nLr;
+
+  // ---- blocks of every column, sorted by elimination position of the row ----------------------------------------------
+  std::vector<int> bp(ncol + 1, 0), boff, brow, bsrc, col_xoff(ncol), col_yoff(ncol), col_dim(ncol);
+  std::vector<unsigned char> bfmt;
+  std::vector<std::unordered_map<int, int>> colblk(ncol);
+  int64_t lnz = 0;
+  {
+    int y = 0;
+    for (int j = 0; j < ncol; ++j) {
+      const int rj = col_row[j], dj = row_dim(rj);
+      col_xoff[j] = row_xoff(rj); col_dim[j] = dj; col_yoff[j] = y; y += dj;
+      std::vector<int> rows_c;
+      for (int r : cstruct_rows[j]) rows_c.push_back(row_col[r]);
+      std::sort(rows_c.begin(), rows_c.end());
+      bp[j] = (int)boff.size();
+      boff.push_back((int)lnz); brow.push_back(j);
+      bsrc.push_back(rj < nPr ? rj * 36 : (int)(in.hll_base + (int64_t)(rj - nPr) * 9)); bfmt.push_back(0);
+      colblk[j][j] = bp[j];
+      lnz += dj * dj;
+      for (int i : rows_c) {
+        if (i <= j) { out.error = "symbolic factorisation inconsistent (row not below its column)"; return -1; }
+        const int ri = col_row[i], di = row_dim(ri);
+        colblk[j][i] = (int)boff.size();
+        boff.push_back((int)lnz); brow.push_back(i);
+        const int a = std::min(ri, rj), c = std::max(ri, rj);
+        auto it = hoff.find(key(a, c));
+        if (it == hoff.end()) { bsrc.push_back(-1); bfmt.push_back(0); }
+        else { bsrc.push_back(it->second); bfmt.push_back(ri == a ? 0 : 1); }   // stored [min][max]; we need [i][j]
+        lnz += di * dj;
+      }
+      if (lnz >= ((int64_t)1 << 31) - 4096) { out.error = "Cholesky factor too large for int32 offsets"; return -1; }
+    }
+  }
+  bp[ncol] = (int)boff.size();
+  const int nblk = (int)boff.size();
+  out.lnz = lnz;
+  // ---- update lists: column k updates every (i, j) pair of its structure with pos(j) <= pos(i) ---------------------------
+  std::vector<std::vector<std::array<int, 3>>> ulist(nblk);
+  for (int k = 0; k < ncol; ++k) {
+    const int k0 = bp[k] + 1, k1 = bp[k + 1];
+    for (int p = k0; p < k1; ++p) {
+      const int j = brow[p];
+      for (int q = p; q < k1; ++q) {
+        const int i = brow[q];
+        auto it = colblk[j].find(i);
+        if (it == colblk[j].end()) { out.error = "symbolic factorisation inconsistent (missing fill block)"; return -1; }
+        ulist[it->second].push_back({boff[q], boff[p], k});
+      }
+    }
+  }
+  // ---- levels of the block elimination tree (multi right-hand-side solves) ---------------------------------------------
+  std::vector<int> level(ncol, 0), col_il(ncol, 0);
+  int nlev = 0;
+  for (int j = 0; j < ncol; ++j) {
+    if (bp[j + 1] - bp[j] > 1) {
+      const int par = brow[bp[j] + 1];
+      level[par] = std::max(level[par], level[j] + 1);
+      if (col_piece[par] == col_piece[j]) col_il[par] = std::max(col_il[par], col_il[j] + 1);
+    }
+    nlev = std::max(nlev, level[j] + 1);
+  }
+  out.nlevels = nlev;
+  out.lvl_ptr.assign(nlev + 1, 0);
+  for (int j = 0; j < ncol; ++j) out.lvl_ptr[level[j] + 1]++;
+  for (int l = 0; l < nlev; ++l) out.lvl_ptr[l + 1] += out.lvl_ptr[l];
+  out.lvl_cols.resize(ncol);
+  {
+    std::vector<int> cursor(out.lvl_ptr.begin(), out.lvl_ptr.end() - 1);
+    for (int j = 0; j < ncol; ++j) out.lvl_cols[cursor[level[j]]++] = j;
+  }
+  // ---- pieces: column / block ranges (contiguous by construction) --------------------------------------------------------
+  out.piece.assign(npiece, PieceMeta{});
+  std::vector<char> piece_tail(npiece, 0);
+  for (int p = 0; p < npiece; ++p) out.piece[p].nc = 0;
+  for (int j = 0; j < ncol; ++j) {
+    PieceMeta& pm = out.piece[col_piece[j]];
+    if (pm.nc == 0) { pm.graph = col_graph[j]; pm.c0 = j; pm.b0 = bp[j]; pm.lbase = boff[bp[j]]; pm.y0 = col_yoff[j]; }
+    if (j != pm.c0 + pm.nc) { out.error = "piece columns are not contiguous"; return -1; }
+    pm.nc++;
+    pm.nb = bp[j + 1] - pm.b0;
+    pm.ysize = col_yoff[j] + col_dim[j] - pm.y0;
+    const int last = bp[j + 1] - 1;
+    pm.lsize = boff[last] + col_dim[brow[last]] * col_dim[j] - pm.lbase;
+    piece_tail[col_piece[j]] = (char)col_tail[j];
+  }
+  // depth of the non-tail pieces in the piece tree
+  std::vector<int> plev(npiece, 0);
+  for (int j = 0; j < ncol; ++j)
+    if (bp[j + 1] - bp[j] > 1) {
+      const int par = brow[bp[j] + 1];
+      const int pj = col_piece[j], pp = col_piece[par];
+      if (pp != pj) plev[pp] = std::max(plev[pp], plev[pj] + 1);   // pieces are in elimination order: children are final before their parents' columns are visited
+    }
+  {
+    // (a parent piece may have been reached through an earlier column before a deeper child was visited: fix-point over the ordered pieces)
+    bool changed = true;
+    while (changed) {
+      changed = false;
+      for (int j = 0; j < ncol; ++j)
+        if (bp[j + 1] - bp[j] > 1) {
+          const int par = brow[bp[j] + 1];
+          const int pj = col_piece[j], pp = col_piece[par];
+          if (pp != pj && plev[pp] < plev[pj] + 1) { plev[pp] = plev[pj] + 1; changed = true; }
+        }
+    }
+  }
+  int nplv = 0;
+  for (int p = 0; p < npiece; ++p) if (!piece_tail[p]) nplv = std::max(nplv, plev[p] + 1);
+  out.plv_ptr.assign(nplv + 1, 0);
+  for (int p = 0; p < npiece; ++p) if (!piece_tail[p]) out.plv_ptr[plev[p] + 1]++;
+  for (int l = 0; l < nplv; ++l) out.plv_ptr[l + 1] += out.plv_ptr[l];
+  out.plv_pieces.resize(out.plv_ptr[nplv]);
+  {
+    std::vector<int> cursor(out.plv_ptr.begin(), out.plv_ptr.end() - 1);
+    for (int p = 0; p < npiece; ++p) if (!piece_tail[p]) out.plv_pieces[cursor[plev[p]]++] = p;
+  }
+  out.tail_ptr.assign(B + 1, 0);
+  for (int p = 0; p < npiece; ++p) if (piece_tail[p]) out.tail_ptr[out.piece[p].graph + 1]++;
+  for (int g = 0; g < B; ++g) out.tail_ptr[g + 1] += out.tail_ptr[g];
+  out.tail_pieces.resize(out.tail_ptr[B]);
+  {
+    std::vector<int> cursor(out.tail_ptr.begin(), out.tail_ptr.end() - 1);
+    for (int p = 0; p < npiece; ++p) if (piece_tail[p]) out.tail_pieces[cursor[out.piece[p].graph]++] = p;   // ascending id = elimination order
+  }
+  // ---- update records (external sources first), columns, blocks ------------------------------------------------------------
+  out.col.assign(ncol, ColMeta{});
+  out.blk.assign(nblk, BlkMeta{});
+  std::vector<int> upx(nblk, 0);   // first internal update of every block
+  out.upd.clear();
+  {
+    size_t total = 0;
+    for (int t = 0; t < nblk; ++t) total += ulist[t].size();
+    out.upd.reserve(total);
+  }
+  for (int j = 0; j < ncol; ++j) {
+    const int pj = col_piece[j];
+    const int last = bp[j + 1] - 1;
+    const int csize = boff[last] - boff[bp[j]] + col_dim[brow[last]] * col_dim[j];
+    int nbi = 0;
+    for (int t = bp[j]; t < bp[j + 1]; ++t) if (col_piece[brow[t]] == pj) ++nbi;   // rows sorted by position: in-piece rows come first
+    for (int t = bp[j]; t < bp[j] + nbi; ++t) if (col_piece[brow[t]] != pj) { out.error = "in-piece rows of a column are not a prefix"; return -1; }
+    out.col[j] = ColMeta{col_xoff[j], col_yoff[j], col_dim[j], col_graph[j], bp[j], bp[j + 1] - bp[j], nbi, boff[bp[j]], csize, pj, col_il[j], 0};
+    for (int t = bp[j]; t < bp[j + 1]; ++t) {
+      const int i = brow[t];
+      const int tpk = (col_dim[i] == 6 ? kUpdDi6 : 0) | (t == bp[j] ? kUpdDiag : 0) | (col_dim[j] == 6 ? kUpdDj6 : 0);
+      BlkMeta& bm = out.blk[t];
+      bm.off = boff[t]; bm.src = bsrc[t];
+      bm.up0 = (int)out.upd.size();
+      for (int pass = 0; pass < 2; ++pass) {   // external sources first, each part ascending in k
+        if (pass == 1) upx[t] = (int)out.upd.size();
+        for (auto& u : ulist[t]) {
+          const bool internal = col_piece[u[2]] == pj;
+          if ((int)internal != pass) continue;
+          out.upd.push_back(UpdMeta{u[0], u[1], col_yoff[u[2]], tpk | (col_dim[u[2]] == 6 ? kUpdDk6 : 0)});
+        }
+      }
+      bm.up1 = (int)out.upd.size();
+      bm.xoff_row = col_xoff[i]; bm.yoff_row = col_yoff[i]; bm.rowcol = i;
+      bm.info = col_dim[i] | (col_dim[j] << 4) | (bfmt[t] ? kBlkFmt : 0) | (t == bp[j] ? kBlkDiag : 0) | (col_piece[i] == pj ? kBlkRowIn : 0);
+      std::vector<std::array<int, 3>>().swap(ulist[t]);
+    }
+  }
+  // ---- work items per piece: the external phase, then one phase per internal level -----------------------------------------
+  std::vector<int> block_col(nblk);
+  for (int j = 0; j < ncol; ++j) for (int t = bp[j]; t < bp[j + 1]; ++t) block_col[t] = j;
+  out.item.clear(); out.mb.clear(); out.ilv.clear();
+  std::vector<int> piece_pmax(npiece, 0);   // most partial tiles any phase of the piece needs
+  for (int p = 0; p < npiece; ++p) {
+    PieceMeta& pm = out.piece[p];
+    const int nt = piece_tail[p] ? opt.nt_tail : opt.nt_leaf;
+    const int slots = nt / 4;
+    const int pcap = std::min(slots, kItemSlotMask);
+    // one phase over the blocks [b_begin, b_end): part 0 = external updates [up0, upx), part 1 = internal [upx, up1);
+    // item indices of part 1 are piece-local (the internal items of a piece are copied to LDS)
+    auto build_phase = [&](int b_begin, int b_end, int part, int& mb0, int& mb1) {
+      auto count = [&](int t) { return part == 0 ? upx[t] - out.blk[t].up0 : out.blk[t].up1 - upx[t]; };
+      int U = 0;
+      for (int t = b_begin; t < b_end; ++t) U += count(t);
+      int chunk = std::max(kMinChunk, (U + slots - 1) / slots);
+      for (;; ++chunk) {   // raise the chunk until the partial tiles of the split lists fit the LDS budget
+        int nonsole = 0;
+        for (int t = b_begin; t < b_end; ++t) { const int k = (count(t) + chunk - 1) / chunk; if (k > 1) nonsole += k; }
+        if (nonsole <= pcap || chunk >= std::max(U, 1)) break;
+      }
+      mb0 = (int)out.mb.size();
+      int ps = 0;
+      for (int t = b_begin; t < b_end; ++t) {
+        BlkMeta& bm = out.blk[t];
+        const int u0 = part == 0 ? bm.up0 : upx[t], u1 = part == 0 ? upx[t] : bm.up1;
+        const int n = u1 - u0;
+        const int it0 = (int)out.item.size();
+        if (part == 0) { bm.eit0 = it0; bm.enit = 0; } else { bm.iit0 = it0 - pm.iit0; bm.init = 0; }
+        if (n <= 0) continue;
+        const int k = (n + chunk - 1) / chunk;
+        const int tloff = bm.off - pm.lbase;
+        const int ylocal = out.col[block_col[t]].yoff - pm.y0;
+        for (int q = 0; q < k; ++q) {
+          const int a = u0 + q * chunk, b2 = std::min(u1, a + chunk);
+          int flags = ylocal << kItemYShift;
+          if (k == 1) flags |= kItemSole; else flags |= (ps + q) << kItemSlotShift;
+          out.item.push_back(ItemMeta{a, b2 - a, tloff, flags});
+        }
+        if (k > 1) {
+          out.mb.push_back(MbMeta{tloff, ps, k, (bm.info & 0xFF) | (bm.info & kBlkDiag) | (ylocal << 12)});
+          ps += k;
+        }
+        if (part == 0) bm.enit = k; else bm.init = k;
+      }
+      mb1 = (int)out.mb.size();
+      piece_pmax[p] = std::max(piece_pmax[p], ps);
+    };
+    int mb0, mb1;
+    pm.eit0 = (int)out.item.size();
+    build_phase(pm.b0, pm.b0 + pm.nb, 0, mb0, mb1);
+    pm.enit = (int)out.item.size() - pm.eit0; pm.emb0 = mb0; pm.nemb = mb1 - mb0;
+    pm.iit0 = (int)out.item.size();
+    pm.ilv0 = (int)out.ilv.size();
+    int c = pm.c0;
+    const int cend = pm.c0 + pm.nc;
+    while (c < cend) {
+      int c1 = c;
+      while (c1 < cend && col_il[c1] == col_il[c]) ++c1;
+      if (col_il[c] != (int)out.ilv.size() - pm.ilv0) { out.error = "internal levels of a piece are not contiguous"; return -1; }
+      ILevel lv{};
+      lv.c0 = c; lv.c1 = c1; lv.b0 = bp[c]; lv.b1 = bp[c1];
+      lv.it0 = (int)out.item.size() - pm.iit0;
+      build_phase(lv.b0, lv.b1, 1, lv.mb0, lv.mb1);
+      lv.it1 = (int)out.item.size() - pm.iit0;
+      out.ilv.push_back(lv);
+      c = c1;
+    }
+    pm.nilv = (int)out.ilv.size() - pm.ilv0;
+    pm.nit_i = (int)out.item.size() - pm.iit0;
+    if (pm.nilv > kMaxILevels) { out.error = "a piece has too many internal levels"; return -1; }
+    if (pm.ysize >= (1 << (32 - kItemYShift - 1))) { out.error = "a piece has too many unknowns"; return -1; }
+  }
+  // ---- LDS needs (doubles) ---------------------------------------------------------------------------------------------------
+  auto lds_f = [&](int p) {
+    const PieceMeta& pm = out.piece[p];
+    return ((pm.lsize + 1) & ~1) + 2 * ((pm.ysize + 1) & ~1) + 2 * pm.nb + 2 * pm.nc + 2 * pm.nit_i + kItemDoubles * piece_pmax[p] + 8;
+  };
+  auto lds_b = [&](int p) {
+    const PieceMeta& pm = out.piece[p];
+    return ((pm.lsize + 1) & ~1) + ((pm.ysize + 1) & ~1) + pm.nb + 2 * pm.nc + 8;
+  };
+  out.plv_lds_f.assign(nplv, 0); out.plv_lds_b.assign(nplv, 0);
+  for (int l = 0; l < nplv; ++l)
+    for (int q = out.plv_ptr[l]; q < out.plv_ptr[l + 1]; ++q) {
+      out.plv_lds_f[l] = std::max(out.plv_lds_f[l], lds_f(out.plv_pieces[q]));
+      out.plv_lds_b[l] = std::max(out.plv_lds_b[l], lds_b(out.plv_pieces[q]));
+    }
+  for (int p : out.tail_pieces) { out.tail_lds_f = std::max(out.tail_lds_f, lds_f(p)); out.tail_lds_b = std::max(out.tail_lds_b, lds_b(p)); }
+  if (opt.dump) {
+    fprintf(stderr, "[chol-dump] B %d cols %d blocks %d lnz %lld updates %zu items %zu multi-blocks %zu column-levels %d pieces %d piece-levels %d tail pieces %zu\n",
+            B, ncol, nblk, (long long)lnz, out.upd.size(), out.item.size(), out.mb.size(), nlev, npiece, nplv, out.tail_pieces.size());
+    for (int l = 0; l < nplv; ++l)
+      fprintf(stderr, "[chol-dump]   piece-level %d: %d pieces, LDS factor %d B backward %d B\n", l, out.plv_ptr[l + 1] - out.plv_ptr[l],
+              out.plv_lds_f[l] * 8, out.plv_lds_b[l] * 8);
+    int tmax = 0, tlv = 0;
+    for (int g = 0; g < B; ++g) tmax = std::max(tmax, out.tail_ptr[g + 1] - out.tail_ptr[g]);
+    for (int q = out.tail_ptr[0]; q < out.tail_ptr[std::min(1, B)]; ++q) tlv += out.piece[out.tail_pieces[q]].nilv;
+    fprintf(stderr, "[chol-dump]   tail: <= %d pieces per graph (graph 0: %d internal levels), LDS factor %d B backward %d B\n", tmax, tlv,
+            out.tail_lds_f * 8, out.tail_lds_b * 8);
+  }
+  return 0;
+}
+
+}  // namespace sslam
