@@ -173,7 +173,7 @@ def main():
             g = make_graph(args.poses, args.landmarks, seed=1000 * rank + d, landmark_kind=kind)
             gp = GraphProblem.from_synth(g)
             problems.append(gp)
-            G0 = GraphSLAM.from_problem(gp, device=dev)
+            G0 = GraphSLAM.from_synth(g, device=dev)
             p = os.path.join(tmpdir, f"{kind}{d}.g2o")
             G0.save(p)
             paths.append(p)

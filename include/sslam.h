@@ -123,6 +123,15 @@ int sslam_graph_solve(sslam_graph* g, double lambda, double* x, int64_t* solver_
 /* x <- x [+] dx for all active vertices (VertexSE3/PointXYZ/Plane::oplus) */
 int sslam_graph_oplus(sslam_graph* g, const double* dx);
 
+/* ---- plan introspection (host only: works without a HIP device) ----------------------------
+ * The symbolic sparse-Cholesky plan of a batch (ordering, elimination-tree pieces, work items) as flat arrays of int32
+ * records, for the CPU-side plan tests (tests/test_chol_plan_cpu.py).  Arrays: "col","blk","upd","item","mb","ilv","piece",
+ * "lvl_ptr","lvl_cols","plv_ptr","plv_pieces","tail_ptr","tail_pieces","plv_lds_f","plv_lds_b","scalars".
+ * sslam_debug_plan_array returns the byte size of the array (copies it when out != NULL and cap_bytes suffices). */
+void* sslam_debug_plan_create(sslam_graph* const* graphs, int n);
+void sslam_debug_plan_destroy(void* plan);
+int64_t sslam_debug_plan_array(void* plan, const char* name, void* out, int64_t cap_bytes);
+
 /* ---- batched, device-resident form (MI355X extension) ---------------------------------------
  * B independent graphs laid out contiguously in HBM and optimised together: every kernel runs
  * over the union, LM control (rho, lambda, accept/reject) is per graph on the device. */

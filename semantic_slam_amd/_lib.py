@@ -73,6 +73,9 @@ def load_library():
         "sslam_graph_linearize": (ci, [vp, C.POINTER(ci), C.POINTER(i64), vp, vp, vp, vp]),
         "sslam_graph_solve": (ci, [vp, cd, dp, C.POINTER(i64)]),
         "sslam_graph_oplus": (ci, [vp, dp]),
+        "sslam_debug_plan_create": (vp, [C.POINTER(vp), ci]),
+        "sslam_debug_plan_destroy": (None, [vp]),
+        "sslam_debug_plan_array": (i64, [vp, C.c_char_p, vp, i64]),
         "sslam_batch_create": (vp, [C.POINTER(vp), ci]),
         "sslam_batch_destroy": (None, [vp]),
         "sslam_batch_upload": (ci, [vp]),

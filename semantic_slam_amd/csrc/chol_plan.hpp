@@ -33,14 +33,15 @@
 
 namespace sslam {
 
-struct ColMeta { int xoff, yoff, dim, graph, b0, nb, nbi, base, csize, piece, ilevel, pad; };
+struct ColMeta { int xoff, yoff, dim, graph, b0, nb, nbi, base, up0, up1, piece, ilevel; };
 // xoff: offset in the unknown vector (internal row order); yoff: offset in elimination order (the forward-substituted
 // rhs y lives in that order so that a piece's y is contiguous); blocks [b0, b0 + nb), diagonal first, the first nbi
-// (diagonal included) have their row inside the column's own piece; base = Lval offset of the diagonal block
+// (diagonal included) have their row inside the column's own piece; base = Lval offset of the diagonal block;
+// [up0, up1) = updates of the diagonal block (forward substitution of the multi right-hand-side solves)
 
-struct BlkMeta { int off, src, up0, up1, xoff_row, yoff_row, rowcol, eit0, enit, iit0, init, info; };
-// off: Lval offset; src: H offset or -1; [up0, up1) updates (external sources first); eit0/enit: external items (global item
-// index), iit0/init: internal items (piece-local index); info = di | dj << 4 | fmt << 8 | diag << 9 | row-in-piece << 10
+struct BlkMeta { int off, src, xoff_row, yoff_row, coldiag, colyoff, info, pad; };
+// off: Lval offset; src: H offset or -1; x / y offsets of the block's row; Lval offset of the diagonal block and y offset of
+// the block's column; info = di | dj << 4 | fmt << 8 | diag << 9 | row-in-piece << 10
 constexpr int kBlkFmt = 1 << 8, kBlkDiag = 1 << 9, kBlkRowIn = 1 << 10;
 
 struct UpdMeta { int ua, ub, ux, pk; };  // Lval offsets of L_ik, L_jk; y offset (elimination order) of y_k; flags below
@@ -431,7 +432,7 @@ inline int chol_symbolic(const SymIn& in, CholOpts opt, CholHost& out) {
   // ---- update records (external sources first), columns, blocks ------------------------------------------------------------
   out.col.assign(ncol, ColMeta{});
   out.blk.assign(nblk, BlkMeta{});
-  std::vector<int> upx(nblk, 0);   // first internal update of every block
+  std::vector<int> upx(nblk, 0), bup0(nblk, 0), bup1(nblk, 0);   // per block: [bup0, upx) external, [upx, bup1) internal updates
   out.upd.clear();
   {
     size_t total = 0;
@@ -440,18 +441,16 @@ inline int chol_symbolic(const SymIn& in, CholOpts opt, CholHost& out) {
   }
   for (int j = 0; j < ncol; ++j) {
     const int pj = col_piece[j];
-    const int last = bp[j + 1] - 1;
-    const int csize = boff[last] - boff[bp[j]] + col_dim[brow[last]] * col_dim[j];
     int nbi = 0;
     for (int t = bp[j]; t < bp[j + 1]; ++t) if (col_piece[brow[t]] == pj) ++nbi;   // rows sorted by position: in-piece rows come first
     for (int t = bp[j]; t < bp[j] + nbi; ++t) if (col_piece[brow[t]] != pj) { out.error = "in-piece rows of a column are not a prefix"; return -1; }
-    out.col[j] = ColMeta{col_xoff[j], col_yoff[j], col_dim[j], col_graph[j], bp[j], bp[j + 1] - bp[j], nbi, boff[bp[j]], csize, pj, col_il[j], 0};
+    out.col[j] = ColMeta{col_xoff[j], col_yoff[j], col_dim[j], col_graph[j], bp[j], bp[j + 1] - bp[j], nbi, boff[bp[j]], 0, 0, pj, col_il[j]};
     for (int t = bp[j]; t < bp[j + 1]; ++t) {
       const int i = brow[t];
       const int tpk = (col_dim[i] == 6 ? kUpdDi6 : 0) | (t == bp[j] ? kUpdDiag : 0) | (col_dim[j] == 6 ? kUpdDj6 : 0);
       BlkMeta& bm = out.blk[t];
       bm.off = boff[t]; bm.src = bsrc[t];
-      bm.up0 = (int)out.upd.size();
+      bup0[t] = (int)out.upd.size();
       for (int pass = 0; pass < 2; ++pass) {   // external sources first, each part ascending in k
         if (pass == 1) upx[t] = (int)out.upd.size();
         for (auto& u : ulist[t]) {
@@ -460,8 +459,9 @@ inline int chol_symbolic(const SymIn& in, CholOpts opt, CholHost& out) {
           out.upd.push_back(UpdMeta{u[0], u[1], col_yoff[u[2]], tpk | (col_dim[u[2]] == 6 ? kUpdDk6 : 0)});
         }
       }
-      bm.up1 = (int)out.upd.size();
-      bm.xoff_row = col_xoff[i]; bm.yoff_row = col_yoff[i]; bm.rowcol = i;
+      bup1[t] = (int)out.upd.size();
+      if (t == bp[j]) { out.col[j].up0 = bup0[t]; out.col[j].up1 = bup1[t]; }
+      bm.xoff_row = col_xoff[i]; bm.yoff_row = col_yoff[i]; bm.coldiag = boff[bp[j]]; bm.colyoff = col_yoff[j]; bm.pad = 0;
       bm.info = col_dim[i] | (col_dim[j] << 4) | (bfmt[t] ? kBlkFmt : 0) | (t == bp[j] ? kBlkDiag : 0) | (col_piece[i] == pj ? kBlkRowIn : 0);
       std::vector<std::array<int, 3>>().swap(ulist[t]);
     }
@@ -479,7 +479,7 @@ inline int chol_symbolic(const SymIn& in, CholOpts opt, CholHost& out) {
     // one phase over the blocks [b_begin, b_end): part 0 = external updates [up0, upx), part 1 = internal [upx, up1);
     // item indices of part 1 are piece-local (the internal items of a piece are copied to LDS)
     auto build_phase = [&](int b_begin, int b_end, int part, int& mb0, int& mb1) {
-      auto count = [&](int t) { return part == 0 ? upx[t] - out.blk[t].up0 : out.blk[t].up1 - upx[t]; };
+      auto count = [&](int t) { return part == 0 ? upx[t] - bup0[t] : bup1[t] - upx[t]; };
       int U = 0;
       for (int t = b_begin; t < b_end; ++t) U += count(t);
       int chunk = std::max(kMinChunk, (U + slots - 1) / slots);
@@ -491,11 +491,9 @@ inline int chol_symbolic(const SymIn& in, CholOpts opt, CholHost& out) {
       mb0 = (int)out.mb.size();
       int ps = 0;
       for (int t = b_begin; t < b_end; ++t) {
-        BlkMeta& bm = out.blk[t];
-        const int u0 = part == 0 ? bm.up0 : upx[t], u1 = part == 0 ? upx[t] : bm.up1;
+        const BlkMeta& bm = out.blk[t];
+        const int u0 = part == 0 ? bup0[t] : upx[t], u1 = part == 0 ? upx[t] : bup1[t];
         const int n = u1 - u0;
-        const int it0 = (int)out.item.size();
-        if (part == 0) { bm.eit0 = it0; bm.enit = 0; } else { bm.iit0 = it0 - pm.iit0; bm.init = 0; }
         if (n <= 0) continue;
         const int k = (n + chunk - 1) / chunk;
         const int tloff = bm.off - pm.lbase;
@@ -510,7 +508,6 @@ inline int chol_symbolic(const SymIn& in, CholOpts opt, CholHost& out) {
           out.mb.push_back(MbMeta{tloff, ps, k, (bm.info & 0xFF) | (bm.info & kBlkDiag) | (ylocal << 12)});
           ps += k;
         }
-        if (part == 0) bm.enit = k; else bm.init = k;
       }
       mb1 = (int)out.mb.size();
       piece_pmax[p] = std::max(piece_pmax[p], ps);
@@ -547,7 +544,7 @@ inline int chol_symbolic(const SymIn& in, CholOpts opt, CholHost& out) {
   };
   auto lds_b = [&](int p) {
     const PieceMeta& pm = out.piece[p];
-    return ((pm.lsize + 1) & ~1) + ((pm.ysize + 1) & ~1) + pm.nb + 2 * pm.nc + 8;
+    return ((pm.lsize + 1) & ~1) + ((pm.ysize + 1) & ~1) + 9 * pm.nb + 3 * pm.nc + 10;
   };
   out.plv_lds_f.assign(nplv, 0); out.plv_lds_b.assign(nplv, 0);
   for (int l = 0; l < nplv; ++l)

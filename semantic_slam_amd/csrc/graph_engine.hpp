@@ -109,8 +109,11 @@ inline int dev_alloc(Batch& b, size_t n, T** out, bool zero = true) {
 }
 
 
-// sparse block Cholesky (sslam_chol.hip)
+// sparse block Cholesky (sslam_chol.hip; symbolic phase in chol_plan.hpp)
+struct SymIn;
+void chol_sym_input(const Batch& b, SymIn& in);
 int chol_plan_build(Batch& b);
+int chol_plan_launches(const Batch& b);
 int chol_factor_and_forward(Batch& b);   // (H + lambda I) = L L^T for in_trial graphs, y = L^-1 b
 int chol_backward(Batch& b);             // x = L^-T y  -> V.x
 int64_t chol_plan_lnz(const Batch& b);

@@ -15,8 +15,6 @@ struct Options {
   int solver = 1;            // 0 PCG, 1 sparse block Cholesky
   double pcg_tol = 1e-10;    // relative residual ||r|| / ||b||
   int pcg_max_iters = 20000;
-  int schur = 0;             // PCG on the landmark-eliminated (Schur) system, matrix-free
-  int deterministic = 3;     // Jacobian build variant: 3 thread per row (default), 1 8-lane groups, 2 LDS tiles, 0 FP64 atomics
 };
 
 struct HostGraph {

@@ -32,6 +32,7 @@ struct LmState {
   double lambda, nu, cur_chi, tmp_chi, rho, scale, chi_before, max_diag;
   long long pcg_iters;
   int q, iter, status, in_trial, active, accept, trials, solve_failed;
+  int lin, pad0;   // lin: the graph starts a new LM iteration at the next step (its system is rebuilt)
 };
 
 // Device view of a batch (plain pointers; passed by value to kernels).

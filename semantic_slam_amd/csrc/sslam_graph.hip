@@ -17,6 +17,7 @@
 #include "graph_kernels.hpp"
 #include "sslam_common.hpp"
 #include "graph_engine.hpp"
+#include "chol_plan.hpp"
 
 namespace sslam {
 
@@ -80,510 +81,15 @@ __global__ __launch_bounds__(kEdgeChunk) void k_chi2(BatchView V, const double* 
   if (threadIdx.x == 0) part[(size_t)g * V.maxEdgeChunks + blockIdx.x] = s;
 }
 
-// ---- Jacobian build, variant A: edge-parallel, hardware FP64 atomics (global_atomic_add_f64) --
-__device__ __forceinline__ void atomic_add(double* p, double v) { unsafeAtomicAdd(p, v); }
 // off-diagonal block codes: >= 0 owner edge, <= -2 a further edge on the same vertex pair, -1 none
 __device__ __forceinline__ int decode_blk(int code) { return code <= -2 ? -2 - code : code; }
-
-__global__ __launch_bounds__(kEdgeChunk) void k_linearize_atomic(BatchView V) {
-  const int g = blockIdx.y;
-  if (!V.lm[g].active) return;
-  const GraphSeg sg = V.seg[g];
-  const int e = blockIdx.x * kEdgeChunk + threadIdx.x;
-  if (e < sg.neo) {
-    const int k = sg.eo0 + e;
-    const int pi = V.eo_i[k], pj = V.eo_j[k];
-    const Pose Xi = load_pose(V.pose, pi), Xj = load_pose(V.pose, pj);
-    const int n = V.nEo;
-    const Pose Z{{V.eo_z[0 * (size_t)n + k], V.eo_z[1 * (size_t)n + k], V.eo_z[2 * (size_t)n + k]},
-                 {V.eo_z[3 * (size_t)n + k], V.eo_z[4 * (size_t)n + k], V.eo_z[5 * (size_t)n + k], V.eo_z[6 * (size_t)n + k]}};
-    Se3Lin L;
-    se3_error(Xi, Xj, Z, L);
-    double Ji[36], Jj[36], W[36];
-    se3_full_jacobians(L, Ji, Jj);
-    load_sym6(V.eo_w, n, k, W);
-    const int ri = V.pose_row[pi], rj = V.pose_row[pj];
-    const int blk = decode_blk(V.eo_blk[k]);
-    double We[6];
-    for (int r = 0; r < 6; ++r) { double a = 0; for (int s = 0; s < 6; ++s) a += W[r * 6 + s] * L.e[s]; We[r] = a; }
-    // WJ = W * J  (one side at a time to bound live registers)
-    double WJ[36];
-    for (int r = 0; r < 6; ++r) for (int c = 0; c < 6; ++c) { double a = 0; for (int s = 0; s < 6; ++s) a += W[r * 6 + s] * Jj[s * 6 + c]; WJ[r * 6 + c] = a; }
-    if (rj >= 0) {
-      double* D = V.Hpp_diag + (size_t)rj * 36;
-      for (int r = 0; r < 6; ++r) for (int c = 0; c < 6; ++c) { double a = 0; for (int s = 0; s < 6; ++s) a += Jj[s * 6 + r] * WJ[s * 6 + c]; atomic_add(D + r * 6 + c, a); }
-      for (int r = 0; r < 6; ++r) { double a = 0; for (int s = 0; s < 6; ++s) a += Jj[s * 6 + r] * We[s]; atomic_add(V.bvec + 6 * (size_t)rj + r, -a); }
-    }
-    if (blk >= 0) {  // off-diagonal block (min row, max row): Ji^T W Jj or its transpose
-      double* O = V.Hpp_off + (size_t)(blk >> 1) * 36;
-      const int swap = blk & 1;
-      for (int r = 0; r < 6; ++r) for (int c = 0; c < 6; ++c) {
-        double a = 0; for (int s = 0; s < 6; ++s) a += Ji[s * 6 + r] * WJ[s * 6 + c];
-        atomic_add(O + (swap ? c * 6 + r : r * 6 + c), a);
-      }
-    }
-    if (ri >= 0) {
-      for (int r = 0; r < 6; ++r) for (int c = 0; c < 6; ++c) { double a = 0; for (int s = 0; s < 6; ++s) a += W[r * 6 + s] * Ji[s * 6 + c]; WJ[r * 6 + c] = a; }
-      double* D = V.Hpp_diag + (size_t)ri * 36;
-      for (int r = 0; r < 6; ++r) for (int c = 0; c < 6; ++c) { double a = 0; for (int s = 0; s < 6; ++s) a += Ji[s * 6 + r] * WJ[s * 6 + c]; atomic_add(D + r * 6 + c, a); }
-      for (int r = 0; r < 6; ++r) { double a = 0; for (int s = 0; s < 6; ++s) a += Ji[s * 6 + r] * We[s]; atomic_add(V.bvec + 6 * (size_t)ri + r, -a); }
-    }
-  } else if (e < sg.neo + sg.nel) {
-    const int k = sg.el0 + (e - sg.neo);
-    const int n = V.nEl;
-    const int pi = V.el_p[k], li = V.el_l[k];
-    const Pose Xi = load_pose(V.pose, pi);
-    const double* lp = V.lmk + (size_t)li * 4;
-    double err[3], Ji[18], Jl[9];
-    if (V.lm_kind[li] == VT_POINT) {
-      PointLin L;
-      point_error(Xi, Vec3{lp[0], lp[1], lp[2]},
-                  Vec3{V.el_z[0 * (size_t)n + k], V.el_z[1 * (size_t)n + k], V.el_z[2 * (size_t)n + k]}, L);
-      point_jacobians(L, Ji, Jl);
-      err[0] = L.e[0]; err[1] = L.e[1]; err[2] = L.e[2];
-    } else {
-      const Plane pw{{lp[0], lp[1], lp[2]}, lp[3]};
-      const Plane z{{V.el_z[0 * (size_t)n + k], V.el_z[1 * (size_t)n + k], V.el_z[2 * (size_t)n + k]}, V.el_z[3 * (size_t)n + k]};
-      plane_error(Xi, pw, z, err);
-      plane_jacobians(Xi, pw, z, Ji, Jl);
-    }
-    double W[9];
-    load_sym3(V.el_w, n, k, W);
-    double We[3], WJi[18], WJl[9];
-    for (int r = 0; r < 3; ++r) {
-      We[r] = W[r * 3 + 0] * err[0] + W[r * 3 + 1] * err[1] + W[r * 3 + 2] * err[2];
-      for (int c = 0; c < 6; ++c) WJi[r * 6 + c] = W[r * 3 + 0] * Ji[c] + W[r * 3 + 1] * Ji[6 + c] + W[r * 3 + 2] * Ji[12 + c];
-      for (int c = 0; c < 3; ++c) WJl[r * 3 + c] = W[r * 3 + 0] * Jl[c] + W[r * 3 + 1] * Jl[3 + c] + W[r * 3 + 2] * Jl[6 + c];
-    }
-    const int rp = V.pose_row[pi], rl = V.lm_row[li];
-    if (rp >= 0) {
-      double* D = V.Hpp_diag + (size_t)rp * 36;
-      for (int r = 0; r < 6; ++r) {
-        for (int c = 0; c < 6; ++c) atomic_add(D + r * 6 + c, Ji[r] * WJi[c] + Ji[6 + r] * WJi[6 + c] + Ji[12 + r] * WJi[12 + c]);
-        atomic_add(V.bvec + 6 * (size_t)rp + r, -(Ji[r] * We[0] + Ji[6 + r] * We[1] + Ji[12 + r] * We[2]));
-      }
-    }
-    if (rl >= 0) {
-      double* D = V.Hll_diag + (size_t)rl * 9;
-      for (int r = 0; r < 3; ++r) {
-        for (int c = 0; c < 3; ++c) atomic_add(D + r * 3 + c, Jl[r] * WJl[c] + Jl[3 + r] * WJl[3 + c] + Jl[6 + r] * WJl[6 + c]);
-        atomic_add(V.bvec + 6 * (size_t)V.nPr + 3 * (size_t)rl + r, -(Jl[r] * We[0] + Jl[3 + r] * We[1] + Jl[6 + r] * We[2]));
-      }
-    }
-    const int blk = decode_blk(V.el_blk[k]);
-    if (blk >= 0) {
-      double* O = V.Hpl + (size_t)blk * 18;
-      for (int r = 0; r < 6; ++r)
-        for (int c = 0; c < 3; ++c) atomic_add(O + r * 3 + c, Ji[r] * WJl[c] + Ji[6 + r] * WJl[3 + c] + Ji[12 + r] * WJl[6 + c]);
-    }
-  }
-}
-
-// zero H and b of active graphs (variant A needs a cleared accumulator)
-__global__ void k_zero_active(BatchView V) {
-  const int g = blockIdx.y;
-  if (!V.lm[g].active) return;
-  // Whole-batch clear is done with hipMemsetAsync when every graph is active; this kernel handles
-  // the diagonal blocks + b of one graph (off-diagonal blocks are cleared via the edge lists).
-  const GraphSeg sg = V.seg[g];
-  const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  const int np = sg.nprow * 36, nl = sg.nlrow * 9, nb = sg.nprow * 6 + sg.nlrow * 3;
-  if (t < np) V.Hpp_diag[(size_t)sg.prow0 * 36 + t] = 0;
-  else if (t < np + nl) V.Hll_diag[(size_t)sg.lrow0 * 9 + (t - np)] = 0;
-  else if (t < np + nl + nb) {
-    const int u = t - np - nl;
-    if (u < sg.nprow * 6) V.bvec[(size_t)sg.prow0 * 6 + u] = 0;
-    else V.bvec[(size_t)V.nPr * 6 + (size_t)sg.lrow0 * 3 + (u - sg.nprow * 6)] = 0;
-  }
-}
-__global__ void k_zero_offdiag(BatchView V) {
-  const int g = blockIdx.y;
-  if (!V.lm[g].active) return;
-  const GraphSeg sg = V.seg[g];
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e < sg.neo) {
-    const int blk = decode_blk(V.eo_blk[sg.eo0 + e]);
-    if (blk >= 0) { double* O = V.Hpp_off + (size_t)(blk >> 1) * 36; for (int k = 0; k < 36; ++k) O[k] = 0; }
-  } else if (e < sg.neo + sg.nel) {
-    const int blk = decode_blk(V.el_blk[sg.el0 + e - sg.neo]);
-    if (blk >= 0) { double* O = V.Hpl + (size_t)blk * 18; for (int k = 0; k < 18; ++k) O[k] = 0; }
-  }
-}
-
-// ---- Jacobian build, variant B (default): gather form, deterministic, no atomics ----------------
-// One 256-thread workgroup per tile of consecutive pose rows (<= kTileSlots incident-edge slots).
-// Phase A: a group of 8 lanes evaluates one (row, edge) slot; lane r (< 6) owns column r of the
-//   Jacobians and row r of the products.  W*J is exchanged through a per-group LDS scratch; the
-//   off-diagonal block owned by the slot is written straight to HBM (288 / 144 contiguous bytes per
-//   group), the diagonal/b contribution goes to LDS.
-// Phase B: per output scalar, a fixed-order sum over the row's slots -> Hpp_diag, b.
 __device__ __forceinline__ Pose load_meas_pose(const double* z, int n, int k) {
   return Pose{{z[0 * (size_t)n + k], z[1 * (size_t)n + k], z[2 * (size_t)n + k]},
               {z[3 * (size_t)n + k], z[4 * (size_t)n + k], z[5 * (size_t)n + k], z[6 * (size_t)n + k]}};
 }
-
-template <bool PL>
-__global__ __launch_bounds__(256) void k_linearize_rows(BatchView V) {
-  __shared__ double contrib[kTileSlots * 42];   // [slot][r][7]: D row r (6) + b_r
-  __shared__ double scratch[32 * 72];           // per group: WJs[6][6], WJo[6][6]
-  const int tile = blockIdx.x;
-  const int row0 = V.tile_row0[tile], row1 = V.tile_row1[tile];
-  const int g = V.prow_graph[row0];
-  if (!V.lm[g].active) return;
-  const int slot0 = V.pslot_ptr[row0], slot1 = V.pslot_ptr[row1];
-  const int nslots = slot1 - slot0;
-  const int group = threadIdx.x >> 3, r = threadIdx.x & 7;
-  double* sc = scratch + group * 72;
-  const int rounds = (nslots + 31) >> 5;
-  for (int round = 0; round < rounds; ++round) {
-    const int sl = round * 32 + group;           // slot index inside the tile
-    const bool live = sl < nslots && r < 6;
-    int kind = 0, e = 0;
-    double self[6], other[6], We[6];
-    int blk = -1;
-    bool owner = false;
-#pragma unroll
-    for (int q = 0; q < 6; ++q) { self[q] = 0; other[q] = 0; We[q] = 0; }
-    if (live) {
-      kind = V.pslot_kind[slot0 + sl];
-      e = V.pslot_edge[slot0 + sl];
-      if (kind < 2) {
-        const int n = V.nEo;
-        Se3Lin L;
-        se3_error(load_pose(V.pose, V.eo_i[e]), load_pose(V.pose, V.eo_j[e]), load_meas_pose(V.eo_z, n, e), L);
-        L.Re = qmat(L.qe);
-        double ci[6], cj[6];
-        se3_Ji_col(L, r, ci);
-        se3_Jj_col(L, r, cj);
-        blk = V.eo_blk[e];
-        owner = (kind == 0) && blk >= 0;
-#pragma unroll
-        for (int q = 0; q < 6; ++q) { self[q] = kind == 0 ? ci[q] : cj[q]; other[q] = kind == 0 ? cj[q] : ci[q]; }
-        double W[36];
-        load_sym6(V.eo_w, n, e, W);
-#pragma unroll
-        for (int a = 0; a < 6; ++a) {
-          double ws = 0, wo = 0, we = 0;
-#pragma unroll
-          for (int q = 0; q < 6; ++q) { ws += W[a * 6 + q] * self[q]; wo += W[a * 6 + q] * other[q]; we += W[a * 6 + q] * L.e[q]; }
-          sc[a * 6 + r] = ws; sc[36 + a * 6 + r] = wo; We[a] = we;
-        }
-      } else {
-        const int n = V.nEl;
-        const int li = V.el_l[e];
-        const Pose Xi = load_pose(V.pose, V.el_p[e]);
-        const double* lp = V.lmk + (size_t)li * 4;
-        double err[3], jl[3];   // jl: column r of Jl (lanes r < 3)
-        jl[0] = jl[1] = jl[2] = 0;
-        if (!PL || V.lm_kind[li] == VT_POINT) {
-          PointLin L;
-          point_error(Xi, Vec3{lp[0], lp[1], lp[2]}, Vec3{V.el_z[0 * (size_t)n + e], V.el_z[1 * (size_t)n + e], V.el_z[2 * (size_t)n + e]}, L);
-          err[0] = L.e[0]; err[1] = L.e[1]; err[2] = L.e[2];
-          // Ji = [-I | 2[pc]x], column r
-          const double px = L.pc.x, py = L.pc.y, pz = L.pc.z;
-          if (r == 0) { self[0] = -1; } else if (r == 1) { self[1] = -1; } else if (r == 2) { self[2] = -1; }
-          else if (r == 3) { self[1] = 2 * pz; self[2] = -2 * py; }
-          else if (r == 4) { self[0] = -2 * pz; self[2] = 2 * px; }
-          else { self[0] = 2 * py; self[1] = -2 * px; }
-          if (r < 3) {  // Jl = R^T: column r = row r of R
-            jl[0] = pick3(r, L.R.m[0], L.R.m[3], L.R.m[6]); jl[1] = pick3(r, L.R.m[1], L.R.m[4], L.R.m[7]); jl[2] = pick3(r, L.R.m[2], L.R.m[5], L.R.m[8]);
-          }
-        } else {
-          const Plane pw{{lp[0], lp[1], lp[2]}, lp[3]};
-          const Plane z{{V.el_z[0 * (size_t)n + e], V.el_z[1 * (size_t)n + e], V.el_z[2 * (size_t)n + e]}, V.el_z[3 * (size_t)n + e]};
-          plane_error(Xi, pw, z, err);
-          const double delta = 1e-9, scalar = 1.0 / (2 * delta);
-          double dv[6], ep[3], em[3];
-#pragma unroll
-          for (int q = 0; q < 6; ++q) dv[q] = q == r ? delta : 0.0;
-          plane_error(se3_oplus(Xi, dv), pw, z, ep);
-#pragma unroll
-          for (int q = 0; q < 6; ++q) dv[q] = q == r ? -delta : 0.0;
-          plane_error(se3_oplus(Xi, dv), pw, z, em);
-          self[0] = scalar * (ep[0] - em[0]); self[1] = scalar * (ep[1] - em[1]); self[2] = scalar * (ep[2] - em[2]);
-          if (r < 3) {
-            double d3[3];
-#pragma unroll
-            for (int q = 0; q < 3; ++q) d3[q] = q == r ? delta : 0.0;
-            plane_error(Xi, pl_oplus(pw, d3), z, ep);
-#pragma unroll
-            for (int q = 0; q < 3; ++q) d3[q] = q == r ? -delta : 0.0;
-            plane_error(Xi, pl_oplus(pw, d3), z, em);
-            jl[0] = scalar * (ep[0] - em[0]); jl[1] = scalar * (ep[1] - em[1]); jl[2] = scalar * (ep[2] - em[2]);
-          }
-        }
-        blk = V.el_blk[e];
-        owner = blk >= 0;
-        double W[9];
-        load_sym3(V.el_w, n, e, W);
-#pragma unroll
-        for (int a = 0; a < 3; ++a) {
-          sc[a * 6 + r] = W[a * 3 + 0] * self[0] + W[a * 3 + 1] * self[1] + W[a * 3 + 2] * self[2];       // (W Ji)[a][r]
-          if (r < 3) sc[36 + a * 3 + r] = W[a * 3 + 0] * jl[0] + W[a * 3 + 1] * jl[1] + W[a * 3 + 2] * jl[2];  // (W Jl)[a][r]
-          We[a] = W[a * 3 + 0] * err[0] + W[a * 3 + 1] * err[1] + W[a * 3 + 2] * err[2];
-        }
-      }
-    }
-    __syncthreads();
-    if (live) {
-      double* out = contrib + sl * 42 + r * 7;
-      if (kind < 2) {
-#pragma unroll
-        for (int c = 0; c < 6; ++c) {
-          double d = 0;
-#pragma unroll
-          for (int q = 0; q < 6; ++q) d += self[q] * sc[q * 6 + c];
-          out[c] = d;
-        }
-        double bb = 0;
-#pragma unroll
-        for (int q = 0; q < 6; ++q) bb += self[q] * We[q];
-        out[6] = -bb;
-        if (owner) {
-          double* O = V.Hpp_off + (size_t)(blk >> 1) * 36 + r * 6;
-          if (!(blk & 1)) {   // stored [row_i][row_j]: row r of Ji^T W Jj
-#pragma unroll
-            for (int c = 0; c < 6; ++c) { double d = 0;
-#pragma unroll
-              for (int q = 0; q < 6; ++q) d += self[q] * sc[36 + q * 6 + c];
-              O[c] = d; }
-          } else {            // stored [row_j][row_i]: row r of Jj^T W Ji
-#pragma unroll
-            for (int c = 0; c < 6; ++c) { double d = 0;
-#pragma unroll
-              for (int q = 0; q < 6; ++q) d += other[q] * sc[q * 6 + c];
-              O[c] = d; }
-          }
-        }
-      } else {
-#pragma unroll
-        for (int c = 0; c < 6; ++c) out[c] = self[0] * sc[0 * 6 + c] + self[1] * sc[1 * 6 + c] + self[2] * sc[2 * 6 + c];
-        out[6] = -(self[0] * We[0] + self[1] * We[1] + self[2] * We[2]);
-        if (owner) {
-          double* O = V.Hpl + (size_t)blk * 18 + r * 3;
-#pragma unroll
-          for (int c = 0; c < 3; ++c) O[c] = self[0] * sc[36 + 0 * 3 + c] + self[1] * sc[36 + 1 * 3 + c] + self[2] * sc[36 + 2 * 3 + c];
-        }
-      }
-    }
-    __syncthreads();
-  }
-  // phase B: fixed-order sums per output scalar
-  const int nrows = row1 - row0;
-  for (int t = threadIdx.x; t < nrows * 42; t += 256) {
-    const int lr = t / 42, rem = t - lr * 42;
-    const int rr = rem / 7, k = rem - rr * 7;
-    const int row = row0 + lr;
-    const int s0 = V.pslot_ptr[row] - slot0, s1 = V.pslot_ptr[row + 1] - slot0;
-    double acc = 0;
-    for (int s = s0; s < s1; ++s) acc += contrib[s * 42 + rr * 7 + k];
-    if (k < 6) V.Hpp_diag[(size_t)row * 36 + rr * 6 + k] = acc;
-    else V.bvec[(size_t)row * 6 + rr] = acc;
-  }
-}
-
-// ---- Jacobian build, variant C (default): one 8-lane group per pose row ------------------------
-// Lane c (< 6) of a group owns column c of the Jacobians and column c of every product of its row:
-//   D[:,c] = Js^T (W Js[:,c]),   Off[:,c] = Js^T (W Jo[:,c]),   b_c = -Js[:,c] . (W e)
-// so the only data a lane needs from its neighbours is the 6x6 (3x6) block Js itself.  It is exchanged
-// through a 288-byte per-group LDS scratch with 16-byte accesses (3 stores + 9 broadcast loads per
-// lane, wave-synchronous, no barriers).  The diagonal block / b accumulate in registers and are
-// written once (rows of a wave are consecutive -> coalesced); off-diagonal blocks are written by the
-// owner slot.  Slot records are fetched lane-parallel (one latency per 8 slots).
 struct alignas(16) D2 { double a, b; };
-__device__ __forceinline__ void exch_store6(double* scr, int c, const double v[6]) {
-  D2* p = reinterpret_cast<D2*>(scr + c * 6);
-  p[0] = D2{v[0], v[1]}; p[1] = D2{v[2], v[3]}; p[2] = D2{v[4], v[5]};
-}
-__device__ __forceinline__ void exch_load_row(const double* scr, int a, double row[6]) {
-  const D2* p = reinterpret_cast<const D2*>(scr + a * 6);
-  const D2 v0 = p[0], v1 = p[1], v2 = p[2];
-  row[0] = v0.a; row[1] = v0.b; row[2] = v1.a; row[3] = v1.b; row[4] = v2.a; row[5] = v2.b;
-}
-// y = W x for the symmetric 6x6 W given by its 21 upper-triangular entries (row-major order)
-__device__ __forceinline__ void sym6_mul(const double u[21], const double x[6], double y[6]) {
-#pragma unroll
-  for (int a = 0; a < 6; ++a) y[a] = 0;
-  int k = 0;
-#pragma unroll
-  for (int r = 0; r < 6; ++r)
-#pragma unroll
-    for (int cc = r; cc < 6; ++cc) {
-      y[r] += u[k] * x[cc];
-      if (cc != r) y[cc] += u[k] * x[r];
-      ++k;
-    }
-}
-__device__ __forceinline__ void exch_load36(const double* scr, double Jt[36]) {
-  const D2* p = reinterpret_cast<const D2*>(scr);
-#pragma unroll
-  for (int k = 0; k < 18; ++k) { const D2 v = p[k]; Jt[2 * k] = v.a; Jt[2 * k + 1] = v.b; }
-}
 
-template <bool PL>
-__global__ __launch_bounds__(256, 2) void k_linearize_rows2(BatchView V) {
-  __shared__ alignas(16) double scratch[32 * 36];
-  __shared__ double hand[32 * 6 * 7];   // j-side contribution handed over by the row above: [local row][c][D(6), b]
-  bool receives = false;
-  const int row = blockIdx.x * 32 + (threadIdx.x >> 3);
-  const int c = threadIdx.x & 7;
-  const int gbase = (threadIdx.x & 63) & ~7;   // first lane of this group inside the wave
-  double* scr = scratch + (threadIdx.x >> 3) * 36;
-  const bool row_ok = row < V.nPr && V.lm[V.prow_graph[row < V.nPr ? row : 0]].active;
-  const bool lane_ok = row_ok && c < 6;
-  const int s0 = row_ok ? V.pslot_ptr[row] : 0, s1 = row_ok ? V.pslot_ptr[row + 1] : 0;
-  int nmax = s1 - s0;   // all groups of a wave iterate to the longest slot list among them (record shuffles)
-#pragma unroll
-  for (int o = 8; o < 64; o <<= 1) nmax = max(nmax, __shfl_xor(nmax, o, 64));
-  double D[6] = {0, 0, 0, 0, 0, 0};
-  double bacc = 0;
-  int4 rec = make_int4(0, 0, 0, 0);
-  for (int t = 0; t < nmax; ++t) {
-    if ((t & 7) == 0) {  // lane-parallel fetch of the next 8 slot records
-      const int s = s0 + t + c;
-      rec = s < s1 ? V.pslot_rec[s] : make_int4(0, -1, 0, 0);
-    }
-    const int src = gbase + (t & 7);
-    const int e = __shfl(rec.x, src, 64), kflags = __shfl(rec.y, src, 64), ia = __shfl(rec.z, src, 64), ib = __shfl(rec.w, src, 64);
-    const bool live = lane_ok && (s0 + t) < s1;
-    if (!live) continue;
-    const int kind = kflags & 15;
-    const bool provide = (kflags >> 4) & 1;
-    if (kind == 3) { receives = true; continue; }
-    if (kind < 2) {
-      const int n = V.nEo;
-      Se3Lin L;
-      se3_error(load_pose(V.pose, ia), load_pose(V.pose, ib), load_meas_pose(V.eo_z, n, e), L);
-      const int blk = kind == 0 ? V.eo_blk[e] : -1;
-      double self[6], other[6] = {0, 0, 0, 0, 0, 0};
-      if (kind == 0) { se3_Ji_col(L, c, self); } else { L.Re = qmat(L.qe); se3_Jj_col(L, c, self); }
-      double U[21];
-#pragma unroll
-      for (int k = 0; k < 21; ++k) U[k] = V.eo_w[(size_t)k * n + e];
-      double vs[6], We[6], vo[6] = {0, 0, 0, 0, 0, 0};
-      sym6_mul(U, self, vs);
-      sym6_mul(U, L.e, We);
-      const bool owner = blk >= 0;
-      const bool swapped = owner && (blk & 1);
-      if (owner || provide) {
-        L.Re = qmat(L.qe);
-        se3_Jj_col(L, c, other);
-        if (!swapped || provide) sym6_mul(U, other, vo);
-      }
-      double bb = 0;
-#pragma unroll
-      for (int q = 0; q < 6; ++q) bb += self[q] * We[q];
-      bacc -= bb;
-      exch_store6(scr, c, self);
-      double* O = owner ? V.Hpp_off + (size_t)(blk >> 1) * 36 : nullptr;
-#pragma unroll
-      for (int a = 0; a < 6; ++a) {   // row a of Js^T = column a of Js
-        double jr[6];
-        exch_load_row(scr, a, jr);
-        double d = 0, o = 0;
-#pragma unroll
-        for (int q = 0; q < 6; ++q) { d += jr[q] * vs[q]; o += jr[q] * vo[q]; }
-        D[a] += d;
-        if (owner && !swapped) O[a * 6 + c] = o;   // stored [row_i][row_j] = Ji^T W Jj: column c = Ji^T (W Jj[:,c])
-      }
-      if (swapped || provide) {       // needs the columns of Jj
-        exch_store6(scr, c, other);
-        double* hd = hand + (((kflags >> 8) & 31) * 6 + c) * 7;
-#pragma unroll
-        for (int a = 0; a < 6; ++a) {
-          double jr[6];
-          exch_load_row(scr, a, jr);
-          double o = 0, dj = 0;
-#pragma unroll
-          for (int q = 0; q < 6; ++q) { o += jr[q] * vs[q]; dj += jr[q] * vo[q]; }
-          if (swapped) O[a * 6 + c] = o;   // stored [row_j][row_i] = Jj^T W Ji: column c = Jj^T (W Ji[:,c])
-          if (provide) hd[a] = dj;         // D_jj[:,c] = Jj^T (W Jj[:,c])
-        }
-        if (provide) {
-          double bj = 0;
-#pragma unroll
-          for (int q = 0; q < 6; ++q) bj += other[q] * We[q];
-          hd[6] = -bj;
-        }
-      }
-    } else {
-      const int n = V.nEl;
-      const Pose Xi = load_pose(V.pose, ia);
-      const double* lp = V.lmk + (size_t)ib * 4;
-      const double zz[4] = {V.el_z[0 * (size_t)n + e], V.el_z[1 * (size_t)n + e], V.el_z[2 * (size_t)n + e], PL ? V.el_z[3 * (size_t)n + e] : 0.0};
-      double err[3], self[6] = {0, 0, 0, 0, 0, 0}, jl[3] = {0, 0, 0};
-      if (!PL || V.lm_kind[ib] == VT_POINT) {
-        PointLin L;
-        point_error(Xi, Vec3{lp[0], lp[1], lp[2]}, Vec3{zz[0], zz[1], zz[2]}, L);
-        err[0] = L.e[0]; err[1] = L.e[1]; err[2] = L.e[2];
-        const double px = L.pc.x, py = L.pc.y, pz = L.pc.z;
-        if (c == 0) { self[0] = -1; } else if (c == 1) { self[1] = -1; } else if (c == 2) { self[2] = -1; }
-        else if (c == 3) { self[1] = 2 * pz; self[2] = -2 * py; }
-        else if (c == 4) { self[0] = -2 * pz; self[2] = 2 * px; }
-        else { self[0] = 2 * py; self[1] = -2 * px; }
-        if (c < 3) { jl[0] = pick3(c, L.R.m[0], L.R.m[3], L.R.m[6]); jl[1] = pick3(c, L.R.m[1], L.R.m[4], L.R.m[7]); jl[2] = pick3(c, L.R.m[2], L.R.m[5], L.R.m[8]); }
-      } else {
-        const Plane pw{{lp[0], lp[1], lp[2]}, lp[3]};
-        const Plane z{{zz[0], zz[1], zz[2]}, zz[3]};
-        plane_error(Xi, pw, z, err);
-        const double delta = 1e-9, scalar = 1.0 / (2 * delta);
-        double dv[6], ep[3], em[3];
-#pragma unroll
-        for (int q = 0; q < 6; ++q) dv[q] = q == c ? delta : 0.0;
-        plane_error(se3_oplus(Xi, dv), pw, z, ep);
-#pragma unroll
-        for (int q = 0; q < 6; ++q) dv[q] = q == c ? -delta : 0.0;
-        plane_error(se3_oplus(Xi, dv), pw, z, em);
-        self[0] = scalar * (ep[0] - em[0]); self[1] = scalar * (ep[1] - em[1]); self[2] = scalar * (ep[2] - em[2]);
-        if (c < 3) {
-          double d3[3];
-#pragma unroll
-          for (int q = 0; q < 3; ++q) d3[q] = q == c ? delta : 0.0;
-          plane_error(Xi, pl_oplus(pw, d3), z, ep);
-#pragma unroll
-          for (int q = 0; q < 3; ++q) d3[q] = q == c ? -delta : 0.0;
-          plane_error(Xi, pl_oplus(pw, d3), z, em);
-          jl[0] = scalar * (ep[0] - em[0]); jl[1] = scalar * (ep[1] - em[1]); jl[2] = scalar * (ep[2] - em[2]);
-        }
-      }
-      double W[9];
-      load_sym3(V.el_w, n, e, W);
-      double vs[3], vl[3], We[3];
-#pragma unroll
-      for (int a = 0; a < 3; ++a) {
-        vs[a] = W[a * 3 + 0] * self[0] + W[a * 3 + 1] * self[1] + W[a * 3 + 2] * self[2];   // W Ji[:,c]
-        vl[a] = W[a * 3 + 0] * jl[0] + W[a * 3 + 1] * jl[1] + W[a * 3 + 2] * jl[2];         // W Jl[:,c], c < 3
-        We[a] = W[a * 3 + 0] * err[0] + W[a * 3 + 1] * err[1] + W[a * 3 + 2] * err[2];
-      }
-      exch_store6(scr, c, self);   // rows 3..5 of the padded column are zero
-      bacc -= self[0] * We[0] + self[1] * We[1] + self[2] * We[2];
-      const int blk = V.el_blk[e];
-      double* O = (blk >= 0 && c < 3) ? V.Hpl + (size_t)blk * 18 : nullptr;   // Hpl = Ji^T W Jl (6 x 3): column c
-#pragma unroll
-      for (int a = 0; a < 6; ++a) {
-        double jr[6];
-        exch_load_row(scr, a, jr);
-        D[a] += jr[0] * vs[0] + jr[1] * vs[1] + jr[2] * vs[2];
-        if (O) O[a * 3 + c] = jr[0] * vl[0] + jr[1] * vl[1] + jr[2] * vl[2];
-      }
-    }
-  }
-  __syncthreads();
-  if (receives) {  // contribution of the edge (row-1, row), evaluated once by the row above
-    const double* hd = hand + ((row & 31) * 6 + c) * 7;
-#pragma unroll
-    for (int a = 0; a < 6; ++a) D[a] += hd[a];
-    bacc += hd[6];
-  }
-  if (lane_ok) {   // D is symmetric: column c is stored as row c (48 contiguous bytes per lane)
-    double* P = V.Hpp_diag + (size_t)row * 36 + c * 6;
-#pragma unroll
-    for (int a = 0; a < 6; ++a) P[a] = D[a];
-    V.bvec[(size_t)row * 6 + c] = bacc;
-  }
-}
-
-// ---- Jacobian build, variant D: one THREAD per pose row ------------------------------------------
+// ---- Jacobian build (gather form, deterministic, no atomics): one THREAD per pose row ---------------
 // No redundancy across lanes: a thread evaluates each incident edge once, keeps the 6x6 Jacobian of
 // its own vertex in registers, streams the other vertex's columns for the off-diagonal block it
 // owns, and accumulates the symmetric diagonal block (21 values) + b (6) in a thread-private LDS
@@ -605,7 +111,7 @@ __global__ __launch_bounds__(kRowThreads) void k_linearize_rowthread(BatchView V
   const int tid = threadIdx.x;
   const int row = blockIdx.x * kRowThreads + tid;
   if (row >= V.nPr) return;
-  if (!V.lm[V.prow_graph[row]].active) return;
+  if (!V.lm[V.prow_graph[row]].lin) return;
 #pragma unroll
   for (int k = 0; k < 27; ++k) accD[k][tid] = 0.0;
   const int s0 = V.pslot_ptr[row], s1 = V.pslot_ptr[row + 1];
@@ -802,7 +308,7 @@ __global__ __launch_bounds__(256) void k_linearize_lm_rows(BatchView V) {
 #pragma unroll
   for (int q = 0; q < 12; ++q) acc[q] = 0;
   bool live = l < V.nLr;
-  if (live && !V.lm[V.lrow_graph[l]].active) live = false;
+  if (live && !V.lm[V.lrow_graph[l]].lin) live = false;
   if (live) {
     const int li = V.lrow_lm[l];
     const double* lp = V.lmk + (size_t)li * 4;
@@ -878,7 +384,7 @@ __global__ void k_linearize_dups(BatchView V) {
     for (; d < V.nDupEo && (d == t || (decode_blk(V.eo_blk[V.dup_eo[d]]) >> 1) == (decode_blk(V.eo_blk[V.dup_eo[t]]) >> 1)); ++d) {
     const int k = V.dup_eo[d];
     const int pi = V.eo_i[k], pj = V.eo_j[k];
-    if (!V.lm[V.prow_graph[V.pose_row[pi]]].active) continue;
+    if (!V.lm[V.prow_graph[V.pose_row[pi]]].lin) continue;
     Se3Lin L;
     se3_error(load_pose(V.pose, pi), load_pose(V.pose, pj), load_meas_pose(V.eo_z, V.nEo, k), L);
     double Ji[36], Jj[36], W[36], WJ[36];
@@ -898,7 +404,7 @@ __global__ void k_linearize_dups(BatchView V) {
     for (; d < V.nDupEl && (d == t || decode_blk(V.el_blk[V.dup_el[d]]) == decode_blk(V.el_blk[V.dup_el[t]])); ++d) {
     const int k = V.dup_el[d];
     const int pi = V.el_p[k], li = V.el_l[k];
-    if (!V.lm[V.prow_graph[V.pose_row[pi]]].active) continue;
+    if (!V.lm[V.prow_graph[V.pose_row[pi]]].lin) continue;
     const Pose Xi = load_pose(V.pose, pi);
     const double* lp = V.lmk + (size_t)li * 4;
     const int n = V.nEl;
@@ -947,7 +453,7 @@ __device__ __forceinline__ RowRef row_ref(const BatchView& V, const GraphSeg& sg
 __global__ __launch_bounds__(kRowChunk) void k_maxdiag(BatchView V, double* __restrict__ part) {
   __shared__ double red[kRowChunk / 64];
   const int g = blockIdx.y;
-  if (!V.lm[g].active) return;
+  if (!V.lm[g].lin || V.lm[g].iter != 0) return;   // lambda is initialised from the first linearisation only
   const GraphSeg sg = V.seg[g];
   if (blockIdx.x * kRowChunk >= sg.nprow * 6 + sg.nlrow * 3) return;
   const RowRef R = row_ref(V, sg, blockIdx.x * kRowChunk + threadIdx.x);
@@ -960,29 +466,37 @@ __global__ __launch_bounds__(kRowChunk) void k_maxdiag(BatchView V, double* __re
 __device__ __forceinline__ int row_chunks(const GraphSeg& sg) { return (sg.nprow * 6 + sg.nlrow * 3 + kRowChunk - 1) / kRowChunk; }
 __device__ __forceinline__ int edge_chunks(const GraphSeg& sg) { return (sg.neo + sg.nel + kEdgeChunk - 1) / kEdgeChunk; }
 
-// one wave per graph: start of an LM iteration
-__global__ void k_lm_begin_iter(BatchView V, const double* __restrict__ part_maxdiag, int it) {
+// One wave per graph, once per step.  A *step* is one damping trial: graphs flagged `lin` have just been re-linearised and
+// start a new LM iteration (q = 0; lambda = tau * max diag on the very first one), the others are retrying the
+// iteration they are in with the lambda k_lm_control raised.  The host never needs to know which is which.
+__global__ void k_lm_begin_step(BatchView V, const double* __restrict__ part_maxdiag) {
   const int g = blockIdx.x;
   LmState& S = V.lm[g];
   if (!S.active) return;
-  if (it == 0) {
-    const int n = row_chunks(V.seg[g]);
-    double m = 0;
-    for (int k = threadIdx.x; k < n; k += 64) m = fmax(m, part_maxdiag[(size_t)g * V.maxRowChunks + k]);
-    for (int o = 32; o > 0; o >>= 1) m = fmax(m, __shfl_xor(m, o, 64));
-    if (threadIdx.x == 0) { S.max_diag = m; S.lambda = 1e-5 * m; S.nu = 2.0; }
+  if (S.lin) {
+    if (S.iter == 0) {
+      const int n = row_chunks(V.seg[g]);
+      double m = 0;
+      for (int k = threadIdx.x; k < n; k += 64) m = fmax(m, part_maxdiag[(size_t)g * V.maxRowChunks + k]);
+      for (int o = 32; o > 0; o >>= 1) m = fmax(m, __shfl_xor(m, o, 64));
+      if (threadIdx.x == 0) { S.max_diag = m; S.lambda = 1e-5 * m; S.nu = 2.0; }
+    }
+    if (threadIdx.x == 0) { S.q = 0; S.rho = 0; S.in_trial = 1; S.lin = 0; }
   }
-  if (threadIdx.x == 0) { S.q = 0; S.rho = 0; S.in_trial = 1; S.accept = 0; }
+  if (threadIdx.x == 0) S.accept = 0;
 }
 
-// initial chi2 -> cur_chi / chi_before
-__global__ void k_lm_init(BatchView V, const double* __restrict__ part_chi) {
+// initial chi2 -> cur_chi / chi_before.  Graphs with fewer than 10 edges are not optimised (graph_slam.cpp:184-186).
+__global__ void k_lm_init(BatchView V, const double* __restrict__ part_chi, int min_edges) {
   const int g = blockIdx.x;
   LmState& S = V.lm[g];
-  const double c = wave_sum_partials(part_chi + (size_t)g * V.maxEdgeChunks, edge_chunks(V.seg[g]));
+  const GraphSeg sg = V.seg[g];
+  const double c = wave_sum_partials(part_chi + (size_t)g * V.maxEdgeChunks, edge_chunks(sg));
   if (threadIdx.x == 0) {
+    const bool few = sg.neo + sg.nel < min_edges;
     S.cur_chi = c; S.chi_before = c; S.iter = 0; S.trials = 0; S.pcg_iters = 0;
-    S.status = 0; S.active = 1; S.in_trial = 0; S.accept = 0; S.lambda = 0; S.nu = 2; S.rho = 0; S.q = 0; S.solve_failed = 0;
+    S.status = few ? -5 : 0; S.active = few ? 0 : 1; S.lin = few ? 0 : 1;
+    S.in_trial = 0; S.accept = 0; S.lambda = 0; S.nu = 2; S.rho = 0; S.q = 0; S.solve_failed = 0;
   }
 }
 
@@ -1300,12 +814,12 @@ __global__ void k_lm_control(BatchView V, const double* __restrict__ part_chi, i
   }
   S.q += 1;
   const int again = (rho < 0 && S.q < 10);
-  S.in_trial = again;
-  if (again) atomicOr(&V.flags[0], 1);
-  else {
+  S.in_trial = again;   // a rejected trial is repeated at the next step with the raised lambda
+  if (!again) {
     S.iter += 1;
     if (S.q == 10 || rho == 0) { S.status = 1; S.active = 0; }
     else if (S.iter >= max_iters) { S.status = 0; S.active = 0; }
+    else S.lin = 1;     // next step: new linearisation, new iteration
   }
 }
 
@@ -1323,10 +837,6 @@ __global__ __launch_bounds__(256) void k_commit(BatchView V) {
     const int li = V.lrow_lm[l];
     for (int k = 0; k < 4; ++k) V.lmk[(size_t)li * 4 + k] = V.lmk_trial[(size_t)li * 4 + k];
   }
-}
-__global__ void k_clear_accept(BatchView V) {
-  const int g = blockIdx.x * blockDim.x + threadIdx.x;
-  if (g < V.B) V.lm[g].accept = 0;
 }
 __global__ void k_set_trial_all(BatchView V, double lambda) {  // used by the solve() hook
   const int g = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1349,9 +859,11 @@ static inline uint64_t pair_key(int a, int b) { return ((uint64_t)(uint32_t)a <<
 
 // Compile host graphs into the device-resident batch layout (g2o initializeOptimization +
 // BlockSolver::buildStructure analogue; symbolic work only).
-static int batch_build(Batch& b) {
-  SSLAM_HIP_TRY(hipSetDevice(b.device));
-  if (!b.stream) SSLAM_HIP_TRY(hipStreamCreateWithFlags(&b.stream, hipStreamNonBlocking));
+static int batch_build(Batch& b, bool host_only = false) {
+  if (!host_only) {
+    SSLAM_HIP_TRY(hipSetDevice(b.device));
+    if (!b.stream) SSLAM_HIP_TRY(hipStreamCreateWithFlags(&b.stream, hipStreamNonBlocking));
+  }
   const int B = (int)b.graphs.size();
   b.seg.assign(B, GraphSeg{});
   b.v2pose.assign(B, {}); b.v2lm.assign(B, {});
@@ -1500,6 +1012,11 @@ static int batch_build(Batch& b) {
   b.hpl_base = b.hpp_off_base + (int64_t)nPP * 36;
   const int64_t h_total = b.hpl_base + (int64_t)nPL * 18;
   if (h_total >= (int64_t)1 << 31) return set_error(SSLAM_ERR_INVALID, "batch too large: H has %lld doubles (int32 block offsets)", (long long)h_total);
+  if (host_only) {   // symbolic structure only (plan introspection on a box without a GPU)
+    memset(&b.V, 0, sizeof b.V);
+    b.V.B = B; b.V.nPr = nPr; b.V.nLr = nLr; b.V.h_total = h_total;
+    return 0;
+  }
   // adjacency (rows: pose rows then landmark rows)
   std::vector<std::vector<std::array<int, 3>>> adj(nPr + nLr);
   for (int i = 0; i < nPP; ++i) {
@@ -1644,48 +1161,16 @@ static int launch_check(const char* what) {
 static int batch_linearize(Batch& b) {
   ScopedTimer t(b, "linearize");
   const BatchView& V = b.V;
-  const int mode = b.graphs[0]->opt.deterministic;   // 1: per-row groups, 2: LDS tiles, 3: thread per row, 0: atomics
-  const bool gather = mode == 1 || mode == 3 || (mode == 2 && b.max_row_slots <= kTileSlots);
-  if (mode == 3) {
-    const int nblk = (V.nPr + kRowThreads - 1) / kRowThreads;
-    if (V.nPr > 0) {
-      if (b.has_planes) hipLaunchKernelGGL(k_linearize_rowthread<true>, dim3(nblk), dim3(kRowThreads), 0, b.stream, V);
-      else hipLaunchKernelGGL(k_linearize_rowthread<false>, dim3(nblk), dim3(kRowThreads), 0, b.stream, V);
-    }
-    if (V.nLr > 0) {
-      if (b.has_planes) hipLaunchKernelGGL(k_linearize_lm_rows<true>, dim3((V.nLr + 15) / 16), dim3(256), 0, b.stream, V);
-      else hipLaunchKernelGGL(k_linearize_lm_rows<false>, dim3((V.nLr + 15) / 16), dim3(256), 0, b.stream, V);
-    }
-    if (V.nDupEo + V.nDupEl > 0) hipLaunchKernelGGL(k_linearize_dups, dim3((std::max(V.nDupEo, V.nDupEl) + 63) / 64), dim3(64), 0, b.stream, V);
-    return launch_check("linearize");
+  const int nblk = (V.nPr + kRowThreads - 1) / kRowThreads;
+  if (V.nPr > 0) {
+    if (b.has_planes) hipLaunchKernelGGL(k_linearize_rowthread<true>, dim3(nblk), dim3(kRowThreads), 0, b.stream, V);
+    else hipLaunchKernelGGL(k_linearize_rowthread<false>, dim3(nblk), dim3(kRowThreads), 0, b.stream, V);
   }
-  if (gather && mode == 2) {
-    if (b.has_planes) { if (V.nTiles > 0) hipLaunchKernelGGL(k_linearize_rows<true>, dim3(V.nTiles), dim3(256), 0, b.stream, V); }
-    else { if (V.nTiles > 0) hipLaunchKernelGGL(k_linearize_rows<false>, dim3(V.nTiles), dim3(256), 0, b.stream, V); }
-    if (V.nLr > 0) {
-      if (b.has_planes) hipLaunchKernelGGL(k_linearize_lm_rows<true>, dim3((V.nLr + 15) / 16), dim3(256), 0, b.stream, V);
-      else hipLaunchKernelGGL(k_linearize_lm_rows<false>, dim3((V.nLr + 15) / 16), dim3(256), 0, b.stream, V);
-    }
-    if (V.nDupEo + V.nDupEl > 0) hipLaunchKernelGGL(k_linearize_dups, dim3((std::max(V.nDupEo, V.nDupEl) + 63) / 64), dim3(64), 0, b.stream, V);
-    return launch_check("linearize");
+  if (V.nLr > 0) {
+    if (b.has_planes) hipLaunchKernelGGL(k_linearize_lm_rows<true>, dim3((V.nLr + 15) / 16), dim3(256), 0, b.stream, V);
+    else hipLaunchKernelGGL(k_linearize_lm_rows<false>, dim3((V.nLr + 15) / 16), dim3(256), 0, b.stream, V);
   }
-  if (gather) {
-    // every H block and b entry is written exactly once per build: no clearing pass needed
-    if (b.has_planes) {
-      if (V.nPr > 0) hipLaunchKernelGGL(k_linearize_rows2<true>, dim3((V.nPr + 31) / 32), dim3(256), 0, b.stream, V);
-      if (V.nLr > 0) hipLaunchKernelGGL(k_linearize_lm_rows<true>, dim3((V.nLr + 15) / 16), dim3(256), 0, b.stream, V);
-    } else {
-      if (V.nPr > 0) hipLaunchKernelGGL(k_linearize_rows2<false>, dim3((V.nPr + 31) / 32), dim3(256), 0, b.stream, V);
-      if (V.nLr > 0) hipLaunchKernelGGL(k_linearize_lm_rows<false>, dim3((V.nLr + 15) / 16), dim3(256), 0, b.stream, V);
-    }
-    if (V.nDupEo + V.nDupEl > 0) hipLaunchKernelGGL(k_linearize_dups, dim3((std::max(V.nDupEo, V.nDupEl) + 63) / 64), dim3(64), 0, b.stream, V);
-    return launch_check("linearize");
-  }
-  const int per_graph_rows = V.maxRowChunks * kRowChunk;
-  // clear accumulators of the active graphs
-  hipLaunchKernelGGL(k_zero_active, dim3((per_graph_rows * 8 + 255) / 256, V.B), dim3(256), 0, b.stream, V);
-  hipLaunchKernelGGL(k_zero_offdiag, edge_grid(b), dim3(kEdgeChunk), 0, b.stream, V);
-  hipLaunchKernelGGL(k_linearize_atomic, edge_grid(b), dim3(kEdgeChunk), 0, b.stream, V);
+  if (V.nDupEo + V.nDupEl > 0) hipLaunchKernelGGL(k_linearize_dups, dim3((std::max(V.nDupEo, V.nDupEl) + 63) / 64), dim3(64), 0, b.stream, V);
   return launch_check("linearize");
 }
 
@@ -1733,6 +1218,7 @@ static int batch_chi2(Batch& b, const double* pose, const double* lmk, int mask_
   return launch_check("chi2");
 }
 
+constexpr int kStepChunk = 8;   // LM steps enqueued between two looks at the per-graph state
 static int batch_optimize(Batch& b, int max_iters, sslam_opt_stats* out) {
   SSLAM_HIP_TRY(hipSetDevice(b.device));
   const auto t0 = std::chrono::steady_clock::now();
@@ -1740,15 +1226,19 @@ static int batch_optimize(Batch& b, int max_iters, sslam_opt_stats* out) {
   int rc;
   if (!b.uploaded && (rc = batch_upload_estimates(b))) return rc;
   if ((rc = batch_chi2(b, V.pose, V.lmk, 0))) return rc;
-  hipLaunchKernelGGL(k_lm_init, dim3(V.B), dim3(64), 0, b.stream, V, b.d_part_e);
+  hipLaunchKernelGGL(k_lm_init, dim3(V.B), dim3(64), 0, b.stream, V, b.d_part_e, 10);
   std::vector<LmState> st(V.B);
-  for (int it = 0; it < max_iters; ++it) {
-    if ((rc = batch_linearize(b))) return rc;
-    if (it == 0) hipLaunchKernelGGL(k_maxdiag, row_grid(b), dim3(kRowChunk), 0, b.stream, V, b.d_part_m);
-    hipLaunchKernelGGL(k_lm_begin_iter, dim3(V.B), dim3(64), 0, b.stream, V, b.d_part_m, it);
-    for (int trial = 0; trial < 10; ++trial) {
-      SSLAM_HIP_TRY(hipMemsetAsync(V.flags, 0, sizeof(int), b.stream));
-      hipLaunchKernelGGL(k_clear_accept, dim3((V.B + 63) / 64), dim3(64), 0, b.stream, V);
+  // The LM control flow (accept / reject, retry with a larger lambda, terminate) lives on the device: the host enqueues
+  // generic steps in chunks and only looks at the per-graph state between chunks -- no synchronisation per trial.
+  // Every graph needs at least (max_iters - iter) more steps; rejected trials add steps, which later chunks supply.
+  long long budget = 10LL * std::max(max_iters, 0) + 8;    // hard bound: <= 10 trials per iteration
+  int need = max_iters;
+  while (need > 0 && budget > 0) {
+    const int chunk = (int)std::min<long long>(std::min(need, kStepChunk), budget);
+    for (int sidx = 0; sidx < chunk; ++sidx) {
+      if ((rc = batch_linearize(b))) return rc;
+      hipLaunchKernelGGL(k_maxdiag, row_grid(b), dim3(kRowChunk), 0, b.stream, V, b.d_part_m);
+      hipLaunchKernelGGL(k_lm_begin_step, dim3(V.B), dim3(64), 0, b.stream, V, b.d_part_m);
       if ((rc = batch_solve(b))) return rc;
       { ScopedTimer t(b, "oplus");
         hipLaunchKernelGGL(k_oplus, dim3(vert_blocks(b)), dim3(256), 0, b.stream, V, V.x); }
@@ -1756,17 +1246,13 @@ static int batch_optimize(Batch& b, int max_iters, sslam_opt_stats* out) {
       hipLaunchKernelGGL(k_scale, row_grid(b), dim3(kRowChunk), 0, b.stream, V, V.x);
       hipLaunchKernelGGL(k_lm_control, dim3(V.B), dim3(64), 0, b.stream, V, b.d_part_e, max_iters);
       hipLaunchKernelGGL(k_commit, dim3(vert_blocks(b)), dim3(256), 0, b.stream, V);
-      int again = 0;
-      SSLAM_HIP_TRY(hipMemcpyAsync(&again, V.flags, sizeof(int), hipMemcpyDeviceToHost, b.stream));
-      SSLAM_HIP_TRY(hipStreamSynchronize(b.stream));
-      b.harvest();
-      if (!again) break;
     }
+    budget -= chunk;
     SSLAM_HIP_TRY(hipMemcpyAsync(st.data(), V.lm, sizeof(LmState) * V.B, hipMemcpyDeviceToHost, b.stream));
     SSLAM_HIP_TRY(hipStreamSynchronize(b.stream));
-    bool any = false;
-    for (auto& s : st) any |= (s.active != 0);
-    if (!any) break;
+    b.harvest();
+    need = 0;
+    for (auto& q : st) if (q.active) need = std::max(need, max_iters - q.iter);
   }
   SSLAM_HIP_TRY(hipMemcpyAsync(st.data(), V.lm, sizeof(LmState) * V.B, hipMemcpyDeviceToHost, b.stream));
   SSLAM_HIP_TRY(hipStreamSynchronize(b.stream));
@@ -1780,7 +1266,7 @@ static int batch_optimize(Batch& b, int max_iters, sslam_opt_stats* out) {
     o.iterations = st[g].iter; o.trials = st[g].trials; o.status = st[g].status;
     o.chi2_before = st[g].chi_before; o.chi2_after = st[g].cur_chi; o.lambda = st[g].lambda;
     o.seconds = secs; o.solver_iterations = st[g].pcg_iters;
-    if (!std::isfinite(st[g].cur_chi)) { o.status = SSLAM_ERR_NUMERIC; worst = SSLAM_ERR_NUMERIC; }
+    if (st[g].status != SSLAM_ERR_TOO_FEW_EDGES && !std::isfinite(st[g].cur_chi)) { o.status = SSLAM_ERR_NUMERIC; worst = SSLAM_ERR_NUMERIC; }
   }
   if (worst) return set_error(worst, "non-finite chi2 after optimisation");
   return 0;
@@ -1918,8 +1404,7 @@ int sslam_graph_set_option(sslam_graph* h, const char* key, double value) {
   if (k == "solver") o.solver = (int)value;
   else if (k == "pcg_tol") o.pcg_tol = value;
   else if (k == "pcg_max_iters") o.pcg_max_iters = (int)value;
-  else if (k == "schur") o.schur = (int)value;
-  else if (k == "deterministic") o.deterministic = (int)value;
+  else if (k == "deterministic") { if (value == 0) return set_error(SSLAM_ERR_UNSUPPORTED, "the Jacobian build is always deterministic (gather form); the FP64-atomics variant was removed"); }
   else return set_error(SSLAM_ERR_INVALID, "unknown option '%s'", key);
   return 0;
 }
@@ -1948,7 +1433,7 @@ int sslam_graph_chi2(sslam_graph* h, double* chi2) {
   Batch& b = *h->batch;
   if ((rc = batch_upload_estimates(b))) return rc;
   if ((rc = batch_chi2(b, b.V.pose, b.V.lmk, 0))) return rc;
-  hipLaunchKernelGGL(k_lm_init, dim3(b.V.B), dim3(64), 0, b.stream, b.V, b.d_part_e);
+  hipLaunchKernelGGL(k_lm_init, dim3(b.V.B), dim3(64), 0, b.stream, b.V, b.d_part_e, 0);
   LmState s;
   SSLAM_HIP_TRY(hipMemcpyAsync(&s, b.V.lm, sizeof s, hipMemcpyDeviceToHost, b.stream));
   SSLAM_HIP_TRY(hipStreamSynchronize(b.stream));
@@ -1962,7 +1447,7 @@ static int do_linearize(sslam_graph* h) {
   Batch& b = *h->batch;
   if ((rc = batch_upload_estimates(b))) return rc;
   if ((rc = batch_chi2(b, b.V.pose, b.V.lmk, 0))) return rc;
-  hipLaunchKernelGGL(k_lm_init, dim3(b.V.B), dim3(64), 0, b.stream, b.V, b.d_part_e);
+  hipLaunchKernelGGL(k_lm_init, dim3(b.V.B), dim3(64), 0, b.stream, b.V, b.d_part_e, 0);
   if ((rc = batch_linearize(b))) return rc;
   SSLAM_HIP_TRY(hipStreamSynchronize(b.stream));
   b.harvest();
@@ -2221,17 +1706,32 @@ sslam_batch* sslam_batch_create(sslam_graph* const* graphs, int n) {
   h->b.device = graphs[0]->g.device;
   for (int i = 0; i < n; ++i) {
     if (!graphs[i] || graphs[i]->g.device != h->b.device) { set_error(SSLAM_ERR_INVALID, "batch graphs must share one device"); delete h; return nullptr; }
+    const Options &oa = graphs[0]->g.opt, &ob = graphs[i]->g.opt;   // one set of solver options drives the whole batch
+    if (oa.solver != ob.solver || oa.pcg_tol != ob.pcg_tol || oa.pcg_max_iters != ob.pcg_max_iters) {
+      set_error(SSLAM_ERR_INVALID, "batch graphs must share their solver options (graph %d differs from graph 0)", i); delete h; return nullptr;
+    }
     h->b.graphs.push_back(&graphs[i]->g);
   }
   if (batch_build(h->b) != 0) { delete h; return nullptr; }
   return h;
 }
 void sslam_batch_destroy(sslam_batch* h) { delete h; }
-int sslam_batch_upload(sslam_batch* h) { return h ? batch_upload_estimates(h->b) : set_error(SSLAM_ERR_INVALID, "null batch"); }
-int sslam_batch_download(sslam_batch* h) { return h ? batch_download_estimates(h->b) : set_error(SSLAM_ERR_INVALID, "null batch"); }
+// A batch is compiled for the structure its graphs had at sslam_batch_create; the graphs must outlive the batch and must
+// not gain vertices / edges afterwards (estimates may change: sslam_graph_set_vertex + sslam_batch_upload).
+static int batch_check(sslam_batch* h) {
+  if (!h) return set_error(SSLAM_ERR_INVALID, "null batch");
+  const Batch& b = h->b;
+  for (size_t g = 0; g < b.graphs.size(); ++g)
+    if (b.versions[g] != b.graphs[g]->structure_version)
+      return set_error(SSLAM_ERR_INVALID, "graph %zu of the batch gained vertices or edges after sslam_batch_create: create a new batch", g);
+  return 0;
+}
+int sslam_batch_upload(sslam_batch* h) { const int rc = batch_check(h); return rc ? rc : batch_upload_estimates(h->b); }
+int sslam_batch_download(sslam_batch* h) { const int rc = batch_check(h); return rc ? rc : batch_download_estimates(h->b); }
 int sslam_batch_optimize(sslam_batch* h, int max_iters, sslam_opt_stats* out) {
   if (!h || !out) return set_error(SSLAM_ERR_INVALID, "null argument");
-  return batch_optimize(h->b, max_iters, out);
+  const int rc = batch_check(h);
+  return rc ? rc : batch_optimize(h->b, max_iters, out);
 }
 int sslam_batch_time_linearize(sslam_batch* h, int repeats, double* ms_per_build) {
   if (!h || !ms_per_build || repeats <= 0) return set_error(SSLAM_ERR_INVALID, "bad argument");
@@ -2240,7 +1740,7 @@ int sslam_batch_time_linearize(sslam_batch* h, int repeats, double* ms_per_build
   int rc;
   if (!b.uploaded && (rc = batch_upload_estimates(b))) return rc;
   if ((rc = batch_chi2(b, b.V.pose, b.V.lmk, 0))) return rc;
-  hipLaunchKernelGGL(k_lm_init, dim3(b.V.B), dim3(64), 0, b.stream, b.V, b.d_part_e);
+  hipLaunchKernelGGL(k_lm_init, dim3(b.V.B), dim3(64), 0, b.stream, b.V, b.d_part_e, 0);
   const bool prof = b.profiling;
   b.profiling = false;
   if ((rc = batch_linearize(b))) return rc;  // warm-up
@@ -2274,10 +1774,11 @@ int sslam_batch_info(sslam_batch* h, const char* key, double* value) {
   Batch& b = h->b;
   const std::string k(key);
   int rc;
-  if ((k == "factor_lnz" || k == "factor_levels" || k == "factor_bytes") && !b.chol && (rc = chol_plan_build(b))) return rc;
+  if ((k == "factor_lnz" || k == "factor_levels" || k == "factor_launches" || k == "factor_bytes") && !b.chol && (rc = chol_plan_build(b))) return rc;
   const double dim = 6.0 * b.V.nPr + 3.0 * b.V.nLr;
   if (k == "factor_lnz") *value = (double)chol_plan_lnz(b);
   else if (k == "factor_levels") *value = (double)chol_plan_levels(b);
+  else if (k == "factor_launches") *value = (double)chol_plan_launches(b);
   else if (k == "h_doubles") *value = (double)b.V.h_total;
   else if (k == "dim") *value = dim;
   else if (k == "factor_bytes") *value = 8.0 * ((double)b.V.h_total + dim + (double)chol_plan_lnz(b) + dim);
@@ -2296,6 +1797,50 @@ int sslam_batch_kernel_time(sslam_batch* h, const char* name, double* total_ms, 
   if (total_ms) *total_ms = it == h->b.timers.end() ? 0.0 : it->second.total_ms;
   if (launches) *launches = it == h->b.timers.end() ? 0 : it->second.launches;
   return 0;
+}
+
+// ---- plan introspection (host only, no device needed): the symbolic Cholesky plan of a batch as flat int32 arrays ----------
+struct sslam_debug_plan { CholHost H; int64_t h_total = 0; std::vector<int> ppoff, plblk; int sc[16] = {0}; };
+void* sslam_debug_plan_create(sslam_graph* const* graphs, int n) {
+  if (!graphs || n <= 0) { set_error(SSLAM_ERR_INVALID, "empty batch"); return nullptr; }
+  Batch b;
+  for (int i = 0; i < n; ++i) { if (!graphs[i]) { set_error(SSLAM_ERR_INVALID, "null graph"); return nullptr; } b.graphs.push_back(&graphs[i]->g); }
+  if (batch_build(b, true) != 0) return nullptr;
+  SymIn in;
+  chol_sym_input(b, in);
+  CholOpts opt;
+  opt.from_env();
+  if (opt.nt_tail != 1024) opt.nt_tail = 512;
+  sslam_debug_plan* P = new sslam_debug_plan();
+  P->h_total = b.V.h_total;
+  for (auto& q : b.ppoff) { P->ppoff.push_back(q.first); P->ppoff.push_back(q.second); }
+  for (auto& q : b.plblk) { P->plblk.push_back(q.first); P->plblk.push_back(q.second); }
+  P->sc[11] = b.V.nPr; P->sc[12] = b.V.nLr; P->sc[13] = (int)b.hll_base; P->sc[14] = (int)b.hpp_off_base; P->sc[15] = (int)b.hpl_base;
+  if (chol_symbolic(in, opt, P->H)) { set_error(SSLAM_ERR_NUMERIC, "Cholesky plan: %s", P->H.error.c_str()); delete P; return nullptr; }
+  return P;
+}
+void sslam_debug_plan_destroy(void* p) { delete (sslam_debug_plan*)p; }
+int64_t sslam_debug_plan_array(void* p, const char* name, void* out, int64_t cap_bytes) {
+  if (!p || !name) return set_error(SSLAM_ERR_INVALID, "null argument");
+  const CholHost& H = ((sslam_debug_plan*)p)->H;
+  const std::string k(name);
+  const void* src = nullptr; int64_t bytes = 0;
+  const sslam_debug_plan& DP = *(sslam_debug_plan*)p;
+  int scal[16] = {H.ncol, H.nlevels, H.dim, H.B, H.npiece, (int)H.lnz, H.tail_lds_f, H.tail_lds_b, H.nt_leaf, H.nt_tail, (int)DP.h_total,
+                  DP.sc[11], DP.sc[12], DP.sc[13], DP.sc[14], DP.sc[15]};
+#define ARR(nm, vec) if (k == nm) { src = (vec).data(); bytes = (int64_t)(vec).size() * sizeof((vec)[0]); }
+  ARR("col", H.col) ARR("blk", H.blk) ARR("upd", H.upd) ARR("item", H.item) ARR("mb", H.mb) ARR("ilv", H.ilv) ARR("piece", H.piece)
+  ARR("lvl_ptr", H.lvl_ptr) ARR("lvl_cols", H.lvl_cols) ARR("plv_ptr", H.plv_ptr) ARR("plv_pieces", H.plv_pieces)
+  ARR("ppoff", DP.ppoff) ARR("plblk", DP.plblk) ARR("tail_ptr", H.tail_ptr) ARR("tail_pieces", H.tail_pieces) ARR("plv_lds_f", H.plv_lds_f) ARR("plv_lds_b", H.plv_lds_b)
+#undef ARR
+  if (k == "scalars") { src = scal; bytes = sizeof scal; }
+  static const char* known[] = {"col", "blk", "upd", "item", "mb", "ilv", "piece", "lvl_ptr", "lvl_cols", "plv_ptr", "plv_pieces", "ppoff", "plblk",
+                                "tail_ptr", "tail_pieces", "plv_lds_f", "plv_lds_b", "scalars"};
+  bool ok = false;
+  for (const char* q : known) ok |= (k == q);
+  if (!ok) return set_error(SSLAM_ERR_INVALID, "unknown plan array '%s'", name);
+  if (out && cap_bytes >= bytes && bytes > 0) memcpy(out, src, (size_t)bytes);
+  return bytes;
 }
 
 }  // extern "C"

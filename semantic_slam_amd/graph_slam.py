@@ -205,6 +205,22 @@ class GraphSLAM:
                 G.add_se3_plane_edge(i, j, gp.meas[k, :4], gp.info[k, :9].reshape(3, 3))
         return G
 
+    @classmethod
+    def from_synth(cls, g, device: int = 0) -> "GraphSLAM":
+        """Build a graph from a synth.SynthGraph: poses 0..Np-1 (the first fixed, graph_slam.cpp:109-111), then landmarks."""
+        G = cls(False, device)
+        Np = g.n_poses
+        for i in range(Np):
+            G.add_se3_node(g.poses_init[i])
+        plane = g.landmark_kind == "plane"
+        for l in range(g.n_landmarks):
+            (G.add_plane_node if plane else G.add_point_xyz_node)(g.lms_init[l])
+        for k in range(len(g.odom_ij)):
+            G.add_se3_edge(int(g.odom_ij[k, 0]), int(g.odom_ij[k, 1]), g.odom_z[k], g.odom_info[k])
+        for k in range(len(g.lm_ij)):
+            (G.add_se3_plane_edge if plane else G.add_se3_point_xyz_edge)(int(g.lm_ij[k, 0]), Np + int(g.lm_ij[k, 1]), g.lm_z[k], g.lm_info[k])
+        return G
+
     def estimates(self) -> np.ndarray:
         n = self.num_vertices()
         out = np.zeros((n, 7))

@@ -1,0 +1,218 @@
+"""TEST INFRASTRUCTURE — a numpy executor of the symbolic sparse-Cholesky plan (semantic_slam_amd/csrc/chol_plan.hpp).
+
+It walks the exported plan records (pieces, internal levels, work items, update records, multi-block reductions) exactly in
+the order the HIP kernels of sslam_chol.hip do — external updates from the finished factor, internal levels out of a
+piece-local mirror, partial tiles summed in item order — but with dense numpy block arithmetic.  Run on a CPU-only box it
+pins the *plan* (offsets, piece cuts, item lists) against dense linear algebra before any GPU time is spent."""
+import ctypes as C
+
+import numpy as np
+
+COL = np.dtype([(n, "<i4") for n in ("xoff", "yoff", "dim", "graph", "b0", "nb", "nbi", "base", "up0", "up1", "piece", "ilevel")])
+BLK = np.dtype([(n, "<i4") for n in ("off", "src", "xoff_row", "yoff_row", "coldiag", "colyoff", "info", "pad")])
+UPD = np.dtype([(n, "<i4") for n in ("ua", "ub", "ux", "pk")])
+ITEM = np.dtype([(n, "<i4") for n in ("u0", "n", "tloff", "flags")])
+MB = np.dtype([(n, "<i4") for n in ("tloff", "ps0", "n", "info")])
+ILV = np.dtype([(n, "<i4") for n in ("c0", "c1", "b0", "b1", "it0", "it1", "mb0", "mb1")])
+PIECE = np.dtype([(n, "<i4") for n in ("graph", "c0", "nc", "b0", "nb", "lbase", "lsize", "y0", "ysize", "eit0", "enit", "emb0", "nemb",
+                                       "ilv0", "nilv", "iit0", "nit_i", "pad")])
+K_DI6, K_DK6, K_DIAG, K_DJ6 = 1 << 20, 1 << 21, 1 << 22, 1 << 23
+B_FMT, B_DIAG, B_ROWIN = 1 << 8, 1 << 9, 1 << 10
+
+
+class Plan:
+    def __init__(self, lib, graphs):
+        arr = (C.c_void_p * len(graphs))(*[g._h for g in graphs])
+        self._lib = lib
+        self._h = lib.sslam_debug_plan_create(arr, len(graphs))
+        if not self._h:
+            raise RuntimeError(lib.sslam_last_error().decode())
+        g = self._get
+        self.col, self.blk, self.upd = g("col", COL), g("blk", BLK), g("upd", UPD)
+        self.item, self.mb, self.ilv, self.piece = g("item", ITEM), g("mb", MB), g("ilv", ILV), g("piece", PIECE)
+        for n in ("lvl_ptr", "lvl_cols", "plv_ptr", "plv_pieces", "tail_ptr", "tail_pieces", "plv_lds_f", "plv_lds_b", "ppoff", "plblk", "scalars"):
+            setattr(self, n, g(n, np.int32))
+        s = self.scalars
+        (self.ncol, self.nlevels, self.dim, self.B, self.npiece, self.lnz, self.tail_lds_f, self.tail_lds_b, self.nt_leaf, self.nt_tail,
+         self.h_total, self.nPr, self.nLr, self.hll_base, self.hpp_off_base, self.hpl_base) = [int(v) for v in s]
+        lib.sslam_debug_plan_destroy(self._h)
+        self._h = None
+
+    def _get(self, name, dtype):
+        n = self._lib.sslam_debug_plan_array(self._h, name.encode(), None, 0)
+        if n < 0:
+            raise RuntimeError(self._lib.sslam_last_error().decode())
+        buf = np.zeros(max(n, 1), np.uint8)
+        self._lib.sslam_debug_plan_array(self._h, name.encode(), buf.ctypes.data, n)
+        return buf[:n].view(dtype).copy()
+
+    # ---- piece order of the device: launches by depth, then every graph's tail
+    def piece_order(self):
+        order = [int(p) for p in self.plv_pieces]
+        order += [int(p) for p in self.tail_pieces]
+        return order
+
+    # ---- device layout of H from a dense matrix in internal row order (pose rows 6 each, then landmark rows 3 each)
+    def pack_H(self, Hd):
+        nPr, nLr = self.nPr, self.nLr
+        out = np.zeros(self.h_total)
+        xo = lambda r: 6 * r if r < nPr else 6 * nPr + 3 * (r - nPr)
+        for r in range(nPr):
+            out[36 * r:36 * r + 36] = Hd[6 * r:6 * r + 6, 6 * r:6 * r + 6].ravel()
+        for l in range(nLr):
+            o = xo(nPr + l)
+            out[self.hll_base + 9 * l:self.hll_base + 9 * l + 9] = Hd[o:o + 3, o:o + 3].ravel()
+        pp = self.ppoff.reshape(-1, 2)
+        for i, (a, c) in enumerate(pp):
+            out[self.hpp_off_base + 36 * i:self.hpp_off_base + 36 * i + 36] = Hd[6 * a:6 * a + 6, 6 * c:6 * c + 6].ravel()
+        pl = self.plblk.reshape(-1, 2)
+        for i, (rp, rl) in enumerate(pl):
+            o = xo(nPr + rl)
+            out[self.hpl_base + 18 * i:self.hpl_base + 18 * i + 18] = Hd[6 * rp:6 * rp + 6, o:o + 3].ravel()
+        return out
+
+    # ---- factorisation + fused forward substitution, piece by piece
+    def factor(self, Hdev, bvec, lam):
+        Lval = np.zeros(self.lnz + 64)
+        y = np.zeros(self.dim + 8)
+        ok = True
+        for p in self.piece_order():
+            ok &= self._factor_piece(self.piece[p], Hdev, bvec, lam, Lval, y)
+        return Lval, y, ok
+
+    def _run_items(self, items, Ls, Ys, lofs, yofs, smL, smY, part):
+        for im in items:
+            u = self.upd[im["u0"]:im["u0"] + im["n"]]
+            pk0 = int(u[0]["pk"])
+            di = 6 if pk0 & K_DI6 else 3
+            dj = 6 if pk0 & K_DJ6 else 3
+            diag = bool(pk0 & K_DIAG)
+            acc = np.zeros((di, dj)); accy = np.zeros(di)
+            for r in u:
+                dk = 6 if r["pk"] & K_DK6 else 3
+                assert (int(r["pk"]) & ~K_DK6) == (pk0 & ~K_DK6)          # one target per item
+                A = Ls[r["ua"] - lofs:r["ua"] - lofs + di * dk].reshape(di, dk)
+                Bm = Ls[r["ub"] - lofs:r["ub"] - lofs + dj * dk].reshape(dj, dk)
+                acc += A @ Bm.T
+                if diag:
+                    accy += A @ Ys[r["ux"] - yofs:r["ux"] - yofs + dk]
+            fl = int(im["flags"])
+            if fl & 1:
+                smL[im["tloff"]:im["tloff"] + di * dj] -= acc.ravel()
+                if diag:
+                    yl = fl >> 12
+                    smY[yl:yl + dj] -= accy
+            else:
+                part[(fl >> 1) & 0x7FF] = (acc, accy)
+
+    def _reduce(self, mbs, smL, smY, part):
+        for mm in mbs:
+            di, dj = int(mm["info"]) & 15, (int(mm["info"]) >> 4) & 15
+            acc = np.zeros((di, dj)); accy = np.zeros(di)
+            for q in range(mm["n"]):
+                a, ay = part[mm["ps0"] + q]
+                acc += a; accy += ay
+            smL[mm["tloff"]:mm["tloff"] + di * dj] -= acc.ravel()
+            if int(mm["info"]) & B_DIAG:
+                yl = int(mm["info"]) >> 12
+                smY[yl:yl + dj] -= accy
+
+    def _factor_piece(self, pm, Hdev, bvec, lam, Lval, y):
+        lbase, y0 = int(pm["lbase"]), int(pm["y0"])
+        smL = np.zeros(pm["lsize"]); smY = np.zeros(pm["ysize"])
+        part = {}
+        for bm in self.blk[pm["b0"]:pm["b0"] + pm["nb"]]:
+            info = int(bm["info"])
+            di, dj = info & 15, (info >> 4) & 15
+            v = np.zeros((di, dj))
+            if bm["src"] >= 0:
+                raw = Hdev[bm["src"]:bm["src"] + di * dj]
+                v = raw.reshape(dj, di).T.copy() if info & B_FMT else raw.reshape(di, dj).copy()
+            if info & B_DIAG:
+                v += lam * np.eye(dj)
+                assert bm["off"] == bm["coldiag"]
+                smY[bm["colyoff"] - y0:bm["colyoff"] - y0 + dj] = bvec[bm["xoff_row"]:bm["xoff_row"] + dj]
+            smL[bm["off"] - lbase:bm["off"] - lbase + di * dj] = v.ravel()
+        self._run_items(self.item[pm["eit0"]:pm["eit0"] + pm["enit"]], Lval, y, 0, 0, smL, smY, part)
+        self._reduce(self.mb[pm["emb0"]:pm["emb0"] + pm["nemb"]], smL, smY, part)
+        ok = True
+        for lv in self.ilv[pm["ilv0"]:pm["ilv0"] + pm["nilv"]]:
+            part = {}
+            self._run_items(self.item[pm["iit0"] + lv["it0"]:pm["iit0"] + lv["it1"]], smL, smY, lbase, y0, smL, smY, part)
+            self._reduce(self.mb[lv["mb0"]:lv["mb1"]], smL, smY, part)
+            for cm in self.col[lv["c0"]:lv["c1"]]:
+                d = int(cm["dim"]); o = cm["base"] - lbase; yl = cm["yoff"] - y0
+                S = smL[o:o + d * d].reshape(d, d)
+                S = np.tril(S) + np.tril(S, -1).T
+                try:
+                    Lj = np.linalg.cholesky(S)
+                except np.linalg.LinAlgError:
+                    ok = False
+                    Lj = np.eye(d)
+                smL[o:o + d * d] = Lj.ravel()
+                smY[yl:yl + d] = np.linalg.solve(Lj, smY[yl:yl + d])
+            for bm in self.blk[lv["b0"]:lv["b1"]]:
+                info = int(bm["info"])
+                if info & B_DIAG:
+                    continue
+                di, dj = info & 15, (info >> 4) & 15
+                o = bm["off"] - lbase; od = bm["coldiag"] - lbase
+                Lj = smL[od:od + dj * dj].reshape(dj, dj)
+                Vb = smL[o:o + di * dj].reshape(di, dj)
+                smL[o:o + di * dj] = np.linalg.solve(Lj, Vb.T).T.ravel()
+        Lval[lbase:lbase + pm["lsize"]] = smL
+        y[y0:y0 + pm["ysize"]] = smY
+        return ok
+
+    # ---- backward substitution, pieces top-down
+    def backward(self, Lval, y):
+        x = np.zeros(self.dim)
+        for p in reversed(self.piece_order()):
+            pm = self.piece[p]
+            lbase, y0 = int(pm["lbase"]), int(pm["y0"])
+            smX = y[y0:y0 + pm["ysize"]].copy()
+            cols = self.col[pm["c0"]:pm["c0"] + pm["nc"]]
+            for cm in cols:
+                d = int(cm["dim"]); yl = cm["yoff"] - y0
+                for bm in self.blk[cm["b0"] + cm["nbi"]:cm["b0"] + cm["nb"]]:
+                    assert not (int(bm["info"]) & B_ROWIN)
+                    di = int(bm["info"]) & 15
+                    Lb = Lval[bm["off"]:bm["off"] + di * d].reshape(di, d)
+                    smX[yl:yl + d] -= Lb.T @ x[bm["xoff_row"]:bm["xoff_row"] + di]
+            for lv in self.ilv[pm["ilv0"]:pm["ilv0"] + pm["nilv"]][::-1]:
+                for cm in self.col[lv["c0"]:lv["c1"]]:
+                    d = int(cm["dim"]); yl = cm["yoff"] - y0
+                    acc = np.zeros(d)
+                    for bm in self.blk[cm["b0"] + 1:cm["b0"] + cm["nbi"]]:
+                        assert int(bm["info"]) & B_ROWIN
+                        di = int(bm["info"]) & 15
+                        Lb = Lval[bm["off"]:bm["off"] + di * d].reshape(di, d)
+                        yr = bm["yoff_row"] - y0
+                        assert 0 <= yr and yr + di <= pm["ysize"]
+                        acc += Lb.T @ smX[yr:yr + di]
+                    Lj = Lval[cm["base"]:cm["base"] + d * d].reshape(d, d)
+                    smX[yl:yl + d] = np.linalg.solve(Lj.T, smX[yl:yl + d] - acc)
+            for cm in cols:
+                d = int(cm["dim"])
+                x[cm["xoff"]:cm["xoff"] + d] = smX[cm["yoff"] - y0:cm["yoff"] - y0 + d]
+        return x
+
+    # dense L in elimination order (tests)
+    def dense_L(self, Lval):
+        Ld = np.zeros((self.dim, self.dim))
+        for cm in self.col:
+            d = int(cm["dim"])
+            for bm in self.blk[cm["b0"]:cm["b0"] + cm["nb"]]:
+                di = int(bm["info"]) & 15
+                Ld[bm["yoff_row"]:bm["yoff_row"] + di, cm["yoff"]:cm["yoff"] + d] = Lval[bm["off"]:bm["off"] + di * d].reshape(di, d)
+        return Ld
+
+    def perm_x_to_y(self):
+        """index array p with  v_y[p_y] = v_x[p_x]  (x: internal row order, y: elimination order)"""
+        px = np.zeros(self.dim, np.int64); py = np.zeros(self.dim, np.int64)
+        k = 0
+        for cm in self.col:
+            d = int(cm["dim"])
+            px[k:k + d] = np.arange(cm["xoff"], cm["xoff"] + d); py[k:k + d] = np.arange(cm["yoff"], cm["yoff"] + d)
+            k += d
+        return px, py

@@ -1,0 +1,128 @@
+"""CPU-side pin of the symbolic sparse-Cholesky plan (pieces, work items, update records) that the HIP kernels of
+semantic_slam_amd/csrc/sslam_chol.hip execute: the plan is exported through the C-ABI (no GPU needed), walked by a numpy
+executor in the kernels' own order (tests/chol_plan_exec.py) and compared with dense linear algebra on the oracle's normal
+equations.  Reference anchor: the linear solver behind GraphSLAM::optimize (reference src/ps_graph_slam/graph_slam.cpp:27,67-73)."""
+import os
+
+import numpy as np
+import pytest
+
+from semantic_slam_amd.synth import make_graph
+from oracle.oracle import GraphProblem
+from chol_plan_exec import Plan
+
+
+def _internal_order(gp):
+    """g2o hessian offsets -> the backend's internal row order (pose rows, then landmark rows, each by vertex id)."""
+    h, n = gp.hessian_index()
+    idx = []
+    for v in range(gp.nv):
+        if gp.vtype[v] == 0 and h[v] >= 0:
+            idx += list(range(h[v], h[v] + 6))
+    for v in range(gp.nv):
+        if gp.vtype[v] != 0 and h[v] >= 0:
+            idx += list(range(h[v], h[v] + 3))
+    return np.array(idx), n
+
+
+def _plan_and_system(hip_lib, g, interleave, env=None):
+    from semantic_slam_amd import GraphSLAM
+    old = {}
+    for k, v in (env or {}).items():
+        old[k] = os.environ.get(k); os.environ[k] = str(v)
+    try:
+        gp = GraphProblem.from_synth(g, interleave=interleave)
+        G = GraphSLAM.from_problem(gp)
+        plan = Plan(hip_lib, [G])
+    finally:
+        for k, v in old.items():
+            if v is None: os.environ.pop(k)
+            else: os.environ[k] = v
+    U, b = gp.linearize()
+    Hg = (U + U.T).toarray() - np.diag(U.diagonal())
+    idx, n = _internal_order(gp)
+    assert n == plan.dim and len(idx) == n
+    return plan, Hg[np.ix_(idx, idx)], b[idx]
+
+
+def _check(plan, H, b, lam):
+    Hdev = plan.pack_H(H)
+    Lval, y, ok = plan.factor(Hdev, b, lam)
+    assert ok
+    Ld = plan.dense_L(Lval)
+    px, py = plan.perm_x_to_y()
+    A = H + lam * np.eye(plan.dim)
+    Ay = np.zeros_like(A); Ay[np.ix_(py, py)] = A[np.ix_(px, px)]
+    scale = np.abs(A).max()
+    assert np.abs(Ld @ Ld.T - Ay).max() <= 1e-9 * scale
+    assert np.abs(np.triu(Ld, 1)).max() == 0.0
+    by = np.zeros(plan.dim); by[py] = b[px]
+    yref = np.linalg.solve(Ld, by)
+    assert np.abs(y[:plan.dim] - yref).max() <= 1e-9 * max(np.abs(yref).max(), 1e-30)
+    x = plan.backward(Lval, y)
+    xref = np.linalg.solve(A, b)
+    assert np.abs(x - xref).max() <= 1e-7 * np.abs(xref).max()
+    return Lval
+
+
+def _structure_invariants(plan):
+    P = plan.piece
+    # pieces tile the columns, blocks, L storage and y contiguously
+    assert P["c0"][0] == 0 and np.all(P["c0"][1:] == P["c0"][:-1] + P["nc"][:-1]) and P["c0"][-1] + P["nc"][-1] == plan.ncol
+    assert np.all(P["lbase"][1:] == P["lbase"][:-1] + P["lsize"][:-1]) and P["lbase"][-1] + P["lsize"][-1] == plan.lnz
+    assert np.all(P["y0"][1:] == P["y0"][:-1] + P["ysize"][:-1]) and P["y0"][-1] + P["ysize"][-1] == plan.dim
+    # every piece is launched exactly once
+    order = plan.piece_order()
+    assert sorted(order) == list(range(plan.npiece))
+    # an external update source always lies in a piece that runs earlier
+    rank = np.zeros(plan.npiece, int); rank[order] = np.arange(plan.npiece)
+    depth_of = {}
+    for l in range(len(plan.plv_ptr) - 1):
+        for p in plan.plv_pieces[plan.plv_ptr[l]:plan.plv_ptr[l + 1]]:
+            depth_of[int(p)] = l
+    lb = P["lbase"]
+    for p in range(plan.npiece):
+        pm = P[p]
+        for im in plan.item[pm["eit0"]:pm["eit0"] + pm["enit"]]:
+            for r in plan.upd[im["u0"]:im["u0"] + im["n"]]:
+                q = int(np.searchsorted(lb, r["ua"], side="right") - 1)
+                assert q != p and rank[q] < rank[p]
+                if p in depth_of:   # pieces that share a launch must not feed each other
+                    assert q in depth_of and depth_of[q] < depth_of[p]
+        for im in plan.item[pm["iit0"]:pm["iit0"] + pm["nit_i"]]:
+            for r in plan.upd[im["u0"]:im["u0"] + im["n"]]:
+                assert pm["lbase"] <= r["ua"] < pm["lbase"] + pm["lsize"] and pm["lbase"] <= r["ub"] < pm["lbase"] + pm["lsize"]
+    # LDS budgets stay below the hardware's 160 KiB
+    lds = [int(v) for v in plan.plv_lds_f] + [int(v) for v in plan.plv_lds_b] + [plan.tail_lds_f, plan.tail_lds_b]
+    assert max(lds) * 8 <= 158 * 1024
+
+
+@pytest.mark.parametrize("interleave", [False, True])
+def test_plan_small_graph_matches_dense_cholesky(hip_lib, interleave):
+    g = make_graph(60, 12, seed=3)
+    plan, H, b = _plan_and_system(hip_lib, g, interleave)
+    _structure_invariants(plan)
+    _check(plan, H, b, 0.0)
+    _check(plan, H, b, 7.5)
+
+
+def test_plan_with_tiny_pieces_exercises_every_phase(hip_lib):
+    """Caps far below the defaults force many pieces, external phases, split lists (partial tiles) and a multi-piece tail."""
+    g = make_graph(150, 30, seed=5)
+    env = {"SSLAM_CHOL_CAP_LEAF": 400, "SSLAM_CHOL_CAP_TAIL": 700, "SSLAM_CHOL_TAIL_WIDTH": 2}
+    plan, H, b = _plan_and_system(hip_lib, g, False, env)
+    assert plan.npiece > 20 and len(plan.tail_pieces) >= 2 and len(plan.plv_ptr) > 2
+    assert len(plan.mb) > 0 and np.any(plan.piece["enit"] > 0)
+    _structure_invariants(plan)
+    _check(plan, H, b, 1e-3)
+    # same system, no tail: every piece goes through the per-depth launches
+    plan2, H2, b2 = _plan_and_system(hip_lib, g, False, dict(env, SSLAM_CHOL_TAIL_WIDTH=0))
+    assert len(plan2.tail_pieces) == 0
+    _check(plan2, H2, b2, 1e-3)
+
+
+def test_plan_plane_landmarks_and_S_config(hip_lib):
+    g = make_graph(500, 100, seed=1, landmark_kind="plane")
+    plan, H, b = _plan_and_system(hip_lib, g, True)
+    _structure_invariants(plan)
+    _check(plan, H, b, 1e-2)
