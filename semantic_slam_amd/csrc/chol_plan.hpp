@@ -33,11 +33,12 @@
 
 namespace sslam {
 
-struct ColMeta { int xoff, yoff, dim, graph, b0, nb, nbi, base, up0, up1, piece, ilevel; };
+struct ColMeta { int xoff, yoff, dim, graph, b0, nb, nbi, base, up0, up1, ui0, ui1, piece, ilevel, pad0, pad1; };
 // xoff: offset in the unknown vector (internal row order); yoff: offset in elimination order (the forward-substituted
 // rhs y lives in that order so that a piece's y is contiguous); blocks [b0, b0 + nb), diagonal first, the first nbi
 // (diagonal included) have their row inside the column's own piece; base = Lval offset of the diagonal block;
-// [up0, up1) = updates of the diagonal block (forward substitution of the multi right-hand-side solves)
+// [up0, up1) + [ui0, ui1) = updates of the diagonal block with sources outside / inside the column's piece (forward substitution
+// of the multi right-hand-side solves)
 
 struct BlkMeta { int off, src, xoff_row, yoff_row, coldiag, colyoff, info, pad; };
 // off: Lval offset; src: H offset or -1; x / y offsets of the block's row; Lval offset of the diagonal block and y offset of
@@ -50,12 +51,15 @@ constexpr int kUpdDk6 = 1 << 21;         // source column k is 6 wide (else 3)
 constexpr int kUpdDiag = 1 << 22;        // target is the diagonal block (carries the forward-substitution rhs too)
 constexpr int kUpdDj6 = 1 << 23;         // target column is 6 wide (else 3)
 
-struct ItemMeta { int u0, n, tloff, flags; };   // updates [u0, u0 + n) of one target block at piece-local offset tloff
+struct ItemMeta { int u0, n, tloff, flags; };   // updates [u0, u0 + n) of one target block at piece-local offset tloff; u0 indexes upd[] for
+                                                // an external item and the piece's internal update records (LDS copy) for an internal one
 constexpr int kItemSole = 1;                     // flags: bit 0 sole (subtract in place); bits 1..11 partial slot; bits 12.. local y offset
 constexpr int kItemSlotShift = 1, kItemSlotMask = 0x7FF, kItemYShift = 12;
 struct MbMeta { int tloff, ps0, n, info; };      // a target block with n > 1 items: partial slots [ps0, ps0 + n); info = di | dj << 4 | diag << 9 | ylocal << 12
-struct ILevel { int c0, c1, b0, b1, it0, it1, mb0, mb1; };   // one level inside a piece: columns, blocks (global ids), items (piece-local), multi-blocks
-struct PieceMeta { int graph, c0, nc, b0, nb, lbase, lsize, y0, ysize, eit0, enit, emb0, nemb, ilv0, nilv, iit0, nit_i, pad; };
+struct ILevel { int c0, c1, b0, b1, it0, it1, mb0, mb1; };   // one level inside a piece: columns, blocks (global ids), items and multi-blocks (piece-local)
+struct PieceMeta { int graph, c0, nc, b0, nb, lbase, lsize, y0, ysize, eit0, enit, emb0, nemb, ilv0, nilv, iit0, nit_i, iu0, nu_i, imb0, nimb, pad0, pad1, pad2; };
+// external phase: items [eit0, +enit), multi-blocks [emb0, +nemb); internal: items [iit0, +nit_i), update records [iu0, +nu_i),
+// multi-blocks [imb0, +nimb) -- all three copied to LDS when the piece starts, so that the levels inside a piece never wait for HBM
 
 constexpr int kItemDoubles = 42;     // LDS doubles per partial tile: 6 x 6 entries + 6 rhs components
 constexpr int kMaxILevels = 64;      // internal levels per piece (LDS table in the kernels)
@@ -429,10 +433,10 @@ inline int chol_symbolic(const SymIn& in, CholOpts opt, CholHost& out) {
     std::vector<int> cursor(out.tail_ptr.begin(), out.tail_ptr.end() - 1);
     for (int p = 0; p < npiece; ++p) if (piece_tail[p]) out.tail_pieces[cursor[out.piece[p].graph]++] = p;   // ascending id = elimination order
   }
-  // ---- update records (external sources first), columns, blocks ------------------------------------------------------------
+  // ---- columns, blocks; update records piece by piece: all external updates of the piece (block order), then all internal ones
   out.col.assign(ncol, ColMeta{});
   out.blk.assign(nblk, BlkMeta{});
-  std::vector<int> upx(nblk, 0), bup0(nblk, 0), bup1(nblk, 0);   // per block: [bup0, upx) external, [upx, bup1) internal updates
+  std::vector<int> be0(nblk, 0), be1(nblk, 0), bi0(nblk, 0), bi1(nblk, 0);   // per block: external / internal update ranges in upd[]
   out.upd.clear();
   {
     size_t total = 0;
@@ -444,28 +448,34 @@ inline int chol_symbolic(const SymIn& in, CholOpts opt, CholHost& out) {
     int nbi = 0;
     for (int t = bp[j]; t < bp[j + 1]; ++t) if (col_piece[brow[t]] == pj) ++nbi;   // rows sorted by position: in-piece rows come first
     for (int t = bp[j]; t < bp[j] + nbi; ++t) if (col_piece[brow[t]] != pj) { out.error = "in-piece rows of a column are not a prefix"; return -1; }
-    out.col[j] = ColMeta{col_xoff[j], col_yoff[j], col_dim[j], col_graph[j], bp[j], bp[j + 1] - bp[j], nbi, boff[bp[j]], 0, 0, pj, col_il[j]};
+    out.col[j] = ColMeta{col_xoff[j], col_yoff[j], col_dim[j], col_graph[j], bp[j], bp[j + 1] - bp[j], nbi, boff[bp[j]], 0, 0, 0, 0, pj, col_il[j], 0, 0};
     for (int t = bp[j]; t < bp[j + 1]; ++t) {
       const int i = brow[t];
-      const int tpk = (col_dim[i] == 6 ? kUpdDi6 : 0) | (t == bp[j] ? kUpdDiag : 0) | (col_dim[j] == 6 ? kUpdDj6 : 0);
       BlkMeta& bm = out.blk[t];
       bm.off = boff[t]; bm.src = bsrc[t];
-      bup0[t] = (int)out.upd.size();
-      for (int pass = 0; pass < 2; ++pass) {   // external sources first, each part ascending in k
-        if (pass == 1) upx[t] = (int)out.upd.size();
-        for (auto& u : ulist[t]) {
-          const bool internal = col_piece[u[2]] == pj;
-          if ((int)internal != pass) continue;
-          out.upd.push_back(UpdMeta{u[0], u[1], col_yoff[u[2]], tpk | (col_dim[u[2]] == 6 ? kUpdDk6 : 0)});
-        }
-      }
-      bup1[t] = (int)out.upd.size();
-      if (t == bp[j]) { out.col[j].up0 = bup0[t]; out.col[j].up1 = bup1[t]; }
       bm.xoff_row = col_xoff[i]; bm.yoff_row = col_yoff[i]; bm.coldiag = boff[bp[j]]; bm.colyoff = col_yoff[j]; bm.pad = 0;
       bm.info = col_dim[i] | (col_dim[j] << 4) | (bfmt[t] ? kBlkFmt : 0) | (t == bp[j] ? kBlkDiag : 0) | (col_piece[i] == pj ? kBlkRowIn : 0);
-      std::vector<std::array<int, 3>>().swap(ulist[t]);
     }
   }
+  for (int p = 0; p < npiece; ++p) {
+    PieceMeta& pm = out.piece[p];
+    for (int pass = 0; pass < 2; ++pass) {
+      if (pass == 1) pm.iu0 = (int)out.upd.size();
+      for (int j = pm.c0; j < pm.c0 + pm.nc; ++j)
+        for (int t = bp[j]; t < bp[j + 1]; ++t) {
+          const int tpk = (col_dim[brow[t]] == 6 ? kUpdDi6 : 0) | (t == bp[j] ? kUpdDiag : 0) | (col_dim[j] == 6 ? kUpdDj6 : 0);
+          (pass == 0 ? be0 : bi0)[t] = (int)out.upd.size();
+          for (auto& u : ulist[t]) {   // ascending in k
+            if ((int)(col_piece[u[2]] == p) != pass) continue;
+            out.upd.push_back(UpdMeta{u[0], u[1], col_yoff[u[2]], tpk | (col_dim[u[2]] == 6 ? kUpdDk6 : 0)});
+          }
+          (pass == 0 ? be1 : bi1)[t] = (int)out.upd.size();
+          if (pass == 1) std::vector<std::array<int, 3>>().swap(ulist[t]);
+        }
+    }
+    pm.nu_i = (int)out.upd.size() - pm.iu0;
+  }
+  for (int j = 0; j < ncol; ++j) { out.col[j].up0 = be0[bp[j]]; out.col[j].up1 = be1[bp[j]]; out.col[j].ui0 = bi0[bp[j]]; out.col[j].ui1 = bi1[bp[j]]; }
   // ---- work items per piece: the external phase, then one phase per internal level -----------------------------------------
   std::vector<int> block_col(nblk);
   for (int j = 0; j < ncol; ++j) for (int t = bp[j]; t < bp[j + 1]; ++t) block_col[t] = j;
@@ -479,7 +489,7 @@ inline int chol_symbolic(const SymIn& in, CholOpts opt, CholHost& out) {
     // one phase over the blocks [b_begin, b_end): part 0 = external updates [up0, upx), part 1 = internal [upx, up1);
     // item indices of part 1 are piece-local (the internal items of a piece are copied to LDS)
     auto build_phase = [&](int b_begin, int b_end, int part, int& mb0, int& mb1) {
-      auto count = [&](int t) { return part == 0 ? upx[t] - bup0[t] : bup1[t] - upx[t]; };
+      auto count = [&](int t) { return part == 0 ? be1[t] - be0[t] : bi1[t] - bi0[t]; };
       int U = 0;
       for (int t = b_begin; t < b_end; ++t) U += count(t);
       int chunk = std::max(kMinChunk, (U + slots - 1) / slots);
@@ -488,11 +498,11 @@ inline int chol_symbolic(const SymIn& in, CholOpts opt, CholHost& out) {
         for (int t = b_begin; t < b_end; ++t) { const int k = (count(t) + chunk - 1) / chunk; if (k > 1) nonsole += k; }
         if (nonsole <= pcap || chunk >= std::max(U, 1)) break;
       }
-      mb0 = (int)out.mb.size();
+      mb0 = (int)out.mb.size() - (part == 0 ? 0 : pm.imb0);   // internal multi-blocks are indexed piece-locally
       int ps = 0;
       for (int t = b_begin; t < b_end; ++t) {
         const BlkMeta& bm = out.blk[t];
-        const int u0 = part == 0 ? bup0[t] : upx[t], u1 = part == 0 ? upx[t] : bup1[t];
+        const int u0 = part == 0 ? be0[t] : bi0[t] - pm.iu0, u1 = part == 0 ? be1[t] : bi1[t] - pm.iu0;   // internal: piece-local (LDS copy)
         const int n = u1 - u0;
         if (n <= 0) continue;
         const int k = (n + chunk - 1) / chunk;
@@ -509,7 +519,7 @@ inline int chol_symbolic(const SymIn& in, CholOpts opt, CholHost& out) {
           ps += k;
         }
       }
-      mb1 = (int)out.mb.size();
+      mb1 = (int)out.mb.size() - (part == 0 ? 0 : pm.imb0);
       piece_pmax[p] = std::max(piece_pmax[p], ps);
     };
     int mb0, mb1;
@@ -517,6 +527,7 @@ inline int chol_symbolic(const SymIn& in, CholOpts opt, CholHost& out) {
     build_phase(pm.b0, pm.b0 + pm.nb, 0, mb0, mb1);
     pm.enit = (int)out.item.size() - pm.eit0; pm.emb0 = mb0; pm.nemb = mb1 - mb0;
     pm.iit0 = (int)out.item.size();
+    pm.imb0 = (int)out.mb.size();
     pm.ilv0 = (int)out.ilv.size();
     int c = pm.c0;
     const int cend = pm.c0 + pm.nc;
@@ -534,13 +545,15 @@ inline int chol_symbolic(const SymIn& in, CholOpts opt, CholHost& out) {
     }
     pm.nilv = (int)out.ilv.size() - pm.ilv0;
     pm.nit_i = (int)out.item.size() - pm.iit0;
+    pm.nimb = (int)out.mb.size() - pm.imb0;
     if (pm.nilv > kMaxILevels) { out.error = "a piece has too many internal levels"; return -1; }
     if (pm.ysize >= (1 << (32 - kItemYShift - 1))) { out.error = "a piece has too many unknowns"; return -1; }
   }
   // ---- LDS needs (doubles) ---------------------------------------------------------------------------------------------------
   auto lds_f = [&](int p) {
     const PieceMeta& pm = out.piece[p];
-    return ((pm.lsize + 1) & ~1) + 2 * ((pm.ysize + 1) & ~1) + 2 * pm.nb + 2 * pm.nc + 2 * pm.nit_i + kItemDoubles * piece_pmax[p] + 8;
+    return ((pm.lsize + 1) & ~1) + 2 * ((pm.ysize + 1) & ~1) + 2 * pm.nb + 2 * pm.nc + 2 * pm.nit_i + 2 * pm.nu_i + 2 * pm.nimb +
+           kItemDoubles * piece_pmax[p] + 8;
   };
   auto lds_b = [&](int p) {
     const PieceMeta& pm = out.piece[p];

@@ -177,7 +177,9 @@ __device__ __forceinline__ void reduce_multi(const MbMeta* __restrict__ mbs, int
 }
 
 // diagonal block of one column, one thread: L_jj = chol(S_jj) in place (strict upper = 0), reciprocal pivots to inv,
-// y_j = L_jj^-1 rhs_j in place.  Pivots are inverted once (rsqrt) and multiplied from then on.
+// y_j = L_jj^-1 rhs_j in place.  Right-looking form: after a pivot only one multiply and one FMA lie between it and the next
+// pivot (the trailing updates are independent of one another), so the thread's latency is ~D x (rsqrt + 2 ops), not ~D^2 FMAs.
+// Pivots are inverted once (rsqrt) and multiplied from then on.
 template <int D>
 __device__ __forceinline__ bool diag_factor(double* Ljj, double* yj, double* inv_out) {
   double a[D * D], t[D], inv[D];
@@ -189,28 +191,21 @@ __device__ __forceinline__ bool diag_factor(double* Ljj, double* yj, double* inv
 #pragma unroll
   for (int c = 0; c < D; ++c) {
     double d = a[c * D + c];
-#pragma unroll
-    for (int s = 0; s < c; ++s) d -= a[c * D + s] * a[c * D + s];
     if (!(d > 0)) { ok = false; d = 1.0; }
     const double id = rsqrt(d);
     inv[c] = id;
     a[c * D + c] = d * id;
+    t[c] *= id;
+#pragma unroll
+    for (int r = c + 1; r < D; ++r) a[r * D + c] *= id;
 #pragma unroll
     for (int r = c + 1; r < D; ++r) {
-      double x = a[r * D + c];
 #pragma unroll
-      for (int s = 0; s < c; ++s) x -= a[r * D + s] * a[c * D + s];
-      a[r * D + c] = x * id;
+      for (int c2 = c + 1; c2 <= r; ++c2) a[r * D + c2] -= a[r * D + c] * a[c2 * D + c];
+      t[r] -= a[r * D + c] * t[c];
     }
 #pragma unroll
-    for (int s = c + 1; s < D; ++s) a[c * D + s] = 0.0;
-  }
-#pragma unroll
-  for (int r = 0; r < D; ++r) {
-    double v = t[r];
-#pragma unroll
-    for (int s = 0; s < r; ++s) v -= a[r * D + s] * t[s];
-    t[r] = v * inv[r];
+    for (int s2 = c + 1; s2 < D; ++s2) a[c * D + s2] = 0.0;
   }
 #pragma unroll
   for (int q = 0; q < D * D; ++q) Ljj[q] = a[q];
@@ -219,29 +214,19 @@ __device__ __forceinline__ bool diag_factor(double* Ljj, double* yj, double* inv
   return ok;
 }
 
-// off-diagonal block of a factored column, one thread: every row solves x L_jj^T = v in place
+// one row of an off-diagonal block of a factored column, one thread: x L_jj^T = v in place
 template <int D>
-__device__ __forceinline__ void row_solve(double* rows, int di, const double* Ljj, const double* invp) {
-  double a[D * D], inv[D];
+__device__ __forceinline__ void row_solve(double* v, const double* Ljj, const double* invp) {
+  double x[D];
 #pragma unroll
-  for (int r = 0; r < D; ++r) {
-    inv[r] = invp[r];
+  for (int c = 0; c < D; ++c) {
+    double w = v[c];
 #pragma unroll
-    for (int s = 0; s < r; ++s) a[r * D + s] = Ljj[r * D + s];
+    for (int s2 = 0; s2 < c; ++s2) w -= x[s2] * Ljj[c * D + s2];
+    x[c] = w * invp[c];
   }
-  for (int row = 0; row < di; ++row) {
-    double* v = rows + row * D;
-    double x[D];
 #pragma unroll
-    for (int c = 0; c < D; ++c) {
-      double w = v[c];
-#pragma unroll
-      for (int s = 0; s < c; ++s) w -= x[s] * a[c * D + s];
-      x[c] = w * inv[c];
-    }
-#pragma unroll
-    for (int c = 0; c < D; ++c) v[c] = x[c];
-  }
+  for (int c = 0; c < D; ++c) v[c] = x[c];
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -264,13 +249,17 @@ __device__ __forceinline__ void chol_piece(const BatchView& V, const CholView& C
   double* smInv = smY + Yp;
   int4* sBlk = reinterpret_cast<int4*>(smInv + Yp);   // {L offset, info, L offset of the column's diagonal block, y offset of the column} (piece-local)
   int4* sCol = sBlk + pm.nb;                           // {L offset of the diagonal block, dim, y offset, -}
-  ItemMeta* sItem = reinterpret_cast<ItemMeta*>(sCol + pm.nc);
-  double* part = reinterpret_cast<double*>(sItem + pm.nit_i);
+  ItemMeta* sItem = reinterpret_cast<ItemMeta*>(sCol + pm.nc);            // internal work items
+  UpdMeta* sUpd = reinterpret_cast<UpdMeta*>(sItem + pm.nit_i);            // internal update records
+  MbMeta* sMb = reinterpret_cast<MbMeta*>(sUpd + pm.nu_i);                 // internal multi-blocks
+  double* part = reinterpret_cast<double*>(sMb + pm.nimb);
   const double* __restrict__ H = V.Hpp_diag;
   const int ry = lane - 40;
   // ---- 0. tables and A(:, piece) + lambda I, rhs -> LDS (one wave per block, four blocks in flight per wave)
   for (int i = tid; i < pm.nilv; i += NT) s_lv[i] = C.ilv[pm.ilv0 + i];
   for (int i = tid; i < pm.nit_i; i += NT) sItem[i] = C.item[pm.iit0 + i];
+  for (int i = tid; i < pm.nu_i; i += NT) sUpd[i] = C.upd[pm.iu0 + i];
+  for (int i = tid; i < pm.nimb; i += NT) sMb[i] = C.mb[pm.imb0 + i];
   for (int c = tid; c < pm.nc; c += NT) {
     const ColMeta cm = C.col[pm.c0 + c];
     sCol[c] = make_int4(cm.base - pm.lbase, cm.dim, cm.yoff - pm.y0, 0);
@@ -322,10 +311,10 @@ __device__ __forceinline__ void chol_piece(const BatchView& V, const CholView& C
   for (int il = 0; il < pm.nilv; ++il) {
     const ILevel lv = s_lv[il];
     if (lv.it1 > lv.it0) {
-      run_items<NT>(sItem, lv.it0, lv.it1, C.upd, smL, smY, pm.lbase, pm.y0, smL, smY, part, tid);
+      run_items<NT>(sItem, lv.it0, lv.it1, sUpd, smL, smY, pm.lbase, pm.y0, smL, smY, part, tid);
       __syncthreads();
       if (lv.mb1 > lv.mb0) {
-        reduce_multi(C.mb, lv.mb0, lv.mb1, smL, smY, part, wave, lane, NW);
+        reduce_multi(sMb, lv.mb0, lv.mb1, smL, smY, part, wave, lane, NW);
         __syncthreads();
       }
     }
@@ -337,12 +326,13 @@ __device__ __forceinline__ void chol_piece(const BatchView& V, const CholView& C
       if (!ok) C.fail[g] = 1;
     }
     __syncthreads();
-    for (int b = lv.b0 - pm.b0 + tid; b < lv.b1 - pm.b0; b += NT) {
-      const int4 bm = sBlk[b];
-      if (bm.y & kBlkDiag) continue;
+    for (int t = tid; t < (lv.b1 - lv.b0) * 6; t += NT) {   // thread = (block, row)
+      const int b = t / 6, row = t - 6 * b;
+      const int4 bm = sBlk[lv.b0 - pm.b0 + b];
       const int di = bm.y & 15, dj = (bm.y >> 4) & 15;
-      if (dj == 6) row_solve<6>(smL + bm.x, di, smL + bm.z, smInv + bm.w);
-      else row_solve<3>(smL + bm.x, di, smL + bm.z, smInv + bm.w);
+      if ((bm.y & kBlkDiag) || row >= di) continue;
+      if (dj == 6) row_solve<6>(smL + bm.x + row * 6, smL + bm.z, smInv + bm.w);
+      else row_solve<3>(smL + bm.x + row * 3, smL + bm.z, smInv + bm.w);
     }
     __syncthreads();
   }
@@ -510,13 +500,14 @@ __global__ __launch_bounds__(64) void k_chol_forward_level(CholView C, int lvl_b
   const double* __restrict__ L = C.Lval;
   if (lane < dj) {
     double a = rhs[vo + cm.xoff + lane];
-    for (int u = cm.up0; u < cm.up1; ++u) {
-      const UpdMeta um = C.upd[u];
-      const int dk = (um.pk & kUpdDk6) ? 6 : 3;
-      const double* pa = L + um.ua + lane * dk;
-      const double* yk = y + vo + um.ux;
-      for (int q = 0; q < dk; ++q) a -= pa[q] * yk[q];
-    }
+    for (int part = 0; part < 2; ++part)
+      for (int u = part ? cm.ui0 : cm.up0; u < (part ? cm.ui1 : cm.up1); ++u) {
+        const UpdMeta um = C.upd[u];
+        const int dk = (um.pk & kUpdDk6) ? 6 : 3;
+        const double* pa = L + um.ua + lane * dk;
+        const double* yk = y + vo + um.ux;
+        for (int q = 0; q < dk; ++q) a -= pa[q] * yk[q];
+      }
     t[lane] = a;
   }
   __syncthreads();

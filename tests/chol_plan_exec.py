@@ -8,14 +8,14 @@ import ctypes as C
 
 import numpy as np
 
-COL = np.dtype([(n, "<i4") for n in ("xoff", "yoff", "dim", "graph", "b0", "nb", "nbi", "base", "up0", "up1", "piece", "ilevel")])
+COL = np.dtype([(n, "<i4") for n in ("xoff", "yoff", "dim", "graph", "b0", "nb", "nbi", "base", "up0", "up1", "ui0", "ui1", "piece", "ilevel", "pad0", "pad1")])
 BLK = np.dtype([(n, "<i4") for n in ("off", "src", "xoff_row", "yoff_row", "coldiag", "colyoff", "info", "pad")])
 UPD = np.dtype([(n, "<i4") for n in ("ua", "ub", "ux", "pk")])
 ITEM = np.dtype([(n, "<i4") for n in ("u0", "n", "tloff", "flags")])
 MB = np.dtype([(n, "<i4") for n in ("tloff", "ps0", "n", "info")])
 ILV = np.dtype([(n, "<i4") for n in ("c0", "c1", "b0", "b1", "it0", "it1", "mb0", "mb1")])
 PIECE = np.dtype([(n, "<i4") for n in ("graph", "c0", "nc", "b0", "nb", "lbase", "lsize", "y0", "ysize", "eit0", "enit", "emb0", "nemb",
-                                       "ilv0", "nilv", "iit0", "nit_i", "pad")])
+                                       "ilv0", "nilv", "iit0", "nit_i", "iu0", "nu_i", "imb0", "nimb", "pad0", "pad1", "pad2")])
 K_DI6, K_DK6, K_DIAG, K_DJ6 = 1 << 20, 1 << 21, 1 << 22, 1 << 23
 B_FMT, B_DIAG, B_ROWIN = 1 << 8, 1 << 9, 1 << 10
 
@@ -80,9 +80,10 @@ class Plan:
             ok &= self._factor_piece(self.piece[p], Hdev, bvec, lam, Lval, y)
         return Lval, y, ok
 
-    def _run_items(self, items, Ls, Ys, lofs, yofs, smL, smY, part):
+    def _run_items(self, items, upd, Ls, Ys, lofs, yofs, smL, smY, part):
         for im in items:
-            u = self.upd[im["u0"]:im["u0"] + im["n"]]
+            u = upd[im["u0"]:im["u0"] + im["n"]]
+            assert len(u) == im["n"]
             pk0 = int(u[0]["pk"])
             di = 6 if pk0 & K_DI6 else 3
             dj = 6 if pk0 & K_DJ6 else 3
@@ -133,13 +134,15 @@ class Plan:
                 assert bm["off"] == bm["coldiag"]
                 smY[bm["colyoff"] - y0:bm["colyoff"] - y0 + dj] = bvec[bm["xoff_row"]:bm["xoff_row"] + dj]
             smL[bm["off"] - lbase:bm["off"] - lbase + di * dj] = v.ravel()
-        self._run_items(self.item[pm["eit0"]:pm["eit0"] + pm["enit"]], Lval, y, 0, 0, smL, smY, part)
+        self._run_items(self.item[pm["eit0"]:pm["eit0"] + pm["enit"]], self.upd, Lval, y, 0, 0, smL, smY, part)
+        sUpd = self.upd[pm["iu0"]:pm["iu0"] + pm["nu_i"]]          # the LDS copies the kernel makes
+        sMb = self.mb[pm["imb0"]:pm["imb0"] + pm["nimb"]]
         self._reduce(self.mb[pm["emb0"]:pm["emb0"] + pm["nemb"]], smL, smY, part)
         ok = True
         for lv in self.ilv[pm["ilv0"]:pm["ilv0"] + pm["nilv"]]:
             part = {}
-            self._run_items(self.item[pm["iit0"] + lv["it0"]:pm["iit0"] + lv["it1"]], smL, smY, lbase, y0, smL, smY, part)
-            self._reduce(self.mb[lv["mb0"]:lv["mb1"]], smL, smY, part)
+            self._run_items(self.item[pm["iit0"] + lv["it0"]:pm["iit0"] + lv["it1"]], sUpd, smL, smY, lbase, y0, smL, smY, part)
+            self._reduce(sMb[lv["mb0"]:lv["mb1"]], smL, smY, part)
             for cm in self.col[lv["c0"]:lv["c1"]]:
                 d = int(cm["dim"]); o = cm["base"] - lbase; yl = cm["yoff"] - y0
                 S = smL[o:o + d * d].reshape(d, d)

@@ -90,7 +90,8 @@ def _structure_invariants(plan):
                 if p in depth_of:   # pieces that share a launch must not feed each other
                     assert q in depth_of and depth_of[q] < depth_of[p]
         for im in plan.item[pm["iit0"]:pm["iit0"] + pm["nit_i"]]:
-            for r in plan.upd[im["u0"]:im["u0"] + im["n"]]:
+            assert 0 <= im["u0"] and im["u0"] + im["n"] <= pm["nu_i"]
+            for r in plan.upd[pm["iu0"] + im["u0"]:pm["iu0"] + im["u0"] + im["n"]]:
                 assert pm["lbase"] <= r["ua"] < pm["lbase"] + pm["lsize"] and pm["lbase"] <= r["ub"] < pm["lbase"] + pm["lsize"]
     # LDS budgets stay below the hardware's 160 KiB
     lds = [int(v) for v in plan.plv_lds_f] + [int(v) for v in plan.plv_lds_b] + [plan.tail_lds_f, plan.tail_lds_b]
