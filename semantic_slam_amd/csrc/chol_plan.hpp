@@ -5,17 +5,21 @@
 //
 // MI355X design.  The block elimination tree of a SLAM graph is bushy at the bottom and a long chain at the top
 // (151 levels for the 5000-pose / 1000-landmark graph), and one numeric factorisation is only ~25 MFLOP / 7.5 MB per
-// graph: a launch per level is all latency.  The tree is therefore cut into *pieces* -- connected sets of columns
-// (a subtree minus the pieces hanging below it) whose part of L fits in the LDS of one workgroup:
-//   * a piece is factored by ONE workgroup: its columns are gathered into LDS, the updates whose source columns lie
-//     in lower pieces ("external", already final in HBM) are applied in one massively parallel phase, and the
-//     levels *inside* the piece then run out of LDS with workgroup barriers between them -- no launch, no HBM latency;
+// graph: a launch per level is all latency, and so is every dependent trip to HBM.  The tree is therefore cut into
+// *pieces* -- connected sets of columns (a subtree minus the pieces hanging below it) whose part of L fits in the LDS of
+// one workgroup -- and the pieces talk to each other the multifrontal way:
+//   * a piece is factored by ONE workgroup.  Its columns are gathered into LDS (A + lambda I minus the update-matrix
+//     blocks its child pieces left for it: coalesced 288-byte reads, no arithmetic), the levels *inside* the piece run
+//     out of LDS with workgroup barriers between them, and L leaves as one contiguous stream;
+//   * every update  S(i,j) -= L(i,k) L(j,k)^T  is computed exactly once, in the piece that owns the SOURCE column k, from
+//     LDS.  Updates whose target column lies in a higher piece are summed into the piece's *update matrix* U over its
+//     boundary rows (plus whatever its children handed up for the same block) and written to HBM once; the parent either
+//     absorbs a U block into its own column or passes it further up;
 //   * pieces of equal depth in the piece tree share a launch (a handful of launches instead of 151); once a graph is
 //     down to a few pieces per depth, the rest ("tail") is walked by one workgroup per graph in a single launch;
-//   * L is laid out piece by piece, columns of a piece by internal level: a piece is one contiguous, coalesced
-//     stream in both directions, so HBM sees H read once and L written once;
+//   * L is laid out piece by piece, columns of a piece by internal level;
 //   * updates are cut into work items of <= chunk consecutive updates of ONE target block; an item is executed by
-//     four lanes holding the 3x3 tiles of the target.  A target with a single item is subtracted in place ("sole"),
+//     four lanes holding the 3x3 tiles of the target.  A target with a single item is finished in place ("sole"),
 //     longer lists go through per-item partial tiles that are summed in item order -> deterministic.
 // The backward substitution walks the same pieces top-down.
 #pragma once
@@ -33,37 +37,47 @@
 
 namespace sslam {
 
-struct ColMeta { int xoff, yoff, dim, graph, b0, nb, nbi, base, up0, up1, ui0, ui1, piece, ilevel, pad0, pad1; };
+struct ColMeta { int xoff, yoff, dim, graph, b0, nb, nbi, base, f0, f1, piece, ilevel; };
 // xoff: offset in the unknown vector (internal row order); yoff: offset in elimination order (the forward-substituted
 // rhs y lives in that order so that a piece's y is contiguous); blocks [b0, b0 + nb), diagonal first, the first nbi
 // (diagonal included) have their row inside the column's own piece; base = Lval offset of the diagonal block;
-// [up0, up1) + [ui0, ui1) = updates of the diagonal block with sources outside / inside the column's piece (forward substitution
-// of the multi right-hand-side solves)
+// [f0, f1) = the blocks of ROW j (FwdMeta), for the forward substitution of the multi right-hand-side solves
 
-struct BlkMeta { int off, src, xoff_row, yoff_row, coldiag, colyoff, info, pad; };
+struct BlkMeta { int off, src, xoff_row, yoff_row, coldiag, colyoff, info, as0; };
 // off: Lval offset; src: H offset or -1; x / y offsets of the block's row; Lval offset of the diagonal block and y offset of
-// the block's column; info = di | dj << 4 | fmt << 8 | diag << 9 | row-in-piece << 10
-constexpr int kBlkFmt = 1 << 8, kBlkDiag = 1 << 9, kBlkRowIn = 1 << 10;
+// the block's column; info = di | dj << 4 | fmt << 8 | diag << 9 | row-in-piece << 10 | nas << 16; [as0, as0 + nas) = the child
+// update-matrix blocks to subtract when the block is gathered (piece-local index into the piece's AsmSrc records)
+constexpr int kBlkFmt = 1 << 8, kBlkDiag = 1 << 9, kBlkRowIn = 1 << 10, kBlkNasShift = 16;
+
+struct AsmSrc { int uoff, uyoff; };      // an update-matrix block of a child piece (Uval offset); uyoff >= 0: its rhs part too (diagonal blocks)
+struct FwdMeta { int off, yoff; };       // block L(j,k) of row j: Lval offset | (dim k == 6) << 31, y offset of column k
 
 struct UpdMeta { int ua, ub, ux, pk; };  // Lval offsets of L_ik, L_jk; y offset (elimination order) of y_k; flags below
 constexpr int kUpdDi6 = 1 << 20;         // target block has 6 rows (else 3)
 constexpr int kUpdDk6 = 1 << 21;         // source column k is 6 wide (else 3)
-constexpr int kUpdDiag = 1 << 22;        // target is the diagonal block (carries the forward-substitution rhs too)
+constexpr int kUpdDiag = 1 << 22;        // target is a diagonal block (carries the forward-substitution rhs too)
 constexpr int kUpdDj6 = 1 << 23;         // target column is 6 wide (else 3)
 
-struct ItemMeta { int u0, n, tloff, flags; };   // updates [u0, u0 + n) of one target block at piece-local offset tloff; u0 indexes upd[] for
-                                                // an external item and the piece's internal update records (LDS copy) for an internal one
+struct ItemMeta { int u0, n, tloff, flags; };   // updates [u0, u0 + n) (index into the piece's update records, LDS copy) of one target
+                                                // block at piece-local offset tloff
 constexpr int kItemSole = 1;                     // flags: bit 0 sole (subtract in place); bits 1..11 partial slot; bits 12.. local y offset
 constexpr int kItemSlotShift = 1, kItemSlotMask = 0x7FF, kItemYShift = 12;
 struct MbMeta { int tloff, ps0, n, info; };      // a target block with n > 1 items: partial slots [ps0, ps0 + n); info = di | dj << 4 | diag << 9 | ylocal << 12
 struct ILevel { int c0, c1, b0, b1, it0, it1, mb0, mb1; };   // one level inside a piece: columns, blocks (global ids), items and multi-blocks (piece-local)
-struct PieceMeta { int graph, c0, nc, b0, nb, lbase, lsize, y0, ysize, eit0, enit, emb0, nemb, ilv0, nilv, iit0, nit_i, iu0, nu_i, imb0, nimb, pad0, pad1, pad2; };
-// external phase: items [eit0, +enit), multi-blocks [emb0, +nemb); internal: items [iit0, +nit_i), update records [iu0, +nu_i),
-// multi-blocks [imb0, +nimb) -- all three copied to LDS when the piece starts, so that the levels inside a piece never wait for HBM
+
+// update-matrix side: a block U(a,b) of the piece = sum of its own updates [u0, u0 + n) (upd[], sources in the piece) + the
+// child blocks [s0, s0 + ns) (usrc[]); written to Uval[uoff ...] (and the rhs part to Uval[uyoff ...] for a diagonal block)
+struct UItem { int u0, n, uoff, flags, s0, ns, uyoff, pad; };   // flags: bit 0 sole; bits 1..11 partial slot; bit 12 di == 6; bit 13 dj == 6; bit 14 diag
+constexpr int kUItemDi6 = 1 << 12, kUItemDj6 = 1 << 13, kUItemDiag = 1 << 14;
+struct UMb { int uoff, ps0, n, info, s0, ns, uyoff, pad; };     // a U block whose own list was split: info = di | dj << 4 | diag << 9
+
+struct PieceMeta { int graph, c0, nc, b0, nb, lbase, lsize, y0, ysize, ilv0, nilv, iit0, nit_i, iu0, nu_i, imb0, nimb, as0, nas, uit0, nuit, umb0, numb, pad; };
+// inside the piece (all copied to LDS when the piece starts, so that its levels never wait for HBM): levels [ilv0, +nilv), items
+// [iit0, +nit_i), update records [iu0, +nu_i), multi-blocks [imb0, +nimb), assembly sources [as0, +nas);
+// update matrix: U items [uit0, +nuit), split U blocks [umb0, +numb)
 
 constexpr int kItemDoubles = 42;     // LDS doubles per partial tile: 6 x 6 entries + 6 rhs components
 constexpr int kMaxILevels = 64;      // internal levels per piece (LDS table in the kernels)
-constexpr int kMinChunk = 4;         // a list of <= kMinChunk updates is never split
 
 struct SymGraph { int prow0, nprow, lrow0, nlrow; };
 struct SymIn {
@@ -78,12 +92,15 @@ struct CholOpts {
   int max_blocks = 224;    // blocks per piece
   int tail_width = -1;     // a graph's tail starts where it has <= tail_width pieces per depth; -1: 6 for batches >= 32, else 2; 0: no tail
   int nt_leaf = 256, nt_tail = 512;   // workgroup sizes the items are cut for
+  int min_chunk = 4;       // a list of <= min_chunk updates is never split
+  int pcap_leaf = 16, pcap_tail = 64;   // partial tiles per phase (split lists): LDS budget of a piece
   bool dump = false;
   static int env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
   void from_env() {
     cap_leaf = env_int("SSLAM_CHOL_CAP_LEAF", cap_leaf); cap_tail = env_int("SSLAM_CHOL_CAP_TAIL", cap_tail);
     max_blocks = env_int("SSLAM_CHOL_MAX_BLOCKS", max_blocks); tail_width = env_int("SSLAM_CHOL_TAIL_WIDTH", tail_width);
-    nt_tail = env_int("SSLAM_CHOL_NT_TAIL", nt_tail);
+    nt_tail = env_int("SSLAM_CHOL_NT_TAIL", nt_tail); min_chunk = std::max(1, env_int("SSLAM_CHOL_MIN_CHUNK", min_chunk));
+    pcap_leaf = env_int("SSLAM_CHOL_PCAP_LEAF", pcap_leaf); pcap_tail = env_int("SSLAM_CHOL_PCAP_TAIL", pcap_tail);
     dump = getenv("SSLAM_CHOL_DUMP") != nullptr;
   }
 };
@@ -91,8 +108,10 @@ struct CholOpts {
 struct CholHost {
   int ncol = 0, nlevels = 0, dim = 0, B = 0, npiece = 0;
   int64_t lnz = 0;           // doubles in Lval
+  int64_t unz = 0;           // doubles in Uval (update matrices handed between pieces)
   std::vector<ColMeta> col; std::vector<BlkMeta> blk; std::vector<UpdMeta> upd; std::vector<ItemMeta> item; std::vector<MbMeta> mb;
   std::vector<ILevel> ilv; std::vector<PieceMeta> piece;
+  std::vector<AsmSrc> asrc, usrc; std::vector<FwdMeta> fwd; std::vector<UItem> uitem; std::vector<UMb> umb;
   std::vector<int> lvl_ptr, lvl_cols;       // column levels of the elimination tree (multi right-hand-side solves)
   std::vector<int> plv_ptr, plv_pieces;     // pieces grouped by depth (one launch each)
   std::vector<int> tail_ptr, tail_pieces;   // per graph: its tail pieces in elimination order
@@ -345,21 +364,7 @@ inline int chol_symbolic(const SymIn& in, CholOpts opt, CholHost& out) {
   bp[ncol] = (int)boff.size();
   const int nblk = (int)boff.size();
   out.lnz = lnz;
-  // ---- update lists: column k updates every (i, j) pair of its structure with pos(j) <= pos(i) ---------------------------
-  std::vector<std::vector<std::array<int, 3>>> ulist(nblk);
-  for (int k = 0; k < ncol; ++k) {
-    const int k0 = bp[k] + 1, k1 = bp[k + 1];
-    for (int p = k0; p < k1; ++p) {
-      const int j = brow[p];
-      for (int q = p; q < k1; ++q) {
-        const int i = brow[q];
-        auto it = colblk[j].find(i);
-        if (it == colblk[j].end()) { out.error = "symbolic factorisation inconsistent (missing fill block)"; return -1; }
-        ulist[it->second].push_back({boff[q], boff[p], k});
-      }
-    }
-  }
-  // ---- levels of the block elimination tree (multi right-hand-side solves) ---------------------------------------------
+  // ---- levels of the block elimination tree (multi right-hand-side solves) and inside the pieces --------------------------
   std::vector<int> level(ncol, 0), col_il(ncol, 0);
   int nlev = 0;
   for (int j = 0; j < ncol; ++j) {
@@ -379,10 +384,10 @@ inline int chol_symbolic(const SymIn& in, CholOpts opt, CholHost& out) {
     std::vector<int> cursor(out.lvl_ptr.begin(), out.lvl_ptr.end() - 1);
     for (int j = 0; j < ncol; ++j) out.lvl_cols[cursor[level[j]]++] = j;
   }
-  // ---- pieces: column / block ranges (contiguous by construction) --------------------------------------------------------
+  // ---- pieces: column / block ranges (contiguous by construction), parent piece, depth ----------------------------------------
   out.piece.assign(npiece, PieceMeta{});
   std::vector<char> piece_tail(npiece, 0);
-  for (int p = 0; p < npiece; ++p) out.piece[p].nc = 0;
+  std::vector<int> piece_parent(npiece, -1);
   for (int j = 0; j < ncol; ++j) {
     PieceMeta& pm = out.piece[col_piece[j]];
     if (pm.nc == 0) { pm.graph = col_graph[j]; pm.c0 = j; pm.b0 = bp[j]; pm.lbase = boff[bp[j]]; pm.y0 = col_yoff[j]; }
@@ -393,28 +398,20 @@ inline int chol_symbolic(const SymIn& in, CholOpts opt, CholHost& out) {
     const int last = bp[j + 1] - 1;
     pm.lsize = boff[last] + col_dim[brow[last]] * col_dim[j] - pm.lbase;
     piece_tail[col_piece[j]] = (char)col_tail[j];
-  }
-  // depth of the non-tail pieces in the piece tree
-  std::vector<int> plev(npiece, 0);
-  for (int j = 0; j < ncol; ++j)
     if (bp[j + 1] - bp[j] > 1) {
-      const int par = brow[bp[j] + 1];
-      const int pj = col_piece[j], pp = col_piece[par];
-      if (pp != pj) plev[pp] = std::max(plev[pp], plev[pj] + 1);   // pieces are in elimination order: children are final before their parents' columns are visited
-    }
-  {
-    // (a parent piece may have been reached through an earlier column before a deeper child was visited: fix-point over the ordered pieces)
-    bool changed = true;
-    while (changed) {
-      changed = false;
-      for (int j = 0; j < ncol; ++j)
-        if (bp[j + 1] - bp[j] > 1) {
-          const int par = brow[bp[j] + 1];
-          const int pj = col_piece[j], pp = col_piece[par];
-          if (pp != pj && plev[pp] < plev[pj] + 1) { plev[pp] = plev[pj] + 1; changed = true; }
-        }
+      const int pp = col_piece[brow[bp[j] + 1]];
+      if (pp != col_piece[j]) {
+        if (piece_parent[col_piece[j]] >= 0 && piece_parent[col_piece[j]] != pp) { out.error = "a piece has two parents"; return -1; }
+        piece_parent[col_piece[j]] = pp;
+      }
     }
   }
+  std::vector<int> plev(npiece, 0);
+  for (int p = 0; p < npiece; ++p)   // ascending id = elimination order: a child is final before its parent is visited
+    if (piece_parent[p] >= 0) {
+      if (piece_parent[p] <= p) { out.error = "pieces are not in elimination order"; return -1; }
+      plev[piece_parent[p]] = std::max(plev[piece_parent[p]], plev[p] + 1);
+    }
   int nplv = 0;
   for (int p = 0; p < npiece; ++p) if (!piece_tail[p]) nplv = std::max(nplv, plev[p] + 1);
   out.plv_ptr.assign(nplv + 1, 0);
@@ -433,126 +430,230 @@ inline int chol_symbolic(const SymIn& in, CholOpts opt, CholHost& out) {
     std::vector<int> cursor(out.tail_ptr.begin(), out.tail_ptr.end() - 1);
     for (int p = 0; p < npiece; ++p) if (piece_tail[p]) out.tail_pieces[cursor[out.piece[p].graph]++] = p;   // ascending id = elimination order
   }
-  // ---- columns, blocks; update records piece by piece: all external updates of the piece (block order), then all internal ones
+  // ---- columns, blocks, rows (forward lists) ------------------------------------------------------------------------------------
   out.col.assign(ncol, ColMeta{});
   out.blk.assign(nblk, BlkMeta{});
-  std::vector<int> be0(nblk, 0), be1(nblk, 0), bi0(nblk, 0), bi1(nblk, 0);   // per block: external / internal update ranges in upd[]
-  out.upd.clear();
+  std::vector<int> block_col(nblk), col_nbi(ncol, 0);
   {
-    size_t total = 0;
-    for (int t = 0; t < nblk; ++t) total += ulist[t].size();
-    out.upd.reserve(total);
-  }
-  for (int j = 0; j < ncol; ++j) {
-    const int pj = col_piece[j];
-    int nbi = 0;
-    for (int t = bp[j]; t < bp[j + 1]; ++t) if (col_piece[brow[t]] == pj) ++nbi;   // rows sorted by position: in-piece rows come first
-    for (int t = bp[j]; t < bp[j] + nbi; ++t) if (col_piece[brow[t]] != pj) { out.error = "in-piece rows of a column are not a prefix"; return -1; }
-    out.col[j] = ColMeta{col_xoff[j], col_yoff[j], col_dim[j], col_graph[j], bp[j], bp[j + 1] - bp[j], nbi, boff[bp[j]], 0, 0, 0, 0, pj, col_il[j], 0, 0};
-    for (int t = bp[j]; t < bp[j + 1]; ++t) {
-      const int i = brow[t];
-      BlkMeta& bm = out.blk[t];
-      bm.off = boff[t]; bm.src = bsrc[t];
-      bm.xoff_row = col_xoff[i]; bm.yoff_row = col_yoff[i]; bm.coldiag = boff[bp[j]]; bm.colyoff = col_yoff[j]; bm.pad = 0;
-      bm.info = col_dim[i] | (col_dim[j] << 4) | (bfmt[t] ? kBlkFmt : 0) | (t == bp[j] ? kBlkDiag : 0) | (col_piece[i] == pj ? kBlkRowIn : 0);
+    std::vector<int> rowcnt(ncol + 1, 0);
+    for (int j = 0; j < ncol; ++j) for (int t = bp[j] + 1; t < bp[j + 1]; ++t) rowcnt[brow[t] + 1]++;
+    for (int j = 0; j < ncol; ++j) rowcnt[j + 1] += rowcnt[j];
+    out.fwd.resize(rowcnt[ncol]);
+    std::vector<int> cursor(rowcnt.begin(), rowcnt.end() - 1);
+    for (int j = 0; j < ncol; ++j) {
+      const int pj = col_piece[j];
+      int nbi = 0;
+      for (int t = bp[j]; t < bp[j + 1]; ++t) if (col_piece[brow[t]] == pj) ++nbi;   // rows sorted by position: in-piece rows come first
+      for (int t = bp[j]; t < bp[j] + nbi; ++t) if (col_piece[brow[t]] != pj) { out.error = "in-piece rows of a column are not a prefix"; return -1; }
+      col_nbi[j] = nbi;
+      out.col[j] = ColMeta{col_xoff[j], col_yoff[j], col_dim[j], col_graph[j], bp[j], bp[j + 1] - bp[j], nbi, boff[bp[j]], rowcnt[j], rowcnt[j + 1], pj, col_il[j]};
+      for (int t = bp[j]; t < bp[j + 1]; ++t) {
+        const int i = brow[t];
+        block_col[t] = j;
+        BlkMeta& bm = out.blk[t];
+        bm.off = boff[t]; bm.src = bsrc[t];
+        bm.xoff_row = col_xoff[i]; bm.yoff_row = col_yoff[i]; bm.coldiag = boff[bp[j]]; bm.colyoff = col_yoff[j]; bm.as0 = 0;
+        bm.info = col_dim[i] | (col_dim[j] << 4) | (bfmt[t] ? kBlkFmt : 0) | (t == bp[j] ? kBlkDiag : 0) | (col_piece[i] == pj ? kBlkRowIn : 0);
+        if (t > bp[j]) out.fwd[cursor[i]++] = FwdMeta{boff[t] | (col_dim[j] == 6 ? (int)0x80000000u : 0), col_yoff[j]};   // columns ascend: row lists sorted by k
+      }
     }
   }
-  for (int p = 0; p < npiece; ++p) {
-    PieceMeta& pm = out.piece[p];
-    for (int pass = 0; pass < 2; ++pass) {
-      if (pass == 1) pm.iu0 = (int)out.upd.size();
-      for (int j = pm.c0; j < pm.c0 + pm.nc; ++j)
-        for (int t = bp[j]; t < bp[j + 1]; ++t) {
-          const int tpk = (col_dim[brow[t]] == 6 ? kUpdDi6 : 0) | (t == bp[j] ? kUpdDiag : 0) | (col_dim[j] == 6 ? kUpdDj6 : 0);
-          (pass == 0 ? be0 : bi0)[t] = (int)out.upd.size();
-          for (auto& u : ulist[t]) {   // ascending in k
-            if ((int)(col_piece[u[2]] == p) != pass) continue;
-            out.upd.push_back(UpdMeta{u[0], u[1], col_yoff[u[2]], tpk | (col_dim[u[2]] == 6 ? kUpdDk6 : 0)});
-          }
-          (pass == 0 ? be1 : bi1)[t] = (int)out.upd.size();
-          if (pass == 1) std::vector<std::array<int, 3>>().swap(ulist[t]);
-        }
-    }
-    pm.nu_i = (int)out.upd.size() - pm.iu0;
-  }
-  for (int j = 0; j < ncol; ++j) { out.col[j].up0 = be0[bp[j]]; out.col[j].up1 = be1[bp[j]]; out.col[j].ui0 = bi0[bp[j]]; out.col[j].ui1 = bi1[bp[j]]; }
-  // ---- work items per piece: the external phase, then one phase per internal level -----------------------------------------
-  std::vector<int> block_col(nblk);
-  for (int j = 0; j < ncol; ++j) for (int t = bp[j]; t < bp[j + 1]; ++t) block_col[t] = j;
-  out.item.clear(); out.mb.clear(); out.ilv.clear();
+  // ---- piece by piece (elimination order: children before parents): internal updates, update matrix, assembly -------------------------
+  struct URec { int a, b, uoff; };                    // finished update-matrix block (row column-ids a >= b)
+  std::vector<std::vector<URec>> piece_u(npiece);     // kept until the parent has consumed them
+  std::vector<std::vector<int>> piece_R(npiece);      // boundary rows (column ids, ascending)
+  std::vector<int> piece_uy(npiece, 0);               // Uval offset of the piece's rhs part [|R|][6]
+  std::vector<std::vector<int>> kids(npiece);
+  for (int p = 0; p < npiece; ++p) if (piece_parent[p] >= 0) kids[piece_parent[p]].push_back(p);
+  out.upd.clear(); out.item.clear(); out.mb.clear(); out.ilv.clear(); out.asrc.clear(); out.usrc.clear(); out.uitem.clear(); out.umb.clear();
   std::vector<int> piece_pmax(npiece, 0);   // most partial tiles any phase of the piece needs
+  int64_t ucur = 0;
   for (int p = 0; p < npiece; ++p) {
     PieceMeta& pm = out.piece[p];
     const int nt = piece_tail[p] ? opt.nt_tail : opt.nt_leaf;
     const int slots = nt / 4;
-    const int pcap = std::min(slots, kItemSlotMask);
-    // one phase over the blocks [b_begin, b_end): part 0 = external updates [up0, upx), part 1 = internal [upx, up1);
-    // item indices of part 1 are piece-local (the internal items of a piece are copied to LDS)
-    auto build_phase = [&](int b_begin, int b_end, int part, int& mb0, int& mb1) {
-      auto count = [&](int t) { return part == 0 ? be1[t] - be0[t] : bi1[t] - bi0[t]; };
-      int U = 0;
-      for (int t = b_begin; t < b_end; ++t) U += count(t);
-      int chunk = std::max(kMinChunk, (U + slots - 1) / slots);
-      for (;; ++chunk) {   // raise the chunk until the partial tiles of the split lists fit the LDS budget
-        int nonsole = 0;
-        for (int t = b_begin; t < b_end; ++t) { const int k = (count(t) + chunk - 1) / chunk; if (k > 1) nonsole += k; }
-        if (nonsole <= pcap || chunk >= std::max(U, 1)) break;
-      }
-      mb0 = (int)out.mb.size() - (part == 0 ? 0 : pm.imb0);   // internal multi-blocks are indexed piece-locally
-      int ps = 0;
-      for (int t = b_begin; t < b_end; ++t) {
-        const BlkMeta& bm = out.blk[t];
-        const int u0 = part == 0 ? be0[t] : bi0[t] - pm.iu0, u1 = part == 0 ? be1[t] : bi1[t] - pm.iu0;   // internal: piece-local (LDS copy)
-        const int n = u1 - u0;
-        if (n <= 0) continue;
-        const int k = (n + chunk - 1) / chunk;
-        const int tloff = bm.off - pm.lbase;
-        const int ylocal = out.col[block_col[t]].yoff - pm.y0;
-        for (int q = 0; q < k; ++q) {
-          const int a = u0 + q * chunk, b2 = std::min(u1, a + chunk);
-          int flags = ylocal << kItemYShift;
-          if (k == 1) flags |= kItemSole; else flags |= (ps + q) << kItemSlotShift;
-          out.item.push_back(ItemMeta{a, b2 - a, tloff, flags});
-        }
-        if (k > 1) {
-          out.mb.push_back(MbMeta{tloff, ps, k, (bm.info & 0xFF) | (bm.info & kBlkDiag) | (ylocal << 12)});
-          ps += k;
-        }
-      }
-      mb1 = (int)out.mb.size() - (part == 0 ? 0 : pm.imb0);
-      piece_pmax[p] = std::max(piece_pmax[p], ps);
+    const int pcap = piece_tail[p] ? opt.pcap_tail : opt.pcap_leaf;   // partial tiles a phase may use (LDS: 336 B each)
+    // boundary rows
+    std::vector<int>& R = piece_R[p];
+    for (int j = pm.c0; j < pm.c0 + pm.nc; ++j) for (int t = bp[j] + col_nbi[j]; t < bp[j + 1]; ++t) R.push_back(brow[t]);
+    std::sort(R.begin(), R.end());
+    R.erase(std::unique(R.begin(), R.end()), R.end());
+    // update-matrix blocks under construction
+    struct UB { int a, b; std::vector<std::array<int, 3>> own; std::vector<AsmSrc> src; };
+    std::vector<UB> ub;
+    std::unordered_map<uint64_t, int> ubidx;
+    auto ublock = [&](int a, int b2) -> UB& {
+      auto it = ubidx.find(key(a, b2));
+      if (it != ubidx.end()) return ub[it->second];
+      ubidx.emplace(key(a, b2), (int)ub.size());
+      ub.push_back(UB{a, b2, {}, {}});
+      return ub.back();
     };
-    int mb0, mb1;
-    pm.eit0 = (int)out.item.size();
-    build_phase(pm.b0, pm.b0 + pm.nb, 0, mb0, mb1);
-    pm.enit = (int)out.item.size() - pm.eit0; pm.emb0 = mb0; pm.nemb = mb1 - mb0;
+    // internal updates (target column in the piece) and own update-matrix contributions (both rows above the piece)
+    struct IU { int ua, ub2, k; };
+    std::unordered_map<int, std::vector<IU>> iul;   // target block -> internal updates, ascending k
+    for (int k = pm.c0; k < pm.c0 + pm.nc; ++k) {
+      const int k0 = bp[k] + 1, kin = bp[k] + col_nbi[k], k1 = bp[k + 1];
+      for (int pp = k0; pp < k1; ++pp) {
+        const int j = brow[pp];
+        if (pp < kin) {
+          for (int q = pp; q < k1; ++q) {
+            auto it = colblk[j].find(brow[q]);
+            if (it == colblk[j].end()) { out.error = "symbolic factorisation inconsistent (missing fill block)"; return -1; }
+            iul[it->second].push_back(IU{boff[q], boff[pp], k});
+          }
+        } else {
+          for (int q = pp; q < k1; ++q) ublock(brow[q], j).own.push_back({boff[q], boff[pp], k});
+        }
+      }
+    }
+    // what the children hand up: absorbed into a column of this piece (assembly) or passed on (update matrix)
+    std::unordered_map<int, std::vector<AsmSrc>> asml;   // target block -> child blocks
+    for (int c : kids[p]) {
+      const std::vector<int>& Rc = piece_R[c];
+      for (const URec& u : piece_u[c]) {
+        int uy = -1;
+        if (u.a == u.b) uy = piece_uy[c] + 6 * (int)(std::lower_bound(Rc.begin(), Rc.end(), u.a) - Rc.begin());
+        if (col_piece[u.b] == p) {
+          auto it = colblk[u.b].find(u.a);
+          if (it == colblk[u.b].end()) { out.error = "update-matrix block without a target"; return -1; }
+          asml[it->second].push_back(AsmSrc{u.uoff, uy});
+        } else {
+          if (col_piece[u.a] == p) { out.error = "update-matrix block with its row inside the piece but its column above"; return -1; }
+          ublock(u.a, u.b).src.push_back(AsmSrc{u.uoff, uy});
+        }
+      }
+      std::vector<URec>().swap(piece_u[c]);
+    }
+    // assembly records, block order
+    pm.as0 = (int)out.asrc.size();
+    for (int t = pm.b0; t < pm.b0 + pm.nb; ++t) {
+      auto it = asml.find(t);
+      if (it == asml.end()) continue;
+      if (it->second.size() > 255) { out.error = "a block has more than 255 assembly sources"; return -1; }
+      out.blk[t].as0 = (int)out.asrc.size() - pm.as0;
+      out.blk[t].info |= (int)it->second.size() << kBlkNasShift;
+      for (auto& a2 : it->second) out.asrc.push_back(a2);
+    }
+    pm.nas = (int)out.asrc.size() - pm.as0;
+    // internal update records of the piece, level by level / block by block; internal items
+    pm.iu0 = (int)out.upd.size();
+    std::vector<int> bi0(pm.nb, 0), bi1(pm.nb, 0);
+    for (int t = pm.b0; t < pm.b0 + pm.nb; ++t) {
+      const int j = block_col[t];
+      const int tpk = (col_dim[brow[t]] == 6 ? kUpdDi6 : 0) | (t == bp[j] ? kUpdDiag : 0) | (col_dim[j] == 6 ? kUpdDj6 : 0);
+      bi0[t - pm.b0] = (int)out.upd.size() - pm.iu0;
+      auto it = iul.find(t);
+      if (it != iul.end())
+        for (auto& u : it->second) out.upd.push_back(UpdMeta{u.ua, u.ub2, col_yoff[u.k], tpk | (col_dim[u.k] == 6 ? kUpdDk6 : 0)});
+      bi1[t - pm.b0] = (int)out.upd.size() - pm.iu0;
+    }
+    pm.nu_i = (int)out.upd.size() - pm.iu0;
     pm.iit0 = (int)out.item.size();
     pm.imb0 = (int)out.mb.size();
     pm.ilv0 = (int)out.ilv.size();
-    int c = pm.c0;
-    const int cend = pm.c0 + pm.nc;
-    while (c < cend) {
-      int c1 = c;
-      while (c1 < cend && col_il[c1] == col_il[c]) ++c1;
-      if (col_il[c] != (int)out.ilv.size() - pm.ilv0) { out.error = "internal levels of a piece are not contiguous"; return -1; }
-      ILevel lv{};
-      lv.c0 = c; lv.c1 = c1; lv.b0 = bp[c]; lv.b1 = bp[c1];
-      lv.it0 = (int)out.item.size() - pm.iit0;
-      build_phase(lv.b0, lv.b1, 1, lv.mb0, lv.mb1);
-      lv.it1 = (int)out.item.size() - pm.iit0;
-      out.ilv.push_back(lv);
-      c = c1;
+    {
+      int c = pm.c0;
+      const int cend = pm.c0 + pm.nc;
+      while (c < cend) {
+        int c1 = c;
+        while (c1 < cend && col_il[c1] == col_il[c]) ++c1;
+        if (col_il[c] != (int)out.ilv.size() - pm.ilv0) { out.error = "internal levels of a piece are not contiguous"; return -1; }
+        ILevel lv{};
+        lv.c0 = c; lv.c1 = c1; lv.b0 = bp[c]; lv.b1 = bp[c1];
+        lv.it0 = (int)out.item.size() - pm.iit0;
+        lv.mb0 = (int)out.mb.size() - pm.imb0;
+        // one phase: cut every target's list into items of <= chunk updates; raise the chunk until the partial tiles fit
+        int U = 0;
+        for (int t = lv.b0; t < lv.b1; ++t) U += bi1[t - pm.b0] - bi0[t - pm.b0];
+        int chunk = std::max(opt.min_chunk, (U + slots - 1) / slots);
+        for (;; ++chunk) {
+          int nonsole = 0;
+          for (int t = lv.b0; t < lv.b1; ++t) { const int k = (bi1[t - pm.b0] - bi0[t - pm.b0] + chunk - 1) / chunk; if (k > 1) nonsole += k; }
+          if (nonsole <= pcap || chunk >= std::max(U, 1)) break;
+        }
+        int ps = 0;
+        for (int t = lv.b0; t < lv.b1; ++t) {
+          const int u0 = bi0[t - pm.b0], u1 = bi1[t - pm.b0], n = u1 - u0;
+          if (n <= 0) continue;
+          const int k = (n + chunk - 1) / chunk;
+          const int tloff = out.blk[t].off - pm.lbase;
+          const int ylocal = col_yoff[block_col[t]] - pm.y0;
+          for (int q = 0; q < k; ++q) {
+            const int a2 = u0 + q * chunk, b2 = std::min(u1, a2 + chunk);
+            out.item.push_back(ItemMeta{a2, b2 - a2, tloff, (ylocal << kItemYShift) | (k == 1 ? kItemSole : ((ps + q) << kItemSlotShift))});
+          }
+          if (k > 1) { out.mb.push_back(MbMeta{tloff, ps, k, (out.blk[t].info & 0xFF) | (out.blk[t].info & kBlkDiag) | (ylocal << 12)}); ps += k; }
+        }
+        piece_pmax[p] = std::max(piece_pmax[p], ps);
+        lv.it1 = (int)out.item.size() - pm.iit0;
+        lv.mb1 = (int)out.mb.size() - pm.imb0;
+        out.ilv.push_back(lv);
+        c = c1;
+      }
     }
     pm.nilv = (int)out.ilv.size() - pm.ilv0;
     pm.nit_i = (int)out.item.size() - pm.iit0;
     pm.nimb = (int)out.mb.size() - pm.imb0;
     if (pm.nilv > kMaxILevels) { out.error = "a piece has too many internal levels"; return -1; }
     if (pm.ysize >= (1 << (32 - kItemYShift - 1))) { out.error = "a piece has too many unknowns"; return -1; }
+    // update matrix of the piece: blocks in (a, b) order, own update records, child sources, U items
+    std::vector<int> order(ub.size());
+    for (size_t q = 0; q < ub.size(); ++q) order[q] = (int)q;
+    std::sort(order.begin(), order.end(), [&](int x, int y2) { return ub[x].a != ub[y2].a ? ub[x].a < ub[y2].a : ub[x].b < ub[y2].b; });
+    pm.uit0 = (int)out.uitem.size();
+    pm.umb0 = (int)out.umb.size();
+    {
+      int64_t cur = ucur;
+      std::vector<int> uoffs(ub.size());
+      for (int q : order) { uoffs[q] = (int)cur; cur += col_dim[ub[q].a] * col_dim[ub[q].b]; }
+      piece_uy[p] = (int)cur;
+      cur += 6 * (int64_t)R.size();
+      if (cur >= ((int64_t)1 << 31) - 4096) { out.error = "update matrices too large for int32 offsets"; return -1; }
+      int U = 0;
+      for (auto& x : ub) U += (int)x.own.size();
+      int chunk = std::max(opt.min_chunk, (U + slots - 1) / slots);
+      for (;; ++chunk) {
+        int nonsole = 0;
+        for (auto& x : ub) { const int k = ((int)x.own.size() + chunk - 1) / chunk; if (k > 1) nonsole += k; }
+        if (nonsole <= pcap || chunk >= std::max(U, 1)) break;
+      }
+      int ps = 0;
+      piece_u[p].reserve(ub.size());
+      for (int q : order) {
+        UB& x = ub[q];
+        const int di = col_dim[x.a], dj = col_dim[x.b];
+        const bool diag = x.a == x.b;
+        int uy = -1;
+        if (diag) uy = piece_uy[p] + 6 * (int)(std::lower_bound(R.begin(), R.end(), x.a) - R.begin());
+        const int tpk = (di == 6 ? kUpdDi6 : 0) | (diag ? kUpdDiag : 0) | (dj == 6 ? kUpdDj6 : 0);
+        const int u0 = (int)out.upd.size();
+        for (auto& u : x.own) out.upd.push_back(UpdMeta{u[0], u[1], col_yoff[u[2]], tpk | (col_dim[u[2]] == 6 ? kUpdDk6 : 0)});
+        const int n = (int)x.own.size();
+        const int s0 = (int)out.usrc.size();
+        for (auto& a2 : x.src) out.usrc.push_back(a2);
+        const int ns = (int)x.src.size();
+        const int k = std::max(1, (n + chunk - 1) / chunk);
+        const int shape = (di == 6 ? kUItemDi6 : 0) | (dj == 6 ? kUItemDj6 : 0) | (diag ? kUItemDiag : 0);
+        for (int qq = 0; qq < k; ++qq) {
+          const int a2 = u0 + qq * chunk, b2 = std::min(u0 + n, a2 + chunk);
+          out.uitem.push_back(UItem{a2, std::max(0, b2 - a2), uoffs[q], shape | (k == 1 ? kItemSole : ((ps + qq) << kItemSlotShift)), s0, ns, uy, 0});
+        }
+        if (k > 1) { out.umb.push_back(UMb{uoffs[q], ps, k, di | (dj << 4) | (diag ? kBlkDiag : 0), s0, ns, uy, 0}); ps += k; }
+        piece_u[p].push_back(URec{x.a, x.b, uoffs[q]});
+      }
+      piece_pmax[p] = std::max(piece_pmax[p], ps);
+      ucur = cur;
+    }
+    pm.nuit = (int)out.uitem.size() - pm.uit0;
+    pm.numb = (int)out.umb.size() - pm.umb0;
+    if (piece_parent[p] < 0 && !ub.empty()) { out.error = "a root piece has an update matrix"; return -1; }
   }
+  out.unz = ucur;
   // ---- LDS needs (doubles) ---------------------------------------------------------------------------------------------------
   auto lds_f = [&](int p) {
     const PieceMeta& pm = out.piece[p];
-    return ((pm.lsize + 1) & ~1) + 2 * ((pm.ysize + 1) & ~1) + 2 * pm.nb + 2 * pm.nc + 2 * pm.nit_i + 2 * pm.nu_i + 2 * pm.nimb +
+    return ((pm.lsize + 1) & ~1) + 2 * ((pm.ysize + 1) & ~1) + 4 * pm.nb + 2 * pm.nc + 2 * pm.nit_i + 2 * pm.nu_i + 2 * pm.nimb + pm.nas +
            kItemDoubles * piece_pmax[p] + 8;
   };
   auto lds_b = [&](int p) {
@@ -567,8 +668,8 @@ inline int chol_symbolic(const SymIn& in, CholOpts opt, CholHost& out) {
     }
   for (int p : out.tail_pieces) { out.tail_lds_f = std::max(out.tail_lds_f, lds_f(p)); out.tail_lds_b = std::max(out.tail_lds_b, lds_b(p)); }
   if (opt.dump) {
-    fprintf(stderr, "[chol-dump] B %d cols %d blocks %d lnz %lld updates %zu items %zu multi-blocks %zu column-levels %d pieces %d piece-levels %d tail pieces %zu\n",
-            B, ncol, nblk, (long long)lnz, out.upd.size(), out.item.size(), out.mb.size(), nlev, npiece, nplv, out.tail_pieces.size());
+    fprintf(stderr, "[chol-dump] B %d cols %d blocks %d lnz %lld unz %lld updates %zu (internal items %zu, U items %zu) column-levels %d pieces %d piece-levels %d tail pieces %zu\n",
+            B, ncol, nblk, (long long)lnz, (long long)out.unz, out.upd.size(), out.item.size(), out.uitem.size(), nlev, npiece, nplv, out.tail_pieces.size());
     for (int l = 0; l < nplv; ++l)
       fprintf(stderr, "[chol-dump]   piece-level %d: %d pieces, LDS factor %d B backward %d B\n", l, out.plv_ptr[l + 1] - out.plv_ptr[l],
               out.plv_lds_f[l] * 8, out.plv_lds_b[l] * 8);

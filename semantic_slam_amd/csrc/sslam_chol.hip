@@ -14,6 +14,7 @@
 // SSLAM_CHOL_TAIL_WIDTH, SSLAM_CHOL_NT_TAIL (512 or 1024), SSLAM_CHOL_MAX_BLOCKS, SSLAM_CHOL_DUMP.
 #include <hip/hip_runtime.h>
 #include <algorithm>
+#include <cstdio>
 #include <cstring>
 #include <vector>
 
@@ -32,13 +33,20 @@ struct CholView {
   const MbMeta* mb;
   const ILevel* ilv;
   const PieceMeta* piece;
+  const AsmSrc* asrc;       // child update-matrix blocks absorbed when a piece is gathered
+  const AsmSrc* usrc;       // child update-matrix blocks passed on through a piece's own update matrix
+  const UItem* uitem;
+  const UMb* umb;
+  const FwdMeta* fwd;       // blocks of every row (multi right-hand-side forward substitution)
   const int* lvl_cols;      // columns grouped by level of the elimination tree
   const int* plv_pieces;    // pieces grouped by depth
   const int* tail_ptr;      // [B + 1]
   const int* tail_pieces;
   double* Lval;
+  double* Uval;             // update matrices handed from child pieces to their parents
   double* y;                // forward-substituted rhs, elimination order [dim]
   int* fail;                // [B]
+  long long* dbg;           // SSLAM_CHOL_STAMPS: shader-clock totals per phase of workgroup 0 ([16] tail kernel, [16] per-depth kernels)
 };
 
 struct CholPlan {
@@ -46,7 +54,7 @@ struct CholPlan {
   std::vector<int> lvl_ptr, plv_ptr, plv_lds_f, plv_lds_b;
   int tail_lds_f = 0, tail_lds_b = 0, tail_total = 0, nt_tail = 512;
   std::vector<void*> allocs;
-  int64_t lnz = 0;
+  int64_t lnz = 0, unz = 0;
   double* d_multi_y = nullptr;  // scratch for multi-rhs solves
   double* d_multi_x = nullptr;
   int multi_cap = 0;
@@ -54,6 +62,15 @@ struct CholPlan {
 
 void chol_plan_free(CholPlan* p) {
   if (!p) return;
+  if (p->C.dbg) {   // SSLAM_CHOL_STAMPS: where workgroup 0 of the factor kernels spent its shader clocks
+    long long h[32];
+    if (hipMemcpy(h, p->C.dbg, sizeof h, hipMemcpyDeviceToHost) == hipSuccess)
+      for (int k = 0; k < 2; ++k) {
+        const long long* d = h + 16 * k;
+        fprintf(stderr, "[chol-stamps] %s: pieces %lld levels %lld U-items %lld int-items %lld | clocks: tables %lld gather %lld items %lld reduce %lld diag %lld rows %lld U %lld out %lld\n",
+                k ? "depth kernels (wg 0)" : "tail (graph 0)", d[8], d[9], d[10], d[11], d[0], d[1], d[2], d[3], d[4], d[5], d[6], d[7]);
+      }
+  }
   for (void* a : p->allocs) (void)hipFree(a);
   if (p->d_multi_y) (void)hipFree(p->d_multi_y);
   if (p->d_multi_x) (void)hipFree(p->d_multi_x);
@@ -176,6 +193,95 @@ __device__ __forceinline__ void reduce_multi(const MbMeta* __restrict__ mbs, int
   }
 }
 
+// Update-matrix items [it_begin, it_end) of a piece: the block U(a,b) = sum of the piece's own updates L(a,k) L(b,k)^T (sources in
+// LDS) + the blocks its children handed up for the same pair; a diagonal block carries the rhs part sum_k L(a,k) y_k along.
+// A sole item finishes its block and writes it to HBM; the items of a split list park their tiles in `part` (reduce_umulti).
+template <int NT>
+__device__ __forceinline__ void run_uitems(const UItem* __restrict__ items, int it_begin, int it_end, const UpdMeta* __restrict__ upd,
+                                           const AsmSrc* __restrict__ usrc, const double* __restrict__ smL, const double* __restrict__ smY,
+                                           int lofs, int yofs, double* __restrict__ U, double* part, int tid) {
+  const int lq = tid & 3, tr = lq >> 1, tc = lq & 1;
+  for (int it = it_begin + (tid >> 2); it < it_end; it += NT / 4) {
+    const UItem im = items[it];
+    const int n = im.n;
+    const int di = (im.flags & kUItemDi6) ? 6 : 3, dj = (im.flags & kUItemDj6) ? 6 : 3;
+    const bool diag = im.flags & kUItemDiag;
+    const int tre = 3 * tr < di ? tr : 0, tce = 3 * tc < dj ? tc : 0;
+    double acc[9], accy[3];
+#pragma unroll
+    for (int q = 0; q < 9; ++q) acc[q] = 0;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) accy[q] = 0;
+    for (int k0 = 0; k0 < n; k0 += 8) {
+      const UpdMeta r0 = upd[im.u0 + min(k0 + lq, n - 1)];
+      const UpdMeta r1 = upd[im.u0 + min(k0 + 4 + lq, n - 1)];
+#define SSLAM_STEP(KK, R)                                                                                        \
+  if (k0 + KK < n)                                                                                               \
+    tile_update(smL, smY, quad_bcast<(KK) & 3>(R.ua) - lofs, quad_bcast<(KK) & 3>(R.ub) - lofs,                  \
+                quad_bcast<(KK) & 3>(R.ux) - yofs, quad_bcast<(KK) & 3>(R.pk), tre, tce, acc, accy);
+      SSLAM_STEP(0, r0) SSLAM_STEP(1, r0) SSLAM_STEP(2, r0) SSLAM_STEP(3, r0)
+      SSLAM_STEP(4, r1) SSLAM_STEP(5, r1) SSLAM_STEP(6, r1) SSLAM_STEP(7, r1)
+#undef SSLAM_STEP
+    }
+    if (3 * tr < di && 3 * tc < dj) {
+      if (im.flags & kItemSole) {
+        for (int s2 = 0; s2 < im.ns; ++s2) {
+          const AsmSrc src = usrc[im.s0 + s2];
+          const double* o = U + src.uoff;
+#pragma unroll
+          for (int rr = 0; rr < 3; ++rr)
+#pragma unroll
+            for (int cc = 0; cc < 3; ++cc) acc[rr * 3 + cc] += o[(3 * tr + rr) * dj + 3 * tc + cc];
+          if (diag && tc == 0 && src.uyoff >= 0) {
+#pragma unroll
+            for (int rr = 0; rr < 3; ++rr) accy[rr] += U[src.uyoff + 3 * tr + rr];
+          }
+        }
+        double* o = U + im.uoff;
+#pragma unroll
+        for (int rr = 0; rr < 3; ++rr)
+#pragma unroll
+          for (int cc = 0; cc < 3; ++cc) o[(3 * tr + rr) * dj + 3 * tc + cc] = acc[rr * 3 + cc];
+        if (diag && tc == 0) {
+#pragma unroll
+          for (int rr = 0; rr < 3; ++rr) U[im.uyoff + 3 * tr + rr] = accy[rr];
+        }
+      } else {
+        double* o = part + ((im.flags >> kItemSlotShift) & kItemSlotMask) * kItemDoubles;
+#pragma unroll
+        for (int rr = 0; rr < 3; ++rr) {
+#pragma unroll
+          for (int cc = 0; cc < 3; ++cc) o[(3 * tr + rr) * dj + 3 * tc + cc] = acc[rr * 3 + cc];
+          if (diag && tc == 0) o[36 + 3 * tr + rr] = accy[rr];
+        }
+      }
+    }
+  }
+}
+
+// U blocks whose own list was split: partial tiles in item order + the children's blocks -> HBM (one wave per block, lane = entry)
+__device__ __forceinline__ void reduce_umulti(const UMb* __restrict__ mbs, int m0, int m1, const AsmSrc* __restrict__ usrc, double* __restrict__ U,
+                                              const double* part, int wave, int lane, int nw) {
+  const int ry = lane - 40;
+  for (int m = m0 + wave; m < m1; m += nw) {
+    const UMb mm = mbs[m];
+    const int di = mm.info & 15, dj = (mm.info >> 4) & 15;
+    const bool diag = mm.info & kBlkDiag;
+    const double* p = part + mm.ps0 * kItemDoubles;
+    if (lane < di * dj) {
+      double v = 0;
+      for (int q = 0; q < mm.n; ++q) v += p[q * kItemDoubles + lane];
+      for (int s2 = 0; s2 < mm.ns; ++s2) v += U[usrc[mm.s0 + s2].uoff + lane];
+      U[mm.uoff + lane] = v;
+    } else if (diag && ry >= 0 && ry < dj) {
+      double v = 0;
+      for (int q = 0; q < mm.n; ++q) v += p[q * kItemDoubles + 36 + ry];
+      for (int s2 = 0; s2 < mm.ns; ++s2) { const int uy = usrc[mm.s0 + s2].uyoff; if (uy >= 0) v += U[uy + ry]; }
+      U[mm.uyoff + ry] = v;
+    }
+  }
+}
+
 // diagonal block of one column, one thread: L_jj = chol(S_jj) in place (strict upper = 0), reciprocal pivots to inv,
 // y_j = L_jj^-1 rhs_j in place.  Right-looking form: after a pivot only one multiply and one FMA lie between it and the next
 // pivot (the trailing updates are independent of one another), so the thread's latency is ~D x (rsqrt + 2 ops), not ~D^2 FMAs.
@@ -235,9 +341,16 @@ __device__ __forceinline__ void row_solve(double* v, const double* Ljj, const do
 //   y(j) = L(j,j)^-1 (b(j) - sum_k L(j,k) y(k))
 // LDS: [L of the piece | y | reciprocal pivots | block table | column table | internal items | partial tiles]
 // ------------------------------------------------------------------------------------------------
+#define SSLAM_STAMP(k)                                                          \
+  if (dbg) {                                                                    \
+    const long long now_ = clock64();                                           \
+    if (threadIdx.x == 0) dbg[k] += now_ - tprev;                               \
+    tprev = now_;                                                               \
+  }
 template <int NT>
-__device__ __forceinline__ void chol_piece(const BatchView& V, const CholView& C, const PieceMeta pm, double* sm) {
+__device__ __forceinline__ void chol_piece(const BatchView& V, const CholView& C, const PieceMeta pm, double* sm, long long* dbg) {
   constexpr int NW = NT / 64;
+  long long tprev = dbg ? clock64() : 0;
   __shared__ ILevel s_lv[kMaxILevels];
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
@@ -247,41 +360,53 @@ __device__ __forceinline__ void chol_piece(const BatchView& V, const CholView& C
   double* smL = sm;
   double* smY = smL + Lp;
   double* smInv = smY + Yp;
-  int4* sBlk = reinterpret_cast<int4*>(smInv + Yp);   // {L offset, info, L offset of the column's diagonal block, y offset of the column} (piece-local)
-  int4* sCol = sBlk + pm.nb;                           // {L offset of the diagonal block, dim, y offset, -}
+  BlkMeta* sBlk = reinterpret_cast<BlkMeta*>(smInv + Yp);                 // the piece's block records
+  int4* sCol = reinterpret_cast<int4*>(sBlk + pm.nb);                      // {L offset of the diagonal block, dim, y offset, -} (piece-local)
   ItemMeta* sItem = reinterpret_cast<ItemMeta*>(sCol + pm.nc);            // internal work items
   UpdMeta* sUpd = reinterpret_cast<UpdMeta*>(sItem + pm.nit_i);            // internal update records
   MbMeta* sMb = reinterpret_cast<MbMeta*>(sUpd + pm.nu_i);                 // internal multi-blocks
-  double* part = reinterpret_cast<double*>(sMb + pm.nimb);
+  AsmSrc* sAsm = reinterpret_cast<AsmSrc*>(sMb + pm.nimb);                 // child update-matrix blocks to absorb
+  double* part = reinterpret_cast<double*>(sAsm + pm.nas + (pm.nas & 1));
   const double* __restrict__ H = V.Hpp_diag;
+  const double* __restrict__ U = C.Uval;
   const int ry = lane - 40;
-  // ---- 0. tables and A(:, piece) + lambda I, rhs -> LDS (one wave per block, four blocks in flight per wave)
+  // ---- 0. every table of the piece -> LDS in one round of independent loads
   for (int i = tid; i < pm.nilv; i += NT) s_lv[i] = C.ilv[pm.ilv0 + i];
+  for (int i = tid; i < pm.nb; i += NT) sBlk[i] = C.blk[pm.b0 + i];
   for (int i = tid; i < pm.nit_i; i += NT) sItem[i] = C.item[pm.iit0 + i];
   for (int i = tid; i < pm.nu_i; i += NT) sUpd[i] = C.upd[pm.iu0 + i];
   for (int i = tid; i < pm.nimb; i += NT) sMb[i] = C.mb[pm.imb0 + i];
+  for (int i = tid; i < pm.nas; i += NT) sAsm[i] = C.asrc[pm.as0 + i];
   for (int c = tid; c < pm.nc; c += NT) {
     const ColMeta cm = C.col[pm.c0 + c];
     sCol[c] = make_int4(cm.base - pm.lbase, cm.dim, cm.yoff - pm.y0, 0);
   }
+  __syncthreads();
+  SSLAM_STAMP(0)
+  // ---- 1. gather: A(:, piece) + lambda I, rhs, minus what the child pieces left for these blocks (their update matrices:
+  //         coalesced 288-byte reads) -> LDS.  One wave per block, lane = entry; four blocks in flight per wave.
   {
     constexpr int kPipe = 4;
     for (int b0 = wave; b0 < pm.nb; b0 += NW * kPipe) {
-      BlkMeta bm[kPipe];
       double hv[kPipe];
 #pragma unroll
-      for (int k = 0; k < kPipe; ++k) bm[k] = C.blk[pm.b0 + min(b0 + k * NW, pm.nb - 1)];
-#pragma unroll
       for (int k = 0; k < kPipe; ++k) {
-        const int di = bm[k].info & 15, dj = (bm[k].info >> 4) & 15;
-        const bool diag = bm[k].info & kBlkDiag;
+        const BlkMeta bm = sBlk[min(b0 + k * NW, pm.nb - 1)];
+        const int di = bm.info & 15, dj = (bm.info >> 4) & 15, nas = (bm.info >> kBlkNasShift) & 255;
+        const bool diag = bm.info & kBlkDiag;
+        const bool ent = lane < di * dj, rhs = diag && ry >= 0 && ry < dj;
         const int r = lane / dj, c = lane - r * dj;
         double v = 0;
-        if (lane < di * dj) {
-          if (bm[k].src >= 0) v = (bm[k].info & kBlkFmt) ? H[bm[k].src + c * di + r] : H[bm[k].src + lane];
+        if (ent) {
+          if (bm.src >= 0) v = (bm.info & kBlkFmt) ? H[bm.src + c * di + r] : H[bm.src + lane];
           if (diag && r == c) v += lambda;
-        } else if (diag && ry >= 0 && ry < dj) {
-          v = V.bvec[bm[k].xoff_row + ry];
+        } else if (rhs) {
+          v = V.bvec[bm.xoff_row + ry];
+        }
+        for (int s2 = 0; s2 < nas; ++s2) {
+          const AsmSrc as = sAsm[bm.as0 + s2];
+          if (ent) v -= U[as.uoff + lane];
+          else if (rhs && as.uyoff >= 0) v -= U[as.uyoff + ry];
         }
         hv[k] = v;
       }
@@ -289,33 +414,27 @@ __device__ __forceinline__ void chol_piece(const BatchView& V, const CholView& C
       for (int k = 0; k < kPipe; ++k) {
         const int idx = b0 + k * NW;
         if (idx >= pm.nb) continue;
-        const int di = bm[k].info & 15, dj = (bm[k].info >> 4) & 15;
-        const bool diag = bm[k].info & kBlkDiag;
-        if (lane < di * dj) smL[bm[k].off - pm.lbase + lane] = hv[k];
-        else if (diag && ry >= 0 && ry < dj) smY[bm[k].colyoff - pm.y0 + ry] = hv[k];
-        if (lane == 63) sBlk[idx] = make_int4(bm[k].off - pm.lbase, bm[k].info, bm[k].coldiag - pm.lbase, bm[k].colyoff - pm.y0);
+        const BlkMeta bm = sBlk[idx];
+        const int di = bm.info & 15, dj = (bm.info >> 4) & 15;
+        const bool diag = bm.info & kBlkDiag;
+        if (lane < di * dj) smL[bm.off - pm.lbase + lane] = hv[k];
+        else if (diag && ry >= 0 && ry < dj) smY[bm.colyoff - pm.y0 + ry] = hv[k];
       }
     }
   }
   __syncthreads();
-  // ---- 1. external updates: sources are final columns of lower pieces, in HBM / L2
-  if (pm.enit > 0) {
-    run_items<NT>(C.item, pm.eit0, pm.eit0 + pm.enit, C.upd, C.Lval, C.y, 0, 0, smL, smY, part, tid);
-    __syncthreads();
-    if (pm.nemb > 0) {
-      reduce_multi(C.mb, pm.emb0, pm.emb0 + pm.nemb, smL, smY, part, wave, lane, NW);
-      __syncthreads();
-    }
-  }
-  // ---- 2. the levels inside the piece, sources in LDS
+  SSLAM_STAMP(1)
+  // ---- 2. the levels inside the piece, everything in LDS
   for (int il = 0; il < pm.nilv; ++il) {
     const ILevel lv = s_lv[il];
     if (lv.it1 > lv.it0) {
       run_items<NT>(sItem, lv.it0, lv.it1, sUpd, smL, smY, pm.lbase, pm.y0, smL, smY, part, tid);
       __syncthreads();
+      SSLAM_STAMP(2)
       if (lv.mb1 > lv.mb0) {
         reduce_multi(sMb, lv.mb0, lv.mb1, smL, smY, part, wave, lane, NW);
         __syncthreads();
+        SSLAM_STAMP(3)
       }
     }
     for (int c = lv.c0 - pm.c0 + tid; c < lv.c1 - pm.c0; c += NT) {
@@ -326,27 +445,41 @@ __device__ __forceinline__ void chol_piece(const BatchView& V, const CholView& C
       if (!ok) C.fail[g] = 1;
     }
     __syncthreads();
+    SSLAM_STAMP(4)
     for (int t = tid; t < (lv.b1 - lv.b0) * 6; t += NT) {   // thread = (block, row)
       const int b = t / 6, row = t - 6 * b;
-      const int4 bm = sBlk[lv.b0 - pm.b0 + b];
-      const int di = bm.y & 15, dj = (bm.y >> 4) & 15;
-      if ((bm.y & kBlkDiag) || row >= di) continue;
-      if (dj == 6) row_solve<6>(smL + bm.x + row * 6, smL + bm.z, smInv + bm.w);
-      else row_solve<3>(smL + bm.x + row * 3, smL + bm.z, smInv + bm.w);
+      const BlkMeta bm = sBlk[lv.b0 - pm.b0 + b];
+      const int di = bm.info & 15, dj = (bm.info >> 4) & 15;
+      if ((bm.info & kBlkDiag) || row >= di) continue;
+      if (dj == 6) row_solve<6>(smL + (bm.off - pm.lbase) + row * 6, smL + (bm.coldiag - pm.lbase), smInv + (bm.colyoff - pm.y0));
+      else row_solve<3>(smL + (bm.off - pm.lbase) + row * 3, smL + (bm.coldiag - pm.lbase), smInv + (bm.colyoff - pm.y0));
     }
     __syncthreads();
+    SSLAM_STAMP(5)
   }
-  // ---- 3. one coalesced stream out
+  // ---- 3. the update matrix over the rows above the piece: own updates out of LDS + the children's blocks -> HBM
+  if (pm.nuit > 0) {
+    run_uitems<NT>(C.uitem, pm.uit0, pm.uit0 + pm.nuit, C.upd, C.usrc, smL, smY, pm.lbase, pm.y0, C.Uval, part, tid);
+    if (pm.numb > 0) {
+      __syncthreads();
+      reduce_umulti(C.umb, pm.umb0, pm.umb0 + pm.numb, C.usrc, C.Uval, part, wave, lane, NW);
+    }
+  }
+  SSLAM_STAMP(6)
+  // ---- 4. one coalesced stream out
   for (int e = tid; e < pm.lsize; e += NT) C.Lval[pm.lbase + e] = smL[e];
   for (int e = tid; e < pm.ysize; e += NT) C.y[pm.y0 + e] = smY[e];
+  SSLAM_STAMP(7)
+  if (dbg && threadIdx.x == 0) { dbg[8] += 1; dbg[9] += pm.nilv; dbg[10] += pm.nuit; dbg[11] += pm.nit_i; }
 }
+#undef SSLAM_STAMP
 
 template <int NT>
 __global__ __launch_bounds__(NT) void k_chol_pieces(BatchView V, CholView C, int begin) {
   extern __shared__ double sm[];
   const PieceMeta pm = C.piece[C.plv_pieces[begin + blockIdx.x]];
   if (!V.lm[pm.graph].in_trial) return;
-  chol_piece<NT>(V, C, pm, sm);
+  chol_piece<NT>(V, C, pm, sm, (C.dbg && blockIdx.x == 0) ? C.dbg + 16 : nullptr);
 }
 
 // Top of the elimination tree: once a graph is down to a few pieces per depth a launch per depth only buys launch
@@ -359,7 +492,7 @@ __global__ __launch_bounds__(NT) void k_chol_tail(BatchView V, CholView C) {
   if (!V.lm[g].in_trial) return;
   const int q1 = C.tail_ptr[g + 1];
   for (int q = C.tail_ptr[g]; q < q1; ++q) {
-    chol_piece<NT>(V, C, C.piece[C.tail_pieces[q]], sm);
+    chol_piece<NT>(V, C, C.piece[C.tail_pieces[q]], sm, (C.dbg && g == 0) ? C.dbg : nullptr);
     __threadfence_block();
     __syncthreads();
   }
@@ -500,14 +633,13 @@ __global__ __launch_bounds__(64) void k_chol_forward_level(CholView C, int lvl_b
   const double* __restrict__ L = C.Lval;
   if (lane < dj) {
     double a = rhs[vo + cm.xoff + lane];
-    for (int part = 0; part < 2; ++part)
-      for (int u = part ? cm.ui0 : cm.up0; u < (part ? cm.ui1 : cm.up1); ++u) {
-        const UpdMeta um = C.upd[u];
-        const int dk = (um.pk & kUpdDk6) ? 6 : 3;
-        const double* pa = L + um.ua + lane * dk;
-        const double* yk = y + vo + um.ux;
-        for (int q = 0; q < dk; ++q) a -= pa[q] * yk[q];
-      }
+    for (int u = cm.f0; u < cm.f1; ++u) {   // the blocks of row j, ascending k
+      const FwdMeta fm = C.fwd[u];
+      const int dk = fm.off < 0 ? 6 : 3;
+      const double* pa = L + (fm.off & 0x7FFFFFFF) + lane * dk;
+      const double* yk = y + vo + fm.yoff;
+      for (int q = 0; q < dk; ++q) a -= pa[q] * yk[q];
+    }
     t[lane] = a;
   }
   __syncthreads();
@@ -624,6 +756,11 @@ int chol_plan_build(Batch& b) {
   if ((rc = up_to_dev(*P, b.stream, H.mb, &C.mb))) return rc;
   if ((rc = up_to_dev(*P, b.stream, H.ilv, &C.ilv))) return rc;
   if ((rc = up_to_dev(*P, b.stream, H.piece, &C.piece))) return rc;
+  if ((rc = up_to_dev(*P, b.stream, H.asrc, &C.asrc))) return rc;
+  if ((rc = up_to_dev(*P, b.stream, H.usrc, &C.usrc))) return rc;
+  if ((rc = up_to_dev(*P, b.stream, H.uitem, &C.uitem))) return rc;
+  if ((rc = up_to_dev(*P, b.stream, H.umb, &C.umb))) return rc;
+  if ((rc = up_to_dev(*P, b.stream, H.fwd, &C.fwd))) return rc;
   if ((rc = up_to_dev(*P, b.stream, H.lvl_cols, &C.lvl_cols))) return rc;
   if ((rc = up_to_dev(*P, b.stream, H.plv_pieces, &C.plv_pieces))) return rc;
   if ((rc = up_to_dev(*P, b.stream, H.tail_ptr, &C.tail_ptr))) return rc;
@@ -631,10 +768,18 @@ int chol_plan_build(Batch& b) {
   void* p = nullptr;
   SSLAM_HIP_TRY(hipMalloc(&p, (H.lnz + 64) * sizeof(double))); P->allocs.push_back(p); C.Lval = (double*)p;
   SSLAM_HIP_TRY(hipMemsetAsync(p, 0, (H.lnz + 64) * sizeof(double), b.stream));
+  SSLAM_HIP_TRY(hipMalloc(&p, (H.unz + 64) * sizeof(double))); P->allocs.push_back(p); C.Uval = (double*)p;
+  SSLAM_HIP_TRY(hipMemsetAsync(p, 0, (H.unz + 64) * sizeof(double), b.stream));
+  P->unz = H.unz;
   SSLAM_HIP_TRY(hipMalloc(&p, (C.dim + 8) * sizeof(double))); P->allocs.push_back(p); C.y = (double*)p;
   SSLAM_HIP_TRY(hipMemsetAsync(p, 0, (C.dim + 8) * sizeof(double), b.stream));
   SSLAM_HIP_TRY(hipMalloc(&p, std::max(b.V.B, 1) * sizeof(int))); P->allocs.push_back(p); C.fail = (int*)p;
   SSLAM_HIP_TRY(hipMemsetAsync(C.fail, 0, std::max(b.V.B, 1) * sizeof(int), b.stream));
+  C.dbg = nullptr;
+  if (getenv("SSLAM_CHOL_STAMPS")) {
+    SSLAM_HIP_TRY(hipMalloc(&p, 32 * sizeof(long long))); P->allocs.push_back(p); C.dbg = (long long*)p;
+    SSLAM_HIP_TRY(hipMemsetAsync(p, 0, 32 * sizeof(long long), b.stream));
+  }
   // LDS opt-in above 64 KiB
   size_t lds_max = (size_t)std::max(P->tail_lds_f, P->tail_lds_b);
   for (size_t l = 0; l < P->plv_lds_f.size(); ++l) lds_max = std::max(lds_max, (size_t)std::max(P->plv_lds_f[l], P->plv_lds_b[l]));

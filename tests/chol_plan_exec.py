@@ -8,14 +8,18 @@ import ctypes as C
 
 import numpy as np
 
-COL = np.dtype([(n, "<i4") for n in ("xoff", "yoff", "dim", "graph", "b0", "nb", "nbi", "base", "up0", "up1", "ui0", "ui1", "piece", "ilevel", "pad0", "pad1")])
-BLK = np.dtype([(n, "<i4") for n in ("off", "src", "xoff_row", "yoff_row", "coldiag", "colyoff", "info", "pad")])
+COL = np.dtype([(n, "<i4") for n in ("xoff", "yoff", "dim", "graph", "b0", "nb", "nbi", "base", "f0", "f1", "piece", "ilevel")])
+BLK = np.dtype([(n, "<i4") for n in ("off", "src", "xoff_row", "yoff_row", "coldiag", "colyoff", "info", "as0")])
+ASRC = np.dtype([("uoff", "<i4"), ("uyoff", "<i4")])
+FWD = np.dtype([("off", "<i4"), ("yoff", "<i4")])
+UITEM = np.dtype([(n, "<i4") for n in ("u0", "n", "uoff", "flags", "s0", "ns", "uyoff", "pad")])
+UMB = np.dtype([(n, "<i4") for n in ("uoff", "ps0", "n", "info", "s0", "ns", "uyoff", "pad")])
 UPD = np.dtype([(n, "<i4") for n in ("ua", "ub", "ux", "pk")])
 ITEM = np.dtype([(n, "<i4") for n in ("u0", "n", "tloff", "flags")])
 MB = np.dtype([(n, "<i4") for n in ("tloff", "ps0", "n", "info")])
 ILV = np.dtype([(n, "<i4") for n in ("c0", "c1", "b0", "b1", "it0", "it1", "mb0", "mb1")])
-PIECE = np.dtype([(n, "<i4") for n in ("graph", "c0", "nc", "b0", "nb", "lbase", "lsize", "y0", "ysize", "eit0", "enit", "emb0", "nemb",
-                                       "ilv0", "nilv", "iit0", "nit_i", "iu0", "nu_i", "imb0", "nimb", "pad0", "pad1", "pad2")])
+PIECE = np.dtype([(n, "<i4") for n in ("graph", "c0", "nc", "b0", "nb", "lbase", "lsize", "y0", "ysize", "ilv0", "nilv", "iit0", "nit_i",
+                                       "iu0", "nu_i", "imb0", "nimb", "as0", "nas", "uit0", "nuit", "umb0", "numb", "pad")])
 K_DI6, K_DK6, K_DIAG, K_DJ6 = 1 << 20, 1 << 21, 1 << 22, 1 << 23
 B_FMT, B_DIAG, B_ROWIN = 1 << 8, 1 << 9, 1 << 10
 
@@ -30,11 +34,12 @@ class Plan:
         g = self._get
         self.col, self.blk, self.upd = g("col", COL), g("blk", BLK), g("upd", UPD)
         self.item, self.mb, self.ilv, self.piece = g("item", ITEM), g("mb", MB), g("ilv", ILV), g("piece", PIECE)
+        self.asrc, self.usrc, self.fwd, self.uitem, self.umb = g("asrc", ASRC), g("usrc", ASRC), g("fwd", FWD), g("uitem", UITEM), g("umb", UMB)
         for n in ("lvl_ptr", "lvl_cols", "plv_ptr", "plv_pieces", "tail_ptr", "tail_pieces", "plv_lds_f", "plv_lds_b", "ppoff", "plblk", "scalars"):
             setattr(self, n, g(n, np.int32))
         s = self.scalars
         (self.ncol, self.nlevels, self.dim, self.B, self.npiece, self.lnz, self.tail_lds_f, self.tail_lds_b, self.nt_leaf, self.nt_tail,
-         self.h_total, self.nPr, self.nLr, self.hll_base, self.hpp_off_base, self.hpl_base) = [int(v) for v in s]
+         self.h_total, self.nPr, self.nLr, self.hll_base, self.hpp_off_base, self.hpl_base, self.unz) = [int(v) for v in s[:17]]
         lib.sslam_debug_plan_destroy(self._h)
         self._h = None
 
@@ -74,29 +79,35 @@ class Plan:
     # ---- factorisation + fused forward substitution, piece by piece
     def factor(self, Hdev, bvec, lam):
         Lval = np.zeros(self.lnz + 64)
+        Uval = np.full(self.unz + 64, np.nan)      # every update-matrix entry must be written before it is read
         y = np.zeros(self.dim + 8)
         ok = True
         for p in self.piece_order():
-            ok &= self._factor_piece(self.piece[p], Hdev, bvec, lam, Lval, y)
+            ok &= self._factor_piece(self.piece[p], Hdev, bvec, lam, Lval, Uval, y)
+        self.Uval = Uval
         return Lval, y, ok
+
+    def _tile_sum(self, upd, Ls, Ys, lofs, yofs, di, dj, diag):
+        acc = np.zeros((di, dj)); accy = np.zeros(di)
+        for r in upd:
+            dk = 6 if r["pk"] & K_DK6 else 3
+            assert bool(r["pk"] & K_DI6) == (di == 6) and bool(r["pk"] & K_DJ6) == (dj == 6) and bool(r["pk"] & K_DIAG) == diag
+            A = Ls[r["ua"] - lofs:r["ua"] - lofs + di * dk].reshape(di, dk)
+            Bm = Ls[r["ub"] - lofs:r["ub"] - lofs + dj * dk].reshape(dj, dk)
+            acc += A @ Bm.T
+            if diag:
+                accy += A @ Ys[r["ux"] - yofs:r["ux"] - yofs + dk]
+        return acc, accy
 
     def _run_items(self, items, upd, Ls, Ys, lofs, yofs, smL, smY, part):
         for im in items:
             u = upd[im["u0"]:im["u0"] + im["n"]]
-            assert len(u) == im["n"]
+            assert len(u) == im["n"] and im["n"] > 0
             pk0 = int(u[0]["pk"])
             di = 6 if pk0 & K_DI6 else 3
             dj = 6 if pk0 & K_DJ6 else 3
             diag = bool(pk0 & K_DIAG)
-            acc = np.zeros((di, dj)); accy = np.zeros(di)
-            for r in u:
-                dk = 6 if r["pk"] & K_DK6 else 3
-                assert (int(r["pk"]) & ~K_DK6) == (pk0 & ~K_DK6)          # one target per item
-                A = Ls[r["ua"] - lofs:r["ua"] - lofs + di * dk].reshape(di, dk)
-                Bm = Ls[r["ub"] - lofs:r["ub"] - lofs + dj * dk].reshape(dj, dk)
-                acc += A @ Bm.T
-                if diag:
-                    accy += A @ Ys[r["ux"] - yofs:r["ux"] - yofs + dk]
+            acc, accy = self._tile_sum(u, Ls, Ys, lofs, yofs, di, dj, diag)
             fl = int(im["flags"])
             if fl & 1:
                 smL[im["tloff"]:im["tloff"] + di * dj] -= acc.ravel()
@@ -118,26 +129,37 @@ class Plan:
                 yl = int(mm["info"]) >> 12
                 smY[yl:yl + dj] -= accy
 
-    def _factor_piece(self, pm, Hdev, bvec, lam, Lval, y):
+    def _factor_piece(self, pm, Hdev, bvec, lam, Lval, Uval, y):
         lbase, y0 = int(pm["lbase"]), int(pm["y0"])
         smL = np.zeros(pm["lsize"]); smY = np.zeros(pm["ysize"])
-        part = {}
+        sAsm = self.asrc[pm["as0"]:pm["as0"] + pm["nas"]]
+        # gather: A + lambda I, rhs, minus the children's update-matrix blocks
         for bm in self.blk[pm["b0"]:pm["b0"] + pm["nb"]]:
             info = int(bm["info"])
-            di, dj = info & 15, (info >> 4) & 15
+            di, dj, nas = info & 15, (info >> 4) & 15, (info >> 16) & 255
             v = np.zeros((di, dj))
             if bm["src"] >= 0:
                 raw = Hdev[bm["src"]:bm["src"] + di * dj]
                 v = raw.reshape(dj, di).T.copy() if info & B_FMT else raw.reshape(di, dj).copy()
+            rhs = None
             if info & B_DIAG:
                 v += lam * np.eye(dj)
                 assert bm["off"] == bm["coldiag"]
-                smY[bm["colyoff"] - y0:bm["colyoff"] - y0 + dj] = bvec[bm["xoff_row"]:bm["xoff_row"] + dj]
+                rhs = bvec[bm["xoff_row"]:bm["xoff_row"] + dj].copy()
+            for a in sAsm[bm["as0"]:bm["as0"] + nas]:
+                blk = Uval[a["uoff"]:a["uoff"] + di * dj]
+                assert not np.isnan(blk).any()
+                v -= blk.reshape(di, dj)
+                if a["uyoff"] >= 0:
+                    assert info & B_DIAG
+                    uy = Uval[a["uyoff"]:a["uyoff"] + dj]
+                    assert not np.isnan(uy).any()
+                    rhs -= uy
+            if info & B_DIAG:
+                smY[bm["colyoff"] - y0:bm["colyoff"] - y0 + dj] = rhs
             smL[bm["off"] - lbase:bm["off"] - lbase + di * dj] = v.ravel()
-        self._run_items(self.item[pm["eit0"]:pm["eit0"] + pm["enit"]], self.upd, Lval, y, 0, 0, smL, smY, part)
         sUpd = self.upd[pm["iu0"]:pm["iu0"] + pm["nu_i"]]          # the LDS copies the kernel makes
         sMb = self.mb[pm["imb0"]:pm["imb0"] + pm["nimb"]]
-        self._reduce(self.mb[pm["emb0"]:pm["emb0"] + pm["nemb"]], smL, smY, part)
         ok = True
         for lv in self.ilv[pm["ilv0"]:pm["ilv0"] + pm["nilv"]]:
             part = {}
@@ -163,6 +185,43 @@ class Plan:
                 Lj = smL[od:od + dj * dj].reshape(dj, dj)
                 Vb = smL[o:o + di * dj].reshape(di, dj)
                 smL[o:o + di * dj] = np.linalg.solve(Lj, Vb.T).T.ravel()
+        # update matrix of the piece: own updates (sources in the piece) + the children's blocks
+        part = {}
+        for im in self.uitem[pm["uit0"]:pm["uit0"] + pm["nuit"]]:
+            fl = int(im["flags"])
+            di = 6 if fl & (1 << 12) else 3
+            dj = 6 if fl & (1 << 13) else 3
+            diag = bool(fl & (1 << 14))
+            u = self.upd[im["u0"]:im["u0"] + im["n"]]
+            for r in u:
+                assert lbase <= r["ua"] < lbase + pm["lsize"] and lbase <= r["ub"] < lbase + pm["lsize"]
+            acc, accy = self._tile_sum(u, smL, smY, lbase, y0, di, dj, diag)
+            if fl & 1:
+                for a in self.usrc[im["s0"]:im["s0"] + im["ns"]]:
+                    blk = Uval[a["uoff"]:a["uoff"] + di * dj]
+                    assert not np.isnan(blk).any()
+                    acc += blk.reshape(di, dj)
+                    if diag and a["uyoff"] >= 0:
+                        accy += Uval[a["uyoff"]:a["uyoff"] + dj]
+                Uval[im["uoff"]:im["uoff"] + di * dj] = acc.ravel()
+                if diag:
+                    Uval[im["uyoff"]:im["uyoff"] + dj] = accy
+            else:
+                part[(fl >> 1) & 0x7FF] = (acc, accy)
+        for mm in self.umb[pm["umb0"]:pm["umb0"] + pm["numb"]]:
+            di, dj = int(mm["info"]) & 15, (int(mm["info"]) >> 4) & 15
+            diag = bool(int(mm["info"]) & B_DIAG)
+            acc = np.zeros((di, dj)); accy = np.zeros(di)
+            for q in range(mm["n"]):
+                a, ay = part[mm["ps0"] + q]
+                acc += a; accy += ay
+            for a in self.usrc[mm["s0"]:mm["s0"] + mm["ns"]]:
+                acc += Uval[a["uoff"]:a["uoff"] + di * dj].reshape(di, dj)
+                if diag and a["uyoff"] >= 0:
+                    accy += Uval[a["uyoff"]:a["uyoff"] + dj]
+            Uval[mm["uoff"]:mm["uoff"] + di * dj] = acc.ravel()
+            if diag:
+                Uval[mm["uyoff"]:mm["uyoff"] + dj] = accy
         Lval[lbase:lbase + pm["lsize"]] = smL
         y[y0:y0 + pm["ysize"]] = smY
         return ok
@@ -199,6 +258,21 @@ class Plan:
                 d = int(cm["dim"])
                 x[cm["xoff"]:cm["xoff"] + d] = smX[cm["yoff"] - y0:cm["yoff"] - y0 + d]
         return x
+
+    # level-scheduled forward substitution through the row lists (what the multi right-hand-side kernel does)
+    def forward_rows(self, Lval, rhs_x):
+        y = np.zeros(self.dim)
+        for l in range(self.nlevels):
+            for j in self.lvl_cols[self.lvl_ptr[l]:self.lvl_ptr[l + 1]]:
+                cm = self.col[j]; d = int(cm["dim"])
+                a = rhs_x[cm["xoff"]:cm["xoff"] + d].copy()
+                for fm in self.fwd[cm["f0"]:cm["f1"]]:
+                    dk = 6 if fm["off"] < 0 else 3
+                    o = int(fm["off"]) & 0x7FFFFFFF
+                    a -= Lval[o:o + d * dk].reshape(d, dk) @ y[fm["yoff"]:fm["yoff"] + dk]
+                Lj = Lval[cm["base"]:cm["base"] + d * d].reshape(d, d)
+                y[cm["yoff"]:cm["yoff"] + d] = np.linalg.solve(Lj, a)
+        return y
 
     # dense L in elimination order (tests)
     def dense_L(self, Lval):

@@ -62,6 +62,8 @@ def _check(plan, H, b, lam):
     x = plan.backward(Lval, y)
     xref = np.linalg.solve(A, b)
     assert np.abs(x - xref).max() <= 1e-7 * np.abs(xref).max()
+    y2 = plan.forward_rows(Lval, b)          # the row lists of the multi right-hand-side forward substitution
+    assert np.abs(y2 - yref).max() <= 1e-9 * max(np.abs(yref).max(), 1e-30)
     return Lval
 
 
@@ -74,25 +76,34 @@ def _structure_invariants(plan):
     # every piece is launched exactly once
     order = plan.piece_order()
     assert sorted(order) == list(range(plan.npiece))
-    # an external update source always lies in a piece that runs earlier
+    # internal updates stay inside their piece; the update-matrix blocks a piece absorbs or passes on were written by pieces that
+    # run earlier, and never by a piece of the same launch
     rank = np.zeros(plan.npiece, int); rank[order] = np.arange(plan.npiece)
     depth_of = {}
     for l in range(len(plan.plv_ptr) - 1):
         for p in plan.plv_pieces[plan.plv_ptr[l]:plan.plv_ptr[l + 1]]:
             depth_of[int(p)] = l
-    lb = P["lbase"]
+    writer = {}
     for p in range(plan.npiece):
         pm = P[p]
-        for im in plan.item[pm["eit0"]:pm["eit0"] + pm["enit"]]:
-            for r in plan.upd[im["u0"]:im["u0"] + im["n"]]:
-                q = int(np.searchsorted(lb, r["ua"], side="right") - 1)
-                assert q != p and rank[q] < rank[p]
-                if p in depth_of:   # pieces that share a launch must not feed each other
-                    assert q in depth_of and depth_of[q] < depth_of[p]
+        for im in plan.uitem[pm["uit0"]:pm["uit0"] + pm["nuit"]]:
+            writer[int(im["uoff"])] = p
+            if im["uyoff"] >= 0:
+                writer[int(im["uyoff"])] = p
+    for p in range(plan.npiece):
+        pm = P[p]
         for im in plan.item[pm["iit0"]:pm["iit0"] + pm["nit_i"]]:
             assert 0 <= im["u0"] and im["u0"] + im["n"] <= pm["nu_i"]
             for r in plan.upd[pm["iu0"] + im["u0"]:pm["iu0"] + im["u0"] + im["n"]]:
                 assert pm["lbase"] <= r["ua"] < pm["lbase"] + pm["lsize"] and pm["lbase"] <= r["ub"] < pm["lbase"] + pm["lsize"]
+        srcs = list(plan.asrc[pm["as0"]:pm["as0"] + pm["nas"]])
+        for im in plan.uitem[pm["uit0"]:pm["uit0"] + pm["nuit"]]:
+            srcs += list(plan.usrc[im["s0"]:im["s0"] + im["ns"]])
+        for a in srcs:
+            q = writer[int(a["uoff"])]
+            assert rank[q] < rank[p]
+            if p in depth_of:
+                assert q in depth_of and depth_of[q] < depth_of[p]
     # LDS budgets stay below the hardware's 160 KiB
     lds = [int(v) for v in plan.plv_lds_f] + [int(v) for v in plan.plv_lds_b] + [plan.tail_lds_f, plan.tail_lds_b]
     assert max(lds) * 8 <= 158 * 1024
@@ -110,10 +121,10 @@ def test_plan_small_graph_matches_dense_cholesky(hip_lib, interleave):
 def test_plan_with_tiny_pieces_exercises_every_phase(hip_lib):
     """Caps far below the defaults force many pieces, external phases, split lists (partial tiles) and a multi-piece tail."""
     g = make_graph(150, 30, seed=5)
-    env = {"SSLAM_CHOL_CAP_LEAF": 400, "SSLAM_CHOL_CAP_TAIL": 700, "SSLAM_CHOL_TAIL_WIDTH": 2}
+    env = {"SSLAM_CHOL_CAP_LEAF": 400, "SSLAM_CHOL_CAP_TAIL": 700, "SSLAM_CHOL_TAIL_WIDTH": 2, "SSLAM_CHOL_MIN_CHUNK": 1}
     plan, H, b = _plan_and_system(hip_lib, g, False, env)
     assert plan.npiece > 20 and len(plan.tail_pieces) >= 2 and len(plan.plv_ptr) > 2
-    assert len(plan.mb) > 0 and np.any(plan.piece["enit"] > 0)
+    assert len(plan.mb) > 0 and len(plan.umb) > 0 and np.any(plan.piece["nas"] > 0) and np.any(plan.uitem["ns"] > 0)
     _structure_invariants(plan)
     _check(plan, H, b, 1e-3)
     # same system, no tail: every piece goes through the per-depth launches
