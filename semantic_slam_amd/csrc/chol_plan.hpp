@@ -71,10 +71,12 @@ struct UItem { int u0, n, uoff, flags, s0, ns, uyoff, pad; };   // flags: bit 0 
 constexpr int kUItemDi6 = 1 << 12, kUItemDj6 = 1 << 13, kUItemDiag = 1 << 14;
 struct UMb { int uoff, ps0, n, info, s0, ns, uyoff, pad; };     // a U block whose own list was split: info = di | dj << 4 | diag << 9
 
-struct PieceMeta { int graph, c0, nc, b0, nb, lbase, lsize, y0, ysize, ilv0, nilv, iit0, nit_i, iu0, nu_i, imb0, nimb, as0, nas, uit0, nuit, umb0, numb, pad; };
+struct PieceMeta { int graph, c0, nc, b0, nb, lbase, lsize, y0, ysize, ilv0, nilv, iit0, nit_i, iu0, nu_i, imb0, nimb, as0, nas, uit0, nuit, umb0, numb,
+                   uu0, nuu, us0, nus, pad0, pad1, pad2, pad3, pad4; };
 // inside the piece (all copied to LDS when the piece starts, so that its levels never wait for HBM): levels [ilv0, +nilv), items
 // [iit0, +nit_i), update records [iu0, +nu_i), multi-blocks [imb0, +nimb), assembly sources [as0, +nas);
-// update matrix: U items [uit0, +nuit), split U blocks [umb0, +numb)
+// update matrix: U items [uit0, +nuit), split U blocks [umb0, +numb), their update records [uu0, +nuu) and child sources [us0, +nus)
+// (UItem.u0 / .s0 and UMb.s0 are relative to uu0 / us0: the per-depth kernels stage these records in LDS as well)
 
 constexpr int kItemDoubles = 42;     // LDS doubles per partial tile: 6 x 6 entries + 6 rhs components
 constexpr int kMaxILevels = 64;      // internal levels per piece (LDS table in the kernels)
@@ -88,18 +90,18 @@ struct SymIn {
 };
 struct CholOpts {
   int cap_leaf = 3072;     // doubles of L per piece (pieces that share launches)
-  int cap_tail = 6144;     // doubles of L per piece of a tail
+  int cap_tail = 4608;     // doubles of L per piece of a tail (two tail workgroups per CU must fit the LDS)
   int max_blocks = 224;    // blocks per piece
   int tail_width = -1;     // a graph's tail starts where it has <= tail_width pieces per depth; -1: 6 for batches >= 32, else 2; 0: no tail
   int nt_leaf = 256, nt_tail = 512;   // workgroup sizes the items are cut for
   int min_chunk = 4;       // a list of <= min_chunk updates is never split
-  int pcap_leaf = 16, pcap_tail = 64;   // partial tiles per phase (split lists): LDS budget of a piece
+  int pcap_leaf = 16, pcap_tail = 32;   // partial tiles per phase (split lists): LDS budget of a piece
   bool dump = false;
   static int env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
   void from_env() {
     cap_leaf = env_int("SSLAM_CHOL_CAP_LEAF", cap_leaf); cap_tail = env_int("SSLAM_CHOL_CAP_TAIL", cap_tail);
     max_blocks = env_int("SSLAM_CHOL_MAX_BLOCKS", max_blocks); tail_width = env_int("SSLAM_CHOL_TAIL_WIDTH", tail_width);
-    nt_tail = env_int("SSLAM_CHOL_NT_TAIL", nt_tail); min_chunk = std::max(1, env_int("SSLAM_CHOL_MIN_CHUNK", min_chunk));
+    nt_tail = env_int("SSLAM_CHOL_NT_TAIL", nt_tail); nt_leaf = env_int("SSLAM_CHOL_NT_LEAF", nt_leaf); min_chunk = std::max(1, env_int("SSLAM_CHOL_MIN_CHUNK", min_chunk));
     pcap_leaf = env_int("SSLAM_CHOL_PCAP_LEAF", pcap_leaf); pcap_tail = env_int("SSLAM_CHOL_PCAP_TAIL", pcap_tail);
     dump = getenv("SSLAM_CHOL_DUMP") != nullptr;
   }
@@ -114,6 +116,7 @@ struct CholHost {
   std::vector<AsmSrc> asrc, usrc; std::vector<FwdMeta> fwd; std::vector<UItem> uitem; std::vector<UMb> umb;
   std::vector<int> lvl_ptr, lvl_cols;       // column levels of the elimination tree (multi right-hand-side solves)
   std::vector<int> plv_ptr, plv_pieces;     // pieces grouped by depth (one launch each)
+  std::vector<PieceMeta> lpiece;            // piece records in launch order: plv_pieces then tail_pieces (one dependent load less per workgroup)
   std::vector<int> tail_ptr, tail_pieces;   // per graph: its tail pieces in elimination order
   std::vector<int> plv_lds_f, plv_lds_b;    // LDS doubles per launch (factor / backward)
   int tail_lds_f = 0, tail_lds_b = 0;
@@ -603,6 +606,8 @@ inline int chol_symbolic(const SymIn& in, CholOpts opt, CholHost& out) {
     std::sort(order.begin(), order.end(), [&](int x, int y2) { return ub[x].a != ub[y2].a ? ub[x].a < ub[y2].a : ub[x].b < ub[y2].b; });
     pm.uit0 = (int)out.uitem.size();
     pm.umb0 = (int)out.umb.size();
+    pm.uu0 = (int)out.upd.size();
+    pm.us0 = (int)out.usrc.size();
     {
       int64_t cur = ucur;
       std::vector<int> uoffs(ub.size());
@@ -627,10 +632,10 @@ inline int chol_symbolic(const SymIn& in, CholOpts opt, CholHost& out) {
         int uy = -1;
         if (diag) uy = piece_uy[p] + 6 * (int)(std::lower_bound(R.begin(), R.end(), x.a) - R.begin());
         const int tpk = (di == 6 ? kUpdDi6 : 0) | (diag ? kUpdDiag : 0) | (dj == 6 ? kUpdDj6 : 0);
-        const int u0 = (int)out.upd.size();
+        const int u0 = (int)out.upd.size() - pm.uu0;
         for (auto& u : x.own) out.upd.push_back(UpdMeta{u[0], u[1], col_yoff[u[2]], tpk | (col_dim[u[2]] == 6 ? kUpdDk6 : 0)});
         const int n = (int)x.own.size();
-        const int s0 = (int)out.usrc.size();
+        const int s0 = (int)out.usrc.size() - pm.us0;
         for (auto& a2 : x.src) out.usrc.push_back(a2);
         const int ns = (int)x.src.size();
         const int k = std::max(1, (n + chunk - 1) / chunk);
@@ -647,13 +652,20 @@ inline int chol_symbolic(const SymIn& in, CholOpts opt, CholHost& out) {
     }
     pm.nuit = (int)out.uitem.size() - pm.uit0;
     pm.numb = (int)out.umb.size() - pm.umb0;
+    pm.nuu = (int)out.upd.size() - pm.uu0;
+    pm.nus = (int)out.usrc.size() - pm.us0;
     if (piece_parent[p] < 0 && !ub.empty()) { out.error = "a root piece has an update matrix"; return -1; }
   }
   out.unz = ucur;
+  out.lpiece.clear();
+  out.lpiece.reserve(npiece);
+  for (int p : out.plv_pieces) out.lpiece.push_back(out.piece[p]);
+  for (int p : out.tail_pieces) out.lpiece.push_back(out.piece[p]);
   // ---- LDS needs (doubles) ---------------------------------------------------------------------------------------------------
   auto lds_f = [&](int p) {
     const PieceMeta& pm = out.piece[p];
-    return ((pm.lsize + 1) & ~1) + 2 * ((pm.ysize + 1) & ~1) + 4 * pm.nb + 2 * pm.nc + 2 * pm.nit_i + 2 * pm.nu_i + 2 * pm.nimb + pm.nas +
+    const int ustage = piece_tail[p] ? 0 : 4 * pm.nuit + 4 * pm.numb + 2 * pm.nuu + pm.nus + 2;
+    return ((pm.lsize + 1) & ~1) + 2 * ((pm.ysize + 1) & ~1) + 4 * pm.nb + 2 * pm.nc + 2 * pm.nit_i + 2 * pm.nu_i + 2 * pm.nimb + pm.nas + ustage +
            kItemDoubles * piece_pmax[p] + 8;
   };
   auto lds_b = [&](int p) {

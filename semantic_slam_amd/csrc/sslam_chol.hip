@@ -33,6 +33,8 @@ struct CholView {
   const MbMeta* mb;
   const ILevel* ilv;
   const PieceMeta* piece;
+  const PieceMeta* lpiece;  // the same records in launch order: [pieces by depth | tails by graph]
+  int ltail0;               // first tail record in lpiece
   const AsmSrc* asrc;       // child update-matrix blocks absorbed when a piece is gathered
   const AsmSrc* usrc;       // child update-matrix blocks passed on through a piece's own update matrix
   const UItem* uitem;
@@ -52,7 +54,7 @@ struct CholView {
 struct CholPlan {
   CholView C{};
   std::vector<int> lvl_ptr, plv_ptr, plv_lds_f, plv_lds_b;
-  int tail_lds_f = 0, tail_lds_b = 0, tail_total = 0, nt_tail = 512;
+  int tail_lds_f = 0, tail_lds_b = 0, tail_total = 0, nt_tail = 512, nt_leaf = 256;
   std::vector<void*> allocs;
   int64_t lnz = 0, unz = 0;
   double* d_multi_y = nullptr;  // scratch for multi-rhs solves
@@ -208,10 +210,20 @@ __device__ __forceinline__ void run_uitems(const UItem* __restrict__ items, int 
     const bool diag = im.flags & kUItemDiag;
     const int tre = 3 * tr < di ? tr : 0, tce = 3 * tc < dj ? tc : 0;
     double acc[9], accy[3];
+    // the first child block of this tile: its loads travel while the own updates are computed out of LDS
+    const bool sole = im.flags & kItemSole;
+    const AsmSrc src0 = (sole && im.ns > 0) ? usrc[im.s0] : AsmSrc{0, -1};
+    {
+      const double* o = U + src0.uoff;
+      const bool on = sole && im.ns > 0;
 #pragma unroll
-    for (int q = 0; q < 9; ++q) acc[q] = 0;
+      for (int rr = 0; rr < 3; ++rr)
 #pragma unroll
-    for (int q = 0; q < 3; ++q) accy[q] = 0;
+        for (int cc = 0; cc < 3; ++cc) { const double v = o[(3 * tre + rr) * dj + 3 * tce + cc]; acc[rr * 3 + cc] = on ? v : 0.0; }
+      const double* oy = U + (src0.uyoff >= 0 ? src0.uyoff : 0);
+#pragma unroll
+      for (int rr = 0; rr < 3; ++rr) { const double v = oy[3 * tre + rr]; accy[rr] = (on && diag && src0.uyoff >= 0) ? v : 0.0; }
+    }
     for (int k0 = 0; k0 < n; k0 += 8) {
       const UpdMeta r0 = upd[im.u0 + min(k0 + lq, n - 1)];
       const UpdMeta r1 = upd[im.u0 + min(k0 + 4 + lq, n - 1)];
@@ -224,8 +236,8 @@ __device__ __forceinline__ void run_uitems(const UItem* __restrict__ items, int 
 #undef SSLAM_STEP
     }
     if (3 * tr < di && 3 * tc < dj) {
-      if (im.flags & kItemSole) {
-        for (int s2 = 0; s2 < im.ns; ++s2) {
+      if (sole) {
+        for (int s2 = 1; s2 < im.ns; ++s2) {
           const AsmSrc src = usrc[im.s0 + s2];
           const double* o = U + src.uoff;
 #pragma unroll
@@ -347,7 +359,7 @@ __device__ __forceinline__ void row_solve(double* v, const double* Ljj, const do
     if (threadIdx.x == 0) dbg[k] += now_ - tprev;                               \
     tprev = now_;                                                               \
   }
-template <int NT>
+template <int NT, bool USTAGE>
 __device__ __forceinline__ void chol_piece(const BatchView& V, const CholView& C, const PieceMeta pm, double* sm, long long* dbg) {
   constexpr int NW = NT / 64;
   long long tprev = dbg ? clock64() : 0;
@@ -366,7 +378,12 @@ __device__ __forceinline__ void chol_piece(const BatchView& V, const CholView& C
   UpdMeta* sUpd = reinterpret_cast<UpdMeta*>(sItem + pm.nit_i);            // internal update records
   MbMeta* sMb = reinterpret_cast<MbMeta*>(sUpd + pm.nu_i);                 // internal multi-blocks
   AsmSrc* sAsm = reinterpret_cast<AsmSrc*>(sMb + pm.nimb);                 // child update-matrix blocks to absorb
-  double* part = reinterpret_cast<double*>(sAsm + pm.nas + (pm.nas & 1));
+  // update-matrix records: staged in LDS by the per-depth kernels (USTAGE), read from HBM by the tail
+  UItem* sUItem = reinterpret_cast<UItem*>(sAsm + pm.nas + (pm.nas & 1));
+  UMb* sUMb = reinterpret_cast<UMb*>(sUItem + (USTAGE ? pm.nuit : 0));
+  UpdMeta* sUUpd = reinterpret_cast<UpdMeta*>(sUMb + (USTAGE ? pm.numb : 0));
+  AsmSrc* sUSrc = reinterpret_cast<AsmSrc*>(sUUpd + (USTAGE ? pm.nuu : 0));
+  double* part = reinterpret_cast<double*>(sUSrc + (USTAGE ? pm.nus + (pm.nus & 1) : 0));
   const double* __restrict__ H = V.Hpp_diag;
   const double* __restrict__ U = C.Uval;
   const int ry = lane - 40;
@@ -377,48 +394,92 @@ __device__ __forceinline__ void chol_piece(const BatchView& V, const CholView& C
   for (int i = tid; i < pm.nu_i; i += NT) sUpd[i] = C.upd[pm.iu0 + i];
   for (int i = tid; i < pm.nimb; i += NT) sMb[i] = C.mb[pm.imb0 + i];
   for (int i = tid; i < pm.nas; i += NT) sAsm[i] = C.asrc[pm.as0 + i];
+  if (USTAGE) {
+    for (int i = tid; i < pm.nuit; i += NT) sUItem[i] = C.uitem[pm.uit0 + i];
+    for (int i = tid; i < pm.numb; i += NT) sUMb[i] = C.umb[pm.umb0 + i];
+    for (int i = tid; i < pm.nuu; i += NT) sUUpd[i] = C.upd[pm.uu0 + i];
+    for (int i = tid; i < pm.nus; i += NT) sUSrc[i] = C.usrc[pm.us0 + i];
+  }
   for (int c = tid; c < pm.nc; c += NT) {
     const ColMeta cm = C.col[pm.c0 + c];
     sCol[c] = make_int4(cm.base - pm.lbase, cm.dim, cm.yoff - pm.y0, 0);
   }
   __syncthreads();
   SSLAM_STAMP(0)
-  // ---- 1. gather: A(:, piece) + lambda I, rhs, minus what the child pieces left for these blocks (their update matrices:
-  //         coalesced 288-byte reads) -> LDS.  One wave per block, lane = entry; four blocks in flight per wave.
+  // ---- 1. gather: A(:, piece) + lambda I and the rhs -> LDS.  One wave per block, lane = entry; sixteen blocks' loads are in
+  //         flight per wave before the first one is consumed (unconditional loads from always-valid addresses: no branches
+  //         between them, or the compiler serialises the round trips).
   {
-    constexpr int kPipe = 4;
-    for (int b0 = wave; b0 < pm.nb; b0 += NW * kPipe) {
+    constexpr int kPipe = 16;
+    for (int b0 = wave * kPipe; b0 < pm.nb; b0 += NW * kPipe) {
       double hv[kPipe];
 #pragma unroll
       for (int k = 0; k < kPipe; ++k) {
-        const BlkMeta bm = sBlk[min(b0 + k * NW, pm.nb - 1)];
-        const int di = bm.info & 15, dj = (bm.info >> 4) & 15, nas = (bm.info >> kBlkNasShift) & 255;
+        const BlkMeta bm = sBlk[min(b0 + k, pm.nb - 1)];
+        const int di = bm.info & 15, dj = (bm.info >> 4) & 15;
         const bool diag = bm.info & kBlkDiag;
         const bool ent = lane < di * dj, rhs = diag && ry >= 0 && ry < dj;
         const int r = lane / dj, c = lane - r * dj;
-        double v = 0;
-        if (ent) {
-          if (bm.src >= 0) v = (bm.info & kBlkFmt) ? H[bm.src + c * di + r] : H[bm.src + lane];
-          if (diag && r == c) v += lambda;
-        } else if (rhs) {
-          v = V.bvec[bm.xoff_row + ry];
-        }
-        for (int s2 = 0; s2 < nas; ++s2) {
-          const AsmSrc as = sAsm[bm.as0 + s2];
-          if (ent) v -= U[as.uoff + lane];
-          else if (rhs && as.uyoff >= 0) v -= U[as.uyoff + ry];
-        }
-        hv[k] = v;
+        const double* pa = H;                                    // idle lanes / fill blocks: any valid address
+        if (ent && bm.src >= 0) pa = H + bm.src + ((bm.info & kBlkFmt) ? c * di + r : lane);
+        else if (rhs) pa = V.bvec + bm.xoff_row + ry;
+        hv[k] = *pa;
       }
 #pragma unroll
       for (int k = 0; k < kPipe; ++k) {
-        const int idx = b0 + k * NW;
+        const int idx = b0 + k;
         if (idx >= pm.nb) continue;
         const BlkMeta bm = sBlk[idx];
         const int di = bm.info & 15, dj = (bm.info >> 4) & 15;
         const bool diag = bm.info & kBlkDiag;
-        if (lane < di * dj) smL[bm.off - pm.lbase + lane] = hv[k];
+        const int r = lane / dj, c = lane - r * dj;
+        if (lane < di * dj) smL[bm.off - pm.lbase + lane] = (bm.src >= 0 ? hv[k] : 0.0) + ((diag && r == c) ? lambda : 0.0);
         else if (diag && ry >= 0 && ry < dj) smY[bm.colyoff - pm.y0 + ry] = hv[k];
+      }
+    }
+  }
+  // ---- 1b. minus what the child pieces left for these blocks (their update matrices: coalesced 288-byte reads, no arithmetic).
+  //          A block's sources are summed by one wave -> no conflicts, fixed order.
+  if (pm.nas > 0) {
+    __syncthreads();
+    constexpr int kPipe = 8;
+    for (int b0 = wave * kPipe; b0 < pm.nb; b0 += NW * kPipe) {
+      double uv[kPipe];
+#pragma unroll
+      for (int k = 0; k < kPipe; ++k) {     // first source of every block in flight together
+        const BlkMeta bm = sBlk[min(b0 + k, pm.nb - 1)];
+        const int di = bm.info & 15, dj = (bm.info >> 4) & 15, nas = (bm.info >> kBlkNasShift) & 255;
+        const bool diag = bm.info & kBlkDiag;
+        const bool ent = lane < di * dj, rhs = diag && ry >= 0 && ry < dj;
+        const double* pa = U;
+        if (nas > 0) {
+          const AsmSrc as = sAsm[bm.as0];
+          if (ent) pa = U + as.uoff + lane;
+          else if (rhs && as.uyoff >= 0) pa = U + as.uyoff + ry;
+        }
+        uv[k] = *pa;
+      }
+#pragma unroll
+      for (int k = 0; k < kPipe; ++k) {
+        const int idx = b0 + k;
+        if (idx >= pm.nb) continue;
+        const BlkMeta bm = sBlk[idx];
+        const int di = bm.info & 15, dj = (bm.info >> 4) & 15, nas = (bm.info >> kBlkNasShift) & 255;
+        if (nas == 0) continue;
+        const bool diag = bm.info & kBlkDiag;
+        const bool ent = lane < di * dj, rhs = diag && ry >= 0 && ry < dj;
+        double v = 0;
+        {
+          const AsmSrc as = sAsm[bm.as0];
+          if (ent || (rhs && as.uyoff >= 0)) v = uv[k];
+        }
+        for (int s2 = 1; s2 < nas; ++s2) {
+          const AsmSrc as = sAsm[bm.as0 + s2];
+          if (ent) v += U[as.uoff + lane];
+          else if (rhs && as.uyoff >= 0) v += U[as.uyoff + ry];
+        }
+        if (ent) smL[bm.off - pm.lbase + lane] -= v;
+        else if (rhs) smY[bm.colyoff - pm.y0 + ry] -= v;
       }
     }
   }
@@ -459,10 +520,12 @@ __device__ __forceinline__ void chol_piece(const BatchView& V, const CholView& C
   }
   // ---- 3. the update matrix over the rows above the piece: own updates out of LDS + the children's blocks -> HBM
   if (pm.nuit > 0) {
-    run_uitems<NT>(C.uitem, pm.uit0, pm.uit0 + pm.nuit, C.upd, C.usrc, smL, smY, pm.lbase, pm.y0, C.Uval, part, tid);
+    if (USTAGE) run_uitems<NT>(sUItem, 0, pm.nuit, sUUpd, sUSrc, smL, smY, pm.lbase, pm.y0, C.Uval, part, tid);
+    else run_uitems<NT>(C.uitem + pm.uit0, 0, pm.nuit, C.upd + pm.uu0, C.usrc + pm.us0, smL, smY, pm.lbase, pm.y0, C.Uval, part, tid);
     if (pm.numb > 0) {
       __syncthreads();
-      reduce_umulti(C.umb, pm.umb0, pm.umb0 + pm.numb, C.usrc, C.Uval, part, wave, lane, NW);
+      if (USTAGE) reduce_umulti(sUMb, 0, pm.numb, sUSrc, C.Uval, part, wave, lane, NW);
+      else reduce_umulti(C.umb + pm.umb0, 0, pm.numb, C.usrc + pm.us0, C.Uval, part, wave, lane, NW);
     }
   }
   SSLAM_STAMP(6)
@@ -477,22 +540,22 @@ __device__ __forceinline__ void chol_piece(const BatchView& V, const CholView& C
 template <int NT>
 __global__ __launch_bounds__(NT) void k_chol_pieces(BatchView V, CholView C, int begin) {
   extern __shared__ double sm[];
-  const PieceMeta pm = C.piece[C.plv_pieces[begin + blockIdx.x]];
+  const PieceMeta pm = C.lpiece[begin + blockIdx.x];
   if (!V.lm[pm.graph].in_trial) return;
-  chol_piece<NT>(V, C, pm, sm, (C.dbg && blockIdx.x == 0) ? C.dbg + 16 : nullptr);
+  chol_piece<NT, true>(V, C, pm, sm, (C.dbg && blockIdx.x == 0) ? C.dbg + 16 : nullptr);
 }
 
 // Top of the elimination tree: once a graph is down to a few pieces per depth a launch per depth only buys launch
 // latency.  One workgroup per graph walks its remaining pieces in elimination order; the barrier between pieces orders
 // the L / y stores of one piece before the loads of the next (same CU).
 template <int NT>
-__global__ __launch_bounds__(NT) void k_chol_tail(BatchView V, CholView C) {
+__global__ __launch_bounds__(NT, 4) void k_chol_tail(BatchView V, CholView C) {   // <= 128 VGPRs: two 512-thread workgroups per CU
   extern __shared__ double sm[];
   const int g = blockIdx.x;
   if (!V.lm[g].in_trial) return;
   const int q1 = C.tail_ptr[g + 1];
   for (int q = C.tail_ptr[g]; q < q1; ++q) {
-    chol_piece<NT>(V, C, C.piece[C.tail_pieces[q]], sm, (C.dbg && g == 0) ? C.dbg : nullptr);
+    chol_piece<NT, false>(V, C, C.lpiece[C.ltail0 + q], sm, (C.dbg && g == 0) ? C.dbg : nullptr);
     __threadfence_block();
     __syncthreads();
   }
@@ -520,7 +583,7 @@ __device__ __forceinline__ void chol_piece_backward(const CholView& C, const Pie
   for (int b = tid; b < pm.nb; b += NT) {
     const BlkMeta bm = C.blk[pm.b0 + b];
     const bool in = bm.info & kBlkRowIn;
-    sBlk[b] = make_int2((bm.off - pm.lbase) | ((bm.info & 15) << 24), in ? bm.yoff_row - pm.y0 : bm.xoff_row);
+    sBlk[b] = make_int2((bm.off - pm.lbase) | ((bm.info & 15) << 24) | (((bm.info >> 4) & 15) << 28), in ? (bm.yoff_row - pm.y0) | (int)0x80000000u : bm.xoff_row);
   }
   for (int c = tid; c < pm.nc; c += NT) {
     const ColMeta cm = C.col[pm.c0 + c];
@@ -531,11 +594,11 @@ __device__ __forceinline__ void chol_piece_backward(const CholView& C, const Pie
   // ---- 1. rows above the piece (x already final in HBM): thread (block, component) -> smE; then summed per column in block order
   for (int t = tid; t < pm.nb * 8; t += NT) {
     const int b = t >> 3, c = t & 7;
-    const BlkMeta bm = C.blk[pm.b0 + b];   // the table above is complete, but info (dj, row-in-piece) is only in the record
-    const int di = bm.info & 15, dj = (bm.info >> 4) & 15;
-    if ((bm.info & kBlkRowIn) || c >= dj) continue;
-    const double* Bk = smL + (bm.off - pm.lbase) + c;
-    const double* xi = x + bm.xoff_row;
+    const int2 bm = sBlk[b];
+    const int di = (bm.x >> 24) & 15, dj = (bm.x >> 28) & 15;
+    if (bm.y < 0 || c >= dj) continue;     // row inside the piece / idle lane
+    const double* Bk = smL + (bm.x & 0xFFFFFF) + c;
+    const double* xi = x + bm.y;
     double s = Bk[0] * xi[0] + Bk[dj] * xi[1] + Bk[2 * dj] * xi[2];
     if (di == 6) s += Bk[3 * dj] * xi[3] + Bk[4 * dj] * xi[4] + Bk[5 * dj] * xi[5];
     smE[t] = s;
@@ -568,9 +631,9 @@ __device__ __forceinline__ void chol_piece_backward(const CholView& C, const Pie
       for (int bi = 1 + q; bi < nbi; bi += Q) {
         const int2 bm = sBlk[cm.w + bi];
         const double* Bk = smL + (bm.x & 0xFFFFFF) + cc;
-        const double* xi = smX + bm.y;
+        const double* xi = smX + (bm.y & 0x7FFFFFFF);
         double s = Bk[0] * xi[0] + Bk[dj] * xi[1] + Bk[2 * dj] * xi[2];
-        if ((bm.x >> 24) == 6) s += Bk[3 * dj] * xi[3] + Bk[4 * dj] * xi[4] + Bk[5 * dj] * xi[5];
+        if (((bm.x >> 24) & 15) == 6) s += Bk[3 * dj] * xi[3] + Bk[4 * dj] * xi[4] + Bk[5 * dj] * xi[5];
         acc += s;
       }
       if (Q > 1) acc += __shfl_xor(acc, 8, 64);
@@ -602,7 +665,7 @@ __device__ __forceinline__ void chol_piece_backward(const CholView& C, const Pie
 template <int NT>
 __global__ __launch_bounds__(NT) void k_chol_back_pieces(CholView C, int begin, const double* __restrict__ y, double* x, const LmState* __restrict__ lm) {
   extern __shared__ double sm[];
-  const PieceMeta pm = C.piece[C.plv_pieces[begin + blockIdx.x]];
+  const PieceMeta pm = C.lpiece[begin + blockIdx.x];
   if (lm && !lm[pm.graph].in_trial) return;
   chol_piece_backward<NT>(C, pm, y, x, sm);
 }
@@ -613,7 +676,7 @@ __global__ __launch_bounds__(NT) void k_chol_back_tail(CholView C, const double*
   if (lm && !lm[g].in_trial) return;
   const int q0 = C.tail_ptr[g];
   for (int q = C.tail_ptr[g + 1] - 1; q >= q0; --q) {
-    chol_piece_backward<NT>(C, C.piece[C.tail_pieces[q]], y, x, sm);
+    chol_piece_backward<NT>(C, C.lpiece[C.ltail0 + q], y, x, sm);
     __threadfence_block();
     __syncthreads();
   }
@@ -739,6 +802,7 @@ int chol_plan_build(Batch& b) {
   CholOpts opt;
   opt.from_env();
   if (opt.nt_tail != 1024) opt.nt_tail = 512;
+  if (opt.nt_leaf != 64 && opt.nt_leaf != 128) opt.nt_leaf = 256;
   CholHost H;
   if (chol_symbolic(in, opt, H)) return set_error(SSLAM_ERR_NUMERIC, "Cholesky plan: %s", H.error.c_str());
   CholPlan* P = new CholPlan();
@@ -746,7 +810,7 @@ int chol_plan_build(Batch& b) {
   CholView& C = P->C;
   C.ncol = H.ncol; C.nlevels = H.nlevels; C.dim = H.dim; C.npiece = H.npiece;
   P->lvl_ptr = H.lvl_ptr; P->plv_ptr = H.plv_ptr; P->plv_lds_f = H.plv_lds_f; P->plv_lds_b = H.plv_lds_b;
-  P->tail_lds_f = H.tail_lds_f; P->tail_lds_b = H.tail_lds_b; P->tail_total = (int)H.tail_pieces.size(); P->nt_tail = H.nt_tail;
+  P->tail_lds_f = H.tail_lds_f; P->tail_lds_b = H.tail_lds_b; P->tail_total = (int)H.tail_pieces.size(); P->nt_tail = H.nt_tail; P->nt_leaf = H.nt_leaf;
   P->lnz = H.lnz;
   int rc;
   if ((rc = up_to_dev(*P, b.stream, H.col, &C.col))) return rc;
@@ -756,6 +820,8 @@ int chol_plan_build(Batch& b) {
   if ((rc = up_to_dev(*P, b.stream, H.mb, &C.mb))) return rc;
   if ((rc = up_to_dev(*P, b.stream, H.ilv, &C.ilv))) return rc;
   if ((rc = up_to_dev(*P, b.stream, H.piece, &C.piece))) return rc;
+  if ((rc = up_to_dev(*P, b.stream, H.lpiece, &C.lpiece))) return rc;
+  C.ltail0 = (int)H.plv_pieces.size();
   if ((rc = up_to_dev(*P, b.stream, H.asrc, &C.asrc))) return rc;
   if ((rc = up_to_dev(*P, b.stream, H.usrc, &C.usrc))) return rc;
   if ((rc = up_to_dev(*P, b.stream, H.uitem, &C.uitem))) return rc;
@@ -788,6 +854,10 @@ int chol_plan_build(Batch& b) {
   if (lds_max > 48 * 1024) {
     const int v = (int)lds_max;
     SSLAM_HIP_TRY(hipFuncSetAttribute((const void*)k_chol_pieces<256>, hipFuncAttributeMaxDynamicSharedMemorySize, v));
+    SSLAM_HIP_TRY(hipFuncSetAttribute((const void*)k_chol_pieces<128>, hipFuncAttributeMaxDynamicSharedMemorySize, v));
+    SSLAM_HIP_TRY(hipFuncSetAttribute((const void*)k_chol_pieces<64>, hipFuncAttributeMaxDynamicSharedMemorySize, v));
+    SSLAM_HIP_TRY(hipFuncSetAttribute((const void*)k_chol_back_pieces<128>, hipFuncAttributeMaxDynamicSharedMemorySize, v));
+    SSLAM_HIP_TRY(hipFuncSetAttribute((const void*)k_chol_back_pieces<64>, hipFuncAttributeMaxDynamicSharedMemorySize, v));
     SSLAM_HIP_TRY(hipFuncSetAttribute((const void*)k_chol_tail<512>, hipFuncAttributeMaxDynamicSharedMemorySize, v));
     SSLAM_HIP_TRY(hipFuncSetAttribute((const void*)k_chol_tail<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, v));
     SSLAM_HIP_TRY(hipFuncSetAttribute((const void*)k_chol_back_pieces<256>, hipFuncAttributeMaxDynamicSharedMemorySize, v));
@@ -809,7 +879,11 @@ int chol_factor_and_forward(Batch& b) {
   const int nplv = (int)P.plv_lds_f.size();
   for (int l = 0; l < nplv; ++l) {
     const int n = P.plv_ptr[l + 1] - P.plv_ptr[l];
-    if (n > 0) hipLaunchKernelGGL(k_chol_pieces<256>, dim3(n), dim3(256), (size_t)P.plv_lds_f[l] * sizeof(double), b.stream, b.V, C, P.plv_ptr[l]);
+    if (n <= 0) continue;
+    const size_t lds = (size_t)P.plv_lds_f[l] * sizeof(double);
+    if (P.nt_leaf == 64) hipLaunchKernelGGL(k_chol_pieces<64>, dim3(n), dim3(64), lds, b.stream, b.V, C, P.plv_ptr[l]);
+    else if (P.nt_leaf == 128) hipLaunchKernelGGL(k_chol_pieces<128>, dim3(n), dim3(128), lds, b.stream, b.V, C, P.plv_ptr[l]);
+    else hipLaunchKernelGGL(k_chol_pieces<256>, dim3(n), dim3(256), lds, b.stream, b.V, C, P.plv_ptr[l]);
   }
   if (P.tail_total > 0) {
     if (P.nt_tail == 1024) hipLaunchKernelGGL(k_chol_tail<1024>, dim3(b.V.B), dim3(1024), (size_t)P.tail_lds_f * sizeof(double), b.stream, b.V, C);
@@ -829,7 +903,11 @@ int chol_backward(Batch& b) {
     hipLaunchKernelGGL(k_chol_back_tail<512>, dim3(b.V.B), dim3(512), (size_t)P.tail_lds_b * sizeof(double), b.stream, C, (const double*)C.y, b.V.x, (const LmState*)b.V.lm);
   for (int l = (int)P.plv_lds_b.size() - 1; l >= 0; --l) {
     const int n = P.plv_ptr[l + 1] - P.plv_ptr[l];
-    if (n > 0) hipLaunchKernelGGL(k_chol_back_pieces<256>, dim3(n), dim3(256), (size_t)P.plv_lds_b[l] * sizeof(double), b.stream, C, P.plv_ptr[l], (const double*)C.y, b.V.x, (const LmState*)b.V.lm);
+    if (n <= 0) continue;
+    const size_t lds = (size_t)P.plv_lds_b[l] * sizeof(double);
+    if (P.nt_leaf == 64) hipLaunchKernelGGL(k_chol_back_pieces<64>, dim3(n), dim3(64), lds, b.stream, C, P.plv_ptr[l], (const double*)C.y, b.V.x, (const LmState*)b.V.lm);
+    else if (P.nt_leaf == 128) hipLaunchKernelGGL(k_chol_back_pieces<128>, dim3(n), dim3(128), lds, b.stream, C, P.plv_ptr[l], (const double*)C.y, b.V.x, (const LmState*)b.V.lm);
+    else hipLaunchKernelGGL(k_chol_back_pieces<256>, dim3(n), dim3(256), lds, b.stream, C, P.plv_ptr[l], (const double*)C.y, b.V.x, (const LmState*)b.V.lm);
   }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return set_error(SSLAM_ERR_HIP, "cholesky solve launch: %s", hipGetErrorString(e));

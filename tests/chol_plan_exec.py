@@ -19,7 +19,8 @@ ITEM = np.dtype([(n, "<i4") for n in ("u0", "n", "tloff", "flags")])
 MB = np.dtype([(n, "<i4") for n in ("tloff", "ps0", "n", "info")])
 ILV = np.dtype([(n, "<i4") for n in ("c0", "c1", "b0", "b1", "it0", "it1", "mb0", "mb1")])
 PIECE = np.dtype([(n, "<i4") for n in ("graph", "c0", "nc", "b0", "nb", "lbase", "lsize", "y0", "ysize", "ilv0", "nilv", "iit0", "nit_i",
-                                       "iu0", "nu_i", "imb0", "nimb", "as0", "nas", "uit0", "nuit", "umb0", "numb", "pad")])
+                                       "iu0", "nu_i", "imb0", "nimb", "as0", "nas", "uit0", "nuit", "umb0", "numb",
+                                       "uu0", "nuu", "us0", "nus", "pad0", "pad1", "pad2", "pad3", "pad4")])
 K_DI6, K_DK6, K_DIAG, K_DJ6 = 1 << 20, 1 << 21, 1 << 22, 1 << 23
 B_FMT, B_DIAG, B_ROWIN = 1 << 8, 1 << 9, 1 << 10
 
@@ -187,17 +188,21 @@ class Plan:
                 smL[o:o + di * dj] = np.linalg.solve(Lj, Vb.T).T.ravel()
         # update matrix of the piece: own updates (sources in the piece) + the children's blocks
         part = {}
+        uupd = self.upd[pm["uu0"]:pm["uu0"] + pm["nuu"]]
+        usrc = self.usrc[pm["us0"]:pm["us0"] + pm["nus"]]
         for im in self.uitem[pm["uit0"]:pm["uit0"] + pm["nuit"]]:
             fl = int(im["flags"])
             di = 6 if fl & (1 << 12) else 3
             dj = 6 if fl & (1 << 13) else 3
             diag = bool(fl & (1 << 14))
-            u = self.upd[im["u0"]:im["u0"] + im["n"]]
+            u = uupd[im["u0"]:im["u0"] + im["n"]]
+            assert len(u) == im["n"]
             for r in u:
                 assert lbase <= r["ua"] < lbase + pm["lsize"] and lbase <= r["ub"] < lbase + pm["lsize"]
             acc, accy = self._tile_sum(u, smL, smY, lbase, y0, di, dj, diag)
             if fl & 1:
-                for a in self.usrc[im["s0"]:im["s0"] + im["ns"]]:
+                assert im["s0"] + im["ns"] <= pm["nus"]
+                for a in usrc[im["s0"]:im["s0"] + im["ns"]]:
                     blk = Uval[a["uoff"]:a["uoff"] + di * dj]
                     assert not np.isnan(blk).any()
                     acc += blk.reshape(di, dj)
@@ -215,7 +220,7 @@ class Plan:
             for q in range(mm["n"]):
                 a, ay = part[mm["ps0"] + q]
                 acc += a; accy += ay
-            for a in self.usrc[mm["s0"]:mm["s0"] + mm["ns"]]:
+            for a in usrc[mm["s0"]:mm["s0"] + mm["ns"]]:
                 acc += Uval[a["uoff"]:a["uoff"] + di * dj].reshape(di, dj)
                 if diag and a["uyoff"] >= 0:
                     accy += Uval[a["uyoff"]:a["uyoff"] + dj]

@@ -97,8 +97,7 @@ def _structure_invariants(plan):
             for r in plan.upd[pm["iu0"] + im["u0"]:pm["iu0"] + im["u0"] + im["n"]]:
                 assert pm["lbase"] <= r["ua"] < pm["lbase"] + pm["lsize"] and pm["lbase"] <= r["ub"] < pm["lbase"] + pm["lsize"]
         srcs = list(plan.asrc[pm["as0"]:pm["as0"] + pm["nas"]])
-        for im in plan.uitem[pm["uit0"]:pm["uit0"] + pm["nuit"]]:
-            srcs += list(plan.usrc[im["s0"]:im["s0"] + im["ns"]])
+        srcs += list(plan.usrc[pm["us0"]:pm["us0"] + pm["nus"]])
         for a in srcs:
             q = writer[int(a["uoff"])]
             assert rank[q] < rank[p]
@@ -124,7 +123,7 @@ def test_plan_with_tiny_pieces_exercises_every_phase(hip_lib):
     env = {"SSLAM_CHOL_CAP_LEAF": 400, "SSLAM_CHOL_CAP_TAIL": 700, "SSLAM_CHOL_TAIL_WIDTH": 2, "SSLAM_CHOL_MIN_CHUNK": 1}
     plan, H, b = _plan_and_system(hip_lib, g, False, env)
     assert plan.npiece > 20 and len(plan.tail_pieces) >= 2 and len(plan.plv_ptr) > 2
-    assert len(plan.mb) > 0 and len(plan.umb) > 0 and np.any(plan.piece["nas"] > 0) and np.any(plan.uitem["ns"] > 0)
+    assert len(plan.mb) > 0 and len(plan.umb) > 0 and np.any(plan.piece["nas"] > 0) and np.any(plan.piece["nus"] > 0)
     _structure_invariants(plan)
     _check(plan, H, b, 1e-3)
     # same system, no tail: every piece goes through the per-depth launches

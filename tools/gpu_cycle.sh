@@ -9,4 +9,5 @@ for B in 512 1; do
   rocprofv3 --kernel-trace --output-format csv -d $O/_p$B -- python $R/tools/prof_opt.py $B 3 > $O/${T}_p$B.log 2>&1
   python $R/tools/level_profile.py $O/_p$B > $O/${T}_lv$B.txt; rm -rf $O/_p$B
 done
-head -12 $O/${T}_lv512.txt; grep -E "k_chol" $O/${T}_lv512.txt | tail -20; head -8 $O/${T}_lv1.txt
+head -8 $O/${T}_lv512.txt; grep -E "k_chol" $O/${T}_lv512.txt | tail -18; head -6 $O/${T}_lv1.txt
+SSLAM_CHOL_STAMPS=1 python $R/tools/prof_opt.py 1 3 2>&1 | grep stamps
