@@ -78,6 +78,9 @@ struct PieceMeta { int graph, c0, nc, b0, nb, lbase, lsize, y0, ysize, ilv0, nil
 // update matrix: U items [uit0, +nuit), split U blocks [umb0, +numb), their update records [uu0, +nuu) and child sources [us0, +nus)
 // (UItem.u0 / .s0 and UMb.s0 are relative to uu0 / us0: the per-depth kernels stage these records in LDS as well)
 
+// storage of a di x dj block: 3 x 3 blocks are padded to 10 doubles so that every block (and every row of a 6-wide block) starts
+// on a 16-byte boundary (ds_read_b128 / global_load_dwordx4 in the update kernels)
+inline int blk_doubles(int di, int dj) { return (di * dj + 1) & ~1; }
 constexpr int kItemDoubles = 42;     // LDS doubles per partial tile: 6 x 6 entries + 6 rhs components
 constexpr int kMaxILevels = 64;      // internal levels per piece (LDS table in the kernels)
 
@@ -349,7 +352,7 @@ inline int chol_symbolic(const SymIn& in, CholOpts opt, CholHost& out) {
       boff.push_back((int)lnz); brow.push_back(j);
       bsrc.push_back(rj < nPr ? rj * 36 : (int)(in.hll_base + (int64_t)(rj - nPr) * 9)); bfmt.push_back(0);
       colblk[j][j] = bp[j];
-      lnz += dj * dj;
+      lnz += blk_doubles(dj, dj);
       for (int i : rows_c) {
         if (i <= j) { out.error = "symbolic factorisation inconsistent (row not below its column)"; return -1; }
         const int ri = col_row[i], di = row_dim(ri);
@@ -359,7 +362,7 @@ inline int chol_symbolic(const SymIn& in, CholOpts opt, CholHost& out) {
         auto it = hoff.find(key(a, c));
         if (it == hoff.end()) { bsrc.push_back(-1); bfmt.push_back(0); }
         else { bsrc.push_back(it->second); bfmt.push_back(ri == a ? 0 : 1); }   // stored [min][max]; we need [i][j]
-        lnz += di * dj;
+        lnz += blk_doubles(di, dj);
       }
       if (lnz >= ((int64_t)1 << 31) - 4096) { out.error = "Cholesky factor too large for int32 offsets"; return -1; }
     }
@@ -399,7 +402,7 @@ inline int chol_symbolic(const SymIn& in, CholOpts opt, CholHost& out) {
     pm.nb = bp[j + 1] - pm.b0;
     pm.ysize = col_yoff[j] + col_dim[j] - pm.y0;
     const int last = bp[j + 1] - 1;
-    pm.lsize = boff[last] + col_dim[brow[last]] * col_dim[j] - pm.lbase;
+    pm.lsize = boff[last] + blk_doubles(col_dim[brow[last]], col_dim[j]) - pm.lbase;
     piece_tail[col_piece[j]] = (char)col_tail[j];
     if (bp[j + 1] - bp[j] > 1) {
       const int pp = col_piece[brow[bp[j] + 1]];
@@ -611,7 +614,7 @@ inline int chol_symbolic(const SymIn& in, CholOpts opt, CholHost& out) {
     {
       int64_t cur = ucur;
       std::vector<int> uoffs(ub.size());
-      for (int q : order) { uoffs[q] = (int)cur; cur += col_dim[ub[q].a] * col_dim[ub[q].b]; }
+      for (int q : order) { uoffs[q] = (int)cur; cur += blk_doubles(col_dim[ub[q].a], col_dim[ub[q].b]); }
       piece_uy[p] = (int)cur;
       cur += 6 * (int64_t)R.size();
       if (cur >= ((int64_t)1 << 31) - 4096) { out.error = "update matrices too large for int32 offsets"; return -1; }

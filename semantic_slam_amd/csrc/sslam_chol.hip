@@ -86,32 +86,56 @@ void chol_plan_free(CholPlan* p) {
 template <int K>
 __device__ __forceinline__ int quad_bcast(int v) { return __builtin_amdgcn_mov_dpp(v, K * 0x55, 0xF, 0xF, true); }
 
+struct alignas(16) D2 { double a, b; };
 // one update S(i,j) -= L(i,k) L(j,k)^T (and rhs_j -= L(j,k) y_k on the diagonal) restricted to this lane's 3 x 3 tile.
-// Ls / Ys: Lval / y in HBM (lofs = yofs = 0) or the piece's LDS mirror (lofs / yofs = the piece's base offsets).
+// Ls / Ys: the piece's LDS mirror of L / y.  DK (width of the source column k) is a template parameter so that every offset is an
+// instruction immediate; for DK = 6 the three rows of each operand are 16-byte aligned (blocks are stored at even offsets) and
+// travel as 128-bit loads: 18 LDS loads + 6 for y feed 63 FMAs.
+template <int DK>
+__device__ __forceinline__ void tile_update_k(const double* __restrict__ Ls, const double* __restrict__ Ys, int ua, int ub, int ux,
+                                              int tre, int tce, double (&acc)[9], double (&accy)[3]) {
+  const double* A = Ls + ua + 3 * tre * DK;
+  const double* B = Ls + ub + 3 * tce * DK;
+  const double* yk = Ys + ux;
+  double bb[3 * DK], yv[DK];
+  if (DK == 6) {
+    const D2* B2 = reinterpret_cast<const D2*>(B);
+#pragma unroll
+    for (int q = 0; q < 9; ++q) { const D2 v = B2[q]; bb[2 * q] = v.a; bb[2 * q + 1] = v.b; }
+  } else {
+#pragma unroll
+    for (int q = 0; q < 3 * DK; ++q) bb[q] = B[q];
+  }
+#pragma unroll
+  for (int q = 0; q < DK; ++q) yv[q] = yk[q];
+#pragma unroll
+  for (int rr = 0; rr < 3; ++rr) {   // one row of the A operand at a time: 30 live doubles instead of 42
+    double a[DK];
+    if (DK == 6) {
+      const D2* A2 = reinterpret_cast<const D2*>(A + rr * DK);
+#pragma unroll
+      for (int q = 0; q < 3; ++q) { const D2 v = A2[q]; a[2 * q] = v.a; a[2 * q + 1] = v.b; }
+    } else {
+#pragma unroll
+      for (int q = 0; q < DK; ++q) a[q] = A[rr * DK + q];
+    }
+#pragma unroll
+    for (int cc = 0; cc < 3; ++cc) {
+      double v = acc[rr * 3 + cc];
+#pragma unroll
+      for (int q = 0; q < DK; ++q) v += a[q] * bb[cc * DK + q];
+      acc[rr * 3 + cc] = v;
+    }
+    double w = accy[rr];
+#pragma unroll
+    for (int q = 0; q < DK; ++q) w += a[q] * yv[q];
+    accy[rr] = w;
+  }
+}
 __device__ __forceinline__ void tile_update(const double* __restrict__ Ls, const double* __restrict__ Ys, int ua, int ub, int ux, int pk,
                                             int tre, int tce, double (&acc)[9], double (&accy)[3]) {
-  const int dk = (pk & kUpdDk6) ? 6 : 3;
-  const double* A = Ls + ua + 3 * tre * dk;
-  const double* B = Ls + ub + 3 * tce * dk;
-  const double* yk = Ys + ux;
-#pragma unroll
-  for (int h = 0; h < 2; ++h) {   // K in halves of 3 (one half when the source column is 3 wide)
-    if (3 * h < dk) {
-      double a[9], bb[9], yv[3];
-#pragma unroll
-      for (int rr = 0; rr < 3; ++rr)
-#pragma unroll
-        for (int q = 0; q < 3; ++q) { a[rr * 3 + q] = A[rr * dk + 3 * h + q]; bb[rr * 3 + q] = B[rr * dk + 3 * h + q]; }
-#pragma unroll
-      for (int q = 0; q < 3; ++q) yv[q] = yk[3 * h + q];
-#pragma unroll
-      for (int rr = 0; rr < 3; ++rr) {
-#pragma unroll
-        for (int cc = 0; cc < 3; ++cc) acc[rr * 3 + cc] += a[rr * 3] * bb[cc * 3] + a[rr * 3 + 1] * bb[cc * 3 + 1] + a[rr * 3 + 2] * bb[cc * 3 + 2];
-        accy[rr] += a[rr * 3] * yv[0] + a[rr * 3 + 1] * yv[1] + a[rr * 3 + 2] * yv[2];
-      }
-    }
-  }
+  if (pk & kUpdDk6) tile_update_k<6>(Ls, Ys, ua, ub, ux, tre, tce, acc, accy);
+  else tile_update_k<3>(Ls, Ys, ua, ub, ux, tre, tce, acc, accy);
 }
 
 // Work items [it_begin, it_end): four lanes per item (lane = 3 x 3 tile (tr, tc) of the target block).  The item's update
@@ -406,81 +430,54 @@ __device__ __forceinline__ void chol_piece(const BatchView& V, const CholView& C
   }
   __syncthreads();
   SSLAM_STAMP(0)
-  // ---- 1. gather: A(:, piece) + lambda I and the rhs -> LDS.  One wave per block, lane = entry; sixteen blocks' loads are in
-  //         flight per wave before the first one is consumed (unconditional loads from always-valid addresses: no branches
-  //         between them, or the compiler serialises the round trips).
-  {
-    constexpr int kPipe = 16;
-    for (int b0 = wave * kPipe; b0 < pm.nb; b0 += NW * kPipe) {
-      double hv[kPipe];
+  // ---- 1. gather: A(:, piece) + lambda I and the rhs -> LDS.  One thread per (block, row): a handful of instructions per row
+  //         (these kernels are bound by instruction issue, not by bytes), every thread's loads independent of one another.
+  for (int t = tid; t < pm.nb * 6; t += NT) {
+    const int b = t / 6, row = t - 6 * b;
+    const BlkMeta bm = sBlk[b];
+    const int di = bm.info & 15, dj = (bm.info >> 4) & 15;
+    if (row >= di) continue;
+    double v[6];
+    if (bm.src >= 0) {
+      const double* ph = H + bm.src + ((bm.info & kBlkFmt) ? row : row * dj);
+      const int st = (bm.info & kBlkFmt) ? di : 1;
 #pragma unroll
-      for (int k = 0; k < kPipe; ++k) {
-        const BlkMeta bm = sBlk[min(b0 + k, pm.nb - 1)];
-        const int di = bm.info & 15, dj = (bm.info >> 4) & 15;
-        const bool diag = bm.info & kBlkDiag;
-        const bool ent = lane < di * dj, rhs = diag && ry >= 0 && ry < dj;
-        const int r = lane / dj, c = lane - r * dj;
-        const double* pa = H;                                    // idle lanes / fill blocks: any valid address
-        if (ent && bm.src >= 0) pa = H + bm.src + ((bm.info & kBlkFmt) ? c * di + r : lane);
-        else if (rhs) pa = V.bvec + bm.xoff_row + ry;
-        hv[k] = *pa;
-      }
+      for (int c = 0; c < 6; ++c) v[c] = c < dj ? ph[c * st] : 0.0;
+    } else {
 #pragma unroll
-      for (int k = 0; k < kPipe; ++k) {
-        const int idx = b0 + k;
-        if (idx >= pm.nb) continue;
-        const BlkMeta bm = sBlk[idx];
-        const int di = bm.info & 15, dj = (bm.info >> 4) & 15;
-        const bool diag = bm.info & kBlkDiag;
-        const int r = lane / dj, c = lane - r * dj;
-        if (lane < di * dj) smL[bm.off - pm.lbase + lane] = (bm.src >= 0 ? hv[k] : 0.0) + ((diag && r == c) ? lambda : 0.0);
-        else if (diag && ry >= 0 && ry < dj) smY[bm.colyoff - pm.y0 + ry] = hv[k];
-      }
+      for (int c = 0; c < 6; ++c) v[c] = 0.0;
     }
+    double* o = smL + (bm.off - pm.lbase) + row * dj;
+    const bool diag = bm.info & kBlkDiag;
+#pragma unroll
+    for (int c = 0; c < 6; ++c)
+      if (c < dj) o[c] = v[c] + ((diag && c == row) ? lambda : 0.0);
+    if (diag) smY[bm.colyoff - pm.y0 + row] = V.bvec[bm.xoff_row + row];
   }
-  // ---- 1b. minus what the child pieces left for these blocks (their update matrices: coalesced 288-byte reads, no arithmetic).
-  //          A block's sources are summed by one wave -> no conflicts, fixed order.
+  // ---- 1b. minus what the child pieces left for these blocks (their update matrices).  A row's sources are summed by one thread
+  //          -> no conflicts, fixed order.
   if (pm.nas > 0) {
     __syncthreads();
-    constexpr int kPipe = 8;
-    for (int b0 = wave * kPipe; b0 < pm.nb; b0 += NW * kPipe) {
-      double uv[kPipe];
+    for (int t = tid; t < pm.nb * 6; t += NT) {
+      const int b = t / 6, row = t - 6 * b;
+      const BlkMeta bm = sBlk[b];
+      const int di = bm.info & 15, dj = (bm.info >> 4) & 15, nas = (bm.info >> kBlkNasShift) & 255;
+      if (row >= di || nas == 0) continue;
+      double v[6], vy = 0;
 #pragma unroll
-      for (int k = 0; k < kPipe; ++k) {     // first source of every block in flight together
-        const BlkMeta bm = sBlk[min(b0 + k, pm.nb - 1)];
-        const int di = bm.info & 15, dj = (bm.info >> 4) & 15, nas = (bm.info >> kBlkNasShift) & 255;
-        const bool diag = bm.info & kBlkDiag;
-        const bool ent = lane < di * dj, rhs = diag && ry >= 0 && ry < dj;
-        const double* pa = U;
-        if (nas > 0) {
-          const AsmSrc as = sAsm[bm.as0];
-          if (ent) pa = U + as.uoff + lane;
-          else if (rhs && as.uyoff >= 0) pa = U + as.uyoff + ry;
-        }
-        uv[k] = *pa;
-      }
+      for (int c = 0; c < 6; ++c) v[c] = 0.0;
+      const bool diag = bm.info & kBlkDiag;
+      for (int s2 = 0; s2 < nas; ++s2) {
+        const AsmSrc as = sAsm[bm.as0 + s2];
+        const double* pu = U + as.uoff + row * dj;
 #pragma unroll
-      for (int k = 0; k < kPipe; ++k) {
-        const int idx = b0 + k;
-        if (idx >= pm.nb) continue;
-        const BlkMeta bm = sBlk[idx];
-        const int di = bm.info & 15, dj = (bm.info >> 4) & 15, nas = (bm.info >> kBlkNasShift) & 255;
-        if (nas == 0) continue;
-        const bool diag = bm.info & kBlkDiag;
-        const bool ent = lane < di * dj, rhs = diag && ry >= 0 && ry < dj;
-        double v = 0;
-        {
-          const AsmSrc as = sAsm[bm.as0];
-          if (ent || (rhs && as.uyoff >= 0)) v = uv[k];
-        }
-        for (int s2 = 1; s2 < nas; ++s2) {
-          const AsmSrc as = sAsm[bm.as0 + s2];
-          if (ent) v += U[as.uoff + lane];
-          else if (rhs && as.uyoff >= 0) v += U[as.uyoff + ry];
-        }
-        if (ent) smL[bm.off - pm.lbase + lane] -= v;
-        else if (rhs) smY[bm.colyoff - pm.y0 + ry] -= v;
+        for (int c = 0; c < 6; ++c) if (c < dj) v[c] += pu[c];
+        if (diag && as.uyoff >= 0) vy += U[as.uyoff + row];
       }
+      double* o = smL + (bm.off - pm.lbase) + row * dj;
+#pragma unroll
+      for (int c = 0; c < 6; ++c) if (c < dj) o[c] -= v[c];
+      if (diag) smY[bm.colyoff - pm.y0 + row] -= vy;
     }
   }
   __syncthreads();
