@@ -29,6 +29,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <functional>
+#include <map>
 #include <queue>
 #include <string>
 #include <unordered_map>
@@ -99,6 +100,9 @@ struct CholOpts {
   int nt_leaf = 256, nt_tail = 512;   // workgroup sizes the items are cut for
   int min_chunk = 4;       // a list of <= min_chunk updates is never split
   int pcap_leaf = 16, pcap_tail = 32;   // partial tiles per phase (split lists): LDS budget of a piece
+  int group_cap = 0;       // > 0: pieces of equal depth are packed into groups of <= group_cap doubles of L (and <= group_blocks blocks) that one
+  int group_blocks = 1024; //      workgroup factors side by side: the per-level latencies and barriers are shared by all members
+  int ustage = 1;          // the per-depth kernels stage the update-matrix records in LDS too
   bool dump = false;
   static int env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
   void from_env() {
@@ -106,6 +110,8 @@ struct CholOpts {
     max_blocks = env_int("SSLAM_CHOL_MAX_BLOCKS", max_blocks); tail_width = env_int("SSLAM_CHOL_TAIL_WIDTH", tail_width);
     nt_tail = env_int("SSLAM_CHOL_NT_TAIL", nt_tail); nt_leaf = env_int("SSLAM_CHOL_NT_LEAF", nt_leaf); min_chunk = std::max(1, env_int("SSLAM_CHOL_MIN_CHUNK", min_chunk));
     pcap_leaf = env_int("SSLAM_CHOL_PCAP_LEAF", pcap_leaf); pcap_tail = env_int("SSLAM_CHOL_PCAP_TAIL", pcap_tail);
+    group_cap = env_int("SSLAM_CHOL_GROUP_CAP", group_cap); group_blocks = env_int("SSLAM_CHOL_GROUP_BLOCKS", group_blocks);
+    ustage = env_int("SSLAM_CHOL_USTAGE", ustage);
     dump = getenv("SSLAM_CHOL_DUMP") != nullptr;
   }
 };
@@ -123,7 +129,7 @@ struct CholHost {
   std::vector<int> tail_ptr, tail_pieces;   // per graph: its tail pieces in elimination order
   std::vector<int> plv_lds_f, plv_lds_b;    // LDS doubles per launch (factor / backward)
   int tail_lds_f = 0, tail_lds_b = 0;
-  int nt_leaf = 256, nt_tail = 512;
+  int nt_leaf = 256, nt_tail = 512, ustage = 1;
   std::string error;
 };
 
@@ -228,7 +234,7 @@ inline int chol_symbolic(const SymIn& in, CholOpts opt, CholHost& out) {
   const int nPr = in.nPr, nLr = in.nLr, nrow = nPr + nLr, B = in.B;
   if (opt.tail_width < 0) opt.tail_width = B >= 32 ? 6 : 2;
   out = CholHost();
-  out.B = B; out.nt_leaf = opt.nt_leaf; out.nt_tail = opt.nt_tail;
+  out.B = B; out.nt_leaf = opt.nt_leaf; out.nt_tail = opt.nt_tail; out.ustage = opt.ustage;
   auto row_dim = [&](int r) { return r < nPr ? 6 : 3; };
   auto row_xoff = [&](int r) { return r < nPr ? 6 * r : 6 * nPr + 3 * (r - nPr); };
   auto key = [](int a, int c) { return ((uint64_t)(uint32_t)a << 32) | (uint32_t)c; };
@@ -241,10 +247,10 @@ inline int chol_symbolic(const SymIn& in, CholOpts opt, CholHost& out) {
   for (auto& pr : in.plblk) { adj[pr.first].push_back(nPr + pr.second); adj[nPr + pr.second].push_back(pr.first); }
 
   // ---- per graph: ordering, elimination tree, pieces, final (piece-contiguous) elimination order ------------------
-  std::vector<int> col_row, col_graph, col_piece, col_tail;   // by final column id
+  std::vector<int> col_row, col_graph, col_piece, col_comp, col_tail;   // by final column id; piece = execution group, comp = connected piece
   std::vector<int> row_col(nrow, -1);
   std::vector<std::vector<int>> cstruct_rows;                 // per column: rows of the off-diagonal blocks
-  int npiece = 0;
+  int npiece = 0, ncomp = 0;
   for (int g = 0; g < B; ++g) {
     const SymGraph& sg = in.seg[g];
     const int n = sg.nprow + sg.nlrow;
@@ -302,7 +308,7 @@ inline int chol_symbolic(const SymIn& in, CholOpts opt, CholHost& out) {
     if (any_tail) np2 = cut_pieces(n, parent, colsz, colnb, fixed, np1, opt.cap_tail, opt.max_blocks, pc2);
     std::vector<char> is_tail(np2, 0);
     for (int s = 0; s < n; ++s) if (fixed[s] < 0) is_tail[pc2[s]] = 1;
-    // final order: pieces by root position, columns of a piece by (internal level, position)
+    // depth of every connected piece ("component") in the piece tree of this graph
     std::vector<int> proot(np2, -1);
     for (int s = 0; s < n; ++s) proot[pc2[s]] = std::max(proot[pc2[s]], s);
     std::vector<int> il(n, 0);
@@ -310,13 +316,39 @@ inline int chol_symbolic(const SymIn& in, CholOpts opt, CholHost& out) {
     std::vector<int> ids;
     for (int p = 0; p < np2; ++p) if (proot[p] >= 0) ids.push_back(p);
     std::sort(ids.begin(), ids.end(), [&](int a, int b) { return proot[a] < proot[b]; });
-    std::vector<int> rank(np2, -1);
-    for (size_t k = 0; k < ids.size(); ++k) rank[ids[k]] = (int)k;
+    std::vector<int> cpar(np2, -1), cplev(np2, 0), csize(np2, 0), cblk(np2, 0);
+    for (int s = 0; s < n; ++s) {
+      if (parent[s] >= 0 && pc2[parent[s]] != pc2[s]) cpar[pc2[s]] = pc2[parent[s]];
+      csize[pc2[s]] += colsz[s]; cblk[pc2[s]] += colnb[s];
+    }
+    for (int c : ids) if (cpar[c] >= 0) cplev[cpar[c]] = std::max(cplev[cpar[c]], cplev[c] + 1);   // ascending root: children first
+    // execution groups: the non-tail components by (depth, root), packed side by side up to the group caps (group_cap = 0: one
+    // component per group); then the tail components in elimination order, one per group.  The tail is closed upwards, so every
+    // group only depends on groups before it.
+    std::vector<int> gorder;
+    for (int c : ids) if (!is_tail[c]) gorder.push_back(c);
+    std::stable_sort(gorder.begin(), gorder.end(), [&](int a, int b) { return cplev[a] < cplev[b]; });
+    std::vector<int> grank(np2, -1);
+    int ngroup = 0;
+    {
+      int gsz = 0, gnb = 0, glev = -1;
+      for (int c : gorder) {
+        const bool fits = opt.group_cap > 0 && glev == cplev[c] && gsz + csize[c] <= opt.group_cap && gnb + cblk[c] <= opt.group_blocks;
+        if (!fits) { ++ngroup; gsz = 0; gnb = 0; glev = cplev[c]; }
+        gsz += csize[c]; gnb += cblk[c];
+        grank[c] = ngroup - 1;
+      }
+      for (int c : ids) if (is_tail[c]) grank[c] = ngroup++;
+    }
+    std::vector<int> crank(np2, -1);
+    for (size_t k = 0; k < ids.size(); ++k) crank[ids[k]] = (int)k;
+    // final order: groups; inside a group by (level inside the component, component, position): one contiguous column range per level
     std::vector<int> perm(n);
     for (int s = 0; s < n; ++s) perm[s] = s;
     std::sort(perm.begin(), perm.end(), [&](int a, int b) {
-      if (pc2[a] != pc2[b]) return rank[pc2[a]] < rank[pc2[b]];
+      if (grank[pc2[a]] != grank[pc2[b]]) return grank[pc2[a]] < grank[pc2[b]];
       if (il[a] != il[b]) return il[a] < il[b];
+      if (pc2[a] != pc2[b]) return crank[pc2[a]] < crank[pc2[b]];
       return a < b;
     });
     const int c0 = (int)col_row.size();
@@ -325,12 +357,13 @@ inline int chol_symbolic(const SymIn& in, CholOpts opt, CholHost& out) {
       const int r = loc2row(S.order[s]);
       row_col[r] = c0 + k;
       col_row.push_back(r); col_graph.push_back(g);
-      col_piece.push_back(npiece + rank[pc2[s]]); col_tail.push_back(is_tail[pc2[s]]);
+      col_piece.push_back(npiece + grank[pc2[s]]); col_comp.push_back(ncomp + crank[pc2[s]]); col_tail.push_back(is_tail[pc2[s]]);
       std::vector<int> rows;
       for (int w : S.cstruct[S.order[s]]) rows.push_back(loc2row(w));
       cstruct_rows.push_back(std::move(rows));
     }
-    npiece += (int)ids.size();
+    npiece += ngroup;
+    ncomp += (int)ids.size();
   }
   const int ncol = (int)col_row.size();
   out.ncol = ncol; out.npiece = npiece; out.dim = 6 * nPr + 3 * nLr;
@@ -377,7 +410,7 @@ inline int chol_symbolic(const SymIn& in, CholOpts opt, CholHost& out) {
     if (bp[j + 1] - bp[j] > 1) {
       const int par = brow[bp[j] + 1];
       level[par] = std::max(level[par], level[j] + 1);
-      if (col_piece[par] == col_piece[j]) col_il[par] = std::max(col_il[par], col_il[j] + 1);
+      if (col_comp[par] == col_comp[j]) col_il[par] = std::max(col_il[par], col_il[j] + 1);
     }
     nlev = std::max(nlev, level[j] + 1);
   }
@@ -393,7 +426,7 @@ inline int chol_symbolic(const SymIn& in, CholOpts opt, CholHost& out) {
   // ---- pieces: column / block ranges (contiguous by construction), parent piece, depth ----------------------------------------
   out.piece.assign(npiece, PieceMeta{});
   std::vector<char> piece_tail(npiece, 0);
-  std::vector<int> piece_parent(npiece, -1);
+  std::vector<int> comp_parent(ncomp, -1), comp_dest(ncomp, -1);   // parent component; the group that holds it
   for (int j = 0; j < ncol; ++j) {
     PieceMeta& pm = out.piece[col_piece[j]];
     if (pm.nc == 0) { pm.graph = col_graph[j]; pm.c0 = j; pm.b0 = bp[j]; pm.lbase = boff[bp[j]]; pm.y0 = col_yoff[j]; }
@@ -405,18 +438,20 @@ inline int chol_symbolic(const SymIn& in, CholOpts opt, CholHost& out) {
     pm.lsize = boff[last] + blk_doubles(col_dim[brow[last]], col_dim[j]) - pm.lbase;
     piece_tail[col_piece[j]] = (char)col_tail[j];
     if (bp[j + 1] - bp[j] > 1) {
-      const int pp = col_piece[brow[bp[j] + 1]];
-      if (pp != col_piece[j]) {
-        if (piece_parent[col_piece[j]] >= 0 && piece_parent[col_piece[j]] != pp) { out.error = "a piece has two parents"; return -1; }
-        piece_parent[col_piece[j]] = pp;
+      const int par = brow[bp[j] + 1];
+      if (col_comp[par] != col_comp[j]) {
+        if (comp_parent[col_comp[j]] >= 0 && comp_parent[col_comp[j]] != col_comp[par]) { out.error = "a connected piece has two parents"; return -1; }
+        if (col_piece[par] <= col_piece[j]) { out.error = "groups are not in elimination order"; return -1; }
+        comp_parent[col_comp[j]] = col_comp[par];
+        comp_dest[col_comp[j]] = col_piece[par];
       }
     }
   }
   std::vector<int> plev(npiece, 0);
-  for (int p = 0; p < npiece; ++p)   // ascending id = elimination order: a child is final before its parent is visited
-    if (piece_parent[p] >= 0) {
-      if (piece_parent[p] <= p) { out.error = "pieces are not in elimination order"; return -1; }
-      plev[piece_parent[p]] = std::max(plev[piece_parent[p]], plev[p] + 1);
+  for (int j = 0; j < ncol; ++j)   // ascending columns = ascending groups: a group's depth is final before any of its parents' columns is visited
+    if (bp[j + 1] - bp[j] > 1) {
+      const int pp = col_piece[brow[bp[j] + 1]], pj = col_piece[j];
+      if (pp != pj) plev[pp] = std::max(plev[pp], plev[pj] + 1);
     }
   int nplv = 0;
   for (int p = 0; p < npiece; ++p) if (!piece_tail[p]) nplv = std::max(nplv, plev[p] + 1);
@@ -465,12 +500,9 @@ inline int chol_symbolic(const SymIn& in, CholOpts opt, CholHost& out) {
     }
   }
   // ---- piece by piece (elimination order: children before parents): internal updates, update matrix, assembly -------------------------
-  struct URec { int a, b, uoff; };                    // finished update-matrix block (row column-ids a >= b)
-  std::vector<std::vector<URec>> piece_u(npiece);     // kept until the parent has consumed them
-  std::vector<std::vector<int>> piece_R(npiece);      // boundary rows (column ids, ascending)
-  std::vector<int> piece_uy(npiece, 0);               // Uval offset of the piece's rhs part [|R|][6]
-  std::vector<std::vector<int>> kids(npiece);
-  for (int p = 0; p < npiece; ++p) if (piece_parent[p] >= 0) kids[piece_parent[p]].push_back(p);
+  struct URec { int a, b, uoff, uy, comp; };          // finished update-matrix block (row column-ids a >= b; uy: rhs part of a diagonal block) of component comp
+  std::vector<std::vector<URec>> inbox(npiece);       // per group: the blocks its child components handed up (kept until consumed)
+  std::vector<std::vector<int>> comp_R(ncomp);        // boundary rows of a component (column ids, ascending)
   out.upd.clear(); out.item.clear(); out.mb.clear(); out.ilv.clear(); out.asrc.clear(); out.usrc.clear(); out.uitem.clear(); out.umb.clear();
   std::vector<int> piece_pmax(npiece, 0);   // most partial tiles any phase of the piece needs
   int64_t ucur = 0;
@@ -479,20 +511,29 @@ inline int chol_symbolic(const SymIn& in, CholOpts opt, CholHost& out) {
     const int nt = piece_tail[p] ? opt.nt_tail : opt.nt_leaf;
     const int slots = nt / 4;
     const int pcap = piece_tail[p] ? opt.pcap_tail : opt.pcap_leaf;   // partial tiles a phase may use (LDS: 336 B each)
-    // boundary rows
-    std::vector<int>& R = piece_R[p];
-    for (int j = pm.c0; j < pm.c0 + pm.nc; ++j) for (int t = bp[j] + col_nbi[j]; t < bp[j + 1]; ++t) R.push_back(brow[t]);
-    std::sort(R.begin(), R.end());
-    R.erase(std::unique(R.begin(), R.end()), R.end());
-    // update-matrix blocks under construction
-    struct UB { int a, b; std::vector<std::array<int, 3>> own; std::vector<AsmSrc> src; };
+    // boundary rows of every component of the group
+    std::vector<int> comps;
+    for (int j = pm.c0; j < pm.c0 + pm.nc; ++j) {
+      if (comps.empty() || std::find(comps.begin(), comps.end(), col_comp[j]) == comps.end()) comps.push_back(col_comp[j]);
+      std::vector<int>& R = comp_R[col_comp[j]];
+      for (int t = bp[j] + col_nbi[j]; t < bp[j + 1]; ++t) R.push_back(brow[t]);
+    }
+    std::sort(comps.begin(), comps.end());
+    for (int c : comps) {
+      std::vector<int>& R = comp_R[c];
+      std::sort(R.begin(), R.end());
+      R.erase(std::unique(R.begin(), R.end()), R.end());
+    }
+    // update-matrix blocks under construction: one matrix per component (different components of a group may have different parents)
+    struct UB { int comp, a, b; std::vector<std::array<int, 3>> own; std::vector<AsmSrc> src; };
     std::vector<UB> ub;
-    std::unordered_map<uint64_t, int> ubidx;
-    auto ublock = [&](int a, int b2) -> UB& {
-      auto it = ubidx.find(key(a, b2));
+    std::map<std::array<int, 3>, int> ubidx;
+    auto ublock = [&](int comp, int a, int b2) -> UB& {
+      const std::array<int, 3> k3{comp, a, b2};
+      auto it = ubidx.find(k3);
       if (it != ubidx.end()) return ub[it->second];
-      ubidx.emplace(key(a, b2), (int)ub.size());
-      ub.push_back(UB{a, b2, {}, {}});
+      ubidx.emplace(k3, (int)ub.size());
+      ub.push_back(UB{comp, a, b2, {}, {}});
       return ub.back();
     };
     // internal updates (target column in the piece) and own update-matrix contributions (both rows above the piece)
@@ -509,28 +550,25 @@ inline int chol_symbolic(const SymIn& in, CholOpts opt, CholHost& out) {
             iul[it->second].push_back(IU{boff[q], boff[pp], k});
           }
         } else {
-          for (int q = pp; q < k1; ++q) ublock(brow[q], j).own.push_back({boff[q], boff[pp], k});
+          for (int q = pp; q < k1; ++q) ublock(col_comp[k], brow[q], j).own.push_back({boff[q], boff[pp], k});
         }
       }
     }
     // what the children hand up: absorbed into a column of this piece (assembly) or passed on (update matrix)
     std::unordered_map<int, std::vector<AsmSrc>> asml;   // target block -> child blocks
-    for (int c : kids[p]) {
-      const std::vector<int>& Rc = piece_R[c];
-      for (const URec& u : piece_u[c]) {
-        int uy = -1;
-        if (u.a == u.b) uy = piece_uy[c] + 6 * (int)(std::lower_bound(Rc.begin(), Rc.end(), u.a) - Rc.begin());
-        if (col_piece[u.b] == p) {
-          auto it = colblk[u.b].find(u.a);
-          if (it == colblk[u.b].end()) { out.error = "update-matrix block without a target"; return -1; }
-          asml[it->second].push_back(AsmSrc{u.uoff, uy});
-        } else {
-          if (col_piece[u.a] == p) { out.error = "update-matrix block with its row inside the piece but its column above"; return -1; }
-          ublock(u.a, u.b).src.push_back(AsmSrc{u.uoff, uy});
-        }
+    for (const URec& u : inbox[p]) {
+      if (col_piece[u.b] == p) {
+        auto it = colblk[u.b].find(u.a);
+        if (it == colblk[u.b].end()) { out.error = "update-matrix block without a target"; return -1; }
+        asml[it->second].push_back(AsmSrc{u.uoff, u.uy});
+      } else {
+        if (col_piece[u.a] == p) { out.error = "update-matrix block with its row inside the piece but its column above"; return -1; }
+        const int pc = comp_parent[u.comp];   // the component of this group that the sender hangs below
+        if (pc < 0 || !std::binary_search(comps.begin(), comps.end(), pc)) { out.error = "update-matrix block routed to the wrong group"; return -1; }
+        ublock(pc, u.a, u.b).src.push_back(AsmSrc{u.uoff, u.uy});
       }
-      std::vector<URec>().swap(piece_u[c]);
     }
+    std::vector<URec>().swap(inbox[p]);
     // assembly records, block order
     pm.as0 = (int)out.asrc.size();
     for (int t = pm.b0; t < pm.b0 + pm.nb; ++t) {
@@ -606,7 +644,10 @@ inline int chol_symbolic(const SymIn& in, CholOpts opt, CholHost& out) {
     // update matrix of the piece: blocks in (a, b) order, own update records, child sources, U items
     std::vector<int> order(ub.size());
     for (size_t q = 0; q < ub.size(); ++q) order[q] = (int)q;
-    std::sort(order.begin(), order.end(), [&](int x, int y2) { return ub[x].a != ub[y2].a ? ub[x].a < ub[y2].a : ub[x].b < ub[y2].b; });
+    std::sort(order.begin(), order.end(), [&](int x, int y2) {
+      if (ub[x].comp != ub[y2].comp) return ub[x].comp < ub[y2].comp;
+      return ub[x].a != ub[y2].a ? ub[x].a < ub[y2].a : ub[x].b < ub[y2].b;
+    });
     pm.uit0 = (int)out.uitem.size();
     pm.umb0 = (int)out.umb.size();
     pm.uu0 = (int)out.upd.size();
@@ -615,8 +656,8 @@ inline int chol_symbolic(const SymIn& in, CholOpts opt, CholHost& out) {
       int64_t cur = ucur;
       std::vector<int> uoffs(ub.size());
       for (int q : order) { uoffs[q] = (int)cur; cur += blk_doubles(col_dim[ub[q].a], col_dim[ub[q].b]); }
-      piece_uy[p] = (int)cur;
-      cur += 6 * (int64_t)R.size();
+      std::unordered_map<int, int> comp_uy;   // Uval offset of a component's rhs part [|R|][6]
+      for (int c : comps) { comp_uy[c] = (int)cur; cur += 6 * (int64_t)comp_R[c].size(); }
       if (cur >= ((int64_t)1 << 31) - 4096) { out.error = "update matrices too large for int32 offsets"; return -1; }
       int U = 0;
       for (auto& x : ub) U += (int)x.own.size();
@@ -627,13 +668,12 @@ inline int chol_symbolic(const SymIn& in, CholOpts opt, CholHost& out) {
         if (nonsole <= pcap || chunk >= std::max(U, 1)) break;
       }
       int ps = 0;
-      piece_u[p].reserve(ub.size());
       for (int q : order) {
         UB& x = ub[q];
         const int di = col_dim[x.a], dj = col_dim[x.b];
         const bool diag = x.a == x.b;
         int uy = -1;
-        if (diag) uy = piece_uy[p] + 6 * (int)(std::lower_bound(R.begin(), R.end(), x.a) - R.begin());
+        if (diag) { const std::vector<int>& R = comp_R[x.comp]; uy = comp_uy[x.comp] + 6 * (int)(std::lower_bound(R.begin(), R.end(), x.a) - R.begin()); }
         const int tpk = (di == 6 ? kUpdDi6 : 0) | (diag ? kUpdDiag : 0) | (dj == 6 ? kUpdDj6 : 0);
         const int u0 = (int)out.upd.size() - pm.uu0;
         for (auto& u : x.own) out.upd.push_back(UpdMeta{u[0], u[1], col_yoff[u[2]], tpk | (col_dim[u[2]] == 6 ? kUpdDk6 : 0)});
@@ -648,7 +688,8 @@ inline int chol_symbolic(const SymIn& in, CholOpts opt, CholHost& out) {
           out.uitem.push_back(UItem{a2, std::max(0, b2 - a2), uoffs[q], shape | (k == 1 ? kItemSole : ((ps + qq) << kItemSlotShift)), s0, ns, uy, 0});
         }
         if (k > 1) { out.umb.push_back(UMb{uoffs[q], ps, k, di | (dj << 4) | (diag ? kBlkDiag : 0), s0, ns, uy, 0}); ps += k; }
-        piece_u[p].push_back(URec{x.a, x.b, uoffs[q]});
+        if (comp_dest[x.comp] < 0) { out.error = "a root component has an update matrix"; return -1; }
+        inbox[comp_dest[x.comp]].push_back(URec{x.a, x.b, uoffs[q], uy, x.comp});
       }
       piece_pmax[p] = std::max(piece_pmax[p], ps);
       ucur = cur;
@@ -657,7 +698,6 @@ inline int chol_symbolic(const SymIn& in, CholOpts opt, CholHost& out) {
     pm.numb = (int)out.umb.size() - pm.umb0;
     pm.nuu = (int)out.upd.size() - pm.uu0;
     pm.nus = (int)out.usrc.size() - pm.us0;
-    if (piece_parent[p] < 0 && !ub.empty()) { out.error = "a root piece has an update matrix"; return -1; }
   }
   out.unz = ucur;
   out.lpiece.clear();
@@ -667,7 +707,7 @@ inline int chol_symbolic(const SymIn& in, CholOpts opt, CholHost& out) {
   // ---- LDS needs (doubles) ---------------------------------------------------------------------------------------------------
   auto lds_f = [&](int p) {
     const PieceMeta& pm = out.piece[p];
-    const int ustage = piece_tail[p] ? 0 : 4 * pm.nuit + 4 * pm.numb + 2 * pm.nuu + pm.nus + 2;
+    const int ustage = (piece_tail[p] || !opt.ustage) ? 0 : 4 * pm.nuit + 4 * pm.numb + 2 * pm.nuu + pm.nus + 2;
     return ((pm.lsize + 1) & ~1) + 2 * ((pm.ysize + 1) & ~1) + 4 * pm.nb + 2 * pm.nc + 2 * pm.nit_i + 2 * pm.nu_i + 2 * pm.nimb + pm.nas + ustage +
            kItemDoubles * piece_pmax[p] + 8;
   };

@@ -54,7 +54,7 @@ struct CholView {
 struct CholPlan {
   CholView C{};
   std::vector<int> lvl_ptr, plv_ptr, plv_lds_f, plv_lds_b;
-  int tail_lds_f = 0, tail_lds_b = 0, tail_total = 0, nt_tail = 512, nt_leaf = 256;
+  int tail_lds_f = 0, tail_lds_b = 0, tail_total = 0, nt_tail = 512, nt_leaf = 256, ustage = 1;
   std::vector<void*> allocs;
   int64_t lnz = 0, unz = 0;
   double* d_multi_y = nullptr;  // scratch for multi-rhs solves
@@ -411,73 +411,101 @@ __device__ __forceinline__ void chol_piece(const BatchView& V, const CholView& C
   const double* __restrict__ H = V.Hpp_diag;
   const double* __restrict__ U = C.Uval;
   const int ry = lane - 40;
-  // ---- 0. every table of the piece -> LDS in one round of independent loads
-  for (int i = tid; i < pm.nilv; i += NT) s_lv[i] = C.ilv[pm.ilv0 + i];
-  for (int i = tid; i < pm.nb; i += NT) sBlk[i] = C.blk[pm.b0 + i];
-  for (int i = tid; i < pm.nit_i; i += NT) sItem[i] = C.item[pm.iit0 + i];
-  for (int i = tid; i < pm.nu_i; i += NT) sUpd[i] = C.upd[pm.iu0 + i];
-  for (int i = tid; i < pm.nimb; i += NT) sMb[i] = C.mb[pm.imb0 + i];
-  for (int i = tid; i < pm.nas; i += NT) sAsm[i] = C.asrc[pm.as0 + i];
-  if (USTAGE) {
-    for (int i = tid; i < pm.nuit; i += NT) sUItem[i] = C.uitem[pm.uit0 + i];
-    for (int i = tid; i < pm.numb; i += NT) sUMb[i] = C.umb[pm.umb0 + i];
-    for (int i = tid; i < pm.nuu; i += NT) sUUpd[i] = C.upd[pm.uu0 + i];
-    for (int i = tid; i < pm.nus; i += NT) sUSrc[i] = C.usrc[pm.us0 + i];
+  // ---- 0. every table of the piece -> LDS in ONE round trip: all loads are issued (unconditionally, clamped indices) before the
+  //         first store, then the stores; only tables longer than their unroll x NT go round again.
+#define SSLAM_LD(T, name, src, n, UNR)                                                     \
+  T name##_r[UNR];                                                                         \
+  _Pragma("unroll") for (int k_ = 0; k_ < UNR; ++k_) name##_r[k_] = (src)[min(tid + k_ * NT, max((n)-1, 0))];
+#define SSLAM_ST(name, dst, src, n, UNR)                                                   \
+  _Pragma("unroll") for (int k_ = 0; k_ < UNR; ++k_) if (tid + k_ * NT < (n)) (dst)[tid + k_ * NT] = name##_r[k_]; \
+  for (int i_ = tid + UNR * NT; i_ < (n); i_ += NT) (dst)[i_] = (src)[i_];
+  {
+    SSLAM_LD(ILevel, t_lv, C.ilv + pm.ilv0, pm.nilv, 1)
+    SSLAM_LD(BlkMeta, t_blk, C.blk + pm.b0, pm.nb, 2)
+    SSLAM_LD(ItemMeta, t_item, C.item + pm.iit0, pm.nit_i, 2)
+    SSLAM_LD(UpdMeta, t_upd, C.upd + pm.iu0, pm.nu_i, 2)
+    SSLAM_LD(MbMeta, t_mb, C.mb + pm.imb0, pm.nimb, 1)
+    SSLAM_LD(AsmSrc, t_asm, C.asrc + pm.as0, pm.nas, 2)
+    SSLAM_LD(ColMeta, t_col, C.col + pm.c0, pm.nc, 1)
+    SSLAM_LD(UItem, t_uit, C.uitem + pm.uit0, USTAGE ? pm.nuit : 0, 2)
+    SSLAM_LD(UMb, t_umb, C.umb + pm.umb0, USTAGE ? pm.numb : 0, 1)
+    SSLAM_LD(UpdMeta, t_uupd, C.upd + pm.uu0, USTAGE ? pm.nuu : 0, 2)
+    SSLAM_LD(AsmSrc, t_usrc, C.usrc + pm.us0, USTAGE ? pm.nus : 0, 2)
+    SSLAM_ST(t_lv, s_lv, C.ilv + pm.ilv0, pm.nilv, 1)
+    SSLAM_ST(t_blk, sBlk, C.blk + pm.b0, pm.nb, 2)
+    SSLAM_ST(t_item, sItem, C.item + pm.iit0, pm.nit_i, 2)
+    SSLAM_ST(t_upd, sUpd, C.upd + pm.iu0, pm.nu_i, 2)
+    SSLAM_ST(t_mb, sMb, C.mb + pm.imb0, pm.nimb, 1)
+    SSLAM_ST(t_asm, sAsm, C.asrc + pm.as0, pm.nas, 2)
+    if (tid < pm.nc) sCol[tid] = make_int4(t_col_r[0].base - pm.lbase, t_col_r[0].dim, t_col_r[0].yoff - pm.y0, 0);
+    for (int c = tid + NT; c < pm.nc; c += NT) {
+      const ColMeta cm = C.col[pm.c0 + c];
+      sCol[c] = make_int4(cm.base - pm.lbase, cm.dim, cm.yoff - pm.y0, 0);
+    }
+    if (USTAGE) {
+      SSLAM_ST(t_uit, sUItem, C.uitem + pm.uit0, pm.nuit, 2)
+      SSLAM_ST(t_umb, sUMb, C.umb + pm.umb0, pm.numb, 1)
+      SSLAM_ST(t_uupd, sUUpd, C.upd + pm.uu0, pm.nuu, 2)
+      SSLAM_ST(t_usrc, sUSrc, C.usrc + pm.us0, pm.nus, 2)
+    }
   }
-  for (int c = tid; c < pm.nc; c += NT) {
-    const ColMeta cm = C.col[pm.c0 + c];
-    sCol[c] = make_int4(cm.base - pm.lbase, cm.dim, cm.yoff - pm.y0, 0);
-  }
+#undef SSLAM_LD
+#undef SSLAM_ST
   __syncthreads();
   SSLAM_STAMP(0)
-  // ---- 1. gather: A(:, piece) + lambda I and the rhs -> LDS.  One thread per (block, row): a handful of instructions per row
-  //         (these kernels are bound by instruction issue, not by bytes), every thread's loads independent of one another.
-  for (int t = tid; t < pm.nb * 6; t += NT) {
-    const int b = t / 6, row = t - 6 * b;
-    const BlkMeta bm = sBlk[b];
-    const int di = bm.info & 15, dj = (bm.info >> 4) & 15;
-    if (row >= di) continue;
-    double v[6];
-    if (bm.src >= 0) {
-      const double* ph = H + bm.src + ((bm.info & kBlkFmt) ? row : row * dj);
-      const int st = (bm.info & kBlkFmt) ? di : 1;
+  // ---- 1. gather: A(:, piece) + lambda I and the rhs, minus what the child pieces left for these blocks (their update matrices)
+  //         -> LDS.  One thread per (block, row): a handful of instructions per row (these kernels are bound by instruction issue,
+  //         not by bytes).  kG rows per thread are in flight together, H row and first child row side by side; a row's sources
+  //         are summed by its own thread -> no conflicts, fixed order.
+  {
+    constexpr int kG = 4;
+    const int nrow = pm.nb * 6;
+    for (int t0 = tid; t0 < nrow; t0 += NT * kG) {
+      double v[kG][6], w[kG][6], rhsv[kG], uyv[kG];
 #pragma unroll
-      for (int c = 0; c < 6; ++c) v[c] = c < dj ? ph[c * st] : 0.0;
-    } else {
+      for (int g2 = 0; g2 < kG; ++g2) {
+        const int t = min(t0 + g2 * NT, nrow - 1);
+        const int b = t / 6, row = t - 6 * b;
+        const BlkMeta bm = sBlk[b];
+        const int di = bm.info & 15, dj = (bm.info >> 4) & 15, nas = (bm.info >> kBlkNasShift) & 255;
+        const int rw = min(row, di - 1);                                   // idle threads shadow the last row: valid addresses
+        const double* ph = H + max(bm.src, 0) + ((bm.info & kBlkFmt) ? rw : rw * dj);
+        const int st = (bm.info & kBlkFmt) ? di : 1;
+        const AsmSrc as = nas > 0 ? sAsm[bm.as0] : AsmSrc{0, -1};
+        const double* pu = U + as.uoff + rw * dj;
 #pragma unroll
-      for (int c = 0; c < 6; ++c) v[c] = 0.0;
-    }
-    double* o = smL + (bm.off - pm.lbase) + row * dj;
-    const bool diag = bm.info & kBlkDiag;
-#pragma unroll
-    for (int c = 0; c < 6; ++c)
-      if (c < dj) o[c] = v[c] + ((diag && c == row) ? lambda : 0.0);
-    if (diag) smY[bm.colyoff - pm.y0 + row] = V.bvec[bm.xoff_row + row];
-  }
-  // ---- 1b. minus what the child pieces left for these blocks (their update matrices).  A row's sources are summed by one thread
-  //          -> no conflicts, fixed order.
-  if (pm.nas > 0) {
-    __syncthreads();
-    for (int t = tid; t < pm.nb * 6; t += NT) {
-      const int b = t / 6, row = t - 6 * b;
-      const BlkMeta bm = sBlk[b];
-      const int di = bm.info & 15, dj = (bm.info >> 4) & 15, nas = (bm.info >> kBlkNasShift) & 255;
-      if (row >= di || nas == 0) continue;
-      double v[6], vy = 0;
-#pragma unroll
-      for (int c = 0; c < 6; ++c) v[c] = 0.0;
-      const bool diag = bm.info & kBlkDiag;
-      for (int s2 = 0; s2 < nas; ++s2) {
-        const AsmSrc as = sAsm[bm.as0 + s2];
-        const double* pu = U + as.uoff + row * dj;
-#pragma unroll
-        for (int c = 0; c < 6; ++c) if (c < dj) v[c] += pu[c];
-        if (diag && as.uyoff >= 0) vy += U[as.uyoff + row];
+        for (int c = 0; c < 6; ++c) { const int cc = min(c, dj - 1); v[g2][c] = ph[cc * st]; w[g2][c] = pu[cc]; }
+        rhsv[g2] = V.bvec[bm.xoff_row + rw];
+        uyv[g2] = U[max(as.uyoff, 0) + rw];
       }
-      double* o = smL + (bm.off - pm.lbase) + row * dj;
 #pragma unroll
-      for (int c = 0; c < 6; ++c) if (c < dj) o[c] -= v[c];
-      if (diag) smY[bm.colyoff - pm.y0 + row] -= vy;
+      for (int g2 = 0; g2 < kG; ++g2) {
+        const int t = t0 + g2 * NT;
+        if (t >= nrow) continue;
+        const int b = t / 6, row = t - 6 * b;
+        const BlkMeta bm = sBlk[b];
+        const int di = bm.info & 15, dj = (bm.info >> 4) & 15, nas = (bm.info >> kBlkNasShift) & 255;
+        if (row >= di) continue;
+        const bool diag = bm.info & kBlkDiag;
+        double vy = diag ? rhsv[g2] : 0.0;
+#pragma unroll
+        for (int c = 0; c < 6; ++c) v[g2][c] = (bm.src >= 0 ? v[g2][c] : 0.0) + ((diag && c == row) ? lambda : 0.0) - (nas > 0 ? w[g2][c] : 0.0);
+        if (nas > 0) {
+          const AsmSrc as0 = sAsm[bm.as0];
+          if (diag && as0.uyoff >= 0) vy -= uyv[g2];
+          for (int s2 = 1; s2 < nas; ++s2) {
+            const AsmSrc as = sAsm[bm.as0 + s2];
+            const double* pu = U + as.uoff + row * dj;
+#pragma unroll
+            for (int c = 0; c < 6; ++c) if (c < dj) v[g2][c] -= pu[c];
+            if (diag && as.uyoff >= 0) vy -= U[as.uyoff + row];
+          }
+        }
+        double* o = smL + (bm.off - pm.lbase) + row * dj;
+#pragma unroll
+        for (int c = 0; c < 6; ++c) if (c < dj) o[c] = v[g2][c];
+        if (diag) smY[bm.colyoff - pm.y0 + row] = vy;
+      }
     }
   }
   __syncthreads();
@@ -534,12 +562,12 @@ __device__ __forceinline__ void chol_piece(const BatchView& V, const CholView& C
 }
 #undef SSLAM_STAMP
 
-template <int NT>
+template <int NT, bool USTAGE>
 __global__ __launch_bounds__(NT) void k_chol_pieces(BatchView V, CholView C, int begin) {
   extern __shared__ double sm[];
   const PieceMeta pm = C.lpiece[begin + blockIdx.x];
   if (!V.lm[pm.graph].in_trial) return;
-  chol_piece<NT, true>(V, C, pm, sm, (C.dbg && blockIdx.x == 0) ? C.dbg + 16 : nullptr);
+  chol_piece<NT, USTAGE>(V, C, pm, sm, (C.dbg && blockIdx.x == 0) ? C.dbg + 16 : nullptr);
 }
 
 // Top of the elimination tree: once a graph is down to a few pieces per depth a launch per depth only buys launch
@@ -574,7 +602,18 @@ __device__ __forceinline__ void chol_piece_backward(const CholView& C, const Pie
   int4* sCol = reinterpret_cast<int4*>(sBlk + pm.nb + (pm.nb & 1));   // {L offset of the diagonal block, dim | nb << 8 | nbi << 20, y offset, first block (piece-local)}
   int* sXoff = reinterpret_cast<int*>(sCol + pm.nc);
   // ---- 0. stream the piece in
-  for (int e = tid; e < pm.lsize; e += NT) smL[e] = C.Lval[pm.lbase + e];
+  {   // 16-byte loads, eight in flight per thread (lbase and lsize are even: blocks are stored at even offsets)
+    const D2* src = reinterpret_cast<const D2*>(C.Lval + pm.lbase);
+    D2* dst = reinterpret_cast<D2*>(smL);
+    const int n2 = pm.lsize >> 1;
+    for (int e0 = tid; e0 < n2; e0 += NT * 8) {
+      D2 r[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) r[k] = src[min(e0 + k * NT, n2 - 1)];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) if (e0 + k * NT < n2) dst[e0 + k * NT] = r[k];
+    }
+  }
   for (int e = tid; e < pm.ysize; e += NT) smX[e] = y[pm.y0 + e];
   for (int i = tid; i < pm.nilv; i += NT) s_lvb[i] = C.ilv[pm.ilv0 + i];
   for (int b = tid; b < pm.nb; b += NT) {
@@ -774,8 +813,9 @@ namespace {
 template <typename T>
 int up_to_dev(CholPlan& P, hipStream_t s, const std::vector<T>& h, const T** out) {
   void* p = nullptr;
-  const size_t n = std::max<size_t>(h.size(), 1);
+  const size_t n = h.size() + 4;   // slack: the kernels' clamped table loads may read one record past an empty range
   SSLAM_HIP_TRY(hipMalloc(&p, n * sizeof(T)));
+  SSLAM_HIP_TRY(hipMemsetAsync(p, 0, n * sizeof(T), s));
   P.allocs.push_back(p);
   if (!h.empty()) SSLAM_HIP_TRY(hipMemcpyAsync(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, s));
   *out = (const T*)p;
@@ -799,7 +839,7 @@ int chol_plan_build(Batch& b) {
   CholOpts opt;
   opt.from_env();
   if (opt.nt_tail != 1024) opt.nt_tail = 512;
-  if (opt.nt_leaf != 64 && opt.nt_leaf != 128) opt.nt_leaf = 256;
+  if (opt.nt_leaf != 64 && opt.nt_leaf != 128 && opt.nt_leaf != 512 && opt.nt_leaf != 1024) opt.nt_leaf = 256;
   CholHost H;
   if (chol_symbolic(in, opt, H)) return set_error(SSLAM_ERR_NUMERIC, "Cholesky plan: %s", H.error.c_str());
   CholPlan* P = new CholPlan();
@@ -807,7 +847,7 @@ int chol_plan_build(Batch& b) {
   CholView& C = P->C;
   C.ncol = H.ncol; C.nlevels = H.nlevels; C.dim = H.dim; C.npiece = H.npiece;
   P->lvl_ptr = H.lvl_ptr; P->plv_ptr = H.plv_ptr; P->plv_lds_f = H.plv_lds_f; P->plv_lds_b = H.plv_lds_b;
-  P->tail_lds_f = H.tail_lds_f; P->tail_lds_b = H.tail_lds_b; P->tail_total = (int)H.tail_pieces.size(); P->nt_tail = H.nt_tail; P->nt_leaf = H.nt_leaf;
+  P->tail_lds_f = H.tail_lds_f; P->tail_lds_b = H.tail_lds_b; P->tail_total = (int)H.tail_pieces.size(); P->nt_tail = H.nt_tail; P->nt_leaf = H.nt_leaf; P->ustage = H.ustage;
   P->lnz = H.lnz;
   int rc;
   if ((rc = up_to_dev(*P, b.stream, H.col, &C.col))) return rc;
@@ -850,15 +890,14 @@ int chol_plan_build(Batch& b) {
   if (lds_max > 160 * 1024 - 2048) return set_error(SSLAM_ERR_UNSUPPORTED, "a piece of the factor needs %zu B of LDS (> 158 KiB)", lds_max);
   if (lds_max > 48 * 1024) {
     const int v = (int)lds_max;
-    SSLAM_HIP_TRY(hipFuncSetAttribute((const void*)k_chol_pieces<256>, hipFuncAttributeMaxDynamicSharedMemorySize, v));
-    SSLAM_HIP_TRY(hipFuncSetAttribute((const void*)k_chol_pieces<128>, hipFuncAttributeMaxDynamicSharedMemorySize, v));
-    SSLAM_HIP_TRY(hipFuncSetAttribute((const void*)k_chol_pieces<64>, hipFuncAttributeMaxDynamicSharedMemorySize, v));
-    SSLAM_HIP_TRY(hipFuncSetAttribute((const void*)k_chol_back_pieces<128>, hipFuncAttributeMaxDynamicSharedMemorySize, v));
-    SSLAM_HIP_TRY(hipFuncSetAttribute((const void*)k_chol_back_pieces<64>, hipFuncAttributeMaxDynamicSharedMemorySize, v));
-    SSLAM_HIP_TRY(hipFuncSetAttribute((const void*)k_chol_tail<512>, hipFuncAttributeMaxDynamicSharedMemorySize, v));
-    SSLAM_HIP_TRY(hipFuncSetAttribute((const void*)k_chol_tail<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, v));
-    SSLAM_HIP_TRY(hipFuncSetAttribute((const void*)k_chol_back_pieces<256>, hipFuncAttributeMaxDynamicSharedMemorySize, v));
-    SSLAM_HIP_TRY(hipFuncSetAttribute((const void*)k_chol_back_tail<512>, hipFuncAttributeMaxDynamicSharedMemorySize, v));
+    const void* fns[] = {(const void*)k_chol_pieces<64, true>, (const void*)k_chol_pieces<128, true>, (const void*)k_chol_pieces<256, true>,
+                         (const void*)k_chol_pieces<512, true>, (const void*)k_chol_pieces<1024, true>,
+                         (const void*)k_chol_pieces<64, false>, (const void*)k_chol_pieces<128, false>, (const void*)k_chol_pieces<256, false>,
+                         (const void*)k_chol_pieces<512, false>, (const void*)k_chol_pieces<1024, false>,
+                         (const void*)k_chol_tail<512>, (const void*)k_chol_tail<1024>,
+                         (const void*)k_chol_back_pieces<64>, (const void*)k_chol_back_pieces<128>, (const void*)k_chol_back_pieces<256>,
+                         (const void*)k_chol_back_pieces<512>, (const void*)k_chol_back_pieces<1024>, (const void*)k_chol_back_tail<512>};
+    for (const void* f : fns) SSLAM_HIP_TRY(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, v));
   }
   SSLAM_HIP_TRY(hipStreamSynchronize(b.stream));
   return 0;
@@ -878,9 +917,17 @@ int chol_factor_and_forward(Batch& b) {
     const int n = P.plv_ptr[l + 1] - P.plv_ptr[l];
     if (n <= 0) continue;
     const size_t lds = (size_t)P.plv_lds_f[l] * sizeof(double);
-    if (P.nt_leaf == 64) hipLaunchKernelGGL(k_chol_pieces<64>, dim3(n), dim3(64), lds, b.stream, b.V, C, P.plv_ptr[l]);
-    else if (P.nt_leaf == 128) hipLaunchKernelGGL(k_chol_pieces<128>, dim3(n), dim3(128), lds, b.stream, b.V, C, P.plv_ptr[l]);
-    else hipLaunchKernelGGL(k_chol_pieces<256>, dim3(n), dim3(256), lds, b.stream, b.V, C, P.plv_ptr[l]);
+#define SSLAM_LAUNCH_PIECES(NTV)                                                                                                   \
+  if (P.ustage) hipLaunchKernelGGL((k_chol_pieces<NTV, true>), dim3(n), dim3(NTV), lds, b.stream, b.V, C, P.plv_ptr[l]);            \
+  else hipLaunchKernelGGL((k_chol_pieces<NTV, false>), dim3(n), dim3(NTV), lds, b.stream, b.V, C, P.plv_ptr[l]);
+    switch (P.nt_leaf) {
+      case 64: SSLAM_LAUNCH_PIECES(64) break;
+      case 128: SSLAM_LAUNCH_PIECES(128) break;
+      case 512: SSLAM_LAUNCH_PIECES(512) break;
+      case 1024: SSLAM_LAUNCH_PIECES(1024) break;
+      default: SSLAM_LAUNCH_PIECES(256) break;
+    }
+#undef SSLAM_LAUNCH_PIECES
   }
   if (P.tail_total > 0) {
     if (P.nt_tail == 1024) hipLaunchKernelGGL(k_chol_tail<1024>, dim3(b.V.B), dim3(1024), (size_t)P.tail_lds_f * sizeof(double), b.stream, b.V, C);
@@ -902,9 +949,15 @@ int chol_backward(Batch& b) {
     const int n = P.plv_ptr[l + 1] - P.plv_ptr[l];
     if (n <= 0) continue;
     const size_t lds = (size_t)P.plv_lds_b[l] * sizeof(double);
-    if (P.nt_leaf == 64) hipLaunchKernelGGL(k_chol_back_pieces<64>, dim3(n), dim3(64), lds, b.stream, C, P.plv_ptr[l], (const double*)C.y, b.V.x, (const LmState*)b.V.lm);
-    else if (P.nt_leaf == 128) hipLaunchKernelGGL(k_chol_back_pieces<128>, dim3(n), dim3(128), lds, b.stream, C, P.plv_ptr[l], (const double*)C.y, b.V.x, (const LmState*)b.V.lm);
-    else hipLaunchKernelGGL(k_chol_back_pieces<256>, dim3(n), dim3(256), lds, b.stream, C, P.plv_ptr[l], (const double*)C.y, b.V.x, (const LmState*)b.V.lm);
+#define SSLAM_LAUNCH_BACK(NTV) hipLaunchKernelGGL(k_chol_back_pieces<NTV>, dim3(n), dim3(NTV), lds, b.stream, C, P.plv_ptr[l], (const double*)C.y, b.V.x, (const LmState*)b.V.lm);
+    switch (P.nt_leaf) {
+      case 64: SSLAM_LAUNCH_BACK(64) break;
+      case 128: SSLAM_LAUNCH_BACK(128) break;
+      case 512: SSLAM_LAUNCH_BACK(512) break;
+      case 1024: SSLAM_LAUNCH_BACK(1024) break;
+      default: SSLAM_LAUNCH_BACK(256) break;
+    }
+#undef SSLAM_LAUNCH_BACK
   }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return set_error(SSLAM_ERR_HIP, "cholesky solve launch: %s", hipGetErrorString(e));

@@ -126,6 +126,11 @@ def test_plan_with_tiny_pieces_exercises_every_phase(hip_lib):
     assert len(plan.mb) > 0 and len(plan.umb) > 0 and np.any(plan.piece["nas"] > 0) and np.any(plan.piece["nus"] > 0)
     _structure_invariants(plan)
     _check(plan, H, b, 1e-3)
+    # pieces of equal depth packed into execution groups (one workgroup factors several subtrees side by side)
+    plan3, H3, b3 = _plan_and_system(hip_lib, g, False, dict(env, SSLAM_CHOL_GROUP_CAP=1500, SSLAM_CHOL_NT_LEAF=512))
+    assert plan3.npiece < plan.npiece
+    _structure_invariants(plan3)
+    _check(plan3, H3, b3, 1e-3)
     # same system, no tail: every piece goes through the per-depth launches
     plan2, H2, b2 = _plan_and_system(hip_lib, g, False, dict(env, SSLAM_CHOL_TAIL_WIDTH=0))
     assert len(plan2.tail_pieces) == 0
