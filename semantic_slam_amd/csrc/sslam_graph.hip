@@ -1008,7 +1008,7 @@ static int batch_build(Batch& b, bool host_only = false) {
   }
   const int nPP = (int)b.ppoff.size(), nPL = (int)b.plblk.size();
   b.hll_base = (int64_t)nPr * 36;
-  b.hpp_off_base = b.hll_base + (int64_t)nLr * 9;
+  b.hpp_off_base = b.hll_base + (((int64_t)nLr * 9 + 1) & ~(int64_t)1);   // even: the 6-wide blocks behind it stay 16-byte aligned
   b.hpl_base = b.hpp_off_base + (int64_t)nPP * 36;
   const int64_t h_total = b.hpl_base + (int64_t)nPL * 18;
   if (h_total >= (int64_t)1 << 31) return set_error(SSLAM_ERR_INVALID, "batch too large: H has %lld doubles (int32 block offsets)", (long long)h_total);
@@ -1833,11 +1833,11 @@ int64_t sslam_debug_plan_array(void* p, const char* name, void* out, int64_t cap
   ARR("col", H.col) ARR("blk", H.blk) ARR("upd", H.upd) ARR("item", H.item) ARR("mb", H.mb) ARR("ilv", H.ilv) ARR("piece", H.piece)
   ARR("lvl_ptr", H.lvl_ptr) ARR("lvl_cols", H.lvl_cols) ARR("plv_ptr", H.plv_ptr) ARR("plv_pieces", H.plv_pieces)
   ARR("ppoff", DP.ppoff) ARR("plblk", DP.plblk) ARR("tail_ptr", H.tail_ptr)
-  ARR("asrc", H.asrc) ARR("usrc", H.usrc) ARR("fwd", H.fwd) ARR("uitem", H.uitem) ARR("umb", H.umb) ARR("tail_pieces", H.tail_pieces) ARR("plv_lds_f", H.plv_lds_f) ARR("plv_lds_b", H.plv_lds_b)
+  ARR("asrc", H.asrc) ARR("usrc", H.usrc) ARR("fwd", H.fwd) ARR("uitem", H.uitem) ARR("umb", H.umb) ARR("uround", H.uround) ARR("tail_pieces", H.tail_pieces) ARR("plv_lds_f", H.plv_lds_f) ARR("plv_lds_b", H.plv_lds_b)
 #undef ARR
   if (k == "scalars") { src = scal; bytes = sizeof scal; }
   static const char* known[] = {"col", "blk", "upd", "item", "mb", "ilv", "piece", "lvl_ptr", "lvl_cols", "plv_ptr", "plv_pieces", "ppoff", "plblk",
-                                "tail_ptr", "tail_pieces", "plv_lds_f", "plv_lds_b", "scalars", "asrc", "usrc", "fwd", "uitem", "umb"};
+                                "tail_ptr", "tail_pieces", "plv_lds_f", "plv_lds_b", "scalars", "asrc", "usrc", "fwd", "uitem", "umb", "uround"};
   bool ok = false;
   for (const char* q : known) ok |= (k == q);
   if (!ok) return set_error(SSLAM_ERR_INVALID, "unknown plan array '%s'", name);
