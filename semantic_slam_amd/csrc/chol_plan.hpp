@@ -68,14 +68,12 @@ struct ILevel { int c0, c1, b0, b1, it0, it1, mb0, mb1; };   // one level inside
 
 // update-matrix side: a block U(a,b) of the piece = sum of its own updates [u0, u0 + n) (upd[], sources in the piece) + the
 // child blocks [s0, s0 + ns) (usrc[]); written to Uval[uoff ...] (and the rhs part to Uval[uyoff ...] for a diagonal block)
-struct UItem { int u0, n, uoff, flags, s0, ns, uyoff, pad; };   // flags: bits 1..11 tile slot of its round; bit 12 di == 6; bit 13 dj == 6; bit 14 diag
+struct UItem { int u0, n, uoff, flags, s0, ns, uyoff, pad; };   // flags: bit 0 sole; bits 1..11 partial slot; bit 12 di == 6; bit 13 dj == 6; bit 14 diag
 constexpr int kUItemDi6 = 1 << 12, kUItemDj6 = 1 << 13, kUItemDiag = 1 << 14;
-struct UMb { int uoff, ps0, n, info, s0, ns, uyoff, pad; };     // a U block: tile slots [ps0, ps0 + n) of its round; info = di | dj << 4 | diag << 9
-struct URound { int it0, it1, mb0, mb1; };                      // the U items / blocks (piece-local) computed and streamed out together: the
-                                                                // tiles of a round are staged in LDS and leave as coalesced 16-byte stores
+struct UMb { int uoff, ps0, n, info, s0, ns, uyoff, pad; };     // a U block whose own list was split: info = di | dj << 4 | diag << 9
 
 struct PieceMeta { int graph, c0, nc, b0, nb, lbase, lsize, y0, ysize, ilv0, nilv, iit0, nit_i, iu0, nu_i, imb0, nimb, as0, nas, uit0, nuit, umb0, numb,
-                   uu0, nuu, us0, nus, ur0, nur, pad2, pad3, pad4; };
+                   uu0, nuu, us0, nus, pad0, pad1, pad2, pad3, pad4; };
 // inside the piece (all copied to LDS when the piece starts, so that its levels never wait for HBM): levels [ilv0, +nilv), items
 // [iit0, +nit_i), update records [iu0, +nu_i), multi-blocks [imb0, +nimb), assembly sources [as0, +nas);
 // update matrix: U items [uit0, +nuit), split U blocks [umb0, +numb), their update records [uu0, +nuu) and child sources [us0, +nus)
@@ -104,8 +102,7 @@ struct CholOpts {
   int pcap_leaf = 16, pcap_tail = 32;   // partial tiles per phase (split lists): LDS budget of a piece
   int group_cap = 0;       // > 0: pieces of equal depth are packed into groups of <= group_cap doubles of L (and <= group_blocks blocks) that one
   int group_blocks = 1024; //      workgroup factors side by side: the per-level latencies and barriers are shared by all members
-  int ustage = 1;          // the per-depth kernels stage the update-matrix records in LDS too
-  int uslots = 32;         // tiles per update-matrix round (LDS staging: 336 B each)
+  int ustage = 0;          // 1: the per-depth kernels stage the update-matrix records in LDS too (costs residency)
   bool dump = false;
   static int env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
   void from_env() {
@@ -114,7 +111,7 @@ struct CholOpts {
     nt_tail = env_int("SSLAM_CHOL_NT_TAIL", nt_tail); nt_leaf = env_int("SSLAM_CHOL_NT_LEAF", nt_leaf); min_chunk = std::max(1, env_int("SSLAM_CHOL_MIN_CHUNK", min_chunk));
     pcap_leaf = env_int("SSLAM_CHOL_PCAP_LEAF", pcap_leaf); pcap_tail = env_int("SSLAM_CHOL_PCAP_TAIL", pcap_tail);
     group_cap = env_int("SSLAM_CHOL_GROUP_CAP", group_cap); group_blocks = env_int("SSLAM_CHOL_GROUP_BLOCKS", group_blocks);
-    ustage = env_int("SSLAM_CHOL_USTAGE", ustage); uslots = std::max(4, env_int("SSLAM_CHOL_USLOTS", uslots));
+    ustage = env_int("SSLAM_CHOL_USTAGE", ustage);
     dump = getenv("SSLAM_CHOL_DUMP") != nullptr;
   }
 };
@@ -125,14 +122,14 @@ struct CholHost {
   int64_t unz = 0;           // doubles in Uval (update matrices handed between pieces)
   std::vector<ColMeta> col; std::vector<BlkMeta> blk; std::vector<UpdMeta> upd; std::vector<ItemMeta> item; std::vector<MbMeta> mb;
   std::vector<ILevel> ilv; std::vector<PieceMeta> piece;
-  std::vector<AsmSrc> asrc, usrc; std::vector<FwdMeta> fwd; std::vector<UItem> uitem; std::vector<UMb> umb; std::vector<URound> uround;
+  std::vector<AsmSrc> asrc, usrc; std::vector<FwdMeta> fwd; std::vector<UItem> uitem; std::vector<UMb> umb;
   std::vector<int> lvl_ptr, lvl_cols;       // column levels of the elimination tree (multi right-hand-side solves)
   std::vector<int> plv_ptr, plv_pieces;     // pieces grouped by depth (one launch each)
   std::vector<PieceMeta> lpiece;            // piece records in launch order: plv_pieces then tail_pieces (one dependent load less per workgroup)
   std::vector<int> tail_ptr, tail_pieces;   // per graph: its tail pieces in elimination order
   std::vector<int> plv_lds_f, plv_lds_b;    // LDS doubles per launch (factor / backward)
   int tail_lds_f = 0, tail_lds_b = 0;
-  int nt_leaf = 256, nt_tail = 512, ustage = 1;
+  int nt_leaf = 256, nt_tail = 512, ustage = 0;
   std::string error;
 };
 
@@ -506,7 +503,7 @@ inline int chol_symbolic(const SymIn& in, CholOpts opt, CholHost& out) {
   struct URec { int a, b, uoff, uy, comp; };          // finished update-matrix block (row column-ids a >= b; uy: rhs part of a diagonal block) of component comp
   std::vector<std::vector<URec>> inbox(npiece);       // per group: the blocks its child components handed up (kept until consumed)
   std::vector<std::vector<int>> comp_R(ncomp);        // boundary rows of a component (column ids, ascending)
-  out.upd.clear(); out.item.clear(); out.mb.clear(); out.ilv.clear(); out.asrc.clear(); out.usrc.clear(); out.uitem.clear(); out.umb.clear(); out.uround.clear();
+  out.upd.clear(); out.item.clear(); out.mb.clear(); out.ilv.clear(); out.asrc.clear(); out.usrc.clear(); out.uitem.clear(); out.umb.clear();
   std::vector<int> piece_pmax(npiece, 0);   // most partial tiles any phase of the piece needs
   int64_t ucur = 0;
   for (int p = 0; p < npiece; ++p) {
@@ -662,18 +659,15 @@ inline int chol_symbolic(const SymIn& in, CholOpts opt, CholHost& out) {
       std::unordered_map<int, int> comp_uy;   // Uval offset of a component's rhs part [|R|][6]
       for (int c : comps) { comp_uy[c] = (int)cur; cur += 6 * (int64_t)comp_R[c].size(); }
       if (cur >= ((int64_t)1 << 31) - 4096) { out.error = "update matrices too large for int32 offsets"; return -1; }
-      const int rcap = std::min(slots, opt.uslots);   // tiles per round
       int U = 0;
       for (auto& x : ub) U += (int)x.own.size();
       int chunk = std::max(opt.min_chunk, (U + slots - 1) / slots);
-      for (;; ++chunk) {   // a block's tiles must fit one round
-        int worst = 0;
-        for (auto& x : ub) worst = std::max(worst, ((int)x.own.size() + chunk - 1) / chunk);
-        if (worst <= rcap || chunk >= std::max(U, 1)) break;
+      for (;; ++chunk) {
+        int nonsole = 0;
+        for (auto& x : ub) { const int k = ((int)x.own.size() + chunk - 1) / chunk; if (k > 1) nonsole += k; }
+        if (nonsole <= pcap || chunk >= std::max(U, 1)) break;
       }
-      pm.ur0 = (int)out.uround.size();
-      int ps = 0, rmax = 0;
-      URound rd{0, 0, 0, 0};
+      int ps = 0;
       for (int q : order) {
         UB& x = ub[q];
         const int di = col_dim[x.a], dj = col_dim[x.b];
@@ -681,35 +675,23 @@ inline int chol_symbolic(const SymIn& in, CholOpts opt, CholHost& out) {
         int uy = -1;
         if (diag) { const std::vector<int>& R = comp_R[x.comp]; uy = comp_uy[x.comp] + 6 * (int)(std::lower_bound(R.begin(), R.end(), x.a) - R.begin()); }
         const int tpk = (di == 6 ? kUpdDi6 : 0) | (diag ? kUpdDiag : 0) | (dj == 6 ? kUpdDj6 : 0);
-        const int n = (int)x.own.size();
-        const int k = std::max(1, (n + chunk - 1) / chunk);
-        if (ps + k > rcap) {   // close the round
-          rd.it1 = (int)out.uitem.size() - pm.uit0; rd.mb1 = (int)out.umb.size() - pm.umb0;
-          out.uround.push_back(rd);
-          rd.it0 = rd.it1; rd.mb0 = rd.mb1; ps = 0;
-        }
         const int u0 = (int)out.upd.size() - pm.uu0;
         for (auto& u : x.own) out.upd.push_back(UpdMeta{u[0], u[1], col_yoff[u[2]], tpk | (col_dim[u[2]] == 6 ? kUpdDk6 : 0)});
+        const int n = (int)x.own.size();
         const int s0 = (int)out.usrc.size() - pm.us0;
         for (auto& a2 : x.src) out.usrc.push_back(a2);
         const int ns = (int)x.src.size();
+        const int k = std::max(1, (n + chunk - 1) / chunk);
         const int shape = (di == 6 ? kUItemDi6 : 0) | (dj == 6 ? kUItemDj6 : 0) | (diag ? kUItemDiag : 0);
         for (int qq = 0; qq < k; ++qq) {
           const int a2 = u0 + qq * chunk, b2 = std::min(u0 + n, a2 + chunk);
-          out.uitem.push_back(UItem{a2, std::max(0, b2 - a2), uoffs[q], shape | ((ps + qq) << kItemSlotShift), s0, ns, uy, 0});
+          out.uitem.push_back(UItem{a2, std::max(0, b2 - a2), uoffs[q], shape | (k == 1 ? kItemSole : ((ps + qq) << kItemSlotShift)), s0, ns, uy, 0});
         }
-        out.umb.push_back(UMb{uoffs[q], ps, k, di | (dj << 4) | (diag ? kBlkDiag : 0), s0, ns, uy, 0});
-        ps += k;
-        rmax = std::max(rmax, ps);
+        if (k > 1) { out.umb.push_back(UMb{uoffs[q], ps, k, di | (dj << 4) | (diag ? kBlkDiag : 0), s0, ns, uy, 0}); ps += k; }
         if (comp_dest[x.comp] < 0) { out.error = "a root component has an update matrix"; return -1; }
         inbox[comp_dest[x.comp]].push_back(URec{x.a, x.b, uoffs[q], uy, x.comp});
       }
-      if (!ub.empty()) {
-        rd.it1 = (int)out.uitem.size() - pm.uit0; rd.mb1 = (int)out.umb.size() - pm.umb0;
-        out.uround.push_back(rd);
-      }
-      pm.nur = (int)out.uround.size() - pm.ur0;
-      piece_pmax[p] = std::max(piece_pmax[p], rmax);
+      piece_pmax[p] = std::max(piece_pmax[p], ps);
       ucur = cur;
     }
     pm.nuit = (int)out.uitem.size() - pm.uit0;
@@ -725,7 +707,7 @@ inline int chol_symbolic(const SymIn& in, CholOpts opt, CholHost& out) {
   // ---- LDS needs (doubles) ---------------------------------------------------------------------------------------------------
   auto lds_f = [&](int p) {
     const PieceMeta& pm = out.piece[p];
-    const int ustage = (piece_tail[p] || !opt.ustage) ? 0 : 4 * pm.nuit + 4 * pm.numb + 2 * pm.nur + 2 * pm.nuu + pm.nus + 2;
+    const int ustage = (piece_tail[p] || !opt.ustage) ? 0 : 4 * pm.nuit + 4 * pm.numb + 2 * pm.nuu + pm.nus + 2;
     return ((pm.lsize + 1) & ~1) + 2 * ((pm.ysize + 1) & ~1) + 4 * pm.nb + 2 * pm.nc + 2 * pm.nit_i + 2 * pm.nu_i + 2 * pm.nimb + pm.nas + ustage +
            kItemDoubles * piece_pmax[p] + 8;
   };

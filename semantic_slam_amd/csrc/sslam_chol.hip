@@ -39,7 +39,6 @@ struct CholView {
   const AsmSrc* usrc;       // child update-matrix blocks passed on through a piece's own update matrix
   const UItem* uitem;
   const UMb* umb;
-  const URound* uround;
   const FwdMeta* fwd;       // blocks of every row (multi right-hand-side forward substitution)
   const int* lvl_cols;      // columns grouped by level of the elimination tree
   const int* plv_pieces;    // pieces grouped by depth
@@ -220,11 +219,13 @@ __device__ __forceinline__ void reduce_multi(const MbMeta* __restrict__ mbs, int
   }
 }
 
-// Update-matrix items [it_begin, it_end) of one round: the tile of U(a,b) from the piece's own updates L(a,k) L(b,k)^T (sources in
-// LDS) goes to its slot of the LDS staging area; a diagonal block carries the rhs part sum_k L(a,k) y_k along.  No global access.
+// Update-matrix items [it_begin, it_end) of a piece: the block U(a,b) = sum of the piece's own updates L(a,k) L(b,k)^T (sources in
+// LDS) + the blocks its children handed up for the same pair; a diagonal block carries the rhs part sum_k L(a,k) y_k along.
+// A sole item finishes its block and writes it to HBM; the items of a split list park their tiles in `part` (reduce_umulti).
 template <int NT>
 __device__ __forceinline__ void run_uitems(const UItem* __restrict__ items, int it_begin, int it_end, const UpdMeta* __restrict__ upd,
-                                           const double* __restrict__ smL, const double* __restrict__ smY, int lofs, int yofs, double* part, int tid) {
+                                           const AsmSrc* __restrict__ usrc, const double* __restrict__ smL, const double* __restrict__ smY,
+                                           int lofs, int yofs, double* __restrict__ U, double* part, int tid) {
   const int lq = tid & 3, tr = lq >> 1, tc = lq & 1;
   for (int it = it_begin + (tid >> 2); it < it_end; it += NT / 4) {
     const UItem im = items[it];
@@ -233,10 +234,20 @@ __device__ __forceinline__ void run_uitems(const UItem* __restrict__ items, int 
     const bool diag = im.flags & kUItemDiag;
     const int tre = 3 * tr < di ? tr : 0, tce = 3 * tc < dj ? tc : 0;
     double acc[9], accy[3];
+    // the first child block of this tile: its loads travel while the own updates are computed out of LDS
+    const bool sole = im.flags & kItemSole;
+    const AsmSrc src0 = (sole && im.ns > 0) ? usrc[im.s0] : AsmSrc{0, -1};
+    {
+      const double* o = U + src0.uoff;
+      const bool on = sole && im.ns > 0;
 #pragma unroll
-    for (int q = 0; q < 9; ++q) acc[q] = 0;
+      for (int rr = 0; rr < 3; ++rr)
 #pragma unroll
-    for (int q = 0; q < 3; ++q) accy[q] = 0;
+        for (int cc = 0; cc < 3; ++cc) { const double v = o[(3 * tre + rr) * dj + 3 * tce + cc]; acc[rr * 3 + cc] = on ? v : 0.0; }
+      const double* oy = U + (src0.uyoff >= 0 ? src0.uyoff : 0);
+#pragma unroll
+      for (int rr = 0; rr < 3; ++rr) { const double v = oy[3 * tre + rr]; accy[rr] = (on && diag && src0.uyoff >= 0) ? v : 0.0; }
+    }
     for (int k0 = 0; k0 < n; k0 += 8) {
       const UpdMeta r0 = upd[im.u0 + min(k0 + lq, n - 1)];
       const UpdMeta r1 = upd[im.u0 + min(k0 + 4 + lq, n - 1)];
@@ -249,40 +260,61 @@ __device__ __forceinline__ void run_uitems(const UItem* __restrict__ items, int 
 #undef SSLAM_STEP
     }
     if (3 * tr < di && 3 * tc < dj) {
-      double* o = part + ((im.flags >> kItemSlotShift) & kItemSlotMask) * kItemDoubles;
+      if (sole) {
+        for (int s2 = 1; s2 < im.ns; ++s2) {
+          const AsmSrc src = usrc[im.s0 + s2];
+          const double* o = U + src.uoff;
 #pragma unroll
-      for (int rr = 0; rr < 3; ++rr) {
+          for (int rr = 0; rr < 3; ++rr)
 #pragma unroll
-        for (int cc = 0; cc < 3; ++cc) o[(3 * tr + rr) * dj + 3 * tc + cc] = acc[rr * 3 + cc];
-        if (diag && tc == 0) o[36 + 3 * tr + rr] = accy[rr];
+            for (int cc = 0; cc < 3; ++cc) acc[rr * 3 + cc] += o[(3 * tr + rr) * dj + 3 * tc + cc];
+          if (diag && tc == 0 && src.uyoff >= 0) {
+#pragma unroll
+            for (int rr = 0; rr < 3; ++rr) accy[rr] += U[src.uyoff + 3 * tr + rr];
+          }
+        }
+        double* o = U + im.uoff;
+#pragma unroll
+        for (int rr = 0; rr < 3; ++rr)
+#pragma unroll
+          for (int cc = 0; cc < 3; ++cc) o[(3 * tr + rr) * dj + 3 * tc + cc] = acc[rr * 3 + cc];
+        if (diag && tc == 0) {
+#pragma unroll
+          for (int rr = 0; rr < 3; ++rr) U[im.uyoff + 3 * tr + rr] = accy[rr];
+        }
+      } else {
+        double* o = part + ((im.flags >> kItemSlotShift) & kItemSlotMask) * kItemDoubles;
+#pragma unroll
+        for (int rr = 0; rr < 3; ++rr) {
+#pragma unroll
+          for (int cc = 0; cc < 3; ++cc) o[(3 * tr + rr) * dj + 3 * tc + cc] = acc[rr * 3 + cc];
+          if (diag && tc == 0) o[36 + 3 * tr + rr] = accy[rr];
+        }
       }
     }
   }
 }
 
-// The U blocks [m0, m1) of one round leave for HBM: staged tiles in slot order + the blocks the children handed up for the same
-// pair, as coalesced 16-byte loads / stores (thread = one 16-byte chunk of one block; 18 chunks of entries + 3 of rhs per block).
-template <int NT>
-__device__ __forceinline__ void ustream(const UMb* __restrict__ mbs, int m0, int m1, const AsmSrc* __restrict__ usrc, double* __restrict__ U,
-                                        const double* part, int tid) {
-  const int nq = (m1 - m0) * 21;
-  for (int q = tid; q < nq; q += NT) {
-    const int m = q / 21, c = q - 21 * m;
-    const UMb mm = mbs[m0 + m];
+// U blocks whose own list was split: partial tiles in item order + the children's blocks -> HBM (one wave per block, lane = entry)
+__device__ __forceinline__ void reduce_umulti(const UMb* __restrict__ mbs, int m0, int m1, const AsmSrc* __restrict__ usrc, double* __restrict__ U,
+                                              const double* part, int wave, int lane, int nw) {
+  const int ry = lane - 40;
+  for (int m = m0 + wave; m < m1; m += nw) {
+    const UMb mm = mbs[m];
     const int di = mm.info & 15, dj = (mm.info >> 4) & 15;
     const bool diag = mm.info & kBlkDiag;
-    const bool ent = c < 18;
-    if (ent ? (2 * c >= di * dj) : (!diag || 2 * (c - 18) >= dj)) continue;
-    const int po = ent ? 2 * c : 36 + 2 * (c - 18);
-    const D2* p = reinterpret_cast<const D2*>(part + mm.ps0 * kItemDoubles + po);
-    D2 v = p[0];
-    for (int k = 1; k < mm.n; ++k) { const D2 w = p[k * (kItemDoubles / 2)]; v.a += w.a; v.b += w.b; }
-    for (int s2 = 0; s2 < mm.ns; ++s2) {
-      const AsmSrc src = usrc[mm.s0 + s2];
-      if (ent) { const D2 w = *reinterpret_cast<const D2*>(U + src.uoff + 2 * c); v.a += w.a; v.b += w.b; }
-      else if (src.uyoff >= 0) { const D2 w = *reinterpret_cast<const D2*>(U + src.uyoff + 2 * (c - 18)); v.a += w.a; v.b += w.b; }
+    const double* p = part + mm.ps0 * kItemDoubles;
+    if (lane < di * dj) {
+      double v = 0;
+      for (int q = 0; q < mm.n; ++q) v += p[q * kItemDoubles + lane];
+      for (int s2 = 0; s2 < mm.ns; ++s2) v += U[usrc[mm.s0 + s2].uoff + lane];
+      U[mm.uoff + lane] = v;
+    } else if (diag && ry >= 0 && ry < dj) {
+      double v = 0;
+      for (int q = 0; q < mm.n; ++q) v += p[q * kItemDoubles + 36 + ry];
+      for (int s2 = 0; s2 < mm.ns; ++s2) { const int uy = usrc[mm.s0 + s2].uyoff; if (uy >= 0) v += U[uy + ry]; }
+      U[mm.uyoff + ry] = v;
     }
-    *reinterpret_cast<D2*>(U + (ent ? mm.uoff + 2 * c : mm.uyoff + 2 * (c - 18))) = v;
   }
 }
 
@@ -373,8 +405,7 @@ __device__ __forceinline__ void chol_piece(const BatchView& V, const CholView& C
   // update-matrix records: staged in LDS by the per-depth kernels (USTAGE), read from HBM by the tail
   UItem* sUItem = reinterpret_cast<UItem*>(sAsm + pm.nas + (pm.nas & 1));
   UMb* sUMb = reinterpret_cast<UMb*>(sUItem + (USTAGE ? pm.nuit : 0));
-  URound* sURound = reinterpret_cast<URound*>(sUMb + (USTAGE ? pm.numb : 0));
-  UpdMeta* sUUpd = reinterpret_cast<UpdMeta*>(sURound + (USTAGE ? pm.nur : 0));
+  UpdMeta* sUUpd = reinterpret_cast<UpdMeta*>(sUMb + (USTAGE ? pm.numb : 0));
   AsmSrc* sUSrc = reinterpret_cast<AsmSrc*>(sUUpd + (USTAGE ? pm.nuu : 0));
   double* part = reinterpret_cast<double*>(sUSrc + (USTAGE ? pm.nus + (pm.nus & 1) : 0));
   const double* __restrict__ H = V.Hpp_diag;
@@ -398,7 +429,6 @@ __device__ __forceinline__ void chol_piece(const BatchView& V, const CholView& C
     SSLAM_LD(ColMeta, t_col, C.col + pm.c0, pm.nc, 1)
     SSLAM_LD(UItem, t_uit, C.uitem + pm.uit0, USTAGE ? pm.nuit : 0, 2)
     SSLAM_LD(UMb, t_umb, C.umb + pm.umb0, USTAGE ? pm.numb : 0, 1)
-    SSLAM_LD(URound, t_ur, C.uround + pm.ur0, USTAGE ? pm.nur : 0, 1)
     SSLAM_LD(UpdMeta, t_uupd, C.upd + pm.uu0, USTAGE ? pm.nuu : 0, 2)
     SSLAM_LD(AsmSrc, t_usrc, C.usrc + pm.us0, USTAGE ? pm.nus : 0, 2)
     SSLAM_ST(t_lv, s_lv, C.ilv + pm.ilv0, pm.nilv, 1)
@@ -415,7 +445,6 @@ __device__ __forceinline__ void chol_piece(const BatchView& V, const CholView& C
     if (USTAGE) {
       SSLAM_ST(t_uit, sUItem, C.uitem + pm.uit0, pm.nuit, 2)
       SSLAM_ST(t_umb, sUMb, C.umb + pm.umb0, pm.numb, 1)
-      SSLAM_ST(t_ur, sURound, C.uround + pm.ur0, pm.nur, 1)
       SSLAM_ST(t_uupd, sUUpd, C.upd + pm.uu0, pm.nuu, 2)
       SSLAM_ST(t_usrc, sUSrc, C.usrc + pm.us0, pm.nus, 2)
     }
@@ -429,7 +458,7 @@ __device__ __forceinline__ void chol_piece(const BatchView& V, const CholView& C
   //         not by bytes).  kG rows per thread are in flight together, H row and first child row side by side; a row's sources
   //         are summed by its own thread -> no conflicts, fixed order.
   {
-    constexpr int kG = 4;
+    constexpr int kG = 2;
     const int nrow = pm.nb * 6;
     for (int t0 = tid; t0 < nrow; t0 += NT * kG) {
       double v[kG][6], w[kG][6], rhsv[kG], uyv[kG];
@@ -523,14 +552,14 @@ __device__ __forceinline__ void chol_piece(const BatchView& V, const CholView& C
     SSLAM_STAMP(5)
   }
   // ---- 3. the update matrix over the rows above the piece: own updates out of LDS + the children's blocks -> HBM
-  for (int r = 0; r < pm.nur; ++r) {   // round by round: tiles -> LDS staging -> coalesced 16-byte stream to HBM
-    const URound ur = USTAGE ? sURound[r] : C.uround[pm.ur0 + r];
-    if (USTAGE) run_uitems<NT>(sUItem, ur.it0, ur.it1, sUUpd, smL, smY, pm.lbase, pm.y0, part, tid);
-    else run_uitems<NT>(C.uitem + pm.uit0, ur.it0, ur.it1, C.upd + pm.uu0, smL, smY, pm.lbase, pm.y0, part, tid);
-    __syncthreads();
-    if (USTAGE) ustream<NT>(sUMb, ur.mb0, ur.mb1, sUSrc, C.Uval, part, tid);
-    else ustream<NT>(C.umb + pm.umb0, ur.mb0, ur.mb1, C.usrc + pm.us0, C.Uval, part, tid);
-    if (r + 1 < pm.nur) __syncthreads();
+  if (pm.nuit > 0) {
+    if (USTAGE) run_uitems<NT>(sUItem, 0, pm.nuit, sUUpd, sUSrc, smL, smY, pm.lbase, pm.y0, C.Uval, part, tid);
+    else run_uitems<NT>(C.uitem + pm.uit0, 0, pm.nuit, C.upd + pm.uu0, C.usrc + pm.us0, smL, smY, pm.lbase, pm.y0, C.Uval, part, tid);
+    if (pm.numb > 0) {
+      __syncthreads();
+      if (USTAGE) reduce_umulti(sUMb, 0, pm.numb, sUSrc, C.Uval, part, wave, lane, NW);
+      else reduce_umulti(C.umb + pm.umb0, 0, pm.numb, C.usrc + pm.us0, C.Uval, part, wave, lane, NW);
+    }
   }
   SSLAM_STAMP(6)
   // ---- 4. one coalesced stream out
@@ -546,7 +575,7 @@ __device__ __forceinline__ void chol_piece(const BatchView& V, const CholView& C
 #undef SSLAM_STAMP
 
 template <int NT, bool USTAGE>
-__global__ __launch_bounds__(NT) void k_chol_pieces(BatchView V, CholView C, int begin) {
+__global__ __launch_bounds__(NT, 4) void k_chol_pieces(BatchView V, CholView C, int begin) {   // <= 128 VGPRs: four waves per SIMD
   extern __shared__ double sm[];
   const PieceMeta pm = C.lpiece[begin + blockIdx.x];
   if (!V.lm[pm.graph].in_trial) return;
@@ -557,7 +586,7 @@ __global__ __launch_bounds__(NT) void k_chol_pieces(BatchView V, CholView C, int
 // latency.  One workgroup per graph walks its remaining pieces in elimination order; the barrier between pieces orders
 // the L / y stores of one piece before the loads of the next (same CU).
 template <int NT>
-__global__ __launch_bounds__(NT, 4) void k_chol_tail(BatchView V, CholView C) {   // <= 128 VGPRs: two 512-thread workgroups per CU
+__global__ __launch_bounds__(NT) void k_chol_tail(BatchView V, CholView C) {
   extern __shared__ double sm[];
   const int g = blockIdx.x;
   if (!V.lm[g].in_trial) return;
@@ -610,8 +639,7 @@ __device__ __forceinline__ void chol_piece_backward(const CholView& C, const Pie
     sXoff[c] = cm.xoff;
   }
   __syncthreads();
-  // ---- 1. rows above the piece (x already final in HBM): one thread per block loads x_i once (the 8-lane form issued eight times
-  //         the global loads: these kernels are bound by the number of memory instructions) -> smE; then summed per column in block order
+  // ---- 1. rows above the piece (x already final in HBM): one thread per block loads x_i once -> smE; then summed per column in block order
   for (int b = tid; b < pm.nb; b += NT) {
     const int2 bm = sBlk[b];
     if (bm.y < 0) continue;     // row inside the piece
@@ -858,7 +886,6 @@ int chol_plan_build(Batch& b) {
   if ((rc = up_to_dev(*P, b.stream, H.usrc, &C.usrc))) return rc;
   if ((rc = up_to_dev(*P, b.stream, H.uitem, &C.uitem))) return rc;
   if ((rc = up_to_dev(*P, b.stream, H.umb, &C.umb))) return rc;
-  if ((rc = up_to_dev(*P, b.stream, H.uround, &C.uround))) return rc;
   if ((rc = up_to_dev(*P, b.stream, H.fwd, &C.fwd))) return rc;
   if ((rc = up_to_dev(*P, b.stream, H.lvl_cols, &C.lvl_cols))) return rc;
   if ((rc = up_to_dev(*P, b.stream, H.plv_pieces, &C.plv_pieces))) return rc;

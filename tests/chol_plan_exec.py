@@ -14,14 +14,13 @@ ASRC = np.dtype([("uoff", "<i4"), ("uyoff", "<i4")])
 FWD = np.dtype([("off", "<i4"), ("yoff", "<i4")])
 UITEM = np.dtype([(n, "<i4") for n in ("u0", "n", "uoff", "flags", "s0", "ns", "uyoff", "pad")])
 UMB = np.dtype([(n, "<i4") for n in ("uoff", "ps0", "n", "info", "s0", "ns", "uyoff", "pad")])
-UROUND = np.dtype([(n, "<i4") for n in ("it0", "it1", "mb0", "mb1")])
 UPD = np.dtype([(n, "<i4") for n in ("ua", "ub", "ux", "pk")])
 ITEM = np.dtype([(n, "<i4") for n in ("u0", "n", "tloff", "flags")])
 MB = np.dtype([(n, "<i4") for n in ("tloff", "ps0", "n", "info")])
 ILV = np.dtype([(n, "<i4") for n in ("c0", "c1", "b0", "b1", "it0", "it1", "mb0", "mb1")])
 PIECE = np.dtype([(n, "<i4") for n in ("graph", "c0", "nc", "b0", "nb", "lbase", "lsize", "y0", "ysize", "ilv0", "nilv", "iit0", "nit_i",
                                        "iu0", "nu_i", "imb0", "nimb", "as0", "nas", "uit0", "nuit", "umb0", "numb",
-                                       "uu0", "nuu", "us0", "nus", "ur0", "nur", "pad2", "pad3", "pad4")])
+                                       "uu0", "nuu", "us0", "nus", "pad0", "pad1", "pad2", "pad3", "pad4")])
 K_DI6, K_DK6, K_DIAG, K_DJ6 = 1 << 20, 1 << 21, 1 << 22, 1 << 23
 B_FMT, B_DIAG, B_ROWIN = 1 << 8, 1 << 9, 1 << 10
 
@@ -37,7 +36,6 @@ class Plan:
         self.col, self.blk, self.upd = g("col", COL), g("blk", BLK), g("upd", UPD)
         self.item, self.mb, self.ilv, self.piece = g("item", ITEM), g("mb", MB), g("ilv", ILV), g("piece", PIECE)
         self.asrc, self.usrc, self.fwd, self.uitem, self.umb = g("asrc", ASRC), g("usrc", ASRC), g("fwd", FWD), g("uitem", UITEM), g("umb", UMB)
-        self.uround = g("uround", UROUND)
         for n in ("lvl_ptr", "lvl_cols", "plv_ptr", "plv_pieces", "tail_ptr", "tail_pieces", "plv_lds_f", "plv_lds_b", "ppoff", "plblk", "scalars"):
             setattr(self, n, g(n, np.int32))
         s = self.scalars
@@ -188,49 +186,47 @@ class Plan:
                 Lj = smL[od:od + dj * dj].reshape(dj, dj)
                 Vb = smL[o:o + di * dj].reshape(di, dj)
                 smL[o:o + di * dj] = np.linalg.solve(Lj, Vb.T).T.ravel()
-        # update matrix of the piece, round by round: own updates (sources in the piece) -> staged tiles; then every block of the
-        # round = its tiles in slot order + the children's blocks
+        # update matrix of the piece: own updates (sources in the piece) + the children's blocks
+        part = {}
         uupd = self.upd[pm["uu0"]:pm["uu0"] + pm["nuu"]]
         usrc = self.usrc[pm["us0"]:pm["us0"] + pm["nus"]]
-        uitems = self.uitem[pm["uit0"]:pm["uit0"] + pm["nuit"]]
-        umbs = self.umb[pm["umb0"]:pm["umb0"] + pm["numb"]]
-        seen_items = 0; seen_mbs = 0
-        for ur in self.uround[pm["ur0"]:pm["ur0"] + pm["nur"]]:
-            part = {}
-            assert ur["it0"] == seen_items and ur["mb0"] == seen_mbs
-            for im in uitems[ur["it0"]:ur["it1"]]:
-                fl = int(im["flags"])
-                di = 6 if fl & (1 << 12) else 3
-                dj = 6 if fl & (1 << 13) else 3
-                diag = bool(fl & (1 << 14))
-                u = uupd[im["u0"]:im["u0"] + im["n"]]
-                assert len(u) == im["n"]
-                for r in u:
-                    assert lbase <= r["ua"] < lbase + pm["lsize"] and lbase <= r["ub"] < lbase + pm["lsize"]
-                slot = (fl >> 1) & 0x7FF
-                assert slot not in part
-                part[slot] = self._tile_sum(u, smL, smY, lbase, y0, di, dj, diag)
-            for mm in umbs[ur["mb0"]:ur["mb1"]]:
-                di, dj = int(mm["info"]) & 15, (int(mm["info"]) >> 4) & 15
-                diag = bool(int(mm["info"]) & B_DIAG)
-                acc = np.zeros((di, dj)); accy = np.zeros(di)
-                for q in range(mm["n"]):
-                    a, ay = part[mm["ps0"] + q]
-                    assert a.shape == (di, dj)
-                    acc += a; accy += ay
-                assert mm["s0"] + mm["ns"] <= pm["nus"]
-                for a in usrc[mm["s0"]:mm["s0"] + mm["ns"]]:
+        for im in self.uitem[pm["uit0"]:pm["uit0"] + pm["nuit"]]:
+            fl = int(im["flags"])
+            di = 6 if fl & (1 << 12) else 3
+            dj = 6 if fl & (1 << 13) else 3
+            diag = bool(fl & (1 << 14))
+            u = uupd[im["u0"]:im["u0"] + im["n"]]
+            assert len(u) == im["n"]
+            for r in u:
+                assert lbase <= r["ua"] < lbase + pm["lsize"] and lbase <= r["ub"] < lbase + pm["lsize"]
+            acc, accy = self._tile_sum(u, smL, smY, lbase, y0, di, dj, diag)
+            if fl & 1:
+                assert im["s0"] + im["ns"] <= pm["nus"]
+                for a in usrc[im["s0"]:im["s0"] + im["ns"]]:
                     blk = Uval[a["uoff"]:a["uoff"] + di * dj]
                     assert not np.isnan(blk).any()
                     acc += blk.reshape(di, dj)
                     if diag and a["uyoff"] >= 0:
                         accy += Uval[a["uyoff"]:a["uyoff"] + dj]
-                assert mm["uoff"] % 2 == 0 and (not diag or mm["uyoff"] % 2 == 0)      # 16-byte stores
-                Uval[mm["uoff"]:mm["uoff"] + di * dj] = acc.ravel()
+                Uval[im["uoff"]:im["uoff"] + di * dj] = acc.ravel()
                 if diag:
-                    Uval[mm["uyoff"]:mm["uyoff"] + dj] = accy
-            seen_items = int(ur["it1"]); seen_mbs = int(ur["mb1"])
-        assert seen_items == pm["nuit"] and seen_mbs == pm["numb"]
+                    Uval[im["uyoff"]:im["uyoff"] + dj] = accy
+            else:
+                part[(fl >> 1) & 0x7FF] = (acc, accy)
+        for mm in self.umb[pm["umb0"]:pm["umb0"] + pm["numb"]]:
+            di, dj = int(mm["info"]) & 15, (int(mm["info"]) >> 4) & 15
+            diag = bool(int(mm["info"]) & B_DIAG)
+            acc = np.zeros((di, dj)); accy = np.zeros(di)
+            for q in range(mm["n"]):
+                a, ay = part[mm["ps0"] + q]
+                acc += a; accy += ay
+            for a in usrc[mm["s0"]:mm["s0"] + mm["ns"]]:
+                acc += Uval[a["uoff"]:a["uoff"] + di * dj].reshape(di, dj)
+                if diag and a["uyoff"] >= 0:
+                    accy += Uval[a["uyoff"]:a["uyoff"] + dj]
+            Uval[mm["uoff"]:mm["uoff"] + di * dj] = acc.ravel()
+            if diag:
+                Uval[mm["uyoff"]:mm["uyoff"] + dj] = accy
         Lval[lbase:lbase + pm["lsize"]] = smL
         y[y0:y0 + pm["ysize"]] = smY
         return ok
