@@ -93,13 +93,13 @@ struct SymIn {
   int64_t hll_base = 0, hpp_off_base = 0, hpl_base = 0;
 };
 struct CholOpts {
-  int cap_leaf = 3072;     // doubles of L per piece (pieces that share launches)
+  int cap_leaf = 900;      // doubles of L per piece (pieces that share launches): small pieces, many resident per CU
   int cap_tail = 4608;     // doubles of L per piece of a tail (two tail workgroups per CU must fit the LDS)
   int max_blocks = 224;    // blocks per piece
   int tail_width = -1;     // a graph's tail starts where it has <= tail_width pieces per depth; -1: 6 for batches >= 32, else 2; 0: no tail
-  int nt_leaf = 256, nt_tail = 512;   // workgroup sizes the items are cut for
+  int nt_leaf = 64, nt_tail = 512;    // workgroup sizes the items are cut for
   int min_chunk = 4;       // a list of <= min_chunk updates is never split
-  int pcap_leaf = 16, pcap_tail = 32;   // partial tiles per phase (split lists): LDS budget of a piece
+  int pcap_leaf = 4, pcap_tail = 32;   // partial tiles per phase (split lists): LDS budget of a piece
   int group_cap = 0;       // > 0: pieces of equal depth are packed into groups of <= group_cap doubles of L (and <= group_blocks blocks) that one
   int group_blocks = 1024; //      workgroup factors side by side: the per-level latencies and barriers are shared by all members
   int ustage = 0;          // 1: the per-depth kernels stage the update-matrix records in LDS too (costs residency)
@@ -129,7 +129,7 @@ struct CholHost {
   std::vector<int> tail_ptr, tail_pieces;   // per graph: its tail pieces in elimination order
   std::vector<int> plv_lds_f, plv_lds_b;    // LDS doubles per launch (factor / backward)
   int tail_lds_f = 0, tail_lds_b = 0;
-  int nt_leaf = 256, nt_tail = 512, ustage = 0;
+  int nt_leaf = 64, nt_tail = 512, ustage = 0;
   std::string error;
 };
 

@@ -54,7 +54,7 @@ struct CholView {
 struct CholPlan {
   CholView C{};
   std::vector<int> lvl_ptr, plv_ptr, plv_lds_f, plv_lds_b;
-  int tail_lds_f = 0, tail_lds_b = 0, tail_total = 0, nt_tail = 512, nt_leaf = 256, ustage = 1;
+  int tail_lds_f = 0, tail_lds_b = 0, tail_total = 0, nt_tail = 512, nt_leaf = 64, ustage = 0;
   std::vector<void*> allocs;
   int64_t lnz = 0, unz = 0;
   double* d_multi_y = nullptr;  // scratch for multi-rhs solves
@@ -862,7 +862,7 @@ int chol_plan_build(Batch& b) {
   CholOpts opt;
   opt.from_env();
   if (opt.nt_tail != 1024) opt.nt_tail = 512;
-  if (opt.nt_leaf != 64 && opt.nt_leaf != 128 && opt.nt_leaf != 512 && opt.nt_leaf != 1024) opt.nt_leaf = 256;
+  if (opt.nt_leaf != 128 && opt.nt_leaf != 256 && opt.nt_leaf != 512 && opt.nt_leaf != 1024) opt.nt_leaf = 64;
   CholHost H;
   if (chol_symbolic(in, opt, H)) return set_error(SSLAM_ERR_NUMERIC, "Cholesky plan: %s", H.error.c_str());
   CholPlan* P = new CholPlan();
@@ -944,11 +944,11 @@ int chol_factor_and_forward(Batch& b) {
   if (P.ustage) hipLaunchKernelGGL((k_chol_pieces<NTV, true>), dim3(n), dim3(NTV), lds, b.stream, b.V, C, P.plv_ptr[l]);            \
   else hipLaunchKernelGGL((k_chol_pieces<NTV, false>), dim3(n), dim3(NTV), lds, b.stream, b.V, C, P.plv_ptr[l]);
     switch (P.nt_leaf) {
-      case 64: SSLAM_LAUNCH_PIECES(64) break;
       case 128: SSLAM_LAUNCH_PIECES(128) break;
       case 512: SSLAM_LAUNCH_PIECES(512) break;
       case 1024: SSLAM_LAUNCH_PIECES(1024) break;
-      default: SSLAM_LAUNCH_PIECES(256) break;
+      case 256: SSLAM_LAUNCH_PIECES(256) break;
+      default: SSLAM_LAUNCH_PIECES(64) break;
     }
 #undef SSLAM_LAUNCH_PIECES
   }
@@ -974,11 +974,11 @@ int chol_backward(Batch& b) {
     const size_t lds = (size_t)P.plv_lds_b[l] * sizeof(double);
 #define SSLAM_LAUNCH_BACK(NTV) hipLaunchKernelGGL(k_chol_back_pieces<NTV>, dim3(n), dim3(NTV), lds, b.stream, C, P.plv_ptr[l], (const double*)C.y, b.V.x, (const LmState*)b.V.lm);
     switch (P.nt_leaf) {
-      case 64: SSLAM_LAUNCH_BACK(64) break;
       case 128: SSLAM_LAUNCH_BACK(128) break;
       case 512: SSLAM_LAUNCH_BACK(512) break;
       case 1024: SSLAM_LAUNCH_BACK(1024) break;
-      default: SSLAM_LAUNCH_BACK(256) break;
+      case 256: SSLAM_LAUNCH_BACK(256) break;
+      default: SSLAM_LAUNCH_BACK(64) break;
     }
 #undef SSLAM_LAUNCH_BACK
   }

@@ -1811,7 +1811,7 @@ void* sslam_debug_plan_create(sslam_graph* const* graphs, int n) {
   CholOpts opt;
   opt.from_env();
   if (opt.nt_tail != 1024) opt.nt_tail = 512;
-  if (opt.nt_leaf != 64 && opt.nt_leaf != 128 && opt.nt_leaf != 512 && opt.nt_leaf != 1024) opt.nt_leaf = 256;
+  if (opt.nt_leaf != 128 && opt.nt_leaf != 256 && opt.nt_leaf != 512 && opt.nt_leaf != 1024) opt.nt_leaf = 64;
   sslam_debug_plan* P = new sslam_debug_plan();
   P->h_total = b.V.h_total;
   for (auto& q : b.ppoff) { P->ppoff.push_back(q.first); P->ppoff.push_back(q.second); }
