@@ -120,7 +120,7 @@ def test_plan_small_graph_matches_dense_cholesky(hip_lib, interleave):
 def test_plan_with_tiny_pieces_exercises_every_phase(hip_lib):
     """Caps far below the defaults force many pieces, external phases, split lists (partial tiles) and a multi-piece tail."""
     g = make_graph(150, 30, seed=5)
-    env = {"SSLAM_CHOL_CAP_LEAF": 400, "SSLAM_CHOL_CAP_TAIL": 700, "SSLAM_CHOL_TAIL_WIDTH": 2, "SSLAM_CHOL_MIN_CHUNK": 1, "SSLAM_CHOL_PCAP_LEAF": 16}
+    env = {"SSLAM_CHOL_CAP_LEAF": 400, "SSLAM_CHOL_CAP_TAIL": 700, "SSLAM_CHOL_TAIL_WIDTH": 2, "SSLAM_CHOL_MIN_CHUNK": 1, "SSLAM_CHOL_PCAP_LEAF": 16, "SSLAM_CHOL_NT_LEAF": 256}
     plan, H, b = _plan_and_system(hip_lib, g, False, env)
     assert plan.npiece > 20 and len(plan.tail_pieces) >= 2 and len(plan.plv_ptr) > 2
     assert len(plan.mb) > 0 and len(plan.umb) > 0 and np.any(plan.piece["nas"] > 0) and np.any(plan.piece["nus"] > 0)

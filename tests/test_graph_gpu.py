@@ -125,7 +125,7 @@ def test_cholesky_solve_matches_oracle_cholesky(gpu_lib, lam):
 
 
 @pytest.mark.parametrize("env", [
-    {"SSLAM_CHOL_CAP_LEAF": "400", "SSLAM_CHOL_CAP_TAIL": "700", "SSLAM_CHOL_TAIL_WIDTH": "2", "SSLAM_CHOL_MIN_CHUNK": "1", "SSLAM_CHOL_PCAP_LEAF": "16"},   # many pieces, split lists, a multi-piece tail
+    {"SSLAM_CHOL_CAP_LEAF": "400", "SSLAM_CHOL_CAP_TAIL": "700", "SSLAM_CHOL_TAIL_WIDTH": "2", "SSLAM_CHOL_MIN_CHUNK": "1", "SSLAM_CHOL_PCAP_LEAF": "16", "SSLAM_CHOL_NT_LEAF": "256"},   # many pieces, split lists, a multi-piece tail
     {"SSLAM_CHOL_CAP_LEAF": "400", "SSLAM_CHOL_CAP_TAIL": "700", "SSLAM_CHOL_TAIL_WIDTH": "0"},     # no tail: one launch per depth
     {"SSLAM_CHOL_CAP_LEAF": "900", "SSLAM_CHOL_CAP_TAIL": "2000", "SSLAM_CHOL_NT_TAIL": "1024"},    # 1024-thread tail workgroups
     {"SSLAM_CHOL_CAP_LEAF": "400", "SSLAM_CHOL_GROUP_CAP": "1500", "SSLAM_CHOL_NT_LEAF": "512", "SSLAM_CHOL_USTAGE": "0"},   # groups of subtrees per workgroup
