@@ -7,6 +7,8 @@
 //   node->hessianIndex()        (semantic_graph_slam.cpp:188-190)
 //   node->unlockQuadraticForm() (semantic_graph_slam.cpp:187)     -- no-op here
 //   node->id()
+// Like g2o, the GraphSLAM object owns its vertices: add_*_node return raw pointers that stay valid for the life of the graph,
+// so `keyframe->node` / `landmark.node` (keyframe.hpp:47, landmark.h:31) keep their pointer types.
 // Eigen is not required: poses are sslam::Isometry (3x4 row-major R|t), points std::array<double,3>;
 // when the including translation unit has Eigen available define SSLAM_WITH_EIGEN before including
 // this header to get overloads taking Eigen::Isometry3d / Eigen::Vector3d / Eigen::MatrixXd exactly as
@@ -18,6 +20,7 @@
 #include <chrono>
 #include <cmath>
 #include <iostream>
+#include <map>
 #include <memory>
 #include <stdexcept>
 #include <string>
@@ -64,6 +67,8 @@ class VertexHandle {
   int id() const { return id_; }
   int hessianIndex() const { return sslam_graph_hessian_index(g_, id_); }
   void unlockQuadraticForm() const {}
+  virtual int dimension() const { return 3; }
+  virtual ~VertexHandle() {}
  protected:
   sslam_graph* g_;
   int id_;
@@ -71,6 +76,7 @@ class VertexHandle {
 class VertexSE3 : public VertexHandle {
  public:
   using VertexHandle::VertexHandle;
+  int dimension() const override { return 6; }
   Isometry estimate() const { double tq[7]; sslam_graph_get_vertex(g_, id_, tq); return tq_to_isometry(tq); }
   void setEstimate(const Isometry& T) { double tq[7]; isometry_to_tq(T, tq); sslam_graph_set_vertex(g_, id_, tq); }
 };
@@ -86,6 +92,28 @@ class VertexPlane : public VertexHandle {
 };
 struct EdgeHandle { int id; };
 
+// What the caller reads out of g2o::SparseBlockMatrix<Eigen::MatrixXd> after computeMarginals
+// (semantic_graph_slam.cpp:196-203: `spinv.block(r, c)->eval().cast<float>()`): blocks of H^-1 addressed by hessian indices.
+struct MarginalBlock {
+  int rows = 0, cols = 0;
+  std::vector<double> v;   // row-major rows x cols
+  double operator()(int r, int c) const { return v[(size_t)r * cols + c]; }
+#ifdef SSLAM_WITH_EIGEN
+  Eigen::MatrixXd eval() const { Eigen::MatrixXd M(rows, cols); for (int r = 0; r < rows; ++r) for (int c = 0; c < cols; ++c) M(r, c) = (*this)(r, c); return M; }
+#else
+  const MarginalBlock& eval() const { return *this; }
+#endif
+};
+class SparseBlockMatrix {
+ public:
+  const MarginalBlock* block(int r, int c) const { auto it = blocks_.find({r, c}); return it == blocks_.end() ? nullptr : &it->second; }
+  MarginalBlock* block(int r, int c, bool alloc) { if (alloc) return &blocks_[{r, c}]; auto it = blocks_.find({r, c}); return it == blocks_.end() ? nullptr : &it->second; }
+  void clear() { blocks_.clear(); }
+  size_t size() const { return blocks_.size(); }
+ private:
+  std::map<std::pair<int, int>, MarginalBlock> blocks_;
+};
+
 }  // namespace sslam
 
 namespace ps_graph_slam {
@@ -99,18 +127,18 @@ class GraphSLAM {
   }
 
   /** add_se3_node (graph_slam.cpp:104-115): the first vertex of the graph is fixed */
-  std::shared_ptr<sslam::VertexSE3> add_se3_node(const sslam::Isometry& pose) {
+  sslam::VertexSE3* add_se3_node(const sslam::Isometry& pose) {
     double tq[7]; sslam::isometry_to_tq(pose, tq);
     const int id = check(sslam_graph_add_vertex_se3(graph.get(), tq, -1));
-    return std::make_shared<sslam::VertexSE3>(graph.get(), id);
+    return own(new sslam::VertexSE3(graph.get(), id));
   }
   /** add_plane_node (graph_slam.cpp:117-125, commented out upstream) */
-  std::shared_ptr<sslam::VertexPlane> add_plane_node(const std::array<double, 4>& plane_coeffs) {
-    return std::make_shared<sslam::VertexPlane>(graph.get(), check(sslam_graph_add_vertex_plane(graph.get(), plane_coeffs.data())));
+  sslam::VertexPlane* add_plane_node(const std::array<double, 4>& plane_coeffs) {
+    return own(new sslam::VertexPlane(graph.get(), check(sslam_graph_add_vertex_plane(graph.get(), plane_coeffs.data()))));
   }
   /** add_point_xyz_node (graph_slam.cpp:127-134) */
-  std::shared_ptr<sslam::VertexPointXYZ> add_point_xyz_node(const std::array<double, 3>& xyz) {
-    return std::make_shared<sslam::VertexPointXYZ>(graph.get(), check(sslam_graph_add_vertex_point(graph.get(), xyz.data())));
+  sslam::VertexPointXYZ* add_point_xyz_node(const std::array<double, 3>& xyz) {
+    return own(new sslam::VertexPointXYZ(graph.get(), check(sslam_graph_add_vertex_point(graph.get(), xyz.data()))));
   }
   /** add_se3_edge (graph_slam.cpp:136-148); information_matrix: 36 doubles row-major 6x6 */
   sslam::EdgeHandle add_se3_edge(const sslam::VertexSE3* v1, const sslam::VertexSE3* v2, const sslam::Isometry& relative_pose,
@@ -143,8 +171,29 @@ class GraphSLAM {
     return true;
   }
 
-  /** computeLandmarkMarginals (graph_slam.cpp:221-234): spinv[k] = 3x3 (row-major) block of H^-1 for
-   *  vert_pairs_vec[k] = (hessianIndex, hessianIndex) of a landmark, as semantic_graph_slam.cpp:186-191 asks */
+  /** computeLandmarkMarginals (graph_slam.cpp:221-234), the reference's own signature: vert_pairs_vec holds (hessianIndex,
+   *  hessianIndex) pairs as built at semantic_graph_slam.cpp:186-191; afterwards spinv.block(r, c) is that block of H^-1. */
+  bool computeLandmarkMarginals(sslam::SparseBlockMatrix& spinv, std::vector<std::pair<int, int>> vert_pairs_vec) {
+    std::vector<int> rc2;
+    for (auto& pr : vert_pairs_vec) { rc2.push_back(pr.first); rc2.push_back(pr.second); }
+    std::vector<double> out(vert_pairs_vec.size() * 36);
+    const int rc = sslam_graph_marginals_by_hessian_index(graph.get(), rc2.data(), (int)vert_pairs_vec.size(), out.data());
+    if (rc < 0) { if (verbose_) std::cout << "not computing marginals " << std::endl; return false; }
+    std::map<int, int> dim_of;   // hessian index -> vertex dimension
+    for (auto& v : vertices_) { const int hi = v->hessianIndex(); if (hi >= 0) dim_of[hi] = v->dimension(); }
+    spinv.clear();
+    size_t o = 0;
+    for (auto& pr : vert_pairs_vec) {
+      const int dr = dim_of[pr.first], dc = dim_of[pr.second];
+      sslam::MarginalBlock* bl = spinv.block(pr.first, pr.second, true);
+      bl->rows = dr; bl->cols = dc;
+      bl->v.assign(out.begin() + o, out.begin() + o + (size_t)dr * dc);
+      o += (size_t)dr * dc;
+    }
+    if (verbose_) std::cout << "computed marginals " << std::endl;
+    return true;
+  }
+  /** convenience form: 3x3 blocks for a list of landmark vertex ids */
   bool computeLandmarkMarginals(std::vector<std::array<double, 9>>& spinv, const std::vector<int>& landmark_vertex_ids) {
     std::vector<double> out(landmark_vertex_ids.size() * 9);
     const int rc = sslam_graph_marginals(graph.get(), landmark_vertex_ids.data(), (int)landmark_vertex_ids.size(), out.data());
@@ -155,8 +204,12 @@ class GraphSLAM {
     return true;
   }
 
-  /** save the pose graph (graph_slam.cpp:236-239), g2o text format */
-  void save(const std::string& filename) { sslam_graph_save_g2o(graph.get(), filename.c_str()); }
+  /** save the pose graph (graph_slam.cpp:236-239), g2o text format; like g2o's save() the failure is reported, not thrown */
+  bool save(const std::string& filename) {
+    const int rc = sslam_graph_save_g2o(graph.get(), filename.c_str());
+    if (rc < 0) std::cerr << "error : failed to save the graph: " << sslam_last_error() << std::endl;
+    return rc >= 0;
+  }
 
 #ifdef SSLAM_WITH_EIGEN
   static sslam::Isometry from_eigen(const Eigen::Isometry3d& T) {
@@ -164,8 +217,8 @@ class GraphSLAM {
     for (int r = 0; r < 3; ++r) { for (int c = 0; c < 3; ++c) I.R[r * 3 + c] = T.linear()(r, c); I.t[r] = T.translation()(r); }
     return I;
   }
-  std::shared_ptr<sslam::VertexSE3> add_se3_node(const Eigen::Isometry3d& pose) { return add_se3_node(from_eigen(pose)); }
-  std::shared_ptr<sslam::VertexPointXYZ> add_point_xyz_node(const Eigen::Vector3d& xyz) { return add_point_xyz_node(std::array<double, 3>{xyz[0], xyz[1], xyz[2]}); }
+  sslam::VertexSE3* add_se3_node(const Eigen::Isometry3d& pose) { return add_se3_node(from_eigen(pose)); }
+  sslam::VertexPointXYZ* add_point_xyz_node(const Eigen::Vector3d& xyz) { return add_point_xyz_node(std::array<double, 3>{xyz[0], xyz[1], xyz[2]}); }
   sslam::EdgeHandle add_se3_edge(const sslam::VertexSE3* v1, const sslam::VertexSE3* v2, const Eigen::Isometry3d& rel, const Eigen::MatrixXd& info) {
     double W[36]; for (int r = 0; r < 6; ++r) for (int c = 0; c < 6; ++c) W[r * 6 + c] = info(r, c);
     return add_se3_edge(v1, v2, from_eigen(rel), W);
@@ -182,6 +235,8 @@ class GraphSLAM {
   sslam_opt_stats last_stats{};
 
  private:
+  template <typename T> T* own(T* v) { vertices_.emplace_back(v); return v; }
+  std::vector<std::unique_ptr<sslam::VertexHandle>> vertices_;   // the graph owns its vertices, as g2o's optimizer does
   static int check(int rc) {
     if (rc < 0) throw std::runtime_error(std::string("sslam: ") + sslam_last_error());
     return rc;

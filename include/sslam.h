@@ -90,8 +90,8 @@ int sslam_graph_set_vertex(sslam_graph* g, int id, const double* in);
  * scalar offset in g2o's ordering (non-fixed vertices with edges, by id), or -1. */
 int sslam_graph_hessian_index(sslam_graph* g, int id);
 
-/* Options (doubles): "solver" 0 = PCG (block-Jacobi, matrix-free Schur optional), 1 = sparse block
- * Cholesky; "pcg_tol" relative residual; "pcg_max_iters"; "schur" 0/1; "deterministic" 0/1 */
+/* Options (doubles): "solver" 1 = sparse block Cholesky (default; what "lm_var" + csparse selects in the reference),
+ * 0 = block-Jacobi PCG; "pcg_tol" relative residual; "pcg_max_iters" */
 int sslam_graph_set_option(sslam_graph* g, const char* key, double value);
 
 /* GraphSLAM::optimize (graph_slam.cpp:182-219) with the iteration cap as a parameter (the
@@ -106,6 +106,10 @@ int sslam_graph_chi2(sslam_graph* g, double* chi2);
  * linearisation for the listed vertex ids (the caller asks for (idx,idx) pairs only,
  * semantic_graph_slam.cpp:186-191); out = packed row-major d x d blocks. */
 int sslam_graph_marginals(sslam_graph* g, const int* ids, int n, double* out_blocks);
+/* the same with the reference's own argument: n (row, col) pairs of vertex hessianIndex() values, as built at
+ * semantic_graph_slam.cpp:186-191 and handed to g2o::SparseOptimizer::computeMarginals (graph_slam.cpp:225); row_col = 2n ints.
+ * Off-diagonal pairs are allowed; out = packed row-major d(row) x d(col) blocks of H^-1. */
+int sslam_graph_marginals_by_hessian_index(sslam_graph* g, const int* row_col, int n, double* out_blocks);
 
 /* GraphSLAM::save (graph_slam.cpp:236-239): g2o text format */
 int sslam_graph_save_g2o(const sslam_graph* g, const char* path);

@@ -68,6 +68,7 @@ def load_library():
         "sslam_graph_optimize": (ci, [vp, ci, C.POINTER(OptStats)]),
         "sslam_graph_chi2": (ci, [vp, dp]),
         "sslam_graph_marginals": (ci, [vp, C.POINTER(ci), ci, dp]),
+        "sslam_graph_marginals_by_hessian_index": (ci, [vp, C.POINTER(ci), ci, dp]),
         "sslam_graph_save_g2o": (ci, [vp, C.c_char_p]),
         "sslam_graph_load_g2o": (ci, [vp, C.c_char_p]),
         "sslam_graph_linearize": (ci, [vp, C.POINTER(ci), C.POINTER(i64), vp, vp, vp, vp]),

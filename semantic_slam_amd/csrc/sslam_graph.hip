@@ -1549,15 +1549,28 @@ int sslam_graph_oplus(sslam_graph* h, const double* dx) {
   return batch_download_estimates(b);
 }
 
-int sslam_graph_marginals(sslam_graph* h, const int* ids, int n, double* out) {
-  if (!h || !ids || !out || n < 0) return set_error(SSLAM_ERR_INVALID, "null argument");
+// Blocks (row vertex vr, column vertex vc) of H^-1 at the current linearisation: the columns of H^-1 that belong to the
+// requested column vertices are computed (Cholesky: one multi right-hand-side solve; PCG: one solve per column) and the
+// requested row blocks are read out of them.  out: packed row-major d(vr) x d(vc) blocks, zeros for fixed / edge-less vertices.
+static int marginal_blocks(sslam_graph* h, const std::vector<std::pair<int, int>>& pairs, double* out) {
   int rc;
   if ((rc = do_linearize(h))) return rc;  // undamped H at the current estimates
   Batch& b = *h->batch;
   std::vector<int> hidx;
   const int dim = hessian_indices(h->g, hidx);
-  std::vector<double> rhs_g2o(dim, 0.0), rhs_int, xi((size_t)6 * b.V.nPr + (size_t)3 * b.V.nLr), xg(dim);
-  size_t o = 0;
+  for (auto& pr : pairs)
+    if (pr.first < 0 || pr.first >= h->g.nv() || pr.second < 0 || pr.second >= h->g.nv()) return set_error(SSLAM_ERR_INVALID, "bad vertex id (%d, %d)", pr.first, pr.second);
+  // unique column vertices, their scalar columns
+  std::vector<int> colv;
+  for (auto& pr : pairs) if (hidx[pr.second] >= 0 && hidx[pr.first] >= 0) colv.push_back(pr.second);
+  std::sort(colv.begin(), colv.end());
+  colv.erase(std::unique(colv.begin(), colv.end()), colv.end());
+  std::vector<int> col0(h->g.nv(), -1);   // first scalar column of a column vertex in X
+  int nrhs = 0;
+  for (int v : colv) { col0[v] = nrhs; nrhs += vertex_dim(h->g.vtype[v]); }
+  const size_t idim = (size_t)6 * b.V.nPr + (size_t)3 * b.V.nLr;
+  std::vector<double> X((size_t)nrhs * dim);   // [scalar column][g2o order]
+  std::vector<double> rhs_g2o(dim, 0.0), rhs_int, xi(idim);
   if (h->g.opt.solver != 0) {
     // factor the undamped H once, then solve all unit right-hand sides together
     hipLaunchKernelGGL(k_set_trial_all, dim3((b.V.B + 63) / 64), dim3(64), 0, b.stream, b.V, 0.0);
@@ -1567,59 +1580,67 @@ int sslam_graph_marginals(sslam_graph* h, const int* ids, int n, double* out) {
     SSLAM_HIP_TRY(hipMemcpyAsync(&fail, b.V.pcg_fail, sizeof fail, hipMemcpyDeviceToHost, b.stream));
     SSLAM_HIP_TRY(hipStreamSynchronize(b.stream));
     if (fail) return set_error(SSLAM_ERR_NUMERIC, "H is not positive definite: no marginals");
-    const size_t idim = xi.size();
-    std::vector<int> col_v, col_c;
-    for (int k = 0; k < n; ++k) {
-      const int v = ids[k];
-      if (v < 0 || v >= h->g.nv()) return set_error(SSLAM_ERR_INVALID, "bad vertex id %d", v);
-      if (hidx[v] < 0) continue;
-      for (int c = 0; c < vertex_dim(h->g.vtype[v]); ++c) { col_v.push_back(v); col_c.push_back(c); }
-    }
-    const int nrhs = (int)col_v.size();
-    std::vector<double> R((size_t)nrhs * idim, 0.0), X((size_t)nrhs * idim);
-    for (int q = 0; q < nrhs; ++q) {
-      rhs_g2o[hidx[col_v[q]] + col_c[q]] = 1.0;
-      from_g2o_order(h, rhs_g2o.data(), rhs_int);
-      rhs_g2o[hidx[col_v[q]] + col_c[q]] = 0.0;
-      std::copy(rhs_int.begin(), rhs_int.end(), R.begin() + (size_t)q * idim);
-    }
-    if ((rc = chol_solve_multi(b, R.data(), nrhs, X.data()))) return rc;
-    int q = 0;
-    for (int k = 0; k < n; ++k) {
-      const int v = ids[k];
-      const int d = vertex_dim(h->g.vtype[v]);
-      if (hidx[v] < 0) { for (int e = 0; e < d * d; ++e) out[o++] = 0; continue; }
-      for (int c = 0; c < d; ++c, ++q) {
-        std::copy(X.begin() + (size_t)q * idim, X.begin() + (size_t)(q + 1) * idim, xi.begin());
-        to_g2o_order(h, xi, xg.data());
-        for (int r = 0; r < d; ++r) out[o + r * d + c] = xg[hidx[v] + r];
+    std::vector<double> R((size_t)nrhs * idim, 0.0), Xi((size_t)nrhs * idim);
+    for (int v : colv)
+      for (int c = 0; c < vertex_dim(h->g.vtype[v]); ++c) {
+        rhs_g2o[hidx[v] + c] = 1.0;
+        from_g2o_order(h, rhs_g2o.data(), rhs_int);
+        rhs_g2o[hidx[v] + c] = 0.0;
+        std::copy(rhs_int.begin(), rhs_int.end(), R.begin() + (size_t)(col0[v] + c) * idim);
       }
-      o += (size_t)d * d;
+    if ((rc = chol_solve_multi(b, R.data(), nrhs, Xi.data()))) return rc;
+    for (int q = 0; q < nrhs; ++q) {
+      std::copy(Xi.begin() + (size_t)q * idim, Xi.begin() + (size_t)(q + 1) * idim, xi.begin());
+      to_g2o_order(h, xi, X.data() + (size_t)q * dim);
     }
-    return 0;
+  } else {
+    for (int v : colv)
+      for (int c = 0; c < vertex_dim(h->g.vtype[v]); ++c) {
+        rhs_g2o[hidx[v] + c] = 1.0;
+        from_g2o_order(h, rhs_g2o.data(), rhs_int);
+        rhs_g2o[hidx[v] + c] = 0.0;
+        SSLAM_HIP_TRY(hipMemcpyAsync(b.V.bvec, rhs_int.data(), rhs_int.size() * 8, hipMemcpyHostToDevice, b.stream));
+        hipLaunchKernelGGL(k_set_trial_all, dim3((b.V.B + 63) / 64), dim3(64), 0, b.stream, b.V, 0.0);
+        if ((rc = batch_solve(b))) return rc;
+        SSLAM_HIP_TRY(hipMemcpyAsync(xi.data(), b.V.x, xi.size() * 8, hipMemcpyDeviceToHost, b.stream));
+        SSLAM_HIP_TRY(hipStreamSynchronize(b.stream));
+        to_g2o_order(h, xi, X.data() + (size_t)(col0[v] + c) * dim);
+      }
+    h->linearized = false;  // b was overwritten
   }
-  for (int k = 0; k < n; ++k) {
-    const int v = ids[k];
-    if (v < 0 || v >= h->g.nv()) return set_error(SSLAM_ERR_INVALID, "bad vertex id %d", v);
-    const int d = vertex_dim(h->g.vtype[v]);
-    const int hi = hidx[v];
-    if (hi < 0) { for (int e = 0; e < d * d; ++e) out[o++] = 0; continue; }
-    for (int c = 0; c < d; ++c) {
-      rhs_g2o[hi + c] = 1.0;
-      from_g2o_order(h, rhs_g2o.data(), rhs_int);
-      rhs_g2o[hi + c] = 0.0;
-      SSLAM_HIP_TRY(hipMemcpyAsync(b.V.bvec, rhs_int.data(), rhs_int.size() * 8, hipMemcpyHostToDevice, b.stream));
-      hipLaunchKernelGGL(k_set_trial_all, dim3((b.V.B + 63) / 64), dim3(64), 0, b.stream, b.V, 0.0);
-      if ((rc = batch_solve(b))) return rc;
-      SSLAM_HIP_TRY(hipMemcpyAsync(xi.data(), b.V.x, xi.size() * 8, hipMemcpyDeviceToHost, b.stream));
-      SSLAM_HIP_TRY(hipStreamSynchronize(b.stream));
-      to_g2o_order(h, xi, xg.data());
-      for (int r = 0; r < d; ++r) out[o + r * d + c] = xg[hi + r];
-    }
-    o += (size_t)d * d;
+  size_t o = 0;
+  for (auto& pr : pairs) {
+    const int vr = pr.first, vc = pr.second;
+    const int dr = vertex_dim(h->g.vtype[vr]), dc = vertex_dim(h->g.vtype[vc]);
+    for (int r = 0; r < dr; ++r)
+      for (int c = 0; c < dc; ++c)
+        out[o + r * dc + c] = (hidx[vr] < 0 || hidx[vc] < 0) ? 0.0 : X[(size_t)(col0[vc] + c) * dim + hidx[vr] + r];
+    o += (size_t)dr * dc;
   }
-  h->linearized = false;  // b was overwritten
   return 0;
+}
+
+int sslam_graph_marginals(sslam_graph* h, const int* ids, int n, double* out) {
+  if (!h || !ids || !out || n < 0) return set_error(SSLAM_ERR_INVALID, "null argument");
+  std::vector<std::pair<int, int>> pairs(n);
+  for (int k = 0; k < n; ++k) pairs[k] = {ids[k], ids[k]};
+  return marginal_blocks(h, pairs, out);
+}
+
+int sslam_graph_marginals_by_hessian_index(sslam_graph* h, const int* row_col, int n, double* out) {
+  if (!h || !row_col || !out || n < 0) return set_error(SSLAM_ERR_INVALID, "null argument");
+  std::vector<int> hidx;
+  hessian_indices(h->g, hidx);
+  std::unordered_map<int, int> vert_of;   // hessian index -> vertex id
+  for (int v = 0; v < h->g.nv(); ++v) if (hidx[v] >= 0) vert_of[hidx[v]] = v;
+  std::vector<std::pair<int, int>> pairs(n);
+  for (int k = 0; k < n; ++k) {
+    auto ir = vert_of.find(row_col[2 * k]), ic = vert_of.find(row_col[2 * k + 1]);
+    if (ir == vert_of.end() || ic == vert_of.end())
+      return set_error(SSLAM_ERR_INVALID, "(%d, %d) is not a pair of hessian indices of active vertices", row_col[2 * k], row_col[2 * k + 1]);
+    pairs[k] = {ir->second, ic->second};
+  }
+  return marginal_blocks(h, pairs, out);
 }
 
 // ---- g2o text format (GraphSLAM::save, graph_slam.cpp:236-239; SURVEY §5 checkpoint row) ------

@@ -147,6 +147,24 @@ class GraphSLAM:
             o += d * d
         return blocks
 
+    def computeMarginals(self, vert_pairs_vec):
+        """graph_slam.cpp:221-234 with the reference's own argument: (row, col) pairs of ``hessian_index`` values
+        (semantic_graph_slam.cpp:186-191).  Returns {(row, col): block of H^-1}."""
+        pairs = np.ascontiguousarray(vert_pairs_vec, np.int32).reshape(-1, 2)
+        dim_of = {}
+        for v in range(self.num_vertices()):
+            h = self.hessian_index(v)
+            if h >= 0:
+                dim_of[h] = 6 if len(self.estimate(v)) == 7 else 3
+        dims = [(dim_of[int(r)], dim_of[int(c)]) for r, c in pairs]
+        out = np.zeros(int(sum(a * b for a, b in dims)))
+        _check(self._lib, self._lib.sslam_graph_marginals_by_hessian_index(self._h, pairs.ctypes.data_as(C.POINTER(C.c_int)), len(pairs), _dptr(out)))
+        res, o = {}, 0
+        for (r, c), (a, b) in zip(pairs, dims):
+            res[(int(r), int(c))] = out[o:o + a * b].reshape(a, b).copy()
+            o += a * b
+        return res
+
     def save(self, filename: str) -> None:
         """graph_slam.cpp:236-239 (g2o text format)"""
         _check(self._lib, self._lib.sslam_graph_save_g2o(self._h, filename.encode()))

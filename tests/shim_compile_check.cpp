@@ -1,24 +1,66 @@
-// Compile-and-link check of the two C++ shims (and, on a GPU box, a tiny end-to-end run).
-#include <cstdio>
+// Compile-and-link check of the two C++ shims and, on a GPU box, an end-to-end run of both through the reference's own
+// method names (GraphSLAM::optimize / computeLandmarkMarginals, point_cloud_segmentation::segmentallPointCloudData).
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
 #include "../include/ps_graph_slam_amd/graph_slam.hpp"
 #include "../include/planar_segmentation_amd/point_cloud_segmentation.hpp"
 
-int main() {
+int main(int argc, char** argv) {
   ps_graph_slam::GraphSLAM slam(false);
-  std::vector<std::shared_ptr<sslam::VertexSE3>> nodes;
+  std::vector<sslam::VertexSE3*> nodes;                 // raw pointers owned by the graph, like g2o::VertexSE3*
   double W[36] = {0};
   for (int k = 0; k < 6; ++k) W[k * 7] = k < 3 ? 150.0 : 1e5;
   for (int i = 0; i < 12; ++i) {
     sslam::Isometry T = sslam::Isometry::Identity();
     T.t[0] = 0.5 * i + 0.01 * std::sin(3.0 * i);
     nodes.push_back(slam.add_se3_node(T));
-    if (i > 0) { sslam::Isometry rel = sslam::Isometry::Identity(); rel.t[0] = 0.5; slam.add_se3_edge(nodes[i - 1].get(), nodes[i].get(), rel, W); }
+    if (i > 0) { sslam::Isometry rel = sslam::Isometry::Identity(); rel.t[0] = 0.5; slam.add_se3_edge(nodes[i - 1], nodes[i], rel, W); }
   }
+  // two landmarks seen from three poses each (semantic_graph_slam.cpp:160-174)
+  double Wl[9] = {2.5, 0, 0, 0, 2.5, 0, 0, 0, 2.5};
+  sslam::VertexPointXYZ* lm[2] = {slam.add_point_xyz_node({1.0, 1.0, 0.5}), slam.add_point_xyz_node({4.0, -1.0, 0.2})};
+  for (int l = 0; l < 2; ++l)
+    for (int i = 3 * l + 1; i < 3 * l + 4; ++i) {
+      const std::array<double, 3> z = {(l ? 4.0 : 1.0) - 0.5 * i, l ? -1.0 : 1.0, l ? 0.2 : 0.5};
+      slam.add_se3_point_xyz_edge(nodes[i], lm[l], z, Wl);
+    }
   if (nodes[0]->hessianIndex() != -1 || nodes[1]->hessianIndex() != 0) { std::printf("hessian index wrong\n"); return 2; }
   if (sslam_device_count() < 1) { std::printf("shim ok (no GPU: compile/link/host-logic only)\n"); return 0; }
   if (!slam.optimize()) { std::printf("optimize returned false\n"); return 3; }
   const double x11 = nodes[11]->estimate().t[0];
-  std::printf("shim ok: chi2 %.3e -> %.3e, x[11] = %.6f\n", slam.last_stats.chi2_before, slam.last_stats.chi2_after, x11);
-  return std::fabs(x11 - 5.5) < 1e-6 ? 0 : 4;
+  // getAndSetLandmarkCov, semantic_graph_slam.cpp:181-205
+  sslam::SparseBlockMatrix spinv;
+  std::vector<std::pair<int, int>> pairs;
+  for (auto* l : lm) { l->unlockQuadraticForm(); pairs.push_back(std::make_pair(l->hessianIndex(), l->hessianIndex())); }
+  if (!slam.computeLandmarkMarginals(spinv, pairs)) { std::printf("marginals failed\n"); return 5; }
+  const sslam::MarginalBlock* c0 = spinv.block(lm[0]->hessianIndex(), lm[0]->hessianIndex());
+  if (!c0 || c0->rows != 3 || !(c0->eval()(0, 0) > 0) || std::fabs(c0->eval()(0, 1) - c0->eval()(1, 0)) > 1e-9) { std::printf("marginal block wrong\n"); return 6; }
+  if (slam.save("/nonexistent-dir/graph.g2o")) { std::printf("save() to a bad path reported success\n"); return 7; }
+  std::printf("shim ok: chi2 %.3e -> %.3e, x[11] = %.6f, cov(l0)[0][0] = %.4e\n", slam.last_stats.chi2_before, slam.last_stats.chi2_after, x11, c0->eval()(0, 0));
+  if (std::fabs(x11 - 5.5) > 1e-3) return 4;
+
+  // frontend: the frame the caller wrote (tests/test_graph_gpu.py: a synthetic 640 x 480 cloud + boxes, little-endian:
+  // int32 width, height, point_step, n_boxes; n_boxes x {int32 tl_x, tl_y, w, h}; float32 robot_pose[6], cam_angle; cloud bytes)
+  if (argc < 3) { std::printf("frontend shim skipped (no frame file)\n"); return 0; }
+  FILE* f = std::fopen(argv[1], "rb");
+  if (!f) { std::printf("cannot open %s\n", argv[1]); return 8; }
+  int32_t hdr[4];
+  if (std::fread(hdr, 4, 4, f) != 4) return 8;
+  const int w = hdr[0], h = hdr[1], step = hdr[2], nb = hdr[3];
+  std::vector<ObjectInfo> info;
+  for (int k = 0; k < nb; ++k) { int32_t b[4]; if (std::fread(b, 4, 4, f) != 4) return 8; info.push_back(ObjectInfo{"chair", 0.9f, b[0], b[1], b[2], b[3]}); }
+  float pose7[7];
+  if (std::fread(pose7, 4, 7, f) != 7) return 8;
+  std::vector<uint8_t> cloud((size_t)w * h * step);
+  if (std::fread(cloud.data(), 1, cloud.size(), f) != cloud.size()) return 8;
+  std::fclose(f);
+  point_cloud_segmentation seg(false);
+  PointCloud2View view{cloud.data(), w, h, step, step * w, 0, 4, 8};
+  std::vector<detected_object> objs = seg.segmentallPointCloudData({pose7[0], pose7[1], pose7[2], pose7[3], pose7[4], pose7[5]}, pose7[6], info, view);
+  double cs = 0;   // checksum the caller recomputes from the Python mirror's planes
+  for (auto& o : objs) cs += (double)o.normal_orientation[0] + 2.0 * o.normal_orientation[1] + 3.0 * o.normal_orientation[2] + 0.5 * o.normal_orientation[3] + o.num_points;
+  std::printf("frontend shim ok: %zu planes checksum %.9e\n", objs.size(), cs);
+  return (int)objs.size() == std::atoi(argv[2]) ? 0 : 9;
 }

@@ -350,16 +350,57 @@ def test_golden_graph_through_g2o_loader(gpu_lib, kind):
 
 
 def test_cpp_shim_end_to_end(gpu_lib, tmp_path):
-    """The reference-named C++ class (include/ps_graph_slam_amd/graph_slam.hpp) drives the GPU path."""
-    import os, subprocess
+    """The reference-named C++ classes (include/ps_graph_slam_amd/graph_slam.hpp, include/planar_segmentation_amd/
+    point_cloud_segmentation.hpp) drive the GPU path: optimise + computeLandmarkMarginals with the reference's own argument
+    (hessian-index pairs), and segmentallPointCloudData on a synthetic frame whose planes must equal the Python mirror's."""
+    import os, re, subprocess
     from semantic_slam_amd import library_path
+    from semantic_slam_amd.segmentation import PointCloudSegmentation
+    from semantic_slam_amd.synth import make_frame
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     exe = str(tmp_path / "shim_check")
     libdir = os.path.dirname(library_path())
     subprocess.check_call(["g++", "-std=c++17", "-O1", os.path.join(root, "tests", "shim_compile_check.cpp"), "-o", exe,
                            "-L" + libdir, "-lsslam_hip", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"])
-    out = subprocess.run([exe], capture_output=True, text=True)
-    assert out.returncode == 0 and "shim ok: chi2" in out.stdout, out.stdout + out.stderr
+    fr = make_frame(seed=1, n_boxes=12)
+    seg = PointCloudSegmentation()
+    planes = seg.segmentallPointCloudData(fr.robot_pose, fr.cam_angle, fr.boxes, fr)
+    assert len(planes) > 0
+    path = str(tmp_path / "frame.bin")
+    with open(path, "wb") as f:
+        np.array([fr.width, fr.height, fr.point_step, len(fr.boxes)], "<i4").tofile(f)
+        for b in fr.boxes:
+            np.array([b["tl_x"], b["tl_y"], b["width"], b["height"]], "<i4").tofile(f)
+        np.concatenate([fr.robot_pose, [fr.cam_angle]]).astype("<f4").tofile(f)
+        f.write(fr.cloud.tobytes())
+    out = subprocess.run([exe, path, str(len(planes))], capture_output=True, text=True)
+    assert out.returncode == 0 and "shim ok: chi2" in out.stdout and "frontend shim ok" in out.stdout, out.stdout + out.stderr
+    cs = sum(float(p.normal_orientation[0]) + 2.0 * float(p.normal_orientation[1]) + 3.0 * float(p.normal_orientation[2])
+             + 0.5 * float(p.normal_orientation[3]) + float(p.num_points) for p in planes)
+    got = float(re.search(r"checksum (\S+)", out.stdout).group(1))
+    assert got == pytest.approx(cs, rel=1e-9)
+
+
+def test_marginals_by_hessian_index_pairs(gpu_lib):
+    """computeMarginals with (hessianIndex, hessianIndex) pairs as the reference builds them (semantic_graph_slam.cpp:186-191),
+    including an off-diagonal pair, against the dense inverse of the oracle's H."""
+    from semantic_slam_amd import GraphSLAM
+    g = make_graph(40, 8, seed=6)
+    gp = GraphProblem.from_synth(g, interleave=True)
+    G = GraphSLAM.from_problem(gp)
+    G.optimize(6)
+    gp.est[:] = G.estimates()
+    U, _ = gp.linearize()
+    Hinv = np.linalg.inv((U + sp.triu(U, 1).T).toarray())
+    lm = [int(v) for v in gp.lm_ids]
+    hi = [G.hessian_index(v) for v in lm]
+    pose_h = G.hessian_index(int(gp.pose_ids[5]))
+    pairs = [(h, h) for h in hi] + [(hi[0], hi[1]), (pose_h, hi[2])]
+    blocks = G.computeMarginals(pairs)
+    for (r, c), blk in blocks.items():
+        ref = Hinv[r:r + blk.shape[0], c:c + blk.shape[1]]
+        assert np.abs(blk - ref).max() <= 1e-6 * np.abs(Hinv).max()
+    assert blocks[(pose_h, hi[2])].shape == (6, 3)
 
 
 def test_marginals_L_config_sample(gpu_lib):

@@ -48,18 +48,53 @@ def test_frame_matches_oracle_bit_exact(gpu_lib, seed):
 
 
 def test_noise_free_planes_are_recovered(gpu_lib):
-    """A noise-free piecewise-planar scene: every reported plane satisfies its own inliers to < 1 mm."""
-    f = make_frame(seed=5, noise=0.0, nan_fraction=0.0)
+    """A noise-free piecewise-planar scene: every pixel a plane owns (label image of the HIP path) lies on the reported plane.
+    PlaneRefinementComparator admits a pixel within 0.02 z^2 of the model (depth-dependent threshold), the fitted inliers
+    of a noise-free plane sit at float rounding level: the median residual of a region is < 0.1 mm, none exceeds the
+    comparator's own bound."""
+    f = make_frame(seed=5, noise=0.0, nan_fraction=0.0, n_holes=0)
     seg, planes, ref, _, _ = _run_both(f)
     assert len(planes) == len(ref) and len(planes) > 0
     xyz = f.xyz()
+    per_box = {}
     for p in planes:
-        b = f.boxes[p.box_index]
-        pts = xyz[b["tl_y"]:b["tl_y"] + b["height"], b["tl_x"]:b["tl_x"] + b["width"]].reshape(-1, 3)
-        lab = seg.labels(p.box_index).reshape(-1)
-        # region index of this plane inside its box = order of appearance among the box's planes
-        d = np.abs(pts @ p.normal_orientation[:3] + p.normal_orientation[3])
-        assert np.nanmin(d) < 1e-3
+        per_box.setdefault(p.box_index, []).append(p)
+    checked = 0
+    for bi, plist in per_box.items():
+        b = f.boxes[bi]
+        pts = xyz[b["tl_y"]:b["tl_y"] + b["height"], b["tl_x"]:b["tl_x"] + b["width"]].reshape(-1, 3).astype(np.float64)
+        lab = seg.labels(bi).reshape(-1)
+        # label k = k-th region segmentAndRefine accepted in this box; the post-filter (contour > 100, area, orientation) may drop
+        # some of them, so match every reported plane to the label whose pixels it fits
+        for p in plist:
+            n4 = p.normal_orientation.astype(np.float64)
+            best = None
+            for k in range(int(lab.max()) + 1):
+                m = lab == k
+                if not m.any():
+                    continue
+                d = np.abs(pts[m] @ n4[:3] + n4[3])
+                if best is None or np.median(d) < best[0]:
+                    best = (float(np.median(d)), float(d.max()), int(m.sum()), float((0.02 * pts[m][:, 2] ** 2).max()))
+            assert best is not None
+            med, dmax, npx, bound = best
+            assert npx == p.inlier_count
+            assert med < 1e-4 and dmax <= bound
+            checked += 1
+    assert checked == len(planes)
+
+
+def test_salt_and_pepper_nans_match_oracle(gpu_lib):
+    """the degenerate sensor model (isolated NaN pixels collapse the smoothing windows around them): still bit-exact"""
+    f = make_frame(seed=0, nan_fraction=0.02, noise=3e-5, n_holes=0)
+    seg, planes, ref, nrm, lab = _run_both(f)
+    assert len(planes) == len(ref)
+    off = 0
+    for bi, b in enumerate(f.boxes):
+        n = int(b["width"]) * int(b["height"])
+        assert np.array_equal(seg.labels(bi).reshape(n), lab[off:off + n])
+        assert np.array_equal(seg.normals(bi).reshape(n, 4), nrm[off:off + n], equal_nan=True)
+        off += n
 
 
 def test_ragged_and_rejected_boxes(gpu_lib):
