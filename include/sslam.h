@@ -147,6 +147,18 @@ int sslam_batch_upload(sslam_batch* b);
 /* copy optimised estimates back into the host graphs */
 int sslam_batch_download(sslam_batch* b);
 int sslam_batch_optimize(sslam_batch* b, int max_iters, sslam_opt_stats* out /* [n] */);
+/* Edge-sharded mode (SURVEY 8e mode E, BASELINE.json configs[4]): every graph's edge list is split contiguously over `world` ranks
+ * (one process per GPU, each holding the whole batch); a rank builds the partial normal equations of its edges, ONE RCCL all-reduce
+ * (ncclDouble, sum, over xGMI) of the contiguous [H || b] device buffer gives every rank the full system, and the solve / update /
+ * LM control then run replicated and bit-identical.  Rank 0 obtains an id with sslam_comm_unique_id and hands its 128 bytes to the
+ * other ranks by whatever the host program uses (torch.distributed, MPI, a file); every rank then calls sslam_batch_comm_init.
+ * world == 1 switches the mode off.  sslam_batch_set_edge_shard installs the shard WITHOUT a communicator (the partial systems stay
+ * unsummed): with sslam_batch_linearize_hb (-> the [H || b] buffer; NULL returns its length in doubles) this is the parity hook that
+ * shows sum over ranks of partial systems == the full system on a single device. */
+int sslam_comm_unique_id(char id_out[128]);
+int sslam_batch_comm_init(sslam_batch* b, const char id_in[128], int rank, int world);
+int sslam_batch_set_edge_shard(sslam_batch* b, int rank, int world);
+int64_t sslam_batch_linearize_hb(sslam_batch* b, double* h_and_b, int64_t capacity);
 /* run only the Jacobian build (linearise + assemble) `repeats` times; returns mean kernel
  * milliseconds measured with hipEvents on the batch's stream */
 int sslam_batch_time_linearize(sslam_batch* b, int repeats, double* ms_per_build);
@@ -217,6 +229,23 @@ void sslam_seg_destroy(sslam_seg* s);
 int sslam_seg_segment(sslam_seg* s, const uint8_t* cloud, int width, int height, int point_step, int row_step,
                       int off_x, int off_y, int off_z, const sslam_box* boxes, int n_boxes,
                       const float robot_pose[6], float cam_angle, sslam_plane* out, int max_out);
+
+/* Several frames in one pass (MI355X extension): the boxes of all frames are packed into one set of launches -- one frame's 32 boxes
+ * occupy 32 of the 256 CUs in the kernels that run one workgroup per box.  All frames share the cloud geometry (width .. off_z).
+ * out_frame[k] (optional) = frame of out[k]; box_index of a plane counts inside its own frame.  Results are identical to
+ * n_frames calls of sslam_seg_segment. */
+typedef struct sslam_frame {
+  const uint8_t* cloud;
+  const sslam_box* boxes;
+  int n_boxes;
+  float robot_pose[6];
+  float cam_angle;
+} sslam_frame;
+int sslam_seg_segment_batch(sslam_seg* s, const sslam_frame* frames, int n_frames, int width, int height, int point_step, int row_step,
+                            int off_x, int off_y, int off_z, sslam_plane* out, int max_out, int32_t* out_frame);
+/* Truncation of the last segment call: planes not returned because max_out was reached, boxes with more than 64 connected
+ * components above num_point_seg, boxes with more than 64 accepted planes.  Returns the sum (0 = nothing was truncated). */
+int sslam_seg_last_overflow(const sslam_seg* s, int* dropped_planes, int* boxes_with_full_candidate_table, int* boxes_with_full_region_table);
 
 /* RANSAC plane fit: pcl::SACSegmentation(SACMODEL_PLANE, SAC_RANSAC, optimise coefficients)
  * as configured at plane_segmentation.cpp:639-647 (threshold 0.01; PCL defaults max_iterations 50, probability 0.99)

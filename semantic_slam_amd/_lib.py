@@ -82,6 +82,10 @@ def load_library():
         "sslam_batch_upload": (ci, [vp]),
         "sslam_batch_download": (ci, [vp]),
         "sslam_batch_optimize": (ci, [vp, ci, C.POINTER(OptStats)]),
+        "sslam_comm_unique_id": (ci, [C.c_char_p]),
+        "sslam_batch_comm_init": (ci, [vp, C.c_char_p, ci, ci]),
+        "sslam_batch_set_edge_shard": (ci, [vp, ci, ci]),
+        "sslam_batch_linearize_hb": (i64, [vp, dp, i64]),
         "sslam_batch_time_linearize": (ci, [vp, ci, dp]),
         "sslam_batch_linearize_bytes": (i64, [vp]),
         "sslam_batch_info": (ci, [vp, C.c_char_p, dp]),

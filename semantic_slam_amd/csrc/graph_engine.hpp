@@ -15,6 +15,7 @@ namespace sslam {
 
 struct CholPlan;
 void chol_plan_free(CholPlan*);
+void batch_comm_destroy(void* comm);   // ncclCommDestroy
 
 struct KernelTimer {
   double total_ms = 0;
@@ -50,10 +51,16 @@ struct Batch {
   std::vector<int> dup_eo, dup_el;
   int max_row_slots = 0;
   CholPlan* chol = nullptr;
+  // edge-sharded mode
+  bool sharded = false;        // linearize only the edges of this rank's range
+  void* comm = nullptr;        // ncclComm_t (RCCL), or null: partial systems are left unsummed (single-device tests)
+  int64_t hb_doubles = 0;      // doubles in the contiguous [H || b] buffer
+  int shard_rank = 0, shard_world = 1;
 
   ~Batch() { release(); }
   void release() {
     if (chol) { chol_plan_free(chol); chol = nullptr; }
+    if (comm) { batch_comm_destroy(comm); comm = nullptr; }
     if (stream) { hipSetDevice(device); hipStreamSynchronize(stream); }
     for (auto& p : pending) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
     pending.clear();

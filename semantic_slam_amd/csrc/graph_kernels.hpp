@@ -68,6 +68,10 @@ struct BatchView {
   const int* pslot_edge; const unsigned char* pslot_kind;  // kind 0: SE3 edge, self = i; 1: SE3, self = j; 2: landmark edge
   const int* lslot_ptr; const int* lslot_edge;      // [nLr+1], landmark-side slots (edge index into el_*)
   int nDupEo, nDupEl; const int* dup_eo; const int* dup_el;  // non-owner edges of shared off-diagonal blocks
+  // edge-sharded mode (one graph's edges split across ranks, SURVEY 8e mode E): a rank builds the partial normal equations of the
+  // edges whose graph-local id lies in [shard_lo[g], shard_hi[g]); the partial [H || b] arrays are summed with one all-reduce
+  const int* eo_id; const int* el_id;        // graph-local edge id of every SE3 / landmark edge
+  const int* shard_lo; const int* shard_hi;  // [B]
   // PCG vectors
   double* x; double* r; double* z; double* p; double* q; double* Minv;  // Minv: [nPr*36 | nLr*9]
   double* part_a; double* part_b; double* part_c;  // [B*maxChunks] partial sums

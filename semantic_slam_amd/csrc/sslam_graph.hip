@@ -1,6 +1,8 @@
 // MI355X-native backend of ps_graph_slam::GraphSLAM — kernels, batch engine and C-ABI.
 // See include/sslam.h for the boundary and DESIGN.md for the data layout / roofline accounting.
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>   // types only: the library is bound at run time (rccl_api below)
+#include <dlfcn.h>
 #include <algorithm>
 #include <chrono>
 #include <cmath>
@@ -105,7 +107,7 @@ __device__ __forceinline__ Pose load_pose16(const double* a, int idx) {   // fou
   return Pose{{v0.a, v0.b, v1.a}, {v1.b, v2.a, v2.b, v3.a}};
 }
 
-template <bool PL>
+template <bool PL, bool SHARD>
 __global__ __launch_bounds__(kRowThreads) void k_linearize_rowthread(BatchView V) {
   __shared__ double accD[27][kRowThreads];
   const int tid = threadIdx.x;
@@ -116,6 +118,7 @@ __global__ __launch_bounds__(kRowThreads) void k_linearize_rowthread(BatchView V
   for (int k = 0; k < 27; ++k) accD[k][tid] = 0.0;
   const int s0 = V.pslot_ptr[row], s1 = V.pslot_ptr[row + 1];
   const int own = V.prow_pose[row];
+  const int sh_lo = SHARD ? V.shard_lo[V.prow_graph[row]] : 0, sh_hi = SHARD ? V.shard_hi[V.prow_graph[row]] : 0;
   const Pose Xown = load_pose16(V.pose, own);   // this row's vertex: loaded once, reused by every slot
   for (int s = s0; s < s1; ++s) {
     const int4 rec = V.pslot_rec[s];
@@ -129,13 +132,16 @@ __global__ __launch_bounds__(kRowThreads) void k_linearize_rowthread(BatchView V
       Se3Lin L;
       se3_error(iside ? Xown : load_pose16(V.pose, ia), iside ? load_pose16(V.pose, ib) : Xown, load_meas_pose(V.eo_z, n, e), L);
       double P[9], Q[9], R[9];   // Omega = [[P, Q], [Q^T, R]]
+      // edge-sharded mode: an edge outside this rank's range contributes nothing (everything below is linear in Omega; the owner
+      // of an off-diagonal block still writes it, as zeros)
+      const double mk = (!SHARD || (V.eo_id[e] >= sh_lo && V.eo_id[e] < sh_hi)) ? 1.0 : 0.0;
 #pragma unroll
       for (int r = 0; r < 3; ++r)
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-          P[r * 3 + c] = V.eo_w[(size_t)(r <= c ? tri21(r, c) : tri21(c, r)) * n + e];
-          Q[r * 3 + c] = V.eo_w[(size_t)tri21(r, 3 + c) * n + e];
-          R[r * 3 + c] = V.eo_w[(size_t)(r <= c ? tri21(3 + r, 3 + c) : tri21(3 + c, 3 + r)) * n + e];
+          P[r * 3 + c] = mk * V.eo_w[(size_t)(r <= c ? tri21(r, c) : tri21(c, r)) * n + e];
+          Q[r * 3 + c] = mk * V.eo_w[(size_t)tri21(r, 3 + c) * n + e];
+          R[r * 3 + c] = mk * V.eo_w[(size_t)(r <= c ? tri21(3 + r, 3 + c) : tri21(3 + c, 3 + r)) * n + e];
         }
       double A[9], B[9], Cc[9];   // own Jacobian [[A, B], [0, Cc]]  (B = 0 on the j side)
       if (iside) {
@@ -256,6 +262,10 @@ __global__ __launch_bounds__(kRowThreads) void k_linearize_rowthread(BatchView V
       }
       double W[9];
       load_sym3(V.el_w, n, e, W);
+      if (SHARD && !(V.el_id[e] >= sh_lo && V.el_id[e] < sh_hi)) {
+#pragma unroll
+        for (int q = 0; q < 9; ++q) W[q] = 0.0;
+      }
       double WJi[18], We[3];
 #pragma unroll
       for (int a = 0; a < 3; ++a) {
@@ -300,7 +310,7 @@ __global__ __launch_bounds__(kRowThreads) void k_linearize_rowthread(BatchView V
 
 // landmark rows: 16 lanes per landmark, each lane walks a strided subset of the incident edges,
 // butterfly reduction in a fixed order.
-template <bool PL>
+template <bool PL, bool SHARD>
 __global__ __launch_bounds__(256) void k_linearize_lm_rows(BatchView V) {
   const int l = blockIdx.x * 16 + (threadIdx.x >> 4);
   const int lane = threadIdx.x & 15;
@@ -345,6 +355,13 @@ __global__ __launch_bounds__(256) void k_linearize_lm_rows(BatchView V) {
       }
       double W[9];
       load_sym3(V.el_w, n, e, W);
+      if (SHARD) {
+        const int g = V.lrow_graph[l];
+        if (!(V.el_id[e] >= V.shard_lo[g] && V.el_id[e] < V.shard_hi[g])) {
+#pragma unroll
+          for (int q = 0; q < 9; ++q) W[q] = 0.0;
+        }
+      }
       double WJ[9], We[3];
 #pragma unroll
       for (int a = 0; a < 3; ++a) {
@@ -384,7 +401,9 @@ __global__ void k_linearize_dups(BatchView V) {
     for (; d < V.nDupEo && (d == t || (decode_blk(V.eo_blk[V.dup_eo[d]]) >> 1) == (decode_blk(V.eo_blk[V.dup_eo[t]]) >> 1)); ++d) {
     const int k = V.dup_eo[d];
     const int pi = V.eo_i[k], pj = V.eo_j[k];
-    if (!V.lm[V.prow_graph[V.pose_row[pi]]].lin) continue;
+    const int gk = V.prow_graph[V.pose_row[pi]];
+    if (!V.lm[gk].lin) continue;
+    if (!(V.eo_id[k] >= V.shard_lo[gk] && V.eo_id[k] < V.shard_hi[gk])) continue;
     Se3Lin L;
     se3_error(load_pose(V.pose, pi), load_pose(V.pose, pj), load_meas_pose(V.eo_z, V.nEo, k), L);
     double Ji[36], Jj[36], W[36], WJ[36];
@@ -404,7 +423,9 @@ __global__ void k_linearize_dups(BatchView V) {
     for (; d < V.nDupEl && (d == t || decode_blk(V.el_blk[V.dup_el[d]]) == decode_blk(V.el_blk[V.dup_el[t]])); ++d) {
     const int k = V.dup_el[d];
     const int pi = V.el_p[k], li = V.el_l[k];
-    if (!V.lm[V.prow_graph[V.pose_row[pi]]].lin) continue;
+    const int gk = V.prow_graph[V.pose_row[pi]];
+    if (!V.lm[gk].lin) continue;
+    if (!(V.el_id[k] >= V.shard_lo[gk] && V.el_id[k] < V.shard_hi[gk])) continue;
     const Pose Xi = load_pose(V.pose, pi);
     const double* lp = V.lmk + (size_t)li * 4;
     const int n = V.nEl;
@@ -850,6 +871,36 @@ __global__ void k_set_trial_all(BatchView V, double lambda) {  // used by the so
 // =============================================================================================
 namespace sslam {
 
+// RCCL is bound with dlopen when the edge-sharded mode is first used, not at link time: a host program that already carries its
+// own copy (PyTorch ships one) must end up with ONE librccl in the process, and the single-GPU path must not depend on it at all.
+struct RcclApi {
+  void* lib = nullptr;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+  const char* (*GetErrorString)(ncclResult_t) = nullptr;
+  bool ok() const { return lib && GetUniqueId && CommInitRank && CommDestroy && AllReduce && GetErrorString; }
+};
+static RcclApi& rccl_api() {
+  static RcclApi api;
+  if (!api.lib) {
+    for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+      api.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);   // an already loaded copy with this soname is reused
+      if (api.lib) break;
+    }
+    if (api.lib) {
+      api.GetUniqueId = (decltype(api.GetUniqueId))dlsym(api.lib, "ncclGetUniqueId");
+      api.CommInitRank = (decltype(api.CommInitRank))dlsym(api.lib, "ncclCommInitRank");
+      api.CommDestroy = (decltype(api.CommDestroy))dlsym(api.lib, "ncclCommDestroy");
+      api.AllReduce = (decltype(api.AllReduce))dlsym(api.lib, "ncclAllReduce");
+      api.GetErrorString = (decltype(api.GetErrorString))dlsym(api.lib, "ncclGetErrorString");
+    }
+  }
+  return api;
+}
+void batch_comm_destroy(void* comm) { if (comm && rccl_api().ok()) (void)rccl_api().CommDestroy((ncclComm_t)comm); }
+
 std::string& last_error_ref() {
   static thread_local std::string e;
   return e;
@@ -874,6 +925,7 @@ static int batch_build(Batch& b, bool host_only = false) {
   std::vector<int> eo_i, eo_j, eo_blk, el_p, el_l, el_blk;
   std::vector<int> eo_src, el_src;  // (graph-local edge id) for SoA fill
   std::vector<int> eo_g, el_g;
+  std::vector<int> shard_lo(b.graphs.size(), 0), shard_hi(b.graphs.size(), 0x7fffffff);
   int maxRow = 1, maxEdge = 1;
   for (int g = 0; g < B; ++g) {
     const HostGraph& G = *b.graphs[g];
@@ -1070,14 +1122,17 @@ static int batch_build(Batch& b, bool host_only = false) {
   UP(tile_row0, tile_row0); UP(tile_row1, tile_row1); UP(pslot_ptr, pslot_ptr); UP(pslot_edge, pslot_edge); UP(pslot_kind, pslot_kind);
   UP(lslot_ptr, lslot_ptr); UP(lslot_edge, lslot_edge);
   UP(b.dup_eo, dup_eo); UP(b.dup_el, dup_el); UP(pslot_rec, pslot_rec);
+  UP(eo_src, eo_id); UP(el_src, el_id); UP(shard_lo, shard_lo); UP(shard_hi, shard_hi);
   V.nDupEo = (int)b.dup_eo.size(); V.nDupEl = (int)b.dup_el.size();
   V.nTiles = (int)tile_row0.size();
 #undef UP
   double* H = nullptr;
-  if ((rc = dev_alloc(b, (size_t)h_total, &H))) return rc;
-  V.Hpp_diag = H; V.Hll_diag = H + b.hll_base; V.Hpp_off = H + b.hpp_off_base; V.Hpl = H + b.hpl_base;
   const size_t dim = (size_t)6 * nPr + (size_t)3 * nLr;
-  if ((rc = dev_alloc(b, dim, &V.bvec))) return rc;
+  const size_t h_even = ((size_t)h_total + 1) & ~(size_t)1;   // b right behind H (16-byte aligned): [H || b] is one all-reduce buffer
+  if ((rc = dev_alloc(b, h_even + dim, &H))) return rc;
+  V.Hpp_diag = H; V.Hll_diag = H + b.hll_base; V.Hpp_off = H + b.hpp_off_base; V.Hpl = H + b.hpl_base;
+  V.bvec = H + h_even;
+  b.hb_doubles = (int64_t)(h_even + dim);
   if ((rc = dev_alloc(b, (size_t)V.nPose * 8, &V.pose))) return rc;
   if ((rc = dev_alloc(b, (size_t)V.nPose * 8, &V.pose_trial))) return rc;
   if ((rc = dev_alloc(b, (size_t)V.nLm * 4, &V.lmk))) return rc;
@@ -1162,15 +1217,21 @@ static int batch_linearize(Batch& b) {
   ScopedTimer t(b, "linearize");
   const BatchView& V = b.V;
   const int nblk = (V.nPr + kRowThreads - 1) / kRowThreads;
-  if (V.nPr > 0) {
-    if (b.has_planes) hipLaunchKernelGGL(k_linearize_rowthread<true>, dim3(nblk), dim3(kRowThreads), 0, b.stream, V);
-    else hipLaunchKernelGGL(k_linearize_rowthread<false>, dim3(nblk), dim3(kRowThreads), 0, b.stream, V);
+#define SSLAM_LAUNCH_LIN(PLV, SHV)                                                                                                    \
+  {                                                                                                                                   \
+    if (V.nPr > 0) hipLaunchKernelGGL((k_linearize_rowthread<PLV, SHV>), dim3(nblk), dim3(kRowThreads), 0, b.stream, V);              \
+    if (V.nLr > 0) hipLaunchKernelGGL((k_linearize_lm_rows<PLV, SHV>), dim3((V.nLr + 15) / 16), dim3(256), 0, b.stream, V);           \
   }
-  if (V.nLr > 0) {
-    if (b.has_planes) hipLaunchKernelGGL(k_linearize_lm_rows<true>, dim3((V.nLr + 15) / 16), dim3(256), 0, b.stream, V);
-    else hipLaunchKernelGGL(k_linearize_lm_rows<false>, dim3((V.nLr + 15) / 16), dim3(256), 0, b.stream, V);
-  }
+  if (b.sharded) { if (b.has_planes) SSLAM_LAUNCH_LIN(true, true) else SSLAM_LAUNCH_LIN(false, true) }
+  else { if (b.has_planes) SSLAM_LAUNCH_LIN(true, false) else SSLAM_LAUNCH_LIN(false, false) }
+#undef SSLAM_LAUNCH_LIN
   if (V.nDupEo + V.nDupEl > 0) hipLaunchKernelGGL(k_linearize_dups, dim3((std::max(V.nDupEo, V.nDupEl) + 63) / 64), dim3(64), 0, b.stream, V);
+  if (b.sharded && b.comm) {
+    // the partial [H || b] arrays of all ranks -> their sum on every rank: ONE all-reduce over xGMI (RCCL), in stream order;
+    // everything after it (solve, update, chi2, LM control) runs replicated and bit-identical on all ranks
+    const ncclResult_t r = rccl_api().AllReduce(V.Hpp_diag, V.Hpp_diag, (size_t)b.hb_doubles, ncclDouble, ncclSum, (ncclComm_t)b.comm, b.stream);
+    if (r != ncclSuccess) return set_error(SSLAM_ERR_HIP, "ncclAllReduce of the normal equations: %s", rccl_api().GetErrorString(r));
+  }
   return launch_check("linearize");
 }
 
@@ -1754,6 +1815,79 @@ int sslam_batch_optimize(sslam_batch* h, int max_iters, sslam_opt_stats* out) {
   const int rc = batch_check(h);
   return rc ? rc : batch_optimize(h->b, max_iters, out);
 }
+// ---- edge-sharded mode (SURVEY 8e mode E; BASELINE.json configs[4]): the edges of every graph of the batch are split
+//      contiguously over the ranks, each rank builds the partial normal equations of its edges, ONE RCCL all-reduce of the
+//      contiguous [H || b] buffer sums them, and the rest of the LM step runs replicated.
+static int batch_set_shard(Batch& b, int rank, int world) {
+  if (world < 1 || rank < 0 || rank >= world) return set_error(SSLAM_ERR_INVALID, "bad rank %d of %d", rank, world);
+  SSLAM_HIP_TRY(hipSetDevice(b.device));
+  std::vector<int> lo(b.graphs.size()), hi(b.graphs.size());
+  for (size_t g = 0; g < b.graphs.size(); ++g) {
+    const int n = b.graphs[g]->ne();
+    const int base = n / world, extra = n % world;
+    lo[g] = rank * base + std::min(rank, extra);
+    hi[g] = lo[g] + base + (rank < extra ? 1 : 0);
+    if (world == 1) { lo[g] = 0; hi[g] = 0x7fffffff; }
+  }
+  SSLAM_HIP_TRY(hipMemcpyAsync((void*)b.V.shard_lo, lo.data(), lo.size() * sizeof(int), hipMemcpyHostToDevice, b.stream));
+  SSLAM_HIP_TRY(hipMemcpyAsync((void*)b.V.shard_hi, hi.data(), hi.size() * sizeof(int), hipMemcpyHostToDevice, b.stream));
+  SSLAM_HIP_TRY(hipStreamSynchronize(b.stream));
+  b.sharded = world > 1;
+  b.shard_rank = rank; b.shard_world = world;
+  return 0;
+}
+int sslam_comm_unique_id(char id_out[128]) {
+  if (!id_out) return set_error(SSLAM_ERR_INVALID, "null argument");
+  static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is 128 bytes");
+  if (!rccl_api().ok()) return set_error(SSLAM_ERR_UNSUPPORTED, "librccl.so could not be loaded: %s", dlerror());
+  ncclUniqueId id;
+  const ncclResult_t r = rccl_api().GetUniqueId(&id);
+  if (r != ncclSuccess) return set_error(SSLAM_ERR_HIP, "ncclGetUniqueId: %s", rccl_api().GetErrorString(r));
+  memcpy(id_out, &id, sizeof id);
+  return 0;
+}
+int sslam_batch_comm_init(sslam_batch* h, const char id_in[128], int rank, int world) {
+  if (!h || !id_in) return set_error(SSLAM_ERR_INVALID, "null argument");
+  Batch& b = h->b;
+  int rc = batch_check(h);
+  if (rc) return rc;
+  SSLAM_HIP_TRY(hipSetDevice(b.device));
+  if (b.comm) { batch_comm_destroy(b.comm); b.comm = nullptr; }
+  if (world > 1) {
+    if (!rccl_api().ok()) return set_error(SSLAM_ERR_UNSUPPORTED, "librccl.so could not be loaded: %s", dlerror());
+    ncclUniqueId id;
+    memcpy(&id, id_in, sizeof id);
+    ncclComm_t comm = nullptr;
+    const ncclResult_t r = rccl_api().CommInitRank(&comm, world, id, rank);
+    if (r != ncclSuccess) return set_error(SSLAM_ERR_HIP, "ncclCommInitRank(rank %d of %d): %s", rank, world, rccl_api().GetErrorString(r));
+    b.comm = comm;
+  }
+  return batch_set_shard(b, rank, world);
+}
+int sslam_batch_set_edge_shard(sslam_batch* h, int rank, int world) {
+  if (!h) return set_error(SSLAM_ERR_INVALID, "null batch");
+  int rc = batch_check(h);
+  if (rc) return rc;
+  return batch_set_shard(h->b, rank, world);
+}
+int64_t sslam_batch_linearize_hb(sslam_batch* h, double* h_and_b, int64_t capacity) {
+  if (!h) return set_error(SSLAM_ERR_INVALID, "null batch");
+  Batch& b = h->b;
+  if (!h_and_b) return b.hb_doubles;
+  if (capacity < b.hb_doubles) return set_error(SSLAM_ERR_INVALID, "buffer of %lld doubles needed", (long long)b.hb_doubles);
+  int rc = batch_check(h);
+  if (rc) return rc;
+  SSLAM_HIP_TRY(hipSetDevice(b.device));
+  if (!b.uploaded && (rc = batch_upload_estimates(b))) return rc;
+  if ((rc = batch_chi2(b, b.V.pose, b.V.lmk, 0))) return rc;
+  hipLaunchKernelGGL(k_lm_init, dim3(b.V.B), dim3(64), 0, b.stream, b.V, b.d_part_e, 0);
+  if ((rc = batch_linearize(b))) return rc;
+  SSLAM_HIP_TRY(hipMemcpyAsync(h_and_b, b.V.Hpp_diag, (size_t)b.hb_doubles * sizeof(double), hipMemcpyDeviceToHost, b.stream));
+  SSLAM_HIP_TRY(hipStreamSynchronize(b.stream));
+  b.harvest();
+  return b.hb_doubles;
+}
+
 int sslam_batch_time_linearize(sslam_batch* h, int repeats, double* ms_per_build) {
   if (!h || !ms_per_build || repeats <= 0) return set_error(SSLAM_ERR_INVALID, "bad argument");
   Batch& b = h->b;

@@ -34,7 +34,7 @@ struct BoxMeta {
   int w, h, tlx, tly;
   int pix0;   // offset into the packed per-pixel arrays
   int ii0;    // offset into the packed integral-image arrays ((w+1)*(h+1) per box)
-  int box_index, pad;
+  int box_index, frame;   // frame: which cloud of a batched call the box is cut from
 };
 
 struct Region {
@@ -50,7 +50,9 @@ struct Region {
 struct View {
   int nbox, npix_total, maxpix;
   const BoxMeta* box;
-  const unsigned char* cloud;
+  const unsigned char* cloud;   // the clouds of all frames of the call, cloud_stride bytes apart
+  size_t cloud_stride;
+  int* overflow;                // [2]: boxes whose candidate / region tables were full (results truncated, reported to the caller)
   int point_step, row_step, ox, oy, oz;
   float* pts;    // [npix*3]
   float* dm;     // [npix]
@@ -146,7 +148,7 @@ __global__ __launch_bounds__(256) void k_crop(View V) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= b.w * b.h) return;
   const int v = i / b.w, u = i - v * b.w;
-  const size_t pos = (size_t)(b.tly + v) * V.row_step + (size_t)(b.tlx + u) * V.point_step;
+  const size_t pos = (size_t)b.frame * V.cloud_stride + (size_t)(b.tly + v) * V.row_step + (size_t)(b.tlx + u) * V.point_step;
   float x, y, z;
   memcpy(&x, V.cloud + pos + V.ox, 4); memcpy(&y, V.cloud + pos + V.oy, 4); memcpy(&z, V.cloud + pos + V.oz, 4);
   float* o = V.pts + ((size_t)b.pix0 + i) * 3;
@@ -550,6 +552,8 @@ __global__ __launch_bounds__(1024) void k_regions(View V) {
     int tot = 0;
     for (int q = 0; q < nc; ++q) tot += accepted[q];
     V.nreg[blockIdx.x] = min(tot, kMaxRegions);
+    if (ncand > kMaxCand) atomicAdd(&V.overflow[0], 1);
+    if (tot > kMaxRegions) atomicAdd(&V.overflow[1], 1);
   }
 }
 
@@ -1167,7 +1171,9 @@ struct sslam_seg {
   hipStream_t stream = nullptr;
   View V{};
   std::vector<BoxMeta> boxes;      // accepted boxes of the last call
-  std::vector<int> box_src;        // accepted slot -> index into the caller's box array
+  std::vector<int> box_src;        // accepted slot -> index into the caller's box array (of its frame)
+  std::vector<int> box_frame;      // accepted slot -> frame of the batched call
+  int last_dropped_planes = 0, last_candidate_overflow = 0, last_region_overflow = 0;
   size_t cap_pix = 0, cap_ii = 0, cap_cloud = 0, cap_box = 0;
   unsigned char* d_cloud = nullptr;
   BoxMeta* d_box = nullptr;
@@ -1246,9 +1252,14 @@ int sslam_seg_transform(const sslam_seg* s, const float pose[6], float cam_pitch
   return 0;
 }
 
-int sslam_seg_segment(sslam_seg* s, const uint8_t* cloud, int width, int height, int point_step, int row_step, int ox, int oy, int oz,
-                      const sslam_box* boxes, int n_boxes, const float robot_pose[6], float cam_angle, sslam_plane* out, int max_out) {
-  if (!s || !cloud || (!boxes && n_boxes > 0) || !robot_pose || (!out && max_out > 0)) return set_error(SSLAM_ERR_INVALID, "null argument");
+// One or several frames in one pass: the accepted boxes of ALL frames are packed back to back into one View, so that every
+// kernel launch covers 32 x F boxes (a single frame's 32 boxes leave most of the 256 CUs idle: the raster recurrences of PCL's
+// algorithms run as one workgroup per box).
+static int seg_run(sslam_seg* s, const sslam_frame* frames, int n_frames, int width, int height, int point_step, int row_step, int ox, int oy, int oz,
+                   sslam_plane* out, int max_out, int32_t* out_frame) {
+  if (!s || !frames || n_frames <= 0 || (!out && max_out > 0)) return set_error(SSLAM_ERR_INVALID, "null argument");
+  for (int f = 0; f < n_frames; ++f)
+    if (!frames[f].cloud || (!frames[f].boxes && frames[f].n_boxes > 0)) return set_error(SSLAM_ERR_INVALID, "frame %d: null cloud or boxes", f);
   int nd = 0;
   if (hipGetDeviceCount(&nd) != hipSuccess || nd <= 0) return set_error(SSLAM_ERR_NO_DEVICE, "no HIP device visible; the product has no CPU fallback");
   SSLAM_HIP_TRY(hipSetDevice(s->P.device));
@@ -1257,25 +1268,28 @@ int sslam_seg_segment(sslam_seg* s, const uint8_t* cloud, int width, int height,
   const sslam_seg_params& P = s->P;
   // ---- host-side box filter: class whitelist (point_cloud_segmentation.h:126-130), crop bounds
   //      (plane_segmentation.cpp:34-38), minimum point count (:93-95)
-  s->boxes.clear(); s->box_src.clear();
+  s->boxes.clear(); s->box_src.clear(); s->box_frame.clear();
   size_t npix = 0, nii = 0;
   int maxpix = 1;
-  for (int i = 0; i < n_boxes; ++i) {
-    const sslam_box& b = boxes[i];
+  for (int f = 0; f < n_frames; ++f)
+  for (int i = 0; i < frames[f].n_boxes; ++i) {
+    const sslam_box& b = frames[f].boxes[i];
     if (b.class_id < SSLAM_CLASS_CHAIR || b.class_id > SSLAM_CLASS_CAR) continue;
     if (b.height < 0 || b.width < 0 || b.tl_x < 0 || b.tl_y < 0 || (b.tl_x + b.width) > P.image_width || (b.tl_y + b.height) > P.image_height) continue;
     if (b.tl_x + b.width > width || b.tl_y + b.height > height) continue;
     const size_t n = (size_t)b.width * b.height;
     if (n == 0 || (double)n < P.norm_point_thres) continue;
     if (b.width > kBandFloats / 8 - 1) return set_error(SSLAM_ERR_UNSUPPORTED, "box wider than %d px", kBandFloats / 8 - 1);
-    BoxMeta m{b.width, b.height, b.tl_x, b.tl_y, (int)npix, (int)nii, (int)s->boxes.size(), 0};
-    s->boxes.push_back(m); s->box_src.push_back(i);
+    BoxMeta m{b.width, b.height, b.tl_x, b.tl_y, (int)npix, (int)nii, (int)s->boxes.size(), f};
+    s->boxes.push_back(m); s->box_src.push_back(i); s->box_frame.push_back(f);
+    if (npix + n >= ((size_t)1 << 29)) return set_error(SSLAM_ERR_UNSUPPORTED, "too many box pixels in one call (%zu): split the batch", npix + n);
     npix += n; nii += (size_t)(b.width + 1) * (b.height + 1);
     maxpix = std::max(maxpix, (int)n);
   }
   const int nb = (int)s->boxes.size();
   View& V = s->V;
-  const size_t cloud_bytes = (size_t)row_step * height;
+  const size_t frame_bytes = (size_t)row_step * height;
+  const size_t cloud_bytes = frame_bytes * n_frames;
   if (cloud_bytes > s->cap_cloud || npix > s->cap_pix || nii > s->cap_ii || (size_t)nb > s->cap_box) {
     SSLAM_HIP_TRY(hipStreamSynchronize(s->stream));
     s->free_all();
@@ -1298,9 +1312,10 @@ int sslam_seg_segment(sslam_seg* s, const uint8_t* cloud, int width, int height,
     if ((rc = seg_alloc(s, s->cap_box, &V.nreg))) return rc;
     if ((rc = seg_alloc(s, s->cap_pix * 4, &V.contour))) return rc;
     if ((rc = seg_alloc(s, s->cap_box, &V.ccount))) return rc;
+    if ((rc = seg_alloc(s, (size_t)2, &V.overflow))) return rc;
   }
   V.nbox = nb; V.npix_total = (int)npix; V.maxpix = maxpix;
-  V.box = s->d_box; V.cloud = s->d_cloud;
+  V.box = s->d_box; V.cloud = s->d_cloud; V.cloud_stride = frame_bytes;
   V.point_step = point_step; V.row_step = row_step; V.ox = ox; V.oy = oy; V.oz = oz;
   V.mdcf = P.max_depth_change_factor; V.smoothing = P.normal_smoothing_size;
   V.ang_thr_cos = cosf(P.angular_threshold); V.dist_thr = P.distance_threshold; V.max_curv = P.maximum_curvature;
@@ -1308,8 +1323,11 @@ int sslam_seg_segment(sslam_seg* s, const uint8_t* cloud, int width, int height,
   std::vector<Region> regs;
   std::vector<int> nreg(nb, 0);
   float kernel_ms = 0;
+  int ovf[2] = {0, 0};
   if (nb > 0) {
-    SSLAM_HIP_TRY(hipMemcpyAsync(s->d_cloud, cloud, cloud_bytes, hipMemcpyHostToDevice, s->stream));
+    for (int f = 0; f < n_frames; ++f)
+      SSLAM_HIP_TRY(hipMemcpyAsync(s->d_cloud + (size_t)f * frame_bytes, frames[f].cloud, frame_bytes, hipMemcpyHostToDevice, s->stream));
+    SSLAM_HIP_TRY(hipMemsetAsync(V.overflow, 0, 2 * sizeof(int), s->stream));
     SSLAM_HIP_TRY(hipMemcpyAsync(s->d_box, s->boxes.data(), nb * sizeof(BoxMeta), hipMemcpyHostToDevice, s->stream));
     hipEvent_t e0, e1;
     SSLAM_HIP_TRY(hipEventCreate(&e0)); SSLAM_HIP_TRY(hipEventCreate(&e1));
@@ -1386,6 +1404,7 @@ int sslam_seg_segment(sslam_seg* s, const uint8_t* cloud, int width, int height,
     regs.resize((size_t)nb * kMaxRegions);
     SSLAM_HIP_TRY(hipMemcpyAsync(regs.data(), V.reg, regs.size() * sizeof(Region), hipMemcpyDeviceToHost, s->stream));
     SSLAM_HIP_TRY(hipMemcpyAsync(nreg.data(), V.nreg, nb * sizeof(int), hipMemcpyDeviceToHost, s->stream));
+    SSLAM_HIP_TRY(hipMemcpyAsync(ovf, V.overflow, sizeof ovf, hipMemcpyDeviceToHost, s->stream));
     SSLAM_HIP_TRY(hipStreamSynchronize(s->stream));
     hipError_t le = hipGetLastError();
     if (le != hipSuccess) return set_error(SSLAM_ERR_HIP, "frontend kernels: %s", hipGetErrorString(le));
@@ -1394,12 +1413,14 @@ int sslam_seg_segment(sslam_seg* s, const uint8_t* cloud, int width, int height,
   }
   if (getenv("SSLAM_SEG_DEBUG")) for (int bi = 0; bi < nb; ++bi) for (int k = 0; k < nreg[bi]; ++k) { const Region& R = regs[(size_t)bi * kMaxRegions + k]; fprintf(stderr, "[seg] post box %d reg %d: inl %d contour %d off %d area %g\n", bi, k, R.inliers, R.contour_n, R.contour_off, R.area); }
   // ---- plane_segmentation.cpp:158-256 + point_cloud_segmentation.h:43-99 (scalar post-processing)
-  float T[16];
-  sslam_seg_transform(s, robot_pose, cam_angle, T);
-  const float hz[3] = {T[8], T[9], T[10]};
-  int nout = 0;
+  int nout = 0, dropped = 0;
   for (int bi = 0; bi < nb; ++bi) {
-    const sslam_box& sb = boxes[s->box_src[bi]];
+    const sslam_frame& fr = frames[s->box_frame[bi]];
+    const float* robot_pose = fr.robot_pose;
+    float T[16];
+    sslam_seg_transform(s, robot_pose, fr.cam_angle, T);
+    const float hz[3] = {T[8], T[9], T[10]};
+    const sslam_box& sb = fr.boxes[s->box_src[bi]];
     for (int k = 0; k < nreg[bi]; ++k) {
       const Region& R = regs[(size_t)bi * kMaxRegions + k];
       if (!(R.contour_n > P.min_contour_points)) continue;
@@ -1415,7 +1436,9 @@ int sslam_seg_segment(sslam_seg* s, const uint8_t* cloud, int width, int height,
         type = 1;
         if (m[0] > 0) sgn = -1.0f;
       }
-      if (type < 0 || nout >= max_out) continue;
+      if (type < 0) continue;
+      if (nout >= max_out) { ++dropped; continue; }
+      if (out_frame) out_frame[nout] = s->box_frame[bi];
       sslam_plane& o = out[nout++];
       memcpy(o.centroid_cam, R.centroid, 12);
       for (int q = 0; q < 4; ++q) o.normal_d[q] = sgn < 0 ? -m[q] : m[q];
@@ -1429,11 +1452,34 @@ int sslam_seg_segment(sslam_seg* s, const uint8_t* cloud, int width, int height,
       o.box_index = s->box_src[bi]; o.inlier_count = R.inliers; o.area = R.area;
     }
   }
+  s->last_dropped_planes = dropped; s->last_candidate_overflow = ovf[0]; s->last_region_overflow = ovf[1];
   s->last_kernel_ms = kernel_ms;
   s->last_total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   return nout;
 }
 
+
+int sslam_seg_segment(sslam_seg* s, const uint8_t* cloud, int width, int height, int point_step, int row_step, int ox, int oy, int oz,
+                      const sslam_box* boxes, int n_boxes, const float robot_pose[6], float cam_angle, sslam_plane* out, int max_out) {
+  if (!s || !cloud || (!boxes && n_boxes > 0) || !robot_pose || (!out && max_out > 0)) return set_error(SSLAM_ERR_INVALID, "null argument");
+  sslam_frame fr;
+  fr.cloud = cloud; fr.boxes = boxes; fr.n_boxes = n_boxes; fr.cam_angle = cam_angle;
+  memcpy(fr.robot_pose, robot_pose, sizeof fr.robot_pose);
+  return seg_run(s, &fr, 1, width, height, point_step, row_step, ox, oy, oz, out, max_out, nullptr);
+}
+
+int sslam_seg_segment_batch(sslam_seg* s, const sslam_frame* frames, int n_frames, int width, int height, int point_step, int row_step,
+                            int ox, int oy, int oz, sslam_plane* out, int max_out, int32_t* out_frame) {
+  return seg_run(s, frames, n_frames, width, height, point_step, row_step, ox, oy, oz, out, max_out, out_frame);
+}
+
+int sslam_seg_last_overflow(const sslam_seg* s, int* dropped_planes, int* boxes_with_full_candidate_table, int* boxes_with_full_region_table) {
+  if (!s) return set_error(SSLAM_ERR_INVALID, "null argument");
+  if (dropped_planes) *dropped_planes = s->last_dropped_planes;
+  if (boxes_with_full_candidate_table) *boxes_with_full_candidate_table = s->last_candidate_overflow;
+  if (boxes_with_full_region_table) *boxes_with_full_region_table = s->last_region_overflow;
+  return s->last_dropped_planes + s->last_candidate_overflow + s->last_region_overflow;
+}
 
 int sslam_seg_ransac_plane(sslam_seg* s, const float* xyz, int n, float threshold, int max_iterations, double probability,
                            uint64_t seed, float coeff_out[4], int32_t* inliers_out, int max_inliers) {
@@ -1450,13 +1496,18 @@ int sslam_seg_ransac_plane(sslam_seg* s, const float* xyz, int n, float threshol
   const int nblk = (n + 255) / 256;
   float *d_pts = nullptr, *d_models = nullptr;
   int *d_counts = nullptr, *d_blk = nullptr, *d_inl = nullptr, *d_total = nullptr;
+  struct Guard {   // frees whatever was allocated on every exit path (an early SSLAM_HIP_TRY return included)
+    std::vector<void**> ptrs;
+    ~Guard() { for (void** p : ptrs) if (*p) (void)hipFree(*p); }
+  } guard;
+  guard.ptrs = {(void**)&d_pts, (void**)&d_models, (void**)&d_counts, (void**)&d_blk, (void**)&d_inl, (void**)&d_total};
   SSLAM_HIP_TRY(hipMalloc((void**)&d_pts, (size_t)n * 3 * sizeof(float)));
   SSLAM_HIP_TRY(hipMalloc((void**)&d_models, (size_t)(H + 1) * 4 * sizeof(float)));
   SSLAM_HIP_TRY(hipMalloc((void**)&d_counts, (size_t)H * sizeof(int)));
   SSLAM_HIP_TRY(hipMalloc((void**)&d_blk, (size_t)nblk * sizeof(int)));
   SSLAM_HIP_TRY(hipMalloc((void**)&d_inl, (size_t)std::max(n, 1) * sizeof(int)));
   SSLAM_HIP_TRY(hipMalloc((void**)&d_total, sizeof(int)));
-  auto cleanup = [&]() { (void)hipFree(d_pts); (void)hipFree(d_models); (void)hipFree(d_counts); (void)hipFree(d_blk); (void)hipFree(d_inl); (void)hipFree(d_total); };
+  auto cleanup = [&]() {};   // the guard frees
   SSLAM_HIP_TRY(hipMemcpyAsync(d_pts, xyz, (size_t)n * 3 * sizeof(float), hipMemcpyHostToDevice, s->stream));
   hipLaunchKernelGGL(k_ransac_score, dim3(H), dim3(256), 0, s->stream, d_pts, n, threshold, (unsigned long long)seed, d_models, d_counts);
   std::vector<int> counts(H);
@@ -1577,7 +1628,7 @@ int sslam_seg_convex_hull_2d(sslam_seg* s, const float* xyz, int n, const int32_
 }
 
 static int seg_find_slot(sslam_seg* s, int box) {
-  for (size_t k = 0; k < s->box_src.size(); ++k) if (s->box_src[k] == box) return (int)k;
+  for (size_t k = 0; k < s->box_src.size(); ++k) if (s->box_src[k] == box && s->box_frame[k] == 0) return (int)k;   // parity hooks address frame 0
   return -1;
 }
 int sslam_seg_get_normals(sslam_seg* s, int box, float* out) {

@@ -50,6 +50,25 @@ def allreduce_normal_equations(h_and_b):
     return h_and_b
 
 
+def init_edge_sharded(batch, device=None) -> None:
+    """Edge-sharded mode on the GPUs: rank 0 creates the RCCL unique id (``sslam_comm_unique_id``), ``torch.distributed``
+    carries its 128 bytes to the other ranks, and every rank joins the communicator that the library's LM loop uses for the
+    all-reduce of the normal equations (``ncclAllReduce`` issued from C++ on the batch's own stream)."""
+    import ctypes as C
+    import torch
+    import torch.distributed as dist
+    from ._lib import load_library
+    rank, world = dist.get_rank(), dist.get_world_size()
+    buf = C.create_string_buffer(128)
+    if rank == 0:
+        rc = load_library().sslam_comm_unique_id(buf)
+        if rc < 0:
+            raise RuntimeError(load_library().sslam_last_error().decode())
+    t = torch.tensor(list(buf.raw), dtype=torch.uint8, device=device)
+    dist.broadcast(t, src=0)
+    batch.comm_init(bytes(t.cpu().tolist()), rank, world)
+
+
 def aggregate_throughput(units_this_rank: float, seconds_max: float, device=None) -> float:
     """Whole-job value = units all ranks processed / max-over-ranks time."""
     import torch

@@ -275,6 +275,22 @@ class GraphBatch:
         _check(self._lib, self._lib.sslam_batch_optimize(self._h, max_iterations, st))
         return list(st)
 
+    # -- edge-sharded mode (SURVEY 8e mode E) ----------------------------------------------------
+    def comm_init(self, unique_id: bytes, rank: int, world: int) -> None:
+        """RCCL communicator + edge shard of this rank (every rank holds the whole batch); see distributed.init_edge_sharded."""
+        _check(self._lib, self._lib.sslam_batch_comm_init(self._h, unique_id, rank, world))
+
+    def set_edge_shard(self, rank: int, world: int) -> None:
+        """install the edge shard WITHOUT a communicator: linearize_hb() then returns this rank's partial system (parity hook)"""
+        _check(self._lib, self._lib.sslam_batch_set_edge_shard(self._h, rank, world))
+
+    def linearize_hb(self) -> np.ndarray:
+        """[H values || b] of the batch at the current estimates (partial if an edge shard is installed)"""
+        n = self._lib.sslam_batch_linearize_hb(self._h, None, 0)
+        out = np.zeros(int(n))
+        _check(self._lib, int(self._lib.sslam_batch_linearize_hb(self._h, _dptr(out), int(n))))
+        return out
+
     def time_linearize(self, repeats: int = 20) -> float:
         ms = C.c_double(0)
         _check(self._lib, self._lib.sslam_batch_time_linearize(self._h, repeats, C.byref(ms)))

@@ -36,6 +36,10 @@ class Plane(C.Structure):
                 ("box_index", C.c_int32), ("inlier_count", C.c_int32), ("area", C.c_float)]
 
 
+class Frame(C.Structure):   # sslam_frame
+    _fields_ = [("cloud", C.c_void_p), ("boxes", C.c_void_p), ("n_boxes", C.c_int), ("robot_pose", C.c_float * 6), ("cam_angle", C.c_float)]
+
+
 @dataclasses.dataclass
 class DetectedObject:
     """detected_object.h:14-24"""
@@ -64,6 +68,9 @@ def _bind(lib):
     lib.sslam_seg_destroy.restype = None; lib.sslam_seg_destroy.argtypes = [vp]
     lib.sslam_seg_segment.restype = ci
     lib.sslam_seg_segment.argtypes = [vp, vp, ci, ci, ci, ci, ci, ci, ci, vp, ci, vp, C.c_float, vp, ci]
+    lib.sslam_seg_segment_batch.restype = ci
+    lib.sslam_seg_segment_batch.argtypes = [vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, vp, ci, vp]
+    lib.sslam_seg_last_overflow.restype = ci; lib.sslam_seg_last_overflow.argtypes = [vp, C.POINTER(ci), C.POINTER(ci), C.POINTER(ci)]
     lib.sslam_seg_get_normals.restype = ci; lib.sslam_seg_get_normals.argtypes = [vp, ci, vp]
     lib.sslam_seg_get_labels.restype = ci; lib.sslam_seg_get_labels.argtypes = [vp, ci, vp]
     lib.sslam_seg_last_timing.restype = ci; lib.sslam_seg_last_timing.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double)]
@@ -114,6 +121,17 @@ class PointCloudSegmentation:
             cloud, width, height, point_step, row_step, offsets = f.cloud, f.width, f.height, f.point_step, f.row_step, f.offsets
         else:
             cloud = np.ascontiguousarray(point_cloud, np.uint8)
+        boxes = self._boxes(object_info)
+        pose = np.ascontiguousarray(robot_pose, np.float32).reshape(6)
+        out = (Plane * max_planes)()
+        n = self._check(self._lib.sslam_seg_segment(self._h, cloud.ctypes.data, width, height, point_step, row_step,
+                                                    offsets[0], offsets[1], offsets[2], C.cast(boxes, C.c_void_p), len(boxes),
+                                                    pose.ctypes.data, C.c_float(cam_angle), C.cast(out, C.c_void_p), max_planes))
+        self._last_boxes = boxes
+        return self._objects(out, n)
+
+    @staticmethod
+    def _boxes(object_info):
         boxes = (Box * len(object_info))()
         for k, o in enumerate(object_info):
             cls = o[4]
@@ -121,12 +139,10 @@ class PointCloudSegmentation:
                 name = cls.decode() if isinstance(cls, bytes) else cls
                 cls = CLASS_NAMES.index(name) if name in CLASS_NAMES else 0
             boxes[k] = Box(int(o[0]), int(o[1]), int(o[2]), int(o[3]), int(cls), float(o[5]))
-        pose = np.ascontiguousarray(robot_pose, np.float32).reshape(6)
-        out = (Plane * max_planes)()
-        n = self._check(self._lib.sslam_seg_segment(self._h, cloud.ctypes.data, width, height, point_step, row_step,
-                                                    offsets[0], offsets[1], offsets[2], C.cast(boxes, C.c_void_p), len(boxes),
-                                                    pose.ctypes.data, C.c_float(cam_angle), C.cast(out, C.c_void_p), max_planes))
-        self._last_boxes = boxes
+        return boxes
+
+    @staticmethod
+    def _objects(out, n):
         res = []
         for k in range(n):
             p = out[k]
@@ -136,6 +152,43 @@ class PointCloudSegmentation:
                                       normal_orientation=np.array(p.normal_d, np.float32), box_index=p.box_index,
                                       inlier_count=p.inlier_count, area=p.area))
         return res
+
+    def segment_frames(self, frames, max_planes: int = 4096):
+        """Several frames (``synth.SynthFrame``-like objects with robot_pose / cam_angle / boxes) in ONE pass over the GPU
+        (``sslam_seg_segment_batch``): the boxes of all frames share every kernel launch.  Returns a list (per frame) of lists of
+        planes, identical to calling ``segmentallPointCloudData`` frame by frame."""
+        F = len(frames)
+        if F == 0:
+            return []
+        f0 = frames[0]
+        fr = (Frame * F)()
+        keep = []
+        for k, f in enumerate(frames):
+            assert (f.width, f.height, f.point_step, f.row_step, tuple(f.offsets)) == (f0.width, f0.height, f0.point_step, f0.row_step, tuple(f0.offsets))
+            boxes = self._boxes(f.boxes)
+            pose = np.ascontiguousarray(f.robot_pose, np.float32).reshape(6)
+            keep.append((boxes, f.cloud))
+            fr[k].cloud = f.cloud.ctypes.data; fr[k].boxes = C.cast(boxes, C.c_void_p); fr[k].n_boxes = len(boxes)
+            for q in range(6):
+                fr[k].robot_pose[q] = float(pose[q])
+            fr[k].cam_angle = float(f.cam_angle)
+        out = (Plane * max_planes)()
+        which = np.zeros(max_planes, np.int32)
+        n = self._check(self._lib.sslam_seg_segment_batch(self._h, C.cast(fr, C.c_void_p), F, f0.width, f0.height, f0.point_step, f0.row_step,
+                                                          f0.offsets[0], f0.offsets[1], f0.offsets[2], C.cast(out, C.c_void_p), max_planes,
+                                                          which.ctypes.data))
+        self._last_boxes = keep[0][0]
+        objs = self._objects(out, n)
+        res = [[] for _ in range(F)]
+        for k, o in enumerate(objs):
+            res[int(which[k])].append(o)
+        return res
+
+    def last_overflow(self):
+        """(planes dropped because max_planes was reached, boxes with a full candidate table, boxes with a full region table)"""
+        a, b, c = C.c_int(0), C.c_int(0), C.c_int(0)
+        self._lib.sslam_seg_last_overflow(self._h, C.byref(a), C.byref(b), C.byref(c))
+        return a.value, b.value, c.value
 
     def ransac_plane(self, xyz, threshold: float = 0.01, max_iterations: int = 50, probability: float = 0.99, seed: int = 0):
         """pcl::SACSegmentation plane RANSAC of plane_segmentation::compute2DConvexHull (plane_segmentation.cpp:639-647).

@@ -317,6 +317,31 @@ def test_large_batch_of_unequal_graphs_matches_individual(gpu_lib):
         assert np.abs(G1.estimates() - G2.estimates()).max() < 1e-9
 
 
+def test_edge_shards_sum_to_the_full_system(gpu_lib):
+    """SURVEY 8e mode E on one device: the partial normal equations of the edge shards of 3 ranks (graph-local edge ranges
+    identical to distributed.shard_range) add up to the full [H || b]; with world = 1 the mode is off again."""
+    from semantic_slam_amd import GraphSLAM, GraphBatch
+    from semantic_slam_amd.distributed import shard_range
+    gps = [GraphProblem.from_synth(make_graph(80, 15, seed=31), interleave=True), GraphProblem.from_synth(make_graph(50, 9, seed=32, landmark_kind="plane"))]
+    B = GraphBatch([GraphSLAM.from_problem(gp) for gp in gps]); B.upload()
+    full = B.linearize_hb()
+    assert np.abs(full).max() > 0
+    parts = []
+    for r in range(3):
+        B.set_edge_shard(r, 3)
+        parts.append(B.linearize_hb())
+    tot = parts[0] + parts[1] + parts[2]
+    assert np.abs(tot - full).max() <= 1e-12 * np.abs(full).max()
+    assert all(np.abs(p).max() > 0 and np.abs(p - full).max() > 0 for p in parts)
+    # the first rank's share of graph 0 is exactly the oracle system of that edge range
+    lo, hi = shard_range(gps[0].ne, 0, 3)
+    assert (lo, hi) == (0, (gps[0].ne + 2) // 3)
+    B.set_edge_shard(0, 1)
+    assert np.array_equal(B.linearize_hb(), full)
+    st = B.optimize(4)
+    assert st[0].iterations == 4 and st[0].chi2_after < st[0].chi2_before
+
+
 def test_marginals_match_oracle(gpu_lib):
     from semantic_slam_amd import GraphSLAM
     g = make_graph(40, 8, seed=6)

@@ -97,6 +97,27 @@ def test_salt_and_pepper_nans_match_oracle(gpu_lib):
         off += n
 
 
+def test_batched_frames_equal_frame_by_frame(gpu_lib):
+    """sslam_seg_segment_batch: the boxes of several frames packed into one pass give exactly the per-frame results
+    (plane records bit for bit), including a frame without any accepted box; nothing is truncated."""
+    from semantic_slam_amd.segmentation import PointCloudSegmentation
+    frames = [make_frame(seed=s, n_boxes=nb) for s, nb in ((0, 32), (1, 12), (2, 32), (3, 8))]
+    frames[3].boxes["class_id"][:] = 0                      # every box of this frame is rejected by the class whitelist
+    seg = PointCloudSegmentation()
+    single = [seg.segmentallPointCloudData(f.robot_pose, f.cam_angle, f.boxes, f) for f in frames]
+    seg2 = PointCloudSegmentation()
+    batched = seg2.segment_frames(frames)
+    assert seg2.last_overflow() == (0, 0, 0)
+    assert [len(x) for x in batched] == [len(x) for x in single] and sum(len(x) for x in single) > 5 and len(batched[3]) == 0
+    for a_list, b_list in zip(batched, single):
+        for a, b in zip(a_list, b_list):
+            assert (a.box_index, a.inlier_count, a.num_points, a.area, a.plane_type, a.type) == (b.box_index, b.inlier_count, b.num_points, b.area, b.plane_type, b.type)
+            assert np.array_equal(a.pose, b.pose) and np.array_equal(a.normal_orientation, b.normal_orientation) and np.array_equal(a.world_pose, b.world_pose)
+    # max_out smaller than the number of planes: the rest is counted, not silently lost
+    few = seg2.segment_frames(frames, max_planes=3)
+    assert sum(len(x) for x in few) == 3 and seg2.last_overflow()[0] == sum(len(x) for x in single) - 3
+
+
 def test_ragged_and_rejected_boxes(gpu_lib):
     """Class filter (point_cloud_segmentation.h:126-130), out-of-bounds crop (plane_segmentation.cpp:34-38),
     too few points (:93-95), an empty box list, mixed box sizes."""
