@@ -67,12 +67,17 @@ def timed_optimize(batch, steps, warmup, sync_all):
     return stats, time.perf_counter() - t0
 
 
-def bench_frontend(device, frames=8, cpu_baseline=True):
-    """planes/sec on synthetic 640x480 clouds with 32 detection boxes of 128x96 px (BASELINE.json configs[3])."""
+def bench_frontend(device, frames=8, cpu_baseline=True, batch_frames=32, dist=None, ddev=None):
+    """planes/sec on synthetic 640x480 clouds with 32 detection boxes of 128x96 px (BASELINE.json configs[3]).
+    Headline: `batch_frames` frames per pass through ONE handle (sslam_seg_segment_batch: the boxes of all frames share every
+    launch; 32 frames x 12.6 MB of box pixels = 400 MB, beyond the 256 MiB MALL).  With N ranks the frames shard across ranks
+    (no collective) and the planes/s of all ranks are summed."""
     import numpy as np
     from semantic_slam_amd.segmentation import PointCloudSegmentation
+    from semantic_slam_amd import distributed as D
     from semantic_slam_amd.synth import make_frame
-    fs = [make_frame(seed=s) for s in range(3)]
+    rank = int(os.environ.get("RANK", "0"))
+    fs = [make_frame(seed=100 * rank + s) for s in range(4)]
     seg = PointCloudSegmentation(device=device)
     for f in fs:
         seg.segmentallPointCloudData(f.robot_pose, f.cam_angle, f.boxes, f)  # warm-up (allocation)
@@ -84,34 +89,36 @@ def bench_frontend(device, frames=8, cpu_baseline=True):
         kms += seg.last_timing()[0]
     wall = time.perf_counter() - t0
     npx = int(sum(int(b["width"]) * int(b["height"]) for b in fs[0].boxes))
-    res = {"workload": "synthetic 640x480 organised cloud, 32 boxes of 128x96 px per frame (BASELINE.json configs[3])",
-           "frames": frames, "planes": nplanes, "planes_per_frame": round(nplanes / frames, 2),
-           "planes_per_sec_kernels": round(nplanes / (kms * 1e-3), 1), "frames_per_sec_kernels": round(frames / (kms * 1e-3), 1),
-           "planes_per_sec_incl_pcie_and_host": round(nplanes / wall, 1), "kernel_ms_per_frame": round(kms / frames, 4),
-           "algorithmic_bytes_per_frame": 32 * npx,
-           "achieved_GBps": round(32 * npx / (kms / frames * 1e-3) / 1e9, 3)}
-    import threading
-    nh = 8
-    segs = [PointCloudSegmentation(device=device) for _ in range(nh)]
-    for sg in segs:
-        sg.segmentallPointCloudData(fs[0].robot_pose, fs[0].cam_angle, fs[0].boxes, fs[0])
-    counts = [0] * nh
-
-    def work(i):
-        for k in range(frames):
-            f = fs[(i + k) % len(fs)]
-            counts[i] += len(segs[i].segmentallPointCloudData(f.robot_pose, f.cam_angle, f.boxes, f))
-    ths = [threading.Thread(target=work, args=(i,)) for i in range(nh)]
-    t2 = time.perf_counter()
-    for t in ths:
-        t.start()
-    for t in ths:
-        t.join()
-    wall_c = time.perf_counter() - t2
-    res["concurrent_handles"] = {"handles": nh, "frames": nh * frames,
-                                 "planes_per_sec_incl_pcie_and_host": round(sum(counts) / wall_c, 1),
-                                 "frames_per_sec": round(nh * frames / wall_c, 1)}
-    del segs
+    res = {"workload": "synthetic 640x480 organised cloud (depth noise 1.5e-3 z^2, clustered drop-outs), 32 boxes of 128x96 px per frame "
+                       "(BASELINE.json configs[3])",
+           "single_frame_calls": {"frames": frames, "planes_per_frame": round(nplanes / frames, 2),
+                                  "planes_per_sec_kernels": round(nplanes / (kms * 1e-3), 1), "frames_per_sec_kernels": round(frames / (kms * 1e-3), 1),
+                                  "planes_per_sec_incl_pcie_and_host": round(nplanes / wall, 1), "kernel_ms_per_frame": round(kms / frames, 4)},
+           "algorithmic_bytes_per_frame": 32 * npx}
+    # batched frames through one handle
+    bf = [fs[k % len(fs)] for k in range(batch_frames)]
+    seg.segment_frames(bf)                                                   # warm-up (allocation)
+    reps, bpl, bk = 3, 0, 0.0
+    if dist is not None:
+        import torch
+        torch.cuda.synchronize(); dist.barrier()
+    t1 = time.perf_counter()
+    for _ in range(reps):
+        bpl += sum(len(x) for x in seg.segment_frames(bf))
+        bk += seg.last_timing()[0]
+    if dist is not None:
+        import torch
+        torch.cuda.synchronize(); dist.barrier()
+    bwall = D.max_over_ranks(time.perf_counter() - t1, device=ddev)
+    kern_s = D.max_over_ranks(bk * 1e-3, device=ddev)
+    tot_planes = D.aggregate_throughput(float(bpl), 1.0, device=ddev)
+    tot_frames = D.aggregate_throughput(float(reps * batch_frames), 1.0, device=ddev)
+    gbs = 32 * npx * tot_frames / kern_s / 1e9
+    res["batched"] = {"frames_per_call": batch_frames, "calls": reps, "planes_per_frame": round(bpl / (reps * batch_frames), 2),
+                      "planes_per_sec_kernels": round(tot_planes / kern_s, 1), "frames_per_sec_kernels": round(tot_frames / kern_s, 1),
+                      "planes_per_sec_incl_pcie_and_host": round(tot_planes / bwall, 1), "kernel_ms_per_frame": round(1e3 * kern_s / (reps * batch_frames), 4),
+                      "achieved_GBps": round(gbs, 2), "hbm_frac": round(gbs / PEAK_HBM_GBS, 5), "truncated": list(seg.last_overflow())}
+    res["planes_per_sec"] = res["batched"]["planes_per_sec_kernels"]
     if cpu_baseline:
         from oracle.oracle import segment_frame   # cpu_baseline leg only
         t1 = time.perf_counter(); np_cpu = 0; nf = 0
@@ -136,6 +143,9 @@ def main():
     ap.add_argument("--distinct", type=int, default=4, help="distinct seeds generated per rank (tiled to --batch)")
     ap.add_argument("--solver", type=int, default=-1, help="-1 library default, 0 PCG, 1 sparse Cholesky")
     ap.add_argument("--plane-batch", type=int, default=64, help="graphs in the plane-landmark leg (0 = skip)")
+    ap.add_argument("--edge-sharded", action="store_true",
+                    help="N > 1: every rank holds the SAME batch, builds the partial normal equations of its edge shard and the ranks "
+                         "all-reduce [H || b] over RCCL each LM step (SURVEY 8e mode E / BASELINE.json configs[4]); strong scaling")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-frontend", action="store_true")
     ap.add_argument("--no-single", action="store_true", help="skip the single-graph latency section (used under rocprofv3 --pmc)")
@@ -167,10 +177,12 @@ def main():
             torch.cuda.synchronize()
             dist.barrier()
 
+    sharded = bool(args.edge_sharded and world > 1)
+
     def write_graphs(kind, n_distinct, tmpdir):
         paths, problems = [], []
         for d in range(n_distinct):
-            g = make_graph(args.poses, args.landmarks, seed=1000 * rank + d, landmark_kind=kind)
+            g = make_graph(args.poses, args.landmarks, seed=(0 if sharded else 1000 * rank) + d, landmark_kind=kind)
             gp = GraphProblem.from_synth(g)
             problems.append(gp)
             G0 = GraphSLAM.from_synth(g, device=dev)
@@ -185,6 +197,8 @@ def main():
     tmpdir = tempfile.mkdtemp(prefix="sslam_bench_")
     paths, problems = write_graphs("point", max(1, min(args.distinct, args.batch)), tmpdir)
     batch = build_batch(paths, args.batch, dev, args.solver)
+    if sharded:
+        D.init_edge_sharded(batch, device=ddev)   # RCCL communicator inside the library; all-reduce issued from the C++ LM loop
     setup_s = time.time() - t_setup
 
     # ---- warmup (untimed), reset to the initial estimates, K timed steps ---------------------------
@@ -202,7 +216,7 @@ def main():
     iters_total = float(sum(iters))
     steps_done = max(iters) if iters else 0
     # whole-job value: graph-iterations actually performed by ALL ranks / max-over-ranks time (replicas: no data-path collective)
-    value = D.aggregate_throughput(iters_total, dt, device=ddev)
+    value = iters_total / dt if sharded else D.aggregate_throughput(iters_total, dt, device=ddev)
 
     # ---- kernel times (hipEvents on the batch's stream, inside the timed region) -------------------
     names = ["linearize", "chi2", "spmv", "pcg_update", "precond", "oplus", "factor", "solve"]
@@ -251,13 +265,14 @@ def main():
     out = {
         "metric": "graph-optimize LM iters/sec (5k poses, 1k landmarks)",
         "value": round(value, 3), "unit": "iters/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(1e3 * dt / max(steps_done, 1), 4), "higher_is_better": True, "scaling": "weak",
+        "ms_per_step": round(1e3 * dt / max(steps_done, 1), 4), "higher_is_better": True, "scaling": "strong" if sharded else "weak",
         "vs_baseline": None, "dtype": "f64", "data": f"synthetic ({len(paths)} distinct seeds per GPU tiled to the batch)",
         "config": {"workload": f"synthetic {args.poses}-pose / {args.landmarks}-landmark graph with loop closures "
                                f"(BASELINE.json configs[2]), batch of {args.batch} independent graphs per GPU, point landmarks "
                                f"(EdgeSE3PointXYZ, the reference's live landmark type)",
                    "graphs_per_gpu": args.batch, "se3_edges": Eo, "landmark_edges": El,
-                   "solver": int(args.solver), "parallelism": f"replicas x{world}"},
+                   "solver": int(args.solver),
+                   "parallelism": (f"edge-sharded x{world}: RCCL all-reduce of [H || b] per LM step" if sharded else f"replicas x{world}")},
         "steps_done": steps_done, "iters_min": min(iters), "iters_max": max(iters),
         "graphs_terminated": int(sum(1 for s in stats if s.status == 1)),
         "timed_seconds": round(dt, 4),
@@ -271,7 +286,17 @@ def main():
         out["roofline_factor"] = roof_factor
     del batch
 
+    frontend = None
+    if not args.no_frontend:   # every rank: the frames shard across ranks
+        try:
+            frontend = bench_frontend(dev, cpu_baseline=(not args.no_cpu_baseline and world == 1 and rank == 0), dist=dist, ddev=ddev)
+        except Exception as e:
+            if dist is not None:
+                raise
+            frontend = {"error": str(e)[:200]}
     if rank == 0:
+        if frontend is not None:
+            out["frontend"] = frontend
         if not args.no_single:
             # ---- single-graph latency (same graph, batch of one) -----------------------------------
             b1 = build_batch(paths[:1], 1, dev, args.solver)
@@ -324,11 +349,6 @@ def main():
             dA = time.perf_counter() - tA
             out["cpu_baseline_multicore"] = {"value": round(its / dA, 3), "unit": "iters/s", "cores": ncore, "kind": "port",
                                              "sample": f"{its} LM iterations over {ncore} threads in {dA:.1f} s, independent graphs (same oracle)"}
-        if not args.no_frontend:
-            try:
-                out["frontend"] = bench_frontend(dev, cpu_baseline=(not args.no_cpu_baseline and world == 1))
-            except Exception as e:
-                out["frontend"] = {"error": str(e)[:200]}
         print(json.dumps(out))
         sys.stdout.flush()
     if dist is not None:
