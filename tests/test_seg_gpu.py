@@ -75,7 +75,7 @@ def test_noise_free_planes_are_recovered(gpu_lib):
                     continue
                 d = np.abs(pts[m] @ n4[:3] + n4[3])
                 if best is None or np.median(d) < best[0]:
-                    best = (float(np.median(d)), float(d.max()), int(m.sum()), float((0.02 * pts[m][:, 2] ** 2).max()))
+                    best = (float(np.median(d)), float(d.max()), int(m.sum()), float((0.02 * pts[m][:, 2] ** 2).max()), int((d < 5e-3).sum()))
             assert best is not None
             med, dmax, npx, bound, close = best
             assert npx == p.inlier_count
