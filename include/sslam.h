@@ -275,6 +275,88 @@ int sslam_seg_last_timing(const sslam_seg* s, double* kernel_ms, double* total_m
 /* semantic_tools::transformNormalsToWorld (include/tools.h:18-102): 4x4 row-major float */
 int sslam_seg_transform(const sslam_seg* s, const float robot_pose[6], float cam_angle, float out16[16]);
 
+
+/* ============================================================================================
+ * Orchestrator tick without ROS: semantic_graph_slam (reference include/ps_graph_slam/semantic_graph_slam.h,
+ * src/ps_graph_slam/semantic_graph_slam.cpp) + KeyframeUpdater (keyframe_updater.hpp:41-65) + data_association
+ * (data_association.h:70-389) + InformationMatrixCalculator (information_matrix_calculator.cpp:28-35).  SURVEY §8 rows f3, f2.
+ * The ROS node becomes a thin shell: its callbacks call the set_* / vio entry points, its 30 Hz loop calls sslam_slam_run.
+ * ==========================================================================================*/
+typedef struct sslam_slam sslam_slam;
+
+typedef struct sslam_slam_params {
+  double keyframe_delta_trans, keyframe_delta_angle, keyframe_delta_time; /* 0.5, 0.5, 1 (keyframe_updater.hpp:24-29) */
+  int max_keyframes_per_update;          /* 10 (semantic_graph_slam.cpp:18) */
+  int update_keyframes_using_detections; /* ~update_key_using_det, false (semantic_graph_slam.cpp:22-23) */
+  double camera_angle_deg;               /* ~camera_angle, degrees (semantic_graph_slam.cpp:24,29) */
+  int add_first_lan;                     /* ~add_first_lan (semantic_graph_slam.cpp:25,54-55,289-329) */
+  double first_lan[3];                   /* 1.8, 0, 0.3 */
+  int use_const_inf_matrix;              /* information_matrix_calculator.cpp:9,29 */
+  double const_stddev_x, const_stddev_q; /* 0 -> 0.0667 (information_matrix_calculator.cpp:11-17) */
+  double maha_dist_thres, eq_dist_thres; /* 0.5, 1.21 (data_association.h:49-50) */
+  double land_noise_low, land_noise_high;/* 0.5, 0.9  (data_association.h:51-52) */
+  int use_maha_dist, use_eq_dist, use_rtab_map_odom; /* true, false, false (data_association.h:53-55) */
+  int max_iterations;                    /* 1024 (graph_slam.cpp:205) */
+  int reference_quirks;                  /* bit 0: keep distance_min across the detections of a frame (quirk B5, data_association.h:101);
+                                            default 0 = reset per detection */
+  int device;
+} sslam_slam_params;
+
+/* data_association's landmark (include/ps_graph_slam/landmark.h:17-33) */
+typedef struct sslam_landmark {
+  int32_t id;            /* index in the landmark list */
+  int32_t vertex;        /* graph vertex id of landmark::node (-1 before it is added) */
+  int32_t class_id;      /* landmark::type */
+  int32_t plane_type;    /* landmark::plane_type: 0 horizontal, 1 vertical */
+  int32_t is_new;
+  float pose[3];         /* world position the landmark was created / last observed at */
+  float local_pose[3];   /* observation in the robot frame (the edge measurement) */
+  float covariance[9];   /* 3x3, row-major: marginal of the last optimisation (getAndSetLandmarkCov) */
+  float normal[4];       /* normal_orientation in the world frame */
+  float distance;        /* association distance of the observation that produced this record (extension) */
+} sslam_landmark;
+
+typedef struct sslam_tick_stats {
+  int keyframes_added;     /* <= max_keyframes_per_update */
+  int landmarks_added, landmarks_matched, landmark_edges_added;
+  int optimized;           /* GraphSLAM::optimize() returned true */
+  int marginals_ok;        /* computeLandmarkMarginals returned true */
+  sslam_opt_stats opt;
+  double seconds_frontend, seconds_association, seconds_optimize, seconds_marginals;
+} sslam_tick_stats;
+
+void sslam_slam_default_params(sslam_slam_params* p);
+/* semantic_graph_slam::init (semantic_graph_slam.cpp:11-56).  seg: the frontend handle used for keyframes that carry a cloud and
+ * boxes (NULL when every keyframe brings pre-segmented objects); it is borrowed, not owned. */
+sslam_slam* sslam_slam_create(const sslam_slam_params* p, sslam_seg* seg);
+void sslam_slam_destroy(sslam_slam* s);
+/* setPointCloudData (semantic_graph_slam.cpp:341-345): the cloud is copied */
+int sslam_slam_set_point_cloud(sslam_slam* s, const uint8_t* cloud, int width, int height, int point_step, int row_step,
+                               int off_x, int off_y, int off_z);
+/* setDetectedObjectInfo (semantic_graph_slam.cpp:353-357) */
+int sslam_slam_set_detected_objects(sslam_slam* s, const sslam_box* boxes, int n_boxes);
+/* extension: objects segmented elsewhere (e.g. by one sslam_seg_segment_batch call over a recorded sequence) for the next keyframe;
+ * they replace the frontend call of semantic_data_ass (semantic_graph_slam.cpp:217-219) and count as an available detection */
+int sslam_slam_set_segmented_objects(sslam_slam* s, const sslam_plane* objects, int n);
+/* VIOCallback (semantic_graph_slam.cpp:234-287): keyframe gate, dead-reckoned robot pose, queue.  Returns 1 when the odometry sample
+ * became a keyframe, 0 when the gate rejected it. */
+int sslam_slam_vio(sslam_slam* s, int32_t stamp_sec, int32_t stamp_nsec, const double odom_tq[7]);
+/* run (semantic_graph_slam.cpp:58-102): returns 1 when keyframes were processed, 0 when the queue was empty */
+int sslam_slam_run(sslam_slam* s, sslam_tick_stats* stats);
+/* getRobotPose / getMap2OdomTrans / getVIOPose (semantic_graph_slam.cpp:375-381,333-339) */
+int sslam_slam_robot_pose(const sslam_slam* s, double tq[7]);
+int sslam_slam_map2odom(const sslam_slam* s, double tq[7]);
+/* getMappedLandmarks (semantic_graph_slam.cpp:366-368): returns the number of landmarks (copies min(n, max)) */
+int sslam_slam_landmarks(const sslam_slam* s, sslam_landmark* out, int max);
+/* getKeyframes (semantic_graph_slam.cpp:370-373): graph vertex ids and current estimates (7 doubles each) of the processed keyframes */
+int sslam_slam_keyframes(const sslam_slam* s, int32_t* vertex_ids, double* estimates_tq, int max);
+/* the underlying GraphSLAM (saveGraph, semantic_graph_slam.cpp:391-394; borrowed) */
+sslam_graph* sslam_slam_graph(sslam_slam* s);
+/* data_association::find_matches (data_association.h:75-95) on its own: associates n segmented objects seen from robot_pose
+ * (x,y,z,roll,pitch,yaw) against the mapped landmarks ON THE DEVICE and appends the new ones to the landmark list (without adding
+ * graph vertices: parity hook for the association kernel).  out = n records. */
+int sslam_slam_find_matches(sslam_slam* s, const sslam_plane* objects, int n, const float robot_pose[6], sslam_landmark* out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -371,3 +371,74 @@ def make_frame(seed: int = 0, width: int = 640, height: int = 480, n_boxes: int 
     pose = np.array([rng.uniform(-1, 1), rng.uniform(-1, 1), 1.3, 0.0, 0.0, rng.uniform(-np.pi, np.pi)], np.float32)
     return SynthFrame(buf.reshape(-1).view(np.uint8).copy(), width, height, point_step, point_step * width, (0, 4, 8), boxes,
                       pose, float(pitch))
+
+
+# ----------------------------------------------------------------------------
+# recorded-run stand-in for the orchestrator tick
+# ----------------------------------------------------------------------------
+
+@dataclasses.dataclass
+class ReplayEvent:
+    """One odometry sample of a synthetic run: what the node's callbacks would have received before ``VIOCallback``."""
+    stamp: tuple                 # (sec, nsec)
+    odom: np.ndarray             # [t, q(x,y,z,w)] drifting odometry
+    true_pose: np.ndarray        # [t, q] ground truth (not shown to the system)
+    objects: list | None         # segmented objects seen from this pose (dicts: pose, normal, class_id, plane_type) or None
+    run_after: bool              # the node's loop calls run() after this sample
+
+
+def make_replay(seed: int = 0, n_samples: int = 400, n_landmarks: int = 24, *, rate_hz: float = 10.0, speed: float = 1.0,
+                detect_every: int = 1, detect_from: int = 130, run_every: int = 1, first_run_at: int = 130, view_range: float = 4.0,
+                meas_sigma: float = 0.02, odom_sigma_t: float = 0.002, odom_sigma_r: float = 0.0005):
+    """A robot driving a closed planar loop past point landmarks of two classes and two plane types, sampled at ``rate_hz``:
+    drifting odometry (what ``VIOCallback`` gets, semantic_graph_slam.cpp:234), and every ``detect_every`` samples the objects the
+    frontend would have returned for that view (centroid in the camera frame, z forward / x right / y down, the frame
+    ``transformNormalsToWorld`` maps from, tools.h:18-102).  ``run()`` is withheld until ``first_run_at`` so that the first tick
+    finds more than ``max_keyframes_per_update`` keyframes queued (semantic_graph_slam.cpp:113-116); detections start at
+    ``detect_from`` (before the first tick every keyframe carries robot_pose_ = identity, semantic_graph_slam.cpp:46,274-276, and a
+    keyframe's own odometry increment never reaches robot_pose_, :239-262 -- with detections inside a stall the association works
+    on those stale poses, which the parity tests exercise separately)."""
+    rng = np.random.default_rng(seed)
+    R = max(speed * n_samples / rate_hz / (2 * np.pi * 1.15), 3.0)   # 1.15 laps: the first landmarks are seen again at the end
+    s = np.arange(n_samples) * speed / rate_hz / R
+    xy = np.stack([R * np.cos(s) - R, R * np.sin(s)], -1)
+    yaw = s + np.pi / 2
+    true = np.zeros((n_samples, 7))
+    true[:, :2] = xy
+    true[:, 5] = np.sin(yaw / 2); true[:, 6] = np.cos(yaw / 2)
+    # drifting odometry: noisy increments of the true motion
+    odom = np.zeros_like(true); odom[0] = true[0]
+    for k in range(1, n_samples):
+        inc = pose_compose(pose_inverse(true[k - 1]), true[k])
+        inc[:3] += rng.normal(0, odom_sigma_t, 3) * np.array([1, 1, 0])
+        inc[3:] = quat_mul(inc[3:], quat_from_rotvec(rng.normal(0, odom_sigma_r, 3) * np.array([0, 0, 1])))
+        odom[k] = pose_compose(odom[k - 1], inc)
+    # landmarks in a band around the track, at least 2.2 m apart
+    lms = []
+    tries = 0
+    while len(lms) < n_landmarks and tries < 20000:
+        tries += 1
+        a = rng.uniform(0, 2 * np.pi); r = R + rng.choice([-1, 1]) * rng.uniform(1.0, 2.5)
+        p = np.array([r * np.cos(a) - R, r * np.sin(a), rng.uniform(0.2, 1.2)])
+        if all(np.linalg.norm(p - q[0]) > 2.2 for q in lms):
+            lms.append((p, int(rng.integers(1, 3)), int(rng.integers(0, 2))))
+    # camera axes in the robot frame: Rz(-90) Rx(-90) (tools.h:104-135 with zero camera pitch)
+    c2r = np.array([[0.0, 0.0, 1.0], [-1.0, 0.0, 0.0], [0.0, -1.0, 0.0]])
+    events = []
+    for k in range(n_samples):
+        objs = None
+        if k % detect_every == 0 and k >= detect_from:
+            objs = []
+            for p, cls, pt in lms:
+                pr = quat_rotate(quat_conj(true[k, 3:]), p - true[k, :3])
+                d = np.linalg.norm(pr[:2])
+                if 0.5 < d < view_range and abs(np.arctan2(pr[1], pr[0])) < np.pi / 3:
+                    pc = c2r.T @ pr + rng.normal(0, meas_sigma, 3)
+                    nrm = rng.normal(size=3); nrm /= np.linalg.norm(nrm)
+                    objs.append(dict(pose=pc.astype(np.float32), normal=np.append(nrm, rng.uniform(-2, 2)).astype(np.float32),
+                                     class_id=cls, plane_type=pt))
+        t = k / rate_hz
+        sec = int(np.floor(t + 1e-9)); nsec = int(round((t - sec) * 1e9))
+        events.append(ReplayEvent((sec, nsec), odom[k], true[k], objs, k >= first_run_at and (k - first_run_at) % run_every == 0))
+    events[-1].run_after = True
+    return events, lms

@@ -1,0 +1,80 @@
+"""CPU tests of the orchestrator oracle (oracle/np_slam.py) -- the checker the GPU parity tests of rows f3 / f2 rely on --
+against properties the reference's code implies; no GPU, no product code."""
+import numpy as np
+
+from semantic_slam_amd.synth import make_replay
+from tests.slam_replay import oracle_instance, feed
+from oracle import np_slam as S
+
+
+def test_keyframe_gate_follows_the_three_thresholds():
+    """keyframe_updater.hpp:41-65: first sample always; afterwards only when 1 s, 0.5 m or 0.5 rad (acos of the quaternion w) passed"""
+    o = oracle_instance()
+    I = np.array([0, 0, 0, 0, 0, 0, 1.0])
+    assert o.vio(0, 0, I)
+    assert not o.vio(0, 500000000, I + np.array([0.4, 0, 0, 0, 0, 0, 0]))
+    assert o.vio(0, 600000000, I + np.array([0.5, 0, 0, 0, 0, 0, 0]))          # translation
+    assert not o.vio(1, 500000000, I + np.array([0.5, 0, 0, 0, 0, 0, 0]))      # 0.9 s: Duration.sec == 0
+    assert o.vio(1, 600000000, I + np.array([0.5, 0, 0, 0, 0, 0, 0]))          # 1.0 s
+    a = 1.02                                                                     # rotation by 1.02 rad: acos(w) = 0.51
+    assert o.vio(1, 700000000, np.array([0.5, 0, 0, 0, 0, np.sin(a / 2), np.cos(a / 2)]))
+    assert len(o.queue) == 4
+
+
+def test_tick_grows_the_graph_as_the_reference_does():
+    events, lms = make_replay(0, n_samples=300)
+    o = oracle_instance()
+    n_kf = 0
+    for ev in events:
+        k, ran = feed(o, ev, False)
+        n_kf += k
+        if ran:
+            st = o.last_stats
+            assert 1 <= st["keyframes_added"] <= 10
+            # every keyframe but the very first brings one odometry edge; every record one landmark edge
+            assert sum(1 for t in o.etype if t == S.O.ET_SE3) == len(o.keyframes) - 1
+            assert sum(1 for t in o.etype if t == S.O.ET_SE3_POINT) == sum(len(r) for r in _all_records(o))
+    assert len(o.keyframes) + len(o.queue) == n_kf
+    # the map: one landmark per true landmark seen, within the stale-pose error
+    tr = np.array([p for p, _, _ in lms])
+    est = np.array([o.est[l["vertex"]][:3] for l in o.assoc.landmarks])
+    d = np.linalg.norm(tr[None] - est[:, None], axis=2)
+    assert d.min(1).max() < 0.25 and len(set(d.argmin(1))) == len(est)
+    # map2odom * odom of the last keyframe = its optimised pose (semantic_graph_slam.cpp:94-95)
+    last = o.keyframes[-1]
+    assert np.allclose(o.map2odom @ last["odom"], S.tq_to_iso(o.est[last["node"]]), atol=1e-12)
+
+
+_RECORDS = {}
+
+
+def _all_records(o):
+    rec = _RECORDS.setdefault(id(o), [])
+    if o.last_stats is not None and (not rec or rec[-1] is not o.last_stats):
+        rec.append(o.last_stats)
+    return [r for st in rec for r in st["records"]]
+
+
+def test_mahalanobis_restatement_matches_a_double_precision_inverse():
+    rng = np.random.default_rng(0)
+    for _ in range(50):
+        A = rng.normal(size=(3, 3)); sig = (A @ A.T + 0.05 * np.eye(3)).astype(np.float32)
+        z = rng.normal(size=3).astype(np.float32)
+        ref = float(z.astype(float) @ np.linalg.inv(sig.astype(float) + 0.5 * np.eye(3)) @ z.astype(float))
+        assert abs(float(S.mahalanobis(sig, 0.5, z)) - ref) <= 2e-5 * max(1.0, ref)
+
+
+def test_same_frame_twin_matches_the_landmark_just_created_and_b5_carry():
+    pose = np.zeros(6, np.float32)
+    est = lambda l: l["pose"]
+    mk = lambda x, cls=1: dict(pose=np.array([x, 0, 2], np.float32), normal=np.array([0, 0, 1, 0], np.float32), class_id=cls, plane_type=0)
+    D = S.DataAssociation()
+    first = D.find_matches([mk(0.0), mk(0.0)], pose, np.float32(0), est)
+    assert [r["is_new"] for r in first] == [True, True]            # first_object: no association at all (data_association.h:79-86)
+    second = D.find_matches([mk(5.0), mk(5.0), mk(5.0, cls=2)], pose, np.float32(0), est)
+    assert [(r["is_new"], r["id"]) for r in second] == [(True, 2), (False, 2), (True, 3)]
+    # quirk B5: with the carried distance_min the second detection cannot beat the first one's zero distance
+    Dq = S.DataAssociation(keep_distance_min=True)
+    Dq.find_matches([mk(0.0)], pose, np.float32(0), est)
+    q = Dq.find_matches([mk(0.0), mk(0.1)], pose, np.float32(0), est)
+    assert [(r["is_new"], r["id"]) for r in q] == [(False, 0), (True, 1)]
