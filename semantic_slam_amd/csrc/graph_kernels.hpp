@@ -72,6 +72,7 @@ struct BatchView {
   // edges whose graph-local id lies in [shard_lo[g], shard_hi[g]); the partial [H || b] arrays are summed with one all-reduce
   const int* eo_id; const int* el_id;        // graph-local edge id of every SE3 / landmark edge
   const int* shard_lo; const int* shard_hi;  // [B]
+  int dbg = 0;                               // SSLAM_LIN_DBG: timing experiments only (results are wrong when set)
   // PCG vectors
   double* x; double* r; double* z; double* p; double* q; double* Minv;  // Minv: [nPr*36 | nLr*9]
   double* part_a; double* part_b; double* part_c;  // [B*maxChunks] partial sums

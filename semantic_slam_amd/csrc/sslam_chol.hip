@@ -973,7 +973,8 @@ int chol_backward(Batch& b) {
     if (n <= 0) continue;
     const size_t lds = (size_t)P.plv_lds_b[l] * sizeof(double);
 #define SSLAM_LAUNCH_BACK(NTV) hipLaunchKernelGGL(k_chol_back_pieces<NTV>, dim3(n), dim3(NTV), lds, b.stream, C, P.plv_ptr[l], (const double*)C.y, b.V.x, (const LmState*)b.V.lm);
-    switch (P.nt_leaf) {
+    static const int nt_back_env = [] { const char* e = getenv("SSLAM_CHOL_NT_BACK"); return e ? atoi(e) : 0; }();
+    switch (nt_back_env > 0 ? nt_back_env : P.nt_leaf) {
       case 128: SSLAM_LAUNCH_BACK(128) break;
       case 512: SSLAM_LAUNCH_BACK(512) break;
       case 1024: SSLAM_LAUNCH_BACK(1024) break;

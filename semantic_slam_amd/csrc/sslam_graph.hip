@@ -107,41 +107,95 @@ __device__ __forceinline__ Pose load_pose16(const double* a, int idx) {   // fou
   return Pose{{v0.a, v0.b, v1.a}, {v1.b, v2.a, v2.b, v3.a}};
 }
 
+// What one slot reads from HBM, fetched one slot ahead of its use (the loop below is a two-deep software pipeline: the slot
+// record two iterations ahead, the slot's operands one iteration ahead; with ~300 VGPRs only one wave fits a SIMD, so the
+// memory-level parallelism has to come from inside the thread).
+struct SlotData {
+  double o[8];    // EdgeSE3: the other vertex' pose record; landmark edge: the landmark (4 doubles)
+  double z[7];    // measurement
+  double w[21];   // information, upper triangle (21 / 6 values)
+  int blk, id, lk;
+};
+template <bool PL, bool SHARD>
+__device__ __forceinline__ void slot_fetch(const BatchView& V, const int4 rec, SlotData& D) {
+  const int e = rec.x, kind = rec.y & 15;
+  if (kind == 3) return;                       // contribution arrives by hand-over: nothing to read
+  if (kind != 2) {
+    const D2* p = reinterpret_cast<const D2*>(V.pose + (size_t)(kind == 0 ? rec.w : rec.z) * 8);
+    const D2 v0 = p[0], v1 = p[1], v2 = p[2], v3 = p[3];
+    D.o[0] = v0.a; D.o[1] = v0.b; D.o[2] = v1.a; D.o[3] = v1.b; D.o[4] = v2.a; D.o[5] = v2.b; D.o[6] = v3.a; D.o[7] = v3.b;
+    const size_t n = V.nEo;
+#pragma unroll
+    for (int k = 0; k < 7; ++k) D.z[k] = V.eo_z[k * n + e];
+#pragma unroll
+    for (int k = 0; k < 21; ++k) D.w[k] = V.eo_w[k * n + e];
+    D.blk = kind == 0 ? V.eo_blk[e] : -1;
+    if (SHARD) D.id = V.eo_id[e];
+  } else {
+    const D2* p = reinterpret_cast<const D2*>(V.lmk + (size_t)rec.w * 4);
+    const D2 v0 = p[0], v1 = p[1];
+    D.o[0] = v0.a; D.o[1] = v0.b; D.o[2] = v1.a; D.o[3] = v1.b;
+    const size_t n = V.nEl;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) D.z[k] = V.el_z[k * n + e];
+    if (PL) { D.z[3] = V.el_z[3 * n + e]; D.lk = V.lm_kind[rec.w]; }
+#pragma unroll
+    for (int k = 0; k < 6; ++k) D.w[k] = V.el_w[k * n + e];
+    D.blk = V.el_blk[e];
+    if (SHARD) D.id = V.el_id[e];
+  }
+}
+
 template <bool PL, bool SHARD>
 __global__ __launch_bounds__(kRowThreads) void k_linearize_rowthread(BatchView V) {
-  __shared__ double accD[27][kRowThreads];
+  __shared__ double accD[27][kRowThreads];    // this row's diagonal block (upper triangle) and rhs, thread-private column
+  __shared__ double accIn[27][kRowThreads];   // what the i-side thread of a paired EdgeSE3 hands to the row of its j vertex
   const int tid = threadIdx.x;
-  const int row = blockIdx.x * kRowThreads + tid;
-  if (row >= V.nPr) return;
-  if (!V.lm[V.prow_graph[row]].lin) return;
+  const int row0 = blockIdx.x * kRowThreads;
+  const int row = row0 + tid;
+  const bool active = row < V.nPr && V.lm[V.prow_graph[min(row, V.nPr - 1)]].lin;
 #pragma unroll
-  for (int k = 0; k < 27; ++k) accD[k][tid] = 0.0;
+  for (int k = 0; k < 27; ++k) { accD[k][tid] = 0.0; accIn[k][tid] = 0.0; }
+  if (active) {
   const int s0 = V.pslot_ptr[row], s1 = V.pslot_ptr[row + 1];
   const int own = V.prow_pose[row];
   const int sh_lo = SHARD ? V.shard_lo[V.prow_graph[row]] : 0, sh_hi = SHARD ? V.shard_hi[V.prow_graph[row]] : 0;
   const Pose Xown = load_pose16(V.pose, own);   // this row's vertex: loaded once, reused by every slot
+  const int4 kNone = make_int4(0, 3, 0, 0);
+  constexpr bool kPrefetch = !PL;   // the plane variant (central-difference Jacobians) has no registers to spare for a slot in flight
+  int4 rec = s0 < s1 ? V.pslot_rec[s0] : kNone;
+  int4 rec_next = s0 + 1 < s1 ? V.pslot_rec[s0 + 1] : kNone;
+  SlotData D;
+  slot_fetch<PL, SHARD>(V, rec, D);
   for (int s = s0; s < s1; ++s) {
-    const int4 rec = V.pslot_rec[s];
-    const int e = rec.x, kind = rec.y & 15, ia = rec.z, ib = rec.w;   // kind 3 (hand-over) is evaluated like kind 1 here
-    if (kind != 2) {
+    const int4 rec_next2 = s + 2 < s1 ? V.pslot_rec[s + 2] : kNone;
+    SlotData Dn;
+    if (kPrefetch) slot_fetch<PL, SHARD>(V, rec_next, Dn);
+    int kind = rec.y & 15;
+    if ((V.dbg & 4) && kind != 2) kind = 3;
+    if ((V.dbg & 8) && kind == 2) kind = 3;
+    if (kind == 3) {
+      // the i-side thread of this edge (same workgroup) evaluates it once and hands J_j^T Omega J_j, J_j^T Omega e over
+    } else if (kind != 2) {
       // EdgeSE3: both Jacobians are 2 x 2 block upper triangular in 3 x 3 blocks,
       //   J_i = [[-Ra, 2 Ra [tb]x], [0, Ci]],   J_j = [[Re, 0], [0, Fj]],
       // so J^T Omega J is formed from 3 x 3 products of the blocks (half the FMAs and a smaller live set than dense 6 x 6).
-      const int n = V.nEo;
       const bool iside = (kind == 0);
+      const bool hand = iside && ((rec.y >> 4) & 1);
       Se3Lin L;
-      se3_error(iside ? Xown : load_pose16(V.pose, ia), iside ? load_pose16(V.pose, ib) : Xown, load_meas_pose(V.eo_z, n, e), L);
+      const Pose Xo{{D.o[0], D.o[1], D.o[2]}, {D.o[3], D.o[4], D.o[5], D.o[6]}};
+      se3_error(iside ? Xown : Xo, iside ? Xo : Xown, Pose{{D.z[0], D.z[1], D.z[2]}, {D.z[3], D.z[4], D.z[5], D.z[6]}}, L);
       double P[9], Q[9], R[9];   // Omega = [[P, Q], [Q^T, R]]
       // edge-sharded mode: an edge outside this rank's range contributes nothing (everything below is linear in Omega; the owner
       // of an off-diagonal block still writes it, as zeros)
-      const double mk = (!SHARD || (V.eo_id[e] >= sh_lo && V.eo_id[e] < sh_hi)) ? 1.0 : 0.0;
+      const double mk = (!SHARD || (D.id >= sh_lo && D.id < sh_hi)) ? 1.0 : 0.0;
 #pragma unroll
       for (int r = 0; r < 3; ++r)
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-          P[r * 3 + c] = mk * V.eo_w[(size_t)(r <= c ? tri21(r, c) : tri21(c, r)) * n + e];
-          Q[r * 3 + c] = mk * V.eo_w[(size_t)tri21(r, 3 + c) * n + e];
-          R[r * 3 + c] = mk * V.eo_w[(size_t)(r <= c ? tri21(3 + r, 3 + c) : tri21(3 + c, 3 + r)) * n + e];
+          P[r * 3 + c] = mk * D.w[r <= c ? tri21(r, c) : tri21(c, r)];
+          Q[r * 3 + c] = mk * D.w[tri21(r, 3 + c)];
+          R[r * 3 + c] = mk * D.w[r <= c ? tri21(3 + r, 3 + c) : tri21(3 + c, 3 + r)];
         }
       double A[9], B[9], Cc[9];   // own Jacobian [[A, B], [0, Cc]]  (B = 0 on the j side)
       if (iside) {
@@ -169,6 +223,40 @@ __global__ __launch_bounds__(kRowThreads) void k_linearize_rowthread(BatchView V
         for (int q = 0; q < 9; ++q) E[q] = Re.m[q];
         F[0] = w; F[1] = -z; F[2] = y; F[3] = z; F[4] = w; F[5] = -x; F[6] = -y; F[7] = x; F[8] = w;
       }
+      if (hand) {
+        // the j side of the same edge, for the neighbouring row:  J_j^T Omega J_j = [[E^T P E, E^T Q F], [., F^T R F]],
+        // J_j^T Omega e = [E^T (P e_t + Q e_r); F^T (Q^T e_t + R e_r)]
+        const int tl = (tid & ~31) | ((rec.y >> 8) & 31);
+        double T1[9], T2[9], T3[9];   // E^T P, E^T Q, F^T R
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+          for (int c = 0; c < 3; ++c) {
+            double t1 = 0, t2 = 0, t3 = 0;
+#pragma unroll
+            for (int r = 0; r < 3; ++r) { t1 += E[r * 3 + a] * P[r * 3 + c]; t2 += E[r * 3 + a] * Q[r * 3 + c]; t3 += F[r * 3 + a] * R[r * 3 + c]; }
+            T1[a * 3 + c] = t1; T2[a * 3 + c] = t2; T3[a * 3 + c] = t3;
+          }
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+#pragma unroll
+          for (int c = 0; c < 3; ++c) {
+            double d11 = 0, d12 = 0, d22 = 0;
+#pragma unroll
+            for (int r = 0; r < 3; ++r) { d11 += T1[a * 3 + r] * E[r * 3 + c]; d12 += T2[a * 3 + r] * F[r * 3 + c]; d22 += T3[a * 3 + r] * F[r * 3 + c]; }
+            if (a <= c) { accIn[tri21(a, c)][tl] = d11; accIn[tri21(3 + a, 3 + c)][tl] = d22; }
+            accIn[tri21(a, 3 + c)][tl] = d12;
+          }
+          accIn[21 + a][tl] = -(T1[a * 3] * L.e[0] + T1[a * 3 + 1] * L.e[1] + T1[a * 3 + 2] * L.e[2] +
+                                T2[a * 3] * L.e[3] + T2[a * 3 + 1] * L.e[4] + T2[a * 3 + 2] * L.e[5]);
+          // F^T Q^T e_t + F^T R e_r
+          double qe0 = Q[0 * 3 + 0] * L.e[0] + Q[1 * 3 + 0] * L.e[1] + Q[2 * 3 + 0] * L.e[2];
+          double qe1 = Q[0 * 3 + 1] * L.e[0] + Q[1 * 3 + 1] * L.e[1] + Q[2 * 3 + 1] * L.e[2];
+          double qe2 = Q[0 * 3 + 2] * L.e[0] + Q[1 * 3 + 2] * L.e[1] + Q[2 * 3 + 2] * L.e[2];
+          accIn[24 + a][tl] = -(F[0 * 3 + a] * qe0 + F[1 * 3 + a] * qe1 + F[2 * 3 + a] * qe2 +
+                                T3[a * 3] * L.e[3] + T3[a * 3 + 1] * L.e[4] + T3[a * 3 + 2] * L.e[5]);
+        }
+      }
       if (!iside) {
 #pragma unroll
         for (int q = 0; q < 9; ++q) { A[q] = E[q]; B[q] = 0.0; Cc[q] = F[q]; }
@@ -193,7 +281,7 @@ __global__ __launch_bounds__(kRowThreads) void k_linearize_rowthread(BatchView V
           }
           M11[a * 3 + c] = m11; M12[a * 3 + c] = m12; M21[a * 3 + c] = m21; M22[a * 3 + c] = m22;
         }
-      const int blk = iside ? V.eo_blk[e] : -1;
+      const int blk = (V.dbg & 1) ? -1 : D.blk;
       if (blk >= 0) {   // owner of the off-diagonal block: J_i^T Omega J_j = [[M11 E, M12 F], [M21 E, M22 F]]
         double* O = V.Hpp_off + (size_t)(blk >> 1) * 36;
         const bool swapped = blk & 1;
@@ -245,24 +333,22 @@ __global__ __launch_bounds__(kRowThreads) void k_linearize_rowthread(BatchView V
                              M22[a * 3] * L.e[3] + M22[a * 3 + 1] * L.e[4] + M22[a * 3 + 2] * L.e[5];
       }
     } else {
-      const int n = V.nEl;
       const Pose Xi = Xown;
-      const double* lp = V.lmk + (size_t)ib * 4;
       double err[3], Ji[18], Jl[9];   // Ji row-major 3x6, Jl row-major 3x3
-      if (!PL || V.lm_kind[ib] == VT_POINT) {
+      if (!PL || D.lk == VT_POINT) {
         PointLin L;
-        point_error(Xi, Vec3{lp[0], lp[1], lp[2]}, Vec3{V.el_z[0 * (size_t)n + e], V.el_z[1 * (size_t)n + e], V.el_z[2 * (size_t)n + e]}, L);
+        point_error(Xi, Vec3{D.o[0], D.o[1], D.o[2]}, Vec3{D.z[0], D.z[1], D.z[2]}, L);
         point_jacobians(L, Ji, Jl);
         err[0] = L.e[0]; err[1] = L.e[1]; err[2] = L.e[2];
       } else {
-        const Plane pw{{lp[0], lp[1], lp[2]}, lp[3]};
-        const Plane z{{V.el_z[0 * (size_t)n + e], V.el_z[1 * (size_t)n + e], V.el_z[2 * (size_t)n + e]}, V.el_z[3 * (size_t)n + e]};
+        const Plane pw{{D.o[0], D.o[1], D.o[2]}, D.o[3]};
+        const Plane z{{D.z[0], D.z[1], D.z[2]}, D.z[3]};
         plane_error(Xi, pw, z, err);
         plane_jacobians(Xi, pw, z, Ji, Jl);
       }
       double W[9];
-      load_sym3(V.el_w, n, e, W);
-      if (SHARD && !(V.el_id[e] >= sh_lo && V.el_id[e] < sh_hi)) {
+      W[0] = D.w[0]; W[1] = W[3] = D.w[1]; W[2] = W[6] = D.w[2]; W[4] = D.w[3]; W[5] = W[7] = D.w[4]; W[8] = D.w[5];
+      if (SHARD && !(D.id >= sh_lo && D.id < sh_hi)) {
 #pragma unroll
         for (int q = 0; q < 9; ++q) W[q] = 0.0;
       }
@@ -279,7 +365,7 @@ __global__ __launch_bounds__(kRowThreads) void k_linearize_rowthread(BatchView V
         for (int a = 0; a <= c; ++a) accD[tri21(a, c)][tid] += Ji[a] * WJi[c] + Ji[6 + a] * WJi[6 + c] + Ji[12 + a] * WJi[12 + c];
         accD[21 + c][tid] -= Ji[c] * We[0] + Ji[6 + c] * We[1] + Ji[12 + c] * We[2];
       }
-      const int blk = V.el_blk[e];
+      const int blk = (V.dbg & 1) ? -1 : D.blk;
       if (blk >= 0) {
         double WJl[9];
 #pragma unroll
@@ -296,16 +382,34 @@ __global__ __launch_bounds__(kRowThreads) void k_linearize_rowthread(BatchView V
         for (int k = 0; k < 18; k += 2) store2(O + k, o[k], o[k + 1]);
       }
     }
+    rec = rec_next; rec_next = rec_next2;
+    if (kPrefetch) D = Dn; else slot_fetch<PL, SHARD>(V, rec, D);
   }
-  double* P = V.Hpp_diag + (size_t)row * 36;
+  }
+  __syncthreads();
+  // the workgroup's 64 diagonal blocks and rhs segments are contiguous in HBM: written as one coalesced stream (16-byte
+  // stores, consecutive lanes on consecutive addresses) out of the LDS columns; rows of graphs that are not linearising keep
+  // their previous values
+  const unsigned long long act = (V.dbg & 2) ? 0ull : __ballot(active);
+  if (act == 0ull) return;
+  double* Pd = V.Hpp_diag + (size_t)row0 * 36;
+#pragma unroll 2
+  for (int k = 0; k < 18; ++k) {
+    const int idx = k * kRowThreads + tid;
+    const int r = idx / 18, p = idx - r * 18;
+    const int a = p / 3, c = 2 * (p - 3 * a);
+    if (!((act >> r) & 1ull)) continue;
+    const int t0 = a <= c ? tri21(a, c) : tri21(c, a), t1 = a <= c + 1 ? tri21(a, c + 1) : tri21(c + 1, a);
+    store2(Pd + (size_t)idx * 2, accD[t0][r] + accIn[t0][r], accD[t1][r] + accIn[t1][r]);
+  }
+  double* Bv = V.bvec + (size_t)row0 * 6;
 #pragma unroll
-  for (int a = 0; a < 6; ++a)
-#pragma unroll
-    for (int c = 0; c < 6; c += 2)
-      store2(P + a * 6 + c, accD[a <= c ? tri21(a, c) : tri21(c, a)][tid], accD[a <= c + 1 ? tri21(a, c + 1) : tri21(c + 1, a)][tid]);
-  double* Bv = V.bvec + (size_t)row * 6;
-#pragma unroll
-  for (int c = 0; c < 6; c += 2) store2(Bv + c, accD[21 + c][tid], accD[22 + c][tid]);
+  for (int k = 0; k < 3; ++k) {
+    const int idx = k * kRowThreads + tid;
+    const int r = idx / 3, p = idx - r * 3;
+    if (!((act >> r) & 1ull)) continue;
+    store2(Bv + (size_t)idx * 2, accD[21 + 2 * p][r] + accIn[21 + 2 * p][r], accD[22 + 2 * p][r] + accIn[22 + 2 * p][r]);
+  }
 }
 
 // landmark rows: 16 lanes per landmark, each lane walks a strided subset of the incident edges,
@@ -1217,6 +1321,8 @@ static int batch_linearize(Batch& b) {
   ScopedTimer t(b, "linearize");
   const BatchView& V = b.V;
   const int nblk = (V.nPr + kRowThreads - 1) / kRowThreads;
+  static const int lin_dbg = [] { const char* e = getenv("SSLAM_LIN_DBG"); return e ? atoi(e) : 0; }();
+  b.V.dbg = lin_dbg;
 #define SSLAM_LAUNCH_LIN(PLV, SHV)                                                                                                    \
   {                                                                                                                                   \
     if (V.nPr > 0) hipLaunchKernelGGL((k_linearize_rowthread<PLV, SHV>), dim3(nblk), dim3(kRowThreads), 0, b.stream, V);              \
