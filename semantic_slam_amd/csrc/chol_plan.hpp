@@ -49,6 +49,13 @@ struct BlkMeta { int off, src, xoff_row, yoff_row, coldiag, colyoff, info, as0; 
 // the block's column; info = di | dj << 4 | fmt << 8 | diag << 9 | row-in-piece << 10 | nas << 16; [as0, as0 + nas) = the child
 // update-matrix blocks to subtract when the block is gathered (piece-local index into the piece's AsmSrc records)
 constexpr int kBlkFmt = 1 << 8, kBlkDiag = 1 << 9, kBlkRowIn = 1 << 10, kBlkNasShift = 16;
+// rank of a row-in-piece block among the piece's row-in-piece blocks (the slot the backward substitution keeps it in): low 5 bits at 11,
+// high 8 bits at 24
+inline int blk_irank_bits(int r) { return ((r & 31) << 11) | ((r >> 5) << 24); }
+#if defined(__HIPCC__)
+__host__ __device__
+#endif
+inline int blk_irank(int info) { return ((info >> 11) & 31) | (((info >> 24) & 255) << 5); }
 
 struct AsmSrc { int uoff, uyoff; };      // an update-matrix block of a child piece (Uval offset); uyoff >= 0: its rhs part too (diagonal blocks)
 struct FwdMeta { int off, yoff; };       // block L(j,k) of row j: Lval offset | (dim k == 6) << 31, y offset of column k
@@ -73,12 +80,17 @@ constexpr int kUItemDi6 = 1 << 12, kUItemDj6 = 1 << 13, kUItemDiag = 1 << 14;
 struct UMb { int uoff, ps0, n, info, s0, ns, uyoff, pad; };     // a U block whose own list was split: info = di | dj << 4 | diag << 9
 
 struct PieceMeta { int graph, c0, nc, b0, nb, lbase, lsize, y0, ysize, ilv0, nilv, iit0, nit_i, iu0, nu_i, imb0, nimb, as0, nas, uit0, nuit, umb0, numb,
-                   uu0, nuu, us0, nus, pad0, pad1, pad2, pad3, pad4; };
+                   uu0, nuu, us0, nus, n36, n18, nint, pad3, pad4; };
 // inside the piece (all copied to LDS when the piece starts, so that its levels never wait for HBM): levels [ilv0, +nilv), items
 // [iit0, +nit_i), update records [iu0, +nu_i), multi-blocks [imb0, +nimb), assembly sources [as0, +nas);
 // update matrix: U items [uit0, +nuit), split U blocks [umb0, +numb), their update records [uu0, +nuu) and child sources [us0, +nus)
 // (UItem.u0 / .s0 and UMb.s0 are relative to uu0 / us0: the per-depth kernels stage these records in LDS as well)
 
+// Factor storage of a piece.  Flat form (LDS, and HBM when CholView::flat_L is set for the multi right-hand-side kernels): the
+// piece's blocks sorted by size class, [n36 blocks of 36 doubles | n18 of 18 | the rest of 10], each block row-major.  HBM form of
+// the LM loop: every class transposed -- element k of the i-th block of a class at  class start + k * (blocks in the class) + i --
+// so that the backward substitution, which runs one thread per block and touches every element once, reads with consecutive lanes
+// on consecutive addresses and needs no LDS staging of the factor.
 // storage of a di x dj block: 3 x 3 blocks are padded to 10 doubles so that every block (and every row of a 6-wide block) starts
 // on a 16-byte boundary (ds_read_b128 / global_load_dwordx4 in the update kernels)
 inline int blk_doubles(int di, int dj) { return (di * dj + 1) & ~1; }
@@ -99,16 +111,19 @@ struct CholOpts {
   int tail_width = -1;     // a graph's tail starts where it has <= tail_width pieces per depth; -1: 6 for batches >= 32, else 2; 0: no tail
   int nt_leaf = 64, nt_tail = 512;    // workgroup sizes the items are cut for
   int min_chunk = 4;       // a list of <= min_chunk updates is never split
+  int split_min = 4096;    // a depth with at least this many pieces is launched in up to four parts, by LDS need
   int pcap_leaf = 4, pcap_tail = 32;   // partial tiles per phase (split lists): LDS budget of a piece
   int group_cap = 0;       // > 0: pieces of equal depth are packed into groups of <= group_cap doubles of L (and <= group_blocks blocks) that one
   int group_blocks = 1024; //      workgroup factors side by side: the per-level latencies and barriers are shared by all members
-  int ustage = 0;          // 1: the per-depth kernels stage the update-matrix records in LDS too (costs residency)
+  int ustage = -1;         // 1: the per-depth kernels stage the update-matrix records in LDS too (one round trip for all tables: shorter
+                           //    piece latency, fewer pieces per CU); -1: 1 for batches < 32 (latency-bound), else 0 (residency-bound)
   bool dump = false;
   static int env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
   void from_env() {
     cap_leaf = env_int("SSLAM_CHOL_CAP_LEAF", cap_leaf); cap_tail = env_int("SSLAM_CHOL_CAP_TAIL", cap_tail);
     max_blocks = env_int("SSLAM_CHOL_MAX_BLOCKS", max_blocks); tail_width = env_int("SSLAM_CHOL_TAIL_WIDTH", tail_width);
     nt_tail = env_int("SSLAM_CHOL_NT_TAIL", nt_tail); nt_leaf = env_int("SSLAM_CHOL_NT_LEAF", nt_leaf); min_chunk = std::max(1, env_int("SSLAM_CHOL_MIN_CHUNK", min_chunk));
+    split_min = std::max(2, env_int("SSLAM_CHOL_SPLIT_MIN", split_min));
     pcap_leaf = env_int("SSLAM_CHOL_PCAP_LEAF", pcap_leaf); pcap_tail = env_int("SSLAM_CHOL_PCAP_TAIL", pcap_tail);
     group_cap = env_int("SSLAM_CHOL_GROUP_CAP", group_cap); group_blocks = env_int("SSLAM_CHOL_GROUP_BLOCKS", group_blocks);
     ustage = env_int("SSLAM_CHOL_USTAGE", ustage);
@@ -233,6 +248,7 @@ inline int chol_symbolic(const SymIn& in, CholOpts opt, CholHost& out) {
   using namespace chol_detail;
   const int nPr = in.nPr, nLr = in.nLr, nrow = nPr + nLr, B = in.B;
   if (opt.tail_width < 0) opt.tail_width = B >= 32 ? 6 : 2;
+  if (opt.ustage < 0) opt.ustage = B >= 32 ? 0 : 1;
   out = CholHost();
   out.B = B; out.nt_leaf = opt.nt_leaf; out.nt_tail = opt.nt_tail; out.ustage = opt.ustage;
   auto row_dim = [&](int r) { return r < nPr ? 6 : 3; };
@@ -403,6 +419,29 @@ inline int chol_symbolic(const SymIn& in, CholOpts opt, CholHost& out) {
   bp[ncol] = (int)boff.size();
   const int nblk = (int)boff.size();
   out.lnz = lnz;
+  // flat layout inside a piece: blocks sorted by size class (stable in block order)
+  std::vector<int> piece_base, piece_size, piece_n36, piece_n18;
+  {
+    int j = 0;
+    while (j < ncol) {
+      int j1 = j;
+      while (j1 < ncol && col_piece[j1] == col_piece[j]) ++j1;
+      const int base = boff[bp[j]];
+      int cnt[3] = {0, 0, 0};
+      auto cls = [&](int t, int jj) { const int d = blk_doubles(col_dim[brow[t]], col_dim[jj]); return d == 36 ? 0 : (d == 18 ? 1 : 2); };
+      for (int jj = j; jj < j1; ++jj)
+        for (int t = bp[jj]; t < bp[jj + 1]; ++t) cnt[cls(t, jj)]++;
+      const int size[3] = {36, 18, 10};
+      int start[3] = {base, base + 36 * cnt[0], base + 36 * cnt[0] + 18 * cnt[1]};
+      int idx[3] = {0, 0, 0};
+      for (int jj = j; jj < j1; ++jj)
+        for (int t = bp[jj]; t < bp[jj + 1]; ++t) { const int c = cls(t, jj); boff[t] = start[c] + size[c] * idx[c]++; }
+      if ((int)piece_base.size() <= col_piece[j]) { piece_base.resize(col_piece[j] + 1, 0); piece_size.resize(col_piece[j] + 1, 0); piece_n36.resize(col_piece[j] + 1, 0); piece_n18.resize(col_piece[j] + 1, 0); }
+      piece_base[col_piece[j]] = base; piece_size[col_piece[j]] = 36 * cnt[0] + 18 * cnt[1] + 10 * cnt[2];
+      piece_n36[col_piece[j]] = cnt[0]; piece_n18[col_piece[j]] = cnt[1];
+      j = j1;
+    }
+  }
   // ---- levels of the block elimination tree (multi right-hand-side solves) and inside the pieces --------------------------
   std::vector<int> level(ncol, 0), col_il(ncol, 0);
   int nlev = 0;
@@ -429,13 +468,12 @@ inline int chol_symbolic(const SymIn& in, CholOpts opt, CholHost& out) {
   std::vector<int> comp_parent(ncomp, -1), comp_dest(ncomp, -1);   // parent component; the group that holds it
   for (int j = 0; j < ncol; ++j) {
     PieceMeta& pm = out.piece[col_piece[j]];
-    if (pm.nc == 0) { pm.graph = col_graph[j]; pm.c0 = j; pm.b0 = bp[j]; pm.lbase = boff[bp[j]]; pm.y0 = col_yoff[j]; }
+    if (pm.nc == 0) { pm.graph = col_graph[j]; pm.c0 = j; pm.b0 = bp[j]; pm.lbase = piece_base[col_piece[j]]; pm.y0 = col_yoff[j];
+                      pm.lsize = piece_size[col_piece[j]]; pm.n36 = piece_n36[col_piece[j]]; pm.n18 = piece_n18[col_piece[j]]; }
     if (j != pm.c0 + pm.nc) { out.error = "piece columns are not contiguous"; return -1; }
     pm.nc++;
     pm.nb = bp[j + 1] - pm.b0;
     pm.ysize = col_yoff[j] + col_dim[j] - pm.y0;
-    const int last = bp[j + 1] - 1;
-    pm.lsize = boff[last] + blk_doubles(col_dim[brow[last]], col_dim[j]) - pm.lbase;
     piece_tail[col_piece[j]] = (char)col_tail[j];
     if (bp[j + 1] - bp[j] > 1) {
       const int par = brow[bp[j] + 1];
@@ -498,6 +536,16 @@ inline int chol_symbolic(const SymIn& in, CholOpts opt, CholHost& out) {
         if (t > bp[j]) out.fwd[cursor[i]++] = FwdMeta{boff[t] | (col_dim[j] == 6 ? (int)0x80000000u : 0), col_yoff[j]};   // columns ascend: row lists sorted by k
       }
     }
+  }
+  for (int p = 0; p < npiece; ++p) {   // slots of the row-in-piece blocks, in block order
+    PieceMeta& pm = out.piece[p];
+    int r = 0;
+    for (int t = pm.b0; t < pm.b0 + pm.nb; ++t)
+      if (out.blk[t].info & kBlkRowIn) {
+        if (r >= 8192) { out.error = "piece with more than 8191 row-in-piece blocks"; return -1; }
+        out.blk[t].info |= blk_irank_bits(r++);
+      }
+    pm.nint = r;
   }
   // ---- piece by piece (elimination order: children before parents): internal updates, update matrix, assembly -------------------------
   struct URec { int a, b, uoff, uy, comp; };          // finished update-matrix block (row column-ids a >= b; uy: rhs part of a diagonal block) of component comp
@@ -700,10 +748,6 @@ inline int chol_symbolic(const SymIn& in, CholOpts opt, CholHost& out) {
     pm.nus = (int)out.usrc.size() - pm.us0;
   }
   out.unz = ucur;
-  out.lpiece.clear();
-  out.lpiece.reserve(npiece);
-  for (int p : out.plv_pieces) out.lpiece.push_back(out.piece[p]);
-  for (int p : out.tail_pieces) out.lpiece.push_back(out.piece[p]);
   // ---- LDS needs (doubles) ---------------------------------------------------------------------------------------------------
   auto lds_f = [&](int p) {
     const PieceMeta& pm = out.piece[p];
@@ -713,10 +757,43 @@ inline int chol_symbolic(const SymIn& in, CholOpts opt, CholHost& out) {
   };
   auto lds_b = [&](int p) {
     const PieceMeta& pm = out.piece[p];
-    return ((pm.lsize + 1) & ~1) + ((pm.ysize + 1) & ~1) + 9 * pm.nb + 3 * pm.nc + 10;
+    return 36 * pm.nint + ((pm.ysize + 1) & ~1) + 7 * pm.nb + 3 * pm.nc + 12;
   };
-  out.plv_lds_f.assign(nplv, 0); out.plv_lds_b.assign(nplv, 0);
-  for (int l = 0; l < nplv; ++l)
+  // ---- launches: one per depth, and a depth with many pieces split by LDS need.  A launch reserves the LDS of its largest piece for
+  //      every workgroup, and the pieces of a depth are independent, so they are sorted by need and cut where the number of
+  //      workgroups a CU can hold changes (160 KB / 32, 24, 16 workgroups): the typical piece then runs at twice the residency the
+  //      largest one of its depth would allow.
+  {
+    std::vector<int> ptr{0}, order;
+    order.reserve(out.plv_pieces.size());
+    const int cut[3] = {640, 853, 1280};
+    for (int l = 0; l < nplv; ++l) {
+      std::vector<int> ps(out.plv_pieces.begin() + out.plv_ptr[l], out.plv_pieces.begin() + out.plv_ptr[l + 1]);
+      const int n = (int)ps.size();
+      if (n >= opt.split_min) {
+        std::stable_sort(ps.begin(), ps.end(), [&](int a, int b) { return lds_b(a) < lds_b(b); });
+        int q0 = 0;
+        for (int k = 0; k < 3 && q0 < n; ++k) {
+          int q1 = q0;
+          while (q1 < n && lds_b(ps[q1]) <= cut[k]) ++q1;
+          if (q1 - q0 >= opt.split_min / 2 && n - q1 >= opt.split_min / 2) { for (int q = q0; q < q1; ++q) order.push_back(ps[q]); ptr.push_back((int)order.size()); q0 = q1; }
+        }
+        for (int q = q0; q < n; ++q) order.push_back(ps[q]);
+      } else {
+        for (int p : ps) order.push_back(p);
+      }
+      if ((int)order.size() > ptr.back()) ptr.push_back((int)order.size());
+    }
+    out.plv_pieces = order;
+    out.plv_ptr = ptr;
+  }
+  const int nlaunch = (int)out.plv_ptr.size() - 1;
+  out.lpiece.clear();
+  out.lpiece.reserve(npiece);
+  for (int p : out.plv_pieces) out.lpiece.push_back(out.piece[p]);
+  for (int p : out.tail_pieces) out.lpiece.push_back(out.piece[p]);
+  out.plv_lds_f.assign(nlaunch, 0); out.plv_lds_b.assign(nlaunch, 0);
+  for (int l = 0; l < nlaunch; ++l)
     for (int q = out.plv_ptr[l]; q < out.plv_ptr[l + 1]; ++q) {
       out.plv_lds_f[l] = std::max(out.plv_lds_f[l], lds_f(out.plv_pieces[q]));
       out.plv_lds_b[l] = std::max(out.plv_lds_b[l], lds_b(out.plv_pieces[q]));
@@ -725,8 +802,8 @@ inline int chol_symbolic(const SymIn& in, CholOpts opt, CholHost& out) {
   if (opt.dump) {
     fprintf(stderr, "[chol-dump] B %d cols %d blocks %d lnz %lld unz %lld updates %zu (internal items %zu, U items %zu) column-levels %d pieces %d piece-levels %d tail pieces %zu\n",
             B, ncol, nblk, (long long)lnz, (long long)out.unz, out.upd.size(), out.item.size(), out.uitem.size(), nlev, npiece, nplv, out.tail_pieces.size());
-    for (int l = 0; l < nplv; ++l)
-      fprintf(stderr, "[chol-dump]   piece-level %d: %d pieces, LDS factor %d B backward %d B\n", l, out.plv_ptr[l + 1] - out.plv_ptr[l],
+    for (int l = 0; l < nlaunch; ++l)
+      fprintf(stderr, "[chol-dump]   launch %d: %d pieces, LDS factor %d B backward %d B\n", l, out.plv_ptr[l + 1] - out.plv_ptr[l],
               out.plv_lds_f[l] * 8, out.plv_lds_b[l] * 8);
     int tmax = 0, tlv = 0;
     for (int g = 0; g < B; ++g) tmax = std::max(tmax, out.tail_ptr[g + 1] - out.tail_ptr[g]);

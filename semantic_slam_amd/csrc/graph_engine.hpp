@@ -121,7 +121,7 @@ struct SymIn;
 void chol_sym_input(const Batch& b, SymIn& in);
 int chol_plan_build(Batch& b);
 int chol_plan_launches(const Batch& b);
-int chol_factor_and_forward(Batch& b);   // (H + lambda I) = L L^T for in_trial graphs, y = L^-1 b
+int chol_factor_and_forward(Batch& b, bool flat = false);   // (H + lambda I) = L L^T for in_trial graphs, y = L^-1 b
 int chol_backward(Batch& b);             // x = L^-T y  -> V.x
 int64_t chol_plan_lnz(const Batch& b);
 int chol_plan_levels(const Batch& b);

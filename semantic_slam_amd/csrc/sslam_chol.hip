@@ -48,6 +48,7 @@ struct CholView {
   double* Uval;             // update matrices handed from child pieces to their parents
   double* y;                // forward-substituted rhs, elimination order [dim]
   int* fail;                // [B]
+  int flat_L;               // 1: the factor is written in flat form (multi right-hand-side kernels); 0: class-interleaved (LM loop)
   long long* dbg;           // SSLAM_CHOL_STAMPS: shader-clock totals per phase of workgroup 0 ([16] tail kernel, [16] per-depth kernels)
 };
 
@@ -65,13 +66,19 @@ struct CholPlan {
 void chol_plan_free(CholPlan* p) {
   if (!p) return;
   if (p->C.dbg) {   // SSLAM_CHOL_STAMPS: where workgroup 0 of the factor kernels spent its shader clocks
-    long long h[32];
-    if (hipMemcpy(h, p->C.dbg, sizeof h, hipMemcpyDeviceToHost) == hipSuccess)
+    long long h[48];
+    if (hipMemcpy(h, p->C.dbg, sizeof h, hipMemcpyDeviceToHost) == hipSuccess) {
+      for (int k = 0; k < 2; ++k) {
+        const long long* d = h + 32 + 8 * k;
+        fprintf(stderr, "[chol-stamps] backward %s: pieces %lld levels %lld blocks %lld | clocks: blocks pass %lld column sums %lld levels %lld store %lld\n",
+                k ? "depth kernels (wg 0)" : "tail (graph 0)", d[4], d[5], d[6], d[0], d[1], d[2], d[3]);
+      }
       for (int k = 0; k < 2; ++k) {
         const long long* d = h + 16 * k;
         fprintf(stderr, "[chol-stamps] %s: pieces %lld levels %lld U-items %lld int-items %lld | clocks: tables %lld gather %lld items %lld reduce %lld diag %lld rows %lld U %lld out %lld\n",
                 k ? "depth kernels (wg 0)" : "tail (graph 0)", d[8], d[9], d[10], d[11], d[0], d[1], d[2], d[3], d[4], d[5], d[6], d[7]);
       }
+    }
   }
   for (void* a : p->allocs) (void)hipFree(a);
   if (p->d_multi_y) (void)hipFree(p->d_multi_y);
@@ -562,11 +569,29 @@ __device__ __forceinline__ void chol_piece(const BatchView& V, const CholView& C
     }
   }
   SSLAM_STAMP(6)
-  // ---- 4. one coalesced stream out
-  {
+  // ---- 4. one coalesced stream out.  The class-interleaved form carries the reciprocal pivots on the diagonal (the backward
+  //         substitution multiplies); the flat form of the multi right-hand-side kernels keeps L_jj itself.
+  if (!C.flat_L) {
+    __syncthreads();   // the update-matrix phase has read its last L block
+    for (int c = tid; c < pm.nc; c += NT) {
+      const int4 cm = sCol[c];
+      for (int r = 0; r < cm.y; ++r) smL[cm.x + r * cm.y + r] = smInv[cm.z + r];
+    }
+    __syncthreads();
+  }
+  if (C.flat_L) {
     D2* dst = reinterpret_cast<D2*>(C.Lval + pm.lbase);
     const D2* src = reinterpret_cast<const D2*>(smL);
     for (int e = tid; e < (pm.lsize >> 1); e += NT) dst[e] = src[e];
+  } else {
+    // class-interleaved form (chol_plan.hpp): every size class of the piece transposed, element k of its i-th block at k * n + i;
+    // consecutive lanes still write consecutive addresses.  t / n by a float reciprocal (exact for t < 2^22).
+    double* dst = C.Lval + pm.lbase;
+    const int nA = pm.n36, nB = pm.n18, nC = pm.nb - nA - nB, eA = 36 * nA, eB = eA + 18 * nB;
+    const float rA = 1.0f / (float)max(nA, 1), rB = 1.0f / (float)max(nB, 1), rC = 1.0f / (float)max(nC, 1);
+    for (int t = tid; t < eA; t += NT) { const int k = (int)(((float)t + 0.5f) * rA), i = t - k * nA; dst[t] = smL[i * 36 + k]; }
+    for (int t = tid; t < 18 * nB; t += NT) { const int k = (int)(((float)t + 0.5f) * rB), i = t - k * nB; dst[eA + t] = smL[eA + i * 18 + k]; }
+    for (int t = tid; t < 9 * nC; t += NT) { const int k = (int)(((float)t + 0.5f) * rC), i = t - k * nC; dst[eB + t] = smL[eB + i * 10 + k]; }
   }
   for (int e = tid; e < pm.ysize; e += NT) C.y[pm.y0 + e] = smY[e];
   SSLAM_STAMP(7)
@@ -600,77 +625,116 @@ __global__ __launch_bounds__(NT) void k_chol_tail(BatchView V, CholView C) {
 
 // ------------------------------------------------------------------------------------------------
 // backward substitution of one piece:  x_j = L_jj^-T (y_j - sum_i L_ij^T x_i),  columns of the piece top-down.
-// LDS: [L of the piece | y -> x of the piece | per-block contributions of rows above the piece | block table | column table]
+// The factor is read in its class-interleaved HBM form, one thread per block, every element once, consecutive lanes on consecutive
+// addresses -- no LDS copy of the piece: a block whose row lies above the piece is multiplied with its (final) x_i out of
+// registers straight away; only the blocks with their row inside the piece are parked in LDS for the levels.
+// LDS: [row-in-piece blocks, 36 doubles each | y -> x of the piece | contributions of the rows above, 6 per block | block table | column table]
 // ------------------------------------------------------------------------------------------------
-template <int NT>
-__device__ __forceinline__ void chol_piece_backward(const CholView& C, const PieceMeta pm, const double* __restrict__ y, double* x, double* sm) {
-  __shared__ ILevel s_lvb[kMaxILevels];
-  const int tid = threadIdx.x;
-  const int Lp = (pm.lsize + 1) & ~1, Yp = (pm.ysize + 1) & ~1;
-  double* smL = sm;
-  double* smX = smL + Lp;
-  double* smE = smX + Yp;                                   // [nb][8]
-  int2* sBlk = reinterpret_cast<int2*>(smE + 8 * pm.nb);    // {L offset | di << 24, row reference: local y offset (row in piece) or global x offset}
-  int4* sCol = reinterpret_cast<int4*>(sBlk + pm.nb + (pm.nb & 1));   // {L offset of the diagonal block, dim | nb << 8 | nbi << 20, y offset, first block (piece-local)}
-  int* sXoff = reinterpret_cast<int*>(sCol + pm.nc);
-  // ---- 0. stream the piece in
-  {   // 16-byte loads, eight in flight per thread (lbase and lsize are even: blocks are stored at even offsets)
-    const D2* src = reinterpret_cast<const D2*>(C.Lval + pm.lbase);
-    D2* dst = reinterpret_cast<D2*>(smL);
-    const int n2 = pm.lsize >> 1;
-    for (int e0 = tid; e0 < n2; e0 += NT * 8) {
-      D2 r[8];
-#pragma unroll
-      for (int k = 0; k < 8; ++k) r[k] = src[min(e0 + k * NT, n2 - 1)];
-#pragma unroll
-      for (int k = 0; k < 8; ++k) if (e0 + k * NT < n2) dst[e0 + k * NT] = r[k];
-    }
+#define SSLAM_BSTAMP(k)                                                         \
+  if (dbg) {                                                                    \
+    const long long now_ = clock64();                                           \
+    if (threadIdx.x == 0) dbg[k] += now_ - tprev;                               \
+    tprev = now_;                                                               \
   }
-  for (int e = tid; e < pm.ysize; e += NT) smX[e] = y[pm.y0 + e];
-  for (int i = tid; i < pm.nilv; i += NT) s_lvb[i] = C.ilv[pm.ilv0 + i];
+template <int NT>
+__device__ __forceinline__ void chol_piece_backward(const CholView& C, const PieceMeta pm, const double* __restrict__ y, double* x, double* sm, long long* dbg) {
+  __shared__ ILevel s_lvb[kMaxILevels];
+  long long tprev = dbg ? clock64() : 0;
+  const int tid = threadIdx.x;
+  const int Yp = (pm.ysize + 1) & ~1;
+  double* smI = sm;
+  double* smX = smI + 36 * pm.nint;
+  double* smE = smX + Yp;                                   // [nb][6]
+  int2* sBlk = reinterpret_cast<int2*>(smE + 6 * pm.nb);    // {LDS offset of a row-in-piece block | di << 24 | dj << 28, local y offset of the row}
+  int4* sCol = reinterpret_cast<int4*>(sBlk + pm.nb + (pm.nb & 1));   // {first block (piece-local), dim | nb << 8 | nbi << 20, y offset, -}
+  int* sXoff = reinterpret_cast<int*>(sCol + pm.nc);
+  const int nA = pm.n36, nB = pm.n18, nC = pm.nb - nA - nB, eA = 36 * nA, eB = eA + 18 * nB;
+  // ---- 0. one pass over the blocks
+  const double y_r = y[pm.y0 + min(tid, pm.ysize - 1)];
+  const ILevel lv_r = C.ilv[pm.ilv0 + min(tid, max(pm.nilv - 1, 0))];
+  const ColMeta col_r = C.col[pm.c0 + min(tid, pm.nc - 1)];
   for (int b = tid; b < pm.nb; b += NT) {
     const BlkMeta bm = C.blk[pm.b0 + b];
+    const int di = bm.info & 15, dj = (bm.info >> 4) & 15;
     const bool in = bm.info & kBlkRowIn;
-    sBlk[b] = make_int2((bm.off - pm.lbase) | ((bm.info & 15) << 24) | (((bm.info >> 4) & 15) << 28), in ? (bm.yoff_row - pm.y0) | (int)0x80000000u : bm.xoff_row);
+    const int ol = bm.off - pm.lbase;
+    int st, n, i;
+    if (ol < eA) { st = 0; n = nA; i = ol / 36; }
+    else if (ol < eB) { st = eA; n = nB; i = (ol - eA) / 18; }
+    else { st = eB; n = nC; i = (ol - eB) / 10; }
+    const double* __restrict__ g = C.Lval + pm.lbase + st + i;
+    if (in) {
+      const int lo = 36 * blk_irank(bm.info);
+      sBlk[b] = make_int2(lo | (di << 24) | (dj << 28), bm.yoff_row - pm.y0);
+      double* o = smI + lo;
+      if (dj == 6) {
+        for (int r = 0; r < di; r += 3) {
+          double v[18];
+#pragma unroll
+          for (int k = 0; k < 18; ++k) v[k] = g[(size_t)(r * 6 + k) * n];
+#pragma unroll
+          for (int k = 0; k < 18; ++k) o[r * 6 + k] = v[k];
+        }
+      } else {
+        for (int r = 0; r < di; r += 3) {
+          double v[9];
+#pragma unroll
+          for (int k = 0; k < 9; ++k) v[k] = g[(size_t)(r * 3 + k) * n];
+#pragma unroll
+          for (int k = 0; k < 9; ++k) o[r * 3 + k] = v[k];
+        }
+      }
+    } else {
+      const double* xi = x + bm.xoff_row;
+      double sv[6] = {0, 0, 0, 0, 0, 0};
+      if (dj == 6) {
+        for (int r = 0; r < di; r += 3) {
+          double v[18];
+          const double x0 = xi[r], x1 = xi[r + 1], x2 = xi[r + 2];
+#pragma unroll
+          for (int k = 0; k < 18; ++k) v[k] = g[(size_t)(r * 6 + k) * n];
+#pragma unroll
+          for (int c = 0; c < 6; ++c) sv[c] += v[c] * x0 + v[6 + c] * x1 + v[12 + c] * x2;
+        }
+      } else {
+        for (int r = 0; r < di; r += 3) {
+          double v[9];
+          const double x0 = xi[r], x1 = xi[r + 1], x2 = xi[r + 2];
+#pragma unroll
+          for (int k = 0; k < 9; ++k) v[k] = g[(size_t)(r * 3 + k) * n];
+#pragma unroll
+          for (int c = 0; c < 3; ++c) sv[c] += v[c] * x0 + v[3 + c] * x1 + v[6 + c] * x2;
+        }
+      }
+#pragma unroll
+      for (int c = 0; c < 6; ++c) smE[b * 6 + c] = sv[c];
+    }
   }
-  for (int c = tid; c < pm.nc; c += NT) {
+  // the small tables: loaded above (in flight together with the block records), stored here
+  if (tid < pm.ysize) smX[tid] = y_r;
+  for (int e = tid + NT; e < pm.ysize; e += NT) smX[e] = y[pm.y0 + e];
+  if (tid < pm.nilv) s_lvb[tid] = lv_r;
+  for (int i = tid + NT; i < pm.nilv; i += NT) s_lvb[i] = C.ilv[pm.ilv0 + i];
+  if (tid < pm.nc) { sCol[tid] = make_int4(col_r.b0 - pm.b0, col_r.dim | (col_r.nb << 8) | (col_r.nbi << 20), col_r.yoff - pm.y0, 0); sXoff[tid] = col_r.xoff; }
+  for (int c = tid + NT; c < pm.nc; c += NT) {
     const ColMeta cm = C.col[pm.c0 + c];
-    sCol[c] = make_int4(cm.base - pm.lbase, cm.dim | (cm.nb << 8) | (cm.nbi << 20), cm.yoff - pm.y0, cm.b0 - pm.b0);
+    sCol[c] = make_int4(cm.b0 - pm.b0, cm.dim | (cm.nb << 8) | (cm.nbi << 20), cm.yoff - pm.y0, 0);
     sXoff[c] = cm.xoff;
   }
   __syncthreads();
-  // ---- 1. rows above the piece (x already final in HBM): one thread per block loads x_i once -> smE; then summed per column in block order
-  for (int b = tid; b < pm.nb; b += NT) {
-    const int2 bm = sBlk[b];
-    if (bm.y < 0) continue;     // row inside the piece
-    const int di = (bm.x >> 24) & 15, dj = (bm.x >> 28) & 15;
-    const double* Bk = smL + (bm.x & 0xFFFFFF);
-    const double* xi = x + bm.y;
-    double xv[6];
-#pragma unroll
-    for (int r = 0; r < 6; ++r) xv[r] = xi[min(r, di - 1)];
-    double sv[6];
-#pragma unroll
-    for (int c = 0; c < 6; ++c) sv[c] = 0.0;
-    for (int r = 0; r < di; ++r) {
-      const double xr = r == 0 ? xv[0] : r == 1 ? xv[1] : r == 2 ? xv[2] : r == 3 ? xv[3] : r == 4 ? xv[4] : xv[5];
-#pragma unroll
-      for (int c = 0; c < 6; ++c) if (c < dj) sv[c] += Bk[r * dj + c] * xr;
-    }
-#pragma unroll
-    for (int c = 0; c < 6; ++c) smE[b * 8 + c] = sv[c];
-  }
-  __syncthreads();
+  SSLAM_BSTAMP(0)
+  // ---- 1. rows above the piece: summed per column in block order
   for (int t = tid; t < pm.nc * 8; t += NT) {
     const int cidx = t >> 3, c = t & 7;
     const int4 cm = sCol[cidx];
     const int dj = cm.y & 255, nb = (cm.y >> 8) & 0xFFF, nbi = cm.y >> 20;
     if (c >= dj) continue;
     double acc = 0;
-    for (int bi = nbi; bi < nb; ++bi) acc += smE[(cm.w + bi) * 8 + c];
+    for (int bi = nbi; bi < nb; ++bi) acc += smE[(cm.x + bi) * 6 + c];
     smX[cm.z + c] -= acc;
   }
   __syncthreads();
+  SSLAM_BSTAMP(1)
   // ---- 2. the levels inside the piece, top-down; a team of 8 Q lanes per column (lane = component c of block slice q)
   for (int il = pm.nilv - 1; il >= 0; --il) {
     const ILevel lv = s_lvb[il];
@@ -683,12 +747,12 @@ __device__ __forceinline__ void chol_piece_backward(const CholView& C, const Pie
       const int4 cm = sCol[lv.c0 - pm.c0 + ci];
       const int dj = cm.y & 255, nbi = cm.y >> 20;
       const int cc = min(c, dj - 1);   // idle lanes of the team shadow the last component
-      const double* D = smL + cm.x;
+      const double* D = smI + (sBlk[cm.x].x & 0xFFFFFF);
       double acc = 0;
       for (int bi = 1 + q; bi < nbi; bi += Q) {
-        const int2 bm = sBlk[cm.w + bi];
-        const double* Bk = smL + (bm.x & 0xFFFFFF) + cc;
-        const double* xi = smX + (bm.y & 0x7FFFFFFF);
+        const int2 bm = sBlk[cm.x + bi];
+        const double* Bk = smI + (bm.x & 0xFFFFFF) + cc;
+        const double* xi = smX + bm.y;
         double s = Bk[0] * xi[0] + Bk[dj] * xi[1] + Bk[2 * dj] * xi[2];
         if (((bm.x >> 24) & 15) == 6) s += Bk[3 * dj] * xi[3] + Bk[4 * dj] * xi[4] + Bk[5 * dj] * xi[5];
         acc += s;
@@ -696,21 +760,38 @@ __device__ __forceinline__ void chol_piece_backward(const CholView& C, const Pie
       if (Q > 1) acc += __shfl_xor(acc, 8, 64);
       if (Q > 2) acc += __shfl_xor(acc, 16, 64);
       if (Q > 4) acc += __shfl_xor(acc, 32, 64);
-      double t = smX[cm.z + cc] - acc;
+      // every lane of the team redoes the small triangular solve  x = L_jj^-T t  on its own (the factor stores the reciprocal
+      // pivots on the diagonal): one LDS hand-over of t instead of a chain of six shuffles and six divisions
+      if (q == 0 && c < dj) smX[cm.z + c] -= acc;
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      double tv[6], xv[6];
 #pragma unroll
-      for (int r = 5; r >= 0; --r) {
-        const int rr = min(r, dj - 1);
-        const double drr = D[rr * dj + rr], drc = D[rr * dj + cc];
-        const double xr = __shfl(t, rr, 8) / drr;
-        if (r < dj) {
-          if (c == r) t = xr;
-          else if (c < r) t -= drc * xr;
+      for (int r = 0; r < 6; ++r) tv[r] = smX[cm.z + min(r, dj - 1)];
+      if (dj == 6) {
+#pragma unroll
+        for (int r = 5; r >= 0; --r) {
+          double a = tv[r];
+#pragma unroll
+          for (int s2 = 5; s2 > r; --s2) a -= D[s2 * 6 + r] * xv[s2];
+          xv[r] = a * D[r * 6 + r];
         }
+      } else {
+#pragma unroll
+        for (int r = 2; r >= 0; --r) {
+          double a = tv[r];
+#pragma unroll
+          for (int s2 = 2; s2 > r; --s2) a -= D[s2 * 3 + r] * xv[s2];
+          xv[r] = a * D[r * 3 + r];
+        }
+        xv[3] = xv[4] = xv[5] = 0.0;
       }
-      if (q == 0 && c < dj) smX[cm.z + c] = t;
+      __builtin_amdgcn_wave_barrier();
+      if (q == 0 && c < dj) smX[cm.z + c] = c == 0 ? xv[0] : c == 1 ? xv[1] : c == 2 ? xv[2] : c == 3 ? xv[3] : c == 4 ? xv[4] : xv[5];
     }
     __syncthreads();
   }
+  SSLAM_BSTAMP(2)
   // ---- 3. x of the piece -> HBM (internal row order), one thread per column
   for (int cidx = tid; cidx < pm.nc; cidx += NT) {
     const int4 cm = sCol[cidx];
@@ -719,14 +800,17 @@ __device__ __forceinline__ void chol_piece_backward(const CholView& C, const Pie
 #pragma unroll
     for (int c = 0; c < 6; ++c) if (c < dj) xo[c] = smX[cm.z + c];
   }
+  SSLAM_BSTAMP(3)
+  if (dbg && threadIdx.x == 0) { dbg[4] += 1; dbg[5] += pm.nilv; dbg[6] += pm.nb; }
 }
+#undef SSLAM_BSTAMP
 
 template <int NT>
-__global__ __launch_bounds__(NT) void k_chol_back_pieces(CholView C, int begin, const double* __restrict__ y, double* x, const LmState* __restrict__ lm) {
+__global__ __launch_bounds__(NT, NT == 64 ? 8 : 1) void k_chol_back_pieces(CholView C, int begin, const double* __restrict__ y, double* x, const LmState* __restrict__ lm) {
   extern __shared__ double sm[];
   const PieceMeta pm = C.lpiece[begin + blockIdx.x];
   if (lm && !lm[pm.graph].in_trial) return;
-  chol_piece_backward<NT>(C, pm, y, x, sm);
+  chol_piece_backward<NT>(C, pm, y, x, sm, (C.dbg && blockIdx.x == 0) ? C.dbg + 40 : nullptr);
 }
 template <int NT>
 __global__ __launch_bounds__(NT) void k_chol_back_tail(CholView C, const double* __restrict__ y, double* x, const LmState* __restrict__ lm) {
@@ -735,7 +819,7 @@ __global__ __launch_bounds__(NT) void k_chol_back_tail(CholView C, const double*
   if (lm && !lm[g].in_trial) return;
   const int q0 = C.tail_ptr[g];
   for (int q = C.tail_ptr[g + 1] - 1; q >= q0; --q) {
-    chol_piece_backward<NT>(C, C.lpiece[C.ltail0 + q], y, x, sm);
+    chol_piece_backward<NT>(C, C.lpiece[C.ltail0 + q], y, x, sm, (C.dbg && g == 0) ? C.dbg + 32 : nullptr);
     __threadfence_block();
     __syncthreads();
   }
@@ -902,9 +986,10 @@ int chol_plan_build(Batch& b) {
   SSLAM_HIP_TRY(hipMalloc(&p, std::max(b.V.B, 1) * sizeof(int))); P->allocs.push_back(p); C.fail = (int*)p;
   SSLAM_HIP_TRY(hipMemsetAsync(C.fail, 0, std::max(b.V.B, 1) * sizeof(int), b.stream));
   C.dbg = nullptr;
+  C.flat_L = 0;
   if (getenv("SSLAM_CHOL_STAMPS")) {
-    SSLAM_HIP_TRY(hipMalloc(&p, 32 * sizeof(long long))); P->allocs.push_back(p); C.dbg = (long long*)p;
-    SSLAM_HIP_TRY(hipMemsetAsync(p, 0, 32 * sizeof(long long), b.stream));
+    SSLAM_HIP_TRY(hipMalloc(&p, 48 * sizeof(long long))); P->allocs.push_back(p); C.dbg = (long long*)p;
+    SSLAM_HIP_TRY(hipMemsetAsync(p, 0, 48 * sizeof(long long), b.stream));
   }
   // LDS opt-in above 64 KiB
   size_t lds_max = (size_t)std::max(P->tail_lds_f, P->tail_lds_b);
@@ -930,8 +1015,9 @@ int64_t chol_plan_lnz(const Batch& b) { return b.chol ? b.chol->lnz : 0; }
 int chol_plan_levels(const Batch& b) { return b.chol ? b.chol->C.nlevels : 0; }
 int chol_plan_launches(const Batch& b) { return b.chol ? (int)b.chol->plv_lds_f.size() + (b.chol->tail_total > 0 ? 1 : 0) : 0; }
 
-int chol_factor_and_forward(Batch& b) {
+int chol_factor_and_forward(Batch& b, bool flat) {
   CholPlan& P = *b.chol;
+  P.C.flat_L = flat ? 1 : 0;   // form of the factor in HBM: flat for the multi right-hand-side kernels, class-interleaved for chol_backward
   const CholView& C = P.C;
   ScopedTimer t(b, "factor");
   hipLaunchKernelGGL(k_chol_begin, dim3((b.V.B + 63) / 64), dim3(64), 0, b.stream, b.V, C);
@@ -965,6 +1051,7 @@ int chol_factor_and_forward(Batch& b) {
 int chol_backward(Batch& b) {
   CholPlan& P = *b.chol;
   const CholView& C = P.C;
+  if (C.flat_L) return set_error(SSLAM_ERR_INVALID, "chol_backward needs the class-interleaved factor (the last factorisation was a flat one)");
   ScopedTimer t(b, "solve");
   if (P.tail_total > 0)
     hipLaunchKernelGGL(k_chol_back_tail<512>, dim3(b.V.B), dim3(512), (size_t)P.tail_lds_b * sizeof(double), b.stream, C, (const double*)C.y, b.V.x, (const LmState*)b.V.lm);
@@ -993,6 +1080,7 @@ int chol_solve_multi(Batch& b, const double* rhs_host, int nrhs, double* x_host)
   CholPlan& P = *b.chol;
   const CholView& C = P.C;
   if (nrhs <= 0) return 0;
+  if (!C.flat_L) return set_error(SSLAM_ERR_INVALID, "chol_solve_multi needs the flat factor (chol_factor_and_forward(b, true))");
   const int chunk_max = std::max(1, std::min(nrhs, (int)std::min<int64_t>(4096, ((int64_t)1 << 30) / std::max(1, C.dim) / 8)));
   if (P.multi_cap < chunk_max) {
     if (P.d_multi_y) (void)hipFree(P.d_multi_y);

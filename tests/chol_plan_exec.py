@@ -20,7 +20,7 @@ MB = np.dtype([(n, "<i4") for n in ("tloff", "ps0", "n", "info")])
 ILV = np.dtype([(n, "<i4") for n in ("c0", "c1", "b0", "b1", "it0", "it1", "mb0", "mb1")])
 PIECE = np.dtype([(n, "<i4") for n in ("graph", "c0", "nc", "b0", "nb", "lbase", "lsize", "y0", "ysize", "ilv0", "nilv", "iit0", "nit_i",
                                        "iu0", "nu_i", "imb0", "nimb", "as0", "nas", "uit0", "nuit", "umb0", "numb",
-                                       "uu0", "nuu", "us0", "nus", "pad0", "pad1", "pad2", "pad3", "pad4")])
+                                       "uu0", "nuu", "us0", "nus", "n36", "n18", "nint", "pad3", "pad4")])
 K_DI6, K_DK6, K_DIAG, K_DJ6 = 1 << 20, 1 << 21, 1 << 22, 1 << 23
 B_FMT, B_DIAG, B_ROWIN = 1 << 8, 1 << 9, 1 << 10
 

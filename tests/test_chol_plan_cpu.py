@@ -103,7 +103,27 @@ def _structure_invariants(plan):
             assert rank[q] < rank[p]
             if p in depth_of:
                 assert q in depth_of and depth_of[q] < depth_of[p]
-    # LDS budgets stay below the hardware's 160 KiB
+    # factor storage of a piece: blocks sorted by size class (36 | 18 | 10 doubles), the row-in-piece blocks numbered in block order
+    for p in range(plan.npiece):
+        pm = P[p]
+        blks = plan.blk[pm["b0"]:pm["b0"] + pm["nb"]]
+        di, dj = blks["info"] & 15, (blks["info"] >> 4) & 15
+        size = (di * dj + 1) & ~1
+        n36, n18 = int((size == 36).sum()), int((size == 18).sum())
+        assert (n36, n18) == (int(pm["n36"]), int(pm["n18"]))
+        start = {36: 0, 18: 36 * n36, 10: 36 * n36 + 18 * n18}
+        seen = {36: 0, 18: 0, 10: 0}
+        rank = 0
+        for bm, s in zip(blks, size):
+            s = int(s)
+            assert int(bm["off"]) - int(pm["lbase"]) == start[s] + s * seen[s]
+            seen[s] += 1
+            if int(bm["info"]) & (1 << 10):
+                info = int(bm["info"])
+                assert (((info >> 11) & 31) | (((info >> 24) & 255) << 5)) == rank
+                rank += 1
+        assert rank == int(pm["nint"]) and int(pm["lsize"]) == 36 * n36 + 18 * n18 + 10 * (len(blks) - n36 - n18)
+    # a launch never mixes depths; its LDS reservation covers its pieces; budgets stay below the hardware's 160 KiB
     lds = [int(v) for v in plan.plv_lds_f] + [int(v) for v in plan.plv_lds_b] + [plan.tail_lds_f, plan.tail_lds_b]
     assert max(lds) * 8 <= 158 * 1024
 
@@ -135,6 +155,14 @@ def test_plan_with_tiny_pieces_exercises_every_phase(hip_lib):
     plan2, H2, b2 = _plan_and_system(hip_lib, g, False, dict(env, SSLAM_CHOL_TAIL_WIDTH=0))
     assert len(plan2.tail_pieces) == 0
     _check(plan2, H2, b2, 1e-3)
+    # a depth with many pieces is launched in parts, by LDS need (sorted inside the depth; cuts where a CU holds 32 / 24 / 16 workgroups)
+    g5 = make_graph(400, 80, seed=2)
+    plan5, H5, b5 = _plan_and_system(hip_lib, g5, False, {"SSLAM_CHOL_TAIL_WIDTH": 2})
+    plan4, H4, b4 = _plan_and_system(hip_lib, g5, False, {"SSLAM_CHOL_TAIL_WIDTH": 2, "SSLAM_CHOL_SPLIT_MIN": 4})
+    assert len(plan4.plv_ptr) > len(plan5.plv_ptr) and plan4.npiece == plan5.npiece
+    assert int(plan4.plv_lds_b[0]) < int(plan5.plv_lds_b[0])   # the small pieces of the first depth no longer reserve what its largest needs
+    _structure_invariants(plan4)
+    _check(plan4, H4, b4, 1e-3)
 
 
 def test_plan_plane_landmarks_and_S_config(hip_lib):
