@@ -101,6 +101,10 @@ class point_cloud_segmentation {
 
  private:
   sslam_seg* seg_ = nullptr;
+
+ public:
+  // the C-ABI handle (the orchestrator shim, ps_graph_slam_amd/semantic_graph_slam.hpp, borrows it for the tick's batched frontend pass)
+  sslam_seg* handle() const { return seg_; }
 };
 
 #endif

@@ -569,16 +569,7 @@ __device__ __forceinline__ void chol_piece(const BatchView& V, const CholView& C
     }
   }
   SSLAM_STAMP(6)
-  // ---- 4. one coalesced stream out.  The class-interleaved form carries the reciprocal pivots on the diagonal (the backward
-  //         substitution multiplies); the flat form of the multi right-hand-side kernels keeps L_jj itself.
-  if (!C.flat_L) {
-    __syncthreads();   // the update-matrix phase has read its last L block
-    for (int c = tid; c < pm.nc; c += NT) {
-      const int4 cm = sCol[c];
-      for (int r = 0; r < cm.y; ++r) smL[cm.x + r * cm.y + r] = smInv[cm.z + r];
-    }
-    __syncthreads();
-  }
+  // ---- 4. one coalesced stream out
   if (C.flat_L) {
     D2* dst = reinterpret_cast<D2*>(C.Lval + pm.lbase);
     const D2* src = reinterpret_cast<const D2*>(smL);
@@ -694,7 +685,7 @@ __device__ __forceinline__ void chol_piece_backward(const CholView& C, const Pie
 #pragma unroll
           for (int k = 0; k < 18; ++k) v[k] = g[(size_t)(r * 6 + k) * n];
 #pragma unroll
-          for (int c = 0; c < 6; ++c) sv[c] += v[c] * x0 + v[6 + c] * x1 + v[12 + c] * x2;
+          for (int c = 0; c < 6; ++c) { sv[c] += v[c] * x0; sv[c] += v[6 + c] * x1; sv[c] += v[12 + c] * x2; }   // row by row, like the dense product
         }
       } else {
         for (int r = 0; r < di; r += 3) {
@@ -703,7 +694,7 @@ __device__ __forceinline__ void chol_piece_backward(const CholView& C, const Pie
 #pragma unroll
           for (int k = 0; k < 9; ++k) v[k] = g[(size_t)(r * 3 + k) * n];
 #pragma unroll
-          for (int c = 0; c < 3; ++c) sv[c] += v[c] * x0 + v[3 + c] * x1 + v[6 + c] * x2;
+          for (int c = 0; c < 3; ++c) { sv[c] += v[c] * x0; sv[c] += v[3 + c] * x1; sv[c] += v[6 + c] * x2; }
         }
       }
 #pragma unroll
@@ -760,8 +751,9 @@ __device__ __forceinline__ void chol_piece_backward(const CholView& C, const Pie
       if (Q > 1) acc += __shfl_xor(acc, 8, 64);
       if (Q > 2) acc += __shfl_xor(acc, 16, 64);
       if (Q > 4) acc += __shfl_xor(acc, 32, 64);
-      // every lane of the team redoes the small triangular solve  x = L_jj^-T t  on its own (the factor stores the reciprocal
-      // pivots on the diagonal): one LDS hand-over of t instead of a chain of six shuffles and six divisions
+      // every lane of the team redoes the small triangular solve  x = L_jj^-T t  on its own: one LDS hand-over of t instead of a
+      // chain of six shuffles (the divisions stay: x_r = a / L_rr is what the reference's csparse back-substitution computes, and
+      // LM's accept / reject decisions at convergence follow the last bit)
       if (q == 0 && c < dj) smX[cm.z + c] -= acc;
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
       __builtin_amdgcn_wave_barrier();
@@ -774,7 +766,7 @@ __device__ __forceinline__ void chol_piece_backward(const CholView& C, const Pie
           double a = tv[r];
 #pragma unroll
           for (int s2 = 5; s2 > r; --s2) a -= D[s2 * 6 + r] * xv[s2];
-          xv[r] = a * D[r * 6 + r];
+          xv[r] = a / D[r * 6 + r];
         }
       } else {
 #pragma unroll
@@ -782,7 +774,7 @@ __device__ __forceinline__ void chol_piece_backward(const CholView& C, const Pie
           double a = tv[r];
 #pragma unroll
           for (int s2 = 2; s2 > r; --s2) a -= D[s2 * 3 + r] * xv[s2];
-          xv[r] = a * D[r * 3 + r];
+          xv[r] = a / D[r * 3 + r];
         }
         xv[3] = xv[4] = xv[5] = 0.0;
       }

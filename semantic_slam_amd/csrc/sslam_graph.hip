@@ -147,7 +147,7 @@ __device__ __forceinline__ void slot_fetch(const BatchView& V, const int4 rec, S
 }
 
 template <bool PL, bool SHARD>
-__global__ __launch_bounds__(kRowThreads) void k_linearize_rowthread(BatchView V) {
+__global__ __launch_bounds__(kRowThreads) void k_linearize_rowthread_handover(BatchView V) {
   __shared__ double accD[27][kRowThreads];    // this row's diagonal block (upper triangle) and rhs, thread-private column
   __shared__ double accIn[27][kRowThreads];   // what the i-side thread of a paired EdgeSE3 hands to the row of its j vertex
   const int tid = threadIdx.x;
@@ -410,6 +410,211 @@ __global__ __launch_bounds__(kRowThreads) void k_linearize_rowthread(BatchView V
     if (!((act >> r) & 1ull)) continue;
     store2(Bv + (size_t)idx * 2, accD[21 + 2 * p][r] + accIn[21 + 2 * p][r], accD[22 + 2 * p][r] + accIn[22 + 2 * p][r]);
   }
+}
+
+// Default pose-row kernel: every slot of a row evaluated by the row's own thread, contributions summed in slot order.  The hand-over form
+// above (SSLAM_LIN_HANDOVER=1) evaluates a chain edge once and is as fast (1.97 vs 2.0 ms per 512-graph build), but adds the handed
+// block last; LM's accept / reject decisions at convergence follow the last bit of H, and on the bench's seeds that order costs 13
+// extra rejected trials per 20 iterations.
+template <bool PL, bool SHARD>
+__global__ __launch_bounds__(kRowThreads) void k_linearize_rowthread(BatchView V) {
+  __shared__ double accD[27][kRowThreads];
+  const int tid = threadIdx.x;
+  const int row = blockIdx.x * kRowThreads + tid;
+  if (row >= V.nPr) return;
+  if (!V.lm[V.prow_graph[row]].lin) return;
+#pragma unroll
+  for (int k = 0; k < 27; ++k) accD[k][tid] = 0.0;
+  const int s0 = V.pslot_ptr[row], s1 = V.pslot_ptr[row + 1];
+  const int own = V.prow_pose[row];
+  const int sh_lo = SHARD ? V.shard_lo[V.prow_graph[row]] : 0, sh_hi = SHARD ? V.shard_hi[V.prow_graph[row]] : 0;
+  const Pose Xown = load_pose16(V.pose, own);   // this row's vertex: loaded once, reused by every slot
+  for (int s = s0; s < s1; ++s) {
+    const int4 rec = V.pslot_rec[s];
+    const int e = rec.x, kind = rec.y & 15, ia = rec.z, ib = rec.w;   // kind 3 (hand-over) is evaluated like kind 1 here
+    if (kind != 2) {
+      // EdgeSE3: both Jacobians are 2 x 2 block upper triangular in 3 x 3 blocks,
+      //   J_i = [[-Ra, 2 Ra [tb]x], [0, Ci]],   J_j = [[Re, 0], [0, Fj]],
+      // so J^T Omega J is formed from 3 x 3 products of the blocks (half the FMAs and a smaller live set than dense 6 x 6).
+      const int n = V.nEo;
+      const bool iside = (kind == 0);
+      Se3Lin L;
+      se3_error(iside ? Xown : load_pose16(V.pose, ia), iside ? load_pose16(V.pose, ib) : Xown, load_meas_pose(V.eo_z, n, e), L);
+      double P[9], Q[9], R[9];   // Omega = [[P, Q], [Q^T, R]]
+      // edge-sharded mode: an edge outside this rank's range contributes nothing (everything below is linear in Omega; the owner
+      // of an off-diagonal block still writes it, as zeros)
+      const double mk = (!SHARD || (V.eo_id[e] >= sh_lo && V.eo_id[e] < sh_hi)) ? 1.0 : 0.0;
+#pragma unroll
+      for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          P[r * 3 + c] = mk * V.eo_w[(size_t)(r <= c ? tri21(r, c) : tri21(c, r)) * n + e];
+          Q[r * 3 + c] = mk * V.eo_w[(size_t)tri21(r, 3 + c) * n + e];
+          R[r * 3 + c] = mk * V.eo_w[(size_t)(r <= c ? tri21(3 + r, 3 + c) : tri21(3 + c, 3 + r)) * n + e];
+        }
+      double A[9], B[9], Cc[9];   // own Jacobian [[A, B], [0, Cc]]  (B = 0 on the j side)
+      if (iside) {
+        const Vec3 tb = L.tb;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+          const double r0 = L.Ra.m[r * 3], r1 = L.Ra.m[r * 3 + 1], r2 = L.Ra.m[r * 3 + 2];
+          A[r * 3] = -r0; A[r * 3 + 1] = -r1; A[r * 3 + 2] = -r2;
+          B[r * 3 + 0] = 2 * (r1 * tb.z - r2 * tb.y);     // Ra * (0, tz, -ty)
+          B[r * 3 + 1] = 2 * (-r0 * tb.z + r2 * tb.x);    // Ra * (-tz, 0, tx)
+          B[r * 3 + 2] = 2 * (r0 * tb.y - r1 * tb.x);     // Ra * (ty, -tx, 0)
+        }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          const Quat vk = {k == 0 ? 1.0 : 0.0, k == 1 ? 1.0 : 0.0, k == 2 ? 1.0 : 0.0, 0.0};
+          const Quat t = qmul(qmul(L.qa, vk), L.qb);
+          Cc[0 * 3 + k] = -L.s * t.x; Cc[1 * 3 + k] = -L.s * t.y; Cc[2 * 3 + k] = -L.s * t.z;
+        }
+      }
+      double E[9], F[9];          // J_j = [[E, 0], [0, F]]
+      {
+        const Mat3 Re = qmat(L.qe);
+        const double w = L.s * L.qe.w, x = L.s * L.qe.x, y = L.s * L.qe.y, z = L.s * L.qe.z;
+#pragma unroll
+        for (int q = 0; q < 9; ++q) E[q] = Re.m[q];
+        F[0] = w; F[1] = -z; F[2] = y; F[3] = z; F[4] = w; F[5] = -x; F[6] = -y; F[7] = x; F[8] = w;
+      }
+      if (!iside) {
+#pragma unroll
+        for (int q = 0; q < 9; ++q) { A[q] = E[q]; B[q] = 0.0; Cc[q] = F[q]; }
+      }
+      // M = J_self^T Omega = [[A^T P, A^T Q], [B^T P + C^T Q^T, B^T Q + C^T R]]
+      double M11[9], M12[9], M21[9], M22[9];
+#pragma unroll
+      for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          double m11 = 0, m12 = 0, m21 = 0, m22 = 0;
+#pragma unroll
+          for (int r = 0; r < 3; ++r) {
+            m11 += A[r * 3 + a] * P[r * 3 + c];
+            m12 += A[r * 3 + a] * Q[r * 3 + c];
+            m21 += Cc[r * 3 + a] * Q[c * 3 + r];
+            m22 += Cc[r * 3 + a] * R[r * 3 + c];
+          }
+          if (iside) {
+#pragma unroll
+            for (int r = 0; r < 3; ++r) { m21 += B[r * 3 + a] * P[r * 3 + c]; m22 += B[r * 3 + a] * Q[r * 3 + c]; }
+          }
+          M11[a * 3 + c] = m11; M12[a * 3 + c] = m12; M21[a * 3 + c] = m21; M22[a * 3 + c] = m22;
+        }
+      const int blk = iside ? V.eo_blk[e] : -1;
+      if (blk >= 0) {   // owner of the off-diagonal block: J_i^T Omega J_j = [[M11 E, M12 F], [M21 E, M22 F]]
+        double* O = V.Hpp_off + (size_t)(blk >> 1) * 36;
+        const bool swapped = blk & 1;
+        double o[36];
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+          for (int c = 0; c < 3; ++c) {
+            double o11 = 0, o12 = 0, o21 = 0, o22 = 0;
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+              o11 += M11[a * 3 + r] * E[r * 3 + c]; o12 += M12[a * 3 + r] * F[r * 3 + c];
+              o21 += M21[a * 3 + r] * E[r * 3 + c]; o22 += M22[a * 3 + r] * F[r * 3 + c];
+            }
+            o[a * 6 + c] = o11; o[a * 6 + 3 + c] = o12; o[(3 + a) * 6 + c] = o21; o[(3 + a) * 6 + 3 + c] = o22;
+          }
+        if (!swapped) {   // stored [row_i][row_j]
+#pragma unroll
+          for (int k = 0; k < 36; k += 2) store2(O + k, o[k], o[k + 1]);
+        } else {          // stored transposed
+#pragma unroll
+          for (int c = 0; c < 6; ++c)
+#pragma unroll
+            for (int a = 0; a < 6; a += 2) store2(O + c * 6 + a, o[a * 6 + c], o[(a + 1) * 6 + c]);
+        }
+      }
+      // diagonal block J^T Omega J (upper triangle) and b -= J^T Omega e
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          double d11 = 0, d12 = 0, d22 = 0;
+#pragma unroll
+          for (int r = 0; r < 3; ++r) {
+            d11 += M11[a * 3 + r] * A[r * 3 + c];
+            d12 += M12[a * 3 + r] * Cc[r * 3 + c];
+            d22 += M22[a * 3 + r] * Cc[r * 3 + c];
+          }
+          if (iside) {
+#pragma unroll
+            for (int r = 0; r < 3; ++r) { d12 += M11[a * 3 + r] * B[r * 3 + c]; d22 += M21[a * 3 + r] * B[r * 3 + c]; }
+          }
+          if (a <= c) { accD[tri21(a, c)][tid] += d11; accD[tri21(3 + a, 3 + c)][tid] += d22; }
+          accD[tri21(a, 3 + c)][tid] += d12;
+        }
+        accD[21 + a][tid] -= M11[a * 3] * L.e[0] + M11[a * 3 + 1] * L.e[1] + M11[a * 3 + 2] * L.e[2] +
+                             M12[a * 3] * L.e[3] + M12[a * 3 + 1] * L.e[4] + M12[a * 3 + 2] * L.e[5];
+        accD[24 + a][tid] -= M21[a * 3] * L.e[0] + M21[a * 3 + 1] * L.e[1] + M21[a * 3 + 2] * L.e[2] +
+                             M22[a * 3] * L.e[3] + M22[a * 3 + 1] * L.e[4] + M22[a * 3 + 2] * L.e[5];
+      }
+    } else {
+      const int n = V.nEl;
+      const Pose Xi = Xown;
+      const double* lp = V.lmk + (size_t)ib * 4;
+      double err[3], Ji[18], Jl[9];   // Ji row-major 3x6, Jl row-major 3x3
+      if (!PL || V.lm_kind[ib] == VT_POINT) {
+        PointLin L;
+        point_error(Xi, Vec3{lp[0], lp[1], lp[2]}, Vec3{V.el_z[0 * (size_t)n + e], V.el_z[1 * (size_t)n + e], V.el_z[2 * (size_t)n + e]}, L);
+        point_jacobians(L, Ji, Jl);
+        err[0] = L.e[0]; err[1] = L.e[1]; err[2] = L.e[2];
+      } else {
+        const Plane pw{{lp[0], lp[1], lp[2]}, lp[3]};
+        const Plane z{{V.el_z[0 * (size_t)n + e], V.el_z[1 * (size_t)n + e], V.el_z[2 * (size_t)n + e]}, V.el_z[3 * (size_t)n + e]};
+        plane_error(Xi, pw, z, err);
+        plane_jacobians(Xi, pw, z, Ji, Jl);
+      }
+      double W[9];
+      load_sym3(V.el_w, n, e, W);
+      if (SHARD && !(V.el_id[e] >= sh_lo && V.el_id[e] < sh_hi)) {
+#pragma unroll
+        for (int q = 0; q < 9; ++q) W[q] = 0.0;
+      }
+      double WJi[18], We[3];
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        We[a] = W[a * 3 + 0] * err[0] + W[a * 3 + 1] * err[1] + W[a * 3 + 2] * err[2];
+#pragma unroll
+        for (int c = 0; c < 6; ++c) WJi[a * 6 + c] = W[a * 3 + 0] * Ji[c] + W[a * 3 + 1] * Ji[6 + c] + W[a * 3 + 2] * Ji[12 + c];
+      }
+#pragma unroll
+      for (int c = 0; c < 6; ++c) {
+#pragma unroll
+        for (int a = 0; a <= c; ++a) accD[tri21(a, c)][tid] += Ji[a] * WJi[c] + Ji[6 + a] * WJi[6 + c] + Ji[12 + a] * WJi[12 + c];
+        accD[21 + c][tid] -= Ji[c] * We[0] + Ji[6 + c] * We[1] + Ji[12 + c] * We[2];
+      }
+      const int blk = V.el_blk[e];
+      if (blk >= 0) {
+        double WJl[9];
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+          for (int c = 0; c < 3; ++c) WJl[a * 3 + c] = W[a * 3 + 0] * Jl[c] + W[a * 3 + 1] * Jl[3 + c] + W[a * 3 + 2] * Jl[6 + c];
+        double o[18];
+#pragma unroll
+        for (int a = 0; a < 6; ++a)
+#pragma unroll
+          for (int c = 0; c < 3; ++c) o[a * 3 + c] = Ji[a] * WJl[c] + Ji[6 + a] * WJl[3 + c] + Ji[12 + a] * WJl[6 + c];
+        double* O = V.Hpl + (size_t)blk * 18;
+#pragma unroll
+        for (int k = 0; k < 18; k += 2) store2(O + k, o[k], o[k + 1]);
+      }
+    }
+  }
+  double* P = V.Hpp_diag + (size_t)row * 36;
+#pragma unroll
+  for (int a = 0; a < 6; ++a)
+#pragma unroll
+    for (int c = 0; c < 6; c += 2)
+      store2(P + a * 6 + c, accD[a <= c ? tri21(a, c) : tri21(c, a)][tid], accD[a <= c + 1 ? tri21(a, c + 1) : tri21(c + 1, a)][tid]);
+  double* Bv = V.bvec + (size_t)row * 6;
+#pragma unroll
+  for (int c = 0; c < 6; c += 2) store2(Bv + c, accD[21 + c][tid], accD[22 + c][tid]);
 }
 
 // landmark rows: 16 lanes per landmark, each lane walks a strided subset of the incident edges,
@@ -1323,9 +1528,13 @@ static int batch_linearize(Batch& b) {
   const int nblk = (V.nPr + kRowThreads - 1) / kRowThreads;
   static const int lin_dbg = [] { const char* e = getenv("SSLAM_LIN_DBG"); return e ? atoi(e) : 0; }();
   b.V.dbg = lin_dbg;
+  static const int lin_handover = [] { const char* e = getenv("SSLAM_LIN_HANDOVER"); return e ? atoi(e) : 0; }();
 #define SSLAM_LAUNCH_LIN(PLV, SHV)                                                                                                    \
   {                                                                                                                                   \
-    if (V.nPr > 0) hipLaunchKernelGGL((k_linearize_rowthread<PLV, SHV>), dim3(nblk), dim3(kRowThreads), 0, b.stream, V);              \
+    if (V.nPr > 0) {                                                                                                                  \
+      if (lin_handover) hipLaunchKernelGGL((k_linearize_rowthread_handover<PLV, SHV>), dim3(nblk), dim3(kRowThreads), 0, b.stream, V); \
+      else hipLaunchKernelGGL((k_linearize_rowthread<PLV, SHV>), dim3(nblk), dim3(kRowThreads), 0, b.stream, V);                      \
+    }                                                                                                                                 \
     if (V.nLr > 0) hipLaunchKernelGGL((k_linearize_lm_rows<PLV, SHV>), dim3((V.nLr + 15) / 16), dim3(256), 0, b.stream, V);           \
   }
   if (b.sharded) { if (b.has_planes) SSLAM_LAUNCH_LIN(true, true) else SSLAM_LAUNCH_LIN(false, true) }

@@ -6,6 +6,7 @@
 #include <cstring>
 #include "../include/ps_graph_slam_amd/graph_slam.hpp"
 #include "../include/planar_segmentation_amd/point_cloud_segmentation.hpp"
+#include "../include/ps_graph_slam_amd/semantic_graph_slam.hpp"
 
 int main(int argc, char** argv) {
   ps_graph_slam::GraphSLAM slam(false);
@@ -62,5 +63,34 @@ int main(int argc, char** argv) {
   double cs = 0;   // checksum the caller recomputes from the Python mirror's planes
   for (auto& o : objs) cs += (double)o.normal_orientation[0] + 2.0 * o.normal_orientation[1] + 3.0 * o.normal_orientation[2] + 0.5 * o.normal_orientation[3] + o.num_points;
   std::printf("frontend shim ok: %zu planes checksum %.9e\n", objs.size(), cs);
-  return (int)objs.size() == std::atoi(argv[2]) ? 0 : 9;
+  if ((int)objs.size() != std::atoi(argv[2])) return 9;
+
+  // orchestrator (semantic_graph_slam): the node's callbacks and loop on the same frame, seen from two keyframes 0.6 m apart
+  semantic_graph_slam sgs;
+  sgs.params().const_stddev_x = 0.00667; sgs.params().const_stddev_q = 0.00001;
+  sgs.params().camera_angle_deg = pose7[6] * 180.0 / M_PI;   // ~camera_angle (semantic_graph_slam.cpp:24,29)
+  sgs.init(false, seg.handle());
+  std::vector<sslam_box> boxes;
+  for (auto& o : info) boxes.push_back(sslam_box{o.tl_x, o.tl_y, o.width, o.height, SSLAM_CLASS_CHAIR, o.prob});
+  for (int k = 0; k < 2; ++k) {
+    sslam::Isometry odom = sslam::Isometry::Identity();
+    odom.t[0] = 0.6 * k;
+    sgs.setPointCloudData(cloud.data(), w, h, step, step * w, 0, 4, 8);
+    sgs.setDetectedObjectInfo(boxes);
+    if (!sgs.VIOCallback(k, 0, odom)) { std::printf("keyframe %d rejected\n", k); return 10; }
+  }
+  if (!sgs.run()) { std::printf("run() found no keyframes\n"); return 11; }
+  std::vector<sslam_landmark> lms;
+  sgs.getMappedLandmarks(lms);
+  std::vector<std::pair<int, sslam::Isometry>> kfs;
+  sgs.getKeyframes(kfs);
+  const sslam_tick_stats& st = sgs.lastTick();
+  std::printf("orchestrator shim ok: %d keyframes, %zu landmarks (%d new, %d matched), optimised %d, marginals %d\n", st.keyframes_added, lms.size(),
+              st.landmarks_added, st.landmarks_matched, st.optimized, st.marginals_ok);
+  // both keyframes carry the same cloud and boxes (seen from the orchestrator's own robot pose, so the plane count may differ from
+  // the direct call above): every object of the first keyframe becomes a landmark, every object is an edge
+  const bool enough = 1 + st.landmark_edges_added >= 10;   // GraphSLAM::optimize refuses fewer than 10 edges (graph_slam.cpp:184-186)
+  if (kfs.size() != 2 || st.keyframes_added != 2 || st.landmark_edges_added != st.landmarks_added + st.landmarks_matched ||
+      (int)lms.size() != st.landmarks_added || (enough && (!st.optimized || !st.marginals_ok))) return 12;
+  return 0;
 }

@@ -400,7 +400,7 @@ def test_cpp_shim_end_to_end(gpu_lib, tmp_path):
         np.concatenate([fr.robot_pose, [fr.cam_angle]]).astype("<f4").tofile(f)
         f.write(fr.cloud.tobytes())
     out = subprocess.run([exe, path, str(len(planes))], capture_output=True, text=True)
-    assert out.returncode == 0 and "shim ok: chi2" in out.stdout and "frontend shim ok" in out.stdout, out.stdout + out.stderr
+    assert out.returncode == 0 and "shim ok: chi2" in out.stdout and "frontend shim ok" in out.stdout and "orchestrator shim ok" in out.stdout, out.stdout + out.stderr
     cs = sum(float(p.normal_orientation[0]) + 2.0 * float(p.normal_orientation[1]) + 3.0 * float(p.normal_orientation[2])
              + 0.5 * float(p.normal_orientation[3]) + float(p.num_points) for p in planes)
     got = float(re.search(r"checksum (\S+)", out.stdout).group(1))
@@ -464,3 +464,29 @@ def test_seg_golden_patch(gpu_lib):
                                  point_step=32, row_step=32 * w)
     assert np.array_equal(seg.normals(0).reshape(-1, 4), g["normals"], equal_nan=True)
     assert np.array_equal(seg.labels(0).reshape(-1), g["labels"])
+
+
+def test_handover_jacobian_kernel_matches_oracle(gpu_lib):
+    """The hand-over form of the pose-row kernel (SSLAM_LIN_HANDOVER=1: a chain EdgeSE3 evaluated once, J_j^T Omega J_j handed to the
+    neighbouring row through LDS, operands prefetched a slot ahead) builds the same normal equations: H, b vs the oracle to 1e-11.
+    The switch is read once per process, hence the child process."""
+    import os, subprocess, sys
+    code = r'''
+import sys, numpy as np, scipy.sparse as sp
+sys.path.insert(0, %r)
+from semantic_slam_amd import GraphSLAM
+from semantic_slam_amd.synth import make_graph
+from oracle.oracle import GraphProblem
+for kind, tol in (("point", 1e-11), ("plane", 2e-5)):
+    gp = GraphProblem.from_synth(make_graph(200, 40, seed=4, landmark_kind=kind))
+    G = GraphSLAM.from_problem(gp)
+    U, b = G.linearize(); Uo, bo = gp.linearize()
+    f = lambda M: (M + sp.triu(M, 1).T).tocsc()
+    assert abs(f(U) - f(Uo)).max() <= tol * abs(Uo).max() and np.abs(b - bo).max() <= tol * max(1.0, np.abs(bo).max())
+    assert G.optimize(6)
+    st = gp.optimize(6)
+    assert G.last_stats.iterations == st.iterations and abs(G.last_stats.chi2_after - st.chi2_after) <= 1e-6 * st.chi2_after
+print("handover ok")
+''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, SSLAM_LIN_HANDOVER="1"), capture_output=True, text=True)
+    assert out.returncode == 0 and "handover ok" in out.stdout, out.stdout + out.stderr
