@@ -91,7 +91,8 @@ int sslam_graph_set_vertex(sslam_graph* g, int id, const double* in);
 int sslam_graph_hessian_index(sslam_graph* g, int id);
 
 /* Options (doubles): "solver" 1 = sparse block Cholesky (default; what "lm_var" + csparse selects in the reference),
- * 0 = block-Jacobi PCG; "pcg_tol" relative residual; "pcg_max_iters" */
+ * 0 = block-Jacobi PCG on the full system, 2 = Schur complement on the landmark block + PCG on the reduced pose system (matrix-free;
+ * BASELINE.json north_star); "pcg_tol" relative residual; "pcg_max_iters" */
 int sslam_graph_set_option(sslam_graph* g, const char* key, double value);
 
 /* GraphSLAM::optimize (graph_slam.cpp:182-219) with the iteration cap as a parameter (the

@@ -905,8 +905,54 @@ __device__ __forceinline__ double apply_minv(const BatchView& V, const RowRef& R
   return z;
 }
 
-// PCG start: x = 0, r = b, z = Minv r, p = z; partials of r.z and b.b
-__global__ __launch_bounds__(kRowChunk) void k_pcg_init(BatchView V) {
+// ---- Schur complement on the landmark block (solver 2, BASELINE.json north_star "Schur-complement + PCG") ------------------------
+// PCG runs on the reduced pose system  S = (Hpp + lambda I) - Hpl (Hll + lambda I)^-1 Hlp  without ever forming it: for a vector v
+// whose landmark part is  v_l = -(Hll + lambda I)^-1 Hlp v_p,  the pose rows of (H + lambda I) v are S v_p and its landmark rows
+// vanish, so the full-space SpMV / update kernels are reused as they are.  One thread per landmark (its 3 x 3 inverse is the
+// block-Jacobi preconditioner's, k_precond):
+//   mode 0: v_l = -(Hll + lambda I)^-1 (Hlp v_p)
+//   mode 1: v_l = -(Hll + lambda I)^-1 b_l and v_p = 0   (then the pose rows of (H + lambda I) v are  -Hpl (Hll + lambda I)^-1 b_l)
+//   mode 2: v_l += (Hll + lambda I)^-1 b_l               (the landmarks' back-substitution:  x_l = (Hll + lambda I)^-1 (b_l - Hlp x_p))
+__global__ __launch_bounds__(256) void k_schur_lm(BatchView V, double* v, int mode, int parity) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < V.nLr) {
+    const int l = t, g = V.lrow_graph[l];
+    if (!V.lm[g].in_trial) return;
+    if (mode == 0 && V.pcg_done[parity * V.B + g]) return;
+    const double* M = V.Minv + (size_t)V.nPr * 36 + (size_t)l * 9;
+    const size_t base = (size_t)6 * V.nPr + (size_t)3 * l;
+    double s[3] = {0, 0, 0};
+    if (mode == 0) {
+      const int arow = V.nPr + l;
+      const double* Hbase = V.Hpp_diag;
+      for (int a = V.adj_ptr[arow]; a < V.adj_ptr[arow + 1]; ++a) {   // a landmark row has pose neighbours only: blocks stored [pose][landmark]
+        const double* Bk = Hbase + V.adj_blk[a];
+        const double* pn = v + V.adj_x[a];
+#pragma unroll
+        for (int c = 0; c < 6; ++c) { s[0] += Bk[c * 3] * pn[c]; s[1] += Bk[c * 3 + 1] * pn[c]; s[2] += Bk[c * 3 + 2] * pn[c]; }
+      }
+    } else {
+      s[0] = V.bvec[base]; s[1] = V.bvec[base + 1]; s[2] = V.bvec[base + 2];
+    }
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      const double m = M[r * 3] * s[0] + M[r * 3 + 1] * s[1] + M[r * 3 + 2] * s[2];
+      if (mode == 2) v[base + r] += m; else v[base + r] = -m;
+    }
+  } else if (mode == 1 && t < V.nLr + V.nPr) {
+    const int row = t - V.nLr;
+    if (!V.lm[V.prow_graph[row]].in_trial) return;
+#pragma unroll
+    for (int c = 0; c < 6; ++c) v[(size_t)6 * row + c] = 0.0;
+  }
+}
+__global__ void k_pcg_reset(BatchView V) {   // before the right-hand-side SpMV of the Schur path: flags of the previous solve are stale
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g < V.B) { const int d = V.lm[g].in_trial ? 0 : 1; V.pcg_done[g] = d; V.pcg_done[V.B + g] = d; }
+}
+
+// PCG start: x = 0, r = b, z = Minv r, p = z; partials of r.z and b.b  (schur: r_p = b_p + q_p with q from the right-hand-side SpMV, r_l = 0)
+__global__ __launch_bounds__(kRowChunk) void k_pcg_init(BatchView V, int schur) {
   __shared__ double red[kRowChunk / 64];
   __shared__ double lr[kRowChunk];
   const int g = blockIdx.y;
@@ -915,7 +961,7 @@ __global__ __launch_bounds__(kRowChunk) void k_pcg_init(BatchView V) {
   if (blockIdx.x * kRowChunk >= sg.nprow * 6 + sg.nlrow * 3) return;
   const RowRef R = row_ref(V, sg, blockIdx.x * kRowChunk + threadIdx.x);
   double rv = 0;
-  if (R.valid) rv = V.bvec[R.xoff];
+  if (R.valid) rv = !schur ? V.bvec[R.xoff] : (R.is_pose ? V.bvec[R.xoff] + V.q[R.xoff] : 0.0);
   lr[threadIdx.x] = rv;
   __syncthreads();
   double zv = 0;
@@ -1555,7 +1601,14 @@ static int pcg_solve(Batch& b) {
   const BatchView& V = b.V;
   { ScopedTimer t(b, "precond");
     hipLaunchKernelGGL(k_precond, dim3(vert_blocks(b)), dim3(256), 0, b.stream, V); }
-  hipLaunchKernelGGL(k_pcg_init, row_grid(b), dim3(kRowChunk), 0, b.stream, V);
+  const bool schur = opt.solver == 2;
+  const dim3 lm_grid((V.nLr + V.nPr + 255) / 256);
+  if (schur) {   // reduced right-hand side  b_p - Hpl (Hll + lambda I)^-1 b_l  through one SpMV
+    hipLaunchKernelGGL(k_pcg_reset, dim3((V.B + 63) / 64), dim3(64), 0, b.stream, V);
+    hipLaunchKernelGGL(k_schur_lm, lm_grid, dim3(256), 0, b.stream, V, V.p, 1, 0);
+    hipLaunchKernelGGL(k_spmv, row_grid(b), dim3(kRowChunk), 0, b.stream, V, 0);
+  }
+  hipLaunchKernelGGL(k_pcg_init, row_grid(b), dim3(kRowChunk), 0, b.stream, V, schur ? 1 : 0);
   hipLaunchKernelGGL(k_pcg_init2, dim3(V.B), dim3(64), 0, b.stream, V);
   const double tol2 = opt.pcg_tol * opt.pcg_tol;
   int it = 0;
@@ -1563,6 +1616,7 @@ static int pcg_solve(Batch& b) {
   while (it < opt.pcg_max_iters) {
     for (int k = 0; k < check_every && it < opt.pcg_max_iters; ++k, ++it) {
       const int parity = it & 1;
+      if (schur) hipLaunchKernelGGL(k_schur_lm, lm_grid, dim3(256), 0, b.stream, V, V.p, 0, parity);
       { ScopedTimer t(b, "spmv");
         hipLaunchKernelGGL(k_spmv, row_grid(b), dim3(kRowChunk), 0, b.stream, V, parity); }
       { ScopedTimer t(b, "pcg_update");
@@ -1576,12 +1630,13 @@ static int pcg_solve(Batch& b) {
     b.harvest();
     if (flag) break;
   }
+  if (schur) hipLaunchKernelGGL(k_schur_lm, lm_grid, dim3(256), 0, b.stream, V, V.x, 2, 0);
   return launch_check("pcg");
 }
 
 static int batch_solve(Batch& b) {
   // (H + lambda I) dx = b for every graph with in_trial set; result in V.x
-  if (b.graphs[0]->opt.solver == 0) return pcg_solve(b);
+  if (b.graphs[0]->opt.solver == 0 || b.graphs[0]->opt.solver == 2) return pcg_solve(b);
   int rc;
   if (!b.chol && (rc = chol_plan_build(b))) return rc;
   if ((rc = chol_factor_and_forward(b))) return rc;
@@ -1777,7 +1832,7 @@ int sslam_graph_set_option(sslam_graph* h, const char* key, double value) {
   if (!h || !key) return set_error(SSLAM_ERR_INVALID, "null argument");
   Options& o = h->g.opt;
   const std::string k(key);
-  if (k == "solver") o.solver = (int)value;
+  if (k == "solver") { if (value != 0 && value != 1 && value != 2) return set_error(SSLAM_ERR_INVALID, "solver: 0 block-Jacobi PCG, 1 sparse block Cholesky, 2 Schur complement on the landmarks + PCG"); o.solver = (int)value; }
   else if (k == "pcg_tol") o.pcg_tol = value;
   else if (k == "pcg_max_iters") o.pcg_max_iters = (int)value;
   else if (k == "deterministic") { if (value == 0) return set_error(SSLAM_ERR_UNSUPPORTED, "the Jacobian build is always deterministic (gather form); the FP64-atomics variant was removed"); }

@@ -107,6 +107,27 @@ def test_pcg_solve_matches_oracle_cholesky(gpu_lib, lam):
     assert np.abs(x - xo).max() <= 1e-6 * np.abs(xo).max()
 
 
+@pytest.mark.parametrize("lam", [5.0, 1e-3])
+def test_schur_pcg_solve_matches_oracle_cholesky(gpu_lib, lam):
+    """solver 2: landmarks eliminated (Hll is block diagonal), PCG on the reduced pose system applied matrix-free, landmarks
+    back-substituted; same solution as the oracle's Cholesky.  A short LM run on top follows the oracle."""
+    from semantic_slam_amd import GraphSLAM
+    g = make_graph(120, 25, seed=1)
+    gp = GraphProblem.from_synth(g)
+    G = GraphSLAM.from_problem(gp)
+    G.set_option("solver", 2)
+    G.set_option("pcg_tol", 1e-10)
+    x, its = G.solve(lam)
+    xo = gp.solve(lam)
+    assert its > 0
+    assert np.abs(x - xo).max() <= 1e-6 * np.abs(xo).max()
+    if lam == 5.0:
+        assert G.optimize(4)
+        st = gp.optimize(4)
+        assert G.last_stats.iterations == st.iterations
+        assert G.last_stats.chi2_after == pytest.approx(st.chi2_after, rel=1e-5)
+
+
 @pytest.mark.parametrize("lam", [5.0, 1e-3, 0.0])
 def test_cholesky_solve_matches_oracle_cholesky(gpu_lib, lam):
     from semantic_slam_amd import GraphSLAM
