@@ -1783,6 +1783,13 @@ static int add_edge(sslam_graph* h, int type, int i, int j, const double* z, int
   if (G.vtype[i] != VT_SE3) return set_error(SSLAM_ERR_INVALID, "vertex %d is not an SE3 vertex", i);
   const int want = type == ET_SE3 ? VT_SE3 : (type == ET_SE3_POINT ? VT_POINT : VT_PLANE);
   if (G.vtype[j] != want) return set_error(SSLAM_ERR_INVALID, "vertex %d has the wrong type for this edge", j);
+  // only the upper triangle of the information matrix travels to the device: an asymmetric one would be symmetrised silently
+  double amax = 0;
+  for (int k = 0; k < d * d; ++k) { if (!std::isfinite(info[k])) return set_error(SSLAM_ERR_INVALID, "information matrix has a non-finite entry"); amax = std::max(amax, std::fabs(info[k])); }
+  for (int r = 0; r < d; ++r)
+    for (int c = r + 1; c < d; ++c)
+      if (std::fabs(info[r * d + c] - info[c * d + r]) > 1e-9 * amax)
+        return set_error(SSLAM_ERR_INVALID, "information matrix is not symmetric (entries (%d,%d) and (%d,%d) differ)", r, c, c, r);
   const int id = G.ne();
   G.etype.push_back(type); G.evi.push_back(i); G.evj.push_back(j);
   for (int k = 0; k < 7; ++k) G.meas.push_back(k < nz ? z[k] : 0.0);

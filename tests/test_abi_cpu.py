@@ -50,6 +50,14 @@ def test_vertex_and_edge_bookkeeping(hip_lib):
         G.add_plane_node([0, 0, 0, 1.0])                             # zero normal
     pl = G.add_plane_node([0, 0, 2.0, 4.0])
     assert np.allclose(G.estimate(pl), [0, 0, 1, 2])                 # Plane3D normalises its vector
+    # only the upper triangle of an information matrix reaches the device: asymmetric or non-finite ones are refused
+    W = np.eye(6); W[0, 1] = 0.3
+    with pytest.raises(SslamError):
+        G.add_se3_edge(a, b, [1, 2, 3, 0, 0, 0, 1], W)
+    W[1, 0] = 0.3
+    assert G.add_se3_edge(a, b, [1, 2, 3, 0, 0, 0, 1], W) == 2
+    with pytest.raises(SslamError):
+        G.add_se3_point_xyz_edge(a, p, [1, 2, 3], np.diag([1.0, np.nan, 1.0]))
 
 
 def test_optimize_with_fewer_than_ten_edges_returns_false(hip_lib):
@@ -60,6 +68,30 @@ def test_optimize_with_fewer_than_ten_edges_returns_false(hip_lib):
         G.add_se3_edge(a, b, [1, 0, 0, 0, 0, 0, 1], np.eye(6))
     assert G.optimize() is False                                      # graph_slam.cpp:184-186
     assert G.last_stats.status == -5
+
+
+def test_orchestrator_host_logic(hip_lib):
+    """keyframe gate and queue of the orchestrator C-ABI (keyframe_updater.hpp:41-65, semantic_graph_slam.cpp:234-287) need no device;
+    the tick itself does and says so"""
+    from semantic_slam_amd import SslamError
+    from semantic_slam_amd.semantic_graph_slam import SemanticGraphSLAM, default_slam_params
+    p = default_slam_params()
+    assert (p.keyframe_delta_trans, p.keyframe_delta_angle, p.keyframe_delta_time, p.max_keyframes_per_update) == (0.5, 0.5, 1.0, 10)
+    assert (p.maha_dist_thres, p.eq_dist_thres, p.land_noise_low, p.use_maha_dist, p.max_iterations) == (0.5, 1.21, 0.5, 1, 1024)
+    S = SemanticGraphSLAM(p)
+    I = [0, 0, 0, 0, 0, 0, 1.0]
+    assert S.VIOCallback((0, 0), I)                                   # first sample always
+    assert not S.VIOCallback((0, 900000000), [0.4, 0, 0, 0, 0, 0, 1])
+    assert S.VIOCallback((0, 950000000), [0.5, 0, 0, 0, 0, 0, 1])     # 0.5 m
+    assert not S.VIOCallback((1, 900000000), [0.5, 0, 0, 0, 0, 0, 1]) # 0.95 s: ros::Duration::sec == 0
+    assert S.VIOCallback((1, 950000000), [0.5, 0, 0, 0, 0, 0, 1])     # 1.0 s
+    p2 = default_slam_params(); p2.use_const_inf_matrix = 0
+    with pytest.raises(SslamError):                                    # the reference's other branch reads uninitialised members
+        SemanticGraphSLAM(p2)
+    if hip_lib.sslam_device_count() == 0:
+        # three keyframes, two odometry edges: GraphSLAM::optimize refuses (< 10 edges) before any device work, like the reference
+        assert S.run() and S.last_stats.keyframes_added == 3 and not S.last_stats.optimized
+        assert len(S.getKeyframes()[0]) == 3 and S.getMappedLandmarks() == []
 
 
 def test_compute_entry_points_fail_loudly_without_a_gpu(hip_lib):
