@@ -103,6 +103,16 @@ class point_cloud_segmentation {
   sslam_seg* seg_ = nullptr;
 
  public:
+  // point-to-plane ICP of labelled points against planes (north_star; no counterpart in the reference): T = R row-major | t
+  struct IcpResult { std::array<double, 12> T; double rms; int points; };
+  IcpResult icpPointToPlane(const float* xyz, const int32_t* labels, int n, const float* planes, int n_planes, int iterations = 10,
+                            const double* T0 = nullptr) {
+    IcpResult r{};
+    r.points = sslam_seg_icp_point_to_plane(seg_, xyz, labels, n, planes, n_planes, iterations, T0, r.T.data(), &r.rms);
+    if (r.points < 0) throw std::runtime_error(std::string("sslam_seg_icp_point_to_plane: ") + sslam_last_error());
+    return r;
+  }
+
   // the C-ABI handle (the orchestrator shim, ps_graph_slam_amd/semantic_graph_slam.hpp, borrows it for the tick's batched frontend pass)
   sslam_seg* handle() const { return seg_; }
 };

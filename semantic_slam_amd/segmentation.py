@@ -79,6 +79,8 @@ def _bind(lib):
     lib.sslam_seg_ransac_plane.argtypes = [vp, vp, ci, C.c_float, ci, C.c_double, C.c_uint64, vp, vp, ci]
     lib.sslam_seg_convex_hull_2d.restype = ci
     lib.sslam_seg_convex_hull_2d.argtypes = [vp, vp, ci, vp, ci, vp, vp, vp, ci, vp]
+    lib.sslam_seg_icp_point_to_plane.restype = ci
+    lib.sslam_seg_icp_point_to_plane.argtypes = [vp, vp, vp, ci, vp, ci, ci, vp, vp, C.POINTER(C.c_double)]
     _BOUND = True
 
 
@@ -212,6 +214,20 @@ class PointCloudSegmentation:
         h = self._check(self._lib.sslam_seg_convex_hull_2d(self._h, pts.ctypes.data, len(pts), inl.ctypes.data, len(inl), co.ctypes.data,
                                                             proj.ctypes.data, hull.ctypes.data, len(hull), C.byref(axes)))
         return proj, hull[:h].copy(), axes.value
+
+
+    def icp_point_to_plane(self, xyz, labels, planes, iterations: int = 10, T0=None):
+        """Point-to-plane ICP of labelled points against planes (row J1, ``sslam_seg_icp_point_to_plane``).
+        Returns (T[12] = R row-major | t, rms, points used)."""
+        pts = np.ascontiguousarray(xyz, np.float32).reshape(-1, 3)
+        lab = np.ascontiguousarray(labels, np.int32).reshape(-1)
+        pl = np.ascontiguousarray(planes, np.float32).reshape(-1, 4)
+        t0 = None if T0 is None else np.ascontiguousarray(T0, np.float64).reshape(12)
+        out = np.zeros(12); rms = C.c_double(0.0)
+        n = self._check(self._lib.sslam_seg_icp_point_to_plane(self._h, pts.ctypes.data, lab.ctypes.data, len(pts), pl.ctypes.data, len(pl),
+                                                               int(iterations), None if t0 is None else t0.ctypes.data, out.ctypes.data,
+                                                               C.byref(rms)))
+        return out, rms.value, n
 
     def compute2DConvexHull(self, xyz, seed: int = 0):
         """plane_segmentation::compute2DConvexHull (plane_segmentation.cpp:631-665): RANSAC plane (threshold 0.01, refined

@@ -305,3 +305,15 @@ def test_np_restatement_matches_c_oracle_on_a_full_frame():
         pts = np.ascontiguousarray(xyz[b["tl_y"]:b["tl_y"] + b["height"], b["tl_x"]:b["tl_x"] + b["width"]]).reshape(-1, 3)
         planes += _compare_box(pts, int(b["width"]), int(b["height"]), 500)
     assert planes >= 1
+
+
+def test_icp_oracle_recovers_a_known_motion():
+    """oracle/np_icp.py (row J1): a cloud moved by 0.03 rad / 5 cm against four planes is brought back to them"""
+    from oracle.np_icp import icp_point_to_plane
+    from tests.icp_scene import make_icp_scene
+    obs, lab, planes, T_true = make_icp_scene(seed=0)
+    T, rms, n = icp_point_to_plane(obs, lab, planes, 8)
+    assert n > 14000 and rms < 3e-3
+    assert np.abs(T - T_true).max() < 2e-3
+    T0, rms0, _ = icp_point_to_plane(obs, lab, planes, 0)
+    assert np.allclose(T0, [1, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0]) and rms0 > 5 * rms

@@ -295,3 +295,30 @@ def test_golden_hull_fixture(gpu_lib):
     assert np.array_equal(inl, g["inliers"]) and np.array_equal(coeff, g["coeff"])
     proj, hull, axes = seg.convex_hull_2d(g["points"], inl, coeff)
     assert axes == int(g["axes"]) and np.array_equal(hull, g["hull"]) and np.array_equal(proj[hull], g["hull_points"])
+
+
+def test_icp_point_to_plane_matches_oracle(gpu_lib):
+    """row J1: Gauss-Newton point-to-plane ICP, one reduction pass per round on the device.  Same transform as the NumPy oracle to
+    1e-9 (double sums in a different order), the known motion recovered, residual at the noise level; a plane set that leaves a
+    direction free is refused."""
+    from oracle.np_icp import icp_point_to_plane
+    from tests.icp_scene import make_icp_scene
+    from semantic_slam_amd import SslamError
+    from semantic_slam_amd.segmentation import PointCloudSegmentation
+    seg = PointCloudSegmentation()
+    for seed in (0, 1):
+        obs, lab, planes, T_true = make_icp_scene(seed=seed)
+        for iters in (1, 8):
+            T, rms, n = seg.icp_point_to_plane(obs, lab, planes, iters)
+            To, rmso, no = icp_point_to_plane(obs, lab, planes, iters)
+            assert n == no
+            assert np.abs(T - To).max() <= 1e-9 and abs(rms - rmso) <= 1e-9
+        assert np.abs(T - T_true).max() < 2e-3 and rms < 3e-3
+        # warm start from the answer: nothing moves
+        T2, rms2, _ = seg.icp_point_to_plane(obs, lab, planes, 2, T0=T)
+        assert np.abs(T2 - T).max() < 1e-6
+    obs, lab, planes, _ = make_icp_scene(seed=2)
+    only_floor = np.where(lab == 0, 0, -1).astype(np.int32)
+    with pytest.raises(SslamError) as ei:
+        seg.icp_point_to_plane(obs, only_floor, planes, 3)
+    assert ei.value.code == -4
