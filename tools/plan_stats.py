@@ -1,6 +1,7 @@
-"""Structure of the Cholesky plan of one L graph: pieces, columns per piece, U sizes."""
+"""Structure of the Cholesky plan of one L graph (host only, no GPU): pieces, columns per piece, update-matrix sizes, launches, LDS needs.
+usage: python tools/plan_stats.py"""
 import sys, numpy as np
-sys.path.insert(0, '/root/repo')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from semantic_slam_amd import GraphSLAM, _lib
 from semantic_slam_amd.synth import make_graph
 from tests.chol_plan_exec import Plan
