@@ -103,6 +103,28 @@ class point_cloud_segmentation {
   sslam_seg* seg_ = nullptr;
 
  public:
+  // cloud filters of the legacy path (plane_segmentation.cpp:557-629), on unorganised xyz float clouds
+  std::vector<int32_t> distance_filter(const float* xyz, int n, double dmin = 0.3, double dmax = 3.0) {
+    std::vector<int32_t> keep(n > 0 ? n : 1);
+    const int m = sslam_seg_distance_filter(seg_, xyz, n, dmin, dmax, keep.data(), n);
+    if (m < 0) throw std::runtime_error(std::string("sslam_seg_distance_filter: ") + sslam_last_error());
+    keep.resize(m);
+    return keep;
+  }
+  std::vector<std::array<float, 3>> downsamplePointcloud(const float* xyz, int n, float leaf = 0.1f) {
+    std::vector<std::array<float, 3>> out(n > 0 ? n : 1);
+    const int m = sslam_seg_voxel_grid(seg_, xyz, n, leaf, &out[0][0], nullptr, (int)out.size());
+    if (m < 0) throw std::runtime_error(std::string("sslam_seg_voxel_grid: ") + sslam_last_error());
+    out.resize(m);
+    return out;
+  }
+  std::vector<int32_t> removeOutliers(const float* xyz, int n, int mean_k = 50, double stddev_mul = 1.0) {
+    std::vector<int32_t> keep(n > 0 ? n : 1);
+    const int m = sslam_seg_statistical_outlier_removal(seg_, xyz, n, mean_k, stddev_mul, keep.data(), n, nullptr);
+    if (m < 0) throw std::runtime_error(std::string("sslam_seg_statistical_outlier_removal: ") + sslam_last_error());
+    keep.resize(m);
+    return keep;
+  }
   // point-to-plane ICP of labelled points against planes (north_star; no counterpart in the reference): T = R row-major | t
   struct IcpResult { std::array<double, 12> T; double rms; int points; };
   IcpResult icpPointToPlane(const float* xyz, const int32_t* labels, int n, const float* planes, int n_planes, int iterations = 10,

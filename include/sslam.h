@@ -276,6 +276,22 @@ int sslam_seg_convex_hull_2d(sslam_seg* s, const float* xyz, int n, const int32_
 int sslam_seg_icp_point_to_plane(sslam_seg* s, const float* xyz, const int32_t* labels, int n, const float* planes, int n_planes,
                                  int iterations, const double T0[12], double T_out[12], double* rms_out);
 
+/* ---- cloud filters of the legacy path (dead code upstream) -----------------------------------------------------
+ * All three take an unorganised cloud of n xyz float points and run on the GPU; index outputs are ascending and complete when the
+ * return value (the true count) does not exceed max_out. */
+/* plane_segmentation::distance_filter (plane_segmentation.cpp:607-629): indices of the points with dmin < |p| < dmax (0.3, 3 upstream) */
+int sslam_seg_distance_filter(sslam_seg* s, const float* xyz, int n, double dmin, double dmax, int32_t* keep_out, int max_out);
+/* plane_segmentation::downsamplePointcloud -> pcl::VoxelGrid (plane_segmentation.cpp:565-581; leaf 0.1 upstream): one centroid per
+ * occupied voxel of the bounding box of the finite points, in ascending voxel index (x fastest), optionally with the voxel's point
+ * count.  Sums are kept in 2^-20 fixed point with integer atomics (order independent; PCL accumulates in float in the order of an
+ * unstable sort).  Returns the number of occupied voxels. */
+int sslam_seg_voxel_grid(sslam_seg* s, const float* xyz, int n, float leaf, float* centroids_out, int32_t* counts_out, int max_out);
+/* plane_segmentation::removeOutliers -> pcl::StatisticalOutlierRemoval (plane_segmentation.cpp:583-605; meanK 50, multiplier 1.0
+ * upstream): a point stays when its mean distance to its mean_k nearest neighbours (exact search) is not above mean + stddev_mul *
+ * standard deviation of those mean distances.  mean_dist_out (optional, n floats; -1 for non-finite points).  Returns the inlier count. */
+int sslam_seg_statistical_outlier_removal(sslam_seg* s, const float* xyz, int n, int mean_k, double stddev_mul, int32_t* keep_out, int max_out,
+                                          float* mean_dist_out);
+
 /* parity hooks: per-box products of the last sslam_seg_segment call.
  * normals: w*h*4 floats (nx,ny,nz,curvature), labels: w*h int32 (-1 = no plane; otherwise the
  * region index in output order of pcl::OrganizedMultiPlaneSegmentation::segmentAndRefine). */

@@ -1203,6 +1203,137 @@ __global__ __launch_bounds__(256) void k_icp_accumulate(const float* __restrict_
   __syncthreads();
   if (threadIdx.x < kIcpSums) partial[(size_t)blockIdx.x * kIcpSums + threadIdx.x] = ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
 }
+
+// ---- cloud filters of the legacy path (plane_segmentation.cpp:557-629) ---------------------------------------------
+// ordered compaction of a flag array (ascending indices): per-block counts -> k_ransac_scan -> write
+__global__ __launch_bounds__(256) void k_flag_count(const unsigned char* __restrict__ flag, int n, int* __restrict__ block_counts) {
+  __shared__ int wsum[4];
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  int c = (i < n && flag[i]) ? 1 : 0;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o, 64);
+  if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) block_counts[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+__global__ __launch_bounds__(256) void k_flag_write(const unsigned char* __restrict__ flag, int n, const int* __restrict__ block_off, int* __restrict__ out, int max_out) {
+  __shared__ int woff[4];
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  const bool in = i < n && flag[i];
+  const unsigned long long mask = __ballot(in);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) woff[wave] = __popcll(mask);
+  __syncthreads();
+  int base = block_off[blockIdx.x];
+  for (int w = 0; w < wave; ++w) base += woff[w];
+  if (in) {
+    const int pos = base + __popcll(mask & ((1ull << lane) - 1ull));
+    if (pos < max_out) out[pos] = i;
+  }
+}
+// distance_filter (plane_segmentation.cpp:607-629): keep p with 0.3 < |p| < 3 (float norm, compared as double)
+__global__ __launch_bounds__(256) void k_range_flag(const float* __restrict__ pts, int n, double dmin, double dmax, unsigned char* __restrict__ flag) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const float x = pts[3 * (size_t)i], y = pts[3 * (size_t)i + 1], z = pts[3 * (size_t)i + 2];
+  const double d = (double)sqrtf((x * x + y * y) + z * z);
+  flag[i] = (d > dmin && d < dmax) ? 1 : 0;
+}
+// pcl::VoxelGrid (leaf 0.1, plane_segmentation.cpp:565-581).  Bounding box of the finite points: per-block float min / max
+__global__ __launch_bounds__(256) void k_voxel_minmax(const float* __restrict__ pts, int n, float* __restrict__ part) {
+  __shared__ float red[4][6];
+  float lo[3] = {3.402823466e+38f, 3.402823466e+38f, 3.402823466e+38f}, hi[3] = {-3.402823466e+38f, -3.402823466e+38f, -3.402823466e+38f};
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+    const float x = pts[3 * (size_t)i], y = pts[3 * (size_t)i + 1], z = pts[3 * (size_t)i + 2];
+    if (!(isfinite(x) && isfinite(y) && isfinite(z))) continue;
+    lo[0] = fminf(lo[0], x); lo[1] = fminf(lo[1], y); lo[2] = fminf(lo[2], z);
+    hi[0] = fmaxf(hi[0], x); hi[1] = fmaxf(hi[1], y); hi[2] = fmaxf(hi[2], z);
+  }
+#pragma unroll
+  for (int k = 0; k < 3; ++k)
+    for (int o = 32; o > 0; o >>= 1) { lo[k] = fminf(lo[k], __shfl_down(lo[k], o, 64)); hi[k] = fmaxf(hi[k], __shfl_down(hi[k], o, 64)); }
+  if ((threadIdx.x & 63) == 0) for (int k = 0; k < 3; ++k) { red[threadIdx.x >> 6][k] = lo[k]; red[threadIdx.x >> 6][3 + k] = hi[k]; }
+  __syncthreads();
+  if (threadIdx.x < 3) part[blockIdx.x * 6 + threadIdx.x] = fminf(fminf(red[0][threadIdx.x], red[1][threadIdx.x]), fminf(red[2][threadIdx.x], red[3][threadIdx.x]));
+  else if (threadIdx.x < 6) part[blockIdx.x * 6 + threadIdx.x] = fmaxf(fmaxf(red[0][threadIdx.x], red[1][threadIdx.x]), fmaxf(red[2][threadIdx.x], red[3][threadIdx.x]));
+}
+struct VoxelGeom { float inv[3]; int minb[3]; int mul[3]; };
+// cell of every finite point; per cell: point count and the coordinate sums in 2^-20 fixed point (integer atomics: exact and
+// independent of the order in which the points arrive -- PCL's own accumulation order is that of an unstable sort)
+__global__ __launch_bounds__(256) void k_voxel_accumulate(const float* __restrict__ pts, int n, VoxelGeom G, int* __restrict__ count, long long* __restrict__ sums) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const float x = pts[3 * (size_t)i], y = pts[3 * (size_t)i + 1], z = pts[3 * (size_t)i + 2];
+  if (!(isfinite(x) && isfinite(y) && isfinite(z))) return;
+  const int ix = (int)floorf(x * G.inv[0]) - G.minb[0], iy = (int)floorf(y * G.inv[1]) - G.minb[1], iz = (int)floorf(z * G.inv[2]) - G.minb[2];
+  const size_t c = (size_t)ix * G.mul[0] + (size_t)iy * G.mul[1] + (size_t)iz * G.mul[2];
+  atomicAdd(&count[c], 1);
+  atomicAdd((unsigned long long*)&sums[3 * c], (unsigned long long)llrint((double)x * 1048576.0));
+  atomicAdd((unsigned long long*)&sums[3 * c + 1], (unsigned long long)llrint((double)y * 1048576.0));
+  atomicAdd((unsigned long long*)&sums[3 * c + 2], (unsigned long long)llrint((double)z * 1048576.0));
+}
+__global__ __launch_bounds__(256) void k_voxel_flag(const int* __restrict__ count, int ncell, unsigned char* __restrict__ flag) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c < ncell) flag[c] = count[c] > 0;
+}
+__global__ __launch_bounds__(256) void k_voxel_centroids(const int* __restrict__ cells, int nocc, const int* __restrict__ count, const long long* __restrict__ sums,
+                                                        float* __restrict__ out, int* __restrict__ out_count) {
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  if (k >= nocc) return;
+  const int c = cells[k], m = count[c];
+#pragma unroll
+  for (int d = 0; d < 3; ++d) out[3 * (size_t)k + d] = (float)(((double)sums[3 * (size_t)c + d] / 1048576.0) / (double)m);
+  if (out_count) out_count[k] = m;
+}
+// pcl::StatisticalOutlierRemoval (meanK 50, plane_segmentation.cpp:583-605): mean distance of every point to its k nearest
+// neighbours, exact (brute force): candidates stream through LDS tiles, every thread keeps the k + 1 smallest squared distances of
+// its query in an LDS column (replace-the-maximum; after the first tiles almost every candidate is rejected by one compare)
+constexpr int kSorMaxK = 64;
+__global__ __launch_bounds__(128) void k_sor_mean_distance(const float* __restrict__ pts, int n, int k, float* __restrict__ mean_dist) {
+  extern __shared__ float sm[];
+  float* tile = sm;                         // [128][3]
+  float* best = sm + 128 * 3;               // [k + 1][128]
+  const int i = blockIdx.x * 128 + threadIdx.x, tid = threadIdx.x;
+  const bool valid_i = i < n;
+  float qx = 0, qy = 0, qz = 0;
+  bool fin = false;
+  if (valid_i) { qx = pts[3 * (size_t)i]; qy = pts[3 * (size_t)i + 1]; qz = pts[3 * (size_t)i + 2]; fin = isfinite(qx) && isfinite(qy) && isfinite(qz); }
+  const int K = k + 1;
+  for (int j = 0; j < K; ++j) best[j * 128 + tid] = 3.402823466e+38f;
+  float cur_max = 3.402823466e+38f;
+  int arg_max = 0;
+  for (int t0 = 0; t0 < n; t0 += 128) {
+    __syncthreads();
+    const int c = t0 + tid;
+    tile[tid * 3] = c < n ? pts[3 * (size_t)c] : __int_as_float(0x7fc00000);
+    tile[tid * 3 + 1] = c < n ? pts[3 * (size_t)c + 1] : __int_as_float(0x7fc00000);
+    tile[tid * 3 + 2] = c < n ? pts[3 * (size_t)c + 2] : __int_as_float(0x7fc00000);
+    __syncthreads();
+    if (!fin) continue;
+    const int m = min(128, n - t0);
+    for (int j = 0; j < m; ++j) {
+      const float dx = qx - tile[j * 3], dy = qy - tile[j * 3 + 1], dz = qz - tile[j * 3 + 2];
+      const float d = (dx * dx + dy * dy) + dz * dz;      // flann::L2_Simple<float>
+      if (d < cur_max) {                                   // NaN candidates fail the compare
+        best[arg_max * 128 + tid] = d;
+        cur_max = best[tid]; arg_max = 0;
+        for (int q = 1; q < K; ++q) { const float v = best[q * 128 + tid]; if (v > cur_max) { cur_max = v; arg_max = q; } }
+      }
+    }
+  }
+  if (!valid_i) return;
+  if (!fin) { mean_dist[i] = -1.0f; return; }              // not a finite point: takes no part (marked for the host)
+  // ascending insertion sort of the k + 1 values, then the sum of the square roots of entries 1..k in that order (entry 0 is the point itself)
+  for (int a = 1; a < K; ++a) {
+    const float v = best[a * 128 + tid];
+    int b = a - 1;
+    while (b >= 0 && best[b * 128 + tid] > v) { best[(b + 1) * 128 + tid] = best[b * 128 + tid]; --b; }
+    best[(b + 1) * 128 + tid] = v;
+  }
+  double sum = 0;
+  for (int a = 1; a < K; ++a) sum += (double)sqrtf(best[a * 128 + tid]);
+  mean_dist[i] = (float)(sum / (double)k);
+}
 }  // namespace seg
 }  // namespace sslam
 
@@ -1255,6 +1386,41 @@ static int seg_alloc(sslam_seg* s, size_t n, T** out) {
   *out = (T*)p;
   return 0;
 }
+
+// helpers of the cloud filters (row f4)
+namespace {
+struct DevGuard {
+  std::vector<void*> ptrs;
+  ~DevGuard() { for (void* p : ptrs) if (p) (void)hipFree(p); }
+  template <class T> int alloc(T** p, size_t count) {
+    void* q = nullptr;
+    SSLAM_HIP_TRY(hipMalloc(&q, std::max<size_t>(count, 1) * sizeof(T)));
+    ptrs.push_back(q); *p = (T*)q;
+    return 0;
+  }
+};
+int seg_device(sslam_seg* s) {
+  int nd = 0;
+  if (hipGetDeviceCount(&nd) != hipSuccess || nd <= 0) return set_error(SSLAM_ERR_NO_DEVICE, "no HIP device visible; the product has no CPU fallback");
+  SSLAM_HIP_TRY(hipSetDevice(s->P.device));
+  if (!s->stream) SSLAM_HIP_TRY(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
+  return 0;
+}
+// ascending indices of the set flags -> out (host); returns their number
+int compact_flags(sslam_seg* s, DevGuard& g, const unsigned char* d_flag, int n, int* d_out, int max_out, int* total_out) {
+  const int nblk = (n + 255) / 256;
+  int *d_blk = nullptr, *d_total = nullptr;
+  int rc;
+  if ((rc = g.alloc(&d_blk, nblk)) || (rc = g.alloc(&d_total, 1))) return rc;
+  hipLaunchKernelGGL(k_flag_count, dim3(nblk), dim3(256), 0, s->stream, d_flag, n, d_blk);
+  hipLaunchKernelGGL(k_ransac_scan, dim3(1), dim3(64), 0, s->stream, d_blk, nblk, d_total);
+  hipLaunchKernelGGL(k_flag_write, dim3(nblk), dim3(256), 0, s->stream, d_flag, n, d_blk, d_out, max_out);
+  SSLAM_HIP_TRY(hipGetLastError());
+  SSLAM_HIP_TRY(hipMemcpyAsync(total_out, d_total, sizeof(int), hipMemcpyDeviceToHost, s->stream));
+  SSLAM_HIP_TRY(hipStreamSynchronize(s->stream));
+  return 0;
+}
+}  // namespace
 
 extern "C" {
 
@@ -1786,6 +1952,108 @@ int sslam_seg_icp_point_to_plane(sslam_seg* s, const float* xyz, const int32_t* 
   for (int k = 0; k < 3; ++k) T_out[9 + k] = T.t[k];
   if (rms_out) *rms_out = sums[28] > 0 ? std::sqrt(sums[27] / sums[28]) : 0.0;
   return (int)sums[28];
+}
+
+
+// ---- cloud filters ------------------------------------------------------------------------------------------------
+
+int sslam_seg_distance_filter(sslam_seg* s, const float* xyz, int n, double dmin, double dmax, int32_t* keep_out, int max_out) {
+  if (!s || !xyz || n < 0 || (!keep_out && max_out > 0)) return set_error(SSLAM_ERR_INVALID, "bad argument");
+  int rc = seg_device(s);
+  if (rc) return rc;
+  if (n == 0) return 0;
+  DevGuard g;
+  float* d_pts = nullptr; unsigned char* d_flag = nullptr; int* d_out = nullptr;
+  if ((rc = g.alloc(&d_pts, (size_t)n * 3)) || (rc = g.alloc(&d_flag, n)) || (rc = g.alloc(&d_out, n))) return rc;
+  SSLAM_HIP_TRY(hipMemcpyAsync(d_pts, xyz, (size_t)n * 3 * sizeof(float), hipMemcpyHostToDevice, s->stream));
+  hipLaunchKernelGGL(k_range_flag, dim3((n + 255) / 256), dim3(256), 0, s->stream, d_pts, n, dmin, dmax, d_flag);
+  int total = 0;
+  if ((rc = compact_flags(s, g, d_flag, n, d_out, n, &total))) return rc;
+  const int m = std::min(total, max_out);
+  if (m > 0) SSLAM_HIP_TRY(hipMemcpy(keep_out, d_out, (size_t)m * sizeof(int), hipMemcpyDeviceToHost));
+  return total;
+}
+
+int sslam_seg_voxel_grid(sslam_seg* s, const float* xyz, int n, float leaf, float* centroids_out, int32_t* counts_out, int max_out) {
+  if (!s || !xyz || n < 0 || !(leaf > 0) || (!centroids_out && max_out > 0)) return set_error(SSLAM_ERR_INVALID, "bad argument");
+  int rc = seg_device(s);
+  if (rc) return rc;
+  if (n == 0) return 0;
+  DevGuard g;
+  float *d_pts = nullptr, *d_part = nullptr;
+  const int nblk = std::min(256, (n + 255) / 256);
+  if ((rc = g.alloc(&d_pts, (size_t)n * 3)) || (rc = g.alloc(&d_part, (size_t)nblk * 6))) return rc;
+  SSLAM_HIP_TRY(hipMemcpyAsync(d_pts, xyz, (size_t)n * 3 * sizeof(float), hipMemcpyHostToDevice, s->stream));
+  hipLaunchKernelGGL(k_voxel_minmax, dim3(nblk), dim3(256), 0, s->stream, d_pts, n, d_part);
+  std::vector<float> part((size_t)nblk * 6);
+  SSLAM_HIP_TRY(hipMemcpyAsync(part.data(), d_part, part.size() * sizeof(float), hipMemcpyDeviceToHost, s->stream));
+  SSLAM_HIP_TRY(hipStreamSynchronize(s->stream));
+  float lo[3] = {3.402823466e+38f, 3.402823466e+38f, 3.402823466e+38f}, hi[3] = {-3.402823466e+38f, -3.402823466e+38f, -3.402823466e+38f};
+  for (int b = 0; b < nblk; ++b) for (int k = 0; k < 3; ++k) { lo[k] = std::min(lo[k], part[(size_t)b * 6 + k]); hi[k] = std::max(hi[k], part[(size_t)b * 6 + 3 + k]); }
+  if (!(lo[0] <= hi[0])) return 0;   // no finite point
+  // pcl::VoxelGrid::applyFilter: inverse leaf size, integer bounds of the box, cell strides
+  VoxelGeom G;
+  long long div[3];
+  for (int k = 0; k < 3; ++k) {
+    G.inv[k] = 1.0f / leaf;
+    G.minb[k] = (int)std::floor(lo[k] * G.inv[k]);
+    const int maxb = (int)std::floor(hi[k] * G.inv[k]);
+    div[k] = (long long)maxb - G.minb[k] + 1;
+  }
+  const long long ncell = div[0] * div[1] * div[2];
+  if (ncell > (1ll << 26)) return set_error(SSLAM_ERR_UNSUPPORTED, "voxel grid of %lld cells: leaf size too small for the extent of the cloud (PCL refuses as well)", ncell);
+  G.mul[0] = 1; G.mul[1] = (int)div[0]; G.mul[2] = (int)(div[0] * div[1]);
+  int* d_count = nullptr; long long* d_sums = nullptr; unsigned char* d_flag = nullptr; int* d_cells = nullptr;
+  if ((rc = g.alloc(&d_count, (size_t)ncell)) || (rc = g.alloc(&d_sums, (size_t)ncell * 3)) || (rc = g.alloc(&d_flag, (size_t)ncell)) || (rc = g.alloc(&d_cells, (size_t)ncell))) return rc;
+  SSLAM_HIP_TRY(hipMemsetAsync(d_count, 0, (size_t)ncell * sizeof(int), s->stream));
+  SSLAM_HIP_TRY(hipMemsetAsync(d_sums, 0, (size_t)ncell * 3 * sizeof(long long), s->stream));
+  hipLaunchKernelGGL(k_voxel_accumulate, dim3((n + 255) / 256), dim3(256), 0, s->stream, d_pts, n, G, d_count, d_sums);
+  hipLaunchKernelGGL(k_voxel_flag, dim3((int)((ncell + 255) / 256)), dim3(256), 0, s->stream, d_count, (int)ncell, d_flag);
+  int nocc = 0;
+  if ((rc = compact_flags(s, g, d_flag, (int)ncell, d_cells, (int)ncell, &nocc))) return rc;
+  if (nocc == 0) return 0;
+  float* d_out = nullptr; int* d_oc = nullptr;
+  if ((rc = g.alloc(&d_out, (size_t)nocc * 3)) || (rc = g.alloc(&d_oc, nocc))) return rc;
+  hipLaunchKernelGGL(k_voxel_centroids, dim3((nocc + 255) / 256), dim3(256), 0, s->stream, d_cells, nocc, d_count, d_sums, d_out, d_oc);
+  SSLAM_HIP_TRY(hipGetLastError());
+  const int m = std::min(nocc, max_out);
+  if (m > 0) {
+    SSLAM_HIP_TRY(hipMemcpyAsync(centroids_out, d_out, (size_t)m * 3 * sizeof(float), hipMemcpyDeviceToHost, s->stream));
+    if (counts_out) SSLAM_HIP_TRY(hipMemcpyAsync(counts_out, d_oc, (size_t)m * sizeof(int), hipMemcpyDeviceToHost, s->stream));
+  }
+  SSLAM_HIP_TRY(hipStreamSynchronize(s->stream));
+  return nocc;
+}
+
+int sslam_seg_statistical_outlier_removal(sslam_seg* s, const float* xyz, int n, int mean_k, double stddev_mul, int32_t* keep_out, int max_out,
+                                          float* mean_dist_out) {
+  if (!s || !xyz || n < 0 || mean_k < 1 || mean_k >= kSorMaxK || (!keep_out && max_out > 0)) return set_error(SSLAM_ERR_INVALID, "bad argument (mean_k must be in [1, %d))", kSorMaxK);
+  int rc = seg_device(s);
+  if (rc) return rc;
+  if (n == 0) return 0;
+  if (n < mean_k + 1) return set_error(SSLAM_ERR_INVALID, "fewer points (%d) than neighbours asked for (%d)", n, mean_k);
+  DevGuard g;
+  float *d_pts = nullptr, *d_md = nullptr;
+  if ((rc = g.alloc(&d_pts, (size_t)n * 3)) || (rc = g.alloc(&d_md, n))) return rc;
+  SSLAM_HIP_TRY(hipMemcpyAsync(d_pts, xyz, (size_t)n * 3 * sizeof(float), hipMemcpyHostToDevice, s->stream));
+  const size_t lds = (size_t)(128 * 3 + (mean_k + 1) * 128) * sizeof(float);
+  hipLaunchKernelGGL(k_sor_mean_distance, dim3((n + 127) / 128), dim3(128), lds, s->stream, d_pts, n, mean_k, d_md);
+  SSLAM_HIP_TRY(hipGetLastError());
+  std::vector<float> md(n);
+  SSLAM_HIP_TRY(hipMemcpyAsync(md.data(), d_md, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, s->stream));
+  SSLAM_HIP_TRY(hipStreamSynchronize(s->stream));
+  // pcl::StatisticalOutlierRemoval::applyFilterIndices: mean and standard deviation of the mean distances in double, in index order
+  double sum = 0, sq = 0;
+  int valid = 0;
+  for (int i = 0; i < n; ++i) if (md[i] >= 0) { sum += md[i]; sq += (double)md[i] * md[i]; ++valid; }
+  if (mean_dist_out) for (int i = 0; i < n; ++i) mean_dist_out[i] = md[i];
+  if (valid < 2) return 0;
+  const double mean = sum / valid, variance = (sq - sum * sum / valid) / (valid - 1.0), stddev = std::sqrt(variance);
+  const double thr = mean + stddev_mul * stddev;
+  int kept = 0;
+  for (int i = 0; i < n; ++i)
+    if (md[i] >= 0 && !((double)md[i] > thr)) { if (kept < max_out) keep_out[kept] = i; ++kept; }
+  return kept;
 }
 
 }  // extern "C"

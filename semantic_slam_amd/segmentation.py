@@ -79,6 +79,10 @@ def _bind(lib):
     lib.sslam_seg_ransac_plane.argtypes = [vp, vp, ci, C.c_float, ci, C.c_double, C.c_uint64, vp, vp, ci]
     lib.sslam_seg_convex_hull_2d.restype = ci
     lib.sslam_seg_convex_hull_2d.argtypes = [vp, vp, ci, vp, ci, vp, vp, vp, ci, vp]
+    lib.sslam_seg_distance_filter.restype = ci; lib.sslam_seg_distance_filter.argtypes = [vp, vp, ci, C.c_double, C.c_double, vp, ci]
+    lib.sslam_seg_voxel_grid.restype = ci; lib.sslam_seg_voxel_grid.argtypes = [vp, vp, ci, C.c_float, vp, vp, ci]
+    lib.sslam_seg_statistical_outlier_removal.restype = ci
+    lib.sslam_seg_statistical_outlier_removal.argtypes = [vp, vp, ci, ci, C.c_double, vp, ci, vp]
     lib.sslam_seg_icp_point_to_plane.restype = ci
     lib.sslam_seg_icp_point_to_plane.argtypes = [vp, vp, vp, ci, vp, ci, ci, vp, vp, C.POINTER(C.c_double)]
     _BOUND = True
@@ -215,6 +219,30 @@ class PointCloudSegmentation:
                                                             proj.ctypes.data, hull.ctypes.data, len(hull), C.byref(axes)))
         return proj, hull[:h].copy(), axes.value
 
+
+    # ---- cloud filters of the legacy path --------------------------------------------------------------------
+    def distance_filter(self, xyz, dmin: float = 0.3, dmax: float = 3.0):
+        """plane_segmentation::distance_filter (plane_segmentation.cpp:607-629): ascending indices of the points kept"""
+        pts = np.ascontiguousarray(xyz, np.float32).reshape(-1, 3)
+        out = np.zeros(max(len(pts), 1), np.int32)
+        n = self._check(self._lib.sslam_seg_distance_filter(self._h, pts.ctypes.data, len(pts), dmin, dmax, out.ctypes.data, len(pts)))
+        return out[:n]
+
+    def downsamplePointcloud(self, xyz, leaf: float = 0.1):
+        """pcl::VoxelGrid (plane_segmentation.cpp:565-581): (centroids [m, 3], points per voxel [m]) in ascending voxel index"""
+        pts = np.ascontiguousarray(xyz, np.float32).reshape(-1, 3)
+        cap = max(len(pts), 1)
+        cent = np.zeros((cap, 3), np.float32); cnt = np.zeros(cap, np.int32)
+        m = self._check(self._lib.sslam_seg_voxel_grid(self._h, pts.ctypes.data, len(pts), C.c_float(leaf), cent.ctypes.data, cnt.ctypes.data, cap))
+        return cent[:m], cnt[:m]
+
+    def removeOutliers(self, xyz, mean_k: int = 50, stddev_mul: float = 1.0):
+        """pcl::StatisticalOutlierRemoval (plane_segmentation.cpp:583-605): (ascending inlier indices, mean neighbour distance per point)"""
+        pts = np.ascontiguousarray(xyz, np.float32).reshape(-1, 3)
+        out = np.zeros(max(len(pts), 1), np.int32); md = np.zeros(max(len(pts), 1), np.float32)
+        n = self._check(self._lib.sslam_seg_statistical_outlier_removal(self._h, pts.ctypes.data, len(pts), mean_k, stddev_mul, out.ctypes.data,
+                                                                        len(pts), md.ctypes.data))
+        return out[:n], md[:len(pts)]
 
     def icp_point_to_plane(self, xyz, labels, planes, iterations: int = 10, T0=None):
         """Point-to-plane ICP of labelled points against planes (row J1, ``sslam_seg_icp_point_to_plane``).

@@ -317,3 +317,19 @@ def test_icp_oracle_recovers_a_known_motion():
     assert np.abs(T - T_true).max() < 2e-3
     T0, rms0, _ = icp_point_to_plane(obs, lab, planes, 0)
     assert np.allclose(T0, [1, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0]) and rms0 > 5 * rms
+
+
+def test_filter_oracles_on_constructed_clouds():
+    """oracle/np_filters.py (row f4): range filter thresholds, voxel centroids / counts of a hand-made cloud, outliers of a plane with
+    a few far points"""
+    from oracle import np_filters as NF
+    pts = np.array([[0.2, 0, 0], [0.31, 0, 0], [0, 2.9, 0], [0, 0, 3.0], [np.nan, 1, 1], [1, 1, 1]], np.float32)
+    assert NF.distance_filter(pts).tolist() == [1, 2, 5]
+    cloud = np.array([[0.01, 0.01, 0.01], [0.09, 0.09, 0.09], [0.11, 0.01, 0.01], [np.nan, 0, 0], [0.05, 0.25, 0.0]], np.float32)
+    cent, cnt = NF.voxel_grid(cloud, 0.1)
+    assert cnt.tolist() == [2, 1, 1] and np.allclose(cent[0], [0.05, 0.05, 0.05], atol=1e-6) and np.allclose(cent[2], [0.05, 0.25, 0.0], atol=1e-6)
+    rng = np.random.default_rng(0)
+    plane = np.c_[rng.uniform(-1, 1, (400, 2)), rng.normal(0, 0.002, 400)].astype(np.float32)
+    far = np.array([[0, 0, 0.8], [0.5, 0.5, -0.7], [np.nan, 0, 0]], np.float32)
+    keep, md = NF.statistical_outlier_removal(np.vstack([plane, far]), 20, 1.0)
+    assert 400 not in keep and 401 not in keep and 402 not in keep and len(keep) > 300 and md[402] == -1

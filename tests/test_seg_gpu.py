@@ -322,3 +322,35 @@ def test_icp_point_to_plane_matches_oracle(gpu_lib):
     with pytest.raises(SslamError) as ei:
         seg.icp_point_to_plane(obs, only_floor, planes, 3)
     assert ei.value.code == -4
+
+
+def test_cloud_filters_match_oracle(gpu_lib):
+    """row f4: range filter, voxel grid and statistical outlier removal on the xyz of a synthetic frame (NaN drop-outs included):
+    index sets and voxel counts bit-exact, centroids and mean neighbour distances bit-exact (fixed-point sums / exact kNN in float32)."""
+    from oracle import np_filters as NF
+    from semantic_slam_amd.segmentation import PointCloudSegmentation
+    seg = PointCloudSegmentation()
+    f = make_frame(seed=3)
+    xyz = f.xyz().reshape(-1, 3)
+    # 1. range filter on the full frame
+    keep = seg.distance_filter(xyz)
+    assert np.array_equal(keep, NF.distance_filter(xyz)) and 0 < len(keep) < len(xyz)
+    assert np.array_equal(seg.distance_filter(xyz, 1.0, 2.0), NF.distance_filter(xyz, 1.0, 2.0))
+    # 2. voxel grid (leaf 0.1 like upstream, and a finer one)
+    for leaf in (0.1, 0.04):
+        cent, cnt = seg.downsamplePointcloud(xyz, leaf)
+        co, no = NF.voxel_grid(xyz, leaf)
+        assert np.array_equal(cnt, no) and cnt.sum() == np.isfinite(xyz).all(1).sum()
+        assert np.array_equal(cent, co)
+    # 3. statistical outlier removal on the downsampled cloud (what preprocessPointCloud feeds it) plus a few stray points and a NaN
+    cent, _ = seg.downsamplePointcloud(xyz, 0.1)
+    stray = np.array([[0.0, 0.0, 0.2], [2.0, -2.0, 0.5], [np.nan, 0, 1]], np.float32)
+    cloud = np.vstack([cent, stray])
+    for k, mul in ((50, 1.0), (8, 2.0)):
+        keep, md = seg.removeOutliers(cloud, k, mul)
+        ko, mo = NF.statistical_outlier_removal(cloud, k, mul)
+        assert np.array_equal(md, mo)
+        assert np.array_equal(keep, ko) and 0 < len(keep) < len(cloud)
+    assert len(cloud) - 1 not in keep
+    with pytest.raises(Exception):
+        seg.removeOutliers(cloud[:10], 50, 1.0)
