@@ -292,6 +292,13 @@ int sslam_seg_voxel_grid(sslam_seg* s, const float* xyz, int n, float leaf, floa
 int sslam_seg_statistical_outlier_removal(sslam_seg* s, const float* xyz, int n, int mean_k, double stddev_mul, int32_t* keep_out, int max_out,
                                           float* mean_dist_out);
 
+/* plane_segmentation::computeKmeans -> cv::kmeans(points, k, labels, TermCriteria(EPS + ITER, 10, 0.01), 10 attempts, KMEANS_RANDOM_CENTERS)
+ * (plane_segmentation.cpp:524-535) on n points of dimension dim (3: normals, k = 4; 1: plane distances, k = 2 upstream).  Restated with
+ * centres drawn uniformly in the bounding box from a counter-based hash of (seed, attempt, centre, coordinate) instead of cv::RNG,
+ * order-independent fixed-point sums in the centre update, and an empty cluster keeping its centre.  The assignment step runs on the GPU.
+ * labels_out[n], centers_out[k * dim]; returns k. */
+int sslam_seg_kmeans(sslam_seg* s, const float* pts, int n, int dim, int k, uint64_t seed, int32_t* labels_out, float* centers_out, double* compactness_out);
+
 /* parity hooks: per-box products of the last sslam_seg_segment call.
  * normals: w*h*4 floats (nx,ny,nz,curvature), labels: w*h int32 (-1 = no plane; otherwise the
  * region index in output order of pcl::OrganizedMultiPlaneSegmentation::segmentAndRefine). */

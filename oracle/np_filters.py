@@ -70,3 +70,58 @@ def statistical_outlier_removal(xyz, mean_k=50, stddev_mul=1.0):
     thr = mean + stddev_mul * std
     keep = valid & ~(md.astype(np.float64) > thr)
     return np.nonzero(keep)[0].astype(np.int32), md
+
+
+# ---- plane_segmentation::computeKmeans -> cv::kmeans (plane_segmentation.cpp:524-535), restated as sslam.h describes --------------
+_M64 = (1 << 64) - 1
+
+
+def _mix(x):
+    x = (x + 0x9E3779B97F4A7C15) & _M64
+    x = ((x ^ (x >> 30)) * 0xBF58476D1CE4E5B9) & _M64
+    x = ((x ^ (x >> 27)) * 0x94D049BB133111EB) & _M64
+    return x ^ (x >> 31)
+
+
+def kmeans(pts, k, seed=0, attempts=10, max_count=10, eps=0.01):
+    """[UPSTREAM: OpenCV cv::kmeans loop] for every attempt: random centres; then (update centres from the last labels, stop when the
+    largest squared centre shift <= eps^2 or after max(max_count, 2) rounds, else assign) -- the labels kept are those of the last
+    assignment, the centres those updated after it; the attempt with the smallest compactness wins."""
+    p = np.asarray(pts, F)
+    p = p.reshape(len(p), -1)
+    n, dim = p.shape
+    lo, hi = p.min(0), p.max(0)
+    fixed = np.rint(p.astype(np.float64) * 1048576.0).astype(np.int64)
+    best, out = np.inf, None
+    for a in range(attempts):
+        C = np.zeros((k, dim), F)
+        labels, compact, assigned = None, 0.0, False
+        max_shift = np.inf
+        it = 0
+        while True:
+            if it == 0:
+                for j in range(k):
+                    for d in range(dim):
+                        u = F(_mix(seed ^ (a << 40) ^ (j << 20) ^ d) >> 40) / F(16777216.0)
+                        C[j, d] = F(lo[d] + F(u * F(hi[d] - lo[d])))
+            else:
+                max_shift = 0.0
+                for j in range(k):
+                    old = C[j].copy()
+                    m = labels == j
+                    if m.any():
+                        C[j] = ((fixed[m].sum(0).astype(np.float64) / 1048576.0) / float(m.sum())).astype(F)
+                    max_shift = max(max_shift, float(((C[j].astype(np.float64) - old.astype(np.float64)) ** 2).sum()))
+            it += 1
+            if it == max(max_count, 2) or max_shift <= eps * eps:
+                break
+            d2 = np.zeros((n, k), F)
+            for d in range(dim):
+                t = (p[:, d, None] - C[None, :, d]).astype(F)
+                d2 = (d2 + (t * t).astype(F)).astype(F)
+            labels = d2.argmin(1)                       # first minimum: lowest centre wins ties
+            compact = float(np.rint(d2[np.arange(n), labels].astype(np.float64) * 1048576.0).astype(np.int64).sum()) / 1048576.0
+            assigned = True
+        if assigned and compact < best:
+            best, out = compact, (labels.astype(np.int32), C.copy())
+    return out[0], out[1], best

@@ -1334,6 +1334,42 @@ __global__ __launch_bounds__(128) void k_sor_mean_distance(const float* __restri
   for (int a = 1; a < K; ++a) sum += (double)sqrtf(best[a * 128 + tid]);
   mean_dist[i] = (float)(sum / (double)k);
 }
+
+// ---- k-means of the legacy path (plane_segmentation::computeKmeans -> cv::kmeans, plane_segmentation.cpp:524-535) -----------------
+// assignment step: nearest centre in float32 (squared distance accumulated coordinate by coordinate; ties -> lowest centre), and for
+// the next centre update the coordinate sums / counts per cluster and the compactness, all in 2^-20 fixed point (integer atomics)
+constexpr int kKmMaxK = 16;
+struct KmCenters { float c[kKmMaxK * 3]; int k, dim; };
+__global__ __launch_bounds__(256) void k_kmeans_assign(const float* __restrict__ pts, int n, KmCenters C, int* __restrict__ labels,
+                                                      long long* __restrict__ sums, int* __restrict__ counts, long long* __restrict__ compact) {
+  __shared__ long long s_sum[kKmMaxK * 3];
+  __shared__ int s_cnt[kKmMaxK];
+  __shared__ long long s_cmp;
+  for (int t = threadIdx.x; t < kKmMaxK * 3; t += 256) s_sum[t] = 0;
+  if (threadIdx.x < kKmMaxK) s_cnt[threadIdx.x] = 0;
+  if (threadIdx.x == 0) s_cmp = 0;
+  __syncthreads();
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) {
+    float p[3] = {0, 0, 0};
+    for (int d = 0; d < C.dim; ++d) p[d] = pts[(size_t)i * C.dim + d];
+    float best = 3.402823466e+38f;
+    int arg = 0;
+    for (int j = 0; j < C.k; ++j) {
+      float dist = 0;
+      for (int d = 0; d < C.dim; ++d) { const float t = p[d] - C.c[j * 3 + d]; dist += t * t; }
+      if (dist < best) { best = dist; arg = j; }
+    }
+    labels[i] = arg;
+    for (int d = 0; d < C.dim; ++d) atomicAdd((unsigned long long*)&s_sum[arg * 3 + d], (unsigned long long)llrint((double)p[d] * 1048576.0));
+    atomicAdd(&s_cnt[arg], 1);
+    atomicAdd((unsigned long long*)&s_cmp, (unsigned long long)llrint((double)best * 1048576.0));
+  }
+  __syncthreads();
+  for (int t = threadIdx.x; t < C.k * 3; t += 256) if (s_sum[t]) atomicAdd((unsigned long long*)&sums[t], (unsigned long long)s_sum[t]);
+  if (threadIdx.x < C.k && s_cnt[threadIdx.x]) atomicAdd(&counts[threadIdx.x], s_cnt[threadIdx.x]);
+  if (threadIdx.x == 0 && s_cmp) atomicAdd((unsigned long long*)compact, (unsigned long long)s_cmp);
+}
 }  // namespace seg
 }  // namespace sslam
 
@@ -2054,6 +2090,79 @@ int sslam_seg_statistical_outlier_removal(sslam_seg* s, const float* xyz, int n,
   for (int i = 0; i < n; ++i)
     if (md[i] >= 0 && !((double)md[i] > thr)) { if (kept < max_out) keep_out[kept] = i; ++kept; }
   return kept;
+}
+
+
+// cv::kmeans as plane_segmentation::computeKmeans configures it (10 attempts, <= 10 iterations or a centre shift <= 0.01, random
+// centres), restated with (a) centres drawn uniformly in the bounding box from splitmix64(seed, attempt, centre, coordinate) instead
+// of cv::RNG, (b) order-independent fixed-point sums in the centre update, (c) an empty cluster keeping its centre.
+int sslam_seg_kmeans(sslam_seg* s, const float* pts, int n, int dim, int k, uint64_t seed, int32_t* labels_out, float* centers_out, double* compactness_out) {
+  if (!s || !pts || !labels_out || !centers_out || n <= 0 || (dim != 1 && dim != 3) || k < 1 || k > kKmMaxK) return set_error(SSLAM_ERR_INVALID, "bad argument (dim 1 or 3, 1 <= k <= %d)", kKmMaxK);
+  int rc = seg_device(s);
+  if (rc) return rc;
+  for (size_t t = 0; t < (size_t)n * dim; ++t) if (!std::isfinite(pts[t])) return set_error(SSLAM_ERR_INVALID, "k-means input holds a non-finite value (the reference removes them first, removeNans)");
+  float lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
+  for (int d = 0; d < dim; ++d) { lo[d] = hi[d] = pts[d]; }
+  for (int i = 1; i < n; ++i) for (int d = 0; d < dim; ++d) { const float v = pts[(size_t)i * dim + d]; lo[d] = std::min(lo[d], v); hi[d] = std::max(hi[d], v); }
+  DevGuard g;
+  float* d_pts = nullptr; int *d_lab = nullptr, *d_cnt = nullptr; long long *d_sums = nullptr, *d_cmp = nullptr;
+  if ((rc = g.alloc(&d_pts, (size_t)n * dim)) || (rc = g.alloc(&d_lab, n)) || (rc = g.alloc(&d_cnt, kKmMaxK)) || (rc = g.alloc(&d_sums, kKmMaxK * 3)) || (rc = g.alloc(&d_cmp, 1))) return rc;
+  SSLAM_HIP_TRY(hipMemcpyAsync(d_pts, pts, (size_t)n * dim * sizeof(float), hipMemcpyHostToDevice, s->stream));
+  auto mix = [](uint64_t x) { x += 0x9E3779B97F4A7C15ull; x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull; x = (x ^ (x >> 27)) * 0x94D049BB133111EBull; return x ^ (x >> 31); };
+  const int attempts = 10, max_count = 10;
+  const double eps2 = 0.01 * 0.01;
+  double best = 1.7976931348623157e308;
+  std::vector<int32_t> lab(n);
+  KmCenters C; C.k = k; C.dim = dim;
+  long long h_sums[kKmMaxK * 3]; int h_cnt[kKmMaxK]; long long h_cmp = 0;
+  bool have = false;
+  for (int a = 0; a < attempts; ++a) {
+    double max_shift = 1.7976931348623157e308, compact = 0;
+    bool assigned = false;
+    for (int iter = 0;;) {
+      if (iter == 0) {
+        for (int j = 0; j < k; ++j)
+          for (int d = 0; d < 3; ++d) {
+            const float u = (float)(mix(seed ^ ((uint64_t)a << 40) ^ ((uint64_t)j << 20) ^ (uint64_t)d) >> 40) / 16777216.0f;
+            C.c[j * 3 + d] = d < dim ? lo[d] + u * (hi[d] - lo[d]) : 0.0f;
+          }
+      } else {   // means of the clusters of the last assignment
+        max_shift = 0;
+        for (int j = 0; j < k; ++j) {
+          double sh = 0;
+          for (int d = 0; d < dim; ++d) {
+            const float old = C.c[j * 3 + d];
+            if (h_cnt[j] > 0) C.c[j * 3 + d] = (float)(((double)h_sums[j * 3 + d] / 1048576.0) / (double)h_cnt[j]);
+            const double t = (double)C.c[j * 3 + d] - (double)old;
+            sh += t * t;
+          }
+          max_shift = std::max(max_shift, sh);
+        }
+      }
+      if (++iter == std::max(max_count, 2) || max_shift <= eps2) break;
+      SSLAM_HIP_TRY(hipMemsetAsync(d_sums, 0, sizeof(long long) * kKmMaxK * 3, s->stream));
+      SSLAM_HIP_TRY(hipMemsetAsync(d_cnt, 0, sizeof(int) * kKmMaxK, s->stream));
+      SSLAM_HIP_TRY(hipMemsetAsync(d_cmp, 0, sizeof(long long), s->stream));
+      hipLaunchKernelGGL(k_kmeans_assign, dim3((n + 255) / 256), dim3(256), 0, s->stream, d_pts, n, C, d_lab, d_sums, d_cnt, d_cmp);
+      SSLAM_HIP_TRY(hipGetLastError());
+      SSLAM_HIP_TRY(hipMemcpyAsync(h_sums, d_sums, sizeof h_sums, hipMemcpyDeviceToHost, s->stream));
+      SSLAM_HIP_TRY(hipMemcpyAsync(h_cnt, d_cnt, sizeof h_cnt, hipMemcpyDeviceToHost, s->stream));
+      SSLAM_HIP_TRY(hipMemcpyAsync(&h_cmp, d_cmp, sizeof h_cmp, hipMemcpyDeviceToHost, s->stream));
+      SSLAM_HIP_TRY(hipStreamSynchronize(s->stream));
+      compact = (double)h_cmp / 1048576.0;
+      assigned = true;
+    }
+    if (assigned && compact < best) {   // cv::kmeans keeps the labels of the last assignment and the centres updated after it
+      best = compact;
+      SSLAM_HIP_TRY(hipMemcpy(lab.data(), d_lab, (size_t)n * sizeof(int), hipMemcpyDeviceToHost));
+      for (int j = 0; j < k; ++j) for (int d = 0; d < dim; ++d) centers_out[j * dim + d] = C.c[j * 3 + d];
+      have = true;
+    }
+  }
+  if (!have) return set_error(SSLAM_ERR_NUMERIC, "k-means made no assignment");
+  for (int i = 0; i < n; ++i) labels_out[i] = lab[i];
+  if (compactness_out) *compactness_out = best;
+  return k;
 }
 
 }  // extern "C"

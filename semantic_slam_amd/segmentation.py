@@ -83,6 +83,7 @@ def _bind(lib):
     lib.sslam_seg_voxel_grid.restype = ci; lib.sslam_seg_voxel_grid.argtypes = [vp, vp, ci, C.c_float, vp, vp, ci]
     lib.sslam_seg_statistical_outlier_removal.restype = ci
     lib.sslam_seg_statistical_outlier_removal.argtypes = [vp, vp, ci, ci, C.c_double, vp, ci, vp]
+    lib.sslam_seg_kmeans.restype = ci; lib.sslam_seg_kmeans.argtypes = [vp, vp, ci, ci, ci, C.c_uint64, vp, vp, C.POINTER(C.c_double)]
     lib.sslam_seg_icp_point_to_plane.restype = ci
     lib.sslam_seg_icp_point_to_plane.argtypes = [vp, vp, vp, ci, vp, ci, ci, vp, vp, C.POINTER(C.c_double)]
     _BOUND = True
@@ -243,6 +244,48 @@ class PointCloudSegmentation:
         n = self._check(self._lib.sslam_seg_statistical_outlier_removal(self._h, pts.ctypes.data, len(pts), mean_k, stddev_mul, out.ctypes.data,
                                                                         len(pts), md.ctypes.data))
         return out[:n], md[:len(pts)]
+
+    def computeKmeans(self, points, num_centroids: int, seed: int = 0):
+        """plane_segmentation::computeKmeans (plane_segmentation.cpp:524-535) -> (labels, centroids, compactness)"""
+        pts = np.ascontiguousarray(points, np.float32)
+        pts = pts.reshape(len(pts), -1)
+        n, dim = pts.shape
+        lab = np.zeros(n, np.int32); cen = np.zeros((num_centroids, dim), np.float32); comp = C.c_double(0)
+        self._check(self._lib.sslam_seg_kmeans(self._h, pts.ctypes.data, n, dim, num_centroids, seed, lab.ctypes.data, cen.ctypes.data, C.byref(comp)))
+        return lab, cen, comp.value
+
+    def clusterAndSegmentAllPlanes(self, xyz, normals, transformation_mat, seed: int = 0, kmeans=None, hull=None):
+        """plane_segmentation::clusterAndSegmentAllPlanes (plane_segmentation.cpp:261-497; dead code upstream): k-means on the normals
+        (4 centres) -> centres within +-0.3 of the horizontal-plane normal seen from the camera -> per centre a k-means on the plane
+        distances (2 centres) -> clusters of more than 500 points -> compute2DConvexHull.  Returns the 1 x 8 rows the reference
+        builds, [hull x, y, z, normal x, y, z, distance, 0].  `kmeans` / `hull` replace the GPU primitives (the tests pass the oracle's)."""
+        kmeans = kmeans or self.computeKmeans
+        hull = hull or self.compute2DConvexHull
+        pts = np.ascontiguousarray(xyz, np.float32).reshape(-1, 3)
+        nrm = np.ascontiguousarray(normals, np.float32).reshape(-1, 3)
+        ok = ~np.isnan(nrm).any(1)                                     # removeNans (:479-497)
+        P, N = pts[ok], nrm[ok]
+        if len(N) <= 10:
+            return np.zeros((0, 8), np.float32)
+        labels, centers, _ = kmeans(N, 4, seed)                        # num_centroids_normals (plane_segmentation.h:41)
+        T = np.asarray(transformation_mat, np.float32).reshape(4, 4)
+        n_cam = T.T @ np.array([0, 0, 1, 0], np.float32)               # (:343-345)
+        rows = []
+        for cid in range(len(centers)):
+            c = centers[cid]
+            if not all(n_cam[d] - 0.3 < c[d] < n_cam[d] + 0.3 for d in range(3)):     # filterCentroids (:499-518)
+                continue
+            Pi = P[labels == cid]
+            if len(Pi) < 2:
+                continue
+            dist = -((Pi[:, 0] * c[0] + Pi[:, 1] * c[1]).astype(np.float32) + Pi[:, 2] * c[2]).astype(np.float32)   # (:383-391)
+            dl, dc, _ = kmeans(dist.reshape(-1, 1), 2, seed + 1 + cid)     # num_centroids_distance (plane_segmentation.h:42)
+            for d in range(2):
+                Q = Pi[dl == d]
+                if len(Q) > 500:                                           # (:418)
+                    for h in hull(Q, seed):
+                        rows.append([h[0], h[1], h[2], c[0], c[1], c[2], dc[d, 0], 0.0])
+        return np.asarray(rows, np.float32).reshape(-1, 8)
 
     def icp_point_to_plane(self, xyz, labels, planes, iterations: int = 10, T0=None):
         """Point-to-plane ICP of labelled points against planes (row J1, ``sslam_seg_icp_point_to_plane``).

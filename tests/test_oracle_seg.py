@@ -333,3 +333,18 @@ def test_filter_oracles_on_constructed_clouds():
     far = np.array([[0, 0, 0.8], [0.5, 0.5, -0.7], [np.nan, 0, 0]], np.float32)
     keep, md = NF.statistical_outlier_removal(np.vstack([plane, far]), 20, 1.0)
     assert 400 not in keep and 401 not in keep and 402 not in keep and len(keep) > 300 and md[402] == -1
+
+
+def test_kmeans_oracle_separates_clusters():
+    """oracle/np_filters.kmeans (row f4): three well separated blobs are recovered; 1-D data works; deterministic in the seed"""
+    from oracle import np_filters as NF
+    rng = np.random.default_rng(1)
+    cent = np.array([[0, 0, 1.0], [1, 0, 0], [0, -1, 0]], np.float32)
+    pts = (cent[rng.integers(0, 3, 3000)] + rng.normal(0, 0.05, (3000, 3))).astype(np.float32)
+    lab, C, comp = NF.kmeans(pts, 3, seed=2)
+    assert sorted(np.round(C, 1).tolist()) == sorted(np.round(cent, 1).tolist()) and comp < 3000 * 3 * 0.05 ** 2 * 1.5
+    lab2, C2, comp2 = NF.kmeans(pts, 3, seed=2)
+    assert np.array_equal(lab, lab2) and np.array_equal(C, C2) and comp == comp2
+    d = np.concatenate([rng.normal(-1.0, 0.01, 800), rng.normal(-2.5, 0.01, 900)]).astype(np.float32).reshape(-1, 1)
+    l1, c1, _ = NF.kmeans(d, 2, seed=0)
+    assert sorted(np.round(c1[:, 0], 1).tolist()) == [-2.5, -1.0] and {int((l1 == 0).sum()), int((l1 == 1).sum())} == {800, 900}

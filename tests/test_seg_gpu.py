@@ -354,3 +354,42 @@ def test_cloud_filters_match_oracle(gpu_lib):
     assert len(cloud) - 1 not in keep
     with pytest.raises(Exception):
         seg.removeOutliers(cloud[:10], 50, 1.0)
+
+
+def test_kmeans_and_legacy_cluster_path_match_oracle(gpu_lib):
+    """row f4: computeKmeans (assignment on the GPU, fixed-point centre updates) bit-exact vs the oracle on 3-D normals and 1-D
+    distances; clusterAndSegmentAllPlanes composed from it finds the two horizontal surfaces of a synthetic scene and equals the same
+    composition over the oracle's k-means."""
+    from oracle import np_filters as NF
+    from semantic_slam_amd.segmentation import PointCloudSegmentation
+    seg = PointCloudSegmentation()
+    rng = np.random.default_rng(4)
+    cent = np.array([[0, 0, 1.0], [1, 0, 0], [0, -1, 0], [0.6, 0, 0.8]], np.float32)
+    nrm = (cent[rng.integers(0, 4, 20000)] + rng.normal(0, 0.04, (20000, 3))).astype(np.float32)
+    for seed in (0, 5):
+        lab, C, comp = seg.computeKmeans(nrm, 4, seed)
+        lo, Co, compo = NF.kmeans(nrm, 4, seed)
+        assert np.array_equal(lab, lo) and np.array_equal(C, Co) and comp == compo
+    d = np.concatenate([rng.normal(-1.0, 0.01, 5000), rng.normal(-2.5, 0.02, 7000)]).astype(np.float32).reshape(-1, 1)
+    lab, C, comp = seg.computeKmeans(d, 2, 3)
+    lo, Co, compo = NF.kmeans(d, 2, 3)
+    assert np.array_equal(lab, lo) and np.array_equal(C, Co) and comp == compo
+    # scene in the camera frame of an identity transformation: a floor patch (z = -1) and a table top (z = -0.4), normals +z, plus two
+    # vertical walls; the horizontal filter keeps the +z centre, the distance k-means splits floor and table
+    def patch(n, origin, u, v, normal):
+        ab = rng.uniform(0, 1, (n, 2))
+        p = origin + ab[:, :1] * u + ab[:, 1:] * v + rng.normal(0, 0.002, (n, 1)) * normal
+        return p.astype(np.float32), (normal + rng.normal(0, 0.02, (n, 3))).astype(np.float32)
+    parts = [patch(6000, np.array([-1, -1, -1.0]), np.array([2.0, 0, 0]), np.array([0, 2.0, 0]), np.array([0, 0, 1.0])),
+             patch(4000, np.array([0.2, 0.2, -0.4]), np.array([0.8, 0, 0]), np.array([0, 0.6, 0]), np.array([0, 0, 1.0])),
+             patch(5000, np.array([1.5, -1, -1.0]), np.array([0, 2.0, 0]), np.array([0, 0, 1.5]), np.array([-1.0, 0, 0])),
+             patch(5000, np.array([-1, 1.5, -1.0]), np.array([2.0, 0, 0]), np.array([0, 0, 1.5]), np.array([0, -1.0, 0]))]
+    xyz = np.vstack([p for p, _ in parts]); nr = np.vstack([n for _, n in parts])
+    nr[::97] = np.nan
+    T = np.eye(4, dtype=np.float32)
+    rows = seg.clusterAndSegmentAllPlanes(xyz, nr, T, seed=1)
+    rows_o = seg.clusterAndSegmentAllPlanes(xyz, nr, T, seed=1, kmeans=NF.kmeans)
+    assert np.array_equal(rows, rows_o) and len(rows) >= 6
+    dists = sorted(set(np.round(rows[:, 6].astype(np.float64), 1).tolist()))
+    assert np.allclose(dists, [0.4, 1.0])                                 # -(n . p): the table top at z = -0.4 and the floor at z = -1
+    assert np.all(np.abs(rows[:, 3:6] - [0, 0, 1]) < 0.05)
