@@ -140,6 +140,9 @@ int64_t sslam_debug_plan_array(void* plan, const char* name, void* out, int64_t 
 /* ---- batched, device-resident form (MI355X extension) ---------------------------------------
  * B independent graphs laid out contiguously in HBM and optimised together: every kernel runs
  * over the union, LM control (rho, lambda, accept/reject) is per graph on the device. */
+/* Lifetime and structure: the batch borrows the graphs -- they must outlive it (destroy the batch first) -- and is built for their
+ * structure at creation: after a vertex or an edge is added to a member, every sslam_batch_* entry point returns SSLAM_ERR_INVALID
+ * until a new batch is created.  All members must carry the same options (sslam_graph_set_option). */
 typedef struct sslam_batch sslam_batch;
 sslam_batch* sslam_batch_create(sslam_graph* const* graphs, int n);
 void sslam_batch_destroy(sslam_batch* b);
