@@ -22,6 +22,41 @@ struct KernelTimer {
   int64_t launches = 0;
 };
 
+// Device memory of a single-graph handle across structure rebuilds.  The orchestrator's graph grows every tick and every tick rebuilds
+// its batch of one (about 65 device arrays with the factorisation plan): a hipMalloc / hipFree pair per array costs more than
+// optimising a small graph.  Bump allocation out of one block that is kept from rebuild to rebuild and regrown (x 1.5) when a
+// rebuild needed more than it holds; what did not fit meanwhile lives in spill blocks until the next reset.
+struct DevArena {
+  char* base = nullptr;
+  size_t cap = 0, used = 0, need = 0;
+  std::vector<void*> spill;
+  void* take(size_t bytes) {
+    bytes = (bytes + 255) & ~(size_t)255;
+    need += bytes;
+    if (used + bytes <= cap) { void* p = base + used; used += bytes; return p; }
+    void* p = nullptr;
+    if (hipMalloc(&p, bytes) != hipSuccess) return nullptr;
+    spill.push_back(p);
+    return p;
+  }
+  void reset() {   // the caller guarantees that no kernel still uses the memory (the owning batch has been released)
+    for (void* p : spill) (void)hipFree(p);
+    spill.clear();
+    if (need > cap) {
+      if (base) (void)hipFree(base);
+      base = nullptr; cap = 0;
+      const size_t want = need + need / 2 + (1u << 20);
+      void* p = nullptr;
+      if (hipMalloc(&p, want) == hipSuccess) { base = (char*)p; cap = want; }
+    }
+    used = 0; need = 0;
+  }
+  ~DevArena() {
+    for (void* p : spill) (void)hipFree(p);
+    if (base) (void)hipFree(base);
+  }
+};
+
 struct Batch {
   int device = 0;
   hipStream_t stream = nullptr;
@@ -29,6 +64,7 @@ struct Batch {
   std::vector<uint64_t> versions;
   BatchView V{};
   std::vector<void*> allocs;
+  DevArena* arena = nullptr;   // set for the batch of one behind a graph handle: device arrays come out of the handle's arena
   // host-side metadata
   std::vector<GraphSeg> seg;
   std::vector<std::vector<int>> v2pose, v2lm;     // per graph: vertex id -> pose / landmark index (global), -1
@@ -98,8 +134,8 @@ template <typename T>
 inline int dev_upload(Batch& b, const std::vector<T>& h, T** out, size_t min_elems = 1) {
   const size_t n = std::max(h.size(), min_elems);
   void* p = nullptr;
-  SSLAM_HIP_TRY(hipMalloc(&p, n * sizeof(T)));
-  b.allocs.push_back(p);
+  if (b.arena) { p = b.arena->take(n * sizeof(T)); if (!p) return set_error(-3, "device allocation of %zu bytes failed", n * sizeof(T)); }
+  else { SSLAM_HIP_TRY(hipMalloc(&p, n * sizeof(T))); b.allocs.push_back(p); }
   if (!h.empty()) SSLAM_HIP_TRY(hipMemcpyAsync(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, b.stream));
   *out = (T*)p;
   return 0;
@@ -108,8 +144,8 @@ template <typename T>
 inline int dev_alloc(Batch& b, size_t n, T** out, bool zero = true) {
   void* p = nullptr;
   n = std::max<size_t>(n, 1);
-  SSLAM_HIP_TRY(hipMalloc(&p, n * sizeof(T)));
-  b.allocs.push_back(p);
+  if (b.arena) { p = b.arena->take(n * sizeof(T)); if (!p) return set_error(-3, "device allocation of %zu bytes failed", n * sizeof(T)); }
+  else { SSLAM_HIP_TRY(hipMalloc(&p, n * sizeof(T))); b.allocs.push_back(p); }
   if (zero) SSLAM_HIP_TRY(hipMemsetAsync(p, 0, n * sizeof(T), b.stream));
   *out = (T*)p;
   return 0;

@@ -57,6 +57,7 @@ struct CholPlan {
   std::vector<int> lvl_ptr, plv_ptr, plv_lds_f, plv_lds_b;
   int tail_lds_f = 0, tail_lds_b = 0, tail_total = 0, nt_tail = 512, nt_leaf = 64, ustage = 0;
   std::vector<void*> allocs;
+  DevArena* arena = nullptr;    // the owning batch's arena (single-graph handles), else hipMalloc
   int64_t lnz = 0, unz = 0;
   double* d_multi_y = nullptr;  // scratch for multi-rhs solves
   double* d_multi_x = nullptr;
@@ -913,9 +914,9 @@ template <typename T>
 int up_to_dev(CholPlan& P, hipStream_t s, const std::vector<T>& h, const T** out) {
   void* p = nullptr;
   const size_t n = h.size() + 4;   // slack: the kernels' clamped table loads may read one record past an empty range
-  SSLAM_HIP_TRY(hipMalloc(&p, n * sizeof(T)));
+  if (P.arena) { p = P.arena->take(n * sizeof(T)); if (!p) return set_error(SSLAM_ERR_HIP, "device allocation of %zu bytes failed", n * sizeof(T)); }
+  else { SSLAM_HIP_TRY(hipMalloc(&p, n * sizeof(T))); P.allocs.push_back(p); }
   SSLAM_HIP_TRY(hipMemsetAsync(p, 0, n * sizeof(T), s));
-  P.allocs.push_back(p);
   if (!h.empty()) SSLAM_HIP_TRY(hipMemcpyAsync(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, s));
   *out = (const T*)p;
   return 0;
@@ -943,6 +944,7 @@ int chol_plan_build(Batch& b) {
   if (chol_symbolic(in, opt, H)) return set_error(SSLAM_ERR_NUMERIC, "Cholesky plan: %s", H.error.c_str());
   CholPlan* P = new CholPlan();
   b.chol = P;
+  P->arena = b.arena;
   CholView& C = P->C;
   C.ncol = H.ncol; C.nlevels = H.nlevels; C.dim = H.dim; C.npiece = H.npiece;
   P->lvl_ptr = H.lvl_ptr; P->plv_ptr = H.plv_ptr; P->plv_lds_f = H.plv_lds_f; P->plv_lds_b = H.plv_lds_b;
@@ -968,19 +970,29 @@ int chol_plan_build(Batch& b) {
   if ((rc = up_to_dev(*P, b.stream, H.tail_ptr, &C.tail_ptr))) return rc;
   if ((rc = up_to_dev(*P, b.stream, H.tail_pieces, &C.tail_pieces))) return rc;
   void* p = nullptr;
-  SSLAM_HIP_TRY(hipMalloc(&p, (H.lnz + 64) * sizeof(double))); P->allocs.push_back(p); C.Lval = (double*)p;
+  auto plan_alloc = [&](void** q, size_t bytes) -> int {
+    if (P->arena) { *q = P->arena->take(bytes); return *q ? 0 : set_error(SSLAM_ERR_HIP, "device allocation of %zu bytes failed", bytes); }
+    SSLAM_HIP_TRY(hipMalloc(q, bytes)); P->allocs.push_back(*q);
+    return 0;
+  };
+  if ((rc = plan_alloc(&p, (H.lnz + 64) * sizeof(double)))) return rc;
+  C.Lval = (double*)p;
   SSLAM_HIP_TRY(hipMemsetAsync(p, 0, (H.lnz + 64) * sizeof(double), b.stream));
-  SSLAM_HIP_TRY(hipMalloc(&p, (H.unz + 64) * sizeof(double))); P->allocs.push_back(p); C.Uval = (double*)p;
+  if ((rc = plan_alloc(&p, (H.unz + 64) * sizeof(double)))) return rc;
+  C.Uval = (double*)p;
   SSLAM_HIP_TRY(hipMemsetAsync(p, 0, (H.unz + 64) * sizeof(double), b.stream));
   P->unz = H.unz;
-  SSLAM_HIP_TRY(hipMalloc(&p, (C.dim + 8) * sizeof(double))); P->allocs.push_back(p); C.y = (double*)p;
+  if ((rc = plan_alloc(&p, (C.dim + 8) * sizeof(double)))) return rc;
+  C.y = (double*)p;
   SSLAM_HIP_TRY(hipMemsetAsync(p, 0, (C.dim + 8) * sizeof(double), b.stream));
-  SSLAM_HIP_TRY(hipMalloc(&p, std::max(b.V.B, 1) * sizeof(int))); P->allocs.push_back(p); C.fail = (int*)p;
+  if ((rc = plan_alloc(&p, std::max(b.V.B, 1) * sizeof(int)))) return rc;
+  C.fail = (int*)p;
   SSLAM_HIP_TRY(hipMemsetAsync(C.fail, 0, std::max(b.V.B, 1) * sizeof(int), b.stream));
   C.dbg = nullptr;
   C.flat_L = 0;
   if (getenv("SSLAM_CHOL_STAMPS")) {
-    SSLAM_HIP_TRY(hipMalloc(&p, 48 * sizeof(long long))); P->allocs.push_back(p); C.dbg = (long long*)p;
+    if ((rc = plan_alloc(&p, 48 * sizeof(long long)))) return rc;
+    C.dbg = (long long*)p;
     SSLAM_HIP_TRY(hipMemsetAsync(p, 0, 48 * sizeof(long long), b.stream));
   }
   // LDS opt-in above 64 KiB

@@ -1712,6 +1712,7 @@ using namespace sslam;
 
 struct sslam_graph {
   HostGraph g;
+  DevArena arena;                // device memory of the batch below, kept across structure rebuilds (declared first: destroyed last)
   std::unique_ptr<Batch> batch;  // batch of one, rebuilt when the structure changes
   bool linearized = false;
 };
@@ -1725,7 +1726,11 @@ static int ensure_batch(sslam_graph* h) {
   if (e != hipSuccess || n <= 0) return set_error(SSLAM_ERR_NO_DEVICE, "no HIP device visible (%s); the product has no CPU fallback", hipGetErrorString(e));
   if (h->g.device < 0 || h->g.device >= n) return set_error(SSLAM_ERR_NO_DEVICE, "device %d out of range (%d visible)", h->g.device, n);
   if (!h->batch || h->batch->versions.empty() || h->batch->versions[0] != h->g.structure_version) {
+    h->batch.reset();                              // the old batch synchronises its stream; its arrays belong to the arena
+    SSLAM_HIP_TRY(hipSetDevice(h->g.device));
+    h->arena.reset();
     h->batch.reset(new Batch());
+    h->batch->arena = &h->arena;
     h->batch->device = h->g.device;
     h->batch->graphs = {&h->g};
     int rc = batch_build(*h->batch);
