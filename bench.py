@@ -41,6 +41,28 @@ def pmc_traffic(name, algorithmic_bytes):
     return None, None, None
 
 
+def generate_graphs(kind, poses, landmarks, seeds, cache_dir):
+    """One .g2o file per seed (semantic_slam_amd.synth.make_graph -> GraphSLAM::save), written by a pool of plain host processes
+    (`python -m semantic_slam_amd.synth`, no HIP call) and kept in `cache_dir`: 512 distinct 5000-pose graphs cost ~1 s of Python
+    each; the cache and the pool keep the setup bounded."""
+    import subprocess
+    os.makedirs(cache_dir, exist_ok=True)
+    jobs = [(int(sd), os.path.join(cache_dir, f"{kind}_{poses}_{landmarks}_{int(sd)}.g2o")) for sd in seeds]
+    todo = [sd for sd, p in jobs if not (os.path.exists(p) and os.path.getsize(p) > 0)]
+    if todo:
+        nproc = max(1, min(len(todo), len(os.sched_getaffinity(0)), 48))
+        procs = []
+        for w in range(nproc):
+            mine = todo[w::nproc]
+            if mine:
+                procs.append(subprocess.Popen([sys.executable, "-m", "semantic_slam_amd.synth", kind, str(poses), str(landmarks), cache_dir]
+                                              + [str(x) for x in mine], cwd=ROOT))
+        for pr in procs:
+            if pr.wait() != 0:
+                raise RuntimeError("graph generator process failed")
+    return [p for _, p in jobs]
+
+
 def build_batch(paths, n, dev, solver):
     from semantic_slam_amd import GraphSLAM, GraphBatch
     graphs = []
@@ -67,7 +89,31 @@ def timed_optimize(batch, steps, warmup, sync_all):
     return stats, time.perf_counter() - t0
 
 
-def bench_tick(device, n_samples=600):
+def bench_tick_cpu(events):
+    """the CPU oracle (oracle/np_slam.py: NumPy association + the C oracle's LM / marginals, one core) replaying the same run"""
+    from oracle import np_slam as S
+    o = S.SemanticGraphSlam(const_stddev_x=0.00667, const_stddev_q=0.00001)
+    ticks, t_tick, t_opt = 0, 0.0, 0.0
+    for ev in events:
+        if ev.objects is not None:
+            o.set_segmented_objects(ev.objects)
+        o.vio(ev.stamp[0], ev.stamp[1], ev.odom)
+        if ev.run_after:
+            t0 = time.perf_counter()
+            ran = o.run()
+            dt = time.perf_counter() - t0
+            if ran:
+                ticks += 1; t_tick += dt
+                st = o.last_stats
+                if st.get("optimized"):
+                    t_opt += float(st["opt"].seconds)
+    return {"ticks": ticks, "ms_per_tick": round(1e3 * t_tick / max(ticks, 1), 3), "ms_per_tick_optimize": round(1e3 * t_opt / max(ticks, 1), 3),
+            "cores": 1, "kind": "port", "keyframes": len(o.keyframes), "landmarks": len(o.assoc.landmarks),
+            "sample": "the same replay through oracle/np_slam.py; ms_per_tick_optimize is the C oracle's own LM timer (oracle_graph.c), the "
+                      "rest is NumPy association + marginals + Python overhead"}
+
+
+def bench_tick(device, n_samples=600, cpu_baseline=True):
     """Orchestrator tick replay: a synthetic run fed through sslam_slam_* -- keyframe gate, data association
     on the device, graph growth (structure rebuilt every tick), optimise to LM termination, marginals of every landmark."""
     import ctypes as C
@@ -104,7 +150,13 @@ def bench_tick(device, n_samples=600):
                 ticks += 1; t_tick += dt; lm_iters += int(st.opt.iterations) if st.optimized else 0
                 parts[0] += st.seconds_association; parts[1] += st.seconds_optimize; parts[2] += st.seconds_marginals
     ids, _ = S.getKeyframes()
-    return {"workload": f"synthetic run of {n_samples} odometry samples at 10 Hz, detections every sample (semantic_slam_amd.synth.make_replay), "
+    cpu = None
+    if cpu_baseline:
+        try:
+            cpu = bench_tick_cpu(events)
+        except Exception as e:
+            cpu = {"error": str(e)[:200]}
+    return {"cpu_baseline": cpu, "workload": f"synthetic run of {n_samples} odometry samples at 10 Hz, detections every sample (semantic_slam_amd.synth.make_replay), "
                         "objects pre-segmented; every tick re-optimises the whole graph to LM termination (graph_slam.cpp:205)",
             "ticks": ticks, "keyframes": int(len(ids)), "landmarks": len(S.getMappedLandmarks()),
             "ticks_per_sec": round(ticks / t_tick, 2) if t_tick > 0 else None,
@@ -188,9 +240,11 @@ def main():
                     help="independent graphs resident per GPU (512 x ~10 MB of H + 7.5 MB of L each: far beyond the 256 MiB MALL)")
     ap.add_argument("--poses", type=int, default=5000)
     ap.add_argument("--landmarks", type=int, default=1000)
-    ap.add_argument("--distinct", type=int, default=4, help="distinct seeds generated per rank (tiled to --batch)")
+    ap.add_argument("--distinct", type=int, default=-1, help="distinct seeds generated per rank (tiled to --batch); -1 = one per graph of the batch")
+    ap.add_argument("--plane-distinct", type=int, default=64, help="distinct seeds of the plane-landmark leg (tiled to --plane-batch)")
+    ap.add_argument("--cache-dir", default=os.environ.get("SSLAM_BENCH_CACHE", os.path.join(tempfile.gettempdir(), "sslam_bench_cache")))
     ap.add_argument("--solver", type=int, default=-1, help="-1 library default, 0 PCG, 1 sparse Cholesky")
-    ap.add_argument("--plane-batch", type=int, default=64, help="graphs in the plane-landmark leg (0 = skip)")
+    ap.add_argument("--plane-batch", type=int, default=512, help="graphs in the plane-landmark leg (0 = skip)")
     ap.add_argument("--edge-sharded", action="store_true",
                     help="N > 1: every rank holds the SAME batch, builds the partial normal equations of its edge shard and the ranks "
                          "all-reduce [H || b] over RCCL each LM step (SURVEY 8e mode E / BASELINE.json configs[4]); strong scaling")
@@ -227,23 +281,15 @@ def main():
 
     sharded = bool(args.edge_sharded and world > 1)
 
-    def write_graphs(kind, n_distinct, tmpdir):
-        paths, problems = [], []
-        for d in range(n_distinct):
-            g = make_graph(args.poses, args.landmarks, seed=(0 if sharded else 1000 * rank) + d, landmark_kind=kind)
-            gp = GraphProblem.from_synth(g)
-            problems.append(gp)
-            G0 = GraphSLAM.from_synth(g, device=dev)
-            p = os.path.join(tmpdir, f"{kind}{d}.g2o")
-            G0.save(p)
-            paths.append(p)
-            del G0
-        return paths, problems
+    def seeds_of(n_distinct):
+        return [(0 if sharded else 100000 * rank) + d for d in range(n_distinct)]
 
     # ---- synthetic workload, resident in HBM before timing -------------------------------------
     t_setup = time.time()
-    tmpdir = tempfile.mkdtemp(prefix="sslam_bench_")
-    paths, problems = write_graphs("point", max(1, min(args.distinct, args.batch)), tmpdir)
+    n_distinct = args.batch if args.distinct < 0 else max(1, min(args.distinct, args.batch))
+    paths = generate_graphs("point", args.poses, args.landmarks, seeds_of(n_distinct), args.cache_dir)
+    # the first graphs again as flat arrays: problem sizes for the byte accounting and the cpu_baseline leg
+    problems = [GraphProblem.from_synth(make_graph(args.poses, args.landmarks, seed=sd)) for sd in seeds_of(min(n_distinct, 4))]
     batch = build_batch(paths, args.batch, dev, args.solver)
     if sharded:
         D.init_edge_sharded(batch, device=ddev)   # RCCL communicator inside the library; all-reduce issued from the C++ LM loop
@@ -314,7 +360,8 @@ def main():
         "metric": "graph-optimize LM iters/sec (5k poses, 1k landmarks)",
         "value": round(value, 3), "unit": "iters/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(1e3 * dt / max(steps_done, 1), 4), "higher_is_better": True, "scaling": "strong" if sharded else "weak",
-        "vs_baseline": None, "dtype": "f64", "data": f"synthetic ({len(paths)} distinct seeds per GPU tiled to the batch)",
+        "vs_baseline": None, "dtype": "f64",
+        "data": f"synthetic ({len(paths)} distinct graphs per GPU" + (")" if len(paths) >= args.batch else f" tiled to the batch of {args.batch})"),
         "config": {"workload": f"synthetic {args.poses}-pose / {args.landmarks}-landmark graph with loop closures "
                                f"(BASELINE.json configs[2]), batch of {args.batch} independent graphs per GPU, point landmarks "
                                f"(EdgeSE3PointXYZ, the reference's live landmark type)",
@@ -322,6 +369,8 @@ def main():
                    "solver": int(args.solver),
                    "parallelism": (f"edge-sharded x{world}: RCCL all-reduce of [H || b] per LM step" if sharded else f"replicas x{world}")},
         "steps_done": steps_done, "iters_min": min(iters), "iters_max": max(iters),
+        "trial_rounds": int(ktimes["factor"][1] or ktimes["spmv"][1] and ktimes["precond"][1]),
+        "lm_trials_total": int(sum(int(s.trials) for s in stats)), "distinct_graphs": len(paths),
         "graphs_terminated": int(sum(1 for s in stats if s.status == 1)),
         "timed_seconds": round(dt, 4),
         "keyframes_landmarks_per_sec": round(value * (args.poses + args.landmarks), 1),
@@ -347,7 +396,7 @@ def main():
             out["frontend"] = frontend
         if not args.no_single:
             try:
-                out["tick_replay"] = bench_tick(dev)
+                out["tick_replay"] = bench_tick(dev, cpu_baseline=not args.no_cpu_baseline)
             except Exception as e:   # the headline line must still be printed
                 out["tick_replay"] = {"error": str(e)[:200]}
             # ---- single-graph latency (same graph, batch of one) -----------------------------------
@@ -360,12 +409,12 @@ def main():
         if args.plane_batch > 0 and world == 1:
             # ---- plane landmarks (BASELINE.json metric: "5k poses, 1k planes"): VertexPlane + EdgeSE3Plane, numeric Jacobians
             try:
-                ppaths, _ = write_graphs("plane", 1, tmpdir)
+                ppaths = generate_graphs("plane", args.poses, args.landmarks, seeds_of(max(1, min(args.plane_distinct, args.plane_batch))), args.cache_dir)
                 pb = build_batch(ppaths, args.plane_batch, dev, args.solver)
                 ps, pdt = timed_optimize(pb, args.steps, min(args.warmup, 2), lambda: None)
                 pit = [int(s.iterations) for s in ps]
                 out["plane_landmarks"] = {"value": round(sum(pit) / pdt, 3), "unit": "iters/s", "graphs": args.plane_batch,
-                                          "iters_min": min(pit), "iters_max": max(pit), "chi2_after": ps[0].chi2_after,
+                                          "distinct_graphs": len(ppaths), "iters_min": min(pit), "iters_max": max(pit), "chi2_after": ps[0].chi2_after,
                                           "workload": f"{args.poses} poses / {args.landmarks} plane landmarks (in-tree EdgeSE3Plane, "
                                                       f"central-difference Jacobians), batch of {args.plane_batch}"}
                 del pb

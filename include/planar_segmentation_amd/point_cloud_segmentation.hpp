@@ -67,6 +67,12 @@ class point_cloud_segmentation {
                                     point_cloud.offset_x, point_cloud.offset_y, point_cloud.offset_z, boxes.data(), (int)boxes.size(),
                                     robot_pose.data(), cam_angle, planes.data(), (int)planes.size());
     if (n < 0) throw std::runtime_error(std::string("sslam_seg_segment: ") + sslam_last_error());
+    // truncation is reported by the C-ABI, and so by the drop-in: planes beyond the output capacity, boxes whose candidate / region
+    // tables filled up (the reference has no such limits -- std::vector grows; a frame that hits them is not the reference's result)
+    sslam_seg_last_overflow(seg_, &overflow_planes_, &overflow_candidate_boxes_, &overflow_region_boxes_);
+    if (overflow_planes_ || overflow_candidate_boxes_ || overflow_region_boxes_)
+      std::cerr << "point_cloud_segmentation: frontend tables overflowed (planes dropped " << overflow_planes_ << ", boxes with a full candidate table "
+                << overflow_candidate_boxes_ << ", with a full region table " << overflow_region_boxes_ << ")" << std::endl;
     std::vector<detected_object> out(n);
     for (int k = 0; k < n; ++k) {
       const sslam_plane& p = planes[k];
@@ -97,10 +103,78 @@ class point_cloud_segmentation {
     return out;
   }
 
+  /** plane_segmentation::computeKmeans (plane_segmentation.cpp:524-535): cv::kmeans(points, k, TermCriteria(EPS + MAX_ITER, 10000,
+   *  1e-4), 10 attempts, KMEANS_RANDOM_CENTERS) on n x dim float rows -> labels, centres (k x dim), compactness */
+  double computeKmeans(const float* points, int n, int dim, int num_centroids, std::vector<int32_t>& labels, std::vector<float>& centroids,
+                       uint64_t seed = 0) {
+    labels.assign(n > 0 ? n : 1, 0);
+    centroids.assign((size_t)num_centroids * dim, 0.f);
+    double compactness = 0;
+    const int rc = sslam_seg_kmeans(seg_, points, n, dim, num_centroids, seed, labels.data(), centroids.data(), &compactness);
+    if (rc < 0) throw std::runtime_error(std::string("sslam_seg_kmeans: ") + sslam_last_error());
+    labels.resize(n);
+    return compactness;
+  }
+
+  /** plane_segmentation::clusterAndSegmentAllPlanes (plane_segmentation.cpp:261-497; dead code upstream): k-means on the normals
+   *  (4 centres, plane_segmentation.h:41) -> centres within +-0.3 of the horizontal-plane normal seen from the camera
+   *  (filterCentroids, :499-518) -> per centre a k-means on the plane distances (2 centres, plane_segmentation.h:42) -> clusters
+   *  of more than 500 points (:418) -> compute2DConvexHull.  xyz / normals: n x 3 floats (NaN normals are dropped, :479-497);
+   *  transformation_mat: 4 x 4 row-major.  Returns the 1 x 8 rows the reference builds: [hull x, y, z, normal x, y, z, distance, 0]. */
+  std::vector<std::array<float, 8>> clusterAndSegmentAllPlanes(const float* xyz, const float* normals, int n, const float transformation_mat[16],
+                                                               uint64_t seed = 0) {
+    std::vector<float> P, N;
+    for (int i = 0; i < n; ++i) {
+      const float* q = normals + 3 * (size_t)i;
+      if (q[0] != q[0] || q[1] != q[1] || q[2] != q[2]) continue;
+      P.insert(P.end(), xyz + 3 * (size_t)i, xyz + 3 * (size_t)i + 3);
+      N.insert(N.end(), q, q + 3);
+    }
+    const int m = (int)(N.size() / 3);
+    std::vector<std::array<float, 8>> rows;
+    if (m <= 10) return rows;
+    std::vector<int32_t> labels, dl;
+    std::vector<float> centers, dc;
+    computeKmeans(N.data(), m, 3, 4, labels, centers, seed);
+    float n_cam[3];                                                        // T^T (0, 0, 1, 0)  (:343-345)
+    for (int d = 0; d < 3; ++d) n_cam[d] = transformation_mat[2 * 4 + d];
+    for (int cid = 0; cid < 4; ++cid) {
+      const float* c = &centers[3 * (size_t)cid];
+      bool near = true;
+      for (int d = 0; d < 3; ++d) near = near && (n_cam[d] - 0.3f < c[d]) && (c[d] < n_cam[d] + 0.3f);
+      if (!near) continue;
+      std::vector<float> Pi;
+      for (int i = 0; i < m; ++i) if (labels[i] == cid) Pi.insert(Pi.end(), &P[3 * (size_t)i], &P[3 * (size_t)i] + 3);
+      const int mi = (int)(Pi.size() / 3);
+      if (mi < 2) continue;
+      std::vector<float> dist(mi);
+      for (int i = 0; i < mi; ++i) {                                       // (:383-391), float accumulation in the reference's order
+        const float a = Pi[3 * (size_t)i] * c[0] + Pi[3 * (size_t)i + 1] * c[1];
+        const float b = a + Pi[3 * (size_t)i + 2] * c[2];
+        dist[i] = -b;
+      }
+      computeKmeans(dist.data(), mi, 1, 2, dl, dc, seed + 1 + cid);
+      for (int d = 0; d < 2; ++d) {
+        std::vector<float> Q;
+        for (int i = 0; i < mi; ++i) if (dl[i] == d) Q.insert(Q.end(), &Pi[3 * (size_t)i], &Pi[3 * (size_t)i] + 3);
+        if ((int)(Q.size() / 3) <= 500) continue;
+        for (const auto& h : compute2DConvexHull(Q.data(), (int)(Q.size() / 3), seed))
+          rows.push_back({h[0], h[1], h[2], c[0], c[1], c[2], dc[d], 0.f});
+      }
+    }
+    return rows;
+  }
+
+  /** truncation counters of the last segmentallPointCloudData call (sslam_seg_last_overflow): all zero = complete result */
+  int overflow_planes() const { return overflow_planes_; }
+  int overflow_candidate_boxes() const { return overflow_candidate_boxes_; }
+  int overflow_region_boxes() const { return overflow_region_boxes_; }
+
   bool verbose_;
 
  private:
   sslam_seg* seg_ = nullptr;
+  int overflow_planes_ = 0, overflow_candidate_boxes_ = 0, overflow_region_boxes_ = 0;
 
  public:
   // cloud filters of the legacy path (plane_segmentation.cpp:557-629), on unorganised xyz float clouds

@@ -156,7 +156,10 @@ int sslam_batch_optimize(sslam_batch* b, int max_iters, sslam_opt_stats* out /* 
  * (ncclDouble, sum, over xGMI) of the contiguous [H || b] device buffer gives every rank the full system, and the solve / update /
  * LM control then run replicated and bit-identical.  Rank 0 obtains an id with sslam_comm_unique_id and hands its 128 bytes to the
  * other ranks by whatever the host program uses (torch.distributed, MPI, a file); every rank then calls sslam_batch_comm_init.
- * world == 1 switches the mode off.  sslam_batch_set_edge_shard installs the shard WITHOUT a communicator (the partial systems stay
+ * world == 1 switches the mode off, unless the environment sets SSLAM_FORCE_COMM=1: then a single-rank communicator is created and the
+ * whole path (masked kernels, ncclCommInitRank, ncclAllReduce on the batch stream) runs on one GPU (sslam_batch_info "allreduce_calls"
+ * counts the collectives issued).  The all-reduce is out of place, partial buffer -> [H || b]: graphs that do not re-linearise in a
+ * step keep their old partial system, so the sum stays the system they already had.  sslam_batch_set_edge_shard installs the shard WITHOUT a communicator (the partial systems stay
  * unsummed): with sslam_batch_linearize_hb (-> the [H || b] buffer; NULL returns its length in doubles) this is the parity hook that
  * shows sum over ranks of partial systems == the full system on a single device. */
 int sslam_comm_unique_id(char id_out[128]);

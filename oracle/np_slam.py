@@ -417,6 +417,8 @@ class SemanticGraphSlam:
                     self.assoc.landmarks[l["id"]]["vertex"] = l["vertex"]
                     stats["landmarks_added"] += 1
                 else:
+                    if l["vertex"] < 0:      # matched a landmark an earlier detection of the same frame created: it has its vertex by now
+                        l["vertex"] = self.assoc.landmarks[l["id"]]["vertex"]
                     stats["landmarks_matched"] += 1
                 inf = _inverse3f(l["covariance"]).astype(float)
                 self._add_edge(O.ET_SE3_POINT, kf["node"], l["vertex"], l["local_pose"].astype(float), inf)

@@ -91,6 +91,8 @@ struct Batch {
   bool sharded = false;        // linearize only the edges of this rank's range
   void* comm = nullptr;        // ncclComm_t (RCCL), or null: partial systems are left unsummed (single-device tests)
   int64_t hb_doubles = 0;      // doubles in the contiguous [H || b] buffer
+  double* d_hb_part = nullptr; // edge-sharded mode: this rank's partial [H || b] (send buffer of the out-of-place all-reduce)
+  int64_t allreduce_calls = 0; // ncclAllReduce calls issued so far (tests: the collective really ran)
   int shard_rank = 0, shard_world = 1;
 
   ~Batch() { release(); }

@@ -1583,16 +1583,33 @@ static int batch_linearize(Batch& b) {
     }                                                                                                                                 \
     if (V.nLr > 0) hipLaunchKernelGGL((k_linearize_lm_rows<PLV, SHV>), dim3((V.nLr + 15) / 16), dim3(256), 0, b.stream, V);           \
   }
-  if (b.sharded) { if (b.has_planes) SSLAM_LAUNCH_LIN(true, true) else SSLAM_LAUNCH_LIN(false, true) }
-  else { if (b.has_planes) SSLAM_LAUNCH_LIN(true, false) else SSLAM_LAUNCH_LIN(false, false) }
-#undef SSLAM_LAUNCH_LIN
-  if (V.nDupEo + V.nDupEl > 0) hipLaunchKernelGGL(k_linearize_dups, dim3((std::max(V.nDupEo, V.nDupEl) + 63) / 64), dim3(64), 0, b.stream, V);
-  if (b.sharded && b.comm) {
-    // the partial [H || b] arrays of all ranks -> their sum on every rank: ONE all-reduce over xGMI (RCCL), in stream order;
-    // everything after it (solve, update, chi2, LM control) runs replicated and bit-identical on all ranks
-    const ncclResult_t r = rccl_api().AllReduce(V.Hpp_diag, V.Hpp_diag, (size_t)b.hb_doubles, ncclDouble, ncclSum, (ncclComm_t)b.comm, b.stream);
-    if (r != ncclSuccess) return set_error(SSLAM_ERR_HIP, "ncclAllReduce of the normal equations: %s", rccl_api().GetErrorString(r));
+  if (b.sharded) {
+    // edge-sharded mode: the rank-partial system is built in its own buffer and summed OUT OF PLACE into [H || b].  A graph that does not
+    // re-linearise in this step (a rejected trial being retried, a finished graph) keeps its old partial system there, so the sum over
+    // ranks is again the system it already had: the all-reduce is idempotent for it.  (Summing in place would multiply the H of such a
+    // graph by `world` on every step: the damping of a retried trial would fall instead of rising -- round-2 ADVICE.)
+    BatchView Vp = V;
+    Vp.Hpp_diag = b.d_hb_part; Vp.Hll_diag = b.d_hb_part + b.hll_base; Vp.Hpp_off = b.d_hb_part + b.hpp_off_base;
+    Vp.Hpl = b.d_hb_part + b.hpl_base; Vp.bvec = b.d_hb_part + (V.bvec - V.Hpp_diag);
+    {
+      const BatchView& V = Vp;
+      if (b.has_planes) SSLAM_LAUNCH_LIN(true, true) else SSLAM_LAUNCH_LIN(false, true)
+      if (V.nDupEo + V.nDupEl > 0) hipLaunchKernelGGL(k_linearize_dups, dim3((std::max(V.nDupEo, V.nDupEl) + 63) / 64), dim3(64), 0, b.stream, V);
+    }
+    if (b.comm) {
+      // the partial [H || b] arrays of all ranks -> their sum on every rank: ONE all-reduce over xGMI (RCCL), in stream order;
+      // everything after it (solve, update, chi2, LM control) runs replicated and bit-identical on all ranks
+      const ncclResult_t r = rccl_api().AllReduce(b.d_hb_part, V.Hpp_diag, (size_t)b.hb_doubles, ncclDouble, ncclSum, (ncclComm_t)b.comm, b.stream);
+      if (r != ncclSuccess) return set_error(SSLAM_ERR_HIP, "ncclAllReduce of the normal equations: %s", rccl_api().GetErrorString(r));
+      b.allreduce_calls++;
+    } else {   // no communicator (single-device parity hook): the partial system is what the caller reads
+      SSLAM_HIP_TRY(hipMemcpyAsync(V.Hpp_diag, b.d_hb_part, (size_t)b.hb_doubles * sizeof(double), hipMemcpyDeviceToDevice, b.stream));
+    }
+  } else {
+    if (b.has_planes) SSLAM_LAUNCH_LIN(true, false) else SSLAM_LAUNCH_LIN(false, false)
+    if (V.nDupEo + V.nDupEl > 0) hipLaunchKernelGGL(k_linearize_dups, dim3((std::max(V.nDupEo, V.nDupEl) + 63) / 64), dim3(64), 0, b.stream, V);
   }
+#undef SSLAM_LAUNCH_LIN
   return launch_check("linearize");
 }
 
@@ -2214,8 +2231,13 @@ static int batch_set_shard(Batch& b, int rank, int world) {
   SSLAM_HIP_TRY(hipMemcpyAsync((void*)b.V.shard_lo, lo.data(), lo.size() * sizeof(int), hipMemcpyHostToDevice, b.stream));
   SSLAM_HIP_TRY(hipMemcpyAsync((void*)b.V.shard_hi, hi.data(), hi.size() * sizeof(int), hipMemcpyHostToDevice, b.stream));
   SSLAM_HIP_TRY(hipStreamSynchronize(b.stream));
-  b.sharded = world > 1;
+  b.sharded = world > 1 || b.comm != nullptr;   // a forced single-rank communicator keeps the whole sharded path (masked kernels + all-reduce) on
   b.shard_rank = rank; b.shard_world = world;
+  if (b.sharded && !b.d_hb_part) {
+    int rc;
+    if ((rc = dev_alloc(b, (size_t)b.hb_doubles, &b.d_hb_part))) return rc;
+    SSLAM_HIP_TRY(hipStreamSynchronize(b.stream));
+  }
   return 0;
 }
 int sslam_comm_unique_id(char id_out[128]) {
@@ -2235,7 +2257,10 @@ int sslam_batch_comm_init(sslam_batch* h, const char id_in[128], int rank, int w
   if (rc) return rc;
   SSLAM_HIP_TRY(hipSetDevice(b.device));
   if (b.comm) { batch_comm_destroy(b.comm); b.comm = nullptr; }
-  if (world > 1) {
+  // world == 1 switches the mode off -- unless SSLAM_FORCE_COMM=1 asks for a single-rank communicator: the whole product path of the
+  // mode (shard-masked kernels, ncclCommInitRank, the out-of-place ncclAllReduce on the batch's stream) then runs on one GPU
+  const char* force = getenv("SSLAM_FORCE_COMM");
+  if (world > 1 || (force && atoi(force) != 0)) {
     if (!rccl_api().ok()) return set_error(SSLAM_ERR_UNSUPPORTED, "librccl.so could not be loaded: %s", dlerror());
     ncclUniqueId id;
     memcpy(&id, id_in, sizeof id);
@@ -2318,6 +2343,7 @@ int sslam_batch_info(sslam_batch* h, const char* key, double* value) {
   else if (k == "factor_launches") *value = (double)chol_plan_launches(b);
   else if (k == "h_doubles") *value = (double)b.V.h_total;
   else if (k == "dim") *value = dim;
+  else if (k == "allreduce_calls") *value = (double)b.allreduce_calls;
   else if (k == "factor_bytes") *value = 8.0 * ((double)b.V.h_total + dim + (double)chol_plan_lnz(b) + dim);
   else return set_error(SSLAM_ERR_INVALID, "unknown info key '%s'", key);
   return 0;

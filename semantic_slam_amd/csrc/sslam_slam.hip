@@ -441,23 +441,26 @@ int empty_keyframe_queue(sslam_slam* s) {
   const int n = std::min<int>((int)s->keyframe_queue.size(), s->P.max_keyframes_per_update);
   double info[36];
   odometry_information(s, info);
-  for (int i = 0; i < n; ++i) {
+  int err = 0, used = 0;
+  for (int i = 0; i < n && !err; ++i) {
     const std::shared_ptr<KeyFrame>& kf = s->keyframe_queue[i];
-    s->new_keyframes.push_back(kf);
     double tq[7];
     to_tq(kf->odom, tq);
     kf->node = sslam_graph_add_vertex_se3(s->graph, tq, -1);
-    if (kf->node < 0) return kf->node;
+    used = i + 1;
+    if (kf->node < 0) { err = kf->node; break; }      // the keyframe is dropped: it never reached the graph
+    s->new_keyframes.push_back(kf);
     if (i == 0 && s->keyframes.empty()) continue;
     const std::shared_ptr<KeyFrame>& prev = i == 0 ? s->keyframes.back() : s->keyframe_queue[i - 1];
     const Pose rel = compose(inverse(prev->odom), kf->odom);
     double z[7];
     to_tq(rel, z);
     const int rc = sslam_graph_add_edge_se3(s->graph, prev->node, kf->node, z, info);
-    if (rc < 0) return rc;
+    if (rc < 0) err = rc;
   }
-  s->keyframe_queue.erase(s->keyframe_queue.begin(), s->keyframe_queue.begin() + n);
-  return 1;
+  // whatever was touched leaves the queue, also on an error: a second call must not add the same keyframes again
+  s->keyframe_queue.erase(s->keyframe_queue.begin(), s->keyframe_queue.begin() + (err ? used : n));
+  return err ? err : 1;
 }
 
 // Eigen's fixed-size 3x3 inverse (cofactors times 1/det), as `covariance.inverse()` of a Matrix3f evaluates (semantic_graph_slam.cpp:170)
@@ -480,7 +483,12 @@ int empty_landmark_queue(sslam_slam* s, std::vector<sslam_landmark>& q, const Ke
       l.is_new = 0;
       s->landmarks[l.id].vertex = l.vertex;            // assignLandmarkNode (:163-164)
       if (st) st->landmarks_added++;
-    } else if (st) st->landmarks_matched++;
+    } else {
+      // a landmark created by an earlier detection of the same frame had no vertex yet when find_matches copied it; the earlier
+      // record of this queue has assigned it by now
+      if (l.vertex < 0) l.vertex = s->landmarks[l.id].vertex;
+      if (st) st->landmarks_matched++;
+    }
     float inf[9];
     inverse3f(l.covariance, inf);
     double z[3], info[9];
@@ -497,13 +505,12 @@ int empty_landmark_queue(sslam_slam* s, std::vector<sslam_landmark>& q, const Ke
 int get_and_set_landmark_cov(sslam_slam* s, sslam_tick_stats* st) {
   const int n = (int)s->landmarks.size();
   if (n == 0) { if (st) st->marginals_ok = 1; return 0; }   // computeMarginals over an empty pair list
-  std::vector<int> pairs(2 * n);
-  for (int i = 0; i < n; ++i) {
-    const int h = sslam_graph_hessian_index(s->graph, s->landmarks[i].vertex);
-    pairs[2 * i] = pairs[2 * i + 1] = h;
-  }
+  // the reference hands (hessianIndex, hessianIndex) pairs to computeMarginals (:186-191); the vertex ids name the same blocks and
+  // spare one scan of the vertex list per landmark
+  std::vector<int> ids(n);
+  for (int i = 0; i < n; ++i) ids[i] = s->landmarks[i].vertex;
   std::vector<double> blocks(9 * (size_t)n);
-  const int rc = sslam_graph_marginals_by_hessian_index(s->graph, pairs.data(), n, blocks.data());
+  const int rc = sslam_graph_marginals(s->graph, ids.data(), n, blocks.data());
   if (rc == SSLAM_ERR_NUMERIC || rc == SSLAM_ERR_INVALID) return 0;   // computeLandmarkMarginals returned false: covariances keep their values
   if (rc < 0) return rc;
   for (int i = 0; i < n; ++i)
@@ -646,7 +653,9 @@ int sslam_slam_vio(sslam_slam* s, int32_t sec, int32_t nsec, const double odom_t
   } else {
     const Pose delta = compose(inverse(s->prev_keypose), odom);
     const double dx = std::sqrt(dot(delta.t, delta.t));
-    const double da = std::acos(delta.q.w);   // Eigen::Quaterniond(delta.linear()).w(): the matrix -> quaternion conversion yields w >= 0
+    // Eigen::Quaterniond(delta.linear()).w(): the matrix -> quaternion conversion yields w >= 0, whatever the sign of the odometry
+    // quaternions that went in (q and -q are the same rotation)
+    const double da = std::acos(std::min(1.0, std::fabs(delta.q.w)));
     // ros::Duration::sec: whole seconds of the normalised difference (nsec part in [0, 1e9))
     int64_t dsec = (int64_t)sec - s->prev_sec, dnsec = (int64_t)nsec - s->prev_nsec;
     if (dnsec < 0) { dnsec += 1000000000; dsec -= 1; }
@@ -687,11 +696,20 @@ int sslam_slam_run(sslam_slam* s, sslam_tick_stats* st) {
   sslam_tick_stats local;
   if (!st) st = &local;
   std::memset(st, 0, sizeof *st);
+  // on an error after the queue was touched the bookkeeping is completed before the error is returned (the keyframes that reached the
+  // graph move to `keyframes`): the next call must neither add them again nor associate them a second time
+  auto fail = [&](int code) {
+    for (auto& kf : s->new_keyframes) { kf->cloud.clear(); kf->cloud.shrink_to_fit(); s->keyframes.push_back(kf); }
+    s->new_keyframes.clear();
+    s->table_dirty = true;
+    return code;
+  };
   int rc = empty_keyframe_queue(s);
-  if (rc <= 0) return rc;
+  if (rc < 0) return fail(rc);
+  if (rc == 0) return 0;
   st->keyframes_added = (int)s->new_keyframes.size();
   double t0 = now_s();
-  if ((rc = segment_new_keyframes(s)) < 0) return rc;
+  if ((rc = segment_new_keyframes(s)) < 0) return fail(rc);
   st->seconds_frontend = now_s() - t0;
   t0 = now_s();
   for (auto& kfp : s->new_keyframes) {   // semantic_graph_slam.cpp:62-70
@@ -700,8 +718,8 @@ int sslam_slam_run(sslam_slam* s, sslam_tick_stats* st) {
     float rp[6];
     pose_to_vector6(kf.robot_pose, rp);
     std::vector<sslam_landmark> cur;
-    if ((rc = find_matches(s, kf.objects.data(), (int)kf.objects.size(), rp, cur)) < 0) return rc;
-    if ((rc = empty_landmark_queue(s, cur, kf, st)) < 0) return rc;
+    if ((rc = find_matches(s, kf.objects.data(), (int)kf.objects.size(), rp, cur)) < 0) return fail(rc);
+    if ((rc = empty_landmark_queue(s, cur, kf, st)) < 0) return fail(rc);
     kf.cloud.clear(); kf.cloud.shrink_to_fit();
   }
   st->seconds_association = now_s() - t0;

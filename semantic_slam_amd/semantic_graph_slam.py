@@ -157,6 +157,9 @@ class SemanticGraphSLAM:
         if rc < 0:
             raise SslamError(rc, self._lib.sslam_last_error().decode())
 
+    def num_edges(self) -> int:
+        return int(self._lib.sslam_graph_num_edges(self._lib.sslam_slam_graph(self._h)))
+
     def graph_vertex(self, vid: int, n: int = 3) -> np.ndarray:
         out = np.zeros(7)
         g = self._lib.sslam_slam_graph(self._h)

@@ -442,3 +442,24 @@ def make_replay(seed: int = 0, n_samples: int = 400, n_landmarks: int = 24, *, r
         events.append(ReplayEvent((sec, nsec), odom[k], true[k], objs, k >= first_run_at and (k - first_run_at) % run_every == 0))
     events[-1].run_after = True
     return events, lms
+
+
+def _main(argv):
+    """python -m semantic_slam_amd.synth KIND POSES LANDMARKS OUT_DIR SEED...  -> OUT_DIR/KIND_POSES_LANDMARKS_SEED.g2o
+    (bench.py's workload generator: plain host processes, no HIP call is made)"""
+    import os
+    from .graph_slam import GraphSLAM
+    kind, poses, landmarks, out_dir = argv[0], int(argv[1]), int(argv[2]), argv[3]
+    for sd in argv[4:]:
+        path = os.path.join(out_dir, f"{kind}_{poses}_{landmarks}_{int(sd)}.g2o")
+        if os.path.exists(path) and os.path.getsize(path) > 0:
+            continue
+        G = GraphSLAM.from_synth(make_graph(poses, landmarks, seed=int(sd), landmark_kind=kind))
+        tmp = f"{path}.{os.getpid()}.tmp"
+        G.save(tmp)
+        os.replace(tmp, path)
+
+
+if __name__ == "__main__":
+    import sys
+    _main(sys.argv[1:])

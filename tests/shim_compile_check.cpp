@@ -92,5 +92,22 @@ int main(int argc, char** argv) {
   const bool enough = 1 + st.landmark_edges_added >= 10;   // GraphSLAM::optimize refuses fewer than 10 edges (graph_slam.cpp:184-186)
   if (kfs.size() != 2 || st.keyframes_added != 2 || st.landmark_edges_added != st.landmarks_added + st.landmarks_matched ||
       (int)lms.size() != st.landmarks_added || (enough && (!st.optimized || !st.marginals_ok))) return 12;
+  if (seg.overflow_planes() || seg.overflow_candidate_boxes() || seg.overflow_region_boxes()) { std::printf("frontend tables overflowed\n"); return 13; }
+
+  // legacy path (plane_segmentation::clusterAndSegmentAllPlanes / computeKmeans) through the shim: the scene the caller wrote
+  // (int32 n; n x 3 float32 xyz; n x 3 float32 normals), identity transformation
+  if (argc < 4) { std::printf("legacy shim skipped (no scene file)\n"); return 0; }
+  f = std::fopen(argv[3], "rb");
+  if (!f) { std::printf("cannot open %s\n", argv[3]); return 14; }
+  int32_t n = 0;
+  if (std::fread(&n, 4, 1, f) != 1 || n <= 0) return 14;
+  std::vector<float> xyz((size_t)n * 3), nrm((size_t)n * 3);
+  if (std::fread(xyz.data(), 4, xyz.size(), f) != xyz.size() || std::fread(nrm.data(), 4, nrm.size(), f) != nrm.size()) return 14;
+  std::fclose(f);
+  const float T[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+  const std::vector<std::array<float, 8>> rows = seg.clusterAndSegmentAllPlanes(xyz.data(), nrm.data(), n, T, 1);
+  double rcs = 0;
+  for (auto& r : rows) for (int k = 0; k < 8; ++k) rcs += (k + 1) * (double)r[k];
+  std::printf("legacy shim ok: %zu rows rowsum %.9e\n", rows.size(), rcs);
   return 0;
 }

@@ -364,6 +364,64 @@ def test_edge_shards_sum_to_the_full_system(gpu_lib):
     assert st[0].iterations == 4 and st[0].chi2_after < st[0].chi2_before
 
 
+def test_edge_shards_of_the_L_graph_sum_to_the_full_system(gpu_lib):
+    """BASELINE.json configs[4] geometry on one device: the 8 edge shards of a 5000-pose / 1000-landmark graph (the ranges 8 ranks
+    would own) each build their partial [H || b] with the product's shard-masked kernels; their sum is the full system."""
+    from semantic_slam_amd import GraphSLAM, GraphBatch
+    from semantic_slam_amd.distributed import shard_range
+    g = make_graph(5000, 1000, seed=0)
+    G = GraphSLAM.from_synth(g)
+    B = GraphBatch([G]); B.upload()
+    full = B.linearize_hb()
+    tot = np.zeros_like(full)
+    ne = G.num_edges()
+    covered = 0
+    for r in range(8):
+        B.set_edge_shard(r, 8)
+        part = B.linearize_hb()
+        assert np.abs(part).max() > 0 and np.abs(part - full).max() > 0
+        tot += part
+        lo, hi = shard_range(ne, r, 8)
+        covered += hi - lo
+    assert covered == ne == 20099
+    assert np.abs(tot - full).max() <= 1e-12 * np.abs(full).max()
+    B.set_edge_shard(0, 1)
+    assert np.array_equal(B.linearize_hb(), full)
+
+
+def test_single_rank_communicator_runs_the_allreduce_inside_the_lm_loop(gpu_lib, monkeypatch):
+    """The RCCL path of the edge-sharded mode with a live communicator on ONE GPU (SSLAM_FORCE_COMM=1): ncclCommInitRank(world 1),
+    shard-masked Jacobian kernels, the out-of-place ncclAllReduce of [H || b] on the batch stream inside batch_optimize.  Results
+    are bit-identical to the unsharded run, including the steps in which a graph only retries a rejected trial (its partial system
+    is not rebuilt; the all-reduce must leave its H as it was -- round-2 ADVICE)."""
+    import ctypes as C
+    from semantic_slam_amd import GraphSLAM, GraphBatch, load_library
+    lib = load_library()
+    gps = [GraphProblem.from_synth(make_graph(70 + 5 * i, 14, seed=40 + i), interleave=bool(i & 1)) for i in range(5)]
+    gps.append(GraphProblem.from_synth(make_graph(50, 9, seed=46, landmark_kind="plane")))
+
+    def run(force):
+        gs = [GraphSLAM.from_problem(gp) for gp in gps]
+        B = GraphBatch(gs); B.upload()
+        if force:
+            buf = C.create_string_buffer(128)
+            assert lib.sslam_comm_unique_id(buf) == 0, lib.sslam_last_error()
+            B.comm_init(buf.raw, 0, 1)
+        st = B.optimize(60)
+        B.download()
+        return B, st, [G.estimates() for G in gs]
+
+    _, s0, e0 = run(False)
+    monkeypatch.setenv("SSLAM_FORCE_COMM", "1")
+    B, s1, e1 = run(True)
+    assert B.info("allreduce_calls") >= max(st.trials for st in s1) > 0
+    assert any(st.trials > st.iterations for st in s1)          # some graph retried with a raised lambda
+    for a, b, x, y in zip(s0, s1, e0, e1):
+        assert (a.iterations, a.trials, a.status) == (b.iterations, b.trials, b.status)
+        assert a.chi2_after == b.chi2_after and a.chi2_before == b.chi2_before
+        assert np.array_equal(x, y)
+
+
 def test_marginals_match_oracle(gpu_lib):
     from semantic_slam_amd import GraphSLAM
     g = make_graph(40, 8, seed=6)
@@ -420,8 +478,26 @@ def test_cpp_shim_end_to_end(gpu_lib, tmp_path):
             np.array([b["tl_x"], b["tl_y"], b["width"], b["height"]], "<i4").tofile(f)
         np.concatenate([fr.robot_pose, [fr.cam_angle]]).astype("<f4").tofile(f)
         f.write(fr.cloud.tobytes())
-    out = subprocess.run([exe, path, str(len(planes))], capture_output=True, text=True)
+    # the legacy k-means path of the shim (computeKmeans / clusterAndSegmentAllPlanes) on a floor + table + two walls scene
+    rng = np.random.default_rng(4)
+
+    def patch(n, origin, u, v, normal):
+        ab = rng.uniform(0, 1, (n, 2))
+        p = np.asarray(origin) + ab[:, :1] * np.asarray(u) + ab[:, 1:] * np.asarray(v) + rng.normal(0, 0.002, (n, 1)) * np.asarray(normal)
+        return p.astype(np.float32), (np.asarray(normal) + rng.normal(0, 0.02, (n, 3))).astype(np.float32)
+    parts = [patch(6000, [-1, -1, -1.0], [2.0, 0, 0], [0, 2.0, 0], [0, 0, 1.0]), patch(4000, [0.2, 0.2, -0.4], [0.8, 0, 0], [0, 0.6, 0], [0, 0, 1.0]),
+             patch(5000, [1.5, -1, -1.0], [0, 2.0, 0], [0, 0, 1.5], [-1.0, 0, 0]), patch(5000, [-1, 1.5, -1.0], [2.0, 0, 0], [0, 0, 1.5], [0, -1.0, 0])]
+    xyz = np.vstack([p for p, _ in parts]); nr = np.vstack([q for _, q in parts])
+    nr[::97] = np.nan
+    rows = seg.clusterAndSegmentAllPlanes(xyz, nr, np.eye(4, dtype=np.float32), seed=1)
+    scene = str(tmp_path / "scene.bin")
+    with open(scene, "wb") as f:
+        np.array([len(xyz)], "<i4").tofile(f); xyz.astype("<f4").tofile(f); nr.astype("<f4").tofile(f)
+    out = subprocess.run([exe, path, str(len(planes)), scene], capture_output=True, text=True)
     assert out.returncode == 0 and "shim ok: chi2" in out.stdout and "frontend shim ok" in out.stdout and "orchestrator shim ok" in out.stdout, out.stdout + out.stderr
+    m = re.search(r"legacy shim ok: (\d+) rows rowsum (\S+)", out.stdout)
+    assert m and int(m.group(1)) == len(rows) >= 6, out.stdout
+    assert float(m.group(2)) == pytest.approx(float((rows.astype(np.float64) * np.arange(1, 9)).sum()), rel=1e-9)
     cs = sum(float(p.normal_orientation[0]) + 2.0 * float(p.normal_orientation[1]) + 3.0 * float(p.normal_orientation[2])
              + 0.5 * float(p.normal_orientation[3]) + float(p.num_points) for p in planes)
     got = float(re.search(r"checksum (\S+)", out.stdout).group(1))

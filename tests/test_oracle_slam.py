@@ -78,3 +78,30 @@ def test_same_frame_twin_matches_the_landmark_just_created_and_b5_carry():
     Dq.find_matches([mk(0.0)], pose, np.float32(0), est)
     q = Dq.find_matches([mk(0.0), mk(0.1)], pose, np.float32(0), est)
     assert [(r["is_new"], r["id"]) for r in q] == [(False, 0), (True, 1)]
+
+
+def test_full_tick_with_same_frame_twins_adds_both_edges_to_the_new_vertex():
+    """a detection that matches a landmark created earlier in the same frame: its record is copied before the vertex exists
+    (data_association.h:309 on an uninitialised node); the landmark queue must resolve it to the vertex the earlier record created"""
+    events, _ = make_replay(4, n_samples=220)
+    for ev in events:
+        if ev.objects:
+            t = dict(ev.objects[0])
+            t["pose"] = ev.objects[0]["pose"] + np.array([0.05, 0.0, 0.0], np.float32)
+            ev.objects.insert(1, t)
+    o = oracle_instance()
+    for ev in events:
+        feed(o, ev, False)
+    pairs = [(i, j) for t, i, j in zip(o.etype, o.evi, o.evj) if t == S.O.ET_SE3_POINT]
+    assert pairs and all(j >= 0 and o.vtype[j] == S.O.VT_POINT for _, j in pairs)
+    assert len(set(pairs)) < len(pairs)          # a keyframe with two edges to one landmark
+
+
+def test_keyframe_gate_is_blind_to_the_quaternion_sign():
+    a, b = oracle_instance(), oracle_instance()
+    events, _ = make_replay(5, n_samples=120)
+    for k, ev in enumerate(events):
+        q = ev.odom.copy()
+        if k % 2:
+            q[3:] = -q[3:]
+        assert a.vio(ev.stamp[0], ev.stamp[1], ev.odom) == b.vio(ev.stamp[0], ev.stamp[1], q)

@@ -37,11 +37,8 @@ def _compare_state(P, Or, tol_est=1e-6):
     assert np.abs(mp[:3] - mo[:3]).max() <= 10 * tol_est
 
 
-@pytest.mark.parametrize("seed,kw", [(0, {}), (1, {}), (2, dict(detect_from=0, first_run_at=60, run_every=9))])
-def test_replay_matches_oracle_tick_by_tick(gpu_lib, seed, kw):
-    """seeds 0/1: the node's loop keeps up (one or two keyframes per tick after an initial stall that queues > 10 keyframes);
-    seed 2: detections inside the stall and a slow loop -- association on the stale robot_pose_ the reference would use"""
-    events, lms = make_replay(seed, n_samples=300, **kw)
+def _run_both(events):
+    """the product and the oracle through the same events, compared tick by tick; returns (product, oracle, ticks)"""
     P, Or = product_instance(), oracle_instance()
     ticks = 0
     for ev in events:
@@ -58,11 +55,56 @@ def test_replay_matches_oracle_tick_by_tick(gpu_lib, seed, kw):
         if so["optimized"]:
             assert abs(st.opt.chi2_after - so["opt"].chi2_after) <= 1e-6 * max(1.0, so["opt"].chi2_after)
         _compare_state(P, Or)
+    return P, Or, ticks
+
+
+@pytest.mark.parametrize("seed,kw", [(0, {}), (1, {}), (2, dict(detect_from=0, first_run_at=60, run_every=9))])
+def test_replay_matches_oracle_tick_by_tick(gpu_lib, seed, kw):
+    """seeds 0/1: the node's loop keeps up (one or two keyframes per tick after an initial stall that queues > 10 keyframes);
+    seed 2: detections inside the stall and a slow loop -- association on the stale robot_pose_ the reference would use"""
+    events, lms = make_replay(seed, n_samples=300, **kw)
+    P, Or, ticks = _run_both(events)
     assert ticks > 20 and len(Or.assoc.landmarks) >= 8
     if not kw:   # the loop kept up: the map is the true one (every landmark within the stale-pose error of a true landmark)
         tr = np.array([p for p, _, _ in lms])
         for l in P.getMappedLandmarks():
             assert np.linalg.norm(tr - P.graph_vertex(l.vertex), axis=1).min() < 0.25
+
+
+def test_same_frame_twin_detections_through_the_full_tick(gpu_lib):
+    """two same-class, same-plane-type detections 5 cm apart in one frame: the second one matches the landmark the first one has just
+    created, which has no graph vertex yet when find_matches copies it (data_association.h:309 reads the uninitialised node there).
+    The tick must add both landmark edges to the one new vertex, not abort (round-2 ADVICE, high)."""
+    events, _ = make_replay(4, n_samples=260)
+    twins = 0
+    for ev in events:
+        if ev.objects:
+            t = dict(ev.objects[0])
+            t["pose"] = ev.objects[0]["pose"] + np.array([0.05, 0.0, 0.0], np.float32)
+            ev.objects.insert(1, t)
+            twins += 1
+    P, Or, ticks = _run_both(events)
+    assert twins > 20 and ticks > 20
+    # every landmark edge of the oracle's graph points at a real vertex, and some landmark got two edges from one keyframe
+    pairs = [(i, j) for t, i, j in zip(Or.etype, Or.evi, Or.evj) if t == S.O.ET_SE3_POINT]
+    assert all(j >= 0 for _, j in pairs) and len(set(pairs)) < len(pairs)
+    assert P.num_edges() == len(Or.etype)
+
+
+def test_keyframe_gate_ignores_the_sign_of_the_odometry_quaternion(gpu_lib):
+    """q and -q are one rotation: Eigen::Quaterniond(delta.linear()).w() of the reference's gate (keyframe_updater.hpp:52-54) is >= 0
+    whatever the sign of the quaternions the odometry source publishes (round-2 ADVICE, medium)"""
+    events, _ = make_replay(5, n_samples=200)
+    for k, ev in enumerate(events):
+        if k % 2:
+            ev.odom = ev.odom.copy()
+            ev.odom[3:] = -ev.odom[3:]
+    plain, _ = make_replay(5, n_samples=200)
+    P, Or, ticks = _run_both(events)
+    Pp = product_instance()
+    for ev in plain:
+        feed(Pp, ev, True)
+    assert ticks > 10 and len(P.getKeyframes()[0]) == len(Pp.getKeyframes()[0]) == len(Or.keyframes)
 
 
 def test_first_tick_takes_at_most_ten_keyframes(gpu_lib):
