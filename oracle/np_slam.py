@@ -13,6 +13,8 @@ tests or golden vectors for this path, and it cannot be built here (ROS / g2o / 
     src/ps_graph_slam/information_matrix_calculator.cpp:28-35
     include/ps_graph_slam/ros_utils.hpp:90-106          matrix2vector
     include/tools.h:18-135                              transformNormalsToWorld, transformPoseFromCameraToRobot
+    src/ps_graph_slam/semantic_graph_slam.cpp:207-232   semantic_data_ass: matrix2vector(robot_pose) -> segmentallPointCloudData
+                                                        (the frontend oracle, oracle_seg.c) -> find_matches
 
 with rigid transforms as 4x4 double matrices (Eigen::Isometry3d), the association in float32 (Eigen::MatrixXf / VectorXf), the
 optimiser and the marginals through the C oracle (oracle_graph.c).  The decisions taken on the reference's undefined behaviour
@@ -302,7 +304,7 @@ def _inverse3f(m):
 class SemanticGraphSlam:
     def __init__(self, keyframe_delta_trans=0.5, keyframe_delta_angle=0.5, keyframe_delta_time=1.0, max_keyframes_per_update=10,
                  update_keyframes_using_detections=False, camera_angle_deg=0.0, const_stddev_x=0.0, const_stddev_q=0.0,
-                 max_iterations=1024, **da):
+                 max_iterations=1024, seg_params=None, **da):
         self.dt, self.da_, self.dtime = keyframe_delta_trans, keyframe_delta_angle, keyframe_delta_time
         self.max_kf = max_keyframes_per_update
         self.using_det = update_keyframes_using_detections
@@ -316,6 +318,8 @@ class SemanticGraphSlam:
         self.robot_pose = np.eye(4); self.prev_odom = np.eye(4); self.map2odom = np.eye(4); self.vio_pose = np.eye(4)
         self.queue, self.new_keyframes, self.keyframes = [], [], []
         self.latest_objects = None
+        self.latest_cloud = None; self.latest_boxes = None
+        self.seg_params = seg_params        # sslam_seg_params-layout struct for the frontend oracle (cloud path only)
         self.is_first, self.prev_keypose, self.prev_stamp, self.accum = True, np.eye(4), (0, 0), 0.0
         # the graph, as flat lists in the oracle's layout
         self.vtype, self.vfixed, self.est = [], [], []
@@ -326,6 +330,27 @@ class SemanticGraphSlam:
     def set_segmented_objects(self, objs):
         self.object_detection_available = True
         self.latest_objects = [dict(o) for o in objs]
+
+    def set_point_cloud(self, frame):
+        """setPointCloudData (semantic_graph_slam.cpp:341-345); `frame`: synth.SynthFrame-like (cloud bytes + geometry)"""
+        self.latest_cloud = frame
+
+    def set_detected_objects(self, boxes):
+        """setDetectedObjectInfo (semantic_graph_slam.cpp:353-357); `boxes`: the frame's structured box array"""
+        self.object_detection_available = True
+        self.latest_boxes = boxes
+        self.latest_objects = None
+
+    def _segment(self, kf):
+        """semantic_data_ass (semantic_graph_slam.cpp:207-232): the keyframe's cloud and boxes through the frontend oracle, seen from
+        matrix2vector(keyframe->robot_pose) (ros_utils.hpp:90-106)"""
+        import dataclasses
+        if self.seg_params is None:
+            raise RuntimeError("a keyframe carries detection boxes but the oracle was built without seg_params")
+        fr = dataclasses.replace(kf["cloud"], boxes=kf["boxes"], robot_pose=matrix2vector(kf["robot_pose"]).astype(F), cam_angle=float(F(self.cam_angle)))
+        planes, _, _ = O.segment_frame(fr, self.seg_params)
+        return [dict(pose=np.array(pl.centroid_cam[:], F), normal=np.array(pl.normal_d[:], F), class_id=int(pl.class_id), plane_type=int(pl.plane_type))
+                for pl in planes]
 
     def _gate(self, odom, stamp):
         if self.is_first:
@@ -351,10 +376,13 @@ class SemanticGraphSlam:
                 self.robot_pose = self.robot_pose @ (iso_inv(self.prev_odom) @ odom)
             self.vio_pose = odom; self.prev_odom = odom
             return False
-        kf = dict(odom=odom, robot_pose=self.robot_pose.copy(), node=-1, objects=[])
+        kf = dict(odom=odom, robot_pose=self.robot_pose.copy(), node=-1, objects=[], boxes=None, cloud=None)
         if self.object_detection_available:
             self.object_detection_available = False
-            kf["objects"] = self.latest_objects
+            if self.latest_objects is not None:
+                kf["objects"] = self.latest_objects
+            else:                                    # getPointCloudData / getDetectedObjectInfo (:264-272)
+                kf["boxes"], kf["cloud"] = self.latest_boxes, self.latest_cloud
         self.queue.append(kf)
         self.vio_pose = odom; self.prev_odom = odom
         return True
@@ -405,6 +433,9 @@ class SemanticGraphSlam:
         stats = dict(keyframes_added=len(self.new_keyframes), landmarks_added=0, landmarks_matched=0, landmark_edges_added=0,
                      optimized=False, marginals_ok=False, records=[])
         for kf in self.new_keyframes:
+            if kf["boxes"] is not None and len(kf["boxes"]) > 0:
+                kf["objects"] = self._segment(kf)
+                kf["cloud"] = None
             if not kf["objects"]:
                 continue
             rp = matrix2vector(kf["robot_pose"])

@@ -23,6 +23,16 @@ def product_instance(**kw):
     return SemanticGraphSLAM(p)
 
 
+def product_instance_with(segmentation, **kw):
+    """the product with a frontend handle (the cloud path of the tick)"""
+    from semantic_slam_amd.semantic_graph_slam import SemanticGraphSLAM, default_slam_params
+    p = default_slam_params()
+    p.const_stddev_x, p.const_stddev_q = ODOM_STDDEV_X, ODOM_STDDEV_Q
+    for k, v in kw.items():
+        setattr(p, k, v)
+    return SemanticGraphSLAM(p, segmentation)
+
+
 def planes_of(objs):
     from semantic_slam_amd.segmentation import Plane
     out = []

@@ -10,7 +10,7 @@ import numpy as np
 import pytest
 
 from semantic_slam_amd.synth import make_replay
-from tests.slam_replay import oracle_instance, product_instance, feed, planes_of
+from tests.slam_replay import oracle_instance, product_instance, product_instance_with, feed, planes_of
 from oracle import np_slam as S
 
 pytestmark = pytest.mark.gpu
@@ -147,3 +147,44 @@ def test_association_kernel_matches_oracle(gpu_lib, quirk):
                     assert abs(g.distance - r["distance"]) <= 1e-4 * max(1.0, abs(r["distance"]))
             pose[:3] += rng.normal(0, 0.2, 3).astype(np.float32)
         assert len(P.getMappedLandmarks()) == len(D.landmarks) > 10
+
+
+def test_tick_parity_through_the_frontend(gpu_lib):
+    """Row f3 with the cloud path: keyframes that carry a real synthetic organised cloud + detection boxes go through
+    sslam_slam_set_point_cloud / set_detected_objects -> the tick's batched frontend pass (sslam_seg_segment_batch seen from
+    pose_to_vector6(robot_pose)) -> association -> graph growth -> optimise -> marginals, against the oracle composition
+    matrix2vector -> oracle_seg.c -> np_slam association (reference semantic_graph_slam.cpp:207-232, ros_utils.hpp:90-106).
+    Same bars as the pre-segmented replay."""
+    from semantic_slam_amd.segmentation import PointCloudSegmentation
+    from semantic_slam_amd.synth import make_frame
+    events, _ = make_replay(6, n_samples=420, detect_every=3)
+    frames = [make_frame(seed=20 + k, n_boxes=10) for k in range(6)]
+    seg = PointCloudSegmentation()
+    P = product_instance_with(seg)
+    Or = oracle_instance(seg_params=seg.params)
+    ticks = kfs = with_planes = 0
+    nd = 0
+    for ev in events:
+        if ev.objects is not None:
+            fr = frames[nd % len(frames)]; nd += 1
+            P.setPointCloudData(fr); P.setDetectedObjectInfo(fr.boxes)
+            Or.set_point_cloud(fr); Or.set_detected_objects(fr.boxes)
+        kp = bool(P.VIOCallback(ev.stamp, ev.odom)); ko = bool(Or.vio(ev.stamp[0], ev.stamp[1], ev.odom))
+        assert kp == ko
+        kfs += kp
+        if not ev.run_after:
+            continue
+        rp, ro = bool(P.run()), bool(Or.run())
+        assert rp == ro
+        if not rp:
+            continue
+        ticks += 1
+        st, so = P.last_stats, Or.last_stats
+        assert (st.keyframes_added, st.landmarks_added, st.landmarks_matched, st.landmark_edges_added, bool(st.optimized), bool(st.marginals_ok)) == \
+               (so["keyframes_added"], so["landmarks_added"], so["landmarks_matched"], so["landmark_edges_added"], so["optimized"], so["marginals_ok"])
+        with_planes += so["landmark_edges_added"]
+        if so["optimized"]:
+            assert abs(st.opt.chi2_after - so["opt"].chi2_after) <= 1e-6 * max(1.0, so["opt"].chi2_after)
+        _compare_state(P, Or)
+    assert ticks >= 20 and kfs >= 20 and with_planes >= 40 and len(Or.assoc.landmarks) >= 3
+    assert seg.last_overflow() == (0, 0, 0)
