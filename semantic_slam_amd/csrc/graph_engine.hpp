@@ -15,6 +15,8 @@ namespace sslam {
 
 struct CholPlan;
 void chol_plan_free(CholPlan*);
+struct WPlan;
+void wchol_plan_free(WPlan*);
 void batch_comm_destroy(void* comm);   // ncclCommDestroy
 
 struct KernelTimer {
@@ -86,7 +88,8 @@ struct Batch {
   bool has_planes = false;
   std::vector<int> dup_eo, dup_el;
   int max_row_slots = 0;
-  CholPlan* chol = nullptr;
+  CholPlan* chol = nullptr;    // piece plan (chol_plan.hpp): multi right-hand-side solves of the marginals; SSLAM_CHOL_LEGACY=1: the LM loop too
+  WPlan* wchol = nullptr;      // window plan (wchol_plan.hpp): factorisation + solve of the LM loop
   // edge-sharded mode
   bool sharded = false;        // linearize only the edges of this rank's range
   void* comm = nullptr;        // ncclComm_t (RCCL), or null: partial systems are left unsummed (single-device tests)
@@ -98,6 +101,7 @@ struct Batch {
   ~Batch() { release(); }
   void release() {
     if (chol) { chol_plan_free(chol); chol = nullptr; }
+    if (wchol) { wchol_plan_free(wchol); wchol = nullptr; }
     if (comm) { batch_comm_destroy(comm); comm = nullptr; }
     if (stream) { hipSetDevice(device); hipStreamSynchronize(stream); }
     for (auto& p : pending) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
@@ -164,5 +168,17 @@ int chol_backward(Batch& b);             // x = L^-T y  -> V.x
 int64_t chol_plan_lnz(const Batch& b);
 int chol_plan_levels(const Batch& b);
 int chol_solve_multi(Batch& b, const double* rhs_host, int nrhs, double* x_host);  // uses the last factorisation
+
+// window multifrontal block Cholesky (sslam_wchol.hip; symbolic phase in wchol_plan.hpp): the solver of the LM loop
+int wchol_plan_build(Batch& b);
+int wchol_factor_and_forward(Batch& b);  // (H + lambda I) = L L^T for in_trial graphs, y = L^-1 b
+int wchol_backward(Batch& b);            // x = L^-T y  -> V.x
+int64_t wchol_plan_lnz(const Batch& b);
+int64_t wchol_plan_unz(const Batch& b);
+int wchol_plan_levels(const Batch& b);
+int wchol_plan_launches(const Batch& b);
+int wchol_plan_segments(const Batch& b);
+// the same plan and the same per-thread phases executed on the host (no device needed): x of (H + lambda I) x = b per graph
+int wchol_emulate(const SymIn& in, const double* Hb, int64_t h_total, const double* lambda, double* x_out, int* fail_out, int64_t* stats);
 
 }  // namespace sslam

@@ -1655,6 +1655,12 @@ static int batch_solve(Batch& b) {
   // (H + lambda I) dx = b for every graph with in_trial set; result in V.x
   if (b.graphs[0]->opt.solver == 0 || b.graphs[0]->opt.solver == 2) return pcg_solve(b);
   int rc;
+  static const bool legacy = [] { const char* e = getenv("SSLAM_CHOL_LEGACY"); return e && atoi(e) != 0; }();
+  if (!legacy) {   // window multifrontal factorisation (sslam_wchol.hip)
+    if (!b.wchol && (rc = wchol_plan_build(b))) return rc;
+    if ((rc = wchol_factor_and_forward(b))) return rc;
+    return wchol_backward(b);
+  }
   if (!b.chol && (rc = chol_plan_build(b))) return rc;
   if ((rc = chol_factor_and_forward(b))) return rc;
   return chol_backward(b);
@@ -2360,6 +2366,27 @@ int sslam_batch_kernel_time(sslam_batch* h, const char* name, double* total_ms, 
   if (total_ms) *total_ms = it == h->b.timers.end() ? 0.0 : it->second.total_ms;
   if (launches) *launches = it == h->b.timers.end() ? 0 : it->second.launches;
   return 0;
+}
+
+// ---- the window Cholesky on the host (no device needed): plan + the kernels' per-thread phases run by a CPU executor ---------
+int64_t sslam_debug_wchol_solve(sslam_graph* const* graphs, int n, const double* h_and_b, int64_t hb_doubles, const double* lambda,
+                                double* x_out, int32_t* fail_out, int64_t* stats8) {
+  if (!graphs || n <= 0) return set_error(SSLAM_ERR_INVALID, "empty batch");
+  Batch b;
+  for (int i = 0; i < n; ++i) { if (!graphs[i]) return set_error(SSLAM_ERR_INVALID, "null graph"); b.graphs.push_back(&graphs[i]->g); }
+  int rc = batch_build(b, true);
+  if (rc) return rc;
+  const int64_t dim = 6 * (int64_t)b.V.nPr + 3 * (int64_t)b.V.nLr;
+  const int64_t need = ((b.V.h_total + 1) & ~(int64_t)1) + dim;
+  if (!h_and_b || !lambda || !x_out) return need;   // size query: doubles in the [H || b] buffer
+  if (hb_doubles < need) return set_error(SSLAM_ERR_INVALID, "[H || b] buffer of %lld doubles needed", (long long)need);
+  SymIn in;
+  chol_sym_input(b, in);
+  std::vector<int> fail(n, 0);
+  rc = wchol_emulate(in, h_and_b, b.V.h_total, lambda, x_out, fail.data(), stats8);
+  if (rc) return rc;
+  if (fail_out) for (int i = 0; i < n; ++i) fail_out[i] = fail[i];
+  return need;
 }
 
 // ---- plan introspection (host only, no device needed): the symbolic Cholesky plan of a batch as flat int32 arrays ----------

@@ -1,0 +1,617 @@
+// Window multifrontal block Cholesky for the LM normal equations on gfx950 (FP64), numeric phase (round 3).
+//
+// Replaces g2o's BlockSolverX + LinearSolverCSparse pair that the reference selects with "lm_var"
+// (reference src/ps_graph_slam/graph_slam.cpp:27,67-73).  Symbolic phase and the design: wchol_plan.hpp.
+//   k_wchol_factor<CLS>     one workgroup per SEGMENT of the elimination tree: the active submatrix of the segment (a window of <= W
+//                           block rows) lives in registers, four lanes per 6 x 6 tile; per pivot column: assemble (H blocks, update
+//                           matrices of child segments), pivot panel -> LDS, 6 x 6 Cholesky + row solves, rank-6 update of the window;
+//                           the factor leaves as one contiguous panel per column, the forward substitution rides along
+//   k_wchol_backward<CLS>   the same segments top-down for x = L^-T y, the window's x in LDS
+// Every phase of a step is written once, as a function of (thread id, that thread's registers, the workgroup's LDS block), and run
+// by an executor: on the GPU one thread each with a barrier behind every phase, on the host (sslam_debug_wchol_solve, CPU-only
+// tests of the plan AND of the kernel logic) a loop over the thread ids per phase.  A phase never reads an LDS word that another
+// thread writes in the same phase, so both executions are equivalent.
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+#include "../../include/sslam.h"
+#include "graph_engine.hpp"
+#include "wchol_plan.hpp"
+
+namespace sslam {
+
+struct WView {
+  const WStep* step; const WRow* row; const WChild* child; const WFin* fin; const WSeg* seg; const unsigned char* wmap;
+  const double* H;      // the [H || b] buffer (block offsets of WRow::hsrc are relative to it)
+  const double* bvec;
+  double* Lval; double* Uval; double* y; double* x;
+  int* fail;            // [B]
+};
+
+constexpr int kWMaxCh = 4;   // child update matrices absorbed per pass
+
+template <int W>
+struct WShared {
+  double P[W][36];        // the pivot column: P[slot] = F(row in slot, pivot column), 6 x 6 row-major, zero padded
+  double rhs[W][6];       // the right-hand-side row of the window (factor) / x of the window's rows (backward)
+  double part[W][6];      // backward: per row of the column, its contribution to the pivot's right-hand side
+  double yc[6];
+  double Lc[21], linv[6]; // factor: L_cc (packed lower by rows) and its reciprocal pivots
+  double Ld[36];          // backward: the pivot's diagonal block
+  int hsrc[W], info[W];   // per slot, valid for the slots of the current column: H source; dim | fmt << 8
+  int rowslot[W], rlofs[W], rdim[W];   // per row of the current column
+  int ch_uoff[kWMaxCh], ch_m[kWMaxCh];
+  unsigned char inv[kWMaxCh][W + 2];   // per child of the pass: window slot -> local row of the child's update matrix (0xFF none)
+};
+
+template <int S>
+struct WThread {
+  double acc[S][9];       // S tiles of the window, this lane's 3 x 3 quarter of each
+  int ta[S], tb[S];       // window slots (a >= b) of the tiles; a >= W: no such tile
+};
+
+#define SSLAM_HD __host__ __device__ __forceinline__
+// the per-tile bodies of a phase are unrolled (a tile's registers need compile-time indices); without a fence the scheduler overlaps
+// the operand loads of all of a thread's tiles and the register count doubles
+#if defined(__HIP_DEVICE_COMPILE__)
+#define SSLAM_TILE_FENCE() __builtin_amdgcn_sched_barrier(0)
+// everything derived from a tile's slots is invariant over the columns of a segment; hoisted out of the column loop those address
+// computations cost ~100 VGPRs for the whole kernel.  Launder the slots once per phase instead.
+#define SSLAM_OPAQUE(x) asm volatile("" : "+v"(x))
+#else
+#define SSLAM_TILE_FENCE() ((void)0)
+#define SSLAM_OPAQUE(x) ((void)0)
+#endif
+
+// tile index T = a (a + 1) / 2 + b  ->  (a, b), a >= b
+SSLAM_HD void wtile_ab(int T, int& a, int& b) {
+  int q = (int)((sqrtf(8.0f * (float)T + 1.0f) - 1.0f) * 0.5f);
+  while (q * (q + 1) / 2 > T) --q;
+  while ((q + 1) * (q + 2) / 2 <= T) ++q;
+  a = q; b = T - q * (q + 1) / 2;
+}
+SSLAM_HD bool wbit(unsigned long long m, int s) { return (m >> s) & 1ull; }
+SSLAM_HD int wrank(unsigned long long live, int s) {
+  const unsigned long long below = live & ((1ull << s) - 1ull);
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __popcll(below);
+#else
+  return __builtin_popcountll(below);
+#endif
+}
+
+// 6 x 6 (or 3 x 3 in the leading block of a padded 6 x 6) Cholesky of the lower triangle of A (row-major, ld 6), in place in 21
+// registers: L packed by rows -> Lc, reciprocal pivots -> linv.  Right-looking: one rsqrt + one multiply between consecutive pivots.
+SSLAM_HD bool wchol6(const double* A, double* Lc /* 21 */, double* linv /* 6 */) {
+  double a[21];
+#pragma unroll
+  for (int r = 0; r < 6; ++r)
+#pragma unroll
+    for (int c = 0; c <= r; ++c) a[r * (r + 1) / 2 + c] = A[r * 6 + c];
+  bool ok = true;
+#pragma unroll
+  for (int c = 0; c < 6; ++c) {
+    double d = a[c * (c + 1) / 2 + c];
+    if (!(d > 0)) { ok = false; d = 1.0; }
+    const double id = 1.0 / sqrt(d);
+    linv[c] = id;
+    a[c * (c + 1) / 2 + c] = d * id;
+#pragma unroll
+    for (int r = c + 1; r < 6; ++r) a[r * (r + 1) / 2 + c] *= id;
+#pragma unroll
+    for (int r = c + 1; r < 6; ++r)
+#pragma unroll
+      for (int c2 = c + 1; c2 <= r; ++c2) a[r * (r + 1) / 2 + c2] -= a[r * (r + 1) / 2 + c] * a[c2 * (c2 + 1) / 2 + c];
+  }
+#pragma unroll
+  for (int q = 0; q < 21; ++q) Lc[q] = a[q];
+  return ok;
+}
+
+// ------------------------------------------------------------------------------------------------
+// factorisation of one segment.  Ex: executor (phase runner); W / NT / S: window slots, threads, tile registers per thread
+// ------------------------------------------------------------------------------------------------
+template <int W, int NT, int S, class Ex>
+SSLAM_HD void wchol_factor_segment(Ex& ex, WShared<W>& sm, const WView& C, const WSeg sg, const double lambda) {
+  // ---- start: empty window
+  ex.phase([&](int tid, WThread<S>& ts) {
+#pragma unroll
+    for (int k = 0; k < S; ++k) {
+#pragma unroll
+      for (int q = 0; q < 9; ++q) ts.acc[k][q] = 0.0;
+      wtile_ab(k * (NT / 4) + (tid >> 2), ts.ta[k], ts.tb[k]);
+    }
+    for (int t = tid; t < W * 6; t += NT) sm.rhs[t / 6][t % 6] = 0.0;
+  });
+  for (int s = 0; s < sg.nsteps; ++s) {
+    const WStep st = C.step[sg.step0 + s];
+    const int c = st.piv & 255, dj = (st.piv >> 8) & 255, nr = st.piv >> 16;
+    const unsigned long long mask = (unsigned long long)st.mask_lo | ((unsigned long long)st.mask_hi << 32);
+    // ---- update matrices of child segments that join at this column, kWMaxCh per pass
+    for (int c0 = 0; c0 < st.nchild; c0 += kWMaxCh) {
+      const int nc = st.nchild - c0 < kWMaxCh ? st.nchild - c0 : kWMaxCh;
+      ex.phase([&](int tid, WThread<S>& ts) {
+        for (int t = tid; t < kWMaxCh * (W + 2); t += NT) sm.inv[t / (W + 2)][t % (W + 2)] = 0xFF;
+      });
+      ex.phase([&](int tid, WThread<S>& ts) {
+        for (int ch = 0; ch < nc; ++ch) {
+          const WChild wc = C.child[st.child0 + c0 + ch];
+          if (tid == 0) { sm.ch_uoff[ch] = wc.uoff; sm.ch_m[ch] = wc.m; }
+          for (int p = tid; p < wc.m; p += NT) sm.inv[ch][C.wmap[wc.map0 + p]] = (unsigned char)p;
+        }
+      });
+      ex.phase([&](int tid, WThread<S>& ts) {
+        int tq = tid; SSLAM_OPAQUE(tq); const int tr = (tq >> 1) & 1, tc = tq & 1;
+#pragma unroll
+        for (int k = 0; k < S; ++k) {
+          SSLAM_TILE_FENCE();
+          int a = ts.ta[k], b = ts.tb[k];
+          SSLAM_OPAQUE(a); SSLAM_OPAQUE(b);
+          if (a >= W || !wbit(mask, a) || !wbit(mask, b)) continue;
+          for (int ch = 0; ch < nc; ++ch) {
+            const int pa = sm.inv[ch][a], pb = sm.inv[ch][b];
+            if (pa == 0xFF || pb == 0xFF) continue;
+            const int hi = pa > pb ? pa : pb, lo = pa > pb ? pb : pa;
+            const double* U = C.Uval + sm.ch_uoff[ch] + 36 * (hi * (hi + 1) / 2 + lo);
+            if (pa >= pb) {
+#pragma unroll
+              for (int rr = 0; rr < 3; ++rr)
+#pragma unroll
+                for (int cc = 0; cc < 3; ++cc) ts.acc[k][rr * 3 + cc] += U[(3 * tr + rr) * 6 + 3 * tc + cc];
+            } else {   // the child stores the tile of this row pair the other way round
+#pragma unroll
+              for (int rr = 0; rr < 3; ++rr)
+#pragma unroll
+                for (int cc = 0; cc < 3; ++cc) ts.acc[k][rr * 3 + cc] += U[(3 * tc + cc) * 6 + 3 * tr + rr];
+            }
+          }
+        }
+        for (int t = tid; t < W * 6; t += NT) {   // right-hand-side parts, one thread per (slot, component)
+          const int slot = t / 6, r = t % 6;
+          if (!wbit(mask, slot)) continue;
+          double v = sm.rhs[slot][r];
+          for (int ch = 0; ch < nc; ++ch) {
+            const int p = sm.inv[ch][slot];
+            if (p != 0xFF) { const int m = sm.ch_m[ch]; v += C.Uval[sm.ch_uoff[ch] + 36 * (m * (m + 1) / 2) + 6 * p + r]; }
+          }
+          sm.rhs[slot][r] = v;
+        }
+      });
+    }
+    // ---- 0. the rows of the column: slot tables; b of the pivot
+    ex.phase([&](int tid, WThread<S>& ts) {
+      for (int ri = tid; ri < nr; ri += NT) {
+        const WRow wr = C.row[st.row0 + ri];
+        const int slot = wr.slot & 255, di = (wr.slot >> 8) & 255, fmt = (wr.slot >> 16) & 1;
+        sm.hsrc[slot] = wr.hsrc; sm.info[slot] = di | (fmt << 8);
+        sm.rowslot[ri] = slot; sm.rlofs[ri] = wr.lofs; sm.rdim[ri] = di;
+      }
+      if (tid < dj) sm.rhs[c][tid] += C.bvec[st.xoff + tid];
+    });
+    // ---- A. H blocks of the column into the pivot cross of the window; the cross leaves the registers for the LDS panel
+    ex.phase([&](int tid, WThread<S>& ts) {
+      int tq = tid; SSLAM_OPAQUE(tq); const int tr = (tq >> 1) & 1, tc = tq & 1;
+#pragma unroll
+      for (int k = 0; k < S; ++k) {
+        SSLAM_TILE_FENCE();
+        int a = ts.ta[k], b = ts.tb[k];
+        SSLAM_OPAQUE(a); SSLAM_OPAQUE(b);
+        if (a >= W) continue;
+        const bool inb = b == c;
+        if (!(a == c || inb)) continue;
+        const int other = inb ? a : b;              // diagonal tile: other == c
+        if (!wbit(mask, other)) continue;           // not a row of this column: structurally zero
+        // this lane's quarter of the panel block P[other] = F(row of `other`, pivot): the tile itself when its column slot is the
+        // pivot, its transpose when its row slot is
+        const int ptr = inb ? tr : tc, ptc = inb ? tc : tr;
+        double v[9];
+#pragma unroll
+        for (int rr = 0; rr < 3; ++rr)
+#pragma unroll
+          for (int cc = 0; cc < 3; ++cc) v[rr * 3 + cc] = inb ? ts.acc[k][rr * 3 + cc] : ts.acc[k][cc * 3 + rr];
+        const int inf = sm.info[other], di = inf & 255, fmt = (inf >> 8) & 1, hs = sm.hsrc[other];
+        if (hs >= 0 && 3 * ptr < di && 3 * ptc < dj) {
+          const double* Hb = C.H + hs;
+#pragma unroll
+          for (int rr = 0; rr < 3; ++rr)
+#pragma unroll
+            for (int cc = 0; cc < 3; ++cc) {
+              const int r = 3 * ptr + rr, q = 3 * ptc + cc;
+              v[rr * 3 + cc] += fmt ? Hb[q * di + r] : Hb[r * dj + q];
+            }
+        }
+        if (other == c && ptr == ptc) {             // damping; the padding of a 3-wide pivot becomes an identity block
+#pragma unroll
+          for (int rr = 0; rr < 3; ++rr) { if (3 * ptr + rr < dj) v[rr * 4] += lambda; else v[rr * 4] = 1.0; }
+        }
+        double* o = &sm.P[other][(3 * ptr) * 6 + 3 * ptc];
+#pragma unroll
+        for (int rr = 0; rr < 3; ++rr)
+#pragma unroll
+          for (int cc = 0; cc < 3; ++cc) { o[rr * 6 + cc] = v[rr * 3 + cc]; ts.acc[k][rr * 3 + cc] = 0.0; }
+      }
+    });
+    // ---- B1. L_cc = chol(S_cc) and y_c = L_cc^-1 rhs_c by one thread (a chain of six dependent pivots: nothing to share out)
+    ex.phase([&](int tid, WThread<S>& ts) {
+      if (tid != 0) return;
+      if (!wchol6(&sm.P[c][0], sm.Lc, sm.linv)) C.fail[sg.graph] = 1;
+      double y[6];
+#pragma unroll
+      for (int r = 0; r < 6; ++r) {
+        double w = sm.rhs[c][r];
+#pragma unroll
+        for (int q = 0; q < r; ++q) w -= sm.Lc[r * (r + 1) / 2 + q] * y[q];
+        y[r] = w * sm.linv[r];
+      }
+#pragma unroll
+      for (int r = 0; r < 6; ++r) { sm.yc[r] = r < dj ? y[r] : 0.0; if (r < dj) C.y[st.xoff + r] = y[r]; }
+    });
+    // ---- B2. one thread per row of the panel: x L_cc^T = v (L_cc streamed from LDS); the factor leaves for HBM
+    ex.phase([&](int tid, WThread<S>& ts) {
+      for (int t = tid; t < 6 * nr; t += NT) {
+        const int ri = t / 6, r = t - 6 * ri;
+        const int slot = sm.rowslot[ri], di = sm.rdim[ri];
+        if (r >= di) continue;
+        double* out = C.Lval + st.loff + sm.rlofs[ri] + r * dj;
+        if (ri == 0) {                              // the pivot's own rows: row r of L_cc
+          for (int q = 0; q < dj; ++q) out[q] = q <= r ? sm.Lc[r * (r + 1) / 2 + q] : 0.0;
+          continue;
+        }
+        double* v = &sm.P[slot][r * 6];
+        double xr[6];
+#pragma unroll
+        for (int q = 0; q < 6; ++q) {
+          double w = v[q];
+#pragma unroll
+          for (int q2 = 0; q2 < q; ++q2) w -= xr[q2] * sm.Lc[q * (q + 1) / 2 + q2];
+          xr[q] = w * sm.linv[q];
+        }
+#pragma unroll
+        for (int q = 0; q < 6; ++q) { v[q] = xr[q]; if (q < dj) out[q] = xr[q]; }
+      }
+    });
+    // ---- C. window(a, b) -= L(a, c) L(b, c)^T for the rows a, b of the column; right-hand-side row; the pivot's slot is free again
+    ex.phase([&](int tid, WThread<S>& ts) {
+      int tq = tid; SSLAM_OPAQUE(tq); const int tr = (tq >> 1) & 1, tc = tq & 1;
+#pragma unroll
+      for (int k = 0; k < S; ++k) {
+        SSLAM_TILE_FENCE();
+        int a = ts.ta[k], b = ts.tb[k];
+        SSLAM_OPAQUE(a); SSLAM_OPAQUE(b);
+        if (a >= W || a == c || b == c || !wbit(mask, a) || !wbit(mask, b)) continue;
+        const double* A = &sm.P[a][(3 * tr) * 6];
+        const double* Bm = &sm.P[b][(3 * tc) * 6];
+        double bb[18];
+#pragma unroll
+        for (int q = 0; q < 18; ++q) bb[q] = Bm[q];
+#pragma unroll
+        for (int rr = 0; rr < 3; ++rr) {
+          double ar[6];
+#pragma unroll
+          for (int q = 0; q < 6; ++q) ar[q] = A[rr * 6 + q];
+#pragma unroll
+          for (int cc = 0; cc < 3; ++cc) {
+            double w = ts.acc[k][rr * 3 + cc];
+#pragma unroll
+            for (int q = 0; q < 6; ++q) w -= ar[q] * bb[cc * 6 + q];
+            ts.acc[k][rr * 3 + cc] = w;
+          }
+        }
+      }
+      for (int t = tid; t < 6 * nr; t += NT) {
+        const int ri = t / 6, r = t - 6 * ri;
+        const int slot = sm.rowslot[ri];
+        if (ri == 0) { sm.rhs[slot][r] = 0.0; continue; }
+        double w = sm.rhs[slot][r];
+#pragma unroll
+        for (int q = 0; q < 6; ++q) w -= sm.P[slot][r * 6 + q] * sm.yc[q];
+        sm.rhs[slot][r] = w;
+      }
+    });
+  }
+  // ---- end: what is left in the window is the update matrix for the parent segment
+  if (sg.m > 0) {
+    unsigned long long live = 0;
+    for (int p = 0; p < sg.m; ++p) live |= 1ull << (C.fin[sg.fin0 + p].slot & 255);
+    ex.phase([&](int tid, WThread<S>& ts) {
+      int tq = tid; SSLAM_OPAQUE(tq); const int tr = (tq >> 1) & 1, tc = tq & 1;
+      double* U = C.Uval + sg.uoff;
+#pragma unroll
+      for (int k = 0; k < S; ++k) {
+        SSLAM_TILE_FENCE();
+        int a = ts.ta[k], b = ts.tb[k];
+        SSLAM_OPAQUE(a); SSLAM_OPAQUE(b);
+        if (a >= W || !wbit(live, a) || !wbit(live, b)) continue;
+        const int p = wrank(live, a), q = wrank(live, b);
+        double* o = U + 36 * (p * (p + 1) / 2 + q) + (3 * tr) * 6 + 3 * tc;
+#pragma unroll
+        for (int rr = 0; rr < 3; ++rr)
+#pragma unroll
+          for (int cc = 0; cc < 3; ++cc) o[rr * 6 + cc] = ts.acc[k][rr * 3 + cc];
+      }
+      for (int t = tid; t < W * 6; t += NT) {
+        const int slot = t / 6, r = t % 6;
+        if (wbit(live, slot)) U[36 * (sg.m * (sg.m + 1) / 2) + 6 * wrank(live, slot) + r] = sm.rhs[slot][r];
+      }
+    });
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward substitution of one segment: x_c = L_cc^-T (y_c - sum_i L_ic^T x_i), columns in reverse order
+// ------------------------------------------------------------------------------------------------
+template <int W, int NT, int S, class Ex>
+SSLAM_HD void wchol_backward_segment(Ex& ex, WShared<W>& sm, const WView& C, const WSeg sg) {
+  // the rows above the segment (its update-matrix rows) are final: their x comes from HBM
+  ex.phase([&](int tid, WThread<S>& ts) {
+    for (int t = tid; t < sg.m * 6; t += NT) {
+      const int p = t / 6, r = t - 6 * p;
+      const WFin f = C.fin[sg.fin0 + p];
+      const int slot = f.slot & 255, d = (f.slot >> 8) & 255;
+      sm.rhs[slot][r] = r < d ? C.x[f.xoff + r] : 0.0;
+    }
+  });
+  for (int s = sg.nsteps - 1; s >= 0; --s) {
+    const WStep st = C.step[sg.step0 + s];
+    const int c = st.piv & 255, dj = (st.piv >> 8) & 255, nr = st.piv >> 16;
+    ex.phase([&](int tid, WThread<S>& ts) {
+      for (int ri = tid; ri < nr; ri += NT) {
+        const WRow wr = C.row[st.row0 + ri];
+        sm.rowslot[ri] = wr.slot & 255; sm.rlofs[ri] = wr.lofs; sm.rdim[ri] = (wr.slot >> 8) & 255;
+      }
+      for (int e = tid; e < dj * dj; e += NT) sm.Ld[e] = C.Lval[st.loff + e];
+      if (tid < 6) sm.yc[tid] = tid < dj ? C.y[st.xoff + tid] : 0.0;
+    });
+    ex.phase([&](int tid, WThread<S>& ts) {
+      for (int t = tid; t < 6 * (nr - 1); t += NT) {
+        const int ri = 1 + t / 6, q = t % 6;
+        double w = 0.0;
+        if (q < dj) {
+          const int slot = sm.rowslot[ri], di = sm.rdim[ri];
+          const double* Lb = C.Lval + st.loff + sm.rlofs[ri] + q;
+          for (int r = 0; r < di; ++r) w += Lb[r * dj] * sm.rhs[slot][r];
+        }
+        sm.part[ri][q] = w;
+      }
+    });
+    ex.phase([&](int tid, WThread<S>& ts) {
+      if (tid != 0) return;
+      double t[6], x[6];
+#pragma unroll
+      for (int q = 0; q < 6; ++q) {
+        double w = sm.yc[q];
+        for (int ri = 1; ri < nr; ++ri) w -= sm.part[ri][q];
+        t[q] = w;
+      }
+      for (int r = dj - 1; r >= 0; --r) {
+        double w = t[r];
+        for (int s2 = dj - 1; s2 > r; --s2) w -= sm.Ld[s2 * dj + r] * x[s2];
+        x[r] = w / sm.Ld[r * dj + r];
+      }
+      for (int r = 0; r < 6; ++r) {
+        sm.rhs[c][r] = r < dj ? x[r] : 0.0;
+        if (r < dj) C.x[st.xoff + r] = x[r];
+      }
+    });
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// executors
+// ------------------------------------------------------------------------------------------------
+template <int S>
+struct WGpuExec {
+  WThread<S> ts;
+  template <class F>
+  __device__ __forceinline__ void phase(F&& f) {
+    f((int)threadIdx.x, ts);
+    __syncthreads();
+  }
+};
+template <int S>
+struct WCpuExec {
+  std::vector<WThread<S>> ts;
+  int nt;
+  explicit WCpuExec(int n) : ts(n), nt(n) {}
+  template <class F>
+  void phase(F&& f) { for (int t = 0; t < nt; ++t) f(t, ts[t]); }
+};
+
+// minimum waves per SIMD asked of the compiler (register budget): the one-wave class at four waves per SIMD (<= 128 VGPRs)
+constexpr int kWWaves[3] = {3, 2, 1};
+template <int CLS>
+__global__ __launch_bounds__(kWClass[CLS].nt, kWWaves[CLS]) void k_wchol_factor(WView C, const LmState* __restrict__ lm, int seg0) {
+  constexpr int W = kWClass[CLS].wmax, NT = kWClass[CLS].nt, S = kWClass[CLS].S;
+  __shared__ WShared<W> sm;
+  const WSeg sg = C.seg[seg0 + blockIdx.x];
+  if (!lm[sg.graph].in_trial) return;
+  WGpuExec<S> ex;
+  wchol_factor_segment<W, NT, S>(ex, sm, C, sg, lm[sg.graph].lambda);
+}
+template <int CLS>
+__global__ __launch_bounds__(kWClass[CLS].nt) void k_wchol_backward(WView C, const LmState* __restrict__ lm, int seg0) {
+  constexpr int W = kWClass[CLS].wmax, NT = kWClass[CLS].nt, S = kWClass[CLS].S;
+  __shared__ WShared<W> sm;
+  const WSeg sg = C.seg[seg0 + blockIdx.x];
+  if (lm && !lm[sg.graph].in_trial) return;
+  WGpuExec<S> ex;
+  wchol_backward_segment<W, NT, S>(ex, sm, C, sg);
+}
+__global__ void k_wchol_begin(BatchView V, WView C) {   // clear the failure flags of the graphs being solved
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g < V.B && V.lm[g].in_trial) C.fail[g] = 0;
+}
+__global__ void k_wchol_end(BatchView V, WView C) {     // publish failures through the solver-agnostic flag
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g < V.B && V.lm[g].in_trial) V.pcg_fail[g] = C.fail[g];
+}
+
+// ------------------------------------------------------------------------------------------------
+// host
+// ------------------------------------------------------------------------------------------------
+struct WPlan {
+  WView C{};
+  std::vector<int> launch_ptr, launch_cls;
+  std::vector<void*> allocs;
+  DevArena* arena = nullptr;
+  int64_t lnz = 0, unz = 0;
+  int nlevels = 0, nseg = 0;
+};
+
+void wchol_plan_free(WPlan* p) {
+  if (!p) return;
+  for (void* a : p->allocs) (void)hipFree(a);
+  delete p;
+}
+
+namespace {
+template <typename T>
+int w_up(WPlan& P, hipStream_t s, const std::vector<T>& h, const T** out) {
+  void* p = nullptr;
+  const size_t n = h.size() + 4;
+  if (P.arena) { p = P.arena->take(n * sizeof(T)); if (!p) return set_error(SSLAM_ERR_HIP, "device allocation of %zu bytes failed", n * sizeof(T)); }
+  else { SSLAM_HIP_TRY(hipMalloc(&p, n * sizeof(T))); P.allocs.push_back(p); }
+  if (!h.empty()) SSLAM_HIP_TRY(hipMemcpyAsync(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, s));
+  *out = (const T*)p;
+  return 0;
+}
+int w_alloc(WPlan& P, void** q, size_t bytes) {
+  if (P.arena) { *q = P.arena->take(bytes); return *q ? 0 : set_error(SSLAM_ERR_HIP, "device allocation of %zu bytes failed", bytes); }
+  SSLAM_HIP_TRY(hipMalloc(q, bytes)); P.allocs.push_back(*q);
+  return 0;
+}
+}  // namespace
+
+int wchol_plan_build(Batch& b) {
+  if (b.wchol) { wchol_plan_free(b.wchol); b.wchol = nullptr; }
+  SSLAM_HIP_TRY(hipSetDevice(b.device));
+  SymIn in;
+  chol_sym_input(b, in);
+  WOpts opt;
+  opt.from_env(b.V.B);
+  WHost H;
+  if (wchol_symbolic(in, opt, H)) return set_error(SSLAM_ERR_UNSUPPORTED, "window Cholesky plan: %s", H.error.c_str());
+  WPlan* P = new WPlan();
+  b.wchol = P;
+  P->arena = b.arena;
+  P->launch_ptr = H.launch_ptr; P->launch_cls = H.launch_cls; P->lnz = H.lnz; P->unz = H.unz; P->nlevels = H.nlevels; P->nseg = (int)H.seg.size();
+  WView& C = P->C;
+  int rc;
+  if ((rc = w_up(*P, b.stream, H.step, &C.step))) return rc;
+  if ((rc = w_up(*P, b.stream, H.row, &C.row))) return rc;
+  if ((rc = w_up(*P, b.stream, H.child, &C.child))) return rc;
+  if ((rc = w_up(*P, b.stream, H.fin, &C.fin))) return rc;
+  if ((rc = w_up(*P, b.stream, H.seg, &C.seg))) return rc;
+  if ((rc = w_up(*P, b.stream, H.wmap, &C.wmap))) return rc;
+  void* p = nullptr;
+  if ((rc = w_alloc(*P, &p, (H.lnz + 64) * sizeof(double)))) return rc;
+  C.Lval = (double*)p;
+  if ((rc = w_alloc(*P, &p, (H.unz + 64) * sizeof(double)))) return rc;
+  C.Uval = (double*)p;
+  if ((rc = w_alloc(*P, &p, ((size_t)H.dim + 8) * sizeof(double)))) return rc;
+  C.y = (double*)p;
+  if ((rc = w_alloc(*P, &p, std::max(b.V.B, 1) * sizeof(int)))) return rc;
+  C.fail = (int*)p;
+  SSLAM_HIP_TRY(hipMemsetAsync(C.fail, 0, std::max(b.V.B, 1) * sizeof(int), b.stream));
+  C.H = b.V.Hpp_diag; C.bvec = b.V.bvec; C.x = b.V.x;
+  SSLAM_HIP_TRY(hipStreamSynchronize(b.stream));
+  return 0;
+}
+
+int64_t wchol_plan_lnz(const Batch& b) { return b.wchol ? b.wchol->lnz : 0; }
+int64_t wchol_plan_unz(const Batch& b) { return b.wchol ? b.wchol->unz : 0; }
+int wchol_plan_levels(const Batch& b) { return b.wchol ? b.wchol->nlevels : 0; }
+int wchol_plan_launches(const Batch& b) { return b.wchol ? (int)b.wchol->launch_cls.size() : 0; }
+int wchol_plan_segments(const Batch& b) { return b.wchol ? b.wchol->nseg : 0; }
+
+int wchol_factor_and_forward(Batch& b) {
+  WPlan& P = *b.wchol;
+  const WView& C = P.C;
+  ScopedTimer t(b, "factor");
+  hipLaunchKernelGGL(k_wchol_begin, dim3((b.V.B + 63) / 64), dim3(64), 0, b.stream, b.V, C);
+  for (size_t l = 0; l < P.launch_cls.size(); ++l) {
+    const int n = P.launch_ptr[l + 1] - P.launch_ptr[l];
+    if (n <= 0) continue;
+    switch (P.launch_cls[l]) {
+      case 0: hipLaunchKernelGGL(k_wchol_factor<0>, dim3(n), dim3(kWClass[0].nt), 0, b.stream, C, (const LmState*)b.V.lm, P.launch_ptr[l]); break;
+      case 1: hipLaunchKernelGGL(k_wchol_factor<1>, dim3(n), dim3(kWClass[1].nt), 0, b.stream, C, (const LmState*)b.V.lm, P.launch_ptr[l]); break;
+      default: hipLaunchKernelGGL(k_wchol_factor<2>, dim3(n), dim3(kWClass[2].nt), 0, b.stream, C, (const LmState*)b.V.lm, P.launch_ptr[l]); break;
+    }
+  }
+  hipLaunchKernelGGL(k_wchol_end, dim3((b.V.B + 63) / 64), dim3(64), 0, b.stream, b.V, C);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return set_error(SSLAM_ERR_HIP, "window cholesky factor launch: %s", hipGetErrorString(e));
+  return 0;
+}
+
+int wchol_backward(Batch& b) {
+  WPlan& P = *b.wchol;
+  const WView& C = P.C;
+  ScopedTimer t(b, "solve");
+  for (int l = (int)P.launch_cls.size() - 1; l >= 0; --l) {
+    const int n = P.launch_ptr[l + 1] - P.launch_ptr[l];
+    if (n <= 0) continue;
+    switch (P.launch_cls[l]) {
+      case 0: hipLaunchKernelGGL(k_wchol_backward<0>, dim3(n), dim3(kWClass[0].nt), 0, b.stream, C, (const LmState*)b.V.lm, P.launch_ptr[l]); break;
+      case 1: hipLaunchKernelGGL(k_wchol_backward<1>, dim3(n), dim3(kWClass[1].nt), 0, b.stream, C, (const LmState*)b.V.lm, P.launch_ptr[l]); break;
+      default: hipLaunchKernelGGL(k_wchol_backward<2>, dim3(n), dim3(kWClass[2].nt), 0, b.stream, C, (const LmState*)b.V.lm, P.launch_ptr[l]); break;
+    }
+  }
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return set_error(SSLAM_ERR_HIP, "window cholesky solve launch: %s", hipGetErrorString(e));
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// CPU execution of the same phases (plan + kernel logic tests on a box without a GPU): (H + lambda I) x = b for every graph
+// ------------------------------------------------------------------------------------------------
+template <int CLS>
+static void wchol_emulate_segment(const WView& C, const WSeg sg, double lambda, bool backward) {
+  constexpr int W = kWClass[CLS].wmax, NT = kWClass[CLS].nt, S = kWClass[CLS].S;
+  static thread_local WShared<W>* sm = nullptr;
+  if (!sm) sm = new WShared<W>();
+  WCpuExec<S> ex(NT);
+  if (backward) wchol_backward_segment<W, NT, S>(ex, *sm, C, sg);
+  else wchol_factor_segment<W, NT, S>(ex, *sm, C, sg, lambda);
+}
+
+int wchol_emulate(const SymIn& in, const double* Hb, int64_t h_total, const double* lambda, double* x_out, int* fail_out, int64_t* stats /* [8] */) {
+  WOpts opt;
+  opt.from_env(in.B);
+  WHost H;
+  if (wchol_symbolic(in, opt, H)) return set_error(SSLAM_ERR_UNSUPPORTED, "window Cholesky plan: %s", H.error.c_str());
+  std::vector<double> L((size_t)H.lnz + 8, NAN), U((size_t)H.unz + 8, NAN), y((size_t)H.dim + 8, NAN), x((size_t)H.dim + 8, NAN);
+  std::vector<int> fail(std::max(in.B, 1), 0);
+  WView C{};
+  C.step = H.step.data(); C.row = H.row.data(); C.child = H.child.data(); C.fin = H.fin.data(); C.seg = H.seg.data(); C.wmap = H.wmap.data();
+  const int64_t h_even = (h_total + 1) & ~(int64_t)1;
+  C.H = Hb; C.bvec = Hb + h_even; C.Lval = L.data(); C.Uval = U.data(); C.y = y.data(); C.x = x.data(); C.fail = fail.data();
+  auto run = [&](size_t l, bool backward) {
+    for (int k = H.launch_ptr[l]; k < H.launch_ptr[l + 1]; ++k) {
+      const WSeg sg = H.seg[k];
+      switch (H.launch_cls[l]) {
+        case 0: wchol_emulate_segment<0>(C, sg, lambda[sg.graph], backward); break;
+        case 1: wchol_emulate_segment<1>(C, sg, lambda[sg.graph], backward); break;
+        default: wchol_emulate_segment<2>(C, sg, lambda[sg.graph], backward); break;
+      }
+    }
+  };
+  for (size_t l = 0; l < H.launch_cls.size(); ++l) run(l, false);
+  for (size_t l = H.launch_cls.size(); l-- > 0;) run(l, true);
+  for (int i = 0; i < H.dim; ++i) x_out[i] = x[i];
+  if (fail_out) for (int g = 0; g < in.B; ++g) fail_out[g] = fail[g];
+  if (stats) {
+    stats[0] = H.lnz; stats[1] = H.unz; stats[2] = (int64_t)H.seg.size(); stats[3] = (int64_t)H.launch_cls.size(); stats[4] = H.nlevels;
+    stats[5] = (int64_t)H.row.size(); stats[6] = H.ncol;
+    int64_t n2 = 0;
+    for (const WSeg& s : H.seg) n2 += s.cls >= 1;
+    stats[7] = n2;
+  }
+  return 0;
+}
+
+}  // namespace sslam
