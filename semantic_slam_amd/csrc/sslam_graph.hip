@@ -1655,8 +1655,11 @@ static int batch_solve(Batch& b) {
   // (H + lambda I) dx = b for every graph with in_trial set; result in V.x
   if (b.graphs[0]->opt.solver == 0 || b.graphs[0]->opt.solver == 2) return pcg_solve(b);
   int rc;
-  static const bool legacy = [] { const char* e = getenv("SSLAM_CHOL_LEGACY"); return e && atoi(e) != 0; }();
-  if (!legacy) {   // window multifrontal factorisation (sslam_wchol.hip)
+  // SSLAM_WCHOL=1 (or solver option 3): the window multifrontal factorisation (sslam_wchol.hip).  Correct and leaner in traffic, but at
+  // one 6-wide pivot per step its rank-6 window update is LDS-bandwidth bound (profiles/r3_pmc_wchol_v2_batch128.txt): 2.5x slower
+  // than the piece plan on the L batch, so the piece plan stays the default of the LM loop
+  static const bool wenv = [] { const char* e = getenv("SSLAM_WCHOL"); return e && atoi(e) != 0; }();
+  if (wenv || b.graphs[0]->opt.solver == 3) {
     if (!b.wchol && (rc = wchol_plan_build(b))) return rc;
     if ((rc = wchol_factor_and_forward(b))) return rc;
     return wchol_backward(b);
@@ -1867,7 +1870,7 @@ int sslam_graph_set_option(sslam_graph* h, const char* key, double value) {
   if (!h || !key) return set_error(SSLAM_ERR_INVALID, "null argument");
   Options& o = h->g.opt;
   const std::string k(key);
-  if (k == "solver") { if (value != 0 && value != 1 && value != 2) return set_error(SSLAM_ERR_INVALID, "solver: 0 block-Jacobi PCG, 1 sparse block Cholesky, 2 Schur complement on the landmarks + PCG"); o.solver = (int)value; }
+  if (k == "solver") { if (value != 0 && value != 1 && value != 2 && value != 3) return set_error(SSLAM_ERR_INVALID, "solver: 0 block-Jacobi PCG, 1 sparse block Cholesky (piece plan), 2 Schur complement on the landmarks + PCG, 3 sparse block Cholesky (window plan)"); o.solver = (int)value; }
   else if (k == "pcg_tol") o.pcg_tol = value;
   else if (k == "pcg_max_iters") o.pcg_max_iters = (int)value;
   else if (k == "deterministic") { if (value == 0) return set_error(SSLAM_ERR_UNSUPPORTED, "the Jacobian build is always deterministic (gather form); the FP64-atomics variant was removed"); }

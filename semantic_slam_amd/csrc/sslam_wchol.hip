@@ -33,17 +33,19 @@ struct WView {
 };
 
 constexpr int kWMaxCh = 4;   // child update matrices absorbed per pass
+constexpr int kWKS = 16;     // columns whose step / row records are staged in LDS at a time
 
 template <int W>
 struct WShared {
   double P[W][36];        // the pivot column: P[slot] = F(row in slot, pivot column), 6 x 6 row-major, zero padded
+  double Hs[W][36];       // factor: the H blocks of the NEXT pivot column, same orientation, staged one column ahead by the row threads
+                          // backward: the pivot column of L as stored (panel), staged one column ahead
   double rhs[W][6];       // the right-hand-side row of the window (factor) / x of the window's rows (backward)
   double part[W][6];      // backward: per row of the column, its contribution to the pivot's right-hand side
-  double yc[6];
+  double yc[6], bs[6];    // y of the pivot column; b of the next pivot column
   double Lc[21], linv[6]; // factor: L_cc (packed lower by rows) and its reciprocal pivots
-  double Ld[36];          // backward: the pivot's diagonal block
-  int hsrc[W], info[W];   // per slot, valid for the slots of the current column: H source; dim | fmt << 8
-  int rowslot[W], rlofs[W], rdim[W];   // per row of the current column
+  WStep stS[kWKS];        // step records of the staged columns
+  WRow stR[kWKS * W];     // their row records
   int ch_uoff[kWMaxCh], ch_m[kWMaxCh];
   unsigned char inv[kWMaxCh][W + 2];   // per child of the pass: window slot -> local row of the child's update matrix (0xFF none)
 };
@@ -52,6 +54,8 @@ template <int S>
 struct WThread {
   double acc[S][9];       // S tiles of the window, this lane's 3 x 3 quarter of each
   int ta[S], tb[S];       // window slots (a >= b) of the tiles; a >= W: no such tile
+  double hreg[6];         // prefetch: this thread's row of an H block (factor) / elements of the next L panel (backward, up to 6)
+  double breg;
 };
 
 #define SSLAM_HD __host__ __device__ __forceinline__
@@ -97,7 +101,11 @@ SSLAM_HD bool wchol6(const double* A, double* Lc /* 21 */, double* linv /* 6 */)
   for (int c = 0; c < 6; ++c) {
     double d = a[c * (c + 1) / 2 + c];
     if (!(d > 0)) { ok = false; d = 1.0; }
+#if defined(__HIP_DEVICE_COMPILE__)
+    const double id = rsqrt(d);
+#else
     const double id = 1.0 / sqrt(d);
+#endif
     linv[c] = id;
     a[c * (c + 1) / 2 + c] = d * id;
 #pragma unroll
@@ -114,7 +122,41 @@ SSLAM_HD bool wchol6(const double* A, double* Lc /* 21 */, double* linv /* 6 */)
 
 // ------------------------------------------------------------------------------------------------
 // factorisation of one segment.  Ex: executor (phase runner); W / NT / S: window slots, threads, tile registers per thread
+// Per column the critical path touches no HBM load: the step / row records of kWKS columns at a time are staged in LDS, and the H
+// blocks and b of column s + 1 are fetched by the row threads while column s is being eliminated.
 // ------------------------------------------------------------------------------------------------
+// row thread t = (row of the column, scalar row of the block): fetch its row of the H block of column `sn` (P orientation) and b
+template <int W, int S>
+SSLAM_HD void wchol_prefetch(int tid, WThread<S>& ts, const WShared<W>& sm, const WView& C, int sn /* index in the staged chunk */, int rbase) {
+  const WStep st = sm.stS[sn];
+  const int dj = (st.piv >> 8) & 255, nr = st.piv >> 16;
+  const int ri = tid / 6, r = tid - 6 * ri;
+#pragma unroll
+  for (int q = 0; q < 6; ++q) ts.hreg[q] = 0.0;
+  ts.breg = 0.0;
+  if (ri >= nr) return;
+  const WRow wr = sm.stR[st.row0 - rbase + ri];
+  const int di = (wr.slot >> 8) & 255, fmt = (wr.slot >> 16) & 1;
+  if (wr.hsrc >= 0 && r < di) {
+    const double* Hb = C.H + wr.hsrc;
+#pragma unroll
+    for (int q = 0; q < 6; ++q) if (q < dj) ts.hreg[q] = fmt ? Hb[q * di + r] : Hb[r * dj + q];
+  }
+  if (ri == 0 && r < dj) ts.breg = C.bvec[st.xoff + r];
+}
+// ... and park what was fetched for column `sn` in LDS (Hs, bs) before that column starts
+template <int W, int S>
+SSLAM_HD void wchol_stage(int tid, WThread<S>& ts, WShared<W>& sm, int sn, int rbase) {
+  const WStep st = sm.stS[sn];
+  const int nr = st.piv >> 16;
+  const int ri = tid / 6, r = tid - 6 * ri;
+  if (ri >= nr) return;
+  const int slot = sm.stR[st.row0 - rbase + ri].slot & 255;
+#pragma unroll
+  for (int q = 0; q < 6; ++q) sm.Hs[slot][r * 6 + q] = ts.hreg[q];
+  if (ri == 0) sm.bs[r] = ts.breg;
+}
+
 template <int W, int NT, int S, class Ex>
 SSLAM_HD void wchol_factor_segment(Ex& ex, WShared<W>& sm, const WView& C, const WSeg sg, const double lambda) {
   // ---- start: empty window
@@ -127,8 +169,25 @@ SSLAM_HD void wchol_factor_segment(Ex& ex, WShared<W>& sm, const WView& C, const
     }
     for (int t = tid; t < W * 6; t += NT) sm.rhs[t / 6][t % 6] = 0.0;
   });
+  int rbase = 0;   // first row record of the staged chunk
   for (int s = 0; s < sg.nsteps; ++s) {
-    const WStep st = C.step[sg.step0 + s];
+    const int sn = s % kWKS;
+    if (sn == 0) {
+      // ---- the records of the next kWKS columns -> LDS (one round trip), then this column's H blocks (exposed once per chunk)
+      const int nst = sg.nsteps - s < kWKS ? sg.nsteps - s : kWKS;
+      rbase = C.step[sg.step0 + s].row0;
+      const int rend = C.step[sg.step0 + s + nst - 1].row0 + (C.step[sg.step0 + s + nst - 1].piv >> 16);
+      ex.phase([&](int tid, WThread<S>& ts) {
+        for (int t = tid; t < nst; t += NT) sm.stS[t] = C.step[sg.step0 + s + t];
+        for (int t = tid; t < rend - rbase; t += NT) sm.stR[t] = C.row[rbase + t];
+      });
+      ex.phase([&](int tid, WThread<S>& ts) {
+        wchol_prefetch<W, S>(tid, ts, sm, C, 0, rbase);
+        wchol_stage<W, S>(tid, ts, sm, 0, rbase);
+        if (nst > 1) wchol_prefetch<W, S>(tid, ts, sm, C, 1, rbase);
+      });
+    }
+    const WStep st = sm.stS[sn];
     const int c = st.piv & 255, dj = (st.piv >> 8) & 255, nr = st.piv >> 16;
     const unsigned long long mask = (unsigned long long)st.mask_lo | ((unsigned long long)st.mask_hi << 32);
     // ---- update matrices of child segments that join at this column, kWMaxCh per pass
@@ -182,17 +241,7 @@ SSLAM_HD void wchol_factor_segment(Ex& ex, WShared<W>& sm, const WView& C, const
         }
       });
     }
-    // ---- 0. the rows of the column: slot tables; b of the pivot
-    ex.phase([&](int tid, WThread<S>& ts) {
-      for (int ri = tid; ri < nr; ri += NT) {
-        const WRow wr = C.row[st.row0 + ri];
-        const int slot = wr.slot & 255, di = (wr.slot >> 8) & 255, fmt = (wr.slot >> 16) & 1;
-        sm.hsrc[slot] = wr.hsrc; sm.info[slot] = di | (fmt << 8);
-        sm.rowslot[ri] = slot; sm.rlofs[ri] = wr.lofs; sm.rdim[ri] = di;
-      }
-      if (tid < dj) sm.rhs[c][tid] += C.bvec[st.xoff + tid];
-    });
-    // ---- A. H blocks of the column into the pivot cross of the window; the cross leaves the registers for the LDS panel
+    // ---- A. the pivot cross of the window leaves the registers for the LDS panel, the column's H blocks (staged) join it there
     ex.phase([&](int tid, WThread<S>& ts) {
       int tq = tid; SSLAM_OPAQUE(tq); const int tr = (tq >> 1) & 1, tc = tq & 1;
 #pragma unroll
@@ -208,22 +257,12 @@ SSLAM_HD void wchol_factor_segment(Ex& ex, WShared<W>& sm, const WView& C, const
         // this lane's quarter of the panel block P[other] = F(row of `other`, pivot): the tile itself when its column slot is the
         // pivot, its transpose when its row slot is
         const int ptr = inb ? tr : tc, ptc = inb ? tc : tr;
+        const double* hq = &sm.Hs[other][(3 * ptr) * 6 + 3 * ptc];
         double v[9];
 #pragma unroll
         for (int rr = 0; rr < 3; ++rr)
 #pragma unroll
-          for (int cc = 0; cc < 3; ++cc) v[rr * 3 + cc] = inb ? ts.acc[k][rr * 3 + cc] : ts.acc[k][cc * 3 + rr];
-        const int inf = sm.info[other], di = inf & 255, fmt = (inf >> 8) & 1, hs = sm.hsrc[other];
-        if (hs >= 0 && 3 * ptr < di && 3 * ptc < dj) {
-          const double* Hb = C.H + hs;
-#pragma unroll
-          for (int rr = 0; rr < 3; ++rr)
-#pragma unroll
-            for (int cc = 0; cc < 3; ++cc) {
-              const int r = 3 * ptr + rr, q = 3 * ptc + cc;
-              v[rr * 3 + cc] += fmt ? Hb[q * di + r] : Hb[r * dj + q];
-            }
-        }
+          for (int cc = 0; cc < 3; ++cc) v[rr * 3 + cc] = (inb ? ts.acc[k][rr * 3 + cc] : ts.acc[k][cc * 3 + rr]) + hq[rr * 6 + cc];
         if (other == c && ptr == ptc) {             // damping; the padding of a 3-wide pivot becomes an identity block
 #pragma unroll
           for (int rr = 0; rr < 3; ++rr) { if (3 * ptr + rr < dj) v[rr * 4] += lambda; else v[rr * 4] = 1.0; }
@@ -242,7 +281,7 @@ SSLAM_HD void wchol_factor_segment(Ex& ex, WShared<W>& sm, const WView& C, const
       double y[6];
 #pragma unroll
       for (int r = 0; r < 6; ++r) {
-        double w = sm.rhs[c][r];
+        double w = sm.rhs[c][r] + sm.bs[r];
 #pragma unroll
         for (int q = 0; q < r; ++q) w -= sm.Lc[r * (r + 1) / 2 + q] * y[q];
         y[r] = w * sm.linv[r];
@@ -252,29 +291,30 @@ SSLAM_HD void wchol_factor_segment(Ex& ex, WShared<W>& sm, const WView& C, const
     });
     // ---- B2. one thread per row of the panel: x L_cc^T = v (L_cc streamed from LDS); the factor leaves for HBM
     ex.phase([&](int tid, WThread<S>& ts) {
-      for (int t = tid; t < 6 * nr; t += NT) {
-        const int ri = t / 6, r = t - 6 * ri;
-        const int slot = sm.rowslot[ri], di = sm.rdim[ri];
-        if (r >= di) continue;
-        double* out = C.Lval + st.loff + sm.rlofs[ri] + r * dj;
-        if (ri == 0) {                              // the pivot's own rows: row r of L_cc
-          for (int q = 0; q < dj; ++q) out[q] = q <= r ? sm.Lc[r * (r + 1) / 2 + q] : 0.0;
-          continue;
-        }
-        double* v = &sm.P[slot][r * 6];
-        double xr[6];
-#pragma unroll
-        for (int q = 0; q < 6; ++q) {
-          double w = v[q];
-#pragma unroll
-          for (int q2 = 0; q2 < q; ++q2) w -= xr[q2] * sm.Lc[q * (q + 1) / 2 + q2];
-          xr[q] = w * sm.linv[q];
-        }
-#pragma unroll
-        for (int q = 0; q < 6; ++q) { v[q] = xr[q]; if (q < dj) out[q] = xr[q]; }
+      const int ri = tid / 6, r = tid - 6 * ri;
+      if (ri >= nr) return;
+      const WRow wr = sm.stR[st.row0 - rbase + ri];
+      const int slot = wr.slot & 255, di = (wr.slot >> 8) & 255;
+      if (r >= di) return;
+      double* out = C.Lval + st.loff + wr.lofs + r * dj;
+      if (ri == 0) {                              // the pivot's own rows: row r of L_cc
+        for (int q = 0; q < dj; ++q) out[q] = q <= r ? sm.Lc[r * (r + 1) / 2 + q] : 0.0;
+        return;
       }
+      double* v = &sm.P[slot][r * 6];
+      double xr[6];
+#pragma unroll
+      for (int q = 0; q < 6; ++q) {
+        double w = v[q];
+#pragma unroll
+        for (int q2 = 0; q2 < q; ++q2) w -= xr[q2] * sm.Lc[q * (q + 1) / 2 + q2];
+        xr[q] = w * sm.linv[q];
+      }
+#pragma unroll
+      for (int q = 0; q < 6; ++q) { v[q] = xr[q]; if (q < dj) out[q] = xr[q]; }
     });
-    // ---- C. window(a, b) -= L(a, c) L(b, c)^T for the rows a, b of the column; right-hand-side row; the pivot's slot is free again
+    // ---- C. window(a, b) -= L(a, c) L(b, c)^T for the rows a, b of the column; right-hand-side row; the pivot's slot is free again.
+    //         Then the next column's H blocks (fetched one column ago) are parked in LDS and the fetch of the one after is issued.
     ex.phase([&](int tid, WThread<S>& ts) {
       int tq = tid; SSLAM_OPAQUE(tq); const int tr = (tq >> 1) & 1, tc = tq & 1;
 #pragma unroll
@@ -302,14 +342,22 @@ SSLAM_HD void wchol_factor_segment(Ex& ex, WShared<W>& sm, const WView& C, const
           }
         }
       }
-      for (int t = tid; t < 6 * nr; t += NT) {
-        const int ri = t / 6, r = t - 6 * ri;
-        const int slot = sm.rowslot[ri];
-        if (ri == 0) { sm.rhs[slot][r] = 0.0; continue; }
-        double w = sm.rhs[slot][r];
+      {
+        const int ri = tid / 6, r = tid - 6 * ri;
+        if (ri < nr) {
+          const int slot = sm.stR[st.row0 - rbase + ri].slot & 255;
+          if (ri == 0) sm.rhs[slot][r] = 0.0;
+          else {
+            double w = sm.rhs[slot][r];
 #pragma unroll
-        for (int q = 0; q < 6; ++q) w -= sm.P[slot][r * 6 + q] * sm.yc[q];
-        sm.rhs[slot][r] = w;
+            for (int q = 0; q < 6; ++q) w -= sm.P[slot][r * 6 + q] * sm.yc[q];
+            sm.rhs[slot][r] = w;
+          }
+        }
+      }
+      if (s + 1 < sg.nsteps && sn + 1 < kWKS) {
+        wchol_stage<W, S>(tid, ts, sm, sn + 1, rbase);
+        if (s + 2 < sg.nsteps && sn + 2 < kWKS) wchol_prefetch<W, S>(tid, ts, sm, C, sn + 2, rbase);
       }
     });
   }
@@ -342,10 +390,27 @@ SSLAM_HD void wchol_factor_segment(Ex& ex, WShared<W>& sm, const WView& C, const
 }
 
 // ------------------------------------------------------------------------------------------------
-// backward substitution of one segment: x_c = L_cc^-T (y_c - sum_i L_ic^T x_i), columns in reverse order
+// backward substitution of one segment: x_c = L_cc^-T (y_c - sum_i L_ic^T x_i), columns in reverse order.  Same staging: the
+// records of kWKS columns at a time in LDS, the panel of column s - 1 fetched while column s is solved.
 // ------------------------------------------------------------------------------------------------
+template <int W, int NT, int S>
+SSLAM_HD void wback_prefetch(int tid, WThread<S>& ts, const WView& C, const WStep st, int lsz) {
+  const double* Lp = C.Lval + st.loff;
+#pragma unroll
+  for (int k = 0; k < 6; ++k) { const int e = tid + k * NT; ts.hreg[k] = e < lsz ? Lp[e] : 0.0; }
+  ts.breg = tid < 6 && tid < ((st.piv >> 8) & 255) ? C.y[st.xoff + tid] : 0.0;
+}
+template <int W, int NT, int S>
+SSLAM_HD void wback_stage(int tid, WThread<S>& ts, WShared<W>& sm, int lsz) {
+  double* Lp = &sm.Hs[0][0];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) { const int e = tid + k * NT; if (e < lsz) Lp[e] = ts.hreg[k]; }
+  if (tid < 6) sm.yc[tid] = ts.breg;
+}
+
 template <int W, int NT, int S, class Ex>
 SSLAM_HD void wchol_backward_segment(Ex& ex, WShared<W>& sm, const WView& C, const WSeg sg) {
+  static_assert(6 * NT >= W * 36, "a panel is fetched with at most six elements per thread");
   // the rows above the segment (its update-matrix rows) are final: their x comes from HBM
   ex.phase([&](int tid, WThread<S>& ts) {
     for (int t = tid; t < sg.m * 6; t += NT) {
@@ -355,61 +420,98 @@ SSLAM_HD void wchol_backward_segment(Ex& ex, WShared<W>& sm, const WView& C, con
       sm.rhs[slot][r] = r < d ? C.x[f.xoff + r] : 0.0;
     }
   });
+  int rbase = 0, s0 = 0;   // first row record / first column of the staged chunk
+  auto panel_doubles = [&](const WStep& st) {   // rows of the panel x width of the column (the row records are staged)
+    const WRow last = sm.stR[st.row0 - rbase + (st.piv >> 16) - 1];
+    return last.lofs + ((last.slot >> 8) & 255) * ((st.piv >> 8) & 255);
+  };
   for (int s = sg.nsteps - 1; s >= 0; --s) {
-    const WStep st = C.step[sg.step0 + s];
+    if (s == sg.nsteps - 1 || s < s0) {
+      // ---- the records of the previous kWKS columns -> LDS, then this column's panel (exposed once per chunk)
+      s0 = s + 1 - kWKS > 0 ? s + 1 - kWKS : 0;
+      const int nst = s + 1 - s0;
+      rbase = C.step[sg.step0 + s0].row0;
+      const int rend = C.step[sg.step0 + s].row0 + (C.step[sg.step0 + s].piv >> 16);
+      ex.phase([&](int tid, WThread<S>& ts) {
+        for (int t = tid; t < nst; t += NT) sm.stS[t] = C.step[sg.step0 + s0 + t];
+        for (int t = tid; t < rend - rbase; t += NT) sm.stR[t] = C.row[rbase + t];
+      });
+      ex.phase([&](int tid, WThread<S>& ts) {
+        const WStep st = sm.stS[s - s0];
+        const int lsz = panel_doubles(st);
+        wback_prefetch<W, NT, S>(tid, ts, C, st, lsz);
+        wback_stage<W, NT, S>(tid, ts, sm, lsz);
+        if (s - 1 >= s0) { const WStep sp = sm.stS[s - 1 - s0]; wback_prefetch<W, NT, S>(tid, ts, C, sp, panel_doubles(sp)); }
+      });
+    }
+    const WStep st = sm.stS[s - s0];
     const int c = st.piv & 255, dj = (st.piv >> 8) & 255, nr = st.piv >> 16;
-    ex.phase([&](int tid, WThread<S>& ts) {
-      for (int ri = tid; ri < nr; ri += NT) {
-        const WRow wr = C.row[st.row0 + ri];
-        sm.rowslot[ri] = wr.slot & 255; sm.rlofs[ri] = wr.lofs; sm.rdim[ri] = (wr.slot >> 8) & 255;
-      }
-      for (int e = tid; e < dj * dj; e += NT) sm.Ld[e] = C.Lval[st.loff + e];
-      if (tid < 6) sm.yc[tid] = tid < dj ? C.y[st.xoff + tid] : 0.0;
-    });
+    // ---- every row of the column: its block's contribution L_ic^T x_i, one thread per (row, component of the pivot)
     ex.phase([&](int tid, WThread<S>& ts) {
       for (int t = tid; t < 6 * (nr - 1); t += NT) {
         const int ri = 1 + t / 6, q = t % 6;
         double w = 0.0;
         if (q < dj) {
-          const int slot = sm.rowslot[ri], di = sm.rdim[ri];
-          const double* Lb = C.Lval + st.loff + sm.rlofs[ri] + q;
+          const WRow wr = sm.stR[st.row0 - rbase + ri];
+          const int slot = wr.slot & 255, di = (wr.slot >> 8) & 255;
+          const double* Lb = &sm.Hs[0][0] + wr.lofs + q;
           for (int r = 0; r < di; ++r) w += Lb[r * dj] * sm.rhs[slot][r];
         }
         sm.part[ri][q] = w;
       }
     });
+    // ---- the pivot: t = y_c - sum of the contributions, x_c = L_cc^-T t
     ex.phase([&](int tid, WThread<S>& ts) {
       if (tid != 0) return;
+      const double* Ld = &sm.Hs[0][0];
       double t[6], x[6];
 #pragma unroll
       for (int q = 0; q < 6; ++q) {
         double w = sm.yc[q];
         for (int ri = 1; ri < nr; ++ri) w -= sm.part[ri][q];
-        t[q] = w;
+        t[q] = w; x[q] = 0.0;
       }
-      for (int r = dj - 1; r >= 0; --r) {
-        double w = t[r];
-        for (int s2 = dj - 1; s2 > r; --s2) w -= sm.Ld[s2 * dj + r] * x[s2];
-        x[r] = w / sm.Ld[r * dj + r];
+#pragma unroll
+      for (int r = 5; r >= 0; --r) {
+        if (r < dj) {
+          double w = t[r];
+#pragma unroll
+          for (int s2 = 5; s2 > r; --s2) if (s2 < dj) w -= Ld[s2 * dj + r] * x[s2];
+          x[r] = w / Ld[r * dj + r];
+        }
       }
+#pragma unroll
       for (int r = 0; r < 6; ++r) {
         sm.rhs[c][r] = r < dj ? x[r] : 0.0;
         if (r < dj) C.x[st.xoff + r] = x[r];
       }
     });
+    // ---- the next column's panel (fetched while this one was solved) -> LDS; fetch of the one after
+    if (s - 1 >= s0) {
+      ex.phase([&](int tid, WThread<S>& ts) {
+        const WStep sp = sm.stS[s - 1 - s0];
+        wback_stage<W, NT, S>(tid, ts, sm, panel_doubles(sp));
+        if (s - 2 >= s0) { const WStep sq = sm.stS[s - 2 - s0]; wback_prefetch<W, NT, S>(tid, ts, C, sq, panel_doubles(sq)); }
+      });
+    }
   }
 }
 
 // ------------------------------------------------------------------------------------------------
 // executors
 // ------------------------------------------------------------------------------------------------
-template <int S>
+// Phase boundary on the GPU.  __syncthreads() is a workgroup-scope fence on ALL address spaces: the compiler drains every outstanding
+// global load and store (s_waitcnt vmcnt(0)) in front of each barrier, i.e. every phase would wait for the L stores of the previous one
+// and for the H prefetch that is meant to fly across the whole column.  The phases only communicate through LDS: one wave needs no
+// barrier at all (its LDS operations execute in order), several waves need their LDS operations retired + s_barrier.
+template <int S, int NT>
 struct WGpuExec {
   WThread<S> ts;
   template <class F>
   __device__ __forceinline__ void phase(F&& f) {
     f((int)threadIdx.x, ts);
-    __syncthreads();
+    if (NT <= 64) asm volatile("" ::: "memory");
+    else asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
   }
 };
 template <int S>
@@ -429,7 +531,7 @@ __global__ __launch_bounds__(kWClass[CLS].nt, kWWaves[CLS]) void k_wchol_factor(
   __shared__ WShared<W> sm;
   const WSeg sg = C.seg[seg0 + blockIdx.x];
   if (!lm[sg.graph].in_trial) return;
-  WGpuExec<S> ex;
+  WGpuExec<S, NT> ex;
   wchol_factor_segment<W, NT, S>(ex, sm, C, sg, lm[sg.graph].lambda);
 }
 template <int CLS>
@@ -438,7 +540,7 @@ __global__ __launch_bounds__(kWClass[CLS].nt) void k_wchol_backward(WView C, con
   __shared__ WShared<W> sm;
   const WSeg sg = C.seg[seg0 + blockIdx.x];
   if (lm && !lm[sg.graph].in_trial) return;
-  WGpuExec<S> ex;
+  WGpuExec<S, NT> ex;
   wchol_backward_segment<W, NT, S>(ex, sm, C, sg);
 }
 __global__ void k_wchol_begin(BatchView V, WView C) {   // clear the failure flags of the graphs being solved
