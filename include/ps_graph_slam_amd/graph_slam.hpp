@@ -157,6 +157,10 @@ class GraphSLAM {
     return {check(sslam_graph_add_edge_se3_plane(graph.get(), v_se3->id(), v_plane->id(), plane_coeffs.data(), information_matrix))};
   }
 
+  /** The robust kernel graph_slam.cpp:155,161 means to install on the landmark edges (g2o::RobustKernelDCS; the reference passes an
+   *  uninitialised pointer, so the default here is "none").  phi > 0 switches it on for every landmark edge, 0 off. */
+  void setRobustKernelDCS(double phi = 1.0) { check(sslam_graph_set_option(graph.get(), "robust_kernel_dcs", phi)); }
+
   /** perform graph optimization (graph_slam.cpp:182-219): false iff the graph has fewer than 10 edges */
   bool optimize(int max_iterations = 1024) {
     sslam_opt_stats st;

@@ -74,7 +74,8 @@ int sslam_graph_add_vertex_plane(sslam_graph* g, const double n_d[4]);
 /* add_se3_edge (graph_slam.cpp:136-148): g2o::EdgeSE3 between SE3 vertices i and j. Returns edge id. */
 int sslam_graph_add_edge_se3(sslam_graph* g, int i, int j, const double z_tq[7], const double info[36]);
 /* add_se3_point_xyz_edge (graph_slam.cpp:150-166): g2o::EdgeSE3PointXYZ, offset parameter 0.
- * The reference passes an uninitialised robust-kernel pointer (quirk B1); no kernel is applied. */
+ * The reference passes an uninitialised robust-kernel pointer (quirk B1): no kernel is applied unless the option
+ * "robust_kernel_dcs" asks for the one it names (g2o::RobustKernelDCS). */
 int sslam_graph_add_edge_se3_point(sslam_graph* g, int i, int l, const double z[3], const double info[9]);
 /* add_se3_plane_edge (commented out, graph_slam.hpp:73-75) -> g2o::EdgeSE3Plane
  * (reference include/g2o/edge_se3_plane.hpp:8-48; numeric Jacobian). */
@@ -92,7 +93,10 @@ int sslam_graph_hessian_index(sslam_graph* g, int id);
 
 /* Options (doubles): "solver" 1 = sparse block Cholesky (default; what "lm_var" + csparse selects in the reference),
  * 0 = block-Jacobi PCG on the full system, 2 = Schur complement on the landmark block + PCG on the reduced pose system (matrix-free;
- * BASELINE.json north_star); "pcg_tol" relative residual; "pcg_max_iters" */
+ * BASELINE.json north_star), 3 = sparse block Cholesky with the window plan (csrc/wchol_plan.hpp: register-resident sliding fronts;
+ * correct, leaner in traffic, slower than 1 on today's kernels); "pcg_tol" relative residual; "pcg_max_iters";
+ * "robust_kernel_dcs" = phi > 0: g2o::RobustKernelDCS(delta = phi) on every landmark edge (EdgeSE3PointXYZ / EdgeSE3Plane), as
+ * graph_slam.cpp:155,161 intends (opt-in, phi = 1 is g2o's default delta); 0 = no kernel (default). */
 int sslam_graph_set_option(sslam_graph* g, const char* key, double value);
 
 /* GraphSLAM::optimize (graph_slam.cpp:182-219) with the iteration cap as a parameter (the

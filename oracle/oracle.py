@@ -45,6 +45,13 @@ class OgStats(C.Structure):
                 ("seconds_linearize", C.c_double), ("seconds_solve", C.c_double), ("status", C.c_int)]
 
 
+def set_dcs(phi: float) -> None:
+    """g2o::RobustKernelDCS(delta = phi) on the landmark edges of every problem evaluated from now on (0 = no kernel, the default)"""
+    f = lib().og_set_dcs
+    f.argtypes = [C.c_double]; f.restype = None
+    f(float(phi))
+
+
 class GraphProblem:
     """Flat arrays describing a graph in the oracle's layout (vertex ids = array index)."""
 

@@ -218,6 +218,17 @@ static void plane_edge(const double *Xi, const double *pw, const double *z, doub
   }
 }
 
+/* g2o::RobustKernelDCS on the landmark edges (the reference installs an UNINITIALISED kernel pointer at
+ * graph_slam.cpp:155,161; "no kernel" is the default, DCS with delta = phi the opt-in).  robustify(e2): scale = 2 phi / (phi + e2);
+ * scale >= 1: rho = (e2, 1); else rho = (scale^2 e2, scale^2).  chi2 uses rho[0], the quadratic form scales Omega by rho[1]. */
+static double g_dcs_phi = 0.0;
+void og_set_dcs(double phi) { g_dcs_phi = phi; }
+static double dcs_rho1(double e2) {
+  if (!(g_dcs_phi > 0)) return 1.0;
+  const double scale = (2.0 * g_dcs_phi) / (g_dcs_phi + e2);
+  return scale >= 1.0 ? 1.0 : scale * scale;
+}
+
 static int vdim(int t) { return t == VT_SE3 ? 6 : 3; }
 static int edim(int t) { return t == ET_SE3 ? 6 : 3; }
 
@@ -243,6 +254,7 @@ static double edge_chi2(const og_problem *P, const double *est, int k) {
     for (int s = 0; s < d; ++s) a += W[r * d + s] * e[s];
     c += e[r] * a;
   }
+  if (P->etype[k] != ET_SE3) c *= dcs_rho1(c);   /* rho[0] = rho[1] * e2 in both branches */
   return c;
 }
 
@@ -389,7 +401,17 @@ static void sys_build(const og_problem *P, const int *hidx, og_system *S) {
     int oi = hidx[vi], oj = hidx[vj];
     int di = vdim(P->vtype[vi]), dj = vdim(P->vtype[vj]);
     int d = edim(P->etype[k]);
-    const double *W = P->info + 36 * (size_t)k;
+    const double *W0 = P->info + 36 * (size_t)k;
+    double W[36];
+    {
+      double rho1 = 1.0;
+      if (P->etype[k] != ET_SE3 && g_dcs_phi > 0) {
+        double e2 = 0;
+        for (int r = 0; r < d; ++r) { double a = 0; for (int s = 0; s < d; ++s) a += W0[r * d + s] * e[s]; e2 += e[r] * a; }
+        rho1 = dcs_rho1(e2);
+      }
+      for (int q = 0; q < d * d; ++q) W[q] = rho1 * W0[q];
+    }
     for (int r = 0; r < d; ++r) {
       for (int c = 0; c < di; ++c) { double a = 0; for (int s = 0; s < d; ++s) a += W[r * d + s] * Ji[s * di + c]; WJi[r * di + c] = a; }
       for (int c = 0; c < dj; ++c) { double a = 0; for (int s = 0; s < d; ++s) a += W[r * d + s] * Jj[s * dj + c]; WJj[r * dj + c] = a; }

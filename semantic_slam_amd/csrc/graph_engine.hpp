@@ -165,6 +165,7 @@ int chol_plan_build(Batch& b);
 int chol_plan_launches(const Batch& b);
 int chol_factor_and_forward(Batch& b, bool flat = false);   // (H + lambda I) = L L^T for in_trial graphs, y = L^-1 b
 int chol_backward(Batch& b);             // x = L^-T y  -> V.x
+int chol_set_active(Batch& b, const std::vector<char>* active);   // LM endgame: size the launches for the graphs still active (nullptr: all)
 int64_t chol_plan_lnz(const Batch& b);
 int chol_plan_levels(const Batch& b);
 int chol_solve_multi(Batch& b, const double* rhs_host, int nrhs, double* x_host);  // uses the last factorisation

@@ -15,6 +15,7 @@ struct Options {
   int solver = 1;            // 0 PCG, 1 sparse block Cholesky
   double pcg_tol = 1e-10;    // relative residual ||r|| / ||b||
   int pcg_max_iters = 20000;
+  double dcs_phi = 0.0;      // > 0: g2o::RobustKernelDCS(delta = phi) on the landmark edges (quirk B1: off by default)
 };
 
 struct HostGraph {

@@ -73,6 +73,7 @@ struct BatchView {
   const int* eo_id; const int* el_id;        // graph-local edge id of every SE3 / landmark edge
   const int* shard_lo; const int* shard_hi;  // [B]
   int dbg = 0;                               // SSLAM_LIN_DBG: timing experiments only (results are wrong when set)
+  double dcs_phi = 0.0;                      // > 0: RobustKernelDCS on the landmark edges (chi2 uses rho[0], Omega is scaled by rho[1])
   // PCG vectors
   double* x; double* r; double* z; double* p; double* q; double* Minv;  // Minv: [nPr*36 | nLr*9]
   double* part_a; double* part_b; double* part_c;  // [B*maxChunks] partial sums
@@ -82,6 +83,18 @@ struct BatchView {
   int* pcg_fail;    // [B]
   int* flags;       // [0] any_in_trial, [1] all_pcg_done
 };
+
+// g2o::RobustKernelDCS::robustify: rho[1], the factor on Omega; rho[0] = rho[1] * e2
+__device__ __forceinline__ double dcs_rho1(double phi, double e2) {
+  const double scale = (2.0 * phi) / (phi + e2);
+  return scale >= 1.0 ? 1.0 : scale * scale;
+}
+__device__ __forceinline__ double quad3(const double W[9], const double e[3]) {
+  double c = 0;
+#pragma unroll
+  for (int r = 0; r < 3; ++r) c += e[r] * (W[r * 3 + 0] * e[0] + W[r * 3 + 1] * e[1] + W[r * 3 + 2] * e[2]);
+  return c;
+}
 
 // ------------------------------------------------------------------------------------------
 // deterministic workgroup reduction: wave shuffles, then a fixed-order sum of the wave partials

@@ -59,6 +59,12 @@ struct CholPlan {
   std::vector<void*> allocs;
   DevArena* arena = nullptr;    // the owning batch's arena (single-graph handles), else hipMalloc
   int64_t lnz = 0, unz = 0;
+  // active-graph compaction (LM endgame: a retry by a handful of graphs must not dispatch the pieces of all of them)
+  std::vector<int> lp_graph;    // graph of every launch-order piece record
+  std::vector<int> c_ptr;       // per launch: first entry of its compact index list in d_idx; back() = first tail entry; then the end
+  int* d_idx = nullptr;         // [pieces of the active graphs, launch by launch | active graphs that have a tail]
+  size_t idx_cap = 0;
+  bool compact = false;
   double* d_multi_y = nullptr;  // scratch for multi-rhs solves
   double* d_multi_x = nullptr;
   int multi_cap = 0;
@@ -82,6 +88,7 @@ void chol_plan_free(CholPlan* p) {
     }
   }
   for (void* a : p->allocs) (void)hipFree(a);
+  if (p->d_idx) (void)hipFree(p->d_idx);
   if (p->d_multi_y) (void)hipFree(p->d_multi_y);
   if (p->d_multi_x) (void)hipFree(p->d_multi_x);
   delete p;
@@ -592,9 +599,9 @@ __device__ __forceinline__ void chol_piece(const BatchView& V, const CholView& C
 #undef SSLAM_STAMP
 
 template <int NT, bool USTAGE>
-__global__ __launch_bounds__(NT, 4) void k_chol_pieces(BatchView V, CholView C, int begin) {   // <= 128 VGPRs: four waves per SIMD
+__global__ __launch_bounds__(NT, 4) void k_chol_pieces(BatchView V, CholView C, int begin, const int* __restrict__ idx) {   // <= 128 VGPRs: four waves per SIMD
   extern __shared__ double sm[];
-  const PieceMeta pm = C.lpiece[begin + blockIdx.x];
+  const PieceMeta pm = C.lpiece[idx ? idx[blockIdx.x] : begin + blockIdx.x];   // idx: the pieces of the graphs that are still active
   if (!V.lm[pm.graph].in_trial) return;
   chol_piece<NT, USTAGE>(V, C, pm, sm, (C.dbg && blockIdx.x == 0) ? C.dbg + 16 : nullptr);
 }
@@ -603,9 +610,9 @@ __global__ __launch_bounds__(NT, 4) void k_chol_pieces(BatchView V, CholView C, 
 // latency.  One workgroup per graph walks its remaining pieces in elimination order; the barrier between pieces orders
 // the L / y stores of one piece before the loads of the next (same CU).
 template <int NT>
-__global__ __launch_bounds__(NT) void k_chol_tail(BatchView V, CholView C) {
+__global__ __launch_bounds__(NT) void k_chol_tail(BatchView V, CholView C, const int* __restrict__ idx) {
   extern __shared__ double sm[];
-  const int g = blockIdx.x;
+  const int g = idx ? idx[blockIdx.x] : blockIdx.x;
   if (!V.lm[g].in_trial) return;
   const int q1 = C.tail_ptr[g + 1];
   for (int q = C.tail_ptr[g]; q < q1; ++q) {
@@ -799,16 +806,16 @@ __device__ __forceinline__ void chol_piece_backward(const CholView& C, const Pie
 #undef SSLAM_BSTAMP
 
 template <int NT>
-__global__ __launch_bounds__(NT, NT == 64 ? 8 : 1) void k_chol_back_pieces(CholView C, int begin, const double* __restrict__ y, double* x, const LmState* __restrict__ lm) {
+__global__ __launch_bounds__(NT, NT == 64 ? 8 : 1) void k_chol_back_pieces(CholView C, int begin, const double* __restrict__ y, double* x, const LmState* __restrict__ lm, const int* __restrict__ idx) {
   extern __shared__ double sm[];
-  const PieceMeta pm = C.lpiece[begin + blockIdx.x];
+  const PieceMeta pm = C.lpiece[idx ? idx[blockIdx.x] : begin + blockIdx.x];
   if (lm && !lm[pm.graph].in_trial) return;
   chol_piece_backward<NT>(C, pm, y, x, sm, (C.dbg && blockIdx.x == 0) ? C.dbg + 40 : nullptr);
 }
 template <int NT>
-__global__ __launch_bounds__(NT) void k_chol_back_tail(CholView C, const double* __restrict__ y, double* x, const LmState* __restrict__ lm) {
+__global__ __launch_bounds__(NT) void k_chol_back_tail(CholView C, const double* __restrict__ y, double* x, const LmState* __restrict__ lm, const int* __restrict__ idx) {
   extern __shared__ double sm[];
-  const int g = blockIdx.x;
+  const int g = idx ? idx[blockIdx.x] : blockIdx.x;
   if (lm && !lm[g].in_trial) return;
   const int q0 = C.tail_ptr[g];
   for (int q = C.tail_ptr[g + 1] - 1; q >= q0; --q) {
@@ -960,6 +967,8 @@ int chol_plan_build(Batch& b) {
   if ((rc = up_to_dev(*P, b.stream, H.piece, &C.piece))) return rc;
   if ((rc = up_to_dev(*P, b.stream, H.lpiece, &C.lpiece))) return rc;
   C.ltail0 = (int)H.plv_pieces.size();
+  P->lp_graph.resize(H.lpiece.size());
+  for (size_t q = 0; q < H.lpiece.size(); ++q) P->lp_graph[q] = H.lpiece[q].graph;
   if ((rc = up_to_dev(*P, b.stream, H.asrc, &C.asrc))) return rc;
   if ((rc = up_to_dev(*P, b.stream, H.usrc, &C.usrc))) return rc;
   if ((rc = up_to_dev(*P, b.stream, H.uitem, &C.uitem))) return rc;
@@ -1019,6 +1028,41 @@ int64_t chol_plan_lnz(const Batch& b) { return b.chol ? b.chol->lnz : 0; }
 int chol_plan_levels(const Batch& b) { return b.chol ? b.chol->C.nlevels : 0; }
 int chol_plan_launches(const Batch& b) { return b.chol ? (int)b.chol->plv_lds_f.size() + (b.chol->tail_total > 0 ? 1 : 0) : 0; }
 
+// LM endgame: from now on only the graphs flagged in `active` can be in a trial (a terminated graph never comes back within an
+// optimize call).  With few of them left, the factor / solve launches are sized for their pieces alone: index lists instead of the
+// full piece ranges.  active == nullptr (or most graphs active): back to the full ranges.
+int chol_set_active(Batch& b, const std::vector<char>* active) {
+  if (!b.chol) return 0;
+  CholPlan& P = *b.chol;
+  P.compact = false;
+  if (!active) return 0;
+  const int B = b.V.B;
+  int na = 0;
+  for (int g = 0; g < B; ++g) na += (*active)[g] ? 1 : 0;
+  if (B < 8 || na == 0 || 2 * na > B) return 0;
+  const int nplv = (int)P.plv_lds_f.size();
+  std::vector<int> idx;
+  idx.reserve(P.lp_graph.size() * (size_t)na / B + 64);
+  P.c_ptr.assign(nplv + 2, 0);
+  for (int l = 0; l < nplv; ++l) {
+    P.c_ptr[l] = (int)idx.size();
+    for (int q = P.plv_ptr[l]; q < P.plv_ptr[l + 1]; ++q) if ((*active)[P.lp_graph[q]]) idx.push_back(q);
+  }
+  P.c_ptr[nplv] = (int)idx.size();
+  if (P.tail_total > 0) for (int g = 0; g < B; ++g) if ((*active)[g]) idx.push_back(g);   // one tail workgroup per graph (a graph without tail pieces returns at once)
+  P.c_ptr[nplv + 1] = (int)idx.size();
+  if (idx.size() > P.idx_cap) {
+    if (P.d_idx) (void)hipFree(P.d_idx);
+    P.d_idx = nullptr; P.idx_cap = 0;
+    SSLAM_HIP_TRY(hipMalloc((void**)&P.d_idx, (idx.size() + 1024) * sizeof(int)));
+    P.idx_cap = idx.size() + 1024;
+  }
+  if (!idx.empty()) SSLAM_HIP_TRY(hipMemcpyAsync(P.d_idx, idx.data(), idx.size() * sizeof(int), hipMemcpyHostToDevice, b.stream));
+  SSLAM_HIP_TRY(hipStreamSynchronize(b.stream));   // idx is a local
+  P.compact = true;
+  return 0;
+}
+
 int chol_factor_and_forward(Batch& b, bool flat) {
   CholPlan& P = *b.chol;
   P.C.flat_L = flat ? 1 : 0;   // form of the factor in HBM: flat for the multi right-hand-side kernels, class-interleaved for chol_backward
@@ -1027,12 +1071,13 @@ int chol_factor_and_forward(Batch& b, bool flat) {
   hipLaunchKernelGGL(k_chol_begin, dim3((b.V.B + 63) / 64), dim3(64), 0, b.stream, b.V, C);
   const int nplv = (int)P.plv_lds_f.size();
   for (int l = 0; l < nplv; ++l) {
-    const int n = P.plv_ptr[l + 1] - P.plv_ptr[l];
+    const int n = P.compact ? P.c_ptr[l + 1] - P.c_ptr[l] : P.plv_ptr[l + 1] - P.plv_ptr[l];
     if (n <= 0) continue;
+    const int* idx = P.compact ? P.d_idx + P.c_ptr[l] : nullptr;
     const size_t lds = (size_t)P.plv_lds_f[l] * sizeof(double);
 #define SSLAM_LAUNCH_PIECES(NTV)                                                                                                   \
-  if (P.ustage) hipLaunchKernelGGL((k_chol_pieces<NTV, true>), dim3(n), dim3(NTV), lds, b.stream, b.V, C, P.plv_ptr[l]);            \
-  else hipLaunchKernelGGL((k_chol_pieces<NTV, false>), dim3(n), dim3(NTV), lds, b.stream, b.V, C, P.plv_ptr[l]);
+  if (P.ustage) hipLaunchKernelGGL((k_chol_pieces<NTV, true>), dim3(n), dim3(NTV), lds, b.stream, b.V, C, P.plv_ptr[l], idx);       \
+  else hipLaunchKernelGGL((k_chol_pieces<NTV, false>), dim3(n), dim3(NTV), lds, b.stream, b.V, C, P.plv_ptr[l], idx);
     switch (P.nt_leaf) {
       case 128: SSLAM_LAUNCH_PIECES(128) break;
       case 512: SSLAM_LAUNCH_PIECES(512) break;
@@ -1043,8 +1088,12 @@ int chol_factor_and_forward(Batch& b, bool flat) {
 #undef SSLAM_LAUNCH_PIECES
   }
   if (P.tail_total > 0) {
-    if (P.nt_tail == 1024) hipLaunchKernelGGL(k_chol_tail<1024>, dim3(b.V.B), dim3(1024), (size_t)P.tail_lds_f * sizeof(double), b.stream, b.V, C);
-    else hipLaunchKernelGGL(k_chol_tail<512>, dim3(b.V.B), dim3(512), (size_t)P.tail_lds_f * sizeof(double), b.stream, b.V, C);
+    const int n = P.compact ? P.c_ptr[nplv + 1] - P.c_ptr[nplv] : b.V.B;
+    const int* idx = P.compact ? P.d_idx + P.c_ptr[nplv] : nullptr;
+    if (n > 0) {
+      if (P.nt_tail == 1024) hipLaunchKernelGGL(k_chol_tail<1024>, dim3(n), dim3(1024), (size_t)P.tail_lds_f * sizeof(double), b.stream, b.V, C, idx);
+      else hipLaunchKernelGGL(k_chol_tail<512>, dim3(n), dim3(512), (size_t)P.tail_lds_f * sizeof(double), b.stream, b.V, C, idx);
+    }
   }
   hipLaunchKernelGGL(k_chol_end, dim3((b.V.B + 63) / 64), dim3(64), 0, b.stream, b.V, C);
   hipError_t e = hipGetLastError();
@@ -1057,13 +1106,18 @@ int chol_backward(Batch& b) {
   const CholView& C = P.C;
   if (C.flat_L) return set_error(SSLAM_ERR_INVALID, "chol_backward needs the class-interleaved factor (the last factorisation was a flat one)");
   ScopedTimer t(b, "solve");
-  if (P.tail_total > 0)
-    hipLaunchKernelGGL(k_chol_back_tail<512>, dim3(b.V.B), dim3(512), (size_t)P.tail_lds_b * sizeof(double), b.stream, C, (const double*)C.y, b.V.x, (const LmState*)b.V.lm);
-  for (int l = (int)P.plv_lds_b.size() - 1; l >= 0; --l) {
-    const int n = P.plv_ptr[l + 1] - P.plv_ptr[l];
+  const int nplv = (int)P.plv_lds_b.size();
+  if (P.tail_total > 0) {
+    const int n = P.compact ? P.c_ptr[nplv + 1] - P.c_ptr[nplv] : b.V.B;
+    const int* idx = P.compact ? P.d_idx + P.c_ptr[nplv] : nullptr;
+    if (n > 0) hipLaunchKernelGGL(k_chol_back_tail<512>, dim3(n), dim3(512), (size_t)P.tail_lds_b * sizeof(double), b.stream, C, (const double*)C.y, b.V.x, (const LmState*)b.V.lm, idx);
+  }
+  for (int l = nplv - 1; l >= 0; --l) {
+    const int n = P.compact ? P.c_ptr[l + 1] - P.c_ptr[l] : P.plv_ptr[l + 1] - P.plv_ptr[l];
     if (n <= 0) continue;
+    const int* idx = P.compact ? P.d_idx + P.c_ptr[l] : nullptr;
     const size_t lds = (size_t)P.plv_lds_b[l] * sizeof(double);
-#define SSLAM_LAUNCH_BACK(NTV) hipLaunchKernelGGL(k_chol_back_pieces<NTV>, dim3(n), dim3(NTV), lds, b.stream, C, P.plv_ptr[l], (const double*)C.y, b.V.x, (const LmState*)b.V.lm);
+#define SSLAM_LAUNCH_BACK(NTV) hipLaunchKernelGGL(k_chol_back_pieces<NTV>, dim3(n), dim3(NTV), lds, b.stream, C, P.plv_ptr[l], (const double*)C.y, b.V.x, (const LmState*)b.V.lm, idx);
     static const int nt_back_env = [] { const char* e = getenv("SSLAM_CHOL_NT_BACK"); return e ? atoi(e) : 0; }();
     switch (nt_back_env > 0 ? nt_back_env : P.nt_leaf) {
       case 128: SSLAM_LAUNCH_BACK(128) break;

@@ -78,6 +78,7 @@ __global__ __launch_bounds__(kEdgeChunk) void k_chi2(BatchView V, const double* 
       for (int s = 0; s < 3; ++s) a += W[r * 3 + s] * err[s];
       c += err[r] * a;
     }
+    if (V.dcs_phi > 0) c *= dcs_rho1(V.dcs_phi, c);
   }
   const double s = block_sum<kEdgeChunk>(c, red);
   if (threadIdx.x == 0) part[(size_t)g * V.maxEdgeChunks + blockIdx.x] = s;
@@ -348,9 +349,15 @@ __global__ __launch_bounds__(kRowThreads) void k_linearize_rowthread_handover(Ba
       }
       double W[9];
       W[0] = D.w[0]; W[1] = W[3] = D.w[1]; W[2] = W[6] = D.w[2]; W[4] = D.w[3]; W[5] = W[7] = D.w[4]; W[8] = D.w[5];
+      double dcs = 1.0;
+      if (V.dcs_phi > 0) dcs = dcs_rho1(V.dcs_phi, quad3(W, err));   // from the unmasked Omega: every rank scales its share alike
       if (SHARD && !(D.id >= sh_lo && D.id < sh_hi)) {
 #pragma unroll
         for (int q = 0; q < 9; ++q) W[q] = 0.0;
+      }
+      if (V.dcs_phi > 0) {
+#pragma unroll
+        for (int q = 0; q < 9; ++q) W[q] *= dcs;
       }
       double WJi[18], We[3];
 #pragma unroll
@@ -571,9 +578,15 @@ __global__ __launch_bounds__(kRowThreads) void k_linearize_rowthread(BatchView V
       }
       double W[9];
       load_sym3(V.el_w, n, e, W);
+      double dcs = 1.0;
+      if (V.dcs_phi > 0) dcs = dcs_rho1(V.dcs_phi, quad3(W, err));   // from the unmasked Omega: every rank scales its share alike
       if (SHARD && !(V.el_id[e] >= sh_lo && V.el_id[e] < sh_hi)) {
 #pragma unroll
         for (int q = 0; q < 9; ++q) W[q] = 0.0;
+      }
+      if (V.dcs_phi > 0) {
+#pragma unroll
+        for (int q = 0; q < 9; ++q) W[q] *= dcs;
       }
       double WJi[18], We[3];
 #pragma unroll
@@ -664,6 +677,11 @@ __global__ __launch_bounds__(256) void k_linearize_lm_rows(BatchView V) {
       }
       double W[9];
       load_sym3(V.el_w, n, e, W);
+      if (V.dcs_phi > 0) {
+        const double r1 = dcs_rho1(V.dcs_phi, quad3(W, err));
+#pragma unroll
+        for (int q = 0; q < 9; ++q) W[q] *= r1;
+      }
       if (SHARD) {
         const int g = V.lrow_graph[l];
         if (!(V.el_id[e] >= V.shard_lo[g] && V.el_id[e] < V.shard_hi[g])) {
@@ -748,6 +766,19 @@ __global__ void k_linearize_dups(BatchView V) {
                       Plane{{V.el_z[0 * (size_t)n + k], V.el_z[1 * (size_t)n + k], V.el_z[2 * (size_t)n + k]}, V.el_z[3 * (size_t)n + k]}, Ji, Jl);
     }
     load_sym3(V.el_w, n, k, W);
+    if (V.dcs_phi > 0) {
+      double err[3];
+      if (V.lm_kind[li] == VT_POINT) {
+        PointLin L;
+        point_error(Xi, Vec3{lp[0], lp[1], lp[2]}, Vec3{V.el_z[0 * (size_t)n + k], V.el_z[1 * (size_t)n + k], V.el_z[2 * (size_t)n + k]}, L);
+        err[0] = L.e[0]; err[1] = L.e[1]; err[2] = L.e[2];
+      } else {
+        plane_error(Xi, Plane{{lp[0], lp[1], lp[2]}, lp[3]},
+                    Plane{{V.el_z[0 * (size_t)n + k], V.el_z[1 * (size_t)n + k], V.el_z[2 * (size_t)n + k]}, V.el_z[3 * (size_t)n + k]}, err);
+      }
+      const double r1 = dcs_rho1(V.dcs_phi, quad3(W, err));
+      for (int q = 0; q < 9; ++q) W[q] *= r1;
+    }
     double WJl[9];
     for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) WJl[r * 3 + c] = W[r * 3 + 0] * Jl[c] + W[r * 3 + 1] * Jl[3 + c] + W[r * 3 + 2] * Jl[6 + c];
     double* O = V.Hpl + (size_t)decode_blk(V.el_blk[k]) * 18;
@@ -1467,6 +1498,7 @@ static int batch_build(Batch& b, bool host_only = false) {
   V.B = B; V.nPr = nPr; V.nLr = nLr; V.nPose = (int)b.pose_row.size(); V.nLm = (int)b.lm_row.size();
   V.nEo = nEo; V.nEl = nEl; V.maxRowChunks = maxRow; V.maxEdgeChunks = maxEdge;
   V.h_total = h_total;
+  V.dcs_phi = b.graphs[0]->opt.dcs_phi;
   int rc;
 #define UP(vec, field) if ((rc = dev_upload(b, vec, (std::remove_const<std::remove_pointer<decltype(V.field)>::type>::type**)&V.field)) != 0) return rc
   UP(b.seg, seg); UP(b.pose_row, pose_row); UP(b.lm_row, lm_row); UP(b.prow_pose, prow_pose); UP(b.lrow_lm, lrow_lm);
@@ -1664,7 +1696,12 @@ static int batch_solve(Batch& b) {
     if ((rc = wchol_factor_and_forward(b))) return rc;
     return wchol_backward(b);
   }
-  if (!b.chol && (rc = chol_plan_build(b))) return rc;
+  if (!b.chol) {
+    static const bool timing = getenv("SSLAM_TIMING") != nullptr;
+    const auto t0 = std::chrono::steady_clock::now();
+    if ((rc = chol_plan_build(b))) return rc;
+    if (timing) fprintf(stderr, "[timing] cholesky plan build %.3f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+  }
   if ((rc = chol_factor_and_forward(b))) return rc;
   return chol_backward(b);
 }
@@ -1690,6 +1727,9 @@ static int batch_optimize(Batch& b, int max_iters, sslam_opt_stats* out) {
   // Every graph needs at least (max_iters - iter) more steps; rejected trials add steps, which later chunks supply.
   long long budget = 10LL * std::max(max_iters, 0) + 8;    // hard bound: <= 10 trials per iteration
   int need = max_iters;
+  if ((rc = chol_set_active(b, nullptr))) return rc;
+  std::vector<char> act(V.B, 1);
+  int n_act = V.B;
   while (need > 0 && budget > 0) {
     const int chunk = (int)std::min<long long>(std::min(need, kStepChunk), budget);
     for (int sidx = 0; sidx < chunk; ++sidx) {
@@ -1709,8 +1749,20 @@ static int batch_optimize(Batch& b, int max_iters, sslam_opt_stats* out) {
     SSLAM_HIP_TRY(hipStreamSynchronize(b.stream));
     b.harvest();
     need = 0;
-    for (auto& q : st) if (q.active) need = std::max(need, max_iters - q.iter);
+    int na = 0;
+    for (int g = 0; g < V.B; ++g) { act[g] = st[g].active ? 1 : 0; na += act[g]; if (st[g].active) need = std::max(need, max_iters - st[g].iter); }
+    // the graphs that are still iterating only ever shrink: once half of the batch is done, the factor / solve launches are sized
+    // for the rest (a retry by three graphs then costs three graphs' pieces, not the dispatch of everybody's)
+    static const bool timing = getenv("SSLAM_TIMING") != nullptr;
+    if (timing && V.B > 1) fprintf(stderr, "[timing] LM chunk of %d steps done: %d of %d graphs still active, %d more iterations needed\n", chunk, na, V.B, need);
+    if (need > 0 && na < n_act && 2 * na <= V.B) {
+      const auto tc = std::chrono::steady_clock::now();
+      if ((rc = chol_set_active(b, &act))) return rc;
+      n_act = na;
+      if (timing) fprintf(stderr, "[timing] launches resized for %d active graphs in %.3f ms\n", na, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tc).count());
+    }
   }
+  if ((rc = chol_set_active(b, nullptr))) return rc;
   SSLAM_HIP_TRY(hipMemcpyAsync(st.data(), V.lm, sizeof(LmState) * V.B, hipMemcpyDeviceToHost, b.stream));
   SSLAM_HIP_TRY(hipStreamSynchronize(b.stream));
   b.harvest();
@@ -1871,6 +1923,7 @@ int sslam_graph_set_option(sslam_graph* h, const char* key, double value) {
   Options& o = h->g.opt;
   const std::string k(key);
   if (k == "solver") { if (value != 0 && value != 1 && value != 2 && value != 3) return set_error(SSLAM_ERR_INVALID, "solver: 0 block-Jacobi PCG, 1 sparse block Cholesky (piece plan), 2 Schur complement on the landmarks + PCG, 3 sparse block Cholesky (window plan)"); o.solver = (int)value; }
+  else if (k == "robust_kernel_dcs") { if (!(value >= 0)) return set_error(SSLAM_ERR_INVALID, "robust_kernel_dcs: phi >= 0 (0 = no kernel)"); o.dcs_phi = value; if (h->batch) h->batch->V.dcs_phi = value; h->linearized = false; }
   else if (k == "pcg_tol") o.pcg_tol = value;
   else if (k == "pcg_max_iters") o.pcg_max_iters = (int)value;
   else if (k == "deterministic") { if (value == 0) return set_error(SSLAM_ERR_UNSUPPORTED, "the Jacobian build is always deterministic (gather form); the FP64-atomics variant was removed"); }
@@ -1887,12 +1940,21 @@ int sslam_graph_optimize(sslam_graph* h, int max_iters, sslam_opt_stats* out) {
     out->status = SSLAM_ERR_TOO_FEW_EDGES;
     return set_error(SSLAM_ERR_TOO_FEW_EDGES, "graph has %d edges (< 10): not optimised", h->g.ne());
   }
+  static const bool timing = getenv("SSLAM_TIMING") != nullptr;
+  auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  const double t0 = now();
   int rc = ensure_batch(h);
   if (rc) { out->status = rc; return rc; }
+  const double t1 = now();
   if ((rc = batch_upload_estimates(*h->batch))) return rc;
+  const double t2 = now();
   if ((rc = batch_optimize(*h->batch, max_iters, out))) return rc;
+  const double t3 = now();
   h->linearized = false;
-  return batch_download_estimates(*h->batch);
+  rc = batch_download_estimates(*h->batch);
+  if (timing) fprintf(stderr, "[timing] optimize: vertices %d edges %d | structure %.3f upload %.3f LM %.3f (iterations %d trials %d) download %.3f ms\n",
+                      h->g.nv(), h->g.ne(), t1 - t0, t2 - t1, t3 - t2, out->iterations, out->trials, now() - t3);
+  return rc;
 }
 
 int sslam_graph_chi2(sslam_graph* h, double* chi2) {
@@ -2197,7 +2259,7 @@ sslam_batch* sslam_batch_create(sslam_graph* const* graphs, int n) {
   for (int i = 0; i < n; ++i) {
     if (!graphs[i] || graphs[i]->g.device != h->b.device) { set_error(SSLAM_ERR_INVALID, "batch graphs must share one device"); delete h; return nullptr; }
     const Options &oa = graphs[0]->g.opt, &ob = graphs[i]->g.opt;   // one set of solver options drives the whole batch
-    if (oa.solver != ob.solver || oa.pcg_tol != ob.pcg_tol || oa.pcg_max_iters != ob.pcg_max_iters) {
+    if (oa.solver != ob.solver || oa.pcg_tol != ob.pcg_tol || oa.pcg_max_iters != ob.pcg_max_iters || oa.dcs_phi != ob.dcs_phi) {
       set_error(SSLAM_ERR_INVALID, "batch graphs must share their solver options (graph %d differs from graph 0)", i); delete h; return nullptr;
     }
     h->b.graphs.push_back(&graphs[i]->g);

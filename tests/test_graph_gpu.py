@@ -289,6 +289,37 @@ def test_L_config_termination_iteration(gpu_lib, seed):
     assert np.abs(G.estimates() - gp.est).max() <= 1e-6 * np.abs(gp.est).max()
 
 
+def test_dcs_robust_kernel_matches_oracle(gpu_lib):
+    """opt-in RobustKernelDCS on the landmark edges (sslam_graph_set_option "robust_kernel_dcs" = phi): chi2, the
+    normal equations and the optimised estimates equal the oracle's with the same kernel, for point and plane landmarks, with a few gross
+    outliers among the landmark measurements"""
+    from semantic_slam_amd import GraphSLAM
+    from oracle import oracle as O
+    for kind, tol in (("point", 1e-11), ("plane", 2e-5)):
+        g = make_graph(120, 24, seed=8, landmark_kind=kind)
+        gp = GraphProblem.from_synth(g, interleave=True)
+        out = np.nonzero(gp.etype != 0)[0][::17]
+        gp.meas[out, :3] += np.array([0.8, -0.6, 0.5]) if kind == "point" else np.array([0.3, -0.2, 0.1])
+        if kind == "plane":
+            gp.meas[out, :3] /= np.linalg.norm(gp.meas[out, :3], axis=1, keepdims=True)
+        G = GraphSLAM.from_problem(gp)
+        G.set_option("robust_kernel_dcs", 1.0)
+        try:
+            O.set_dcs(1.0)
+            assert G.chi2() == pytest.approx(gp.chi2(), rel=1e-12)
+            U, b = G.linearize()
+            Uo, bo = gp.linearize()
+            assert np.abs((U - Uo).toarray()).max() <= tol * np.abs(Uo.toarray()).max() and np.abs(b - bo).max() <= tol * np.abs(bo).max()
+            assert G.optimize(15)
+            st = gp.optimize(15)
+        finally:
+            O.set_dcs(0.0)
+        assert G.last_stats.chi2_after == pytest.approx(st.chi2_after, rel=1e-6)
+        assert np.abs(G.estimates() - gp.est).max() <= 1e-4 * np.abs(gp.est).max()
+        G.set_option("robust_kernel_dcs", 0.0)
+        assert G.chi2() == pytest.approx(gp.chi2(), rel=1e-9)          # kernel off again: the plain chi2 of the optimised state
+
+
 def test_too_few_edges_returns_false(gpu_lib):
     from semantic_slam_amd import GraphSLAM
     G = GraphSLAM()

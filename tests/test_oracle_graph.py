@@ -216,3 +216,55 @@ def test_analytic_invariants(kind):
         assert np.array_equal(g2.est[0], est0[0])          # gauge: vertex 0 is fixed (graph_slam.cpp:109-111)
     assert all(chis[i + 1] <= chis[i] * (1 + 1e-12) for i in range(len(chis) - 1))
     assert chis[-1] < 0.5 * chis[0]
+
+
+def test_dcs_robust_kernel_follows_g2o_robustify():
+    """RobustKernelDCS (the reference means to install it at graph_slam.cpp:155,161 but passes an uninitialised pointer, quirk
+    B1): opt-in on the landmark edges.  chi2 = sum rho0(e2) with rho0 = e2 while scale = 2 phi / (phi + e2) >= 1, scale^2 e2 beyond;
+    H and b use Omega scaled by rho1.  Checked against a NumPy evaluation from the oracle's own per-edge errors and Jacobians."""
+    from oracle import oracle as O
+    g = make_graph(40, 8, seed=3)
+    gp = GraphProblem.from_synth(g, interleave=True)
+    # a gross outlier among the landmark measurements
+    k_out = int(np.nonzero(gp.etype == 1)[0][5])
+    gp.meas[k_out, :3] += np.array([1.5, -2.0, 1.0])
+    phi = 1.0
+    chi_plain = gp.chi2()
+    U0, b0 = gp.linearize()
+    try:
+        O.set_dcs(phi)
+        chi_dcs = gp.chi2()
+        U1, b1 = gp.linearize()
+        st = gp.copy().optimize(30)
+    finally:
+        O.set_dcs(0.0)
+    h, n = gp.hessian_index()
+    ref_chi = 0.0
+    Hd = np.zeros((n, n)); bd = np.zeros(n)
+    n_down = 0
+    for k in range(gp.ne):
+        e, Ji, Jj = gp.edge_eval(k)
+        d = 6 if gp.etype[k] == 0 else 3
+        dj = 6 if gp.vtype[gp.evj[k]] == 0 else 3
+        e, Ji, Jj = e[:d], Ji[:d * 6].reshape(d, 6), Jj[:d * dj].reshape(d, dj)
+        W = gp.info[k, :d * d].reshape(d, d)
+        e2 = float(e @ W @ e)
+        r1 = 1.0
+        if gp.etype[k] != 0:
+            scale = 2 * phi / (phi + e2)
+            if scale < 1:
+                r1 = scale * scale; n_down += 1
+        ref_chi += r1 * e2
+        for (v, J) in ((gp.evi[k], Ji), (gp.evj[k], Jj)):
+            if h[v] >= 0:
+                bd[h[v]:h[v] + J.shape[1]] -= J.T @ (r1 * W) @ e
+        for (va, Ja) in ((gp.evi[k], Ji), (gp.evj[k], Jj)):
+            for (vb, Jb) in ((gp.evi[k], Ji), (gp.evj[k], Jj)):
+                if h[va] >= 0 and h[vb] >= 0:
+                    Hd[h[va]:h[va] + Ja.shape[1], h[vb]:h[vb] + Jb.shape[1]] += Ja.T @ (r1 * W) @ Jb
+    assert n_down >= 1 and chi_dcs < chi_plain
+    assert abs(chi_dcs - ref_chi) <= 1e-12 * ref_chi
+    H1 = (U1 + U1.T).toarray() - np.diag(U1.diagonal())
+    assert np.abs(H1 - Hd).max() <= 1e-10 * np.abs(Hd).max() and np.abs(b1 - bd).max() <= 1e-10 * np.abs(bd).max()
+    assert np.abs((U1 - U0).toarray()).max() > 0
+    assert st.chi2_after <= chi_dcs
