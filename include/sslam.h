@@ -173,6 +173,9 @@ int64_t sslam_batch_linearize_hb(sslam_batch* b, double* h_and_b, int64_t capaci
 /* run only the Jacobian build (linearise + assemble) `repeats` times; returns mean kernel
  * milliseconds measured with hipEvents on the batch's stream */
 int sslam_batch_time_linearize(sslam_batch* b, int repeats, double* ms_per_build);
+/* one numeric factorisation (+ fused forward substitution) and one backward substitution of EVERY graph of the batch, `repeats` times:
+ * mean kernel milliseconds (hipEvents on the batch's stream); direct solvers only */
+int sslam_batch_time_solver(sslam_batch* b, int repeats, double* factor_ms, double* solve_ms);
 /* algorithmic bytes of one Jacobian build over the whole batch (SURVEY §8d formula) */
 int64_t sslam_batch_linearize_bytes(const sslam_batch* b);
 /* structural facts of a batch (doubles): "factor_lnz" (doubles in the Cholesky factor), "factor_levels",

@@ -87,6 +87,7 @@ def load_library():
         "sslam_batch_set_edge_shard": (ci, [vp, ci, ci]),
         "sslam_batch_linearize_hb": (i64, [vp, dp, i64]),
         "sslam_batch_time_linearize": (ci, [vp, ci, dp]),
+        "sslam_batch_time_solver": (ci, [vp, ci, dp, dp]),
         "sslam_batch_linearize_bytes": (i64, [vp]),
         "sslam_batch_info": (ci, [vp, C.c_char_p, dp]),
         "sslam_batch_set_profiling": (ci, [vp, ci]),

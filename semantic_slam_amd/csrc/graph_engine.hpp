@@ -4,6 +4,7 @@
 #include <algorithm>
 #include <array>
 #include <cstdint>
+#include <cstring>
 #include <map>
 #include <string>
 #include <vector>
@@ -32,6 +33,12 @@ struct DevArena {
   char* base = nullptr;
   size_t cap = 0, used = 0, need = 0;
   std::vector<void*> spill;
+  // Host mirror of the arena (pinned): the ~65 small index / table arrays of a rebuild are written into it and travel to the
+  // device as ONE copy (flush) instead of one hipMemcpyAsync + hipMemsetAsync each -- the uploads were most of the 3 ms a tick
+  // spent on its structure rebuild.  Large zero-filled arrays (H, L, update matrices) keep their own memset.
+  char* mirror = nullptr;
+  size_t mirror_cap = 0, flushed = 0;
+  static constexpr size_t kMirrorMax = 256 << 10;   // arrays above this size bypass the mirror
   void* take(size_t bytes) {
     bytes = (bytes + 255) & ~(size_t)255;
     need += bytes;
@@ -41,6 +48,36 @@ struct DevArena {
     spill.push_back(p);
     return p;
   }
+  bool in_block(const void* p) const { return base && (const char*)p >= base && (const char*)p < base + cap; }
+  // host address that shadows device address p (arena block only), or nullptr
+  char* shadow(void* p, size_t bytes) {
+    if (!in_block(p) || bytes > kMirrorMax) return nullptr;
+    if (mirror_cap < cap) {
+      if (mirror) (void)hipHostFree(mirror);
+      mirror = nullptr; mirror_cap = 0;
+      void* q = nullptr;
+      if (hipHostMalloc(&q, cap, hipHostMallocDefault) != hipSuccess) return nullptr;
+      mirror = (char*)q; mirror_cap = cap; flushed = 0;
+    }
+    return mirror + ((char*)p - base);
+  }
+  // everything written to the mirror since the last flush -> device, one copy.  Ranges that bypassed the mirror inside
+  // [flushed, used) were written directly (memset / memcpy on the same stream, issued BEFORE this copy): the copy must not clobber
+  // them, so bypassing arrays are recorded and the flush is cut around them.
+  std::vector<std::pair<size_t, size_t>> holes;   // [begin, end) offsets that went to the device directly
+  int flush(hipStream_t st) {
+    if (!mirror || flushed >= used) { flushed = used; holes.clear(); return 0; }
+    std::sort(holes.begin(), holes.end());
+    size_t a = flushed;
+    for (auto& h : holes) {
+      if (h.first > a && hipMemcpyAsync(base + a, mirror + a, h.first - a, hipMemcpyHostToDevice, st) != hipSuccess) return -3;
+      a = std::max(a, h.second);
+    }
+    if (used > a && hipMemcpyAsync(base + a, mirror + a, used - a, hipMemcpyHostToDevice, st) != hipSuccess) return -3;
+    flushed = used; holes.clear();
+    return 0;
+  }
+  void note_direct(void* p, size_t bytes) { if (in_block(p)) holes.push_back({(size_t)((char*)p - base), (size_t)((char*)p - base) + ((bytes + 255) & ~(size_t)255)}); }
   void reset() {   // the caller guarantees that no kernel still uses the memory (the owning batch has been released)
     for (void* p : spill) (void)hipFree(p);
     spill.clear();
@@ -51,11 +88,12 @@ struct DevArena {
       void* p = nullptr;
       if (hipMalloc(&p, want) == hipSuccess) { base = (char*)p; cap = want; }
     }
-    used = 0; need = 0;
+    used = 0; need = 0; flushed = 0; holes.clear();
   }
   ~DevArena() {
     for (void* p : spill) (void)hipFree(p);
     if (base) (void)hipFree(base);
+    if (mirror) (void)hipHostFree(mirror);
   }
 };
 
@@ -140,8 +178,16 @@ template <typename T>
 inline int dev_upload(Batch& b, const std::vector<T>& h, T** out, size_t min_elems = 1) {
   const size_t n = std::max(h.size(), min_elems);
   void* p = nullptr;
-  if (b.arena) { p = b.arena->take(n * sizeof(T)); if (!p) return set_error(-3, "device allocation of %zu bytes failed", n * sizeof(T)); }
-  else { SSLAM_HIP_TRY(hipMalloc(&p, n * sizeof(T))); b.allocs.push_back(p); }
+  if (b.arena) {
+    p = b.arena->take(n * sizeof(T));
+    if (!p) return set_error(-3, "device allocation of %zu bytes failed", n * sizeof(T));
+    if (char* m = b.arena->shadow(p, n * sizeof(T))) {   // travels with the arena's next flush
+      if (!h.empty()) memcpy(m, h.data(), h.size() * sizeof(T));
+      *out = (T*)p;
+      return 0;
+    }
+    b.arena->note_direct(p, n * sizeof(T));
+  } else { SSLAM_HIP_TRY(hipMalloc(&p, n * sizeof(T))); b.allocs.push_back(p); }
   if (!h.empty()) SSLAM_HIP_TRY(hipMemcpyAsync(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, b.stream));
   *out = (T*)p;
   return 0;
@@ -150,8 +196,16 @@ template <typename T>
 inline int dev_alloc(Batch& b, size_t n, T** out, bool zero = true) {
   void* p = nullptr;
   n = std::max<size_t>(n, 1);
-  if (b.arena) { p = b.arena->take(n * sizeof(T)); if (!p) return set_error(-3, "device allocation of %zu bytes failed", n * sizeof(T)); }
-  else { SSLAM_HIP_TRY(hipMalloc(&p, n * sizeof(T))); b.allocs.push_back(p); }
+  if (b.arena) {
+    p = b.arena->take(n * sizeof(T));
+    if (!p) return set_error(-3, "device allocation of %zu bytes failed", n * sizeof(T));
+    if (char* m = b.arena->shadow(p, n * sizeof(T))) {
+      memset(m, 0, n * sizeof(T));
+      *out = (T*)p;
+      return 0;
+    }
+    b.arena->note_direct(p, n * sizeof(T));
+  } else { SSLAM_HIP_TRY(hipMalloc(&p, n * sizeof(T))); b.allocs.push_back(p); }
   if (zero) SSLAM_HIP_TRY(hipMemsetAsync(p, 0, n * sizeof(T), b.stream));
   *out = (T*)p;
   return 0;

@@ -921,8 +921,17 @@ template <typename T>
 int up_to_dev(CholPlan& P, hipStream_t s, const std::vector<T>& h, const T** out) {
   void* p = nullptr;
   const size_t n = h.size() + 4;   // slack: the kernels' clamped table loads may read one record past an empty range
-  if (P.arena) { p = P.arena->take(n * sizeof(T)); if (!p) return set_error(SSLAM_ERR_HIP, "device allocation of %zu bytes failed", n * sizeof(T)); }
-  else { SSLAM_HIP_TRY(hipMalloc(&p, n * sizeof(T))); P.allocs.push_back(p); }
+  if (P.arena) {
+    p = P.arena->take(n * sizeof(T));
+    if (!p) return set_error(SSLAM_ERR_HIP, "device allocation of %zu bytes failed", n * sizeof(T));
+    if (char* m = P.arena->shadow(p, n * sizeof(T))) {   // travels with the arena's next flush (one copy for all tables)
+      memset(m, 0, n * sizeof(T));
+      if (!h.empty()) memcpy(m, h.data(), h.size() * sizeof(T));
+      *out = (const T*)p;
+      return 0;
+    }
+    P.arena->note_direct(p, n * sizeof(T));
+  } else { SSLAM_HIP_TRY(hipMalloc(&p, n * sizeof(T))); P.allocs.push_back(p); }
   SSLAM_HIP_TRY(hipMemsetAsync(p, 0, n * sizeof(T), s));
   if (!h.empty()) SSLAM_HIP_TRY(hipMemcpyAsync(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, s));
   *out = (const T*)p;
@@ -980,7 +989,11 @@ int chol_plan_build(Batch& b) {
   if ((rc = up_to_dev(*P, b.stream, H.tail_pieces, &C.tail_pieces))) return rc;
   void* p = nullptr;
   auto plan_alloc = [&](void** q, size_t bytes) -> int {
-    if (P->arena) { *q = P->arena->take(bytes); return *q ? 0 : set_error(SSLAM_ERR_HIP, "device allocation of %zu bytes failed", bytes); }
+    if (P->arena) {
+      *q = P->arena->take(bytes);
+      if (*q) P->arena->note_direct(*q, bytes);   // zero-filled below with its own memset: the arena's flush must leave it alone
+      return *q ? 0 : set_error(SSLAM_ERR_HIP, "device allocation of %zu bytes failed", bytes);
+    }
     SSLAM_HIP_TRY(hipMalloc(q, bytes)); P->allocs.push_back(*q);
     return 0;
   };
@@ -1020,6 +1033,7 @@ int chol_plan_build(Batch& b) {
                          (const void*)k_chol_back_pieces<512>, (const void*)k_chol_back_pieces<1024>, (const void*)k_chol_back_tail<512>};
     for (const void* f : fns) SSLAM_HIP_TRY(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, v));
   }
+  if (P->arena && P->arena->flush(b.stream)) return set_error(SSLAM_ERR_HIP, "upload of the plan tables failed");
   SSLAM_HIP_TRY(hipStreamSynchronize(b.stream));
   return 0;
 }

@@ -1541,6 +1541,7 @@ static int batch_build(Batch& b, bool host_only = false) {
   if ((rc = dev_alloc(b, (size_t)B, &V.pcg_fail))) return rc;
   if ((rc = dev_alloc(b, (size_t)4, &V.flags))) return rc;
   if ((rc = dev_alloc(b, (size_t)B, &V.lm))) return rc;
+  if (b.arena && b.arena->flush(b.stream)) return set_error(SSLAM_ERR_HIP, "upload of the batch tables failed");
   SSLAM_HIP_TRY(hipStreamSynchronize(b.stream));
   b.versions.resize(B);
   for (int g = 0; g < B; ++g) b.versions[g] = b.graphs[g]->structure_version;
@@ -2388,6 +2389,42 @@ int sslam_batch_time_linearize(sslam_batch* h, int repeats, double* ms_per_build
   hipEventDestroy(e0); hipEventDestroy(e1);
   b.profiling = prof;
   *ms_per_build = (double)ms / repeats;
+  return 0;
+}
+// one numeric factorisation (+ fused forward solve) and one backward solve of EVERY graph of the batch, `repeats` times: mean
+// milliseconds by hipEvents on the batch's stream (the LM loop's own launches mix full and partial rounds)
+int sslam_batch_time_solver(sslam_batch* h, int repeats, double* factor_ms, double* solve_ms) {
+  if (!h || repeats <= 0 || !factor_ms || !solve_ms) return set_error(SSLAM_ERR_INVALID, "bad argument");
+  Batch& b = h->b;
+  if (b.graphs[0]->opt.solver == 0 || b.graphs[0]->opt.solver == 2) return set_error(SSLAM_ERR_UNSUPPORTED, "direct solvers only");
+  SSLAM_HIP_TRY(hipSetDevice(b.device));
+  int rc;
+  if (!b.uploaded && (rc = batch_upload_estimates(b))) return rc;
+  if ((rc = batch_chi2(b, b.V.pose, b.V.lmk, 0))) return rc;
+  hipLaunchKernelGGL(k_lm_init, dim3(b.V.B), dim3(64), 0, b.stream, b.V, b.d_part_e, 0);
+  if ((rc = batch_linearize(b))) return rc;
+  hipLaunchKernelGGL(k_set_trial_all, dim3((b.V.B + 63) / 64), dim3(64), 0, b.stream, b.V, 1.0);
+  const bool prof = b.profiling;
+  b.profiling = false;
+  if ((rc = batch_solve(b))) return rc;   // warm-up (builds the plan)
+  hipEvent_t e0, e1, e2;
+  SSLAM_HIP_TRY(hipEventCreate(&e0)); SSLAM_HIP_TRY(hipEventCreate(&e1)); SSLAM_HIP_TRY(hipEventCreate(&e2));
+  double tf = 0, ts = 0;
+  const bool wplan = b.wchol != nullptr;
+  for (int k = 0; k < repeats; ++k) {
+    SSLAM_HIP_TRY(hipEventRecord(e0, b.stream));
+    if ((rc = wplan ? wchol_factor_and_forward(b) : chol_factor_and_forward(b))) return rc;
+    SSLAM_HIP_TRY(hipEventRecord(e1, b.stream));
+    if ((rc = wplan ? wchol_backward(b) : chol_backward(b))) return rc;
+    SSLAM_HIP_TRY(hipEventRecord(e2, b.stream));
+    SSLAM_HIP_TRY(hipEventSynchronize(e2));
+    float a = 0, c = 0;
+    SSLAM_HIP_TRY(hipEventElapsedTime(&a, e0, e1)); SSLAM_HIP_TRY(hipEventElapsedTime(&c, e1, e2));
+    tf += a; ts += c;
+  }
+  hipEventDestroy(e0); hipEventDestroy(e1); hipEventDestroy(e2);
+  b.profiling = prof;
+  *factor_ms = tf / repeats; *solve_ms = ts / repeats;
   return 0;
 }
 int64_t sslam_batch_linearize_bytes(const sslam_batch* h) {

@@ -296,6 +296,12 @@ class GraphBatch:
         _check(self._lib, self._lib.sslam_batch_time_linearize(self._h, repeats, C.byref(ms)))
         return ms.value
 
+    def time_solver(self, repeats: int = 5):
+        """(factor ms, backward-solve ms) of one full-batch factorisation + solve, hipEvents on the batch's stream"""
+        f = C.c_double(0); s = C.c_double(0)
+        _check(self._lib, self._lib.sslam_batch_time_solver(self._h, repeats, C.byref(f), C.byref(s)))
+        return f.value, s.value
+
     def linearize_bytes(self) -> int:
         return int(self._lib.sslam_batch_linearize_bytes(self._h))
 

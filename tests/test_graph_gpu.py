@@ -244,6 +244,27 @@ def test_optimize_S_config_10_iterations(gpu_lib, solver):
     assert np.array_equal(E[0], g.poses_init[0])
 
 
+def test_schur_pcg_on_the_S_config(gpu_lib):
+    """BASELINE.json configs[1] through solver 2 (north_star's "Schur-complement + PCG": landmarks eliminated, matrix-free PCG on the
+    reduced pose system with the block-Jacobi preconditioner): ten LM iterations land on the oracle's chi2 / estimates.  The CG
+    iteration count per trial is what keeps this solver from being the default: printed, and bounded here."""
+    from semantic_slam_amd import GraphSLAM
+    g = make_graph(500, 100, seed=0)
+    gp = GraphProblem.from_synth(g)
+    G = GraphSLAM.from_problem(gp)
+    G.set_option("solver", 2)
+    G.set_option("pcg_tol", 1e-10)
+    assert G.optimize(10)
+    st = gp.optimize(10)
+    s = G.last_stats
+    assert s.iterations == st.iterations == 10
+    assert s.chi2_after == pytest.approx(st.chi2_after, rel=1e-6)
+    assert np.abs(G.estimates() - gp.est).max() <= 1e-4 * np.abs(gp.est).max()
+    per_trial = s.solver_iterations / max(s.trials, 1)
+    print(f"schur+pcg S config: {s.solver_iterations} CG iterations over {s.trials} trials ({per_trial:.0f} per trial)")
+    assert 10 < per_trial < 6000
+
+
 def test_optimize_L_config(gpu_lib):
     """BASELINE.json configs[2]: 5000 poses / 1000 landmarks + loop closures; 10 iterations, then to termination."""
     from semantic_slam_amd import GraphSLAM
