@@ -60,7 +60,7 @@ inline int64_t wchol_u_doubles(int m) { return 36 * ((int64_t)m * (m + 1) / 2) +
 
 struct WClass { int nt, S, wmax; };        // threads, tile registers per thread (tiles per thread / 4 lanes per tile), window slots
 // tiles of a window of w slots: w (w + 1) / 2 <= S * nt / 4 ;  rows of a column need 6 * rows + 1 threads in the solve phase
-constexpr WClass kWClass[3] = {{64, 4, 10}, {256, 6, 27}, {1024, 6, 54}};
+constexpr WClass kWClass[3] = {{64, 4, 10}, {512, 6, 38}, {1024, 6, 54}};
 
 struct WOpts {
   int colcap[3] = {48, 192, 4096};   // columns per segment, by class
@@ -251,7 +251,7 @@ inline void plan_graph(const SymIn& in, int g, const WOpts& opt, const std::unor
       }
       st.piv = slot_of[j] | (dj << 8) | ((int)rows.size() << 16);
       st.mask_lo = (unsigned)(mask & 0xFFFFFFFFull); st.mask_hi = (unsigned)(mask >> 32);
-      out.lnz += lofs;
+      out.lnz += (lofs + 1) & ~1;   // panels start on 16-byte boundaries (the kernels store them with 16-byte stores)
       // update matrices of child segments that hang below this column
       for (int ck : ext[j]) {
         if (ck >= k) { out.error = "segment order inconsistent"; return; }

@@ -89,13 +89,22 @@ def _check(hip_lib, specs, lams, env=None):
     return stats
 
 
-def test_window_cholesky_solves_small_graphs(hip_lib):
+@pytest.mark.parametrize("form", ["mfma", "valu"])
+def test_window_cholesky_solves_small_graphs(hip_lib, form, monkeypatch):
+    """both forms of the window update: the matrix-core form (16 x 16 accumulator tiles, panel P P^T) and the VALU form (3 x 3 quarters)"""
+    monkeypatch.setenv("SSLAM_WCHOL_VALU", "1" if form == "valu" else "0")
     specs = [(40, 8, 1, False, {}), (60, 12, 2, True, {}), (30, 6, 3, True, dict(landmark_kind="plane")), (25, 5, 4, False, dict(loop_every=5))]
     st = _check(hip_lib, specs, [0.0, 1e-3, 2.5, 10.0])
     assert st[2] >= 4 and st[6] == sum(a - 1 + b for a, b, *_ in specs)     # segments, columns
 
 
-def test_window_cholesky_S_config_with_both_classes(hip_lib):
+@pytest.mark.parametrize("form", ["mfma", "valu"])
+def test_window_cholesky_S_config_with_both_classes(hip_lib, form, monkeypatch):
+    monkeypatch.setenv("SSLAM_WCHOL_VALU", "1" if form == "valu" else "0")
+    _S_config(hip_lib)
+
+
+def _S_config(hip_lib):
     """the S graph has columns with more than 9 off-diagonal blocks: its top runs in the four-wave class, the rest in one-wave segments,
     with update matrices crossing the class border"""
     st = _check(hip_lib, [(500, 100, 0, False, {})], [1e-5 * 3e5])
