@@ -151,6 +151,11 @@ class GraphSLAM {
                                            const std::array<double, 3>& xyz, const double* information_matrix) {
     return {check(sslam_graph_add_edge_se3_point(graph.get(), v_se3->id(), v_xyz->id(), xyz.data(), information_matrix))};
   }
+  /** add_point_xyz_point_xyz_edge (graph_slam.cpp:168-180): g2o::EdgePointXYZ, measurement = p2 - p1 (never called upstream) */
+  sslam::EdgeHandle add_point_xyz_point_xyz_edge(const sslam::VertexPointXYZ* v1_xyz, const sslam::VertexPointXYZ* v2_xyz,
+                                                 const std::array<double, 3>& xyz, const double* information_matrix) {
+    return {check(sslam_graph_add_edge_point_point(graph.get(), v1_xyz->id(), v2_xyz->id(), xyz.data(), information_matrix))};
+  }
   /** add_se3_plane_edge (graph_slam.hpp:73-75, commented out upstream; include/g2o/edge_se3_plane.hpp) */
   sslam::EdgeHandle add_se3_plane_edge(const sslam::VertexSE3* v_se3, const sslam::VertexPlane* v_plane,
                                        const std::array<double, 4>& plane_coeffs, const double* information_matrix) {

@@ -81,6 +81,11 @@ int sslam_graph_add_edge_se3_point(sslam_graph* g, int i, int l, const double z[
  * (reference include/g2o/edge_se3_plane.hpp:8-48; numeric Jacobian). */
 int sslam_graph_add_edge_se3_plane(sslam_graph* g, int i, int l, const double z[4], const double info[9]);
 
+/* add_point_xyz_point_xyz_edge (graph_slam.cpp:168-180): g2o::EdgePointXYZ between two VertexPointXYZ, e = (p2 - p1) - z.  Declared and
+ * defined by the reference, never called there.  With such edges the landmark block of H is no longer block diagonal: solver 2
+ * (Schur complement on the landmarks) refuses the graph, the Cholesky solvers and solver 0 take it as it is. */
+int sslam_graph_add_edge_point_point(sslam_graph* g, int l1, int l2, const double z[3], const double info[9]);
+
 int sslam_graph_num_vertices(const sslam_graph* g);
 int sslam_graph_num_edges(const sslam_graph* g);
 

@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
 
 VT_SE3, VT_POINT, VT_PLANE = 0, 1, 2
-ET_SE3, ET_SE3_POINT, ET_SE3_PLANE = 0, 1, 2
+ET_SE3, ET_SE3_POINT, ET_SE3_PLANE, ET_POINT_POINT = 0, 1, 2, 3
 
 
 def build(force: bool = False) -> str:

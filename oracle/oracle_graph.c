@@ -42,6 +42,7 @@
 #define ET_SE3 0
 #define ET_SE3_POINT 1
 #define ET_SE3_PLANE 2
+#define ET_POINT_POINT 3   /* g2o::EdgePointXYZ between two VertexPointXYZ (reference graph_slam.cpp:168-180; never called upstream) */
 
 typedef struct {
   int nv, ne;
@@ -239,6 +240,11 @@ static void edge_eval(const og_problem *P, const double *est, int k, double *e, 
   switch (P->etype[k]) {
     case ET_SE3: se3_edge(Xi, Xj, z, e, Ji, Jj); break;
     case ET_SE3_POINT: point_edge(Xi, Xj, z, e, Ji, Jj); break;
+    case ET_POINT_POINT:   /* EdgePointXYZ::computeError: e = (p2 - p1) - z;  linearizeOplus: de/dp1 = -I, de/dp2 = I */
+      for (int r = 0; r < 3; ++r) e[r] = (Xj[r] - Xi[r]) - z[r];
+      if (Ji) for (int q = 0; q < 9; ++q) Ji[q] = (q % 4 == 0) ? -1.0 : 0.0;
+      if (Jj) for (int q = 0; q < 9; ++q) Jj[q] = (q % 4 == 0) ? 1.0 : 0.0;
+      break;
     default: plane_edge(Xi, Xj, z, e, Ji, Jj); break;
   }
 }
@@ -254,7 +260,7 @@ static double edge_chi2(const og_problem *P, const double *est, int k) {
     for (int s = 0; s < d; ++s) a += W[r * d + s] * e[s];
     c += e[r] * a;
   }
-  if (P->etype[k] != ET_SE3) c *= dcs_rho1(c);   /* rho[0] = rho[1] * e2 in both branches */
+  if (P->etype[k] == ET_SE3_POINT || P->etype[k] == ET_SE3_PLANE) c *= dcs_rho1(c);   /* rho[0] = rho[1] * e2 in both branches */
   return c;
 }
 
@@ -405,7 +411,7 @@ static void sys_build(const og_problem *P, const int *hidx, og_system *S) {
     double W[36];
     {
       double rho1 = 1.0;
-      if (P->etype[k] != ET_SE3 && g_dcs_phi > 0) {
+      if ((P->etype[k] == ET_SE3_POINT || P->etype[k] == ET_SE3_PLANE) && g_dcs_phi > 0) {
         double e2 = 0;
         for (int r = 0; r < d; ++r) { double a = 0; for (int s = 0; s < d; ++s) a += W0[r * d + s] * e[s]; e2 += e[r] * a; }
         rho1 = dcs_rho1(e2);

@@ -59,6 +59,7 @@ def load_library():
         "sslam_graph_add_edge_se3": (ci, [vp, ci, ci, dp, dp]),
         "sslam_graph_add_edge_se3_point": (ci, [vp, ci, ci, dp, dp]),
         "sslam_graph_add_edge_se3_plane": (ci, [vp, ci, ci, dp, dp]),
+        "sslam_graph_add_edge_point_point": (ci, [vp, ci, ci, dp, dp]),
         "sslam_graph_num_vertices": (ci, [vp]),
         "sslam_graph_num_edges": (ci, [vp]),
         "sslam_graph_get_vertex": (ci, [vp, ci, dp]),

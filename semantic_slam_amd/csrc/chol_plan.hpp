@@ -97,12 +97,13 @@ inline int blk_doubles(int di, int dj) { return (di * dj + 1) & ~1; }
 constexpr int kItemDoubles = 42;     // LDS doubles per partial tile: 6 x 6 entries + 6 rhs components
 constexpr int kMaxILevels = 64;      // internal levels per piece (LDS table in the kernels)
 
-struct SymGraph { int prow0, nprow, lrow0, nlrow; int pp0 = 0, pp1 = 0, pl0 = 0, pl1 = 0; };   // pp / pl: the graph's range of ppoff / plblk (wchol_plan.hpp)
+struct SymGraph { int prow0, nprow, lrow0, nlrow; int pp0 = 0, pp1 = 0, pl0 = 0, pl1 = 0, ll0 = 0, ll1 = 0; };   // pp / pl: the graph's range of ppoff / plblk (wchol_plan.hpp)
 struct SymIn {
   int B = 0, nPr = 0, nLr = 0;
   std::vector<SymGraph> seg;
   std::vector<std::pair<int, int>> ppoff, plblk;   // unique off-diagonal blocks: (pose row a < pose row b), (pose row, landmark row)
-  int64_t hll_base = 0, hpp_off_base = 0, hpl_base = 0;
+  std::vector<std::pair<int, int>> llblk;          // (landmark row a < landmark row b): point-point edges
+  int64_t hll_base = 0, hpp_off_base = 0, hpl_base = 0, hll_off_base = 0;
 };
 struct CholOpts {
   int cap_leaf = 900;      // doubles of L per piece (pieces that share launches): small pieces, many resident per CU
@@ -258,9 +259,11 @@ inline int chol_symbolic(const SymIn& in, CholOpts opt, CholHost& out) {
   hoff.reserve(in.ppoff.size() + in.plblk.size());
   for (size_t i = 0; i < in.ppoff.size(); ++i) hoff[key(in.ppoff[i].first, in.ppoff[i].second)] = (int)(in.hpp_off_base + (int64_t)i * 36);
   for (size_t i = 0; i < in.plblk.size(); ++i) hoff[key(in.plblk[i].first, nPr + in.plblk[i].second)] = (int)(in.hpl_base + (int64_t)i * 18);
+  for (size_t i = 0; i < in.llblk.size(); ++i) hoff[key(nPr + in.llblk[i].first, nPr + in.llblk[i].second)] = (int)(in.hll_off_base + (int64_t)i * 9);
   std::vector<std::vector<int>> adj(nrow);
   for (auto& pr : in.ppoff) { adj[pr.first].push_back(pr.second); adj[pr.second].push_back(pr.first); }
   for (auto& pr : in.plblk) { adj[pr.first].push_back(nPr + pr.second); adj[nPr + pr.second].push_back(pr.first); }
+  for (auto& pr : in.llblk) { adj[nPr + pr.first].push_back(nPr + pr.second); adj[nPr + pr.second].push_back(nPr + pr.first); }
 
   // ---- per graph: ordering, elimination tree, pieces, final (piece-contiguous) elimination order ------------------
   std::vector<int> col_row, col_graph, col_piece, col_comp, col_tail;   // by final column id; piece = execution group, comp = connected piece

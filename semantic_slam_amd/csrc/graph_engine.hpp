@@ -112,6 +112,8 @@ struct Batch {
   std::vector<int> prow_pose, lrow_lm;
   std::vector<std::pair<int, int>> ppoff;         // unique pose-pose blocks (row a < row b)
   std::vector<std::pair<int, int>> plblk;         // unique pose-landmark blocks (pose row, lm row)
+  std::vector<std::pair<int, int>> llblk;         // unique landmark-landmark blocks (lm row a < lm row b): point-point edges
+  int64_t hll_off_base = 0;
   std::vector<int> pose_vertex, lm_vertex;        // global pose/lm index -> vertex id in its graph
   int64_t hpp_off_base = 0, hpl_base = 0, hll_base = 0;
   double* d_part_e = nullptr;  // [B*maxEdgeChunks]

@@ -9,7 +9,7 @@
 namespace sslam {
 
 enum { VT_SE3 = 0, VT_POINT = 1, VT_PLANE = 2 };
-enum { ET_SE3 = 0, ET_SE3_POINT = 1, ET_SE3_PLANE = 2 };
+enum { ET_SE3 = 0, ET_SE3_POINT = 1, ET_SE3_PLANE = 2, ET_POINT_POINT = 3 };   // 3: g2o::EdgePointXYZ (graph_slam.cpp:168-180)
 
 struct Options {
   int solver = 1;            // 0 PCG, 1 sparse block Cholesky

@@ -26,6 +26,7 @@ struct GraphSeg {
   int el0, nel;      // landmark edges
   int pose0, npose;  // all SE3 vertices (incl. fixed)
   int lm0, nlm;      // all landmark vertices
+  int ell0, nell;    // point-point edges (g2o::EdgePointXYZ)
 };
 
 struct LmState {
@@ -55,6 +56,14 @@ struct BatchView {
   // edges
   const int* eo_i; const int* eo_j; const double* eo_z; const double* eo_w; const int* eo_blk;  // eo_blk: off block idx*2 + swap, or -1
   const int* el_p; const int* el_l; const double* el_z; const double* el_w; const int* el_blk;
+  // point-point edges (g2o::EdgePointXYZ, reference graph_slam.cpp:168-180): e = (p_b - p_a) - z, Jacobians -I / +I
+  int nEll, nLL;                       // edges; unique landmark-landmark blocks
+  const int* ell_a; const int* ell_b;  // landmark indices
+  const double* ell_z; const double* ell_w;   // SoA: z[3][nEll], upper triangle of Omega [6][nEll]
+  const int* ell_id;                   // graph-local edge id (edge-sharded mode)
+  const int* llslot_ptr; const int2* llslot_rec;   // per landmark row: {edge, side (0: first vertex, 1: second)}
+  const int* llblk_ptr; const int* llblk_edge;     // per landmark-landmark block: its edges
+  double* Hll_off;                     // [nLL][9], block (row a < row b) = sum over its edges of -Omega
   // H
   double* Hpp_diag; double* Hll_diag; double* Hpp_off; double* Hpl; double* bvec;
   int64_t h_total;  // doubles in the H allocation

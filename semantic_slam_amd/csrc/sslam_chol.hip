@@ -943,8 +943,8 @@ void chol_sym_input(const Batch& b, SymIn& in) {
   in.B = b.V.B; in.nPr = b.V.nPr; in.nLr = b.V.nLr;
   in.seg.resize(b.seg.size());
   for (size_t g = 0; g < b.seg.size(); ++g) in.seg[g] = SymGraph{b.seg[g].prow0, b.seg[g].nprow, b.seg[g].lrow0, b.seg[g].nlrow};
-  in.ppoff = b.ppoff; in.plblk = b.plblk;
-  in.hll_base = b.hll_base; in.hpp_off_base = b.hpp_off_base; in.hpl_base = b.hpl_base;
+  in.ppoff = b.ppoff; in.plblk = b.plblk; in.llblk = b.llblk;
+  in.hll_base = b.hll_base; in.hpp_off_base = b.hpp_off_base; in.hpl_base = b.hpl_base; in.hll_off_base = b.hll_off_base;
 }
 
 int chol_plan_build(Batch& b) {

@@ -38,7 +38,7 @@ __global__ __launch_bounds__(kEdgeChunk) void k_chi2(BatchView V, const double* 
   if (mask_mode == 2 && !S.active) return;
   const GraphSeg sg = V.seg[g];
   const int e = blockIdx.x * kEdgeChunk + threadIdx.x;
-  if (blockIdx.x * kEdgeChunk >= sg.neo + sg.nel) return;
+  if (blockIdx.x * kEdgeChunk >= sg.neo + sg.nel + sg.nell) return;
   double c = 0;
   if (e < sg.neo) {
     const int k = sg.eo0 + e;
@@ -79,6 +79,16 @@ __global__ __launch_bounds__(kEdgeChunk) void k_chi2(BatchView V, const double* 
       c += err[r] * a;
     }
     if (V.dcs_phi > 0) c *= dcs_rho1(V.dcs_phi, c);
+  } else if (e < sg.neo + sg.nel + sg.nell) {   // g2o::EdgePointXYZ: e = (p_b - p_a) - z
+    const int k = sg.ell0 + (e - sg.neo - sg.nel);
+    const size_t n = V.nEll;
+    const double* pa = lmk + (size_t)V.ell_a[k] * 4;
+    const double* pb = lmk + (size_t)V.ell_b[k] * 4;
+    double err[3], W[9];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) err[r] = (pb[r] - pa[r]) - V.ell_z[r * n + k];
+    load_sym3(V.ell_w, (int)n, k, W);
+    c = quad3(W, err);
   }
   const double s = block_sum<kEdgeChunk>(c, red);
   if (threadIdx.x == 0) part[(size_t)g * V.maxEdgeChunks + blockIdx.x] = s;
@@ -704,6 +714,34 @@ __global__ __launch_bounds__(256) void k_linearize_lm_rows(BatchView V) {
       }
     }
   }
+  if (live && V.nEll > 0) {
+    // point-point edges of this landmark: J = -I on the first vertex, +I on the second  ->  H_ll += Omega, b -/+= Omega e
+    const size_t n = V.nEll;
+    for (int s = V.llslot_ptr[l] + lane; s < V.llslot_ptr[l + 1]; s += 16) {
+      const int2 rec = V.llslot_rec[s];
+      const int k = rec.x;
+      const double* pa = V.lmk + (size_t)V.ell_a[k] * 4;
+      const double* pb = V.lmk + (size_t)V.ell_b[k] * 4;
+      double err[3], W[9];
+#pragma unroll
+      for (int r = 0; r < 3; ++r) err[r] = (pb[r] - pa[r]) - V.ell_z[r * n + k];
+      load_sym3(V.ell_w, (int)n, k, W);
+      if (SHARD) {
+        const int g = V.lrow_graph[l];
+        if (!(V.ell_id[k] >= V.shard_lo[g] && V.ell_id[k] < V.shard_hi[g])) {
+#pragma unroll
+          for (int q = 0; q < 9; ++q) W[q] = 0.0;
+        }
+      }
+      const double sgn = rec.y ? -1.0 : 1.0;   // b = -J^T Omega e
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) acc[a * 3 + c] += W[a * 3 + c];
+        acc[9 + a] += sgn * (W[a * 3 + 0] * err[0] + W[a * 3 + 1] * err[1] + W[a * 3 + 2] * err[2]);
+      }
+    }
+  }
 #pragma unroll
   for (int q = 0; q < 12; ++q) {
     double v = acc[q];
@@ -716,6 +754,27 @@ __global__ __launch_bounds__(256) void k_linearize_lm_rows(BatchView V) {
 #pragma unroll
     for (int q = 0; q < 3; ++q) V.bvec[(size_t)6 * V.nPr + (size_t)3 * l + q] = acc[9 + q];
   }
+}
+
+// landmark-landmark blocks of the point-point edges: block (a, b) = sum over the edges on that pair of J_a^T Omega J_b = -Omega
+template <bool SHARD>
+__global__ __launch_bounds__(64) void k_linearize_ll(BatchView V) {
+  const int i = blockIdx.x * 64 + threadIdx.x;
+  if (i >= V.nLL) return;
+  const int e0 = V.llblk_ptr[i], e1 = V.llblk_ptr[i + 1];
+  const int g = V.lrow_graph[V.lm_row[V.ell_a[V.llblk_edge[e0]]]];
+  if (!V.lm[g].lin) return;
+  double acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  for (int e = e0; e < e1; ++e) {
+    const int k = V.llblk_edge[e];
+    if (SHARD && !(V.ell_id[k] >= V.shard_lo[g] && V.ell_id[k] < V.shard_hi[g])) continue;
+    double W[9];
+    load_sym3(V.ell_w, V.nEll, k, W);
+#pragma unroll
+    for (int q = 0; q < 9; ++q) acc[q] -= W[q];
+  }
+#pragma unroll
+  for (int q = 0; q < 9; ++q) V.Hll_off[(size_t)i * 9 + q] = acc[q];
 }
 
 // Further edges on an already-owned vertex pair (e.g. a repeated loop closure): their off-diagonal
@@ -825,7 +884,7 @@ __global__ __launch_bounds__(kRowChunk) void k_maxdiag(BatchView V, double* __re
 }
 
 __device__ __forceinline__ int row_chunks(const GraphSeg& sg) { return (sg.nprow * 6 + sg.nlrow * 3 + kRowChunk - 1) / kRowChunk; }
-__device__ __forceinline__ int edge_chunks(const GraphSeg& sg) { return (sg.neo + sg.nel + kEdgeChunk - 1) / kEdgeChunk; }
+__device__ __forceinline__ int edge_chunks(const GraphSeg& sg) { return (sg.neo + sg.nel + sg.nell + kEdgeChunk - 1) / kEdgeChunk; }
 
 // One wave per graph, once per step.  A *step* is one damping trial: graphs flagged `lin` have just been re-linearised and
 // start a new LM iteration (q = 0; lambda = tau * max diag on the very first one), the others are retrying the
@@ -854,7 +913,7 @@ __global__ void k_lm_init(BatchView V, const double* __restrict__ part_chi, int 
   const GraphSeg sg = V.seg[g];
   const double c = wave_sum_partials(part_chi + (size_t)g * V.maxEdgeChunks, edge_chunks(sg));
   if (threadIdx.x == 0) {
-    const bool few = sg.neo + sg.nel < min_edges;
+    const bool few = sg.neo + sg.nel + sg.nell < min_edges;
     S.cur_chi = c; S.chi_before = c; S.iter = 0; S.trials = 0; S.pcg_iters = 0;
     S.status = few ? -5 : 0; S.active = few ? 0 : 1; S.lin = few ? 0 : 1;
     S.in_trial = 0; S.accept = 0; S.lambda = 0; S.nu = 2; S.rho = 0; S.q = 0; S.solve_failed = 0;
@@ -1062,6 +1121,12 @@ __global__ __launch_bounds__(kRowChunk) void k_spmv(BatchView V, int parity) {
       } else if (fmt == 2) {
 #pragma unroll
         for (int c = 0; c < 3; ++c) acc += Bk[R.r * 3 + c] * pn[c];
+      } else if (fmt == 4) {       // landmark-landmark block, this row first
+#pragma unroll
+        for (int c = 0; c < 3; ++c) acc += Bk[R.r * 3 + c] * pn[c];
+      } else if (fmt == 5) {       // landmark-landmark block, this row second
+#pragma unroll
+        for (int c = 0; c < 3; ++c) acc += Bk[c * 3 + R.r] * pn[c];
       } else {
 #pragma unroll
         for (int c = 0; c < 6; ++c) acc += Bk[c * 3 + R.r] * pn[c];
@@ -1305,12 +1370,13 @@ static int batch_build(Batch& b, bool host_only = false) {
   b.seg.assign(B, GraphSeg{});
   b.v2pose.assign(B, {}); b.v2lm.assign(B, {});
   b.pose_row.clear(); b.lm_row.clear(); b.prow_pose.clear(); b.lrow_lm.clear();
-  b.ppoff.clear(); b.plblk.clear(); b.pose_vertex.clear(); b.lm_vertex.clear();
+  b.ppoff.clear(); b.plblk.clear(); b.llblk.clear(); b.pose_vertex.clear(); b.lm_vertex.clear();
   std::vector<int> prow_graph, lrow_graph;
   std::vector<unsigned char> lm_kind;
   std::vector<int> eo_i, eo_j, eo_blk, el_p, el_l, el_blk;
   std::vector<int> eo_src, el_src;  // (graph-local edge id) for SoA fill
   std::vector<int> eo_g, el_g;
+  std::vector<int> ell_a, ell_b, ell_src, ell_g, ell_blk;   // point-point edges (g2o::EdgePointXYZ)
   std::vector<int> shard_lo(b.graphs.size(), 0), shard_hi(b.graphs.size(), 0x7fffffff);
   int maxRow = 1, maxEdge = 1;
   for (int g = 0; g < B; ++g) {
@@ -1320,7 +1386,7 @@ static int batch_build(Batch& b, bool host_only = false) {
     GraphSeg& sg = b.seg[g];
     sg.pose0 = (int)b.pose_row.size(); sg.lm0 = (int)b.lm_row.size();
     sg.prow0 = (int)b.prow_pose.size(); sg.lrow0 = (int)b.lrow_lm.size();
-    sg.eo0 = (int)eo_i.size(); sg.el0 = (int)el_p.size();
+    sg.eo0 = (int)eo_i.size(); sg.el0 = (int)el_p.size(); sg.ell0 = (int)ell_a.size();
     auto& vp = b.v2pose[g]; auto& vl = b.v2lm[g];
     vp.assign(G.nv(), -1); vl.assign(G.nv(), -1);
     for (int v = 0; v < G.nv(); ++v) {
@@ -1341,16 +1407,33 @@ static int batch_build(Batch& b, bool host_only = false) {
     sg.nprow = (int)b.prow_pose.size() - sg.prow0; sg.nlrow = (int)b.lrow_lm.size() - sg.lrow0;
     for (int k = 0; k < G.ne(); ++k) {
       if (G.etype[k] == ET_SE3) { eo_i.push_back(vp[G.evi[k]]); eo_j.push_back(vp[G.evj[k]]); eo_src.push_back(k); eo_g.push_back(g); }
+      else if (G.etype[k] == ET_POINT_POINT) { ell_a.push_back(vl[G.evi[k]]); ell_b.push_back(vl[G.evj[k]]); ell_src.push_back(k); ell_g.push_back(g); }
       else { el_p.push_back(vp[G.evi[k]]); el_l.push_back(vl[G.evj[k]]); el_src.push_back(k); el_g.push_back(g); }
     }
-    sg.neo = (int)eo_i.size() - sg.eo0; sg.nel = (int)el_p.size() - sg.el0;
+    sg.neo = (int)eo_i.size() - sg.eo0; sg.nel = (int)el_p.size() - sg.el0; sg.nell = (int)ell_a.size() - sg.ell0;
     maxRow = std::max(maxRow, (sg.nprow * 6 + sg.nlrow * 3 + kRowChunk - 1) / kRowChunk);
-    maxEdge = std::max(maxEdge, (sg.neo + sg.nel + kEdgeChunk - 1) / kEdgeChunk);
+    maxEdge = std::max(maxEdge, (sg.neo + sg.nel + sg.nell + kEdgeChunk - 1) / kEdgeChunk);
   }
   const int nPr = (int)b.prow_pose.size(), nLr = (int)b.lrow_lm.size();
-  const int nEo = (int)eo_i.size(), nEl = (int)el_p.size();
+  const int nEo = (int)eo_i.size(), nEl = (int)el_p.size(), nEll = (int)ell_a.size();
   // unique off-diagonal blocks
-  std::unordered_map<uint64_t, int> ppmap, plmap;
+  std::unordered_map<uint64_t, int> ppmap, plmap, llmap;
+  std::vector<std::vector<int>> llblk_edges;                 // per landmark-landmark block: its edges
+  std::vector<std::vector<std::pair<int, int>>> llslots(nLr);   // per landmark row: {edge, side}
+  ell_blk.assign(nEll, -1);
+  for (int k = 0; k < nEll; ++k) {
+    const int ra = b.lm_row[ell_a[k]], rb = b.lm_row[ell_b[k]];
+    if (ra >= 0) llslots[ra].push_back({k, 0});
+    if (rb >= 0) llslots[rb].push_back({k, 1});
+    if (ra < 0 || rb < 0 || ra == rb) continue;
+    const int a = std::min(ra, rb), c = std::max(ra, rb);
+    auto it = llmap.find(pair_key(a, c));
+    int idx;
+    if (it == llmap.end()) { idx = (int)b.llblk.size(); llmap.emplace(pair_key(a, c), idx); b.llblk.push_back({a, c}); llblk_edges.push_back({}); }
+    else idx = it->second;
+    llblk_edges[idx].push_back(k);
+    ell_blk[k] = idx;
+  }
   eo_blk.assign(nEo, -1); el_blk.assign(nEl, -1);
   for (int k = 0; k < nEo; ++k) {
     const int ri = b.pose_row[eo_i[k]], rj = b.pose_row[eo_j[k]];
@@ -1444,11 +1527,12 @@ static int batch_build(Batch& b, bool host_only = false) {
       r = r1;
     }
   }
-  const int nPP = (int)b.ppoff.size(), nPL = (int)b.plblk.size();
+  const int nPP = (int)b.ppoff.size(), nPL = (int)b.plblk.size(), nLL = (int)b.llblk.size();
   b.hll_base = (int64_t)nPr * 36;
   b.hpp_off_base = b.hll_base + (((int64_t)nLr * 9 + 1) & ~(int64_t)1);   // even: the 6-wide blocks behind it stay 16-byte aligned
   b.hpl_base = b.hpp_off_base + (int64_t)nPP * 36;
-  const int64_t h_total = b.hpl_base + (int64_t)nPL * 18;
+  b.hll_off_base = b.hpl_base + (int64_t)nPL * 18;
+  const int64_t h_total = b.hll_off_base + (int64_t)nLL * 9;
   if (h_total >= (int64_t)1 << 31) return set_error(SSLAM_ERR_INVALID, "batch too large: H has %lld doubles (int32 block offsets)", (long long)h_total);
   if (host_only) {   // symbolic structure only (plan introspection on a box without a GPU)
     memset(&b.V, 0, sizeof b.V);
@@ -1468,6 +1552,12 @@ static int batch_build(Batch& b, bool host_only = false) {
     const int off = (int)(b.hpl_base + (int64_t)i * 18);
     adj[rp].push_back({off, 6 * nPr + 3 * rl, 2});
     adj[nPr + rl].push_back({off, 6 * rp, 3});
+  }
+  for (int i = 0; i < nLL; ++i) {
+    const int a = b.llblk[i].first, c = b.llblk[i].second;
+    const int off = (int)(b.hll_off_base + (int64_t)i * 9);
+    adj[nPr + a].push_back({off, 6 * nPr + 3 * c, 4});
+    adj[nPr + c].push_back({off, 6 * nPr + 3 * a, 5});
   }
   std::vector<int> adj_ptr(nPr + nLr + 1, 0), adj_blk, adj_x;
   std::vector<unsigned char> adj_fmt;
@@ -1492,11 +1582,23 @@ static int batch_build(Batch& b, bool host_only = false) {
     int q = 0;
     for (int r = 0; r < 3; ++r) for (int c = r; c < 3; ++c) el_w[(size_t)(q++) * nEl + k] = G.info[(size_t)s * 36 + r * 3 + c];
   }
+  std::vector<double> ell_z((size_t)3 * nEll), ell_w((size_t)6 * nEll);
+  for (int k = 0; k < nEll; ++k) {
+    const HostGraph& G = *b.graphs[ell_g[k]];
+    const int s = ell_src[k];
+    for (int c = 0; c < 3; ++c) ell_z[(size_t)c * nEll + k] = G.meas[(size_t)s * 7 + c];
+    int q = 0;
+    for (int r = 0; r < 3; ++r) for (int c = r; c < 3; ++c) ell_w[(size_t)(q++) * nEll + k] = G.info[(size_t)s * 36 + r * 3 + c];
+  }
+  std::vector<int> llslot_ptr(nLr + 1, 0), llblk_ptr(nLL + 1, 0), llblk_edge;
+  std::vector<int2> llslot_rec;
+  for (int r = 0; r < nLr; ++r) { for (auto& q : llslots[r]) llslot_rec.push_back(make_int2(q.first, q.second)); llslot_ptr[r + 1] = (int)llslot_rec.size(); }
+  for (int i = 0; i < nLL; ++i) { for (int k : llblk_edges[i]) llblk_edge.push_back(k); llblk_ptr[i + 1] = (int)llblk_edge.size(); }
   // ---- device allocation
   BatchView& V = b.V;
   memset(&V, 0, sizeof V);
   V.B = B; V.nPr = nPr; V.nLr = nLr; V.nPose = (int)b.pose_row.size(); V.nLm = (int)b.lm_row.size();
-  V.nEo = nEo; V.nEl = nEl; V.maxRowChunks = maxRow; V.maxEdgeChunks = maxEdge;
+  V.nEo = nEo; V.nEl = nEl; V.nEll = nEll; V.nLL = nLL; V.maxRowChunks = maxRow; V.maxEdgeChunks = maxEdge;
   V.h_total = h_total;
   V.dcs_phi = b.graphs[0]->opt.dcs_phi;
   int rc;
@@ -1510,6 +1612,8 @@ static int batch_build(Batch& b, bool host_only = false) {
   UP(lslot_ptr, lslot_ptr); UP(lslot_edge, lslot_edge);
   UP(b.dup_eo, dup_eo); UP(b.dup_el, dup_el); UP(pslot_rec, pslot_rec);
   UP(eo_src, eo_id); UP(el_src, el_id); UP(shard_lo, shard_lo); UP(shard_hi, shard_hi);
+  UP(ell_a, ell_a); UP(ell_b, ell_b); UP(ell_z, ell_z); UP(ell_w, ell_w); UP(ell_src, ell_id);
+  UP(llslot_ptr, llslot_ptr); UP(llslot_rec, llslot_rec); UP(llblk_ptr, llblk_ptr); UP(llblk_edge, llblk_edge);
   V.nDupEo = (int)b.dup_eo.size(); V.nDupEl = (int)b.dup_el.size();
   V.nTiles = (int)tile_row0.size();
 #undef UP
@@ -1517,7 +1621,7 @@ static int batch_build(Batch& b, bool host_only = false) {
   const size_t dim = (size_t)6 * nPr + (size_t)3 * nLr;
   const size_t h_even = ((size_t)h_total + 1) & ~(size_t)1;   // b right behind H (16-byte aligned): [H || b] is one all-reduce buffer
   if ((rc = dev_alloc(b, h_even + dim, &H))) return rc;
-  V.Hpp_diag = H; V.Hll_diag = H + b.hll_base; V.Hpp_off = H + b.hpp_off_base; V.Hpl = H + b.hpl_base;
+  V.Hpp_diag = H; V.Hll_diag = H + b.hll_base; V.Hpp_off = H + b.hpp_off_base; V.Hpl = H + b.hpl_base; V.Hll_off = H + b.hll_off_base;
   V.bvec = H + h_even;
   b.hb_doubles = (int64_t)(h_even + dim);
   if ((rc = dev_alloc(b, (size_t)V.nPose * 8, &V.pose))) return rc;
@@ -1615,6 +1719,7 @@ static int batch_linearize(Batch& b) {
       else hipLaunchKernelGGL((k_linearize_rowthread<PLV, SHV>), dim3(nblk), dim3(kRowThreads), 0, b.stream, V);                      \
     }                                                                                                                                 \
     if (V.nLr > 0) hipLaunchKernelGGL((k_linearize_lm_rows<PLV, SHV>), dim3((V.nLr + 15) / 16), dim3(256), 0, b.stream, V);           \
+    if (V.nLL > 0) hipLaunchKernelGGL((k_linearize_ll<SHV>), dim3((V.nLL + 63) / 64), dim3(64), 0, b.stream, V);                      \
   }
   if (b.sharded) {
     // edge-sharded mode: the rank-partial system is built in its own buffer and summed OUT OF PLACE into [H || b].  A graph that does not
@@ -1623,7 +1728,7 @@ static int batch_linearize(Batch& b) {
     // graph by `world` on every step: the damping of a retried trial would fall instead of rising -- round-2 ADVICE.)
     BatchView Vp = V;
     Vp.Hpp_diag = b.d_hb_part; Vp.Hll_diag = b.d_hb_part + b.hll_base; Vp.Hpp_off = b.d_hb_part + b.hpp_off_base;
-    Vp.Hpl = b.d_hb_part + b.hpl_base; Vp.bvec = b.d_hb_part + (V.bvec - V.Hpp_diag);
+    Vp.Hpl = b.d_hb_part + b.hpl_base; Vp.Hll_off = b.d_hb_part + b.hll_off_base; Vp.bvec = b.d_hb_part + (V.bvec - V.Hpp_diag);
     {
       const BatchView& V = Vp;
       if (b.has_planes) SSLAM_LAUNCH_LIN(true, true) else SSLAM_LAUNCH_LIN(false, true)
@@ -1649,6 +1754,8 @@ static int batch_linearize(Batch& b) {
 static int pcg_solve(Batch& b) {
   const Options& opt = b.graphs[0]->opt;
   const BatchView& V = b.V;
+  if (opt.solver == 2 && V.nLL > 0)
+    return set_error(SSLAM_ERR_UNSUPPORTED, "solver 2 (Schur complement on the landmark block) needs a block-diagonal landmark block: the graph holds point-point edges");
   { ScopedTimer t(b, "precond");
     hipLaunchKernelGGL(k_precond, dim3(vert_blocks(b)), dim3(256), 0, b.stream, V); }
   const bool schur = opt.solver == 2;
@@ -1864,8 +1971,8 @@ static int add_edge(sslam_graph* h, int type, int i, int j, const double* z, int
   if (!h || !z || !info) return set_error(SSLAM_ERR_INVALID, "null argument");
   HostGraph& G = h->g;
   if (i < 0 || j < 0 || i >= G.nv() || j >= G.nv() || i == j) return set_error(SSLAM_ERR_INVALID, "edge vertex ids (%d,%d) invalid", i, j);
-  if (G.vtype[i] != VT_SE3) return set_error(SSLAM_ERR_INVALID, "vertex %d is not an SE3 vertex", i);
-  const int want = type == ET_SE3 ? VT_SE3 : (type == ET_SE3_POINT ? VT_POINT : VT_PLANE);
+  if (G.vtype[i] != (type == ET_POINT_POINT ? VT_POINT : VT_SE3)) return set_error(SSLAM_ERR_INVALID, "vertex %d has the wrong type for this edge", i);
+  const int want = type == ET_SE3 ? VT_SE3 : ((type == ET_SE3_POINT || type == ET_POINT_POINT) ? VT_POINT : VT_PLANE);
   if (G.vtype[j] != want) return set_error(SSLAM_ERR_INVALID, "vertex %d has the wrong type for this edge", j);
   // only the upper triangle of the information matrix travels to the device: an asymmetric one would be symmetrised silently
   double amax = 0;
@@ -1893,6 +2000,10 @@ int sslam_graph_add_edge_se3_plane(sslam_graph* h, int i, int l, const double z[
   if (!(nn > 0)) return set_error(SSLAM_ERR_INVALID, "plane normal has zero length");
   const double p[4] = {z[0] / nn, z[1] / nn, z[2] / nn, z[3] / nn};
   return add_edge(h, ET_SE3_PLANE, i, l, p, 4, info, 3);
+}
+
+int sslam_graph_add_edge_point_point(sslam_graph* h, int l1, int l2, const double z[3], const double info[9]) {
+  return add_edge(h, ET_POINT_POINT, l1, l2, z, 3, info, 3);
 }
 
 int sslam_graph_num_vertices(const sslam_graph* h) { return h ? h->g.nv() : SSLAM_ERR_INVALID; }
@@ -1996,7 +2107,7 @@ int sslam_graph_linearize(sslam_graph* h, int* dim, int64_t* nnz_upper, int32_t*
   const int n = hessian_indices(h->g, hidx);
   *dim = n;
   const int nPr = b.V.nPr, nLr = b.V.nLr;
-  const int64_t nnz = (int64_t)nPr * 21 + (int64_t)nLr * 6 + (int64_t)b.ppoff.size() * 36 + (int64_t)b.plblk.size() * 18;
+  const int64_t nnz = (int64_t)nPr * 21 + (int64_t)nLr * 6 + (int64_t)b.ppoff.size() * 36 + (int64_t)b.plblk.size() * 18 + (int64_t)b.llblk.size() * 9;
   *nnz_upper = nnz;
   if (!rows || !cols || !vals || !bout) return 0;
   if ((rc = do_linearize(h))) return rc;
@@ -2022,6 +2133,13 @@ int sslam_graph_linearize(sslam_graph* h, int* dim, int64_t* nnz_upper, int32_t*
   for (size_t i = 0; i < b.plblk.size(); ++i) {
     const int op = prow_off(b.plblk[i].first), ol = lrow_off(b.plblk[i].second);
     for (int a = 0; a < 6; ++a) for (int c = 0; c < 3; ++c) emit(op + a, ol + c, H[(size_t)b.hpl_base + i * 18 + a * 3 + c]);
+  }
+  for (size_t i = 0; i < b.llblk.size(); ++i) {   // emit() orders (row, column) into the upper triangle; the block is symmetric (-Omega)
+    const int oa = lrow_off(b.llblk[i].first), oc = lrow_off(b.llblk[i].second);
+    for (int a = 0; a < 3; ++a) for (int c = 0; c < 3; ++c) {
+      const double v = H[(size_t)b.hll_off_base + i * 9 + a * 3 + c];
+      if (oa < oc) emit(oa + a, oc + c, v); else emit(oc + c, oa + a, v);
+    }
   }
   return 0;
 }
@@ -2200,6 +2318,10 @@ int sslam_graph_save_g2o(const sslam_graph* h, const char* path) {
       fprintf(f, "EDGE_SE3_TRACKXYZ %d %d 0", G.evi[k], G.evj[k]);
       for (int c = 0; c < 3; ++c) fprintf(f, " %.17g", z[c]);
       for (int r = 0; r < 3; ++r) for (int c = r; c < 3; ++c) fprintf(f, " %.17g", W[r * 3 + c]);
+    } else if (G.etype[k] == ET_POINT_POINT) {   // g2o::EdgePointXYZ
+      fprintf(f, "EDGE_POINTXYZ %d %d", G.evi[k], G.evj[k]);
+      for (int c = 0; c < 3; ++c) fprintf(f, " %.17g", z[c]);
+      for (int r = 0; r < 3; ++r) for (int c = r; c < 3; ++c) fprintf(f, " %.17g", W[r * 3 + c]);
     } else {  // row format of the in-tree EdgeSE3Plane::write (edge_se3_plane.hpp:40-47)
       fprintf(f, "EDGE_SE3_PLANE %d %d", G.evi[k], G.evj[k]);
       for (int c = 0; c < 4; ++c) fprintf(f, " %.17g", z[c]);
@@ -2236,6 +2358,11 @@ int sslam_graph_load_g2o(sslam_graph* h, const char* path) {
       if (fscanf(f, "%d %d %d", &i, &j, &pid) != 3 || !rd(z, 3) || !rd(u, 6) || !idmap.count(i) || !idmap.count(j)) { rc = -1; break; }
       int q = 0; for (int r = 0; r < 3; ++r) for (int c = r; c < 3; ++c) { W[r * 3 + c] = u[q]; W[c * 3 + r] = u[q]; ++q; }
       if (add_edge(h, ET_SE3_POINT, idmap[i], idmap[j], z, 3, W, 3) < 0) { rc = -1; break; }
+    } else if (t == "EDGE_POINTXYZ") {
+      int i, j; double z[3], u[6], W[9];
+      if (fscanf(f, "%d %d", &i, &j) != 2 || !rd(z, 3) || !rd(u, 6) || !idmap.count(i) || !idmap.count(j)) { rc = -1; break; }
+      int q = 0; for (int r = 0; r < 3; ++r) for (int c = r; c < 3; ++c) { W[r * 3 + c] = u[q]; W[c * 3 + r] = u[q]; ++q; }
+      if (add_edge(h, ET_POINT_POINT, idmap[i], idmap[j], z, 3, W, 3) < 0) { rc = -1; break; }
     } else if (t == "EDGE_SE3_PLANE") {
       int i, j; double z[4], u[6], W[9];
       if (fscanf(f, "%d %d", &i, &j) != 2 || !rd(z, 4) || !rd(u, 6) || !idmap.count(i) || !idmap.count(j)) { rc = -1; break; }
@@ -2434,7 +2561,8 @@ int64_t sslam_batch_linearize_bytes(const sslam_batch* h) {
   int64_t bytes = 0;
   for (size_t g = 0; g < b.graphs.size(); ++g) {
     const HostGraph& G = *b.graphs[g];
-    for (int k = 0; k < G.ne(); ++k) bytes += G.etype[k] == ET_SE3 ? 344 + 288 : (G.etype[k] == ET_SE3_POINT ? 160 + 144 : 176 + 144);
+    for (int k = 0; k < G.ne(); ++k)
+      bytes += G.etype[k] == ET_SE3 ? 344 + 288 : (G.etype[k] == ET_SE3_POINT ? 160 + 144 : (G.etype[k] == ET_SE3_PLANE ? 176 + 144 : 8 + 24 + 48 + 48 + 72));
   }
   bytes += (int64_t)b.V.nPr * (288 + 48) + (int64_t)b.V.nLr * (72 + 24);
   return bytes;

@@ -125,6 +125,7 @@ inline void plan_graph(const SymIn& in, int g, const WOpts& opt, const std::unor
     auto row2loc = [&](int r) { return r < nPr ? r - sg.prow0 : sg.nprow + (r - nPr - sg.lrow0); };
     for (int k = sg.pp0; k < sg.pp1; ++k) { const int a = row2loc(in.ppoff[k].first), c = row2loc(in.ppoff[k].second); ladj[a].push_back(c); ladj[c].push_back(a); }
     for (int k = sg.pl0; k < sg.pl1; ++k) { const int a = row2loc(in.plblk[k].first), c = row2loc(nPr + in.plblk[k].second); ladj[a].push_back(c); ladj[c].push_back(a); }
+    for (int k = sg.ll0; k < sg.ll1; ++k) { const int a = row2loc(nPr + in.llblk[k].first), c = row2loc(nPr + in.llblk[k].second); ladj[a].push_back(c); ladj[c].push_back(a); }
   }
   GraphSym S;
   chol_detail::min_degree(n, ladj, S);
@@ -299,10 +300,11 @@ inline int wchol_symbolic(const SymIn& in, const WOpts& opt, WHost& out) {
   hoff.reserve(in.ppoff.size() + in.plblk.size());
   for (size_t i = 0; i < in.ppoff.size(); ++i) hoff[key(in.ppoff[i].first, in.ppoff[i].second)] = (int)(in.hpp_off_base + (int64_t)i * 36);
   for (size_t i = 0; i < in.plblk.size(); ++i) hoff[key(in.plblk[i].first, in.nPr + in.plblk[i].second)] = (int)(in.hpl_base + (int64_t)i * 18);
+  for (size_t i = 0; i < in.llblk.size(); ++i) hoff[key(in.nPr + in.llblk[i].first, in.nPr + in.llblk[i].second)] = (int)(in.hll_off_base + (int64_t)i * 9);
   // the off-diagonal blocks of every graph are a contiguous range of ppoff / plblk (batch_build emits them graph by graph)
   SymIn in2 = in;
   {
-    size_t pp = 0, pl = 0;
+    size_t pp = 0, pl = 0, ll = 0;
     for (int g = 0; g < B; ++g) {
       SymGraph& sg = in2.seg[g];
       sg.pp0 = (int)pp;
@@ -311,8 +313,11 @@ inline int wchol_symbolic(const SymIn& in, const WOpts& opt, WHost& out) {
       sg.pl0 = (int)pl;
       while (pl < in.plblk.size() && in.plblk[pl].first >= sg.prow0 && in.plblk[pl].first < sg.prow0 + sg.nprow) ++pl;
       sg.pl1 = (int)pl;
+      sg.ll0 = (int)ll;
+      while (ll < in.llblk.size() && in.llblk[ll].first >= sg.lrow0 && in.llblk[ll].first < sg.lrow0 + sg.nlrow) ++ll;
+      sg.ll1 = (int)ll;
     }
-    if (pp != in.ppoff.size() || pl != in.plblk.size()) { out.error = "off-diagonal blocks are not grouped by graph"; return -1; }
+    if (pp != in.ppoff.size() || pl != in.plblk.size() || ll != in.llblk.size()) { out.error = "off-diagonal blocks are not grouped by graph"; return -1; }
   }
   std::vector<GraphPlan> gp(B);
   {

@@ -92,6 +92,12 @@ class GraphSLAM:
         w = np.ascontiguousarray(information_matrix, np.float64).reshape(9)
         return _check(self._lib, self._lib.sslam_graph_add_edge_se3_plane(self._h, v_se3, v_plane, _dptr(z), _dptr(w)))
 
+    def add_point_xyz_point_xyz_edge(self, v1_xyz: int, v2_xyz: int, xyz, information_matrix) -> int:
+        """graph_slam.cpp:168-180: g2o::EdgePointXYZ between two point landmarks, measurement = p2 - p1"""
+        z = np.ascontiguousarray(xyz, np.float64).reshape(3)
+        w = np.ascontiguousarray(information_matrix, np.float64).reshape(9)
+        return _check(self._lib, self._lib.sslam_graph_add_edge_point_point(self._h, v1_xyz, v2_xyz, _dptr(z), _dptr(w)))
+
     # -- queries -----------------------------------------------------------------------------
     def num_vertices(self) -> int:
         return self._lib.sslam_graph_num_vertices(self._h)
@@ -219,6 +225,8 @@ class GraphSLAM:
                 G.add_se3_edge(i, j, gp.meas[k], gp.info[k].reshape(6, 6))
             elif t == 1:
                 G.add_se3_point_xyz_edge(i, j, gp.meas[k, :3], gp.info[k, :9].reshape(3, 3))
+            elif t == 3:
+                G.add_point_xyz_point_xyz_edge(i, j, gp.meas[k, :3], gp.info[k, :9].reshape(3, 3))
             else:
                 G.add_se3_plane_edge(i, j, gp.meas[k, :4], gp.info[k, :9].reshape(3, 3))
         return G

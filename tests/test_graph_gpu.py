@@ -341,6 +341,39 @@ def test_dcs_robust_kernel_matches_oracle(gpu_lib):
         assert G.chi2() == pytest.approx(gp.chi2(), rel=1e-9)          # kernel off again: the plain chi2 of the optimised state
 
 
+@pytest.mark.parametrize("solver", [1, 3, 0])
+def test_point_point_edges_match_oracle(gpu_lib, solver, tmp_path):
+    """add_point_xyz_point_xyz_edge (g2o::EdgePointXYZ, reference graph_slam.cpp:168-180): landmark-landmark blocks in H (the landmark
+    block is no longer block diagonal), two edges on one vertex pair; chi2, the normal equations, the optimised estimates and the g2o
+    text round trip against the oracle; solver 2 (Schur on the landmarks) refuses such a graph"""
+    from semantic_slam_amd import GraphSLAM
+    from semantic_slam_amd.graph_slam import SslamError
+    from tests.test_oracle_graph import _with_point_point_edges
+    rng = np.random.default_rng(9)
+    gp = _with_point_point_edges(GraphProblem.from_synth(make_graph(90, 18, seed=6), interleave=True), rng, n_extra=20)
+    G = GraphSLAM.from_problem(gp)
+    G.set_option("solver", solver)
+    assert G.chi2() == pytest.approx(gp.chi2(), rel=1e-12)
+    U, b = G.linearize()
+    Uo, bo = gp.linearize()
+    assert np.abs((U - Uo).toarray()).max() <= 1e-11 * np.abs(Uo.toarray()).max() and np.abs(b - bo).max() <= 1e-11 * np.abs(bo).max()
+    x, _ = G.solve(0.7)
+    xr = gp.solve(0.7)
+    assert np.abs(x - xr).max() <= (1e-6 if solver == 0 else 1e-8) * np.abs(xr).max()
+    path = str(tmp_path / "pp.g2o")
+    G.save(path)
+    G2 = GraphSLAM(); G2.load(path)
+    assert G2.num_edges() == gp.ne and G2.chi2() == pytest.approx(gp.chi2(), rel=1e-12)
+    assert G.optimize(12)
+    st = gp.optimize(12)
+    assert G.last_stats.chi2_after == pytest.approx(st.chi2_after, rel=1e-6)
+    assert np.abs(G.estimates() - gp.est).max() <= 1e-4 * np.abs(gp.est).max()
+    if solver == 1:
+        G.set_option("solver", 2)
+        with pytest.raises(SslamError):
+            G.solve(0.7)
+
+
 def test_too_few_edges_returns_false(gpu_lib):
     from semantic_slam_amd import GraphSLAM
     G = GraphSLAM()

@@ -268,3 +268,54 @@ def test_dcs_robust_kernel_follows_g2o_robustify():
     assert np.abs(H1 - Hd).max() <= 1e-10 * np.abs(Hd).max() and np.abs(b1 - bd).max() <= 1e-10 * np.abs(bd).max()
     assert np.abs((U1 - U0).toarray()).max() > 0
     assert st.chi2_after <= chi_dcs
+
+
+def _with_point_point_edges(gp, rng, n_extra=12):
+    """append g2o::EdgePointXYZ edges (reference graph_slam.cpp:168-180) between random pairs of point landmarks: measurement = true
+    offset + noise, information 4 I (+ a little off-diagonal so that the symmetric-storage paths are exercised)"""
+    lms = np.nonzero(gp.vtype == 1)[0]
+    pairs = set()
+    while len(pairs) < n_extra:
+        a, b = rng.choice(lms, 2, replace=False)
+        pairs.add((int(a), int(b)))
+    pairs = sorted(pairs)
+    pairs.append(pairs[0])                                       # a second edge on the same vertex pair
+    z = np.zeros((len(pairs), 7)); W = np.zeros((len(pairs), 36))
+    for k, (a, b) in enumerate(pairs):
+        z[k, :3] = gp.est[b, :3] - gp.est[a, :3] + rng.normal(0, 0.05, 3)
+        M = 4.0 * np.eye(3); M[0, 1] = M[1, 0] = 0.3
+        W[k, :9] = M.ravel()
+    return GraphProblem(gp.vtype, gp.vfixed, gp.est, np.concatenate([gp.etype, np.full(len(pairs), 3, np.int32)]),
+                        np.concatenate([gp.evi, [p[0] for p in pairs]]), np.concatenate([gp.evj, [p[1] for p in pairs]]),
+                        np.vstack([gp.meas, z]), np.vstack([gp.info, W]))
+
+
+def test_point_point_edge_follows_g2o_edge_pointxyz():
+    """EdgePointXYZ: e = (p2 - p1) - z, Jacobians -I / +I: the oracle's analytic Jacobians equal central differences, the normal
+    equations equal a dense J^T W J assembly, and LM drives the chi2 down"""
+    rng = np.random.default_rng(9)
+    gp = _with_point_point_edges(GraphProblem.from_synth(make_graph(30, 8, seed=5), interleave=True), rng)
+    h, n = gp.hessian_index()
+    Hd = np.zeros((n, n)); bd = np.zeros(n)
+    for k in range(gp.ne):
+        e, Ji, Jj = gp.edge_eval(k)
+        d = 6 if gp.etype[k] == 0 else 3
+        di = 6 if gp.vtype[gp.evi[k]] == 0 else 3
+        dj = 6 if gp.vtype[gp.evj[k]] == 0 else 3
+        e, Ji, Jj = e[:d], Ji[:d * di].reshape(d, di), Jj[:d * dj].reshape(d, dj)
+        if gp.etype[k] == 3:
+            assert np.array_equal(Ji, -np.eye(3)) and np.array_equal(Jj, np.eye(3))
+            assert np.allclose(e, gp.est[gp.evj[k], :3] - gp.est[gp.evi[k], :3] - gp.meas[k, :3])
+        W = gp.info[k, :d * d].reshape(d, d)
+        for (va, Ja) in ((gp.evi[k], Ji), (gp.evj[k], Jj)):
+            if h[va] >= 0:
+                bd[h[va]:h[va] + Ja.shape[1]] -= Ja.T @ W @ e
+            for (vb, Jb) in ((gp.evi[k], Ji), (gp.evj[k], Jj)):
+                if h[va] >= 0 and h[vb] >= 0:
+                    Hd[h[va]:h[va] + Ja.shape[1], h[vb]:h[vb] + Jb.shape[1]] += Ja.T @ W @ Jb
+    U, b = gp.linearize()
+    H = (U + U.T).toarray() - np.diag(U.diagonal())
+    assert np.abs(H - Hd).max() <= 1e-10 * np.abs(Hd).max() and np.abs(b - bd).max() <= 1e-10 * np.abs(bd).max()
+    c0 = gp.chi2()
+    st = gp.optimize(20)
+    assert st.chi2_after < c0
