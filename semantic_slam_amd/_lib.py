@@ -79,6 +79,7 @@ def load_library():
         "sslam_debug_plan_destroy": (None, [vp]),
         "sslam_debug_plan_array": (i64, [vp, C.c_char_p, vp, i64]),
         "sslam_batch_create": (vp, [C.POINTER(vp), ci]),
+        "sslam_batch_create_streams": (vp, [C.POINTER(vp), ci, ci]),
         "sslam_batch_destroy": (None, [vp]),
         "sslam_batch_upload": (ci, [vp]),
         "sslam_batch_download": (ci, [vp]),

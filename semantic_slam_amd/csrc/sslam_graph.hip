@@ -12,6 +12,7 @@
 #include <memory>
 #include <string>
 #include <unordered_map>
+#include <thread>
 #include <vector>
 
 #include "../../include/sslam.h"
@@ -1904,7 +1905,33 @@ struct sslam_graph {
 };
 struct sslam_batch {
   Batch b;
+  // Stream group (sslam_batch_create_streams): the graphs split into contiguous parts, every part a batch of its own with its own HIP
+  // stream, optimised from its own host thread.  A batch marches batch-synchronously through the depths of its graphs' elimination trees
+  // and through its LM trial rounds; parts that are out of phase with one another fill the chip while one of them is at the narrow top
+  // of its trees or in the LM endgame with a few graphs left.  `b` is unused in a group handle.
+  std::vector<sslam_batch*> parts;
+  std::vector<int> part0;      // first graph of every part, then n
+  ~sslam_batch() { for (sslam_batch* p : parts) delete p; }
 };
+
+// run f(part, index) for every part of a group handle, one host thread per part (f = nullptr-safe single batches never come here);
+// the first failing part's status and message are handed to the calling thread
+template <class F>
+static int for_each_part(sslam_batch* h, bool threaded, F f) {
+  const int K = (int)h->parts.size();
+  std::vector<int> rcs(K, 0);
+  std::vector<std::string> errs(K);
+  if (threaded) {
+    std::vector<std::thread> th;
+    for (int k = 0; k < K; ++k)
+      th.emplace_back([&, k] { rcs[k] = f(h->parts[k], k); if (rcs[k]) errs[k] = last_error_ref(); });
+    for (auto& t : th) t.join();
+  } else {
+    for (int k = 0; k < K; ++k) { rcs[k] = f(h->parts[k], k); if (rcs[k]) errs[k] = last_error_ref(); }
+  }
+  for (int k = 0; k < K; ++k) if (rcs[k]) return set_error(rcs[k], "part %d of the stream group: %s", k, errs[k].c_str());
+  return 0;
+}
 
 static int ensure_batch(sslam_graph* h) {
   int n = 0;
@@ -2378,8 +2405,35 @@ int sslam_graph_load_g2o(sslam_graph* h, const char* path) {
 }
 
 // ---- batch API --------------------------------------------------------------------------------
+static sslam_batch* batch_create_single(sslam_graph* const* graphs, int n);
 sslam_batch* sslam_batch_create(sslam_graph* const* graphs, int n) {
+  const char* e = getenv("SSLAM_BATCH_STREAMS");
+  return sslam_batch_create_streams(graphs, n, e ? atoi(e) : 1);
+}
+sslam_batch* sslam_batch_create_streams(sslam_graph* const* graphs, int n, int n_streams) {
   if (!graphs || n <= 0) { set_error(SSLAM_ERR_INVALID, "empty batch"); return nullptr; }
+  const int K = std::min(std::max(n_streams, 1), std::min(n, 64));
+  if (K == 1) return batch_create_single(graphs, n);
+  for (int i = 0; i < n; ++i) {   // the same rule as inside one batch, across the parts
+    if (!graphs[i]) { set_error(SSLAM_ERR_INVALID, "null graph"); return nullptr; }
+    const Options &oa = graphs[0]->g.opt, &ob = graphs[i]->g.opt;
+    if (graphs[i]->g.device != graphs[0]->g.device || oa.solver != ob.solver || oa.pcg_tol != ob.pcg_tol || oa.pcg_max_iters != ob.pcg_max_iters || oa.dcs_phi != ob.dcs_phi) {
+      set_error(SSLAM_ERR_INVALID, "batch graphs must share one device and their solver options (graph %d differs from graph 0)", i); return nullptr;
+    }
+  }
+  sslam_batch* h = new sslam_batch();
+  h->b.device = graphs[0]->g.device;
+  for (int k = 0; k < K; ++k) {
+    const int lo = (int)((int64_t)n * k / K), hi = (int)((int64_t)n * (k + 1) / K);
+    sslam_batch* part = batch_create_single(graphs + lo, hi - lo);
+    if (!part) { delete h; return nullptr; }
+    h->parts.push_back(part);
+    h->part0.push_back(lo);
+  }
+  h->part0.push_back(n);
+  return h;
+}
+static sslam_batch* batch_create_single(sslam_graph* const* graphs, int n) {
   int nd = 0;
   if (hipGetDeviceCount(&nd) != hipSuccess || nd <= 0) { set_error(SSLAM_ERR_NO_DEVICE, "no HIP device visible; the product has no CPU fallback"); return nullptr; }
   sslam_batch* h = new sslam_batch();
@@ -2400,18 +2454,32 @@ void sslam_batch_destroy(sslam_batch* h) { delete h; }
 // not gain vertices / edges afterwards (estimates may change: sslam_graph_set_vertex + sslam_batch_upload).
 static int batch_check(sslam_batch* h) {
   if (!h) return set_error(SSLAM_ERR_INVALID, "null batch");
+  for (sslam_batch* p : h->parts) { const int rc = batch_check(p); if (rc) return rc; }
   const Batch& b = h->b;
   for (size_t g = 0; g < b.graphs.size(); ++g)
     if (b.versions[g] != b.graphs[g]->structure_version)
       return set_error(SSLAM_ERR_INVALID, "graph %zu of the batch gained vertices or edges after sslam_batch_create: create a new batch", g);
   return 0;
 }
-int sslam_batch_upload(sslam_batch* h) { const int rc = batch_check(h); return rc ? rc : batch_upload_estimates(h->b); }
-int sslam_batch_download(sslam_batch* h) { const int rc = batch_check(h); return rc ? rc : batch_download_estimates(h->b); }
+int sslam_batch_upload(sslam_batch* h) {
+  const int rc = batch_check(h);
+  if (rc) return rc;
+  if (!h->parts.empty()) return for_each_part(h, false, [](sslam_batch* p, int) { return batch_upload_estimates(p->b); });
+  return batch_upload_estimates(h->b);
+}
+int sslam_batch_download(sslam_batch* h) {
+  const int rc = batch_check(h);
+  if (rc) return rc;
+  if (!h->parts.empty()) return for_each_part(h, false, [](sslam_batch* p, int) { return batch_download_estimates(p->b); });
+  return batch_download_estimates(h->b);
+}
 int sslam_batch_optimize(sslam_batch* h, int max_iters, sslam_opt_stats* out) {
   if (!h || !out) return set_error(SSLAM_ERR_INVALID, "null argument");
   const int rc = batch_check(h);
-  return rc ? rc : batch_optimize(h->b, max_iters, out);
+  if (rc) return rc;
+  if (!h->parts.empty())
+    return for_each_part(h, true, [&](sslam_batch* p, int k) { return batch_optimize(p->b, max_iters, out + h->part0[k]); });
+  return batch_optimize(h->b, max_iters, out);
 }
 // ---- edge-sharded mode (SURVEY 8e mode E; BASELINE.json configs[4]): the edges of every graph of the batch are split
 //      contiguously over the ranks, each rank builds the partial normal equations of its edges, ONE RCCL all-reduce of the
@@ -2451,6 +2519,7 @@ int sslam_comm_unique_id(char id_out[128]) {
 }
 int sslam_batch_comm_init(sslam_batch* h, const char id_in[128], int rank, int world) {
   if (!h || !id_in) return set_error(SSLAM_ERR_INVALID, "null argument");
+  if (!h->parts.empty()) return set_error(SSLAM_ERR_UNSUPPORTED, "not available on a stream group: the edge-sharded mode and the [H || b] read-back work on single-stream batches");
   Batch& b = h->b;
   int rc = batch_check(h);
   if (rc) return rc;
@@ -2472,12 +2541,14 @@ int sslam_batch_comm_init(sslam_batch* h, const char id_in[128], int rank, int w
 }
 int sslam_batch_set_edge_shard(sslam_batch* h, int rank, int world) {
   if (!h) return set_error(SSLAM_ERR_INVALID, "null batch");
+  if (!h->parts.empty()) return set_error(SSLAM_ERR_UNSUPPORTED, "not available on a stream group: the edge-sharded mode and the [H || b] read-back work on single-stream batches");
   int rc = batch_check(h);
   if (rc) return rc;
   return batch_set_shard(h->b, rank, world);
 }
 int64_t sslam_batch_linearize_hb(sslam_batch* h, double* h_and_b, int64_t capacity) {
   if (!h) return set_error(SSLAM_ERR_INVALID, "null batch");
+  if (!h->parts.empty()) return set_error(SSLAM_ERR_UNSUPPORTED, "not available on a stream group: the edge-sharded mode and the [H || b] read-back work on single-stream batches");
   Batch& b = h->b;
   if (!h_and_b) return b.hb_doubles;
   if (capacity < b.hb_doubles) return set_error(SSLAM_ERR_INVALID, "buffer of %lld doubles needed", (long long)b.hb_doubles);
@@ -2496,6 +2567,10 @@ int64_t sslam_batch_linearize_hb(sslam_batch* h, double* h_and_b, int64_t capaci
 
 int sslam_batch_time_linearize(sslam_batch* h, int repeats, double* ms_per_build) {
   if (!h || !ms_per_build || repeats <= 0) return set_error(SSLAM_ERR_INVALID, "bad argument");
+  if (!h->parts.empty()) {   // the parts one after the other: their times add up to one build of every graph
+    *ms_per_build = 0;
+    return for_each_part(h, false, [&](sslam_batch* p, int) { double ms = 0; const int rc = sslam_batch_time_linearize(p, repeats, &ms); *ms_per_build += ms; return rc; });
+  }
   Batch& b = h->b;
   SSLAM_HIP_TRY(hipSetDevice(b.device));
   int rc;
@@ -2522,6 +2597,11 @@ int sslam_batch_time_linearize(sslam_batch* h, int repeats, double* ms_per_build
 // milliseconds by hipEvents on the batch's stream (the LM loop's own launches mix full and partial rounds)
 int sslam_batch_time_solver(sslam_batch* h, int repeats, double* factor_ms, double* solve_ms) {
   if (!h || repeats <= 0 || !factor_ms || !solve_ms) return set_error(SSLAM_ERR_INVALID, "bad argument");
+  if (!h->parts.empty()) {
+    *factor_ms = *solve_ms = 0;
+    return for_each_part(h, false, [&](sslam_batch* p, int) {
+      double f = 0, v = 0; const int rc = sslam_batch_time_solver(p, repeats, &f, &v); *factor_ms += f; *solve_ms += v; return rc; });
+  }
   Batch& b = h->b;
   if (b.graphs[0]->opt.solver == 0 || b.graphs[0]->opt.solver == 2) return set_error(SSLAM_ERR_UNSUPPORTED, "direct solvers only");
   SSLAM_HIP_TRY(hipSetDevice(b.device));
@@ -2556,6 +2636,7 @@ int sslam_batch_time_solver(sslam_batch* h, int repeats, double* factor_ms, doub
 }
 int64_t sslam_batch_linearize_bytes(const sslam_batch* h) {
   if (!h) return 0;
+  if (!h->parts.empty()) { int64_t t = 0; for (const sslam_batch* p : h->parts) t += sslam_batch_linearize_bytes(p); return t; }
   const Batch& b = h->b;
   // 344*Eo + 160*El(176 plane) + 288*Np + 72*Nl + 288*Eo + 144*El + 48*Np + 24*Nl
   int64_t bytes = 0;
@@ -2569,6 +2650,20 @@ int64_t sslam_batch_linearize_bytes(const sslam_batch* h) {
 }
 int sslam_batch_info(sslam_batch* h, const char* key, double* value) {
   if (!h || !key || !value) return set_error(SSLAM_ERR_INVALID, "null argument");
+  if (!h->parts.empty()) {   // sums over the parts; the depth of the plans is their maximum
+    const std::string kk(key);
+    if (kk == "streams") { *value = (double)h->parts.size(); return 0; }
+    double acc = 0;
+    for (sslam_batch* p : h->parts) {
+      double v = 0;
+      const int rc = sslam_batch_info(p, key, &v);
+      if (rc) return rc;
+      acc = kk == "factor_levels" ? std::max(acc, v) : acc + v;
+    }
+    *value = acc;
+    return 0;
+  }
+  if (std::string(key) == "streams") { *value = 1; return 0; }
   Batch& b = h->b;
   const std::string k(key);
   int rc;
@@ -2586,12 +2681,20 @@ int sslam_batch_info(sslam_batch* h, const char* key, double* value) {
 }
 int sslam_batch_set_profiling(sslam_batch* h, int enable) {
   if (!h) return set_error(SSLAM_ERR_INVALID, "null batch");
+  for (sslam_batch* p : h->parts) sslam_batch_set_profiling(p, enable);
   h->b.profiling = enable != 0;
   h->b.timers.clear();
   return 0;
 }
 int sslam_batch_kernel_time(sslam_batch* h, const char* name, double* total_ms, int64_t* launches) {
   if (!h || !name) return set_error(SSLAM_ERR_INVALID, "null argument");
+  if (!h->parts.empty()) {   // per-stream event times, summed: the parts' kernels overlap on the chip, so the sum exceeds the wall time
+    double t = 0; int64_t n = 0;
+    for (sslam_batch* p : h->parts) { double a = 0; int64_t c = 0; sslam_batch_kernel_time(p, name, &a, &c); t += a; n += c; }
+    if (total_ms) *total_ms = t;
+    if (launches) *launches = n;
+    return 0;
+  }
   auto it = h->b.timers.find(name);
   if (total_ms) *total_ms = it == h->b.timers.end() ? 0.0 : it->second.total_ms;
   if (launches) *launches = it == h->b.timers.end() ? 0 : it->second.launches;

@@ -259,11 +259,16 @@ class GraphSLAM:
 class GraphBatch:
     """Device-resident batch of independent graphs optimised together (MI355X extension)."""
 
-    def __init__(self, graphs: Sequence[GraphSLAM]):
+    def __init__(self, graphs: Sequence[GraphSLAM], streams: int = 0):
+        """streams > 1: a stream group (sslam_batch_create_streams) -- the graphs split into that many parts, each on its own HIP stream
+        and host thread; 0: sslam_batch_create (one stream unless SSLAM_BATCH_STREAMS says otherwise)"""
         self._lib = load_library()
         self.graphs = list(graphs)
         arr = (C.c_void_p * len(self.graphs))(*[g._h for g in self.graphs])
-        self._h = self._lib.sslam_batch_create(arr, len(self.graphs))
+        if streams > 0:
+            self._h = self._lib.sslam_batch_create_streams(arr, len(self.graphs), int(streams))
+        else:
+            self._h = self._lib.sslam_batch_create(arr, len(self.graphs))
         if not self._h:
             raise SslamError(-1, self._lib.sslam_last_error().decode())
 
@@ -294,8 +299,9 @@ class GraphBatch:
 
     def linearize_hb(self) -> np.ndarray:
         """[H values || b] of the batch at the current estimates (partial if an edge shard is installed)"""
-        n = self._lib.sslam_batch_linearize_hb(self._h, None, 0)
-        out = np.zeros(int(n))
+        n = int(self._lib.sslam_batch_linearize_hb(self._h, None, 0))
+        _check(self._lib, min(n, 0))
+        out = np.zeros(n)
         _check(self._lib, int(self._lib.sslam_batch_linearize_hb(self._h, _dptr(out), int(n))))
         return out
 

@@ -438,6 +438,51 @@ def test_large_batch_of_unequal_graphs_matches_individual(gpu_lib):
         assert np.abs(G1.estimates() - G2.estimates()).max() < 1e-9
 
 
+def test_stream_group_matches_the_single_stream_batch(gpu_lib):
+    """sslam_batch_create_streams: the graphs split over several batches, each on its own stream + host thread.  Every graph runs its own
+    LM, so the parts only change what overlaps on the chip: with parts of >= 32 graphs (same plan parameters as the whole batch) the
+    results are bitwise those of one batch; info keys are sums over the parts; the edge-sharded mode refuses a group"""
+    from semantic_slam_amd import GraphSLAM, GraphBatch
+    from semantic_slam_amd.graph_slam import SslamError
+    gps = []
+    for i in range(70):
+        g = make_graph(40 + 2 * i, 8 + (i % 5), seed=300 + i, noise_scale=0.0 if i == 11 else 1.0)
+        gps.append(GraphProblem.from_synth(g, interleave=bool(i & 1)))
+    one = [GraphSLAM.from_problem(gp) for gp in gps]
+    B1 = GraphBatch(one)
+    B1.upload()
+    s1 = B1.optimize(7)
+    B1.download()
+    grp = [GraphSLAM.from_problem(gp) for gp in gps]
+    B2 = GraphBatch(grp, streams=2)
+    assert B2.info("streams") == 2 and B1.info("streams") == 1
+    B2.upload()
+    s2 = B2.optimize(7)
+    B2.download()
+    for a, b, G1, G2 in zip(s1, s2, one, grp):
+        assert (a.iterations, a.trials, a.status) == (b.iterations, b.trials, b.status)
+        assert a.chi2_after == b.chi2_after
+        assert np.array_equal(G1.estimates(), G2.estimates())
+    assert B2.info("dim") == B1.info("dim") and B2.info("factor_lnz") == B1.info("factor_lnz")
+    assert B2.linearize_bytes() == B1.linearize_bytes()
+    f, v = B2.time_solver(1)
+    assert f > 0 and v > 0
+    with pytest.raises(SslamError):
+        B2.set_edge_shard(0, 2)
+    with pytest.raises(SslamError):
+        B2.linearize_hb()
+    # more streams than a part can fill: parts of 3-4 graphs, a second optimize on the same handle continues from the first
+    few = [GraphSLAM.from_problem(gp) for gp in gps[:10]]
+    B3 = GraphBatch(few, streams=3)
+    B3.upload()
+    s3 = B3.optimize(7)
+    B3.download()
+    for a, b, G1, G3 in zip(s1, s3, one, few):
+        assert a.iterations == b.iterations
+        assert b.chi2_after == pytest.approx(a.chi2_after, rel=1e-9, abs=1e-18)
+        assert np.abs(G1.estimates() - G3.estimates()).max() < 1e-9
+
+
 def test_edge_shards_sum_to_the_full_system(gpu_lib):
     """SURVEY 8e mode E on one device: the partial normal equations of the edge shards of 3 ranks (graph-local edge ranges
     identical to distributed.shard_range) add up to the full [H || b]; with world = 1 the mode is off again."""
