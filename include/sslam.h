@@ -269,6 +269,16 @@ typedef struct sslam_frame {
 } sslam_frame;
 int sslam_seg_segment_batch(sslam_seg* s, const sslam_frame* frames, int n_frames, int width, int height, int point_step, int row_step,
                             int off_x, int off_y, int off_z, sslam_plane* out, int max_out, int32_t* out_frame);
+/* Pipelined form of sslam_seg_segment_batch for a stream of batches: submit enqueues the H2D copy of the clouds, every kernel and
+ * the read-back of the result tables on one of two pipelines of the handle (own HIP stream, own device buffers, used in turn) and
+ * returns; collect waits for the OLDEST submitted batch and runs the scalar post-processing.  At most two batches are in flight:
+ *     submit(0);  for (k = 0; ...; ++k) { submit(k + 1); collect(k); }
+ * so that the copy of batch k+1 (9.8 MB per 640x480 frame) runs under the kernels of batch k.  The cloud buffers of a batch must stay
+ * valid until it is collected (boxes and poses are copied at submit); pinned clouds (hipHostMalloc / hipHostRegister) make submit
+ * itself asynchronous.  Results are those of sslam_seg_segment_batch.  The blocking calls refuse to run while a batch is in flight. */
+int sslam_seg_submit_batch(sslam_seg* s, const sslam_frame* frames, int n_frames, int width, int height, int point_step, int row_step,
+                           int off_x, int off_y, int off_z);
+int sslam_seg_collect_batch(sslam_seg* s, sslam_plane* out, int max_out, int32_t* out_frame);
 /* Truncation of the last segment call: planes not returned because max_out was reached, boxes with more than 64 connected
  * components above num_point_seg, boxes with more than 64 accepted planes.  Returns the sum (0 = nothing was truncated). */
 int sslam_seg_last_overflow(const sslam_seg* s, int* dropped_planes, int* boxes_with_full_candidate_table, int* boxes_with_full_region_table);

@@ -71,6 +71,7 @@ struct View {
   int* nreg;     // [nbox]
   float mdcf, smoothing, ang_thr_cos, dist_thr, max_curv;
   unsigned min_inliers;
+  int refine_bh;   // rows per LDS band of k_refine (64: one box per CU, lowest latency; 24: three boxes per CU for calls with many boxes)
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -457,17 +458,76 @@ __global__ __launch_bounds__(256) void k_cc_flatten2(View V) {  // second hop: e
   if (L[i] >= 0) L[i] = uf_find(L, i);
 }
 
+// The four kernels above as ONE workgroup per box with the union-find forest in LDS (boxes of <= kCcLdsMax pixels; the YOLO boxes of
+// the reference are a few thousand pixels).  Roots are the smallest pixel index of a component whatever the order of the unions, so
+// labels and counts are those of the global-memory kernels; the comparator's plane distance p.n is recomputed for the neighbour
+// (same expression, no contraction) instead of being parked in HBM.  LDS: 4 bytes per pixel -> three 12k-pixel boxes per CU.
+constexpr int kCcLdsMax = 16384;
+__device__ __forceinline__ bool coeff_compare_direct(const View& V, size_t g1, size_t g2) {
+  const float* p1 = V.pts + g1 * 3;
+  const float* p2 = V.pts + g2 * 3;
+  const float* a = V.nrm + g1 * 4;
+  const float* b = V.nrm + g2 * 4;
+  const float pd1 = p1[0] * a[0] + p1[1] * a[1] + p1[2] * a[2];
+  const float pd2 = p2[0] * b[0] + p2[1] * b[1] + p2[2] * b[2];
+  const float z = p1[2];
+  const float thr = V.dist_thr * (z * z);
+  const float dot = a[0] * b[0] + a[1] * b[1] + a[2] * b[2];
+  return (fabsf(pd1 - pd2) < thr) && (dot > V.ang_thr_cos);
+}
+__global__ __launch_bounds__(1024) void k_cc_lds(View V) {
+  extern __shared__ int Ls[];
+  constexpr int NT = 1024, PER = kCcLdsMax / NT;
+  const BoxMeta b = V.box[blockIdx.x];
+  const int w = b.w, n = w * b.h, tid = threadIdx.x;
+  for (int i = tid; i < n; i += NT) {
+    const size_t g = (size_t)b.pix0 + i;
+    Ls[i] = isfinite(V.pts[g * 3]) ? i : -1;
+    V.l2m[g] = -1;
+  }
+  __syncthreads();
+  for (int i = tid; i < n; i += NT) {
+    if (Ls[i] < 0) continue;
+    const int r = i / w, c = i - r * w;
+    const size_t g = (size_t)b.pix0 + i;
+    if (c > 0 && Ls[i - 1] >= 0 && coeff_compare_direct(V, g, g - 1)) uf_union(Ls, i, i - 1);
+    if (r > 0 && Ls[i - w] >= 0 && coeff_compare_direct(V, g, g - w)) uf_union(Ls, i, i - w);
+  }
+  __syncthreads();
+  int root[PER];
+#pragma unroll
+  for (int k = 0; k < PER; ++k) {
+    const int i = tid + k * NT;
+    root[k] = (i < n && Ls[i] >= 0) ? uf_find(Ls, i) : -1;
+  }
+  __syncthreads();   // every find is done: the forest may go
+#pragma unroll
+  for (int k = 0; k < PER; ++k) {
+    const int i = tid + k * NT;
+    if (i < n) { V.lab[(size_t)b.pix0 + i] = root[k]; Ls[i] = 0; }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < PER; ++k) if (root[k] >= 0) atomicAdd(&Ls[root[k]], 1);
+  __syncthreads();
+  for (int i = tid; i < n; i += NT) V.cnt[(size_t)b.pix0 + i] = Ls[i];
+}
+
 // per-label plane fit (OrganizedMultiPlaneSegmentation::segment): labels with more than
 // min_inliers pixels; PCL accumulates the 9 float sums in index (raster) order, so the additions stay
 // a serial chain, but everything around them is parallel: candidate roots are found by all threads,
 // each candidate gets a wave, pixels are loaded 64 at a time (coalesced), the 9 products are formed
 // lane-parallel and parked in LDS, and lanes 0..8 each run one component's chain over the chunk.
+// NT = 1024 (16 candidates at a time) for a call with few boxes; NT = 256 when a call brings more boxes than the chip has CUs: a box
+// rarely has more than four candidate labels, and four times as many boxes are resident.
 constexpr int kMaxCand = 64;
-__global__ __launch_bounds__(1024) void k_regions(View V) {
+template <int NT>
+__global__ __launch_bounds__(NT) void k_regions(View V) {
+  constexpr int NW = NT / 64;
   __shared__ int cand[kMaxCand];
   __shared__ int ncand;
   __shared__ int accepted[kMaxCand];
-  __shared__ float prod[16][64][9];
+  __shared__ float prod[NW][64][9];
   __shared__ Region regs[kMaxCand];
   const BoxMeta b = V.box[blockIdx.x];
   const int n = b.w * b.h;
@@ -477,7 +537,7 @@ __global__ __launch_bounds__(1024) void k_regions(View V) {
   if (threadIdx.x == 0) ncand = 0;
   if (threadIdx.x < kMaxCand) accepted[threadIdx.x] = 0;
   __syncthreads();
-  for (int i = threadIdx.x; i < n; i += 1024)
+  for (int i = threadIdx.x; i < n; i += NT)
     if (L[i] == i && (unsigned)cnt[i] > V.min_inliers) { const int k = atomicAdd(&ncand, 1); if (k < kMaxCand) cand[k] = i; }
   __syncthreads();
   const int nc = min(ncand, kMaxCand);
@@ -486,7 +546,7 @@ __global__ __launch_bounds__(1024) void k_regions(View V) {
   }
   __syncthreads();
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  for (int k = wave; k < nc; k += 16) {
+  for (int k = wave; k < nc; k += NW) {
     const int label = cand[k];
     float acc = 0;            // lanes 0..8: component `lane`
     int first = -1, last = -1;
@@ -502,9 +562,20 @@ __global__ __launch_bounds__(1024) void k_regions(View V) {
       if (mask) {
         if (first < 0) first = i0 + __ffsll((long long)mask) - 1;
         last = i0 + 63 - __clzll((long long)mask);
+        // the additions are a serial chain in pixel order (PCL's), the LDS reads are not: eight products are fetched together,
+        // then added under the (wave-uniform) inlier bits
         if (lane < 9) {
-          unsigned long long mm = mask;
-          while (mm) { const int bpos = __ffsll((long long)mm) - 1; mm &= mm - 1; acc += prod[wave][bpos][lane]; }
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const unsigned bits = (unsigned)(mask >> (8 * j)) & 0xffu;
+            if (bits) {
+              float v[8];
+#pragma unroll
+              for (int q = 0; q < 8; ++q) v[q] = prod[wave][8 * j + q][lane];
+#pragma unroll
+              for (int q = 0; q < 8; ++q) if (bits & (1u << q)) acc += v[q];
+            }
+          }
         }
       }
     }
@@ -596,7 +667,7 @@ __global__ __launch_bounds__(256) void k_refine(View V) {
   const int w = b.w, h = b.h;
   int* L = V.code + b.pix0;
   const float* gp = V.pts + (size_t)b.pix0 * 3;
-  const int BH = min(64, kBandFloats / (4 * w) - 1);     // labels (1 word) + xyz (3 words) per staged pixel
+  const int BH = min(V.refine_bh, kBandFloats / (4 * w) - 1);     // labels (1 word) + xyz (3 words) per staged pixel
   float* pband = reinterpret_cast<float*>(lband + (BH + 1) * w);
   const float dthr = V.dist_thr;
   __syncthreads();
@@ -1392,9 +1463,31 @@ struct sslam_seg {
   BoxMeta* d_box = nullptr;
   double last_kernel_ms = 0, last_total_ms = 0;
   std::vector<void*> allocs;
+  // a batch between its enqueue (H2D + kernels + result tables D2H, all asynchronous on `stream`) and its finish (wait + scalar
+  // post-processing): what the post-processing needs from the caller's frames, copied so that only the clouds must stay alive
+  struct FrameMeta { float robot_pose[6]; float cam_angle; };
+  struct BoxInfo { float prob; int class_id; };
+  std::vector<FrameMeta> q_frames;
+  std::vector<BoxInfo> q_boxes;    // per accepted slot
+  Region* q_regs = nullptr;        // pinned: the result tables come back asynchronously (a pageable target would make the enqueue wait)
+  int* q_nreg = nullptr;           // [cap_q_box + 2]: region counts, then the two overflow counters
+  size_t cap_q_box = 0;
+  hipEvent_t q_e0 = nullptr, q_e1 = nullptr;
+  bool q_busy = false;
+  std::chrono::steady_clock::time_point q_t0;
+  // sslam_seg_submit_batch / _collect_batch: two pipelines (this handle and a twin with its own stream and buffers) used in turn, so
+  // that the H2D copy of one batch runs under the kernels of the previous one
+  sslam_seg* twin = nullptr;
+  int fifo[2] = {0, 0};            // which pipeline (0 = this, 1 = twin) holds the oldest / the newer submitted batch
+  int n_inflight = 0;
   ~sslam_seg() {
+    delete twin;
     if (stream) { (void)hipSetDevice(P.device); (void)hipStreamSynchronize(stream); }
     free_all();
+    if (q_regs) (void)hipHostFree(q_regs);
+    if (q_nreg) (void)hipHostFree(q_nreg);
+    if (q_e0) (void)hipEventDestroy(q_e0);
+    if (q_e1) (void)hipEventDestroy(q_e1);
     if (stream) (void)hipStreamDestroy(stream);
   }
   void free_all() {
@@ -1503,16 +1596,16 @@ int sslam_seg_transform(const sslam_seg* s, const float pose[6], float cam_pitch
 // One or several frames in one pass: the accepted boxes of ALL frames are packed back to back into one View, so that every
 // kernel launch covers 32 x F boxes (a single frame's 32 boxes leave most of the 256 CUs idle: the raster recurrences of PCL's
 // algorithms run as one workgroup per box).
-static int seg_run(sslam_seg* s, const sslam_frame* frames, int n_frames, int width, int height, int point_step, int row_step, int ox, int oy, int oz,
-                   sslam_plane* out, int max_out, int32_t* out_frame) {
-  if (!s || !frames || n_frames <= 0 || (!out && max_out > 0)) return set_error(SSLAM_ERR_INVALID, "null argument");
+static int seg_enqueue(sslam_seg* s, const sslam_frame* frames, int n_frames, int width, int height, int point_step, int row_step, int ox, int oy, int oz) {
+  if (!s || !frames || n_frames <= 0) return set_error(SSLAM_ERR_INVALID, "null argument");
+  if (s->q_busy) return set_error(SSLAM_ERR_INVALID, "the previous batch of this pipeline has not been collected");
   for (int f = 0; f < n_frames; ++f)
     if (!frames[f].cloud || (!frames[f].boxes && frames[f].n_boxes > 0)) return set_error(SSLAM_ERR_INVALID, "frame %d: null cloud or boxes", f);
   int nd = 0;
   if (hipGetDeviceCount(&nd) != hipSuccess || nd <= 0) return set_error(SSLAM_ERR_NO_DEVICE, "no HIP device visible; the product has no CPU fallback");
   SSLAM_HIP_TRY(hipSetDevice(s->P.device));
   if (!s->stream) SSLAM_HIP_TRY(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
-  const auto t0 = std::chrono::steady_clock::now();
+  s->q_t0 = std::chrono::steady_clock::now();
   const sslam_seg_params& P = s->P;
   // ---- host-side box filter: class whitelist (point_cloud_segmentation.h:126-130), crop bounds
   //      (plane_segmentation.cpp:34-38), minimum point count (:93-95)
@@ -1568,17 +1661,31 @@ static int seg_run(sslam_seg* s, const sslam_frame* frames, int n_frames, int wi
   V.mdcf = P.max_depth_change_factor; V.smoothing = P.normal_smoothing_size;
   V.ang_thr_cos = cosf(P.angular_threshold); V.dist_thr = P.distance_threshold; V.max_curv = P.maximum_curvature;
   V.min_inliers = (unsigned)P.num_point_seg;
-  std::vector<Region> regs;
-  std::vector<int> nreg(nb, 0);
-  float kernel_ms = 0;
-  int ovf[2] = {0, 0};
+  { const char* e = getenv("SSLAM_SEG_REFINE_BH"); V.refine_bh = e ? std::max(2, std::min(64, atoi(e))) : (nb > 512 ? 24 : 64); }
+  s->q_frames.resize(n_frames);
+  for (int f = 0; f < n_frames; ++f) { memcpy(s->q_frames[f].robot_pose, frames[f].robot_pose, sizeof(float) * 6); s->q_frames[f].cam_angle = frames[f].cam_angle; }
+  s->q_boxes.resize(nb);
+  for (int bi = 0; bi < nb; ++bi) { const sslam_box& sb = frames[s->box_frame[bi]].boxes[s->box_src[bi]]; s->q_boxes[bi] = {sb.prob, sb.class_id}; }
+  if ((size_t)nb > s->cap_q_box || !s->q_regs) {
+    if (s->q_regs) (void)hipHostFree(s->q_regs);
+    if (s->q_nreg) (void)hipHostFree(s->q_nreg);
+    s->q_regs = nullptr; s->q_nreg = nullptr;
+    s->cap_q_box = std::max<size_t>(nb, 1);
+    SSLAM_HIP_TRY(hipHostMalloc((void**)&s->q_regs, s->cap_q_box * kMaxRegions * sizeof(Region), hipHostMallocDefault));
+    SSLAM_HIP_TRY(hipHostMalloc((void**)&s->q_nreg, (s->cap_q_box + 2) * sizeof(int), hipHostMallocDefault));
+  }
+  Region* regs = s->q_regs;
+  int* nreg = s->q_nreg;
+  for (int bi = 0; bi < nb; ++bi) nreg[bi] = 0;
+  int* ovf = s->q_nreg + s->cap_q_box;
+  ovf[0] = ovf[1] = 0;
   if (nb > 0) {
     for (int f = 0; f < n_frames; ++f)
       SSLAM_HIP_TRY(hipMemcpyAsync(s->d_cloud + (size_t)f * frame_bytes, frames[f].cloud, frame_bytes, hipMemcpyHostToDevice, s->stream));
     SSLAM_HIP_TRY(hipMemsetAsync(V.overflow, 0, 2 * sizeof(int), s->stream));
     SSLAM_HIP_TRY(hipMemcpyAsync(s->d_box, s->boxes.data(), nb * sizeof(BoxMeta), hipMemcpyHostToDevice, s->stream));
-    hipEvent_t e0, e1;
-    SSLAM_HIP_TRY(hipEventCreate(&e0)); SSLAM_HIP_TRY(hipEventCreate(&e1));
+    if (!s->q_e0) { SSLAM_HIP_TRY(hipEventCreate(&s->q_e0)); SSLAM_HIP_TRY(hipEventCreate(&s->q_e1)); }
+    hipEvent_t e0 = s->q_e0, e1 = s->q_e1;
     SSLAM_HIP_TRY(hipEventRecord(e0, s->stream));
     const dim3 pg((maxpix + 255) / 256, nb), pb(256);
     int maxw = 1;
@@ -1588,7 +1695,7 @@ static int seg_run(sslam_seg* s, const sslam_frame* frames, int n_frames, int wi
     for (auto& b : s->boxes) {
       const int bh = std::min(64, kBandFloats / b.w - 1);
       band_bytes = std::max(band_bytes, (size_t)(bh + 1) * b.w * sizeof(float));
-      const int bhr = std::min(64, kBandFloats / (4 * b.w) - 1);
+      const int bhr = std::min(V.refine_bh, kBandFloats / (4 * b.w) - 1);
       rband_bytes = std::max(rband_bytes, (size_t)(bhr + 1) * b.w * 4 * sizeof(float));
     }
     if (band_bytes > 64 * 1024) SSLAM_HIP_TRY(hipFuncSetAttribute((const void*)k_distance_map, hipFuncAttributeMaxDynamicSharedMemorySize, (int)band_bytes));
@@ -1613,15 +1720,21 @@ static int seg_run(sslam_seg* s, const sslam_frame* frames, int n_frames, int wi
     DBG("k_integral");
     hipLaunchKernelGGL(k_normals, pg, pb, 0, s->stream, V);
     DBG("k_normals");
-    hipLaunchKernelGGL(k_cc_init, pg, pb, 0, s->stream, V);
-    DBG("k_cc_init");
-    hipLaunchKernelGGL(k_cc_merge, pg, pb, 0, s->stream, V);
-    DBG("k_cc_merge");
-    hipLaunchKernelGGL(k_cc_flatten, pg, pb, 0, s->stream, V);
-    DBG("k_cc_flatten");
-    hipLaunchKernelGGL(k_cc_flatten2, pg, pb, 0, s->stream, V);
-    DBG("k_cc_flatten2");
-    hipLaunchKernelGGL(k_regions, dim3(nb), dim3(1024), 0, s->stream, V);
+    if (maxpix <= kCcLdsMax && !getenv("SSLAM_SEG_GLOBAL_CC")) {
+      hipLaunchKernelGGL(k_cc_lds, dim3(nb), dim3(1024), (size_t)maxpix * sizeof(int), s->stream, V);
+      DBG("k_cc_lds");
+    } else {
+      hipLaunchKernelGGL(k_cc_init, pg, pb, 0, s->stream, V);
+      DBG("k_cc_init");
+      hipLaunchKernelGGL(k_cc_merge, pg, pb, 0, s->stream, V);
+      DBG("k_cc_merge");
+      hipLaunchKernelGGL(k_cc_flatten, pg, pb, 0, s->stream, V);
+      DBG("k_cc_flatten");
+      hipLaunchKernelGGL(k_cc_flatten2, pg, pb, 0, s->stream, V);
+      DBG("k_cc_flatten2");
+    }
+    if (nb > 256) hipLaunchKernelGGL(k_regions<256>, dim3(nb), dim3(256), 0, s->stream, V);
+    else hipLaunchKernelGGL(k_regions<1024>, dim3(nb), dim3(1024), 0, s->stream, V);
     DBG("k_regions");
     hipLaunchKernelGGL(k_relabel, pg, pb, 0, s->stream, V);
     DBG("k_relabel");
@@ -1649,26 +1762,42 @@ static int seg_run(sslam_seg* s, const sslam_frame* frames, int n_frames, int wi
     hipLaunchKernelGGL(k_area, dim3(nb, kMaxRegions), dim3(64), 0, s->stream, V);
     DBG("k_area");
     SSLAM_HIP_TRY(hipEventRecord(e1, s->stream));
-    regs.resize((size_t)nb * kMaxRegions);
-    SSLAM_HIP_TRY(hipMemcpyAsync(regs.data(), V.reg, regs.size() * sizeof(Region), hipMemcpyDeviceToHost, s->stream));
-    SSLAM_HIP_TRY(hipMemcpyAsync(nreg.data(), V.nreg, nb * sizeof(int), hipMemcpyDeviceToHost, s->stream));
-    SSLAM_HIP_TRY(hipMemcpyAsync(ovf, V.overflow, sizeof ovf, hipMemcpyDeviceToHost, s->stream));
+    SSLAM_HIP_TRY(hipMemcpyAsync(regs, V.reg, (size_t)nb * kMaxRegions * sizeof(Region), hipMemcpyDeviceToHost, s->stream));
+    SSLAM_HIP_TRY(hipMemcpyAsync(nreg, V.nreg, nb * sizeof(int), hipMemcpyDeviceToHost, s->stream));
+    SSLAM_HIP_TRY(hipMemcpyAsync(ovf, V.overflow, 2 * sizeof(int), hipMemcpyDeviceToHost, s->stream));
+  }
+  s->q_busy = true;
+  return 0;
+}
+
+// wait for the batch seg_enqueue put on this pipeline, then plane_segmentation.cpp:158-256 + point_cloud_segmentation.h:43-99
+// (scalar post-processing)
+static int seg_finish(sslam_seg* s, sslam_plane* out, int max_out, int32_t* out_frame) {
+  if (!s || (!out && max_out > 0)) return set_error(SSLAM_ERR_INVALID, "null argument");
+  if (!s->q_busy) return set_error(SSLAM_ERR_INVALID, "no batch was submitted on this pipeline");
+  s->q_busy = false;
+  SSLAM_HIP_TRY(hipSetDevice(s->P.device));
+  const sslam_seg_params& P = s->P;
+  const int nb = (int)s->boxes.size();
+  const Region* regs = s->q_regs;
+  const int* nreg = s->q_nreg;
+  const int* ovf = s->q_nreg + s->cap_q_box;
+  float kernel_ms = 0;
+  if (nb > 0) {
     SSLAM_HIP_TRY(hipStreamSynchronize(s->stream));
     hipError_t le = hipGetLastError();
     if (le != hipSuccess) return set_error(SSLAM_ERR_HIP, "frontend kernels: %s", hipGetErrorString(le));
-    SSLAM_HIP_TRY(hipEventElapsedTime(&kernel_ms, e0, e1));
-    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    SSLAM_HIP_TRY(hipEventElapsedTime(&kernel_ms, s->q_e0, s->q_e1));
   }
   if (getenv("SSLAM_SEG_DEBUG")) for (int bi = 0; bi < nb; ++bi) for (int k = 0; k < nreg[bi]; ++k) { const Region& R = regs[(size_t)bi * kMaxRegions + k]; fprintf(stderr, "[seg] post box %d reg %d: inl %d contour %d off %d area %g\n", bi, k, R.inliers, R.contour_n, R.contour_off, R.area); }
-  // ---- plane_segmentation.cpp:158-256 + point_cloud_segmentation.h:43-99 (scalar post-processing)
   int nout = 0, dropped = 0;
   for (int bi = 0; bi < nb; ++bi) {
-    const sslam_frame& fr = frames[s->box_frame[bi]];
+    const sslam_seg::FrameMeta& fr = s->q_frames[s->box_frame[bi]];
     const float* robot_pose = fr.robot_pose;
     float T[16];
     sslam_seg_transform(s, robot_pose, fr.cam_angle, T);
     const float hz[3] = {T[8], T[9], T[10]};
-    const sslam_box& sb = fr.boxes[s->box_src[bi]];
+    const sslam_seg::BoxInfo& sb = s->q_boxes[bi];
     for (int k = 0; k < nreg[bi]; ++k) {
       const Region& R = regs[(size_t)bi * kMaxRegions + k];
       if (!(R.contour_n > P.min_contour_points)) continue;
@@ -1702,8 +1831,16 @@ static int seg_run(sslam_seg* s, const sslam_frame* frames, int n_frames, int wi
   }
   s->last_dropped_planes = dropped; s->last_candidate_overflow = ovf[0]; s->last_region_overflow = ovf[1];
   s->last_kernel_ms = kernel_ms;
-  s->last_total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  s->last_total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - s->q_t0).count();
   return nout;
+}
+static int seg_run(sslam_seg* s, const sslam_frame* frames, int n_frames, int width, int height, int point_step, int row_step, int ox, int oy, int oz,
+                   sslam_plane* out, int max_out, int32_t* out_frame) {
+  if (!s || !frames || n_frames <= 0 || (!out && max_out > 0)) return set_error(SSLAM_ERR_INVALID, "null argument");
+  if (s->n_inflight > 0) return set_error(SSLAM_ERR_INVALID, "%d submitted batch(es) must be collected first", s->n_inflight);
+  const int rc = seg_enqueue(s, frames, n_frames, width, height, point_step, row_step, ox, oy, oz);
+  if (rc) { s->q_busy = false; return rc; }
+  return seg_finish(s, out, max_out, out_frame);
 }
 
 
@@ -1719,6 +1856,38 @@ int sslam_seg_segment(sslam_seg* s, const uint8_t* cloud, int width, int height,
 int sslam_seg_segment_batch(sslam_seg* s, const sslam_frame* frames, int n_frames, int width, int height, int point_step, int row_step,
                             int ox, int oy, int oz, sslam_plane* out, int max_out, int32_t* out_frame) {
   return seg_run(s, frames, n_frames, width, height, point_step, row_step, ox, oy, oz, out, max_out, out_frame);
+}
+
+// Pipelined form: at most two batches in flight, on two pipelines (own stream, own device buffers) used in turn; the 9.8 MB-per-frame
+// H2D copy of batch k+1 runs under the kernels of batch k.  submit(0); loop { submit(k+1); collect(k); }
+int sslam_seg_submit_batch(sslam_seg* s, const sslam_frame* frames, int n_frames, int width, int height, int point_step, int row_step,
+                           int ox, int oy, int oz) {
+  if (!s) return set_error(SSLAM_ERR_INVALID, "null argument");
+  if (s->n_inflight >= 2) return set_error(SSLAM_ERR_INVALID, "two batches are in flight: collect one first");
+  int which = 0;
+  if (s->n_inflight == 1) which = 1 - s->fifo[0];
+  sslam_seg* pipe = s;
+  if (which == 1) {
+    if (!s->twin) { s->twin = new sslam_seg(); s->twin->P = s->P; }
+    pipe = s->twin;
+  }
+  const int rc = seg_enqueue(pipe, frames, n_frames, width, height, point_step, row_step, ox, oy, oz);
+  if (rc) { pipe->q_busy = false; return rc; }
+  s->fifo[s->n_inflight++] = which;
+  return 0;
+}
+int sslam_seg_collect_batch(sslam_seg* s, sslam_plane* out, int max_out, int32_t* out_frame) {
+  if (!s) return set_error(SSLAM_ERR_INVALID, "null argument");
+  if (s->n_inflight <= 0) return set_error(SSLAM_ERR_INVALID, "no batch in flight");
+  sslam_seg* pipe = s->fifo[0] ? s->twin : s;
+  s->fifo[0] = s->fifo[1];
+  --s->n_inflight;
+  const int n = seg_finish(pipe, out, max_out, out_frame);
+  if (pipe != s) {   // the handle reports the last collected batch
+    s->last_dropped_planes = pipe->last_dropped_planes; s->last_candidate_overflow = pipe->last_candidate_overflow;
+    s->last_region_overflow = pipe->last_region_overflow; s->last_kernel_ms = pipe->last_kernel_ms; s->last_total_ms = pipe->last_total_ms;
+  }
+  return n;
 }
 
 int sslam_seg_last_overflow(const sslam_seg* s, int* dropped_planes, int* boxes_with_full_candidate_table, int* boxes_with_full_region_table) {

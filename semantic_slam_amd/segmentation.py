@@ -70,6 +70,10 @@ def _bind(lib):
     lib.sslam_seg_segment.argtypes = [vp, vp, ci, ci, ci, ci, ci, ci, ci, vp, ci, vp, C.c_float, vp, ci]
     lib.sslam_seg_segment_batch.restype = ci
     lib.sslam_seg_segment_batch.argtypes = [vp, vp, ci, ci, ci, ci, ci, ci, ci, ci, vp, ci, vp]
+    lib.sslam_seg_submit_batch.restype = ci
+    lib.sslam_seg_submit_batch.argtypes = [vp, vp, ci, ci, ci, ci, ci, ci, ci, ci]
+    lib.sslam_seg_collect_batch.restype = ci
+    lib.sslam_seg_collect_batch.argtypes = [vp, vp, ci, vp]
     lib.sslam_seg_last_overflow.restype = ci; lib.sslam_seg_last_overflow.argtypes = [vp, C.POINTER(ci), C.POINTER(ci), C.POINTER(ci)]
     lib.sslam_seg_get_normals.restype = ci; lib.sslam_seg_get_normals.argtypes = [vp, ci, vp]
     lib.sslam_seg_get_labels.restype = ci; lib.sslam_seg_get_labels.argtypes = [vp, ci, vp]
@@ -160,13 +164,8 @@ class PointCloudSegmentation:
                                       inlier_count=p.inlier_count, area=p.area))
         return res
 
-    def segment_frames(self, frames, max_planes: int = 4096):
-        """Several frames (``synth.SynthFrame``-like objects with robot_pose / cam_angle / boxes) in ONE pass over the GPU
-        (``sslam_seg_segment_batch``): the boxes of all frames share every kernel launch.  Returns a list (per frame) of lists of
-        planes, identical to calling ``segmentallPointCloudData`` frame by frame."""
+    def _pack_frames(self, frames):
         F = len(frames)
-        if F == 0:
-            return []
         f0 = frames[0]
         fr = (Frame * F)()
         keep = []
@@ -179,12 +178,59 @@ class PointCloudSegmentation:
             for q in range(6):
                 fr[k].robot_pose[q] = float(pose[q])
             fr[k].cam_angle = float(f.cam_angle)
+        return fr, keep
+
+    def submit_frames(self, frames) -> None:
+        """``sslam_seg_submit_batch``: enqueue one batch of frames (H2D copy + kernels) and return; at most two batches in flight.
+        The frames' clouds are kept alive until the batch is collected."""
+        fr, keep = self._pack_frames(frames)
+        f0 = frames[0]
+        self._check(self._lib.sslam_seg_submit_batch(self._h, C.cast(fr, C.c_void_p), len(frames), f0.width, f0.height, f0.point_step, f0.row_step,
+                                                     f0.offsets[0], f0.offsets[1], f0.offsets[2]))
+        if not hasattr(self, "_inflight"):
+            self._inflight = []
+        self._inflight.append((len(frames), keep))
+
+    def collect_frames(self, max_planes: int = 4096):
+        """``sslam_seg_collect_batch``: the planes of the oldest submitted batch, per frame (as ``segment_frames`` returns them)"""
+        out = (Plane * max_planes)()
+        which = np.zeros(max_planes, np.int32)
+        n = self._check(self._lib.sslam_seg_collect_batch(self._h, C.cast(out, C.c_void_p), max_planes, which.ctypes.data))
+        F, keep = self._inflight.pop(0)
+        self._last_boxes = [bx for (boxes, _) in keep for bx in boxes]   # accepted slot = position, when no box is rejected
+        res = [[] for _ in range(F)]
+        for k, o in enumerate(self._objects(out, n)):
+            res[int(which[k])].append(o)
+        return res
+
+    def segment_stream(self, batches, max_planes: int = 4096):
+        """generator over an iterable of frame batches: batch k+1 is submitted before batch k is collected, so its H2D copy runs under
+        the kernels of batch k"""
+        it = iter(batches)
+        try:
+            self.submit_frames(next(it))
+        except StopIteration:
+            return
+        for nxt in it:
+            self.submit_frames(nxt)
+            yield self.collect_frames(max_planes)
+        yield self.collect_frames(max_planes)
+
+    def segment_frames(self, frames, max_planes: int = 4096):
+        """Several frames (``synth.SynthFrame``-like objects with robot_pose / cam_angle / boxes) in ONE pass over the GPU
+        (``sslam_seg_segment_batch``): the boxes of all frames share every kernel launch.  Returns a list (per frame) of lists of
+        planes, identical to calling ``segmentallPointCloudData`` frame by frame."""
+        F = len(frames)
+        if F == 0:
+            return []
+        f0 = frames[0]
+        fr, keep = self._pack_frames(frames)
         out = (Plane * max_planes)()
         which = np.zeros(max_planes, np.int32)
         n = self._check(self._lib.sslam_seg_segment_batch(self._h, C.cast(fr, C.c_void_p), F, f0.width, f0.height, f0.point_step, f0.row_step,
                                                           f0.offsets[0], f0.offsets[1], f0.offsets[2], C.cast(out, C.c_void_p), max_planes,
                                                           which.ctypes.data))
-        self._last_boxes = keep[0][0]
+        self._last_boxes = [bx for (boxes, _) in keep for bx in boxes]   # accepted slot = position, when no box is rejected
         objs = self._objects(out, n)
         res = [[] for _ in range(F)]
         for k, o in enumerate(objs):

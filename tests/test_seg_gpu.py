@@ -120,6 +120,58 @@ def test_batched_frames_equal_frame_by_frame(gpu_lib):
     assert sum(len(x) for x in few) == 3 and seg2.last_overflow()[0] == sum(len(x) for x in single) - 3
 
 
+def _same_planes(a_list, b_list):
+    assert len(a_list) == len(b_list)
+    for a, b in zip(a_list, b_list):
+        assert (a.box_index, a.inlier_count, a.num_points, a.area, a.plane_type, a.type) == (b.box_index, b.inlier_count, b.num_points, b.area, b.plane_type, b.type)
+        assert np.array_equal(a.pose, b.pose) and np.array_equal(a.normal_orientation, b.normal_orientation) and np.array_equal(a.world_pose, b.world_pose)
+
+
+def test_many_boxes_per_call_equal_frame_by_frame(gpu_lib):
+    """a call with more boxes than the chip has CUs switches the per-box kernels to their high-residency forms (256-thread plane fit,
+    24-row refinement bands); the label images and plane records stay those of the one-frame calls"""
+    from semantic_slam_amd.segmentation import PointCloudSegmentation
+    frames = [make_frame(seed=40 + s, n_boxes=32) for s in range(18)]          # 576 boxes in one call
+    seg = PointCloudSegmentation()
+    single = [seg.segmentallPointCloudData(f.robot_pose, f.cam_angle, f.boxes, f) for f in frames[5::-1]][::-1]
+    lab_single = [seg.labels(bi) for bi in range(32)]                            # label images of frame 0 (the last one-frame call)
+    seg2 = PointCloudSegmentation()
+    batched = seg2.segment_frames(frames)
+    assert seg2.last_overflow() == (0, 0, 0)
+    for a_list, b_list in zip(batched[:6], single):
+        _same_planes(a_list, b_list)
+    assert sum(len(x) for x in batched) > 40
+    for bi in range(32):                                                        # the parity hooks address frame 0 of a call
+        assert np.array_equal(seg2.labels(bi), lab_single[bi])
+
+
+def test_pipelined_batches_equal_blocking_calls(gpu_lib):
+    """sslam_seg_submit_batch / _collect_batch: two batches in flight on the handle's two pipelines, results in submission order and
+    equal to the blocking call; a third submit and a blocking call while batches are in flight are refused"""
+    from semantic_slam_amd.segmentation import PointCloudSegmentation
+    from semantic_slam_amd.graph_slam import SslamError
+    batches = [[make_frame(seed=60 + 4 * k + j, n_boxes=8 + 4 * j) for j in range(3)] for k in range(4)]
+    ref = PointCloudSegmentation()
+    want = [ref.segment_frames(b) for b in batches]
+    seg = PointCloudSegmentation()
+    got = list(seg.segment_stream(batches))
+    assert len(got) == len(want)
+    for g, w_ in zip(got, want):
+        for a_list, b_list in zip(g, w_):
+            _same_planes(a_list, b_list)
+    seg.submit_frames(batches[0]); seg.submit_frames(batches[1])
+    with pytest.raises(SslamError):
+        seg.submit_frames(batches[2])
+    with pytest.raises(SslamError):
+        seg.segment_frames(batches[2])
+    first = seg.collect_frames(); second = seg.collect_frames()
+    for a_list, b_list in zip(first + second, want[0] + want[1]):
+        _same_planes(a_list, b_list)
+    with pytest.raises(SslamError):
+        seg.collect_frames()
+    _same_planes(seg.segment_frames(batches[3])[0], want[3][0])              # the handle is usable again
+
+
 def test_ragged_and_rejected_boxes(gpu_lib):
     """Class filter (point_cloud_segmentation.h:126-130), out-of-bounds crop (plane_segmentation.cpp:34-38),
     too few points (:93-95), an empty box list, mixed box sizes."""
