@@ -62,15 +62,14 @@ struct View {
   int* cnt;      // [npix] pixels per root
   int* l2m;      // [npix] root label -> region index, or -1
   int* code;     // [npix] region index | kOther | -1  (labels as seen by refinement / contour)
-  double* fo;    // [nii*3]
-  double* so;    // [nii*6]
-  unsigned* ic;  // [nii]
+  double* ii;    // [nii*10] integral images, one 80-byte record per entry: first order (3), second order (6), finite-point count
   Region* reg;   // [nbox*kMaxRegions]
   int* contour;  // [4*npix] boundary pixel indices, one arena of 4*w*h ints per box at 4*pix0
   int* ccount;   // [nbox] ints used in each arena
   int* nreg;     // [nbox]
   float mdcf, smoothing, ang_thr_cos, dist_thr, max_curv;
   unsigned min_inliers;
+  int dbg;         // timing experiments (SSLAM_SEG_DBG; results are wrong when set): 1 = refine without its region records, 2 = refine without the sweeps, 4 = integral images without stores
   int refine_bh;   // rows per LDS band of k_refine (64: one box per CU, lowest latency; 24: three boxes per CU for calls with many boxes)
 };
 
@@ -245,102 +244,91 @@ __global__ __launch_bounds__(256) void k_distance_map(View V) {
   }
 }
 
-// integral images (IntegralImage2D<float,3>::computeIntegralImages, second order on): one wave per
-// box, lane l owns row r0+l, two columns behind lane l-1; the previous row's running values arrive by
-// wave shuffle.  Recurrence and operation order are PCL's:  cur[c+1] = prev[c+1] + cur[c] - prev[c] (+ element).
+// integral images (IntegralImage2D<float,3>::computeIntegralImages, second order on).  Lane l of a wave owns row r0+l, two columns
+// behind lane l-1; the previous row's running values arrive by wave shuffle.  Recurrence and operation order are PCL's:
+// cur[c+1] = prev[c+1] + cur[c] - prev[c] (+ element).  The ten running sums (x y z | xx xy xz | yy yz | zz count) are independent of
+// one another, so the four waves of the workgroup each carry two or three of them over the same rows: a step is bound by one wave's
+// instruction issue, and no barrier is needed between the waves.  One 80-byte record per entry: [x y z xx xy xz yy yz zz count].
+struct alignas(16) IiPair { double a, b; };
+template <int Q>
+__device__ __forceinline__ float ii_elem(float ex, float ey, float ez) {
+  return Q == 0 ? ex : Q == 1 ? ey : Q == 2 ? ez : Q == 3 ? ex * ex : Q == 4 ? ex * ey : Q == 5 ? ex * ez : Q == 6 ? ey * ey : Q == 7 ? ey * ez : Q == 8 ? ez * ez : 1.0f;
+}
+template <int C0, int NC>
+__device__ __forceinline__ void ii_store(double* e, const double (&v)[NC]) {   // e = record + C0; 16-byte stores where the pair is aligned
+  if (NC == 2) { *reinterpret_cast<IiPair*>(e) = IiPair{v[0], v[1]}; }
+  else if (C0 % 2 == 0) { *reinterpret_cast<IiPair*>(e) = IiPair{v[0], v[1]}; e[2] = v[NC - 1]; }
+  else { e[0] = v[0]; *reinterpret_cast<IiPair*>(e + 1) = IiPair{v[1], v[NC - 1]}; }
+}
+template <int C0, int NC>
+__device__ __forceinline__ void integral_wave(const float* bpts, const double* prevrow, double* rec, int w, int nr, int r0, int l, int dbg) {
+  const int W1 = w + 1, r = r0 + l;
+  double cur[NC], h1[NC], h2[NC], p0[NC];   // cur[c] of the running column; own outputs one / two steps ago; prev[c]
+#pragma unroll
+  for (int q = 0; q < NC; ++q) { cur[q] = 0; h1[q] = 0; h2[q] = 0; p0[q] = 0; }
+  const int steps = w + 2 * (nr - 1);
+  for (int t = 0; t < steps; ++t) {
+    const int c = t - 2 * l;
+    // prev[c+1]: lane l-1's output two steps ago; lane 0 reads the staged last row of the previous band
+    double p1[NC];
+#pragma unroll
+    for (int q = 0; q < NC; ++q) p1[q] = __shfl_up(h2[q], 1, 64);
+    const bool active = l < nr && c >= 0 && c < w;
+    if (l == 0 && active) {
+#pragma unroll
+      for (int q = 0; q < NC; ++q) p1[q] = prevrow[(c + 1) * 10 + C0 + q];
+    }
+    double out[NC];
+#pragma unroll
+    for (int q = 0; q < NC; ++q) out[q] = h1[q];
+    if (active) {
+#pragma unroll
+      for (int q = 0; q < NC; ++q) out[q] = p1[q] + cur[q] - p0[q];
+      const float* ep = bpts + ((size_t)l * w + c) * 3;
+      const float ex = ep[0], ey = ep[1], ez = ep[2];
+      if (isfinite(ex + ey + ez)) {
+        out[0] += (double)ii_elem<C0>(ex, ey, ez);
+        out[1] += (double)ii_elem<C0 + 1>(ex, ey, ez);
+        if (NC == 3) out[NC - 1] += (double)ii_elem<C0 + NC - 1>(ex, ey, ez);
+      }
+      const size_t o = (size_t)(r + 1) * W1 + (c + 1);
+      ii_store<C0, NC>(rec + ((dbg & 4) ? (size_t)l : o) * 10 + C0, out);
+      if (c == 0) {  // integral column 0 of this row is zero
+        const double zero[NC] = {};
+        ii_store<C0, NC>(rec + (size_t)(r + 1) * W1 * 10 + C0, zero);
+      }
+#pragma unroll
+      for (int q = 0; q < NC; ++q) { cur[q] = out[q]; p0[q] = p1[q]; }
+    }
+    // shift the output history (every lane, every step: the shuffle above reads h2)
+#pragma unroll
+    for (int q = 0; q < NC; ++q) { h2[q] = h1[q]; h1[q] = out[q]; }
+  }
+}
 __global__ __launch_bounds__(256) void k_integral(View V, int band_rows) {
   extern __shared__ double prevrow[];  // (w+1) x 10 doubles: last row of the previous band; then the band's points (floats)
   const BoxMeta b = V.box[blockIdx.x];
   const int w = b.w, h = b.h, W1 = w + 1;
   const float* pts = V.pts + (size_t)b.pix0 * 3;
   float* bpts = reinterpret_cast<float*>(prevrow + (size_t)W1 * 10);
-  double* fo = V.fo + (size_t)b.ii0 * 3;
-  double* so = V.so + (size_t)b.ii0 * 6;
-  unsigned* ic = V.ic + b.ii0;
-  const int tid = threadIdx.x;
-  const int l = tid;   // lanes of wave 0 own rows; the other waves only help staging
+  double* rec = V.ii + (size_t)b.ii0 * 10;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   // row 0 of the integral images is zero
-  for (int k = tid; k < W1; k += 256) {
-    for (int q = 0; q < 3; ++q) fo[(size_t)k * 3 + q] = 0;
-    for (int q = 0; q < 6; ++q) so[(size_t)k * 6 + q] = 0;
-    ic[k] = 0;
-  }
-  for (int k = tid; k < W1 * 10; k += 256) prevrow[k] = 0;
+  for (int k = tid; k < W1 * 10; k += 256) { rec[k] = 0; prevrow[k] = 0; }
   __syncthreads();
   for (int r0 = 0; r0 < h; r0 += band_rows) {
     const int nr = min(band_rows, h - r0);
     for (int k = tid; k < nr * w * 3; k += 256) bpts[k] = pts[(size_t)r0 * w * 3 + k];   // coalesced
     __syncthreads();
-    if (tid < 64) {
-    const int r = r0 + l;
-    double cur[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};   // cur[c] of the running column
-    unsigned curc = 0;
-    double h1[9], h2[9], p0[9];                       // own outputs one / two steps ago; prev[c]
-    unsigned h1c = 0, h2c = 0, p0c = 0;
-#pragma unroll
-    for (int q = 0; q < 9; ++q) { h1[q] = 0; h2[q] = 0; p0[q] = 0; }
-    const int steps = w + 2 * (nr - 1);
-    for (int t = 0; t < steps; ++t) {
-      const int c = t - 2 * l;
-      // prev[c+1]: lane l-1's output two steps ago; lane 0 reads the staged last row of the previous band
-      double p1[9];
-      unsigned p1c;
-#pragma unroll
-      for (int q = 0; q < 9; ++q) p1[q] = __shfl_up(h2[q], 1, 64);
-      p1c = __shfl_up(h2c, 1, 64);
-      const bool active = l < nr && c >= 0 && c < w;
-      if (l == 0 && active) {
-#pragma unroll
-        for (int q = 0; q < 9; ++q) p1[q] = prevrow[(c + 1) * 10 + q];
-        p1c = (unsigned)prevrow[(c + 1) * 10 + 9];
-      }
-      double out[9];
-      unsigned outc = h1c;
-#pragma unroll
-      for (int q = 0; q < 9; ++q) out[q] = h1[q];
-      if (active) {
-#pragma unroll
-        for (int q = 0; q < 9; ++q) out[q] = p1[q] + cur[q] - p0[q];
-        outc = p1c + curc - p0c;
-        const float* ep = bpts + ((size_t)l * w + c) * 3;
-        const float ex = ep[0], ey = ep[1], ez = ep[2];
-        if (isfinite(ex + ey + ez)) {
-          out[0] += (double)ex; out[1] += (double)ey; out[2] += (double)ez;
-          ++outc;
-          out[3] += (double)(ex * ex); out[4] += (double)(ex * ey); out[5] += (double)(ex * ez);
-          out[6] += (double)(ey * ey); out[7] += (double)(ey * ez); out[8] += (double)(ez * ez);
-        }
-        const size_t o = (size_t)(r + 1) * W1 + (c + 1);
-        fo[o * 3 + 0] = out[0]; fo[o * 3 + 1] = out[1]; fo[o * 3 + 2] = out[2];
-#pragma unroll
-        for (int q = 0; q < 6; ++q) so[o * 6 + q] = out[3 + q];
-        ic[o] = outc;
-        if (c == 0) {  // integral column 0 of this row is zero
-          const size_t o0 = (size_t)(r + 1) * W1;
-          fo[o0 * 3 + 0] = 0; fo[o0 * 3 + 1] = 0; fo[o0 * 3 + 2] = 0;
-#pragma unroll
-          for (int q = 0; q < 6; ++q) so[o0 * 6 + q] = 0;
-          ic[o0] = 0;
-        }
-#pragma unroll
-        for (int q = 0; q < 9; ++q) { cur[q] = out[q]; p0[q] = p1[q]; }
-        curc = outc; p0c = p1c;
-      }
-      // shift the output history (every lane, every step: the shuffle above reads h2)
-#pragma unroll
-      for (int q = 0; q < 9; ++q) { h2[q] = h1[q]; h1[q] = out[q]; }
-      h2c = h1c; h1c = outc;
-    }
-    }
+    if (wave == 0) integral_wave<0, 3>(bpts, prevrow, rec, w, nr, r0, lane, V.dbg);
+    else if (wave == 1) integral_wave<3, 3>(bpts, prevrow, rec, w, nr, r0, lane, V.dbg);
+    else if (wave == 2) integral_wave<6, 2>(bpts, prevrow, rec, w, nr, r0, lane, V.dbg);
+    else integral_wave<8, 2>(bpts, prevrow, rec, w, nr, r0, lane, V.dbg);
     // stage the last row of this band for the next band's lane 0
     __syncthreads();
     if (r0 + band_rows < h) {
-      const size_t rowo = (size_t)(r0 + band_rows) * W1;
-      for (int k = tid; k < W1; k += 256) {
-        prevrow[k * 10 + 0] = fo[(rowo + k) * 3 + 0]; prevrow[k * 10 + 1] = fo[(rowo + k) * 3 + 1]; prevrow[k * 10 + 2] = fo[(rowo + k) * 3 + 2];
-        for (int q = 0; q < 6; ++q) prevrow[k * 10 + 3 + q] = so[(rowo + k) * 6 + q];
-        prevrow[k * 10 + 9] = (double)ic[rowo + k];
-      }
+      const double* src = rec + (size_t)(r0 + band_rows) * W1 * 10;     // same record layout as the carry row
+      for (int k = tid; k < W1 * 10; k += 256) prevrow[k] = src[k];
     }
     __syncthreads();
   }
@@ -364,16 +352,14 @@ __global__ __launch_bounds__(256) void k_normals(View V) {
   const int rw = (int)smoothing, rh = (int)smoothing;
   const int sx = c - rw / 2, sy = r - rh / 2;
   const size_t ul = (size_t)sy * W1 + sx, ur = ul + rw, ll = (size_t)(sy + rh) * W1 + sx, lr = ll + rw;
-  const unsigned* ic = V.ic + b.ii0;
-  const unsigned count = ic[lr] + ic[ul] - ic[ur] - ic[ll];
+  const double* ii = V.ii + (size_t)b.ii0 * 10;
+  const unsigned count = (unsigned)ii[lr * 10 + 9] + (unsigned)ii[ul * 10 + 9] - (unsigned)ii[ur * 10 + 9] - (unsigned)ii[ll * 10 + 9];
   if (count == 0) return;
-  const double* fo = V.fo + (size_t)b.ii0 * 3;
-  const double* so = V.so + (size_t)b.ii0 * 6;
   float cen[3], sov[6], cov[9];
 #pragma unroll
-  for (int k = 0; k < 3; ++k) cen[k] = (float)(fo[lr * 3 + k] + fo[ul * 3 + k] - fo[ur * 3 + k] - fo[ll * 3 + k]);
+  for (int k = 0; k < 3; ++k) cen[k] = (float)(ii[lr * 10 + k] + ii[ul * 10 + k] - ii[ur * 10 + k] - ii[ll * 10 + k]);
 #pragma unroll
-  for (int k = 0; k < 6; ++k) sov[k] = (float)(so[lr * 6 + k] + so[ul * 6 + k] - so[ur * 6 + k] - so[ll * 6 + k]);
+  for (int k = 0; k < 6; ++k) sov[k] = (float)(ii[lr * 10 + 3 + k] + ii[ul * 10 + 3 + k] - ii[ur * 10 + 3 + k] - ii[ll * 10 + 3 + k]);
   cov[0] = sov[0]; cov[1] = cov[3] = sov[1]; cov[2] = cov[6] = sov[2]; cov[4] = sov[3]; cov[5] = cov[7] = sov[4]; cov[8] = sov[5];
   const float fc = (float)count;
 #pragma unroll
@@ -652,6 +638,7 @@ __device__ __forceinline__ bool refine_compare(float dist_thr, const float* mode
   return d < (double)t;
 }
 __device__ __forceinline__ void refine_record(const View& V, int slot, int model_idx, unsigned long long pass, unsigned long long key, int target) {
+  if (V.dbg & 1) return;
   Region* R = &V.reg[(size_t)slot * kMaxRegions + model_idx];
   atomicAdd(&R->inliers, 1);
   atomicMax(&R->last_key, (pass << 60) | (key << 24) | (unsigned long long)target);
@@ -677,27 +664,57 @@ __global__ __launch_bounds__(256) void k_refine(View V) {
     for (int k = threadIdx.x; k < (nr + 1) * w; k += 256) lband[k] = L[(size_t)r0 * w + k];
     for (int k = threadIdx.x; k < (nr + 1) * w * 3; k += 256) pband[k] = gp[(size_t)r0 * w * 3 + k];
     __syncthreads();
-    if (threadIdx.x < 64) {
+    if (threadIdx.x < 64 && !(V.dbg & 2)) {
+      // One step = one pixel of this lane's row.  Only the two neighbour labels have to be read after the previous step's writes; the
+      // lane's own label is carried in a register (the row above wrote it at least one step before it was read as `rl`), and the
+      // points / the plane model of the NEXT step are fetched while this step's labels are on their way.
       const int l = threadIdx.x;
       const int steps = (w - 1) + 2 * (nr - 1);
+      const bool rowok = l < nr;
+      int* cur = lband + (rowok ? l : 0) * w;
+      const float* prow = pband + (size_t)(rowok ? l : 0) * w * 3;
+      const int r = r0 + l;
+      int cl = -1;
+      float z = 0, m0 = 0, m1 = 0, m2 = 0, m3 = 0, pr0 = 0, pr1 = 0, pr2 = 0, pd0 = 0, pd1 = 0, pd2 = 0;
       for (int t = 0; t < steps; ++t) {
         const int c = t - 2 * l;
-        if (l < nr && c >= 0 && c < w - 1) {
-          int* cur = lband + l * w;
-          const float* pc = pband + ((size_t)l * w + c) * 3;
-          const int r = r0 + l;
-          // independent LDS reads first (the right-neighbour write below never touches cur[w + c])
-          const int cl = cur[c], rl = cur[c + 1], ll = cur[w + c];
-          if (cl >= 0 && rl >= 0) {
-            if (refine_compare(dthr, models, cl, rl, pc, pc + 3)) {
-              cur[c + 1] = cl;
-              refine_record(V, slot, cl, 1ull, (unsigned long long)(r * w + c) * 2ull, r * w + c + 1);
-            }
-            if (ll >= 0 && refine_compare(dthr, models, cl, ll, pc, pc + 3 * w)) {
-              cur[w + c] = cl;
-              refine_record(V, slot, cl, 1ull, (unsigned long long)(r * w + c) * 2ull + 1ull, (r + 1) * w + c);
-            }
+        const bool act = rowok && c >= 0 && c < w - 1;
+        if (act && c == 0) {   // first pixel of the row: nothing carried yet
+          cl = cur[0];
+          z = prow[2];
+          pr0 = prow[3]; pr1 = prow[4]; pr2 = prow[5];
+          pd0 = prow[3 * w]; pd1 = prow[3 * w + 1]; pd2 = prow[3 * w + 2];
+          const float* m = models + ((cl >= 0 && cl < kMaxRegions) ? cl : 0) * 4;
+          m0 = m[0]; m1 = m[1]; m2 = m[2]; m3 = m[3];
+        }
+        const int cc = act ? c : 0;
+        const int rl = cur[cc + 1], ll = cur[w + cc];
+        const int cn = min(cc + 1, w - 2);                     // next step's pixel: its right and lower neighbours
+        const float* qn = prow + (size_t)(cn + 1) * 3;
+        const float* qd = prow + (size_t)(w + cn) * 3;
+        const float nr0 = qn[0], nr1 = qn[1], nr2 = qn[2], nd0 = qd[0], nd1 = qd[1], nd2 = qd[2];
+        if (act) {
+          // PlaneRefinementComparator::compare twice (right, lower): grow[current] && !grow[next] && distance of the next point to the
+          // current label's plane < threshold * z^2 of the current point; the lower check only runs when the right label is valid
+          const bool ok = cl >= 0 && rl >= 0 && cl < kMaxRegions;
+          const float thr = dthr * (z * z);
+          const double d1 = fabs((double)(m0 * pr0 + m1 * pr1 + m2 * pr2 + m3));
+          const double d2 = fabs((double)(m0 * pd0 + m1 * pd1 + m2 * pd2 + m3));
+          const bool c1 = ok && rl >= kMaxRegions && d1 < (double)thr;
+          const bool c2 = ok && ll >= kMaxRegions && d2 < (double)thr;
+          if (c1) {
+            cur[c + 1] = cl;
+            refine_record(V, slot, cl, 1ull, (unsigned long long)(r * w + c) * 2ull, r * w + c + 1);
           }
+          if (c2) {
+            cur[w + c] = cl;
+            refine_record(V, slot, cl, 1ull, (unsigned long long)(r * w + c) * 2ull + 1ull, (r + 1) * w + c);
+          }
+          cl = c1 ? cl : rl;
+          z = pr2;
+          pr0 = nr0; pr1 = nr1; pr2 = nr2; pd0 = nd0; pd1 = nd1; pd2 = nd2;
+          const float* m = models + ((cl >= 0 && cl < kMaxRegions) ? cl : 0) * 4;
+          m0 = m[0]; m1 = m[1]; m2 = m[2]; m3 = m[3];
         }
       }
     }
@@ -712,36 +729,225 @@ __global__ __launch_bounds__(256) void k_refine(View V) {
     for (int k = threadIdx.x; k < (nr + 1) * w; k += 256) lband[k] = L[(size_t)rlo * w + k];
     for (int k = threadIdx.x; k < (nr + 1) * w * 3; k += 256) pband[k] = gp[(size_t)rlo * w * 3 + k];
     __syncthreads();
-    if (threadIdx.x < 64) {
-      const int l = threadIdx.x;  // lane l owns row rhi - l
+    if (threadIdx.x < 64 && !(V.dbg & 2)) {
+      const int l = threadIdx.x;  // lane l owns row rhi - l; same register-carried form as sweep 1, mirrored
       const int steps = w + 2 * (nr - 1);
+      const bool rowok = l < nr;
+      const int r = rhi - (rowok ? l : 0);
+      int* cur = lband + (r - rlo) * w;
+      const float* prow = pband + (size_t)(r - rlo) * w * 3;
+      int cl = -1;
+      float z = 0, m0 = 0, m1 = 0, m2 = 0, m3 = 0, pl0 = 0, pl1 = 0, pl2 = 0, pu0 = 0, pu1 = 0, pu2 = 0;
       for (int t = 0; t < steps; ++t) {
         const int c = (w - 1) - (t - 2 * l);
-        if (l < nr && c >= 0 && c <= w - 1) {
-          const int r = rhi - l;
-          int* cur = lband + (r - rlo) * w;
-          const float* pc = pband + ((size_t)(r - rlo) * w + c) * 3;
-          // column 0 has no left neighbour here (PCL reads the previous row's last pixel)
-          const int cl = cur[c];
-          const int lf = c >= 1 ? cur[c - 1] : 0;
-          const int ul = cur[c - w];
-          if (cl >= 0 && lf >= 0) {
-            const unsigned long long key = (unsigned long long)((h - 1 - r) * w + (w - 1 - c)) * 2ull;
-            if (c >= 1 && refine_compare(dthr, models, cl, lf, pc, pc - 3)) {
-              cur[c - 1] = cl;
-              refine_record(V, slot, cl, 2ull, key, r * w + c - 1);
-            }
-            if (ul >= 0 && refine_compare(dthr, models, cl, ul, pc, pc - 3 * w)) {
-              cur[c - w] = cl;
-              refine_record(V, slot, cl, 2ull, key + 1ull, (r - 1) * w + c);
-            }
+        const bool act = rowok && c >= 0 && c <= w - 1;
+        if (act && c == w - 1) {   // first pixel of the row (sweep 2 runs right to left)
+          cl = cur[c];
+          const float* pc = prow + (size_t)c * 3;
+          z = pc[2];
+          pl0 = pc[-3]; pl1 = pc[-2]; pl2 = pc[-1];
+          pu0 = pc[-3 * w]; pu1 = pc[-3 * w + 1]; pu2 = pc[-3 * w + 2];
+          const float* m = models + ((cl >= 0 && cl < kMaxRegions) ? cl : 0) * 4;
+          m0 = m[0]; m1 = m[1]; m2 = m[2]; m3 = m[3];
+        }
+        const int cc = act ? c : 1;
+        // column 0 has no left neighbour here (PCL reads the previous row's last pixel): label 0 stands in, unused
+        const int lf = cc >= 1 ? cur[cc - 1] : 0;
+        const int ul = cur[cc - w];
+        const float* ql = prow + (size_t)max(cc - 2, 0) * 3;                       // next step's pixel (c - 1): its left neighbour ...
+        const float* qu = prow + (size_t)max(cc - 1, 0) * 3 - (size_t)w * 3;      // ... and its upper neighbour
+        const float nl0 = ql[0], nl1 = ql[1], nl2 = ql[2];
+        const float nu0 = qu[0], nu1 = qu[1], nu2 = qu[2];
+        if (act) {
+          const bool ok = cl >= 0 && lf >= 0 && cl < kMaxRegions;
+          const float thr = dthr * (z * z);
+          const double d1 = fabs((double)(m0 * pl0 + m1 * pl1 + m2 * pl2 + m3));
+          const double d2 = fabs((double)(m0 * pu0 + m1 * pu1 + m2 * pu2 + m3));
+          const bool c1 = ok && c >= 1 && lf >= kMaxRegions && d1 < (double)thr;
+          const bool c2 = ok && ul >= kMaxRegions && d2 < (double)thr;
+          const unsigned long long key = (unsigned long long)((h - 1 - r) * w + (w - 1 - c)) * 2ull;
+          if (c1) {
+            cur[c - 1] = cl;
+            refine_record(V, slot, cl, 2ull, key, r * w + c - 1);
           }
+          if (c2) {
+            cur[c - w] = cl;
+            refine_record(V, slot, cl, 2ull, key + 1ull, (r - 1) * w + c);
+          }
+          cl = c1 ? cl : lf;
+          z = pl2;
+          pl0 = nl0; pl1 = nl1; pl2 = nl2; pu0 = nu0; pu1 = nu1; pu2 = nu2;
+          const float* m = models + ((cl >= 0 && cl < kMaxRegions) ? cl : 0) * 4;
+          m0 = m[0]; m1 = m[1]; m2 = m[2]; m3 = m[3];
         }
       }
     }
     __syncthreads();
     for (int k = threadIdx.x; k < (nr + 1) * w; k += 256) L[(size_t)rlo * w + k] = lband[k];
     __syncthreads();
+  }
+}
+
+// The same two sweeps for boxes whose label image fits LDS (<= kCcLdsMax pixels), as a fixed-point iteration instead of a wavefront.
+// A pixel is only ever written while it still carries kOther, and only by the two neighbours the raster order visits before it (sweep 1:
+// the upper one first, then the left one; sweep 2: the lower one first, then the right one), each with the label it ends the sweep with.
+// So the result of a sweep is the unique solution of   label(T) = F(label(first neighbour), label(second neighbour))   on a DAG, and
+// re-evaluating F for every kOther pixel until nothing changes reaches it -- with all the threads of the workgroup, in as many passes
+// as the longest chain of newly absorbed pixels (a thread walks its pixels in sweep order, so chains along a row cost one pass).  The
+// region records (absorbed pixels, the last one in PCL's order) are taken once a sweep has converged.
+constexpr int kRefTX = 32, kRefTY = 16;   // k_refine_lds: 512 threads, thread (tx, ty) owns a tile of ceil(w/32) x ceil(h/16) <= 32 pixels
+constexpr int kRefMaskRegions = 8;         // boxes with at most this many planes take the precomputed-mask form
+// does region `a` absorb pixel i when it arrives from writer pixel s (threshold from the writer's depth)?
+__device__ __forceinline__ bool refine_fits(const float* models, const float* pts, float dthr, int a, int i, int s) {
+  const float* m = models + a * 4;
+  const float z = pts[(size_t)s * 3 + 2];
+  const float t = dthr * (z * z);
+  const float d = fabsf(m[0] * pts[(size_t)i * 3] + m[1] * pts[(size_t)i * 3 + 1] + m[2] * pts[(size_t)i * 3 + 2] + m[3]);
+  return d < t;
+}
+// first / second candidate writer of pixel i in this sweep's order and whether they exist as "current" pixels of the sweep; the first
+// writer's own gate (its right neighbour in sweep 1 / its left one in sweep 2, label 0 standing in at column 0, must be a valid pixel)
+template <int SWEEP>
+__device__ __forceinline__ void refine_writers(const short* Lc, int i, int r, int c, int w, int h, int* s1, int* s2, bool* ok1, bool* ok2) {
+  *s1 = SWEEP == 1 ? i - w : i + w;
+  *s2 = SWEEP == 1 ? i - 1 : i + 1;
+  bool o1 = SWEEP == 1 ? (r >= 1 && c <= w - 2) : (r + 1 <= h - 1);
+  if (o1) o1 = SWEEP == 1 ? Lc[*s1 + 1] >= 0 : (c >= 1 ? Lc[*s1 - 1] >= 0 : true);
+  *ok1 = o1;
+  *ok2 = SWEEP == 1 ? (c >= 1 && r <= h - 2) : (c + 1 <= w - 1 && r >= 1);
+}
+// label of pixel i given its writers' current labels; MASKED: the distance tests were done once per sweep (bit a of the low / high byte
+// of M[i]: region a fits when it arrives from the first / second writer; zero where that writer does not exist)
+template <int SWEEP, bool MASKED>
+__device__ __forceinline__ int refine_eval(const short* Lc, const unsigned short* M, const float* models, const float* pts, float dthr, int i, int r, int c,
+                                           int w, int h, int* writer) {
+  *writer = 0;
+  if (MASKED) {
+    const unsigned m = M[i];
+    if (m == 0) return kOther;
+    const int s1 = SWEEP == 1 ? i - w : i + w, s2 = SWEEP == 1 ? i - 1 : i + 1;
+    if (m & 0xffu) {
+      const int a1 = Lc[s1];
+      if (a1 >= 0 && a1 < kRefMaskRegions && ((m >> a1) & 1u)) { *writer = 1; return a1; }
+    }
+    if (m >> 8) {
+      const int a2 = Lc[s2];
+      if (a2 >= 0 && a2 < kRefMaskRegions && ((m >> (8 + a2)) & 1u)) { *writer = 2; return a2; }
+    }
+    return kOther;
+  }
+  int s1, s2; bool ok1, ok2;
+  refine_writers<SWEEP>(Lc, i, r, c, w, h, &s1, &s2, &ok1, &ok2);
+  if (ok1) {
+    const int a1 = Lc[s1];
+    if (a1 >= 0 && a1 < kMaxRegions && refine_fits(models, pts, dthr, a1, i, s1)) { *writer = 1; return a1; }
+  }
+  if (ok2) {
+    const int a2 = Lc[s2];
+    if (a2 >= 0 && a2 < kMaxRegions && refine_fits(models, pts, dthr, a2, i, s2)) { *writer = 2; return a2; }
+  }
+  return kOther;
+}
+template <int SWEEP, bool MASKED>
+__device__ __forceinline__ void refine_sweep_lds(short* Lc, unsigned short* M, const float* models, int nregs, const float* pts, float dthr, int w, int h,
+                                                 int* s_changed, int* rcnt, unsigned long long* rkey, int* dbgc) {
+  const int tid = threadIdx.x;
+  const int tw = (w + kRefTX - 1) / kRefTX, th = (h + kRefTY - 1) / kRefTY;
+  const int c0 = (tid % kRefTX) * tw, r0 = (tid / kRefTX) * th;
+  const int c1 = min(w, c0 + tw), r1 = min(h, r0 + th);
+  unsigned cand = 0;                            // bit (dy * tw + dx): the pixel carried kOther when the sweep began
+  for (int r = r0; r < r1; ++r)
+    for (int c = c0; c < c1; ++c) {
+      const int i = r * w + c;
+      if (Lc[i] < kMaxRegions) continue;
+      cand |= 1u << ((r - r0) * tw + (c - c0));
+      if (MASKED) {
+        int s1, s2; bool ok1, ok2;
+        refine_writers<SWEEP>(Lc, i, r, c, w, h, &s1, &s2, &ok1, &ok2);
+        unsigned m = 0;
+        for (int a = 0; a < nregs; ++a) {
+          if (ok1 && refine_fits(models, pts, dthr, a, i, s1)) m |= 1u << a;
+          if (ok2 && refine_fits(models, pts, dthr, a, i, s2)) m |= 1u << (8 + a);
+        }
+        M[i] = (unsigned short)m;
+      }
+    }
+  int passes = 0;
+  for (int pass = 0; pass < w + h + 2; ++pass) {
+    if (tid == 0) *s_changed = 0;
+    __syncthreads();
+    bool ch = false;
+    if (cand) {
+      // the tile in sweep order, so that a chain inside the tile is followed to its end in one pass
+      for (int dy = 0; dy < r1 - r0; ++dy) {
+        const int r = SWEEP == 1 ? r0 + dy : r1 - 1 - dy;
+        for (int dx = 0; dx < c1 - c0; ++dx) {
+          const int c = SWEEP == 1 ? c0 + dx : c1 - 1 - dx;
+          if (!((cand >> ((r - r0) * tw + (c - c0))) & 1u)) continue;
+          const int i = r * w + c;
+          int wr;
+          const int v = refine_eval<SWEEP, MASKED>(Lc, M, models, pts, dthr, i, r, c, w, h, &wr);
+          if (v != Lc[i]) { Lc[i] = (short)v; ch = true; }
+        }
+      }
+    }
+    if (ch) *s_changed = 1;
+    __syncthreads();
+    const int any = *s_changed;
+    __syncthreads();
+    ++passes;
+    if (!any) break;
+  }
+  if (dbgc && tid == 0) { atomicMax(&dbgc[SWEEP], passes); atomicAdd(&dbgc[2 + SWEEP], passes); }
+  for (int r = r0; r < r1; ++r)
+    for (int c = c0; c < c1; ++c) {
+      const int i = r * w + c;
+      if (!((cand >> ((r - r0) * tw + (c - c0))) & 1u) || Lc[i] >= kMaxRegions) continue;
+      int wr;
+      const int v = refine_eval<SWEEP, MASKED>(Lc, M, models, pts, dthr, i, r, c, w, h, &wr);
+      // order key of the writing pixel: its raster position (sweep 1) / reverse raster position (sweep 2), x 2, + 1 for the vertical write
+      const int sidx = SWEEP == 1 ? (wr == 1 ? i - w : i - 1) : (wr == 1 ? i + w : i + 1);
+      const int sr = sidx / w, sc = sidx - sr * w;
+      const unsigned long long pos = SWEEP == 1 ? (unsigned long long)sidx : (unsigned long long)((h - 1 - sr) * w + (w - 1 - sc));
+      const unsigned long long key = pos * 2ull + (wr == 1 ? 1ull : 0ull);
+      atomicAdd(&rcnt[v], 1);
+      atomicMax(&rkey[v], ((unsigned long long)SWEEP << 60) | (key << 24) | (unsigned long long)i);
+    }
+  __syncthreads();
+}
+__global__ __launch_bounds__(kRefTX * kRefTY) void k_refine_lds(View V) {
+  extern __shared__ short Lc[];                  // labels (-1, 0..63, kOther) as 16-bit words, then the masks
+  __shared__ float models[kMaxRegions * 4];
+  __shared__ int rcnt[kMaxRegions];
+  __shared__ unsigned long long rkey[kMaxRegions];
+  __shared__ int s_changed;
+  constexpr int NT = kRefTX * kRefTY;
+  const BoxMeta b = V.box[blockIdx.x];
+  const int slot = blockIdx.x;
+  const int nregs = V.nreg[slot];
+  if (nregs == 0) return;
+  const int w = b.w, h = b.h, n = w * h, tid = threadIdx.x;
+  unsigned short* M = reinterpret_cast<unsigned short*>(Lc + ((n + 1) & ~1));
+  for (int k = tid; k < nregs * 4; k += NT) models[k] = V.reg[(size_t)slot * kMaxRegions + (k >> 2)].model[k & 3];
+  if (tid < kMaxRegions) { rcnt[tid] = 0; rkey[tid] = 0; }
+  int* L = V.code + b.pix0;
+  const float* gp = V.pts + (size_t)b.pix0 * 3;
+  for (int i = tid; i < n; i += NT) Lc[i] = (short)L[i];
+  __syncthreads();
+  int* dbgc = (V.dbg & 8) ? V.overflow + 2 : nullptr;
+  if (nregs <= kRefMaskRegions) {
+    refine_sweep_lds<1, true>(Lc, M, models, nregs, gp, V.dist_thr, w, h, &s_changed, rcnt, rkey, dbgc);
+    refine_sweep_lds<2, true>(Lc, M, models, nregs, gp, V.dist_thr, w, h, &s_changed, rcnt, rkey, dbgc);
+  } else {
+    refine_sweep_lds<1, false>(Lc, M, models, nregs, gp, V.dist_thr, w, h, &s_changed, rcnt, rkey, dbgc);
+    refine_sweep_lds<2, false>(Lc, M, models, nregs, gp, V.dist_thr, w, h, &s_changed, rcnt, rkey, dbgc);
+  }
+  if (dbgc && tid == 0) atomicAdd(&dbgc[5], 1);
+  for (int i = tid; i < n; i += NT) L[i] = Lc[i];
+  if (tid < nregs && rcnt[tid] > 0) {
+    Region* R = &V.reg[(size_t)slot * kMaxRegions + tid];
+    R->inliers += rcnt[tid];
+    if (rkey[tid] > R->last_key) R->last_key = rkey[tid];
   }
 }
 
@@ -1646,14 +1852,12 @@ static int seg_enqueue(sslam_seg* s, const sslam_frame* frames, int n_frames, in
     if ((rc = seg_alloc(s, s->cap_pix, &V.cnt))) return rc;
     if ((rc = seg_alloc(s, s->cap_pix, &V.l2m))) return rc;
     if ((rc = seg_alloc(s, s->cap_pix, &V.code))) return rc;
-    if ((rc = seg_alloc(s, s->cap_ii * 3, &V.fo))) return rc;
-    if ((rc = seg_alloc(s, s->cap_ii * 6, &V.so))) return rc;
-    if ((rc = seg_alloc(s, s->cap_ii, &V.ic))) return rc;
+    if ((rc = seg_alloc(s, s->cap_ii * 10, &V.ii))) return rc;
     if ((rc = seg_alloc(s, s->cap_box * kMaxRegions, &V.reg))) return rc;
     if ((rc = seg_alloc(s, s->cap_box, &V.nreg))) return rc;
     if ((rc = seg_alloc(s, s->cap_pix * 4, &V.contour))) return rc;
     if ((rc = seg_alloc(s, s->cap_box, &V.ccount))) return rc;
-    if ((rc = seg_alloc(s, (size_t)2, &V.overflow))) return rc;
+    if ((rc = seg_alloc(s, (size_t)8, &V.overflow))) return rc;   // [2] overflow counters + [6] debug counters (SSLAM_SEG_DBG & 8)
   }
   V.nbox = nb; V.npix_total = (int)npix; V.maxpix = maxpix;
   V.box = s->d_box; V.cloud = s->d_cloud; V.cloud_stride = frame_bytes;
@@ -1661,6 +1865,7 @@ static int seg_enqueue(sslam_seg* s, const sslam_frame* frames, int n_frames, in
   V.mdcf = P.max_depth_change_factor; V.smoothing = P.normal_smoothing_size;
   V.ang_thr_cos = cosf(P.angular_threshold); V.dist_thr = P.distance_threshold; V.max_curv = P.maximum_curvature;
   V.min_inliers = (unsigned)P.num_point_seg;
+  { const char* e = getenv("SSLAM_SEG_DBG"); V.dbg = e ? atoi(e) : 0; }
   { const char* e = getenv("SSLAM_SEG_REFINE_BH"); V.refine_bh = e ? std::max(2, std::min(64, atoi(e))) : (nb > 512 ? 24 : 64); }
   s->q_frames.resize(n_frames);
   for (int f = 0; f < n_frames; ++f) { memcpy(s->q_frames[f].robot_pose, frames[f].robot_pose, sizeof(float) * 6); s->q_frames[f].cam_angle = frames[f].cam_angle; }
@@ -1682,7 +1887,7 @@ static int seg_enqueue(sslam_seg* s, const sslam_frame* frames, int n_frames, in
   if (nb > 0) {
     for (int f = 0; f < n_frames; ++f)
       SSLAM_HIP_TRY(hipMemcpyAsync(s->d_cloud + (size_t)f * frame_bytes, frames[f].cloud, frame_bytes, hipMemcpyHostToDevice, s->stream));
-    SSLAM_HIP_TRY(hipMemsetAsync(V.overflow, 0, 2 * sizeof(int), s->stream));
+    SSLAM_HIP_TRY(hipMemsetAsync(V.overflow, 0, 8 * sizeof(int), s->stream));
     SSLAM_HIP_TRY(hipMemcpyAsync(s->d_box, s->boxes.data(), nb * sizeof(BoxMeta), hipMemcpyHostToDevice, s->stream));
     if (!s->q_e0) { SSLAM_HIP_TRY(hipEventCreate(&s->q_e0)); SSLAM_HIP_TRY(hipEventCreate(&s->q_e1)); }
     hipEvent_t e0 = s->q_e0, e1 = s->q_e1;
@@ -1712,7 +1917,10 @@ static int seg_enqueue(sslam_seg* s, const sslam_frame* frames, int n_frames, in
     {
       // band rows: as many as fit next to the (w+1) x 10 double carry row in ~150 KiB of LDS (<= 64 lanes)
       const size_t carry = (size_t)(maxw + 1) * 10 * sizeof(double);
-      const int ib_rows = (int)std::max<size_t>(1, std::min<size_t>(64, (150 * 1024 - carry) / ((size_t)maxw * 12)));
+      // (a call with more boxes than CUs takes 24-row bands: three boxes per CU instead of one)
+      const char* ie = getenv("SSLAM_SEG_INTEGRAL_ROWS");
+      const size_t row_cap = ie ? (size_t)std::max(1, std::min(64, atoi(ie))) : (nb > 512 ? 24 : 64);
+      const int ib_rows = (int)std::max<size_t>(1, std::min<size_t>(row_cap, (150 * 1024 - carry) / ((size_t)maxw * 12)));
       const size_t ilds = carry + (size_t)ib_rows * maxw * 12;
       if (ilds > 64 * 1024) SSLAM_HIP_TRY(hipFuncSetAttribute((const void*)k_integral, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ilds));
       hipLaunchKernelGGL(k_integral, dim3(nb), dim3(256), ilds, s->stream, V, ib_rows);
@@ -1721,6 +1929,7 @@ static int seg_enqueue(sslam_seg* s, const sslam_frame* frames, int n_frames, in
     hipLaunchKernelGGL(k_normals, pg, pb, 0, s->stream, V);
     DBG("k_normals");
     if (maxpix <= kCcLdsMax && !getenv("SSLAM_SEG_GLOBAL_CC")) {
+      if ((size_t)maxpix * sizeof(int) > 60 * 1024) SSLAM_HIP_TRY(hipFuncSetAttribute((const void*)k_cc_lds, hipFuncAttributeMaxDynamicSharedMemorySize, kCcLdsMax * (int)sizeof(int)));
       hipLaunchKernelGGL(k_cc_lds, dim3(nb), dim3(1024), (size_t)maxpix * sizeof(int), s->stream, V);
       DBG("k_cc_lds");
     } else {
@@ -1738,8 +1947,24 @@ static int seg_enqueue(sslam_seg* s, const sslam_frame* frames, int n_frames, in
     DBG("k_regions");
     hipLaunchKernelGGL(k_relabel, pg, pb, 0, s->stream, V);
     DBG("k_relabel");
-    hipLaunchKernelGGL(k_refine, dim3(nb), dim3(256), rband_bytes, s->stream, V);
-    DBG("k_refine");
+    bool tiles_ok = true;   // k_refine_lds: every thread's tile must fit its 32-bit candidate mask
+    for (auto& b : s->boxes) tiles_ok = tiles_ok && ((b.w + kRefTX - 1) / kRefTX) * ((b.h + kRefTY - 1) / kRefTY) <= 32;
+    if (maxpix <= kCcLdsMax && tiles_ok && !getenv("SSLAM_SEG_WAVEFRONT_REFINE")) {
+      // 16-bit labels + 16-bit masks: 4 bytes per pixel (three 12k-pixel boxes per CU)
+      if ((size_t)maxpix * 4 + 8 > 60 * 1024) SSLAM_HIP_TRY(hipFuncSetAttribute((const void*)k_refine_lds, hipFuncAttributeMaxDynamicSharedMemorySize, kCcLdsMax * 4 + 8));
+      hipLaunchKernelGGL(k_refine_lds, dim3(nb), dim3(kRefTX * kRefTY), (size_t)maxpix * 4 + 8, s->stream, V);
+      DBG("k_refine_lds");
+      if (V.dbg & 8) {
+        int dc[6];
+        (void)hipStreamSynchronize(s->stream);
+        (void)hipMemcpy(dc, V.overflow + 2, sizeof dc, hipMemcpyDeviceToHost);
+        fprintf(stderr, "[seg] refine passes: sweep 1 max %d mean %.1f, sweep 2 max %d mean %.1f over %d boxes\n", dc[1], dc[3] / (double)std::max(dc[5], 1), dc[2],
+                dc[4] / (double)std::max(dc[5], 1), dc[5]);
+      }
+    } else {
+      hipLaunchKernelGGL(k_refine, dim3(nb), dim3(256), rband_bytes, s->stream, V);
+      DBG("k_refine");
+    }
     if (dbg) {
       std::vector<Region> rr((size_t)nb * kMaxRegions); std::vector<int> nn(nb);
       (void)hipMemcpy(rr.data(), V.reg, rr.size() * sizeof(Region), hipMemcpyDeviceToHost);

@@ -47,6 +47,26 @@ def test_frame_matches_oracle_bit_exact(gpu_lib, seed):
         assert np.array_equal(a.world_pose, np.array(r.world_pose, np.float32))
 
 
+@pytest.mark.parametrize("box_w,box_h,env", [(160, 102, None), (168, 100, None), (128, 96, "SSLAM_SEG_GLOBAL_CC"), (128, 96, "SSLAM_SEG_WAVEFRONT_REFINE")])
+def test_box_sizes_either_side_of_the_lds_limit(gpu_lib, monkeypatch, box_w, box_h, env):
+    """connected components and refinement run out of LDS for boxes of <= 16384 pixels (160 x 102 = 16320 takes the full 64 KB) and
+    through HBM above (168 x 100); both forms, and the HBM forms forced on small boxes, give the oracle's label images"""
+    if env:
+        monkeypatch.setenv(env, "1")
+    f = make_frame(seed=5, n_boxes=12, box_w=box_w, box_h=box_h)
+    seg, planes, ref, nrm, lab = _run_both(f)
+    off = 0
+    for bi, b in enumerate(f.boxes):
+        n = int(b["width"]) * int(b["height"])
+        gl = seg.labels(bi).reshape(n)
+        assert np.array_equal(gl, lab[off:off + n]), f"box {bi}: label image differs in {(gl != lab[off:off+n]).sum()} px"
+        off += n
+    assert len(planes) == len(ref) and len(ref) > 0
+    for a, r in zip(planes, ref):
+        assert (a.box_index, a.inlier_count, a.num_points, a.area) == (r.box_index, r.inlier_count, r.num_points, r.area)
+        assert np.array_equal(a.normal_orientation, np.array(r.normal_d, np.float32))
+
+
 def test_noise_free_planes_are_recovered(gpu_lib):
     """A noise-free piecewise-planar scene: every pixel a plane owns (label image of the HIP path) lies on the reported plane.
     PlaneRefinementComparator admits a pixel within 0.02 z^2 of the model (depth-dependent threshold), the fitted inliers
