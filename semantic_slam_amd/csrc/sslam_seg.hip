@@ -69,7 +69,7 @@ struct View {
   int* nreg;     // [nbox]
   float mdcf, smoothing, ang_thr_cos, dist_thr, max_curv;
   unsigned min_inliers;
-  int dbg;         // timing experiments (SSLAM_SEG_DBG; results are wrong when set): 1 = refine without its region records, 2 = refine without the sweeps, 4 = integral images without stores
+  int dbg;         // timing experiments (SSLAM_SEG_DBG; results are wrong when set): 1 = refine without its region records, 2 = refine without the sweeps, 4 = integral images without stores, 8 = print refine pass counts, 16 / 32 = refine without masks / passes, 64 = integral staging only
   int refine_bh;   // rows per LDS band of k_refine (64: one box per CU, lowest latency; 24: three boxes per CU for calls with many boxes)
 };
 
@@ -320,7 +320,8 @@ __global__ __launch_bounds__(256) void k_integral(View V, int band_rows) {
     const int nr = min(band_rows, h - r0);
     for (int k = tid; k < nr * w * 3; k += 256) bpts[k] = pts[(size_t)r0 * w * 3 + k];   // coalesced
     __syncthreads();
-    if (wave == 0) integral_wave<0, 3>(bpts, prevrow, rec, w, nr, r0, lane, V.dbg);
+    if (V.dbg & 64) {}
+    else if (wave == 0) integral_wave<0, 3>(bpts, prevrow, rec, w, nr, r0, lane, V.dbg);
     else if (wave == 1) integral_wave<3, 3>(bpts, prevrow, rec, w, nr, r0, lane, V.dbg);
     else if (wave == 2) integral_wave<6, 2>(bpts, prevrow, rec, w, nr, r0, lane, V.dbg);
     else integral_wave<8, 2>(bpts, prevrow, rec, w, nr, r0, lane, V.dbg);
@@ -536,11 +537,21 @@ __global__ __launch_bounds__(NT) void k_regions(View V) {
     const int label = cand[k];
     float acc = 0;            // lanes 0..8: component `lane`
     int first = -1, last = -1;
+    // the next chunk's label and point travel while this chunk's serial additions run (the loop is otherwise one HBM / L2 round trip
+    // per 64 pixels long)
+    int ln = lane < n ? L[lane] : -2;
+    float xn = 0, yn = 0, zn = 0;
+    if (lane < n) { xn = pts[(size_t)lane * 3]; yn = pts[(size_t)lane * 3 + 1]; zn = pts[(size_t)lane * 3 + 2]; }
     for (int i0 = 0; i0 < n; i0 += 64) {
       const int i = i0 + lane;
-      const bool m = i < n && L[i] == label;
+      const bool m = i < n && ln == label;
+      const float x = xn, y = yn, z = zn;
+      {
+        const int j = i + 64;
+        ln = j < n ? L[j] : -2;
+        if (j < n) { xn = pts[(size_t)j * 3]; yn = pts[(size_t)j * 3 + 1]; zn = pts[(size_t)j * 3 + 2]; }
+      }
       if (m) {
-        const float x = pts[(size_t)i * 3], y = pts[(size_t)i * 3 + 1], z = pts[(size_t)i * 3 + 2];
         float* p = prod[wave][lane];
         p[0] = x * x; p[1] = x * y; p[2] = x * z; p[3] = y * y; p[4] = y * z; p[5] = z * z; p[6] = x; p[7] = y; p[8] = z;
       }
@@ -823,17 +834,13 @@ __device__ __forceinline__ int refine_eval(const short* Lc, const unsigned short
                                            int w, int h, int* writer) {
   *writer = 0;
   if (MASKED) {
+    // the mask and both writers' labels in one LDS round trip (clamped addresses; a writer that does not exist has an empty mask byte)
+    const int n = w * h;
+    const int s1 = SWEEP == 1 ? max(i - w, 0) : min(i + w, n - 1), s2 = SWEEP == 1 ? max(i - 1, 0) : min(i + 1, n - 1);
     const unsigned m = M[i];
-    if (m == 0) return kOther;
-    const int s1 = SWEEP == 1 ? i - w : i + w, s2 = SWEEP == 1 ? i - 1 : i + 1;
-    if (m & 0xffu) {
-      const int a1 = Lc[s1];
-      if (a1 >= 0 && a1 < kRefMaskRegions && ((m >> a1) & 1u)) { *writer = 1; return a1; }
-    }
-    if (m >> 8) {
-      const int a2 = Lc[s2];
-      if (a2 >= 0 && a2 < kRefMaskRegions && ((m >> (8 + a2)) & 1u)) { *writer = 2; return a2; }
-    }
+    const int a1 = Lc[s1], a2 = Lc[s2];
+    if (a1 >= 0 && a1 < kRefMaskRegions && ((m >> a1) & 1u)) { *writer = 1; return a1; }
+    if (a2 >= 0 && a2 < kRefMaskRegions && ((m >> (8 + a2)) & 1u)) { *writer = 2; return a2; }
     return kOther;
   }
   int s1, s2; bool ok1, ok2;
@@ -850,54 +857,64 @@ __device__ __forceinline__ int refine_eval(const short* Lc, const unsigned short
 }
 template <int SWEEP, bool MASKED>
 __device__ __forceinline__ void refine_sweep_lds(short* Lc, unsigned short* M, const float* models, int nregs, const float* pts, float dthr, int w, int h,
-                                                 int* s_changed, int* rcnt, unsigned long long* rkey, int* dbgc) {
+                                                 int* s_changed, int* rcnt, unsigned long long* rkey, int* dbgc, int dbg) {
   const int tid = threadIdx.x;
   const int tw = (w + kRefTX - 1) / kRefTX, th = (h + kRefTY - 1) / kRefTY;
   const int c0 = (tid % kRefTX) * tw, r0 = (tid / kRefTX) * th;
   const int c1 = min(w, c0 + tw), r1 = min(h, r0 + th);
+  const int tw_inv = 65536 / tw + 1;
   unsigned cand = 0;                            // bit (dy * tw + dx): the pixel carried kOther when the sweep began
+  unsigned act = 0;                             // MASKED: ... and some plane fits it from some writer (the others can never change)
   for (int r = r0; r < r1; ++r)
     for (int c = c0; c < c1; ++c) {
       const int i = r * w + c;
       if (Lc[i] < kMaxRegions) continue;
       cand |= 1u << ((r - r0) * tw + (c - c0));
-      if (MASKED) {
+      if (MASKED && (dbg & 16)) M[i] = 0;
+      else if (MASKED) {
         int s1, s2; bool ok1, ok2;
         refine_writers<SWEEP>(Lc, i, r, c, w, h, &s1, &s2, &ok1, &ok2);
         unsigned m = 0;
-        for (int a = 0; a < nregs; ++a) {
-          if (ok1 && refine_fits(models, pts, dthr, a, i, s1)) m |= 1u << a;
-          if (ok2 && refine_fits(models, pts, dthr, a, i, s2)) m |= 1u << (8 + a);
+        if (ok1 || ok2) {   // the distance to a plane does not depend on the writer, only the threshold (the writer's depth) does
+          const float px = pts[(size_t)i * 3], py = pts[(size_t)i * 3 + 1], pz = pts[(size_t)i * 3 + 2];
+          const float z1 = pts[(size_t)(ok1 ? s1 : i) * 3 + 2], z2 = pts[(size_t)(ok2 ? s2 : i) * 3 + 2];
+          const float t1 = dthr * (z1 * z1), t2 = dthr * (z2 * z2);
+          for (int a = 0; a < nregs; ++a) {
+            const float* mm = models + a * 4;
+            const float d = fabsf(mm[0] * px + mm[1] * py + mm[2] * pz + mm[3]);
+            if (ok1 && d < t1) m |= 1u << a;
+            if (ok2 && d < t2) m |= 1u << (8 + a);
+          }
         }
         M[i] = (unsigned short)m;
+        if (m) act |= 1u << ((r - r0) * tw + (c - c0));
       }
     }
   int passes = 0;
-  for (int pass = 0; pass < w + h + 2; ++pass) {
-    if (tid == 0) *s_changed = 0;
-    __syncthreads();
+  if (tid < 3) s_changed[tid] = 0;
+  __syncthreads();
+  for (int pass = 0; pass < ((dbg & 32) ? 0 : w + h + 2); ++pass) {
+    // three flags in rotation: pass p raises [p % 3], clears [(p + 1) % 3] (last read before the barrier of pass p - 1): one barrier per pass
+    if (tid == 0) s_changed[(pass + 1) % 3] = 0;
     bool ch = false;
-    if (cand) {
-      // the tile in sweep order, so that a chain inside the tile is followed to its end in one pass
-      for (int dy = 0; dy < r1 - r0; ++dy) {
-        const int r = SWEEP == 1 ? r0 + dy : r1 - 1 - dy;
-        for (int dx = 0; dx < c1 - c0; ++dx) {
-          const int c = SWEEP == 1 ? c0 + dx : c1 - 1 - dx;
-          if (!((cand >> ((r - r0) * tw + (c - c0))) & 1u)) continue;
-          const int i = r * w + c;
-          int wr;
-          const int v = refine_eval<SWEEP, MASKED>(Lc, M, models, pts, dthr, i, r, c, w, h, &wr);
-          if (v != Lc[i]) { Lc[i] = (short)v; ch = true; }
-        }
-      }
+    // the tile's live pixels in sweep order (lowest bit first in sweep 1, highest first in sweep 2), so that a chain inside the tile is
+    // followed to its end in one pass; k / tw by a reciprocal that is exact for k < 32
+    unsigned bits = MASKED ? act : cand;
+    while (bits) {
+      const int k = SWEEP == 1 ? __ffs((int)bits) - 1 : 31 - __clz((int)bits);
+      bits &= ~(1u << k);
+      const int dy = (k * tw_inv) >> 16, dx = k - dy * tw;
+      const int r = r0 + dy, c = c0 + dx, i = r * w + c;
+      int wr;
+      const int v = refine_eval<SWEEP, MASKED>(Lc, M, models, pts, dthr, i, r, c, w, h, &wr);
+      if (v != Lc[i]) { Lc[i] = (short)v; ch = true; }
     }
-    if (ch) *s_changed = 1;
-    __syncthreads();
-    const int any = *s_changed;
+    if (ch) s_changed[pass % 3] = 1;
     __syncthreads();
     ++passes;
-    if (!any) break;
+    if (!s_changed[pass % 3]) break;
   }
+  __syncthreads();
   if (dbgc && tid == 0) { atomicMax(&dbgc[SWEEP], passes); atomicAdd(&dbgc[2 + SWEEP], passes); }
   for (int r = r0; r < r1; ++r)
     for (int c = c0; c < c1; ++c) {
@@ -920,7 +937,7 @@ __global__ __launch_bounds__(kRefTX * kRefTY) void k_refine_lds(View V) {
   __shared__ float models[kMaxRegions * 4];
   __shared__ int rcnt[kMaxRegions];
   __shared__ unsigned long long rkey[kMaxRegions];
-  __shared__ int s_changed;
+  __shared__ int s_changed[3];
   constexpr int NT = kRefTX * kRefTY;
   const BoxMeta b = V.box[blockIdx.x];
   const int slot = blockIdx.x;
@@ -936,11 +953,11 @@ __global__ __launch_bounds__(kRefTX * kRefTY) void k_refine_lds(View V) {
   __syncthreads();
   int* dbgc = (V.dbg & 8) ? V.overflow + 2 : nullptr;
   if (nregs <= kRefMaskRegions) {
-    refine_sweep_lds<1, true>(Lc, M, models, nregs, gp, V.dist_thr, w, h, &s_changed, rcnt, rkey, dbgc);
-    refine_sweep_lds<2, true>(Lc, M, models, nregs, gp, V.dist_thr, w, h, &s_changed, rcnt, rkey, dbgc);
+    refine_sweep_lds<1, true>(Lc, M, models, nregs, gp, V.dist_thr, w, h, s_changed, rcnt, rkey, dbgc, V.dbg);
+    refine_sweep_lds<2, true>(Lc, M, models, nregs, gp, V.dist_thr, w, h, s_changed, rcnt, rkey, dbgc, V.dbg);
   } else {
-    refine_sweep_lds<1, false>(Lc, M, models, nregs, gp, V.dist_thr, w, h, &s_changed, rcnt, rkey, dbgc);
-    refine_sweep_lds<2, false>(Lc, M, models, nregs, gp, V.dist_thr, w, h, &s_changed, rcnt, rkey, dbgc);
+    refine_sweep_lds<1, false>(Lc, M, models, nregs, gp, V.dist_thr, w, h, s_changed, rcnt, rkey, dbgc, V.dbg);
+    refine_sweep_lds<2, false>(Lc, M, models, nregs, gp, V.dist_thr, w, h, s_changed, rcnt, rkey, dbgc, V.dbg);
   }
   if (dbgc && tid == 0) atomicAdd(&dbgc[5], 1);
   for (int i = tid; i < n; i += NT) L[i] = Lc[i];

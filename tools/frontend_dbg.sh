@@ -1,7 +1,7 @@
 #!/bin/bash
 # kernel times of the batched frontend call under the timing switches of SSLAM_SEG_DBG
 R=${GRAFT_REPO_ROOT:-/root/repo}; cd /tmp; export TMPDIR=/tmp
-for d in 0 1 2 4; do
+for d in ${DBGS:-0 1 2 4}; do
   rm -rf /tmp/fp; SSLAM_SEG_DBG=$d rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/fp -- python $R/tools/frontend_kernels.py > /dev/null 2>&1
   echo "== SSLAM_SEG_DBG=$d"; python - <<PY
 import csv,glob
