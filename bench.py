@@ -492,10 +492,12 @@ def main():
             try:
                 ppaths = generate_graphs("plane", args.poses, args.landmarks, seeds_of(max(1, min(args.plane_distinct, args.plane_batch))), args.cache_dir)
                 pb = build_batch(ppaths, args.plane_batch, dev, args.solver)
+                if n_streams > 1:   # the same stream group as the headline
+                    pb = GraphBatch(pb.graphs, streams=min(n_streams, args.plane_batch))
                 ps, pdt = timed_optimize(pb, args.steps, min(args.warmup, 2), lambda: None)
                 pit = [int(s.iterations) for s in ps]
                 out["plane_landmarks"] = {"value": round(sum(pit) / pdt, 3), "unit": "iters/s", "graphs": args.plane_batch,
-                                          "distinct_graphs": len(ppaths), "iters_min": min(pit), "iters_max": max(pit), "chi2_after": ps[0].chi2_after,
+                                          "distinct_graphs": len(ppaths), "streams": n_streams, "iters_min": min(pit), "iters_max": max(pit), "chi2_after": ps[0].chi2_after,
                                           "workload": f"{args.poses} poses / {args.landmarks} plane landmarks (in-tree EdgeSE3Plane, "
                                                       f"central-difference Jacobians), batch of {args.plane_batch}"}
                 del pb
