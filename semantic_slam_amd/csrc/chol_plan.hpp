@@ -755,12 +755,12 @@ inline int chol_symbolic(const SymIn& in, CholOpts opt, CholHost& out) {
   auto lds_f = [&](int p) {
     const PieceMeta& pm = out.piece[p];
     const int ustage = (piece_tail[p] || !opt.ustage) ? 0 : 4 * pm.nuit + 4 * pm.numb + 2 * pm.nuu + pm.nus + 2;
-    return ((pm.lsize + 1) & ~1) + 2 * ((pm.ysize + 1) & ~1) + 4 * pm.nb + 2 * pm.nc + 2 * pm.nit_i + 2 * pm.nu_i + 2 * pm.nimb + pm.nas + ustage +
+    return 4 * pm.nilv + ((pm.lsize + 1) & ~1) + 2 * ((pm.ysize + 1) & ~1) + 4 * pm.nb + 2 * pm.nc + 2 * pm.nit_i + 2 * pm.nu_i + 2 * pm.nimb + pm.nas + ustage +
            kItemDoubles * piece_pmax[p] + 8;
   };
   auto lds_b = [&](int p) {
     const PieceMeta& pm = out.piece[p];
-    return 36 * pm.nint + ((pm.ysize + 1) & ~1) + 7 * pm.nb + 3 * pm.nc + 12;
+    return 4 * pm.nilv + 36 * pm.nint + ((pm.ysize + 1) & ~1) + 7 * pm.nb + 3 * pm.nc + 12;
   };
   // ---- launches: one per depth, and a depth with many pieces split by LDS need.  A launch reserves the LDS of its largest piece for
   //      every workgroup, and the pieces of a depth are independent, so they are sorted by need and cut where the number of

@@ -402,13 +402,13 @@ template <int NT, bool USTAGE>
 __device__ __forceinline__ void chol_piece(const BatchView& V, const CholView& C, const PieceMeta pm, double* sm, long long* dbg) {
   constexpr int NW = NT / 64;
   long long tprev = dbg ? clock64() : 0;
-  __shared__ ILevel s_lv[kMaxILevels];
-  const int tid = threadIdx.x;
+  ILevel* s_lv = reinterpret_cast<ILevel*>(sm);              // the piece's level records first (32 bytes each): no static table, the LDS a
+  const int tid = threadIdx.x;                               // piece reserves is what it uses (residency is LDS-bound)
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   const int g = pm.graph;
   const double lambda = V.lm[g].lambda;
   const int Lp = (pm.lsize + 1) & ~1, Yp = (pm.ysize + 1) & ~1;
-  double* smL = sm;
+  double* smL = sm + 4 * pm.nilv;
   double* smY = smL + Lp;
   double* smInv = smY + Yp;
   BlkMeta* sBlk = reinterpret_cast<BlkMeta*>(smInv + Yp);                 // the piece's block records
@@ -637,11 +637,11 @@ __global__ __launch_bounds__(NT) void k_chol_tail(BatchView V, CholView C, const
   }
 template <int NT>
 __device__ __forceinline__ void chol_piece_backward(const CholView& C, const PieceMeta pm, const double* __restrict__ y, double* x, double* sm, long long* dbg) {
-  __shared__ ILevel s_lvb[kMaxILevels];
+  ILevel* s_lvb = reinterpret_cast<ILevel*>(sm);
   long long tprev = dbg ? clock64() : 0;
   const int tid = threadIdx.x;
   const int Yp = (pm.ysize + 1) & ~1;
-  double* smI = sm;
+  double* smI = sm + 4 * pm.nilv;
   double* smX = smI + 36 * pm.nint;
   double* smE = smX + Yp;                                   // [nb][6]
   int2* sBlk = reinterpret_cast<int2*>(smE + 6 * pm.nb);    // {LDS offset of a row-in-piece block | di << 24 | dj << 28, local y offset of the row}
