@@ -15,7 +15,8 @@ for K in Ks:
     bt = GraphBatch(graphs, streams=K)
     bt.optimize(5)
     best = None
-    for rep in range(2):
+    reps = []
+    for rep in range(int(os.environ.get('REPS', '2'))):
         bt.upload()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -23,7 +24,8 @@ for K in Ks:
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         best = dt if best is None else min(best, dt)
+        reps.append(round(dt * 1e3, 1))
     its = sum(int(s.iterations) for s in st)
     chi = sum(float(s.chi2_after) for s in st)
-    print(f"K={K}: {best*1e3:.1f} ms, {its} graph-iterations, {its/best:.0f} iters/s, chi2 sum {chi:.9e}", flush=True)
+    print(f"K={K}: reps {reps} best {best*1e3:.1f} ms, {its} graph-iterations, {its/best:.0f} iters/s, chi2 sum {chi:.9e}", flush=True)
     del bt
