@@ -71,6 +71,9 @@ struct ItemMeta { int u0, n, tloff, flags; };   // updates [u0, u0 + n) (index i
 constexpr int kItemSole = 1;                     // flags: bit 0 sole (subtract in place); bits 1..11 partial slot; bits 12.. local y offset
 constexpr int kItemSlotShift = 1, kItemSlotMask = 0x7FF, kItemYShift = 12;
 struct MbMeta { int tloff, ps0, n, info; };      // a target block with n > 1 items: partial slots [ps0, ps0 + n); info = di | dj << 4 | diag << 9 | ylocal << 12
+struct RCol { int u0, n; };             // tail pieces: the internal updates a finished column applies to later columns of its piece (right-looking form),
+                                         // records [u0, u0 + n) of rupd[] counted from the piece's first record (PieceMeta.pad3); UpdMeta with
+                                         // ux = target offset in the piece | local y offset of the target's column << 16
 struct ILevel { int c0, c1, b0, b1, it0, it1, mb0, mb1; };   // one level inside a piece: columns, blocks (global ids), items and multi-blocks (piece-local)
 
 // update-matrix side: a block U(a,b) of the piece = sum of its own updates [u0, u0 + n) (upd[], sources in the piece) + the
@@ -139,6 +142,7 @@ struct CholHost {
   std::vector<ColMeta> col; std::vector<BlkMeta> blk; std::vector<UpdMeta> upd; std::vector<ItemMeta> item; std::vector<MbMeta> mb;
   std::vector<ILevel> ilv; std::vector<PieceMeta> piece;
   std::vector<AsmSrc> asrc, usrc; std::vector<FwdMeta> fwd; std::vector<UItem> uitem; std::vector<UMb> umb;
+  std::vector<RCol> rcol; std::vector<UpdMeta> rupd;   // right-looking update lists of the tail pieces, [ncol] and per piece
   std::vector<int> lvl_ptr, lvl_cols;       // column levels of the elimination tree (multi right-hand-side solves)
   std::vector<int> plv_ptr, plv_pieces;     // pieces grouped by depth (one launch each)
   std::vector<PieceMeta> lpiece;            // piece records in launch order: plv_pieces then tail_pieces (one dependent load less per workgroup)
@@ -555,6 +559,7 @@ inline int chol_symbolic(const SymIn& in, CholOpts opt, CholHost& out) {
   std::vector<std::vector<URec>> inbox(npiece);       // per group: the blocks its child components handed up (kept until consumed)
   std::vector<std::vector<int>> comp_R(ncomp);        // boundary rows of a component (column ids, ascending)
   out.upd.clear(); out.item.clear(); out.mb.clear(); out.ilv.clear(); out.asrc.clear(); out.usrc.clear(); out.uitem.clear(); out.umb.clear();
+  out.rupd.clear(); out.rcol.assign(ncol, RCol{0, 0});
   std::vector<int> piece_pmax(npiece, 0);   // most partial tiles any phase of the piece needs
   int64_t ucur = 0;
   for (int p = 0; p < npiece; ++p) {
@@ -603,6 +608,26 @@ inline int chol_symbolic(const SymIn& in, CholOpts opt, CholHost& out) {
         } else {
           for (int q = pp; q < k1; ++q) ublock(col_comp[k], brow[q], j).own.push_back({boff[q], boff[pp], k});
         }
+      }
+    }
+    // tail pieces: the same internal updates once more, grouped by SOURCE column (right-looking form: a finished column updates every
+    // later block of the piece at once -- one tile update deep, where the target-major lists are as deep as the piece has columns)
+    pm.pad3 = (int)out.rupd.size();
+    if (piece_tail[p]) {
+      for (int k = pm.c0; k < pm.c0 + pm.nc; ++k) {
+        const int k0 = bp[k] + 1, kin = bp[k] + col_nbi[k], k1 = bp[k + 1];
+        out.rcol[k].u0 = (int)out.rupd.size() - pm.pad3;
+        for (int pp = k0; pp < kin; ++pp) {
+          const int j = brow[pp];
+          for (int q = pp; q < k1; ++q) {
+            const int t = colblk[j].find(brow[q])->second;     // present: checked when iul was built
+            const int tl = out.blk[t].off - pm.lbase, yl = col_yoff[j] - pm.y0;
+            if (tl < 0 || tl >= (1 << 16) || yl < 0 || yl >= (1 << 15)) { out.error = "a tail piece is too large for the packed right-looking records"; return -1; }
+            const int tpk = (col_dim[brow[t]] == 6 ? kUpdDi6 : 0) | (t == bp[j] ? kUpdDiag : 0) | (col_dim[j] == 6 ? kUpdDj6 : 0) | (col_dim[k] == 6 ? kUpdDk6 : 0);
+            out.rupd.push_back(UpdMeta{boff[q], boff[pp], tl | (yl << 16), tpk});
+          }
+        }
+        out.rcol[k].n = (int)out.rupd.size() - pm.pad3 - out.rcol[k].u0;
       }
     }
     // what the children hand up: absorbed into a column of this piece (assembly) or passed on (update matrix)
@@ -755,7 +780,7 @@ inline int chol_symbolic(const SymIn& in, CholOpts opt, CholHost& out) {
   auto lds_f = [&](int p) {
     const PieceMeta& pm = out.piece[p];
     const int ustage = (piece_tail[p] || !opt.ustage) ? 0 : 4 * pm.nuit + 4 * pm.numb + 2 * pm.nuu + pm.nus + 2;
-    return 4 * pm.nilv + ((pm.lsize + 1) & ~1) + 2 * ((pm.ysize + 1) & ~1) + 4 * pm.nb + 2 * pm.nc + 2 * pm.nit_i + 2 * pm.nu_i + 2 * pm.nimb + pm.nas + ustage +
+    return 4 * pm.nilv + ((pm.lsize + 1) & ~1) + 2 * ((pm.ysize + 1) & ~1) + 4 * pm.nb + 3 * pm.nc + 2 * pm.nit_i + 2 * pm.nu_i + 2 * pm.nimb + pm.nas + ustage +
            kItemDoubles * piece_pmax[p] + 8;
   };
   auto lds_b = [&](int p) {

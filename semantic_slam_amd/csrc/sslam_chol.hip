@@ -39,6 +39,8 @@ struct CholView {
   const AsmSrc* usrc;       // child update-matrix blocks passed on through a piece's own update matrix
   const UItem* uitem;
   const UMb* umb;
+  const RCol* rcol;         // tail pieces, right-looking form: per column, its internal updates of later blocks of the piece ...
+  const UpdMeta* rupd;      // ... (ux = target offset in the piece | local y offset of the target's column << 16); nullptr: target-major items
   const FwdMeta* fwd;       // blocks of every row (multi right-hand-side forward substitution)
   const int* lvl_cols;      // columns grouped by level of the elimination tree
   const int* plv_pieces;    // pieces grouped by depth
@@ -398,7 +400,7 @@ __device__ __forceinline__ void row_solve(double* v, const double* Ljj, const do
     if (threadIdx.x == 0) dbg[k] += now_ - tprev;                               \
     tprev = now_;                                                               \
   }
-template <int NT, bool USTAGE>
+template <int NT, bool USTAGE, bool RIGHT>
 __device__ __forceinline__ void chol_piece(const BatchView& V, const CholView& C, const PieceMeta pm, double* sm, long long* dbg) {
   constexpr int NW = NT / 64;
   long long tprev = dbg ? clock64() : 0;
@@ -413,10 +415,12 @@ __device__ __forceinline__ void chol_piece(const BatchView& V, const CholView& C
   double* smInv = smY + Yp;
   BlkMeta* sBlk = reinterpret_cast<BlkMeta*>(smInv + Yp);                 // the piece's block records
   int4* sCol = reinterpret_cast<int4*>(sBlk + pm.nb);                      // {L offset of the diagonal block, dim, y offset, -} (piece-local)
-  ItemMeta* sItem = reinterpret_cast<ItemMeta*>(sCol + pm.nc);            // internal work items
-  UpdMeta* sUpd = reinterpret_cast<UpdMeta*>(sItem + pm.nit_i);            // internal update records
-  MbMeta* sMb = reinterpret_cast<MbMeta*>(sUpd + pm.nu_i);                 // internal multi-blocks
-  AsmSrc* sAsm = reinterpret_cast<AsmSrc*>(sMb + pm.nimb);                 // child update-matrix blocks to absorb
+  // internal updates: target-major items + records + multi-blocks, or (RIGHT) one {first record, count} per column + source-major records
+  ItemMeta* sItem = reinterpret_cast<ItemMeta*>(sCol + pm.nc);
+  UpdMeta* sUpd = reinterpret_cast<UpdMeta*>(sItem + (RIGHT ? (pm.nc + 1) / 2 : pm.nit_i));
+  MbMeta* sMb = reinterpret_cast<MbMeta*>(sUpd + pm.nu_i);
+  AsmSrc* sAsm = reinterpret_cast<AsmSrc*>(sMb + (RIGHT ? 0 : pm.nimb));   // child update-matrix blocks to absorb
+  RCol* sRcol = reinterpret_cast<RCol*>(sItem);
   // update-matrix records: staged in LDS by the per-depth kernels (USTAGE), read from HBM by the tail
   UItem* sUItem = reinterpret_cast<UItem*>(sAsm + pm.nas + (pm.nas & 1));
   UMb* sUMb = reinterpret_cast<UMb*>(sUItem + (USTAGE ? pm.nuit : 0));
@@ -437,9 +441,10 @@ __device__ __forceinline__ void chol_piece(const BatchView& V, const CholView& C
   {
     SSLAM_LD(ILevel, t_lv, C.ilv + pm.ilv0, pm.nilv, 1)
     SSLAM_LD(BlkMeta, t_blk, C.blk + pm.b0, pm.nb, 2)
-    SSLAM_LD(ItemMeta, t_item, C.item + pm.iit0, pm.nit_i, 2)
-    SSLAM_LD(UpdMeta, t_upd, C.upd + pm.iu0, pm.nu_i, 2)
-    SSLAM_LD(MbMeta, t_mb, C.mb + pm.imb0, pm.nimb, 1)
+    SSLAM_LD(ItemMeta, t_item, C.item + pm.iit0, RIGHT ? 0 : pm.nit_i, 2)
+    SSLAM_LD(UpdMeta, t_upd, (RIGHT ? C.rupd + pm.pad3 : C.upd + pm.iu0), pm.nu_i, 2)
+    SSLAM_LD(MbMeta, t_mb, C.mb + pm.imb0, RIGHT ? 0 : pm.nimb, 1)
+    SSLAM_LD(RCol, t_rcol, C.rcol + pm.c0, RIGHT ? pm.nc : 0, 1)
     SSLAM_LD(AsmSrc, t_asm, C.asrc + pm.as0, pm.nas, 2)
     SSLAM_LD(ColMeta, t_col, C.col + pm.c0, pm.nc, 1)
     SSLAM_LD(UItem, t_uit, C.uitem + pm.uit0, USTAGE ? pm.nuit : 0, 2)
@@ -448,9 +453,10 @@ __device__ __forceinline__ void chol_piece(const BatchView& V, const CholView& C
     SSLAM_LD(AsmSrc, t_usrc, C.usrc + pm.us0, USTAGE ? pm.nus : 0, 2)
     SSLAM_ST(t_lv, s_lv, C.ilv + pm.ilv0, pm.nilv, 1)
     SSLAM_ST(t_blk, sBlk, C.blk + pm.b0, pm.nb, 2)
-    SSLAM_ST(t_item, sItem, C.item + pm.iit0, pm.nit_i, 2)
-    SSLAM_ST(t_upd, sUpd, C.upd + pm.iu0, pm.nu_i, 2)
-    SSLAM_ST(t_mb, sMb, C.mb + pm.imb0, pm.nimb, 1)
+    SSLAM_ST(t_item, sItem, C.item + pm.iit0, RIGHT ? 0 : pm.nit_i, 2)
+    SSLAM_ST(t_upd, sUpd, (RIGHT ? C.rupd + pm.pad3 : C.upd + pm.iu0), pm.nu_i, 2)
+    SSLAM_ST(t_mb, sMb, C.mb + pm.imb0, RIGHT ? 0 : pm.nimb, 1)
+    SSLAM_ST(t_rcol, sRcol, C.rcol + pm.c0, RIGHT ? pm.nc : 0, 1)
     SSLAM_ST(t_asm, sAsm, C.asrc + pm.as0, pm.nas, 2)
     if (tid < pm.nc) sCol[tid] = make_int4(t_col_r[0].base - pm.lbase, t_col_r[0].dim, t_col_r[0].yoff - pm.y0, 0);
     for (int c = tid + NT; c < pm.nc; c += NT) {
@@ -536,7 +542,7 @@ __device__ __forceinline__ void chol_piece(const BatchView& V, const CholView& C
   // ---- 2. the levels inside the piece, everything in LDS
   for (int il = 0; il < pm.nilv; ++il) {
     const ILevel lv = s_lv[il];
-    if (lv.it1 > lv.it0) {
+    if (!RIGHT && lv.it1 > lv.it0) {
       run_items<NT>(sItem, lv.it0, lv.it1, sUpd, smL, smY, pm.lbase, pm.y0, smL, smY, part, tid);
       __syncthreads();
       SSLAM_STAMP(2)
@@ -565,6 +571,40 @@ __device__ __forceinline__ void chol_piece(const BatchView& V, const CholView& C
     }
     __syncthreads();
     SSLAM_STAMP(5)
+    if (RIGHT) {
+      // the finished columns update every later block of the piece, one column per round (two columns of a level may meet in a target):
+      // four lanes per tile, one tile update deep
+      const int lq = tid & 3, tr = lq >> 1, tc = lq & 1;
+      for (int c = lv.c0 - pm.c0; c < lv.c1 - pm.c0; ++c) {
+        const RCol rc = sRcol[c];
+        const int yk = sCol[c].z;
+        for (int it = tid >> 2; it < rc.n; it += NT / 4) {
+          const UpdMeta r = sUpd[rc.u0 + it];
+          const int di = (r.pk & kUpdDi6) ? 6 : 3, dj = (r.pk & kUpdDj6) ? 6 : 3;
+          const int tre = 3 * tr < di ? tr : 0, tce = 3 * tc < dj ? tc : 0;   // idle lanes shadow tile (0, 0): valid addresses
+          double acc[9], accy[3];
+#pragma unroll
+          for (int q = 0; q < 9; ++q) acc[q] = 0;
+#pragma unroll
+          for (int q = 0; q < 3; ++q) accy[q] = 0;
+          tile_update(smL, smY, r.ua - pm.lbase, r.ub - pm.lbase, yk, r.pk, tre, tce, acc, accy);
+          if (3 * tr < di && 3 * tc < dj) {
+            double* o = smL + (r.ux & 0xFFFF);
+#pragma unroll
+            for (int rr = 0; rr < 3; ++rr)
+#pragma unroll
+              for (int cc = 0; cc < 3; ++cc) o[(3 * tr + rr) * dj + 3 * tc + cc] -= acc[rr * 3 + cc];
+            if ((r.pk & kUpdDiag) && tc == 0) {
+              double* oy = smY + (r.ux >> 16);
+#pragma unroll
+              for (int rr = 0; rr < 3; ++rr) oy[3 * tr + rr] -= accy[rr];
+            }
+          }
+        }
+        __syncthreads();
+      }
+      SSLAM_STAMP(2)
+    }
   }
   // ---- 3. the update matrix over the rows above the piece: own updates out of LDS + the children's blocks -> HBM
   if (pm.nuit > 0) {
@@ -603,7 +643,7 @@ __global__ __launch_bounds__(NT, 4) void k_chol_pieces(BatchView V, CholView C, 
   extern __shared__ double sm[];
   const PieceMeta pm = C.lpiece[idx ? idx[blockIdx.x] : begin + blockIdx.x];   // idx: the pieces of the graphs that are still active
   if (!V.lm[pm.graph].in_trial) return;
-  chol_piece<NT, USTAGE>(V, C, pm, sm, (C.dbg && blockIdx.x == 0) ? C.dbg + 16 : nullptr);
+  chol_piece<NT, USTAGE, false>(V, C, pm, sm, (C.dbg && blockIdx.x == 0) ? C.dbg + 16 : nullptr);
 }
 
 // Top of the elimination tree: once a graph is down to a few pieces per depth a launch per depth only buys launch
@@ -616,7 +656,8 @@ __global__ __launch_bounds__(NT) void k_chol_tail(BatchView V, CholView C, const
   if (!V.lm[g].in_trial) return;
   const int q1 = C.tail_ptr[g + 1];
   for (int q = C.tail_ptr[g]; q < q1; ++q) {
-    chol_piece<NT, false>(V, C, C.lpiece[C.ltail0 + q], sm, (C.dbg && g == 0) ? C.dbg : nullptr);
+    if (C.rupd) chol_piece<NT, false, true>(V, C, C.lpiece[C.ltail0 + q], sm, (C.dbg && g == 0) ? C.dbg : nullptr);
+    else chol_piece<NT, false, false>(V, C, C.lpiece[C.ltail0 + q], sm, (C.dbg && g == 0) ? C.dbg : nullptr);
     __threadfence_block();
     __syncthreads();
   }
@@ -982,6 +1023,14 @@ int chol_plan_build(Batch& b) {
   if ((rc = up_to_dev(*P, b.stream, H.usrc, &C.usrc))) return rc;
   if ((rc = up_to_dev(*P, b.stream, H.uitem, &C.uitem))) return rc;
   if ((rc = up_to_dev(*P, b.stream, H.umb, &C.umb))) return rc;
+  {   // right-looking tail (default; SSLAM_CHOL_RIGHT=0: the target-major items everywhere)
+    const char* e = getenv("SSLAM_CHOL_RIGHT");
+    C.rcol = nullptr; C.rupd = nullptr;
+    if (!(e && atoi(e) == 0) && !H.rupd.empty()) {
+      if ((rc = up_to_dev(*P, b.stream, H.rcol, &C.rcol))) return rc;
+      if ((rc = up_to_dev(*P, b.stream, H.rupd, &C.rupd))) return rc;
+    }
+  }
   if ((rc = up_to_dev(*P, b.stream, H.fwd, &C.fwd))) return rc;
   if ((rc = up_to_dev(*P, b.stream, H.lvl_cols, &C.lvl_cols))) return rc;
   if ((rc = up_to_dev(*P, b.stream, H.plv_pieces, &C.plv_pieces))) return rc;

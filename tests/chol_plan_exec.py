@@ -17,6 +17,7 @@ UMB = np.dtype([(n, "<i4") for n in ("uoff", "ps0", "n", "info", "s0", "ns", "uy
 UPD = np.dtype([(n, "<i4") for n in ("ua", "ub", "ux", "pk")])
 ITEM = np.dtype([(n, "<i4") for n in ("u0", "n", "tloff", "flags")])
 MB = np.dtype([(n, "<i4") for n in ("tloff", "ps0", "n", "info")])
+RCOL = np.dtype([("u0", "<i4"), ("n", "<i4")])
 ILV = np.dtype([(n, "<i4") for n in ("c0", "c1", "b0", "b1", "it0", "it1", "mb0", "mb1")])
 PIECE = np.dtype([(n, "<i4") for n in ("graph", "c0", "nc", "b0", "nb", "lbase", "lsize", "y0", "ysize", "ilv0", "nilv", "iit0", "nit_i",
                                        "iu0", "nu_i", "imb0", "nimb", "as0", "nas", "uit0", "nuit", "umb0", "numb",
@@ -36,6 +37,7 @@ class Plan:
         self.col, self.blk, self.upd = g("col", COL), g("blk", BLK), g("upd", UPD)
         self.item, self.mb, self.ilv, self.piece = g("item", ITEM), g("mb", MB), g("ilv", ILV), g("piece", PIECE)
         self.asrc, self.usrc, self.fwd, self.uitem, self.umb = g("asrc", ASRC), g("usrc", ASRC), g("fwd", FWD), g("uitem", UITEM), g("umb", UMB)
+        self.rcol, self.rupd = g("rcol", RCOL), g("rupd", UPD)     # right-looking update lists of the tail pieces
         for n in ("lvl_ptr", "lvl_cols", "plv_ptr", "plv_pieces", "tail_ptr", "tail_pieces", "plv_lds_f", "plv_lds_b", "ppoff", "plblk", "scalars"):
             setattr(self, n, g(n, np.int32))
         s = self.scalars
@@ -78,13 +80,16 @@ class Plan:
         return out
 
     # ---- factorisation + fused forward substitution, piece by piece
-    def factor(self, Hdev, bvec, lam):
+    def factor(self, Hdev, bvec, lam, right=False):
+        """right: the tail pieces apply their internal updates column by column (rcol / rupd: what k_chol_tail does by default)
+        instead of target by target (item / upd / mb)"""
         Lval = np.zeros(self.lnz + 64)
         Uval = np.full(self.unz + 64, np.nan)      # every update-matrix entry must be written before it is read
         y = np.zeros(self.dim + 8)
         ok = True
+        tail = set(int(p) for p in self.tail_pieces)
         for p in self.piece_order():
-            ok &= self._factor_piece(self.piece[p], Hdev, bvec, lam, Lval, Uval, y)
+            ok &= self._factor_piece(self.piece[p], Hdev, bvec, lam, Lval, Uval, y, right=right and p in tail)
         self.Uval = Uval
         return Lval, y, ok
 
@@ -130,7 +135,7 @@ class Plan:
                 yl = int(mm["info"]) >> 12
                 smY[yl:yl + dj] -= accy
 
-    def _factor_piece(self, pm, Hdev, bvec, lam, Lval, Uval, y):
+    def _factor_piece(self, pm, Hdev, bvec, lam, Lval, Uval, y, right=False):
         lbase, y0 = int(pm["lbase"]), int(pm["y0"])
         smL = np.zeros(pm["lsize"]); smY = np.zeros(pm["ysize"])
         sAsm = self.asrc[pm["as0"]:pm["as0"] + pm["nas"]]
@@ -164,8 +169,9 @@ class Plan:
         ok = True
         for lv in self.ilv[pm["ilv0"]:pm["ilv0"] + pm["nilv"]]:
             part = {}
-            self._run_items(self.item[pm["iit0"] + lv["it0"]:pm["iit0"] + lv["it1"]], sUpd, smL, smY, lbase, y0, smL, smY, part)
-            self._reduce(sMb[lv["mb0"]:lv["mb1"]], smL, smY, part)
+            if not right:
+                self._run_items(self.item[pm["iit0"] + lv["it0"]:pm["iit0"] + lv["it1"]], sUpd, smL, smY, lbase, y0, smL, smY, part)
+                self._reduce(sMb[lv["mb0"]:lv["mb1"]], smL, smY, part)
             for cm in self.col[lv["c0"]:lv["c1"]]:
                 d = int(cm["dim"]); o = cm["base"] - lbase; yl = cm["yoff"] - y0
                 S = smL[o:o + d * d].reshape(d, d)
@@ -186,6 +192,25 @@ class Plan:
                 Lj = smL[od:od + dj * dj].reshape(dj, dj)
                 Vb = smL[o:o + di * dj].reshape(di, dj)
                 smL[o:o + di * dj] = np.linalg.solve(Lj, Vb.T).T.ravel()
+            if right:   # the finished columns update every later block of the piece
+                for c in range(int(lv["c0"]), int(lv["c1"])):
+                    rc = self.rcol[c]
+                    cm = self.col[c]
+                    dk = int(cm["dim"]); yk = int(cm["yoff"]) - y0
+                    recs = self.rupd[int(pm["pad3"]) + int(rc["u0"]):int(pm["pad3"]) + int(rc["u0"]) + int(rc["n"])]
+                    assert len(recs) == rc["n"]
+                    for r in recs:
+                        pk = int(r["pk"])
+                        di = 6 if pk & K_DI6 else 3
+                        dj = 6 if pk & K_DJ6 else 3
+                        assert (6 if pk & K_DK6 else 3) == dk
+                        A = smL[r["ua"] - lbase:r["ua"] - lbase + di * dk].reshape(di, dk)
+                        Bm = smL[r["ub"] - lbase:r["ub"] - lbase + dj * dk].reshape(dj, dk)
+                        tl, yl = int(r["ux"]) & 0xFFFF, int(r["ux"]) >> 16
+                        smL[tl:tl + di * dj] -= (A @ Bm.T).ravel()
+                        if pk & K_DIAG:
+                            assert r["ua"] == r["ub"]
+                            smY[yl:yl + dj] -= A @ smY[yk:yk + dk]
         # update matrix of the piece: own updates (sources in the piece) + the children's blocks
         part = {}
         uupd = self.upd[pm["uu0"]:pm["uu0"] + pm["nuu"]]

@@ -64,6 +64,12 @@ def _check(plan, H, b, lam):
     assert np.abs(x - xref).max() <= 1e-7 * np.abs(xref).max()
     y2 = plan.forward_rows(Lval, b)          # the row lists of the multi right-hand-side forward substitution
     assert np.abs(y2 - yref).max() <= 1e-9 * max(np.abs(yref).max(), 1e-30)
+    if len(plan.tail_pieces):                # the tail pieces' right-looking update lists give the same factor (other summation order)
+        assert len(plan.rupd) == int(sum(plan.piece[int(p)]["nu_i"] for p in plan.tail_pieces))
+        Lr, yr, okr = plan.factor(Hdev, b, lam, right=True)
+        assert okr
+        assert np.abs(Lr - Lval).max() <= 1e-10 * max(np.abs(Lval).max(), 1e-30)
+        assert np.abs(yr[:plan.dim] - y[:plan.dim]).max() <= 1e-9 * max(np.abs(yref).max(), 1e-30)
     return Lval
 
 
