@@ -1066,6 +1066,13 @@ int chol_plan_build(Batch& b) {
     C.dbg = (long long*)p;
     SSLAM_HIP_TRY(hipMemsetAsync(p, 0, 48 * sizeof(long long), b.stream));
   }
+  // index lists of the LM endgame (chol_set_active), sized once: no allocation inside an optimize call (a stream group runs several of
+  // them side by side)
+  if (b.V.B >= 8 && !P->d_idx) {
+    const size_t cap = P->lp_graph.size() + (size_t)b.V.B + 1024;
+    SSLAM_HIP_TRY(hipMalloc((void**)&P->d_idx, cap * sizeof(int)));
+    P->idx_cap = cap;
+  }
   // LDS opt-in above 64 KiB
   size_t lds_max = (size_t)std::max(P->tail_lds_f, P->tail_lds_b);
   for (size_t l = 0; l < P->plv_lds_f.size(); ++l) lds_max = std::max(lds_max, (size_t)std::max(P->plv_lds_f[l], P->plv_lds_b[l]));
