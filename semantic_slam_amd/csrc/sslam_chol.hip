@@ -16,6 +16,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <vector>
 
 #include "../../include/sslam.h"
@@ -1079,15 +1080,23 @@ int chol_plan_build(Batch& b) {
   lds_max *= sizeof(double);
   if (lds_max > 160 * 1024 - 2048) return set_error(SSLAM_ERR_UNSUPPORTED, "a piece of the factor needs %zu B of LDS (> 158 KiB)", lds_max);
   if (lds_max > 48 * 1024) {
-    const int v = (int)lds_max;
-    const void* fns[] = {(const void*)k_chol_pieces<64, true>, (const void*)k_chol_pieces<128, true>, (const void*)k_chol_pieces<256, true>,
-                         (const void*)k_chol_pieces<512, true>, (const void*)k_chol_pieces<1024, true>,
-                         (const void*)k_chol_pieces<64, false>, (const void*)k_chol_pieces<128, false>, (const void*)k_chol_pieces<256, false>,
-                         (const void*)k_chol_pieces<512, false>, (const void*)k_chol_pieces<1024, false>,
-                         (const void*)k_chol_tail<512>, (const void*)k_chol_tail<1024>,
-                         (const void*)k_chol_back_pieces<64>, (const void*)k_chol_back_pieces<128>, (const void*)k_chol_back_pieces<256>,
-                         (const void*)k_chol_back_pieces<512>, (const void*)k_chol_back_pieces<1024>, (const void*)k_chol_back_tail<512>};
-    for (const void* f : fns) SSLAM_HIP_TRY(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, v));
+    // One value for every plan, set once per device under a lock: the attribute belongs to the kernel, not to a plan, and the parts of a
+    // stream group build their plans side by side (a smaller value written last would fail another part's launches).
+    static std::mutex mu;
+    static std::vector<int> done;
+    std::lock_guard<std::mutex> lk(mu);
+    if (std::find(done.begin(), done.end(), b.device) == done.end()) {
+      const int v = 160 * 1024 - 2048;
+      const void* fns[] = {(const void*)k_chol_pieces<64, true>, (const void*)k_chol_pieces<128, true>, (const void*)k_chol_pieces<256, true>,
+                           (const void*)k_chol_pieces<512, true>, (const void*)k_chol_pieces<1024, true>,
+                           (const void*)k_chol_pieces<64, false>, (const void*)k_chol_pieces<128, false>, (const void*)k_chol_pieces<256, false>,
+                           (const void*)k_chol_pieces<512, false>, (const void*)k_chol_pieces<1024, false>,
+                           (const void*)k_chol_tail<512>, (const void*)k_chol_tail<1024>,
+                           (const void*)k_chol_back_pieces<64>, (const void*)k_chol_back_pieces<128>, (const void*)k_chol_back_pieces<256>,
+                           (const void*)k_chol_back_pieces<512>, (const void*)k_chol_back_pieces<1024>, (const void*)k_chol_back_tail<512>};
+      for (const void* f : fns) SSLAM_HIP_TRY(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, v));
+      done.push_back(b.device);
+    }
   }
   if (P->arena && P->arena->flush(b.stream)) return set_error(SSLAM_ERR_HIP, "upload of the plan tables failed");
   SSLAM_HIP_TRY(hipStreamSynchronize(b.stream));

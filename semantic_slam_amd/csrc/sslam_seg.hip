@@ -19,6 +19,7 @@
 #include <cstring>
 #include <cstdio>
 #include <cstdlib>
+#include <mutex>
 #include <vector>
 
 #include "../../include/sslam.h"
@@ -1819,6 +1820,20 @@ int sslam_seg_transform(const sslam_seg* s, const float pose[6], float cam_pitch
 // One or several frames in one pass: the accepted boxes of ALL frames are packed back to back into one View, so that every
 // kernel launch covers 32 x F boxes (a single frame's 32 boxes leave most of the 256 CUs idle: the raster recurrences of PCL's
 // algorithms run as one workgroup per box).
+// The kernels that stage bands / label images take up to ~150 KiB of dynamic LDS.  The opt-in belongs to the kernel, not to a call: one
+// value, set once per device under a lock (handles on several host threads would otherwise overwrite one another's smaller values).
+static int seg_lds_opt_in(int device) {
+  static std::mutex mu;
+  static std::vector<int> done;
+  std::lock_guard<std::mutex> lk(mu);
+  if (std::find(done.begin(), done.end(), device) != done.end()) return 0;
+  const int v = 156 * 1024;
+  const void* fns[] = {(const void*)k_distance_map, (const void*)k_refine, (const void*)k_integral, (const void*)k_cc_lds, (const void*)k_refine_lds,
+                       (const void*)k_contour<true>};
+  for (const void* f : fns) SSLAM_HIP_TRY(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, v));
+  done.push_back(device);
+  return 0;
+}
 static int seg_enqueue(sslam_seg* s, const sslam_frame* frames, int n_frames, int width, int height, int point_step, int row_step, int ox, int oy, int oz) {
   if (!s || !frames || n_frames <= 0) return set_error(SSLAM_ERR_INVALID, "null argument");
   if (s->q_busy) return set_error(SSLAM_ERR_INVALID, "the previous batch of this pipeline has not been collected");
@@ -1920,8 +1935,7 @@ static int seg_enqueue(sslam_seg* s, const sslam_frame* frames, int n_frames, in
       const int bhr = std::min(V.refine_bh, kBandFloats / (4 * b.w) - 1);
       rband_bytes = std::max(rband_bytes, (size_t)(bhr + 1) * b.w * 4 * sizeof(float));
     }
-    if (band_bytes > 64 * 1024) SSLAM_HIP_TRY(hipFuncSetAttribute((const void*)k_distance_map, hipFuncAttributeMaxDynamicSharedMemorySize, (int)band_bytes));
-    if (rband_bytes > 64 * 1024) SSLAM_HIP_TRY(hipFuncSetAttribute((const void*)k_refine, hipFuncAttributeMaxDynamicSharedMemorySize, (int)rband_bytes));
+    { const int rc_lds = seg_lds_opt_in(s->P.device); if (rc_lds) return rc_lds; }   // > 64 KiB of dynamic LDS for the band / label kernels, once per device
     const bool dbg = getenv("SSLAM_SEG_DEBUG") != nullptr;
 #define DBG(name) do { if (dbg) { hipError_t e_ = hipStreamSynchronize(s->stream); fprintf(stderr, "[seg] %s: %s\n", name, hipGetErrorString(e_)); } } while (0)
     SSLAM_HIP_TRY(hipMemsetAsync(V.ccount, 0, nb * sizeof(int), s->stream));
@@ -1939,14 +1953,12 @@ static int seg_enqueue(sslam_seg* s, const sslam_frame* frames, int n_frames, in
       const size_t row_cap = ie ? (size_t)std::max(1, std::min(64, atoi(ie))) : (nb > 512 ? 24 : 64);
       const int ib_rows = (int)std::max<size_t>(1, std::min<size_t>(row_cap, (150 * 1024 - carry) / ((size_t)maxw * 12)));
       const size_t ilds = carry + (size_t)ib_rows * maxw * 12;
-      if (ilds > 64 * 1024) SSLAM_HIP_TRY(hipFuncSetAttribute((const void*)k_integral, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ilds));
       hipLaunchKernelGGL(k_integral, dim3(nb), dim3(256), ilds, s->stream, V, ib_rows);
     }
     DBG("k_integral");
     hipLaunchKernelGGL(k_normals, pg, pb, 0, s->stream, V);
     DBG("k_normals");
     if (maxpix <= kCcLdsMax && !getenv("SSLAM_SEG_GLOBAL_CC")) {
-      if ((size_t)maxpix * sizeof(int) > 60 * 1024) SSLAM_HIP_TRY(hipFuncSetAttribute((const void*)k_cc_lds, hipFuncAttributeMaxDynamicSharedMemorySize, kCcLdsMax * (int)sizeof(int)));
       hipLaunchKernelGGL(k_cc_lds, dim3(nb), dim3(1024), (size_t)maxpix * sizeof(int), s->stream, V);
       DBG("k_cc_lds");
     } else {
@@ -1968,7 +1980,6 @@ static int seg_enqueue(sslam_seg* s, const sslam_frame* frames, int n_frames, in
     for (auto& b : s->boxes) tiles_ok = tiles_ok && ((b.w + kRefTX - 1) / kRefTX) * ((b.h + kRefTY - 1) / kRefTY) <= 32;
     if (maxpix <= kCcLdsMax && tiles_ok && !getenv("SSLAM_SEG_WAVEFRONT_REFINE")) {
       // 16-bit labels + 16-bit masks: 4 bytes per pixel (three 12k-pixel boxes per CU)
-      if ((size_t)maxpix * 4 + 8 > 60 * 1024) SSLAM_HIP_TRY(hipFuncSetAttribute((const void*)k_refine_lds, hipFuncAttributeMaxDynamicSharedMemorySize, kCcLdsMax * 4 + 8));
       hipLaunchKernelGGL(k_refine_lds, dim3(nb), dim3(kRefTX * kRefTY), (size_t)maxpix * 4 + 8, s->stream, V);
       DBG("k_refine_lds");
       if (V.dbg & 8) {
@@ -1994,7 +2005,6 @@ static int seg_enqueue(sslam_seg* s, const sslam_frame* frames, int n_frames, in
     size_t cimg_bytes = 0;
     for (auto& b : s->boxes) cimg_bytes = std::max(cimg_bytes, (size_t)(b.w + 2) * (b.h + 2));
     if (cimg_bytes <= 150 * 1024 && !getenv("SSLAM_SEG_NOSTAGE")) {
-      if (cimg_bytes > 64 * 1024) SSLAM_HIP_TRY(hipFuncSetAttribute((const void*)k_contour<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)cimg_bytes));
       hipLaunchKernelGGL(k_contour<true>, dim3(nb), dim3(256), cimg_bytes, s->stream, V);
     DBG("k_contour");
     } else {
