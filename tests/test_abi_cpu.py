@@ -118,6 +118,18 @@ def test_compute_entry_points_fail_loudly_without_a_gpu(hip_lib):
     with pytest.raises(SslamError) as ei:
         PointCloudSegmentation().convex_hull_2d(pts, np.arange(100, dtype=np.int32), [0, 0, 1, 0])
     assert ei.value.code == -2
+    # round-3 entry points: stream groups and the pipelined frontend
+    from semantic_slam_amd import GraphBatch
+    G2 = GraphSLAM.from_problem(GraphProblem.from_synth(make_graph(20, 5, seed=1)))
+    with pytest.raises(SslamError) as ei:
+        GraphBatch([G, G2], streams=2)
+    assert "no CPU fallback" in str(ei.value)
+    seg = PointCloudSegmentation()
+    with pytest.raises(SslamError) as ei:
+        seg.submit_frames([f])
+    assert ei.value.code == -2
+    with pytest.raises(SslamError):                                    # nothing is in flight after the refused submit
+        seg.collect_frames()
 
 
 def test_g2o_text_round_trip(hip_lib, tmp_path):
