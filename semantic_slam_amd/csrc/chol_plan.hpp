@@ -560,6 +560,7 @@ inline int chol_symbolic(const SymIn& in, CholOpts opt, CholHost& out) {
   std::vector<std::vector<int>> comp_R(ncomp);        // boundary rows of a component (column ids, ascending)
   out.upd.clear(); out.item.clear(); out.mb.clear(); out.ilv.clear(); out.asrc.clear(); out.usrc.clear(); out.uitem.clear(); out.umb.clear();
   out.rupd.clear(); out.rcol.assign(ncol, RCol{0, 0});
+  bool right_ok = true;
   std::vector<int> piece_pmax(npiece, 0);   // most partial tiles any phase of the piece needs
   int64_t ucur = 0;
   for (int p = 0; p < npiece; ++p) {
@@ -613,7 +614,7 @@ inline int chol_symbolic(const SymIn& in, CholOpts opt, CholHost& out) {
     // tail pieces: the same internal updates once more, grouped by SOURCE column (right-looking form: a finished column updates every
     // later block of the piece at once -- one tile update deep, where the target-major lists are as deep as the piece has columns)
     pm.pad3 = (int)out.rupd.size();
-    if (piece_tail[p]) {
+    if (piece_tail[p] && right_ok) {
       for (int k = pm.c0; k < pm.c0 + pm.nc; ++k) {
         const int k0 = bp[k] + 1, kin = bp[k] + col_nbi[k], k1 = bp[k + 1];
         out.rcol[k].u0 = (int)out.rupd.size() - pm.pad3;
@@ -622,7 +623,7 @@ inline int chol_symbolic(const SymIn& in, CholOpts opt, CholHost& out) {
           for (int q = pp; q < k1; ++q) {
             const int t = colblk[j].find(brow[q])->second;     // present: checked when iul was built
             const int tl = out.blk[t].off - pm.lbase, yl = col_yoff[j] - pm.y0;
-            if (tl < 0 || tl >= (1 << 16) || yl < 0 || yl >= (1 << 15)) { out.error = "a tail piece is too large for the packed right-looking records"; return -1; }
+            if (tl < 0 || tl >= (1 << 16) || yl < 0 || yl >= (1 << 15)) right_ok = false;   // (an oversized SSLAM_CHOL_CAP_TAIL) the packed records do not fit: target-major lists everywhere
             const int tpk = (col_dim[brow[t]] == 6 ? kUpdDi6 : 0) | (t == bp[j] ? kUpdDiag : 0) | (col_dim[j] == 6 ? kUpdDj6 : 0) | (col_dim[k] == 6 ? kUpdDk6 : 0);
             out.rupd.push_back(UpdMeta{boff[q], boff[pp], tl | (yl << 16), tpk});
           }
@@ -776,6 +777,7 @@ inline int chol_symbolic(const SymIn& in, CholOpts opt, CholHost& out) {
     pm.nus = (int)out.usrc.size() - pm.us0;
   }
   out.unz = ucur;
+  if (!right_ok) { out.rupd.clear(); out.rcol.assign(ncol, RCol{0, 0}); }
   // ---- LDS needs (doubles) ---------------------------------------------------------------------------------------------------
   auto lds_f = [&](int p) {
     const PieceMeta& pm = out.piece[p];
