@@ -220,20 +220,28 @@ def bench_frontend(device, frames=8, cpu_baseline=True, batch_frames=32, dist=No
                       "achieved_GBps": round(gbs, 2), "hbm_frac": round(gbs / PEAK_HBM_GBS, 5), "truncated": list(seg.last_overflow())}
     # pipelined batches (sslam_seg_submit_batch / _collect_batch): the H2D copy of batch k+1 under the kernels of batch k; the clouds
     # sit in pinned host memory, as a capture pipeline that feeds a GPU would keep them
+    pins = []
+    seg_params = seg.params
+    from semantic_slam_amd import load_library
+    lib = load_library()
     try:
-        import torch
         import copy
+        import ctypes as C
         pinned = []
         for f in fs:
-            t = torch.empty(f.cloud.nbytes, dtype=torch.uint8).pin_memory()
-            arr = t.numpy().view(f.cloud.dtype).reshape(f.cloud.shape)
+            ptr = lib.sslam_pinned_alloc(f.cloud.nbytes)          # page-locked through the product's own C-ABI (no torch needed)
+            if not ptr:
+                raise RuntimeError(lib.sslam_last_error().decode())
+            pins.append(ptr)
+            arr = np.ctypeslib.as_array((C.c_uint8 * f.cloud.nbytes).from_address(ptr)).view(f.cloud.dtype).reshape(f.cloud.shape)
             arr[...] = f.cloud
-            g = copy.copy(f); g.cloud = arr; g._pin = t
+            g = copy.copy(f); g.cloud = arr
             pinned.append(g)
         pbf = [pinned[k % len(pinned)] for k in range(batch_frames)]
         list(seg.segment_stream([pbf, pbf]))                                 # warm-up (allocates the second pipeline)
         preps, ppl = 6, 0
         if dist is not None:
+            import torch
             torch.cuda.synchronize(); dist.barrier()
         t2 = time.perf_counter()
         for planes in seg.segment_stream([pbf] * preps):
@@ -246,14 +254,18 @@ def bench_frontend(device, frames=8, cpu_baseline=True, batch_frames=32, dist=No
                             "planes_per_sec_incl_pcie_and_host": round(ptot / pwall, 1),
                             "ms_per_frame_incl_pcie_and_host": round(1e3 * pwall / (preps * batch_frames), 4),
                             "h2d_MB_per_frame": round(fs[0].cloud.nbytes / 1e6, 2)}
-    except Exception as e:   # the leg needs torch for pinned memory; the product does not
+    except Exception as e:
         res["pipelined"] = {"error": repr(e)}
+    finally:
+        del seg                                                              # the handle's streams are idle before the clouds go
+        for ptr in pins:
+            lib.sslam_pinned_free(ptr)
     res["planes_per_sec"] = res["batched"]["planes_per_sec_kernels"]
     if cpu_baseline:
         from oracle.oracle import segment_frame   # cpu_baseline leg only
         t1 = time.perf_counter(); np_cpu = 0; nf = 0
         while time.perf_counter() - t1 < 6.0:
-            ref, _, _ = segment_frame(fs[nf % len(fs)], seg.params)
+            ref, _, _ = segment_frame(fs[nf % len(fs)], seg_params)
             np_cpu += len(ref); nf += 1
         dt = time.perf_counter() - t1
         res["cpu_baseline"] = {"value": round(np_cpu / dt, 2), "unit": "planes/s", "frames_per_sec": round(nf / dt, 3), "cores": 1,

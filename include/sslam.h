@@ -37,6 +37,10 @@ extern "C" {
 const char* sslam_last_error(void);
 /* number of visible HIP devices (0 on a CPU-only box; never fails) */
 int sslam_device_count(void);
+/* Page-locked host memory (hipHostMalloc / hipHostFree) for callers that do not link HIP themselves: clouds handed to
+ * sslam_seg_submit_batch from such a buffer are copied asynchronously.  NULL (and sslam_last_error) without a device. */
+void* sslam_pinned_alloc(size_t bytes);
+void sslam_pinned_free(void* p);
 
 /* ============================================================================================
  * Backend: ps_graph_slam::GraphSLAM  (reference include/ps_graph_slam/graph_slam.hpp:37-144)

@@ -51,6 +51,8 @@ def load_library():
     sig = {
         "sslam_last_error": (C.c_char_p, []),
         "sslam_device_count": (ci, []),
+        "sslam_pinned_alloc": (vp, [C.c_size_t]),
+        "sslam_pinned_free": (None, [vp]),
         "sslam_graph_create": (vp, [ci]),
         "sslam_graph_destroy": (None, [vp]),
         "sslam_graph_add_vertex_se3": (ci, [vp, dp, ci]),

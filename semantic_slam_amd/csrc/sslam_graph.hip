@@ -1963,6 +1963,18 @@ int sslam_device_count(void) {
   return n;
 }
 
+// page-locked host memory for buffers that travel to the device asynchronously (the clouds of sslam_seg_submit_batch): a caller that
+// does not link HIP itself gets it here
+void* sslam_pinned_alloc(size_t bytes) {
+  void* p = nullptr;
+  if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocPortable) != hipSuccess) {
+    set_error(SSLAM_ERR_NO_DEVICE, "hipHostMalloc of %zu bytes failed (no HIP device?)", bytes);
+    return nullptr;
+  }
+  return p;
+}
+void sslam_pinned_free(void* p) { if (p) (void)hipHostFree(p); }
+
 sslam_graph* sslam_graph_create(int device) {
   sslam_graph* h = new sslam_graph();
   h->g.device = device;
