@@ -273,6 +273,22 @@ def bench_frontend(device, frames=8, cpu_baseline=True, batch_frames=32, dist=No
     return res
 
 
+def launcher_command(argv, gpus, environ, port=None):
+    """`python bench.py --gpus N` typed on its own (no launcher, WORLD_SIZE unset) must still run N ranks: the command line that
+    re-executes this script under torch.distributed.run, one process per GPU over RCCL, rendezvous on 127.0.0.1 (the container hostname
+    may not resolve).  None when no re-launch is needed: N <= 1, or a launcher already set WORLD_SIZE (the driver's own
+    `python -m torch.distributed.run ... bench.py --gpus N`)."""
+    if gpus <= 1 or "WORLD_SIZE" in environ:
+        return None
+    if port is None:
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={int(gpus)}", "--master-addr", "127.0.0.1",
+            "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -298,9 +314,27 @@ def main():
     ap.add_argument("--no-single", action="store_true", help="skip the single-graph latency section (used under rocprofv3 --pmc)")
     args = ap.parse_args()
 
+    cmd = launcher_command(sys.argv[1:], args.gpus, os.environ)
+    if cmd is not None:   # N ranks asked for, none launched yet: become the launcher; rank 0 of the children prints the JSON line
+        import subprocess
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC only on this driver (RCCL fails with the legacy mode)
+        raise SystemExit(subprocess.call(cmd, env=env))
+
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world and rank == 0:
+        print(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s); reporting n_gpus = {world}", file=sys.stderr)
+    if os.environ.get("SSLAM_BENCH_LAUNCH_PROBE"):   # CPU test of the launch path (tests/test_bench_launcher_cpu.py): rendezvous over gloo, no GPU work
+        import torch.distributed as pdist
+        if world > 1:
+            pdist.init_process_group("gloo")
+            pdist.barrier()
+            pdist.destroy_process_group()
+        if rank == 0:
+            print(json.dumps({"probe": True, "n_gpus": world, "gpus_arg": args.gpus, "edge_sharded": bool(args.edge_sharded), "steps": args.steps}))
+        return
     dist = None
     if world > 1:
         import torch  # loaded first so that libamdhip64 is shared with the product library

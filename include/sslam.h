@@ -149,6 +149,14 @@ int sslam_graph_oplus(sslam_graph* g, const double* dx);
 void* sslam_debug_plan_create(sslam_graph* const* graphs, int n);
 void sslam_debug_plan_destroy(void* plan);
 int64_t sslam_debug_plan_array(void* plan, const char* name, void* out, int64_t cap_bytes);
+/* The window plan (solver 3) executed on the HOST: its own symbolic plan + the per-thread phase functions the HIP kernels are made of, run
+ * by a CPU executor (tests/test_wchol_cpu.py pins plan and kernel logic against dense linear algebra without a GPU).  Test hook only: no
+ * product entry point reaches it.  Solves (H + lambda[g] I) x = b per graph from a caller-supplied [H || b] buffer (layout of
+ * sslam_graph_linearize: H values, padded to an even count, then b).  Size query: with h_and_b / lambda / x_out == NULL it returns the
+ * doubles the buffer must hold; otherwise that count on success or a negative SSLAM_ERR_*.  fail_out[n] (optional): 1 where a pivot was
+ * not positive.  stats8[8] (optional): segments, steps, window slots, ... of the emulated plan. */
+int64_t sslam_debug_wchol_solve(sslam_graph* const* graphs, int n, const double* h_and_b, int64_t hb_doubles, const double* lambda,
+                                double* x_out, int32_t* fail_out, int64_t* stats8);
 
 /* ---- batched, device-resident form (MI355X extension) ---------------------------------------
  * B independent graphs laid out contiguously in HBM and optimised together: every kernel runs

@@ -30,18 +30,27 @@ struct KernelTimer {
 // optimising a small graph.  Bump allocation out of one block that is kept from rebuild to rebuild and regrown (x 1.5) when a
 // rebuild needed more than it holds; what did not fit meanwhile lives in spill blocks until the next reset.
 struct DevArena {
+  // One device block, two regions: [0, small_cap) holds the small index / table arrays of a rebuild (each <= kMirrorMax), the rest the
+  // large arrays (H, L, update matrices).  Only the table region has a pinned host mirror: the ~65 small arrays of a rebuild are written
+  // into it and travel to the device as ONE copy (flush) instead of one hipMemcpyAsync + hipMemsetAsync each -- the uploads were most of
+  // the 3 ms a tick spent on its structure rebuild.  (Round 3 mirrored the whole block: tens to hundreds of MB of pinned host memory per
+  // graph handle for tables of a few hundred KB -- ADVICE r3.)  Large arrays keep their own memset / copy.
   char* base = nullptr;
-  size_t cap = 0, used = 0, need = 0;
+  size_t cap = 0, used = 0, need = 0;                     // whole block; the large region is [small_cap, cap), `used` counts from 0
+  size_t small_cap = 0, small_used = 0, small_need = 0;   // table region
   std::vector<void*> spill;
-  // Host mirror of the arena (pinned): the ~65 small index / table arrays of a rebuild are written into it and travel to the
-  // device as ONE copy (flush) instead of one hipMemcpyAsync + hipMemsetAsync each -- the uploads were most of the 3 ms a tick
-  // spent on its structure rebuild.  Large zero-filled arrays (H, L, update matrices) keep their own memset.
   char* mirror = nullptr;
   size_t mirror_cap = 0, flushed = 0;
-  static constexpr size_t kMirrorMax = 256 << 10;   // arrays above this size bypass the mirror
-  void* take(size_t bytes) {
+  static constexpr size_t kMirrorMax = 256 << 10;   // arrays above this size live in the large region
+  // direct: the caller writes the array itself (memset / copy on its stream, issued before the flush): never from the table region,
+  // whose bytes all come from the mirror
+  void* take(size_t bytes, bool direct = false) {
     bytes = (bytes + 255) & ~(size_t)255;
     need += bytes;
+    if (bytes <= kMirrorMax && !direct) {
+      small_need += bytes;
+      if (small_used + bytes <= small_cap) { void* p = base + small_used; small_used += bytes; return p; }
+    }
     if (used + bytes <= cap) { void* p = base + used; used += bytes; return p; }
     void* p = nullptr;
     if (hipMalloc(&p, bytes) != hipSuccess) return nullptr;
@@ -49,46 +58,40 @@ struct DevArena {
     return p;
   }
   bool in_block(const void* p) const { return base && (const char*)p >= base && (const char*)p < base + cap; }
-  // host address that shadows device address p (arena block only), or nullptr
+  // host address that shadows device address p (table region only), or nullptr
   char* shadow(void* p, size_t bytes) {
-    if (!in_block(p) || bytes > kMirrorMax) return nullptr;
-    if (mirror_cap < cap) {
+    if (!base || (const char*)p < base || (const char*)p + bytes > base + small_cap) return nullptr;
+    if (mirror_cap < small_cap) {
       if (mirror) (void)hipHostFree(mirror);
       mirror = nullptr; mirror_cap = 0;
       void* q = nullptr;
-      if (hipHostMalloc(&q, cap, hipHostMallocDefault) != hipSuccess) return nullptr;
-      mirror = (char*)q; mirror_cap = cap; flushed = 0;
+      if (hipHostMalloc(&q, small_cap, hipHostMallocDefault) != hipSuccess) return nullptr;
+      mirror = (char*)q; mirror_cap = small_cap; flushed = 0;
     }
     return mirror + ((char*)p - base);
   }
-  // everything written to the mirror since the last flush -> device, one copy.  Ranges that bypassed the mirror inside
-  // [flushed, used) were written directly (memset / memcpy on the same stream, issued BEFORE this copy): the copy must not clobber
-  // them, so bypassing arrays are recorded and the flush is cut around them.
-  std::vector<std::pair<size_t, size_t>> holes;   // [begin, end) offsets that went to the device directly
+  // everything written to the mirror since the last flush -> device, one copy (every byte of the table region is shadowed: no holes)
   int flush(hipStream_t st) {
-    if (!mirror || flushed >= used) { flushed = used; holes.clear(); return 0; }
-    std::sort(holes.begin(), holes.end());
-    size_t a = flushed;
-    for (auto& h : holes) {
-      if (h.first > a && hipMemcpyAsync(base + a, mirror + a, h.first - a, hipMemcpyHostToDevice, st) != hipSuccess) return -3;
-      a = std::max(a, h.second);
-    }
-    if (used > a && hipMemcpyAsync(base + a, mirror + a, used - a, hipMemcpyHostToDevice, st) != hipSuccess) return -3;
-    flushed = used; holes.clear();
+    if (mirror && small_used > flushed && hipMemcpyAsync(base + flushed, mirror + flushed, small_used - flushed, hipMemcpyHostToDevice, st) != hipSuccess) return -3;
+    flushed = small_used;
     return 0;
   }
-  void note_direct(void* p, size_t bytes) { if (in_block(p)) holes.push_back({(size_t)((char*)p - base), (size_t)((char*)p - base) + ((bytes + 255) & ~(size_t)255)}); }
+  void note_direct(void*, size_t) {}   // large-region arrays are written by their own memset / copy; nothing of the mirror overlaps them
   void reset() {   // the caller guarantees that no kernel still uses the memory (the owning batch has been released)
     for (void* p : spill) (void)hipFree(p);
     spill.clear();
-    if (need > cap) {
+    const size_t big_need = need - small_need;
+    size_t new_small = small_cap;
+    if (small_need > small_cap) new_small = (small_need + small_need / 2 + (64u << 10) + 255) & ~(size_t)255;
+    if (new_small + big_need > cap) {
       if (base) (void)hipFree(base);
-      base = nullptr; cap = 0;
-      const size_t want = need + need / 2 + (1u << 20);
+      base = nullptr; cap = 0; small_cap = 0;
+      const size_t want = new_small + big_need + big_need / 2 + (1u << 20);
       void* p = nullptr;
       if (hipMalloc(&p, want) == hipSuccess) { base = (char*)p; cap = want; }
     }
-    used = 0; need = 0; flushed = 0; holes.clear();
+    small_cap = base ? new_small : 0;
+    used = small_cap; small_used = 0; need = 0; small_need = 0; flushed = 0;
   }
   ~DevArena() {
     for (void* p : spill) (void)hipFree(p);

@@ -1040,7 +1040,7 @@ int chol_plan_build(Batch& b) {
   void* p = nullptr;
   auto plan_alloc = [&](void** q, size_t bytes) -> int {
     if (P->arena) {
-      *q = P->arena->take(bytes);
+      *q = P->arena->take(bytes, true);
       if (*q) P->arena->note_direct(*q, bytes);   // zero-filled below with its own memset: the arena's flush must leave it alone
       return *q ? 0 : set_error(SSLAM_ERR_HIP, "device allocation of %zu bytes failed", bytes);
     }
@@ -1078,7 +1078,8 @@ int chol_plan_build(Batch& b) {
   size_t lds_max = (size_t)std::max(P->tail_lds_f, P->tail_lds_b);
   for (size_t l = 0; l < P->plv_lds_f.size(); ++l) lds_max = std::max(lds_max, (size_t)std::max(P->plv_lds_f[l], P->plv_lds_b[l]));
   lds_max *= sizeof(double);
-  if (lds_max > 160 * 1024 - 2048) return set_error(SSLAM_ERR_UNSUPPORTED, "a piece of the factor needs %zu B of LDS (> 158 KiB)", lds_max);
+  const int lds_lim = lds_optin_limit(b.device, 160 * 1024 - 2048, 2048);
+  if (lds_max > (size_t)lds_lim) return set_error(SSLAM_ERR_UNSUPPORTED, "a piece of the factor needs %zu B of LDS (device limit %d B)", lds_max, lds_lim);
   if (lds_max > 48 * 1024) {
     // One value for every plan, set once per device under a lock: the attribute belongs to the kernel, not to a plan, and the parts of a
     // stream group build their plans side by side (a smaller value written last would fail another part's launches).
@@ -1086,7 +1087,7 @@ int chol_plan_build(Batch& b) {
     static std::vector<int> done;
     std::lock_guard<std::mutex> lk(mu);
     if (std::find(done.begin(), done.end(), b.device) == done.end()) {
-      const int v = 160 * 1024 - 2048;
+      const int v = lds_lim;
       const void* fns[] = {(const void*)k_chol_pieces<64, true>, (const void*)k_chol_pieces<128, true>, (const void*)k_chol_pieces<256, true>,
                            (const void*)k_chol_pieces<512, true>, (const void*)k_chol_pieces<1024, true>,
                            (const void*)k_chol_pieces<64, false>, (const void*)k_chol_pieces<128, false>, (const void*)k_chol_pieces<256, false>,

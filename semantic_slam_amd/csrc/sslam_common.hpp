@@ -16,6 +16,18 @@ inline int set_error(int code, const char* fmt, ...) {
   last_error_ref() = buf;
   return code;
 }
+// Largest dynamic-LDS opt-in a kernel may ask for on `device`: the device's own limit (hipDeviceProp_t::sharedMemPerBlockOptin /
+// maxSharedMemoryPerBlock) minus `reserve` bytes for the kernels' static LDS, never more than `want` (the gfx950 figure the plans were
+// sized for).  A part with less LDS than an MI355X then fails with "needs N B of LDS" instead of a failed hipFuncSetAttribute.
+inline int lds_optin_limit(int device, int want, int reserve) {
+  int v = 0;
+  if (hipDeviceGetAttribute(&v, hipDeviceAttributeSharedMemPerBlockOptin, device) != hipSuccess || v <= 0) {
+    v = 0;
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerBlock, device) != hipSuccess) v = 0;
+  }
+  if (v <= 64 * 1024) return want;   // attribute not reported (or only the 64 KiB no-opt-in figure): keep the gfx950 constant, hipFuncSetAttribute fails loudly if it is too much
+  return v - reserve < want ? v - reserve : want;
+}
 }  // namespace sslam
 
 #define SSLAM_HIP_TRY(expr)                                                                          \

@@ -1708,6 +1708,7 @@ static int launch_check(const char* what) {
 // BlockSolver::buildSystem for the active graphs of the batch
 static int batch_linearize(Batch& b) {
   ScopedTimer t(b, "linearize");
+  b.V.dcs_phi = b.graphs[0]->opt.dcs_phi;   // read live like pcg_tol / solver: an option set after the batch was built must not be ignored
   const BatchView& V = b.V;
   const int nblk = (V.nPr + kRowThreads - 1) / kRowThreads;
   static const int lin_dbg = [] { const char* e = getenv("SSLAM_LIN_DBG"); return e ? atoi(e) : 0; }();
@@ -1817,6 +1818,7 @@ static int batch_solve(Batch& b) {
 
 static int batch_chi2(Batch& b, const double* pose, const double* lmk, int mask_mode) {
   ScopedTimer t(b, "chi2");
+  b.V.dcs_phi = b.graphs[0]->opt.dcs_phi;
   hipLaunchKernelGGL(k_chi2, edge_grid(b), dim3(kEdgeChunk), 0, b.stream, b.V, pose, lmk, mask_mode, b.d_part_e);
   return launch_check("chi2");
 }
@@ -1837,6 +1839,7 @@ static int batch_optimize(Batch& b, int max_iters, sslam_opt_stats* out) {
   long long budget = 10LL * std::max(max_iters, 0) + 8;    // hard bound: <= 10 trials per iteration
   int need = max_iters;
   if ((rc = chol_set_active(b, nullptr))) return rc;
+  struct CompactGuard { Batch& b; ~CompactGuard() { (void)chol_set_active(b, nullptr); } } compact_guard{b};   // every exit leaves the launches sized for all graphs
   std::vector<char> act(V.B, 1);
   int n_act = V.B;
   while (need > 0 && budget > 0) {
@@ -2618,16 +2621,20 @@ int sslam_batch_time_solver(sslam_batch* h, int repeats, double* factor_ms, doub
   if (b.graphs[0]->opt.solver == 0 || b.graphs[0]->opt.solver == 2) return set_error(SSLAM_ERR_UNSUPPORTED, "direct solvers only");
   SSLAM_HIP_TRY(hipSetDevice(b.device));
   int rc;
+  if ((rc = chol_set_active(b, nullptr))) return rc;   // a stale compaction (an optimise that failed half way) must not shrink what is timed
   if (!b.uploaded && (rc = batch_upload_estimates(b))) return rc;
   if ((rc = batch_chi2(b, b.V.pose, b.V.lmk, 0))) return rc;
   hipLaunchKernelGGL(k_lm_init, dim3(b.V.B), dim3(64), 0, b.stream, b.V, b.d_part_e, 0);
   if ((rc = batch_linearize(b))) return rc;
   hipLaunchKernelGGL(k_set_trial_all, dim3((b.V.B + 63) / 64), dim3(64), 0, b.stream, b.V, 1.0);
-  const bool prof = b.profiling;
+  struct Restore {   // events and the profiling switch are put back on every return path
+    Batch& b; bool prof; hipEvent_t e[3] = {nullptr, nullptr, nullptr};
+    ~Restore() { for (hipEvent_t x : e) if (x) (void)hipEventDestroy(x); b.profiling = prof; }
+  } guard{b, b.profiling};
   b.profiling = false;
   if ((rc = batch_solve(b))) return rc;   // warm-up (builds the plan)
-  hipEvent_t e0, e1, e2;
-  SSLAM_HIP_TRY(hipEventCreate(&e0)); SSLAM_HIP_TRY(hipEventCreate(&e1)); SSLAM_HIP_TRY(hipEventCreate(&e2));
+  SSLAM_HIP_TRY(hipEventCreate(&guard.e[0])); SSLAM_HIP_TRY(hipEventCreate(&guard.e[1])); SSLAM_HIP_TRY(hipEventCreate(&guard.e[2]));
+  hipEvent_t e0 = guard.e[0], e1 = guard.e[1], e2 = guard.e[2];
   double tf = 0, ts = 0;
   const bool wplan = b.wchol != nullptr;
   for (int k = 0; k < repeats; ++k) {
@@ -2641,8 +2648,6 @@ int sslam_batch_time_solver(sslam_batch* h, int repeats, double* factor_ms, doub
     SSLAM_HIP_TRY(hipEventElapsedTime(&a, e0, e1)); SSLAM_HIP_TRY(hipEventElapsedTime(&c, e1, e2));
     tf += a; ts += c;
   }
-  hipEventDestroy(e0); hipEventDestroy(e1); hipEventDestroy(e2);
-  b.profiling = prof;
   *factor_ms = tf / repeats; *solve_ms = ts / repeats;
   return 0;
 }

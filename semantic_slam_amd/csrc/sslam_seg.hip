@@ -1827,7 +1827,7 @@ static int seg_lds_opt_in(int device) {
   static std::vector<int> done;
   std::lock_guard<std::mutex> lk(mu);
   if (std::find(done.begin(), done.end(), device) != done.end()) return 0;
-  const int v = 156 * 1024;
+  const int v = lds_optin_limit(device, 156 * 1024, 4096);
   const void* fns[] = {(const void*)k_distance_map, (const void*)k_refine, (const void*)k_integral, (const void*)k_cc_lds, (const void*)k_refine_lds,
                        (const void*)k_contour<true>};
   for (const void* f : fns) SSLAM_HIP_TRY(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, v));

@@ -1036,14 +1036,14 @@ template <typename T>
 int w_up(WPlan& P, hipStream_t s, const std::vector<T>& h, const T** out) {
   void* p = nullptr;
   const size_t n = h.size() + 4;
-  if (P.arena) { p = P.arena->take(n * sizeof(T)); if (!p) return set_error(SSLAM_ERR_HIP, "device allocation of %zu bytes failed", n * sizeof(T)); P.arena->note_direct(p, n * sizeof(T)); }
+  if (P.arena) { p = P.arena->take(n * sizeof(T), true); if (!p) return set_error(SSLAM_ERR_HIP, "device allocation of %zu bytes failed", n * sizeof(T)); P.arena->note_direct(p, n * sizeof(T)); }
   else { SSLAM_HIP_TRY(hipMalloc(&p, n * sizeof(T))); P.allocs.push_back(p); }
   if (!h.empty()) SSLAM_HIP_TRY(hipMemcpyAsync(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, s));
   *out = (const T*)p;
   return 0;
 }
 int w_alloc(WPlan& P, void** q, size_t bytes) {
-  if (P.arena) { *q = P.arena->take(bytes); if (*q) P.arena->note_direct(*q, bytes); return *q ? 0 : set_error(SSLAM_ERR_HIP, "device allocation of %zu bytes failed", bytes); }
+  if (P.arena) { *q = P.arena->take(bytes, true); if (*q) P.arena->note_direct(*q, bytes); return *q ? 0 : set_error(SSLAM_ERR_HIP, "device allocation of %zu bytes failed", bytes); }
   SSLAM_HIP_TRY(hipMalloc(q, bytes)); P.allocs.push_back(*q);
   return 0;
 }

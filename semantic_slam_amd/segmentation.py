@@ -110,6 +110,7 @@ class PointCloudSegmentation:
         self.params = params if params is not None else default_params(device)
         self._h = self._lib.sslam_seg_create(C.byref(self.params))
         self._last_boxes = None
+        self._inflight = []          # (frame count, keep-alive buffers) of every submitted, not yet collected batch
 
     def __del__(self):
         h, self._h = getattr(self, "_h", None), None
@@ -187,16 +188,16 @@ class PointCloudSegmentation:
         f0 = frames[0]
         self._check(self._lib.sslam_seg_submit_batch(self._h, C.cast(fr, C.c_void_p), len(frames), f0.width, f0.height, f0.point_step, f0.row_step,
                                                      f0.offsets[0], f0.offsets[1], f0.offsets[2]))
-        if not hasattr(self, "_inflight"):
-            self._inflight = []
         self._inflight.append((len(frames), keep))
 
     def collect_frames(self, max_planes: int = 4096):
         """``sslam_seg_collect_batch``: the planes of the oldest submitted batch, per frame (as ``segment_frames`` returns them)"""
         out = (Plane * max_planes)()
         which = np.zeros(max_planes, np.int32)
+        # the C side consumes the oldest slot of its fifo whether or not the collect succeeds: the keep-alive list follows it in step
+        # (nothing in flight: the C call refuses and _check raises)
+        F, keep = self._inflight.pop(0) if self._inflight else (0, [])
         n = self._check(self._lib.sslam_seg_collect_batch(self._h, C.cast(out, C.c_void_p), max_planes, which.ctypes.data))
-        F, keep = self._inflight.pop(0)
         self._last_boxes = [bx for (boxes, _) in keep for bx in boxes]   # accepted slot = position, when no box is rejected
         res = [[] for _ in range(F)]
         for k, o in enumerate(self._objects(out, n)):
