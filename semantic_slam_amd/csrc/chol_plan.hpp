@@ -38,6 +38,14 @@
 #include <vector>
 
 namespace sslam {
+#ifdef SSLAM_PLAN_TIMERS
+#include <chrono>
+#define SSLAM_PT_INIT auto pt_ = std::chrono::steady_clock::now();
+#define SSLAM_PT(name) { auto n_ = std::chrono::steady_clock::now(); fprintf(stderr, "[plan-timer] %-14s %.3f ms\n", name, std::chrono::duration<double, std::milli>(n_ - pt_).count()); pt_ = n_; }
+#else
+#define SSLAM_PT_INIT
+#define SSLAM_PT(name)
+#endif
 
 struct ColMeta { int xoff, yoff, dim, graph, b0, nb, nbi, base, f0, f1, piece, ilevel; };
 // xoff: offset in the unknown vector (internal row order); yoff: offset in elimination order (the forward-substituted
@@ -306,6 +314,7 @@ inline int cut_pieces(int n, const std::vector<int>& parent, const std::vector<i
 // Symbolic factorisation + piece plan of a whole batch.  Returns 0, or -1 with out.error set.
 inline int chol_symbolic(const SymIn& in, CholOpts opt, CholHost& out) {
   using namespace chol_detail;
+  SSLAM_PT_INIT
   const int nPr = in.nPr, nLr = in.nLr, nrow = nPr + nLr, B = in.B;
   if (opt.tail_width < 0) opt.tail_width = B >= 32 ? 6 : 2;
   if (opt.ustage < 0) opt.ustage = B >= 32 ? 0 : 1;
@@ -444,13 +453,13 @@ inline int chol_symbolic(const SymIn& in, CholOpts opt, CholHost& out) {
     npiece += ngroup;
     ncomp += (int)ids.size();
   }
+  SSLAM_PT("order+pieces")
   const int ncol = (int)col_row.size();
   out.ncol = ncol; out.npiece = npiece; out.dim = 6 * nPr + 3 * nLr;
 
   // ---- blocks of every column, sorted by elimination position of the row ----------------------------------------------
   std::vector<int> bp(ncol + 1, 0), boff, brow, bsrc, col_xoff(ncol), col_yoff(ncol), col_dim(ncol);
   std::vector<unsigned char> bfmt;
-  std::vector<std::unordered_map<int, int>> colblk(ncol);
   int64_t lnz = 0;
   {
     int y = 0;
@@ -463,12 +472,10 @@ inline int chol_symbolic(const SymIn& in, CholOpts opt, CholHost& out) {
       bp[j] = (int)boff.size();
       boff.push_back((int)lnz); brow.push_back(j);
       bsrc.push_back(rj < nPr ? rj * 36 : (int)(in.hll_base + (int64_t)(rj - nPr) * 9)); bfmt.push_back(0);
-      colblk[j][j] = bp[j];
       lnz += blk_doubles(dj, dj);
       for (int i : rows_c) {
         if (i <= j) { out.error = "symbolic factorisation inconsistent (row not below its column)"; return -1; }
         const int ri = col_row[i], di = row_dim(ri);
-        colblk[j][i] = (int)boff.size();
         boff.push_back((int)lnz); brow.push_back(i);
         const int a = std::min(ri, rj), c = std::max(ri, rj);
         auto it = hoff.find(key(a, c));
@@ -481,6 +488,13 @@ inline int chol_symbolic(const SymIn& in, CholOpts opt, CholHost& out) {
   }
   bp[ncol] = (int)boff.size();
   const int nblk = (int)boff.size();
+  // block (row i, column j), or -1: the rows of a column ascend (diagonal first)
+  auto find_blk = [&](int j, int i) -> int {
+    const int* lo = brow.data() + bp[j];
+    const int* hi = brow.data() + bp[j + 1];
+    const int* it = std::lower_bound(lo, hi, i);
+    return (it != hi && *it == i) ? (int)(it - brow.data()) : -1;
+  };
   out.lnz = lnz;
   // flat layout inside a piece: blocks sorted by size class (stable in block order)
   std::vector<int> piece_base, piece_size, piece_n36, piece_n18;
@@ -505,6 +519,7 @@ inline int chol_symbolic(const SymIn& in, CholOpts opt, CholHost& out) {
       j = j1;
     }
   }
+  SSLAM_PT("blocks")
   // ---- levels of the block elimination tree (multi right-hand-side solves) and inside the pieces --------------------------
   std::vector<int> level(ncol, 0), col_il(ncol, 0);
   int nlev = 0;
@@ -610,6 +625,7 @@ inline int chol_symbolic(const SymIn& in, CholOpts opt, CholHost& out) {
       }
     pm.nint = r;
   }
+  SSLAM_PT("levels+cols")
   // ---- piece by piece (elimination order: children before parents): internal updates, update matrix, assembly -------------------------
   struct URec { int a, b, uoff, uy, comp; };          // finished update-matrix block (row column-ids a >= b; uy: rhs part of a diagonal block) of component comp
   std::vector<std::vector<URec>> inbox(npiece);       // per group: the blocks its child components handed up (kept until consumed)
@@ -637,33 +653,52 @@ inline int chol_symbolic(const SymIn& in, CholOpts opt, CholHost& out) {
       std::sort(R.begin(), R.end());
       R.erase(std::unique(R.begin(), R.end()), R.end());
     }
-    // update-matrix blocks under construction: one matrix per component (different components of a group may have different parents)
-    struct UB { int comp, a, b; std::vector<std::array<int, 3>> own; std::vector<AsmSrc> src; };
+    // update-matrix blocks under construction: one matrix per component (different components of a group may have different parents).
+    // Flat records instead of per-block containers (the host plan is rebuilt every tick of the orchestrator: this loop was 75 % of it):
+    // a block is found through a dense lower-triangular table over its component's boundary rows, contributions are appended to flat
+    // lists and grouped by block with a stable counting sort afterwards -> every list keeps the order it was generated in.
+    struct UB { int comp, a, b; };
     std::vector<UB> ub;
-    std::map<std::array<int, 3>, int> ubidx;
-    auto ublock = [&](int comp, int a, int b2) -> UB& {
-      const std::array<int, 3> k3{comp, a, b2};
-      auto it = ubidx.find(k3);
-      if (it != ubidx.end()) return ub[it->second];
-      ubidx.emplace(k3, (int)ub.size());
-      ub.push_back(UB{comp, a, b2, {}, {}});
-      return ub.back();
+    std::vector<int> ctab_base(comps.size() + 1, 0);
+    for (size_t ci = 0; ci < comps.size(); ++ci) { const int r = (int)comp_R[comps[ci]].size(); ctab_base[ci + 1] = ctab_base[ci] + r * (r + 1) / 2; }
+    std::vector<int> ctab(ctab_base.back(), -1);
+    auto ublock = [&](int comp, int a, int b2) -> int {
+      const int ci = (int)(std::lower_bound(comps.begin(), comps.end(), comp) - comps.begin());
+      const std::vector<int>& R = comp_R[comp];
+      const int ia = (int)(std::lower_bound(R.begin(), R.end(), a) - R.begin()), ib = (int)(std::lower_bound(R.begin(), R.end(), b2) - R.begin());
+      int& slot = ctab[ctab_base[ci] + ia * (ia + 1) / 2 + ib];   // a >= b2: both column ids, R ascending
+      if (slot < 0) { slot = (int)ub.size(); ub.push_back(UB{comp, a, b2}); }
+      return slot;
     };
+    struct OwnRec { int blk, ua, ubo, k; };
+    struct SrcRec { int blk; AsmSrc s; };
+    std::vector<OwnRec> own_flat;
+    std::vector<SrcRec> src_flat;
     // internal updates (target column in the piece) and own update-matrix contributions (both rows above the piece)
-    struct IU { int ua, ub2, k; };
-    std::unordered_map<int, std::vector<IU>> iul;   // target block -> internal updates, ascending k
+    struct IU { int t, ua, ub2, k; };
+    std::vector<IU> iu_flat;   // generation order: ascending source column k
+    std::vector<int> rix;      // per column: position of its rows above the piece in the boundary list of its component
     for (int k = pm.c0; k < pm.c0 + pm.nc; ++k) {
       const int k0 = bp[k] + 1, kin = bp[k] + col_nbi[k], k1 = bp[k + 1];
+      const std::vector<int>& Rk = comp_R[col_comp[k]];
+      const int tb = ctab_base[std::lower_bound(comps.begin(), comps.end(), col_comp[k]) - comps.begin()];
+      rix.resize(k1 - kin);
+      for (int q = kin; q < k1; ++q) rix[q - kin] = (int)(std::lower_bound(Rk.begin(), Rk.end(), brow[q]) - Rk.begin());
       for (int pp = k0; pp < k1; ++pp) {
         const int j = brow[pp];
         if (pp < kin) {
           for (int q = pp; q < k1; ++q) {
-            auto it = colblk[j].find(brow[q]);
-            if (it == colblk[j].end()) { out.error = "symbolic factorisation inconsistent (missing fill block)"; return -1; }
-            iul[it->second].push_back(IU{boff[q], boff[pp], k});
+            const int t = find_blk(j, brow[q]);
+            if (t < 0) { out.error = "symbolic factorisation inconsistent (missing fill block)"; return -1; }
+            iu_flat.push_back(IU{t, boff[q], boff[pp], k});
           }
         } else {
-          for (int q = pp; q < k1; ++q) ublock(col_comp[k], brow[q], j).own.push_back({boff[q], boff[pp], k});
+          for (int q = pp; q < k1; ++q) {
+            const int ia = rix[q - kin], ib = rix[pp - kin];   // rows ascend with q: ia >= ib
+            int& slot = ctab[tb + ia * (ia + 1) / 2 + ib];
+            if (slot < 0) { slot = (int)ub.size(); ub.push_back(UB{col_comp[k], brow[q], j}); }
+            own_flat.push_back(OwnRec{slot, boff[q], boff[pp], k});
+          }
         }
       }
     }
@@ -677,7 +712,7 @@ inline int chol_symbolic(const SymIn& in, CholOpts opt, CholHost& out) {
         for (int pp = k0; pp < kin; ++pp) {
           const int j = brow[pp];
           for (int q = pp; q < k1; ++q) {
-            const int t = colblk[j].find(brow[q])->second;     // present: checked when iul was built
+            const int t = find_blk(j, brow[q]);     // present: checked when the internal updates were listed
             const int tl = out.blk[t].off - pm.lbase, yl = col_yoff[j] - pm.y0;
             if (tl < 0 || tl >= (1 << 16) || yl < 0 || yl >= (1 << 15)) right_ok = false;   // (an oversized SSLAM_CHOL_CAP_TAIL) the packed records do not fit: target-major lists everywhere
             const int tpk = (col_dim[brow[t]] == 6 ? kUpdDi6 : 0) | (t == bp[j] ? kUpdDiag : 0) | (col_dim[j] == 6 ? kUpdDj6 : 0) | (col_dim[k] == 6 ? kUpdDk6 : 0);
@@ -688,29 +723,48 @@ inline int chol_symbolic(const SymIn& in, CholOpts opt, CholHost& out) {
       }
     }
     // what the children hand up: absorbed into a column of this piece (assembly) or passed on (update matrix)
-    std::unordered_map<int, std::vector<AsmSrc>> asml;   // target block -> child blocks
+    struct AsmRec { int t; AsmSrc s; };
+    std::vector<AsmRec> asm_flat;
     for (const URec& u : inbox[p]) {
       if (col_piece[u.b] == p) {
-        auto it = colblk[u.b].find(u.a);
-        if (it == colblk[u.b].end()) { out.error = "update-matrix block without a target"; return -1; }
-        asml[it->second].push_back(AsmSrc{u.uoff, u.uy});
+        const int t = find_blk(u.b, u.a);
+        if (t < 0) { out.error = "update-matrix block without a target"; return -1; }
+        asm_flat.push_back(AsmRec{t, AsmSrc{u.uoff, u.uy}});
       } else {
         if (col_piece[u.a] == p) { out.error = "update-matrix block with its row inside the piece but its column above"; return -1; }
         const int pc = comp_parent[u.comp];   // the component of this group that the sender hangs below
         if (pc < 0 || !std::binary_search(comps.begin(), comps.end(), pc)) { out.error = "update-matrix block routed to the wrong group"; return -1; }
-        ublock(pc, u.a, u.b).src.push_back(AsmSrc{u.uoff, u.uy});
+        src_flat.push_back(SrcRec{ublock(pc, u.a, u.b), AsmSrc{u.uoff, u.uy}});
       }
     }
     std::vector<URec>().swap(inbox[p]);
+    // group the flat lists (stable): internal updates and assembly sources by target block, own / child contributions by U block
+    std::vector<int> iu_ptr(pm.nb + 1, 0), as_ptr(pm.nb + 1, 0), own_ptr(ub.size() + 1, 0), src_ptr(ub.size() + 1, 0);
+    for (auto& r : iu_flat) iu_ptr[r.t - pm.b0 + 1]++;
+    for (auto& r : asm_flat) as_ptr[r.t - pm.b0 + 1]++;
+    for (auto& r : own_flat) own_ptr[r.blk + 1]++;
+    for (auto& r : src_flat) src_ptr[r.blk + 1]++;
+    for (int t = 0; t < pm.nb; ++t) { iu_ptr[t + 1] += iu_ptr[t]; as_ptr[t + 1] += as_ptr[t]; }
+    for (size_t q = 0; q < ub.size(); ++q) { own_ptr[q + 1] += own_ptr[q]; src_ptr[q + 1] += src_ptr[q]; }
+    std::vector<IU> iu_s(iu_flat.size());
+    std::vector<AsmSrc> as_s(asm_flat.size()), src_s(src_flat.size());
+    std::vector<OwnRec> own_s(own_flat.size());
+    {
+      std::vector<int> c1(iu_ptr.begin(), iu_ptr.end() - 1), c2(as_ptr.begin(), as_ptr.end() - 1), c3(own_ptr.begin(), own_ptr.end() - 1), c4(src_ptr.begin(), src_ptr.end() - 1);
+      for (auto& r : iu_flat) iu_s[c1[r.t - pm.b0]++] = r;
+      for (auto& r : asm_flat) as_s[c2[r.t - pm.b0]++] = r.s;
+      for (auto& r : own_flat) own_s[c3[r.blk]++] = r;
+      for (auto& r : src_flat) src_s[c4[r.blk]++] = r.s;
+    }
     // assembly records, block order
     pm.as0 = (int)out.asrc.size();
     for (int t = pm.b0; t < pm.b0 + pm.nb; ++t) {
-      auto it = asml.find(t);
-      if (it == asml.end()) continue;
-      if (it->second.size() > 255) { out.error = "a block has more than 255 assembly sources"; return -1; }
+      const int n_as = as_ptr[t - pm.b0 + 1] - as_ptr[t - pm.b0];
+      if (n_as == 0) continue;
+      if (n_as > 255) { out.error = "a block has more than 255 assembly sources"; return -1; }
       out.blk[t].as0 = (int)out.asrc.size() - pm.as0;
-      out.blk[t].info |= (int)it->second.size() << kBlkNasShift;
-      for (auto& a2 : it->second) out.asrc.push_back(a2);
+      out.blk[t].info |= n_as << kBlkNasShift;
+      for (int q = as_ptr[t - pm.b0]; q < as_ptr[t - pm.b0 + 1]; ++q) out.asrc.push_back(as_s[q]);
     }
     pm.nas = (int)out.asrc.size() - pm.as0;
     // internal update records of the piece, level by level / block by block; internal items
@@ -720,9 +774,10 @@ inline int chol_symbolic(const SymIn& in, CholOpts opt, CholHost& out) {
       const int j = block_col[t];
       const int tpk = (col_dim[brow[t]] == 6 ? kUpdDi6 : 0) | (t == bp[j] ? kUpdDiag : 0) | (col_dim[j] == 6 ? kUpdDj6 : 0);
       bi0[t - pm.b0] = (int)out.upd.size() - pm.iu0;
-      auto it = iul.find(t);
-      if (it != iul.end())
-        for (auto& u : it->second) out.upd.push_back(UpdMeta{u.ua, u.ub2, col_yoff[u.k], tpk | (col_dim[u.k] == 6 ? kUpdDk6 : 0)});
+      for (int q = iu_ptr[t - pm.b0]; q < iu_ptr[t - pm.b0 + 1]; ++q) {
+        const IU& u = iu_s[q];
+        out.upd.push_back(UpdMeta{u.ua, u.ub2, col_yoff[u.k], tpk | (col_dim[u.k] == 6 ? kUpdDk6 : 0)});
+      }
       bi1[t - pm.b0] = (int)out.upd.size() - pm.iu0;
     }
     pm.nu_i = (int)out.upd.size() - pm.iu0;
@@ -775,12 +830,9 @@ inline int chol_symbolic(const SymIn& in, CholOpts opt, CholHost& out) {
     if (pm.nilv > kMaxILevels) { out.error = "a piece has too many internal levels"; return -1; }
     if (pm.ysize >= (1 << (32 - kItemYShift - 1))) { out.error = "a piece has too many unknowns"; return -1; }
     // update matrix of the piece: blocks in (a, b) order, own update records, child sources, U items
-    std::vector<int> order(ub.size());
-    for (size_t q = 0; q < ub.size(); ++q) order[q] = (int)q;
-    std::sort(order.begin(), order.end(), [&](int x, int y2) {
-      if (ub[x].comp != ub[y2].comp) return ub[x].comp < ub[y2].comp;
-      return ub[x].a != ub[y2].a ? ub[x].a < ub[y2].a : ub[x].b < ub[y2].b;
-    });
+    std::vector<int> order;   // (component, a, b) ascending = the order of the dense tables (components and boundary rows ascend)
+    order.reserve(ub.size());
+    for (int slot : ctab) if (slot >= 0) order.push_back(slot);
     pm.uit0 = (int)out.uitem.size();
     pm.umb0 = (int)out.umb.size();
     pm.uu0 = (int)out.upd.size();
@@ -792,28 +844,27 @@ inline int chol_symbolic(const SymIn& in, CholOpts opt, CholHost& out) {
       std::unordered_map<int, int> comp_uy;   // Uval offset of a component's rhs part [|R|][6]
       for (int c : comps) { comp_uy[c] = (int)cur; cur += 6 * (int64_t)comp_R[c].size(); }
       if (cur >= ((int64_t)1 << 31) - 4096) { out.error = "update matrices too large for int32 offsets"; return -1; }
-      int U = 0;
-      for (auto& x : ub) U += (int)x.own.size();
+      const int U = (int)own_s.size();
       int chunk = std::max(opt.min_chunk, (U + slots - 1) / slots);
       for (;; ++chunk) {
         int nonsole = 0;
-        for (auto& x : ub) { const int k = ((int)x.own.size() + chunk - 1) / chunk; if (k > 1) nonsole += k; }
+        for (size_t q = 0; q < ub.size(); ++q) { const int k = (own_ptr[q + 1] - own_ptr[q] + chunk - 1) / chunk; if (k > 1) nonsole += k; }
         if (nonsole <= pcap || chunk >= std::max(U, 1)) break;
       }
       int ps = 0;
       for (int q : order) {
-        UB& x = ub[q];
+        const UB& x = ub[q];
         const int di = col_dim[x.a], dj = col_dim[x.b];
         const bool diag = x.a == x.b;
         int uy = -1;
         if (diag) { const std::vector<int>& R = comp_R[x.comp]; uy = comp_uy[x.comp] + 6 * (int)(std::lower_bound(R.begin(), R.end(), x.a) - R.begin()); }
         const int tpk = (di == 6 ? kUpdDi6 : 0) | (diag ? kUpdDiag : 0) | (dj == 6 ? kUpdDj6 : 0);
         const int u0 = (int)out.upd.size() - pm.uu0;
-        for (auto& u : x.own) out.upd.push_back(UpdMeta{u[0], u[1], col_yoff[u[2]], tpk | (col_dim[u[2]] == 6 ? kUpdDk6 : 0)});
-        const int n = (int)x.own.size();
+        for (int w = own_ptr[q]; w < own_ptr[q + 1]; ++w) { const OwnRec& u = own_s[w]; out.upd.push_back(UpdMeta{u.ua, u.ubo, col_yoff[u.k], tpk | (col_dim[u.k] == 6 ? kUpdDk6 : 0)}); }
+        const int n = own_ptr[q + 1] - own_ptr[q];
         const int s0 = (int)out.usrc.size() - pm.us0;
-        for (auto& a2 : x.src) out.usrc.push_back(a2);
-        const int ns = (int)x.src.size();
+        for (int w = src_ptr[q]; w < src_ptr[q + 1]; ++w) out.usrc.push_back(src_s[w]);
+        const int ns = src_ptr[q + 1] - src_ptr[q];
         const int k = std::max(1, (n + chunk - 1) / chunk);
         const int shape = (di == 6 ? kUItemDi6 : 0) | (dj == 6 ? kUItemDj6 : 0) | (diag ? kUItemDiag : 0);
         for (int qq = 0; qq < k; ++qq) {
@@ -833,6 +884,7 @@ inline int chol_symbolic(const SymIn& in, CholOpts opt, CholHost& out) {
     pm.nus = (int)out.usrc.size() - pm.us0;
   }
   out.unz = ucur;
+  SSLAM_PT("piece loop")
   if (!right_ok) { out.rupd.clear(); out.rcol.assign(ncol, RCol{0, 0}); }
   // ---- LDS needs (doubles) ---------------------------------------------------------------------------------------------------
   auto lds_f = [&](int p) {

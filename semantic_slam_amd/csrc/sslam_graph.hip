@@ -2745,7 +2745,10 @@ void* sslam_debug_plan_create(sslam_graph* const* graphs, int n) {
   if (!graphs || n <= 0) { set_error(SSLAM_ERR_INVALID, "empty batch"); return nullptr; }
   Batch b;
   for (int i = 0; i < n; ++i) { if (!graphs[i]) { set_error(SSLAM_ERR_INVALID, "null graph"); return nullptr; } b.graphs.push_back(&graphs[i]->g); }
+  static const bool timing = getenv("SSLAM_TIMING") != nullptr;
+  const auto t0 = std::chrono::steady_clock::now();
   if (batch_build(b, true) != 0) return nullptr;
+  const auto t1 = std::chrono::steady_clock::now();
   SymIn in;
   chol_sym_input(b, in);
   CholOpts opt;
@@ -2758,6 +2761,8 @@ void* sslam_debug_plan_create(sslam_graph* const* graphs, int n) {
   for (auto& q : b.plblk) { P->plblk.push_back(q.first); P->plblk.push_back(q.second); }
   P->sc[11] = b.V.nPr; P->sc[12] = b.V.nLr; P->sc[13] = (int)b.hll_base; P->sc[14] = (int)b.hpp_off_base; P->sc[15] = (int)b.hpl_base;
   if (chol_symbolic(in, opt, P->H)) { set_error(SSLAM_ERR_NUMERIC, "Cholesky plan: %s", P->H.error.c_str()); delete P; return nullptr; }
+  if (timing) fprintf(stderr, "[timing] host plan: batch tables %.3f ms, symbolic Cholesky %.3f ms\n", std::chrono::duration<double, std::milli>(t1 - t0).count(),
+                      std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count());
   return P;
 }
 void sslam_debug_plan_destroy(void* p) { delete (sslam_debug_plan*)p; }
