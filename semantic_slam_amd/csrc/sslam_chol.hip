@@ -71,6 +71,12 @@ struct CholPlan {
   double* d_multi_y = nullptr;  // scratch for multi-rhs solves
   double* d_multi_x = nullptr;
   int multi_cap = 0;
+  // marginals along the elimination-tree paths (k_chol_marginal_paths)
+  std::vector<int> h_cparent;   // parent column in the elimination tree, -1: root
+  std::vector<int> h_xoff_col;  // offset in the unknown vector (internal row order) -> column, -1 elsewhere
+  int* d_mpath = nullptr;       // [path_ptr | dims | path columns] of a request
+  double* d_mout = nullptr;     // [requests][36]
+  size_t mpath_cap = 0, mout_cap = 0;
 };
 
 void chol_plan_free(CholPlan* p) {
@@ -94,6 +100,8 @@ void chol_plan_free(CholPlan* p) {
   if (p->d_idx) (void)hipFree(p->d_idx);
   if (p->d_multi_y) (void)hipFree(p->d_multi_y);
   if (p->d_multi_x) (void)hipFree(p->d_multi_x);
+  if (p->d_mpath) (void)hipFree(p->d_mpath);
+  if (p->d_mout) (void)hipFree(p->d_mout);
   delete p;
 }
 
@@ -946,6 +954,86 @@ __global__ __launch_bounds__(64) void k_chol_backward_level(CholView C, int lvl_
   if (p < n) chol_backward_column<Q>(C, j, y, x, (size_t)blockIdx.y * C.dim, threadIdx.x % (8 * Q));
 }
 
+// ------------------------------------------------------------------------------------------------
+// Diagonal blocks of H^-1 = (L L^T)^-1 for a list of vertices in ONE launch (computeLandmarkMarginals, reference
+// src/ps_graph_slam/graph_slam.cpp:221-234 -> g2o MarginalCovarianceCholesky).  Z(v,v) = E_v^T L^-T L^-1 E_v = Y^T Y with Y = L^-1 E_v,
+// and Y is non-zero only on the PATH from v's column to the root of the elimination tree; every off-diagonal block of a column on that
+// path has its row further up the same path (struct(k) is a subset of the ancestors of k).  One wave per vertex walks its path bottom-up
+// with a right-looking forward substitution held in LDS: finalise Y_s = L_ss^-1 acc_s, then every block (i, path[s]) of the column
+// subtracts L(i, s) Y_s from acc_i -- one lane per block, distinct rows, no conflicts, fixed order.  Work O(path^2) per vertex instead of
+// two triangular solves over the whole factor per right-hand side column (round 3: 2 x levels launches, 3 N_l right-hand sides and the
+// whole solution matrix over PCIe).  Needs the flat factor (chol_factor_and_forward(b, true)).
+// LDS: [Y: maxlen x 36 | diagonal block 36 | path records: {first block, blocks, diagonal offset, dim | yoff << 8} maxlen x int4]
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_chol_marginal_paths(CholView C, const int* __restrict__ path_ptr, const int* __restrict__ req_dim,
+                                                            const int* __restrict__ path_cols, double* __restrict__ out, int maxlen) {
+  extern __shared__ double sm[];
+  const int r = blockIdx.x, lane = threadIdx.x;
+  const int p0 = path_ptr[r], P = path_ptr[r + 1] - p0, D = req_dim[r];
+  double* Y = sm;
+  double* sD = Y + (size_t)maxlen * 36;
+  int4* prec = reinterpret_cast<int4*>(sD + 36);
+  int* pyoff = reinterpret_cast<int*>(prec + maxlen);
+  const double* __restrict__ L = C.Lval;
+  for (int t = lane; t < P; t += 64) {
+    const ColMeta cm = C.col[path_cols[p0 + t]];
+    prec[t] = make_int4(cm.b0, cm.nb, cm.base, cm.dim);
+    pyoff[t] = cm.yoff;
+  }
+  for (int e = lane; e < P * 36; e += 64) Y[e] = 0.0;
+  __syncthreads();
+  if (lane < D) Y[lane * 6 + lane] = 1.0;   // E_v: identity in the vertex' own rows (path entry 0)
+  __syncthreads();
+  for (int s = 0; s < P; ++s) {
+    const int4 pr = prec[s];
+    const int da = pr.w;
+    if (lane < da * da) sD[lane] = L[pr.z + lane];
+    __syncthreads();
+    if (lane < D) {   // one lane per right-hand side column: Y_s = L_ss^-1 acc_s
+      double yv[6];
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+        if (i < da) {
+          double a = Y[s * 36 + i * 6 + lane];
+#pragma unroll
+          for (int m = 0; m < 6; ++m) if (m < i) a -= sD[i * da + m] * yv[m];
+          yv[i] = a / sD[i * da + i];
+          Y[s * 36 + i * 6 + lane] = yv[i];
+        }
+      }
+    }
+    __syncthreads();
+    for (int bq = lane; bq < pr.y - 1; bq += 64) {   // the blocks below the diagonal: acc_t -= L(t, s) Y_s
+      const BlkMeta bm = C.blk[pr.x + 1 + bq];
+      const int di = bm.info & 15;
+      int lo = s + 1, hi = P - 1;                    // the row's place on the path (y offsets ascend along it)
+      while (lo < hi) { const int mid = (lo + hi) >> 1; if (pyoff[mid] < bm.yoff_row) lo = mid + 1; else hi = mid; }
+      const double* Lb = L + bm.off;
+      double* acc = Y + lo * 36;
+      for (int i = 0; i < di; ++i) {
+        double lrow[6];
+#pragma unroll
+        for (int m = 0; m < 6; ++m) lrow[m] = m < da ? Lb[i * da + m] : 0.0;
+        for (int c = 0; c < D; ++c) {
+          double a = 0;
+#pragma unroll
+          for (int m = 0; m < 6; ++m) a += lrow[m] * Y[s * 36 + m * 6 + c];   // rows >= da of Y_s are zero
+          acc[i * 6 + c] -= a;
+        }
+      }
+    }
+    __syncthreads();
+  }
+  if (lane < D * D) {
+    const int rr = lane / D, cc = lane - rr * D;
+    double z = 0;
+    for (int t = 0; t < P; ++t)
+#pragma unroll
+      for (int i = 0; i < 6; ++i) z += Y[t * 36 + i * 6 + rr] * Y[t * 36 + i * 6 + cc];
+    out[(size_t)r * 36 + lane] = z;
+  }
+}
+
 __global__ void k_chol_begin(BatchView V, CholView C) {  // clear failure flags of the graphs being solved
   const int g = blockIdx.x * blockDim.x + threadIdx.x;
   if (g < V.B && V.lm[g].in_trial) C.fail[g] = 0;
@@ -1008,6 +1096,16 @@ int chol_plan_build(Batch& b) {
   P->lvl_ptr = H.lvl_ptr; P->plv_ptr = H.plv_ptr; P->plv_lds_f = H.plv_lds_f; P->plv_lds_b = H.plv_lds_b;
   P->tail_lds_f = H.tail_lds_f; P->tail_lds_b = H.tail_lds_b; P->tail_total = (int)H.tail_pieces.size(); P->nt_tail = H.nt_tail; P->nt_leaf = H.nt_leaf; P->ustage = H.ustage;
   P->lnz = H.lnz;
+  {   // elimination-tree parents (first block below the diagonal) and the vertex -> column map, for the path marginals
+    std::vector<int> yoff_col(H.dim + 1, -1);
+    for (int j = 0; j < H.ncol; ++j) yoff_col[H.col[j].yoff] = j;
+    P->h_cparent.assign(H.ncol, -1);
+    P->h_xoff_col.assign(H.dim + 1, -1);
+    for (int j = 0; j < H.ncol; ++j) {
+      if (H.col[j].nb > 1) P->h_cparent[j] = yoff_col[H.blk[H.col[j].b0 + 1].yoff_row];
+      P->h_xoff_col[H.col[j].xoff] = j;
+    }
+  }
   int rc;
   if ((rc = up_to_dev(*P, b.stream, H.col, &C.col))) return rc;
   if ((rc = up_to_dev(*P, b.stream, H.blk, &C.blk))) return rc;
@@ -1242,6 +1340,52 @@ int chol_solve_multi(Batch& b, const double* rhs_host, int nrhs, double* x_host)
     SSLAM_HIP_TRY(hipMemcpyAsync(x_host + (size_t)r0 * C.dim, P.d_multi_x, bytes, hipMemcpyDeviceToHost, b.stream));
     SSLAM_HIP_TRY(hipStreamSynchronize(b.stream));
   }
+  return 0;
+}
+
+// Z(v, v) of (L L^T)^-1 for the vertices whose unknowns start at xoff[k] (internal row order, dims[k] = 3 | 6), from the last FLAT
+// factorisation; out: [n][36], the leading dims[k]^2 entries row-major.  Returns SSLAM_ERR_UNSUPPORTED when a path does not fit the LDS of
+// one wave (the caller falls back to the multi right-hand-side solves).
+int chol_marginal_diag(Batch& b, const std::vector<int>& xoff, const std::vector<int>& dims, double* out) {
+  CholPlan& P = *b.chol;
+  const CholView& C = P.C;
+  const int n = (int)xoff.size();
+  if (n == 0) return 0;
+  if (!C.flat_L) return set_error(SSLAM_ERR_INVALID, "chol_marginal_diag needs the flat factor (chol_factor_and_forward(b, true))");
+  std::vector<int> hdr(2 * (size_t)n + 1, 0), cols;
+  int maxlen = 1;
+  for (int k = 0; k < n; ++k) {
+    int j = (xoff[k] >= 0 && xoff[k] < (int)P.h_xoff_col.size()) ? P.h_xoff_col[xoff[k]] : -1;
+    if (j < 0) return set_error(SSLAM_ERR_INVALID, "marginal of an unknown that is not the start of a block row");
+    hdr[k] = (int)cols.size();
+    for (; j >= 0; j = P.h_cparent[j]) cols.push_back(j);
+    maxlen = std::max(maxlen, (int)cols.size() - hdr[k]);
+    hdr[n + 1 + k] = dims[k];
+  }
+  hdr[n] = (int)cols.size();
+  const size_t lds = (size_t)maxlen * 36 * sizeof(double) + 36 * sizeof(double) + (size_t)maxlen * (sizeof(int4) + sizeof(int)) + 16;
+  if (lds > 60 * 1024) return SSLAM_ERR_UNSUPPORTED;
+  const size_t ints = hdr.size() + cols.size();
+  if (P.mpath_cap < ints) {
+    if (P.d_mpath) (void)hipFree(P.d_mpath);
+    P.d_mpath = nullptr; P.mpath_cap = 0;
+    SSLAM_HIP_TRY(hipMalloc((void**)&P.d_mpath, (ints + 4096) * sizeof(int)));
+    P.mpath_cap = ints + 4096;
+  }
+  if (P.mout_cap < (size_t)n * 36) {
+    if (P.d_mout) (void)hipFree(P.d_mout);
+    P.d_mout = nullptr; P.mout_cap = 0;
+    SSLAM_HIP_TRY(hipMalloc((void**)&P.d_mout, ((size_t)n * 36 + 4096) * sizeof(double)));
+    P.mout_cap = (size_t)n * 36 + 4096;
+  }
+  hdr.insert(hdr.end(), cols.begin(), cols.end());
+  SSLAM_HIP_TRY(hipMemcpyAsync(P.d_mpath, hdr.data(), hdr.size() * sizeof(int), hipMemcpyHostToDevice, b.stream));
+  hipLaunchKernelGGL(k_chol_marginal_paths, dim3(n), dim3(64), lds, b.stream, C, (const int*)P.d_mpath, (const int*)(P.d_mpath + n + 1),
+                     (const int*)(P.d_mpath + 2 * (size_t)n + 1), P.d_mout, maxlen);
+  SSLAM_HIP_TRY(hipMemcpyAsync(out, P.d_mout, (size_t)n * 36 * sizeof(double), hipMemcpyDeviceToHost, b.stream));
+  SSLAM_HIP_TRY(hipStreamSynchronize(b.stream));   // hdr is a local
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return set_error(SSLAM_ERR_HIP, "path marginals launch: %s", hipGetErrorString(e));
   return 0;
 }
 

@@ -2261,7 +2261,7 @@ static int marginal_blocks(sslam_graph* h, const std::vector<std::pair<int, int>
   int nrhs = 0;
   for (int v : colv) { col0[v] = nrhs; nrhs += vertex_dim(h->g.vtype[v]); }
   const size_t idim = (size_t)6 * b.V.nPr + (size_t)3 * b.V.nLr;
-  std::vector<double> X((size_t)nrhs * dim);   // [scalar column][g2o order]
+  std::vector<double> X;   // [scalar column][g2o order]; sized when the general path is taken (11 MB at 450 keyframes: not for the path marginals)
   std::vector<double> rhs_g2o(dim, 0.0), rhs_int, xi(idim);
   if (h->g.opt.solver != 0) {
     // factor the undamped H once, then solve all unit right-hand sides together
@@ -2272,6 +2272,37 @@ static int marginal_blocks(sslam_graph* h, const std::vector<std::pair<int, int>
     SSLAM_HIP_TRY(hipMemcpyAsync(&fail, b.V.pcg_fail, sizeof fail, hipMemcpyDeviceToHost, b.stream));
     SSLAM_HIP_TRY(hipStreamSynchronize(b.stream));
     if (fail) return set_error(SSLAM_ERR_NUMERIC, "H is not positive definite: no marginals");
+    // Diagonal blocks only (what computeLandmarkMarginals asks for, semantic_graph_slam.cpp:188-190): one launch, a forward substitution
+    // along each vertex' path of the elimination tree (k_chol_marginal_paths) -- no right-hand side matrix, no backward solve, and only
+    // the requested blocks cross PCIe.  Off-diagonal pairs (or SSLAM_MARGINAL_PATHS=0) take the multi right-hand-side solves below.
+    static const bool paths_on = [] { const char* e = getenv("SSLAM_MARGINAL_PATHS"); return !(e && atoi(e) == 0); }();
+    bool all_diag = paths_on;
+    for (auto& pr : pairs) all_diag = all_diag && pr.first == pr.second;
+    if (all_diag) {
+      std::vector<int> xoffs, dims, slot(pairs.size(), -1);
+      for (size_t k = 0; k < pairs.size(); ++k) {
+        const int v = pairs[k].first;
+        if (hidx[v] < 0) continue;
+        int xo;
+        if (h->g.vtype[v] == VT_SE3) xo = 6 * b.pose_row[b.v2pose[0][v]];
+        else xo = 6 * b.V.nPr + 3 * b.lm_row[b.v2lm[0][v]];
+        slot[k] = (int)xoffs.size();
+        xoffs.push_back(xo); dims.push_back(vertex_dim(h->g.vtype[v]));
+      }
+      std::vector<double> Z(xoffs.size() * 36 + 1);
+      rc = chol_marginal_diag(b, xoffs, dims, Z.data());
+      if (rc == 0) {
+        size_t o = 0;
+        for (size_t k = 0; k < pairs.size(); ++k) {
+          const int d = vertex_dim(h->g.vtype[pairs[k].first]);
+          for (int e = 0; e < d * d; ++e) out[o + e] = slot[k] < 0 ? 0.0 : Z[(size_t)slot[k] * 36 + e];
+          o += (size_t)d * d;
+        }
+        return 0;
+      }
+      if (rc != SSLAM_ERR_UNSUPPORTED) return rc;   // a path longer than one wave's LDS holds: the general path below
+    }
+    X.resize((size_t)nrhs * dim);
     std::vector<double> R((size_t)nrhs * idim, 0.0), Xi((size_t)nrhs * idim);
     for (int v : colv)
       for (int c = 0; c < vertex_dim(h->g.vtype[v]); ++c) {
@@ -2286,6 +2317,7 @@ static int marginal_blocks(sslam_graph* h, const std::vector<std::pair<int, int>
       to_g2o_order(h, xi, X.data() + (size_t)q * dim);
     }
   } else {
+    X.resize((size_t)nrhs * dim);
     for (int v : colv)
       for (int c = 0; c < vertex_dim(h->g.vtype[v]); ++c) {
         rhs_g2o[hidx[v] + c] = 1.0;
