@@ -105,7 +105,10 @@ int sslam_graph_hessian_index(sslam_graph* g, int id);
  * BASELINE.json north_star), 3 = sparse block Cholesky with the window plan (csrc/wchol_plan.hpp: register-resident sliding fronts;
  * correct, leaner in traffic, slower than 1 on today's kernels); "pcg_tol" relative residual; "pcg_max_iters";
  * "robust_kernel_dcs" = phi > 0: g2o::RobustKernelDCS(delta = phi) on every landmark edge (EdgeSE3PointXYZ / EdgeSE3Plane), as
- * graph_slam.cpp:155,161 intends (opt-in, phi = 1 is g2o's default delta); 0 = no kernel (default). */
+ * graph_slam.cpp:155,161 intends (opt-in, phi = 1 is g2o's default delta); 0 = no kernel (default);
+ * "fused_small_graph" 1 (default) / 0: a graph of at most ~1200 vertices runs every damping trial of an LM iteration in one launch
+ * (k_lm_trial_small; the reference's per-tick call pattern, semantic_graph_slam.cpp:58-102) -- results are bitwise those of the
+ * stand-alone kernels. */
 int sslam_graph_set_option(sslam_graph* g, const char* key, double value);
 
 /* GraphSLAM::optimize (graph_slam.cpp:182-219) with the iteration cap as a parameter (the

@@ -130,10 +130,13 @@ struct CholOpts {
   int group_blocks = 1024; //      workgroup factors side by side: the per-level latencies and barriers are shared by all members
   int ustage = -1;         // 1: the per-depth kernels stage the update-matrix records in LDS too (one round trip for all tables: shorter
                            //    piece latency, fewer pieces per CU); -1: 1 for batches < 32 (latency-bound), else 0 (residency-bound)
+  int small_cols = 1200;   // a graph with at most this many block columns is walked by ONE workgroup from the leaves to the root (every piece a tail
+                           // piece, no per-depth launches): the form the fused LM kernel (k_lm_trial_small) needs; 0: never
   int order = 1;           // 0: minimum degree, lowest index first (rounds 1-3: eliminates a pose chain from one end -> a tree as deep as the chain);
                            // 1: multiple minimum degree over independent sets (below): a chain halves per round -> O(log n) levels
-  double order_mul = 2.0;  // a round eliminates an independent set of the nodes with degree <= order_mul * (minimum degree) + order_add
-  int order_add = 4;
+  double order_mul = -1;   // a round eliminates an independent set of the nodes with degree <= order_mul * (minimum degree) + order_add;
+  int order_add = -1;      // -1: (2.0, 4) for batches < 32 (shallowest tree: latency), (1.5, 2) for larger ones (less fill and smaller update
+                           // matrices, five levels more: throughput -- measured 10.7 vs 11.2 ms per 512 factorisations)
   bool dump = false;
   static int env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
   void from_env() {
@@ -144,6 +147,7 @@ struct CholOpts {
     pcap_leaf = env_int("SSLAM_CHOL_PCAP_LEAF", pcap_leaf); pcap_tail = env_int("SSLAM_CHOL_PCAP_TAIL", pcap_tail);
     group_cap = env_int("SSLAM_CHOL_GROUP_CAP", group_cap); group_blocks = env_int("SSLAM_CHOL_GROUP_BLOCKS", group_blocks);
     ustage = env_int("SSLAM_CHOL_USTAGE", ustage);
+    small_cols = env_int("SSLAM_CHOL_SMALL_COLS", small_cols);
     if (const char* e = getenv("SSLAM_CHOL_ORDER")) order = (!strcmp(e, "mindeg") || !strcmp(e, "0")) ? 0 : 1;
     if (const char* e = getenv("SSLAM_CHOL_ORDER_SLACK")) { double m = 0; int a = 0; if (sscanf(e, "%lf,%d", &m, &a) == 2 && m >= 1.0 && a >= 0) { order_mul = m; order_add = a; } }
     dump = getenv("SSLAM_CHOL_DUMP") != nullptr;
@@ -318,6 +322,7 @@ inline int chol_symbolic(const SymIn& in, CholOpts opt, CholHost& out) {
   const int nPr = in.nPr, nLr = in.nLr, nrow = nPr + nLr, B = in.B;
   if (opt.tail_width < 0) opt.tail_width = B >= 32 ? 6 : 2;
   if (opt.ustage < 0) opt.ustage = B >= 32 ? 0 : 1;
+  if (opt.order_mul < 0 || opt.order_add < 0) { opt.order_mul = B >= 32 ? 1.5 : 2.0; opt.order_add = B >= 32 ? 2 : 4; }
   out = CholHost();
   out.B = B; out.nt_leaf = opt.nt_leaf; out.nt_tail = opt.nt_tail; out.ustage = opt.ustage;
   auto row_dim = [&](int r) { return r < nPr ? 6 : 3; };
@@ -387,6 +392,7 @@ inline int chol_symbolic(const SymIn& in, CholOpts opt, CholHost& out) {
     for (int p = 0; p < np1; ++p) cnt[plev[p]]++;
     int T = nlev1;
     if (opt.tail_width > 0) while (T > 0 && cnt[T - 1] <= opt.tail_width) --T;
+    if (n <= opt.small_cols) T = 0;   // small graph: its whole tree belongs to the tail
     // pass 2: the tail columns are cut again with the tail cap (fewer external-update phases on the chain)
     std::vector<int> fixed(n, -1);
     bool any_tail = false;

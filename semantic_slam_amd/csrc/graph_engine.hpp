@@ -228,6 +228,8 @@ int chol_set_active(Batch& b, const std::vector<char>* active);   // LM endgame:
 int64_t chol_plan_lnz(const Batch& b);
 int chol_plan_levels(const Batch& b);
 int chol_solve_multi(Batch& b, const double* rhs_host, int nrhs, double* x_host);  // uses the last factorisation
+bool chol_plan_tail_only(const Batch& b);   // every piece of every graph is walked by the tail kernels (small graphs)
+int chol_lm_trial_fused(Batch& b, int max_iters);   // one LM iteration (all its damping trials) per graph in one launch, after the linearisation
 int chol_marginal_diag(Batch& b, const std::vector<int>& xoff, const std::vector<int>& dims, double* out36);  // diagonal blocks of H^-1 along the tree paths, one launch
 
 // window multifrontal block Cholesky (sslam_wchol.hip; symbolic phase in wchol_plan.hpp): the solver of the LM loop

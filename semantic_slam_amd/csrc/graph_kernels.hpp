@@ -163,4 +163,159 @@ __device__ __forceinline__ void load_sym3(const double* w, int n, int e, double 
     for (int c = r; c < 3; ++c) { const double v = w[(size_t)k * n + e]; W[r * 3 + c] = v; W[c * 3 + r] = v; ++k; }
 }
 
+// ---- scalar-row helpers -------------------------------------------------------------------------
+struct RowRef {
+  int valid;  // inside the graph's range
+  int is_pose;
+  int row;    // pose row or landmark row (global)
+  int r;      // component inside the block
+  int xoff;   // offset in the unknown vector
+  int base;   // xoff of component 0
+};
+__device__ __forceinline__ RowRef row_ref(const BatchView& V, const GraphSeg& sg, int e) {
+  RowRef R;
+  const int npd = sg.nprow * 6;
+  R.valid = e < npd + sg.nlrow * 3;
+  if (e < npd) {
+    R.is_pose = 1; R.row = sg.prow0 + e / 6; R.r = e % 6; R.base = 6 * R.row;
+  } else {
+    const int u = e - npd;
+    R.is_pose = 0; R.row = sg.lrow0 + u / 3; R.r = u % 3; R.base = 6 * V.nPr + 3 * R.row;
+  }
+  R.xoff = R.base + R.r;
+  return R;
+}
+
+__device__ __forceinline__ int row_chunks(const GraphSeg& sg) { return (sg.nprow * 6 + sg.nlrow * 3 + kRowChunk - 1) / kRowChunk; }
+__device__ __forceinline__ int edge_chunks(const GraphSeg& sg) { return (sg.neo + sg.nel + sg.nell + kEdgeChunk - 1) / kEdgeChunk; }
+
+
+// x [+] dx of one block row t (pose rows first, then landmark rows) of a graph that is in a trial -> the trial estimates
+// (VertexSE3 / VertexPointXYZ / VertexPlane::oplus)
+__device__ __forceinline__ void oplus_row(const BatchView& V, int t, const double* __restrict__ dx) {
+  if (t < V.nPr) {
+    const int g = V.prow_graph[t];
+    if (!V.lm[g].in_trial) return;
+    const int pi = V.prow_pose[t];
+    double d[6];
+    for (int k = 0; k < 6; ++k) d[k] = dx[6 * (size_t)t + k];
+    store_pose(V.pose_trial, pi, se3_oplus(load_pose(V.pose, pi), d));
+  } else if (t < V.nPr + V.nLr) {
+    const int l = t - V.nPr;
+    const int g = V.lrow_graph[l];
+    if (!V.lm[g].in_trial) return;
+    const int li = V.lrow_lm[l];
+    const double* d = dx + 6 * (size_t)V.nPr + 3 * (size_t)l;
+    const double* c = V.lmk + (size_t)li * 4;
+    double* o = V.lmk_trial + (size_t)li * 4;
+    if (V.lm_kind[li] == VT_POINT) {
+      o[0] = c[0] + d[0]; o[1] = c[1] + d[1]; o[2] = c[2] + d[2]; o[3] = 0;
+    } else {
+      const double dv[3] = {d[0], d[1], d[2]};
+      const Plane P = pl_oplus(Plane{{c[0], c[1], c[2]}, c[3]}, dv);
+      o[0] = P.n.x; o[1] = P.n.y; o[2] = P.n.z; o[3] = P.d;
+    }
+  }
+}
+
+// an accepted trial becomes the estimate: block row t of its graph
+__device__ __forceinline__ void commit_row(const BatchView& V, int t) {
+  if (t < V.nPr) {
+    const int g = V.prow_graph[t];
+    if (!V.lm[g].accept) return;
+    const int pi = V.prow_pose[t];
+    for (int k = 0; k < 7; ++k) V.pose[(size_t)pi * 8 + k] = V.pose_trial[(size_t)pi * 8 + k];
+  } else if (t < V.nPr + V.nLr) {
+    const int l = t - V.nPr;
+    const int g = V.lrow_graph[l];
+    if (!V.lm[g].accept) return;
+    const int li = V.lrow_lm[l];
+    for (int k = 0; k < 4; ++k) V.lmk[(size_t)li * 4 + k] = V.lmk_trial[(size_t)li * 4 + k];
+  }
+}
+
+// g2o OptimizationAlgorithmLevenberg: accept / reject one damping trial of a graph; one thread
+__device__ __forceinline__ void lm_control_apply(LmState& S, double tchi, double sc, int solve_failed, int max_iters) {
+  double tmp = tchi;
+  double scale = sc + 1e-3;
+  if (solve_failed) { tmp = INFINITY; scale = 1.0; S.solve_failed += 1; }
+  const double rho = (S.cur_chi - tmp) / scale;
+  S.tmp_chi = tmp; S.scale = scale; S.rho = rho; S.trials += 1;
+  if (rho > 0 && isfinite(tmp)) {
+    double a = 2 * rho - 1;
+    double alpha = 1.0 - a * a * a;
+    alpha = fmin(alpha, 2.0 / 3.0);
+    const double sf = fmax(1.0 / 3.0, alpha);
+    S.lambda *= sf; S.nu = 2; S.cur_chi = tmp; S.accept = 1;
+  } else {
+    S.lambda *= S.nu; S.nu *= 2; S.accept = 0;
+  }
+  S.q += 1;
+  const int again = (rho < 0 && S.q < 10);
+  S.in_trial = again;   // a rejected trial is repeated at the next step with the raised lambda
+  if (!again) {
+    S.iter += 1;
+    if (S.q == 10 || rho == 0) { S.status = 1; S.active = 0; }
+    else if (S.iter >= max_iters) { S.status = 0; S.active = 0; }
+    else S.lin = 1;     // next step: new linearisation, new iteration
+  }
+}
+
+// chi2 term of the graph-local edge e of graph segment sg (SE3 edges, then landmark edges, then point-point edges; 0 beyond the last):
+// g2o computeActiveErrors + the robust kernel's rho[0]
+__device__ __forceinline__ double edge_chi2(const BatchView& V, const GraphSeg& sg, int e, const double* __restrict__ pose, const double* __restrict__ lmk) {
+  double c = 0;
+  if (e < sg.neo) {
+    const int k = sg.eo0 + e;
+    const Pose Xi = load_pose(pose, V.eo_i[k]), Xj = load_pose(pose, V.eo_j[k]);
+    const int n = V.nEo;
+    const Pose Z{{V.eo_z[0 * (size_t)n + k], V.eo_z[1 * (size_t)n + k], V.eo_z[2 * (size_t)n + k]},
+                 {V.eo_z[3 * (size_t)n + k], V.eo_z[4 * (size_t)n + k], V.eo_z[5 * (size_t)n + k], V.eo_z[6 * (size_t)n + k]}};
+    Se3Lin L;
+    se3_error(Xi, Xj, Z, L);
+    double W[36];
+    load_sym6(V.eo_w, n, k, W);
+    for (int r = 0; r < 6; ++r) {
+      double a = 0;
+      for (int s = 0; s < 6; ++s) a += W[r * 6 + s] * L.e[s];
+      c += L.e[r] * a;
+    }
+  } else if (e < sg.neo + sg.nel) {
+    const int k = sg.el0 + (e - sg.neo);
+    const int n = V.nEl;
+    const int li = V.el_l[k];
+    const Pose Xi = load_pose(pose, V.el_p[k]);
+    const double* lp = lmk + (size_t)li * 4;
+    double err[3];
+    if (V.lm_kind[li] == VT_POINT) {
+      PointLin L;
+      point_error(Xi, Vec3{lp[0], lp[1], lp[2]},
+                  Vec3{V.el_z[0 * (size_t)n + k], V.el_z[1 * (size_t)n + k], V.el_z[2 * (size_t)n + k]}, L);
+      err[0] = L.e[0]; err[1] = L.e[1]; err[2] = L.e[2];
+    } else {
+      plane_error(Xi, Plane{{lp[0], lp[1], lp[2]}, lp[3]},
+                  Plane{{V.el_z[0 * (size_t)n + k], V.el_z[1 * (size_t)n + k], V.el_z[2 * (size_t)n + k]}, V.el_z[3 * (size_t)n + k]}, err);
+    }
+    double W[9];
+    load_sym3(V.el_w, n, k, W);
+    for (int r = 0; r < 3; ++r) {
+      double a = 0;
+      for (int s = 0; s < 3; ++s) a += W[r * 3 + s] * err[s];
+      c += err[r] * a;
+    }
+    if (V.dcs_phi > 0) c *= dcs_rho1(V.dcs_phi, c);
+  } else if (e < sg.neo + sg.nel + sg.nell) {   // g2o::EdgePointXYZ: e = (p_b - p_a) - z
+    const int k = sg.ell0 + (e - sg.neo - sg.nel);
+    const size_t n = V.nEll;
+    const double* pa = lmk + (size_t)V.ell_a[k] * 4;
+    const double* pb = lmk + (size_t)V.ell_b[k] * 4;
+    double err[3], W[9];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) err[r] = (pb[r] - pa[r]) - V.ell_z[r * n + k];
+    load_sym3(V.ell_w, (int)n, k, W);
+    c = quad3(W, err);
+  }
+  return c;
+}
+
 }  // namespace sslam

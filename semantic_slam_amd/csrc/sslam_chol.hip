@@ -1034,6 +1034,126 @@ __global__ __launch_bounds__(64) void k_chol_marginal_paths(CholView C, const in
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// One LM iteration of a SMALL graph after its linearisation, in ONE launch (the orchestrator's tick re-optimises a
+// graph of a few hundred vertices 25-40 trials per tick, and ~65 launches per trial made the MI355X slower than one host core).
+// One workgroup per graph whose whole elimination tree is walked by the tail kernels (plans with no per-depth launches):
+//   begin step (lambda = tau max diag on the first) -> factor (the tail pieces, chol_piece) -> backward substitution -> x [+] dx ->
+//   chi2 of the trial -> gain ratio, accept / reject (lm_control_apply) -> commit,
+// and, while the trial is rejected, again with the raised lambda -- until the graph needs a new linearisation (the host launches the
+// Jacobian kernels and this kernel once per LM iteration) or terminates.  Every sum runs over the same chunks in the same order as the
+// stand-alone kernels (k_chi2 / k_scale / k_lm_control): results are bitwise those of the unfused path
+// (tests/test_graph_gpu.py::test_fused_small_graph_trials_equal_the_unfused_path).
+// ------------------------------------------------------------------------------------------------
+template <int BS, int NT>
+__device__ __forceinline__ void vblock_store_sum(double v, double* red, double* dst, bool live) {   // block_sum<BS> of every BS-thread slice of the workgroup
+  const int tid = threadIdx.x;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  if ((tid & 63) == 0) red[tid >> 6] = v;
+  __syncthreads();
+  if (live && tid % BS == 0) {
+    double s = 0;
+    for (int k = 0; k < BS / 64; ++k) s += red[(tid >> 6) + k];
+    *dst = s;
+  }
+  __syncthreads();
+}
+
+template <int NT>
+__global__ __launch_bounds__(NT) void k_lm_trial_small(BatchView V, CholView C, double* __restrict__ part_e, int max_iters) {
+  extern __shared__ double sm[];
+  __shared__ double red[NT / 64];
+  const int g = blockIdx.x, tid = threadIdx.x;
+  LmState& S = V.lm[g];
+  if (!S.active) return;
+  const GraphSeg sg = V.seg[g];
+  const int nrows = sg.nprow * 6 + sg.nlrow * 3;
+  const int nec = edge_chunks(sg), nrc = row_chunks(sg);
+  const int q0 = C.tail_ptr[g], q1 = C.tail_ptr[g + 1];
+  // ---- begin step (k_maxdiag + k_lm_begin_step)
+  const int lin = S.lin;
+  if (lin && S.iter == 0) {
+    double d = 0;
+    for (int e = tid; e < nrows; e += NT) {
+      const RowRef R = row_ref(V, sg, e);
+      d = fmax(d, fabs(R.is_pose ? V.Hpp_diag[(size_t)R.row * 36 + R.r * 7] : V.Hll_diag[(size_t)R.row * 9 + R.r * 4]));
+    }
+    const double m = block_max<NT>(d, red);
+    if (tid == 0) { S.max_diag = m; S.lambda = 1e-5 * m; S.nu = 2.0; }
+  }
+  if (tid == 0) {
+    if (lin) { S.q = 0; S.rho = 0; S.in_trial = 1; S.lin = 0; }
+    S.accept = 0;
+  }
+  __threadfence_block();
+  __syncthreads();
+  for (;;) {
+    if (!S.in_trial) return;
+    // ---- (H + lambda I) = L L^T, y = L^-1 b: the pieces of the graph's tree in elimination order
+    if (tid == 0) C.fail[g] = 0;
+    __syncthreads();
+    for (int q = q0; q < q1; ++q) {
+      if (C.rupd) chol_piece<NT, false, true>(V, C, C.lpiece[C.ltail0 + q], sm, nullptr);
+      else chol_piece<NT, false, false>(V, C, C.lpiece[C.ltail0 + q], sm, nullptr);
+      __threadfence_block();
+      __syncthreads();
+    }
+    if (tid == 0) V.pcg_fail[g] = C.fail[g];
+    // ---- x = L^-T y
+    for (int q = q1 - 1; q >= q0; --q) {
+      chol_piece_backward<NT>(C, C.lpiece[C.ltail0 + q], C.y, V.x, sm, nullptr);
+      __threadfence_block();
+      __syncthreads();
+    }
+    // ---- trial estimates
+    for (int i = tid; i < sg.nprow + sg.nlrow; i += NT) oplus_row(V, i < sg.nprow ? sg.prow0 + i : V.nPr + sg.lrow0 + (i - sg.nprow), V.x);
+    __threadfence_block();
+    __syncthreads();
+    // ---- chi2 of the trial: the chunks of k_chi2
+    for (int c0 = 0; c0 < nec; c0 += NT / kEdgeChunk) {
+      const int chunk = c0 + tid / kEdgeChunk;
+      const double c = chunk < nec ? edge_chi2(V, sg, chunk * kEdgeChunk + tid % kEdgeChunk, V.pose_trial, V.lmk_trial) : 0.0;
+      vblock_store_sum<kEdgeChunk, NT>(c, red, part_e + (size_t)g * V.maxEdgeChunks + chunk, chunk < nec);
+    }
+    // ---- dx . (lambda dx + b): the chunks of k_scale
+    {
+      const double lambda = S.lambda;
+      constexpr int NV = NT / kRowChunk;
+      for (int c0 = 0; c0 < nrc; c0 += NV) {
+        const int vb = tid / kRowChunk, chunk = c0 + vb;
+        const bool live = vb < NV && chunk < nrc;
+        double v = 0;
+        if (live) {
+          const RowRef R = row_ref(V, sg, chunk * kRowChunk + tid % kRowChunk);
+          if (R.valid) { const double d = V.x[R.xoff]; v = d * (lambda * d + V.bvec[R.xoff]); }
+        }
+        vblock_store_sum<kRowChunk, NT>(v, red, V.part_a + (size_t)g * V.maxRowChunks + chunk, live);
+      }
+    }
+    __threadfence_block();
+    __syncthreads();
+    // ---- accept / reject (k_lm_control)
+    if (tid < 64) {
+      const double tchi = wave_sum_partials(part_e + (size_t)g * V.maxEdgeChunks, nec);
+      const double sc = wave_sum_partials(V.part_a + (size_t)g * V.maxRowChunks, nrc);
+      if (tid == 0) lm_control_apply(S, tchi, sc, V.pcg_fail[g], max_iters);
+    }
+    __threadfence_block();
+    __syncthreads();
+    // ---- commit (k_commit)
+    if (S.accept) {
+      for (int i = tid; i < sg.nprow + sg.nlrow; i += NT) commit_row(V, i < sg.nprow ? sg.prow0 + i : V.nPr + sg.lrow0 + (i - sg.nprow));
+      __threadfence_block();
+    }
+    __syncthreads();
+    if (!S.active || S.lin) return;   // finished, or the next iteration needs a new linearisation: back to the host's launch sequence
+    if (tid == 0) S.accept = 0;       // a rejected trial: once more with the raised lambda (what k_lm_begin_step does for a retry)
+    __threadfence_block();
+    __syncthreads();
+  }
+}
+
 __global__ void k_chol_begin(BatchView V, CholView C) {  // clear failure flags of the graphs being solved
   const int g = blockIdx.x * blockDim.x + threadIdx.x;
   if (g < V.B && V.lm[g].in_trial) C.fail[g] = 0;
@@ -1192,7 +1312,8 @@ int chol_plan_build(Batch& b) {
                            (const void*)k_chol_pieces<512, false>, (const void*)k_chol_pieces<1024, false>,
                            (const void*)k_chol_tail<512>, (const void*)k_chol_tail<1024>,
                            (const void*)k_chol_back_pieces<64>, (const void*)k_chol_back_pieces<128>, (const void*)k_chol_back_pieces<256>,
-                           (const void*)k_chol_back_pieces<512>, (const void*)k_chol_back_pieces<1024>, (const void*)k_chol_back_tail<512>};
+                           (const void*)k_chol_back_pieces<512>, (const void*)k_chol_back_pieces<1024>, (const void*)k_chol_back_tail<512>,
+                           (const void*)k_lm_trial_small<512>, (const void*)k_lm_trial_small<1024>};
       for (const void* f : fns) SSLAM_HIP_TRY(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, v));
       done.push_back(b.device);
     }
@@ -1340,6 +1461,19 @@ int chol_solve_multi(Batch& b, const double* rhs_host, int nrhs, double* x_host)
     SSLAM_HIP_TRY(hipMemcpyAsync(x_host + (size_t)r0 * C.dim, P.d_multi_x, bytes, hipMemcpyDeviceToHost, b.stream));
     SSLAM_HIP_TRY(hipStreamSynchronize(b.stream));
   }
+  return 0;
+}
+
+// ---- fused LM iterations of small graphs (k_lm_trial_small): plans whose every piece is a tail piece
+bool chol_plan_tail_only(const Batch& b) { return b.chol && b.chol->plv_lds_f.empty() && b.chol->tail_total > 0; }
+int chol_lm_trial_fused(Batch& b, int max_iters) {
+  CholPlan& P = *b.chol;
+  P.C.flat_L = 0;
+  const size_t lds = (size_t)std::max(P.tail_lds_f, P.tail_lds_b) * sizeof(double);
+  if (P.nt_tail == 1024) hipLaunchKernelGGL(k_lm_trial_small<1024>, dim3(b.V.B), dim3(1024), lds, b.stream, b.V, P.C, b.d_part_e, max_iters);
+  else hipLaunchKernelGGL(k_lm_trial_small<512>, dim3(b.V.B), dim3(512), lds, b.stream, b.V, P.C, b.d_part_e, max_iters);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return set_error(SSLAM_ERR_HIP, "fused LM trial launch: %s", hipGetErrorString(e));
   return 0;
 }
 

@@ -40,57 +40,7 @@ __global__ __launch_bounds__(kEdgeChunk) void k_chi2(BatchView V, const double* 
   const GraphSeg sg = V.seg[g];
   const int e = blockIdx.x * kEdgeChunk + threadIdx.x;
   if (blockIdx.x * kEdgeChunk >= sg.neo + sg.nel + sg.nell) return;
-  double c = 0;
-  if (e < sg.neo) {
-    const int k = sg.eo0 + e;
-    const Pose Xi = load_pose(pose, V.eo_i[k]), Xj = load_pose(pose, V.eo_j[k]);
-    const int n = V.nEo;
-    const Pose Z{{V.eo_z[0 * (size_t)n + k], V.eo_z[1 * (size_t)n + k], V.eo_z[2 * (size_t)n + k]},
-                 {V.eo_z[3 * (size_t)n + k], V.eo_z[4 * (size_t)n + k], V.eo_z[5 * (size_t)n + k], V.eo_z[6 * (size_t)n + k]}};
-    Se3Lin L;
-    se3_error(Xi, Xj, Z, L);
-    double W[36];
-    load_sym6(V.eo_w, n, k, W);
-    for (int r = 0; r < 6; ++r) {
-      double a = 0;
-      for (int s = 0; s < 6; ++s) a += W[r * 6 + s] * L.e[s];
-      c += L.e[r] * a;
-    }
-  } else if (e < sg.neo + sg.nel) {
-    const int k = sg.el0 + (e - sg.neo);
-    const int n = V.nEl;
-    const int li = V.el_l[k];
-    const Pose Xi = load_pose(pose, V.el_p[k]);
-    const double* lp = lmk + (size_t)li * 4;
-    double err[3];
-    if (V.lm_kind[li] == VT_POINT) {
-      PointLin L;
-      point_error(Xi, Vec3{lp[0], lp[1], lp[2]},
-                  Vec3{V.el_z[0 * (size_t)n + k], V.el_z[1 * (size_t)n + k], V.el_z[2 * (size_t)n + k]}, L);
-      err[0] = L.e[0]; err[1] = L.e[1]; err[2] = L.e[2];
-    } else {
-      plane_error(Xi, Plane{{lp[0], lp[1], lp[2]}, lp[3]},
-                  Plane{{V.el_z[0 * (size_t)n + k], V.el_z[1 * (size_t)n + k], V.el_z[2 * (size_t)n + k]}, V.el_z[3 * (size_t)n + k]}, err);
-    }
-    double W[9];
-    load_sym3(V.el_w, n, k, W);
-    for (int r = 0; r < 3; ++r) {
-      double a = 0;
-      for (int s = 0; s < 3; ++s) a += W[r * 3 + s] * err[s];
-      c += err[r] * a;
-    }
-    if (V.dcs_phi > 0) c *= dcs_rho1(V.dcs_phi, c);
-  } else if (e < sg.neo + sg.nel + sg.nell) {   // g2o::EdgePointXYZ: e = (p_b - p_a) - z
-    const int k = sg.ell0 + (e - sg.neo - sg.nel);
-    const size_t n = V.nEll;
-    const double* pa = lmk + (size_t)V.ell_a[k] * 4;
-    const double* pb = lmk + (size_t)V.ell_b[k] * 4;
-    double err[3], W[9];
-#pragma unroll
-    for (int r = 0; r < 3; ++r) err[r] = (pb[r] - pa[r]) - V.ell_z[r * n + k];
-    load_sym3(V.ell_w, (int)n, k, W);
-    c = quad3(W, err);
-  }
+  const double c = edge_chi2(V, sg, e, pose, lmk);
   const double s = block_sum<kEdgeChunk>(c, red);
   if (threadIdx.x == 0) part[(size_t)g * V.maxEdgeChunks + blockIdx.x] = s;
 }
@@ -847,29 +797,6 @@ __global__ void k_linearize_dups(BatchView V) {
   }
 }
 
-// ---- scalar-row helpers -------------------------------------------------------------------------
-struct RowRef {
-  int valid;  // inside the graph's range
-  int is_pose;
-  int row;    // pose row or landmark row (global)
-  int r;      // component inside the block
-  int xoff;   // offset in the unknown vector
-  int base;   // xoff of component 0
-};
-__device__ __forceinline__ RowRef row_ref(const BatchView& V, const GraphSeg& sg, int e) {
-  RowRef R;
-  const int npd = sg.nprow * 6;
-  R.valid = e < npd + sg.nlrow * 3;
-  if (e < npd) {
-    R.is_pose = 1; R.row = sg.prow0 + e / 6; R.r = e % 6; R.base = 6 * R.row;
-  } else {
-    const int u = e - npd;
-    R.is_pose = 0; R.row = sg.lrow0 + u / 3; R.r = u % 3; R.base = 6 * V.nPr + 3 * R.row;
-  }
-  R.xoff = R.base + R.r;
-  return R;
-}
-
 // max diagonal entry per graph (lambda init = tau * max diag)
 __global__ __launch_bounds__(kRowChunk) void k_maxdiag(BatchView V, double* __restrict__ part) {
   __shared__ double red[kRowChunk / 64];
@@ -883,9 +810,6 @@ __global__ __launch_bounds__(kRowChunk) void k_maxdiag(BatchView V, double* __re
   const double m = block_max<kRowChunk>(d, red);
   if (threadIdx.x == 0) part[(size_t)g * V.maxRowChunks + blockIdx.x] = m;
 }
-
-__device__ __forceinline__ int row_chunks(const GraphSeg& sg) { return (sg.nprow * 6 + sg.nlrow * 3 + kRowChunk - 1) / kRowChunk; }
-__device__ __forceinline__ int edge_chunks(const GraphSeg& sg) { return (sg.neo + sg.nel + sg.nell + kEdgeChunk - 1) / kEdgeChunk; }
 
 // One wave per graph, once per step.  A *step* is one damping trial: graphs flagged `lin` have just been re-linearised and
 // start a new LM iteration (q = 0; lambda = tau * max diag on the very first one), the others are retrying the
@@ -1222,32 +1146,7 @@ __global__ void k_pcg_alldone(BatchView V, int parity) {
 }
 
 // trial estimate = current [+] dx  (VertexSE3 / VertexPointXYZ / VertexPlane oplus)
-__global__ __launch_bounds__(256) void k_oplus(BatchView V, const double* __restrict__ dx) {
-  const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t < V.nPr) {
-    const int g = V.prow_graph[t];
-    if (!V.lm[g].in_trial) return;
-    const int pi = V.prow_pose[t];
-    double d[6];
-    for (int k = 0; k < 6; ++k) d[k] = dx[6 * (size_t)t + k];
-    store_pose(V.pose_trial, pi, se3_oplus(load_pose(V.pose, pi), d));
-  } else if (t < V.nPr + V.nLr) {
-    const int l = t - V.nPr;
-    const int g = V.lrow_graph[l];
-    if (!V.lm[g].in_trial) return;
-    const int li = V.lrow_lm[l];
-    const double* d = dx + 6 * (size_t)V.nPr + 3 * (size_t)l;
-    const double* c = V.lmk + (size_t)li * 4;
-    double* o = V.lmk_trial + (size_t)li * 4;
-    if (V.lm_kind[li] == VT_POINT) {
-      o[0] = c[0] + d[0]; o[1] = c[1] + d[1]; o[2] = c[2] + d[2]; o[3] = 0;
-    } else {
-      const double dv[3] = {d[0], d[1], d[2]};
-      const Plane P = pl_oplus(Plane{{c[0], c[1], c[2]}, c[3]}, dv);
-      o[0] = P.n.x; o[1] = P.n.y; o[2] = P.n.z; o[3] = P.d;
-    }
-  }
-}
+__global__ __launch_bounds__(256) void k_oplus(BatchView V, const double* __restrict__ dx) { oplus_row(V, blockIdx.x * blockDim.x + threadIdx.x, dx); }
 
 // partial sums of dx . (lambda dx + b)   (denominator of the LM gain ratio)
 __global__ __launch_bounds__(kRowChunk) void k_scale(BatchView V, const double* __restrict__ dx) {
@@ -1271,46 +1170,10 @@ __global__ void k_lm_control(BatchView V, const double* __restrict__ part_chi, i
   const double tchi = wave_sum_partials(part_chi + (size_t)g * V.maxEdgeChunks, edge_chunks(V.seg[g]));
   const double sc = wave_sum_partials(V.part_a + (size_t)g * V.maxRowChunks, row_chunks(V.seg[g]));
   if (threadIdx.x != 0) return;
-  double tmp = tchi;
-  double scale = sc + 1e-3;
-  if (V.pcg_fail[g]) { tmp = INFINITY; scale = 1.0; S.solve_failed += 1; }
-  const double rho = (S.cur_chi - tmp) / scale;
-  S.tmp_chi = tmp; S.scale = scale; S.rho = rho; S.trials += 1;
-  if (rho > 0 && isfinite(tmp)) {
-    double a = 2 * rho - 1;
-    double alpha = 1.0 - a * a * a;
-    alpha = fmin(alpha, 2.0 / 3.0);
-    const double sf = fmax(1.0 / 3.0, alpha);
-    S.lambda *= sf; S.nu = 2; S.cur_chi = tmp; S.accept = 1;
-  } else {
-    S.lambda *= S.nu; S.nu *= 2; S.accept = 0;
-  }
-  S.q += 1;
-  const int again = (rho < 0 && S.q < 10);
-  S.in_trial = again;   // a rejected trial is repeated at the next step with the raised lambda
-  if (!again) {
-    S.iter += 1;
-    if (S.q == 10 || rho == 0) { S.status = 1; S.active = 0; }
-    else if (S.iter >= max_iters) { S.status = 0; S.active = 0; }
-    else S.lin = 1;     // next step: new linearisation, new iteration
-  }
+  lm_control_apply(S, tchi, sc, V.pcg_fail[g], max_iters);
 }
 
-__global__ __launch_bounds__(256) void k_commit(BatchView V) {
-  const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t < V.nPr) {
-    const int g = V.prow_graph[t];
-    if (!V.lm[g].accept) return;
-    const int pi = V.prow_pose[t];
-    for (int k = 0; k < 7; ++k) V.pose[(size_t)pi * 8 + k] = V.pose_trial[(size_t)pi * 8 + k];
-  } else if (t < V.nPr + V.nLr) {
-    const int l = t - V.nPr;
-    const int g = V.lrow_graph[l];
-    if (!V.lm[g].accept) return;
-    const int li = V.lrow_lm[l];
-    for (int k = 0; k < 4; ++k) V.lmk[(size_t)li * 4 + k] = V.lmk_trial[(size_t)li * 4 + k];
-  }
-}
+__global__ __launch_bounds__(256) void k_commit(BatchView V) { commit_row(V, blockIdx.x * blockDim.x + threadIdx.x); }
 __global__ void k_set_trial_all(BatchView V, double lambda) {  // used by the solve() hook
   const int g = blockIdx.x * blockDim.x + threadIdx.x;
   if (g < V.B) { V.lm[g].in_trial = 1; V.lm[g].lambda = lambda; V.lm[g].active = 1; }
@@ -1836,6 +1699,17 @@ static int batch_optimize(Batch& b, int max_iters, sslam_opt_stats* out) {
   // The LM control flow (accept / reject, retry with a larger lambda, terminate) lives on the device: the host enqueues
   // generic steps in chunks and only looks at the per-graph state between chunks -- no synchronisation per trial.
   // Every graph needs at least (max_iters - iter) more steps; rejected trials add steps, which later chunks supply.
+  // Small graphs (plans that are all tail, chol_plan.hpp small_cols): one launch per LM ITERATION after the Jacobian kernels -- every
+  // damping trial of the iteration, factor to commit, inside k_lm_trial_small (sslam_chol.hip); SSLAM_FUSED=0: the stand-alone kernels
+  bool fused = false;
+  {
+    static const bool fused_on = [] { const char* e = getenv("SSLAM_FUSED"); return !(e && atoi(e) == 0); }();
+    static const bool wenv = [] { const char* e = getenv("SSLAM_WCHOL"); return e && atoi(e) != 0; }();
+    if (fused_on && b.graphs[0]->opt.fused && !wenv && b.graphs[0]->opt.solver == 1 && !b.sharded && !b.profiling) {
+      if (!b.chol && (rc = chol_plan_build(b))) return rc;
+      fused = chol_plan_tail_only(b);
+    }
+  }
   long long budget = 10LL * std::max(max_iters, 0) + 8;    // hard bound: <= 10 trials per iteration
   int need = max_iters;
   if ((rc = chol_set_active(b, nullptr))) return rc;
@@ -1846,6 +1720,7 @@ static int batch_optimize(Batch& b, int max_iters, sslam_opt_stats* out) {
     const int chunk = (int)std::min<long long>(std::min(need, kStepChunk), budget);
     for (int sidx = 0; sidx < chunk; ++sidx) {
       if ((rc = batch_linearize(b))) return rc;
+      if (fused) { if ((rc = chol_lm_trial_fused(b, max_iters))) return rc; continue; }
       hipLaunchKernelGGL(k_maxdiag, row_grid(b), dim3(kRowChunk), 0, b.stream, V, b.d_part_m);
       hipLaunchKernelGGL(k_lm_begin_step, dim3(V.B), dim3(64), 0, b.stream, V, b.d_part_m);
       if ((rc = batch_solve(b))) return rc;
@@ -2078,6 +1953,7 @@ int sslam_graph_set_option(sslam_graph* h, const char* key, double value) {
   const std::string k(key);
   if (k == "solver") { if (value != 0 && value != 1 && value != 2 && value != 3) return set_error(SSLAM_ERR_INVALID, "solver: 0 block-Jacobi PCG, 1 sparse block Cholesky (piece plan), 2 Schur complement on the landmarks + PCG, 3 sparse block Cholesky (window plan)"); o.solver = (int)value; }
   else if (k == "robust_kernel_dcs") { if (!(value >= 0)) return set_error(SSLAM_ERR_INVALID, "robust_kernel_dcs: phi >= 0 (0 = no kernel)"); o.dcs_phi = value; if (h->batch) h->batch->V.dcs_phi = value; h->linearized = false; }
+  else if (k == "fused_small_graph") o.fused = value != 0;
   else if (k == "pcg_tol") o.pcg_tol = value;
   else if (k == "pcg_max_iters") o.pcg_max_iters = (int)value;
   else if (k == "deterministic") { if (value == 0) return set_error(SSLAM_ERR_UNSUPPORTED, "the Jacobian build is always deterministic (gather form); the FP64-atomics variant was removed"); }

@@ -146,7 +146,7 @@ def test_plan_small_graph_matches_dense_cholesky(hip_lib, interleave):
 def test_plan_with_tiny_pieces_exercises_every_phase(hip_lib):
     """Caps far below the defaults force many pieces, external phases, split lists (partial tiles) and a multi-piece tail."""
     g = make_graph(150, 30, seed=5)
-    env = {"SSLAM_CHOL_CAP_LEAF": 400, "SSLAM_CHOL_CAP_TAIL": 700, "SSLAM_CHOL_TAIL_WIDTH": 2, "SSLAM_CHOL_MIN_CHUNK": 1, "SSLAM_CHOL_PCAP_LEAF": 16, "SSLAM_CHOL_NT_LEAF": 256}
+    env = {"SSLAM_CHOL_SMALL_COLS": 0, "SSLAM_CHOL_CAP_LEAF": 400, "SSLAM_CHOL_CAP_TAIL": 700, "SSLAM_CHOL_TAIL_WIDTH": 2, "SSLAM_CHOL_MIN_CHUNK": 1, "SSLAM_CHOL_PCAP_LEAF": 16, "SSLAM_CHOL_NT_LEAF": 256}
     plan, H, b = _plan_and_system(hip_lib, g, False, env)
     assert plan.npiece > 20 and len(plan.tail_pieces) >= 2 and len(plan.plv_ptr) > 2
     assert len(plan.mb) > 0 and len(plan.umb) > 0 and np.any(plan.piece["nas"] > 0) and np.any(plan.piece["nus"] > 0)
@@ -163,12 +163,31 @@ def test_plan_with_tiny_pieces_exercises_every_phase(hip_lib):
     _check(plan2, H2, b2, 1e-3)
     # a depth with many pieces is launched in parts, by LDS need (sorted inside the depth; cuts where a CU holds 32 / 24 / 16 workgroups)
     g5 = make_graph(400, 80, seed=2)
-    plan5, H5, b5 = _plan_and_system(hip_lib, g5, False, {"SSLAM_CHOL_TAIL_WIDTH": 2})
-    plan4, H4, b4 = _plan_and_system(hip_lib, g5, False, {"SSLAM_CHOL_TAIL_WIDTH": 2, "SSLAM_CHOL_SPLIT_MIN": 4})
+    plan5, H5, b5 = _plan_and_system(hip_lib, g5, False, {"SSLAM_CHOL_SMALL_COLS": 0, "SSLAM_CHOL_TAIL_WIDTH": 2})
+    plan4, H4, b4 = _plan_and_system(hip_lib, g5, False, {"SSLAM_CHOL_SMALL_COLS": 0, "SSLAM_CHOL_TAIL_WIDTH": 2, "SSLAM_CHOL_SPLIT_MIN": 4})
     assert len(plan4.plv_ptr) > len(plan5.plv_ptr) and plan4.npiece == plan5.npiece
     assert int(plan4.plv_lds_b[0]) < int(plan5.plv_lds_b[0])   # the small pieces of the first depth no longer reserve what its largest needs
     _structure_invariants(plan4)
     _check(plan4, H4, b4, 1e-3)
+
+
+def test_small_graph_plan_is_all_tail_and_both_orderings_factor(hip_lib):
+    """A graph of <= small_cols block columns is walked by one workgroup from the leaves to the root (no per-depth launches: what the fused
+    LM kernel needs); both elimination orders (multiple minimum degree over independent sets, round 4; lowest-index minimum degree) give a
+    valid plan, and the new one a shallower tree."""
+    g = make_graph(150, 30, seed=5)
+    plan, H, b = _plan_and_system(hip_lib, g, False)
+    assert len(plan.plv_pieces) == 0 and len(plan.tail_pieces) == plan.npiece and plan.npiece >= 2
+    _structure_invariants(plan)
+    _check(plan, H, b, 1e-3)
+    g2 = make_graph(600, 120, seed=3)
+    lv = {}
+    for order in ("mmd", "mindeg"):
+        p2, H2, b2 = _plan_and_system(hip_lib, g2, False, {"SSLAM_CHOL_ORDER": order, "SSLAM_CHOL_SMALL_COLS": 0})
+        _structure_invariants(p2)
+        _check(p2, H2, b2, 1e-3)
+        lv[order] = p2.nlevels
+    assert lv["mmd"] < lv["mindeg"]
 
 
 def test_plan_plane_landmarks_and_S_config(hip_lib):

@@ -580,6 +580,61 @@ def test_marginals_match_oracle(gpu_lib):
         assert np.abs(a - r).max() <= 1e-6 * np.abs(r).max()
 
 
+def test_path_marginals_equal_the_multi_rhs_solves(gpu_lib):
+    """Diagonal-only requests take the one-launch path kernel (forward substitution along the elimination-tree path of each vertex,
+    k_chol_marginal_paths); a request that also holds an off-diagonal pair takes the multi right-hand-side solves.  Same blocks, and both
+    equal the dense inverse of the oracle's H -- landmark 3x3 and pose 6x6 blocks."""
+    from semantic_slam_amd import GraphSLAM
+    g = make_graph(60, 12, seed=4)
+    gp = GraphProblem.from_synth(g, interleave=True)
+    G = GraphSLAM.from_problem(gp)
+    G.optimize(5)
+    gp.est[:] = G.estimates()
+    U, _ = gp.linearize()
+    Hinv = np.linalg.inv((U + sp.triu(U, 1).T).toarray())
+    hs = [G.hessian_index(int(v)) for v in gp.lm_ids] + [G.hessian_index(int(gp.pose_ids[k])) for k in (1, 7, 30, 59)]
+    diag = [(h, h) for h in hs]
+    a = G.computeMarginals(diag)
+    b = G.computeMarginals(diag + [(hs[0], hs[1])])
+    for (r, c) in diag:
+        ref = Hinv[r:r + a[(r, c)].shape[0], c:c + a[(r, c)].shape[1]]
+        assert a[(r, c)].shape == b[(r, c)].shape and a[(r, c)].shape[0] in (3, 6)
+        assert np.abs(a[(r, c)] - ref).max() <= 1e-9 * np.abs(Hinv).max()
+        assert np.abs(a[(r, c)] - b[(r, c)]).max() <= 1e-10 * np.abs(Hinv).max()
+
+
+def test_fused_small_graph_trials_equal_the_unfused_path(gpu_lib):
+    """k_lm_trial_small (one launch per LM iteration of a small graph: factor, solve, update, chi2, accept / reject, retries) against the
+    stand-alone kernels: same iterations, same trials, bitwise the same estimates -- single graphs to termination (every damping retry
+    inside the kernel), with planes, and a batch of distinct small graphs; and both equal the oracle."""
+    from semantic_slam_amd import GraphSLAM, GraphBatch
+    for (n, m, kind, iters) in [(120, 24, "point", 40), (80, 16, "plane", 12), (300, 60, "point", 10)]:
+        g = make_graph(n, m, seed=11, landmark_kind=kind)
+        gp = GraphProblem.from_synth(g, interleave=True)
+        res = []
+        for fused in (1, 0):
+            G = GraphSLAM.from_problem(gp)
+            G.set_option("fused_small_graph", fused)
+            assert G.optimize(iters)
+            res.append((G.last_stats.iterations, G.last_stats.trials, G.last_stats.chi2_after, G.estimates().copy()))
+        assert res[0][0] == res[1][0] and res[0][1] == res[1][1], (res[0][:3], res[1][:3])
+        assert res[0][2] == res[1][2] and np.array_equal(res[0][3], res[1][3])
+        st = gp.optimize(iters)
+        assert abs(res[0][2] - st.chi2_after) <= 1e-8 * st.chi2_after
+    gs = [[GraphSLAM.from_synth(make_graph(90 + 7 * k, 18 + k, seed=20 + k)) for k in range(6)] for _ in range(2)]
+    out = []
+    for fused, graphs in zip((1, 0), gs):
+        for G in graphs:
+            G.set_option("fused_small_graph", fused)
+        bt = GraphBatch(graphs); bt.upload()
+        st = bt.optimize(15)
+        bt.download()
+        out.append(([(int(s.iterations), int(s.trials), float(s.chi2_after)) for s in st], [G.estimates().copy() for G in graphs]))
+    assert out[0][0] == out[1][0]
+    for a, b in zip(out[0][1], out[1][1]):
+        assert np.array_equal(a, b)
+
+
 @pytest.mark.parametrize("kind", ["point", "plane"])
 def test_golden_graph_through_g2o_loader(gpu_lib, kind):
     """Committed golden vectors (tests/golden/make_golden.py): .g2o file -> C-ABI loader -> HIP optimise."""

@@ -9,6 +9,7 @@ n1 = max(int(s1[0].iterations), 1)
 f, v = b1.time_solver(5)
 print(json.dumps({"single_graph_iters_per_sec": round(n1 / d1, 1), "ms_per_iter": round(1e3 * d1 / n1, 3), "factor_ms": round(f, 3), "solve_ms": round(v, 3)}))
 t = bench.bench_tick(0, cpu_baseline=False)
-print(json.dumps({k: t[k] for k in ("ms_per_tick", "ms_per_tick_optimize", "lm_iterations_per_tick")}))
+KEYS = ("keyframes", "landmarks", "ms_per_tick", "ms_per_tick_association", "ms_per_tick_optimize", "ms_per_tick_marginals", "lm_iterations_per_tick")
+print(json.dumps({k: t[k] for k in KEYS}))
 t = bench.bench_tick(0, n_samples=2400, cpu_baseline=False, n_landmarks=160)
-print(json.dumps({k: t[k] for k in ("ms_per_tick", "ms_per_tick_optimize", "lm_iterations_per_tick")}))
+print(json.dumps({k: t[k] for k in KEYS}))
