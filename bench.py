@@ -218,6 +218,47 @@ def bench_frontend(device, frames=8, cpu_baseline=True, batch_frames=32, dist=No
                       "planes_per_sec_kernels": round(tot_planes / kern_s, 1), "frames_per_sec_kernels": round(tot_frames / kern_s, 1),
                       "planes_per_sec_incl_pcie_and_host": round(tot_planes / bwall, 1), "kernel_ms_per_frame": round(1e3 * kern_s / (reps * batch_frames), 4),
                       "achieved_GBps": round(gbs, 2), "hbm_frac": round(gbs / PEAK_HBM_GBS, 5), "truncated": list(seg.last_overflow())}
+    # RANSAC plane per box + point-to-plane ICP per frame on the crops that batch left on the device (BASELINE.json configs[3]:
+    # "RANSAC+ICP plane extraction"): one workgroup per box / per frame, 12 bytes per in-box point read once per pass
+    try:
+        rreps, rms, ims, rplanes, rin, rhyp = 3, 0.0, 0.0, 0, 0, 0
+        icp_iters = 5
+        for _ in range(rreps):
+            recs, ms_r = seg.ransac_boxes(0.01, 50, 0.99, 2024)
+            planes_r = np.array([list(r.coeff) for r in recs], np.float32)
+            ok = np.array([r.inliers > 500 and abs(float(np.linalg.norm(planes_r[q, :3])) - 1.0) < 1e-3 for q, r in enumerate(recs)])
+            box_plane = np.where(ok, np.arange(len(recs)), -1).astype(np.int32)     # every box against its own plane: the fixed point of the ICP
+            icp, ms_i = seg.icp_boxes(box_plane, planes_r, icp_iters)
+            rms += ms_r; ims += ms_i; rplanes += int(ok.sum()); rin += int(sum(r.inliers for q, r in enumerate(recs) if ok[q])); rhyp += int(sum(r.hypotheses for r in recs))
+        pts_total = npx * batch_frames                                          # in-box points of a batch
+        rbytes = 12.0 * pts_total * rreps
+        ibytes = 12.0 * rin * (icp_iters + 1)
+        res["ransac_icp"] = {"frames_per_call": batch_frames, "calls": rreps, "ransac_threshold_m": 0.01, "ransac_max_iterations": 50, "icp_iterations": icp_iters,
+                             "planes_per_frame": round(rplanes / (rreps * batch_frames), 2), "hypotheses_per_box": round(rhyp / (rreps * len(recs)), 1),
+                             "ransac_kernel_ms_per_frame": round(rms / (rreps * batch_frames), 4), "icp_kernel_ms_per_frame": round(ims / (rreps * batch_frames), 4),
+                             "planes_per_sec_kernels": round(rplanes / ((rms + ims) * 1e-3), 1),
+                             "ransac_achieved_GBps": round(rbytes / (rms * 1e-3) / 1e9, 2), "ransac_hbm_frac": round(rbytes / (rms * 1e-3) / 1e9 / PEAK_HBM_GBS, 5),
+                             "icp_achieved_GBps": round(ibytes / (ims * 1e-3) / 1e9, 2), "icp_rms_m": round(float(np.mean([r.rms for r in icp])), 5),
+                             "note": "12 B per in-box point, read from HBM once per RANSAC pass (the crop is staged in LDS and all hypotheses are scored there) "
+                                     "and once per ICP round; the crops are those the segmentation left on the device"}
+        if cpu_baseline:
+            import ctypes as C2
+            from oracle import oracle as O
+            olib = O.lib()
+            t3 = time.perf_counter(); nb_cpu = 0
+            while time.perf_counter() - t3 < 3.0:
+                f = fs[nb_cpu // 32 % len(fs)]; b = f.boxes[nb_cpu % 32]
+                crop = np.ascontiguousarray(f.xyz()[b["tl_y"]:b["tl_y"] + b["height"], b["tl_x"]:b["tl_x"] + b["width"]].reshape(-1, 3))
+                coeff = np.zeros(4, np.float32); inl = np.zeros(len(crop), np.int32); bi = C2.c_int(0)
+                olib.os_ransac_plane(crop.ctypes.data_as(C2.c_void_p), len(crop), C2.c_float(0.01), 50, C2.c_double(0.99), C2.c_uint64(2024 + nb_cpu),
+                                     coeff.ctypes.data_as(C2.c_void_p), inl.ctypes.data_as(C2.c_void_p), len(inl), None, C2.byref(bi))
+                nb_cpu += 1
+            dt3 = time.perf_counter() - t3
+            res["ransac_icp"]["cpu_baseline"] = {"value": round(nb_cpu / dt3, 1), "unit": "boxes/s (RANSAC only)", "cores": 1, "kind": "port",
+                                                 "sample": f"{nb_cpu} boxes of the same workload (oracle/oracle_seg.c os_ransac_plane)",
+                                                 "gpu_boxes_per_sec_kernels": round(len(recs) * rreps / (rms * 1e-3), 1)}
+    except Exception as e:
+        res["ransac_icp"] = {"error": repr(e)[:300]}
     # pipelined batches (sslam_seg_submit_batch / _collect_batch): the H2D copy of batch k+1 under the kernels of batch k; the clouds
     # sit in pinned host memory, as a capture pipeline that feeds a GPU would keep them
     pins = []

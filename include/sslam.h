@@ -326,6 +326,45 @@ int sslam_seg_convex_hull_2d(sslam_seg* s, const float* xyz, int n, const int32_
 int sslam_seg_icp_point_to_plane(sslam_seg* s, const float* xyz, const int32_t* labels, int n, const float* planes, int n_planes,
                                  int iterations, const double T0[12], double T_out[12], double* rms_out);
 
+/* ---- RANSAC plane per detection box + point-to-plane ICP per frame, batched over the RESIDENT batch (BASELINE.json configs[3]: "640x480
+ * depth cloud, 32 detection boxes/frame, RANSAC+ICP plane extraction"; north_star: "RANSAC plane fit + point-to-plane ICP over depth
+ * clouds inside detection boxes ... one-thread-per-point HIP kernels with LDS inlier counting").  The reference's only RANSAC is
+ * compute2DConvexHull's pcl::SACSegmentation (plane_segmentation.cpp:631-665, threshold 0.01, 50 iterations, probability 0.99); it has
+ * no ICP.  Both calls work on the cropped clouds that the last blocking sslam_seg_segment / sslam_seg_segment_batch call left on the
+ * device (its accepted boxes, in slot order: frame by frame, box order inside a frame): no second upload.
+ *
+ * sslam_seg_ransac_boxes: for every accepted box, pcl::SACSegmentation(SACMODEL_PLANE, SAC_RANSAC, optimise coefficients) exactly as
+ * sslam_seg_ransac_plane runs it on the box's crop taken as an unorganised cloud of width * height points in crop order (row-major; a
+ * non-finite point is never an inlier and a sample that hits one is a bad sample), with seed + slot * 0x9E3779B97F4A7C15 as the seed
+ * of box `slot`.  One workgroup per box, the crop staged in LDS, sixteen hypotheses scored at a time.  Writes min(boxes, max_out) records
+ * and returns the number of boxes; kernel_ms (optional): device time of the pass.  The inlier flags stay on the device for
+ * sslam_seg_ransac_box_inliers (ascending crop indices of one box; returns the true count) and sslam_seg_icp_boxes. */
+typedef struct sslam_box_plane {
+  float coeff[4];          /* (nx, ny, nz, d) of the refined model; zeros when no model was found */
+  int32_t inliers;         /* points within the threshold of the refined model */
+  int32_t points;          /* width * height of the box */
+  int32_t box_index;       /* index into the caller's box array of its frame */
+  int32_t frame;
+  int32_t hypotheses;      /* hypotheses the adaptive loop consumed (bad samples included) */
+  int32_t best_iteration;  /* hypothesis index of the winning sample, -1: none */
+} sslam_box_plane;
+int sslam_seg_ransac_boxes(sslam_seg* s, float threshold, int max_iterations, double probability, uint64_t seed, sslam_box_plane* out, int max_out,
+                           double* kernel_ms);
+int sslam_seg_ransac_box_inliers(sslam_seg* s, int slot, int32_t* out, int max_out);
+/* sslam_seg_icp_boxes: sslam_seg_icp_point_to_plane per FRAME of the resident batch, all frames and all Gauss-Newton rounds in one launch
+ * (one workgroup per frame; the 6 x 6 solve on the device): the points of a frame are the RANSAC inliers of its boxes, the points of box
+ * slot q measure plane box_plane[q] of `planes` (n_planes x 4 floats, e.g. the previous keyframe's planes in the camera frame of this
+ * one; -1: the box takes no part).  T0: NULL (identity) or 12 doubles per frame.  out[f].status is 0 or SSLAM_ERR_NUMERIC (planes that
+ * leave a degree of freedom unconstrained).  Returns the number of frames. */
+typedef struct sslam_icp_result {
+  double T[12];   /* R row-major, then t */
+  double rms;     /* root mean square point-to-plane distance at T */
+  int32_t used;   /* points that took part */
+  int32_t status;
+} sslam_icp_result;
+int sslam_seg_icp_boxes(sslam_seg* s, const int32_t* box_plane, int n_boxes, const float* planes, int n_planes, int iterations, const double* T0,
+                        sslam_icp_result* out, int max_out, double* kernel_ms);
+
 /* ---- cloud filters of the legacy path (dead code upstream) -----------------------------------------------------
  * All three take an unorganised cloud of n xyz float points and run on the GPU; index outputs are ascending and complete when the
  * return value (the true count) does not exceed max_out. */

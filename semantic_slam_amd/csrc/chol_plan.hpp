@@ -130,8 +130,11 @@ struct CholOpts {
   int group_blocks = 1024; //      workgroup factors side by side: the per-level latencies and barriers are shared by all members
   int ustage = -1;         // 1: the per-depth kernels stage the update-matrix records in LDS too (one round trip for all tables: shorter
                            //    piece latency, fewer pieces per CU); -1: 1 for batches < 32 (latency-bound), else 0 (residency-bound)
-  int small_cols = 1200;   // a graph with at most this many block columns is walked by ONE workgroup from the leaves to the root (every piece a tail
-                           // piece, no per-depth launches): the form the fused LM kernel (k_lm_trial_small) needs; 0: never
+  int small_cols = 0;      // a graph with at most this many block columns is walked by ONE workgroup from the leaves to the root (every piece a tail
+                           // piece, no per-depth launches): the form the fused LM kernel (k_lm_trial_small) needs.  0 (default): never --
+                           // measured, the walk serialises sibling subtrees (61 dependent levels instead of 28 at 110 keyframes, 233 instead of
+                           // 42 at 436) and the tick got slower (8.7 vs 7.8 ms, 22.4 vs 10.5 ms); the dependency-driven launch (k_chol_flow) is
+                           // what small graphs use
   int order = 1;           // 0: minimum degree, lowest index first (rounds 1-3: eliminates a pose chain from one end -> a tree as deep as the chain);
                            // 1: multiple minimum degree over independent sets (below): a chain halves per round -> O(log n) levels
   double order_mul = -1;   // a round eliminates an independent set of the nodes with degree <= order_mul * (minimum degree) + order_add;
@@ -548,6 +551,7 @@ inline int chol_symbolic(const SymIn& in, CholOpts opt, CholHost& out) {
   }
   // ---- pieces: column / block ranges (contiguous by construction), parent piece, depth ----------------------------------------
   out.piece.assign(npiece, PieceMeta{});
+  for (auto& pm0 : out.piece) pm0.pad4 = -1;
   std::vector<char> piece_tail(npiece, 0);
   std::vector<int> comp_parent(ncomp, -1), comp_dest(ncomp, -1);   // parent component; the group that holds it
   for (int j = 0; j < ncol; ++j) {
@@ -566,6 +570,10 @@ inline int chol_symbolic(const SymIn& in, CholOpts opt, CholHost& out) {
         if (col_piece[par] <= col_piece[j]) { out.error = "groups are not in elimination order"; return -1; }
         comp_parent[col_comp[j]] = col_comp[par];
         comp_dest[col_comp[j]] = col_piece[par];
+        // the piece its update matrix goes to (pad4; -1: a root).  A group of several components may hang below several pieces (group_cap > 0):
+        // -2 then, and the dependency-driven kernel (k_chol_flow) is not used for such a plan
+        int& pp4 = out.piece[col_piece[j]].pad4;
+        pp4 = (pp4 == -1 || pp4 == col_piece[par]) ? col_piece[par] : -2;
       }
     }
   }

@@ -103,6 +103,7 @@ struct DevArena {
 struct Batch {
   int device = 0;
   hipStream_t stream = nullptr;
+  bool own_stream = true;      // false: the stream belongs to the graph handle and outlives this batch (no create / destroy per structure rebuild)
   std::vector<HostGraph*> graphs;
   std::vector<uint64_t> versions;
   BatchView V{};
@@ -153,7 +154,8 @@ struct Batch {
     event_pool.clear();
     for (void* p : allocs) hipFree(p);
     allocs.clear();
-    if (stream) { hipStreamDestroy(stream); stream = nullptr; }
+    if (stream && own_stream) hipStreamDestroy(stream);
+    stream = nullptr;
   }
   hipEvent_t get_event() {
     if (!event_pool.empty()) { hipEvent_t e = event_pool.back(); event_pool.pop_back(); return e; }
@@ -228,6 +230,10 @@ int chol_set_active(Batch& b, const std::vector<char>* active);   // LM endgame:
 int64_t chol_plan_lnz(const Batch& b);
 int chol_plan_levels(const Batch& b);
 int chol_solve_multi(Batch& b, const double* rhs_host, int nrhs, double* x_host);  // uses the last factorisation
+bool chol_plan_flow(const Batch& b);        // the plan runs factor + both solves in one dependency-driven launch (small batches)
+int chol_solve_flow(Batch& b);              // (H + lambda I) dx = b for in_trial graphs -> V.x, one launch
+int chol_lm_step_flow(Batch& b, int max_iters);   // begin step + one-launch solve + update / chi2 / accept-reject / commit: 3 launches per damping trial
+int chol_flow_check(Batch& b);              // error flag of that launch (synchronises the stream)
 bool chol_plan_tail_only(const Batch& b);   // every piece of every graph is walked by the tail kernels (small graphs)
 int chol_lm_trial_fused(Batch& b, int max_iters);   // one LM iteration (all its damping trials) per graph in one launch, after the linearisation
 int chol_marginal_diag(Batch& b, const std::vector<int>& xoff, const std::vector<int>& dims, double* out36);  // diagonal blocks of H^-1 along the tree paths, one launch

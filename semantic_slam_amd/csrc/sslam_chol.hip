@@ -71,6 +71,12 @@ struct CholPlan {
   double* d_multi_y = nullptr;  // scratch for multi-rhs solves
   double* d_multi_x = nullptr;
   int multi_cap = 0;
+  // dependency-driven factorisation + solve in ONE launch (k_chol_flow): small batches only
+  bool flow = false;            // the plan can run it (every piece has one parent piece; nt_leaf == nt_tail)
+  int flow_grid = 0;            // persistent workgroups
+  int flow_epoch = 0;           // launches so far: the counters are never reset, a launch waits for epoch * (children)
+  int2* d_dep = nullptr;        // per launch-order piece: {parent (launch order) or -1, children}
+  int* d_flow = nullptr;        // [children done | backward done | forward done] per piece, then [0] error flag at 3 * npiece
   // marginals along the elimination-tree paths (k_chol_marginal_paths)
   std::vector<int> h_cparent;   // parent column in the elimination tree, -1: root
   std::vector<int> h_xoff_col;  // offset in the unknown vector (internal row order) -> column, -1 elsewhere
@@ -100,8 +106,8 @@ void chol_plan_free(CholPlan* p) {
   if (p->d_idx) (void)hipFree(p->d_idx);
   if (p->d_multi_y) (void)hipFree(p->d_multi_y);
   if (p->d_multi_x) (void)hipFree(p->d_multi_x);
-  if (p->d_mpath) (void)hipFree(p->d_mpath);
-  if (p->d_mout) (void)hipFree(p->d_mout);
+  if (p->d_mpath && !p->arena) (void)hipFree(p->d_mpath);
+  if (p->d_mout && !p->arena) (void)hipFree(p->d_mout);
   delete p;
 }
 
@@ -1060,18 +1066,14 @@ __device__ __forceinline__ void vblock_store_sum(double v, double* red, double* 
   __syncthreads();
 }
 
+// the three parts of an LM step around the linear solve, one workgroup per graph (shared by k_lm_trial_small and the begin / end kernels
+// of the single-launch solve)
 template <int NT>
-__global__ __launch_bounds__(NT) void k_lm_trial_small(BatchView V, CholView C, double* __restrict__ part_e, int max_iters) {
-  extern __shared__ double sm[];
-  __shared__ double red[NT / 64];
-  const int g = blockIdx.x, tid = threadIdx.x;
+__device__ __forceinline__ void lm_begin_small(const BatchView& V, const CholView& C, int g, double* red) {   // k_maxdiag + k_lm_begin_step + k_chol_begin
+  const int tid = threadIdx.x;
   LmState& S = V.lm[g];
-  if (!S.active) return;
   const GraphSeg sg = V.seg[g];
   const int nrows = sg.nprow * 6 + sg.nlrow * 3;
-  const int nec = edge_chunks(sg), nrc = row_chunks(sg);
-  const int q0 = C.tail_ptr[g], q1 = C.tail_ptr[g + 1];
-  // ---- begin step (k_maxdiag + k_lm_begin_step)
   const int lin = S.lin;
   if (lin && S.iter == 0) {
     double d = 0;
@@ -1085,72 +1087,168 @@ __global__ __launch_bounds__(NT) void k_lm_trial_small(BatchView V, CholView C, 
   if (tid == 0) {
     if (lin) { S.q = 0; S.rho = 0; S.in_trial = 1; S.lin = 0; }
     S.accept = 0;
+    C.fail[g] = 0;
   }
   __threadfence_block();
   __syncthreads();
+}
+template <int NT>
+__device__ __forceinline__ void lm_end_small(const BatchView& V, const CholView& C, int g, double* __restrict__ part_e, int max_iters, double* red) {
+  // k_chol_end + k_oplus + k_chi2 + k_scale + k_lm_control + k_commit for graph g (in a trial)
+  const int tid = threadIdx.x;
+  LmState& S = V.lm[g];
+  const GraphSeg sg = V.seg[g];
+  const int nec = edge_chunks(sg), nrc = row_chunks(sg);
+  if (tid == 0) V.pcg_fail[g] = C.fail[g];
+  for (int i = tid; i < sg.nprow + sg.nlrow; i += NT) oplus_row(V, i < sg.nprow ? sg.prow0 + i : V.nPr + sg.lrow0 + (i - sg.nprow), V.x);
+  __threadfence_block();
+  __syncthreads();
+  for (int c0 = 0; c0 < nec; c0 += NT / kEdgeChunk) {   // the chunks of k_chi2
+    const int chunk = c0 + tid / kEdgeChunk;
+    const double c = chunk < nec ? edge_chi2(V, sg, chunk * kEdgeChunk + tid % kEdgeChunk, V.pose_trial, V.lmk_trial) : 0.0;
+    vblock_store_sum<kEdgeChunk, NT>(c, red, part_e + (size_t)g * V.maxEdgeChunks + chunk, chunk < nec);
+  }
+  {   // dx . (lambda dx + b): the chunks of k_scale
+    const double lambda = S.lambda;
+    constexpr int NV = NT / kRowChunk;
+    for (int c0 = 0; c0 < nrc; c0 += NV) {
+      const int vb = tid / kRowChunk, chunk = c0 + vb;
+      const bool live = vb < NV && chunk < nrc;
+      double v = 0;
+      if (live) {
+        const RowRef R = row_ref(V, sg, chunk * kRowChunk + tid % kRowChunk);
+        if (R.valid) { const double d = V.x[R.xoff]; v = d * (lambda * d + V.bvec[R.xoff]); }
+      }
+      vblock_store_sum<kRowChunk, NT>(v, red, V.part_a + (size_t)g * V.maxRowChunks + chunk, live);
+    }
+  }
+  __threadfence_block();
+  __syncthreads();
+  if (tid < 64) {   // accept / reject (k_lm_control)
+    const double tchi = wave_sum_partials(part_e + (size_t)g * V.maxEdgeChunks, nec);
+    const double sc = wave_sum_partials(V.part_a + (size_t)g * V.maxRowChunks, nrc);
+    if (tid == 0) lm_control_apply(S, tchi, sc, V.pcg_fail[g], max_iters);
+  }
+  __threadfence_block();
+  __syncthreads();
+  if (S.accept) {   // k_commit
+    for (int i = tid; i < sg.nprow + sg.nlrow; i += NT) commit_row(V, i < sg.nprow ? sg.prow0 + i : V.nPr + sg.lrow0 + (i - sg.nprow));
+    __threadfence_block();
+  }
+  __syncthreads();
+}
+
+template <int NT>
+__global__ __launch_bounds__(NT) void k_lm_trial_small(BatchView V, CholView C, double* __restrict__ part_e, int max_iters) {
+  extern __shared__ double sm[];
+  __shared__ double red[NT / 64];
+  const int g = blockIdx.x, tid = threadIdx.x;
+  LmState& S = V.lm[g];
+  if (!S.active) return;
+  const int q0 = C.tail_ptr[g], q1 = C.tail_ptr[g + 1];
+  lm_begin_small<NT>(V, C, g, red);
   for (;;) {
     if (!S.in_trial) return;
     // ---- (H + lambda I) = L L^T, y = L^-1 b: the pieces of the graph's tree in elimination order
-    if (tid == 0) C.fail[g] = 0;
-    __syncthreads();
     for (int q = q0; q < q1; ++q) {
       if (C.rupd) chol_piece<NT, false, true>(V, C, C.lpiece[C.ltail0 + q], sm, nullptr);
       else chol_piece<NT, false, false>(V, C, C.lpiece[C.ltail0 + q], sm, nullptr);
       __threadfence_block();
       __syncthreads();
     }
-    if (tid == 0) V.pcg_fail[g] = C.fail[g];
     // ---- x = L^-T y
     for (int q = q1 - 1; q >= q0; --q) {
       chol_piece_backward<NT>(C, C.lpiece[C.ltail0 + q], C.y, V.x, sm, nullptr);
       __threadfence_block();
       __syncthreads();
     }
-    // ---- trial estimates
-    for (int i = tid; i < sg.nprow + sg.nlrow; i += NT) oplus_row(V, i < sg.nprow ? sg.prow0 + i : V.nPr + sg.lrow0 + (i - sg.nprow), V.x);
-    __threadfence_block();
-    __syncthreads();
-    // ---- chi2 of the trial: the chunks of k_chi2
-    for (int c0 = 0; c0 < nec; c0 += NT / kEdgeChunk) {
-      const int chunk = c0 + tid / kEdgeChunk;
-      const double c = chunk < nec ? edge_chi2(V, sg, chunk * kEdgeChunk + tid % kEdgeChunk, V.pose_trial, V.lmk_trial) : 0.0;
-      vblock_store_sum<kEdgeChunk, NT>(c, red, part_e + (size_t)g * V.maxEdgeChunks + chunk, chunk < nec);
-    }
-    // ---- dx . (lambda dx + b): the chunks of k_scale
-    {
-      const double lambda = S.lambda;
-      constexpr int NV = NT / kRowChunk;
-      for (int c0 = 0; c0 < nrc; c0 += NV) {
-        const int vb = tid / kRowChunk, chunk = c0 + vb;
-        const bool live = vb < NV && chunk < nrc;
-        double v = 0;
-        if (live) {
-          const RowRef R = row_ref(V, sg, chunk * kRowChunk + tid % kRowChunk);
-          if (R.valid) { const double d = V.x[R.xoff]; v = d * (lambda * d + V.bvec[R.xoff]); }
-        }
-        vblock_store_sum<kRowChunk, NT>(v, red, V.part_a + (size_t)g * V.maxRowChunks + chunk, live);
-      }
-    }
-    __threadfence_block();
-    __syncthreads();
-    // ---- accept / reject (k_lm_control)
-    if (tid < 64) {
-      const double tchi = wave_sum_partials(part_e + (size_t)g * V.maxEdgeChunks, nec);
-      const double sc = wave_sum_partials(V.part_a + (size_t)g * V.maxRowChunks, nrc);
-      if (tid == 0) lm_control_apply(S, tchi, sc, V.pcg_fail[g], max_iters);
-    }
-    __threadfence_block();
-    __syncthreads();
-    // ---- commit (k_commit)
-    if (S.accept) {
-      for (int i = tid; i < sg.nprow + sg.nlrow; i += NT) commit_row(V, i < sg.nprow ? sg.prow0 + i : V.nPr + sg.lrow0 + (i - sg.nprow));
-      __threadfence_block();
-    }
-    __syncthreads();
+    lm_end_small<NT>(V, C, g, part_e, max_iters, red);
     if (!S.active || S.lin) return;   // finished, or the next iteration needs a new linearisation: back to the host's launch sequence
-    if (tid == 0) S.accept = 0;       // a rejected trial: once more with the raised lambda (what k_lm_begin_step does for a retry)
+    if (tid == 0) { S.accept = 0; C.fail[g] = 0; }   // a rejected trial: once more with the raised lambda (what k_lm_begin_step does for a retry)
     __threadfence_block();
     __syncthreads();
+  }
+}
+
+// the same two halves as kernels of their own, for the single-launch solve (k_chol_flow) between them: 3 launches per damping trial after the
+// Jacobian kernels instead of ~12 small ones + two per depth of the tree
+template <int NT>
+__global__ __launch_bounds__(NT) void k_lm_begin_small(BatchView V, CholView C) {
+  __shared__ double red[NT / 64];
+  if (!V.lm[blockIdx.x].active) return;
+  lm_begin_small<NT>(V, C, blockIdx.x, red);
+}
+template <int NT>
+__global__ __launch_bounds__(NT) void k_lm_end_small(BatchView V, CholView C, double* __restrict__ part_e, int max_iters) {
+  __shared__ double red[NT / 64];
+  if (!V.lm[blockIdx.x].active || !V.lm[blockIdx.x].in_trial) return;
+  lm_end_small<NT>(V, C, blockIdx.x, part_e, max_iters, red);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Factorisation + both triangular solves of a SMALL batch in ONE launch, driven by the dependencies of the piece tree instead of a launch
+// per depth (~26 + 26 launches per damping trial; a graph of the orchestrator's size spends its time between launches, and a
+// single 5000-pose graph is latency-bound the same way).  A persistent grid of workgroups walks the pieces in launch order (children
+// before parents); workgroup w takes pieces w, w + G, w + 2G, ...  A piece waits until all its child pieces have signalled (a counter per
+// piece, release / acquire at agent scope: the children's update matrices cross CUs and XCDs), is factored by the same chol_piece() the
+// per-depth kernels run, and signals its parent.  The backward substitution follows in the same launch, top-down: a piece waits for its
+// parent's x.  The grid never exceeds what the device holds at once (a waiting workgroup must not keep the one it waits for off the chip);
+// counters are never reset -- launch number `epoch` waits for epoch x (children).  A wait that does not end (it cannot, short of a lost
+// workgroup) gives up after ~2^22 polls and raises the error flag instead of hanging the GPU.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool flow_wait(const int* p, int target, int* err) {
+  int spins = 0;
+  while (__hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target) {
+    __builtin_amdgcn_s_sleep(2);
+    if (++spins > (1 << 22)) { atomicExch(err, 1); return false; }
+  }
+  return true;
+}
+template <int NT, bool USTAGE>
+__global__ __launch_bounds__(NT) void k_chol_flow(BatchView V, CholView C, int np, int epoch, const int2* __restrict__ dep, int* flow) {
+  extern __shared__ double sm[];
+  const int tid = threadIdx.x;
+  int* child_done = flow;
+  int* back_done = flow + np;
+  int* fwd_done = flow + 2 * np;
+  int* err = flow + 3 * np;
+  // ---- (H + lambda I) = L L^T and y = L^-1 b, leaves to roots
+  for (int q = blockIdx.x; q < np; q += gridDim.x) {
+    const PieceMeta pm = C.lpiece[q];
+    const int2 d = dep[q];
+    if (d.y > 0) {
+      if (tid == 0) flow_wait(child_done + q, d.y * epoch, err);
+      __syncthreads();
+    }
+    if (V.lm[pm.graph].in_trial) {
+      if (q >= C.ltail0) {
+        if (C.rupd) chol_piece<NT, false, true>(V, C, pm, sm, nullptr);
+        else chol_piece<NT, false, false>(V, C, pm, sm, nullptr);
+      } else chol_piece<NT, USTAGE, false>(V, C, pm, sm, nullptr);
+    }
+    __syncthreads();   // every thread's stores of L, y and the update matrix are issued ...
+    if (tid == 0) {    // ... and released to the other CUs together with the signal
+      __threadfence();
+      if (d.x >= 0) __hip_atomic_fetch_add(child_done + d.x, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      else __hip_atomic_store(fwd_done + q, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+  // ---- x = L^-T y, roots to leaves
+  for (int i = blockIdx.x; i < np; i += gridDim.x) {
+    const int q = np - 1 - i;
+    const PieceMeta pm = C.lpiece[q];
+    const int2 d = dep[q];
+    if (tid == 0) {
+      if (d.x >= 0) flow_wait(back_done + d.x, epoch, err);
+      else flow_wait(fwd_done + q, epoch, err);
+    }
+    __syncthreads();
+    if (V.lm[pm.graph].in_trial) chol_piece_backward<NT>(C, pm, C.y, V.x, sm, nullptr);
+    __syncthreads();
+    if (tid == 0) {
+      __threadfence();
+      __hip_atomic_store(back_done + q, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
   }
 }
 
@@ -1206,6 +1304,11 @@ int chol_plan_build(Batch& b) {
   opt.from_env();
   if (opt.nt_tail != 1024) opt.nt_tail = 512;
   if (opt.nt_leaf != 128 && opt.nt_leaf != 256 && opt.nt_leaf != 512 && opt.nt_leaf != 1024) opt.nt_leaf = 64;
+  // small batches (latency-bound: the orchestrator's graph, a single large graph): the dependency-driven single launch (k_chol_flow) runs
+  // every piece with the tail's workgroup size
+  const bool flow_on = [] { const char* e = getenv("SSLAM_CHOL_FLOW"); return !(e && atoi(e) == 0); }();   // read per plan (tests toggle it)
+  const bool want_flow = flow_on && b.V.B < 8 && opt.nt_tail == 512 && opt.group_cap == 0 && !getenv("SSLAM_CHOL_NT_LEAF");
+  if (want_flow) opt.nt_leaf = opt.nt_tail;
   CholHost H;
   if (chol_symbolic(in, opt, H)) return set_error(SSLAM_ERR_NUMERIC, "Cholesky plan: %s", H.error.c_str());
   CholPlan* P = new CholPlan();
@@ -1238,6 +1341,22 @@ int chol_plan_build(Batch& b) {
   C.ltail0 = (int)H.plv_pieces.size();
   P->lp_graph.resize(H.lpiece.size());
   for (size_t q = 0; q < H.lpiece.size(); ++q) P->lp_graph[q] = H.lpiece[q].graph;
+  std::vector<int2> dep;
+  if (want_flow) {
+    const int np = (int)H.lpiece.size();
+    std::vector<int> lidx(H.npiece, -1);
+    int q = 0;
+    for (int p : H.plv_pieces) lidx[p] = q++;
+    for (int p : H.tail_pieces) lidx[p] = q++;
+    dep.assign(np, make_int2(-1, 0));
+    bool ok = q == np;
+    for (int i = 0; i < np && ok; ++i) {
+      const int par = H.lpiece[i].pad4;
+      if (par == -2) ok = false;
+      else if (par >= 0) { const int j = lidx[par]; if (j <= i) ok = false; else { dep[i].x = j; dep[j].y++; } }
+    }
+    P->flow = ok;
+  }
   if ((rc = up_to_dev(*P, b.stream, H.asrc, &C.asrc))) return rc;
   if ((rc = up_to_dev(*P, b.stream, H.usrc, &C.usrc))) return rc;
   if ((rc = up_to_dev(*P, b.stream, H.uitem, &C.uitem))) return rc;
@@ -1285,6 +1404,14 @@ int chol_plan_build(Batch& b) {
     C.dbg = (long long*)p;
     SSLAM_HIP_TRY(hipMemsetAsync(p, 0, 48 * sizeof(long long), b.stream));
   }
+  if (P->flow) {
+    if ((rc = up_to_dev(*P, b.stream, dep, (const int2**)&P->d_dep))) return rc;
+    const size_t nints = 3 * dep.size() + 8;
+    if ((rc = plan_alloc(&p, nints * sizeof(int)))) return rc;
+    P->d_flow = (int*)p;
+    SSLAM_HIP_TRY(hipMemsetAsync(p, 0, nints * sizeof(int), b.stream));
+    P->flow_epoch = 0;
+  }
   // index lists of the LM endgame (chol_set_active), sized once: no allocation inside an optimize call (a stream group runs several of
   // them side by side)
   if (b.V.B >= 8 && !P->d_idx) {
@@ -1313,13 +1440,71 @@ int chol_plan_build(Batch& b) {
                            (const void*)k_chol_tail<512>, (const void*)k_chol_tail<1024>,
                            (const void*)k_chol_back_pieces<64>, (const void*)k_chol_back_pieces<128>, (const void*)k_chol_back_pieces<256>,
                            (const void*)k_chol_back_pieces<512>, (const void*)k_chol_back_pieces<1024>, (const void*)k_chol_back_tail<512>,
-                           (const void*)k_lm_trial_small<512>, (const void*)k_lm_trial_small<1024>};
+                           (const void*)k_lm_trial_small<512>, (const void*)k_lm_trial_small<1024>,
+                           (const void*)k_chol_flow<512, true>, (const void*)k_chol_flow<512, false>};
       for (const void* f : fns) SSLAM_HIP_TRY(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, v));
       done.push_back(b.device);
     }
   }
+  if (P->flow) {
+    // persistent grid: at most half of what the device holds at once of these workgroups (two such launches may run side by side),
+    // never more workgroups than pieces
+    int per_cu = 0, cus = 0;
+    const void* fn = P->ustage ? (const void*)k_chol_flow<512, true> : (const void*)k_chol_flow<512, false>;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 512, lds_max) != hipSuccess || per_cu < 1 ||
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, b.device) != hipSuccess || cus < 1) P->flow = false;
+    else P->flow_grid = std::max(1, std::min((int)dep.size(), per_cu * cus / 2));
+  }
   if (P->arena && P->arena->flush(b.stream)) return set_error(SSLAM_ERR_HIP, "upload of the plan tables failed");
   SSLAM_HIP_TRY(hipStreamSynchronize(b.stream));
+  return 0;
+}
+
+// (H + lambda I) dx = b in ONE launch (k_chol_flow) for plans that allow it; false: the caller takes the launch-per-depth path
+bool chol_plan_flow(const Batch& b) { return b.chol && b.chol->flow && !b.chol->compact; }
+int chol_solve_flow(Batch& b) {
+  CholPlan& P = *b.chol;
+  P.C.flat_L = 0;
+  const CholView& C = P.C;
+  ScopedTimer t(b, "factor");
+  size_t lds = (size_t)std::max(P.tail_lds_f, P.tail_lds_b);
+  for (size_t l = 0; l < P.plv_lds_f.size(); ++l) lds = std::max(lds, (size_t)std::max(P.plv_lds_f[l], P.plv_lds_b[l]));
+  lds *= sizeof(double);
+  const int np = (int)P.lp_graph.size();
+  hipLaunchKernelGGL(k_chol_begin, dim3((b.V.B + 63) / 64), dim3(64), 0, b.stream, b.V, C);
+  ++P.flow_epoch;
+  if (P.ustage) hipLaunchKernelGGL((k_chol_flow<512, true>), dim3(P.flow_grid), dim3(512), lds, b.stream, b.V, C, np, P.flow_epoch, (const int2*)P.d_dep, P.d_flow);
+  else hipLaunchKernelGGL((k_chol_flow<512, false>), dim3(P.flow_grid), dim3(512), lds, b.stream, b.V, C, np, P.flow_epoch, (const int2*)P.d_dep, P.d_flow);
+  hipLaunchKernelGGL(k_chol_end, dim3((b.V.B + 63) / 64), dim3(64), 0, b.stream, b.V, C);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return set_error(SSLAM_ERR_HIP, "cholesky flow launch: %s", hipGetErrorString(e));
+  return 0;
+}
+// one damping trial of every active graph of a small batch after the Jacobian kernels: begin step, single-launch solve, the rest of the step
+int chol_lm_step_flow(Batch& b, int max_iters) {
+  CholPlan& P = *b.chol;
+  P.C.flat_L = 0;
+  const CholView& C = P.C;
+  size_t lds = (size_t)std::max(P.tail_lds_f, P.tail_lds_b);
+  for (size_t l = 0; l < P.plv_lds_f.size(); ++l) lds = std::max(lds, (size_t)std::max(P.plv_lds_f[l], P.plv_lds_b[l]));
+  lds *= sizeof(double);
+  const int np = (int)P.lp_graph.size();
+  hipLaunchKernelGGL(k_lm_begin_small<512>, dim3(b.V.B), dim3(512), 0, b.stream, b.V, C);
+  ++P.flow_epoch;
+  if (P.ustage) hipLaunchKernelGGL((k_chol_flow<512, true>), dim3(P.flow_grid), dim3(512), lds, b.stream, b.V, C, np, P.flow_epoch, (const int2*)P.d_dep, P.d_flow);
+  else hipLaunchKernelGGL((k_chol_flow<512, false>), dim3(P.flow_grid), dim3(512), lds, b.stream, b.V, C, np, P.flow_epoch, (const int2*)P.d_dep, P.d_flow);
+  hipLaunchKernelGGL(k_lm_end_small<512>, dim3(b.V.B), dim3(512), 0, b.stream, b.V, C, b.d_part_e, max_iters);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return set_error(SSLAM_ERR_HIP, "LM step launch: %s", hipGetErrorString(e));
+  return 0;
+}
+// the error flag of k_chol_flow (a dependency wait that gave up); call after a stream synchronisation point
+int chol_flow_check(Batch& b) {
+  if (!b.chol || !b.chol->flow || !b.chol->d_flow) return 0;
+  int err = 0;
+  SSLAM_HIP_TRY(hipMemcpyAsync(&err, b.chol->d_flow + 3 * b.chol->lp_graph.size(), sizeof err, hipMemcpyDeviceToHost, b.stream));
+  SSLAM_HIP_TRY(hipStreamSynchronize(b.stream));
+  if (err) return set_error(SSLAM_ERR_HIP, "sparse Cholesky: a dependency wait of the single-launch factorisation timed out");
   return 0;
 }
 
@@ -1500,17 +1685,17 @@ int chol_marginal_diag(Batch& b, const std::vector<int>& xoff, const std::vector
   const size_t lds = (size_t)maxlen * 36 * sizeof(double) + 36 * sizeof(double) + (size_t)maxlen * (sizeof(int4) + sizeof(int)) + 16;
   if (lds > 60 * 1024) return SSLAM_ERR_UNSUPPORTED;
   const size_t ints = hdr.size() + cols.size();
+  // scratch: out of the graph handle's arena when there is one (a plan is rebuilt every tick of the orchestrator: no hipMalloc / hipFree
+  // pair per tick), else the plan's own allocations
   if (P.mpath_cap < ints) {
-    if (P.d_mpath) (void)hipFree(P.d_mpath);
-    P.d_mpath = nullptr; P.mpath_cap = 0;
-    SSLAM_HIP_TRY(hipMalloc((void**)&P.d_mpath, (ints + 4096) * sizeof(int)));
-    P.mpath_cap = ints + 4096;
+    if (P.arena) { P.d_mpath = (int*)P.arena->take((ints + 1024) * sizeof(int), true); if (!P.d_mpath) return set_error(SSLAM_ERR_HIP, "device allocation failed"); }
+    else { if (P.d_mpath) (void)hipFree(P.d_mpath); P.d_mpath = nullptr; P.mpath_cap = 0; SSLAM_HIP_TRY(hipMalloc((void**)&P.d_mpath, (ints + 1024) * sizeof(int))); }
+    P.mpath_cap = ints + 1024;
   }
   if (P.mout_cap < (size_t)n * 36) {
-    if (P.d_mout) (void)hipFree(P.d_mout);
-    P.d_mout = nullptr; P.mout_cap = 0;
-    SSLAM_HIP_TRY(hipMalloc((void**)&P.d_mout, ((size_t)n * 36 + 4096) * sizeof(double)));
-    P.mout_cap = (size_t)n * 36 + 4096;
+    if (P.arena) { P.d_mout = (double*)P.arena->take(((size_t)n * 36 + 1024) * sizeof(double), true); if (!P.d_mout) return set_error(SSLAM_ERR_HIP, "device allocation failed"); }
+    else { if (P.d_mout) (void)hipFree(P.d_mout); P.d_mout = nullptr; P.mout_cap = 0; SSLAM_HIP_TRY(hipMalloc((void**)&P.d_mout, ((size_t)n * 36 + 1024) * sizeof(double))); }
+    P.mout_cap = (size_t)n * 36 + 1024;
   }
   hdr.insert(hdr.end(), cols.begin(), cols.end());
   SSLAM_HIP_TRY(hipMemcpyAsync(P.d_mpath, hdr.data(), hdr.size() * sizeof(int), hipMemcpyHostToDevice, b.stream));

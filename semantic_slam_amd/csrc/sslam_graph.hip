@@ -1675,6 +1675,7 @@ static int batch_solve(Batch& b) {
     if ((rc = chol_plan_build(b))) return rc;
     if (timing) fprintf(stderr, "[timing] cholesky plan build %.3f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
   }
+  if (chol_plan_flow(b)) return chol_solve_flow(b);
   if ((rc = chol_factor_and_forward(b))) return rc;
   return chol_backward(b);
 }
@@ -1710,6 +1711,16 @@ static int batch_optimize(Batch& b, int max_iters, sslam_opt_stats* out) {
       fused = chol_plan_tail_only(b);
     }
   }
+  // Small batches whose plan runs factor + solves in one dependency-driven launch (k_chol_flow): the rest of a damping trial in two more
+  // launches (k_lm_begin_small / k_lm_end_small) -- same sums, same order, same results as the stand-alone kernels
+  bool flow_steps = false;
+  {
+    static const bool wenv = [] { const char* e = getenv("SSLAM_WCHOL"); return e && atoi(e) != 0; }();
+    if (!fused && b.graphs[0]->opt.fused && !wenv && b.graphs[0]->opt.solver == 1 && !b.sharded && !b.profiling) {
+      if (!b.chol && (rc = chol_plan_build(b))) return rc;
+      flow_steps = chol_plan_flow(b);
+    }
+  }
   long long budget = 10LL * std::max(max_iters, 0) + 8;    // hard bound: <= 10 trials per iteration
   int need = max_iters;
   if ((rc = chol_set_active(b, nullptr))) return rc;
@@ -1721,6 +1732,7 @@ static int batch_optimize(Batch& b, int max_iters, sslam_opt_stats* out) {
     for (int sidx = 0; sidx < chunk; ++sidx) {
       if ((rc = batch_linearize(b))) return rc;
       if (fused) { if ((rc = chol_lm_trial_fused(b, max_iters))) return rc; continue; }
+      if (flow_steps) { if ((rc = chol_lm_step_flow(b, max_iters))) return rc; continue; }
       hipLaunchKernelGGL(k_maxdiag, row_grid(b), dim3(kRowChunk), 0, b.stream, V, b.d_part_m);
       hipLaunchKernelGGL(k_lm_begin_step, dim3(V.B), dim3(64), 0, b.stream, V, b.d_part_m);
       if ((rc = batch_solve(b))) return rc;
@@ -1754,6 +1766,7 @@ static int batch_optimize(Batch& b, int max_iters, sslam_opt_stats* out) {
   SSLAM_HIP_TRY(hipStreamSynchronize(b.stream));
   b.harvest();
   if ((rc = launch_check("optimize"))) return rc;
+  if ((rc = chol_flow_check(b))) return rc;
   const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   int worst = 0;
   for (int g = 0; g < V.B; ++g) {
@@ -1778,8 +1791,14 @@ using namespace sslam;
 struct sslam_graph {
   HostGraph g;
   DevArena arena;                // device memory of the batch below, kept across structure rebuilds (declared first: destroyed last)
+  hipStream_t stream = nullptr;  // the handle's stream, handed to every batch it builds (a stream create / destroy pair per tick costs more
+                                 // than optimising a small graph)
   std::unique_ptr<Batch> batch;  // batch of one, rebuilt when the structure changes
   bool linearized = false;
+  ~sslam_graph() {
+    batch.reset();               // synchronises the stream
+    if (stream) { (void)hipSetDevice(g.device); (void)hipStreamDestroy(stream); }
+  }
 };
 struct sslam_batch {
   Batch b;
@@ -1817,12 +1836,17 @@ static int ensure_batch(sslam_graph* h) {
   if (e != hipSuccess || n <= 0) return set_error(SSLAM_ERR_NO_DEVICE, "no HIP device visible (%s); the product has no CPU fallback", hipGetErrorString(e));
   if (h->g.device < 0 || h->g.device >= n) return set_error(SSLAM_ERR_NO_DEVICE, "device %d out of range (%d visible)", h->g.device, n);
   if (!h->batch || h->batch->versions.empty() || h->batch->versions[0] != h->g.structure_version) {
+    static const bool timing = getenv("SSLAM_TIMING") != nullptr;
+    const auto tr0 = std::chrono::steady_clock::now();
     h->batch.reset();                              // the old batch synchronises its stream; its arrays belong to the arena
     SSLAM_HIP_TRY(hipSetDevice(h->g.device));
     h->arena.reset();
+    if (timing) fprintf(stderr, "[timing] rebuild: release of the old batch + arena reset %.3f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tr0).count());
     h->batch.reset(new Batch());
     h->batch->arena = &h->arena;
     h->batch->device = h->g.device;
+    if (!h->stream) SSLAM_HIP_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    h->batch->stream = h->stream; h->batch->own_stream = false;
     h->batch->graphs = {&h->g};
     int rc = batch_build(*h->batch);
     if (rc) { h->batch.reset(); return rc; }

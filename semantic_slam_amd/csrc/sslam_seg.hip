@@ -1499,6 +1499,279 @@ __global__ __launch_bounds__(256) void k_icp_accumulate(const float* __restrict_
   if (threadIdx.x < kIcpSums) partial[(size_t)blockIdx.x * kIcpSums + threadIdx.x] = ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
 }
 
+
+// ---- RANSAC plane per detection box + point-to-plane ICP per frame over the RESIDENT batch (BASELINE.json configs[3]; north_star "RANSAC
+// plane fit + point-to-plane ICP over depth clouds inside detection boxes ... one-thread-per-point HIP kernels with LDS inlier counting";
+// the only RANSAC hook upstream is compute2DConvexHull, plane_segmentation.cpp:631-665) -------------------------------------------------
+// One workgroup per box.  The box's cropped cloud (w x h points in crop order, invalid points included: they are never inliers and a
+// sample that hits one is a bad sample) is staged in LDS once -- 12 bytes per point read from HBM once -- and every hypothesis is scored
+// out of LDS: sixteen hypotheses at a time, one wave each (lane 0 draws the sample with the counter hash of the single-cloud entry
+// point, the wave counts inliers with a point per lane), then one thread replays pcl::RandomSampleConsensus' adaptive loop over the
+// sixteen counts in order and stops the box as soon as the sequential algorithm would have stopped.  optimizeModelCoefficients needs
+// float sums over the inliers IN INDEX ORDER: the points are walked 1024 at a time, every inlier gets its rank from wave ballots and
+// parks its nine products in LDS, nine lanes add them in rank order -- the arithmetic of oracle_seg.c's serial loop, bit for bit.
+struct RansacBox { float coeff[4]; int inliers, best_count, best_iter, hyps; };
+constexpr int kRsProd = 256;   // inlier products parked per round of the ordered sums
+__global__ __launch_bounds__(1024) void k_ransac_boxes(View V, float thr, int max_iterations, double probability, unsigned long long seed0,
+                                                       int lds_points, RansacBox* __restrict__ out, unsigned char* __restrict__ flag) {
+  extern __shared__ float sp[];
+  __shared__ float s_models[16][4];
+  __shared__ int s_cnt[16];
+  __shared__ float s_best[4], s_acc[9];
+  __shared__ int s_woff[17];
+  __shared__ int s_stop, s_best_n, s_best_it, s_it, s_total;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const BoxMeta b = V.box[blockIdx.x];
+  const int n = b.w * b.h;
+  const float* gp = V.pts + (size_t)b.pix0 * 3;
+  const bool staged = n <= lds_points;
+  if (staged) for (int e = tid; e < 3 * n; e += 1024) sp[e] = gp[e];
+  const float* P = staged ? (const float*)sp : gp;
+  float* prod = sp + (staged ? 3 * n : 0);
+  const unsigned long long seed = seed0 + (unsigned long long)blockIdx.x * 0x9E3779B97F4A7C15ull;
+  if (tid == 0) { s_stop = n < 3 ? 1 : 0; s_best_n = -1; s_best_it = -1; s_it = 0; s_best[0] = s_best[1] = s_best[2] = s_best[3] = 0; }
+  __syncthreads();
+  // ---- hypotheses, sixteen at a time; the adaptive loop's state lives in thread 0
+  double k = 1.0;
+  int iterations = 0, skipped = 0;
+  const int max_skip = max_iterations * 10;
+  const double log_probability = log(1.0 - probability), one_over = 1.0 / (double)n, eps = 2.220446049250313e-16;
+  while (!s_stop) {
+    const int iter = s_it + wave;
+    float m0 = 0, m1 = 0, m2 = 0, m3 = 0;
+    int ok = 0;
+    if (lane == 0) {
+      int good = 0;
+      for (int attempt = 0; attempt < 1000 && !good; ++attempt) {
+        int id[3];
+        for (int j = 0; j < 3; ++j)
+          id[j] = (int)(splitmix64(seed ^ ((unsigned long long)iter << 32) ^ ((unsigned long long)attempt << 8) ^ (unsigned long long)j) % (unsigned long long)n);
+        if (id[0] == id[1] || id[0] == id[2] || id[1] == id[2]) continue;
+        const float* p0 = P + (size_t)id[0] * 3; const float* p1 = P + (size_t)id[1] * 3; const float* p2 = P + (size_t)id[2] * 3;
+        const float a0 = p1[0] - p0[0], a1 = p1[1] - p0[1], a2 = p1[2] - p0[2];
+        const float b0 = p2[0] - p0[0], b1 = p2[1] - p0[1], b2 = p2[2] - p0[2];
+        const float r0 = a0 / b0, r1 = a1 / b1, r2 = a2 / b2;
+        if (!((r0 != r1) || (r2 != r1))) continue;
+        m0 = a1 * b2 - a2 * b1; m1 = a2 * b0 - a0 * b2; m2 = a0 * b1 - a1 * b0;
+        const float nn = sqrtf(m0 * m0 + m1 * m1 + m2 * m2);
+        m0 /= nn; m1 /= nn; m2 /= nn;
+        m3 = -1 * (m0 * p0[0] + m1 * p0[1] + m2 * p0[2]);
+        good = 2;
+      }
+      ok = (good == 2) && isfinite(m0) && isfinite(m3);
+    }
+    m0 = __shfl(m0, 0, 64); m1 = __shfl(m1, 0, 64); m2 = __shfl(m2, 0, 64); m3 = __shfl(m3, 0, 64); ok = __shfl(ok, 0, 64);
+    int cnt = 0;
+    if (ok) {
+      const float m[4] = {m0, m1, m2, m3};
+      for (int i = lane; i < n; i += 64) cnt += plane_inlier(m, P + (size_t)i * 3, thr) ? 1 : 0;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_down(cnt, o, 64);
+    if (lane == 0) { s_cnt[wave] = ok ? cnt : -1; s_models[wave][0] = m0; s_models[wave][1] = m1; s_models[wave][2] = m2; s_models[wave][3] = m3; }
+    __syncthreads();
+    if (tid == 0) {   // pcl::RandomSampleConsensus::computeModel over these sixteen hypotheses, in order
+      int stop = 0;
+      for (int j = 0; j < 16; ++j) {
+        if (!((double)iterations < k && skipped < max_skip)) { stop = 1; break; }
+        const int c = s_cnt[j];
+        ++s_it;
+        if (c < 0) { ++skipped; continue; }
+        if (c > s_best_n) {
+          s_best_n = c; s_best_it = s_it - 1;
+          s_best[0] = s_models[j][0]; s_best[1] = s_models[j][1]; s_best[2] = s_models[j][2]; s_best[3] = s_models[j][3];
+          const double w = (double)c * one_over;
+          double p_no = 1.0 - pow(w, 3.0);
+          if (p_no < eps) p_no = eps;
+          if (p_no > 1.0 - eps) p_no = 1.0 - eps;
+          k = log_probability / log(p_no);
+        }
+        ++iterations;
+        if (iterations > max_iterations) { stop = 1; break; }
+      }
+      s_stop = stop;
+    }
+    __syncthreads();
+  }
+  const int best = s_best_n;
+  float model[4] = {s_best[0], s_best[1], s_best[2], s_best[3]};
+  if (best <= 0) {
+    for (int i = tid; i < n; i += 1024) flag[(size_t)b.pix0 + i] = 0;
+    if (tid == 0) out[blockIdx.x] = RansacBox{{0, 0, 0, 0}, 0, best, s_best_it, s_it};
+    return;
+  }
+  // ---- optimizeModelCoefficients: float mean / covariance of the inliers of the sampled model, summed in index order
+  if (best > 3) {
+    float acc = 0;
+    int total = 0;
+    for (int c0 = 0; c0 < n; c0 += 1024) {
+      const int i = c0 + tid;
+      const bool in = i < n && plane_inlier(model, P + (size_t)i * 3, thr);
+      const unsigned long long mask = __ballot(in);
+      if (lane == 0) s_woff[wave] = __popcll(mask);
+      __syncthreads();
+      if (tid == 0) { int a = 0; for (int w = 0; w < 16; ++w) { const int c = s_woff[w]; s_woff[w] = a; a += c; } s_woff[16] = a; }
+      __syncthreads();
+      const int rank = s_woff[wave] + __popcll(mask & ((1ull << lane) - 1ull));
+      const int cn = s_woff[16];
+      for (int r0 = 0; r0 < cn; r0 += kRsProd) {
+        if (in && rank >= r0 && rank < r0 + kRsProd) {
+          const float* p = P + (size_t)i * 3;
+          float* q = prod + (rank - r0) * 9;
+          q[0] = p[0] * p[0]; q[1] = p[0] * p[1]; q[2] = p[0] * p[2]; q[3] = p[1] * p[1]; q[4] = p[1] * p[2]; q[5] = p[2] * p[2];
+          q[6] = p[0]; q[7] = p[1]; q[8] = p[2];
+        }
+        __syncthreads();
+        if (tid < 9) { const int mcount = min(kRsProd, cn - r0); for (int q = 0; q < mcount; ++q) acc += prod[q * 9 + tid]; }
+        __syncthreads();
+      }
+      total += cn;
+    }
+    if (tid < 9) s_acc[tid] = acc;
+    __syncthreads();
+    if (tid == 0) {
+      float a[9];
+      const float cf = (float)total;
+#pragma unroll
+      for (int q = 0; q < 9; ++q) a[q] = s_acc[q] / cf;
+      float cov[9];
+      cov[0] = a[0] - a[6] * a[6]; cov[1] = a[1] - a[6] * a[7]; cov[2] = a[2] - a[6] * a[8];
+      cov[4] = a[3] - a[7] * a[7]; cov[5] = a[4] - a[7] * a[8]; cov[8] = a[5] - a[8] * a[8];
+      cov[3] = cov[1]; cov[6] = cov[2]; cov[7] = cov[5];
+      float ev, v[3];
+      eigen33(cov, ev, v);
+      s_best[0] = v[0]; s_best[1] = v[1]; s_best[2] = v[2];
+      s_best[3] = -1 * (v[0] * a[6] + v[1] * a[7] + v[2] * a[8]);
+    }
+    __syncthreads();
+    model[0] = s_best[0]; model[1] = s_best[1]; model[2] = s_best[2]; model[3] = s_best[3];
+  }
+  // ---- inliers of the refined model: flags for the box's pixels + their count
+  int cnt = 0;
+  for (int i = tid; i < n; i += 1024) {
+    const bool in = plane_inlier(model, P + (size_t)i * 3, thr);
+    flag[(size_t)b.pix0 + i] = in ? 1 : 0;
+    cnt += in ? 1 : 0;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) cnt += __shfl_down(cnt, o, 64);
+  if (lane == 0) s_woff[wave] = cnt;
+  __syncthreads();
+  if (tid == 0) {
+    int a = 0;
+    for (int w = 0; w < 16; ++w) a += s_woff[w];
+    out[blockIdx.x] = RansacBox{{model[0], model[1], model[2], model[3]}, a, best, s_best_it, s_it};
+  }
+}
+
+// Point-to-plane ICP of every frame of the resident batch against a plane list (e.g. the previous keyframe's planes): the points are the
+// RANSAC inliers of the frame's boxes, box slot q measures plane box_plane[q] (-1: the box takes no part).  One workgroup per frame runs
+// ALL Gauss-Newton rounds: a pass over its points (29 double sums per thread, then a fixed-order reduction), the 6 x 6 Cholesky solve and
+// the update T <- (exp[w]x, u) o T by one thread -- no host round trip per iteration.  Same arithmetic as k_icp_accumulate + the host
+// solve of sslam_seg_icp_point_to_plane; only the order of the sums differs.
+struct IcpFrame { double T[12]; double rms; int used, status; };
+__global__ __launch_bounds__(1024) void k_icp_frames(View V, const unsigned char* __restrict__ flag, const int* __restrict__ frame_box0,
+                                                     const int* __restrict__ box_plane, const float* __restrict__ planes, int n_planes, int iterations,
+                                                     const double* __restrict__ T0, IcpFrame* __restrict__ out) {
+  __shared__ double red[16][kIcpSums];
+  __shared__ double sT[12], sums[kIcpSums];
+  __shared__ int s_status;
+  const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int q0 = frame_box0[f], q1 = frame_box0[f + 1];
+  if (tid < 12) sT[tid] = T0 ? T0[(size_t)f * 12 + tid] : ((tid < 9 && tid % 4 == 0) ? 1.0 : 0.0);
+  if (tid == 0) s_status = 0;
+  __syncthreads();
+  for (int it = 0; it <= iterations; ++it) {   // the last pass only measures the residual at the returned transform
+    double a[kIcpSums];
+#pragma unroll
+    for (int k = 0; k < kIcpSums; ++k) a[k] = 0.0;
+    double R[9], t[3];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) R[k] = sT[k];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) t[k] = sT[9 + k];
+    for (int q = q0; q < q1; ++q) {
+      const int kpl = box_plane[q];
+      if (kpl < 0 || kpl >= n_planes) continue;
+      const BoxMeta b = V.box[q];
+      const double nx = planes[4 * kpl], ny = planes[4 * kpl + 1], nz = planes[4 * kpl + 2], d = planes[4 * kpl + 3];
+      const int n = b.w * b.h;
+      for (int i = tid; i < n; i += 1024) {
+        if (!flag[(size_t)b.pix0 + i]) continue;
+        const float* p = V.pts + ((size_t)b.pix0 + i) * 3;
+        const double px = p[0], py = p[1], pz = p[2];
+        if (!(isfinite(px) && isfinite(py) && isfinite(pz))) continue;
+        const double qx = R[0] * px + R[1] * py + R[2] * pz + t[0];
+        const double qy = R[3] * px + R[4] * py + R[5] * pz + t[1];
+        const double qz = R[6] * px + R[7] * py + R[8] * pz + t[2];
+        const double r = nx * qx + ny * qy + nz * qz + d;
+        const double J[6] = {qy * nz - qz * ny, qz * nx - qx * nz, qx * ny - qy * nx, nx, ny, nz};
+        int m = 0;
+#pragma unroll
+        for (int rr = 0; rr < 6; ++rr)
+#pragma unroll
+          for (int cc = rr; cc < 6; ++cc) a[m++] += J[rr] * J[cc];
+#pragma unroll
+        for (int rr = 0; rr < 6; ++rr) a[21 + rr] += J[rr] * r;
+        a[27] += r * r;
+        a[28] += 1.0;
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < kIcpSums; ++k) {
+      double v = a[k];
+      for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+      if (lane == 0) red[wave][k] = v;
+    }
+    __syncthreads();
+    if (tid < kIcpSums) { double v = 0; for (int w = 0; w < 16; ++w) v += red[w][tid]; sums[tid] = v; }
+    __syncthreads();
+    if (it == iterations || sums[28] < 6 || s_status) break;
+    if (tid == 0) {
+      double A[36], bvec[6], L[36];
+      for (int k = 0; k < 36; ++k) L[k] = 0;
+      int m = 0;
+      for (int r = 0; r < 6; ++r) for (int c = r; c < 6; ++c) { A[r * 6 + c] = A[c * 6 + r] = sums[m++]; }
+      for (int r = 0; r < 6; ++r) bvec[r] = -sums[21 + r];
+      bool okc = true;
+      for (int j = 0; j < 6 && okc; ++j) {
+        double dsum = A[j * 6 + j];
+        for (int k = 0; k < j; ++k) dsum -= L[j * 6 + k] * L[j * 6 + k];
+        if (!(dsum > 1e-12 * A[j * 6 + j]) || !(dsum > 0)) { okc = false; break; }
+        L[j * 6 + j] = sqrt(dsum);
+        for (int i = j + 1; i < 6; ++i) { double v = A[i * 6 + j]; for (int k = 0; k < j; ++k) v -= L[i * 6 + k] * L[j * 6 + k]; L[i * 6 + j] = v / L[j * 6 + j]; }
+      }
+      if (!okc) s_status = SSLAM_ERR_NUMERIC;   // the planes leave a degree of freedom unconstrained
+      else {
+        double y[6], dx[6];
+        for (int i = 0; i < 6; ++i) { double v = bvec[i]; for (int k = 0; k < i; ++k) v -= L[i * 6 + k] * y[k]; y[i] = v / L[i * 6 + i]; }
+        for (int i = 5; i >= 0; --i) { double v = y[i]; for (int k = i + 1; k < 6; ++k) v -= L[k * 6 + i] * dx[k]; dx[i] = v / L[i * 6 + i]; }
+        const double wx = dx[0], wy = dx[1], wz = dx[2], th = sqrt(wx * wx + wy * wy + wz * wz);
+        double E[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+        if (th > 0) {
+          const double sa = sin(th) / th, bq = (1.0 - cos(th)) / (th * th);
+          const double K[9] = {0, -wz, wy, wz, 0, -wx, -wy, wx, 0};
+          for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) { double kk = 0; for (int q = 0; q < 3; ++q) kk += K[r * 3 + q] * K[q * 3 + c]; E[r * 3 + c] += sa * K[r * 3 + c] + bq * kk; }
+        }
+        double Tn[12];
+        for (int r = 0; r < 3; ++r) {
+          for (int c = 0; c < 3; ++c) Tn[r * 3 + c] = E[r * 3] * sT[c] + E[r * 3 + 1] * sT[3 + c] + E[r * 3 + 2] * sT[6 + c];
+          Tn[9 + r] = E[r * 3] * sT[9] + E[r * 3 + 1] * sT[10] + E[r * 3 + 2] * sT[11] + dx[3 + r];
+        }
+        for (int k = 0; k < 12; ++k) sT[k] = Tn[k];
+      }
+    }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    IcpFrame o;
+    for (int k = 0; k < 12; ++k) o.T[k] = sT[k];
+    o.rms = sums[28] > 0 ? sqrt(sums[27] / sums[28]) : 0.0;
+    o.used = (int)sums[28]; o.status = s_status;
+    out[f] = o;
+  }
+}
+
 // ---- cloud filters of the legacy path (plane_segmentation.cpp:557-629) ---------------------------------------------
 // ordered compaction of a flag array (ascending indices): per-block counts -> k_ransac_scan -> write
 __global__ __launch_bounds__(256) void k_flag_count(const unsigned char* __restrict__ flag, int n, int* __restrict__ block_counts) {
@@ -1701,6 +1974,11 @@ struct sslam_seg {
   std::chrono::steady_clock::time_point q_t0;
   // sslam_seg_submit_batch / _collect_batch: two pipelines (this handle and a twin with its own stream and buffers) used in turn, so
   // that the H2D copy of one batch runs under the kernels of the previous one
+  // sslam_seg_ransac_boxes / _icp_boxes over the resident batch of the last blocking segment call
+  unsigned char* d_rflag = nullptr;   // [pixels of the batch] inlier of its box's refined RANSAC model
+  void* d_rbox = nullptr;             // RansacBox per accepted box
+  size_t cap_rflag = 0, cap_rbox = 0;
+  int r_nbox = -1;                    // boxes the flags belong to (-1: no RANSAC has run on the resident batch)
   sslam_seg* twin = nullptr;
   int fifo[2] = {0, 0};            // which pipeline (0 = this, 1 = twin) holds the oldest / the newer submitted batch
   int n_inflight = 0;
@@ -1710,6 +1988,8 @@ struct sslam_seg {
     free_all();
     if (q_regs) (void)hipHostFree(q_regs);
     if (q_nreg) (void)hipHostFree(q_nreg);
+    if (d_rflag) (void)hipFree(d_rflag);
+    if (d_rbox) (void)hipFree(d_rbox);
     if (q_e0) (void)hipEventDestroy(q_e0);
     if (q_e1) (void)hipEventDestroy(q_e1);
     if (stream) (void)hipStreamDestroy(stream);
@@ -1848,6 +2128,7 @@ static int seg_enqueue(sslam_seg* s, const sslam_frame* frames, int n_frames, in
   // ---- host-side box filter: class whitelist (point_cloud_segmentation.h:126-130), crop bounds
   //      (plane_segmentation.cpp:34-38), minimum point count (:93-95)
   s->boxes.clear(); s->box_src.clear(); s->box_frame.clear();
+  s->r_nbox = -1;
   size_t npix = 0, nii = 0;
   int maxpix = 1;
   for (int f = 0; f < n_frames; ++f)
@@ -2221,6 +2502,142 @@ int sslam_seg_ransac_plane(sslam_seg* s, const float* xyz, int n, float threshol
   cleanup();
   if (le != hipSuccess) return set_error(SSLAM_ERR_HIP, "ransac kernels: %s", hipGetErrorString(le));
   return total;
+}
+
+// ---- RANSAC + ICP over the boxes of the resident batch (configs[3]) ------------------------------------------------------------------
+static int seg_resident_check(sslam_seg* s) {
+  if (!s) return set_error(SSLAM_ERR_INVALID, "null handle");
+  int nd = 0;
+  if (hipGetDeviceCount(&nd) != hipSuccess || nd <= 0) return set_error(SSLAM_ERR_NO_DEVICE, "no HIP device visible; the product has no CPU fallback");
+  if (s->q_busy || s->n_inflight > 0) return set_error(SSLAM_ERR_INVALID, "a batch is in flight: collect it first");
+  if (!s->stream || s->V.nbox != (int)s->boxes.size()) return set_error(SSLAM_ERR_INVALID, "no resident batch: call sslam_seg_segment / sslam_seg_segment_batch first");
+  return 0;
+}
+static int seg_ransac_lds_opt_in(int device, int* limit) {
+  static std::mutex mu;
+  static std::vector<std::pair<int, int>> done;
+  std::lock_guard<std::mutex> lk(mu);
+  for (auto& d : done) if (d.first == device) { *limit = d.second; return 0; }
+  const int v = lds_optin_limit(device, 156 * 1024, 4096);
+  SSLAM_HIP_TRY(hipFuncSetAttribute((const void*)k_ransac_boxes, hipFuncAttributeMaxDynamicSharedMemorySize, v));
+  done.push_back({device, v});
+  *limit = v;
+  return 0;
+}
+
+int sslam_seg_ransac_boxes(sslam_seg* s, float threshold, int max_iterations, double probability, uint64_t seed, sslam_box_plane* out, int max_out,
+                           double* kernel_ms) {
+  int rc = seg_resident_check(s);
+  if (rc) return rc;
+  if ((!out && max_out > 0) || max_iterations < 1 || !(threshold > 0) || !(probability > 0 && probability < 1)) return set_error(SSLAM_ERR_INVALID, "bad argument");
+  SSLAM_HIP_TRY(hipSetDevice(s->P.device));
+  const int nb = (int)s->boxes.size();
+  if (kernel_ms) *kernel_ms = 0;
+  if (nb == 0) { s->r_nbox = 0; return 0; }
+  const size_t npix = (size_t)s->V.npix_total;
+  if (npix > s->cap_rflag) {
+    if (s->d_rflag) (void)hipFree(s->d_rflag);
+    s->d_rflag = nullptr; s->cap_rflag = 0;
+    SSLAM_HIP_TRY(hipMalloc((void**)&s->d_rflag, npix));
+    s->cap_rflag = npix;
+  }
+  if ((size_t)nb > s->cap_rbox) {
+    if (s->d_rbox) (void)hipFree(s->d_rbox);
+    s->d_rbox = nullptr; s->cap_rbox = 0;
+    SSLAM_HIP_TRY(hipMalloc(&s->d_rbox, (size_t)nb * sizeof(RansacBox)));
+    s->cap_rbox = nb;
+  }
+  int lds_limit = 0;
+  if ((rc = seg_ransac_lds_opt_in(s->P.device, &lds_limit))) return rc;
+  // a box whose points fit next to the product table is scored out of LDS; larger boxes read their points through L2
+  const int prod_bytes = kRsProd * 9 * (int)sizeof(float);
+  const int lds_points = std::max(0, (lds_limit - prod_bytes - 1024) / 12);
+  int max_staged = 0;
+  for (auto& b : s->boxes) { const int n = b.w * b.h; if (n <= lds_points) max_staged = std::max(max_staged, n); }
+  const size_t lds = (size_t)max_staged * 12 + prod_bytes;
+  if (!s->q_e0) { SSLAM_HIP_TRY(hipEventCreate(&s->q_e0)); SSLAM_HIP_TRY(hipEventCreate(&s->q_e1)); }
+  SSLAM_HIP_TRY(hipEventRecord(s->q_e0, s->stream));
+  hipLaunchKernelGGL(k_ransac_boxes, dim3(nb), dim3(1024), lds, s->stream, s->V, threshold, max_iterations, probability, (unsigned long long)seed, lds_points,
+                     (RansacBox*)s->d_rbox, s->d_rflag);
+  SSLAM_HIP_TRY(hipGetLastError());
+  SSLAM_HIP_TRY(hipEventRecord(s->q_e1, s->stream));
+  std::vector<RansacBox> rb(nb);
+  SSLAM_HIP_TRY(hipMemcpyAsync(rb.data(), s->d_rbox, (size_t)nb * sizeof(RansacBox), hipMemcpyDeviceToHost, s->stream));
+  SSLAM_HIP_TRY(hipStreamSynchronize(s->stream));
+  if (kernel_ms) { float ms = 0; if (hipEventElapsedTime(&ms, s->q_e0, s->q_e1) == hipSuccess) *kernel_ms = ms; }
+  s->r_nbox = nb;
+  for (int q = 0; q < nb && q < max_out; ++q) {
+    sslam_box_plane& o = out[q];
+    for (int k = 0; k < 4; ++k) o.coeff[k] = rb[q].coeff[k];
+    o.inliers = rb[q].inliers; o.points = s->boxes[q].w * s->boxes[q].h; o.box_index = s->box_src[q]; o.frame = s->box_frame[q];
+    o.hypotheses = rb[q].hyps; o.best_iteration = rb[q].best_iter;
+  }
+  return nb;
+}
+
+int sslam_seg_ransac_box_inliers(sslam_seg* s, int slot, int32_t* out, int max_out) {
+  int rc = seg_resident_check(s);
+  if (rc) return rc;
+  if (s->r_nbox < 0) return set_error(SSLAM_ERR_INVALID, "sslam_seg_ransac_boxes has not run on the resident batch");
+  if (slot < 0 || slot >= s->r_nbox || (!out && max_out > 0)) return set_error(SSLAM_ERR_INVALID, "bad box slot %d (of %d)", slot, s->r_nbox);
+  SSLAM_HIP_TRY(hipSetDevice(s->P.device));
+  const BoxMeta& b = s->boxes[slot];
+  std::vector<unsigned char> f((size_t)b.w * b.h);
+  SSLAM_HIP_TRY(hipMemcpyAsync(f.data(), s->d_rflag + b.pix0, f.size(), hipMemcpyDeviceToHost, s->stream));
+  SSLAM_HIP_TRY(hipStreamSynchronize(s->stream));
+  int n = 0;
+  for (size_t i = 0; i < f.size(); ++i) if (f[i]) { if (n < max_out) out[n] = (int32_t)i; ++n; }
+  return n;
+}
+
+int sslam_seg_icp_boxes(sslam_seg* s, const int32_t* box_plane, int n_boxes, const float* planes, int n_planes, int iterations, const double* T0,
+                        sslam_icp_result* out, int max_out, double* kernel_ms) {
+  int rc = seg_resident_check(s);
+  if (rc) return rc;
+  if (s->r_nbox < 0) return set_error(SSLAM_ERR_INVALID, "sslam_seg_ransac_boxes has not run on the resident batch");
+  if (!box_plane || !planes || !out || n_boxes != s->r_nbox || n_planes <= 0 || iterations < 0 || max_out < 0) return set_error(SSLAM_ERR_INVALID, "bad argument (the batch holds %d boxes)", s->r_nbox);
+  SSLAM_HIP_TRY(hipSetDevice(s->P.device));
+  const int nf = (int)s->q_frames.size();
+  if (kernel_ms) *kernel_ms = 0;
+  if (nf == 0) return 0;
+  std::vector<int> fb0(nf + 1, 0);
+  for (int q = 0; q < s->r_nbox; ++q) fb0[s->box_frame[q] + 1]++;   // the slots of a frame are consecutive (frames are packed in order)
+  for (int f = 0; f < nf; ++f) fb0[f + 1] += fb0[f];
+  int *d_fb0 = nullptr, *d_bp = nullptr;
+  float* d_planes = nullptr;
+  double* d_T0 = nullptr;
+  IcpFrame* d_out = nullptr;
+  struct Guard {
+    std::vector<void**> ptrs;
+    ~Guard() { for (void** p : ptrs) if (*p) (void)hipFree(*p); }
+  } guard;
+  guard.ptrs = {(void**)&d_fb0, (void**)&d_bp, (void**)&d_planes, (void**)&d_T0, (void**)&d_out};
+  SSLAM_HIP_TRY(hipMalloc((void**)&d_fb0, (size_t)(nf + 1) * sizeof(int)));
+  SSLAM_HIP_TRY(hipMalloc((void**)&d_bp, (size_t)std::max(n_boxes, 1) * sizeof(int)));
+  SSLAM_HIP_TRY(hipMalloc((void**)&d_planes, (size_t)n_planes * 4 * sizeof(float)));
+  SSLAM_HIP_TRY(hipMalloc((void**)&d_out, (size_t)nf * sizeof(IcpFrame)));
+  SSLAM_HIP_TRY(hipMemcpyAsync(d_fb0, fb0.data(), (size_t)(nf + 1) * sizeof(int), hipMemcpyHostToDevice, s->stream));
+  if (n_boxes > 0) SSLAM_HIP_TRY(hipMemcpyAsync(d_bp, box_plane, (size_t)n_boxes * sizeof(int), hipMemcpyHostToDevice, s->stream));
+  SSLAM_HIP_TRY(hipMemcpyAsync(d_planes, planes, (size_t)n_planes * 4 * sizeof(float), hipMemcpyHostToDevice, s->stream));
+  if (T0) {
+    SSLAM_HIP_TRY(hipMalloc((void**)&d_T0, (size_t)nf * 12 * sizeof(double)));
+    SSLAM_HIP_TRY(hipMemcpyAsync(d_T0, T0, (size_t)nf * 12 * sizeof(double), hipMemcpyHostToDevice, s->stream));
+  }
+  if (!s->q_e0) { SSLAM_HIP_TRY(hipEventCreate(&s->q_e0)); SSLAM_HIP_TRY(hipEventCreate(&s->q_e1)); }
+  SSLAM_HIP_TRY(hipEventRecord(s->q_e0, s->stream));
+  hipLaunchKernelGGL(k_icp_frames, dim3(nf), dim3(1024), 0, s->stream, s->V, (const unsigned char*)s->d_rflag, (const int*)d_fb0, (const int*)d_bp,
+                     (const float*)d_planes, n_planes, iterations, (const double*)d_T0, d_out);
+  SSLAM_HIP_TRY(hipGetLastError());
+  SSLAM_HIP_TRY(hipEventRecord(s->q_e1, s->stream));
+  std::vector<IcpFrame> res(nf);
+  SSLAM_HIP_TRY(hipMemcpyAsync(res.data(), d_out, (size_t)nf * sizeof(IcpFrame), hipMemcpyDeviceToHost, s->stream));
+  SSLAM_HIP_TRY(hipStreamSynchronize(s->stream));
+  if (kernel_ms) { float ms = 0; if (hipEventElapsedTime(&ms, s->q_e0, s->q_e1) == hipSuccess) *kernel_ms = ms; }
+  for (int f = 0; f < nf && f < max_out; ++f) {
+    for (int k = 0; k < 12; ++k) out[f].T[k] = res[f].T[k];
+    out[f].rms = res[f].rms; out[f].used = res[f].used; out[f].status = res[f].status;
+  }
+  return nf;
 }
 
 int sslam_seg_convex_hull_2d(sslam_seg* s, const float* xyz, int n, const int32_t* inliers, int n_inliers, const float coeff[4],

@@ -58,6 +58,17 @@ class DetectedObject:
 _BOUND = False
 
 
+class BoxPlane(C.Structure):
+    """``sslam_box_plane`` (include/sslam.h)"""
+    _fields_ = [("coeff", C.c_float * 4), ("inliers", C.c_int32), ("points", C.c_int32), ("box_index", C.c_int32), ("frame", C.c_int32),
+                ("hypotheses", C.c_int32), ("best_iteration", C.c_int32)]
+
+
+class IcpResult(C.Structure):
+    """``sslam_icp_result`` (include/sslam.h)"""
+    _fields_ = [("T", C.c_double * 12), ("rms", C.c_double), ("used", C.c_int32), ("status", C.c_int32)]
+
+
 def _bind(lib):
     global _BOUND
     if _BOUND:
@@ -88,6 +99,12 @@ def _bind(lib):
     lib.sslam_seg_statistical_outlier_removal.restype = ci
     lib.sslam_seg_statistical_outlier_removal.argtypes = [vp, vp, ci, ci, C.c_double, vp, ci, vp]
     lib.sslam_seg_kmeans.restype = ci; lib.sslam_seg_kmeans.argtypes = [vp, vp, ci, ci, ci, C.c_uint64, vp, vp, C.POINTER(C.c_double)]
+    lib.sslam_seg_ransac_boxes.restype = ci
+    lib.sslam_seg_ransac_boxes.argtypes = [vp, C.c_float, ci, C.c_double, C.c_uint64, vp, ci, C.POINTER(C.c_double)]
+    lib.sslam_seg_ransac_box_inliers.restype = ci
+    lib.sslam_seg_ransac_box_inliers.argtypes = [vp, ci, vp, ci]
+    lib.sslam_seg_icp_boxes.restype = ci
+    lib.sslam_seg_icp_boxes.argtypes = [vp, vp, ci, vp, ci, ci, vp, vp, ci, C.POINTER(C.c_double)]
     lib.sslam_seg_icp_point_to_plane.restype = ci
     lib.sslam_seg_icp_point_to_plane.argtypes = [vp, vp, vp, ci, vp, ci, ci, vp, vp, C.POINTER(C.c_double)]
     _BOUND = True
@@ -253,6 +270,33 @@ class PointCloudSegmentation:
         n = self._check(self._lib.sslam_seg_ransac_plane(self._h, pts.ctypes.data, len(pts), C.c_float(threshold), max_iterations,
                                                           C.c_double(probability), C.c_uint64(seed), coeff.ctypes.data, inl.ctypes.data, len(inl)))
         return coeff, inl[:n].copy()
+
+    def ransac_boxes(self, threshold: float = 0.01, max_iterations: int = 50, probability: float = 0.99, seed: int = 0, max_boxes: int = 4096):
+        """``sslam_seg_ransac_boxes``: RANSAC plane of every accepted box of the resident batch (the last ``segment_frames`` /
+        ``segmentallPointCloudData`` call), one workgroup per box.  Returns (list of BoxPlane records in slot order, kernel ms)."""
+        out = (BoxPlane * max_boxes)()
+        ms = C.c_double(0)
+        n = self._check(self._lib.sslam_seg_ransac_boxes(self._h, C.c_float(threshold), max_iterations, C.c_double(probability), C.c_uint64(seed),
+                                                          C.cast(out, C.c_void_p), max_boxes, C.byref(ms)))
+        return [out[k] for k in range(min(n, max_boxes))], ms.value
+
+    def ransac_box_inliers(self, slot: int, max_points: int = 640 * 480):
+        """ascending crop indices (row-major inside the box) of the inliers of box `slot`'s refined model"""
+        buf = np.zeros(max_points, np.int32)
+        n = self._check(self._lib.sslam_seg_ransac_box_inliers(self._h, slot, buf.ctypes.data, max_points))
+        return buf[:min(n, max_points)].copy()
+
+    def icp_boxes(self, box_plane, planes, iterations: int = 10, T0=None, max_frames: int = 1024):
+        """``sslam_seg_icp_boxes``: point-to-plane ICP per frame of the resident batch over the RANSAC inliers of its boxes; box slot q
+        measures plane box_plane[q] (-1: none).  Returns (list of IcpResult per frame, kernel ms)."""
+        bp = np.ascontiguousarray(box_plane, np.int32)
+        pl = np.ascontiguousarray(planes, np.float32).reshape(-1, 4)
+        t0 = None if T0 is None else np.ascontiguousarray(T0, np.float64).reshape(-1)
+        out = (IcpResult * max_frames)()
+        ms = C.c_double(0)
+        n = self._check(self._lib.sslam_seg_icp_boxes(self._h, bp.ctypes.data, len(bp), pl.ctypes.data, len(pl), iterations,
+                                                       None if t0 is None else t0.ctypes.data, C.cast(out, C.c_void_p), max_frames, C.byref(ms)))
+        return [out[k] for k in range(min(n, max_frames))], ms.value
 
     def convex_hull_2d(self, xyz, inliers, coeff):
         """pcl::ProjectInliers + 2-D pcl::ConvexHull of plane_segmentation::compute2DConvexHull (plane_segmentation.cpp:648-662).

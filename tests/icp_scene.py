@@ -24,3 +24,13 @@ def make_icp_scene(seed=0, n_per_plane=4000, noise=2e-3, angle=0.03, shift=0.05)
     lab[rng.random(len(lab)) < 0.05] = -1
     obs[rng.random(len(obs)) < 0.02] = np.nan
     return obs.astype(np.float32), lab.astype(np.int32), planes.astype(np.float32), np.concatenate([R.reshape(9), t])
+
+
+def small_motion(seed=0, angle=0.02, shift=0.03):
+    """a small rigid motion (R, t) for the batched ICP test"""
+    rng = np.random.default_rng(seed)
+    w = rng.normal(size=3); w *= angle / np.linalg.norm(w)
+    th = np.linalg.norm(w); K = np.array([[0, -w[2], w[1]], [w[2], 0, -w[0]], [-w[1], w[0], 0]])
+    R = np.eye(3) + np.sin(th) / th * K + (1 - np.cos(th)) / th ** 2 * K @ K
+    t = rng.normal(size=3); t *= shift / np.linalg.norm(t)
+    return R, t

@@ -172,15 +172,24 @@ def test_plan_with_tiny_pieces_exercises_every_phase(hip_lib):
 
 
 def test_small_graph_plan_is_all_tail_and_both_orderings_factor(hip_lib):
-    """A graph of <= small_cols block columns is walked by one workgroup from the leaves to the root (no per-depth launches: what the fused
-    LM kernel needs); both elimination orders (multiple minimum degree over independent sets, round 4; lowest-index minimum degree) give a
+    """SSLAM_CHOL_SMALL_COLS: a graph of <= small_cols block columns is walked by one workgroup from the leaves to the root (no per-depth
+    launches: what the fused LM kernel k_lm_trial_small needs; off by default); both elimination orders (multiple minimum degree over independent sets, round 4; lowest-index minimum degree) give a
     valid plan, and the new one a shallower tree."""
     g = make_graph(150, 30, seed=5)
-    plan, H, b = _plan_and_system(hip_lib, g, False)
+    plan, H, b = _plan_and_system(hip_lib, g, False, {"SSLAM_CHOL_SMALL_COLS": 1200})
     assert len(plan.plv_pieces) == 0 and len(plan.tail_pieces) == plan.npiece and plan.npiece >= 2
     _structure_invariants(plan)
     _check(plan, H, b, 1e-3)
     g2 = make_graph(600, 120, seed=3)
+    # every piece names the piece its update matrix goes to (PieceMeta.pad4): later in launch order, -1 only for roots -- what the
+    # dependency-driven launch (k_chol_flow) waits on
+    order_of = {int(p): k for k, p in enumerate(list(plan.plv_pieces) + list(plan.tail_pieces))}
+    par = plan.piece["pad4"]
+    assert (par >= -1).all() and (par == -1).sum() >= 1
+    for p, q in enumerate(par):
+        if q >= 0:
+            assert order_of[int(q)] > order_of[p]
+            assert plan.piece["nus"][p] + plan.piece["nuit"][p] >= 0
     lv = {}
     for order in ("mmd", "mindeg"):
         p2, H2, b2 = _plan_and_system(hip_lib, g2, False, {"SSLAM_CHOL_ORDER": order, "SSLAM_CHOL_SMALL_COLS": 0})

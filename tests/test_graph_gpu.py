@@ -603,36 +603,72 @@ def test_path_marginals_equal_the_multi_rhs_solves(gpu_lib):
         assert np.abs(a[(r, c)] - b[(r, c)]).max() <= 1e-10 * np.abs(Hinv).max()
 
 
-def test_fused_small_graph_trials_equal_the_unfused_path(gpu_lib):
-    """k_lm_trial_small (one launch per LM iteration of a small graph: factor, solve, update, chi2, accept / reject, retries) against the
-    stand-alone kernels: same iterations, same trials, bitwise the same estimates -- single graphs to termination (every damping retry
-    inside the kernel), with planes, and a batch of distinct small graphs; and both equal the oracle."""
-    from semantic_slam_amd import GraphSLAM, GraphBatch
+def _optimize_variant(gp, iters, env, fused):
+    import os
+    from semantic_slam_amd import GraphSLAM
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update({k: str(v) for k, v in env.items()})
+    try:
+        G = GraphSLAM.from_problem(gp)
+        G.set_option("fused_small_graph", fused)
+        assert G.optimize(iters)          # the plan is built inside, under `env`
+    finally:
+        for k, v in old.items():
+            if v is None: os.environ.pop(k)
+            else: os.environ[k] = v
+    return G.last_stats.iterations, G.last_stats.trials, G.last_stats.chi2_after, G.estimates().copy()
+
+
+def test_single_launch_solve_and_fused_steps_equal_the_stand_alone_kernels(gpu_lib):
+    """Round 4's launch-count work on small batches, against the round-3 launch sequence:
+    (a) default: Jacobian kernels + k_lm_begin_small + k_chol_flow (factor and both solves in one dependency-driven launch) + k_lm_end_small;
+    (b) the same plan with the stand-alone LM kernels round the single-launch solve -> bitwise (a);
+    (c) SSLAM_CHOL_FLOW=0: a launch per depth of the tree (other work-item cuts: same result up to rounding);
+    (d) SSLAM_CHOL_SMALL_COLS: the all-tail plan with k_lm_trial_small (every retry inside one launch) -> bitwise its own stand-alone run;
+    and all of them equal the oracle."""
     for (n, m, kind, iters) in [(120, 24, "point", 40), (80, 16, "plane", 12), (300, 60, "point", 10)]:
         g = make_graph(n, m, seed=11, landmark_kind=kind)
         gp = GraphProblem.from_synth(g, interleave=True)
-        res = []
-        for fused in (1, 0):
-            G = GraphSLAM.from_problem(gp)
-            G.set_option("fused_small_graph", fused)
-            assert G.optimize(iters)
-            res.append((G.last_stats.iterations, G.last_stats.trials, G.last_stats.chi2_after, G.estimates().copy()))
-        assert res[0][0] == res[1][0] and res[0][1] == res[1][1], (res[0][:3], res[1][:3])
-        assert res[0][2] == res[1][2] and np.array_equal(res[0][3], res[1][3])
+        a = _optimize_variant(gp, iters, {}, 1)
+        b = _optimize_variant(gp, iters, {}, 0)
+        c = _optimize_variant(gp, iters, {"SSLAM_CHOL_FLOW": 0}, 0)
+        d1 = _optimize_variant(gp, iters, {"SSLAM_CHOL_SMALL_COLS": 1200, "SSLAM_CHOL_FLOW": 0}, 1)
+        d0 = _optimize_variant(gp, iters, {"SSLAM_CHOL_SMALL_COLS": 1200, "SSLAM_CHOL_FLOW": 0}, 0)
+        assert a[:3] == b[:3] and np.array_equal(a[3], b[3]), (a[:3], b[:3])
+        assert d1[:3] == d0[:3] and np.array_equal(d1[3], d0[3]), (d1[:3], d0[:3])
         st = gp.optimize(iters)
-        assert abs(res[0][2] - st.chi2_after) <= 1e-8 * st.chi2_after
-    gs = [[GraphSLAM.from_synth(make_graph(90 + 7 * k, 18 + k, seed=20 + k)) for k in range(6)] for _ in range(2)]
+        for r in (a, c, d1):
+            assert abs(r[2] - st.chi2_after) <= 1e-8 * st.chi2_after
+            assert np.abs(r[3] - gp.est).max() <= 1e-5 * np.abs(gp.est).max()
+        gp = GraphProblem.from_synth(g, interleave=True)   # gp.optimize moved the estimates: fresh problem for the next size
+
+
+def test_single_launch_solve_on_the_L_graph_and_a_small_batch(gpu_lib):
+    """k_chol_flow with more pieces than workgroups (one 5000-pose graph: ~1500 pieces over a persistent grid) and on a batch of four
+    distinct graphs: same chi2 / estimates as the launch-per-depth path up to rounding."""
+    import os
+    from semantic_slam_amd import GraphSLAM, GraphBatch
+    g = make_graph(5000, 1000, seed=2)
+    gp = GraphProblem.from_synth(g)
+    a = _optimize_variant(gp, 4, {}, 1)
+    c = _optimize_variant(gp, 4, {"SSLAM_CHOL_FLOW": 0}, 0)
+    assert a[0] == c[0] and abs(a[2] - c[2]) <= 1e-9 * c[2]
+    assert np.abs(a[3] - c[3]).max() <= 1e-7 * np.abs(c[3]).max()
     out = []
-    for fused, graphs in zip((1, 0), gs):
-        for G in graphs:
-            G.set_option("fused_small_graph", fused)
-        bt = GraphBatch(graphs); bt.upload()
-        st = bt.optimize(15)
-        bt.download()
-        out.append(([(int(s.iterations), int(s.trials), float(s.chi2_after)) for s in st], [G.estimates().copy() for G in graphs]))
-    assert out[0][0] == out[1][0]
-    for a, b in zip(out[0][1], out[1][1]):
-        assert np.array_equal(a, b)
+    for flow in (1, 0):
+        os.environ["SSLAM_CHOL_FLOW"] = str(flow)
+        try:
+            graphs = [GraphSLAM.from_synth(make_graph(90 + 7 * k, 18 + k, seed=20 + k)) for k in range(4)]
+            bt = GraphBatch(graphs); bt.upload()
+            st = bt.optimize(15)
+            bt.download()
+        finally:
+            os.environ.pop("SSLAM_CHOL_FLOW")
+        out.append(([(int(s.iterations), float(s.chi2_after)) for s in st], [G.estimates().copy() for G in graphs]))
+    for (ia, ca), (ib, cb) in zip(out[0][0], out[1][0]):
+        assert abs(ca - cb) <= 1e-9 * cb
+    for x, y in zip(out[0][1], out[1][1]):
+        assert np.abs(x - y).max() <= 1e-6 * np.abs(y).max()
 
 
 @pytest.mark.parametrize("kind", ["point", "plane"])

@@ -465,3 +465,86 @@ def test_kmeans_and_legacy_cluster_path_match_oracle(gpu_lib):
     dists = sorted(set(np.round(rows[:, 6].astype(np.float64), 1).tolist()))
     assert np.allclose(dists, [0.4, 1.0])                                 # -(n . p): the table top at z = -0.4 and the floor at z = -1
     assert np.all(np.abs(rows[:, 3:6] - [0, 0, 1]) < 0.05)
+
+
+def test_ransac_and_icp_over_the_boxes_of_a_batch_match_the_oracle(gpu_lib):
+    """BASELINE.json configs[3] (640x480 cloud, 32 boxes of 128x96 per frame, "RANSAC+ICP plane extraction"): sslam_seg_ransac_boxes on the
+    crops the segmentation left on the device -- refined coefficients, inlier counts, consumed hypotheses and the inlier index sets of every
+    box BIT-EXACT against oracle_seg.c's os_ransac_plane run on the same crop with the same per-box seed -- then sslam_seg_icp_boxes per
+    frame over those inliers against NumPy's point-to-plane ICP (1e-9: double sums in another order)."""
+    from semantic_slam_amd.segmentation import PointCloudSegmentation
+    from oracle.np_icp import icp_point_to_plane
+    frames = [make_frame(seed=s) for s in (0, 1)]
+    seg = PointCloudSegmentation()
+    seg.segment_frames(frames)
+    seed = 12345
+    recs, ms = seg.ransac_boxes(0.01, 50, 0.99, seed)
+    assert len(recs) == 64 and ms > 0
+    GOLD = 0x9E3779B97F4A7C15
+    crops, inl_ref = [], []
+    nonzero = 0
+    for q, r in enumerate(recs):
+        f = frames[r.frame]; b = f.boxes[r.box_index]
+        crop = np.ascontiguousarray(f.xyz()[b["tl_y"]:b["tl_y"] + b["height"], b["tl_x"]:b["tl_x"] + b["width"]].reshape(-1, 3))
+        assert r.points == len(crop) == 128 * 96 and r.frame == q // 32
+        rc, ri = _oracle_ransac(crop, 0.01, 50, 0.99, (seed + q * GOLD) % (1 << 64))
+        assert np.array_equal(np.array(r.coeff[:], np.float32), rc), (q, r.coeff[:], rc)
+        assert r.inliers == len(ri)
+        if q % 5 == 0 or q in (31, 32, 63):                                  # the index sets of a sample of boxes (a D2H copy each)
+            assert np.array_equal(seg.ransac_box_inliers(q), ri)
+        nonzero += r.inliers > 500
+        crops.append(crop); inl_ref.append(ri)
+    assert nonzero >= 48                                                       # the scene is piecewise planar: most boxes hold a plane
+    # ICP: every box measures its own RANSAC plane moved by a small known motion -> the motion comes back; identical to the NumPy oracle
+    from tests.icp_scene import small_motion
+    Rm, tm = small_motion(3)
+    planes, box_plane = [], []
+    for q, r in enumerate(recs):
+        n = np.array(r.coeff[:3], np.float64); d = float(r.coeff[3])
+        if r.inliers > 500 and abs(np.linalg.norm(n) - 1) < 1e-3:
+            n2 = Rm @ n; planes.append(np.concatenate([n2, [d - n2 @ tm]])); box_plane.append(len(planes) - 1)   # plane of the moved points R p + t
+        else:
+            box_plane.append(-1)
+    planes = np.array(planes, np.float32)
+    res, ms2 = seg.icp_boxes(box_plane, planes, 6)
+    assert len(res) == 2 and ms2 > 0
+    for f in range(2):
+        pts = np.concatenate([crops[q][inl_ref[q]] for q in range(32 * f, 32 * f + 32)])
+        lab = np.concatenate([np.full(len(inl_ref[q]), box_plane[q], np.int32) for q in range(32 * f, 32 * f + 32)])
+        To, rmso, no = icp_point_to_plane(pts, lab, planes, 6)
+        T = np.array(res[f].T[:])
+        assert res[f].status == 0 and res[f].used == no
+        assert np.abs(T - To).max() <= 1e-9 and abs(res[f].rms - rmso) <= 1e-9
+        assert np.abs(T[:9].reshape(3, 3) - Rm).max() < 5e-3 and np.abs(T[9:] - tm).max() < 2e-2
+    # no plane constrains anything: refused per frame, not a hang; a batch without RANSAC flags is refused
+    res3, _ = seg.icp_boxes([0] + [-1] * 63, planes, 3)
+    assert res3[0].status == -4 and res3[1].used == 0
+    seg.segment_frames(frames[:1])
+    from semantic_slam_amd import SslamError
+    with pytest.raises(SslamError):
+        seg.icp_boxes([-1] * 32, planes, 1)
+
+
+def test_ransac_boxes_edge_cases(gpu_lib):
+    """boxes larger than the LDS staging limit (points read through L2), a box of NaNs only, a tiny batch"""
+    from semantic_slam_amd.segmentation import PointCloudSegmentation, default_params
+    from semantic_slam_amd.synth import BOX_DTYPE
+    f = make_frame(seed=4, n_boxes=3, box_w=200, box_h=150)                    # 30,000 points per box: above the ~12,400 that fit in LDS
+    p = default_params(); p.norm_point_thres = 100
+    seg = PointCloudSegmentation(params=p)
+    seg.segment_frames([f])
+    recs, _ = seg.ransac_boxes(0.01, 50, 0.99, 7)
+    assert len(recs) == 3
+    for q, r in enumerate(recs):
+        b = f.boxes[r.box_index]
+        crop = np.ascontiguousarray(f.xyz()[b["tl_y"]:b["tl_y"] + b["height"], b["tl_x"]:b["tl_x"] + b["width"]].reshape(-1, 3))
+        rc, ri = _oracle_ransac(crop, 0.01, 50, 0.99, (7 + q * 0x9E3779B97F4A7C15) % (1 << 64))
+        assert np.array_equal(np.array(r.coeff[:], np.float32), rc) and r.inliers == len(ri)
+        assert np.array_equal(seg.ransac_box_inliers(q), ri)
+    g = make_frame(seed=5, n_boxes=2, box_w=40, box_h=30)
+    xyz = g.xyz(); b0 = g.boxes[0]
+    xyz[b0["tl_y"]:b0["tl_y"] + b0["height"], b0["tl_x"]:b0["tl_x"] + b0["width"]] = np.nan     # writes through to the frame's cloud
+    seg.segment_frames([g])
+    recs, _ = seg.ransac_boxes(0.01, 20, 0.99, 1)
+    assert len(recs) == 2 and recs[0].inliers == 0 and not any(recs[0].coeff[:]) and recs[0].best_iteration == -1
+    assert len(seg.ransac_box_inliers(0)) == 0
