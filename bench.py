@@ -31,7 +31,7 @@ PEAK_HBM_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E ~8 TB/s
 def pmc_traffic(name, algorithmic_bytes):
     """HBM bytes per launch from the committed PMC passes (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs,
     FETCH x2 on gfx950 per MI355X_MICROARCH.md); only quoted when the profiled workload had the same algorithmic bytes."""
-    for rnd in ("r3", "r2", "r1"):
+    for rnd in ("r4", "r3", "r2", "r1"):
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", f"{rnd}_pmc_{name}.json")))
         except (OSError, ValueError):
@@ -340,7 +340,7 @@ def main():
     ap.add_argument("--poses", type=int, default=5000)
     ap.add_argument("--landmarks", type=int, default=1000)
     ap.add_argument("--distinct", type=int, default=-1, help="distinct seeds generated per rank (tiled to --batch); -1 = one per graph of the batch")
-    ap.add_argument("--plane-distinct", type=int, default=64, help="distinct seeds of the plane-landmark leg (tiled to --plane-batch)")
+    ap.add_argument("--plane-distinct", type=int, default=-1, help="distinct seeds of the plane-landmark leg (tiled to --plane-batch); -1 = one per graph")
     ap.add_argument("--cache-dir", default=os.environ.get("SSLAM_BENCH_CACHE", os.path.join(tempfile.gettempdir(), "sslam_bench_cache")))
     ap.add_argument("--solver", type=int, default=-1, help="-1 library default, 0 PCG, 1 sparse Cholesky")
     ap.add_argument("--streams", type=int, default=4,
@@ -583,7 +583,8 @@ def main():
         if args.plane_batch > 0 and world == 1:
             # ---- plane landmarks (BASELINE.json metric: "5k poses, 1k planes"): VertexPlane + EdgeSE3Plane, numeric Jacobians
             try:
-                ppaths = generate_graphs("plane", args.poses, args.landmarks, seeds_of(max(1, min(args.plane_distinct, args.plane_batch))), args.cache_dir)
+                n_pd = args.plane_batch if args.plane_distinct < 0 else max(1, min(args.plane_distinct, args.plane_batch))
+                ppaths = generate_graphs("plane", args.poses, args.landmarks, seeds_of(n_pd), args.cache_dir)
                 pb = build_batch(ppaths, args.plane_batch, dev, args.solver)
                 if n_streams > 1:   # the same stream group as the headline
                     pb = GraphBatch(pb.graphs, streams=min(n_streams, args.plane_batch))

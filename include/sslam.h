@@ -102,7 +102,10 @@ int sslam_graph_hessian_index(sslam_graph* g, int id);
 
 /* Options (doubles): "solver" 1 = sparse block Cholesky (default; what "lm_var" + csparse selects in the reference),
  * 0 = block-Jacobi PCG on the full system, 2 = Schur complement on the landmark block + PCG on the reduced pose system (matrix-free;
- * BASELINE.json north_star), 3 = sparse block Cholesky with the window plan (csrc/wchol_plan.hpp: register-resident sliding fronts;
+ * BASELINE.json north_star).  SOLVER 2 IS S-SCALE ONLY: its preconditioner is block-Jacobi, and on a long pose chain with the reference's
+ * odometry information (1 / 0.00001 on the rotation block against 2.5 on a landmark, config/bucket_detector.yaml:22-27) the reduced
+ * system needs ~1,050 CG iterations per damping trial at 5000 poses (157 ms, against 1.5 ms for the direct solver) -- it converges to the
+ * same optimum (tests: S config) but is not a solver for the L configuration; use 1.  3 = sparse block Cholesky with the window plan (csrc/wchol_plan.hpp: register-resident sliding fronts;
  * correct, leaner in traffic, slower than 1 on today's kernels); "pcg_tol" relative residual; "pcg_max_iters";
  * "robust_kernel_dcs" = phi > 0: g2o::RobustKernelDCS(delta = phi) on every landmark edge (EdgeSE3PointXYZ / EdgeSE3Plane), as
  * graph_slam.cpp:155,161 intends (opt-in, phi = 1 is g2o's default delta); 0 = no kernel (default);
