@@ -74,6 +74,8 @@ struct CholPlan {
   // dependency-driven factorisation + solve in ONE launch (k_chol_flow): small batches only
   bool flow = false;            // the plan can run it (every piece has one parent piece; nt_leaf == nt_tail)
   int flow_grid = 0;            // persistent workgroups
+  int flow_first = 0;           // first launch-order piece of the single launch; the per-depth launches [0, flow_launch0) come before it
+  int flow_launch0 = 0;
   int flow_epoch = 0;           // launches so far: the counters are never reset, a launch waits for epoch * (children)
   int2* d_dep = nullptr;        // per launch-order piece: {parent (launch order) or -1, children}
   int* d_flow = nullptr;        // [children done | backward done | forward done] per piece, then [0] error flag at 3 * npiece
@@ -1205,7 +1207,7 @@ __device__ __forceinline__ bool flow_wait(const int* p, int target, int* err) {
   return true;
 }
 template <int NT, bool USTAGE>
-__global__ __launch_bounds__(NT) void k_chol_flow(BatchView V, CholView C, int np, int epoch, const int2* __restrict__ dep, int* flow) {
+__global__ __launch_bounds__(NT) void k_chol_flow(BatchView V, CholView C, int q_first, int np, int epoch, const int2* __restrict__ dep, int* flow) {
   extern __shared__ double sm[];
   const int tid = threadIdx.x;
   int* child_done = flow;
@@ -1213,7 +1215,9 @@ __global__ __launch_bounds__(NT) void k_chol_flow(BatchView V, CholView C, int n
   int* fwd_done = flow + 2 * np;
   int* err = flow + 3 * np;
   // ---- (H + lambda I) = L L^T and y = L^-1 b, leaves to roots
-  for (int q = blockIdx.x; q < np; q += gridDim.x) {
+  // (pieces before q_first -- the wide bottom of a large graph's tree -- were factored by per-depth launches before this one; dep[].y counts
+  // the children inside [q_first, np) only)
+  for (int q = q_first + blockIdx.x; q < np; q += gridDim.x) {
     const PieceMeta pm = C.lpiece[q];
     const int2 d = dep[q];
     if (d.y > 0) {
@@ -1234,7 +1238,7 @@ __global__ __launch_bounds__(NT) void k_chol_flow(BatchView V, CholView C, int n
     }
   }
   // ---- x = L^-T y, roots to leaves
-  for (int i = blockIdx.x; i < np; i += gridDim.x) {
+  for (int i = blockIdx.x; i < np - q_first; i += gridDim.x) {
     const int q = np - 1 - i;
     const PieceMeta pm = C.lpiece[q];
     const int2 d = dep[q];
@@ -1404,14 +1408,6 @@ int chol_plan_build(Batch& b) {
     C.dbg = (long long*)p;
     SSLAM_HIP_TRY(hipMemsetAsync(p, 0, 48 * sizeof(long long), b.stream));
   }
-  if (P->flow) {
-    if ((rc = up_to_dev(*P, b.stream, dep, (const int2**)&P->d_dep))) return rc;
-    const size_t nints = 3 * dep.size() + 8;
-    if ((rc = plan_alloc(&p, nints * sizeof(int)))) return rc;
-    P->d_flow = (int*)p;
-    SSLAM_HIP_TRY(hipMemsetAsync(p, 0, nints * sizeof(int), b.stream));
-    P->flow_epoch = 0;
-  }
   // index lists of the LM endgame (chol_set_active), sized once: no allocation inside an optimize call (a stream group runs several of
   // them side by side)
   if (b.V.B >= 8 && !P->d_idx) {
@@ -1453,7 +1449,26 @@ int chol_plan_build(Batch& b) {
     const void* fn = P->ustage ? (const void*)k_chol_flow<512, true> : (const void*)k_chol_flow<512, false>;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 512, lds_max) != hipSuccess || per_cu < 1 ||
         hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, b.device) != hipSuccess || cus < 1) P->flow = false;
-    else P->flow_grid = std::max(1, std::min((int)dep.size(), per_cu * cus / 2));
+    else {
+      // the wide bottom of a large tree keeps its per-depth launches (hundreds of independent pieces fill the chip at once; a persistent
+      // grid would walk them in rounds): the single launch starts at the first depth that is no wider than its grid
+      const int cap = std::max(1, per_cu * cus / 2);
+      int l0 = 0;
+      while (l0 < (int)P->plv_lds_f.size() && P->plv_ptr[l0 + 1] - P->plv_ptr[l0] > cap) ++l0;
+      P->flow_launch0 = l0;
+      P->flow_first = l0 < (int)P->plv_ptr.size() ? P->plv_ptr[l0] : 0;
+      P->flow_grid = std::max(1, std::min((int)dep.size() - P->flow_first, cap));
+      if (P->flow_first > 0) {   // children that the launches finish are not waited for
+        for (auto& d2 : dep) d2.y = 0;
+        for (int i = P->flow_first; i < (int)dep.size(); ++i) if (dep[i].x >= 0) dep[dep[i].x].y++;
+      }
+      if ((rc = up_to_dev(*P, b.stream, dep, (const int2**)&P->d_dep))) return rc;
+      const size_t nints = 3 * dep.size() + 8;
+      if ((rc = plan_alloc(&p, nints * sizeof(int)))) return rc;
+      P->d_flow = (int*)p;
+      SSLAM_HIP_TRY(hipMemsetAsync(p, 0, nints * sizeof(int), b.stream));
+      P->flow_epoch = 0;
+    }
   }
   if (P->arena && P->arena->flush(b.stream)) return set_error(SSLAM_ERR_HIP, "upload of the plan tables failed");
   SSLAM_HIP_TRY(hipStreamSynchronize(b.stream));
@@ -1462,6 +1477,28 @@ int chol_plan_build(Batch& b) {
 
 // (H + lambda I) dx = b in ONE launch (k_chol_flow) for plans that allow it; false: the caller takes the launch-per-depth path
 bool chol_plan_flow(const Batch& b) { return b.chol && b.chol->flow && !b.chol->compact; }
+// the launches of one solve: per-depth launches over the wide bottom of the tree, the dependency-driven launch over the rest (factor and
+// both substitutions), per-depth launches of the backward substitution over the bottom again
+static void flow_launches(Batch& b) {
+  CholPlan& P = *b.chol;
+  const CholView& C = P.C;
+  size_t lds = (size_t)std::max(P.tail_lds_f, P.tail_lds_b);
+  for (size_t l = 0; l < P.plv_lds_f.size(); ++l) lds = std::max(lds, (size_t)std::max(P.plv_lds_f[l], P.plv_lds_b[l]));
+  lds *= sizeof(double);
+  const int np = (int)P.lp_graph.size();
+  for (int l = 0; l < P.flow_launch0; ++l) {
+    const int n = P.plv_ptr[l + 1] - P.plv_ptr[l];
+    if (P.ustage) hipLaunchKernelGGL((k_chol_pieces<512, true>), dim3(n), dim3(512), (size_t)P.plv_lds_f[l] * sizeof(double), b.stream, b.V, C, P.plv_ptr[l], (const int*)nullptr);
+    else hipLaunchKernelGGL((k_chol_pieces<512, false>), dim3(n), dim3(512), (size_t)P.plv_lds_f[l] * sizeof(double), b.stream, b.V, C, P.plv_ptr[l], (const int*)nullptr);
+  }
+  ++P.flow_epoch;
+  if (P.ustage) hipLaunchKernelGGL((k_chol_flow<512, true>), dim3(P.flow_grid), dim3(512), lds, b.stream, b.V, C, P.flow_first, np, P.flow_epoch, (const int2*)P.d_dep, P.d_flow);
+  else hipLaunchKernelGGL((k_chol_flow<512, false>), dim3(P.flow_grid), dim3(512), lds, b.stream, b.V, C, P.flow_first, np, P.flow_epoch, (const int2*)P.d_dep, P.d_flow);
+  for (int l = P.flow_launch0 - 1; l >= 0; --l) {
+    const int n = P.plv_ptr[l + 1] - P.plv_ptr[l];
+    hipLaunchKernelGGL(k_chol_back_pieces<512>, dim3(n), dim3(512), (size_t)P.plv_lds_b[l] * sizeof(double), b.stream, C, P.plv_ptr[l], (const double*)C.y, b.V.x, (const LmState*)b.V.lm, (const int*)nullptr);
+  }
+}
 int chol_solve_flow(Batch& b) {
   CholPlan& P = *b.chol;
   P.C.flat_L = 0;
@@ -1472,9 +1509,7 @@ int chol_solve_flow(Batch& b) {
   lds *= sizeof(double);
   const int np = (int)P.lp_graph.size();
   hipLaunchKernelGGL(k_chol_begin, dim3((b.V.B + 63) / 64), dim3(64), 0, b.stream, b.V, C);
-  ++P.flow_epoch;
-  if (P.ustage) hipLaunchKernelGGL((k_chol_flow<512, true>), dim3(P.flow_grid), dim3(512), lds, b.stream, b.V, C, np, P.flow_epoch, (const int2*)P.d_dep, P.d_flow);
-  else hipLaunchKernelGGL((k_chol_flow<512, false>), dim3(P.flow_grid), dim3(512), lds, b.stream, b.V, C, np, P.flow_epoch, (const int2*)P.d_dep, P.d_flow);
+  flow_launches(b);
   hipLaunchKernelGGL(k_chol_end, dim3((b.V.B + 63) / 64), dim3(64), 0, b.stream, b.V, C);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return set_error(SSLAM_ERR_HIP, "cholesky flow launch: %s", hipGetErrorString(e));
@@ -1490,9 +1525,7 @@ int chol_lm_step_flow(Batch& b, int max_iters) {
   lds *= sizeof(double);
   const int np = (int)P.lp_graph.size();
   hipLaunchKernelGGL(k_lm_begin_small<512>, dim3(b.V.B), dim3(512), 0, b.stream, b.V, C);
-  ++P.flow_epoch;
-  if (P.ustage) hipLaunchKernelGGL((k_chol_flow<512, true>), dim3(P.flow_grid), dim3(512), lds, b.stream, b.V, C, np, P.flow_epoch, (const int2*)P.d_dep, P.d_flow);
-  else hipLaunchKernelGGL((k_chol_flow<512, false>), dim3(P.flow_grid), dim3(512), lds, b.stream, b.V, C, np, P.flow_epoch, (const int2*)P.d_dep, P.d_flow);
+  flow_launches(b);
   hipLaunchKernelGGL(k_lm_end_small<512>, dim3(b.V.B), dim3(512), 0, b.stream, b.V, C, b.d_part_e, max_iters);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return set_error(SSLAM_ERR_HIP, "LM step launch: %s", hipGetErrorString(e));

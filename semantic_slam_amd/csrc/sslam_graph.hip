@@ -384,8 +384,8 @@ __global__ __launch_bounds__(kRowThreads) void k_linearize_rowthread_handover(Ba
 // above (SSLAM_LIN_HANDOVER=1) evaluates a chain edge once and is as fast (1.97 vs 2.0 ms per 512-graph build), but adds the handed
 // block last; LM's accept / reject decisions at convergence follow the last bit of H, and on the bench's seeds that order costs 13
 // extra rejected trials per 20 iterations.
-template <bool PL, bool SHARD>
-__global__ __launch_bounds__(kRowThreads) void k_linearize_rowthread(BatchView V) {
+template <bool PL, bool SHARD, int WPE>
+__global__ __launch_bounds__(kRowThreads, WPE) void k_linearize_rowthread(BatchView V) {
   __shared__ double accD[27][kRowThreads];
   const int tid = threadIdx.x;
   const int row = blockIdx.x * kRowThreads + tid;
@@ -1577,11 +1577,14 @@ static int batch_linearize(Batch& b) {
   static const int lin_dbg = [] { const char* e = getenv("SSLAM_LIN_DBG"); return e ? atoi(e) : 0; }();
   b.V.dbg = lin_dbg;
   static const int lin_handover = [] { const char* e = getenv("SSLAM_LIN_HANDOVER"); return e ? atoi(e) : 0; }();
+  static const int lin_wpe = [] { const char* e = getenv("SSLAM_LIN_WPE"); return e ? atoi(e) : 1; }();   // waves per SIMD the pose-row kernel is compiled for
 #define SSLAM_LAUNCH_LIN(PLV, SHV)                                                                                                    \
   {                                                                                                                                   \
     if (V.nPr > 0) {                                                                                                                  \
       if (lin_handover) hipLaunchKernelGGL((k_linearize_rowthread_handover<PLV, SHV>), dim3(nblk), dim3(kRowThreads), 0, b.stream, V); \
-      else hipLaunchKernelGGL((k_linearize_rowthread<PLV, SHV>), dim3(nblk), dim3(kRowThreads), 0, b.stream, V);                      \
+      else if (lin_wpe == 2) hipLaunchKernelGGL((k_linearize_rowthread<PLV, SHV, 2>), dim3(nblk), dim3(kRowThreads), 0, b.stream, V); \
+      else if (lin_wpe == 3) hipLaunchKernelGGL((k_linearize_rowthread<PLV, SHV, 3>), dim3(nblk), dim3(kRowThreads), 0, b.stream, V); \
+      else hipLaunchKernelGGL((k_linearize_rowthread<PLV, SHV, 1>), dim3(nblk), dim3(kRowThreads), 0, b.stream, V);                   \
     }                                                                                                                                 \
     if (V.nLr > 0) hipLaunchKernelGGL((k_linearize_lm_rows<PLV, SHV>), dim3((V.nLr + 15) / 16), dim3(256), 0, b.stream, V);           \
     if (V.nLL > 0) hipLaunchKernelGGL((k_linearize_ll<SHV>), dim3((V.nLL + 63) / 64), dim3(64), 0, b.stream, V);                      \
