@@ -649,13 +649,26 @@ inline int chol_symbolic(const SymIn& in, CholOpts opt, CholHost& out) {
   bool right_ok = true;
   std::vector<int> piece_pmax(npiece, 0);   // most partial tiles any phase of the piece needs
   int64_t ucur = 0;
+  // scratch of the piece loop, allocated once (the loop runs per tick of the orchestrator: no allocation per piece)
+  struct UB { int comp, a, b; };
+  struct OwnRec { int blk, ua, ubo, k; };
+  struct SrcRec { int blk; AsmSrc s; };
+  struct IU { int t, ua, ub2, k; };
+  struct AsmRec { int t; AsmSrc s; };
+  std::vector<UB> ub;
+  std::vector<int> comps, ctab_base, ctab, rix, iu_ptr, as_ptr, own_ptr, src_ptr, cur1, cur2, cur3, cur4, bi0, bi1, order, uoffs;
+  std::vector<OwnRec> own_flat, own_s;
+  std::vector<SrcRec> src_flat;
+  std::vector<IU> iu_flat, iu_s;
+  std::vector<AsmRec> asm_flat;
+  std::vector<AsmSrc> as_s, src_s;
   for (int p = 0; p < npiece; ++p) {
     PieceMeta& pm = out.piece[p];
     const int nt = piece_tail[p] ? opt.nt_tail : opt.nt_leaf;
     const int slots = nt / 4;
     const int pcap = piece_tail[p] ? opt.pcap_tail : opt.pcap_leaf;   // partial tiles a phase may use (LDS: 336 B each)
     // boundary rows of every component of the group
-    std::vector<int> comps;
+    comps.clear();
     for (int j = pm.c0; j < pm.c0 + pm.nc; ++j) {
       if (comps.empty() || std::find(comps.begin(), comps.end(), col_comp[j]) == comps.end()) comps.push_back(col_comp[j]);
       std::vector<int>& R = comp_R[col_comp[j]];
@@ -671,11 +684,10 @@ inline int chol_symbolic(const SymIn& in, CholOpts opt, CholHost& out) {
     // Flat records instead of per-block containers (the host plan is rebuilt every tick of the orchestrator: this loop was 75 % of it):
     // a block is found through a dense lower-triangular table over its component's boundary rows, contributions are appended to flat
     // lists and grouped by block with a stable counting sort afterwards -> every list keeps the order it was generated in.
-    struct UB { int comp, a, b; };
-    std::vector<UB> ub;
-    std::vector<int> ctab_base(comps.size() + 1, 0);
+    ub.clear();
+    ctab_base.assign(comps.size() + 1, 0);
     for (size_t ci = 0; ci < comps.size(); ++ci) { const int r = (int)comp_R[comps[ci]].size(); ctab_base[ci + 1] = ctab_base[ci] + r * (r + 1) / 2; }
-    std::vector<int> ctab(ctab_base.back(), -1);
+    ctab.assign(ctab_base.back(), -1);
     auto ublock = [&](int comp, int a, int b2) -> int {
       const int ci = (int)(std::lower_bound(comps.begin(), comps.end(), comp) - comps.begin());
       const std::vector<int>& R = comp_R[comp];
@@ -684,14 +696,9 @@ inline int chol_symbolic(const SymIn& in, CholOpts opt, CholHost& out) {
       if (slot < 0) { slot = (int)ub.size(); ub.push_back(UB{comp, a, b2}); }
       return slot;
     };
-    struct OwnRec { int blk, ua, ubo, k; };
-    struct SrcRec { int blk; AsmSrc s; };
-    std::vector<OwnRec> own_flat;
-    std::vector<SrcRec> src_flat;
+    own_flat.clear(); src_flat.clear();
     // internal updates (target column in the piece) and own update-matrix contributions (both rows above the piece)
-    struct IU { int t, ua, ub2, k; };
-    std::vector<IU> iu_flat;   // generation order: ascending source column k
-    std::vector<int> rix;      // per column: position of its rows above the piece in the boundary list of its component
+    iu_flat.clear();   // generation order: ascending source column k; rix: per column, position of its rows above the piece in the boundary list of its component
     for (int k = pm.c0; k < pm.c0 + pm.nc; ++k) {
       const int k0 = bp[k] + 1, kin = bp[k] + col_nbi[k], k1 = bp[k + 1];
       const std::vector<int>& Rk = comp_R[col_comp[k]];
@@ -737,8 +744,7 @@ inline int chol_symbolic(const SymIn& in, CholOpts opt, CholHost& out) {
       }
     }
     // what the children hand up: absorbed into a column of this piece (assembly) or passed on (update matrix)
-    struct AsmRec { int t; AsmSrc s; };
-    std::vector<AsmRec> asm_flat;
+    asm_flat.clear();
     for (const URec& u : inbox[p]) {
       if (col_piece[u.b] == p) {
         const int t = find_blk(u.b, u.a);
@@ -753,18 +759,17 @@ inline int chol_symbolic(const SymIn& in, CholOpts opt, CholHost& out) {
     }
     std::vector<URec>().swap(inbox[p]);
     // group the flat lists (stable): internal updates and assembly sources by target block, own / child contributions by U block
-    std::vector<int> iu_ptr(pm.nb + 1, 0), as_ptr(pm.nb + 1, 0), own_ptr(ub.size() + 1, 0), src_ptr(ub.size() + 1, 0);
+    iu_ptr.assign(pm.nb + 1, 0); as_ptr.assign(pm.nb + 1, 0); own_ptr.assign(ub.size() + 1, 0); src_ptr.assign(ub.size() + 1, 0);
     for (auto& r : iu_flat) iu_ptr[r.t - pm.b0 + 1]++;
     for (auto& r : asm_flat) as_ptr[r.t - pm.b0 + 1]++;
     for (auto& r : own_flat) own_ptr[r.blk + 1]++;
     for (auto& r : src_flat) src_ptr[r.blk + 1]++;
     for (int t = 0; t < pm.nb; ++t) { iu_ptr[t + 1] += iu_ptr[t]; as_ptr[t + 1] += as_ptr[t]; }
     for (size_t q = 0; q < ub.size(); ++q) { own_ptr[q + 1] += own_ptr[q]; src_ptr[q + 1] += src_ptr[q]; }
-    std::vector<IU> iu_s(iu_flat.size());
-    std::vector<AsmSrc> as_s(asm_flat.size()), src_s(src_flat.size());
-    std::vector<OwnRec> own_s(own_flat.size());
+    iu_s.resize(iu_flat.size()); as_s.resize(asm_flat.size()); src_s.resize(src_flat.size()); own_s.resize(own_flat.size());
     {
-      std::vector<int> c1(iu_ptr.begin(), iu_ptr.end() - 1), c2(as_ptr.begin(), as_ptr.end() - 1), c3(own_ptr.begin(), own_ptr.end() - 1), c4(src_ptr.begin(), src_ptr.end() - 1);
+      std::vector<int>&c1 = cur1, &c2 = cur2, &c3 = cur3, &c4 = cur4;
+      c1.assign(iu_ptr.begin(), iu_ptr.end() - 1); c2.assign(as_ptr.begin(), as_ptr.end() - 1); c3.assign(own_ptr.begin(), own_ptr.end() - 1); c4.assign(src_ptr.begin(), src_ptr.end() - 1);
       for (auto& r : iu_flat) iu_s[c1[r.t - pm.b0]++] = r;
       for (auto& r : asm_flat) as_s[c2[r.t - pm.b0]++] = r.s;
       for (auto& r : own_flat) own_s[c3[r.blk]++] = r;
@@ -783,7 +788,7 @@ inline int chol_symbolic(const SymIn& in, CholOpts opt, CholHost& out) {
     pm.nas = (int)out.asrc.size() - pm.as0;
     // internal update records of the piece, level by level / block by block; internal items
     pm.iu0 = (int)out.upd.size();
-    std::vector<int> bi0(pm.nb, 0), bi1(pm.nb, 0);
+    bi0.assign(pm.nb, 0); bi1.assign(pm.nb, 0);
     for (int t = pm.b0; t < pm.b0 + pm.nb; ++t) {
       const int j = block_col[t];
       const int tpk = (col_dim[brow[t]] == 6 ? kUpdDi6 : 0) | (t == bp[j] ? kUpdDiag : 0) | (col_dim[j] == 6 ? kUpdDj6 : 0);
@@ -844,8 +849,7 @@ inline int chol_symbolic(const SymIn& in, CholOpts opt, CholHost& out) {
     if (pm.nilv > kMaxILevels) { out.error = "a piece has too many internal levels"; return -1; }
     if (pm.ysize >= (1 << (32 - kItemYShift - 1))) { out.error = "a piece has too many unknowns"; return -1; }
     // update matrix of the piece: blocks in (a, b) order, own update records, child sources, U items
-    std::vector<int> order;   // (component, a, b) ascending = the order of the dense tables (components and boundary rows ascend)
-    order.reserve(ub.size());
+    order.clear();   // (component, a, b) ascending = the order of the dense tables (components and boundary rows ascend)
     for (int slot : ctab) if (slot >= 0) order.push_back(slot);
     pm.uit0 = (int)out.uitem.size();
     pm.umb0 = (int)out.umb.size();
@@ -853,7 +857,7 @@ inline int chol_symbolic(const SymIn& in, CholOpts opt, CholHost& out) {
     pm.us0 = (int)out.usrc.size();
     {
       int64_t cur = ucur;
-      std::vector<int> uoffs(ub.size());
+      uoffs.assign(ub.size(), 0);
       for (int q : order) { uoffs[q] = (int)cur; cur += blk_doubles(col_dim[ub[q].a], col_dim[ub[q].b]); }
       std::unordered_map<int, int> comp_uy;   // Uval offset of a component's rhs part [|R|][6]
       for (int c : comps) { comp_uy[c] = (int)cur; cur += 6 * (int64_t)comp_R[c].size(); }

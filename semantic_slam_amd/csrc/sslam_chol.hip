@@ -55,8 +55,24 @@ struct CholView {
   long long* dbg;           // SSLAM_CHOL_STAMPS: shader-clock totals per phase of workgroup 0 ([16] tail kernel, [16] per-depth kernels)
 };
 
+// Speculative damping trials of ONE small graph (B == 1): g2o's LM retries a rejected step with lambda * nu, nu * 2, ... up to ten times
+// (SURVEY A.3), every retry a factorisation + solve + chi2 of the SAME linearisation -- and an optimize() call ends with ten rejected
+// trials in a row.  The ten lambdas of an iteration are known when it starts, the trials do not depend on each other, and a graph of the
+// orchestrator's size leaves the chip idle: all of them run side by side ("lanes": own L, update matrices, y, x, trial estimates, partial
+// sums), then one thread replays the accept / reject sequence over their results in order.  Same arithmetic per trial, same decisions:
+// bitwise the sequential result, an LM iteration in one round of launches instead of up to ten.
+struct SpecLanes {
+  int K = 0;                  // lanes (0: off)
+  LmState* lm = nullptr;      // [K][B] per-lane copy of the graph's state (lambda of the lane, in_trial)
+  double *Lval = nullptr, *Uval = nullptr, *y = nullptr, *x = nullptr, *pose_trial = nullptr, *lmk_trial = nullptr, *part_e = nullptr, *part_a = nullptr;
+  int *fail = nullptr, *flow = nullptr;
+  const double *pose_cur = nullptr, *lmk_cur = nullptr;   // the current estimates (V.pose / V.lmk)
+  long long sL = 0, sU = 0, sy = 0, sx = 0, spose = 0, slmk = 0, spe = 0, spa = 0, sflow = 0;   // lane strides (elements)
+};
+
 struct CholPlan {
   CholView C{};
+  SpecLanes spec{};
   std::vector<int> lvl_ptr, plv_ptr, plv_lds_f, plv_lds_b;
   int tail_lds_f = 0, tail_lds_b = 0, tail_total = 0, nt_tail = 512, nt_leaf = 64, ustage = 0;
   std::vector<void*> allocs;
@@ -74,6 +90,7 @@ struct CholPlan {
   // dependency-driven factorisation + solve in ONE launch (k_chol_flow): small batches only
   bool flow = false;            // the plan can run it (every piece has one parent piece; nt_leaf == nt_tail)
   int flow_grid = 0;            // persistent workgroups
+  int spec_grid = 0;            // workgroups per lane of the speculative trials
   int flow_first = 0;           // first launch-order piece of the single launch; the per-depth launches [0, flow_launch0) come before it
   int flow_launch0 = 0;
   int flow_epoch = 0;           // launches so far: the counters are never reset, a launch waits for epoch * (children)
@@ -1187,6 +1204,106 @@ __global__ __launch_bounds__(NT) void k_lm_end_small(BatchView V, CholView C, do
   lm_end_small<NT>(V, C, blockIdx.x, part_e, max_iters, red);
 }
 
+// ---- speculative damping trials (SpecLanes): begin / per-lane end / replay of the accept-reject sequence + commit ----------------
+template <int NT>
+__global__ __launch_bounds__(NT) void k_lm_begin_spec(BatchView V, CholView C, SpecLanes SL) {
+  __shared__ double red[NT / 64];
+  const int g = blockIdx.x;
+  if (!V.lm[g].active) return;
+  lm_begin_small<NT>(V, C, g, red);
+  if (threadIdx.x == 0) {   // lane k tries the lambda the sequential loop would reach after k rejected trials
+    const LmState S = V.lm[g];
+    double lam = S.lambda, nu = S.nu;
+    for (int k = 0; k < SL.K; ++k) {
+      LmState Lk = S;
+      Lk.lambda = lam; Lk.in_trial = (S.in_trial && S.q + k < 10) ? 1 : 0;
+      SL.lm[(size_t)k * V.B + g] = Lk;
+      SL.fail[(size_t)k * V.B + g] = 0;
+      lam *= nu; nu *= 2;
+    }
+  }
+}
+template <int NT>
+__global__ __launch_bounds__(NT) void k_lm_end_spec(BatchView V, CholView C, SpecLanes SL) {   // x [+] dx, chi2 and dx . (lambda dx + b) of one lane
+  __shared__ double red[NT / 64];
+  const int g = blockIdx.x, tid = threadIdx.x;
+  const long long k = blockIdx.y;
+  V.lm = SL.lm + k * V.B; V.x = SL.x + k * SL.sx; V.pose_trial = SL.pose_trial + k * SL.spose; V.lmk_trial = SL.lmk_trial + k * SL.slmk;
+  V.part_a = SL.part_a + k * SL.spa;
+  double* part_e = SL.part_e + k * SL.spe;
+  const LmState& S = V.lm[g];
+  if (!S.active || !S.in_trial) return;
+  const GraphSeg sg = V.seg[g];
+  const int nec = edge_chunks(sg), nrc = row_chunks(sg);
+  for (int i = tid; i < sg.nprow + sg.nlrow; i += NT) oplus_row(V, i < sg.nprow ? sg.prow0 + i : V.nPr + sg.lrow0 + (i - sg.nprow), V.x);
+  // vertices without a row (fixed: the gauge vertex) keep their estimate in the lane's trial arrays too
+  const double* __restrict__ cur_pose = SL.pose_cur;
+  const double* __restrict__ cur_lmk = SL.lmk_cur;
+  for (int i = tid; i < sg.npose; i += NT) if (V.pose_row[sg.pose0 + i] < 0) for (int q = 0; q < 8; ++q) V.pose_trial[(size_t)(sg.pose0 + i) * 8 + q] = cur_pose[(size_t)(sg.pose0 + i) * 8 + q];
+  for (int i = tid; i < sg.nlm; i += NT) if (V.lm_row[sg.lm0 + i] < 0) for (int q = 0; q < 4; ++q) V.lmk_trial[(size_t)(sg.lm0 + i) * 4 + q] = cur_lmk[(size_t)(sg.lm0 + i) * 4 + q];
+  __threadfence_block();
+  __syncthreads();
+  for (int c0 = 0; c0 < nec; c0 += NT / kEdgeChunk) {
+    const int chunk = c0 + tid / kEdgeChunk;
+    const double c = chunk < nec ? edge_chi2(V, sg, chunk * kEdgeChunk + tid % kEdgeChunk, V.pose_trial, V.lmk_trial) : 0.0;
+    vblock_store_sum<kEdgeChunk, NT>(c, red, part_e + (size_t)g * V.maxEdgeChunks + chunk, chunk < nec);
+  }
+  const double lambda = S.lambda;
+  constexpr int NV = NT / kRowChunk;
+  for (int c0 = 0; c0 < nrc; c0 += NV) {
+    const int vb = tid / kRowChunk, chunk = c0 + vb;
+    const bool live = vb < NV && chunk < nrc;
+    double v = 0;
+    if (live) {
+      const RowRef R = row_ref(V, sg, chunk * kRowChunk + tid % kRowChunk);
+      if (R.valid) { const double d = V.x[R.xoff]; v = d * (lambda * d + V.bvec[R.xoff]); }
+    }
+    vblock_store_sum<kRowChunk, NT>(v, red, V.part_a + (size_t)g * V.maxRowChunks + chunk, live);
+  }
+}
+template <int NT>
+__global__ __launch_bounds__(NT) void k_lm_control_spec(BatchView V, SpecLanes SL, int max_iters) {
+  __shared__ int s_lane;
+  const int g = blockIdx.x, tid = threadIdx.x;
+  LmState& S = V.lm[g];
+  if (!S.active || !S.in_trial) return;
+  const GraphSeg sg = V.seg[g];
+  const int nec = edge_chunks(sg), nrc = row_chunks(sg);
+  if (tid == 0) s_lane = -1;
+  __syncthreads();
+  if (tid < 64) {   // OptimizationAlgorithmLevenberg's do { ... } while (rho < 0 && q < 10) over the finished trials, in order
+    for (int k = 0; k < SL.K; ++k) {
+      if (!SL.lm[(size_t)k * V.B + g].in_trial) break;
+      const double tchi = wave_sum_partials(SL.part_e + (size_t)k * SL.spe + (size_t)g * V.maxEdgeChunks, nec);
+      const double sc = wave_sum_partials(SL.part_a + (size_t)k * SL.spa + (size_t)g * V.maxRowChunks, nrc);
+      int more = 0;
+      if (tid == 0) {
+        const int failed = SL.fail[(size_t)k * V.B + g];
+        V.pcg_fail[g] = failed;
+        lm_control_apply(S, tchi, sc, failed, max_iters);
+        if (S.accept) s_lane = k;
+        more = S.in_trial;
+      }
+      more = __shfl(more, 0, 64);
+      if (!more) break;
+    }
+    if (tid == 0 && S.in_trial) {   // (fewer lanes than trials left: cannot happen with K = 10; close the iteration as the tenth failure would)
+      S.in_trial = 0; S.iter += 1; S.status = 1; S.active = 0;
+    }
+  }
+  __threadfence_block();
+  __syncthreads();
+  const int lane = s_lane;
+  if (lane >= 0) {   // commit the accepted lane's estimates
+    const double* pt = SL.pose_trial + (size_t)lane * SL.spose;
+    const double* lt = SL.lmk_trial + (size_t)lane * SL.slmk;
+    for (int i = tid; i < sg.nprow + sg.nlrow; i += NT) {
+      if (i < sg.nprow) { const int pi = V.prow_pose[sg.prow0 + i]; for (int q = 0; q < 7; ++q) V.pose[(size_t)pi * 8 + q] = pt[(size_t)pi * 8 + q]; }
+      else { const int li = V.lrow_lm[sg.lrow0 + (i - sg.nprow)]; for (int q = 0; q < 4; ++q) V.lmk[(size_t)li * 4 + q] = lt[(size_t)li * 4 + q]; }
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // Factorisation + both triangular solves of a SMALL batch in ONE launch, driven by the dependencies of the piece tree instead of a launch
 // per depth (~26 + 26 launches per damping trial; a graph of the orchestrator's size spends its time between launches, and a
@@ -1207,9 +1324,15 @@ __device__ __forceinline__ bool flow_wait(const int* p, int target, int* err) {
   return true;
 }
 template <int NT, bool USTAGE>
-__global__ __launch_bounds__(NT) void k_chol_flow(BatchView V, CholView C, int q_first, int np, int epoch, const int2* __restrict__ dep, int* flow) {
+__global__ __launch_bounds__(NT) void k_chol_flow(BatchView V, CholView C, int q_first, int np, int epoch, const int2* __restrict__ dep, int* flow, SpecLanes SL) {
   extern __shared__ double sm[];
   const int tid = threadIdx.x;
+  if (SL.K > 0) {   // speculative damping trials: blockIdx.y = lane, with its own factor, vectors, counters and lambda
+    const long long k = blockIdx.y;
+    V.lm = SL.lm + k * V.B; V.x = SL.x + k * SL.sx;
+    C.Lval = SL.Lval + k * SL.sL; C.Uval = SL.Uval + k * SL.sU; C.y = SL.y + k * SL.sy; C.fail = SL.fail + k * V.B;
+    flow = SL.flow + k * SL.sflow;
+  }
   int* child_done = flow;
   int* back_done = flow + np;
   int* fwd_done = flow + 2 * np;
@@ -1310,7 +1433,8 @@ int chol_plan_build(Batch& b) {
   if (opt.nt_leaf != 128 && opt.nt_leaf != 256 && opt.nt_leaf != 512 && opt.nt_leaf != 1024) opt.nt_leaf = 64;
   // small batches (latency-bound: the orchestrator's graph, a single large graph): the dependency-driven single launch (k_chol_flow) runs
   // every piece with the tail's workgroup size
-  const bool flow_on = [] { const char* e = getenv("SSLAM_CHOL_FLOW"); return !(e && atoi(e) == 0); }();   // read per plan (tests toggle it)
+  const int flow_mode = [] { const char* e = getenv("SSLAM_CHOL_FLOW"); return e ? atoi(e) : 1; }();   // 0 off, 1 auto, 2 also on wide trees; read per plan (tests toggle it)
+  const bool flow_on = flow_mode != 0;
   const bool want_flow = flow_on && b.V.B < 8 && opt.nt_tail == 512 && opt.group_cap == 0 && !getenv("SSLAM_CHOL_NT_LEAF");
   if (want_flow) opt.nt_leaf = opt.nt_tail;
   CholHost H;
@@ -1456,9 +1580,15 @@ int chol_plan_build(Batch& b) {
       int l0 = 0;
       while (l0 < (int)P->plv_lds_f.size() && P->plv_ptr[l0 + 1] - P->plv_ptr[l0] > cap) ++l0;
       P->flow_launch0 = l0;
+      // measured on one 5000-pose graph (733 / 358 / 148 / ... pieces per depth): launches for the wide depths + the single launch for the
+      // rest 1.56 ms per LM iteration, a launch per depth 1.01 ms (both with 512-thread pieces; 1.50 ms with round 3's 64-thread pieces) --
+      // a persistent grid walks a wide tree in rounds and pays an agent-scope release / acquire per piece.  The single launch is for trees
+      // that are narrower than the grid at every depth (the orchestrator's graphs: 5.1 vs 5.7 ms per tick at 110 keyframes)
+      if (l0 > 0 && flow_mode != 2) P->flow = false;
       P->flow_first = l0 < (int)P->plv_ptr.size() ? P->plv_ptr[l0] : 0;
       P->flow_grid = std::max(1, std::min((int)dep.size() - P->flow_first, cap));
-      if (P->flow_first > 0) {   // children that the launches finish are not waited for
+      if (!P->flow) { /* launch-per-depth path */ }
+      else if (P->flow_first > 0) {   // children that the launches finish are not waited for
         for (auto& d2 : dep) d2.y = 0;
         for (int i = P->flow_first; i < (int)dep.size(); ++i) if (dep[i].x >= 0) dep[dep[i].x].y++;
       }
@@ -1468,6 +1598,31 @@ int chol_plan_build(Batch& b) {
       P->d_flow = (int*)p;
       SSLAM_HIP_TRY(hipMemsetAsync(p, 0, nints * sizeof(int), b.stream));
       P->flow_epoch = 0;
+      // speculative damping trials: one small graph whose ten lanes of pieces are all on the chip at once
+      const bool spec_on = [] { const char* e = getenv("SSLAM_LM_SPEC"); return !(e && atoi(e) == 0); }();
+      const int K = 10;
+      if (spec_on && b.V.B == 1 && P->flow_launch0 == 0) {
+        P->spec_grid = std::max(1, std::min((int)dep.size(), 2 * cap / K));   // K lanes of persistent workgroups, all of them on the chip at once
+        SpecLanes& SL = P->spec;
+        SL.sL = (H.lnz + 64 + 1) & ~1LL; SL.sU = (H.unz + 64 + 1) & ~1LL; SL.sy = (C.dim + 8 + 1) & ~1LL; SL.sx = (C.dim + 8 + 1) & ~1LL;
+        SL.spose = (long long)b.V.nPose * 8; SL.slmk = (long long)b.V.nLm * 4; SL.spe = (long long)b.V.B * b.V.maxEdgeChunks; SL.spa = (long long)b.V.B * b.V.maxRowChunks;
+        SL.sflow = (long long)nints;
+        const size_t nd = (size_t)K * (SL.sL + SL.sU + SL.sy + SL.sx + SL.spose + SL.slmk + SL.spe + SL.spa);
+        if ((rc = plan_alloc(&p, nd * sizeof(double)))) return rc;
+        SSLAM_HIP_TRY(hipMemsetAsync(p, 0, nd * sizeof(double), b.stream));
+        double* dp = (double*)p;
+        SL.Lval = dp; dp += K * SL.sL; SL.Uval = dp; dp += K * SL.sU; SL.y = dp; dp += K * SL.sy; SL.x = dp; dp += K * SL.sx;
+        SL.pose_trial = dp; dp += K * SL.spose; SL.lmk_trial = dp; dp += K * SL.slmk; SL.part_e = dp; dp += K * SL.spe; SL.part_a = dp;
+        const size_t ni = (size_t)K * (SL.sflow + b.V.B);
+        if ((rc = plan_alloc(&p, ni * sizeof(int)))) return rc;
+        SSLAM_HIP_TRY(hipMemsetAsync(p, 0, ni * sizeof(int), b.stream));
+        SL.flow = (int*)p; SL.fail = (int*)p + (size_t)K * SL.sflow;
+        if ((rc = plan_alloc(&p, (size_t)K * b.V.B * sizeof(LmState)))) return rc;
+        SSLAM_HIP_TRY(hipMemsetAsync(p, 0, (size_t)K * b.V.B * sizeof(LmState), b.stream));
+        SL.lm = (LmState*)p;
+        SL.pose_cur = b.V.pose; SL.lmk_cur = b.V.lmk;
+        SL.K = K;
+      }
     }
   }
   if (P->arena && P->arena->flush(b.stream)) return set_error(SSLAM_ERR_HIP, "upload of the plan tables failed");
@@ -1479,7 +1634,7 @@ int chol_plan_build(Batch& b) {
 bool chol_plan_flow(const Batch& b) { return b.chol && b.chol->flow && !b.chol->compact; }
 // the launches of one solve: per-depth launches over the wide bottom of the tree, the dependency-driven launch over the rest (factor and
 // both substitutions), per-depth launches of the backward substitution over the bottom again
-static void flow_launches(Batch& b) {
+static void flow_launches(Batch& b, bool spec = false) {
   CholPlan& P = *b.chol;
   const CholView& C = P.C;
   size_t lds = (size_t)std::max(P.tail_lds_f, P.tail_lds_b);
@@ -1492,8 +1647,10 @@ static void flow_launches(Batch& b) {
     else hipLaunchKernelGGL((k_chol_pieces<512, false>), dim3(n), dim3(512), (size_t)P.plv_lds_f[l] * sizeof(double), b.stream, b.V, C, P.plv_ptr[l], (const int*)nullptr);
   }
   ++P.flow_epoch;
-  if (P.ustage) hipLaunchKernelGGL((k_chol_flow<512, true>), dim3(P.flow_grid), dim3(512), lds, b.stream, b.V, C, P.flow_first, np, P.flow_epoch, (const int2*)P.d_dep, P.d_flow);
-  else hipLaunchKernelGGL((k_chol_flow<512, false>), dim3(P.flow_grid), dim3(512), lds, b.stream, b.V, C, P.flow_first, np, P.flow_epoch, (const int2*)P.d_dep, P.d_flow);
+  const SpecLanes SL = spec ? P.spec : SpecLanes{};
+  const dim3 grid(spec ? P.spec_grid : P.flow_grid, spec ? P.spec.K : 1);
+  if (P.ustage) hipLaunchKernelGGL((k_chol_flow<512, true>), grid, dim3(512), lds, b.stream, b.V, C, P.flow_first, np, P.flow_epoch, (const int2*)P.d_dep, P.d_flow, SL);
+  else hipLaunchKernelGGL((k_chol_flow<512, false>), grid, dim3(512), lds, b.stream, b.V, C, P.flow_first, np, P.flow_epoch, (const int2*)P.d_dep, P.d_flow, SL);
   for (int l = P.flow_launch0 - 1; l >= 0; --l) {
     const int n = P.plv_ptr[l + 1] - P.plv_ptr[l];
     hipLaunchKernelGGL(k_chol_back_pieces<512>, dim3(n), dim3(512), (size_t)P.plv_lds_b[l] * sizeof(double), b.stream, C, P.plv_ptr[l], (const double*)C.y, b.V.x, (const LmState*)b.V.lm, (const int*)nullptr);
@@ -1529,6 +1686,19 @@ int chol_lm_step_flow(Batch& b, int max_iters) {
   hipLaunchKernelGGL(k_lm_end_small<512>, dim3(b.V.B), dim3(512), 0, b.stream, b.V, C, b.d_part_e, max_iters);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return set_error(SSLAM_ERR_HIP, "LM step launch: %s", hipGetErrorString(e));
+  return 0;
+}
+// one LM ITERATION of a single small graph: all of its (up to ten) damping trials side by side, then the accept / reject replay
+bool chol_plan_spec(const Batch& b) { return chol_plan_flow(b) && b.chol->spec.K > 0; }
+int chol_lm_step_spec(Batch& b, int max_iters) {
+  CholPlan& P = *b.chol;
+  P.C.flat_L = 0;
+  hipLaunchKernelGGL(k_lm_begin_spec<512>, dim3(b.V.B), dim3(512), 0, b.stream, b.V, P.C, P.spec);
+  flow_launches(b, true);
+  hipLaunchKernelGGL(k_lm_end_spec<512>, dim3(b.V.B, P.spec.K), dim3(512), 0, b.stream, b.V, P.C, P.spec);
+  hipLaunchKernelGGL(k_lm_control_spec<512>, dim3(b.V.B), dim3(512), 0, b.stream, b.V, P.spec, max_iters);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return set_error(SSLAM_ERR_HIP, "speculative LM step launch: %s", hipGetErrorString(e));
   return 0;
 }
 // the error flag of k_chol_flow (a dependency wait that gave up); call after a stream synchronisation point

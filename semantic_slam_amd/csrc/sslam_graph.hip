@@ -1724,6 +1724,7 @@ static int batch_optimize(Batch& b, int max_iters, sslam_opt_stats* out) {
       flow_steps = chol_plan_flow(b);
     }
   }
+  const bool spec_steps = flow_steps && b.graphs[0]->opt.speculative && chol_plan_spec(b);
   long long budget = 10LL * std::max(max_iters, 0) + 8;    // hard bound: <= 10 trials per iteration
   int need = max_iters;
   if ((rc = chol_set_active(b, nullptr))) return rc;
@@ -1735,6 +1736,7 @@ static int batch_optimize(Batch& b, int max_iters, sslam_opt_stats* out) {
     for (int sidx = 0; sidx < chunk; ++sidx) {
       if ((rc = batch_linearize(b))) return rc;
       if (fused) { if ((rc = chol_lm_trial_fused(b, max_iters))) return rc; continue; }
+      if (spec_steps) { if ((rc = chol_lm_step_spec(b, max_iters))) return rc; continue; }
       if (flow_steps) { if ((rc = chol_lm_step_flow(b, max_iters))) return rc; continue; }
       hipLaunchKernelGGL(k_maxdiag, row_grid(b), dim3(kRowChunk), 0, b.stream, V, b.d_part_m);
       hipLaunchKernelGGL(k_lm_begin_step, dim3(V.B), dim3(64), 0, b.stream, V, b.d_part_m);
@@ -1981,6 +1983,7 @@ int sslam_graph_set_option(sslam_graph* h, const char* key, double value) {
   if (k == "solver") { if (value != 0 && value != 1 && value != 2 && value != 3) return set_error(SSLAM_ERR_INVALID, "solver: 0 block-Jacobi PCG, 1 sparse block Cholesky (piece plan), 2 Schur complement on the landmarks + PCG, 3 sparse block Cholesky (window plan)"); o.solver = (int)value; }
   else if (k == "robust_kernel_dcs") { if (!(value >= 0)) return set_error(SSLAM_ERR_INVALID, "robust_kernel_dcs: phi >= 0 (0 = no kernel)"); o.dcs_phi = value; if (h->batch) h->batch->V.dcs_phi = value; h->linearized = false; }
   else if (k == "fused_small_graph") o.fused = value != 0;
+  else if (k == "speculative_trials") o.speculative = value != 0;
   else if (k == "pcg_tol") o.pcg_tol = value;
   else if (k == "pcg_max_iters") o.pcg_max_iters = (int)value;
   else if (k == "deterministic") { if (value == 0) return set_error(SSLAM_ERR_UNSUPPORTED, "the Jacobian build is always deterministic (gather form); the FP64-atomics variant was removed"); }

@@ -603,7 +603,7 @@ def test_path_marginals_equal_the_multi_rhs_solves(gpu_lib):
         assert np.abs(a[(r, c)] - b[(r, c)]).max() <= 1e-10 * np.abs(Hinv).max()
 
 
-def _optimize_variant(gp, iters, env, fused):
+def _optimize_variant(gp, iters, env, fused, spec=1):
     import os
     from semantic_slam_amd import GraphSLAM
     old = {k: os.environ.get(k) for k in env}
@@ -611,6 +611,7 @@ def _optimize_variant(gp, iters, env, fused):
     try:
         G = GraphSLAM.from_problem(gp)
         G.set_option("fused_small_graph", fused)
+        G.set_option("speculative_trials", spec)
         assert G.optimize(iters)          # the plan is built inside, under `env`
     finally:
         for k, v in old.items():
@@ -621,7 +622,9 @@ def _optimize_variant(gp, iters, env, fused):
 
 def test_single_launch_solve_and_fused_steps_equal_the_stand_alone_kernels(gpu_lib):
     """Round 4's launch-count work on small batches, against the round-3 launch sequence:
-    (a) default: Jacobian kernels + k_lm_begin_small + k_chol_flow (factor and both solves in one dependency-driven launch) + k_lm_end_small;
+    (s) default for a single small graph: the (up to ten) damping trials of an LM iteration side by side in the lanes of one k_chol_flow
+        launch, then the accept / reject replay (k_lm_control_spec) -> bitwise (a), same iteration AND trial counts;
+    (a) Jacobian kernels + k_lm_begin_small + k_chol_flow (factor and both solves in one dependency-driven launch) + k_lm_end_small;
     (b) the same plan with the stand-alone LM kernels round the single-launch solve -> bitwise (a);
     (c) SSLAM_CHOL_FLOW=0: a launch per depth of the tree (other work-item cuts: same result up to rounding);
     (d) SSLAM_CHOL_SMALL_COLS: the all-tail plan with k_lm_trial_small (every retry inside one launch) -> bitwise its own stand-alone run;
@@ -629,7 +632,9 @@ def test_single_launch_solve_and_fused_steps_equal_the_stand_alone_kernels(gpu_l
     for (n, m, kind, iters) in [(120, 24, "point", 40), (80, 16, "plane", 12), (300, 60, "point", 10)]:
         g = make_graph(n, m, seed=11, landmark_kind=kind)
         gp = GraphProblem.from_synth(g, interleave=True)
-        a = _optimize_variant(gp, iters, {}, 1)
+        sp = _optimize_variant(gp, iters, {}, 1, spec=1)
+        a = _optimize_variant(gp, iters, {}, 1, spec=0)
+        assert sp[:3] == a[:3] and np.array_equal(sp[3], a[3]), (sp[:3], a[:3])
         b = _optimize_variant(gp, iters, {}, 0)
         c = _optimize_variant(gp, iters, {"SSLAM_CHOL_FLOW": 0}, 0)
         d1 = _optimize_variant(gp, iters, {"SSLAM_CHOL_SMALL_COLS": 1200, "SSLAM_CHOL_FLOW": 0}, 1)
@@ -650,7 +655,7 @@ def test_single_launch_solve_on_the_L_graph_and_a_small_batch(gpu_lib):
     from semantic_slam_amd import GraphSLAM, GraphBatch
     g = make_graph(5000, 1000, seed=2)
     gp = GraphProblem.from_synth(g)
-    a = _optimize_variant(gp, 4, {}, 1)
+    a = _optimize_variant(gp, 4, {"SSLAM_CHOL_FLOW": 2}, 1)     # 2: the single launch on a wide tree too (by default such a graph keeps its per-depth launches: measured faster)
     c = _optimize_variant(gp, 4, {"SSLAM_CHOL_FLOW": 0}, 0)
     assert a[0] == c[0] and abs(a[2] - c[2]) <= 1e-9 * c[2]
     assert np.abs(a[3] - c[3]).max() <= 1e-7 * np.abs(c[3]).max()
