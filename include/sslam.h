@@ -112,9 +112,9 @@ int sslam_graph_hessian_index(sslam_graph* g, int id);
  * "fused_small_graph" 1 (default) / 0: a graph of at most ~1200 vertices runs every damping trial of an LM iteration in one launch
  * (k_lm_trial_small; the reference's per-tick call pattern, semantic_graph_slam.cpp:58-102) -- results are bitwise those of the
  * stand-alone kernels;
- * "speculative_trials" 1 (default) / 0: a single small graph runs the (up to ten) damping trials of an LM iteration side by side -- g2o's
+ * "speculative_trials" 1 / 0 (default): a single small graph runs the (up to ten) damping trials of an LM iteration side by side -- g2o's
  * retry lambdas are known when the iteration starts -- and replays the accept / reject sequence over their results: bitwise the
- * sequential result, one round of launches per iteration. */
+ * sequential result, one round of launches per iteration; measured no faster than the sequential trials on today's kernels, hence opt-in. */
 int sslam_graph_set_option(sslam_graph* g, const char* key, double value);
 
 /* GraphSLAM::optimize (graph_slam.cpp:182-219) with the iteration cap as a parameter (the

@@ -235,6 +235,7 @@ int chol_solve_flow(Batch& b);              // (H + lambda I) dx = b for in_tria
 int chol_lm_step_flow(Batch& b, int max_iters);   // begin step + one-launch solve + update / chi2 / accept-reject / commit: 3 launches per damping trial
 bool chol_plan_spec(const Batch& b);        // one small graph: the damping trials of an LM iteration can run side by side
 int chol_lm_step_spec(Batch& b, int max_iters);   // one LM iteration: up to ten speculative trials + the accept / reject replay
+int chol_factor_flat_flow(Batch& b);        // flat factor (marginals) through the single launch
 int chol_flow_check(Batch& b);              // error flag of that launch (synchronises the stream)
 bool chol_plan_tail_only(const Batch& b);   // every piece of every graph is walked by the tail kernels (small graphs)
 int chol_lm_trial_fused(Batch& b, int max_iters);   // one LM iteration (all its damping trials) per graph in one launch, after the linearisation

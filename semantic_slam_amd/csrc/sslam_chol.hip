@@ -94,6 +94,7 @@ struct CholPlan {
   int flow_first = 0;           // first launch-order piece of the single launch; the per-depth launches [0, flow_launch0) come before it
   int flow_launch0 = 0;
   int flow_epoch = 0;           // launches so far: the counters are never reset, a launch waits for epoch * (children)
+  int spec_epoch = 0;           // the same for the lanes' own counters (speculative trials)
   int2* d_dep = nullptr;        // per launch-order piece: {parent (launch order) or -1, children}
   int* d_flow = nullptr;        // [children done | backward done | forward done] per piece, then [0] error flag at 3 * npiece
   // marginals along the elimination-tree paths (k_chol_marginal_paths)
@@ -1324,7 +1325,8 @@ __device__ __forceinline__ bool flow_wait(const int* p, int target, int* err) {
   return true;
 }
 template <int NT, bool USTAGE>
-__global__ __launch_bounds__(NT) void k_chol_flow(BatchView V, CholView C, int q_first, int np, int epoch, const int2* __restrict__ dep, int* flow, SpecLanes SL) {
+__global__ __launch_bounds__(NT) void k_chol_flow(BatchView V, CholView C, int q_first, int np, int epoch, const int2* __restrict__ dep, int* flow, SpecLanes SL,
+                                                  int do_backward) {
   extern __shared__ double sm[];
   const int tid = threadIdx.x;
   if (SL.K > 0) {   // speculative damping trials: blockIdx.y = lane, with its own factor, vectors, counters and lambda
@@ -1360,6 +1362,7 @@ __global__ __launch_bounds__(NT) void k_chol_flow(BatchView V, CholView C, int q
       else __hip_atomic_store(fwd_done + q, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
+  if (!do_backward) return;   // the flat factor of the marginals: L only
   // ---- x = L^-T y, roots to leaves
   for (int i = blockIdx.x; i < np - q_first; i += gridDim.x) {
     const int q = np - 1 - i;
@@ -1597,7 +1600,7 @@ int chol_plan_build(Batch& b) {
       if ((rc = plan_alloc(&p, nints * sizeof(int)))) return rc;
       P->d_flow = (int*)p;
       SSLAM_HIP_TRY(hipMemsetAsync(p, 0, nints * sizeof(int), b.stream));
-      P->flow_epoch = 0;
+      P->flow_epoch = 0; P->spec_epoch = 0;
       // speculative damping trials: one small graph whose ten lanes of pieces are all on the chip at once
       const bool spec_on = [] { const char* e = getenv("SSLAM_LM_SPEC"); return !(e && atoi(e) == 0); }();
       const int K = 10;
@@ -1634,7 +1637,7 @@ int chol_plan_build(Batch& b) {
 bool chol_plan_flow(const Batch& b) { return b.chol && b.chol->flow && !b.chol->compact; }
 // the launches of one solve: per-depth launches over the wide bottom of the tree, the dependency-driven launch over the rest (factor and
 // both substitutions), per-depth launches of the backward substitution over the bottom again
-static void flow_launches(Batch& b, bool spec = false) {
+static void flow_launches(Batch& b, bool spec = false, bool backward = true) {
   CholPlan& P = *b.chol;
   const CholView& C = P.C;
   size_t lds = (size_t)std::max(P.tail_lds_f, P.tail_lds_b);
@@ -1646,12 +1649,12 @@ static void flow_launches(Batch& b, bool spec = false) {
     if (P.ustage) hipLaunchKernelGGL((k_chol_pieces<512, true>), dim3(n), dim3(512), (size_t)P.plv_lds_f[l] * sizeof(double), b.stream, b.V, C, P.plv_ptr[l], (const int*)nullptr);
     else hipLaunchKernelGGL((k_chol_pieces<512, false>), dim3(n), dim3(512), (size_t)P.plv_lds_f[l] * sizeof(double), b.stream, b.V, C, P.plv_ptr[l], (const int*)nullptr);
   }
-  ++P.flow_epoch;
+  const int epoch = spec ? ++P.spec_epoch : ++P.flow_epoch;   // the lanes count on their own counters
   const SpecLanes SL = spec ? P.spec : SpecLanes{};
   const dim3 grid(spec ? P.spec_grid : P.flow_grid, spec ? P.spec.K : 1);
-  if (P.ustage) hipLaunchKernelGGL((k_chol_flow<512, true>), grid, dim3(512), lds, b.stream, b.V, C, P.flow_first, np, P.flow_epoch, (const int2*)P.d_dep, P.d_flow, SL);
-  else hipLaunchKernelGGL((k_chol_flow<512, false>), grid, dim3(512), lds, b.stream, b.V, C, P.flow_first, np, P.flow_epoch, (const int2*)P.d_dep, P.d_flow, SL);
-  for (int l = P.flow_launch0 - 1; l >= 0; --l) {
+  if (P.ustage) hipLaunchKernelGGL((k_chol_flow<512, true>), grid, dim3(512), lds, b.stream, b.V, C, P.flow_first, np, epoch, (const int2*)P.d_dep, P.d_flow, SL, backward ? 1 : 0);
+  else hipLaunchKernelGGL((k_chol_flow<512, false>), grid, dim3(512), lds, b.stream, b.V, C, P.flow_first, np, epoch, (const int2*)P.d_dep, P.d_flow, SL, backward ? 1 : 0);
+  for (int l = P.flow_launch0 - 1; l >= 0 && backward; --l) {
     const int n = P.plv_ptr[l + 1] - P.plv_ptr[l];
     hipLaunchKernelGGL(k_chol_back_pieces<512>, dim3(n), dim3(512), (size_t)P.plv_lds_b[l] * sizeof(double), b.stream, C, P.plv_ptr[l], (const double*)C.y, b.V.x, (const LmState*)b.V.lm, (const int*)nullptr);
   }
@@ -1668,6 +1671,17 @@ int chol_solve_flow(Batch& b) {
   hipLaunchKernelGGL(k_chol_begin, dim3((b.V.B + 63) / 64), dim3(64), 0, b.stream, b.V, C);
   flow_launches(b);
   hipLaunchKernelGGL(k_chol_end, dim3((b.V.B + 63) / 64), dim3(64), 0, b.stream, b.V, C);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return set_error(SSLAM_ERR_HIP, "cholesky flow launch: %s", hipGetErrorString(e));
+  return 0;
+}
+// the flat factor (multi right-hand-side / path-marginal kernels) through the single launch: L only, no backward substitution
+int chol_factor_flat_flow(Batch& b) {
+  CholPlan& P = *b.chol;
+  P.C.flat_L = 1;
+  hipLaunchKernelGGL(k_chol_begin, dim3((b.V.B + 63) / 64), dim3(64), 0, b.stream, b.V, P.C);
+  flow_launches(b, false, false);
+  hipLaunchKernelGGL(k_chol_end, dim3((b.V.B + 63) / 64), dim3(64), 0, b.stream, b.V, P.C);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return set_error(SSLAM_ERR_HIP, "cholesky flow launch: %s", hipGetErrorString(e));
   return 0;
@@ -1706,7 +1720,11 @@ int chol_flow_check(Batch& b) {
   if (!b.chol || !b.chol->flow || !b.chol->d_flow) return 0;
   int err = 0;
   SSLAM_HIP_TRY(hipMemcpyAsync(&err, b.chol->d_flow + 3 * b.chol->lp_graph.size(), sizeof err, hipMemcpyDeviceToHost, b.stream));
+  std::vector<int> lane_err(b.chol->spec.K > 0 && b.chol->spec_epoch > 0 ? b.chol->spec.K : 0, 0);
+  for (size_t k = 0; k < lane_err.size(); ++k)
+    SSLAM_HIP_TRY(hipMemcpyAsync(&lane_err[k], b.chol->spec.flow + k * b.chol->spec.sflow + 3 * b.chol->lp_graph.size(), sizeof(int), hipMemcpyDeviceToHost, b.stream));
   SSLAM_HIP_TRY(hipStreamSynchronize(b.stream));
+  for (int e2 : lane_err) err |= e2;
   if (err) return set_error(SSLAM_ERR_HIP, "sparse Cholesky: a dependency wait of the single-launch factorisation timed out");
   return 0;
 }

@@ -2173,7 +2173,7 @@ static int marginal_blocks(sslam_graph* h, const std::vector<std::pair<int, int>
     // factor the undamped H once, then solve all unit right-hand sides together
     hipLaunchKernelGGL(k_set_trial_all, dim3((b.V.B + 63) / 64), dim3(64), 0, b.stream, b.V, 0.0);
     if (!b.chol && (rc = chol_plan_build(b))) return rc;
-    if ((rc = chol_factor_and_forward(b, /*flat=*/true))) return rc;
+    if ((rc = chol_plan_flow(b) ? chol_factor_flat_flow(b) : chol_factor_and_forward(b, /*flat=*/true))) return rc;
     int fail = 0;
     SSLAM_HIP_TRY(hipMemcpyAsync(&fail, b.V.pcg_fail, sizeof fail, hipMemcpyDeviceToHost, b.stream));
     SSLAM_HIP_TRY(hipStreamSynchronize(b.stream));

@@ -622,7 +622,7 @@ def _optimize_variant(gp, iters, env, fused, spec=1):
 
 def test_single_launch_solve_and_fused_steps_equal_the_stand_alone_kernels(gpu_lib):
     """Round 4's launch-count work on small batches, against the round-3 launch sequence:
-    (s) default for a single small graph: the (up to ten) damping trials of an LM iteration side by side in the lanes of one k_chol_flow
+    (s) opt-in for a single small graph ("speculative_trials"): the (up to ten) damping trials of an LM iteration side by side in the lanes of one k_chol_flow
         launch, then the accept / reject replay (k_lm_control_spec) -> bitwise (a), same iteration AND trial counts;
     (a) Jacobian kernels + k_lm_begin_small + k_chol_flow (factor and both solves in one dependency-driven launch) + k_lm_end_small;
     (b) the same plan with the stand-alone LM kernels round the single-launch solve -> bitwise (a);
