@@ -8,6 +8,7 @@
 #ifndef PLANAR_SEGMENTATION_AMD_POINT_CLOUD_SEGMENTATION_HPP
 #define PLANAR_SEGMENTATION_AMD_POINT_CLOUD_SEGMENTATION_HPP
 
+#include <algorithm>
 #include <array>
 #include <cstdint>
 #include <iostream>
@@ -207,6 +208,32 @@ class point_cloud_segmentation {
     r.points = sslam_seg_icp_point_to_plane(seg_, xyz, labels, n, planes, n_planes, iterations, T0, r.T.data(), &r.rms);
     if (r.points < 0) throw std::runtime_error(std::string("sslam_seg_icp_point_to_plane: ") + sslam_last_error());
     return r;
+  }
+
+  // RANSAC plane of every accepted box of the last segmentallPointCloudData call (the crops are still on the device) and point-to-plane
+  // ICP of the frame over those inliers: BASELINE.json configs[3] "RANSAC+ICP plane extraction".  The reference's only RANSAC is
+  // compute2DConvexHull's pcl::SACSegmentation (plane_segmentation.cpp:639-647: threshold 0.01, 50 iterations, probability 0.99).
+  std::vector<sslam_box_plane> ransacBoxes(float threshold = 0.01f, int max_iterations = 50, double probability = 0.99, uint64_t seed = 0) {
+    std::vector<sslam_box_plane> out(4096);
+    const int n = sslam_seg_ransac_boxes(seg_, threshold, max_iterations, probability, seed, out.data(), (int)out.size(), nullptr);
+    if (n < 0) throw std::runtime_error(std::string("sslam_seg_ransac_boxes: ") + sslam_last_error());
+    out.resize(std::min<size_t>((size_t)n, out.size()));
+    return out;
+  }
+  std::vector<int32_t> ransacBoxInliers(int slot) {
+    std::vector<int32_t> idx(640 * 480);
+    const int n = sslam_seg_ransac_box_inliers(seg_, slot, idx.data(), (int)idx.size());
+    if (n < 0) throw std::runtime_error(std::string("sslam_seg_ransac_box_inliers: ") + sslam_last_error());
+    idx.resize(std::min<size_t>((size_t)n, idx.size()));
+    return idx;
+  }
+  // box_plane[slot]: index into planes (n_planes x 4) or -1; one result per frame of the resident batch
+  std::vector<sslam_icp_result> icpBoxes(const std::vector<int32_t>& box_plane, const float* planes, int n_planes, int iterations = 10, const double* T0 = nullptr) {
+    std::vector<sslam_icp_result> out(1024);
+    const int n = sslam_seg_icp_boxes(seg_, box_plane.data(), (int)box_plane.size(), planes, n_planes, iterations, T0, out.data(), (int)out.size(), nullptr);
+    if (n < 0) throw std::runtime_error(std::string("sslam_seg_icp_boxes: ") + sslam_last_error());
+    out.resize(std::min<size_t>((size_t)n, out.size()));
+    return out;
   }
 
   // the C-ABI handle (the orchestrator shim, ps_graph_slam_amd/semantic_graph_slam.hpp, borrows it for the tick's batched frontend pass)

@@ -279,8 +279,17 @@ __device__ __forceinline__ void run_uitems(const UItem* __restrict__ items, int 
                                            const AsmSrc* __restrict__ usrc, const double* __restrict__ smL, const double* __restrict__ smY,
                                            int lofs, int yofs, double* __restrict__ U, double* part, int tid) {
   const int lq = tid & 3, tr = lq >> 1, tc = lq & 1;
-  for (int it = it_begin + (tid >> 2); it < it_end; it += NT / 4) {
-    const UItem im = items[it];
+  // One item per quad and pass.  A pass used to be three dependent trips to HBM (item record -> its first child-source record -> the
+  // child's block) in front of the arithmetic, and this phase was half of a leaf piece's clocks (SSLAM_CHOL_STAMPS): the record of the
+  // NEXT pass's item and its first source are now fetched one pass ahead, so that a pass starts with everything it needs to issue its
+  // block loads at once.
+  int it = it_begin + (tid >> 2);
+  UItem nxt = items[min(it, max(it_end - 1, it_begin))];
+  AsmSrc nsrc = ((nxt.flags & kItemSole) && nxt.ns > 0) ? usrc[nxt.s0] : AsmSrc{0, -1};
+  for (; it < it_end; it += NT / 4) {
+    const UItem im = nxt;
+    const AsmSrc src0 = nsrc;
+    nxt = items[min(it + NT / 4, it_end - 1)];
     const int n = im.n;
     const int di = (im.flags & kUItemDi6) ? 6 : 3, dj = (im.flags & kUItemDj6) ? 6 : 3;
     const bool diag = im.flags & kUItemDiag;
@@ -288,7 +297,6 @@ __device__ __forceinline__ void run_uitems(const UItem* __restrict__ items, int 
     double acc[9], accy[3];
     // the first child block of this tile: its loads travel while the own updates are computed out of LDS
     const bool sole = im.flags & kItemSole;
-    const AsmSrc src0 = (sole && im.ns > 0) ? usrc[im.s0] : AsmSrc{0, -1};
     {
       const double* o = U + src0.uoff;
       const bool on = sole && im.ns > 0;
@@ -300,6 +308,7 @@ __device__ __forceinline__ void run_uitems(const UItem* __restrict__ items, int 
 #pragma unroll
       for (int rr = 0; rr < 3; ++rr) { const double v = oy[3 * tre + rr]; accy[rr] = (on && diag && src0.uyoff >= 0) ? v : 0.0; }
     }
+    nsrc = ((nxt.flags & kItemSole) && nxt.ns > 0) ? usrc[nxt.s0] : AsmSrc{0, -1};
     for (int k0 = 0; k0 < n; k0 += 8) {
       const UpdMeta r0 = upd[im.u0 + min(k0 + lq, n - 1)];
       const UpdMeta r1 = upd[im.u0 + min(k0 + 4 + lq, n - 1)];

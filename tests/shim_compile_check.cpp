@@ -64,6 +64,22 @@ int main(int argc, char** argv) {
   for (auto& o : objs) cs += (double)o.normal_orientation[0] + 2.0 * o.normal_orientation[1] + 3.0 * o.normal_orientation[2] + 0.5 * o.normal_orientation[3] + o.num_points;
   std::printf("frontend shim ok: %zu planes checksum %.9e\n", objs.size(), cs);
   if ((int)objs.size() != std::atoi(argv[2])) return 9;
+  {  // RANSAC per box + ICP of the frame against the boxes' own planes (the fixed point: T stays the identity, rms at the noise level)
+    const std::vector<sslam_box_plane> rb = seg.ransacBoxes(0.01f, 50, 0.99, 5);
+    std::vector<int32_t> box_plane(rb.size(), -1);
+    std::vector<float> planes;
+    int used = 0;
+    for (size_t q = 0; q < rb.size(); ++q)
+      if (rb[q].inliers > 500) { box_plane[q] = (int32_t)(planes.size() / 4); planes.insert(planes.end(), rb[q].coeff, rb[q].coeff + 4); ++used; }
+    if (rb.empty() || used == 0) { std::printf("ransacBoxes found no plane\n"); return 15; }
+    if ((int)seg.ransacBoxInliers(0).size() != rb[0].inliers) return 15;
+    const std::vector<sslam_icp_result> ir = seg.icpBoxes(box_plane, planes.data(), (int)(planes.size() / 4), 3);
+    if (ir.size() != 1 || ir[0].status != 0 || ir[0].used <= 0 || !(ir[0].rms < 0.01) || std::fabs(ir[0].T[0] - 1.0) > 1e-3 || std::fabs(ir[0].T[9]) > 1e-2) {
+      std::printf("icpBoxes: unexpected result (status %d used %d rms %g)\n", ir.empty() ? -99 : ir[0].status, ir.empty() ? 0 : ir[0].used, ir.empty() ? 0.0 : ir[0].rms);
+      return 16;
+    }
+    std::printf("ransac / icp shim ok: %zu boxes, %d planes, icp rms %.2e over %d points\n", rb.size(), used, ir[0].rms, ir[0].used);
+  }
 
   // orchestrator (semantic_graph_slam): the node's callbacks and loop on the same frame, seen from two keyframes 0.6 m apart
   semantic_graph_slam sgs;
