@@ -135,8 +135,12 @@ struct CholOpts {
                            // measured, the walk serialises sibling subtrees (61 dependent levels instead of 28 at 110 keyframes, 233 instead of
                            // 42 at 436) and the tick got slower (8.7 vs 7.8 ms, 22.4 vs 10.5 ms); the dependency-driven launch (k_chol_flow) is
                            // what small graphs use
-  int order = 1;           // 0: minimum degree, lowest index first (rounds 1-3: eliminates a pose chain from one end -> a tree as deep as the chain);
-                           // 1: multiple minimum degree over independent sets (below): a chain halves per round -> O(log n) levels
+  int order = -1;          // 0: minimum degree, lowest index first (rounds 1-3: eliminates a pose chain from one end -> a tree as deep as the chain);
+                           // 1: multiple minimum degree over independent sets (below): a chain halves per round -> O(log n) levels;
+                           // -1: 1 for batches < 32 (latency-bound: the depth of the tree is the critical path of factor and solves -- one
+                           // 5000-pose graph 588 -> 1022 LM iterations/s, the orchestrator's tick 3x), 0 for larger ones (throughput-bound: the
+                           // depth is hidden by the other graphs; measured on 512 graphs the wide tree costs the same time, 10.48 ms per
+                           // factorisation either way, but its pieces hand 26 % more update-matrix bytes through HBM: 3.08x vs 2.69x algorithmic)
   double order_mul = -1;   // a round eliminates an independent set of the nodes with degree <= order_mul * (minimum degree) + order_add;
   int order_add = -1;      // -1: (2.0, 4) for batches < 32 (shallowest tree: latency), (1.5, 2) for larger ones (less fill and smaller update
                            // matrices, five levels more: throughput -- measured 10.7 vs 11.2 ms per 512 factorisations)
@@ -151,7 +155,7 @@ struct CholOpts {
     group_cap = env_int("SSLAM_CHOL_GROUP_CAP", group_cap); group_blocks = env_int("SSLAM_CHOL_GROUP_BLOCKS", group_blocks);
     ustage = env_int("SSLAM_CHOL_USTAGE", ustage);
     small_cols = env_int("SSLAM_CHOL_SMALL_COLS", small_cols);
-    if (const char* e = getenv("SSLAM_CHOL_ORDER")) order = (!strcmp(e, "mindeg") || !strcmp(e, "0")) ? 0 : 1;
+    if (const char* e = getenv("SSLAM_CHOL_ORDER")) order = (!strcmp(e, "mindeg") || !strcmp(e, "0")) ? 0 : ((!strcmp(e, "auto") || !strcmp(e, "-1")) ? -1 : 1);
     if (const char* e = getenv("SSLAM_CHOL_ORDER_SLACK")) { double m = 0; int a = 0; if (sscanf(e, "%lf,%d", &m, &a) == 2 && m >= 1.0 && a >= 0) { order_mul = m; order_add = a; } }
     dump = getenv("SSLAM_CHOL_DUMP") != nullptr;
   }
@@ -325,6 +329,7 @@ inline int chol_symbolic(const SymIn& in, CholOpts opt, CholHost& out) {
   const int nPr = in.nPr, nLr = in.nLr, nrow = nPr + nLr, B = in.B;
   if (opt.tail_width < 0) opt.tail_width = B >= 32 ? 6 : 2;
   if (opt.ustage < 0) opt.ustage = B >= 32 ? 0 : 1;
+  if (opt.order < 0) opt.order = B >= 32 ? 0 : 1;
   if (opt.order_mul < 0 || opt.order_add < 0) { opt.order_mul = B >= 32 ? 1.5 : 2.0; opt.order_add = B >= 32 ? 2 : 4; }
   out = CholHost();
   out.B = B; out.nt_leaf = opt.nt_leaf; out.nt_tail = opt.nt_tail; out.ustage = opt.ustage;

@@ -282,15 +282,14 @@ __device__ __forceinline__ void run_uitems(const UItem* __restrict__ items, int 
   // One item per quad and pass.  A pass used to be three dependent trips to HBM (item record -> its first child-source record -> the
   // child's block) in front of the arithmetic, and this phase was half of a leaf piece's clocks (SSLAM_CHOL_STAMPS): the record of the
   // NEXT pass's item and its first source are now fetched one pass ahead, so that a pass starts with everything it needs to issue its
-  // block loads at once.
+  // block loads at once (512 factorisations 10.97 -> 10.48 ms).  (Fetching the next item's first update records ahead as well costs 16
+  // spilled VGPRs under the 128-register cap of the leaf kernel and was slower: 12.0 ms.)
   int it = it_begin + (tid >> 2);
   UItem nxt = items[min(it, max(it_end - 1, it_begin))];
   AsmSrc nsrc = ((nxt.flags & kItemSole) && nxt.ns > 0) ? usrc[nxt.s0] : AsmSrc{0, -1};
-  UpdMeta nr0 = upd[nxt.u0 + min(lq, max(nxt.n - 1, 0))], nr1 = upd[nxt.u0 + min(4 + lq, max(nxt.n - 1, 0))];   // its first eight update records
   for (; it < it_end; it += NT / 4) {
     const UItem im = nxt;
     const AsmSrc src0 = nsrc;
-    const UpdMeta pr0 = nr0, pr1 = nr1;
     nxt = items[min(it + NT / 4, it_end - 1)];
     const int n = im.n;
     const int di = (im.flags & kUItemDi6) ? 6 : 3, dj = (im.flags & kUItemDj6) ? 6 : 3;
@@ -311,10 +310,9 @@ __device__ __forceinline__ void run_uitems(const UItem* __restrict__ items, int 
       for (int rr = 0; rr < 3; ++rr) { const double v = oy[3 * tre + rr]; accy[rr] = (on && diag && src0.uyoff >= 0) ? v : 0.0; }
     }
     nsrc = ((nxt.flags & kItemSole) && nxt.ns > 0) ? usrc[nxt.s0] : AsmSrc{0, -1};
-    nr0 = upd[nxt.u0 + min(lq, max(nxt.n - 1, 0))]; nr1 = upd[nxt.u0 + min(4 + lq, max(nxt.n - 1, 0))];
     for (int k0 = 0; k0 < n; k0 += 8) {
-      const UpdMeta r0 = k0 == 0 ? pr0 : upd[im.u0 + min(k0 + lq, n - 1)];
-      const UpdMeta r1 = k0 == 0 ? pr1 : upd[im.u0 + min(k0 + 4 + lq, n - 1)];
+      const UpdMeta r0 = upd[im.u0 + min(k0 + lq, n - 1)];
+      const UpdMeta r1 = upd[im.u0 + min(k0 + 4 + lq, n - 1)];
 #define SSLAM_STEP(KK, R)                                                                                        \
   if (k0 + KK < n)                                                                                               \
     tile_update(smL, smY, quad_bcast<(KK) & 3>(R.ua) - lofs, quad_bcast<(KK) & 3>(R.ub) - lofs,                  \
