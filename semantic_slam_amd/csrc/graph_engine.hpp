@@ -103,6 +103,8 @@ struct DevArena {
 struct Batch {
   int device = 0;
   hipStream_t stream = nullptr;
+  hipStream_t aux_stream = nullptr;   // the landmark-row Jacobian kernel runs here, next to the pose-row kernel on `stream` (large batches)
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   bool own_stream = true;      // false: the stream belongs to the graph handle and outlives this batch (no create / destroy per structure rebuild)
   std::vector<HostGraph*> graphs;
   std::vector<uint64_t> versions;
@@ -154,6 +156,9 @@ struct Batch {
     event_pool.clear();
     for (void* p : allocs) hipFree(p);
     allocs.clear();
+    if (aux_stream) { hipStreamSynchronize(aux_stream); hipStreamDestroy(aux_stream); aux_stream = nullptr; }
+    if (ev_fork) { hipEventDestroy(ev_fork); ev_fork = nullptr; }
+    if (ev_join) { hipEventDestroy(ev_join); ev_join = nullptr; }
     if (stream && own_stream) hipStreamDestroy(stream);
     stream = nullptr;
   }

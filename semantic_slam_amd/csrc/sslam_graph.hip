@@ -591,6 +591,284 @@ __global__ __launch_bounds__(kRowThreads, WPE) void k_linearize_rowthread(BatchV
   for (int c = 0; c < 6; c += 2) store2(Bv + c, accD[21 + c][tid], accD[22 + c][tid]);
 }
 
+// ---- pose rows, two waves per tile of 64 rows (round 4) -------------------------------------------------------------------------
+// The one-thread-per-row kernel above holds J_i^T Omega (36), both Jacobians (45), Omega (27) and an off-diagonal block (36) of an EdgeSE3
+// in registers: 304 VGPRs, ONE wave per SIMD, and the build is bound by what a single resident wave can keep in flight.  Here a tile of 64
+// pose rows is worked by TWO waves with wave-uniform roles (no divergence: each role is its own instantiation): role r owns block row r
+// (scalar rows 3r .. 3r+2) of everything the pose row produces --
+//   EdgeSE3:      M_r = (J^T Omega)_r (3 x 6 instead of 6 x 6), rows 3r.. of the off-diagonal block  M_r J_j,  H_ii(r, >= r),  b_i(r)
+//   landmark edge: rows 3r.. of H_pl = (J_i^T W)_r J_l,  H_ii(r, >= r),  b_i(r)
+// -- so that neither wave needs more than half of the products, role 1 never forms -R_a and role 0 never reads the rotation block of
+// Omega.  Both accumulate into the same thread-private LDS columns as before (disjoint entries), contributions in slot order: the same
+// sums, entry for entry, as the one-thread form.  SSLAM_LIN_PAIR=0 selects the one-thread kernel.
+template <bool PL, bool SHARD, int ROLE>
+__device__ __forceinline__ void rowpair_slots(const BatchView& V, const int row, const int tid, double (*accD)[kRowThreads]) {
+  const int s0 = V.pslot_ptr[row], s1 = V.pslot_ptr[row + 1];
+  const int own = V.prow_pose[row];
+  const int sh_lo = SHARD ? V.shard_lo[V.prow_graph[row]] : 0, sh_hi = SHARD ? V.shard_hi[V.prow_graph[row]] : 0;
+  const Pose Xown = load_pose16(V.pose, own);
+  for (int s = s0; s < s1; ++s) {
+    const int4 rec = V.pslot_rec[s];
+    const int e = rec.x, kind = rec.y & 15, ia = rec.z, ib = rec.w;
+    if (kind != 2) {
+      const int n = V.nEo;
+      const bool iside = (kind == 0);
+      Se3Lin L;
+      se3_error(iside ? Xown : load_pose16(V.pose, ia), iside ? load_pose16(V.pose, ib) : Xown, load_meas_pose(V.eo_z, n, e), L);
+      const double mk = (!SHARD || (V.eo_id[e] >= sh_lo && V.eo_id[e] < sh_hi)) ? 1.0 : 0.0;
+      // J_j = [[E, 0], [0, F]]
+      double E[9], F[9];
+      {
+        const Mat3 Re = qmat(L.qe);
+        const double w = L.s * L.qe.w, x = L.s * L.qe.x, y = L.s * L.qe.y, z = L.s * L.qe.z;
+#pragma unroll
+        for (int q = 0; q < 9; ++q) E[q] = Re.m[q];
+        F[0] = w; F[1] = -z; F[2] = y; F[3] = z; F[4] = w; F[5] = -x; F[6] = -y; F[7] = x; F[8] = w;
+      }
+      // own Jacobian [[A, B], [0, Cc]]: the i side of the edge, or J_j itself on the j side
+      double A[9], B[9], Cc[9];
+      if (iside) {
+        const Vec3 tb = L.tb;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+          const double r0 = L.Ra.m[r * 3], r1 = L.Ra.m[r * 3 + 1], r2 = L.Ra.m[r * 3 + 2];
+          if (ROLE == 0) { A[r * 3] = -r0; A[r * 3 + 1] = -r1; A[r * 3 + 2] = -r2; }
+          B[r * 3 + 0] = 2 * (r1 * tb.z - r2 * tb.y);
+          B[r * 3 + 1] = 2 * (-r0 * tb.z + r2 * tb.x);
+          B[r * 3 + 2] = 2 * (r0 * tb.y - r1 * tb.x);
+        }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          const Quat vk = {k == 0 ? 1.0 : 0.0, k == 1 ? 1.0 : 0.0, k == 2 ? 1.0 : 0.0, 0.0};
+          const Quat t = qmul(qmul(L.qa, vk), L.qb);
+          Cc[0 * 3 + k] = -L.s * t.x; Cc[1 * 3 + k] = -L.s * t.y; Cc[2 * 3 + k] = -L.s * t.z;
+        }
+      } else {
+#pragma unroll
+        for (int q = 0; q < 9; ++q) { if (ROLE == 0) A[q] = E[q]; B[q] = 0.0; Cc[q] = F[q]; }
+      }
+      const int blk = iside ? V.eo_blk[e] : -1;
+      double* O = V.Hpp_off + (size_t)(max(blk, 0) >> 1) * 36;
+      const bool swapped = blk & 1;
+      if (ROLE == 0) {
+        // M_0 = [A^T P, A^T Q]
+        double P[9], Q[9], M1[9], M2[9];
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+          for (int c = 0; c < 3; ++c) {
+            P[r * 3 + c] = mk * V.eo_w[(size_t)(r <= c ? tri21(r, c) : tri21(c, r)) * n + e];
+            Q[r * 3 + c] = mk * V.eo_w[(size_t)tri21(r, 3 + c) * n + e];
+          }
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+          for (int c = 0; c < 3; ++c) {
+            double m11 = 0, m12 = 0;
+#pragma unroll
+            for (int r = 0; r < 3; ++r) { m11 += A[r * 3 + a] * P[r * 3 + c]; m12 += A[r * 3 + a] * Q[r * 3 + c]; }
+            M1[a * 3 + c] = m11; M2[a * 3 + c] = m12;
+          }
+        if (blk >= 0) {   // rows 0..2 of J_i^T Omega J_j = [M11 E, M12 F]
+#pragma unroll
+          for (int a = 0; a < 3; ++a) {
+            double o[6];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+              double o1 = 0, o2 = 0;
+#pragma unroll
+              for (int r = 0; r < 3; ++r) { o1 += M1[a * 3 + r] * E[r * 3 + c]; o2 += M2[a * 3 + r] * F[r * 3 + c]; }
+              o[c] = o1; o[3 + c] = o2;
+            }
+            if (!swapped) { store2(O + a * 6, o[0], o[1]); store2(O + a * 6 + 2, o[2], o[3]); store2(O + a * 6 + 4, o[4], o[5]); }
+            else {
+#pragma unroll
+              for (int c = 0; c < 6; ++c) O[c * 6 + a] = o[c];
+            }
+          }
+        }
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+#pragma unroll
+          for (int c = 0; c < 3; ++c) {
+            double d11 = 0, d12 = 0;
+#pragma unroll
+            for (int r = 0; r < 3; ++r) { d11 += M1[a * 3 + r] * A[r * 3 + c]; d12 += M2[a * 3 + r] * Cc[r * 3 + c]; }
+            if (iside) {
+#pragma unroll
+              for (int r = 0; r < 3; ++r) d12 += M1[a * 3 + r] * B[r * 3 + c];
+            }
+            if (a <= c) accD[tri21(a, c)][tid] += d11;
+            accD[tri21(a, 3 + c)][tid] += d12;
+          }
+          accD[21 + a][tid] -= M1[a * 3] * L.e[0] + M1[a * 3 + 1] * L.e[1] + M1[a * 3 + 2] * L.e[2] +
+                               M2[a * 3] * L.e[3] + M2[a * 3 + 1] * L.e[4] + M2[a * 3 + 2] * L.e[5];
+        }
+      } else {
+        // M_1 = [B^T P + C^T Q^T, B^T Q + C^T R]
+        double Q[9], R[9], M1[9], M2[9];
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+          for (int c = 0; c < 3; ++c) {
+            Q[r * 3 + c] = mk * V.eo_w[(size_t)tri21(r, 3 + c) * n + e];
+            R[r * 3 + c] = mk * V.eo_w[(size_t)(r <= c ? tri21(3 + r, 3 + c) : tri21(3 + c, 3 + r)) * n + e];
+          }
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+          for (int c = 0; c < 3; ++c) {
+            double m21 = 0, m22 = 0;
+#pragma unroll
+            for (int r = 0; r < 3; ++r) { m21 += Cc[r * 3 + a] * Q[c * 3 + r]; m22 += Cc[r * 3 + a] * R[r * 3 + c]; }
+            M1[a * 3 + c] = m21; M2[a * 3 + c] = m22;
+          }
+        if (iside) {
+          double P[9];
+#pragma unroll
+          for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) P[r * 3 + c] = mk * V.eo_w[(size_t)(r <= c ? tri21(r, c) : tri21(c, r)) * n + e];
+#pragma unroll
+          for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+              double m21 = M1[a * 3 + c], m22 = M2[a * 3 + c];
+#pragma unroll
+              for (int r = 0; r < 3; ++r) { m21 += B[r * 3 + a] * P[r * 3 + c]; m22 += B[r * 3 + a] * Q[r * 3 + c]; }
+              M1[a * 3 + c] = m21; M2[a * 3 + c] = m22;
+            }
+        }
+        if (blk >= 0) {   // rows 3..5 of J_i^T Omega J_j = [M21 E, M22 F]
+#pragma unroll
+          for (int a = 0; a < 3; ++a) {
+            double o[6];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+              double o1 = 0, o2 = 0;
+#pragma unroll
+              for (int r = 0; r < 3; ++r) { o1 += M1[a * 3 + r] * E[r * 3 + c]; o2 += M2[a * 3 + r] * F[r * 3 + c]; }
+              o[c] = o1; o[3 + c] = o2;
+            }
+            if (!swapped) { store2(O + (3 + a) * 6, o[0], o[1]); store2(O + (3 + a) * 6 + 2, o[2], o[3]); store2(O + (3 + a) * 6 + 4, o[4], o[5]); }
+            else {
+#pragma unroll
+              for (int c = 0; c < 6; ++c) O[c * 6 + 3 + a] = o[c];
+            }
+          }
+        }
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+#pragma unroll
+          for (int c = 0; c < 3; ++c) {
+            if (a > c) continue;
+            double d22 = 0;
+#pragma unroll
+            for (int r = 0; r < 3; ++r) d22 += M2[a * 3 + r] * Cc[r * 3 + c];
+            if (iside) {
+#pragma unroll
+              for (int r = 0; r < 3; ++r) d22 += M1[a * 3 + r] * B[r * 3 + c];
+            }
+            accD[tri21(3 + a, 3 + c)][tid] += d22;
+          }
+          accD[24 + a][tid] -= M1[a * 3] * L.e[0] + M1[a * 3 + 1] * L.e[1] + M1[a * 3 + 2] * L.e[2] +
+                               M2[a * 3] * L.e[3] + M2[a * 3 + 1] * L.e[4] + M2[a * 3 + 2] * L.e[5];
+        }
+      }
+    } else {
+      const int n = V.nEl;
+      const double* lp = V.lmk + (size_t)ib * 4;
+      double err[3], Ji[18], Jl[9];
+      if (!PL || V.lm_kind[ib] == VT_POINT) {
+        PointLin L;
+        point_error(Xown, Vec3{lp[0], lp[1], lp[2]}, Vec3{V.el_z[0 * (size_t)n + e], V.el_z[1 * (size_t)n + e], V.el_z[2 * (size_t)n + e]}, L);
+        point_jacobians(L, Ji, Jl);
+        err[0] = L.e[0]; err[1] = L.e[1]; err[2] = L.e[2];
+      } else {
+        const Plane pw{{lp[0], lp[1], lp[2]}, lp[3]};
+        const Plane z{{V.el_z[0 * (size_t)n + e], V.el_z[1 * (size_t)n + e], V.el_z[2 * (size_t)n + e]}, V.el_z[3 * (size_t)n + e]};
+        plane_error(Xown, pw, z, err);
+        plane_jacobians(Xown, pw, z, Ji, Jl);
+      }
+      double W[9];
+      load_sym3(V.el_w, n, e, W);
+      double dcs = 1.0;
+      if (V.dcs_phi > 0) dcs = dcs_rho1(V.dcs_phi, quad3(W, err));
+      if (SHARD && !(V.el_id[e] >= sh_lo && V.el_id[e] < sh_hi)) {
+#pragma unroll
+        for (int q = 0; q < 9; ++q) W[q] = 0.0;
+      }
+      if (V.dcs_phi > 0) {
+#pragma unroll
+        for (int q = 0; q < 9; ++q) W[q] *= dcs;
+      }
+      double WJi[18], We[3];
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        We[a] = W[a * 3 + 0] * err[0] + W[a * 3 + 1] * err[1] + W[a * 3 + 2] * err[2];
+#pragma unroll
+        for (int c = 0; c < 6; ++c) WJi[a * 6 + c] = W[a * 3 + 0] * Ji[c] + W[a * 3 + 1] * Ji[6 + c] + W[a * 3 + 2] * Ji[12 + c];
+      }
+#pragma unroll
+      for (int c = 0; c < 6; ++c) {
+#pragma unroll
+        for (int a = 3 * ROLE; a < 3 * ROLE + 3; ++a)
+          if (a <= c) accD[tri21(a, c)][tid] += Ji[a] * WJi[c] + Ji[6 + a] * WJi[6 + c] + Ji[12 + a] * WJi[12 + c];
+      }
+#pragma unroll
+      for (int c = 3 * ROLE; c < 3 * ROLE + 3; ++c) accD[21 + c][tid] -= Ji[c] * We[0] + Ji[6 + c] * We[1] + Ji[12 + c] * We[2];
+      const int blk = V.el_blk[e];
+      if (blk >= 0) {
+        double WJl[9];
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+          for (int c = 0; c < 3; ++c) WJl[a * 3 + c] = W[a * 3 + 0] * Jl[c] + W[a * 3 + 1] * Jl[3 + c] + W[a * 3 + 2] * Jl[6 + c];
+        double o[9];
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+          for (int c = 0; c < 3; ++c) { const int ar = 3 * ROLE + a; o[a * 3 + c] = Ji[ar] * WJl[c] + Ji[6 + ar] * WJl[3 + c] + Ji[12 + ar] * WJl[6 + c]; }
+        double* O = V.Hpl + (size_t)blk * 18 + 9 * ROLE;   // rows 3 ROLE .. of the 6 x 3 block: doubles 0..8 | 9..17
+        if (ROLE == 0) { store2(O, o[0], o[1]); store2(O + 2, o[2], o[3]); store2(O + 4, o[4], o[5]); store2(O + 6, o[6], o[7]); O[8] = o[8]; }
+        else { O[0] = o[0]; store2(O + 1, o[1], o[2]); store2(O + 3, o[3], o[4]); store2(O + 5, o[5], o[6]); store2(O + 7, o[7], o[8]); }
+      }
+    }
+  }
+}
+
+template <bool PL, bool SHARD, int WPE>
+__global__ __launch_bounds__(2 * kRowThreads, WPE) void k_linearize_rowpair(BatchView V) {
+  __shared__ double accD[27][kRowThreads];
+  const int tid = threadIdx.x & (kRowThreads - 1);
+  const int role = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform
+  const int row = blockIdx.x * kRowThreads + tid;
+  const bool live = row < V.nPr && V.lm[V.prow_graph[min(row, V.nPr - 1)]].lin;
+  if (role == 0) {
+#pragma unroll
+    for (int k = 0; k < 15; ++k) accD[k][tid] = 0.0;
+    accD[21][tid] = 0.0; accD[22][tid] = 0.0; accD[23][tid] = 0.0;
+    if (live) rowpair_slots<PL, SHARD, 0>(V, row, tid, accD);
+  } else {
+#pragma unroll
+    for (int k = 15; k < 21; ++k) accD[k][tid] = 0.0;
+    accD[24][tid] = 0.0; accD[25][tid] = 0.0; accD[26][tid] = 0.0;
+    if (live) rowpair_slots<PL, SHARD, 1>(V, row, tid, accD);
+  }
+  __syncthreads();
+  if (!live) return;
+  double* P = V.Hpp_diag + (size_t)row * 36 + 18 * role;   // rows 3 role .. 3 role + 2 of the diagonal block
+#pragma unroll
+  for (int a3 = 0; a3 < 3; ++a3) {
+    const int a = 3 * role + a3;
+    for (int c = 0; c < 6; c += 2)
+      store2(P + a3 * 6 + c, accD[a <= c ? tri21(a, c) : tri21(c, a)][tid], accD[a <= c + 1 ? tri21(a, c + 1) : tri21(c + 1, a)][tid]);
+  }
+  double* Bv = V.bvec + (size_t)row * 6;
+  if (role == 0) { store2(Bv, accD[21][tid], accD[22][tid]); Bv[2] = accD[23][tid]; }
+  else { Bv[3] = accD[24][tid]; store2(Bv + 4, accD[25][tid], accD[26][tid]); }
+}
+
 // landmark rows: 16 lanes per landmark, each lane walks a strided subset of the incident edges,
 // butterfly reduction in a fixed order.
 template <bool PL, bool SHARD>
@@ -1577,18 +1855,43 @@ static int batch_linearize(Batch& b) {
   static const int lin_dbg = [] { const char* e = getenv("SSLAM_LIN_DBG"); return e ? atoi(e) : 0; }();
   b.V.dbg = lin_dbg;
   static const int lin_handover = [] { const char* e = getenv("SSLAM_LIN_HANDOVER"); return e ? atoi(e) : 0; }();
+  static const int lin_pair = [] { const char* e = getenv("SSLAM_LIN_PAIR"); return e ? atoi(e) : 1; }();   // two waves per 64-row tile (default); 0: one thread per row
   static const int lin_wpe = [] { const char* e = getenv("SSLAM_LIN_WPE"); return e ? atoi(e) : 1; }();   // waves per SIMD the pose-row kernel is compiled for
 #define SSLAM_LAUNCH_LIN(PLV, SHV)                                                                                                    \
   {                                                                                                                                   \
     if (V.nPr > 0) {                                                                                                                  \
       if (lin_handover) hipLaunchKernelGGL((k_linearize_rowthread_handover<PLV, SHV>), dim3(nblk), dim3(kRowThreads), 0, b.stream, V); \
+      else if (lin_pair && lin_wpe == 3) hipLaunchKernelGGL((k_linearize_rowpair<PLV, SHV, 3>), dim3(nblk), dim3(2 * kRowThreads), 0, b.stream, V); \
+      else if (lin_pair) hipLaunchKernelGGL((k_linearize_rowpair<PLV, SHV, 2>), dim3(nblk), dim3(2 * kRowThreads), 0, b.stream, V);   \
       else if (lin_wpe == 2) hipLaunchKernelGGL((k_linearize_rowthread<PLV, SHV, 2>), dim3(nblk), dim3(kRowThreads), 0, b.stream, V); \
       else if (lin_wpe == 3) hipLaunchKernelGGL((k_linearize_rowthread<PLV, SHV, 3>), dim3(nblk), dim3(kRowThreads), 0, b.stream, V); \
       else hipLaunchKernelGGL((k_linearize_rowthread<PLV, SHV, 1>), dim3(nblk), dim3(kRowThreads), 0, b.stream, V);                   \
     }                                                                                                                                 \
-    if (V.nLr > 0) hipLaunchKernelGGL((k_linearize_lm_rows<PLV, SHV>), dim3((V.nLr + 15) / 16), dim3(256), 0, b.stream, V);           \
-    if (V.nLL > 0) hipLaunchKernelGGL((k_linearize_ll<SHV>), dim3((V.nLL + 63) / 64), dim3(64), 0, b.stream, V);                      \
+    if (V.nLr > 0) hipLaunchKernelGGL((k_linearize_lm_rows<PLV, SHV>), dim3((V.nLr + 15) / 16), dim3(256), 0, lm_stream, V);           \
+    if (V.nLL > 0) hipLaunchKernelGGL((k_linearize_ll<SHV>), dim3((V.nLL + 63) / 64), dim3(64), 0, lm_stream, V);                      \
   }
+  // Large batches: the landmark-row kernel (96 VGPRs, writes H_ll and the landmark part of b only) runs on a second stream NEXT TO the
+  // pose-row kernel -- disjoint outputs, and the pose-row kernel's register footprint leaves room for its waves on every SIMD; the
+  // duplicate-edge pass and everything after wait for both.  SSLAM_LIN_OVERLAP=0: one stream.
+  static const bool lin_overlap = [] { const char* e = getenv("SSLAM_LIN_OVERLAP"); return !(e && atoi(e) == 0); }();
+  hipStream_t lm_stream = b.stream;
+  const bool forked = lin_overlap && V.B >= 8 && V.nLr > 0 && V.nPr > 0;
+  if (forked) {
+    if (!b.aux_stream) {
+      SSLAM_HIP_TRY(hipStreamCreateWithFlags(&b.aux_stream, hipStreamNonBlocking));
+      SSLAM_HIP_TRY(hipEventCreateWithFlags(&b.ev_fork, hipEventDisableTiming));
+      SSLAM_HIP_TRY(hipEventCreateWithFlags(&b.ev_join, hipEventDisableTiming));
+    }
+    SSLAM_HIP_TRY(hipEventRecord(b.ev_fork, b.stream));
+    SSLAM_HIP_TRY(hipStreamWaitEvent(b.aux_stream, b.ev_fork, 0));
+    lm_stream = b.aux_stream;
+  }
+  auto join = [&]() -> int {
+    if (!forked) return 0;
+    SSLAM_HIP_TRY(hipEventRecord(b.ev_join, b.aux_stream));
+    SSLAM_HIP_TRY(hipStreamWaitEvent(b.stream, b.ev_join, 0));
+    return 0;
+  };
   if (b.sharded) {
     // edge-sharded mode: the rank-partial system is built in its own buffer and summed OUT OF PLACE into [H || b].  A graph that does not
     // re-linearise in this step (a rejected trial being retried, a finished graph) keeps its old partial system there, so the sum over
@@ -1600,6 +1903,7 @@ static int batch_linearize(Batch& b) {
     {
       const BatchView& V = Vp;
       if (b.has_planes) SSLAM_LAUNCH_LIN(true, true) else SSLAM_LAUNCH_LIN(false, true)
+      { const int jr = join(); if (jr) return jr; }
       if (V.nDupEo + V.nDupEl > 0) hipLaunchKernelGGL(k_linearize_dups, dim3((std::max(V.nDupEo, V.nDupEl) + 63) / 64), dim3(64), 0, b.stream, V);
     }
     if (b.comm) {
@@ -1613,6 +1917,7 @@ static int batch_linearize(Batch& b) {
     }
   } else {
     if (b.has_planes) SSLAM_LAUNCH_LIN(true, false) else SSLAM_LAUNCH_LIN(false, false)
+    { const int jr = join(); if (jr) return jr; }
     if (V.nDupEo + V.nDupEl > 0) hipLaunchKernelGGL(k_linearize_dups, dim3((std::max(V.nDupEo, V.nDupEl) + 63) / 64), dim3(64), 0, b.stream, V);
   }
 #undef SSLAM_LAUNCH_LIN
