@@ -600,7 +600,10 @@ __global__ __launch_bounds__(kRowThreads, WPE) void k_linearize_rowthread(BatchV
 //   landmark edge: rows 3r.. of H_pl = (J_i^T W)_r J_l,  H_ii(r, >= r),  b_i(r)
 // -- so that neither wave needs more than half of the products, role 1 never forms -R_a and role 0 never reads the rotation block of
 // Omega.  Both accumulate into the same thread-private LDS columns as before (disjoint entries), contributions in slot order: the same
-// sums, entry for entry, as the one-thread form.  SSLAM_LIN_PAIR=0 selects the one-thread kernel.
+// sums, entry for entry, as the one-thread form.  MEASURED (512 L graphs, same box): 216 VGPRs and two waves per SIMD as intended, H / b
+// equal to the oracle, but 2.23 ms per build against 1.89 ms for the one-thread kernel (3.18 ms when forced to three waves per SIMD: 82
+// spilled registers) -- both roles still evaluate the edge's error and Jacobian blocks, so a tile costs two waves ~70 % of the one-thread
+// work each.  Kept selectable (SSLAM_LIN_PAIR=1); the one-thread kernel stays the default.
 template <bool PL, bool SHARD, int ROLE>
 __device__ __forceinline__ void rowpair_slots(const BatchView& V, const int row, const int tid, double (*accD)[kRowThreads]) {
   const int s0 = V.pslot_ptr[row], s1 = V.pslot_ptr[row + 1];
@@ -1855,7 +1858,7 @@ static int batch_linearize(Batch& b) {
   static const int lin_dbg = [] { const char* e = getenv("SSLAM_LIN_DBG"); return e ? atoi(e) : 0; }();
   b.V.dbg = lin_dbg;
   static const int lin_handover = [] { const char* e = getenv("SSLAM_LIN_HANDOVER"); return e ? atoi(e) : 0; }();
-  static const int lin_pair = [] { const char* e = getenv("SSLAM_LIN_PAIR"); return e ? atoi(e) : 1; }();   // two waves per 64-row tile (default); 0: one thread per row
+  static const int lin_pair = [] { const char* e = getenv("SSLAM_LIN_PAIR"); return e ? atoi(e) : 0; }();   // 1: two role-specialised waves per 64-row tile (measured slower: 2.23 vs 1.89 ms); 0: one thread per row
   static const int lin_wpe = [] { const char* e = getenv("SSLAM_LIN_WPE"); return e ? atoi(e) : 1; }();   // waves per SIMD the pose-row kernel is compiled for
 #define SSLAM_LAUNCH_LIN(PLV, SHV)                                                                                                    \
   {                                                                                                                                   \
