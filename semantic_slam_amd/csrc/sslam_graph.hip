@@ -384,8 +384,11 @@ __global__ __launch_bounds__(kRowThreads) void k_linearize_rowthread_handover(Ba
 // above (SSLAM_LIN_HANDOVER=1) evaluates a chain edge once and is as fast (1.97 vs 2.0 ms per 512-graph build), but adds the handed
 // block last; LM's accept / reject decisions at convergence follow the last bit of H, and on the bench's seeds that order costs 13
 // extra rejected trials per 20 iterations.
-template <bool PL, bool SHARD, int WPE>
-__global__ __launch_bounds__(kRowThreads, WPE) void k_linearize_rowthread(BatchView V) {
+// MODE 0: every slot of the row.  MODE 1 / 2 (round 4, SSLAM_LIN_SPLIT): the row's EdgeSE3 slots and its landmark slots in two launches --
+// the EdgeSE3 pass (the register-hungry one, one wave per SIMD) then carries two of a row's five slots, the landmark pass compiles to ~100
+// VGPRs (five waves per SIMD) and adds its sums to the diagonal block and b the first pass wrote.
+template <bool PL, bool SHARD, int WPE, int MODE>
+__global__ __launch_bounds__(kRowThreads, MODE == 2 ? 4 : WPE) void k_linearize_rowthread(BatchView V) {
   __shared__ double accD[27][kRowThreads];
   const int tid = threadIdx.x;
   const int row = blockIdx.x * kRowThreads + tid;
@@ -397,10 +400,14 @@ __global__ __launch_bounds__(kRowThreads, WPE) void k_linearize_rowthread(BatchV
   const int own = V.prow_pose[row];
   const int sh_lo = SHARD ? V.shard_lo[V.prow_graph[row]] : 0, sh_hi = SHARD ? V.shard_hi[V.prow_graph[row]] : 0;
   const Pose Xown = load_pose16(V.pose, own);   // this row's vertex: loaded once, reused by every slot
+  bool any_lm = false;
   for (int s = s0; s < s1; ++s) {
     const int4 rec = V.pslot_rec[s];
     const int e = rec.x, kind = rec.y & 15, ia = rec.z, ib = rec.w;   // kind 3 (hand-over) is evaluated like kind 1 here
-    if (kind != 2) {
+    if (MODE == 1 && kind == 2) continue;
+    if (MODE == 2 && kind != 2) continue;
+    if (MODE == 2) any_lm = true;
+    if (MODE != 2 && kind != 2) {
       // EdgeSE3: both Jacobians are 2 x 2 block upper triangular in 3 x 3 blocks,
       //   J_i = [[-Ra, 2 Ra [tb]x], [0, Ci]],   J_j = [[Re, 0], [0, Fj]],
       // so J^T Omega J is formed from 3 x 3 products of the blocks (half the FMAs and a smaller live set than dense 6 x 6).
@@ -581,12 +588,25 @@ __global__ __launch_bounds__(kRowThreads, WPE) void k_linearize_rowthread(BatchV
     }
   }
   double* P = V.Hpp_diag + (size_t)row * 36;
+  double* Bv = V.bvec + (size_t)row * 6;
+  if (MODE == 2) {   // add the landmark slots' sums to what the EdgeSE3 pass stored (both triangles get the same sums: the block stays symmetric)
+    if (!any_lm) return;
+#pragma unroll
+    for (int a = 0; a < 6; ++a)
+#pragma unroll
+      for (int c = 0; c < 6; c += 2) {
+        const D2 o = *reinterpret_cast<const D2*>(P + a * 6 + c);
+        store2(P + a * 6 + c, o.a + accD[a <= c ? tri21(a, c) : tri21(c, a)][tid], o.b + accD[a <= c + 1 ? tri21(a, c + 1) : tri21(c + 1, a)][tid]);
+      }
+#pragma unroll
+    for (int c = 0; c < 6; c += 2) { const D2 o = *reinterpret_cast<const D2*>(Bv + c); store2(Bv + c, o.a + accD[21 + c][tid], o.b + accD[22 + c][tid]); }
+    return;
+  }
 #pragma unroll
   for (int a = 0; a < 6; ++a)
 #pragma unroll
     for (int c = 0; c < 6; c += 2)
       store2(P + a * 6 + c, accD[a <= c ? tri21(a, c) : tri21(c, a)][tid], accD[a <= c + 1 ? tri21(a, c + 1) : tri21(c + 1, a)][tid]);
-  double* Bv = V.bvec + (size_t)row * 6;
 #pragma unroll
   for (int c = 0; c < 6; c += 2) store2(Bv + c, accD[21 + c][tid], accD[22 + c][tid]);
 }
@@ -1859,6 +1879,7 @@ static int batch_linearize(Batch& b) {
   b.V.dbg = lin_dbg;
   static const int lin_handover = [] { const char* e = getenv("SSLAM_LIN_HANDOVER"); return e ? atoi(e) : 0; }();
   static const int lin_pair = [] { const char* e = getenv("SSLAM_LIN_PAIR"); return e ? atoi(e) : 0; }();   // 1: two role-specialised waves per 64-row tile (measured slower: 2.23 vs 1.89 ms); 0: one thread per row
+  static const int lin_split = [] { const char* e = getenv("SSLAM_LIN_SPLIT"); return e ? atoi(e) : 0; }();   // EdgeSE3 slots and landmark slots of the pose rows in two launches
   static const int lin_wpe = [] { const char* e = getenv("SSLAM_LIN_WPE"); return e ? atoi(e) : 1; }();   // waves per SIMD the pose-row kernel is compiled for
 #define SSLAM_LAUNCH_LIN(PLV, SHV)                                                                                                    \
   {                                                                                                                                   \
@@ -1866,9 +1887,14 @@ static int batch_linearize(Batch& b) {
       if (lin_handover) hipLaunchKernelGGL((k_linearize_rowthread_handover<PLV, SHV>), dim3(nblk), dim3(kRowThreads), 0, b.stream, V); \
       else if (lin_pair && lin_wpe == 3) hipLaunchKernelGGL((k_linearize_rowpair<PLV, SHV, 3>), dim3(nblk), dim3(2 * kRowThreads), 0, b.stream, V); \
       else if (lin_pair) hipLaunchKernelGGL((k_linearize_rowpair<PLV, SHV, 2>), dim3(nblk), dim3(2 * kRowThreads), 0, b.stream, V);   \
-      else if (lin_wpe == 2) hipLaunchKernelGGL((k_linearize_rowthread<PLV, SHV, 2>), dim3(nblk), dim3(kRowThreads), 0, b.stream, V); \
-      else if (lin_wpe == 3) hipLaunchKernelGGL((k_linearize_rowthread<PLV, SHV, 3>), dim3(nblk), dim3(kRowThreads), 0, b.stream, V); \
-      else hipLaunchKernelGGL((k_linearize_rowthread<PLV, SHV, 1>), dim3(nblk), dim3(kRowThreads), 0, b.stream, V);                   \
+      else if (!lin_split && lin_wpe == 2) hipLaunchKernelGGL((k_linearize_rowthread<PLV, SHV, 2, 0>), dim3(nblk), dim3(kRowThreads), 0, b.stream, V); \
+      else if (!lin_split && lin_wpe == 3) hipLaunchKernelGGL((k_linearize_rowthread<PLV, SHV, 3, 0>), dim3(nblk), dim3(kRowThreads), 0, b.stream, V); \
+      else if (lin_split) {                                                                                                           \
+        if (lin_wpe == 2) hipLaunchKernelGGL((k_linearize_rowthread<PLV, SHV, 2, 1>), dim3(nblk), dim3(kRowThreads), 0, b.stream, V); \
+        else hipLaunchKernelGGL((k_linearize_rowthread<PLV, SHV, 1, 1>), dim3(nblk), dim3(kRowThreads), 0, b.stream, V);              \
+        hipLaunchKernelGGL((k_linearize_rowthread<PLV, SHV, 1, 2>), dim3(nblk), dim3(kRowThreads), 0, b.stream, V);                   \
+      }                                                                                                                               \
+      else hipLaunchKernelGGL((k_linearize_rowthread<PLV, SHV, 1, 0>), dim3(nblk), dim3(kRowThreads), 0, b.stream, V);                \
     }                                                                                                                                 \
     if (V.nLr > 0) hipLaunchKernelGGL((k_linearize_lm_rows<PLV, SHV>), dim3((V.nLr + 15) / 16), dim3(256), 0, lm_stream, V);           \
     if (V.nLL > 0) hipLaunchKernelGGL((k_linearize_ll<SHV>), dim3((V.nLL + 63) / 64), dim3(64), 0, lm_stream, V);                      \
