@@ -1614,7 +1614,7 @@ int chol_plan_build(Batch& b) {
       // speculative damping trials: one small graph whose ten lanes of pieces are all on the chip at once
       const bool spec_on = [] { const char* e = getenv("SSLAM_LM_SPEC"); return !(e && atoi(e) == 0); }();
       const int K = 10;
-      if (spec_on && b.V.B == 1 && P->flow_launch0 == 0) {
+      if (spec_on && b.graphs[0]->opt.speculative && b.V.B == 1 && P->flow_launch0 == 0) {   // (opt-in: the lanes cost three allocations + memsets per rebuild)
         P->spec_grid = std::max(1, std::min((int)dep.size(), 2 * cap / K));   // K lanes of persistent workgroups, all of them on the chip at once
         SpecLanes& SL = P->spec;
         SL.sL = (H.lnz + 64 + 1) & ~1LL; SL.sU = (H.unz + 64 + 1) & ~1LL; SL.sy = (C.dim + 8 + 1) & ~1LL; SL.sx = (C.dim + 8 + 1) & ~1LL;
