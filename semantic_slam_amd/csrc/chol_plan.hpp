@@ -92,7 +92,10 @@ constexpr int kUItemDi6 = 1 << 12, kUItemDj6 = 1 << 13, kUItemDiag = 1 << 14;
 struct UMb { int uoff, ps0, n, info, s0, ns, uyoff, pad; };     // a U block whose own list was split: info = di | dj << 4 | diag << 9
 
 struct PieceMeta { int graph, c0, nc, b0, nb, lbase, lsize, y0, ysize, ilv0, nilv, iit0, nit_i, iu0, nu_i, imb0, nimb, as0, nas, uit0, nuit, umb0, numb,
-                   uu0, nuu, us0, nus, n36, n18, nint, pad3, pad4; };
+                   uu0, nuu, us0, nus, n36, n18, nint, pad3, pad4, nu4, nu2, nu1, pad5; };
+// nu4 / nu2 / nu1 (round 4): the piece's U items are ordered [sole items of 6 x 6 blocks | sole 6 x 3 and 3 x 6 | sole 3 x 3 | items of split
+// lists]; a sole item of nu4 is four 3 x 3 tiles, of nu2 two, of nu1 one -- the update-matrix phase hands the TILES to the lanes (a quad per
+// item left three of four lanes idle on a 3 x 3 block, and 3 x 3 landmark-landmark blocks are most of a leaf piece's update matrix)
 // inside the piece (all copied to LDS when the piece starts, so that its levels never wait for HBM): levels [ilv0, +nilv), items
 // [iit0, +nit_i), update records [iu0, +nu_i), multi-blocks [imb0, +nimb), assembly sources [as0, +nas);
 // update matrix: U items [uit0, +nuit), split U blocks [umb0, +numb), their update records [uu0, +nuu) and child sources [us0, +nus)
@@ -875,6 +878,7 @@ inline int chol_symbolic(const SymIn& in, CholOpts opt, CholHost& out) {
         if (nonsole <= pcap || chunk >= std::max(U, 1)) break;
       }
       int ps = 0;
+      const size_t item_first = out.uitem.size();
       for (int q : order) {
         const UB& x = ub[q];
         const int di = col_dim[x.a], dj = col_dim[x.b];
@@ -900,6 +904,18 @@ inline int chol_symbolic(const SymIn& in, CholOpts opt, CholHost& out) {
       }
       piece_pmax[p] = std::max(piece_pmax[p], ps);
       ucur = cur;
+      // tile-packed order of the items (stable inside a class)
+      {
+        auto cls = [](const UItem& im) {
+          if (!(im.flags & kItemSole)) return 3;
+          const int t = ((im.flags & kUItemDi6) ? 2 : 1) * ((im.flags & kUItemDj6) ? 2 : 1);
+          return t == 4 ? 0 : (t == 2 ? 1 : 2);
+        };
+        int cnt[4] = {0, 0, 0, 0};
+        for (size_t i = item_first; i < out.uitem.size(); ++i) cnt[cls(out.uitem[i])]++;
+        std::stable_sort(out.uitem.begin() + item_first, out.uitem.end(), [&](const UItem& a2, const UItem& b2) { return cls(a2) < cls(b2); });
+        pm.nu4 = cnt[0]; pm.nu2 = cnt[1]; pm.nu1 = cnt[2];
+      }
     }
     pm.nuit = (int)out.uitem.size() - pm.uit0;
     pm.numb = (int)out.umb.size() - pm.umb0;

@@ -51,6 +51,7 @@ struct CholView {
   double* Uval;             // update matrices handed from child pieces to their parents
   double* y;                // forward-substituted rhs, elimination order [dim]
   int* fail;                // [B]
+  int utile_off;            // 1: update-matrix items by quads only (SSLAM_CHOL_UTILES=0)
   int flat_L;               // 1: the factor is written in flat form (multi right-hand-side kernels); 0: class-interleaved (LM loop)
   long long* dbg;           // SSLAM_CHOL_STAMPS: shader-clock totals per phase of workgroup 0 ([16] tail kernel, [16] per-depth kernels)
 };
@@ -357,6 +358,79 @@ __device__ __forceinline__ void run_uitems(const UItem* __restrict__ items, int 
   }
 }
 
+// The sole U items of a piece, one 3 x 3 TILE per lane (round 4).  The items arrive ordered by tile count (PieceMeta.nu4 / nu2 / nu1: 6 x 6
+// blocks, 6 x 3 and 3 x 6, 3 x 3), so a lane finds its (item, tile) by arithmetic.  With a quad per item a 3 x 3 block kept one lane of
+// four busy, and landmark-landmark blocks are most of a leaf piece's update matrix: 31 % lane utilisation, five passes over the item
+// list where two do -- and every pass is a chain of dependent trips to HBM.  Same arithmetic per tile as run_uitems (tile_update, then the
+// children's blocks in list order): same results.  The next tile's item record and first child source are fetched one pass ahead.
+template <int NT>
+__device__ __forceinline__ void run_utiles(const UItem* __restrict__ items, const int n4, const int n2, const int n1, const UpdMeta* __restrict__ upd,
+                                           const AsmSrc* __restrict__ usrc, const double* __restrict__ smL, const double* __restrict__ smY,
+                                           int lofs, int yofs, double* __restrict__ U, int tid) {
+  const int T4 = 4 * n4, T2 = T4 + 2 * n2, T = T2 + n1;
+  auto decode = [&](int t, int& q) -> int {
+    if (t < T4) { q = t & 3; return t >> 2; }
+    if (t < T2) { const int u = t - T4; q = u & 1; return n4 + (u >> 1); }
+    q = 0;
+    return n4 + n2 + (t - T2);
+  };
+  int t = tid, nq = 0;
+  UItem nxt = items[decode(min(t, T - 1), nq)];
+  AsmSrc nsrc = nxt.ns > 0 ? usrc[nxt.s0] : AsmSrc{0, -1};
+  for (; t < T; t += NT) {
+    const UItem im = nxt;
+    const AsmSrc src0 = nsrc;
+    const int qq = nq;
+    nxt = items[decode(min(t + NT, T - 1), nq)];
+    const int n = im.n;
+    const int di = (im.flags & kUItemDi6) ? 6 : 3, dj = (im.flags & kUItemDj6) ? 6 : 3;
+    const bool diag = im.flags & kUItemDiag;
+    int tr, tc;
+    if (di == 6 && dj == 6) { tr = qq >> 1; tc = qq & 1; }
+    else if (di == 6) { tr = qq; tc = 0; }
+    else { tr = 0; tc = qq; }
+    double acc[9], accy[3];
+    {
+      const bool on = im.ns > 0;
+      const double* o = U + src0.uoff;
+#pragma unroll
+      for (int rr = 0; rr < 3; ++rr)
+#pragma unroll
+        for (int cc = 0; cc < 3; ++cc) { const double v = o[(3 * tr + rr) * dj + 3 * tc + cc]; acc[rr * 3 + cc] = on ? v : 0.0; }
+      const double* oy = U + (src0.uyoff >= 0 ? src0.uyoff : 0);
+#pragma unroll
+      for (int rr = 0; rr < 3; ++rr) { const double v = oy[3 * tr + rr]; accy[rr] = (on && diag && src0.uyoff >= 0) ? v : 0.0; }
+    }
+    nsrc = nxt.ns > 0 ? usrc[nxt.s0] : AsmSrc{0, -1};
+    for (int k0 = 0; k0 < n; k0 += 2) {   // the item's own updates out of LDS, records two at a time
+      const UpdMeta r0 = upd[im.u0 + k0], r1 = upd[im.u0 + min(k0 + 1, n - 1)];
+      tile_update(smL, smY, r0.ua - lofs, r0.ub - lofs, r0.ux - yofs, r0.pk, tr, tc, acc, accy);
+      if (k0 + 1 < n) tile_update(smL, smY, r1.ua - lofs, r1.ub - lofs, r1.ux - yofs, r1.pk, tr, tc, acc, accy);
+    }
+    for (int s2 = 1; s2 < im.ns; ++s2) {
+      const AsmSrc src = usrc[im.s0 + s2];
+      const double* o = U + src.uoff;
+#pragma unroll
+      for (int rr = 0; rr < 3; ++rr)
+#pragma unroll
+        for (int cc = 0; cc < 3; ++cc) acc[rr * 3 + cc] += o[(3 * tr + rr) * dj + 3 * tc + cc];
+      if (diag && tc == 0 && src.uyoff >= 0) {
+#pragma unroll
+        for (int rr = 0; rr < 3; ++rr) accy[rr] += U[src.uyoff + 3 * tr + rr];
+      }
+    }
+    double* o = U + im.uoff;
+#pragma unroll
+    for (int rr = 0; rr < 3; ++rr)
+#pragma unroll
+      for (int cc = 0; cc < 3; ++cc) o[(3 * tr + rr) * dj + 3 * tc + cc] = acc[rr * 3 + cc];
+    if (diag && tc == 0) {
+#pragma unroll
+      for (int rr = 0; rr < 3; ++rr) U[im.uyoff + 3 * tr + rr] = accy[rr];
+    }
+  }
+}
+
 // U blocks whose own list was split: partial tiles in item order + the children's blocks -> HBM (one wave per block, lane = entry)
 __device__ __forceinline__ void reduce_umulti(const UMb* __restrict__ mbs, int m0, int m1, const AsmSrc* __restrict__ usrc, double* __restrict__ U,
                                               const double* part, int wave, int lane, int nw) {
@@ -653,8 +727,16 @@ __device__ __forceinline__ void chol_piece(const BatchView& V, const CholView& C
   }
   // ---- 3. the update matrix over the rows above the piece: own updates out of LDS + the children's blocks -> HBM
   if (pm.nuit > 0) {
-    if (USTAGE) run_uitems<NT>(sUItem, 0, pm.nuit, sUUpd, sUSrc, smL, smY, pm.lbase, pm.y0, C.Uval, part, tid);
-    else run_uitems<NT>(C.uitem + pm.uit0, 0, pm.nuit, C.upd + pm.uu0, C.usrc + pm.us0, smL, smY, pm.lbase, pm.y0, C.Uval, part, tid);
+    // sole items by tiles (run_utiles), the items of split lists by quads into their partial slots (run_uitems).  C.utile_off: the quad
+    // form for everything (SSLAM_CHOL_UTILES=0)
+    const int nsole = C.utile_off ? 0 : pm.nu4 + pm.nu2 + pm.nu1;
+    if (USTAGE) {
+      if (nsole > 0) run_utiles<NT>(sUItem, pm.nu4, pm.nu2, pm.nu1, sUUpd, sUSrc, smL, smY, pm.lbase, pm.y0, C.Uval, tid);
+      if (pm.nuit > nsole) run_uitems<NT>(sUItem, nsole, pm.nuit, sUUpd, sUSrc, smL, smY, pm.lbase, pm.y0, C.Uval, part, tid);
+    } else {
+      if (nsole > 0) run_utiles<NT>(C.uitem + pm.uit0, pm.nu4, pm.nu2, pm.nu1, C.upd + pm.uu0, C.usrc + pm.us0, smL, smY, pm.lbase, pm.y0, C.Uval, tid);
+      if (pm.nuit > nsole) run_uitems<NT>(C.uitem + pm.uit0, nsole, pm.nuit, C.upd + pm.uu0, C.usrc + pm.us0, smL, smY, pm.lbase, pm.y0, C.Uval, part, tid);
+    }
     if (pm.numb > 0) {
       __syncthreads();
       if (USTAGE) reduce_umulti(sUMb, 0, pm.numb, sUSrc, C.Uval, part, wave, lane, NW);
@@ -1457,6 +1539,7 @@ int chol_plan_build(Batch& b) {
   P->arena = b.arena;
   CholView& C = P->C;
   C.ncol = H.ncol; C.nlevels = H.nlevels; C.dim = H.dim; C.npiece = H.npiece;
+  { const char* e = getenv("SSLAM_CHOL_UTILES"); C.utile_off = (e && atoi(e) == 0) ? 1 : 0; }
   P->lvl_ptr = H.lvl_ptr; P->plv_ptr = H.plv_ptr; P->plv_lds_f = H.plv_lds_f; P->plv_lds_b = H.plv_lds_b;
   P->tail_lds_f = H.tail_lds_f; P->tail_lds_b = H.tail_lds_b; P->tail_total = (int)H.tail_pieces.size(); P->nt_tail = H.nt_tail; P->nt_leaf = H.nt_leaf; P->ustage = H.ustage;
   P->lnz = H.lnz;

@@ -21,7 +21,7 @@ RCOL = np.dtype([("u0", "<i4"), ("n", "<i4")])
 ILV = np.dtype([(n, "<i4") for n in ("c0", "c1", "b0", "b1", "it0", "it1", "mb0", "mb1")])
 PIECE = np.dtype([(n, "<i4") for n in ("graph", "c0", "nc", "b0", "nb", "lbase", "lsize", "y0", "ysize", "ilv0", "nilv", "iit0", "nit_i",
                                        "iu0", "nu_i", "imb0", "nimb", "as0", "nas", "uit0", "nuit", "umb0", "numb",
-                                       "uu0", "nuu", "us0", "nus", "n36", "n18", "nint", "pad3", "pad4")])
+                                       "uu0", "nuu", "us0", "nus", "n36", "n18", "nint", "pad3", "pad4", "nu4", "nu2", "nu1", "pad5")])
 K_DI6, K_DK6, K_DIAG, K_DJ6 = 1 << 20, 1 << 21, 1 << 22, 1 << 23
 B_FMT, B_DIAG, B_ROWIN = 1 << 8, 1 << 9, 1 << 10
 
