@@ -138,15 +138,15 @@ struct CholOpts {
                            // measured, the walk serialises sibling subtrees (61 dependent levels instead of 28 at 110 keyframes, 233 instead of
                            // 42 at 436) and the tick got slower (8.7 vs 7.8 ms, 22.4 vs 10.5 ms); the dependency-driven launch (k_chol_flow) is
                            // what small graphs use
-  int order = -1;          // 0: minimum degree, lowest index first (rounds 1-3: eliminates a pose chain from one end -> a tree as deep as the chain);
-                           // 1: multiple minimum degree over independent sets (below): a chain halves per round -> O(log n) levels;
-                           // -1: 1 for batches < 32 (latency-bound: the depth of the tree is the critical path of factor and solves -- one
-                           // 5000-pose graph 588 -> 1022 LM iterations/s, the orchestrator's tick 3x), 0 for larger ones (throughput-bound: the
-                           // depth is hidden by the other graphs; measured on 512 graphs the wide tree costs the same time, 10.48 ms per
-                           // factorisation either way, but its pieces hand 26 % more update-matrix bytes through HBM: 3.08x vs 2.69x algorithmic)
+  int order = 1;           // 0: minimum degree, lowest index first (rounds 1-3: eliminates a pose chain from one end -> a tree as deep as the chain);
+                           // 1: multiple minimum degree over independent sets (below): a chain halves per round -> O(log n) levels.  Small
+                           // batches are latency-bound on the depth of the tree (one 5000-pose graph 588 -> 1050 LM iterations/s); on the
+                           // 512-graph batch the two orders took the same time while a quad per update-matrix item left most lanes idle on
+                           // the wider tree's many 3 x 3 blocks, and since the items run by tiles the shallow tree is the faster one there
+                           // too (9.30 vs 9.77 ms per 512 factorisations) -- at 26 % more update-matrix bytes through HBM
   double order_mul = -1;   // a round eliminates an independent set of the nodes with degree <= order_mul * (minimum degree) + order_add;
   int order_add = -1;      // -1: (2.0, 4) for batches < 32 (shallowest tree: latency), (1.5, 2) for larger ones (less fill and smaller update
-                           // matrices, five levels more: throughput -- measured 10.7 vs 11.2 ms per 512 factorisations)
+                           // matrices, five levels more: throughput -- measured 9.30 vs 9.48 ms per 512 factorisations)
   bool dump = false;
   static int env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
   void from_env() {
@@ -332,7 +332,7 @@ inline int chol_symbolic(const SymIn& in, CholOpts opt, CholHost& out) {
   const int nPr = in.nPr, nLr = in.nLr, nrow = nPr + nLr, B = in.B;
   if (opt.tail_width < 0) opt.tail_width = B >= 32 ? 6 : 2;
   if (opt.ustage < 0) opt.ustage = B >= 32 ? 0 : 1;
-  if (opt.order < 0) opt.order = B >= 32 ? 0 : 1;
+  if (opt.order < 0) opt.order = 1;
   if (opt.order_mul < 0 || opt.order_add < 0) { opt.order_mul = B >= 32 ? 1.5 : 2.0; opt.order_add = B >= 32 ? 2 : 4; }
   out = CholHost();
   out.B = B; out.nt_leaf = opt.nt_leaf; out.nt_tail = opt.nt_tail; out.ustage = opt.ustage;
