@@ -479,7 +479,8 @@ def main():
                                "frac": round(jac_bytes / (full_lin_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)}}
     t, raw, src = pmc_traffic("jacobian_build", jac_bytes)
     if t is not None:
-        roof_jac.update({"traffic": t, "traffic_raw_counters": raw, "traffic_source": src})
+        roof_jac.update({"traffic": t, "traffic_raw_counters": raw, "traffic_source": src,
+                         "traffic_kind": "static: the committed rocprofv3 PMC passes over one launch of the same 512-graph workload, not collected in this run"})
     roofline = roof_jac
     roof_factor = None
     if ktimes["factor"][1] > 0:
@@ -497,7 +498,8 @@ def main():
                        "note": "algorithmic bytes = read H, b once + write L, y once per graph factorisation"}
         t, raw, src = pmc_traffic("factor", fbytes)
         if t is not None:
-            roof_factor.update({"traffic": t, "traffic_raw_counters": raw, "traffic_source": src})
+            roof_factor.update({"traffic": t, "traffic_raw_counters": raw, "traffic_source": src,
+                                "traffic_kind": "static: the committed rocprofv3 PMC passes over one launch of the same 512-graph workload, not collected in this run"})
         if dominant == "factor":
             roofline = roof_factor
     if dominant == "spmv" and ktimes["spmv"][1] > 0:

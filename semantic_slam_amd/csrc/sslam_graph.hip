@@ -457,6 +457,56 @@ __global__ __launch_bounds__(kRowThreads, MODE == 2 ? 4 : WPE) void k_linearize_
 #pragma unroll
         for (int q = 0; q < 9; ++q) { A[q] = E[q]; B[q] = 0.0; Cc[q] = F[q]; }
       }
+      if (MODE == 3) {
+        // Row-wise form (SSLAM_LIN_ROWWISE): row a of J^T Omega is formed, used for row a of the off-diagonal block, of the diagonal block and
+        // of b, and dropped -- six live values instead of the 36 of the block form
+        double Wm[21];
+#pragma unroll
+        for (int q = 0; q < 21; ++q) Wm[q] = mk * V.eo_w[(size_t)q * n + e];
+        const int blk = iside ? V.eo_blk[e] : -1;
+        double* O = V.Hpp_off + (size_t)(max(blk, 0) >> 1) * 36;
+        const bool swapped = blk & 1;
+#pragma unroll
+        for (int a = 0; a < 6; ++a) {
+          double Ma[6];
+#pragma unroll
+          for (int c = 0; c < 6; ++c) {
+            double m = 0;
+#pragma unroll
+            for (int r = 0; r < 6; ++r) {
+              // J[r][a]: columns 0-2 = [A; 0], columns 3-5 = [B; Cc]
+              const double w = Wm[r <= c ? tri21(r, c) : tri21(c, r)];
+              if (a < 3) { if (r < 3) m += A[r * 3 + a] * w; }
+              else { if (r < 3) { if (iside) m += B[r * 3 + a - 3] * w; } else m += Cc[(r - 3) * 3 + a - 3] * w; }
+            }
+            Ma[c] = m;
+          }
+          if (blk >= 0) {   // row a of J_i^T Omega J_j,  J_j = [[E, 0], [0, F]]
+            double o[6];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+              o[c] = Ma[0] * E[c] + Ma[1] * E[3 + c] + Ma[2] * E[6 + c];
+              o[3 + c] = Ma[3] * F[c] + Ma[4] * F[3 + c] + Ma[5] * F[6 + c];
+            }
+            if (!swapped) { store2(O + a * 6, o[0], o[1]); store2(O + a * 6 + 2, o[2], o[3]); store2(O + a * 6 + 4, o[4], o[5]); }
+            else {
+#pragma unroll
+              for (int c = 0; c < 6; ++c) O[c * 6 + a] = o[c];
+            }
+          }
+#pragma unroll
+          for (int c = a; c < 6; ++c) {   // row a of J^T Omega J, upper triangle
+            double d = 0;
+            if (c < 3) d = Ma[0] * A[c] + Ma[1] * A[3 + c] + Ma[2] * A[6 + c];
+            else {
+              d = Ma[3] * Cc[c - 3] + Ma[4] * Cc[3 + c - 3] + Ma[5] * Cc[6 + c - 3];
+              if (iside) d += Ma[0] * B[c - 3] + Ma[1] * B[3 + c - 3] + Ma[2] * B[6 + c - 3];
+            }
+            accD[tri21(a, c)][tid] += d;
+          }
+          accD[21 + a][tid] -= Ma[0] * L.e[0] + Ma[1] * L.e[1] + Ma[2] * L.e[2] + Ma[3] * L.e[3] + Ma[4] * L.e[4] + Ma[5] * L.e[5];
+        }
+      } else {
       // M = J_self^T Omega = [[A^T P, A^T Q], [B^T P + C^T Q^T, B^T Q + C^T R]]
       double M11[9], M12[9], M21[9], M22[9];
 #pragma unroll
@@ -527,6 +577,7 @@ __global__ __launch_bounds__(kRowThreads, MODE == 2 ? 4 : WPE) void k_linearize_
                              M12[a * 3] * L.e[3] + M12[a * 3 + 1] * L.e[4] + M12[a * 3 + 2] * L.e[5];
         accD[24 + a][tid] -= M21[a * 3] * L.e[0] + M21[a * 3 + 1] * L.e[1] + M21[a * 3 + 2] * L.e[2] +
                              M22[a * 3] * L.e[3] + M22[a * 3 + 1] * L.e[4] + M22[a * 3 + 2] * L.e[5];
+      }
       }
     } else {
       const int n = V.nEl;
@@ -1879,6 +1930,7 @@ static int batch_linearize(Batch& b) {
   b.V.dbg = lin_dbg;
   static const int lin_handover = [] { const char* e = getenv("SSLAM_LIN_HANDOVER"); return e ? atoi(e) : 0; }();
   static const int lin_pair = [] { const char* e = getenv("SSLAM_LIN_PAIR"); return e ? atoi(e) : 0; }();   // 1: two role-specialised waves per 64-row tile (measured slower: 2.23 vs 1.89 ms); 0: one thread per row
+  static const int lin_rowwise = [] { const char* e = getenv("SSLAM_LIN_ROWWISE"); return e ? atoi(e) : 0; }();   // 1 | 2: row-wise EdgeSE3 form at one | two waves per SIMD
   static const int lin_split = [] { const char* e = getenv("SSLAM_LIN_SPLIT"); return e ? atoi(e) : 0; }();   // 1: EdgeSE3 slots and landmark slots of the pose rows in two launches (measured slower: 2.52 vs 2.01 ms)
   static const int lin_wpe = [] { const char* e = getenv("SSLAM_LIN_WPE"); return e ? atoi(e) : 1; }();   // waves per SIMD the pose-row kernel is compiled for
 #define SSLAM_LAUNCH_LIN(PLV, SHV)                                                                                                    \
@@ -1889,6 +1941,8 @@ static int batch_linearize(Batch& b) {
       else if (lin_pair) hipLaunchKernelGGL((k_linearize_rowpair<PLV, SHV, 2>), dim3(nblk), dim3(2 * kRowThreads), 0, b.stream, V);   \
       else if (!lin_split && lin_wpe == 2) hipLaunchKernelGGL((k_linearize_rowthread<PLV, SHV, 2, 0>), dim3(nblk), dim3(kRowThreads), 0, b.stream, V); \
       else if (!lin_split && lin_wpe == 3) hipLaunchKernelGGL((k_linearize_rowthread<PLV, SHV, 3, 0>), dim3(nblk), dim3(kRowThreads), 0, b.stream, V); \
+      else if (lin_rowwise == 2) hipLaunchKernelGGL((k_linearize_rowthread<PLV, SHV, 2, 3>), dim3(nblk), dim3(kRowThreads), 0, b.stream, V); \
+      else if (lin_rowwise) hipLaunchKernelGGL((k_linearize_rowthread<PLV, SHV, 1, 3>), dim3(nblk), dim3(kRowThreads), 0, b.stream, V); \
       else if (lin_split) {                                                                                                           \
         if (lin_wpe == 2) hipLaunchKernelGGL((k_linearize_rowthread<PLV, SHV, 2, 1>), dim3(nblk), dim3(kRowThreads), 0, b.stream, V); \
         else hipLaunchKernelGGL((k_linearize_rowthread<PLV, SHV, 1, 1>), dim3(nblk), dim3(kRowThreads), 0, b.stream, V);              \
