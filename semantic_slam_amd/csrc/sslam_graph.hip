@@ -387,27 +387,51 @@ __global__ __launch_bounds__(kRowThreads) void k_linearize_rowthread_handover(Ba
 // MODE 0: every slot of the row.  MODE 1 / 2 (round 4, SSLAM_LIN_SPLIT): the row's EdgeSE3 slots and its landmark slots in two launches --
 // the EdgeSE3 pass (the register-hungry one, one wave per SIMD) then carries two of a row's five slots, the landmark pass compiles to ~100
 // VGPRs (five waves per SIMD) and adds its sums to the diagonal block and b the first pass wrote.
-template <bool PL, bool SHARD, int WPE, int MODE>
+// ST (round 4, the default): STAGED STORES.  Timing the kernel without its stores (SSLAM_LIN_DBG=16 / 32 / 48: 1.99 -> 1.22 / 1.69 / 0.95 ms
+// per 512-graph build) showed what bounds it: not registers, occupancy or arithmetic (four restructurings for those were all slower)
+// but the stores -- every thread writing its own 288-byte (or 144-byte) block with 16-byte stores at a 288-byte lane stride is 66 store
+// instructions per row that each touch 64 different cache lines.  With ST a slot's block goes to an LDS row of its thread and the WAVE
+// writes the 64 blocks of the slot round together, consecutive lanes on consecutive 16-byte pieces of one block (a block is 18
+// consecutive lanes: whole cache lines per request); the diagonal blocks and b of the workgroup's 64 rows, contiguous in HBM, leave as
+// one stream.  Same values, same order of the sums.
+constexpr int kStgStride = 37;   // doubles per staged block row (36 + 1: the per-thread writes spread over the LDS banks)
+template <bool PL, bool SHARD, int WPE, int MODE, int ST>
 __global__ __launch_bounds__(kRowThreads, MODE == 2 ? 4 : WPE) void k_linearize_rowthread(BatchView V) {
   __shared__ double accD[27][kRowThreads];
+  __shared__ double stg[ST ? kRowThreads * kStgStride : 1];
+  __shared__ double* s_dst[ST ? kRowThreads : 1];
+  __shared__ int s_sz[ST ? kRowThreads : 1];
   const int tid = threadIdx.x;
   const int row = blockIdx.x * kRowThreads + tid;
-  if (row >= V.nPr) return;
-  if (!V.lm[V.prow_graph[row]].lin) return;
+  const bool active = row < V.nPr && V.lm[V.prow_graph[min(row, V.nPr - 1)]].lin;
+  if (!ST && !active) return;
 #pragma unroll
   for (int k = 0; k < 27; ++k) accD[k][tid] = 0.0;
-  const int s0 = V.pslot_ptr[row], s1 = V.pslot_ptr[row + 1];
-  const int own = V.prow_pose[row];
-  const int sh_lo = SHARD ? V.shard_lo[V.prow_graph[row]] : 0, sh_hi = SHARD ? V.shard_hi[V.prow_graph[row]] : 0;
+  const int s0 = active ? V.pslot_ptr[row] : 0, s1 = active ? V.pslot_ptr[row + 1] : 0;
+  const int own = V.prow_pose[min(row, V.nPr - 1)];
+  const int sh_lo = SHARD ? V.shard_lo[V.prow_graph[min(row, V.nPr - 1)]] : 0, sh_hi = SHARD ? V.shard_hi[V.prow_graph[min(row, V.nPr - 1)]] : 0;
   const Pose Xown = load_pose16(V.pose, own);   // this row's vertex: loaded once, reused by every slot
   bool any_lm = false;
-  for (int s = s0; s < s1; ++s) {
+  int nround = s1 - s0;
+  if (ST) {   // the wave walks its rows' slot lists in lock step: as many rounds as its longest list
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) nround = max(nround, __shfl_xor(nround, o, 64));
+  }
+  // a block of the current slot: to its place in HBM, or (ST) to this thread's staging row
+  double* const my_stg = stg + (ST ? tid * kStgStride : 0);
+  auto put2 = [&](double* O, int k, double x, double y) { if (ST) { my_stg[k] = x; my_stg[k + 1] = y; } else store2(O + k, x, y); };
+  auto put1 = [&](double* O, int k, double x) { if (ST) my_stg[k] = x; else O[k] = x; };
+  for (int si = 0; si < nround; ++si) {
+    const int s = s0 + si;
+    int stage_sz = 0;
+    double* stage_dst = nullptr;
+    if (s < s1) {
     const int4 rec = V.pslot_rec[s];
     const int e = rec.x, kind = rec.y & 15, ia = rec.z, ib = rec.w;   // kind 3 (hand-over) is evaluated like kind 1 here
-    if (MODE == 1 && kind == 2) continue;
-    if (MODE == 2 && kind != 2) continue;
-    if (MODE == 2) any_lm = true;
-    if (MODE != 2 && kind != 2) {
+    const bool skip = (MODE == 1 && kind == 2) || (MODE == 2 && kind != 2);
+    if (MODE == 2 && !skip) any_lm = true;
+    if (skip) {
+    } else if (MODE != 2 && kind != 2) {
       // EdgeSE3: both Jacobians are 2 x 2 block upper triangular in 3 x 3 blocks,
       //   J_i = [[-Ra, 2 Ra [tb]x], [0, Ci]],   J_j = [[Re, 0], [0, Fj]],
       // so J^T Omega J is formed from 3 x 3 products of the blocks (half the FMAs and a smaller live set than dense 6 x 6).
@@ -488,11 +512,12 @@ __global__ __launch_bounds__(kRowThreads, MODE == 2 ? 4 : WPE) void k_linearize_
               o[c] = Ma[0] * E[c] + Ma[1] * E[3 + c] + Ma[2] * E[6 + c];
               o[3 + c] = Ma[3] * F[c] + Ma[4] * F[3 + c] + Ma[5] * F[6 + c];
             }
-            if (!swapped) { store2(O + a * 6, o[0], o[1]); store2(O + a * 6 + 2, o[2], o[3]); store2(O + a * 6 + 4, o[4], o[5]); }
+            if (!swapped) { put2(O, a * 6, o[0], o[1]); put2(O, a * 6 + 2, o[2], o[3]); put2(O, a * 6 + 4, o[4], o[5]); }
             else {
 #pragma unroll
-              for (int c = 0; c < 6; ++c) O[c * 6 + a] = o[c];
+              for (int c = 0; c < 6; ++c) put1(O, c * 6 + a, o[c]);
             }
+            stage_sz = 36; stage_dst = O;
           }
 #pragma unroll
           for (int c = a; c < 6; ++c) {   // row a of J^T Omega J, upper triangle
@@ -527,7 +552,7 @@ __global__ __launch_bounds__(kRowThreads, MODE == 2 ? 4 : WPE) void k_linearize_
           }
           M11[a * 3 + c] = m11; M12[a * 3 + c] = m12; M21[a * 3 + c] = m21; M22[a * 3 + c] = m22;
         }
-      const int blk = iside ? V.eo_blk[e] : -1;
+      const int blk = (iside && !(V.dbg & 16)) ? V.eo_blk[e] : -1;   // (SSLAM_LIN_DBG & 16: timing only, no off-diagonal stores)
       if (blk >= 0) {   // owner of the off-diagonal block: J_i^T Omega J_j = [[M11 E, M12 F], [M21 E, M22 F]]
         double* O = V.Hpp_off + (size_t)(blk >> 1) * 36;
         const bool swapped = blk & 1;
@@ -546,13 +571,14 @@ __global__ __launch_bounds__(kRowThreads, MODE == 2 ? 4 : WPE) void k_linearize_
           }
         if (!swapped) {   // stored [row_i][row_j]
 #pragma unroll
-          for (int k = 0; k < 36; k += 2) store2(O + k, o[k], o[k + 1]);
+          for (int k = 0; k < 36; k += 2) put2(O, k, o[k], o[k + 1]);
         } else {          // stored transposed
 #pragma unroll
           for (int c = 0; c < 6; ++c)
 #pragma unroll
-            for (int a = 0; a < 6; a += 2) store2(O + c * 6 + a, o[a * 6 + c], o[(a + 1) * 6 + c]);
+            for (int a = 0; a < 6; a += 2) put2(O, c * 6 + a, o[a * 6 + c], o[(a + 1) * 6 + c]);
         }
+        stage_sz = 36; stage_dst = O;
       }
       // diagonal block J^T Omega J (upper triangle) and b -= J^T Omega e
 #pragma unroll
@@ -620,7 +646,7 @@ __global__ __launch_bounds__(kRowThreads, MODE == 2 ? 4 : WPE) void k_linearize_
         for (int a = 0; a <= c; ++a) accD[tri21(a, c)][tid] += Ji[a] * WJi[c] + Ji[6 + a] * WJi[6 + c] + Ji[12 + a] * WJi[12 + c];
         accD[21 + c][tid] -= Ji[c] * We[0] + Ji[6 + c] * We[1] + Ji[12 + c] * We[2];
       }
-      const int blk = V.el_blk[e];
+      const int blk = (V.dbg & 16) ? -1 : V.el_blk[e];
       if (blk >= 0) {
         double WJl[9];
 #pragma unroll
@@ -634,9 +660,51 @@ __global__ __launch_bounds__(kRowThreads, MODE == 2 ? 4 : WPE) void k_linearize_
           for (int c = 0; c < 3; ++c) o[a * 3 + c] = Ji[a] * WJl[c] + Ji[6 + a] * WJl[3 + c] + Ji[12 + a] * WJl[6 + c];
         double* O = V.Hpl + (size_t)blk * 18;
 #pragma unroll
-        for (int k = 0; k < 18; k += 2) store2(O + k, o[k], o[k + 1]);
+        for (int k = 0; k < 18; k += 2) put2(O, k, o[k], o[k + 1]);
+        stage_sz = 18; stage_dst = O;
       }
     }
+    }   // s < s1
+    if (ST && __ballot(stage_sz > 0) != 0ull) {   // the staged blocks of this round -> HBM, 18 consecutive lanes per 288-byte block
+      s_dst[tid] = stage_dst; s_sz[tid] = stage_sz;
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll 2
+      for (int k = 0; k < 18; ++k) {
+        const int idx = k * kRowThreads + tid;
+        const int r = idx / 18, p2 = 2 * (idx - r * 18);
+        if (p2 < s_sz[r]) store2(s_dst[r] + p2, stg[r * kStgStride + p2], stg[r * kStgStride + p2 + 1]);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+  if (V.dbg & 32) return;   // (SSLAM_LIN_DBG & 32: timing only, no diagonal-block stores)
+  if (ST) {
+    // the workgroup's 64 diagonal blocks and rhs segments are contiguous in HBM: one coalesced stream out of the LDS columns; rows of
+    // graphs that are not linearising keep their previous values
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const unsigned long long act = __ballot(active);
+    const int row0 = blockIdx.x * kRowThreads;
+    double* Pd = V.Hpp_diag + (size_t)row0 * 36;
+#pragma unroll 2
+    for (int k = 0; k < 18; ++k) {
+      const int idx = k * kRowThreads + tid;
+      const int r = idx / 18, p = idx - r * 18;
+      const int a = p / 3, c = 2 * (p - 3 * a);
+      if (!((act >> r) & 1ull)) continue;
+      store2(Pd + (size_t)idx * 2, accD[a <= c ? tri21(a, c) : tri21(c, a)][r], accD[a <= c + 1 ? tri21(a, c + 1) : tri21(c + 1, a)][r]);
+    }
+    double* Bs = V.bvec + (size_t)row0 * 6;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const int idx = k * kRowThreads + tid;
+      const int r = idx / 3, p = idx - r * 3;
+      if (!((act >> r) & 1ull)) continue;
+      store2(Bs + (size_t)idx * 2, accD[21 + 2 * p][r], accD[22 + 2 * p][r]);
+    }
+    return;
   }
   double* P = V.Hpp_diag + (size_t)row * 36;
   double* Bv = V.bvec + (size_t)row * 6;
@@ -1930,6 +1998,7 @@ static int batch_linearize(Batch& b) {
   b.V.dbg = lin_dbg;
   static const int lin_handover = [] { const char* e = getenv("SSLAM_LIN_HANDOVER"); return e ? atoi(e) : 0; }();
   static const int lin_pair = [] { const char* e = getenv("SSLAM_LIN_PAIR"); return e ? atoi(e) : 0; }();   // 1: two role-specialised waves per 64-row tile (measured slower: 2.23 vs 1.89 ms); 0: one thread per row
+  static const int lin_stage = [] { const char* e = getenv("SSLAM_LIN_STAGE"); return e ? atoi(e) : 1; }();   // 1 (default): staged, coalesced block stores; 2: the same on the row-wise form; 0: per-thread stores
   static const int lin_rowwise = [] { const char* e = getenv("SSLAM_LIN_ROWWISE"); return e ? atoi(e) : 0; }();   // 1 | 2: row-wise EdgeSE3 form at one | two waves per SIMD
   static const int lin_split = [] { const char* e = getenv("SSLAM_LIN_SPLIT"); return e ? atoi(e) : 0; }();   // 1: EdgeSE3 slots and landmark slots of the pose rows in two launches (measured slower: 2.52 vs 2.01 ms)
   static const int lin_wpe = [] { const char* e = getenv("SSLAM_LIN_WPE"); return e ? atoi(e) : 1; }();   // waves per SIMD the pose-row kernel is compiled for
@@ -1939,16 +2008,18 @@ static int batch_linearize(Batch& b) {
       if (lin_handover) hipLaunchKernelGGL((k_linearize_rowthread_handover<PLV, SHV>), dim3(nblk), dim3(kRowThreads), 0, b.stream, V); \
       else if (lin_pair && lin_wpe == 3) hipLaunchKernelGGL((k_linearize_rowpair<PLV, SHV, 3>), dim3(nblk), dim3(2 * kRowThreads), 0, b.stream, V); \
       else if (lin_pair) hipLaunchKernelGGL((k_linearize_rowpair<PLV, SHV, 2>), dim3(nblk), dim3(2 * kRowThreads), 0, b.stream, V);   \
-      else if (!lin_split && lin_wpe == 2) hipLaunchKernelGGL((k_linearize_rowthread<PLV, SHV, 2, 0>), dim3(nblk), dim3(kRowThreads), 0, b.stream, V); \
-      else if (!lin_split && lin_wpe == 3) hipLaunchKernelGGL((k_linearize_rowthread<PLV, SHV, 3, 0>), dim3(nblk), dim3(kRowThreads), 0, b.stream, V); \
-      else if (lin_rowwise == 2) hipLaunchKernelGGL((k_linearize_rowthread<PLV, SHV, 2, 3>), dim3(nblk), dim3(kRowThreads), 0, b.stream, V); \
-      else if (lin_rowwise) hipLaunchKernelGGL((k_linearize_rowthread<PLV, SHV, 1, 3>), dim3(nblk), dim3(kRowThreads), 0, b.stream, V); \
+      else if (!lin_split && lin_wpe == 2) hipLaunchKernelGGL((k_linearize_rowthread<PLV, SHV, 2, 0, 0>), dim3(nblk), dim3(kRowThreads), 0, b.stream, V); \
+      else if (!lin_split && lin_wpe == 3) hipLaunchKernelGGL((k_linearize_rowthread<PLV, SHV, 3, 0, 0>), dim3(nblk), dim3(kRowThreads), 0, b.stream, V); \
+      else if (lin_rowwise == 2) hipLaunchKernelGGL((k_linearize_rowthread<PLV, SHV, 2, 3, 0>), dim3(nblk), dim3(kRowThreads), 0, b.stream, V); \
+      else if (lin_rowwise) hipLaunchKernelGGL((k_linearize_rowthread<PLV, SHV, 1, 3, 0>), dim3(nblk), dim3(kRowThreads), 0, b.stream, V); \
       else if (lin_split) {                                                                                                           \
-        if (lin_wpe == 2) hipLaunchKernelGGL((k_linearize_rowthread<PLV, SHV, 2, 1>), dim3(nblk), dim3(kRowThreads), 0, b.stream, V); \
-        else hipLaunchKernelGGL((k_linearize_rowthread<PLV, SHV, 1, 1>), dim3(nblk), dim3(kRowThreads), 0, b.stream, V);              \
-        hipLaunchKernelGGL((k_linearize_rowthread<PLV, SHV, 1, 2>), dim3(nblk), dim3(kRowThreads), 0, b.stream, V);                   \
+        if (lin_wpe == 2) hipLaunchKernelGGL((k_linearize_rowthread<PLV, SHV, 2, 1, 0>), dim3(nblk), dim3(kRowThreads), 0, b.stream, V); \
+        else hipLaunchKernelGGL((k_linearize_rowthread<PLV, SHV, 1, 1, 0>), dim3(nblk), dim3(kRowThreads), 0, b.stream, V);              \
+        hipLaunchKernelGGL((k_linearize_rowthread<PLV, SHV, 1, 2, 0>), dim3(nblk), dim3(kRowThreads), 0, b.stream, V);                   \
       }                                                                                                                               \
-      else hipLaunchKernelGGL((k_linearize_rowthread<PLV, SHV, 1, 0>), dim3(nblk), dim3(kRowThreads), 0, b.stream, V);                \
+      else if (lin_stage == 2) hipLaunchKernelGGL((k_linearize_rowthread<PLV, SHV, 2, 3, 1>), dim3(nblk), dim3(kRowThreads), 0, b.stream, V); \
+      else if (lin_stage) hipLaunchKernelGGL((k_linearize_rowthread<PLV, SHV, 1, 0, 1>), dim3(nblk), dim3(kRowThreads), 0, b.stream, V); \
+      else hipLaunchKernelGGL((k_linearize_rowthread<PLV, SHV, 1, 0, 0>), dim3(nblk), dim3(kRowThreads), 0, b.stream, V);             \
     }                                                                                                                                 \
     if (V.nLr > 0) hipLaunchKernelGGL((k_linearize_lm_rows<PLV, SHV>), dim3((V.nLr + 15) / 16), dim3(256), 0, lm_stream, V);           \
     if (V.nLL > 0) hipLaunchKernelGGL((k_linearize_ll<SHV>), dim3((V.nLL + 63) / 64), dim3(64), 0, lm_stream, V);                      \
