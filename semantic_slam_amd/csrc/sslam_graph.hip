@@ -387,13 +387,16 @@ __global__ __launch_bounds__(kRowThreads) void k_linearize_rowthread_handover(Ba
 // MODE 0: every slot of the row.  MODE 1 / 2 (round 4, SSLAM_LIN_SPLIT): the row's EdgeSE3 slots and its landmark slots in two launches --
 // the EdgeSE3 pass (the register-hungry one, one wave per SIMD) then carries two of a row's five slots, the landmark pass compiles to ~100
 // VGPRs (five waves per SIMD) and adds its sums to the diagonal block and b the first pass wrote.
-// ST (round 4, the default): STAGED STORES.  Timing the kernel without its stores (SSLAM_LIN_DBG=16 / 32 / 48: 1.99 -> 1.22 / 1.69 / 0.95 ms
-// per 512-graph build) showed what bounds it: not registers, occupancy or arithmetic (four restructurings for those were all slower)
-// but the stores -- every thread writing its own 288-byte (or 144-byte) block with 16-byte stores at a 288-byte lane stride is 66 store
-// instructions per row that each touch 64 different cache lines.  With ST a slot's block goes to an LDS row of its thread and the WAVE
-// writes the 64 blocks of the slot round together, consecutive lanes on consecutive 16-byte pieces of one block (a block is 18
-// consecutive lanes: whole cache lines per request); the diagonal blocks and b of the workgroup's 64 rows, contiguous in HBM, leave as
-// one stream.  Same values, same order of the sums.
+// ST (round 4, SSLAM_LIN_STAGE=1): STAGED STORES.  Timing the kernel without its stores (SSLAM_LIN_DBG=16 / 32 / 48: 1.99 -> 1.22 / 1.69 /
+// 0.95 ms per 512-graph build) showed where half of its time goes: not registers, occupancy or arithmetic (four restructurings for those
+// were all slower) but the 66 store instructions of a row.  With ST a slot's block goes to an LDS row of its thread and the WAVE writes
+// the 64 blocks of the slot round together, consecutive lanes on consecutive 16-byte pieces of one block (whole cache lines per
+// request); the diagonal blocks and b of the workgroup's 64 rows, contiguous in HBM, leave as one stream.  Same values, same order of
+// the sums -- and the SAME TIME (2.06 vs 2.02 ms): it is not the shape of the stores either.  Sending the off-diagonal blocks into a
+// 4.7 MB window that never leaves L2 (SSLAM_LIN_DBG=64) takes 0.18 ms off, so HBM writes are not it (a plain 2.77 GB memset runs at
+// 6.3 TB/s on the same box, tools/hbm_write_probe.py): what costs is issuing a store between the loads of consecutive slots -- on
+// gfx9-class hardware loads and stores share one in-order counter (vmcnt), so the next slot's loads wait for this slot's store
+// acknowledgements.  Not fixed this round; per-thread stores stay the default.
 constexpr int kStgStride = 37;   // doubles per staged block row (36 + 1: the per-thread writes spread over the LDS banks)
 template <bool PL, bool SHARD, int WPE, int MODE, int ST>
 __global__ __launch_bounds__(kRowThreads, MODE == 2 ? 4 : WPE) void k_linearize_rowthread(BatchView V) {
@@ -554,7 +557,7 @@ __global__ __launch_bounds__(kRowThreads, MODE == 2 ? 4 : WPE) void k_linearize_
         }
       const int blk = (iside && !(V.dbg & 16)) ? V.eo_blk[e] : -1;   // (SSLAM_LIN_DBG & 16: timing only, no off-diagonal stores)
       if (blk >= 0) {   // owner of the off-diagonal block: J_i^T Omega J_j = [[M11 E, M12 F], [M21 E, M22 F]]
-        double* O = V.Hpp_off + (size_t)(blk >> 1) * 36;
+        double* O = V.Hpp_off + ((V.dbg & 64) ? (size_t)(tid + 64 * (blockIdx.x & 255)) : (size_t)(blk >> 1)) * 36;   // (dbg 64: timing only, every block into a 4.7 MB window)
         const bool swapped = blk & 1;
         double o[36];
 #pragma unroll
@@ -658,7 +661,7 @@ __global__ __launch_bounds__(kRowThreads, MODE == 2 ? 4 : WPE) void k_linearize_
         for (int a = 0; a < 6; ++a)
 #pragma unroll
           for (int c = 0; c < 3; ++c) o[a * 3 + c] = Ji[a] * WJl[c] + Ji[6 + a] * WJl[3 + c] + Ji[12 + a] * WJl[6 + c];
-        double* O = V.Hpl + (size_t)blk * 18;
+        double* O = V.Hpl + ((V.dbg & 64) ? (size_t)(tid + 64 * (blockIdx.x & 255)) : (size_t)blk) * 18;
 #pragma unroll
         for (int k = 0; k < 18; k += 2) put2(O, k, o[k], o[k + 1]);
         stage_sz = 18; stage_dst = O;
@@ -1998,7 +2001,7 @@ static int batch_linearize(Batch& b) {
   b.V.dbg = lin_dbg;
   static const int lin_handover = [] { const char* e = getenv("SSLAM_LIN_HANDOVER"); return e ? atoi(e) : 0; }();
   static const int lin_pair = [] { const char* e = getenv("SSLAM_LIN_PAIR"); return e ? atoi(e) : 0; }();   // 1: two role-specialised waves per 64-row tile (measured slower: 2.23 vs 1.89 ms); 0: one thread per row
-  static const int lin_stage = [] { const char* e = getenv("SSLAM_LIN_STAGE"); return e ? atoi(e) : 1; }();   // 1 (default): staged, coalesced block stores; 2: the same on the row-wise form; 0: per-thread stores
+  static const int lin_stage = [] { const char* e = getenv("SSLAM_LIN_STAGE"); return e ? atoi(e) : 0; }();   // 1: staged, coalesced block stores; 2: the same on the row-wise form; 0 (default): per-thread stores (measured the same time)
   static const int lin_rowwise = [] { const char* e = getenv("SSLAM_LIN_ROWWISE"); return e ? atoi(e) : 0; }();   // 1 | 2: row-wise EdgeSE3 form at one | two waves per SIMD
   static const int lin_split = [] { const char* e = getenv("SSLAM_LIN_SPLIT"); return e ? atoi(e) : 0; }();   // 1: EdgeSE3 slots and landmark slots of the pose rows in two launches (measured slower: 2.52 vs 2.01 ms)
   static const int lin_wpe = [] { const char* e = getenv("SSLAM_LIN_WPE"); return e ? atoi(e) : 1; }();   // waves per SIMD the pose-row kernel is compiled for
