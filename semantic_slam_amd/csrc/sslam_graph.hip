@@ -394,9 +394,12 @@ __global__ __launch_bounds__(kRowThreads) void k_linearize_rowthread_handover(Ba
 // request); the diagonal blocks and b of the workgroup's 64 rows, contiguous in HBM, leave as one stream.  Same values, same order of
 // the sums -- and the SAME TIME (2.06 vs 2.02 ms): it is not the shape of the stores either.  Sending the off-diagonal blocks into a
 // 4.7 MB window that never leaves L2 (SSLAM_LIN_DBG=64) takes 0.18 ms off, so HBM writes are not it (a plain 2.77 GB memset runs at
-// 6.3 TB/s on the same box, tools/hbm_write_probe.py): what costs is issuing a store between the loads of consecutive slots -- on
-// gfx9-class hardware loads and stores share one in-order counter (vmcnt), so the next slot's loads wait for this slot's store
-// acknowledgements.  Not fixed this round; per-thread stores stay the default.
+// 6.3 TB/s on the same box, tools/hbm_write_probe.py).  ST == 2 (SSLAM_LIN_STAGE=3) tested the remaining suspect -- loads and stores
+// retire through one in-order counter (vmcnt), so a store issued in front of the next slot's loads would delay them by its round trip --
+// by requesting a round's inputs (slot_fetch) BEFORE the previous round's staged blocks are stored: 2.09 vs 2.07 ms, refuted as well.
+// What is left is the life time of a wave at ONE wave per SIMD (304 VGPRs): nothing else runs on the SIMD while it waits, and every
+// store instruction adds its issue and its end-of-wave acknowledgement to that life time.  Not fixed this round;
+// per-thread stores stay the default.
 constexpr int kStgStride = 37;   // doubles per staged block row (36 + 1: the per-thread writes spread over the LDS banks)
 template <bool PL, bool SHARD, int WPE, int MODE, int ST>
 __global__ __launch_bounds__(kRowThreads, MODE == 2 ? 4 : WPE) void k_linearize_rowthread(BatchView V) {
@@ -424,12 +427,34 @@ __global__ __launch_bounds__(kRowThreads, MODE == 2 ? 4 : WPE) void k_linearize_
   double* const my_stg = stg + (ST ? tid * kStgStride : 0);
   auto put2 = [&](double* O, int k, double x, double y) { if (ST) { my_stg[k] = x; my_stg[k + 1] = y; } else store2(O + k, x, y); };
   auto put1 = [&](double* O, int k, double x) { if (ST) my_stg[k] = x; else O[k] = x; };
+  constexpr bool EF = (ST == 2);   // early fetch: a round's inputs are requested BEFORE the previous round's staged blocks are stored
+  bool pending = false;            // (EF) the previous round left staged blocks to write (wave-uniform)
+  auto write_staged = [&]() {      // the staged blocks of a round -> HBM, 18 consecutive lanes per 288-byte block
+#pragma unroll 2
+    for (int k = 0; k < 18; ++k) {
+      const int idx = k * kRowThreads + tid;
+      const int r = idx / 18, p2 = 2 * (idx - r * 18);
+      if (p2 < s_sz[r]) store2(s_dst[r] + p2, stg[r * kStgStride + p2], stg[r * kStgStride + p2 + 1]);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  };
   for (int si = 0; si < nround; ++si) {
     const int s = s0 + si;
     int stage_sz = 0;
     double* stage_dst = nullptr;
+    int4 rec = make_int4(0, 0, 0, 0);
+    SlotData D;
+    if (EF) {
+      // loads and stores retire through one in-order counter: a store issued in front of a load delays it by the store's round trip.
+      // So: this round's loads first, THEN the previous round's stores (their acknowledgements arrive during this round's arithmetic).
+      if (s < s1) { rec = V.pslot_rec[s]; slot_fetch<PL, SHARD>(V, make_int4(rec.x, (rec.y & 15) == 3 ? 1 : (rec.y & 15), rec.z, rec.w), D); }
+      asm volatile("" ::: "memory");
+      if (pending) write_staged();
+      asm volatile("" ::: "memory");
+    }
     if (s < s1) {
-    const int4 rec = V.pslot_rec[s];
+    if (!EF) rec = V.pslot_rec[s];
     const int e = rec.x, kind = rec.y & 15, ia = rec.z, ib = rec.w;   // kind 3 (hand-over) is evaluated like kind 1 here
     const bool skip = (MODE == 1 && kind == 2) || (MODE == 2 && kind != 2);
     if (MODE == 2 && !skip) any_lm = true;
@@ -441,18 +466,22 @@ __global__ __launch_bounds__(kRowThreads, MODE == 2 ? 4 : WPE) void k_linearize_
       const int n = V.nEo;
       const bool iside = (kind == 0);
       Se3Lin L;
-      se3_error(iside ? Xown : load_pose16(V.pose, ia), iside ? load_pose16(V.pose, ib) : Xown, load_meas_pose(V.eo_z, n, e), L);
+      const Pose Xo = EF ? Pose{{D.o[0], D.o[1], D.o[2]}, {D.o[3], D.o[4], D.o[5], D.o[6]}} : load_pose16(V.pose, iside ? ib : ia);
+      const Pose Zm = EF ? Pose{{D.z[0], D.z[1], D.z[2]}, {D.z[3], D.z[4], D.z[5], D.z[6]}} : load_meas_pose(V.eo_z, n, e);
+      se3_error(iside ? Xown : Xo, iside ? Xo : Xown, Zm, L);
       double P[9], Q[9], R[9];   // Omega = [[P, Q], [Q^T, R]]
       // edge-sharded mode: an edge outside this rank's range contributes nothing (everything below is linear in Omega; the owner
       // of an off-diagonal block still writes it, as zeros)
-      const double mk = (!SHARD || (V.eo_id[e] >= sh_lo && V.eo_id[e] < sh_hi)) ? 1.0 : 0.0;
+      const int eid = SHARD ? (EF ? D.id : V.eo_id[e]) : 0;
+      const double mk = (!SHARD || (eid >= sh_lo && eid < sh_hi)) ? 1.0 : 0.0;
+      auto w21 = [&](int q) { return EF ? D.w[q] : V.eo_w[(size_t)q * n + e]; };
 #pragma unroll
       for (int r = 0; r < 3; ++r)
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-          P[r * 3 + c] = mk * V.eo_w[(size_t)(r <= c ? tri21(r, c) : tri21(c, r)) * n + e];
-          Q[r * 3 + c] = mk * V.eo_w[(size_t)tri21(r, 3 + c) * n + e];
-          R[r * 3 + c] = mk * V.eo_w[(size_t)(r <= c ? tri21(3 + r, 3 + c) : tri21(3 + c, 3 + r)) * n + e];
+          P[r * 3 + c] = mk * w21(r <= c ? tri21(r, c) : tri21(c, r));
+          Q[r * 3 + c] = mk * w21(tri21(r, 3 + c));
+          R[r * 3 + c] = mk * w21(r <= c ? tri21(3 + r, 3 + c) : tri21(3 + c, 3 + r));
         }
       double A[9], B[9], Cc[9];   // own Jacobian [[A, B], [0, Cc]]  (B = 0 on the j side)
       if (iside) {
@@ -555,7 +584,7 @@ __global__ __launch_bounds__(kRowThreads, MODE == 2 ? 4 : WPE) void k_linearize_
           }
           M11[a * 3 + c] = m11; M12[a * 3 + c] = m12; M21[a * 3 + c] = m21; M22[a * 3 + c] = m22;
         }
-      const int blk = (iside && !(V.dbg & 16)) ? V.eo_blk[e] : -1;   // (SSLAM_LIN_DBG & 16: timing only, no off-diagonal stores)
+      const int blk = (iside && !(V.dbg & 16)) ? (EF ? D.blk : V.eo_blk[e]) : -1;   // (SSLAM_LIN_DBG & 16: timing only, no off-diagonal stores)
       if (blk >= 0) {   // owner of the off-diagonal block: J_i^T Omega J_j = [[M11 E, M12 F], [M21 E, M22 F]]
         double* O = V.Hpp_off + ((V.dbg & 64) ? (size_t)(tid + 64 * (blockIdx.x & 255)) : (size_t)(blk >> 1)) * 36;   // (dbg 64: timing only, every block into a 4.7 MB window)
         const bool swapped = blk & 1;
@@ -612,23 +641,27 @@ __global__ __launch_bounds__(kRowThreads, MODE == 2 ? 4 : WPE) void k_linearize_
       const int n = V.nEl;
       const Pose Xi = Xown;
       const double* lp = V.lmk + (size_t)ib * 4;
+      auto lpv = [&](int k) { return EF ? D.o[k] : lp[k]; };
+      auto zl = [&](int k) { return EF ? D.z[k] : V.el_z[k * (size_t)n + e]; };
       double err[3], Ji[18], Jl[9];   // Ji row-major 3x6, Jl row-major 3x3
-      if (!PL || V.lm_kind[ib] == VT_POINT) {
+      if (!PL || (EF ? D.lk : V.lm_kind[ib]) == VT_POINT) {
         PointLin L;
-        point_error(Xi, Vec3{lp[0], lp[1], lp[2]}, Vec3{V.el_z[0 * (size_t)n + e], V.el_z[1 * (size_t)n + e], V.el_z[2 * (size_t)n + e]}, L);
+        point_error(Xi, Vec3{lpv(0), lpv(1), lpv(2)}, Vec3{zl(0), zl(1), zl(2)}, L);
         point_jacobians(L, Ji, Jl);
         err[0] = L.e[0]; err[1] = L.e[1]; err[2] = L.e[2];
       } else {
-        const Plane pw{{lp[0], lp[1], lp[2]}, lp[3]};
-        const Plane z{{V.el_z[0 * (size_t)n + e], V.el_z[1 * (size_t)n + e], V.el_z[2 * (size_t)n + e]}, V.el_z[3 * (size_t)n + e]};
+        const Plane pw{{lpv(0), lpv(1), lpv(2)}, lpv(3)};
+        const Plane z{{zl(0), zl(1), zl(2)}, zl(3)};
         plane_error(Xi, pw, z, err);
         plane_jacobians(Xi, pw, z, Ji, Jl);
       }
       double W[9];
-      load_sym3(V.el_w, n, e, W);
+      if (EF) { W[0] = D.w[0]; W[1] = W[3] = D.w[1]; W[2] = W[6] = D.w[2]; W[4] = D.w[3]; W[5] = W[7] = D.w[4]; W[8] = D.w[5]; }
+      else load_sym3(V.el_w, n, e, W);
       double dcs = 1.0;
       if (V.dcs_phi > 0) dcs = dcs_rho1(V.dcs_phi, quad3(W, err));   // from the unmasked Omega: every rank scales its share alike
-      if (SHARD && !(V.el_id[e] >= sh_lo && V.el_id[e] < sh_hi)) {
+      const int lid = SHARD ? (EF ? D.id : V.el_id[e]) : 0;
+      if (SHARD && !(lid >= sh_lo && lid < sh_hi)) {
 #pragma unroll
         for (int q = 0; q < 9; ++q) W[q] = 0.0;
       }
@@ -649,7 +682,7 @@ __global__ __launch_bounds__(kRowThreads, MODE == 2 ? 4 : WPE) void k_linearize_
         for (int a = 0; a <= c; ++a) accD[tri21(a, c)][tid] += Ji[a] * WJi[c] + Ji[6 + a] * WJi[6 + c] + Ji[12 + a] * WJi[12 + c];
         accD[21 + c][tid] -= Ji[c] * We[0] + Ji[6 + c] * We[1] + Ji[12 + c] * We[2];
       }
-      const int blk = (V.dbg & 16) ? -1 : V.el_blk[e];
+      const int blk = (V.dbg & 16) ? -1 : (EF ? D.blk : V.el_blk[e]);
       if (blk >= 0) {
         double WJl[9];
 #pragma unroll
@@ -668,20 +701,17 @@ __global__ __launch_bounds__(kRowThreads, MODE == 2 ? 4 : WPE) void k_linearize_
       }
     }
     }   // s < s1
-    if (ST && __ballot(stage_sz > 0) != 0ull) {   // the staged blocks of this round -> HBM, 18 consecutive lanes per 288-byte block
-      s_dst[tid] = stage_dst; s_sz[tid] = stage_sz;
-      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-#pragma unroll 2
-      for (int k = 0; k < 18; ++k) {
-        const int idx = k * kRowThreads + tid;
-        const int r = idx / 18, p2 = 2 * (idx - r * 18);
-        if (p2 < s_sz[r]) store2(s_dst[r] + p2, stg[r * kStgStride + p2], stg[r * kStgStride + p2 + 1]);
+    if (ST) {
+      pending = __ballot(stage_sz > 0) != 0ull;
+      if (pending) {
+        s_dst[tid] = stage_dst; s_sz[tid] = stage_sz;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (!EF) write_staged();   // (EF: after the next round's loads have been issued)
       }
-      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-      __builtin_amdgcn_wave_barrier();
     }
   }
+  if (EF && pending) write_staged();
   if (V.dbg & 32) return;   // (SSLAM_LIN_DBG & 32: timing only, no diagonal-block stores)
   if (ST) {
     // the workgroup's 64 diagonal blocks and rhs segments are contiguous in HBM: one coalesced stream out of the LDS columns; rows of
@@ -2001,7 +2031,7 @@ static int batch_linearize(Batch& b) {
   b.V.dbg = lin_dbg;
   static const int lin_handover = [] { const char* e = getenv("SSLAM_LIN_HANDOVER"); return e ? atoi(e) : 0; }();
   static const int lin_pair = [] { const char* e = getenv("SSLAM_LIN_PAIR"); return e ? atoi(e) : 0; }();   // 1: two role-specialised waves per 64-row tile (measured slower: 2.23 vs 1.89 ms); 0: one thread per row
-  static const int lin_stage = [] { const char* e = getenv("SSLAM_LIN_STAGE"); return e ? atoi(e) : 0; }();   // 1: staged, coalesced block stores; 2: the same on the row-wise form; 0 (default): per-thread stores (measured the same time)
+  static const int lin_stage = [] { const char* e = getenv("SSLAM_LIN_STAGE"); return e ? atoi(e) : 0; }();   // 1: staged, coalesced block stores; 2: the same on the row-wise form; 3: staged + early fetch; 0 (default): per-thread stores (measured the same time)
   static const int lin_rowwise = [] { const char* e = getenv("SSLAM_LIN_ROWWISE"); return e ? atoi(e) : 0; }();   // 1 | 2: row-wise EdgeSE3 form at one | two waves per SIMD
   static const int lin_split = [] { const char* e = getenv("SSLAM_LIN_SPLIT"); return e ? atoi(e) : 0; }();   // 1: EdgeSE3 slots and landmark slots of the pose rows in two launches (measured slower: 2.52 vs 2.01 ms)
   static const int lin_wpe = [] { const char* e = getenv("SSLAM_LIN_WPE"); return e ? atoi(e) : 1; }();   // waves per SIMD the pose-row kernel is compiled for
@@ -2020,6 +2050,7 @@ static int batch_linearize(Batch& b) {
         else hipLaunchKernelGGL((k_linearize_rowthread<PLV, SHV, 1, 1, 0>), dim3(nblk), dim3(kRowThreads), 0, b.stream, V);              \
         hipLaunchKernelGGL((k_linearize_rowthread<PLV, SHV, 1, 2, 0>), dim3(nblk), dim3(kRowThreads), 0, b.stream, V);                   \
       }                                                                                                                               \
+      else if (lin_stage == 3) hipLaunchKernelGGL((k_linearize_rowthread<PLV, SHV, 1, 0, 2>), dim3(nblk), dim3(kRowThreads), 0, b.stream, V); \
       else if (lin_stage == 2) hipLaunchKernelGGL((k_linearize_rowthread<PLV, SHV, 2, 3, 1>), dim3(nblk), dim3(kRowThreads), 0, b.stream, V); \
       else if (lin_stage) hipLaunchKernelGGL((k_linearize_rowthread<PLV, SHV, 1, 0, 1>), dim3(nblk), dim3(kRowThreads), 0, b.stream, V); \
       else hipLaunchKernelGGL((k_linearize_rowthread<PLV, SHV, 1, 0, 0>), dim3(nblk), dim3(kRowThreads), 0, b.stream, V);             \
