@@ -147,6 +147,7 @@ struct CholOpts {
   double order_mul = -1;   // a round eliminates an independent set of the nodes with degree <= order_mul * (minimum degree) + order_add;
   int order_add = -1;      // -1: (2.0, 4) for batches < 32 (shallowest tree: latency), (1.5, 2) for larger ones (less fill and smaller update
                            // matrices, five levels more: throughput -- measured 9.30 vs 9.48 ms per 512 factorisations)
+  int order_bits_max = 2048;   // graphs up to this many nodes are ordered on adjacency bitsets (same order, a fraction of the time); 0: never
   bool dump = false;
   static int env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
   void from_env() {
@@ -158,6 +159,7 @@ struct CholOpts {
     group_cap = env_int("SSLAM_CHOL_GROUP_CAP", group_cap); group_blocks = env_int("SSLAM_CHOL_GROUP_BLOCKS", group_blocks);
     ustage = env_int("SSLAM_CHOL_USTAGE", ustage);
     small_cols = env_int("SSLAM_CHOL_SMALL_COLS", small_cols);
+    order_bits_max = env_int("SSLAM_CHOL_ORDER_BITS", order_bits_max);
     if (const char* e = getenv("SSLAM_CHOL_ORDER")) order = (!strcmp(e, "mindeg") || !strcmp(e, "0")) ? 0 : ((!strcmp(e, "auto") || !strcmp(e, "-1")) ? -1 : 1);
     if (const char* e = getenv("SSLAM_CHOL_ORDER_SLACK")) { double m = 0; int a = 0; if (sscanf(e, "%lf,%d", &m, &a) == 2 && m >= 1.0 && a >= 0) { order_mul = m; order_add = a; } }
     dump = getenv("SSLAM_CHOL_DUMP") != nullptr;
@@ -186,7 +188,7 @@ namespace chol_detail {
 
 struct GraphSym {
   std::vector<int> order;                  // elimination order (local node ids)
-  std::vector<std::vector<int>> cstruct;   // per node: higher-ordered neighbours at elimination time
+  std::vector<int> cs_start, cs_len, cs_idx;   // per node: higher-ordered neighbours at elimination time, cs_idx[cs_start[v] .. + cs_len[v]) ascending
 };
 
 // minimum degree with explicit fill (the block graphs here have ~1e4 nodes and fill ~1.7x)
@@ -196,7 +198,7 @@ inline void min_degree(int n, std::vector<std::vector<int>>& adj, GraphSym& out)
   std::priority_queue<Item, std::vector<Item>, std::greater<Item>> pq;
   for (int v = 0; v < n; ++v) { std::sort(adj[v].begin(), adj[v].end()); pq.push({(int)adj[v].size(), v}); }
   out.order.clear(); out.order.reserve(n);
-  out.cstruct.assign(n, {});
+  out.cs_start.assign(n, 0); out.cs_len.assign(n, 0); out.cs_idx.clear();
   std::vector<int> merged;
   while (!pq.empty()) {
     const Item it = pq.top(); pq.pop();
@@ -205,7 +207,7 @@ inline void min_degree(int n, std::vector<std::vector<int>>& adj, GraphSym& out)
     done[v] = 1;
     out.order.push_back(v);
     std::vector<int>& nb = adj[v];
-    out.cstruct[v] = nb;
+    out.cs_start[v] = (int)out.cs_idx.size(); out.cs_len[v] = (int)nb.size(); out.cs_idx.insert(out.cs_idx.end(), nb.begin(), nb.end());
     for (int u : nb) {
       std::vector<int>& au = adj[u];
       merged.clear();
@@ -231,7 +233,7 @@ inline void multi_min_degree(int n, std::vector<std::vector<int>>& adj, GraphSym
   std::vector<int> live(n), cand, picked, merged;
   for (int v = 0; v < n; ++v) { std::sort(adj[v].begin(), adj[v].end()); live[v] = v; }
   out.order.clear(); out.order.reserve(n);
-  out.cstruct.assign(n, {});
+  out.cs_start.assign(n, 0); out.cs_len.assign(n, 0); out.cs_idx.clear();
   while (!live.empty()) {
     int mind = n;
     for (int v : live) mind = std::min(mind, (int)adj[v].size());
@@ -250,7 +252,7 @@ inline void multi_min_degree(int n, std::vector<std::vector<int>>& adj, GraphSym
       alive[v] = 0;
       out.order.push_back(v);
       std::vector<int>& nb = adj[v];
-      out.cstruct[v] = nb;
+      out.cs_start[v] = (int)out.cs_idx.size(); out.cs_len[v] = (int)nb.size(); out.cs_idx.insert(out.cs_idx.end(), nb.begin(), nb.end());
       for (int u : nb) {
         std::vector<int>& au = adj[u];
         merged.clear();
@@ -267,6 +269,71 @@ inline void multi_min_degree(int n, std::vector<std::vector<int>>& adj, GraphSym
   }
 }
 
+// The same algorithm on adjacency BITSETS, for the graphs the orchestrator's tick re-plans every time it runs (a few hundred nodes: a row is
+// a handful of words, the fill of an elimination is one OR per neighbour, a node's structure is read off its row in ascending order).
+// Produces exactly the order and the column structures of multi_min_degree (same candidates, same tie breaks); 0.44 -> 0.09 ms of the
+// 2.1 ms host phase at 436 keyframes.
+template <class Neighbours>   // neighbours(v, f): calls f(u) for every neighbour u of node v
+inline void multi_min_degree_bits(int n, Neighbours&& neighbours, GraphSym& out, double mul, int add) {
+  const int W = (n + 63) / 64;
+  std::vector<uint64_t> bits((size_t)n * W, 0);
+  std::vector<int> deg(n, 0);
+  auto row = [&](int v) { return bits.data() + (size_t)v * W; };
+  for (int v = 0; v < n; ++v) neighbours(v, [&](int u) { row(v)[u >> 6] |= 1ull << (u & 63); });
+  for (int v = 0; v < n; ++v) { int d = 0; for (int w = 0; w < W; ++w) d += __builtin_popcountll(row(v)[w]); deg[v] = d; }
+  std::vector<char> alive(n, 1), blocked(n, 0);
+  std::vector<int> live(n), cand, picked, cnt;
+  for (int v = 0; v < n; ++v) live[v] = v;
+  out.order.clear(); out.order.reserve(n);
+  out.cs_start.assign(n, 0); out.cs_len.assign(n, 0); out.cs_idx.clear();
+  auto for_bits = [&](const uint64_t* r, auto&& f) {
+    for (int w = 0; w < W; ++w) { uint64_t m = r[w]; while (m) { const int b = __builtin_ctzll(m); m &= m - 1; f(w * 64 + b); } }
+  };
+  while (!live.empty()) {
+    int mind = n;
+    for (int v : live) mind = std::min(mind, deg[v]);
+    const int lim = (int)(mul * mind) + add;
+    // candidates by (degree, index): live ascends, a counting sort by degree keeps the index order inside a degree
+    cnt.assign(lim - mind + 2, 0);
+    for (int v : live) if (deg[v] <= lim) cnt[deg[v] - mind + 1]++;
+    for (int d = 0; d + 1 < (int)cnt.size(); ++d) cnt[d + 1] += cnt[d];
+    cand.resize(cnt.back());
+    for (int v : live) if (deg[v] <= lim) cand[cnt[deg[v] - mind]++] = v;
+    picked.clear();
+    for (int v : cand) {
+      if (blocked[v]) continue;
+      picked.push_back(v);
+      for_bits(row(v), [&](int u) { blocked[u] = 1; });
+    }
+    for (int v : picked) for_bits(row(v), [&](int u) { blocked[u] = 0; });
+    for (int v : picked) {
+      alive[v] = 0;
+      out.order.push_back(v);
+      uint64_t* rv = row(v);
+      const int cs0 = (int)out.cs_idx.size();
+      out.cs_start[v] = cs0;
+      for_bits(rv, [&](int u) { out.cs_idx.push_back(u); });
+      const int cs1 = (int)out.cs_idx.size();
+      out.cs_len[v] = cs1 - cs0;
+      for (int ci = cs0; ci < cs1; ++ci) {
+        const int u = out.cs_idx[ci];
+        uint64_t* ru = row(u);
+        int d = 0;
+        for (int w = 0; w < W; ++w) ru[w] |= rv[w];
+        ru[u >> 6] &= ~(1ull << (u & 63));
+        ru[v >> 6] &= ~(1ull << (v & 63));
+        for (int w = 0; w < W; ++w) d += __builtin_popcountll(ru[w]);
+        deg[u] = d;
+      }
+      for (int w = 0; w < W; ++w) rv[w] = 0;
+      deg[v] = 0;
+    }
+    size_t k = 0;
+    for (int v : live) if (alive[v]) live[k++] = v;
+    live.resize(k);
+  }
+}
+
 // Greedy bottom-up cut of an elimination tree (columns 0..n-1 in elimination order, parent[s] > s or -1) into pieces:
 // a column joins the still-open pieces of its children, largest first, while the caps hold; whatever does not fit is
 // closed.  fixed[s] >= 0 pins column s to an existing piece id (treated as closed).  Returns the piece id per column
@@ -274,16 +341,25 @@ inline void multi_min_degree(int n, std::vector<std::vector<int>>& adj, GraphSym
 inline int cut_pieces(int n, const std::vector<int>& parent, const std::vector<int>& colsz, const std::vector<int>& colnb,
                       const std::vector<int>& fixed, int first_new_id, int cap, int max_blocks, std::vector<int>& pc) {
   pc.assign(n, -1);
-  std::vector<std::vector<int>> kids(n);
-  for (int s = 0; s < n; ++s) if (parent[s] >= 0) kids[parent[s]].push_back(s);
-  std::vector<std::vector<int>> members;   // per new piece (index = id - first_new_id)
+  // children lists in CSR form (ascending inside a list, like the per-column vectors they replace); the columns of a piece as a linked
+  // list (only ever walked to relabel them); scratch allocated once
+  std::vector<int> kptr(n + 1, 0), kidx(n);
+  for (int s = 0; s < n; ++s) if (parent[s] >= 0) kptr[parent[s] + 1]++;
+  for (int s = 0; s < n; ++s) kptr[s + 1] += kptr[s];
+  {
+    std::vector<int> cur(kptr.begin(), kptr.end() - 1);
+    for (int s = 0; s < n; ++s) if (parent[s] >= 0) kidx[cur[parent[s]]++] = s;
+  }
+  std::vector<int> mhead, mtail, mnext(n, -1);   // per new piece (index = id - first_new_id): first / last column; next column of a column
   std::vector<int> psize, pblk;
   std::vector<char> open;
   std::vector<int> il(n, 0);               // level of a column inside its piece
+  std::vector<int> cand, take;
   for (int s = 0; s < n; ++s) {
     if (fixed[s] >= 0) { pc[s] = fixed[s]; continue; }
-    std::vector<int> cand;                 // open pieces of the children
-    for (int c : kids[s]) {
+    cand.clear();                          // open pieces of the children
+    for (int kq = kptr[s]; kq < kptr[s + 1]; ++kq) {
+      const int c = kidx[kq];
       const int p = pc[c];
       if (fixed[c] >= 0) continue;
       if (open[p - first_new_id] && std::find(cand.begin(), cand.end(), p) == cand.end()) cand.push_back(p);
@@ -293,11 +369,11 @@ inline int cut_pieces(int n, const std::vector<int>& parent, const std::vector<i
       return sa != sb ? sa > sb : a < b;
     });
     int size = colsz[s], nb = colnb[s], lev = 0;
-    std::vector<int> take;
+    take.clear();
     for (int p : cand) {
       const int q = p - first_new_id;
       int l = 0;
-      for (int c : kids[s]) if (pc[c] == p) l = std::max(l, il[c] + 1);
+      for (int kq = kptr[s]; kq < kptr[s + 1]; ++kq) if (pc[kidx[kq]] == p) l = std::max(l, il[kidx[kq]] + 1);
       if (size + psize[q] <= cap && nb + pblk[q] <= max_blocks && std::max(lev, l) < kMaxILevels) {
         size += psize[q]; nb += pblk[q]; lev = std::max(lev, l); take.push_back(p);
       }
@@ -305,22 +381,24 @@ inline int cut_pieces(int n, const std::vector<int>& parent, const std::vector<i
     for (int p : cand) open[p - first_new_id] = 0;   // merged or closed: either way no longer a candidate
     int id;
     if (take.empty()) {
-      id = first_new_id + (int)members.size();
-      members.push_back({}); psize.push_back(0); pblk.push_back(0); open.push_back(1);
+      id = first_new_id + (int)mhead.size();
+      mhead.push_back(-1); mtail.push_back(-1); psize.push_back(0); pblk.push_back(0); open.push_back(1);
     } else {
       id = take[0];                                   // the largest child keeps its id; the others are relabelled into it
+      const int qd = id - first_new_id;
       for (size_t k = 1; k < take.size(); ++k) {
-        auto& mv = members[take[k] - first_new_id];
-        for (int c : mv) pc[c] = id;
-        auto& dst = members[id - first_new_id];
-        dst.insert(dst.end(), mv.begin(), mv.end());
-        std::vector<int>().swap(mv);
+        const int qs = take[k] - first_new_id;
+        for (int c = mhead[qs]; c >= 0; c = mnext[c]) pc[c] = id;
+        if (mhead[qs] >= 0) { if (mtail[qd] >= 0) mnext[mtail[qd]] = mhead[qs]; else mhead[qd] = mhead[qs]; mtail[qd] = mtail[qs]; }
+        mhead[qs] = mtail[qs] = -1;
       }
     }
     const int q = id - first_new_id;
-    members[q].push_back(s); pc[s] = id; psize[q] = size; pblk[q] = nb; open[q] = 1; il[s] = lev;
+    if (mtail[q] >= 0) mnext[mtail[q]] = s; else mhead[q] = s;
+    mtail[q] = s;
+    pc[s] = id; psize[q] = size; pblk[q] = nb; open[q] = 1; il[s] = lev;
   }
-  return first_new_id + (int)members.size();
+  return first_new_id + (int)mhead.size();
 }
 
 }  // namespace chol_detail
@@ -338,36 +416,49 @@ inline int chol_symbolic(const SymIn& in, CholOpts opt, CholHost& out) {
   out.B = B; out.nt_leaf = opt.nt_leaf; out.nt_tail = opt.nt_tail; out.ustage = opt.ustage;
   auto row_dim = [&](int r) { return r < nPr ? 6 : 3; };
   auto row_xoff = [&](int r) { return r < nPr ? 6 * r : 6 * nPr + 3 * (r - nPr); };
-  auto key = [](int a, int c) { return ((uint64_t)(uint32_t)a << 32) | (uint32_t)c; };
-  std::unordered_map<uint64_t, int> hoff;
-  hoff.reserve(in.ppoff.size() + in.plblk.size());
-  for (size_t i = 0; i < in.ppoff.size(); ++i) hoff[key(in.ppoff[i].first, in.ppoff[i].second)] = (int)(in.hpp_off_base + (int64_t)i * 36);
-  for (size_t i = 0; i < in.plblk.size(); ++i) hoff[key(in.plblk[i].first, nPr + in.plblk[i].second)] = (int)(in.hpl_base + (int64_t)i * 18);
-  for (size_t i = 0; i < in.llblk.size(); ++i) hoff[key(nPr + in.llblk[i].first, nPr + in.llblk[i].second)] = (int)(in.hll_off_base + (int64_t)i * 9);
-  std::vector<std::vector<int>> adj(nrow);
-  for (auto& pr : in.ppoff) { adj[pr.first].push_back(pr.second); adj[pr.second].push_back(pr.first); }
-  for (auto& pr : in.plblk) { adj[pr.first].push_back(nPr + pr.second); adj[nPr + pr.second].push_back(pr.first); }
-  for (auto& pr : in.llblk) { adj[nPr + pr.first].push_back(nPr + pr.second); adj[nPr + pr.second].push_back(nPr + pr.first); }
+  // adjacency of the block graph in CSR form (rows: pose rows, then landmark rows), every edge with the offset of its block in H: three
+  // flat arrays instead of a hash map and a vector per row (the plan is rebuilt at every tick of the orchestrator)
+  std::vector<int> aptr(nrow + 1, 0), aidx, aoff;
+  {
+    for (auto& pr : in.ppoff) { aptr[pr.first + 1]++; aptr[pr.second + 1]++; }
+    for (auto& pr : in.plblk) { aptr[pr.first + 1]++; aptr[nPr + pr.second + 1]++; }
+    for (auto& pr : in.llblk) { aptr[nPr + pr.first + 1]++; aptr[nPr + pr.second + 1]++; }
+    for (int r = 0; r < nrow; ++r) aptr[r + 1] += aptr[r];
+    aidx.resize(aptr[nrow]); aoff.resize(aptr[nrow]);
+    std::vector<int> cur(aptr.begin(), aptr.end() - 1);
+    auto edge = [&](int a, int c, int64_t off) { aidx[cur[a]] = c; aoff[cur[a]++] = (int)off; aidx[cur[c]] = a; aoff[cur[c]++] = (int)off; };
+    for (size_t i = 0; i < in.ppoff.size(); ++i) edge(in.ppoff[i].first, in.ppoff[i].second, in.hpp_off_base + (int64_t)i * 36);
+    for (size_t i = 0; i < in.plblk.size(); ++i) edge(in.plblk[i].first, nPr + in.plblk[i].second, in.hpl_base + (int64_t)i * 18);
+    for (size_t i = 0; i < in.llblk.size(); ++i) edge(nPr + in.llblk[i].first, nPr + in.llblk[i].second, in.hll_off_base + (int64_t)i * 9);
+  }
+  auto h_offset = [&](int a, int c) -> int {   // offset of block (a, c) of H, or -1 (fill)
+    for (int q = aptr[a]; q < aptr[a + 1]; ++q) if (aidx[q] == c) return aoff[q];
+    return -1;
+  };
 
   // ---- per graph: ordering, elimination tree, pieces, final (piece-contiguous) elimination order ------------------
   std::vector<int> col_row, col_graph, col_piece, col_comp, col_tail;   // by final column id; piece = execution group, comp = connected piece
   std::vector<int> row_col(nrow, -1);
-  std::vector<std::vector<int>> cstruct_rows;                 // per column: rows of the off-diagonal blocks
+  std::vector<int> cr_ptr{0}, cr_idx;                         // per column: rows of the off-diagonal blocks (CSR)
   int npiece = 0, ncomp = 0;
   for (int g = 0; g < B; ++g) {
     const SymGraph& sg = in.seg[g];
     const int n = sg.nprow + sg.nlrow;
     auto loc2row = [&](int v) { return v < sg.nprow ? sg.prow0 + v : nPr + sg.lrow0 + (v - sg.nprow); };
     auto row2loc = [&](int r) { return r < nPr ? r - sg.prow0 : sg.nprow + (r - nPr - sg.lrow0); };
-    std::vector<std::vector<int>> ladj(n);
-    for (int v = 0; v < n; ++v) {
-      const int r = loc2row(v);
-      ladj[v].reserve(adj[r].size());
-      for (int w : adj[r]) ladj[v].push_back(row2loc(w));
-    }
     GraphSym S;
-    if (opt.order == 1) multi_min_degree(n, ladj, S, opt.order_mul, opt.order_add);
-    else min_degree(n, ladj, S);
+    if (opt.order == 1 && n <= opt.order_bits_max) {
+      multi_min_degree_bits(n, [&](int v, auto&& f) { const int r = loc2row(v); for (int q = aptr[r]; q < aptr[r + 1]; ++q) f(row2loc(aidx[q])); }, S, opt.order_mul, opt.order_add);
+    } else {
+      std::vector<std::vector<int>> ladj(n);
+      for (int v = 0; v < n; ++v) {
+        const int r = loc2row(v);
+        ladj[v].reserve(aptr[r + 1] - aptr[r]);
+        for (int q = aptr[r]; q < aptr[r + 1]; ++q) ladj[v].push_back(row2loc(aidx[q]));
+      }
+      if (opt.order == 1) multi_min_degree(n, ladj, S, opt.order_mul, opt.order_add);
+      else min_degree(n, ladj, S);
+    }
     std::vector<int> pos(n);
     for (int s = 0; s < n; ++s) pos[S.order[s]] = s;
     std::vector<int> parent(n, -1), colsz(n), colnb(n);
@@ -375,10 +466,10 @@ inline int chol_symbolic(const SymIn& in, CholOpts opt, CholHost& out) {
       const int v = S.order[s];
       const int d = row_dim(loc2row(v));
       int rows = 0, par = n;
-      for (int w : S.cstruct[v]) { rows += row_dim(loc2row(w)); par = std::min(par, pos[w]); }
+      for (int q = S.cs_start[v]; q < S.cs_start[v] + S.cs_len[v]; ++q) { const int w = S.cs_idx[q]; rows += row_dim(loc2row(w)); par = std::min(par, pos[w]); }
       parent[s] = par == n ? -1 : par;
       colsz[s] = d * d + d * rows;
-      colnb[s] = 1 + (int)S.cstruct[v].size();
+      colnb[s] = 1 + S.cs_len[v];
     }
     // pass 1: leaf-sized pieces everywhere; depth of every piece in the piece tree
     std::vector<int> pc, none(n, -1);
@@ -463,9 +554,9 @@ inline int chol_symbolic(const SymIn& in, CholOpts opt, CholHost& out) {
       row_col[r] = c0 + k;
       col_row.push_back(r); col_graph.push_back(g);
       col_piece.push_back(npiece + grank[pc2[s]]); col_comp.push_back(ncomp + crank[pc2[s]]); col_tail.push_back(is_tail[pc2[s]]);
-      std::vector<int> rows;
-      for (int w : S.cstruct[S.order[s]]) rows.push_back(loc2row(w));
-      cstruct_rows.push_back(std::move(rows));
+      const int vs = S.order[s];
+      for (int q = S.cs_start[vs]; q < S.cs_start[vs] + S.cs_len[vs]; ++q) cr_idx.push_back(loc2row(S.cs_idx[q]));
+      cr_ptr.push_back((int)cr_idx.size());
     }
     npiece += ngroup;
     ncomp += (int)ids.size();
@@ -480,11 +571,12 @@ inline int chol_symbolic(const SymIn& in, CholOpts opt, CholHost& out) {
   int64_t lnz = 0;
   {
     int y = 0;
+    std::vector<int> rows_c;
     for (int j = 0; j < ncol; ++j) {
       const int rj = col_row[j], dj = row_dim(rj);
       col_xoff[j] = row_xoff(rj); col_dim[j] = dj; col_yoff[j] = y; y += dj;
-      std::vector<int> rows_c;
-      for (int r : cstruct_rows[j]) rows_c.push_back(row_col[r]);
+      rows_c.clear();
+      for (int q = cr_ptr[j]; q < cr_ptr[j + 1]; ++q) rows_c.push_back(row_col[cr_idx[q]]);
       std::sort(rows_c.begin(), rows_c.end());
       bp[j] = (int)boff.size();
       boff.push_back((int)lnz); brow.push_back(j);
@@ -495,9 +587,9 @@ inline int chol_symbolic(const SymIn& in, CholOpts opt, CholHost& out) {
         const int ri = col_row[i], di = row_dim(ri);
         boff.push_back((int)lnz); brow.push_back(i);
         const int a = std::min(ri, rj), c = std::max(ri, rj);
-        auto it = hoff.find(key(a, c));
-        if (it == hoff.end()) { bsrc.push_back(-1); bfmt.push_back(0); }
-        else { bsrc.push_back(it->second); bfmt.push_back(ri == a ? 0 : 1); }   // stored [min][max]; we need [i][j]
+        const int ho = h_offset(a, c);
+        if (ho < 0) { bsrc.push_back(-1); bfmt.push_back(0); }
+        else { bsrc.push_back(ho); bfmt.push_back(ri == a ? 0 : 1); }   // stored [min][max]; we need [i][j]
         lnz += blk_doubles(di, dj);
       }
       if (lnz >= ((int64_t)1 << 31) - 4096) { out.error = "Cholesky factor too large for int32 offsets"; return -1; }
@@ -670,6 +762,17 @@ inline int chol_symbolic(const SymIn& in, CholOpts opt, CholHost& out) {
   std::vector<IU> iu_flat, iu_s;
   std::vector<AsmRec> asm_flat;
   std::vector<AsmSrc> as_s, src_s;
+  std::vector<int> lens, comp_uy;
+  std::vector<UItem> uit_s;
+  // smallest chunk >= lo for which the lists longer than the chunk are cut into <= pcap items in total (or chunk >= hi): the count falls
+  // monotonically with the chunk, so bisection finds what the linear search found
+  auto fit_chunk = [&](int lo, int hi, int pcap) {
+    auto nonsole = [&](int chunk) { int s2 = 0; for (int n : lens) { const int k = (n + chunk - 1) / chunk; if (k > 1) s2 += k; } return s2; };
+    if (lo >= hi || nonsole(lo) <= pcap) return lo;
+    int a = lo, b = hi;   // nonsole(a) > pcap; b is accepted
+    while (b - a > 1) { const int m = a + (b - a) / 2; if (nonsole(m) <= pcap) b = m; else a = m; }
+    return b;
+  };
   for (int p = 0; p < npiece; ++p) {
     PieceMeta& pm = out.piece[p];
     const int nt = piece_tail[p] ? opt.nt_tail : opt.nt_leaf;
@@ -825,12 +928,10 @@ inline int chol_symbolic(const SymIn& in, CholOpts opt, CholHost& out) {
         // one phase: cut every target's list into items of <= chunk updates; raise the chunk until the partial tiles fit
         int U = 0;
         for (int t = lv.b0; t < lv.b1; ++t) U += bi1[t - pm.b0] - bi0[t - pm.b0];
-        int chunk = std::max(opt.min_chunk, (U + slots - 1) / slots);
-        for (;; ++chunk) {
-          int nonsole = 0;
-          for (int t = lv.b0; t < lv.b1; ++t) { const int k = (bi1[t - pm.b0] - bi0[t - pm.b0] + chunk - 1) / chunk; if (k > 1) nonsole += k; }
-          if (nonsole <= pcap || chunk >= std::max(U, 1)) break;
-        }
+        const int chunk0 = std::max(opt.min_chunk, (U + slots - 1) / slots);
+        lens.clear();
+        for (int t = lv.b0; t < lv.b1; ++t) { const int n = bi1[t - pm.b0] - bi0[t - pm.b0]; if (n > chunk0) lens.push_back(n); }
+        const int chunk = fit_chunk(chunk0, std::max(chunk0, std::max(U, 1)), pcap);
         int ps = 0;
         for (int t = lv.b0; t < lv.b1; ++t) {
           const int u0 = bi0[t - pm.b0], u1 = bi1[t - pm.b0], n = u1 - u0;
@@ -867,24 +968,26 @@ inline int chol_symbolic(const SymIn& in, CholOpts opt, CholHost& out) {
       int64_t cur = ucur;
       uoffs.assign(ub.size(), 0);
       for (int q : order) { uoffs[q] = (int)cur; cur += blk_doubles(col_dim[ub[q].a], col_dim[ub[q].b]); }
-      std::unordered_map<int, int> comp_uy;   // Uval offset of a component's rhs part [|R|][6]
-      for (int c : comps) { comp_uy[c] = (int)cur; cur += 6 * (int64_t)comp_R[c].size(); }
+      comp_uy.resize(comps.size());           // Uval offset of a component's rhs part [|R|][6]
+      for (size_t ci = 0; ci < comps.size(); ++ci) { comp_uy[ci] = (int)cur; cur += 6 * (int64_t)comp_R[comps[ci]].size(); }
       if (cur >= ((int64_t)1 << 31) - 4096) { out.error = "update matrices too large for int32 offsets"; return -1; }
       const int U = (int)own_s.size();
-      int chunk = std::max(opt.min_chunk, (U + slots - 1) / slots);
-      for (;; ++chunk) {
-        int nonsole = 0;
-        for (size_t q = 0; q < ub.size(); ++q) { const int k = (own_ptr[q + 1] - own_ptr[q] + chunk - 1) / chunk; if (k > 1) nonsole += k; }
-        if (nonsole <= pcap || chunk >= std::max(U, 1)) break;
-      }
+      const int chunk0 = std::max(opt.min_chunk, (U + slots - 1) / slots);
+      lens.clear();
+      for (size_t q = 0; q < ub.size(); ++q) { const int n = own_ptr[q + 1] - own_ptr[q]; if (n > chunk0) lens.push_back(n); }
+      const int chunk = fit_chunk(chunk0, std::max(chunk0, std::max(U, 1)), pcap);
       int ps = 0;
       const size_t item_first = out.uitem.size();
+      for (int c : comps) if (comp_dest[c] >= 0) inbox[comp_dest[c]].reserve(inbox[comp_dest[c]].size() + order.size());   // one growth step per sender
       for (int q : order) {
         const UB& x = ub[q];
         const int di = col_dim[x.a], dj = col_dim[x.b];
         const bool diag = x.a == x.b;
         int uy = -1;
-        if (diag) { const std::vector<int>& R = comp_R[x.comp]; uy = comp_uy[x.comp] + 6 * (int)(std::lower_bound(R.begin(), R.end(), x.a) - R.begin()); }
+        if (diag) {
+          const std::vector<int>& R = comp_R[x.comp];
+          uy = comp_uy[std::lower_bound(comps.begin(), comps.end(), x.comp) - comps.begin()] + 6 * (int)(std::lower_bound(R.begin(), R.end(), x.a) - R.begin());
+        }
         const int tpk = (di == 6 ? kUpdDi6 : 0) | (diag ? kUpdDiag : 0) | (dj == 6 ? kUpdDj6 : 0);
         const int u0 = (int)out.upd.size() - pm.uu0;
         for (int w = own_ptr[q]; w < own_ptr[q + 1]; ++w) { const OwnRec& u = own_s[w]; out.upd.push_back(UpdMeta{u.ua, u.ubo, col_yoff[u.k], tpk | (col_dim[u.k] == 6 ? kUpdDk6 : 0)}); }
@@ -913,8 +1016,10 @@ inline int chol_symbolic(const SymIn& in, CholOpts opt, CholHost& out) {
         };
         int cnt[4] = {0, 0, 0, 0};
         for (size_t i = item_first; i < out.uitem.size(); ++i) cnt[cls(out.uitem[i])]++;
-        std::stable_sort(out.uitem.begin() + item_first, out.uitem.end(), [&](const UItem& a2, const UItem& b2) { return cls(a2) < cls(b2); });
         pm.nu4 = cnt[0]; pm.nu2 = cnt[1]; pm.nu1 = cnt[2];
+        int at[4] = {0, cnt[0], cnt[0] + cnt[1], cnt[0] + cnt[1] + cnt[2]};
+        uit_s.assign(out.uitem.begin() + item_first, out.uitem.end());
+        for (const UItem& im : uit_s) out.uitem[item_first + at[cls(im)]++] = im;
       }
     }
     pm.nuit = (int)out.uitem.size() - pm.uit0;

@@ -239,6 +239,7 @@ bool chol_plan_flow(const Batch& b);        // the plan runs factor + both solve
 int chol_solve_flow(Batch& b);              // (H + lambda I) dx = b for in_trial graphs -> V.x, one launch
 int chol_lm_step_flow(Batch& b, int max_iters);   // begin step + one-launch solve + update / chi2 / accept-reject / commit: 3 launches per damping trial
 bool chol_plan_spec(const Batch& b);        // one small graph: the damping trials of an LM iteration can run side by side
+int chol_spec_mode(const Batch& b);               // 0 off, 1 adaptive (lanes join after the first rejected trial of an iteration), 2 always
 int chol_lm_step_spec(Batch& b, int max_iters);   // one LM iteration: up to ten speculative trials + the accept / reject replay
 int chol_factor_flat_flow(Batch& b);        // flat factor (marginals) through the single launch
 int chol_flow_check(Batch& b);              // error flag of that launch (synchronises the stream)

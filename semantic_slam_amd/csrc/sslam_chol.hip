@@ -69,6 +69,8 @@ struct SpecLanes {
   int *fail = nullptr, *flow = nullptr;
   const double *pose_cur = nullptr, *lmk_cur = nullptr;   // the current estimates (V.pose / V.lmk)
   long long sL = 0, sU = 0, sy = 0, sx = 0, spose = 0, slmk = 0, spe = 0, spa = 0, sflow = 0;   // lane strides (elements)
+  int g0 = 0, g1 = 0;         // workgroups of lane 0 / of every other lane in the (one-dimensional) grid of k_chol_flow
+  int after = 0;              // lanes 1.. take part once `after` trials of the iteration have been rejected (0: always; 1: adaptive)
 };
 
 struct CholPlan {
@@ -91,10 +93,11 @@ struct CholPlan {
   // dependency-driven factorisation + solve in ONE launch (k_chol_flow): small batches only
   bool flow = false;            // the plan can run it (every piece has one parent piece; nt_leaf == nt_tail)
   int flow_grid = 0;            // persistent workgroups
-  int spec_grid = 0;            // workgroups per lane of the speculative trials
+  int spec_grid = 0;            // workgroups of a speculative round (all lanes)
   int flow_first = 0;           // first launch-order piece of the single launch; the per-depth launches [0, flow_launch0) come before it
   int flow_launch0 = 0;
   int flow_epoch = 0;           // launches so far: the counters are never reset, a launch waits for epoch * (children)
+  int lm_epoch = 0;             // launches that carried the LM halves of a trial (k_chol_flow, bit 2)
   int spec_epoch = 0;           // the same for the lanes' own counters (speculative trials)
   int2* d_dep = nullptr;        // per launch-order piece: {parent (launch order) or -1, children}
   int* d_flow = nullptr;        // [children done | backward done | forward done] per piece, then [0] error flag at 3 * npiece
@@ -519,8 +522,13 @@ __device__ __forceinline__ void row_solve(double* v, const double* Ljj, const do
     if (threadIdx.x == 0) dbg[k] += now_ - tprev;                               \
     tprev = now_;                                                               \
   }
-template <int NT, bool USTAGE, bool RIGHT>
-__device__ __forceinline__ void chol_piece(const BatchView& V, const CholView& C, const PieceMeta pm, double* sm, long long* dbg) {
+// DEFER (k_chol_flow): the piece's tables and its part of H are fetched BEFORE the wait for the child pieces (they do not depend on
+// them); only the children's update-matrix blocks are read after it -- two dependent round trips less on the critical path of a piece.
+// The sums are those of the one-pass gather, in its order: (H + lambda I) first, then the sources one after the other.
+__device__ __forceinline__ bool flow_wait(const int* p, int target, int* err);
+template <int NT, bool USTAGE, bool RIGHT, bool DEFER = false>
+__device__ __forceinline__ void chol_piece(const BatchView& V, const CholView& C, const PieceMeta pm, double* sm, long long* dbg,
+                                           const int* wait_p = nullptr, int wait_target = 0, int* wait_err = nullptr) {
   constexpr int NW = NT / 64;
   long long tprev = dbg ? clock64() : 0;
   ILevel* s_lv = reinterpret_cast<ILevel*>(sm);              // the piece's level records first (32 bytes each): no static table, the LDS a
@@ -607,7 +615,7 @@ __device__ __forceinline__ void chol_piece(const BatchView& V, const CholView& C
         const int t = min(t0 + g2 * NT, nrow - 1);
         const int b = t / 6, row = t - 6 * b;
         const BlkMeta bm = sBlk[b];
-        const int di = bm.info & 15, dj = (bm.info >> 4) & 15, nas = (bm.info >> kBlkNasShift) & 255;
+        const int di = bm.info & 15, dj = (bm.info >> 4) & 15, nas = DEFER ? 0 : (bm.info >> kBlkNasShift) & 255;
         const int rw = min(row, di - 1);                                   // idle threads shadow the last row: valid addresses
         const double* ph = H + max(bm.src, 0) + ((bm.info & kBlkFmt) ? rw : rw * dj);
         const int st = (bm.info & kBlkFmt) ? di : 1;
@@ -632,7 +640,7 @@ __device__ __forceinline__ void chol_piece(const BatchView& V, const CholView& C
         if (t >= nrow) continue;
         const int b = t / 6, row = t - 6 * b;
         const BlkMeta bm = sBlk[b];
-        const int di = bm.info & 15, dj = (bm.info >> 4) & 15, nas = (bm.info >> kBlkNasShift) & 255;
+        const int di = bm.info & 15, dj = (bm.info >> 4) & 15, nas = DEFER ? 0 : (bm.info >> kBlkNasShift) & 255;
         if (row >= di) continue;
         const bool diag = bm.info & kBlkDiag;
         double vy = diag ? rhsv[g2] : 0.0;
@@ -653,6 +661,39 @@ __device__ __forceinline__ void chol_piece(const BatchView& V, const CholView& C
 #pragma unroll
         for (int c = 0; c < 6; ++c) if (c < dj) o[c] = v[g2][c];
         if (diag) smY[bm.colyoff - pm.y0 + row] = vy;
+      }
+    }
+  }
+  if (DEFER) {
+    // ---- 1b. the children's update-matrix blocks, once they are there
+    if (wait_p) {
+      __syncthreads();
+      if (tid == 0) flow_wait(wait_p, wait_target, wait_err);
+    }
+    __syncthreads();
+    if (pm.nas > 0) {
+      const int nrow = pm.nb * 6;
+      for (int t = tid; t < nrow; t += NT) {
+        const int b = t / 6, row = t - 6 * b;
+        const BlkMeta bm = sBlk[b];
+        const int di = bm.info & 15, dj = (bm.info >> 4) & 15, nas = (bm.info >> kBlkNasShift) & 255;
+        if (row >= di || nas == 0) continue;
+        const bool diag = bm.info & kBlkDiag;
+        double* o = smL + (bm.off - pm.lbase) + row * dj;
+        double* oy = smY + (bm.colyoff - pm.y0 + row);
+        double v[6], vy = diag ? *oy : 0.0;
+#pragma unroll
+        for (int c = 0; c < 6; ++c) v[c] = c < dj ? o[c] : 0.0;
+        for (int s2 = 0; s2 < nas; ++s2) {
+          const AsmSrc as = sAsm[bm.as0 + s2];
+          const double* pu = U + as.uoff + row * dj;
+#pragma unroll
+          for (int c = 0; c < 6; ++c) if (c < dj) v[c] -= pu[c];
+          if (diag && as.uyoff >= 0) vy -= U[as.uyoff + row];
+        }
+#pragma unroll
+        for (int c = 0; c < 6; ++c) if (c < dj) o[c] = v[c];
+        if (diag) *oy = vy;
       }
     }
   }
@@ -1309,7 +1350,7 @@ __global__ __launch_bounds__(NT) void k_lm_begin_spec(BatchView V, CholView C, S
     double lam = S.lambda, nu = S.nu;
     for (int k = 0; k < SL.K; ++k) {
       LmState Lk = S;
-      Lk.lambda = lam; Lk.in_trial = (S.in_trial && S.q + k < 10) ? 1 : 0;
+      Lk.lambda = lam; Lk.in_trial = (S.in_trial && S.q + k < 10 && (k == 0 || S.q >= SL.after)) ? 1 : 0;
       SL.lm[(size_t)k * V.B + g] = Lk;
       SL.fail[(size_t)k * V.B + g] = 0;
       lam *= nu; nu *= 2;
@@ -1380,9 +1421,8 @@ __global__ __launch_bounds__(NT) void k_lm_control_spec(BatchView V, SpecLanes S
       more = __shfl(more, 0, 64);
       if (!more) break;
     }
-    if (tid == 0 && S.in_trial) {   // (fewer lanes than trials left: cannot happen with K = 10; close the iteration as the tenth failure would)
-      S.in_trial = 0; S.iter += 1; S.status = 1; S.active = 0;
-    }
+    // (trials left and no lane left -- the adaptive form after the first rejected trial of an iteration: S carries lambda, nu and q on, the
+    // next round's lanes continue the sequence)
   }
   __threadfence_block();
   __syncthreads();
@@ -1418,11 +1458,21 @@ __device__ __forceinline__ bool flow_wait(const int* p, int target, int* err) {
 }
 template <int NT, bool USTAGE>
 __global__ __launch_bounds__(NT) void k_chol_flow(BatchView V, CholView C, int q_first, int np, int epoch, const int2* __restrict__ dep, int* flow, SpecLanes SL,
-                                                  int do_backward) {
+                                                  int do_backward, double* __restrict__ part_e, int max_iters, int lm_epoch) {
   extern __shared__ double sm[];
+  __shared__ double red[NT / 64];
+  __shared__ int s_last;
   const int tid = threadIdx.x;
-  if (SL.K > 0) {   // speculative damping trials: blockIdx.y = lane, with its own factor, vectors, counters and lambda
-    const long long k = blockIdx.y;
+  const bool defer = do_backward & 2;   // bit 1: tables and H before the wait for the children (chol_piece DEFER)
+  // bit 2: a whole damping trial in this launch -- what k_lm_begin_small does before the factorisation (workgroup g for graph g, everybody
+  // waits for it: lambda and in_trial are read by every piece) and what k_lm_end_small does after the backward substitution (the
+  // workgroup that finishes last, by a ticket).  Two launches less per trial of the orchestrator's graphs, which are bound by launches.
+  const bool lmstep = (do_backward & 4) && SL.K == 0;
+  int wg = blockIdx.x, nwg = gridDim.x;
+  if (SL.K > 0) {   // speculative damping trials: a lane = a range of workgroups, with its own factor, vectors, counters and lambda
+    long long k = 0;
+    if (wg < SL.g0) nwg = SL.g0;
+    else { const int r = wg - SL.g0; k = 1 + r / SL.g1; wg = r - (int)(k - 1) * SL.g1; nwg = SL.g1; }
     V.lm = SL.lm + k * V.B; V.x = SL.x + k * SL.sx;
     C.Lval = SL.Lval + k * SL.sL; C.Uval = SL.Uval + k * SL.sU; C.y = SL.y + k * SL.sy; C.fail = SL.fail + k * V.B;
     flow = SL.flow + k * SL.sflow;
@@ -1431,18 +1481,36 @@ __global__ __launch_bounds__(NT) void k_chol_flow(BatchView V, CholView C, int q
   int* back_done = flow + np;
   int* fwd_done = flow + 2 * np;
   int* err = flow + 3 * np;
+  int* begin_done = flow + 3 * np + 1;
+  int* end_ticket = flow + 3 * np + 2;
+  if (lmstep) {
+    if (wg < V.B) {
+      if (V.lm[wg].active) lm_begin_small<NT>(V, C, wg, red);
+      __syncthreads();
+      if (tid == 0) { __threadfence(); __hip_atomic_fetch_add(begin_done, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); }
+    }
+    if (tid == 0) flow_wait(begin_done, V.B * lm_epoch, err);   // (its own count: solves without the LM halves share the counters of the pieces)
+    __syncthreads();
+  }
   // ---- (H + lambda I) = L L^T and y = L^-1 b, leaves to roots
   // (pieces before q_first -- the wide bottom of a large graph's tree -- were factored by per-depth launches before this one; dep[].y counts
   // the children inside [q_first, np) only)
-  for (int q = q_first + blockIdx.x; q < np; q += gridDim.x) {
+  for (int q = q_first + wg; q < np; q += nwg) {
     const PieceMeta pm = C.lpiece[q];
     const int2 d = dep[q];
-    if (d.y > 0) {
+    const bool run = V.lm[pm.graph].in_trial;   // (set by the begin kernel of the step: not touched inside this launch)
+    if (d.y > 0 && !(defer && run)) {
       if (tid == 0) flow_wait(child_done + q, d.y * epoch, err);
       __syncthreads();
     }
-    if (V.lm[pm.graph].in_trial) {
-      if (q >= C.ltail0) {
+    if (run) {
+      const int* wp = d.y > 0 ? child_done + q : nullptr;
+      if (defer) {
+        if (q >= C.ltail0) {
+          if (C.rupd) chol_piece<NT, false, true, true>(V, C, pm, sm, nullptr, wp, d.y * epoch, err);
+          else chol_piece<NT, false, false, true>(V, C, pm, sm, nullptr, wp, d.y * epoch, err);
+        } else chol_piece<NT, USTAGE, false, true>(V, C, pm, sm, nullptr, wp, d.y * epoch, err);
+      } else if (q >= C.ltail0) {
         if (C.rupd) chol_piece<NT, false, true>(V, C, pm, sm, nullptr);
         else chol_piece<NT, false, false>(V, C, pm, sm, nullptr);
       } else chol_piece<NT, USTAGE, false>(V, C, pm, sm, nullptr);
@@ -1454,9 +1522,9 @@ __global__ __launch_bounds__(NT) void k_chol_flow(BatchView V, CholView C, int q
       else __hip_atomic_store(fwd_done + q, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
-  if (!do_backward) return;   // the flat factor of the marginals: L only
+  if (!(do_backward & 1)) return;   // the flat factor of the marginals: L only
   // ---- x = L^-T y, roots to leaves
-  for (int i = blockIdx.x; i < np - q_first; i += gridDim.x) {
+  for (int i = wg; i < np - q_first; i += nwg) {
     const int q = np - 1 - i;
     const PieceMeta pm = C.lpiece[q];
     const int2 d = dep[q];
@@ -1470,6 +1538,19 @@ __global__ __launch_bounds__(NT) void k_chol_flow(BatchView V, CholView C, int q
     if (tid == 0) {
       __threadfence();
       __hip_atomic_store(back_done + q, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+  if (lmstep) {   // the rest of the trial: x [+] dx, chi2, accept / reject, commit -- by the workgroup that finishes last
+    __syncthreads();
+    if (tid == 0) {
+      __threadfence();
+      const int t = __hip_atomic_fetch_add(end_ticket, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+      s_last = ((t + 1) % nwg == 0) ? 1 : 0;   // every such launch adds nwg tickets: no reset, no epoch
+    }
+    __syncthreads();
+    if (s_last) {
+      for (int g = 0; g < V.B; ++g)
+        if (V.lm[g].active && V.lm[g].in_trial) lm_end_small<NT>(V, C, g, part_e, max_iters, red);
     }
   }
 }
@@ -1517,6 +1598,11 @@ void chol_sym_input(const Batch& b, SymIn& in) {
   in.hll_base = b.hll_base; in.hpp_off_base = b.hpp_off_base; in.hpl_base = b.hpl_base; in.hll_off_base = b.hll_off_base;
 }
 
+// speculative damping trials of a single small graph: the graph's option, or SSLAM_LM_SPEC = 0 / 1 / 2 for every graph of the process
+int chol_spec_mode(const Batch& b) {
+  static const int env = [] { const char* e = getenv("SSLAM_LM_SPEC"); return e ? std::max(0, std::min(2, atoi(e))) : -1; }();
+  return env >= 0 ? env : b.graphs[0]->opt.speculative;
+}
 int chol_plan_build(Batch& b) {
   if (b.chol) { chol_plan_free(b.chol); b.chol = nullptr; }
   SSLAM_HIP_TRY(hipSetDevice(b.device));
@@ -1693,13 +1779,18 @@ int chol_plan_build(Batch& b) {
       if ((rc = plan_alloc(&p, nints * sizeof(int)))) return rc;
       P->d_flow = (int*)p;
       SSLAM_HIP_TRY(hipMemsetAsync(p, 0, nints * sizeof(int), b.stream));
-      P->flow_epoch = 0; P->spec_epoch = 0;
+      P->flow_epoch = 0; P->spec_epoch = 0; P->lm_epoch = 0;
       // speculative damping trials: one small graph whose ten lanes of pieces are all on the chip at once
-      const bool spec_on = [] { const char* e = getenv("SSLAM_LM_SPEC"); return !(e && atoi(e) == 0); }();
       const int K = 10;
-      if (spec_on && b.graphs[0]->opt.speculative && b.V.B == 1 && P->flow_launch0 == 0) {   // (opt-in: the lanes cost three allocations + memsets per rebuild)
-        P->spec_grid = std::max(1, std::min((int)dep.size(), 2 * cap / K));   // K lanes of persistent workgroups, all of them on the chip at once
+      const int spec_mode = chol_spec_mode(b);
+      if (spec_mode && b.V.B == 1 && P->flow_launch0 == 0) {   // (the lanes cost three allocations + memsets per rebuild)
+        // K lanes of persistent workgroups, all of them on the chip at once.  Lane 0 -- the only one at work until a trial of the iteration
+        // has been rejected (adaptive form) -- gets a workgroup per piece like the plain single-launch solve, the others share the rest
         SpecLanes& SL = P->spec;
+        SL.g0 = std::max(1, std::min((int)dep.size(), cap));
+        SL.g1 = std::max(1, std::min((int)dep.size(), (2 * cap - SL.g0) / (K - 1)));
+        SL.after = spec_mode == 2 ? 0 : 1;
+        P->spec_grid = SL.g0 + (K - 1) * SL.g1;
         SL.sL = (H.lnz + 64 + 1) & ~1LL; SL.sU = (H.unz + 64 + 1) & ~1LL; SL.sy = (C.dim + 8 + 1) & ~1LL; SL.sx = (C.dim + 8 + 1) & ~1LL;
         SL.spose = (long long)b.V.nPose * 8; SL.slmk = (long long)b.V.nLm * 4; SL.spe = (long long)b.V.B * b.V.maxEdgeChunks; SL.spa = (long long)b.V.B * b.V.maxRowChunks;
         SL.sflow = (long long)nints;
@@ -1730,7 +1821,7 @@ int chol_plan_build(Batch& b) {
 bool chol_plan_flow(const Batch& b) { return b.chol && b.chol->flow && !b.chol->compact; }
 // the launches of one solve: per-depth launches over the wide bottom of the tree, the dependency-driven launch over the rest (factor and
 // both substitutions), per-depth launches of the backward substitution over the bottom again
-static void flow_launches(Batch& b, bool spec = false, bool backward = true) {
+static void flow_launches(Batch& b, bool spec = false, bool backward = true, bool lmstep = false, int max_iters = 0) {
   CholPlan& P = *b.chol;
   const CholView& C = P.C;
   size_t lds = (size_t)std::max(P.tail_lds_f, P.tail_lds_b);
@@ -1744,9 +1835,11 @@ static void flow_launches(Batch& b, bool spec = false, bool backward = true) {
   }
   const int epoch = spec ? ++P.spec_epoch : ++P.flow_epoch;   // the lanes count on their own counters
   const SpecLanes SL = spec ? P.spec : SpecLanes{};
-  const dim3 grid(spec ? P.spec_grid : P.flow_grid, spec ? P.spec.K : 1);
-  if (P.ustage) hipLaunchKernelGGL((k_chol_flow<512, true>), grid, dim3(512), lds, b.stream, b.V, C, P.flow_first, np, epoch, (const int2*)P.d_dep, P.d_flow, SL, backward ? 1 : 0);
-  else hipLaunchKernelGGL((k_chol_flow<512, false>), grid, dim3(512), lds, b.stream, b.V, C, P.flow_first, np, epoch, (const int2*)P.d_dep, P.d_flow, SL, backward ? 1 : 0);
+  const int lm_epoch = lmstep ? ++P.lm_epoch : 0;
+  const dim3 grid(spec ? P.spec_grid : P.flow_grid);
+  static const int defer = [] { const char* e = getenv("SSLAM_FLOW_DEFER"); return (e && atoi(e) == 0) ? 0 : 2; }();   // tables + H before the wait for the children
+  if (P.ustage) hipLaunchKernelGGL((k_chol_flow<512, true>), grid, dim3(512), lds, b.stream, b.V, C, P.flow_first, np, epoch, (const int2*)P.d_dep, P.d_flow, SL, (backward ? 1 : 0) | defer | (lmstep ? 4 : 0), b.d_part_e, max_iters, lm_epoch);
+  else hipLaunchKernelGGL((k_chol_flow<512, false>), grid, dim3(512), lds, b.stream, b.V, C, P.flow_first, np, epoch, (const int2*)P.d_dep, P.d_flow, SL, (backward ? 1 : 0) | defer | (lmstep ? 4 : 0), b.d_part_e, max_iters, lm_epoch);
   for (int l = P.flow_launch0 - 1; l >= 0 && backward; --l) {
     const int n = P.plv_ptr[l + 1] - P.plv_ptr[l];
     hipLaunchKernelGGL(k_chol_back_pieces<512>, dim3(n), dim3(512), (size_t)P.plv_lds_b[l] * sizeof(double), b.stream, C, P.plv_ptr[l], (const double*)C.y, b.V.x, (const LmState*)b.V.lm, (const int*)nullptr);
@@ -1788,9 +1881,14 @@ int chol_lm_step_flow(Batch& b, int max_iters) {
   for (size_t l = 0; l < P.plv_lds_f.size(); ++l) lds = std::max(lds, (size_t)std::max(P.plv_lds_f[l], P.plv_lds_b[l]));
   lds *= sizeof(double);
   const int np = (int)P.lp_graph.size();
-  hipLaunchKernelGGL(k_lm_begin_small<512>, dim3(b.V.B), dim3(512), 0, b.stream, b.V, C);
-  flow_launches(b);
-  hipLaunchKernelGGL(k_lm_end_small<512>, dim3(b.V.B), dim3(512), 0, b.stream, b.V, C, b.d_part_e, max_iters);
+  // the begin / end halves of the trial inside the launch when it covers the whole tree and has a workgroup per graph
+  static const bool lmstep_on = [] { const char* e = getenv("SSLAM_FLOW_LMSTEP"); return !(e && atoi(e) == 0); }();
+  if (lmstep_on && P.flow_launch0 == 0 && P.flow_grid >= b.V.B) { flow_launches(b, false, true, true, max_iters); }
+  else {
+    hipLaunchKernelGGL(k_lm_begin_small<512>, dim3(b.V.B), dim3(512), 0, b.stream, b.V, C);
+    flow_launches(b);
+    hipLaunchKernelGGL(k_lm_end_small<512>, dim3(b.V.B), dim3(512), 0, b.stream, b.V, C, b.d_part_e, max_iters);
+  }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return set_error(SSLAM_ERR_HIP, "LM step launch: %s", hipGetErrorString(e));
   return 0;

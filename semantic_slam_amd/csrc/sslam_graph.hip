@@ -2217,15 +2217,17 @@ static int batch_optimize(Batch& b, int max_iters, sslam_opt_stats* out) {
       flow_steps = chol_plan_flow(b);
     }
   }
-  const bool spec_steps = flow_steps && b.graphs[0]->opt.speculative && chol_plan_spec(b);
+  const bool spec_steps = flow_steps && chol_spec_mode(b) && chol_plan_spec(b);
   long long budget = 10LL * std::max(max_iters, 0) + 8;    // hard bound: <= 10 trials per iteration
   int need = max_iters;
   if ((rc = chol_set_active(b, nullptr))) return rc;
   struct CompactGuard { Batch& b; ~CompactGuard() { (void)chol_set_active(b, nullptr); } } compact_guard{b};   // every exit leaves the launches sized for all graphs
   std::vector<char> act(V.B, 1);
   int n_act = V.B;
+  static const bool chunk_timing = getenv("SSLAM_TIMING") != nullptr;
   while (need > 0 && budget > 0) {
     const int chunk = (int)std::min<long long>(std::min(need, kStepChunk), budget);
+    const auto tq0 = std::chrono::steady_clock::now();
     for (int sidx = 0; sidx < chunk; ++sidx) {
       if ((rc = batch_linearize(b))) return rc;
       if (fused) { if ((rc = chol_lm_trial_fused(b, max_iters))) return rc; continue; }
@@ -2242,8 +2244,13 @@ static int batch_optimize(Batch& b, int max_iters, sslam_opt_stats* out) {
       hipLaunchKernelGGL(k_commit, dim3(vert_blocks(b)), dim3(256), 0, b.stream, V);
     }
     budget -= chunk;
+    const auto tq1 = std::chrono::steady_clock::now();
     SSLAM_HIP_TRY(hipMemcpyAsync(st.data(), V.lm, sizeof(LmState) * V.B, hipMemcpyDeviceToHost, b.stream));
     SSLAM_HIP_TRY(hipStreamSynchronize(b.stream));
+    if (chunk_timing && V.B == 1)
+      fprintf(stderr, "[timing] LM chunk: %d steps enqueued in %.3f ms, waited %.3f ms more; iteration %d trials %d active %d\n", chunk,
+              std::chrono::duration<double, std::milli>(tq1 - tq0).count(), std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tq1).count(),
+              st[0].iter, st[0].trials, st[0].active);
     b.harvest();
     need = 0;
     int na = 0;
@@ -2476,7 +2483,7 @@ int sslam_graph_set_option(sslam_graph* h, const char* key, double value) {
   if (k == "solver") { if (value != 0 && value != 1 && value != 2 && value != 3) return set_error(SSLAM_ERR_INVALID, "solver: 0 block-Jacobi PCG, 1 sparse block Cholesky (piece plan), 2 Schur complement on the landmarks + PCG, 3 sparse block Cholesky (window plan)"); o.solver = (int)value; }
   else if (k == "robust_kernel_dcs") { if (!(value >= 0)) return set_error(SSLAM_ERR_INVALID, "robust_kernel_dcs: phi >= 0 (0 = no kernel)"); o.dcs_phi = value; if (h->batch) h->batch->V.dcs_phi = value; h->linearized = false; }
   else if (k == "fused_small_graph") o.fused = value != 0;
-  else if (k == "speculative_trials") o.speculative = value != 0;
+  else if (k == "speculative_trials") o.speculative = value < 0 ? 0 : (value > 2 ? 2 : (int)value);
   else if (k == "pcg_tol") o.pcg_tol = value;
   else if (k == "pcg_max_iters") o.pcg_max_iters = (int)value;
   else if (k == "deterministic") { if (value == 0) return set_error(SSLAM_ERR_UNSUPPORTED, "the Jacobian build is always deterministic (gather form); the FP64-atomics variant was removed"); }

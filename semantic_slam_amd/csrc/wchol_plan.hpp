@@ -136,7 +136,7 @@ inline void plan_graph(const SymIn& in, int g, const WOpts& opt, const std::unor
   for (int s = 0; s < n; ++s) {
     const int v = S.order[s];
     grow[s] = loc2row(v); dimc[s] = row_dim(grow[s]);
-    for (int w : S.cstruct[v]) cs[s].push_back(pos[w]);
+    for (int q = S.cs_start[v]; q < S.cs_start[v] + S.cs_len[v]; ++q) cs[s].push_back(pos[S.cs_idx[q]]);
     std::sort(cs[s].begin(), cs[s].end());
     if (!cs[s].empty()) {
       if (cs[s][0] <= s) { out.error = "symbolic factorisation inconsistent (row not below its column)"; return; }

@@ -632,9 +632,11 @@ def test_single_launch_solve_and_fused_steps_equal_the_stand_alone_kernels(gpu_l
     for (n, m, kind, iters) in [(120, 24, "point", 40), (80, 16, "plane", 12), (300, 60, "point", 10)]:
         g = make_graph(n, m, seed=11, landmark_kind=kind)
         gp = GraphProblem.from_synth(g, interleave=True)
-        sp = _optimize_variant(gp, iters, {}, 1, spec=1)
+        sp = _optimize_variant(gp, iters, {}, 1, spec=1)      # adaptive: the lanes join after the first rejected trial of an iteration
+        sp2 = _optimize_variant(gp, iters, {}, 1, spec=2)     # every round with all lanes
         a = _optimize_variant(gp, iters, {}, 1, spec=0)
         assert sp[:3] == a[:3] and np.array_equal(sp[3], a[3]), (sp[:3], a[:3])
+        assert sp2[:3] == a[:3] and np.array_equal(sp2[3], a[3]), (sp2[:3], a[:3])
         b = _optimize_variant(gp, iters, {}, 0)
         c = _optimize_variant(gp, iters, {"SSLAM_CHOL_FLOW": 0}, 0)
         d1 = _optimize_variant(gp, iters, {"SSLAM_CHOL_SMALL_COLS": 1200, "SSLAM_CHOL_FLOW": 0}, 1)
