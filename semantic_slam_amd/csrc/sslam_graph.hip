@@ -2254,7 +2254,15 @@ static int batch_optimize(Batch& b, int max_iters, sslam_opt_stats* out) {
     b.harvest();
     need = 0;
     int na = 0;
-    for (int g = 0; g < V.B; ++g) { act[g] = st[g].active ? 1 : 0; na += act[g]; if (st[g].active) need = std::max(need, max_iters - st[g].iter); }
+    for (int g = 0; g < V.B; ++g) {
+      act[g] = st[g].active ? 1 : 0; na += act[g];
+      if (!st[g].active) continue;
+      // a graph in a streak of rejected trials ends its iteration -- at convergence, its optimisation -- after at most 10 - q more of
+      // them: enqueue exactly those (g2o's LM ends every optimisation of the orchestrator with ten rejected trials; a full chunk
+      // behind each look cost 4-6 idle steps per tick).  An accepted trial in between: the next look supplies more steps.
+      const int streak_left = (st[g].in_trial && st[g].q > 0) ? std::max(1, 10 - st[g].q) : kStepChunk;
+      need = std::max(need, std::min(max_iters - st[g].iter, streak_left));
+    }
     // the graphs that are still iterating only ever shrink: once half of the batch is done, the factor / solve launches are sized
     // for the rest (a retry by three graphs then costs three graphs' pieces, not the dispatch of everybody's)
     static const bool timing = getenv("SSLAM_TIMING") != nullptr;
