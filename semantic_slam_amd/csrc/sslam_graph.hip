@@ -2058,10 +2058,12 @@ static int batch_linearize(Batch& b) {
     if (V.nLr > 0) hipLaunchKernelGGL((k_linearize_lm_rows<PLV, SHV>), dim3((V.nLr + 15) / 16), dim3(256), 0, lm_stream, V);           \
     if (V.nLL > 0) hipLaunchKernelGGL((k_linearize_ll<SHV>), dim3((V.nLL + 63) / 64), dim3(64), 0, lm_stream, V);                      \
   }
-  // Large batches: the landmark-row kernel (96 VGPRs, writes H_ll and the landmark part of b only) runs on a second stream NEXT TO the
-  // pose-row kernel -- disjoint outputs, and the pose-row kernel's register footprint leaves room for its waves on every SIMD; the
-  // duplicate-edge pass and everything after wait for both.  SSLAM_LIN_OVERLAP=0: one stream.
-  static const bool lin_overlap = [] { const char* e = getenv("SSLAM_LIN_OVERLAP"); return !(e && atoi(e) == 0); }();
+  // SSLAM_LIN_OVERLAP=1 (large batches): the landmark-row kernel (96 VGPRs, writes H_ll and the landmark part of b only) on a second stream
+  // NEXT TO the pose-row kernel -- disjoint outputs, and the pose-row kernel's register footprint leaves room for its waves on every SIMD;
+  // the duplicate-edge pass and everything after wait for both.  Takes 4 % off a build on ONE stream (2.12 -> 2.04 ms per 512 graphs) and is
+  // OFF by default: in a stream group every part forks and joins its own second stream at every step, and the event round trips between
+  // eight streams cost the group a quarter of its throughput (24.9k vs 32.6k LM iterations/s on the 512-graph batch, same box).
+  static const bool lin_overlap = [] { const char* e = getenv("SSLAM_LIN_OVERLAP"); return e && atoi(e) != 0; }();
   hipStream_t lm_stream = b.stream;
   const bool forked = lin_overlap && V.B >= 8 && V.nLr > 0 && V.nPr > 0;
   if (forked) {
@@ -2260,8 +2262,11 @@ static int batch_optimize(Batch& b, int max_iters, sslam_opt_stats* out) {
       // a graph in a streak of rejected trials ends its iteration -- at convergence, its optimisation -- after at most 10 - q more of
       // them: enqueue exactly those (g2o's LM ends every optimisation of the orchestrator with ten rejected trials; a full chunk
       // behind each look cost 4-6 idle steps per tick).  An accepted trial in between: the next look supplies more steps.
-      const int streak_left = (st[g].in_trial && st[g].q > 0) ? std::max(1, 10 - st[g].q) : kStepChunk;
-      need = std::max(need, std::min(max_iters - st[g].iter, streak_left));
+      static const bool streak_on = [] { const char* e = getenv("SSLAM_LM_STREAK"); return !(e && atoi(e) == 0); }();
+      // (small batches only: on a large batch every look is a host round trip for all graphs, and short chunks in the endgame cost the
+      // 512-graph stream group 12 % -- 25.0k vs 28.5k iterations/s)
+      const int streak_left = (streak_on && V.B < 8 && st[g].in_trial && st[g].q > 0) ? std::max(1, 10 - st[g].q) : kStepChunk;
+      need = std::max(need, streak_on ? std::min(max_iters - st[g].iter, streak_left) : max_iters - st[g].iter);
     }
     // the graphs that are still iterating only ever shrink: once half of the batch is done, the factor / solve launches are sized
     // for the rest (a retry by three graphs then costs three graphs' pieces, not the dispatch of everybody's)
