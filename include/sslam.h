@@ -112,9 +112,11 @@ int sslam_graph_hessian_index(sslam_graph* g, int id);
  * "fused_small_graph" 1 (default) / 0: a graph of at most ~1200 vertices runs every damping trial of an LM iteration in one launch
  * (k_lm_trial_small; the reference's per-tick call pattern, semantic_graph_slam.cpp:58-102) -- results are bitwise those of the
  * stand-alone kernels;
- * "speculative_trials" 1 / 0 (default): a single small graph runs the (up to ten) damping trials of an LM iteration side by side -- g2o's
- * retry lambdas are known when the iteration starts -- and replays the accept / reject sequence over their results: bitwise the
- * sequential result, one round of launches per iteration; measured no faster than the sequential trials on today's kernels, hence opt-in. */
+ * "speculative_trials" 0 (default) / 1 / 2: a single small graph runs the damping trials of an LM iteration side by side -- g2o's retry
+ * lambdas are known when the iteration starts -- and replays the accept / reject sequence over their results: bitwise the sequential
+ * result, trial counts included.  1: the lanes join once a trial of the iteration has been rejected; 2: every round with all ten lanes.
+ * Measured no faster than the sequential trials on today's kernels, hence opt-in; SSLAM_LM_SPEC=0/1/2 in the
+ * environment overrides the option for every graph of the process. */
 int sslam_graph_set_option(sslam_graph* g, const char* key, double value);
 
 /* GraphSLAM::optimize (graph_slam.cpp:182-219) with the iteration cap as a parameter (the
