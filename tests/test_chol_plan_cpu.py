@@ -204,3 +204,19 @@ def test_plan_plane_landmarks_and_S_config(hip_lib):
     plan, H, b = _plan_and_system(hip_lib, g, True)
     _structure_invariants(plan)
     _check(plan, H, b, 1e-2)
+
+
+def test_bitset_ordering_gives_the_plan_of_the_list_ordering(hip_lib):
+    """Graphs of <= 2048 nodes (what the orchestrator re-plans at every tick) are ordered on adjacency bitsets (chol_plan.hpp
+    multi_min_degree_bits); SSLAM_CHOL_ORDER_BITS=0 keeps the sorted-list form that large graphs use.  Same candidates, same tie breaks:
+    every array of the plan is identical."""
+    names = ("col", "blk", "upd", "item", "mb", "ilv", "piece", "asrc", "usrc", "fwd", "uitem", "umb", "rcol", "rupd")
+    for (n, m, seed, kind) in [(110, 39, 4, "point"), (436, 149, 9, "point"), (300, 60, 2, "plane"), (37, 5, 1, "point")]:
+        g = make_graph(n, m, seed=seed, landmark_kind=kind)
+        a, _, _ = _plan_and_system(hip_lib, g, False)
+        b, _, _ = _plan_and_system(hip_lib, g, False, {"SSLAM_CHOL_ORDER_BITS": 0})
+        assert a.ncol == b.ncol and a.lnz == b.lnz and a.unz == b.unz and a.nlevels == b.nlevels
+        for name in names:
+            x, y = getattr(a, name), getattr(b, name)
+            assert x.shape == y.shape and x.tobytes() == y.tobytes(), name
+        assert list(a.plv_pieces) == list(b.plv_pieces) and list(a.tail_pieces) == list(b.tail_pieces)
