@@ -1466,7 +1466,8 @@ __global__ __launch_bounds__(NT) void k_chol_flow(BatchView V, CholView C, int q
   const bool defer = do_backward & 2;   // bit 1: tables and H before the wait for the children (chol_piece DEFER)
   // bit 2: a whole damping trial in this launch -- what k_lm_begin_small does before the factorisation (workgroup g for graph g, everybody
   // waits for it: lambda and in_trial are read by every piece) and what k_lm_end_small does after the backward substitution (the
-  // workgroup that finishes last, by a ticket).  Two launches less per trial of the orchestrator's graphs, which are bound by launches.
+  // workgroup that finishes last, by a ticket).  Two launches less per trial of the orchestrator's graphs (measured: 0.02 - 0.15 ms per
+  // tick -- a trial waits for the chain of pieces inside this launch, not for launches).
   const bool lmstep = (do_backward & 4) && SL.K == 0;
   int wg = blockIdx.x, nwg = gridDim.x;
   if (SL.K > 0) {   // speculative damping trials: a lane = a range of workgroups, with its own factor, vectors, counters and lambda
