@@ -1046,8 +1046,8 @@ inline int chol_symbolic(const SymIn& in, CholOpts opt, CholHost& out) {
   //      workgroups a CU can hold changes (160 KB / 32, 24, 16 workgroups): the typical piece then runs at twice the residency the
   //      largest one of its depth would allow.
   {
-    std::vector<int> ptr{0}, order;
-    order.reserve(out.plv_pieces.size());
+    std::vector<int> ptr{0}, launch_order;
+    launch_order.reserve(out.plv_pieces.size());
     const int cut[3] = {640, 853, 1280};
     for (int l = 0; l < nplv; ++l) {
       std::vector<int> ps(out.plv_pieces.begin() + out.plv_ptr[l], out.plv_pieces.begin() + out.plv_ptr[l + 1]);
@@ -1058,15 +1058,15 @@ inline int chol_symbolic(const SymIn& in, CholOpts opt, CholHost& out) {
         for (int k = 0; k < 3 && q0 < n; ++k) {
           int q1 = q0;
           while (q1 < n && lds_b(ps[q1]) <= cut[k]) ++q1;
-          if (q1 - q0 >= opt.split_min / 2 && n - q1 >= opt.split_min / 2) { for (int q = q0; q < q1; ++q) order.push_back(ps[q]); ptr.push_back((int)order.size()); q0 = q1; }
+          if (q1 - q0 >= opt.split_min / 2 && n - q1 >= opt.split_min / 2) { for (int q = q0; q < q1; ++q) launch_order.push_back(ps[q]); ptr.push_back((int)launch_order.size()); q0 = q1; }
         }
-        for (int q = q0; q < n; ++q) order.push_back(ps[q]);
+        for (int q = q0; q < n; ++q) launch_order.push_back(ps[q]);
       } else {
-        for (int p : ps) order.push_back(p);
+        for (int p : ps) launch_order.push_back(p);
       }
-      if ((int)order.size() > ptr.back()) ptr.push_back((int)order.size());
+      if ((int)launch_order.size() > ptr.back()) ptr.push_back((int)launch_order.size());
     }
-    out.plv_pieces = order;
+    out.plv_pieces = launch_order;
     out.plv_ptr = ptr;
   }
   const int nlaunch = (int)out.plv_ptr.size() - 1;
