@@ -113,10 +113,12 @@ int sslam_graph_hessian_index(sslam_graph* g, int id);
  * (k_lm_trial_small; the reference's per-tick call pattern, semantic_graph_slam.cpp:58-102) -- results are bitwise those of the
  * stand-alone kernels;
  * "speculative_trials" 0 (default) / 1 / 2: a single small graph runs the damping trials of an LM iteration side by side -- g2o's retry
- * lambdas are known when the iteration starts -- and replays the accept / reject sequence over their results: bitwise the sequential
- * result, trial counts included.  1: the lanes join once a trial of the iteration has been rejected; 2: every round with all ten lanes.
- * Measured no faster than the sequential trials on today's kernels, hence opt-in; SSLAM_LM_SPEC=0/1/2 in the
- * environment overrides the option for every graph of the process. */
+ * lambdas are known when the iteration starts -- in the lanes of ONE launch (k_chol_spec_round) that also replays the accept / reject
+ * sequence over their results: bitwise the sequential result, trial counts included.  1: the lanes join once a trial of the iteration
+ * has been rejected, and only while every lane gets a workgroup per piece of the tree (about 200 keyframes); 2: every round with all ten
+ * lanes.  Mode 1 measured 5.5 vs 6.0 ms per tick at 110 keyframes and equal at 436; it arrived at the end of round
+ * 4 and stays opt-in until it has been through a whole round of tests.  SSLAM_LM_SPEC=0/1/2 in the environment overrides the option for
+ * every graph of the process. */
 int sslam_graph_set_option(sslam_graph* g, const char* key, double value);
 
 /* GraphSLAM::optimize (graph_slam.cpp:182-219) with the iteration cap as a parameter (the

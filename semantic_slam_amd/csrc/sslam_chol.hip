@@ -71,6 +71,8 @@ struct SpecLanes {
   long long sL = 0, sU = 0, sy = 0, sx = 0, spose = 0, slmk = 0, spe = 0, spa = 0, sflow = 0;   // lane strides (elements)
   int g0 = 0, g1 = 0;         // workgroups of lane 0 / of every other lane in the (one-dimensional) grid of k_chol_flow
   int after = 0;              // lanes 1.. take part once `after` trials of the iteration have been rejected (0: always; 1: adaptive)
+  int* ctl = nullptr;         // k_chol_spec_round: [0] rounds begun, [1] lanes at work in this round, [2] lanes finished in this round,
+                              // [8 + k] end tickets of lane k, [8 + K + k] rounds lane k has run (its epoch)
 };
 
 struct CholPlan {
@@ -1339,29 +1341,25 @@ __global__ __launch_bounds__(NT) void k_lm_end_small(BatchView V, CholView C, do
 }
 
 // ---- speculative damping trials (SpecLanes): begin / per-lane end / replay of the accept-reject sequence + commit ----------------
-template <int NT>
-__global__ __launch_bounds__(NT) void k_lm_begin_spec(BatchView V, CholView C, SpecLanes SL) {
-  __shared__ double red[NT / 64];
-  const int g = blockIdx.x;
-  if (!V.lm[g].active) return;
-  lm_begin_small<NT>(V, C, g, red);
-  if (threadIdx.x == 0) {   // lane k tries the lambda the sequential loop would reach after k rejected trials
-    const LmState S = V.lm[g];
-    double lam = S.lambda, nu = S.nu;
-    for (int k = 0; k < SL.K; ++k) {
-      LmState Lk = S;
-      Lk.lambda = lam; Lk.in_trial = (S.in_trial && S.q + k < 10 && (k == 0 || S.q >= SL.after)) ? 1 : 0;
-      SL.lm[(size_t)k * V.B + g] = Lk;
-      SL.fail[(size_t)k * V.B + g] = 0;
-      lam *= nu; nu *= 2;
-    }
+// one thread: lane k tries the lambda the sequential loop would reach after k rejected trials; returns the number of lanes at work
+__device__ __forceinline__ int spec_setup_lanes(const BatchView& V, const SpecLanes& SL, int g) {
+  const LmState S = V.lm[g];
+  double lam = S.lambda, nu = S.nu;
+  int n = 0;
+  for (int k = 0; k < SL.K; ++k) {
+    LmState Lk = S;
+    Lk.lambda = lam; Lk.in_trial = (S.active && S.in_trial && S.q + k < 10 && (k == 0 || S.q >= SL.after)) ? 1 : 0;
+    SL.lm[(size_t)k * V.B + g] = Lk;
+    SL.fail[(size_t)k * V.B + g] = 0;
+    n += Lk.in_trial;
+    lam *= nu; nu *= 2;
   }
+  return n;
 }
+// x [+] dx, chi2 and dx . (lambda dx + b) of lane k (one workgroup)
 template <int NT>
-__global__ __launch_bounds__(NT) void k_lm_end_spec(BatchView V, CholView C, SpecLanes SL) {   // x [+] dx, chi2 and dx . (lambda dx + b) of one lane
-  __shared__ double red[NT / 64];
-  const int g = blockIdx.x, tid = threadIdx.x;
-  const long long k = blockIdx.y;
+__device__ __forceinline__ void spec_lane_end(BatchView V, const SpecLanes& SL, const long long k, const int g, double* red) {
+  const int tid = threadIdx.x;
   V.lm = SL.lm + k * V.B; V.x = SL.x + k * SL.sx; V.pose_trial = SL.pose_trial + k * SL.spose; V.lmk_trial = SL.lmk_trial + k * SL.slmk;
   V.part_a = SL.part_a + k * SL.spa;
   double* part_e = SL.part_e + k * SL.spe;
@@ -1395,17 +1393,17 @@ __global__ __launch_bounds__(NT) void k_lm_end_spec(BatchView V, CholView C, Spe
     vblock_store_sum<kRowChunk, NT>(v, red, V.part_a + (size_t)g * V.maxRowChunks + chunk, live);
   }
 }
+// OptimizationAlgorithmLevenberg's do { ... } while (rho < 0 && q < 10) over the finished lanes, in order, and the commit of the accepted one
 template <int NT>
-__global__ __launch_bounds__(NT) void k_lm_control_spec(BatchView V, SpecLanes SL, int max_iters) {
-  __shared__ int s_lane;
-  const int g = blockIdx.x, tid = threadIdx.x;
+__device__ __forceinline__ void spec_control(const BatchView& V, const SpecLanes& SL, const int g, const int max_iters, int* s_lane) {
+  const int tid = threadIdx.x;
   LmState& S = V.lm[g];
   if (!S.active || !S.in_trial) return;
   const GraphSeg sg = V.seg[g];
   const int nec = edge_chunks(sg), nrc = row_chunks(sg);
-  if (tid == 0) s_lane = -1;
+  if (tid == 0) *s_lane = -1;
   __syncthreads();
-  if (tid < 64) {   // OptimizationAlgorithmLevenberg's do { ... } while (rho < 0 && q < 10) over the finished trials, in order
+  if (tid < 64) {
     for (int k = 0; k < SL.K; ++k) {
       if (!SL.lm[(size_t)k * V.B + g].in_trial) break;
       const double tchi = wave_sum_partials(SL.part_e + (size_t)k * SL.spe + (size_t)g * V.maxEdgeChunks, nec);
@@ -1415,7 +1413,7 @@ __global__ __launch_bounds__(NT) void k_lm_control_spec(BatchView V, SpecLanes S
         const int failed = SL.fail[(size_t)k * V.B + g];
         V.pcg_fail[g] = failed;
         lm_control_apply(S, tchi, sc, failed, max_iters);
-        if (S.accept) s_lane = k;
+        if (S.accept) *s_lane = k;
         more = S.in_trial;
       }
       more = __shfl(more, 0, 64);
@@ -1426,7 +1424,7 @@ __global__ __launch_bounds__(NT) void k_lm_control_spec(BatchView V, SpecLanes S
   }
   __threadfence_block();
   __syncthreads();
-  const int lane = s_lane;
+  const int lane = *s_lane;
   if (lane >= 0) {   // commit the accepted lane's estimates
     const double* pt = SL.pose_trial + (size_t)lane * SL.spose;
     const double* lt = SL.lmk_trial + (size_t)lane * SL.slmk;
@@ -1554,6 +1552,100 @@ __global__ __launch_bounds__(NT) void k_chol_flow(BatchView V, CholView C, int q
         if (V.lm[g].active && V.lm[g].in_trial) lm_end_small<NT>(V, C, g, part_e, max_iters, red);
     }
   }
+}
+
+// One LM ITERATION'S WORTH of damping trials of a single small graph in ONE launch (speculative_trials): what k_lm_begin_spec, k_chol_flow over
+// the lanes, k_lm_end_spec and k_lm_control_spec did in four.  Workgroup 0 begins the step and sets the lanes up (lane k: the lambda after k
+// rejected trials; the adaptive form puts lanes 1.. to work only once a trial of the iteration has been rejected); everybody waits for
+// that.  The workgroups of a lane that is not at work leave at once -- a lane counts its own rounds (ctl[8 + K + k]) and waits on its own
+// counters with that number, so rounds it sits out cost it nothing.  A lane's workgroups factor and solve as in k_chol_flow (fetch before
+// the wait); the one that takes the lane's last ticket forms the lane's chi2 / scale partial sums; the lane that finishes last replays
+// g2o's accept / reject sequence over the lanes in order and commits the accepted one.  Same sums, same order: bitwise the sequential loop.
+template <int NT, bool USTAGE>
+__global__ __launch_bounds__(NT) void k_chol_spec_round(BatchView V, CholView C, int np, const int2* __restrict__ dep, SpecLanes SL, int round, int max_iters) {
+  extern __shared__ double sm[];
+  __shared__ double red[NT / 64];
+  __shared__ int s_flag, s_lane;
+  const int tid = threadIdx.x;
+  const BatchView V0 = V;   // the graph's own state and estimates
+  const int g = 0;          // (the lanes exist for batches of one graph)
+  int* ctl = SL.ctl;
+  if (blockIdx.x == 0) {
+    if (V0.lm[g].active) lm_begin_small<NT>(V0, C, g, red);
+    __syncthreads();
+    if (tid == 0) {
+      ctl[1] = spec_setup_lanes(V0, SL, g);
+      ctl[2] = 0;
+      __threadfence();
+      __hip_atomic_fetch_add(ctl, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+  if (tid == 0) flow_wait(ctl, round, SL.flow + 3 * np);
+  __syncthreads();
+  int wg = blockIdx.x, nwg = SL.g0;
+  long long k = 0;
+  if (wg >= SL.g0) { const int r = wg - SL.g0; k = 1 + r / SL.g1; wg = r - (int)(k - 1) * SL.g1; nwg = SL.g1; }
+  V.lm = SL.lm + k * V.B; V.x = SL.x + k * SL.sx;
+  C.Lval = SL.Lval + k * SL.sL; C.Uval = SL.Uval + k * SL.sU; C.y = SL.y + k * SL.sy; C.fail = SL.fail + k * V.B;
+  if (!V.lm[g].in_trial) return;   // this lane sits the round out (uniform over the lane)
+  int* flow = SL.flow + k * SL.sflow;
+  int* child_done = flow;
+  int* back_done = flow + np;
+  int* fwd_done = flow + 2 * np;
+  int* err = flow + 3 * np;
+  const int epoch = ctl[8 + SL.K + k] + 1;
+  for (int q = wg; q < np; q += nwg) {
+    const PieceMeta pm = C.lpiece[q];
+    const int2 d = dep[q];
+    const int* wp = d.y > 0 ? child_done + q : nullptr;
+    if (q >= C.ltail0) {
+      if (C.rupd) chol_piece<NT, false, true, true>(V, C, pm, sm, nullptr, wp, d.y * epoch, err);
+      else chol_piece<NT, false, false, true>(V, C, pm, sm, nullptr, wp, d.y * epoch, err);
+    } else chol_piece<NT, USTAGE, false, true>(V, C, pm, sm, nullptr, wp, d.y * epoch, err);
+    __syncthreads();
+    if (tid == 0) {
+      __threadfence();
+      if (d.x >= 0) __hip_atomic_fetch_add(child_done + d.x, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      else __hip_atomic_store(fwd_done + q, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+  for (int i = wg; i < np; i += nwg) {
+    const int q = np - 1 - i;
+    const PieceMeta pm = C.lpiece[q];
+    const int2 d = dep[q];
+    if (tid == 0) {
+      if (d.x >= 0) flow_wait(back_done + d.x, epoch, err);
+      else flow_wait(fwd_done + q, epoch, err);
+    }
+    __syncthreads();
+    chol_piece_backward<NT>(C, pm, C.y, V.x, sm, nullptr);
+    __syncthreads();
+    if (tid == 0) {
+      __threadfence();
+      __hip_atomic_store(back_done + q, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+  // ---- the lane's last workgroup: its partial sums
+  __syncthreads();
+  if (tid == 0) {
+    __threadfence();
+    const int t = __hip_atomic_fetch_add(ctl + 8 + k, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    s_flag = ((t + 1) % nwg == 0) ? 1 : 0;   // a lane at work adds nwg tickets per round, a lane that sits out none
+  }
+  __syncthreads();
+  if (!s_flag) return;
+  spec_lane_end<NT>(V0, SL, k, g, red);
+  __syncthreads();
+  if (tid == 0) {
+    ctl[8 + SL.K + k] = epoch;
+    __threadfence();
+    const int done = __hip_atomic_fetch_add(ctl + 2, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) + 1;
+    s_flag = (done == ctl[1]) ? 1 : 0;
+  }
+  __syncthreads();
+  if (!s_flag) return;
+  // ---- the round's last lane: accept / reject in g2o's order, commit
+  spec_control<NT>(V0, SL, g, max_iters, &s_lane);
 }
 
 __global__ void k_chol_begin(BatchView V, CholView C) {  // clear failure flags of the graphs being solved
@@ -1744,7 +1836,8 @@ int chol_plan_build(Batch& b) {
                            (const void*)k_chol_back_pieces<64>, (const void*)k_chol_back_pieces<128>, (const void*)k_chol_back_pieces<256>,
                            (const void*)k_chol_back_pieces<512>, (const void*)k_chol_back_pieces<1024>, (const void*)k_chol_back_tail<512>,
                            (const void*)k_lm_trial_small<512>, (const void*)k_lm_trial_small<1024>,
-                           (const void*)k_chol_flow<512, true>, (const void*)k_chol_flow<512, false>};
+                           (const void*)k_chol_flow<512, true>, (const void*)k_chol_flow<512, false>,
+                           (const void*)k_chol_spec_round<512, true>, (const void*)k_chol_spec_round<512, false>};
       for (const void* f : fns) SSLAM_HIP_TRY(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, v));
       done.push_back(b.device);
     }
@@ -1788,28 +1881,41 @@ int chol_plan_build(Batch& b) {
         // K lanes of persistent workgroups, all of them on the chip at once.  Lane 0 -- the only one at work until a trial of the iteration
         // has been rejected (adaptive form) -- gets a workgroup per piece like the plain single-launch solve, the others share the rest
         SpecLanes& SL = P->spec;
-        SL.g0 = std::max(1, std::min((int)dep.size(), cap));
-        SL.g1 = std::max(1, std::min((int)dep.size(), (2 * cap - SL.g0) / (K - 1)));
-        SL.after = spec_mode == 2 ? 0 : 1;
-        P->spec_grid = SL.g0 + (K - 1) * SL.g1;
-        SL.sL = (H.lnz + 64 + 1) & ~1LL; SL.sU = (H.unz + 64 + 1) & ~1LL; SL.sy = (C.dim + 8 + 1) & ~1LL; SL.sx = (C.dim + 8 + 1) & ~1LL;
-        SL.spose = (long long)b.V.nPose * 8; SL.slmk = (long long)b.V.nLm * 4; SL.spe = (long long)b.V.B * b.V.maxEdgeChunks; SL.spa = (long long)b.V.B * b.V.maxRowChunks;
-        SL.sflow = (long long)nints;
-        const size_t nd = (size_t)K * (SL.sL + SL.sU + SL.sy + SL.sx + SL.spose + SL.slmk + SL.spe + SL.spa);
-        if ((rc = plan_alloc(&p, nd * sizeof(double)))) return rc;
-        SSLAM_HIP_TRY(hipMemsetAsync(p, 0, nd * sizeof(double), b.stream));
-        double* dp = (double*)p;
-        SL.Lval = dp; dp += K * SL.sL; SL.Uval = dp; dp += K * SL.sU; SL.y = dp; dp += K * SL.sy; SL.x = dp; dp += K * SL.sx;
-        SL.pose_trial = dp; dp += K * SL.spose; SL.lmk_trial = dp; dp += K * SL.slmk; SL.part_e = dp; dp += K * SL.spe; SL.part_a = dp;
-        const size_t ni = (size_t)K * (SL.sflow + b.V.B);
-        if ((rc = plan_alloc(&p, ni * sizeof(int)))) return rc;
-        SSLAM_HIP_TRY(hipMemsetAsync(p, 0, ni * sizeof(int), b.stream));
-        SL.flow = (int*)p; SL.fail = (int*)p + (size_t)K * SL.sflow;
-        if ((rc = plan_alloc(&p, (size_t)K * b.V.B * sizeof(LmState)))) return rc;
-        SSLAM_HIP_TRY(hipMemsetAsync(p, 0, (size_t)K * b.V.B * sizeof(LmState), b.stream));
-        SL.lm = (LmState*)p;
-        SL.pose_cur = b.V.pose; SL.lmk_cur = b.V.lmk;
-        SL.K = K;
+        int per_cu_s = 0;   // what the device holds at once of the round's own kernel (ten lanes at work must all be resident)
+        const void* fn_s = P->ustage ? (const void*)k_chol_spec_round<512, true> : (const void*)k_chol_spec_round<512, false>;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu_s, fn_s, 512, lds_max) != hipSuccess || per_cu_s < 1) per_cu_s = 1;
+        const int full = std::max(K, std::min(2 * cap, per_cu_s * cus));
+        SL.g0 = std::max(1, std::min((int)dep.size(), std::min(cap, full / 2)));
+        SL.g1 = std::max(1, std::min((int)dep.size(), (full - SL.g0) / (K - 1)));
+        // adaptive form: only while every lane gets a workgroup per piece -- a lane that walks its pieces in rounds makes the one round of
+        // nine trials slower than the trials one after the other (436 keyframes, 121 pieces, 43 workgroups per lane: 7.8 vs 7.5 ms per tick;
+        // 110 keyframes, 26 pieces: 5.45 vs 6.00 ms).  A graph that outgrows the lanes goes on with the sequential trials.
+        const bool lanes_fit = SL.g1 >= (int)dep.size();
+        if (spec_mode == 2 || lanes_fit) {
+          SL.after = spec_mode == 2 ? 0 : 1;
+          P->spec_grid = SL.g0 + (K - 1) * SL.g1;
+          SL.sL = (H.lnz + 64 + 1) & ~1LL; SL.sU = (H.unz + 64 + 1) & ~1LL; SL.sy = (C.dim + 8 + 1) & ~1LL; SL.sx = (C.dim + 8 + 1) & ~1LL;
+          SL.spose = (long long)b.V.nPose * 8; SL.slmk = (long long)b.V.nLm * 4; SL.spe = (long long)b.V.B * b.V.maxEdgeChunks; SL.spa = (long long)b.V.B * b.V.maxRowChunks;
+          SL.sflow = (long long)nints;
+          const size_t nd = (size_t)K * (SL.sL + SL.sU + SL.sy + SL.sx + SL.spose + SL.slmk + SL.spe + SL.spa);
+          if ((rc = plan_alloc(&p, nd * sizeof(double)))) return rc;
+          SSLAM_HIP_TRY(hipMemsetAsync(p, 0, nd * sizeof(double), b.stream));
+          double* dp = (double*)p;
+          SL.Lval = dp; dp += K * SL.sL; SL.Uval = dp; dp += K * SL.sU; SL.y = dp; dp += K * SL.sy; SL.x = dp; dp += K * SL.sx;
+          SL.pose_trial = dp; dp += K * SL.spose; SL.lmk_trial = dp; dp += K * SL.slmk; SL.part_e = dp; dp += K * SL.spe; SL.part_a = dp;
+          const size_t ni = (size_t)K * (SL.sflow + b.V.B);
+          if ((rc = plan_alloc(&p, ni * sizeof(int)))) return rc;
+          SSLAM_HIP_TRY(hipMemsetAsync(p, 0, ni * sizeof(int), b.stream));
+          SL.flow = (int*)p; SL.fail = (int*)p + (size_t)K * SL.sflow;
+          if ((rc = plan_alloc(&p, (size_t)K * b.V.B * sizeof(LmState)))) return rc;
+          SSLAM_HIP_TRY(hipMemsetAsync(p, 0, (size_t)K * b.V.B * sizeof(LmState), b.stream));
+          SL.lm = (LmState*)p;
+          SL.pose_cur = b.V.pose; SL.lmk_cur = b.V.lmk;
+          if ((rc = plan_alloc(&p, (size_t)(2 * K + 16) * sizeof(int)))) return rc;
+          SSLAM_HIP_TRY(hipMemsetAsync(p, 0, (size_t)(2 * K + 16) * sizeof(int), b.stream));
+          SL.ctl = (int*)p;
+          SL.K = K;
+        }
       }
     }
   }
@@ -1899,10 +2005,13 @@ bool chol_plan_spec(const Batch& b) { return chol_plan_flow(b) && b.chol->spec.K
 int chol_lm_step_spec(Batch& b, int max_iters) {
   CholPlan& P = *b.chol;
   P.C.flat_L = 0;
-  hipLaunchKernelGGL(k_lm_begin_spec<512>, dim3(b.V.B), dim3(512), 0, b.stream, b.V, P.C, P.spec);
-  flow_launches(b, true);
-  hipLaunchKernelGGL(k_lm_end_spec<512>, dim3(b.V.B, P.spec.K), dim3(512), 0, b.stream, b.V, P.C, P.spec);
-  hipLaunchKernelGGL(k_lm_control_spec<512>, dim3(b.V.B), dim3(512), 0, b.stream, b.V, P.spec, max_iters);
+  size_t lds = (size_t)std::max(P.tail_lds_f, P.tail_lds_b);
+  for (size_t l = 0; l < P.plv_lds_f.size(); ++l) lds = std::max(lds, (size_t)std::max(P.plv_lds_f[l], P.plv_lds_b[l]));
+  lds *= sizeof(double);
+  const int np = (int)P.lp_graph.size();
+  const int round = ++P.spec_epoch;
+  if (P.ustage) hipLaunchKernelGGL((k_chol_spec_round<512, true>), dim3(P.spec_grid), dim3(512), lds, b.stream, b.V, P.C, np, (const int2*)P.d_dep, P.spec, round, max_iters);
+  else hipLaunchKernelGGL((k_chol_spec_round<512, false>), dim3(P.spec_grid), dim3(512), lds, b.stream, b.V, P.C, np, (const int2*)P.d_dep, P.spec, round, max_iters);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return set_error(SSLAM_ERR_HIP, "speculative LM step launch: %s", hipGetErrorString(e));
   return 0;
