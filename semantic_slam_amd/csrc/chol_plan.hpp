@@ -125,6 +125,16 @@ struct CholOpts {
   int cap_tail = 4608;     // doubles of L per piece of a tail (two tail workgroups per CU must fit the LDS)
   int max_blocks = 224;    // blocks per piece
   int tail_width = -1;     // a graph's tail starts where it has <= tail_width pieces per depth; -1: 6 for batches >= 32, else 2; 0: no tail
+  // Mid class (round 5).  Above the bushy bottom a column has 15-25 blocks and a leaf-sized piece holds two of them: its update matrix
+  // (boundary^2: 160-190 blocks) is 4-5 x its part of L, every such piece reads its children's and writes its own, and ONE wave walks
+  // those ~600 tiles in ten passes of dependent HBM trips (~100 us per piece against ~20 us for a leaf piece; 53 % of all update-matrix
+  // bytes).  The depths between the bottom and the tail -- where a graph has <= mid_width pieces per depth -- are cut again with a larger
+  // cap and run by wider workgroups, one launch per depth next to the leaf pieces of that depth: several columns of a chain share a
+  // piece, their updates stay in LDS (right-looking lists like the tail's), and four waves share the tiles of what is still handed up.
+  int mid_width = -1;      // -1: 100 for batches >= 32, else 0 (small batches run k_chol_flow with one workgroup size); 0: no mid class
+  int cap_mid = 2400;      // doubles of L per mid piece
+  int nt_mid = 256;        // its workgroup
+  int pcap_mid = 16;
   int nt_leaf = 64, nt_tail = 512;    // workgroup sizes the items are cut for
   int min_chunk = 4;       // a list of <= min_chunk updates is never split
   int split_min = 4096;    // a depth with at least this many pieces is launched in up to four parts, by LDS need
@@ -153,6 +163,8 @@ struct CholOpts {
   void from_env() {
     cap_leaf = env_int("SSLAM_CHOL_CAP_LEAF", cap_leaf); cap_tail = env_int("SSLAM_CHOL_CAP_TAIL", cap_tail);
     max_blocks = env_int("SSLAM_CHOL_MAX_BLOCKS", max_blocks); tail_width = env_int("SSLAM_CHOL_TAIL_WIDTH", tail_width);
+    mid_width = env_int("SSLAM_CHOL_MID_WIDTH", mid_width); cap_mid = env_int("SSLAM_CHOL_CAP_MID", cap_mid); nt_mid = env_int("SSLAM_CHOL_NT_MID", nt_mid);
+    pcap_mid = env_int("SSLAM_CHOL_PCAP_MID", pcap_mid);
     nt_tail = env_int("SSLAM_CHOL_NT_TAIL", nt_tail); nt_leaf = env_int("SSLAM_CHOL_NT_LEAF", nt_leaf); min_chunk = std::max(1, env_int("SSLAM_CHOL_MIN_CHUNK", min_chunk));
     split_min = std::max(2, env_int("SSLAM_CHOL_SPLIT_MIN", split_min));
     pcap_leaf = env_int("SSLAM_CHOL_PCAP_LEAF", pcap_leaf); pcap_tail = env_int("SSLAM_CHOL_PCAP_TAIL", pcap_tail);
@@ -179,8 +191,9 @@ struct CholHost {
   std::vector<PieceMeta> lpiece;            // piece records in launch order: plv_pieces then tail_pieces (one dependent load less per workgroup)
   std::vector<int> tail_ptr, tail_pieces;   // per graph: its tail pieces in elimination order
   std::vector<int> plv_lds_f, plv_lds_b;    // LDS doubles per launch (factor / backward)
+  std::vector<int> plv_nt, plv_cls;         // workgroup size (nt_leaf | nt_mid) and class (0 leaf | 1 mid) per launch
   int tail_lds_f = 0, tail_lds_b = 0;
-  int nt_leaf = 64, nt_tail = 512, ustage = 0;
+  int nt_leaf = 64, nt_mid = 256, nt_tail = 512, ustage = 0;
   std::string error;
 };
 
@@ -336,10 +349,12 @@ inline void multi_min_degree_bits(int n, Neighbours&& neighbours, GraphSym& out,
 
 // Greedy bottom-up cut of an elimination tree (columns 0..n-1 in elimination order, parent[s] > s or -1) into pieces:
 // a column joins the still-open pieces of its children, largest first, while the caps hold; whatever does not fit is
-// closed.  fixed[s] >= 0 pins column s to an existing piece id (treated as closed).  Returns the piece id per column
+// closed.  fixed[s] >= 0 pins column s to an existing piece id (treated as closed).  cls (optional): class of every column; a column only
+// joins pieces of its own class and the cap is caps[class] (classes ascend towards the root).  Returns the piece id per column
 // (ids of new pieces start at first_new_id) and the number of ids used.
 inline int cut_pieces(int n, const std::vector<int>& parent, const std::vector<int>& colsz, const std::vector<int>& colnb,
-                      const std::vector<int>& fixed, int first_new_id, int cap, int max_blocks, std::vector<int>& pc) {
+                      const std::vector<int>& fixed, int first_new_id, int cap_all, int max_blocks, std::vector<int>& pc,
+                      const std::vector<int>* cls = nullptr, const int* caps = nullptr) {
   pc.assign(n, -1);
   // children lists in CSR form (ascending inside a list, like the per-column vectors they replace); the columns of a piece as a linked
   // list (only ever walked to relabel them); scratch allocated once
@@ -362,6 +377,7 @@ inline int cut_pieces(int n, const std::vector<int>& parent, const std::vector<i
       const int c = kidx[kq];
       const int p = pc[c];
       if (fixed[c] >= 0) continue;
+      if (cls && (*cls)[c] != (*cls)[s]) continue;
       if (open[p - first_new_id] && std::find(cand.begin(), cand.end(), p) == cand.end()) cand.push_back(p);
     }
     std::sort(cand.begin(), cand.end(), [&](int a, int b) {
@@ -369,6 +385,7 @@ inline int cut_pieces(int n, const std::vector<int>& parent, const std::vector<i
       return sa != sb ? sa > sb : a < b;
     });
     int size = colsz[s], nb = colnb[s], lev = 0;
+    const int cap = cls ? caps[(*cls)[s]] : cap_all;
     take.clear();
     for (int p : cand) {
       const int q = p - first_new_id;
@@ -410,10 +427,11 @@ inline int chol_symbolic(const SymIn& in, CholOpts opt, CholHost& out) {
   const int nPr = in.nPr, nLr = in.nLr, nrow = nPr + nLr, B = in.B;
   if (opt.tail_width < 0) opt.tail_width = B >= 32 ? 6 : 2;
   if (opt.ustage < 0) opt.ustage = B >= 32 ? 0 : 1;
+  if (opt.mid_width < 0) opt.mid_width = B >= 32 ? 100 : 0;
   if (opt.order < 0) opt.order = 1;
   if (opt.order_mul < 0 || opt.order_add < 0) { opt.order_mul = B >= 32 ? 1.5 : 2.0; opt.order_add = B >= 32 ? 2 : 4; }
   out = CholHost();
-  out.B = B; out.nt_leaf = opt.nt_leaf; out.nt_tail = opt.nt_tail; out.ustage = opt.ustage;
+  out.B = B; out.nt_leaf = opt.nt_leaf; out.nt_mid = opt.nt_mid; out.nt_tail = opt.nt_tail; out.ustage = opt.ustage;
   auto row_dim = [&](int r) { return r < nPr ? 6 : 3; };
   auto row_xoff = [&](int r) { return r < nPr ? 6 * r : 6 * nPr + 3 * (r - nPr); };
   // adjacency of the block graph in CSR form (rows: pose rows, then landmark rows), every edge with the offset of its block in H: three
@@ -437,7 +455,7 @@ inline int chol_symbolic(const SymIn& in, CholOpts opt, CholHost& out) {
   };
 
   // ---- per graph: ordering, elimination tree, pieces, final (piece-contiguous) elimination order ------------------
-  std::vector<int> col_row, col_graph, col_piece, col_comp, col_tail;   // by final column id; piece = execution group, comp = connected piece
+  std::vector<int> col_row, col_graph, col_piece, col_comp, col_tail;   // by final column id; piece = execution group, comp = connected piece, tail = class (0 leaf, 1 mid, 2 tail)
   std::vector<int> row_col(nrow, -1);
   std::vector<int> cr_ptr{0}, cr_idx;                         // per column: rows of the off-diagonal blocks (CSR)
   int npiece = 0, ncomp = 0;
@@ -495,15 +513,23 @@ inline int chol_symbolic(const SymIn& in, CholOpts opt, CholHost& out) {
     int T = nlev1;
     if (opt.tail_width > 0) while (T > 0 && cnt[T - 1] <= opt.tail_width) --T;
     if (n <= opt.small_cols) T = 0;   // small graph: its whole tree belongs to the tail
-    // pass 2: the tail columns are cut again with the tail cap (fewer external-update phases on the chain)
-    std::vector<int> fixed(n, -1);
-    bool any_tail = false;
-    for (int s = 0; s < n; ++s) { if (plev[pc[s]] < T) fixed[s] = pc[s]; else any_tail = true; }
+    // pass 2: the columns above the bottom are cut again, by class: mid (depths with <= mid_width pieces of this graph) with the mid cap,
+    // tail with the tail cap (fewer external-update phases on the chain).  Depths ascend towards the root, so do the classes.
+    int M = T;
+    if (opt.mid_width > 0) while (M > 0 && cnt[M - 1] <= opt.mid_width) --M;
+    std::vector<int> fixed(n, -1), ccls(n, 0);
+    bool any_upper = false;
+    for (int s = 0; s < n; ++s) {
+      const int d = plev[pc[s]];
+      ccls[s] = d < M ? 0 : (d < T ? 1 : 2);
+      if (ccls[s] == 0) fixed[s] = pc[s]; else any_upper = true;
+    }
     std::vector<int> pc2 = pc;
     int np2 = np1;
-    if (any_tail) np2 = cut_pieces(n, parent, colsz, colnb, fixed, np1, opt.cap_tail, opt.max_blocks, pc2);
-    std::vector<char> is_tail(np2, 0);
-    for (int s = 0; s < n; ++s) if (fixed[s] < 0) is_tail[pc2[s]] = 1;
+    const int caps[3] = {opt.cap_leaf, opt.cap_mid, opt.cap_tail};
+    if (any_upper) np2 = cut_pieces(n, parent, colsz, colnb, fixed, np1, opt.cap_tail, opt.max_blocks, pc2, &ccls, caps);
+    std::vector<char> is_tail(np2, 0), pcls(np2, 0);
+    for (int s = 0; s < n; ++s) { pcls[pc2[s]] = (char)ccls[s]; if (ccls[s] == 2) is_tail[pc2[s]] = 1; }
     // depth of every connected piece ("component") in the piece tree of this graph
     std::vector<int> proot(np2, -1);
     for (int s = 0; s < n; ++s) proot[pc2[s]] = std::max(proot[pc2[s]], s);
@@ -529,7 +555,7 @@ inline int chol_symbolic(const SymIn& in, CholOpts opt, CholHost& out) {
     {
       int gsz = 0, gnb = 0, glev = -1;
       for (int c : gorder) {
-        const bool fits = opt.group_cap > 0 && glev == cplev[c] && gsz + csize[c] <= opt.group_cap && gnb + cblk[c] <= opt.group_blocks;
+        const bool fits = opt.group_cap > 0 && glev == cplev[c] && pcls[c] == 0 && gsz + csize[c] <= opt.group_cap && gnb + cblk[c] <= opt.group_blocks;
         if (!fits) { ++ngroup; gsz = 0; gnb = 0; glev = cplev[c]; }
         gsz += csize[c]; gnb += cblk[c];
         grank[c] = ngroup - 1;
@@ -553,7 +579,7 @@ inline int chol_symbolic(const SymIn& in, CholOpts opt, CholHost& out) {
       const int r = loc2row(S.order[s]);
       row_col[r] = c0 + k;
       col_row.push_back(r); col_graph.push_back(g);
-      col_piece.push_back(npiece + grank[pc2[s]]); col_comp.push_back(ncomp + crank[pc2[s]]); col_tail.push_back(is_tail[pc2[s]]);
+      col_piece.push_back(npiece + grank[pc2[s]]); col_comp.push_back(ncomp + crank[pc2[s]]); col_tail.push_back(pcls[pc2[s]]);
       const int vs = S.order[s];
       for (int q = S.cs_start[vs]; q < S.cs_start[vs] + S.cs_len[vs]; ++q) cr_idx.push_back(loc2row(S.cs_idx[q]));
       cr_ptr.push_back((int)cr_idx.size());
@@ -652,7 +678,7 @@ inline int chol_symbolic(const SymIn& in, CholOpts opt, CholHost& out) {
   // ---- pieces: column / block ranges (contiguous by construction), parent piece, depth ----------------------------------------
   out.piece.assign(npiece, PieceMeta{});
   for (auto& pm0 : out.piece) pm0.pad4 = -1;
-  std::vector<char> piece_tail(npiece, 0);
+  std::vector<char> piece_tail(npiece, 0), piece_cls(npiece, 0);
   std::vector<int> comp_parent(ncomp, -1), comp_dest(ncomp, -1);   // parent component; the group that holds it
   for (int j = 0; j < ncol; ++j) {
     PieceMeta& pm = out.piece[col_piece[j]];
@@ -662,7 +688,7 @@ inline int chol_symbolic(const SymIn& in, CholOpts opt, CholHost& out) {
     pm.nc++;
     pm.nb = bp[j + 1] - pm.b0;
     pm.ysize = col_yoff[j] + col_dim[j] - pm.y0;
-    piece_tail[col_piece[j]] = (char)col_tail[j];
+    piece_tail[col_piece[j]] = (char)(col_tail[j] == 2); piece_cls[col_piece[j]] = (char)col_tail[j]; pm.pad5 = col_tail[j];
     if (bp[j + 1] - bp[j] > 1) {
       const int par = brow[bp[j] + 1];
       if (col_comp[par] != col_comp[j]) {
@@ -775,9 +801,9 @@ inline int chol_symbolic(const SymIn& in, CholOpts opt, CholHost& out) {
   };
   for (int p = 0; p < npiece; ++p) {
     PieceMeta& pm = out.piece[p];
-    const int nt = piece_tail[p] ? opt.nt_tail : opt.nt_leaf;
+    const int nt = piece_tail[p] ? opt.nt_tail : (piece_cls[p] == 1 ? opt.nt_mid : opt.nt_leaf);
     const int slots = nt / 4;
-    const int pcap = piece_tail[p] ? opt.pcap_tail : opt.pcap_leaf;   // partial tiles a phase may use (LDS: 336 B each)
+    const int pcap = piece_tail[p] ? opt.pcap_tail : (piece_cls[p] == 1 ? opt.pcap_mid : opt.pcap_leaf);   // partial tiles a phase may use (LDS: 336 B each)
     // boundary rows of every component of the group
     comps.clear();
     for (int j = pm.c0; j < pm.c0 + pm.nc; ++j) {
@@ -837,7 +863,7 @@ inline int chol_symbolic(const SymIn& in, CholOpts opt, CholHost& out) {
     // tail pieces: the same internal updates once more, grouped by SOURCE column (right-looking form: a finished column updates every
     // later block of the piece at once -- one tile update deep, where the target-major lists are as deep as the piece has columns)
     pm.pad3 = (int)out.rupd.size();
-    if (piece_tail[p] && right_ok) {
+    if (piece_cls[p] >= 1 && right_ok) {   // tail and mid pieces
       for (int k = pm.c0; k < pm.c0 + pm.nc; ++k) {
         const int k0 = bp[k] + 1, kin = bp[k] + col_nbi[k], k1 = bp[k + 1];
         out.rcol[k].u0 = (int)out.rupd.size() - pm.pad3;
@@ -1033,9 +1059,9 @@ inline int chol_symbolic(const SymIn& in, CholOpts opt, CholHost& out) {
   // ---- LDS needs (doubles) ---------------------------------------------------------------------------------------------------
   auto lds_f = [&](int p) {
     const PieceMeta& pm = out.piece[p];
-    const int ustage = (piece_tail[p] || !opt.ustage) ? 0 : 4 * pm.nuit + 4 * pm.numb + 2 * pm.nuu + pm.nus + 2;
+    const int ustage = (piece_cls[p] >= 1 || !opt.ustage) ? 0 : 4 * pm.nuit + 4 * pm.numb + 2 * pm.nuu + pm.nus + 2;
     return 4 * pm.nilv + ((pm.lsize + 1) & ~1) + 2 * ((pm.ysize + 1) & ~1) + 4 * pm.nb + 3 * pm.nc + 2 * pm.nit_i + 2 * pm.nu_i + 2 * pm.nimb + pm.nas + ustage +
-           kItemDoubles * piece_pmax[p] + 8;
+           kItemDoubles * piece_pmax[p] + 8 + (piece_cls[p] >= 1 ? pm.nc + 2 : 0);   // (right-looking form: one RCol per column where the items were)
   };
   auto lds_b = [&](int p) {
     const PieceMeta& pm = out.piece[p];
@@ -1046,11 +1072,13 @@ inline int chol_symbolic(const SymIn& in, CholOpts opt, CholHost& out) {
   //      workgroups a CU can hold changes (160 KB / 32, 24, 16 workgroups): the typical piece then runs at twice the residency the
   //      largest one of its depth would allow.
   {
-    std::vector<int> ptr{0}, launch_order;
+    std::vector<int> ptr{0}, launch_order, lnt, lcls;
     launch_order.reserve(out.plv_pieces.size());
     const int cut[3] = {640, 853, 1280};
     for (int l = 0; l < nplv; ++l) {
-      std::vector<int> ps(out.plv_pieces.begin() + out.plv_ptr[l], out.plv_pieces.begin() + out.plv_ptr[l + 1]);
+      // the leaf pieces of the depth (split by LDS need when there are many), then its mid pieces as a launch of their own
+      std::vector<int> ps, pmid;
+      for (int q = out.plv_ptr[l]; q < out.plv_ptr[l + 1]; ++q) (piece_cls[out.plv_pieces[q]] == 1 ? pmid : ps).push_back(out.plv_pieces[q]);
       const int n = (int)ps.size();
       if (n >= opt.split_min) {
         std::stable_sort(ps.begin(), ps.end(), [&](int a, int b) { return lds_b(a) < lds_b(b); });
@@ -1058,14 +1086,16 @@ inline int chol_symbolic(const SymIn& in, CholOpts opt, CholHost& out) {
         for (int k = 0; k < 3 && q0 < n; ++k) {
           int q1 = q0;
           while (q1 < n && lds_b(ps[q1]) <= cut[k]) ++q1;
-          if (q1 - q0 >= opt.split_min / 2 && n - q1 >= opt.split_min / 2) { for (int q = q0; q < q1; ++q) launch_order.push_back(ps[q]); ptr.push_back((int)launch_order.size()); q0 = q1; }
+          if (q1 - q0 >= opt.split_min / 2 && n - q1 >= opt.split_min / 2) { for (int q = q0; q < q1; ++q) launch_order.push_back(ps[q]); ptr.push_back((int)launch_order.size()); lnt.push_back(opt.nt_leaf); lcls.push_back(0); q0 = q1; }
         }
         for (int q = q0; q < n; ++q) launch_order.push_back(ps[q]);
       } else {
         for (int p : ps) launch_order.push_back(p);
       }
-      if ((int)launch_order.size() > ptr.back()) ptr.push_back((int)launch_order.size());
+      if ((int)launch_order.size() > ptr.back()) { ptr.push_back((int)launch_order.size()); lnt.push_back(opt.nt_leaf); lcls.push_back(0); }
+      if (!pmid.empty()) { for (int p : pmid) launch_order.push_back(p); ptr.push_back((int)launch_order.size()); lnt.push_back(opt.nt_mid); lcls.push_back(1); }
     }
+    out.plv_nt = lnt; out.plv_cls = lcls;
     out.plv_pieces = launch_order;
     out.plv_ptr = ptr;
   }
@@ -1085,7 +1115,7 @@ inline int chol_symbolic(const SymIn& in, CholOpts opt, CholHost& out) {
     fprintf(stderr, "[chol-dump] B %d cols %d blocks %d lnz %lld unz %lld updates %zu (internal items %zu, U items %zu) column-levels %d pieces %d piece-levels %d tail pieces %zu\n",
             B, ncol, nblk, (long long)lnz, (long long)out.unz, out.upd.size(), out.item.size(), out.uitem.size(), nlev, npiece, nplv, out.tail_pieces.size());
     for (int l = 0; l < nlaunch; ++l)
-      fprintf(stderr, "[chol-dump]   launch %d: %d pieces, LDS factor %d B backward %d B\n", l, out.plv_ptr[l + 1] - out.plv_ptr[l],
+      fprintf(stderr, "[chol-dump]   launch %d: %d pieces x %d threads, LDS factor %d B backward %d B\n", l, out.plv_ptr[l + 1] - out.plv_ptr[l], out.plv_nt[l],
               out.plv_lds_f[l] * 8, out.plv_lds_b[l] * 8);
     int tmax = 0, tlv = 0;
     for (int g = 0; g < B; ++g) tmax = std::max(tmax, out.tail_ptr[g + 1] - out.tail_ptr[g]);

@@ -78,7 +78,7 @@ struct SpecLanes {
 struct CholPlan {
   CholView C{};
   SpecLanes spec{};
-  std::vector<int> lvl_ptr, plv_ptr, plv_lds_f, plv_lds_b;
+  std::vector<int> lvl_ptr, plv_ptr, plv_lds_f, plv_lds_b, plv_nt, plv_cls;
   int tail_lds_f = 0, tail_lds_b = 0, tail_total = 0, nt_tail = 512, nt_leaf = 64, ustage = 0;
   std::vector<void*> allocs;
   DevArena* arena = nullptr;    // the owning batch's arena (single-graph handles), else hipMalloc
@@ -808,12 +808,12 @@ __device__ __forceinline__ void chol_piece(const BatchView& V, const CholView& C
 }
 #undef SSLAM_STAMP
 
-template <int NT, bool USTAGE>
+template <int NT, bool USTAGE, bool RIGHT = false>   // RIGHT: mid pieces (several columns of a chain per piece), internal updates by source column
 __global__ __launch_bounds__(NT, 4) void k_chol_pieces(BatchView V, CholView C, int begin, const int* __restrict__ idx) {   // <= 128 VGPRs: four waves per SIMD
   extern __shared__ double sm[];
   const PieceMeta pm = C.lpiece[idx ? idx[blockIdx.x] : begin + blockIdx.x];   // idx: the pieces of the graphs that are still active
   if (!V.lm[pm.graph].in_trial) return;
-  chol_piece<NT, USTAGE, false>(V, C, pm, sm, (C.dbg && blockIdx.x == 0) ? C.dbg + 16 : nullptr);
+  chol_piece<NT, USTAGE, RIGHT>(V, C, pm, sm, (C.dbg && blockIdx.x == 0) ? C.dbg + 16 : nullptr);
 }
 
 // Top of the elimination tree: once a graph is down to a few pieces per depth a launch per depth only buys launch
@@ -1705,12 +1705,13 @@ int chol_plan_build(Batch& b) {
   opt.from_env();
   if (opt.nt_tail != 1024) opt.nt_tail = 512;
   if (opt.nt_leaf != 128 && opt.nt_leaf != 256 && opt.nt_leaf != 512 && opt.nt_leaf != 1024) opt.nt_leaf = 64;
+  if (opt.nt_mid != 128 && opt.nt_mid != 512) opt.nt_mid = 256;
   // small batches (latency-bound: the orchestrator's graph, a single large graph): the dependency-driven single launch (k_chol_flow) runs
   // every piece with the tail's workgroup size
   const int flow_mode = [] { const char* e = getenv("SSLAM_CHOL_FLOW"); return e ? atoi(e) : 1; }();   // 0 off, 1 auto, 2 also on wide trees; read per plan (tests toggle it)
   const bool flow_on = flow_mode != 0;
   const bool want_flow = flow_on && b.V.B < 8 && opt.nt_tail == 512 && opt.group_cap == 0 && !getenv("SSLAM_CHOL_NT_LEAF");
-  if (want_flow) opt.nt_leaf = opt.nt_tail;
+  if (want_flow) { opt.nt_leaf = opt.nt_tail; opt.mid_width = 0; }
   CholHost H;
   if (chol_symbolic(in, opt, H)) return set_error(SSLAM_ERR_NUMERIC, "Cholesky plan: %s", H.error.c_str());
   CholPlan* P = new CholPlan();
@@ -1719,7 +1720,7 @@ int chol_plan_build(Batch& b) {
   CholView& C = P->C;
   C.ncol = H.ncol; C.nlevels = H.nlevels; C.dim = H.dim; C.npiece = H.npiece;
   { const char* e = getenv("SSLAM_CHOL_UTILES"); C.utile_off = (e && atoi(e) == 0) ? 1 : 0; }
-  P->lvl_ptr = H.lvl_ptr; P->plv_ptr = H.plv_ptr; P->plv_lds_f = H.plv_lds_f; P->plv_lds_b = H.plv_lds_b;
+  P->lvl_ptr = H.lvl_ptr; P->plv_ptr = H.plv_ptr; P->plv_lds_f = H.plv_lds_f; P->plv_lds_b = H.plv_lds_b; P->plv_nt = H.plv_nt; P->plv_cls = H.plv_cls;
   P->tail_lds_f = H.tail_lds_f; P->tail_lds_b = H.tail_lds_b; P->tail_total = (int)H.tail_pieces.size(); P->nt_tail = H.nt_tail; P->nt_leaf = H.nt_leaf; P->ustage = H.ustage;
   P->lnz = H.lnz;
   {   // elimination-tree parents (first block below the diagonal) and the vertex -> column map, for the path marginals
@@ -1832,6 +1833,7 @@ int chol_plan_build(Batch& b) {
                            (const void*)k_chol_pieces<512, true>, (const void*)k_chol_pieces<1024, true>,
                            (const void*)k_chol_pieces<64, false>, (const void*)k_chol_pieces<128, false>, (const void*)k_chol_pieces<256, false>,
                            (const void*)k_chol_pieces<512, false>, (const void*)k_chol_pieces<1024, false>,
+                           (const void*)k_chol_pieces<128, false, true>, (const void*)k_chol_pieces<256, false, true>, (const void*)k_chol_pieces<512, false, true>,
                            (const void*)k_chol_tail<512>, (const void*)k_chol_tail<1024>,
                            (const void*)k_chol_back_pieces<64>, (const void*)k_chol_back_pieces<128>, (const void*)k_chol_back_pieces<256>,
                            (const void*)k_chol_back_pieces<512>, (const void*)k_chol_back_pieces<1024>, (const void*)k_chol_back_tail<512>,
@@ -2084,7 +2086,16 @@ int chol_factor_and_forward(Batch& b, bool flat) {
 #define SSLAM_LAUNCH_PIECES(NTV)                                                                                                   \
   if (P.ustage) hipLaunchKernelGGL((k_chol_pieces<NTV, true>), dim3(n), dim3(NTV), lds, b.stream, b.V, C, P.plv_ptr[l], idx);       \
   else hipLaunchKernelGGL((k_chol_pieces<NTV, false>), dim3(n), dim3(NTV), lds, b.stream, b.V, C, P.plv_ptr[l], idx);
-    switch (P.nt_leaf) {
+#define SSLAM_LAUNCH_MID(NTV)                                                                                                      \
+  if (C.rupd) hipLaunchKernelGGL((k_chol_pieces<NTV, false, true>), dim3(n), dim3(NTV), lds, b.stream, b.V, C, P.plv_ptr[l], idx);  \
+  else hipLaunchKernelGGL((k_chol_pieces<NTV, false, false>), dim3(n), dim3(NTV), lds, b.stream, b.V, C, P.plv_ptr[l], idx);
+    if (P.plv_cls[l] == 1) {   // mid pieces: wider workgroups, right-looking internal updates, update-matrix records from HBM
+      switch (P.plv_nt[l]) {
+        case 128: SSLAM_LAUNCH_MID(128) break;
+        case 512: SSLAM_LAUNCH_MID(512) break;
+        default: SSLAM_LAUNCH_MID(256) break;
+      }
+    } else switch (P.nt_leaf) {
       case 128: SSLAM_LAUNCH_PIECES(128) break;
       case 512: SSLAM_LAUNCH_PIECES(512) break;
       case 1024: SSLAM_LAUNCH_PIECES(1024) break;
@@ -2092,6 +2103,7 @@ int chol_factor_and_forward(Batch& b, bool flat) {
       default: SSLAM_LAUNCH_PIECES(64) break;
     }
 #undef SSLAM_LAUNCH_PIECES
+#undef SSLAM_LAUNCH_MID
   }
   if (P.tail_total > 0) {
     const int n = P.compact ? P.c_ptr[nplv + 1] - P.c_ptr[nplv] : b.V.B;
@@ -2125,7 +2137,7 @@ int chol_backward(Batch& b) {
     const size_t lds = (size_t)P.plv_lds_b[l] * sizeof(double);
 #define SSLAM_LAUNCH_BACK(NTV) hipLaunchKernelGGL(k_chol_back_pieces<NTV>, dim3(n), dim3(NTV), lds, b.stream, C, P.plv_ptr[l], (const double*)C.y, b.V.x, (const LmState*)b.V.lm, idx);
     static const int nt_back_env = [] { const char* e = getenv("SSLAM_CHOL_NT_BACK"); return e ? atoi(e) : 0; }();
-    switch (nt_back_env > 0 ? nt_back_env : P.nt_leaf) {
+    switch (nt_back_env > 0 ? nt_back_env : P.plv_nt[l]) {
       case 128: SSLAM_LAUNCH_BACK(128) break;
       case 512: SSLAM_LAUNCH_BACK(512) break;
       case 1024: SSLAM_LAUNCH_BACK(1024) break;

@@ -3206,6 +3206,7 @@ void* sslam_debug_plan_create(sslam_graph* const* graphs, int n) {
   opt.from_env();
   if (opt.nt_tail != 1024) opt.nt_tail = 512;
   if (opt.nt_leaf != 128 && opt.nt_leaf != 256 && opt.nt_leaf != 512 && opt.nt_leaf != 1024) opt.nt_leaf = 64;
+  if (opt.nt_mid != 128 && opt.nt_mid != 512) opt.nt_mid = 256;
   sslam_debug_plan* P = new sslam_debug_plan();
   P->h_total = b.V.h_total;
   for (auto& q : b.ppoff) { P->ppoff.push_back(q.first); P->ppoff.push_back(q.second); }
@@ -3230,11 +3231,11 @@ int64_t sslam_debug_plan_array(void* p, const char* name, void* out, int64_t cap
   ARR("lvl_ptr", H.lvl_ptr) ARR("lvl_cols", H.lvl_cols) ARR("plv_ptr", H.plv_ptr) ARR("plv_pieces", H.plv_pieces)
   ARR("ppoff", DP.ppoff) ARR("plblk", DP.plblk) ARR("tail_ptr", H.tail_ptr)
   ARR("asrc", H.asrc) ARR("usrc", H.usrc) ARR("fwd", H.fwd) ARR("uitem", H.uitem) ARR("umb", H.umb) ARR("tail_pieces", H.tail_pieces) ARR("plv_lds_f", H.plv_lds_f) ARR("plv_lds_b", H.plv_lds_b)
-  ARR("rcol", H.rcol) ARR("rupd", H.rupd)
+  ARR("rcol", H.rcol) ARR("rupd", H.rupd) ARR("plv_nt", H.plv_nt) ARR("plv_cls", H.plv_cls)
 #undef ARR
   if (k == "scalars") { src = scal; bytes = sizeof scal; }
   static const char* known[] = {"col", "blk", "upd", "item", "mb", "ilv", "piece", "lvl_ptr", "lvl_cols", "plv_ptr", "plv_pieces", "ppoff", "plblk",
-                                "tail_ptr", "tail_pieces", "plv_lds_f", "plv_lds_b", "scalars", "asrc", "usrc", "fwd", "uitem", "umb", "rcol", "rupd"};
+                                "tail_ptr", "tail_pieces", "plv_lds_f", "plv_lds_b", "scalars", "asrc", "usrc", "fwd", "uitem", "umb", "rcol", "rupd", "plv_nt", "plv_cls"};
   bool ok = false;
   for (const char* q : known) ok |= (k == q);
   if (!ok) return set_error(SSLAM_ERR_INVALID, "unknown plan array '%s'", name);

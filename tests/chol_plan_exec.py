@@ -38,7 +38,7 @@ class Plan:
         self.item, self.mb, self.ilv, self.piece = g("item", ITEM), g("mb", MB), g("ilv", ILV), g("piece", PIECE)
         self.asrc, self.usrc, self.fwd, self.uitem, self.umb = g("asrc", ASRC), g("usrc", ASRC), g("fwd", FWD), g("uitem", UITEM), g("umb", UMB)
         self.rcol, self.rupd = g("rcol", RCOL), g("rupd", UPD)     # right-looking update lists of the tail pieces
-        for n in ("lvl_ptr", "lvl_cols", "plv_ptr", "plv_pieces", "tail_ptr", "tail_pieces", "plv_lds_f", "plv_lds_b", "ppoff", "plblk", "scalars"):
+        for n in ("lvl_ptr", "lvl_cols", "plv_ptr", "plv_pieces", "tail_ptr", "tail_pieces", "plv_lds_f", "plv_lds_b", "plv_nt", "plv_cls", "ppoff", "plblk", "scalars"):
             setattr(self, n, g(n, np.int32))
         s = self.scalars
         (self.ncol, self.nlevels, self.dim, self.B, self.npiece, self.lnz, self.tail_lds_f, self.tail_lds_b, self.nt_leaf, self.nt_tail,
@@ -87,9 +87,8 @@ class Plan:
         Uval = np.full(self.unz + 64, np.nan)      # every update-matrix entry must be written before it is read
         y = np.zeros(self.dim + 8)
         ok = True
-        tail = set(int(p) for p in self.tail_pieces)
-        for p in self.piece_order():
-            ok &= self._factor_piece(self.piece[p], Hdev, bvec, lam, Lval, Uval, y, right=right and p in tail)
+        for p in self.piece_order():   # PieceMeta.pad5: class of the piece (0 leaf, 1 mid, 2 tail); mid and tail pieces carry the right-looking lists
+            ok &= self._factor_piece(self.piece[p], Hdev, bvec, lam, Lval, Uval, y, right=right and int(self.piece[p]["pad5"]) >= 1)
         self.Uval = Uval
         return Lval, y, ok
 

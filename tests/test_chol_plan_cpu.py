@@ -64,8 +64,8 @@ def _check(plan, H, b, lam):
     assert np.abs(x - xref).max() <= 1e-7 * np.abs(xref).max()
     y2 = plan.forward_rows(Lval, b)          # the row lists of the multi right-hand-side forward substitution
     assert np.abs(y2 - yref).max() <= 1e-9 * max(np.abs(yref).max(), 1e-30)
-    if len(plan.tail_pieces):                # the tail pieces' right-looking update lists give the same factor (other summation order)
-        assert len(plan.rupd) == int(sum(plan.piece[int(p)]["nu_i"] for p in plan.tail_pieces))
+    if np.any(plan.piece["pad5"] >= 1):      # the tail and mid pieces' right-looking update lists give the same factor (other summation order)
+        assert len(plan.rupd) == int(plan.piece["nu_i"][plan.piece["pad5"] >= 1].sum())
         Lr, yr, okr = plan.factor(Hdev, b, lam, right=True)
         assert okr
         assert np.abs(Lr - Lval).max() <= 1e-10 * max(np.abs(Lval).max(), 1e-30)
@@ -169,6 +169,32 @@ def test_plan_with_tiny_pieces_exercises_every_phase(hip_lib):
     assert int(plan4.plv_lds_b[0]) < int(plan5.plv_lds_b[0])   # the small pieces of the first depth no longer reserve what its largest needs
     _structure_invariants(plan4)
     _check(plan4, H4, b4, 1e-3)
+
+
+def test_mid_class_pieces_between_the_bottom_and_the_tail(hip_lib):
+    """Round 5: the depths between the bushy bottom and the tail are cut with a larger cap and launched with wider workgroups (one launch
+    per depth next to the leaf pieces of that depth); their internal updates come as right-looking lists like the tail's.  Fewer, larger
+    pieces there, less update-matrix storage, same factor."""
+    g = make_graph(600, 120, seed=3)
+    base = {"SSLAM_CHOL_SMALL_COLS": 0, "SSLAM_CHOL_TAIL_WIDTH": 2, "SSLAM_CHOL_CAP_LEAF": 500, "SSLAM_CHOL_MID_WIDTH": 0}
+    p0, H0, b0 = _plan_and_system(hip_lib, g, False, base)
+    assert not np.any(p0.piece["pad5"] == 1) and not np.any(p0.plv_cls == 1)
+    p1, H1, b1 = _plan_and_system(hip_lib, g, False, dict(base, SSLAM_CHOL_MID_WIDTH=12, SSLAM_CHOL_CAP_MID=1600))
+    mid = p1.piece["pad5"] == 1
+    assert mid.sum() >= 3 and np.any(p1.plv_cls == 1) and np.any(p1.plv_cls == 0) and len(p1.tail_pieces) >= 1
+    assert p1.npiece < p0.npiece and p1.unz < p0.unz and p1.lnz == p0.lnz
+    # a launch holds pieces of one class, and its workgroup size is that class's
+    for l in range(len(p1.plv_ptr) - 1):
+        cls = p1.piece["pad5"][p1.plv_pieces[p1.plv_ptr[l]:p1.plv_ptr[l + 1]]]
+        assert np.all(cls == p1.plv_cls[l]) and p1.plv_nt[l] == (256 if p1.plv_cls[l] else 64)
+    assert p1.piece["nc"][mid].mean() > p0.piece["nc"][p0.piece["pad5"] == 0].mean()
+    _structure_invariants(p1)
+    _check(p1, H1, b1, 1e-3)
+    # no tail at all: the mid class runs up to the root
+    p2, H2, b2 = _plan_and_system(hip_lib, g, False, dict(base, SSLAM_CHOL_MID_WIDTH=12, SSLAM_CHOL_CAP_MID=1600, SSLAM_CHOL_TAIL_WIDTH=0))
+    assert len(p2.tail_pieces) == 0 and np.any(p2.piece["pad5"] == 1)
+    _structure_invariants(p2)
+    _check(p2, H2, b2, 1e-3)
 
 
 def test_small_graph_plan_is_all_tail_and_both_orderings_factor(hip_lib):

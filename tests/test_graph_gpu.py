@@ -166,6 +166,9 @@ def test_cholesky_solve_matches_oracle_cholesky(gpu_lib, lam):
     {"SSLAM_CHOL_CAP_LEAF": "400", "SSLAM_CHOL_GROUP_CAP": "1500", "SSLAM_CHOL_NT_LEAF": "512", "SSLAM_CHOL_USTAGE": "0"},   # groups of subtrees per workgroup
     {"SSLAM_CHOL_CAP_LEAF": "400", "SSLAM_CHOL_GROUP_CAP": "1200", "SSLAM_CHOL_NT_LEAF": "64", "SSLAM_CHOL_MIN_CHUNK": "1"},
     {"SSLAM_CHOL_SPLIT_MIN": "4", "SSLAM_CHOL_TAIL_WIDTH": "2"},      # depths launched in parts, by LDS need
+    # round 5, mid class: the depths between the bottom and the tail as larger pieces on 256-thread workgroups (per-depth launches: no k_chol_flow)
+    {"SSLAM_CHOL_FLOW": "0", "SSLAM_CHOL_CAP_LEAF": "400", "SSLAM_CHOL_TAIL_WIDTH": "2", "SSLAM_CHOL_MID_WIDTH": "12", "SSLAM_CHOL_CAP_MID": "1200"},
+    {"SSLAM_CHOL_FLOW": "0", "SSLAM_CHOL_CAP_LEAF": "400", "SSLAM_CHOL_TAIL_WIDTH": "0", "SSLAM_CHOL_MID_WIDTH": "8", "SSLAM_CHOL_CAP_MID": "1500", "SSLAM_CHOL_NT_MID": "512"},
 ])
 def test_cholesky_pieces_of_every_shape(gpu_lib, monkeypatch, env):
     """The piece plan is cut by LDS capacity; caps far below the defaults force what the 5000-pose graph has (pieces with
