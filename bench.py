@@ -90,27 +90,28 @@ def timed_optimize(batch, steps, warmup, sync_all):
 
 
 def bench_tick_cpu(events):
-    """the CPU oracle (oracle/np_slam.py: NumPy association + the C oracle's LM / marginals, one core) replaying the same run"""
-    from oracle import np_slam as S
-    o = S.SemanticGraphSlam(const_stddev_x=0.00667, const_stddev_q=0.00001)
-    ticks, t_tick, t_opt = 0, 0.0, 0.0
+    """the CPU oracle replaying the same run as ONE C driver (oracle/oracle_slam.c: keyframe gate, association, graph growth, the C
+    oracle's LM and marginals -- no Python or NumPy inside a tick; pinned tick by tick against oracle/np_slam.py in
+    tests/test_oracle_slam.py), one core.  Timers are the driver's own (clock_gettime inside oslam_run)."""
+    from oracle.oracle import SlamTickC
+    o = SlamTickC(const_stddev_x=0.00667, const_stddev_q=0.00001)
+    ticks, t_tick, t_opt, t_marg, t_assoc, iters, trials = 0, 0.0, 0.0, 0.0, 0.0, 0, 0
     for ev in events:
         if ev.objects is not None:
             o.set_segmented_objects(ev.objects)
         o.vio(ev.stamp[0], ev.stamp[1], ev.odom)
-        if ev.run_after:
-            t0 = time.perf_counter()
-            ran = o.run()
-            dt = time.perf_counter() - t0
-            if ran:
-                ticks += 1; t_tick += dt
-                st = o.last_stats
-                if st.get("optimized"):
-                    t_opt += float(st["opt"].seconds)
-    return {"ticks": ticks, "ms_per_tick": round(1e3 * t_tick / max(ticks, 1), 3), "ms_per_tick_optimize": round(1e3 * t_opt / max(ticks, 1), 3),
-            "cores": 1, "kind": "port", "keyframes": len(o.keyframes), "landmarks": len(o.assoc.landmarks),
-            "sample": "the same replay through oracle/np_slam.py; ms_per_tick_optimize is the C oracle's own LM timer (oracle_graph.c), the "
-                      "rest is NumPy association + marginals + Python overhead"}
+        if ev.run_after and o.run():
+            st = o.last_stats
+            ticks += 1; t_tick += st.seconds_total; t_opt += st.seconds_optimize; t_marg += st.seconds_marginals; t_assoc += st.seconds_association
+            iters += st.iterations; trials += st.trials
+    nv, ne, nkf, nlm = o.counts()
+    k = max(ticks, 1)
+    return {"ticks": ticks, "ms_per_tick": round(1e3 * t_tick / k, 3), "ms_per_tick_optimize": round(1e3 * t_opt / k, 3),
+            "ms_per_tick_marginals": round(1e3 * t_marg / k, 3), "ms_per_tick_association": round(1e3 * t_assoc / k, 3),
+            "lm_iterations_per_tick": round(iters / k, 1), "lm_trials_per_tick": round(trials / k, 1),
+            "cores": 1, "kind": "port", "keyframes": nkf, "landmarks": nlm,
+            "sample": "the same replay through oracle/oracle_slam.c (C tick driver: association + graph growth + oracle_graph.c LM + "
+                      "marginals); no Python inside the timed tick"}
 
 
 def bench_tick(device, n_samples=600, cpu_baseline=True, n_landmarks=40):

@@ -109,15 +109,17 @@ int sslam_graph_hessian_index(sslam_graph* g, int id);
  * correct, leaner in traffic, slower than 1 on today's kernels); "pcg_tol" relative residual; "pcg_max_iters";
  * "robust_kernel_dcs" = phi > 0: g2o::RobustKernelDCS(delta = phi) on every landmark edge (EdgeSE3PointXYZ / EdgeSE3Plane), as
  * graph_slam.cpp:155,161 intends (opt-in, phi = 1 is g2o's default delta); 0 = no kernel (default);
- * "fused_small_graph" 1 (default) / 0: a graph of at most ~1200 vertices runs every damping trial of an LM iteration in one launch
- * (k_lm_trial_small; the reference's per-tick call pattern, semantic_graph_slam.cpp:58-102) -- results are bitwise those of the
- * stand-alone kernels;
- * "speculative_trials" 0 (default) / 1 / 2: a single small graph runs the damping trials of an LM iteration side by side -- g2o's retry
+ * "fused_small_graph" 1 (default) / 0: a batch of fewer than eight graphs whose elimination tree is narrower than the chip runs the
+ * factorisation, both triangular solves and the begin / end halves of a damping trial in ONE dependency-driven launch (k_chol_flow; the
+ * reference's per-tick call pattern, semantic_graph_slam.cpp:58-102); 0: the stand-alone kernels -- same results, bitwise.  (The
+ * one-workgroup-per-graph kernel k_lm_trial_small of round 4 is only reachable with SSLAM_CHOL_SMALL_COLS in the environment: measured
+ * slower)
+ * "speculative_trials" 0 / 1 (default since round 5) / 2: a single small graph runs the damping trials of an LM iteration side by side -- g2o's retry
  * lambdas are known when the iteration starts -- in the lanes of ONE launch (k_chol_spec_round) that also replays the accept / reject
  * sequence over their results: bitwise the sequential result, trial counts included.  1: the lanes join once a trial of the iteration
  * has been rejected, and only while every lane gets a workgroup per piece of the tree (about 200 keyframes); 2: every round with all ten
- * lanes.  Mode 1 measured 5.5 vs 6.0 ms per tick at 110 keyframes and equal at 436; it arrived at the end of round
- * 4 and stays opt-in until it has been through a whole round of tests.  SSLAM_LM_SPEC=0/1/2 in the environment overrides the option for
+ * lanes.  Mode 1 measured 5.5 vs 6.0 ms per tick at 110 keyframes and 7.4 vs 7.6 at 436 (re-measured
+ * in round 5) and is never slower with the lanes-fit rule: the default.  SSLAM_LM_SPEC=0/1/2 in the environment overrides the option for
  * every graph of the process. */
 int sslam_graph_set_option(sslam_graph* g, const char* key, double value);
 

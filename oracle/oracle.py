@@ -18,7 +18,7 @@ ET_SE3, ET_SE3_POINT, ET_SE3_PLANE, ET_POINT_POINT = 0, 1, 2, 3
 
 def build(force: bool = False) -> str:
     so = os.path.join(_HERE, "liboracle.so")
-    srcs = [os.path.join(_HERE, f) for f in ("oracle_graph.c", "oracle_seg.c") if os.path.exists(os.path.join(_HERE, f))]
+    srcs = [os.path.join(_HERE, f) for f in ("oracle_graph.c", "oracle_seg.c", "oracle_slam.c") if os.path.exists(os.path.join(_HERE, f))]
     stale = force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs)
     if stale:
         subprocess.check_call(["make", "-C", _HERE, "-s", "-B", "liboracle.so"])
@@ -162,15 +162,106 @@ class GraphProblem:
         lib().og_optimize(C.byref(p), C.c_int(max_iters), C.byref(st))
         return st
 
-    def marginals(self, ids):
+    def marginals(self, ids, by_solves: bool = False):
+        """diagonal blocks of H^-1: g2o's recursion over the factor (og_marginals), or full triangular solves (by_solves: the cross-check)"""
         ids = np.ascontiguousarray(ids, np.int32)
         dims = np.where(self.vtype[ids] == VT_SE3, 6, 3)
         out = np.zeros(int((dims * dims).sum()))
         p = self.c_struct()
-        rc = lib().og_marginals(C.byref(p), ids.ctypes.data_as(C.c_void_p), C.c_int(len(ids)), out.ctypes.data_as(C.c_void_p))
+        f = lib().og_marginals_by_solves if by_solves else lib().og_marginals
+        rc = f(C.byref(p), ids.ctypes.data_as(C.c_void_p), C.c_int(len(ids)), out.ctypes.data_as(C.c_void_p))
         if rc != 0:
             raise RuntimeError("oracle marginals: H not positive definite")
         return out
+
+
+# ---- the orchestrator tick as one C driver (oracle_slam.c): the like-for-like CPU baseline of bench.py's tick replay ------------------
+class OslamObject(C.Structure):
+    _fields_ = [("pose", C.c_float * 3), ("normal", C.c_float * 4), ("class_id", C.c_int), ("plane_type", C.c_int)]
+
+
+class OslamParams(C.Structure):
+    _fields_ = [("keyframe_delta_trans", C.c_double), ("keyframe_delta_angle", C.c_double), ("keyframe_delta_time", C.c_double),
+                ("max_keyframes_per_update", C.c_int), ("update_keyframes_using_detections", C.c_int),
+                ("camera_angle_rad", C.c_double), ("const_stddev_x", C.c_double), ("const_stddev_q", C.c_double),
+                ("max_iterations", C.c_int), ("maha_dist_thres", C.c_double), ("eq_dist_thres", C.c_double), ("land_noise_low", C.c_float),
+                ("use_maha_dist", C.c_int), ("use_eq_dist", C.c_int), ("use_rtab_map_odom", C.c_int), ("keep_distance_min", C.c_int), ("quirks", C.c_int)]
+
+
+class OslamTickStats(C.Structure):
+    _fields_ = [("keyframes_added", C.c_int), ("landmarks_added", C.c_int), ("landmarks_matched", C.c_int), ("landmark_edges_added", C.c_int),
+                ("optimized", C.c_int), ("marginals_ok", C.c_int), ("iterations", C.c_int), ("trials", C.c_int),
+                ("chi2_after", C.c_double), ("seconds_optimize", C.c_double), ("seconds_marginals", C.c_double),
+                ("seconds_association", C.c_double), ("seconds_total", C.c_double)]
+
+
+class SlamTickC:
+    """oracle_slam.c: keyframe gate, association, graph growth, og_optimize, og_marginals -- nothing but C inside a tick.
+    Same constructor arguments as np_slam.SemanticGraphSlam (pre-segmented objects only)."""
+
+    def __init__(self, keyframe_delta_trans=0.5, keyframe_delta_angle=0.5, keyframe_delta_time=1.0, max_keyframes_per_update=10,
+                 update_keyframes_using_detections=False, camera_angle_deg=0.0, const_stddev_x=0.0, const_stddev_q=0.0, max_iterations=1024,
+                 maha_dist_thres=0.5, eq_dist_thres=1.21, land_noise_low=0.5, use_maha_dist=True, use_eq_dist=False,
+                 use_rtab_map_odom=False, keep_distance_min=False, quirks=True):
+        import math
+        L = lib()
+        L.oslam_create.restype = C.c_void_p
+        p = OslamParams(keyframe_delta_trans, keyframe_delta_angle, keyframe_delta_time, max_keyframes_per_update,
+                        int(update_keyframes_using_detections), camera_angle_deg * (math.pi / 180), const_stddev_x, const_stddev_q, max_iterations,
+                        maha_dist_thres, eq_dist_thres, land_noise_low, int(use_maha_dist), int(use_eq_dist), int(use_rtab_map_odom),
+                        int(keep_distance_min), int(quirks))
+        self._L = L
+        self._h = C.c_void_p(L.oslam_create(C.byref(p)))
+        self.last_stats = None
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            self._L.oslam_destroy(self._h)
+            self._h = None
+
+    def set_segmented_objects(self, objs):
+        arr = (OslamObject * max(len(objs), 1))()
+        for a, o in zip(arr, objs):
+            for k in range(3):
+                a.pose[k] = float(o["pose"][k])
+            for k in range(4):
+                a.normal[k] = float(o["normal"][k])
+            a.class_id, a.plane_type = int(o["class_id"]), int(o["plane_type"])
+        self._L.oslam_set_objects(self._h, arr, len(objs))
+
+    def vio(self, sec, nsec, odom_tq):
+        tq = np.ascontiguousarray(odom_tq, np.float64)
+        return bool(self._L.oslam_vio(self._h, int(sec), int(nsec), tq.ctypes.data_as(C.c_void_p)))
+
+    def run(self):
+        st = OslamTickStats()
+        ran = bool(self._L.oslam_run(self._h, C.byref(st)))
+        if ran:
+            self.last_stats = st
+        return ran
+
+    def counts(self):
+        v = [C.c_int(0) for _ in range(4)]
+        self._L.oslam_counts(self._h, *[C.byref(x) for x in v])
+        return tuple(x.value for x in v)    # vertices, edges, keyframes, landmarks
+
+    def graph(self):
+        nv, ne, _, _ = self.counts()
+        vtype = np.zeros(nv, np.int32); est = np.zeros((nv, 7)); etype = np.zeros(ne, np.int32); evi = np.zeros(ne, np.int32); evj = np.zeros(ne, np.int32)
+        meas = np.zeros((ne, 7)); info = np.zeros((ne, 36))
+        self._L.oslam_graph(self._h, *[a.ctypes.data_as(C.c_void_p) for a in (vtype, est, etype, evi, evj, meas, info)])
+        return dict(vtype=vtype, est=est, etype=etype, evi=evi, evj=evj, meas=meas, info=info)
+
+    def landmarks(self):
+        n = self.counts()[3]
+        vertex = np.zeros(n, np.int32); cls = np.zeros(n, np.int32); pose = np.zeros((n, 3), np.float32); cov = np.zeros((n, 3, 3), np.float32)
+        self._L.oslam_landmarks(self._h, *[a.ctypes.data_as(C.c_void_p) for a in (vertex, cls, pose, cov)])
+        return dict(vertex=vertex, class_id=cls, pose=pose, covariance=cov)
+
+    def robot_pose(self):
+        T = np.zeros((4, 4))
+        self._L.oslam_robot_pose(self._h, T.ctypes.data_as(C.c_void_p))
+        return T
 
 
 # ---- frontend oracle entry (oracle_seg.c) ------------------------------------------------------

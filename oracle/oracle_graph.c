@@ -736,9 +736,84 @@ int og_optimize(og_problem *P, int max_iters, og_stats *st) {
   return it;
 }
 
-/* computeLandmarkMarginals (graph_slam.cpp:221-234): diagonal blocks of H^-1 (undamped H of the
- * current linearisation) for the given vertex ids; out = row-major d x d per vertex, packed. */
+/* computeLandmarkMarginals (graph_slam.cpp:221-234): diagonal blocks of H^-1 (undamped H of the current linearisation) for the given
+ * vertex ids; out = row-major d x d per vertex, packed.
+ *
+ * [UPSTREAM] g2o::SparseOptimizer::computeMarginals -> LinearSolverCSparse::solveBlocks -> MarginalCovarianceCholesky::computeCovariance:
+ * the requested entries of Sigma = (L L^T)^-1 by the recursion over the factor
+ *     Sigma(r,c) = [r == c] / L(r,r)^2  -  (1 / L(r,r)) * sum_{j > r, L(j,r) != 0} L(j,r) Sigma(min(j,c), max(j,c))        (r <= c)
+ * with every computed entry kept in a map (g2o: std::unordered_map keyed by r * n + c) -- only entries along the elimination-tree paths
+ * of the requested rows are ever touched.  Rounds 1-4 took full triangular solves with unit right-hand sides here (same numbers to
+ * rounding, O(requests x nnz(L)) work): that made the CPU side of the tick comparison slower than the reference's own library would
+ * be, so the faithful form replaced it; the solve form stays as og_marginals_by_solves and the two are compared in tests/test_oracle_graph.py. */
+typedef struct { long long *key; double *val; size_t cap, used; } og_memo;
+static void memo_init(og_memo *M, size_t cap) {
+  M->cap = 1; while (M->cap < cap) M->cap <<= 1;
+  M->key = (long long *)malloc(M->cap * sizeof(long long)); M->val = (double *)malloc(M->cap * sizeof(double));
+  for (size_t i = 0; i < M->cap; ++i) M->key[i] = -1;
+  M->used = 0;
+}
+static size_t memo_slot(const og_memo *M, long long k) {
+  size_t h = (size_t)((unsigned long long)k * 0x9E3779B97F4A7C15ull) & (M->cap - 1);
+  while (M->key[h] != -1 && M->key[h] != k) h = (h + 1) & (M->cap - 1);
+  return h;
+}
+static void memo_put(og_memo *M, long long k, double v) {
+  if (2 * (M->used + 1) > M->cap) {
+    og_memo N; memo_init(&N, 2 * M->cap);
+    for (size_t i = 0; i < M->cap; ++i) if (M->key[i] != -1) { size_t h = memo_slot(&N, M->key[i]); N.key[h] = M->key[i]; N.val[h] = M->val[i]; N.used++; }
+    free(M->key); free(M->val); *M = N;
+  }
+  size_t h = memo_slot(M, k);
+  if (M->key[h] == -1) M->used++;
+  M->key[h] = k; M->val[h] = v;
+}
+static double marg_entry(const og_chol *C, const double *diag, og_memo *M, int r, int c) {   /* r <= c, permuted indices */
+  const long long k = (long long)r * C->n + c;
+  size_t h = memo_slot(M, k);
+  if (M->key[h] == k) return M->val[h];
+  double s = 0;
+  for (int p = C->Lp[r] + 1; p < C->Lp[r + 1]; ++p) {
+    const int j = C->Li[p];
+    const double v = j < c ? marg_entry(C, diag, M, j, c) : marg_entry(C, diag, M, c, j);
+    s += v * C->Lx[p];
+  }
+  const double res = r == c ? diag[r] * (diag[r] - s) : -s * diag[r];
+  memo_put(M, k, res);
+  return res;
+}
 int og_marginals(const og_problem *P, const int *ids, int nids, double *out) {
+  int *hidx = (int *)malloc(P->nv * sizeof(int));
+  int n = og_hessian_index(P, hidx);
+  og_system S; sys_structure(P, hidx, n, &S); sys_build(P, hidx, &S);
+  int *perm = (int *)malloc(n * sizeof(int));
+  scalar_perm_from_blocks(P, hidx, n, perm);
+  og_chol C; chol_symbolic(&C, n, S.Ap, S.Ai, perm);
+  int rc = chol_numeric(&C, S.Ap, S.Ai, S.Ax, 0.0);
+  if (rc == 0) {
+    /* the up-looking factorisation appends the entries of a column in ROW order of their creation (ascending k): rows ascend already */
+    double *diag = (double *)malloc(n * sizeof(double));
+    for (int j = 0; j < n; ++j) diag[j] = 1.0 / C.Lx[C.Lp[j]];
+    og_memo M; memo_init(&M, 1 << 14);
+    size_t o = 0;
+    for (int k = 0; k < nids; ++k) {
+      int v = ids[k]; int d = vdim(P->vtype[v]); int h = hidx[v];
+      if (h < 0) { for (int r = 0; r < d * d; ++r) out[o++] = 0; continue; }
+      for (int a = 0; a < d; ++a)
+        for (int b = a; b < d; ++b) {
+          const int pa = C.pinv[h + a], pb = C.pinv[h + b];
+          const double val = pa <= pb ? marg_entry(&C, diag, &M, pa, pb) : marg_entry(&C, diag, &M, pb, pa);
+          out[o + a * d + b] = val; out[o + b * d + a] = val;
+        }
+      o += (size_t)d * d;
+    }
+    free(M.key); free(M.val); free(diag);
+  }
+  chol_free(&C); free(perm); sys_free(&S); free(hidx);
+  return rc;
+}
+/* the same blocks by full triangular solves with unit right-hand sides (what rounds 1-4 used; cross-check of the recursion) */
+int og_marginals_by_solves(const og_problem *P, const int *ids, int nids, double *out) {
   int *hidx = (int *)malloc(P->nv * sizeof(int));
   int n = og_hessian_index(P, hidx);
   og_system S; sys_structure(P, hidx, n, &S); sys_build(P, hidx, &S);

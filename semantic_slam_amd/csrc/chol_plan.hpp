@@ -132,7 +132,7 @@ struct CholOpts {
   // cap and run by wider workgroups, one launch per depth next to the leaf pieces of that depth: several columns of a chain share a
   // piece, their updates stay in LDS (right-looking lists like the tail's), and four waves share the tiles of what is still handed up.
   int mid_width = -1;      // -1: 100 for batches >= 32, else 0 (small batches run k_chol_flow with one workgroup size); 0: no mid class
-  int cap_mid = 2400;      // doubles of L per mid piece
+  int cap_mid = 1800;      // doubles of L per mid piece (512 L graphs: 1800 / 2400 / 3600 -> 9.14 / 9.47 / 10.2 ms per factorisation, 9.55 without the class)
   int nt_mid = 256;        // its workgroup
   int pcap_mid = 16;
   int nt_leaf = 64, nt_tail = 512;    // workgroup sizes the items are cut for

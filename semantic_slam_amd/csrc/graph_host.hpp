@@ -16,8 +16,8 @@ struct Options {
   double pcg_tol = 1e-10;    // relative residual ||r|| / ||b||
   int pcg_max_iters = 20000;
   double dcs_phi = 0.0;      // > 0: g2o::RobustKernelDCS(delta = phi) on the landmark edges (quirk B1: off by default)
-  int speculative = 0;       // 1 / 2: a single small graph runs the damping trials of an LM iteration side by side in one launch (1: once a trial has
-                             // been rejected and while the lanes fit the chip, 2: always); same results, bitwise.  Opt-in
+  int speculative = 1;       // 1 / 2: a single small graph runs the damping trials of an LM iteration side by side in one launch (1, the default since
+                             // round 5: once a trial has been rejected and while the lanes fit the chip; 2: always); same results, bitwise; 0: off
   int fused = 1;             // small graphs: one launch per LM iteration (k_lm_trial_small); 0: the stand-alone kernels (same results, bitwise)
 };
 

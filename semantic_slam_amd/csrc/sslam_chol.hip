@@ -527,7 +527,7 @@ __device__ __forceinline__ void row_solve(double* v, const double* Ljj, const do
 // DEFER (k_chol_flow): the piece's tables and its part of H are fetched BEFORE the wait for the child pieces (they do not depend on
 // them); only the children's update-matrix blocks are read after it -- two dependent round trips less on the critical path of a piece.
 // The sums are those of the one-pass gather, in its order: (H + lambda I) first, then the sources one after the other.
-__device__ __forceinline__ bool flow_wait(const int* p, int target, int* err);
+__device__ __forceinline__ bool flow_wait(const int* p, int target, int* err, int* fail = nullptr);
 template <int NT, bool USTAGE, bool RIGHT, bool DEFER = false>
 __device__ __forceinline__ void chol_piece(const BatchView& V, const CholView& C, const PieceMeta pm, double* sm, long long* dbg,
                                            const int* wait_p = nullptr, int wait_target = 0, int* wait_err = nullptr) {
@@ -670,7 +670,7 @@ __device__ __forceinline__ void chol_piece(const BatchView& V, const CholView& C
     // ---- 1b. the children's update-matrix blocks, once they are there
     if (wait_p) {
       __syncthreads();
-      if (tid == 0) flow_wait(wait_p, wait_target, wait_err);
+      if (tid == 0) flow_wait(wait_p, wait_target, wait_err, C.fail + g);
     }
     __syncthreads();
     if (pm.nas > 0) {
@@ -1446,11 +1446,13 @@ __device__ __forceinline__ void spec_control(const BatchView& V, const SpecLanes
 // counters are never reset -- launch number `epoch` waits for epoch x (children).  A wait that does not end (it cannot, short of a lost
 // workgroup) gives up after ~2^22 polls and raises the error flag instead of hanging the GPU.
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ bool flow_wait(const int* p, int target, int* err) {
+// fail (optional): the failure flag of the graph the waiting piece belongs to -- a wait that gives up must not let the trial go on as if the
+// data it waited for were there: the graph's trial counts as a failed factorisation (lm_control rejects it) and the host reports the flag
+__device__ __forceinline__ bool flow_wait(const int* p, int target, int* err, int* fail) {
   int spins = 0;
   while (__hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target) {
     __builtin_amdgcn_s_sleep(2);
-    if (++spins > (1 << 22)) { atomicExch(err, 1); return false; }
+    if (++spins > (1 << 22)) { atomicExch(err, 1); if (fail) atomicExch(fail, 1); return false; }
   }
   return true;
 }
@@ -1499,7 +1501,7 @@ __global__ __launch_bounds__(NT) void k_chol_flow(BatchView V, CholView C, int q
     const int2 d = dep[q];
     const bool run = V.lm[pm.graph].in_trial;   // (set by the begin kernel of the step: not touched inside this launch)
     if (d.y > 0 && !(defer && run)) {
-      if (tid == 0) flow_wait(child_done + q, d.y * epoch, err);
+      if (tid == 0) flow_wait(child_done + q, d.y * epoch, err, C.fail + pm.graph);
       __syncthreads();
     }
     if (run) {
@@ -1528,8 +1530,8 @@ __global__ __launch_bounds__(NT) void k_chol_flow(BatchView V, CholView C, int q
     const PieceMeta pm = C.lpiece[q];
     const int2 d = dep[q];
     if (tid == 0) {
-      if (d.x >= 0) flow_wait(back_done + d.x, epoch, err);
-      else flow_wait(fwd_done + q, epoch, err);
+      if (d.x >= 0) flow_wait(back_done + d.x, epoch, err, C.fail + pm.graph);
+      else flow_wait(fwd_done + q, epoch, err, C.fail + pm.graph);
     }
     __syncthreads();
     if (V.lm[pm.graph].in_trial) chol_piece_backward<NT>(C, pm, C.y, V.x, sm, nullptr);
@@ -1614,8 +1616,8 @@ __global__ __launch_bounds__(NT) void k_chol_spec_round(BatchView V, CholView C,
     const PieceMeta pm = C.lpiece[q];
     const int2 d = dep[q];
     if (tid == 0) {
-      if (d.x >= 0) flow_wait(back_done + d.x, epoch, err);
-      else flow_wait(fwd_done + q, epoch, err);
+      if (d.x >= 0) flow_wait(back_done + d.x, epoch, err, C.fail + pm.graph);
+      else flow_wait(fwd_done + q, epoch, err, C.fail + pm.graph);
     }
     __syncthreads();
     chol_piece_backward<NT>(C, pm, C.y, V.x, sm, nullptr);
@@ -1926,6 +1928,33 @@ int chol_plan_build(Batch& b) {
   return 0;
 }
 
+// Persistent launches (k_chol_flow, k_chol_spec_round) spin on counters that only workgroups of the SAME launch advance: a launch whose
+// grid is not wholly on the chip can wait for a workgroup that has not started.  Every such grid is sized for an otherwise free device
+// (flow: half of it, a speculative round: all of it) -- so launches of different handles / streams / host threads must not overlap
+// (round-4 ADVICE).  They are chained per device: a launch waits for the event its predecessor recorded, whatever stream that was on.  On
+// one stream (a single graph handle: the orchestrator) the wait is already implied and costs an event record per launch.
+struct PersistGate {
+  std::mutex mu;
+  hipEvent_t ev = nullptr;
+  bool armed = false;
+};
+static PersistGate& persist_gate(int device) {
+  static std::mutex mu;
+  static std::vector<PersistGate*> gates;
+  std::lock_guard<std::mutex> lk(mu);
+  if ((int)gates.size() <= device) gates.resize(device + 1, nullptr);
+  if (!gates[device]) gates[device] = new PersistGate();
+  return *gates[device];
+}
+struct PersistScope {   // construct before the launch (waits for the previous persistent launch of the device), destroy after it (records)
+  PersistGate& g; hipStream_t s; std::unique_lock<std::mutex> lk;
+  PersistScope(int device, hipStream_t stream) : g(persist_gate(device)), s(stream), lk(g.mu) {
+    if (!g.ev && hipEventCreateWithFlags(&g.ev, hipEventDisableTiming) != hipSuccess) g.ev = nullptr;
+    if (g.ev && g.armed) (void)hipStreamWaitEvent(s, g.ev, 0);
+  }
+  ~PersistScope() { if (g.ev && hipEventRecord(g.ev, s) == hipSuccess) g.armed = true; }
+};
+
 // (H + lambda I) dx = b in ONE launch (k_chol_flow) for plans that allow it; false: the caller takes the launch-per-depth path
 bool chol_plan_flow(const Batch& b) { return b.chol && b.chol->flow && !b.chol->compact; }
 // the launches of one solve: per-depth launches over the wide bottom of the tree, the dependency-driven launch over the rest (factor and
@@ -1947,8 +1976,11 @@ static void flow_launches(Batch& b, bool spec = false, bool backward = true, boo
   const int lm_epoch = lmstep ? ++P.lm_epoch : 0;
   const dim3 grid(spec ? P.spec_grid : P.flow_grid);
   static const int defer = [] { const char* e = getenv("SSLAM_FLOW_DEFER"); return (e && atoi(e) == 0) ? 0 : 2; }();   // tables + H before the wait for the children
-  if (P.ustage) hipLaunchKernelGGL((k_chol_flow<512, true>), grid, dim3(512), lds, b.stream, b.V, C, P.flow_first, np, epoch, (const int2*)P.d_dep, P.d_flow, SL, (backward ? 1 : 0) | defer | (lmstep ? 4 : 0), b.d_part_e, max_iters, lm_epoch);
-  else hipLaunchKernelGGL((k_chol_flow<512, false>), grid, dim3(512), lds, b.stream, b.V, C, P.flow_first, np, epoch, (const int2*)P.d_dep, P.d_flow, SL, (backward ? 1 : 0) | defer | (lmstep ? 4 : 0), b.d_part_e, max_iters, lm_epoch);
+  {
+    PersistScope gate(b.device, b.stream);
+    if (P.ustage) hipLaunchKernelGGL((k_chol_flow<512, true>), grid, dim3(512), lds, b.stream, b.V, C, P.flow_first, np, epoch, (const int2*)P.d_dep, P.d_flow, SL, (backward ? 1 : 0) | defer | (lmstep ? 4 : 0), b.d_part_e, max_iters, lm_epoch);
+    else hipLaunchKernelGGL((k_chol_flow<512, false>), grid, dim3(512), lds, b.stream, b.V, C, P.flow_first, np, epoch, (const int2*)P.d_dep, P.d_flow, SL, (backward ? 1 : 0) | defer | (lmstep ? 4 : 0), b.d_part_e, max_iters, lm_epoch);
+  }
   for (int l = P.flow_launch0 - 1; l >= 0 && backward; --l) {
     const int n = P.plv_ptr[l + 1] - P.plv_ptr[l];
     hipLaunchKernelGGL(k_chol_back_pieces<512>, dim3(n), dim3(512), (size_t)P.plv_lds_b[l] * sizeof(double), b.stream, C, P.plv_ptr[l], (const double*)C.y, b.V.x, (const LmState*)b.V.lm, (const int*)nullptr);
@@ -2012,8 +2044,11 @@ int chol_lm_step_spec(Batch& b, int max_iters) {
   lds *= sizeof(double);
   const int np = (int)P.lp_graph.size();
   const int round = ++P.spec_epoch;
-  if (P.ustage) hipLaunchKernelGGL((k_chol_spec_round<512, true>), dim3(P.spec_grid), dim3(512), lds, b.stream, b.V, P.C, np, (const int2*)P.d_dep, P.spec, round, max_iters);
-  else hipLaunchKernelGGL((k_chol_spec_round<512, false>), dim3(P.spec_grid), dim3(512), lds, b.stream, b.V, P.C, np, (const int2*)P.d_dep, P.spec, round, max_iters);
+  {
+    PersistScope gate(b.device, b.stream);
+    if (P.ustage) hipLaunchKernelGGL((k_chol_spec_round<512, true>), dim3(P.spec_grid), dim3(512), lds, b.stream, b.V, P.C, np, (const int2*)P.d_dep, P.spec, round, max_iters);
+    else hipLaunchKernelGGL((k_chol_spec_round<512, false>), dim3(P.spec_grid), dim3(512), lds, b.stream, b.V, P.C, np, (const int2*)P.d_dep, P.spec, round, max_iters);
+  }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return set_error(SSLAM_ERR_HIP, "speculative LM step launch: %s", hipGetErrorString(e));
   return 0;
@@ -2028,7 +2063,13 @@ int chol_flow_check(Batch& b) {
     SSLAM_HIP_TRY(hipMemcpyAsync(&lane_err[k], b.chol->spec.flow + k * b.chol->spec.sflow + 3 * b.chol->lp_graph.size(), sizeof(int), hipMemcpyDeviceToHost, b.stream));
   SSLAM_HIP_TRY(hipStreamSynchronize(b.stream));
   for (int e2 : lane_err) err |= e2;
-  if (err) return set_error(SSLAM_ERR_HIP, "sparse Cholesky: a dependency wait of the single-launch factorisation timed out");
+  if (err) {   // reported once: cleared, so that the next solve of the handle is judged on its own
+    SSLAM_HIP_TRY(hipMemsetAsync(b.chol->d_flow + 3 * b.chol->lp_graph.size(), 0, sizeof(int), b.stream));
+    for (size_t k = 0; k < lane_err.size(); ++k)
+      SSLAM_HIP_TRY(hipMemsetAsync(b.chol->spec.flow + k * b.chol->spec.sflow + 3 * b.chol->lp_graph.size(), 0, sizeof(int), b.stream));
+    SSLAM_HIP_TRY(hipStreamSynchronize(b.stream));
+    return set_error(SSLAM_ERR_HIP, "sparse Cholesky: a dependency wait of the single-launch factorisation timed out (the graphs concerned carry a failed trial)");
+  }
   return 0;
 }
 

@@ -2638,6 +2638,7 @@ int sslam_graph_solve(sslam_graph* h, double lambda, double* x, int64_t* solver_
   SSLAM_HIP_TRY(hipStreamSynchronize(b.stream));
   if (solver_iterations) *solver_iterations = s.pcg_iters;
   to_g2o_order(h, xi, x);
+  if ((rc = chol_flow_check(b))) return rc;   // a dependency wait of the single-launch solve that gave up (also raises `fail`)
   if (fail) return set_error(SSLAM_ERR_NUMERIC, "linear solve broke down");
   return 0;
 }
@@ -2690,6 +2691,7 @@ static int marginal_blocks(sslam_graph* h, const std::vector<std::pair<int, int>
     int fail = 0;
     SSLAM_HIP_TRY(hipMemcpyAsync(&fail, b.V.pcg_fail, sizeof fail, hipMemcpyDeviceToHost, b.stream));
     SSLAM_HIP_TRY(hipStreamSynchronize(b.stream));
+    if ((rc = chol_flow_check(b))) return rc;
     if (fail) return set_error(SSLAM_ERR_NUMERIC, "H is not positive definite: no marginals");
     // Diagonal blocks only (what computeLandmarkMarginals asks for, semantic_graph_slam.cpp:188-190): one launch, a forward substitution
     // along each vertex' path of the elimination tree (k_chol_marginal_paths) -- no right-hand side matrix, no backward solve, and only

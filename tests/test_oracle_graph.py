@@ -159,6 +159,14 @@ def test_marginals_equal_dense_inverse_blocks():
     for v, B in zip(ids, blocks):
         ref = Hinv[h[v]:h[v] + 3, h[v]:h[v] + 3]
         assert np.abs(B - ref).max() <= 1e-9 * np.abs(ref).max()
+    # the recursion over the factor (g2o's MarginalCovarianceCholesky, the default) against full triangular solves, poses included
+    ids2 = ids + [int(v) for v in gp.pose_ids[1:7]]
+    a, b = gp.marginals(ids2), gp.marginals(ids2, by_solves=True)
+    assert np.abs(a - b).max() <= 1e-10 * np.abs(b).max()
+    o = 9 * len(ids)
+    for k, v in enumerate(ids2[len(ids):]):
+        ref = Hinv[h[v]:h[v] + 6, h[v]:h[v] + 6]
+        assert np.abs(a[o + 36 * k:o + 36 * k + 36].reshape(6, 6) - ref).max() <= 1e-9 * np.abs(ref).max()
 
 
 def test_noise_free_graph_is_a_fixed_point():

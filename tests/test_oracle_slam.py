@@ -105,3 +105,49 @@ def test_keyframe_gate_is_blind_to_the_quaternion_sign():
         if k % 2:
             q[3:] = -q[3:]
         assert a.vio(ev.stamp[0], ev.stamp[1], ev.odom) == b.vio(ev.stamp[0], ev.stamp[1], q)
+
+
+def test_c_tick_driver_equals_the_numpy_tick():
+    """oracle/oracle_slam.c (the like-for-like CPU baseline of bench.py's tick replay: nothing but C inside a tick) against
+    oracle/np_slam.py on the same run: same keyframes, same graph (structure exactly, measurements to the last few bits -- BLAS vs plain
+    loops in the 4 x 4 products), same associations, same optimised estimates and landmark covariances, tick by tick."""
+    from oracle.oracle import SlamTickC
+    from tests.slam_replay import ODOM_STDDEV_X, ODOM_STDDEV_Q
+    for seed, n in ((0, 300), (4, 260)):
+        events, _ = make_replay(seed, n_samples=n)
+        if seed == 4:                               # same-frame twins (see the test above)
+            for ev in events:
+                if ev.objects:
+                    t = dict(ev.objects[0])
+                    t["pose"] = ev.objects[0]["pose"] + np.array([0.05, 0.0, 0.0], np.float32)
+                    ev.objects.insert(1, t)
+        o = oracle_instance()
+        c = SlamTickC(const_stddev_x=ODOM_STDDEV_X, const_stddev_q=ODOM_STDDEV_Q)
+        ticks = 0
+        for ev in events:
+            if ev.objects is not None:
+                o.set_segmented_objects(ev.objects); c.set_segmented_objects(ev.objects)
+            assert o.vio(ev.stamp[0], ev.stamp[1], ev.odom) == c.vio(ev.stamp[0], ev.stamp[1], ev.odom)
+            if not ev.run_after:
+                continue
+            ran = o.run()
+            assert c.run() == ran
+            if not ran:
+                continue
+            ticks += 1
+            so, sc = o.last_stats, c.last_stats
+            assert (so["keyframes_added"], so["landmarks_added"], so["landmarks_matched"], so["landmark_edges_added"]) == \
+                   (sc.keyframes_added, sc.landmarks_added, sc.landmarks_matched, sc.landmark_edges_added)
+            g = c.graph()
+            assert list(g["vtype"]) == list(o.vtype) and list(g["etype"]) == list(o.etype)
+            assert list(g["evi"]) == list(o.evi) and list(g["evj"]) == list(o.evj)
+            assert np.abs(g["meas"] - np.array(o.meas)).max() <= 1e-12 and np.abs(g["info"] - np.array(o.info)).max() <= 1e-9 * np.abs(g["info"]).max()
+            if so["optimized"]:
+                assert sc.optimized and abs(sc.chi2_after - so["opt"].chi2_after) <= 1e-7 * max(1.0, so["opt"].chi2_after)
+                assert np.abs(g["est"] - np.array(o.est)).max() <= 1e-7
+                lm = c.landmarks()
+                assert list(lm["vertex"]) == [l["vertex"] for l in o.assoc.landmarks]
+                cov = np.array([l["covariance"] for l in o.assoc.landmarks]).reshape(-1, 3, 3)
+                assert len(cov) == 0 or np.abs(lm["covariance"] - cov).max() <= 1e-5 * np.abs(cov).max()
+                assert np.abs(c.robot_pose() - o.robot_pose).max() <= 1e-7
+        assert ticks >= 20 and c.counts()[2] == len(o.keyframes) and c.counts()[3] == len(o.assoc.landmarks)
