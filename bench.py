@@ -296,6 +296,36 @@ def bench_frontend(device, frames=8, cpu_baseline=True, batch_frames=32, dist=No
                             "planes_per_sec_incl_pcie_and_host": round(ptot / pwall, 1),
                             "ms_per_frame_incl_pcie_and_host": round(1e3 * pwall / (preps * batch_frames), 4),
                             "h2d_MB_per_frame": round(fs[0].cloud.nbytes / 1e6, 2)}
+        # the same frames as 12-byte xyz points (the frontend reads x, y, z only; the C-ABI takes any point_step): what a caller that
+        # converts the sensor message anyway (pcl::fromROSMsg in the reference's callback) can hand over -- INTEGRATION.md section 2
+        from semantic_slam_amd.synth import repack_xyz
+        pinned12 = []
+        for f in fs:
+            g = repack_xyz(f, 12)
+            ptr = lib.sslam_pinned_alloc(g.cloud.nbytes)
+            if not ptr:
+                raise RuntimeError(lib.sslam_last_error().decode())
+            pins.append(ptr)
+            arr = np.ctypeslib.as_array((C.c_uint8 * g.cloud.nbytes).from_address(ptr)).view(g.cloud.dtype).reshape(g.cloud.shape)
+            arr[...] = g.cloud
+            g.cloud = arr
+            pinned12.append(g)
+        pbf12 = [pinned12[k % len(pinned12)] for k in range(batch_frames)]
+        list(seg.segment_stream([pbf12, pbf12]))
+        ppl12 = 0
+        if dist is not None:
+            torch.cuda.synchronize(); dist.barrier()
+        t2 = time.perf_counter()
+        for planes in seg.segment_stream([pbf12] * preps):
+            ppl12 += sum(len(x) for x in planes)
+        if dist is not None:
+            torch.cuda.synchronize(); dist.barrier()
+        pwall12 = D.max_over_ranks(time.perf_counter() - t2, device=ddev)
+        ptot12 = D.aggregate_throughput(float(ppl12), 1.0, device=ddev)
+        res["pipelined_xyz12"] = {"frames_per_batch": batch_frames, "batches": preps, "pinned_clouds": True, "point_step_bytes": 12,
+                                  "planes_per_sec_incl_pcie_and_host": round(ptot12 / pwall12, 1),
+                                  "ms_per_frame_incl_pcie_and_host": round(1e3 * pwall12 / (preps * batch_frames), 4),
+                                  "h2d_MB_per_frame": round(pinned12[0].cloud.nbytes / 1e6, 2), "same_planes_as_32_byte_points": bool(ppl12 == ppl)}
     except Exception as e:
         res["pipelined"] = {"error": repr(e)}
     finally:

@@ -1665,111 +1665,117 @@ __global__ __launch_bounds__(1024) void k_ransac_boxes(View V, float thr, int ma
 }
 
 // Point-to-plane ICP of every frame of the resident batch against a plane list (e.g. the previous keyframe's planes): the points are the
-// RANSAC inliers of the frame's boxes, box slot q measures plane box_plane[q] (-1: the box takes no part).  One workgroup per frame runs
-// ALL Gauss-Newton rounds: a pass over its points (29 double sums per thread, then a fixed-order reduction), the 6 x 6 Cholesky solve and
-// the update T <- (exp[w]x, u) o T by one thread -- no host round trip per iteration.  Same arithmetic as k_icp_accumulate + the host
-// solve of sslam_seg_icp_point_to_plane; only the order of the sums differs.
+// RANSAC inliers of the frame's boxes, box slot q measures plane box_plane[q] (-1: the box takes no part).
+// Round 4 ran ONE 1024-thread workgroup per frame through all Gauss-Newton rounds: 32 workgroups on 256 CUs, 0.234 ms per frame -- 2.7 x
+// the whole segmentation.  Round 5: a Gauss-Newton round is two launches over the whole batch --
+//   k_icp_box_sums    one workgroup per BOX: its inliers' 29 double sums under the frame's current transform (fixed-order reduction:
+//                     a thread's points in index order, wave shuffles, the waves in order) -> part[box][29]
+//   k_icp_frame_step  one wave per FRAME: the boxes' partial sums in slot order, the 6 x 6 Cholesky solve and T <- (exp[w]x, u) o T by
+//                     lane 0; a frame that is finished (last pass, < 6 points, rank-deficient plane set) is frozen by its flag
+// -- 2 (iterations + 1) launches of a few microseconds for ALL frames, still no host round trip per iteration.  Same arithmetic per point
+// as k_icp_accumulate + the host solve of sslam_seg_icp_point_to_plane; only the order of the sums differs.
 struct IcpFrame { double T[12]; double rms; int used, status; };
-__global__ __launch_bounds__(1024) void k_icp_frames(View V, const unsigned char* __restrict__ flag, const int* __restrict__ frame_box0,
-                                                     const int* __restrict__ box_plane, const float* __restrict__ planes, int n_planes, int iterations,
-                                                     const double* __restrict__ T0, IcpFrame* __restrict__ out) {
-  __shared__ double red[16][kIcpSums];
-  __shared__ double sT[12], sums[kIcpSums];
-  __shared__ int s_status;
-  const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int q0 = frame_box0[f], q1 = frame_box0[f + 1];
-  if (tid < 12) sT[tid] = T0 ? T0[(size_t)f * 12 + tid] : ((tid < 9 && tid % 4 == 0) ? 1.0 : 0.0);
-  if (tid == 0) s_status = 0;
-  __syncthreads();
-  for (int it = 0; it <= iterations; ++it) {   // the last pass only measures the residual at the returned transform
-    double a[kIcpSums];
+struct IcpState { double T[12]; int status, done, pad0, pad1; };
+__global__ __launch_bounds__(256) void k_icp_box_sums(View V, const unsigned char* __restrict__ flag, const int* __restrict__ box_frame,
+                                                      const int* __restrict__ box_plane, const float* __restrict__ planes, int n_planes,
+                                                      const IcpState* __restrict__ st, double* __restrict__ part) {
+  __shared__ double red[4][kIcpSums];
+  const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int f = box_frame[q], kpl = box_plane[q];
+  double a[kIcpSums];
 #pragma unroll
-    for (int k = 0; k < kIcpSums; ++k) a[k] = 0.0;
+  for (int k = 0; k < kIcpSums; ++k) a[k] = 0.0;
+  if (!st[f].done && kpl >= 0 && kpl < n_planes) {
     double R[9], t[3];
 #pragma unroll
-    for (int k = 0; k < 9; ++k) R[k] = sT[k];
+    for (int k = 0; k < 9; ++k) R[k] = st[f].T[k];
 #pragma unroll
-    for (int k = 0; k < 3; ++k) t[k] = sT[9 + k];
-    for (int q = q0; q < q1; ++q) {
-      const int kpl = box_plane[q];
-      if (kpl < 0 || kpl >= n_planes) continue;
-      const BoxMeta b = V.box[q];
-      const double nx = planes[4 * kpl], ny = planes[4 * kpl + 1], nz = planes[4 * kpl + 2], d = planes[4 * kpl + 3];
-      const int n = b.w * b.h;
-      for (int i = tid; i < n; i += 1024) {
-        if (!flag[(size_t)b.pix0 + i]) continue;
-        const float* p = V.pts + ((size_t)b.pix0 + i) * 3;
-        const double px = p[0], py = p[1], pz = p[2];
-        if (!(isfinite(px) && isfinite(py) && isfinite(pz))) continue;
-        const double qx = R[0] * px + R[1] * py + R[2] * pz + t[0];
-        const double qy = R[3] * px + R[4] * py + R[5] * pz + t[1];
-        const double qz = R[6] * px + R[7] * py + R[8] * pz + t[2];
-        const double r = nx * qx + ny * qy + nz * qz + d;
-        const double J[6] = {qy * nz - qz * ny, qz * nx - qx * nz, qx * ny - qy * nx, nx, ny, nz};
-        int m = 0;
-#pragma unroll
-        for (int rr = 0; rr < 6; ++rr)
-#pragma unroll
-          for (int cc = rr; cc < 6; ++cc) a[m++] += J[rr] * J[cc];
-#pragma unroll
-        for (int rr = 0; rr < 6; ++rr) a[21 + rr] += J[rr] * r;
-        a[27] += r * r;
-        a[28] += 1.0;
-      }
-    }
-#pragma unroll
-    for (int k = 0; k < kIcpSums; ++k) {
-      double v = a[k];
-      for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-      if (lane == 0) red[wave][k] = v;
-    }
-    __syncthreads();
-    if (tid < kIcpSums) { double v = 0; for (int w = 0; w < 16; ++w) v += red[w][tid]; sums[tid] = v; }
-    __syncthreads();
-    if (it == iterations || sums[28] < 6 || s_status) break;
-    if (tid == 0) {
-      double A[36], bvec[6], L[36];
-      for (int k = 0; k < 36; ++k) L[k] = 0;
+    for (int k = 0; k < 3; ++k) t[k] = st[f].T[9 + k];
+    const BoxMeta b = V.box[q];
+    const double nx = planes[4 * kpl], ny = planes[4 * kpl + 1], nz = planes[4 * kpl + 2], d = planes[4 * kpl + 3];
+    const int n = b.w * b.h;
+    for (int i = tid; i < n; i += 256) {
+      if (!flag[(size_t)b.pix0 + i]) continue;
+      const float* p = V.pts + ((size_t)b.pix0 + i) * 3;
+      const double px = p[0], py = p[1], pz = p[2];
+      if (!(isfinite(px) && isfinite(py) && isfinite(pz))) continue;
+      const double qx = R[0] * px + R[1] * py + R[2] * pz + t[0];
+      const double qy = R[3] * px + R[4] * py + R[5] * pz + t[1];
+      const double qz = R[6] * px + R[7] * py + R[8] * pz + t[2];
+      const double r = nx * qx + ny * qy + nz * qz + d;
+      const double J[6] = {qy * nz - qz * ny, qz * nx - qx * nz, qx * ny - qy * nx, nx, ny, nz};
       int m = 0;
-      for (int r = 0; r < 6; ++r) for (int c = r; c < 6; ++c) { A[r * 6 + c] = A[c * 6 + r] = sums[m++]; }
-      for (int r = 0; r < 6; ++r) bvec[r] = -sums[21 + r];
-      bool okc = true;
-      for (int j = 0; j < 6 && okc; ++j) {
-        double dsum = A[j * 6 + j];
-        for (int k = 0; k < j; ++k) dsum -= L[j * 6 + k] * L[j * 6 + k];
-        if (!(dsum > 1e-12 * A[j * 6 + j]) || !(dsum > 0)) { okc = false; break; }
-        L[j * 6 + j] = sqrt(dsum);
-        for (int i = j + 1; i < 6; ++i) { double v = A[i * 6 + j]; for (int k = 0; k < j; ++k) v -= L[i * 6 + k] * L[j * 6 + k]; L[i * 6 + j] = v / L[j * 6 + j]; }
-      }
-      if (!okc) s_status = SSLAM_ERR_NUMERIC;   // the planes leave a degree of freedom unconstrained
-      else {
-        double y[6], dx[6];
-        for (int i = 0; i < 6; ++i) { double v = bvec[i]; for (int k = 0; k < i; ++k) v -= L[i * 6 + k] * y[k]; y[i] = v / L[i * 6 + i]; }
-        for (int i = 5; i >= 0; --i) { double v = y[i]; for (int k = i + 1; k < 6; ++k) v -= L[k * 6 + i] * dx[k]; dx[i] = v / L[i * 6 + i]; }
-        const double wx = dx[0], wy = dx[1], wz = dx[2], th = sqrt(wx * wx + wy * wy + wz * wz);
-        double E[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
-        if (th > 0) {
-          const double sa = sin(th) / th, bq = (1.0 - cos(th)) / (th * th);
-          const double K[9] = {0, -wz, wy, wz, 0, -wx, -wy, wx, 0};
-          for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) { double kk = 0; for (int q = 0; q < 3; ++q) kk += K[r * 3 + q] * K[q * 3 + c]; E[r * 3 + c] += sa * K[r * 3 + c] + bq * kk; }
-        }
-        double Tn[12];
-        for (int r = 0; r < 3; ++r) {
-          for (int c = 0; c < 3; ++c) Tn[r * 3 + c] = E[r * 3] * sT[c] + E[r * 3 + 1] * sT[3 + c] + E[r * 3 + 2] * sT[6 + c];
-          Tn[9 + r] = E[r * 3] * sT[9] + E[r * 3 + 1] * sT[10] + E[r * 3 + 2] * sT[11] + dx[3 + r];
-        }
-        for (int k = 0; k < 12; ++k) sT[k] = Tn[k];
-      }
+#pragma unroll
+      for (int rr = 0; rr < 6; ++rr)
+#pragma unroll
+        for (int cc = rr; cc < 6; ++cc) a[m++] += J[rr] * J[cc];
+#pragma unroll
+      for (int rr = 0; rr < 6; ++rr) a[21 + rr] += J[rr] * r;
+      a[27] += r * r;
+      a[28] += 1.0;
     }
-    __syncthreads();
   }
-  if (tid == 0) {
+#pragma unroll
+  for (int k = 0; k < kIcpSums; ++k) {
+    double v = a[k];
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    if (lane == 0) red[wave][k] = v;
+  }
+  __syncthreads();
+  if (tid < kIcpSums) part[(size_t)q * kIcpSums + tid] = ((red[0][tid] + red[1][tid]) + red[2][tid]) + red[3][tid];
+}
+__global__ __launch_bounds__(64) void k_icp_frame_step(const int* __restrict__ frame_box0, const double* __restrict__ part, int it, int iterations,
+                                                       IcpState* __restrict__ st, IcpFrame* __restrict__ out) {
+  __shared__ double sums[kIcpSums];
+  const int f = blockIdx.x, tid = threadIdx.x;
+  if (st[f].done) return;
+  if (tid < kIcpSums) {
+    double v = 0;
+    for (int q = frame_box0[f]; q < frame_box0[f + 1]; ++q) v += part[(size_t)q * kIcpSums + tid];   // slot order
+    sums[tid] = v;
+  }
+  __syncthreads();
+  if (tid != 0) return;
+  IcpState S = st[f];
+  if (it == iterations || sums[28] < 6 || S.status) {   // the last pass only measures the residual at the returned transform
     IcpFrame o;
-    for (int k = 0; k < 12; ++k) o.T[k] = sT[k];
+    for (int k = 0; k < 12; ++k) o.T[k] = S.T[k];
     o.rms = sums[28] > 0 ? sqrt(sums[27] / sums[28]) : 0.0;
-    o.used = (int)sums[28]; o.status = s_status;
+    o.used = (int)sums[28]; o.status = S.status;
     out[f] = o;
+    st[f].done = 1;
+    return;
   }
+  double A[36], bvec[6], L[36];
+  for (int k = 0; k < 36; ++k) L[k] = 0;
+  int m = 0;
+  for (int r = 0; r < 6; ++r) for (int c = r; c < 6; ++c) { A[r * 6 + c] = A[c * 6 + r] = sums[m++]; }
+  for (int r = 0; r < 6; ++r) bvec[r] = -sums[21 + r];
+  bool okc = true;
+  for (int j = 0; j < 6 && okc; ++j) {
+    double dsum = A[j * 6 + j];
+    for (int k = 0; k < j; ++k) dsum -= L[j * 6 + k] * L[j * 6 + k];
+    if (!(dsum > 1e-12 * A[j * 6 + j]) || !(dsum > 0)) { okc = false; break; }
+    L[j * 6 + j] = sqrt(dsum);
+    for (int i = j + 1; i < 6; ++i) { double v = A[i * 6 + j]; for (int k = 0; k < j; ++k) v -= L[i * 6 + k] * L[j * 6 + k]; L[i * 6 + j] = v / L[j * 6 + j]; }
+  }
+  if (!okc) { st[f].status = SSLAM_ERR_NUMERIC; return; }   // the planes leave a degree of freedom unconstrained: the next pass reports it
+  double y[6], dx[6];
+  for (int i = 0; i < 6; ++i) { double v = bvec[i]; for (int k = 0; k < i; ++k) v -= L[i * 6 + k] * y[k]; y[i] = v / L[i * 6 + i]; }
+  for (int i = 5; i >= 0; --i) { double v = y[i]; for (int k = i + 1; k < 6; ++k) v -= L[k * 6 + i] * dx[k]; dx[i] = v / L[i * 6 + i]; }
+  const double wx = dx[0], wy = dx[1], wz = dx[2], th = sqrt(wx * wx + wy * wy + wz * wz);
+  double E[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+  if (th > 0) {
+    const double sa = sin(th) / th, bq = (1.0 - cos(th)) / (th * th);
+    const double K[9] = {0, -wz, wy, wz, 0, -wx, -wy, wx, 0};
+    for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) { double kk = 0; for (int q = 0; q < 3; ++q) kk += K[r * 3 + q] * K[q * 3 + c]; E[r * 3 + c] += sa * K[r * 3 + c] + bq * kk; }
+  }
+  double Tn[12];
+  for (int r = 0; r < 3; ++r) {
+    for (int c = 0; c < 3; ++c) Tn[r * 3 + c] = E[r * 3] * S.T[c] + E[r * 3 + 1] * S.T[3 + c] + E[r * 3 + 2] * S.T[6 + c];
+    Tn[9 + r] = E[r * 3] * S.T[9] + E[r * 3 + 1] * S.T[10] + E[r * 3 + 2] * S.T[11] + dx[3 + r];
+  }
+  for (int k = 0; k < 12; ++k) st[f].T[k] = Tn[k];
 }
 
 // ---- cloud filters of the legacy path (plane_segmentation.cpp:557-629) ---------------------------------------------
@@ -1977,6 +1983,9 @@ struct sslam_seg {
   // sslam_seg_ransac_boxes / _icp_boxes over the resident batch of the last blocking segment call
   unsigned char* d_rflag = nullptr;   // [pixels of the batch] inlier of its box's refined RANSAC model
   void* d_rbox = nullptr;             // RansacBox per accepted box
+  void* d_icp = nullptr;              // sslam_seg_icp_boxes: [tables | per-frame state | per-box partial sums | results], grows only
+  size_t cap_icp = 0;
+  std::vector<char> h_icp;            // host image of the tables + state (one H2D copy per call)
   size_t cap_rflag = 0, cap_rbox = 0;
   int r_nbox = -1;                    // boxes the flags belong to (-1: no RANSAC has run on the resident batch)
   sslam_seg* twin = nullptr;
@@ -1990,6 +1999,7 @@ struct sslam_seg {
     if (q_nreg) (void)hipHostFree(q_nreg);
     if (d_rflag) (void)hipFree(d_rflag);
     if (d_rbox) (void)hipFree(d_rbox);
+    if (d_icp) (void)hipFree(d_icp);
     if (q_e0) (void)hipEventDestroy(q_e0);
     if (q_e1) (void)hipEventDestroy(q_e1);
     if (stream) (void)hipStreamDestroy(stream);
@@ -2600,37 +2610,51 @@ int sslam_seg_icp_boxes(sslam_seg* s, const int32_t* box_plane, int n_boxes, con
   const int nf = (int)s->q_frames.size();
   if (kernel_ms) *kernel_ms = 0;
   if (nf == 0) return 0;
-  std::vector<int> fb0(nf + 1, 0);
-  for (int q = 0; q < s->r_nbox; ++q) fb0[s->box_frame[q] + 1]++;   // the slots of a frame are consecutive (frames are packed in order)
-  for (int f = 0; f < nf; ++f) fb0[f + 1] += fb0[f];
-  int *d_fb0 = nullptr, *d_bp = nullptr;
-  float* d_planes = nullptr;
-  double* d_T0 = nullptr;
-  IcpFrame* d_out = nullptr;
-  struct Guard {
-    std::vector<void**> ptrs;
-    ~Guard() { for (void** p : ptrs) if (*p) (void)hipFree(*p); }
-  } guard;
-  guard.ptrs = {(void**)&d_fb0, (void**)&d_bp, (void**)&d_planes, (void**)&d_T0, (void**)&d_out};
-  SSLAM_HIP_TRY(hipMalloc((void**)&d_fb0, (size_t)(nf + 1) * sizeof(int)));
-  SSLAM_HIP_TRY(hipMalloc((void**)&d_bp, (size_t)std::max(n_boxes, 1) * sizeof(int)));
-  SSLAM_HIP_TRY(hipMalloc((void**)&d_planes, (size_t)n_planes * 4 * sizeof(float)));
-  SSLAM_HIP_TRY(hipMalloc((void**)&d_out, (size_t)nf * sizeof(IcpFrame)));
-  SSLAM_HIP_TRY(hipMemcpyAsync(d_fb0, fb0.data(), (size_t)(nf + 1) * sizeof(int), hipMemcpyHostToDevice, s->stream));
-  if (n_boxes > 0) SSLAM_HIP_TRY(hipMemcpyAsync(d_bp, box_plane, (size_t)n_boxes * sizeof(int), hipMemcpyHostToDevice, s->stream));
-  SSLAM_HIP_TRY(hipMemcpyAsync(d_planes, planes, (size_t)n_planes * 4 * sizeof(float), hipMemcpyHostToDevice, s->stream));
-  if (T0) {
-    SSLAM_HIP_TRY(hipMalloc((void**)&d_T0, (size_t)nf * 12 * sizeof(double)));
-    SSLAM_HIP_TRY(hipMemcpyAsync(d_T0, T0, (size_t)nf * 12 * sizeof(double), hipMemcpyHostToDevice, s->stream));
+  const int nb = s->r_nbox;
+  // one upload: [frame_box0 (nf + 1) | box_frame (nb) | box_plane (nb) | planes (4 n_planes floats) | IcpState (nf)]; scratch lives in the
+  // handle and only grows (round-4 ADVICE: five hipMalloc / hipFree pairs per call synchronised the device)
+  const size_t o_bf = (size_t)(nf + 1), o_bp = o_bf + nb, o_pl = o_bp + nb;
+  const size_t o_st = ((o_pl + (size_t)4 * n_planes) * 4 + 15) / 16 * 16;   // bytes
+  const size_t in_bytes = o_st + (size_t)nf * sizeof(IcpState);
+  const size_t part_bytes = (size_t)std::max(nb, 1) * kIcpSums * sizeof(double), out_bytes = (size_t)nf * sizeof(IcpFrame);
+  const size_t need = (in_bytes + 255) / 256 * 256 + (part_bytes + 255) / 256 * 256 + out_bytes;
+  if (s->cap_icp < need) {
+    SSLAM_HIP_TRY(hipStreamSynchronize(s->stream));
+    if (s->d_icp) (void)hipFree(s->d_icp);
+    s->d_icp = nullptr; s->cap_icp = 0;
+    SSLAM_HIP_TRY(hipMalloc(&s->d_icp, need + 4096));
+    s->cap_icp = need + 4096;
   }
+  s->h_icp.assign(in_bytes, 0);
+  int* hi = reinterpret_cast<int*>(s->h_icp.data());
+  for (int q = 0; q < nb; ++q) hi[s->box_frame[q] + 1]++;   // the slots of a frame are consecutive (frames are packed in order)
+  for (int f = 0; f < nf; ++f) hi[f + 1] += hi[f];
+  for (int q = 0; q < nb; ++q) { hi[o_bf + q] = s->box_frame[q]; hi[o_bp + q] = box_plane[q]; }
+  std::memcpy(hi + o_pl, planes, (size_t)4 * n_planes * sizeof(float));
+  IcpState* hs = reinterpret_cast<IcpState*>(s->h_icp.data() + o_st);
+  for (int f = 0; f < nf; ++f) {
+    for (int k = 0; k < 12; ++k) hs[f].T[k] = T0 ? T0[(size_t)f * 12 + k] : ((k < 9 && k % 4 == 0) ? 1.0 : 0.0);
+    hs[f].status = 0; hs[f].done = 0;
+  }
+  char* base = static_cast<char*>(s->d_icp);
+  const int* d_fb0 = reinterpret_cast<const int*>(base);
+  const int* d_bf = d_fb0 + o_bf;
+  const int* d_bp = d_fb0 + o_bp;
+  const float* d_planes = reinterpret_cast<const float*>(d_fb0 + o_pl);
+  IcpState* d_st = reinterpret_cast<IcpState*>(base + o_st);
+  double* d_part = reinterpret_cast<double*>(base + (in_bytes + 255) / 256 * 256);
+  IcpFrame* d_out = reinterpret_cast<IcpFrame*>(reinterpret_cast<char*>(d_part) + (part_bytes + 255) / 256 * 256);
+  SSLAM_HIP_TRY(hipMemcpyAsync(base, s->h_icp.data(), in_bytes, hipMemcpyHostToDevice, s->stream));
   if (!s->q_e0) { SSLAM_HIP_TRY(hipEventCreate(&s->q_e0)); SSLAM_HIP_TRY(hipEventCreate(&s->q_e1)); }
   SSLAM_HIP_TRY(hipEventRecord(s->q_e0, s->stream));
-  hipLaunchKernelGGL(k_icp_frames, dim3(nf), dim3(1024), 0, s->stream, s->V, (const unsigned char*)s->d_rflag, (const int*)d_fb0, (const int*)d_bp,
-                     (const float*)d_planes, n_planes, iterations, (const double*)d_T0, d_out);
+  for (int it = 0; it <= iterations; ++it) {
+    if (nb > 0) hipLaunchKernelGGL(k_icp_box_sums, dim3(nb), dim3(256), 0, s->stream, s->V, (const unsigned char*)s->d_rflag, d_bf, d_bp, d_planes, n_planes, (const IcpState*)d_st, d_part);
+    hipLaunchKernelGGL(k_icp_frame_step, dim3(nf), dim3(64), 0, s->stream, d_fb0, (const double*)d_part, it, iterations, d_st, d_out);
+  }
   SSLAM_HIP_TRY(hipGetLastError());
   SSLAM_HIP_TRY(hipEventRecord(s->q_e1, s->stream));
   std::vector<IcpFrame> res(nf);
-  SSLAM_HIP_TRY(hipMemcpyAsync(res.data(), d_out, (size_t)nf * sizeof(IcpFrame), hipMemcpyDeviceToHost, s->stream));
+  SSLAM_HIP_TRY(hipMemcpyAsync(res.data(), d_out, out_bytes, hipMemcpyDeviceToHost, s->stream));
   SSLAM_HIP_TRY(hipStreamSynchronize(s->stream));
   if (kernel_ms) { float ms = 0; if (hipEventElapsedTime(&ms, s->q_e0, s->q_e1) == hipSuccess) *kernel_ms = ms; }
   for (int f = 0; f < nf && f < max_out; ++f) {

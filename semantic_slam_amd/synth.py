@@ -309,6 +309,19 @@ class SynthFrame:
         return a[:, :, :3]
 
 
+def repack_xyz(frame: "SynthFrame", point_step: int = 12) -> "SynthFrame":
+    """The same frame with xyz-only points: 12 bytes (packed floats) or 16 (pcl::PointXYZ's padded layout).  The frontend reads 12 of a
+    registered cloud's 32 bytes per point (reference src/planar_segmentation/plane_segmentation.cpp:24-82 copies x, y, z of the crop); a
+    caller that converts the sensor message anyway (pcl::fromROSMsg in the reference's callback) can hand over this layout and the
+    per-frame PCIe copy shrinks from 9.83 MB to 3.69 MB.  The C-ABI takes any point_step / field offsets."""
+    assert point_step in (12, 16)
+    xyz = np.ascontiguousarray(frame.xyz(), np.float32)
+    out = np.zeros((frame.height, frame.width, point_step // 4), np.float32)
+    out[:, :, :3] = xyz
+    return dataclasses.replace(frame, cloud=out.reshape(-1).view(np.uint8).copy(), point_step=point_step,
+                               row_step=point_step * frame.width, offsets=(0, 4, 8))
+
+
 BOX_DTYPE = np.dtype([("tl_x", "<i4"), ("tl_y", "<i4"), ("width", "<i4"), ("height", "<i4"), ("class_id", "<i4"), ("prob", "<f4")])
 
 

@@ -147,6 +147,31 @@ def _same_planes(a_list, b_list):
         assert np.array_equal(a.pose, b.pose) and np.array_equal(a.normal_orientation, b.normal_orientation) and np.array_equal(a.world_pose, b.world_pose)
 
 
+def test_xyz_only_clouds_give_the_same_planes(gpu_lib):
+    """The frontend reads x, y, z of a point and nothing else (plane_segmentation.cpp:24-82): a 12-byte (packed) or 16-byte (pcl::PointXYZ)
+    cloud through the same entry points -- the C-ABI takes any point_step / field offsets -- gives the plane records of the 32-byte
+    registered cloud bit for bit (blocking call, batched call and the pipelined submit / collect), at 3.69 instead of 9.83 MB per frame
+    over PCIe."""
+    from semantic_slam_amd.segmentation import PointCloudSegmentation
+    from semantic_slam_amd.synth import repack_xyz
+    frames = [make_frame(seed=s, n_boxes=nb) for s, nb in ((0, 32), (1, 12), (2, 32))]
+    seg = PointCloudSegmentation()
+    ref = [seg.segmentallPointCloudData(f.robot_pose, f.cam_angle, f.boxes, f) for f in frames]
+    assert sum(len(x) for x in ref) > 5
+    for step in (12, 16):
+        slim = [repack_xyz(f, step) for f in frames]
+        assert slim[0].cloud.nbytes == step * 640 * 480
+        seg2 = PointCloudSegmentation()
+        for f, r in zip(slim, ref):
+            _same_planes(seg2.segmentallPointCloudData(f.robot_pose, f.cam_angle, f.boxes, f), r)
+        for a, r in zip(PointCloudSegmentation().segment_frames(slim), ref):
+            _same_planes(a, r)
+        got = list(PointCloudSegmentation().segment_stream([slim, slim]))
+        for batch in got:
+            for a, r in zip(batch, ref):
+                _same_planes(a, r)
+
+
 def test_many_boxes_per_call_equal_frame_by_frame(gpu_lib):
     """a call with more boxes than the chip has CUs switches the per-box kernels to their high-residency forms (256-thread plane fit,
     24-row refinement bands); the label images and plane records stay those of the one-frame calls"""
