@@ -105,8 +105,9 @@ int sslam_graph_hessian_index(sslam_graph* g, int id);
  * BASELINE.json north_star).  SOLVER 2 IS S-SCALE ONLY: its preconditioner is block-Jacobi, and on a long pose chain with the reference's
  * odometry information (1 / 0.00001 on the rotation block against 2.5 on a landmark, config/bucket_detector.yaml:22-27) the reduced
  * system needs ~1,050 CG iterations per damping trial at 5000 poses (157 ms, against 1.5 ms for the direct solver) -- it converges to the
- * same optimum (tests: S config) but is not a solver for the L configuration; use 1.  3 = sparse block Cholesky with the window plan (csrc/wchol_plan.hpp: register-resident sliding fronts;
- * correct, leaner in traffic, slower than 1 on today's kernels); "pcg_tol" relative residual; "pcg_max_iters";
+ * same optimum (tests: S config) but is not a solver for the L configuration; use 1.  (3, the window-plan Cholesky of round 3 -- register-resident sliding
+ * fronts, VALU and FP64-MFMA updates; correct, leaner in traffic, 2-2.7x slower -- was removed from the library in round 5; DESIGN.md
+ * section 5 keeps its measurements.)  "pcg_tol" relative residual; "pcg_max_iters";
  * "robust_kernel_dcs" = phi > 0: g2o::RobustKernelDCS(delta = phi) on every landmark edge (EdgeSE3PointXYZ / EdgeSE3Plane), as
  * graph_slam.cpp:155,161 intends (opt-in, phi = 1 is g2o's default delta); 0 = no kernel (default);
  * "fused_small_graph" 1 (default) / 0: a batch of fewer than eight graphs whose elimination tree is narrower than the chip runs the
@@ -164,15 +165,6 @@ int sslam_graph_oplus(sslam_graph* g, const double* dx);
 void* sslam_debug_plan_create(sslam_graph* const* graphs, int n);
 void sslam_debug_plan_destroy(void* plan);
 int64_t sslam_debug_plan_array(void* plan, const char* name, void* out, int64_t cap_bytes);
-/* The window plan (solver 3) executed on the HOST: its own symbolic plan + the per-thread phase functions the HIP kernels are made of, run
- * by a CPU executor (tests/test_wchol_cpu.py pins plan and kernel logic against dense linear algebra without a GPU).  Test hook only: no
- * product entry point reaches it.  Solves (H + lambda[g] I) x = b per graph from a caller-supplied [H || b] buffer (layout of
- * sslam_graph_linearize: H values, padded to an even count, then b).  Size query: with h_and_b / lambda / x_out == NULL it returns the
- * doubles the buffer must hold; otherwise that count on success or a negative SSLAM_ERR_*.  fail_out[n] (optional): 1 where a pivot was
- * not positive.  stats8[8] (optional): segments, steps, window slots, ... of the emulated plan. */
-int64_t sslam_debug_wchol_solve(sslam_graph* const* graphs, int n, const double* h_and_b, int64_t hb_doubles, const double* lambda,
-                                double* x_out, int32_t* fail_out, int64_t* stats8);
-
 /* ---- batched, device-resident form (MI355X extension) ---------------------------------------
  * B independent graphs laid out contiguously in HBM and optimised together: every kernel runs
  * over the union, LM control (rho, lambda, accept/reject) is per graph on the device. */

@@ -112,7 +112,7 @@ inline int blk_doubles(int di, int dj) { return (di * dj + 1) & ~1; }
 constexpr int kItemDoubles = 42;     // LDS doubles per partial tile: 6 x 6 entries + 6 rhs components
 constexpr int kMaxILevels = 64;      // internal levels per piece (LDS table in the kernels)
 
-struct SymGraph { int prow0, nprow, lrow0, nlrow; int pp0 = 0, pp1 = 0, pl0 = 0, pl1 = 0, ll0 = 0, ll1 = 0; };   // pp / pl: the graph's range of ppoff / plblk (wchol_plan.hpp)
+struct SymGraph { int prow0, nprow, lrow0, nlrow; int pp0 = 0, pp1 = 0, pl0 = 0, pl1 = 0, ll0 = 0, ll1 = 0; };   // pp / pl / ll: the graph's range of ppoff / plblk / llblk
 struct SymIn {
   int B = 0, nPr = 0, nLr = 0;
   std::vector<SymGraph> seg;

@@ -16,8 +16,6 @@ namespace sslam {
 
 struct CholPlan;
 void chol_plan_free(CholPlan*);
-struct WPlan;
-void wchol_plan_free(WPlan*);
 void batch_comm_destroy(void* comm);   // ncclCommDestroy
 
 struct KernelTimer {
@@ -103,8 +101,6 @@ struct DevArena {
 struct Batch {
   int device = 0;
   hipStream_t stream = nullptr;
-  hipStream_t aux_stream = nullptr;   // the landmark-row Jacobian kernel runs here, next to the pose-row kernel on `stream` (large batches)
-  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   bool own_stream = true;      // false: the stream belongs to the graph handle and outlives this batch (no create / destroy per structure rebuild)
   std::vector<HostGraph*> graphs;
   std::vector<uint64_t> versions;
@@ -135,7 +131,6 @@ struct Batch {
   std::vector<int> dup_eo, dup_el;
   int max_row_slots = 0;
   CholPlan* chol = nullptr;    // piece plan (chol_plan.hpp): multi right-hand-side solves of the marginals; SSLAM_CHOL_LEGACY=1: the LM loop too
-  WPlan* wchol = nullptr;      // window plan (wchol_plan.hpp): factorisation + solve of the LM loop
   // edge-sharded mode
   bool sharded = false;        // linearize only the edges of this rank's range
   void* comm = nullptr;        // ncclComm_t (RCCL), or null: partial systems are left unsummed (single-device tests)
@@ -147,7 +142,6 @@ struct Batch {
   ~Batch() { release(); }
   void release() {
     if (chol) { chol_plan_free(chol); chol = nullptr; }
-    if (wchol) { wchol_plan_free(wchol); wchol = nullptr; }
     if (comm) { batch_comm_destroy(comm); comm = nullptr; }
     if (stream) { hipSetDevice(device); hipStreamSynchronize(stream); }
     for (auto& p : pending) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
@@ -156,9 +150,6 @@ struct Batch {
     event_pool.clear();
     for (void* p : allocs) hipFree(p);
     allocs.clear();
-    if (aux_stream) { hipStreamSynchronize(aux_stream); hipStreamDestroy(aux_stream); aux_stream = nullptr; }
-    if (ev_fork) { hipEventDestroy(ev_fork); ev_fork = nullptr; }
-    if (ev_join) { hipEventDestroy(ev_join); ev_join = nullptr; }
     if (stream && own_stream) hipStreamDestroy(stream);
     stream = nullptr;
   }
@@ -247,16 +238,5 @@ bool chol_plan_tail_only(const Batch& b);   // every piece of every graph is wal
 int chol_lm_trial_fused(Batch& b, int max_iters);   // one LM iteration (all its damping trials) per graph in one launch, after the linearisation
 int chol_marginal_diag(Batch& b, const std::vector<int>& xoff, const std::vector<int>& dims, double* out36);  // diagonal blocks of H^-1 along the tree paths, one launch
 
-// window multifrontal block Cholesky (sslam_wchol.hip; symbolic phase in wchol_plan.hpp): the solver of the LM loop
-int wchol_plan_build(Batch& b);
-int wchol_factor_and_forward(Batch& b);  // (H + lambda I) = L L^T for in_trial graphs, y = L^-1 b
-int wchol_backward(Batch& b);            // x = L^-T y  -> V.x
-int64_t wchol_plan_lnz(const Batch& b);
-int64_t wchol_plan_unz(const Batch& b);
-int wchol_plan_levels(const Batch& b);
-int wchol_plan_launches(const Batch& b);
-int wchol_plan_segments(const Batch& b);
-// the same plan and the same per-thread phases executed on the host (no device needed): x of (H + lambda I) x = b per graph
-int wchol_emulate(const SymIn& in, const double* Hb, int64_t h_total, const double* lambda, double* x_out, int* fail_out, int64_t* stats);
 
 }  // namespace sslam

@@ -81,7 +81,6 @@ struct BatchView {
   // edges whose graph-local id lies in [shard_lo[g], shard_hi[g]); the partial [H || b] arrays are summed with one all-reduce
   const int* eo_id; const int* el_id;        // graph-local edge id of every SE3 / landmark edge
   const int* shard_lo; const int* shard_hi;  // [B]
-  int dbg = 0;                               // SSLAM_LIN_DBG: timing experiments only (results are wrong when set)
   double dcs_phi = 0.0;                      // > 0: RobustKernelDCS on the landmark edges (chi2 uses rho[0], Omega is scaled by rho[1])
   // PCG vectors
   double* x; double* r; double* z; double* p; double* q; double* Minv;  // Minv: [nPr*36 | nLr*9]

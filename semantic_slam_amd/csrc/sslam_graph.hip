@@ -69,95 +69,54 @@ __device__ __forceinline__ Pose load_pose16(const double* a, int idx) {   // fou
   return Pose{{v0.a, v0.b, v1.a}, {v1.b, v2.a, v2.b, v3.a}};
 }
 
-// What one slot reads from HBM, fetched one slot ahead of its use (the loop below is a two-deep software pipeline: the slot
-// record two iterations ahead, the slot's operands one iteration ahead; with ~300 VGPRs only one wave fits a SIMD, so the
-// memory-level parallelism has to come from inside the thread).
-struct SlotData {
-  double o[8];    // EdgeSE3: the other vertex' pose record; landmark edge: the landmark (4 doubles)
-  double z[7];    // measurement
-  double w[21];   // information, upper triangle (21 / 6 values)
-  int blk, id, lk;
-};
+// Pose-row kernel: every slot (incident edge) of a row evaluated by the row's own thread, contributions summed in slot order.
+// What rounds 2-4 built and measured against it -- all correct, none faster, all removed from the library in round 5 (DESIGN.md section 5
+// keeps the numbers): a hand-over form that evaluates a chain edge once (1.97 vs 2.00 ms per 512-graph build, but it adds the handed block
+// last and LM's accept / reject decisions at convergence follow the last bit of H: 13 extra rejected trials per 20 iterations); two
+// role-specialised waves per 64-row tile (216 VGPRs, two waves per SIMD: 2.23 vs 1.89 ms); EdgeSE3 and landmark slots in two launches
+// (2.52 vs 2.01 ms); a row-wise EdgeSE3 form with 222 VGPRs (2.04 vs 1.96 ms); the kernel compiled for two / three waves per SIMD (50 / 164
+// spilled registers: 2.46 / 4.26 vs 2.12 ms); staged, coalesced block stores, also with the next round's operands requested before the
+// stores (2.06 vs 2.02, 2.09 vs 2.07 ms).  What they established: the build is bound by the life time of ONE wave per SIMD (304 VGPRs: both
+// Jacobians 45, Omega 27, J^T Omega 36, an off-diagonal block 36 doubles) -- instruction issue of a single FP64 wave plus the round trips it
+// cannot overlap -- not by bytes, occupancy alone, or the shape of its stores.
 template <bool PL, bool SHARD>
-__device__ __forceinline__ void slot_fetch(const BatchView& V, const int4 rec, SlotData& D) {
-  const int e = rec.x, kind = rec.y & 15;
-  if (kind == 3) return;                       // contribution arrives by hand-over: nothing to read
-  if (kind != 2) {
-    const D2* p = reinterpret_cast<const D2*>(V.pose + (size_t)(kind == 0 ? rec.w : rec.z) * 8);
-    const D2 v0 = p[0], v1 = p[1], v2 = p[2], v3 = p[3];
-    D.o[0] = v0.a; D.o[1] = v0.b; D.o[2] = v1.a; D.o[3] = v1.b; D.o[4] = v2.a; D.o[5] = v2.b; D.o[6] = v3.a; D.o[7] = v3.b;
-    const size_t n = V.nEo;
-#pragma unroll
-    for (int k = 0; k < 7; ++k) D.z[k] = V.eo_z[k * n + e];
-#pragma unroll
-    for (int k = 0; k < 21; ++k) D.w[k] = V.eo_w[k * n + e];
-    D.blk = kind == 0 ? V.eo_blk[e] : -1;
-    if (SHARD) D.id = V.eo_id[e];
-  } else {
-    const D2* p = reinterpret_cast<const D2*>(V.lmk + (size_t)rec.w * 4);
-    const D2 v0 = p[0], v1 = p[1];
-    D.o[0] = v0.a; D.o[1] = v0.b; D.o[2] = v1.a; D.o[3] = v1.b;
-    const size_t n = V.nEl;
-#pragma unroll
-    for (int k = 0; k < 3; ++k) D.z[k] = V.el_z[k * n + e];
-    if (PL) { D.z[3] = V.el_z[3 * n + e]; D.lk = V.lm_kind[rec.w]; }
-#pragma unroll
-    for (int k = 0; k < 6; ++k) D.w[k] = V.el_w[k * n + e];
-    D.blk = V.el_blk[e];
-    if (SHARD) D.id = V.el_id[e];
-  }
-}
-
-template <bool PL, bool SHARD>
-__global__ __launch_bounds__(kRowThreads) void k_linearize_rowthread_handover(BatchView V) {
-  __shared__ double accD[27][kRowThreads];    // this row's diagonal block (upper triangle) and rhs, thread-private column
-  __shared__ double accIn[27][kRowThreads];   // what the i-side thread of a paired EdgeSE3 hands to the row of its j vertex
+__global__ __launch_bounds__(kRowThreads, 1) void k_linearize_rowthread(BatchView V) {
+  __shared__ double accD[27][kRowThreads];   // this row's diagonal block (upper triangle) and rhs: a thread-private LDS column, conflict free
   const int tid = threadIdx.x;
-  const int row0 = blockIdx.x * kRowThreads;
-  const int row = row0 + tid;
-  const bool active = row < V.nPr && V.lm[V.prow_graph[min(row, V.nPr - 1)]].lin;
+  const int row = blockIdx.x * kRowThreads + tid;
+  if (row >= V.nPr || !V.lm[V.prow_graph[row]].lin) return;
 #pragma unroll
-  for (int k = 0; k < 27; ++k) { accD[k][tid] = 0.0; accIn[k][tid] = 0.0; }
-  if (active) {
+  for (int k = 0; k < 27; ++k) accD[k][tid] = 0.0;
   const int s0 = V.pslot_ptr[row], s1 = V.pslot_ptr[row + 1];
   const int own = V.prow_pose[row];
   const int sh_lo = SHARD ? V.shard_lo[V.prow_graph[row]] : 0, sh_hi = SHARD ? V.shard_hi[V.prow_graph[row]] : 0;
   const Pose Xown = load_pose16(V.pose, own);   // this row's vertex: loaded once, reused by every slot
-  const int4 kNone = make_int4(0, 3, 0, 0);
-  constexpr bool kPrefetch = !PL;   // the plane variant (central-difference Jacobians) has no registers to spare for a slot in flight
-  int4 rec = s0 < s1 ? V.pslot_rec[s0] : kNone;
-  int4 rec_next = s0 + 1 < s1 ? V.pslot_rec[s0 + 1] : kNone;
-  SlotData D;
-  slot_fetch<PL, SHARD>(V, rec, D);
   for (int s = s0; s < s1; ++s) {
-    const int4 rec_next2 = s + 2 < s1 ? V.pslot_rec[s + 2] : kNone;
-    SlotData Dn;
-    if (kPrefetch) slot_fetch<PL, SHARD>(V, rec_next, Dn);
-    int kind = rec.y & 15;
-    if ((V.dbg & 4) && kind != 2) kind = 3;
-    if ((V.dbg & 8) && kind == 2) kind = 3;
-    if (kind == 3) {
-      // the i-side thread of this edge (same workgroup) evaluates it once and hands J_j^T Omega J_j, J_j^T Omega e over
-    } else if (kind != 2) {
+    const int4 rec = V.pslot_rec[s];
+    const int e = rec.x, kind = rec.y & 15, ia = rec.z, ib = rec.w;
+    if (kind != 2) {
       // EdgeSE3: both Jacobians are 2 x 2 block upper triangular in 3 x 3 blocks,
       //   J_i = [[-Ra, 2 Ra [tb]x], [0, Ci]],   J_j = [[Re, 0], [0, Fj]],
       // so J^T Omega J is formed from 3 x 3 products of the blocks (half the FMAs and a smaller live set than dense 6 x 6).
+      const int n = V.nEo;
       const bool iside = (kind == 0);
-      const bool hand = iside && ((rec.y >> 4) & 1);
       Se3Lin L;
-      const Pose Xo{{D.o[0], D.o[1], D.o[2]}, {D.o[3], D.o[4], D.o[5], D.o[6]}};
-      se3_error(iside ? Xown : Xo, iside ? Xo : Xown, Pose{{D.z[0], D.z[1], D.z[2]}, {D.z[3], D.z[4], D.z[5], D.z[6]}}, L);
+      const Pose Xo = load_pose16(V.pose, iside ? ib : ia);
+      const Pose Zm = load_meas_pose(V.eo_z, n, e);
+      se3_error(iside ? Xown : Xo, iside ? Xo : Xown, Zm, L);
       double P[9], Q[9], R[9];   // Omega = [[P, Q], [Q^T, R]]
       // edge-sharded mode: an edge outside this rank's range contributes nothing (everything below is linear in Omega; the owner
       // of an off-diagonal block still writes it, as zeros)
-      const double mk = (!SHARD || (D.id >= sh_lo && D.id < sh_hi)) ? 1.0 : 0.0;
+      const int eid = SHARD ? V.eo_id[e] : 0;
+      const double mk = (!SHARD || (eid >= sh_lo && eid < sh_hi)) ? 1.0 : 0.0;
+      auto w21 = [&](int q) { return V.eo_w[(size_t)q * n + e]; };
 #pragma unroll
       for (int r = 0; r < 3; ++r)
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-          P[r * 3 + c] = mk * D.w[r <= c ? tri21(r, c) : tri21(c, r)];
-          Q[r * 3 + c] = mk * D.w[tri21(r, 3 + c)];
-          R[r * 3 + c] = mk * D.w[r <= c ? tri21(3 + r, 3 + c) : tri21(3 + c, 3 + r)];
+          P[r * 3 + c] = mk * w21(r <= c ? tri21(r, c) : tri21(c, r));
+          Q[r * 3 + c] = mk * w21(tri21(r, 3 + c));
+          R[r * 3 + c] = mk * w21(r <= c ? tri21(3 + r, 3 + c) : tri21(3 + c, 3 + r));
         }
       double A[9], B[9], Cc[9];   // own Jacobian [[A, B], [0, Cc]]  (B = 0 on the j side)
       if (iside) {
@@ -185,40 +144,6 @@ __global__ __launch_bounds__(kRowThreads) void k_linearize_rowthread_handover(Ba
         for (int q = 0; q < 9; ++q) E[q] = Re.m[q];
         F[0] = w; F[1] = -z; F[2] = y; F[3] = z; F[4] = w; F[5] = -x; F[6] = -y; F[7] = x; F[8] = w;
       }
-      if (hand) {
-        // the j side of the same edge, for the neighbouring row:  J_j^T Omega J_j = [[E^T P E, E^T Q F], [., F^T R F]],
-        // J_j^T Omega e = [E^T (P e_t + Q e_r); F^T (Q^T e_t + R e_r)]
-        const int tl = (tid & ~31) | ((rec.y >> 8) & 31);
-        double T1[9], T2[9], T3[9];   // E^T P, E^T Q, F^T R
-#pragma unroll
-        for (int a = 0; a < 3; ++a)
-#pragma unroll
-          for (int c = 0; c < 3; ++c) {
-            double t1 = 0, t2 = 0, t3 = 0;
-#pragma unroll
-            for (int r = 0; r < 3; ++r) { t1 += E[r * 3 + a] * P[r * 3 + c]; t2 += E[r * 3 + a] * Q[r * 3 + c]; t3 += F[r * 3 + a] * R[r * 3 + c]; }
-            T1[a * 3 + c] = t1; T2[a * 3 + c] = t2; T3[a * 3 + c] = t3;
-          }
-#pragma unroll
-        for (int a = 0; a < 3; ++a) {
-#pragma unroll
-          for (int c = 0; c < 3; ++c) {
-            double d11 = 0, d12 = 0, d22 = 0;
-#pragma unroll
-            for (int r = 0; r < 3; ++r) { d11 += T1[a * 3 + r] * E[r * 3 + c]; d12 += T2[a * 3 + r] * F[r * 3 + c]; d22 += T3[a * 3 + r] * F[r * 3 + c]; }
-            if (a <= c) { accIn[tri21(a, c)][tl] = d11; accIn[tri21(3 + a, 3 + c)][tl] = d22; }
-            accIn[tri21(a, 3 + c)][tl] = d12;
-          }
-          accIn[21 + a][tl] = -(T1[a * 3] * L.e[0] + T1[a * 3 + 1] * L.e[1] + T1[a * 3 + 2] * L.e[2] +
-                                T2[a * 3] * L.e[3] + T2[a * 3 + 1] * L.e[4] + T2[a * 3 + 2] * L.e[5]);
-          // F^T Q^T e_t + F^T R e_r
-          double qe0 = Q[0 * 3 + 0] * L.e[0] + Q[1 * 3 + 0] * L.e[1] + Q[2 * 3 + 0] * L.e[2];
-          double qe1 = Q[0 * 3 + 1] * L.e[0] + Q[1 * 3 + 1] * L.e[1] + Q[2 * 3 + 1] * L.e[2];
-          double qe2 = Q[0 * 3 + 2] * L.e[0] + Q[1 * 3 + 2] * L.e[1] + Q[2 * 3 + 2] * L.e[2];
-          accIn[24 + a][tl] = -(F[0 * 3 + a] * qe0 + F[1 * 3 + a] * qe1 + F[2 * 3 + a] * qe2 +
-                                T3[a * 3] * L.e[3] + T3[a * 3 + 1] * L.e[4] + T3[a * 3 + 2] * L.e[5]);
-        }
-      }
       if (!iside) {
 #pragma unroll
         for (int q = 0; q < 9; ++q) { A[q] = E[q]; B[q] = 0.0; Cc[q] = F[q]; }
@@ -243,7 +168,7 @@ __global__ __launch_bounds__(kRowThreads) void k_linearize_rowthread_handover(Ba
           }
           M11[a * 3 + c] = m11; M12[a * 3 + c] = m12; M21[a * 3 + c] = m21; M22[a * 3 + c] = m22;
         }
-      const int blk = (V.dbg & 1) ? -1 : D.blk;
+      const int blk = iside ? V.eo_blk[e] : -1;
       if (blk >= 0) {   // owner of the off-diagonal block: J_i^T Omega J_j = [[M11 E, M12 F], [M21 E, M22 F]]
         double* O = V.Hpp_off + (size_t)(blk >> 1) * 36;
         const bool swapped = blk & 1;
@@ -295,372 +220,27 @@ __global__ __launch_bounds__(kRowThreads) void k_linearize_rowthread_handover(Ba
                              M22[a * 3] * L.e[3] + M22[a * 3 + 1] * L.e[4] + M22[a * 3 + 2] * L.e[5];
       }
     } else {
-      const Pose Xi = Xown;
-      double err[3], Ji[18], Jl[9];   // Ji row-major 3x6, Jl row-major 3x3
-      if (!PL || D.lk == VT_POINT) {
-        PointLin L;
-        point_error(Xi, Vec3{D.o[0], D.o[1], D.o[2]}, Vec3{D.z[0], D.z[1], D.z[2]}, L);
-        point_jacobians(L, Ji, Jl);
-        err[0] = L.e[0]; err[1] = L.e[1]; err[2] = L.e[2];
-      } else {
-        const Plane pw{{D.o[0], D.o[1], D.o[2]}, D.o[3]};
-        const Plane z{{D.z[0], D.z[1], D.z[2]}, D.z[3]};
-        plane_error(Xi, pw, z, err);
-        plane_jacobians(Xi, pw, z, Ji, Jl);
-      }
-      double W[9];
-      W[0] = D.w[0]; W[1] = W[3] = D.w[1]; W[2] = W[6] = D.w[2]; W[4] = D.w[3]; W[5] = W[7] = D.w[4]; W[8] = D.w[5];
-      double dcs = 1.0;
-      if (V.dcs_phi > 0) dcs = dcs_rho1(V.dcs_phi, quad3(W, err));   // from the unmasked Omega: every rank scales its share alike
-      if (SHARD && !(D.id >= sh_lo && D.id < sh_hi)) {
-#pragma unroll
-        for (int q = 0; q < 9; ++q) W[q] = 0.0;
-      }
-      if (V.dcs_phi > 0) {
-#pragma unroll
-        for (int q = 0; q < 9; ++q) W[q] *= dcs;
-      }
-      double WJi[18], We[3];
-#pragma unroll
-      for (int a = 0; a < 3; ++a) {
-        We[a] = W[a * 3 + 0] * err[0] + W[a * 3 + 1] * err[1] + W[a * 3 + 2] * err[2];
-#pragma unroll
-        for (int c = 0; c < 6; ++c) WJi[a * 6 + c] = W[a * 3 + 0] * Ji[c] + W[a * 3 + 1] * Ji[6 + c] + W[a * 3 + 2] * Ji[12 + c];
-      }
-#pragma unroll
-      for (int c = 0; c < 6; ++c) {
-#pragma unroll
-        for (int a = 0; a <= c; ++a) accD[tri21(a, c)][tid] += Ji[a] * WJi[c] + Ji[6 + a] * WJi[6 + c] + Ji[12 + a] * WJi[12 + c];
-        accD[21 + c][tid] -= Ji[c] * We[0] + Ji[6 + c] * We[1] + Ji[12 + c] * We[2];
-      }
-      const int blk = (V.dbg & 1) ? -1 : D.blk;
-      if (blk >= 0) {
-        double WJl[9];
-#pragma unroll
-        for (int a = 0; a < 3; ++a)
-#pragma unroll
-          for (int c = 0; c < 3; ++c) WJl[a * 3 + c] = W[a * 3 + 0] * Jl[c] + W[a * 3 + 1] * Jl[3 + c] + W[a * 3 + 2] * Jl[6 + c];
-        double o[18];
-#pragma unroll
-        for (int a = 0; a < 6; ++a)
-#pragma unroll
-          for (int c = 0; c < 3; ++c) o[a * 3 + c] = Ji[a] * WJl[c] + Ji[6 + a] * WJl[3 + c] + Ji[12 + a] * WJl[6 + c];
-        double* O = V.Hpl + (size_t)blk * 18;
-#pragma unroll
-        for (int k = 0; k < 18; k += 2) store2(O + k, o[k], o[k + 1]);
-      }
-    }
-    rec = rec_next; rec_next = rec_next2;
-    if (kPrefetch) D = Dn; else slot_fetch<PL, SHARD>(V, rec, D);
-  }
-  }
-  __syncthreads();
-  // the workgroup's 64 diagonal blocks and rhs segments are contiguous in HBM: written as one coalesced stream (16-byte
-  // stores, consecutive lanes on consecutive addresses) out of the LDS columns; rows of graphs that are not linearising keep
-  // their previous values
-  const unsigned long long act = (V.dbg & 2) ? 0ull : __ballot(active);
-  if (act == 0ull) return;
-  double* Pd = V.Hpp_diag + (size_t)row0 * 36;
-#pragma unroll 2
-  for (int k = 0; k < 18; ++k) {
-    const int idx = k * kRowThreads + tid;
-    const int r = idx / 18, p = idx - r * 18;
-    const int a = p / 3, c = 2 * (p - 3 * a);
-    if (!((act >> r) & 1ull)) continue;
-    const int t0 = a <= c ? tri21(a, c) : tri21(c, a), t1 = a <= c + 1 ? tri21(a, c + 1) : tri21(c + 1, a);
-    store2(Pd + (size_t)idx * 2, accD[t0][r] + accIn[t0][r], accD[t1][r] + accIn[t1][r]);
-  }
-  double* Bv = V.bvec + (size_t)row0 * 6;
-#pragma unroll
-  for (int k = 0; k < 3; ++k) {
-    const int idx = k * kRowThreads + tid;
-    const int r = idx / 3, p = idx - r * 3;
-    if (!((act >> r) & 1ull)) continue;
-    store2(Bv + (size_t)idx * 2, accD[21 + 2 * p][r] + accIn[21 + 2 * p][r], accD[22 + 2 * p][r] + accIn[22 + 2 * p][r]);
-  }
-}
-
-// Default pose-row kernel: every slot of a row evaluated by the row's own thread, contributions summed in slot order.  The hand-over form
-// above (SSLAM_LIN_HANDOVER=1) evaluates a chain edge once and is as fast (1.97 vs 2.0 ms per 512-graph build), but adds the handed
-// block last; LM's accept / reject decisions at convergence follow the last bit of H, and on the bench's seeds that order costs 13
-// extra rejected trials per 20 iterations.
-// MODE 0: every slot of the row.  MODE 1 / 2 (round 4, SSLAM_LIN_SPLIT): the row's EdgeSE3 slots and its landmark slots in two launches --
-// the EdgeSE3 pass (the register-hungry one, one wave per SIMD) then carries two of a row's five slots, the landmark pass compiles to ~100
-// VGPRs (five waves per SIMD) and adds its sums to the diagonal block and b the first pass wrote.
-// ST (round 4, SSLAM_LIN_STAGE=1): STAGED STORES.  Timing the kernel without its stores (SSLAM_LIN_DBG=16 / 32 / 48: 1.99 -> 1.22 / 1.69 /
-// 0.95 ms per 512-graph build) showed where half of its time goes: not registers, occupancy or arithmetic (four restructurings for those
-// were all slower) but the 66 store instructions of a row.  With ST a slot's block goes to an LDS row of its thread and the WAVE writes
-// the 64 blocks of the slot round together, consecutive lanes on consecutive 16-byte pieces of one block (whole cache lines per
-// request); the diagonal blocks and b of the workgroup's 64 rows, contiguous in HBM, leave as one stream.  Same values, same order of
-// the sums -- and the SAME TIME (2.06 vs 2.02 ms): it is not the shape of the stores either.  Sending the off-diagonal blocks into a
-// 4.7 MB window that never leaves L2 (SSLAM_LIN_DBG=64) takes 0.18 ms off, so HBM writes are not it (a plain 2.77 GB memset runs at
-// 6.3 TB/s on the same box, tools/hbm_write_probe.py).  ST == 2 (SSLAM_LIN_STAGE=3) tested the remaining suspect -- loads and stores
-// retire through one in-order counter (vmcnt), so a store issued in front of the next slot's loads would delay them by its round trip --
-// by requesting a round's inputs (slot_fetch) BEFORE the previous round's staged blocks are stored: 2.09 vs 2.07 ms, refuted as well.
-// What is left is the life time of a wave at ONE wave per SIMD (304 VGPRs): nothing else runs on the SIMD while it waits, and every
-// store instruction adds its issue and its end-of-wave acknowledgement to that life time.  Not fixed this round;
-// per-thread stores stay the default.
-constexpr int kStgStride = 37;   // doubles per staged block row (36 + 1: the per-thread writes spread over the LDS banks)
-template <bool PL, bool SHARD, int WPE, int MODE, int ST>
-__global__ __launch_bounds__(kRowThreads, MODE == 2 ? 4 : WPE) void k_linearize_rowthread(BatchView V) {
-  __shared__ double accD[27][kRowThreads];
-  __shared__ double stg[ST ? kRowThreads * kStgStride : 1];
-  __shared__ double* s_dst[ST ? kRowThreads : 1];
-  __shared__ int s_sz[ST ? kRowThreads : 1];
-  const int tid = threadIdx.x;
-  const int row = blockIdx.x * kRowThreads + tid;
-  const bool active = row < V.nPr && V.lm[V.prow_graph[min(row, V.nPr - 1)]].lin;
-  if (!ST && !active) return;
-#pragma unroll
-  for (int k = 0; k < 27; ++k) accD[k][tid] = 0.0;
-  const int s0 = active ? V.pslot_ptr[row] : 0, s1 = active ? V.pslot_ptr[row + 1] : 0;
-  const int own = V.prow_pose[min(row, V.nPr - 1)];
-  const int sh_lo = SHARD ? V.shard_lo[V.prow_graph[min(row, V.nPr - 1)]] : 0, sh_hi = SHARD ? V.shard_hi[V.prow_graph[min(row, V.nPr - 1)]] : 0;
-  const Pose Xown = load_pose16(V.pose, own);   // this row's vertex: loaded once, reused by every slot
-  bool any_lm = false;
-  int nround = s1 - s0;
-  if (ST) {   // the wave walks its rows' slot lists in lock step: as many rounds as its longest list
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) nround = max(nround, __shfl_xor(nround, o, 64));
-  }
-  // a block of the current slot: to its place in HBM, or (ST) to this thread's staging row
-  double* const my_stg = stg + (ST ? tid * kStgStride : 0);
-  auto put2 = [&](double* O, int k, double x, double y) { if (ST) { my_stg[k] = x; my_stg[k + 1] = y; } else store2(O + k, x, y); };
-  auto put1 = [&](double* O, int k, double x) { if (ST) my_stg[k] = x; else O[k] = x; };
-  constexpr bool EF = (ST == 2);   // early fetch: a round's inputs are requested BEFORE the previous round's staged blocks are stored
-  bool pending = false;            // (EF) the previous round left staged blocks to write (wave-uniform)
-  auto write_staged = [&]() {      // the staged blocks of a round -> HBM, 18 consecutive lanes per 288-byte block
-#pragma unroll 2
-    for (int k = 0; k < 18; ++k) {
-      const int idx = k * kRowThreads + tid;
-      const int r = idx / 18, p2 = 2 * (idx - r * 18);
-      if (p2 < s_sz[r]) store2(s_dst[r] + p2, stg[r * kStgStride + p2], stg[r * kStgStride + p2 + 1]);
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-  };
-  for (int si = 0; si < nround; ++si) {
-    const int s = s0 + si;
-    int stage_sz = 0;
-    double* stage_dst = nullptr;
-    int4 rec = make_int4(0, 0, 0, 0);
-    SlotData D;
-    if (EF) {
-      // loads and stores retire through one in-order counter: a store issued in front of a load delays it by the store's round trip.
-      // So: this round's loads first, THEN the previous round's stores (their acknowledgements arrive during this round's arithmetic).
-      if (s < s1) { rec = V.pslot_rec[s]; slot_fetch<PL, SHARD>(V, make_int4(rec.x, (rec.y & 15) == 3 ? 1 : (rec.y & 15), rec.z, rec.w), D); }
-      asm volatile("" ::: "memory");
-      if (pending) write_staged();
-      asm volatile("" ::: "memory");
-    }
-    if (s < s1) {
-    if (!EF) rec = V.pslot_rec[s];
-    const int e = rec.x, kind = rec.y & 15, ia = rec.z, ib = rec.w;   // kind 3 (hand-over) is evaluated like kind 1 here
-    const bool skip = (MODE == 1 && kind == 2) || (MODE == 2 && kind != 2);
-    if (MODE == 2 && !skip) any_lm = true;
-    if (skip) {
-    } else if (MODE != 2 && kind != 2) {
-      // EdgeSE3: both Jacobians are 2 x 2 block upper triangular in 3 x 3 blocks,
-      //   J_i = [[-Ra, 2 Ra [tb]x], [0, Ci]],   J_j = [[Re, 0], [0, Fj]],
-      // so J^T Omega J is formed from 3 x 3 products of the blocks (half the FMAs and a smaller live set than dense 6 x 6).
-      const int n = V.nEo;
-      const bool iside = (kind == 0);
-      Se3Lin L;
-      const Pose Xo = EF ? Pose{{D.o[0], D.o[1], D.o[2]}, {D.o[3], D.o[4], D.o[5], D.o[6]}} : load_pose16(V.pose, iside ? ib : ia);
-      const Pose Zm = EF ? Pose{{D.z[0], D.z[1], D.z[2]}, {D.z[3], D.z[4], D.z[5], D.z[6]}} : load_meas_pose(V.eo_z, n, e);
-      se3_error(iside ? Xown : Xo, iside ? Xo : Xown, Zm, L);
-      double P[9], Q[9], R[9];   // Omega = [[P, Q], [Q^T, R]]
-      // edge-sharded mode: an edge outside this rank's range contributes nothing (everything below is linear in Omega; the owner
-      // of an off-diagonal block still writes it, as zeros)
-      const int eid = SHARD ? (EF ? D.id : V.eo_id[e]) : 0;
-      const double mk = (!SHARD || (eid >= sh_lo && eid < sh_hi)) ? 1.0 : 0.0;
-      auto w21 = [&](int q) { return EF ? D.w[q] : V.eo_w[(size_t)q * n + e]; };
-#pragma unroll
-      for (int r = 0; r < 3; ++r)
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-          P[r * 3 + c] = mk * w21(r <= c ? tri21(r, c) : tri21(c, r));
-          Q[r * 3 + c] = mk * w21(tri21(r, 3 + c));
-          R[r * 3 + c] = mk * w21(r <= c ? tri21(3 + r, 3 + c) : tri21(3 + c, 3 + r));
-        }
-      double A[9], B[9], Cc[9];   // own Jacobian [[A, B], [0, Cc]]  (B = 0 on the j side)
-      if (iside) {
-        const Vec3 tb = L.tb;
-#pragma unroll
-        for (int r = 0; r < 3; ++r) {
-          const double r0 = L.Ra.m[r * 3], r1 = L.Ra.m[r * 3 + 1], r2 = L.Ra.m[r * 3 + 2];
-          A[r * 3] = -r0; A[r * 3 + 1] = -r1; A[r * 3 + 2] = -r2;
-          B[r * 3 + 0] = 2 * (r1 * tb.z - r2 * tb.y);     // Ra * (0, tz, -ty)
-          B[r * 3 + 1] = 2 * (-r0 * tb.z + r2 * tb.x);    // Ra * (-tz, 0, tx)
-          B[r * 3 + 2] = 2 * (r0 * tb.y - r1 * tb.x);     // Ra * (ty, -tx, 0)
-        }
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-          const Quat vk = {k == 0 ? 1.0 : 0.0, k == 1 ? 1.0 : 0.0, k == 2 ? 1.0 : 0.0, 0.0};
-          const Quat t = qmul(qmul(L.qa, vk), L.qb);
-          Cc[0 * 3 + k] = -L.s * t.x; Cc[1 * 3 + k] = -L.s * t.y; Cc[2 * 3 + k] = -L.s * t.z;
-        }
-      }
-      double E[9], F[9];          // J_j = [[E, 0], [0, F]]
-      {
-        const Mat3 Re = qmat(L.qe);
-        const double w = L.s * L.qe.w, x = L.s * L.qe.x, y = L.s * L.qe.y, z = L.s * L.qe.z;
-#pragma unroll
-        for (int q = 0; q < 9; ++q) E[q] = Re.m[q];
-        F[0] = w; F[1] = -z; F[2] = y; F[3] = z; F[4] = w; F[5] = -x; F[6] = -y; F[7] = x; F[8] = w;
-      }
-      if (!iside) {
-#pragma unroll
-        for (int q = 0; q < 9; ++q) { A[q] = E[q]; B[q] = 0.0; Cc[q] = F[q]; }
-      }
-      if (MODE == 3) {
-        // Row-wise form (SSLAM_LIN_ROWWISE): row a of J^T Omega is formed, used for row a of the off-diagonal block, of the diagonal block and
-        // of b, and dropped -- six live values instead of the 36 of the block form
-        double Wm[21];
-#pragma unroll
-        for (int q = 0; q < 21; ++q) Wm[q] = mk * V.eo_w[(size_t)q * n + e];
-        const int blk = iside ? V.eo_blk[e] : -1;
-        double* O = V.Hpp_off + (size_t)(max(blk, 0) >> 1) * 36;
-        const bool swapped = blk & 1;
-#pragma unroll
-        for (int a = 0; a < 6; ++a) {
-          double Ma[6];
-#pragma unroll
-          for (int c = 0; c < 6; ++c) {
-            double m = 0;
-#pragma unroll
-            for (int r = 0; r < 6; ++r) {
-              // J[r][a]: columns 0-2 = [A; 0], columns 3-5 = [B; Cc]
-              const double w = Wm[r <= c ? tri21(r, c) : tri21(c, r)];
-              if (a < 3) { if (r < 3) m += A[r * 3 + a] * w; }
-              else { if (r < 3) { if (iside) m += B[r * 3 + a - 3] * w; } else m += Cc[(r - 3) * 3 + a - 3] * w; }
-            }
-            Ma[c] = m;
-          }
-          if (blk >= 0) {   // row a of J_i^T Omega J_j,  J_j = [[E, 0], [0, F]]
-            double o[6];
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-              o[c] = Ma[0] * E[c] + Ma[1] * E[3 + c] + Ma[2] * E[6 + c];
-              o[3 + c] = Ma[3] * F[c] + Ma[4] * F[3 + c] + Ma[5] * F[6 + c];
-            }
-            if (!swapped) { put2(O, a * 6, o[0], o[1]); put2(O, a * 6 + 2, o[2], o[3]); put2(O, a * 6 + 4, o[4], o[5]); }
-            else {
-#pragma unroll
-              for (int c = 0; c < 6; ++c) put1(O, c * 6 + a, o[c]);
-            }
-            stage_sz = 36; stage_dst = O;
-          }
-#pragma unroll
-          for (int c = a; c < 6; ++c) {   // row a of J^T Omega J, upper triangle
-            double d = 0;
-            if (c < 3) d = Ma[0] * A[c] + Ma[1] * A[3 + c] + Ma[2] * A[6 + c];
-            else {
-              d = Ma[3] * Cc[c - 3] + Ma[4] * Cc[3 + c - 3] + Ma[5] * Cc[6 + c - 3];
-              if (iside) d += Ma[0] * B[c - 3] + Ma[1] * B[3 + c - 3] + Ma[2] * B[6 + c - 3];
-            }
-            accD[tri21(a, c)][tid] += d;
-          }
-          accD[21 + a][tid] -= Ma[0] * L.e[0] + Ma[1] * L.e[1] + Ma[2] * L.e[2] + Ma[3] * L.e[3] + Ma[4] * L.e[4] + Ma[5] * L.e[5];
-        }
-      } else {
-      // M = J_self^T Omega = [[A^T P, A^T Q], [B^T P + C^T Q^T, B^T Q + C^T R]]
-      double M11[9], M12[9], M21[9], M22[9];
-#pragma unroll
-      for (int a = 0; a < 3; ++a)
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-          double m11 = 0, m12 = 0, m21 = 0, m22 = 0;
-#pragma unroll
-          for (int r = 0; r < 3; ++r) {
-            m11 += A[r * 3 + a] * P[r * 3 + c];
-            m12 += A[r * 3 + a] * Q[r * 3 + c];
-            m21 += Cc[r * 3 + a] * Q[c * 3 + r];
-            m22 += Cc[r * 3 + a] * R[r * 3 + c];
-          }
-          if (iside) {
-#pragma unroll
-            for (int r = 0; r < 3; ++r) { m21 += B[r * 3 + a] * P[r * 3 + c]; m22 += B[r * 3 + a] * Q[r * 3 + c]; }
-          }
-          M11[a * 3 + c] = m11; M12[a * 3 + c] = m12; M21[a * 3 + c] = m21; M22[a * 3 + c] = m22;
-        }
-      const int blk = (iside && !(V.dbg & 16)) ? (EF ? D.blk : V.eo_blk[e]) : -1;   // (SSLAM_LIN_DBG & 16: timing only, no off-diagonal stores)
-      if (blk >= 0) {   // owner of the off-diagonal block: J_i^T Omega J_j = [[M11 E, M12 F], [M21 E, M22 F]]
-        double* O = V.Hpp_off + ((V.dbg & 64) ? (size_t)(tid + 64 * (blockIdx.x & 255)) : (size_t)(blk >> 1)) * 36;   // (dbg 64: timing only, every block into a 4.7 MB window)
-        const bool swapped = blk & 1;
-        double o[36];
-#pragma unroll
-        for (int a = 0; a < 3; ++a)
-#pragma unroll
-          for (int c = 0; c < 3; ++c) {
-            double o11 = 0, o12 = 0, o21 = 0, o22 = 0;
-#pragma unroll
-            for (int r = 0; r < 3; ++r) {
-              o11 += M11[a * 3 + r] * E[r * 3 + c]; o12 += M12[a * 3 + r] * F[r * 3 + c];
-              o21 += M21[a * 3 + r] * E[r * 3 + c]; o22 += M22[a * 3 + r] * F[r * 3 + c];
-            }
-            o[a * 6 + c] = o11; o[a * 6 + 3 + c] = o12; o[(3 + a) * 6 + c] = o21; o[(3 + a) * 6 + 3 + c] = o22;
-          }
-        if (!swapped) {   // stored [row_i][row_j]
-#pragma unroll
-          for (int k = 0; k < 36; k += 2) put2(O, k, o[k], o[k + 1]);
-        } else {          // stored transposed
-#pragma unroll
-          for (int c = 0; c < 6; ++c)
-#pragma unroll
-            for (int a = 0; a < 6; a += 2) put2(O, c * 6 + a, o[a * 6 + c], o[(a + 1) * 6 + c]);
-        }
-        stage_sz = 36; stage_dst = O;
-      }
-      // diagonal block J^T Omega J (upper triangle) and b -= J^T Omega e
-#pragma unroll
-      for (int a = 0; a < 3; ++a) {
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-          double d11 = 0, d12 = 0, d22 = 0;
-#pragma unroll
-          for (int r = 0; r < 3; ++r) {
-            d11 += M11[a * 3 + r] * A[r * 3 + c];
-            d12 += M12[a * 3 + r] * Cc[r * 3 + c];
-            d22 += M22[a * 3 + r] * Cc[r * 3 + c];
-          }
-          if (iside) {
-#pragma unroll
-            for (int r = 0; r < 3; ++r) { d12 += M11[a * 3 + r] * B[r * 3 + c]; d22 += M21[a * 3 + r] * B[r * 3 + c]; }
-          }
-          if (a <= c) { accD[tri21(a, c)][tid] += d11; accD[tri21(3 + a, 3 + c)][tid] += d22; }
-          accD[tri21(a, 3 + c)][tid] += d12;
-        }
-        accD[21 + a][tid] -= M11[a * 3] * L.e[0] + M11[a * 3 + 1] * L.e[1] + M11[a * 3 + 2] * L.e[2] +
-                             M12[a * 3] * L.e[3] + M12[a * 3 + 1] * L.e[4] + M12[a * 3 + 2] * L.e[5];
-        accD[24 + a][tid] -= M21[a * 3] * L.e[0] + M21[a * 3 + 1] * L.e[1] + M21[a * 3 + 2] * L.e[2] +
-                             M22[a * 3] * L.e[3] + M22[a * 3 + 1] * L.e[4] + M22[a * 3 + 2] * L.e[5];
-      }
-      }
-    } else {
       const int n = V.nEl;
       const Pose Xi = Xown;
       const double* lp = V.lmk + (size_t)ib * 4;
-      auto lpv = [&](int k) { return EF ? D.o[k] : lp[k]; };
-      auto zl = [&](int k) { return EF ? D.z[k] : V.el_z[k * (size_t)n + e]; };
+      auto zl = [&](int k) { return V.el_z[k * (size_t)n + e]; };
       double err[3], Ji[18], Jl[9];   // Ji row-major 3x6, Jl row-major 3x3
-      if (!PL || (EF ? D.lk : V.lm_kind[ib]) == VT_POINT) {
+      if (!PL || V.lm_kind[ib] == VT_POINT) {
         PointLin L;
-        point_error(Xi, Vec3{lpv(0), lpv(1), lpv(2)}, Vec3{zl(0), zl(1), zl(2)}, L);
+        point_error(Xi, Vec3{lp[0], lp[1], lp[2]}, Vec3{zl(0), zl(1), zl(2)}, L);
         point_jacobians(L, Ji, Jl);
         err[0] = L.e[0]; err[1] = L.e[1]; err[2] = L.e[2];
       } else {
-        const Plane pw{{lpv(0), lpv(1), lpv(2)}, lpv(3)};
+        const Plane pw{{lp[0], lp[1], lp[2]}, lp[3]};
         const Plane z{{zl(0), zl(1), zl(2)}, zl(3)};
         plane_error(Xi, pw, z, err);
         plane_jacobians(Xi, pw, z, Ji, Jl);
       }
       double W[9];
-      if (EF) { W[0] = D.w[0]; W[1] = W[3] = D.w[1]; W[2] = W[6] = D.w[2]; W[4] = D.w[3]; W[5] = W[7] = D.w[4]; W[8] = D.w[5]; }
-      else load_sym3(V.el_w, n, e, W);
+      load_sym3(V.el_w, n, e, W);
       double dcs = 1.0;
       if (V.dcs_phi > 0) dcs = dcs_rho1(V.dcs_phi, quad3(W, err));   // from the unmasked Omega: every rank scales its share alike
-      const int lid = SHARD ? (EF ? D.id : V.el_id[e]) : 0;
+      const int lid = SHARD ? V.el_id[e] : 0;
       if (SHARD && !(lid >= sh_lo && lid < sh_hi)) {
 #pragma unroll
         for (int q = 0; q < 9; ++q) W[q] = 0.0;
@@ -682,7 +262,7 @@ __global__ __launch_bounds__(kRowThreads, MODE == 2 ? 4 : WPE) void k_linearize_
         for (int a = 0; a <= c; ++a) accD[tri21(a, c)][tid] += Ji[a] * WJi[c] + Ji[6 + a] * WJi[6 + c] + Ji[12 + a] * WJi[12 + c];
         accD[21 + c][tid] -= Ji[c] * We[0] + Ji[6 + c] * We[1] + Ji[12 + c] * We[2];
       }
-      const int blk = (V.dbg & 16) ? -1 : (EF ? D.blk : V.el_blk[e]);
+      const int blk = V.el_blk[e];
       if (blk >= 0) {
         double WJl[9];
 #pragma unroll
@@ -694,66 +274,14 @@ __global__ __launch_bounds__(kRowThreads, MODE == 2 ? 4 : WPE) void k_linearize_
         for (int a = 0; a < 6; ++a)
 #pragma unroll
           for (int c = 0; c < 3; ++c) o[a * 3 + c] = Ji[a] * WJl[c] + Ji[6 + a] * WJl[3 + c] + Ji[12 + a] * WJl[6 + c];
-        double* O = V.Hpl + ((V.dbg & 64) ? (size_t)(tid + 64 * (blockIdx.x & 255)) : (size_t)blk) * 18;
+        double* O = V.Hpl + (size_t)blk * 18;
 #pragma unroll
-        for (int k = 0; k < 18; k += 2) put2(O, k, o[k], o[k + 1]);
-        stage_sz = 18; stage_dst = O;
+        for (int k = 0; k < 18; k += 2) store2(O + k, o[k], o[k + 1]);
       }
     }
-    }   // s < s1
-    if (ST) {
-      pending = __ballot(stage_sz > 0) != 0ull;
-      if (pending) {
-        s_dst[tid] = stage_dst; s_sz[tid] = stage_sz;
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        if (!EF) write_staged();   // (EF: after the next round's loads have been issued)
-      }
-    }
-  }
-  if (EF && pending) write_staged();
-  if (V.dbg & 32) return;   // (SSLAM_LIN_DBG & 32: timing only, no diagonal-block stores)
-  if (ST) {
-    // the workgroup's 64 diagonal blocks and rhs segments are contiguous in HBM: one coalesced stream out of the LDS columns; rows of
-    // graphs that are not linearising keep their previous values
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    const unsigned long long act = __ballot(active);
-    const int row0 = blockIdx.x * kRowThreads;
-    double* Pd = V.Hpp_diag + (size_t)row0 * 36;
-#pragma unroll 2
-    for (int k = 0; k < 18; ++k) {
-      const int idx = k * kRowThreads + tid;
-      const int r = idx / 18, p = idx - r * 18;
-      const int a = p / 3, c = 2 * (p - 3 * a);
-      if (!((act >> r) & 1ull)) continue;
-      store2(Pd + (size_t)idx * 2, accD[a <= c ? tri21(a, c) : tri21(c, a)][r], accD[a <= c + 1 ? tri21(a, c + 1) : tri21(c + 1, a)][r]);
-    }
-    double* Bs = V.bvec + (size_t)row0 * 6;
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-      const int idx = k * kRowThreads + tid;
-      const int r = idx / 3, p = idx - r * 3;
-      if (!((act >> r) & 1ull)) continue;
-      store2(Bs + (size_t)idx * 2, accD[21 + 2 * p][r], accD[22 + 2 * p][r]);
-    }
-    return;
   }
   double* P = V.Hpp_diag + (size_t)row * 36;
   double* Bv = V.bvec + (size_t)row * 6;
-  if (MODE == 2) {   // add the landmark slots' sums to what the EdgeSE3 pass stored (both triangles get the same sums: the block stays symmetric)
-    if (!any_lm) return;
-#pragma unroll
-    for (int a = 0; a < 6; ++a)
-#pragma unroll
-      for (int c = 0; c < 6; c += 2) {
-        const D2 o = *reinterpret_cast<const D2*>(P + a * 6 + c);
-        store2(P + a * 6 + c, o.a + accD[a <= c ? tri21(a, c) : tri21(c, a)][tid], o.b + accD[a <= c + 1 ? tri21(a, c + 1) : tri21(c + 1, a)][tid]);
-      }
-#pragma unroll
-    for (int c = 0; c < 6; c += 2) { const D2 o = *reinterpret_cast<const D2*>(Bv + c); store2(Bv + c, o.a + accD[21 + c][tid], o.b + accD[22 + c][tid]); }
-    return;
-  }
 #pragma unroll
   for (int a = 0; a < 6; ++a)
 #pragma unroll
@@ -761,287 +289,6 @@ __global__ __launch_bounds__(kRowThreads, MODE == 2 ? 4 : WPE) void k_linearize_
       store2(P + a * 6 + c, accD[a <= c ? tri21(a, c) : tri21(c, a)][tid], accD[a <= c + 1 ? tri21(a, c + 1) : tri21(c + 1, a)][tid]);
 #pragma unroll
   for (int c = 0; c < 6; c += 2) store2(Bv + c, accD[21 + c][tid], accD[22 + c][tid]);
-}
-
-// ---- pose rows, two waves per tile of 64 rows (round 4) -------------------------------------------------------------------------
-// The one-thread-per-row kernel above holds J_i^T Omega (36), both Jacobians (45), Omega (27) and an off-diagonal block (36) of an EdgeSE3
-// in registers: 304 VGPRs, ONE wave per SIMD, and the build is bound by what a single resident wave can keep in flight.  Here a tile of 64
-// pose rows is worked by TWO waves with wave-uniform roles (no divergence: each role is its own instantiation): role r owns block row r
-// (scalar rows 3r .. 3r+2) of everything the pose row produces --
-//   EdgeSE3:      M_r = (J^T Omega)_r (3 x 6 instead of 6 x 6), rows 3r.. of the off-diagonal block  M_r J_j,  H_ii(r, >= r),  b_i(r)
-//   landmark edge: rows 3r.. of H_pl = (J_i^T W)_r J_l,  H_ii(r, >= r),  b_i(r)
-// -- so that neither wave needs more than half of the products, role 1 never forms -R_a and role 0 never reads the rotation block of
-// Omega.  Both accumulate into the same thread-private LDS columns as before (disjoint entries), contributions in slot order: the same
-// sums, entry for entry, as the one-thread form.  MEASURED (512 L graphs, same box): 216 VGPRs and two waves per SIMD as intended, H / b
-// equal to the oracle, but 2.23 ms per build against 1.89 ms for the one-thread kernel (3.18 ms when forced to three waves per SIMD: 82
-// spilled registers) -- both roles still evaluate the edge's error and Jacobian blocks, so a tile costs two waves ~70 % of the one-thread
-// work each.  Kept selectable (SSLAM_LIN_PAIR=1); the one-thread kernel stays the default.
-template <bool PL, bool SHARD, int ROLE>
-__device__ __forceinline__ void rowpair_slots(const BatchView& V, const int row, const int tid, double (*accD)[kRowThreads]) {
-  const int s0 = V.pslot_ptr[row], s1 = V.pslot_ptr[row + 1];
-  const int own = V.prow_pose[row];
-  const int sh_lo = SHARD ? V.shard_lo[V.prow_graph[row]] : 0, sh_hi = SHARD ? V.shard_hi[V.prow_graph[row]] : 0;
-  const Pose Xown = load_pose16(V.pose, own);
-  for (int s = s0; s < s1; ++s) {
-    const int4 rec = V.pslot_rec[s];
-    const int e = rec.x, kind = rec.y & 15, ia = rec.z, ib = rec.w;
-    if (kind != 2) {
-      const int n = V.nEo;
-      const bool iside = (kind == 0);
-      Se3Lin L;
-      se3_error(iside ? Xown : load_pose16(V.pose, ia), iside ? load_pose16(V.pose, ib) : Xown, load_meas_pose(V.eo_z, n, e), L);
-      const double mk = (!SHARD || (V.eo_id[e] >= sh_lo && V.eo_id[e] < sh_hi)) ? 1.0 : 0.0;
-      // J_j = [[E, 0], [0, F]]
-      double E[9], F[9];
-      {
-        const Mat3 Re = qmat(L.qe);
-        const double w = L.s * L.qe.w, x = L.s * L.qe.x, y = L.s * L.qe.y, z = L.s * L.qe.z;
-#pragma unroll
-        for (int q = 0; q < 9; ++q) E[q] = Re.m[q];
-        F[0] = w; F[1] = -z; F[2] = y; F[3] = z; F[4] = w; F[5] = -x; F[6] = -y; F[7] = x; F[8] = w;
-      }
-      // own Jacobian [[A, B], [0, Cc]]: the i side of the edge, or J_j itself on the j side
-      double A[9], B[9], Cc[9];
-      if (iside) {
-        const Vec3 tb = L.tb;
-#pragma unroll
-        for (int r = 0; r < 3; ++r) {
-          const double r0 = L.Ra.m[r * 3], r1 = L.Ra.m[r * 3 + 1], r2 = L.Ra.m[r * 3 + 2];
-          if (ROLE == 0) { A[r * 3] = -r0; A[r * 3 + 1] = -r1; A[r * 3 + 2] = -r2; }
-          B[r * 3 + 0] = 2 * (r1 * tb.z - r2 * tb.y);
-          B[r * 3 + 1] = 2 * (-r0 * tb.z + r2 * tb.x);
-          B[r * 3 + 2] = 2 * (r0 * tb.y - r1 * tb.x);
-        }
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-          const Quat vk = {k == 0 ? 1.0 : 0.0, k == 1 ? 1.0 : 0.0, k == 2 ? 1.0 : 0.0, 0.0};
-          const Quat t = qmul(qmul(L.qa, vk), L.qb);
-          Cc[0 * 3 + k] = -L.s * t.x; Cc[1 * 3 + k] = -L.s * t.y; Cc[2 * 3 + k] = -L.s * t.z;
-        }
-      } else {
-#pragma unroll
-        for (int q = 0; q < 9; ++q) { if (ROLE == 0) A[q] = E[q]; B[q] = 0.0; Cc[q] = F[q]; }
-      }
-      const int blk = iside ? V.eo_blk[e] : -1;
-      double* O = V.Hpp_off + (size_t)(max(blk, 0) >> 1) * 36;
-      const bool swapped = blk & 1;
-      if (ROLE == 0) {
-        // M_0 = [A^T P, A^T Q]
-        double P[9], Q[9], M1[9], M2[9];
-#pragma unroll
-        for (int r = 0; r < 3; ++r)
-#pragma unroll
-          for (int c = 0; c < 3; ++c) {
-            P[r * 3 + c] = mk * V.eo_w[(size_t)(r <= c ? tri21(r, c) : tri21(c, r)) * n + e];
-            Q[r * 3 + c] = mk * V.eo_w[(size_t)tri21(r, 3 + c) * n + e];
-          }
-#pragma unroll
-        for (int a = 0; a < 3; ++a)
-#pragma unroll
-          for (int c = 0; c < 3; ++c) {
-            double m11 = 0, m12 = 0;
-#pragma unroll
-            for (int r = 0; r < 3; ++r) { m11 += A[r * 3 + a] * P[r * 3 + c]; m12 += A[r * 3 + a] * Q[r * 3 + c]; }
-            M1[a * 3 + c] = m11; M2[a * 3 + c] = m12;
-          }
-        if (blk >= 0) {   // rows 0..2 of J_i^T Omega J_j = [M11 E, M12 F]
-#pragma unroll
-          for (int a = 0; a < 3; ++a) {
-            double o[6];
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-              double o1 = 0, o2 = 0;
-#pragma unroll
-              for (int r = 0; r < 3; ++r) { o1 += M1[a * 3 + r] * E[r * 3 + c]; o2 += M2[a * 3 + r] * F[r * 3 + c]; }
-              o[c] = o1; o[3 + c] = o2;
-            }
-            if (!swapped) { store2(O + a * 6, o[0], o[1]); store2(O + a * 6 + 2, o[2], o[3]); store2(O + a * 6 + 4, o[4], o[5]); }
-            else {
-#pragma unroll
-              for (int c = 0; c < 6; ++c) O[c * 6 + a] = o[c];
-            }
-          }
-        }
-#pragma unroll
-        for (int a = 0; a < 3; ++a) {
-#pragma unroll
-          for (int c = 0; c < 3; ++c) {
-            double d11 = 0, d12 = 0;
-#pragma unroll
-            for (int r = 0; r < 3; ++r) { d11 += M1[a * 3 + r] * A[r * 3 + c]; d12 += M2[a * 3 + r] * Cc[r * 3 + c]; }
-            if (iside) {
-#pragma unroll
-              for (int r = 0; r < 3; ++r) d12 += M1[a * 3 + r] * B[r * 3 + c];
-            }
-            if (a <= c) accD[tri21(a, c)][tid] += d11;
-            accD[tri21(a, 3 + c)][tid] += d12;
-          }
-          accD[21 + a][tid] -= M1[a * 3] * L.e[0] + M1[a * 3 + 1] * L.e[1] + M1[a * 3 + 2] * L.e[2] +
-                               M2[a * 3] * L.e[3] + M2[a * 3 + 1] * L.e[4] + M2[a * 3 + 2] * L.e[5];
-        }
-      } else {
-        // M_1 = [B^T P + C^T Q^T, B^T Q + C^T R]
-        double Q[9], R[9], M1[9], M2[9];
-#pragma unroll
-        for (int r = 0; r < 3; ++r)
-#pragma unroll
-          for (int c = 0; c < 3; ++c) {
-            Q[r * 3 + c] = mk * V.eo_w[(size_t)tri21(r, 3 + c) * n + e];
-            R[r * 3 + c] = mk * V.eo_w[(size_t)(r <= c ? tri21(3 + r, 3 + c) : tri21(3 + c, 3 + r)) * n + e];
-          }
-#pragma unroll
-        for (int a = 0; a < 3; ++a)
-#pragma unroll
-          for (int c = 0; c < 3; ++c) {
-            double m21 = 0, m22 = 0;
-#pragma unroll
-            for (int r = 0; r < 3; ++r) { m21 += Cc[r * 3 + a] * Q[c * 3 + r]; m22 += Cc[r * 3 + a] * R[r * 3 + c]; }
-            M1[a * 3 + c] = m21; M2[a * 3 + c] = m22;
-          }
-        if (iside) {
-          double P[9];
-#pragma unroll
-          for (int r = 0; r < 3; ++r)
-#pragma unroll
-            for (int c = 0; c < 3; ++c) P[r * 3 + c] = mk * V.eo_w[(size_t)(r <= c ? tri21(r, c) : tri21(c, r)) * n + e];
-#pragma unroll
-          for (int a = 0; a < 3; ++a)
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-              double m21 = M1[a * 3 + c], m22 = M2[a * 3 + c];
-#pragma unroll
-              for (int r = 0; r < 3; ++r) { m21 += B[r * 3 + a] * P[r * 3 + c]; m22 += B[r * 3 + a] * Q[r * 3 + c]; }
-              M1[a * 3 + c] = m21; M2[a * 3 + c] = m22;
-            }
-        }
-        if (blk >= 0) {   // rows 3..5 of J_i^T Omega J_j = [M21 E, M22 F]
-#pragma unroll
-          for (int a = 0; a < 3; ++a) {
-            double o[6];
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-              double o1 = 0, o2 = 0;
-#pragma unroll
-              for (int r = 0; r < 3; ++r) { o1 += M1[a * 3 + r] * E[r * 3 + c]; o2 += M2[a * 3 + r] * F[r * 3 + c]; }
-              o[c] = o1; o[3 + c] = o2;
-            }
-            if (!swapped) { store2(O + (3 + a) * 6, o[0], o[1]); store2(O + (3 + a) * 6 + 2, o[2], o[3]); store2(O + (3 + a) * 6 + 4, o[4], o[5]); }
-            else {
-#pragma unroll
-              for (int c = 0; c < 6; ++c) O[c * 6 + 3 + a] = o[c];
-            }
-          }
-        }
-#pragma unroll
-        for (int a = 0; a < 3; ++a) {
-#pragma unroll
-          for (int c = 0; c < 3; ++c) {
-            if (a > c) continue;
-            double d22 = 0;
-#pragma unroll
-            for (int r = 0; r < 3; ++r) d22 += M2[a * 3 + r] * Cc[r * 3 + c];
-            if (iside) {
-#pragma unroll
-              for (int r = 0; r < 3; ++r) d22 += M1[a * 3 + r] * B[r * 3 + c];
-            }
-            accD[tri21(3 + a, 3 + c)][tid] += d22;
-          }
-          accD[24 + a][tid] -= M1[a * 3] * L.e[0] + M1[a * 3 + 1] * L.e[1] + M1[a * 3 + 2] * L.e[2] +
-                               M2[a * 3] * L.e[3] + M2[a * 3 + 1] * L.e[4] + M2[a * 3 + 2] * L.e[5];
-        }
-      }
-    } else {
-      const int n = V.nEl;
-      const double* lp = V.lmk + (size_t)ib * 4;
-      double err[3], Ji[18], Jl[9];
-      if (!PL || V.lm_kind[ib] == VT_POINT) {
-        PointLin L;
-        point_error(Xown, Vec3{lp[0], lp[1], lp[2]}, Vec3{V.el_z[0 * (size_t)n + e], V.el_z[1 * (size_t)n + e], V.el_z[2 * (size_t)n + e]}, L);
-        point_jacobians(L, Ji, Jl);
-        err[0] = L.e[0]; err[1] = L.e[1]; err[2] = L.e[2];
-      } else {
-        const Plane pw{{lp[0], lp[1], lp[2]}, lp[3]};
-        const Plane z{{V.el_z[0 * (size_t)n + e], V.el_z[1 * (size_t)n + e], V.el_z[2 * (size_t)n + e]}, V.el_z[3 * (size_t)n + e]};
-        plane_error(Xown, pw, z, err);
-        plane_jacobians(Xown, pw, z, Ji, Jl);
-      }
-      double W[9];
-      load_sym3(V.el_w, n, e, W);
-      double dcs = 1.0;
-      if (V.dcs_phi > 0) dcs = dcs_rho1(V.dcs_phi, quad3(W, err));
-      if (SHARD && !(V.el_id[e] >= sh_lo && V.el_id[e] < sh_hi)) {
-#pragma unroll
-        for (int q = 0; q < 9; ++q) W[q] = 0.0;
-      }
-      if (V.dcs_phi > 0) {
-#pragma unroll
-        for (int q = 0; q < 9; ++q) W[q] *= dcs;
-      }
-      double WJi[18], We[3];
-#pragma unroll
-      for (int a = 0; a < 3; ++a) {
-        We[a] = W[a * 3 + 0] * err[0] + W[a * 3 + 1] * err[1] + W[a * 3 + 2] * err[2];
-#pragma unroll
-        for (int c = 0; c < 6; ++c) WJi[a * 6 + c] = W[a * 3 + 0] * Ji[c] + W[a * 3 + 1] * Ji[6 + c] + W[a * 3 + 2] * Ji[12 + c];
-      }
-#pragma unroll
-      for (int c = 0; c < 6; ++c) {
-#pragma unroll
-        for (int a = 3 * ROLE; a < 3 * ROLE + 3; ++a)
-          if (a <= c) accD[tri21(a, c)][tid] += Ji[a] * WJi[c] + Ji[6 + a] * WJi[6 + c] + Ji[12 + a] * WJi[12 + c];
-      }
-#pragma unroll
-      for (int c = 3 * ROLE; c < 3 * ROLE + 3; ++c) accD[21 + c][tid] -= Ji[c] * We[0] + Ji[6 + c] * We[1] + Ji[12 + c] * We[2];
-      const int blk = V.el_blk[e];
-      if (blk >= 0) {
-        double WJl[9];
-#pragma unroll
-        for (int a = 0; a < 3; ++a)
-#pragma unroll
-          for (int c = 0; c < 3; ++c) WJl[a * 3 + c] = W[a * 3 + 0] * Jl[c] + W[a * 3 + 1] * Jl[3 + c] + W[a * 3 + 2] * Jl[6 + c];
-        double o[9];
-#pragma unroll
-        for (int a = 0; a < 3; ++a)
-#pragma unroll
-          for (int c = 0; c < 3; ++c) { const int ar = 3 * ROLE + a; o[a * 3 + c] = Ji[ar] * WJl[c] + Ji[6 + ar] * WJl[3 + c] + Ji[12 + ar] * WJl[6 + c]; }
-        double* O = V.Hpl + (size_t)blk * 18 + 9 * ROLE;   // rows 3 ROLE .. of the 6 x 3 block: doubles 0..8 | 9..17
-        if (ROLE == 0) { store2(O, o[0], o[1]); store2(O + 2, o[2], o[3]); store2(O + 4, o[4], o[5]); store2(O + 6, o[6], o[7]); O[8] = o[8]; }
-        else { O[0] = o[0]; store2(O + 1, o[1], o[2]); store2(O + 3, o[3], o[4]); store2(O + 5, o[5], o[6]); store2(O + 7, o[7], o[8]); }
-      }
-    }
-  }
-}
-
-template <bool PL, bool SHARD, int WPE>
-__global__ __launch_bounds__(2 * kRowThreads, WPE) void k_linearize_rowpair(BatchView V) {
-  __shared__ double accD[27][kRowThreads];
-  const int tid = threadIdx.x & (kRowThreads - 1);
-  const int role = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform
-  const int row = blockIdx.x * kRowThreads + tid;
-  const bool live = row < V.nPr && V.lm[V.prow_graph[min(row, V.nPr - 1)]].lin;
-  if (role == 0) {
-#pragma unroll
-    for (int k = 0; k < 15; ++k) accD[k][tid] = 0.0;
-    accD[21][tid] = 0.0; accD[22][tid] = 0.0; accD[23][tid] = 0.0;
-    if (live) rowpair_slots<PL, SHARD, 0>(V, row, tid, accD);
-  } else {
-#pragma unroll
-    for (int k = 15; k < 21; ++k) accD[k][tid] = 0.0;
-    accD[24][tid] = 0.0; accD[25][tid] = 0.0; accD[26][tid] = 0.0;
-    if (live) rowpair_slots<PL, SHARD, 1>(V, row, tid, accD);
-  }
-  __syncthreads();
-  if (!live) return;
-  double* P = V.Hpp_diag + (size_t)row * 36 + 18 * role;   // rows 3 role .. 3 role + 2 of the diagonal block
-#pragma unroll
-  for (int a3 = 0; a3 < 3; ++a3) {
-    const int a = 3 * role + a3;
-    for (int c = 0; c < 6; c += 2)
-      store2(P + a3 * 6 + c, accD[a <= c ? tri21(a, c) : tri21(c, a)][tid], accD[a <= c + 1 ? tri21(a, c + 1) : tri21(c + 1, a)][tid]);
-  }
-  double* Bv = V.bvec + (size_t)row * 6;
-  if (role == 0) { store2(Bv, accD[21][tid], accD[22][tid]); Bv[2] = accD[23][tid]; }
-  else { Bv[3] = accD[24][tid]; store2(Bv + 4, accD[25][tid], accD[26][tid]); }
 }
 
 // landmark rows: 16 lanes per landmark, each lane walks a strided subset of the incident edges,
@@ -1805,25 +1052,13 @@ static int batch_build(Batch& b, bool host_only = false) {
   std::vector<int> pslot_ptr(nPr + 1, 0), pslot_edge, lslot_ptr(nLr + 1, 0), lslot_edge, tile_row0, tile_row1;
   std::vector<unsigned char> pslot_kind;
   b.max_row_slots = 0;
-  // record.y = kind | (flags << 4) | (local target row << 8):  flag 1 on an i-side slot = also produce the
-  // j-side contribution (D_jj column, b_j) of this edge and hand it to local row (y >> 8) of the same
-  // 32-row workgroup; kind 3 = j-side slot whose contribution arrives that way (not evaluated again)
+  // record = {edge, kind (0: EdgeSE3 seen from its i side, 1: from its j side, 2: landmark edge), vertex i | pose, vertex j | landmark}
   std::vector<int4> pslot_rec;
-  std::vector<char> paired_edge(nEo, 0), row_taken(nPr, 0);   // at most one hand-over per receiving row
-  for (int k = 0; k < nEo; ++k) {
-    const int ri = b.pose_row[eo_i[k]], rj = b.pose_row[eo_j[k]];
-    if (ri >= 0 && rj == ri + 1 && (ri >> 5) == (rj >> 5) && prow_graph[ri] == prow_graph[rj] && !row_taken[rj]) { paired_edge[k] = 1; row_taken[rj] = 1; }
-  }
   for (int r = 0; r < nPr; ++r) {
     for (auto& s : pslots[r]) {
       pslot_edge.push_back(s.first); pslot_kind.push_back(s.second);
-      if (s.second < 2) {
-        const int rj = b.pose_row[eo_j[s.first]];
-        const bool paired = paired_edge[s.first] != 0;
-        int kind = s.second;
-        if (paired) kind = s.second == 0 ? (0 | (1 << 4) | ((rj & 31) << 8)) : 3;
-        pslot_rec.push_back(make_int4(s.first, kind, eo_i[s.first], eo_j[s.first]));
-      } else pslot_rec.push_back(make_int4(s.first, 2, el_p[s.first], el_l[s.first]));
+      if (s.second < 2) pslot_rec.push_back(make_int4(s.first, s.second, eo_i[s.first], eo_j[s.first]));
+      else pslot_rec.push_back(make_int4(s.first, 2, el_p[s.first], el_l[s.first]));
     }
     pslot_ptr[r + 1] = (int)pslot_edge.size();
     b.max_row_slots = std::max(b.max_row_slots, (int)pslots[r].size());
@@ -2027,61 +1262,14 @@ static int batch_linearize(Batch& b) {
   b.V.dcs_phi = b.graphs[0]->opt.dcs_phi;   // read live like pcg_tol / solver: an option set after the batch was built must not be ignored
   const BatchView& V = b.V;
   const int nblk = (V.nPr + kRowThreads - 1) / kRowThreads;
-  static const int lin_dbg = [] { const char* e = getenv("SSLAM_LIN_DBG"); return e ? atoi(e) : 0; }();
-  b.V.dbg = lin_dbg;
-  static const int lin_handover = [] { const char* e = getenv("SSLAM_LIN_HANDOVER"); return e ? atoi(e) : 0; }();
-  static const int lin_pair = [] { const char* e = getenv("SSLAM_LIN_PAIR"); return e ? atoi(e) : 0; }();   // 1: two role-specialised waves per 64-row tile (measured slower: 2.23 vs 1.89 ms); 0: one thread per row
-  static const int lin_stage = [] { const char* e = getenv("SSLAM_LIN_STAGE"); return e ? atoi(e) : 0; }();   // 1: staged, coalesced block stores; 2: the same on the row-wise form; 3: staged + early fetch; 0 (default): per-thread stores (measured the same time)
-  static const int lin_rowwise = [] { const char* e = getenv("SSLAM_LIN_ROWWISE"); return e ? atoi(e) : 0; }();   // 1 | 2: row-wise EdgeSE3 form at one | two waves per SIMD
-  static const int lin_split = [] { const char* e = getenv("SSLAM_LIN_SPLIT"); return e ? atoi(e) : 0; }();   // 1: EdgeSE3 slots and landmark slots of the pose rows in two launches (measured slower: 2.52 vs 2.01 ms)
-  static const int lin_wpe = [] { const char* e = getenv("SSLAM_LIN_WPE"); return e ? atoi(e) : 1; }();   // waves per SIMD the pose-row kernel is compiled for
 #define SSLAM_LAUNCH_LIN(PLV, SHV)                                                                                                    \
   {                                                                                                                                   \
-    if (V.nPr > 0) {                                                                                                                  \
-      if (lin_handover) hipLaunchKernelGGL((k_linearize_rowthread_handover<PLV, SHV>), dim3(nblk), dim3(kRowThreads), 0, b.stream, V); \
-      else if (lin_pair && lin_wpe == 3) hipLaunchKernelGGL((k_linearize_rowpair<PLV, SHV, 3>), dim3(nblk), dim3(2 * kRowThreads), 0, b.stream, V); \
-      else if (lin_pair) hipLaunchKernelGGL((k_linearize_rowpair<PLV, SHV, 2>), dim3(nblk), dim3(2 * kRowThreads), 0, b.stream, V);   \
-      else if (!lin_split && lin_wpe == 2) hipLaunchKernelGGL((k_linearize_rowthread<PLV, SHV, 2, 0, 0>), dim3(nblk), dim3(kRowThreads), 0, b.stream, V); \
-      else if (!lin_split && lin_wpe == 3) hipLaunchKernelGGL((k_linearize_rowthread<PLV, SHV, 3, 0, 0>), dim3(nblk), dim3(kRowThreads), 0, b.stream, V); \
-      else if (lin_rowwise == 2) hipLaunchKernelGGL((k_linearize_rowthread<PLV, SHV, 2, 3, 0>), dim3(nblk), dim3(kRowThreads), 0, b.stream, V); \
-      else if (lin_rowwise) hipLaunchKernelGGL((k_linearize_rowthread<PLV, SHV, 1, 3, 0>), dim3(nblk), dim3(kRowThreads), 0, b.stream, V); \
-      else if (lin_split) {                                                                                                           \
-        if (lin_wpe == 2) hipLaunchKernelGGL((k_linearize_rowthread<PLV, SHV, 2, 1, 0>), dim3(nblk), dim3(kRowThreads), 0, b.stream, V); \
-        else hipLaunchKernelGGL((k_linearize_rowthread<PLV, SHV, 1, 1, 0>), dim3(nblk), dim3(kRowThreads), 0, b.stream, V);              \
-        hipLaunchKernelGGL((k_linearize_rowthread<PLV, SHV, 1, 2, 0>), dim3(nblk), dim3(kRowThreads), 0, b.stream, V);                   \
-      }                                                                                                                               \
-      else if (lin_stage == 3) hipLaunchKernelGGL((k_linearize_rowthread<PLV, SHV, 1, 0, 2>), dim3(nblk), dim3(kRowThreads), 0, b.stream, V); \
-      else if (lin_stage == 2) hipLaunchKernelGGL((k_linearize_rowthread<PLV, SHV, 2, 3, 1>), dim3(nblk), dim3(kRowThreads), 0, b.stream, V); \
-      else if (lin_stage) hipLaunchKernelGGL((k_linearize_rowthread<PLV, SHV, 1, 0, 1>), dim3(nblk), dim3(kRowThreads), 0, b.stream, V); \
-      else hipLaunchKernelGGL((k_linearize_rowthread<PLV, SHV, 1, 0, 0>), dim3(nblk), dim3(kRowThreads), 0, b.stream, V);             \
-    }                                                                                                                                 \
-    if (V.nLr > 0) hipLaunchKernelGGL((k_linearize_lm_rows<PLV, SHV>), dim3((V.nLr + 15) / 16), dim3(256), 0, lm_stream, V);           \
-    if (V.nLL > 0) hipLaunchKernelGGL((k_linearize_ll<SHV>), dim3((V.nLL + 63) / 64), dim3(64), 0, lm_stream, V);                      \
+    if (V.nPr > 0) hipLaunchKernelGGL((k_linearize_rowthread<PLV, SHV>), dim3(nblk), dim3(kRowThreads), 0, b.stream, V);               \
+    if (V.nLr > 0) hipLaunchKernelGGL((k_linearize_lm_rows<PLV, SHV>), dim3((V.nLr + 15) / 16), dim3(256), 0, b.stream, V);            \
+    if (V.nLL > 0) hipLaunchKernelGGL((k_linearize_ll<SHV>), dim3((V.nLL + 63) / 64), dim3(64), 0, b.stream, V);                       \
   }
-  // SSLAM_LIN_OVERLAP=1 (large batches): the landmark-row kernel (96 VGPRs, writes H_ll and the landmark part of b only) on a second stream
-  // NEXT TO the pose-row kernel -- disjoint outputs, and the pose-row kernel's register footprint leaves room for its waves on every SIMD;
-  // the duplicate-edge pass and everything after wait for both.  Takes 4 % off a build on ONE stream (2.12 -> 2.04 ms per 512 graphs) and is
-  // OFF by default: in a stream group every part forks and joins its own second stream at every step, and the event round trips between
-  // eight streams cost the group a quarter of its throughput (24.9k vs 32.6k LM iterations/s on the 512-graph batch, same box).
-  static const bool lin_overlap = [] { const char* e = getenv("SSLAM_LIN_OVERLAP"); return e && atoi(e) != 0; }();
-  hipStream_t lm_stream = b.stream;
-  const bool forked = lin_overlap && V.B >= 8 && V.nLr > 0 && V.nPr > 0;
-  if (forked) {
-    if (!b.aux_stream) {
-      SSLAM_HIP_TRY(hipStreamCreateWithFlags(&b.aux_stream, hipStreamNonBlocking));
-      SSLAM_HIP_TRY(hipEventCreateWithFlags(&b.ev_fork, hipEventDisableTiming));
-      SSLAM_HIP_TRY(hipEventCreateWithFlags(&b.ev_join, hipEventDisableTiming));
-    }
-    SSLAM_HIP_TRY(hipEventRecord(b.ev_fork, b.stream));
-    SSLAM_HIP_TRY(hipStreamWaitEvent(b.aux_stream, b.ev_fork, 0));
-    lm_stream = b.aux_stream;
-  }
-  auto join = [&]() -> int {
-    if (!forked) return 0;
-    SSLAM_HIP_TRY(hipEventRecord(b.ev_join, b.aux_stream));
-    SSLAM_HIP_TRY(hipStreamWaitEvent(b.stream, b.ev_join, 0));
-    return 0;
-  };
+  // (Round 4 could run the landmark-row kernel on a second stream next to the pose-row kernel: +4 % on one stream, -24 % inside a stream
+  // group, where every part forked and joined its own second stream at every step -- removed in round 5.)
   if (b.sharded) {
     // edge-sharded mode: the rank-partial system is built in its own buffer and summed OUT OF PLACE into [H || b].  A graph that does not
     // re-linearise in this step (a rejected trial being retried, a finished graph) keeps its old partial system there, so the sum over
@@ -2093,7 +1281,6 @@ static int batch_linearize(Batch& b) {
     {
       const BatchView& V = Vp;
       if (b.has_planes) SSLAM_LAUNCH_LIN(true, true) else SSLAM_LAUNCH_LIN(false, true)
-      { const int jr = join(); if (jr) return jr; }
       if (V.nDupEo + V.nDupEl > 0) hipLaunchKernelGGL(k_linearize_dups, dim3((std::max(V.nDupEo, V.nDupEl) + 63) / 64), dim3(64), 0, b.stream, V);
     }
     if (b.comm) {
@@ -2107,7 +1294,6 @@ static int batch_linearize(Batch& b) {
     }
   } else {
     if (b.has_planes) SSLAM_LAUNCH_LIN(true, false) else SSLAM_LAUNCH_LIN(false, false)
-    { const int jr = join(); if (jr) return jr; }
     if (V.nDupEo + V.nDupEl > 0) hipLaunchKernelGGL(k_linearize_dups, dim3((std::max(V.nDupEo, V.nDupEl) + 63) / 64), dim3(64), 0, b.stream, V);
   }
 #undef SSLAM_LAUNCH_LIN
@@ -2158,15 +1344,6 @@ static int batch_solve(Batch& b) {
   // (H + lambda I) dx = b for every graph with in_trial set; result in V.x
   if (b.graphs[0]->opt.solver == 0 || b.graphs[0]->opt.solver == 2) return pcg_solve(b);
   int rc;
-  // SSLAM_WCHOL=1 (or solver option 3): the window multifrontal factorisation (sslam_wchol.hip).  Correct and leaner in traffic, but at
-  // one 6-wide pivot per step its rank-6 window update is LDS-bandwidth bound (profiles/r3_pmc_wchol_v2_batch128.txt): 2.5x slower
-  // than the piece plan on the L batch, so the piece plan stays the default of the LM loop
-  static const bool wenv = [] { const char* e = getenv("SSLAM_WCHOL"); return e && atoi(e) != 0; }();
-  if (wenv || b.graphs[0]->opt.solver == 3) {
-    if (!b.wchol && (rc = wchol_plan_build(b))) return rc;
-    if ((rc = wchol_factor_and_forward(b))) return rc;
-    return wchol_backward(b);
-  }
   if (!b.chol) {
     static const bool timing = getenv("SSLAM_TIMING") != nullptr;
     const auto t0 = std::chrono::steady_clock::now();
@@ -2203,8 +1380,7 @@ static int batch_optimize(Batch& b, int max_iters, sslam_opt_stats* out) {
   bool fused = false;
   {
     static const bool fused_on = [] { const char* e = getenv("SSLAM_FUSED"); return !(e && atoi(e) == 0); }();
-    static const bool wenv = [] { const char* e = getenv("SSLAM_WCHOL"); return e && atoi(e) != 0; }();
-    if (fused_on && b.graphs[0]->opt.fused && !wenv && b.graphs[0]->opt.solver == 1 && !b.sharded && !b.profiling) {
+    if (fused_on && b.graphs[0]->opt.fused && b.graphs[0]->opt.solver == 1 && !b.sharded && !b.profiling) {
       if (!b.chol && (rc = chol_plan_build(b))) return rc;
       fused = chol_plan_tail_only(b);
     }
@@ -2213,8 +1389,7 @@ static int batch_optimize(Batch& b, int max_iters, sslam_opt_stats* out) {
   // launches (k_lm_begin_small / k_lm_end_small) -- same sums, same order, same results as the stand-alone kernels
   bool flow_steps = false;
   {
-    static const bool wenv = [] { const char* e = getenv("SSLAM_WCHOL"); return e && atoi(e) != 0; }();
-    if (!fused && b.graphs[0]->opt.fused && !wenv && b.graphs[0]->opt.solver == 1 && !b.sharded && !b.profiling) {
+    if (!fused && b.graphs[0]->opt.fused && b.graphs[0]->opt.solver == 1 && !b.sharded && !b.profiling) {
       if (!b.chol && (rc = chol_plan_build(b))) return rc;
       flow_steps = chol_plan_flow(b);
     }
@@ -2493,7 +1668,7 @@ int sslam_graph_set_option(sslam_graph* h, const char* key, double value) {
   if (!h || !key) return set_error(SSLAM_ERR_INVALID, "null argument");
   Options& o = h->g.opt;
   const std::string k(key);
-  if (k == "solver") { if (value != 0 && value != 1 && value != 2 && value != 3) return set_error(SSLAM_ERR_INVALID, "solver: 0 block-Jacobi PCG, 1 sparse block Cholesky (piece plan), 2 Schur complement on the landmarks + PCG, 3 sparse block Cholesky (window plan)"); o.solver = (int)value; }
+  if (k == "solver") { if (value != 0 && value != 1 && value != 2) return set_error(SSLAM_ERR_INVALID, "solver: 0 block-Jacobi PCG, 1 sparse block Cholesky, 2 Schur complement on the landmarks + PCG (3, the window plan of round 3, was removed in round 5: 2-2.7x slower than 1)"); o.solver = (int)value; }
   else if (k == "robust_kernel_dcs") { if (!(value >= 0)) return set_error(SSLAM_ERR_INVALID, "robust_kernel_dcs: phi >= 0 (0 = no kernel)"); o.dcs_phi = value; if (h->batch) h->batch->V.dcs_phi = value; h->linearized = false; }
   else if (k == "fused_small_graph") o.fused = value != 0;
   else if (k == "speculative_trials") o.speculative = value < 0 ? 0 : (value > 2 ? 2 : (int)value);
@@ -3089,12 +2264,11 @@ int sslam_batch_time_solver(sslam_batch* h, int repeats, double* factor_ms, doub
   SSLAM_HIP_TRY(hipEventCreate(&guard.e[0])); SSLAM_HIP_TRY(hipEventCreate(&guard.e[1])); SSLAM_HIP_TRY(hipEventCreate(&guard.e[2]));
   hipEvent_t e0 = guard.e[0], e1 = guard.e[1], e2 = guard.e[2];
   double tf = 0, ts = 0;
-  const bool wplan = b.wchol != nullptr;
   for (int k = 0; k < repeats; ++k) {
     SSLAM_HIP_TRY(hipEventRecord(e0, b.stream));
-    if ((rc = wplan ? wchol_factor_and_forward(b) : chol_factor_and_forward(b))) return rc;
+    if ((rc = chol_factor_and_forward(b))) return rc;
     SSLAM_HIP_TRY(hipEventRecord(e1, b.stream));
-    if ((rc = wplan ? wchol_backward(b) : chol_backward(b))) return rc;
+    if ((rc = chol_backward(b))) return rc;
     SSLAM_HIP_TRY(hipEventRecord(e2, b.stream));
     SSLAM_HIP_TRY(hipEventSynchronize(e2));
     float a = 0, c = 0;
@@ -3169,27 +2343,6 @@ int sslam_batch_kernel_time(sslam_batch* h, const char* name, double* total_ms, 
   if (total_ms) *total_ms = it == h->b.timers.end() ? 0.0 : it->second.total_ms;
   if (launches) *launches = it == h->b.timers.end() ? 0 : it->second.launches;
   return 0;
-}
-
-// ---- the window Cholesky on the host (no device needed): plan + the kernels' per-thread phases run by a CPU executor ---------
-int64_t sslam_debug_wchol_solve(sslam_graph* const* graphs, int n, const double* h_and_b, int64_t hb_doubles, const double* lambda,
-                                double* x_out, int32_t* fail_out, int64_t* stats8) {
-  if (!graphs || n <= 0) return set_error(SSLAM_ERR_INVALID, "empty batch");
-  Batch b;
-  for (int i = 0; i < n; ++i) { if (!graphs[i]) return set_error(SSLAM_ERR_INVALID, "null graph"); b.graphs.push_back(&graphs[i]->g); }
-  int rc = batch_build(b, true);
-  if (rc) return rc;
-  const int64_t dim = 6 * (int64_t)b.V.nPr + 3 * (int64_t)b.V.nLr;
-  const int64_t need = ((b.V.h_total + 1) & ~(int64_t)1) + dim;
-  if (!h_and_b || !lambda || !x_out) return need;   // size query: doubles in the [H || b] buffer
-  if (hb_doubles < need) return set_error(SSLAM_ERR_INVALID, "[H || b] buffer of %lld doubles needed", (long long)need);
-  SymIn in;
-  chol_sym_input(b, in);
-  std::vector<int> fail(n, 0);
-  rc = wchol_emulate(in, h_and_b, b.V.h_total, lambda, x_out, fail.data(), stats8);
-  if (rc) return rc;
-  if (fail_out) for (int i = 0; i < n; ++i) fail_out[i] = fail[i];
-  return need;
 }
 
 // ---- plan introspection (host only, no device needed): the symbolic Cholesky plan of a batch as flat int32 arrays ----------

@@ -128,20 +128,6 @@ def test_schur_pcg_solve_matches_oracle_cholesky(gpu_lib, lam):
         assert G.last_stats.chi2_after == pytest.approx(st.chi2_after, rel=1e-5)
 
 
-@pytest.mark.parametrize("lam", [0.0, 2.5])
-def test_window_cholesky_solve_matches_oracle_cholesky(gpu_lib, lam):
-    """solver 3: the window multifrontal factorisation (sslam_wchol.hip; register-resident sliding fronts, both segment classes on
-    the S graph) against the oracle's Cholesky; the same kernels' phases are pinned on the CPU by tests/test_wchol_cpu.py"""
-    from semantic_slam_amd import GraphSLAM
-    for g in (make_graph(60, 12, seed=5), make_graph(500, 100, seed=1)):
-        gp = GraphProblem.from_synth(g, interleave=True)
-        G = GraphSLAM.from_problem(gp)
-        G.set_option("solver", 3)
-        x, _ = G.solve(lam)
-        xr = gp.solve(lam)
-        assert np.abs(x - xr).max() <= 1e-8 * np.abs(xr).max()
-
-
 @pytest.mark.parametrize("lam", [5.0, 1e-3, 0.0])
 def test_cholesky_solve_matches_oracle_cholesky(gpu_lib, lam):
     from semantic_slam_amd import GraphSLAM
