@@ -143,11 +143,6 @@ struct CholOpts {
   int group_blocks = 1024; //      workgroup factors side by side: the per-level latencies and barriers are shared by all members
   int ustage = -1;         // 1: the per-depth kernels stage the update-matrix records in LDS too (one round trip for all tables: shorter
                            //    piece latency, fewer pieces per CU); -1: 1 for batches < 32 (latency-bound), else 0 (residency-bound)
-  int small_cols = 0;      // a graph with at most this many block columns is walked by ONE workgroup from the leaves to the root (every piece a tail
-                           // piece, no per-depth launches): the form the fused LM kernel (k_lm_trial_small) needs.  0 (default): never --
-                           // measured, the walk serialises sibling subtrees (61 dependent levels instead of 28 at 110 keyframes, 233 instead of
-                           // 42 at 436) and the tick got slower (8.7 vs 7.8 ms, 22.4 vs 10.5 ms); the dependency-driven launch (k_chol_flow) is
-                           // what small graphs use
   int order = 1;           // 0: minimum degree, lowest index first (rounds 1-3: eliminates a pose chain from one end -> a tree as deep as the chain);
                            // 1: multiple minimum degree over independent sets (below): a chain halves per round -> O(log n) levels.  Small
                            // batches are latency-bound on the depth of the tree (one 5000-pose graph 588 -> 1050 LM iterations/s); on the
@@ -159,23 +154,37 @@ struct CholOpts {
                            // matrices, five levels more: throughput -- measured 9.30 vs 9.48 ms per 512 factorisations)
   int order_bits_max = 2048;   // graphs up to this many nodes are ordered on adjacency bitsets (same order, a fraction of the time); 0: never
   bool dump = false;
-  static int env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
+  int flow = 1;            // small batches: 0 a launch per depth; 1 the dependency-driven single launch (k_chol_flow) when the tree is narrower than its
+                           // grid; 2 also on wide trees (per-depth launches for the bottom, measured slower: tests only)
+  // SSLAM_CHOL_OPTS="key=value,key=value,...": every plan option above by its field name (tests force the piece shapes of a 5000-pose graph
+  // onto small graphs with it; tuning sweeps), plus order=mmd|mindeg and dump=1.  The ONE environment switch of the plan.
   void from_env() {
-    cap_leaf = env_int("SSLAM_CHOL_CAP_LEAF", cap_leaf); cap_tail = env_int("SSLAM_CHOL_CAP_TAIL", cap_tail);
-    max_blocks = env_int("SSLAM_CHOL_MAX_BLOCKS", max_blocks); tail_width = env_int("SSLAM_CHOL_TAIL_WIDTH", tail_width);
-    mid_width = env_int("SSLAM_CHOL_MID_WIDTH", mid_width); cap_mid = env_int("SSLAM_CHOL_CAP_MID", cap_mid); nt_mid = env_int("SSLAM_CHOL_NT_MID", nt_mid);
-    pcap_mid = env_int("SSLAM_CHOL_PCAP_MID", pcap_mid);
-    nt_tail = env_int("SSLAM_CHOL_NT_TAIL", nt_tail); nt_leaf = env_int("SSLAM_CHOL_NT_LEAF", nt_leaf); min_chunk = std::max(1, env_int("SSLAM_CHOL_MIN_CHUNK", min_chunk));
-    split_min = std::max(2, env_int("SSLAM_CHOL_SPLIT_MIN", split_min));
-    pcap_leaf = env_int("SSLAM_CHOL_PCAP_LEAF", pcap_leaf); pcap_tail = env_int("SSLAM_CHOL_PCAP_TAIL", pcap_tail);
-    group_cap = env_int("SSLAM_CHOL_GROUP_CAP", group_cap); group_blocks = env_int("SSLAM_CHOL_GROUP_BLOCKS", group_blocks);
-    ustage = env_int("SSLAM_CHOL_USTAGE", ustage);
-    small_cols = env_int("SSLAM_CHOL_SMALL_COLS", small_cols);
-    order_bits_max = env_int("SSLAM_CHOL_ORDER_BITS", order_bits_max);
-    if (const char* e = getenv("SSLAM_CHOL_ORDER")) order = (!strcmp(e, "mindeg") || !strcmp(e, "0")) ? 0 : ((!strcmp(e, "auto") || !strcmp(e, "-1")) ? -1 : 1);
-    if (const char* e = getenv("SSLAM_CHOL_ORDER_SLACK")) { double m = 0; int a = 0; if (sscanf(e, "%lf,%d", &m, &a) == 2 && m >= 1.0 && a >= 0) { order_mul = m; order_add = a; } }
-    dump = getenv("SSLAM_CHOL_DUMP") != nullptr;
+    const char* e = getenv("SSLAM_CHOL_OPTS");
+    if (!e) return;
+    std::string str(e);
+    size_t pos = 0;
+    while (pos < str.size()) {
+      size_t end = str.find(',', pos);
+      if (end == std::string::npos) end = str.size();
+      const std::string kv = str.substr(pos, end - pos);
+      pos = end + 1;
+      const size_t eq = kv.find('=');
+      if (eq == std::string::npos) continue;
+      const std::string k = kv.substr(0, eq), v = kv.substr(eq + 1);
+      const int iv = atoi(v.c_str());
+      if (k == "cap_leaf") cap_leaf = iv; else if (k == "cap_mid") cap_mid = iv; else if (k == "cap_tail") cap_tail = iv;
+      else if (k == "max_blocks") max_blocks = iv; else if (k == "tail_width") tail_width = iv; else if (k == "mid_width") mid_width = iv;
+      else if (k == "nt_leaf") { nt_leaf = iv; nt_leaf_set = true; } else if (k == "nt_mid") nt_mid = iv; else if (k == "nt_tail") nt_tail = iv;
+      else if (k == "min_chunk") min_chunk = std::max(1, iv); else if (k == "split_min") split_min = std::max(2, iv);
+      else if (k == "pcap_leaf") pcap_leaf = iv; else if (k == "pcap_mid") pcap_mid = iv; else if (k == "pcap_tail") pcap_tail = iv;
+      else if (k == "group_cap") group_cap = iv; else if (k == "group_blocks") group_blocks = iv; else if (k == "ustage") ustage = iv;
+      else if (k == "order_bits_max") order_bits_max = iv; else if (k == "flow") flow = iv; else if (k == "dump") dump = iv != 0;
+      else if (k == "order") order = (v == "mindeg" || v == "0") ? 0 : 1;
+      else if (k == "order_mul") order_mul = atof(v.c_str()); else if (k == "order_add") order_add = iv;
+      else fprintf(stderr, "[sslam] SSLAM_CHOL_OPTS: unknown key '%s'\n", k.c_str());
+    }
   }
+  bool nt_leaf_set = false;   // nt_leaf came from SSLAM_CHOL_OPTS (the single-launch solve leaves it alone then)
 };
 
 struct CholHost {
@@ -512,7 +521,6 @@ inline int chol_symbolic(const SymIn& in, CholOpts opt, CholHost& out) {
     for (int p = 0; p < np1; ++p) cnt[plev[p]]++;
     int T = nlev1;
     if (opt.tail_width > 0) while (T > 0 && cnt[T - 1] <= opt.tail_width) --T;
-    if (n <= opt.small_cols) T = 0;   // small graph: its whole tree belongs to the tail
     // pass 2: the columns above the bottom are cut again, by class: mid (depths with <= mid_width pieces of this graph) with the mid cap,
     // tail with the tail cap (fewer external-update phases on the chain).  Depths ascend towards the root, so do the classes.
     int M = T;

@@ -234,8 +234,6 @@ int chol_spec_mode(const Batch& b);               // 0 off, 1 adaptive (lanes jo
 int chol_lm_step_spec(Batch& b, int max_iters);   // one LM iteration: up to ten speculative trials + the accept / reject replay
 int chol_factor_flat_flow(Batch& b);        // flat factor (marginals) through the single launch
 int chol_flow_check(Batch& b);              // error flag of that launch (synchronises the stream)
-bool chol_plan_tail_only(const Batch& b);   // every piece of every graph is walked by the tail kernels (small graphs)
-int chol_lm_trial_fused(Batch& b, int max_iters);   // one LM iteration (all its damping trials) per graph in one launch, after the linearisation
 int chol_marginal_diag(Batch& b, const std::vector<int>& xoff, const std::vector<int>& dims, double* out36);  // diagonal blocks of H^-1 along the tree paths, one launch
 
 

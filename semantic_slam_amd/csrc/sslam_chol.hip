@@ -51,7 +51,6 @@ struct CholView {
   double* Uval;             // update matrices handed from child pieces to their parents
   double* y;                // forward-substituted rhs, elimination order [dim]
   int* fail;                // [B]
-  int utile_off;            // 1: update-matrix items by quads only (SSLAM_CHOL_UTILES=0)
   int flat_L;               // 1: the factor is written in flat form (multi right-hand-side kernels); 0: class-interleaved (LM loop)
   long long* dbg;           // SSLAM_CHOL_STAMPS: shader-clock totals per phase of workgroup 0 ([16] tail kernel, [16] per-depth kernels)
 };
@@ -770,9 +769,8 @@ __device__ __forceinline__ void chol_piece(const BatchView& V, const CholView& C
   }
   // ---- 3. the update matrix over the rows above the piece: own updates out of LDS + the children's blocks -> HBM
   if (pm.nuit > 0) {
-    // sole items by tiles (run_utiles), the items of split lists by quads into their partial slots (run_uitems).  C.utile_off: the quad
-    // form for everything (SSLAM_CHOL_UTILES=0)
-    const int nsole = C.utile_off ? 0 : pm.nu4 + pm.nu2 + pm.nu1;
+    // sole items by tiles (run_utiles), the items of split lists by quads into their partial slots (run_uitems)
+    const int nsole = pm.nu4 + pm.nu2 + pm.nu1;
     if (USTAGE) {
       if (nsole > 0) run_utiles<NT>(sUItem, pm.nu4, pm.nu2, pm.nu1, sUUpd, sUSrc, smL, smY, pm.lbase, pm.y0, C.Uval, tid);
       if (pm.nuit > nsole) run_uitems<NT>(sUItem, nsole, pm.nuit, sUUpd, sUSrc, smL, smY, pm.lbase, pm.y0, C.Uval, part, tid);
@@ -1221,7 +1219,7 @@ __device__ __forceinline__ void vblock_store_sum(double v, double* red, double* 
   __syncthreads();
 }
 
-// the three parts of an LM step around the linear solve, one workgroup per graph (shared by k_lm_trial_small and the begin / end kernels
+// the three parts of an LM step around the linear solve, one workgroup per graph (shared by the begin / end kernels
 // of the single-launch solve)
 template <int NT>
 __device__ __forceinline__ void lm_begin_small(const BatchView& V, const CholView& C, int g, double* red) {   // k_maxdiag + k_lm_begin_step + k_chol_begin
@@ -1291,38 +1289,6 @@ __device__ __forceinline__ void lm_end_small(const BatchView& V, const CholView&
     __threadfence_block();
   }
   __syncthreads();
-}
-
-template <int NT>
-__global__ __launch_bounds__(NT) void k_lm_trial_small(BatchView V, CholView C, double* __restrict__ part_e, int max_iters) {
-  extern __shared__ double sm[];
-  __shared__ double red[NT / 64];
-  const int g = blockIdx.x, tid = threadIdx.x;
-  LmState& S = V.lm[g];
-  if (!S.active) return;
-  const int q0 = C.tail_ptr[g], q1 = C.tail_ptr[g + 1];
-  lm_begin_small<NT>(V, C, g, red);
-  for (;;) {
-    if (!S.in_trial) return;
-    // ---- (H + lambda I) = L L^T, y = L^-1 b: the pieces of the graph's tree in elimination order
-    for (int q = q0; q < q1; ++q) {
-      if (C.rupd) chol_piece<NT, false, true>(V, C, C.lpiece[C.ltail0 + q], sm, nullptr);
-      else chol_piece<NT, false, false>(V, C, C.lpiece[C.ltail0 + q], sm, nullptr);
-      __threadfence_block();
-      __syncthreads();
-    }
-    // ---- x = L^-T y
-    for (int q = q1 - 1; q >= q0; --q) {
-      chol_piece_backward<NT>(C, C.lpiece[C.ltail0 + q], C.y, V.x, sm, nullptr);
-      __threadfence_block();
-      __syncthreads();
-    }
-    lm_end_small<NT>(V, C, g, part_e, max_iters, red);
-    if (!S.active || S.lin) return;   // finished, or the next iteration needs a new linearisation: back to the host's launch sequence
-    if (tid == 0) { S.accept = 0; C.fail[g] = 0; }   // a rejected trial: once more with the raised lambda (what k_lm_begin_step does for a retry)
-    __threadfence_block();
-    __syncthreads();
-  }
 }
 
 // the same two halves as kernels of their own, for the single-launch solve (k_chol_flow) between them: 3 launches per damping trial after the
@@ -1710,9 +1676,9 @@ int chol_plan_build(Batch& b) {
   if (opt.nt_mid != 128 && opt.nt_mid != 512) opt.nt_mid = 256;
   // small batches (latency-bound: the orchestrator's graph, a single large graph): the dependency-driven single launch (k_chol_flow) runs
   // every piece with the tail's workgroup size
-  const int flow_mode = [] { const char* e = getenv("SSLAM_CHOL_FLOW"); return e ? atoi(e) : 1; }();   // 0 off, 1 auto, 2 also on wide trees; read per plan (tests toggle it)
+  const int flow_mode = opt.flow;   // 0 off, 1 auto, 2 also on wide trees (SSLAM_CHOL_OPTS flow=...; read per plan: tests toggle it)
   const bool flow_on = flow_mode != 0;
-  const bool want_flow = flow_on && b.V.B < 8 && opt.nt_tail == 512 && opt.group_cap == 0 && !getenv("SSLAM_CHOL_NT_LEAF");
+  const bool want_flow = flow_on && b.V.B < 8 && opt.nt_tail == 512 && opt.group_cap == 0 && !opt.nt_leaf_set;
   if (want_flow) { opt.nt_leaf = opt.nt_tail; opt.mid_width = 0; }
   CholHost H;
   if (chol_symbolic(in, opt, H)) return set_error(SSLAM_ERR_NUMERIC, "Cholesky plan: %s", H.error.c_str());
@@ -1721,7 +1687,6 @@ int chol_plan_build(Batch& b) {
   P->arena = b.arena;
   CholView& C = P->C;
   C.ncol = H.ncol; C.nlevels = H.nlevels; C.dim = H.dim; C.npiece = H.npiece;
-  { const char* e = getenv("SSLAM_CHOL_UTILES"); C.utile_off = (e && atoi(e) == 0) ? 1 : 0; }
   P->lvl_ptr = H.lvl_ptr; P->plv_ptr = H.plv_ptr; P->plv_lds_f = H.plv_lds_f; P->plv_lds_b = H.plv_lds_b; P->plv_nt = H.plv_nt; P->plv_cls = H.plv_cls;
   P->tail_lds_f = H.tail_lds_f; P->tail_lds_b = H.tail_lds_b; P->tail_total = (int)H.tail_pieces.size(); P->nt_tail = H.nt_tail; P->nt_leaf = H.nt_leaf; P->ustage = H.ustage;
   P->lnz = H.lnz;
@@ -1767,10 +1732,9 @@ int chol_plan_build(Batch& b) {
   if ((rc = up_to_dev(*P, b.stream, H.usrc, &C.usrc))) return rc;
   if ((rc = up_to_dev(*P, b.stream, H.uitem, &C.uitem))) return rc;
   if ((rc = up_to_dev(*P, b.stream, H.umb, &C.umb))) return rc;
-  {   // right-looking tail (default; SSLAM_CHOL_RIGHT=0: the target-major items everywhere)
-    const char* e = getenv("SSLAM_CHOL_RIGHT");
+  {   // right-looking internal updates of the tail and mid pieces (the plan drops the lists when a piece does not fit their packed records)
     C.rcol = nullptr; C.rupd = nullptr;
-    if (!(e && atoi(e) == 0) && !H.rupd.empty()) {
+    if (!H.rupd.empty()) {
       if ((rc = up_to_dev(*P, b.stream, H.rcol, &C.rcol))) return rc;
       if ((rc = up_to_dev(*P, b.stream, H.rupd, &C.rupd))) return rc;
     }
@@ -1839,7 +1803,6 @@ int chol_plan_build(Batch& b) {
                            (const void*)k_chol_tail<512>, (const void*)k_chol_tail<1024>,
                            (const void*)k_chol_back_pieces<64>, (const void*)k_chol_back_pieces<128>, (const void*)k_chol_back_pieces<256>,
                            (const void*)k_chol_back_pieces<512>, (const void*)k_chol_back_pieces<1024>, (const void*)k_chol_back_tail<512>,
-                           (const void*)k_lm_trial_small<512>, (const void*)k_lm_trial_small<1024>,
                            (const void*)k_chol_flow<512, true>, (const void*)k_chol_flow<512, false>,
                            (const void*)k_chol_spec_round<512, true>, (const void*)k_chol_spec_round<512, false>};
       for (const void* f : fns) SSLAM_HIP_TRY(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, v));
@@ -1975,7 +1938,7 @@ static void flow_launches(Batch& b, bool spec = false, bool backward = true, boo
   const SpecLanes SL = spec ? P.spec : SpecLanes{};
   const int lm_epoch = lmstep ? ++P.lm_epoch : 0;
   const dim3 grid(spec ? P.spec_grid : P.flow_grid);
-  static const int defer = [] { const char* e = getenv("SSLAM_FLOW_DEFER"); return (e && atoi(e) == 0) ? 0 : 2; }();   // tables + H before the wait for the children
+  const int defer = 2;   // tables + H before the wait for the children (round 4: -0.43 ms per tick)
   {
     PersistScope gate(b.device, b.stream);
     if (P.ustage) hipLaunchKernelGGL((k_chol_flow<512, true>), grid, dim3(512), lds, b.stream, b.V, C, P.flow_first, np, epoch, (const int2*)P.d_dep, P.d_flow, SL, (backward ? 1 : 0) | defer | (lmstep ? 4 : 0), b.d_part_e, max_iters, lm_epoch);
@@ -2023,8 +1986,7 @@ int chol_lm_step_flow(Batch& b, int max_iters) {
   lds *= sizeof(double);
   const int np = (int)P.lp_graph.size();
   // the begin / end halves of the trial inside the launch when it covers the whole tree and has a workgroup per graph
-  static const bool lmstep_on = [] { const char* e = getenv("SSLAM_FLOW_LMSTEP"); return !(e && atoi(e) == 0); }();
-  if (lmstep_on && P.flow_launch0 == 0 && P.flow_grid >= b.V.B) { flow_launches(b, false, true, true, max_iters); }
+  if (P.flow_launch0 == 0 && P.flow_grid >= b.V.B) { flow_launches(b, false, true, true, max_iters); }
   else {
     hipLaunchKernelGGL(k_lm_begin_small<512>, dim3(b.V.B), dim3(512), 0, b.stream, b.V, C);
     flow_launches(b);
@@ -2177,8 +2139,7 @@ int chol_backward(Batch& b) {
     const int* idx = P.compact ? P.d_idx + P.c_ptr[l] : nullptr;
     const size_t lds = (size_t)P.plv_lds_b[l] * sizeof(double);
 #define SSLAM_LAUNCH_BACK(NTV) hipLaunchKernelGGL(k_chol_back_pieces<NTV>, dim3(n), dim3(NTV), lds, b.stream, C, P.plv_ptr[l], (const double*)C.y, b.V.x, (const LmState*)b.V.lm, idx);
-    static const int nt_back_env = [] { const char* e = getenv("SSLAM_CHOL_NT_BACK"); return e ? atoi(e) : 0; }();
-    switch (nt_back_env > 0 ? nt_back_env : P.plv_nt[l]) {
+    switch (P.plv_nt[l]) {
       case 128: SSLAM_LAUNCH_BACK(128) break;
       case 512: SSLAM_LAUNCH_BACK(512) break;
       case 1024: SSLAM_LAUNCH_BACK(1024) break;
@@ -2221,19 +2182,6 @@ int chol_solve_multi(Batch& b, const double* rhs_host, int nrhs, double* x_host)
     SSLAM_HIP_TRY(hipMemcpyAsync(x_host + (size_t)r0 * C.dim, P.d_multi_x, bytes, hipMemcpyDeviceToHost, b.stream));
     SSLAM_HIP_TRY(hipStreamSynchronize(b.stream));
   }
-  return 0;
-}
-
-// ---- fused LM iterations of small graphs (k_lm_trial_small): plans whose every piece is a tail piece
-bool chol_plan_tail_only(const Batch& b) { return b.chol && b.chol->plv_lds_f.empty() && b.chol->tail_total > 0; }
-int chol_lm_trial_fused(Batch& b, int max_iters) {
-  CholPlan& P = *b.chol;
-  P.C.flat_L = 0;
-  const size_t lds = (size_t)std::max(P.tail_lds_f, P.tail_lds_b) * sizeof(double);
-  if (P.nt_tail == 1024) hipLaunchKernelGGL(k_lm_trial_small<1024>, dim3(b.V.B), dim3(1024), lds, b.stream, b.V, P.C, b.d_part_e, max_iters);
-  else hipLaunchKernelGGL(k_lm_trial_small<512>, dim3(b.V.B), dim3(512), lds, b.stream, b.V, P.C, b.d_part_e, max_iters);
-  hipError_t e = hipGetLastError();
-  if (e != hipSuccess) return set_error(SSLAM_ERR_HIP, "fused LM trial launch: %s", hipGetErrorString(e));
   return 0;
 }
 

@@ -1375,21 +1375,11 @@ static int batch_optimize(Batch& b, int max_iters, sslam_opt_stats* out) {
   // The LM control flow (accept / reject, retry with a larger lambda, terminate) lives on the device: the host enqueues
   // generic steps in chunks and only looks at the per-graph state between chunks -- no synchronisation per trial.
   // Every graph needs at least (max_iters - iter) more steps; rejected trials add steps, which later chunks supply.
-  // Small graphs (plans that are all tail, chol_plan.hpp small_cols): one launch per LM ITERATION after the Jacobian kernels -- every
-  // damping trial of the iteration, factor to commit, inside k_lm_trial_small (sslam_chol.hip); SSLAM_FUSED=0: the stand-alone kernels
-  bool fused = false;
-  {
-    static const bool fused_on = [] { const char* e = getenv("SSLAM_FUSED"); return !(e && atoi(e) == 0); }();
-    if (fused_on && b.graphs[0]->opt.fused && b.graphs[0]->opt.solver == 1 && !b.sharded && !b.profiling) {
-      if (!b.chol && (rc = chol_plan_build(b))) return rc;
-      fused = chol_plan_tail_only(b);
-    }
-  }
   // Small batches whose plan runs factor + solves in one dependency-driven launch (k_chol_flow): the rest of a damping trial in two more
   // launches (k_lm_begin_small / k_lm_end_small) -- same sums, same order, same results as the stand-alone kernels
   bool flow_steps = false;
   {
-    if (!fused && b.graphs[0]->opt.fused && b.graphs[0]->opt.solver == 1 && !b.sharded && !b.profiling) {
+    if (b.graphs[0]->opt.fused && b.graphs[0]->opt.solver == 1 && !b.sharded && !b.profiling) {
       if (!b.chol && (rc = chol_plan_build(b))) return rc;
       flow_steps = chol_plan_flow(b);
     }
@@ -1407,7 +1397,6 @@ static int batch_optimize(Batch& b, int max_iters, sslam_opt_stats* out) {
     const auto tq0 = std::chrono::steady_clock::now();
     for (int sidx = 0; sidx < chunk; ++sidx) {
       if ((rc = batch_linearize(b))) return rc;
-      if (fused) { if ((rc = chol_lm_trial_fused(b, max_iters))) return rc; continue; }
       if (spec_steps) { if ((rc = chol_lm_step_spec(b, max_iters))) return rc; continue; }
       if (flow_steps) { if ((rc = chol_lm_step_flow(b, max_iters))) return rc; continue; }
       hipLaunchKernelGGL(k_maxdiag, row_grid(b), dim3(kRowChunk), 0, b.stream, V, b.d_part_m);
@@ -1437,11 +1426,10 @@ static int batch_optimize(Batch& b, int max_iters, sslam_opt_stats* out) {
       // a graph in a streak of rejected trials ends its iteration -- at convergence, its optimisation -- after at most 10 - q more of
       // them: enqueue exactly those (g2o's LM ends every optimisation of the orchestrator with ten rejected trials; a full chunk
       // behind each look cost 4-6 idle steps per tick).  An accepted trial in between: the next look supplies more steps.
-      static const bool streak_on = [] { const char* e = getenv("SSLAM_LM_STREAK"); return !(e && atoi(e) == 0); }();
       // (small batches only: on a large batch every look is a host round trip for all graphs, and short chunks in the endgame cost the
       // 512-graph stream group 12 % -- 25.0k vs 28.5k iterations/s)
-      const int streak_left = (streak_on && V.B < 8 && st[g].in_trial && st[g].q > 0) ? std::max(1, 10 - st[g].q) : kStepChunk;
-      need = std::max(need, streak_on ? std::min(max_iters - st[g].iter, streak_left) : max_iters - st[g].iter);
+      const int streak_left = (V.B < 8 && st[g].in_trial && st[g].q > 0) ? std::max(1, 10 - st[g].q) : kStepChunk;
+      need = std::max(need, std::min(max_iters - st[g].iter, streak_left));
     }
     // the graphs that are still iterating only ever shrink: once half of the batch is done, the factor / solve launches are sized
     // for the rest (a retry by three graphs then costs three graphs' pieces, not the dispatch of everybody's)

@@ -70,7 +70,6 @@ struct View {
   int* nreg;     // [nbox]
   float mdcf, smoothing, ang_thr_cos, dist_thr, max_curv;
   unsigned min_inliers;
-  int dbg;         // timing experiments (SSLAM_SEG_DBG; results are wrong when set): 1 = refine without its region records, 2 = refine without the sweeps, 4 = integral images without stores, 8 = print refine pass counts, 16 / 32 = refine without masks / passes, 64 = integral staging only
   int refine_bh;   // rows per LDS band of k_refine (64: one box per CU, lowest latency; 24: three boxes per CU for calls with many boxes)
 };
 
@@ -262,7 +261,7 @@ __device__ __forceinline__ void ii_store(double* e, const double (&v)[NC]) {   /
   else { e[0] = v[0]; *reinterpret_cast<IiPair*>(e + 1) = IiPair{v[1], v[NC - 1]}; }
 }
 template <int C0, int NC>
-__device__ __forceinline__ void integral_wave(const float* bpts, const double* prevrow, double* rec, int w, int nr, int r0, int l, int dbg) {
+__device__ __forceinline__ void integral_wave(const float* bpts, const double* prevrow, double* rec, int w, int nr, int r0, int l) {
   const int W1 = w + 1, r = r0 + l;
   double cur[NC], h1[NC], h2[NC], p0[NC];   // cur[c] of the running column; own outputs one / two steps ago; prev[c]
 #pragma unroll
@@ -293,7 +292,7 @@ __device__ __forceinline__ void integral_wave(const float* bpts, const double* p
         if (NC == 3) out[NC - 1] += (double)ii_elem<C0 + NC - 1>(ex, ey, ez);
       }
       const size_t o = (size_t)(r + 1) * W1 + (c + 1);
-      ii_store<C0, NC>(rec + ((dbg & 4) ? (size_t)l : o) * 10 + C0, out);
+      ii_store<C0, NC>(rec + o * 10 + C0, out);
       if (c == 0) {  // integral column 0 of this row is zero
         const double zero[NC] = {};
         ii_store<C0, NC>(rec + (size_t)(r + 1) * W1 * 10 + C0, zero);
@@ -321,11 +320,10 @@ __global__ __launch_bounds__(256) void k_integral(View V, int band_rows) {
     const int nr = min(band_rows, h - r0);
     for (int k = tid; k < nr * w * 3; k += 256) bpts[k] = pts[(size_t)r0 * w * 3 + k];   // coalesced
     __syncthreads();
-    if (V.dbg & 64) {}
-    else if (wave == 0) integral_wave<0, 3>(bpts, prevrow, rec, w, nr, r0, lane, V.dbg);
-    else if (wave == 1) integral_wave<3, 3>(bpts, prevrow, rec, w, nr, r0, lane, V.dbg);
-    else if (wave == 2) integral_wave<6, 2>(bpts, prevrow, rec, w, nr, r0, lane, V.dbg);
-    else integral_wave<8, 2>(bpts, prevrow, rec, w, nr, r0, lane, V.dbg);
+    if (wave == 0) integral_wave<0, 3>(bpts, prevrow, rec, w, nr, r0, lane);
+    else if (wave == 1) integral_wave<3, 3>(bpts, prevrow, rec, w, nr, r0, lane);
+    else if (wave == 2) integral_wave<6, 2>(bpts, prevrow, rec, w, nr, r0, lane);
+    else integral_wave<8, 2>(bpts, prevrow, rec, w, nr, r0, lane);
     // stage the last row of this band for the next band's lane 0
     __syncthreads();
     if (r0 + band_rows < h) {
@@ -650,7 +648,6 @@ __device__ __forceinline__ bool refine_compare(float dist_thr, const float* mode
   return d < (double)t;
 }
 __device__ __forceinline__ void refine_record(const View& V, int slot, int model_idx, unsigned long long pass, unsigned long long key, int target) {
-  if (V.dbg & 1) return;
   Region* R = &V.reg[(size_t)slot * kMaxRegions + model_idx];
   atomicAdd(&R->inliers, 1);
   atomicMax(&R->last_key, (pass << 60) | (key << 24) | (unsigned long long)target);
@@ -676,7 +673,7 @@ __global__ __launch_bounds__(256) void k_refine(View V) {
     for (int k = threadIdx.x; k < (nr + 1) * w; k += 256) lband[k] = L[(size_t)r0 * w + k];
     for (int k = threadIdx.x; k < (nr + 1) * w * 3; k += 256) pband[k] = gp[(size_t)r0 * w * 3 + k];
     __syncthreads();
-    if (threadIdx.x < 64 && !(V.dbg & 2)) {
+    if (threadIdx.x < 64) {
       // One step = one pixel of this lane's row.  Only the two neighbour labels have to be read after the previous step's writes; the
       // lane's own label is carried in a register (the row above wrote it at least one step before it was read as `rl`), and the
       // points / the plane model of the NEXT step are fetched while this step's labels are on their way.
@@ -741,7 +738,7 @@ __global__ __launch_bounds__(256) void k_refine(View V) {
     for (int k = threadIdx.x; k < (nr + 1) * w; k += 256) lband[k] = L[(size_t)rlo * w + k];
     for (int k = threadIdx.x; k < (nr + 1) * w * 3; k += 256) pband[k] = gp[(size_t)rlo * w * 3 + k];
     __syncthreads();
-    if (threadIdx.x < 64 && !(V.dbg & 2)) {
+    if (threadIdx.x < 64) {
       const int l = threadIdx.x;  // lane l owns row rhi - l; same register-carried form as sweep 1, mirrored
       const int steps = w + 2 * (nr - 1);
       const bool rowok = l < nr;
@@ -858,7 +855,7 @@ __device__ __forceinline__ int refine_eval(const short* Lc, const unsigned short
 }
 template <int SWEEP, bool MASKED>
 __device__ __forceinline__ void refine_sweep_lds(short* Lc, unsigned short* M, const float* models, int nregs, const float* pts, float dthr, int w, int h,
-                                                 int* s_changed, int* rcnt, unsigned long long* rkey, int* dbgc, int dbg) {
+                                                 int* s_changed, int* rcnt, unsigned long long* rkey) {
   const int tid = threadIdx.x;
   const int tw = (w + kRefTX - 1) / kRefTX, th = (h + kRefTY - 1) / kRefTY;
   const int c0 = (tid % kRefTX) * tw, r0 = (tid / kRefTX) * th;
@@ -871,8 +868,7 @@ __device__ __forceinline__ void refine_sweep_lds(short* Lc, unsigned short* M, c
       const int i = r * w + c;
       if (Lc[i] < kMaxRegions) continue;
       cand |= 1u << ((r - r0) * tw + (c - c0));
-      if (MASKED && (dbg & 16)) M[i] = 0;
-      else if (MASKED) {
+      if (MASKED) {
         int s1, s2; bool ok1, ok2;
         refine_writers<SWEEP>(Lc, i, r, c, w, h, &s1, &s2, &ok1, &ok2);
         unsigned m = 0;
@@ -891,10 +887,9 @@ __device__ __forceinline__ void refine_sweep_lds(short* Lc, unsigned short* M, c
         if (m) act |= 1u << ((r - r0) * tw + (c - c0));
       }
     }
-  int passes = 0;
   if (tid < 3) s_changed[tid] = 0;
   __syncthreads();
-  for (int pass = 0; pass < ((dbg & 32) ? 0 : w + h + 2); ++pass) {
+  for (int pass = 0; pass < w + h + 2; ++pass) {
     // three flags in rotation: pass p raises [p % 3], clears [(p + 1) % 3] (last read before the barrier of pass p - 1): one barrier per pass
     if (tid == 0) s_changed[(pass + 1) % 3] = 0;
     bool ch = false;
@@ -912,11 +907,9 @@ __device__ __forceinline__ void refine_sweep_lds(short* Lc, unsigned short* M, c
     }
     if (ch) s_changed[pass % 3] = 1;
     __syncthreads();
-    ++passes;
     if (!s_changed[pass % 3]) break;
   }
   __syncthreads();
-  if (dbgc && tid == 0) { atomicMax(&dbgc[SWEEP], passes); atomicAdd(&dbgc[2 + SWEEP], passes); }
   for (int r = r0; r < r1; ++r)
     for (int c = c0; c < c1; ++c) {
       const int i = r * w + c;
@@ -952,15 +945,13 @@ __global__ __launch_bounds__(kRefTX * kRefTY) void k_refine_lds(View V) {
   const float* gp = V.pts + (size_t)b.pix0 * 3;
   for (int i = tid; i < n; i += NT) Lc[i] = (short)L[i];
   __syncthreads();
-  int* dbgc = (V.dbg & 8) ? V.overflow + 2 : nullptr;
   if (nregs <= kRefMaskRegions) {
-    refine_sweep_lds<1, true>(Lc, M, models, nregs, gp, V.dist_thr, w, h, s_changed, rcnt, rkey, dbgc, V.dbg);
-    refine_sweep_lds<2, true>(Lc, M, models, nregs, gp, V.dist_thr, w, h, s_changed, rcnt, rkey, dbgc, V.dbg);
+    refine_sweep_lds<1, true>(Lc, M, models, nregs, gp, V.dist_thr, w, h, s_changed, rcnt, rkey);
+    refine_sweep_lds<2, true>(Lc, M, models, nregs, gp, V.dist_thr, w, h, s_changed, rcnt, rkey);
   } else {
-    refine_sweep_lds<1, false>(Lc, M, models, nregs, gp, V.dist_thr, w, h, s_changed, rcnt, rkey, dbgc, V.dbg);
-    refine_sweep_lds<2, false>(Lc, M, models, nregs, gp, V.dist_thr, w, h, s_changed, rcnt, rkey, dbgc, V.dbg);
+    refine_sweep_lds<1, false>(Lc, M, models, nregs, gp, V.dist_thr, w, h, s_changed, rcnt, rkey);
+    refine_sweep_lds<2, false>(Lc, M, models, nregs, gp, V.dist_thr, w, h, s_changed, rcnt, rkey);
   }
-  if (dbgc && tid == 0) atomicAdd(&dbgc[5], 1);
   for (int i = tid; i < n; i += NT) L[i] = Lc[i];
   if (tid < nregs && rcnt[tid] > 0) {
     Region* R = &V.reg[(size_t)slot * kMaxRegions + tid];
@@ -2180,7 +2171,7 @@ static int seg_enqueue(sslam_seg* s, const sslam_frame* frames, int n_frames, in
     if ((rc = seg_alloc(s, s->cap_box, &V.nreg))) return rc;
     if ((rc = seg_alloc(s, s->cap_pix * 4, &V.contour))) return rc;
     if ((rc = seg_alloc(s, s->cap_box, &V.ccount))) return rc;
-    if ((rc = seg_alloc(s, (size_t)8, &V.overflow))) return rc;   // [2] overflow counters + [6] debug counters (SSLAM_SEG_DBG & 8)
+    if ((rc = seg_alloc(s, (size_t)8, &V.overflow))) return rc;   // [2] overflow counters (+ spare)
   }
   V.nbox = nb; V.npix_total = (int)npix; V.maxpix = maxpix;
   V.box = s->d_box; V.cloud = s->d_cloud; V.cloud_stride = frame_bytes;
@@ -2188,8 +2179,7 @@ static int seg_enqueue(sslam_seg* s, const sslam_frame* frames, int n_frames, in
   V.mdcf = P.max_depth_change_factor; V.smoothing = P.normal_smoothing_size;
   V.ang_thr_cos = cosf(P.angular_threshold); V.dist_thr = P.distance_threshold; V.max_curv = P.maximum_curvature;
   V.min_inliers = (unsigned)P.num_point_seg;
-  { const char* e = getenv("SSLAM_SEG_DBG"); V.dbg = e ? atoi(e) : 0; }
-  { const char* e = getenv("SSLAM_SEG_REFINE_BH"); V.refine_bh = e ? std::max(2, std::min(64, atoi(e))) : (nb > 512 ? 24 : 64); }
+  V.refine_bh = nb > 512 ? 24 : 64;
   s->q_frames.resize(n_frames);
   for (int f = 0; f < n_frames; ++f) { memcpy(s->q_frames[f].robot_pose, frames[f].robot_pose, sizeof(float) * 6); s->q_frames[f].cam_angle = frames[f].cam_angle; }
   s->q_boxes.resize(nb);
@@ -2227,83 +2217,47 @@ static int seg_enqueue(sslam_seg* s, const sslam_frame* frames, int n_frames, in
       rband_bytes = std::max(rband_bytes, (size_t)(bhr + 1) * b.w * 4 * sizeof(float));
     }
     { const int rc_lds = seg_lds_opt_in(s->P.device); if (rc_lds) return rc_lds; }   // > 64 KiB of dynamic LDS for the band / label kernels, once per device
-    const bool dbg = getenv("SSLAM_SEG_DEBUG") != nullptr;
-#define DBG(name) do { if (dbg) { hipError_t e_ = hipStreamSynchronize(s->stream); fprintf(stderr, "[seg] %s: %s\n", name, hipGetErrorString(e_)); } } while (0)
     SSLAM_HIP_TRY(hipMemsetAsync(V.ccount, 0, nb * sizeof(int), s->stream));
     hipLaunchKernelGGL(k_crop, pg, pb, 0, s->stream, V);
-    DBG("k_crop");
     hipLaunchKernelGGL(k_depth_change, pg, pb, 0, s->stream, V);
-    DBG("k_depth_change");
     hipLaunchKernelGGL(k_distance_map, dim3(nb), dim3(256), band_bytes, s->stream, V);
-    DBG("k_distance_map");
     {
       // band rows: as many as fit next to the (w+1) x 10 double carry row in ~150 KiB of LDS (<= 64 lanes)
       const size_t carry = (size_t)(maxw + 1) * 10 * sizeof(double);
       // (a call with more boxes than CUs takes 24-row bands: three boxes per CU instead of one)
-      const char* ie = getenv("SSLAM_SEG_INTEGRAL_ROWS");
-      const size_t row_cap = ie ? (size_t)std::max(1, std::min(64, atoi(ie))) : (nb > 512 ? 24 : 64);
+      const size_t row_cap = nb > 512 ? 24 : 64;
       const int ib_rows = (int)std::max<size_t>(1, std::min<size_t>(row_cap, (150 * 1024 - carry) / ((size_t)maxw * 12)));
       const size_t ilds = carry + (size_t)ib_rows * maxw * 12;
       hipLaunchKernelGGL(k_integral, dim3(nb), dim3(256), ilds, s->stream, V, ib_rows);
     }
-    DBG("k_integral");
     hipLaunchKernelGGL(k_normals, pg, pb, 0, s->stream, V);
-    DBG("k_normals");
     if (maxpix <= kCcLdsMax && !getenv("SSLAM_SEG_GLOBAL_CC")) {
       hipLaunchKernelGGL(k_cc_lds, dim3(nb), dim3(1024), (size_t)maxpix * sizeof(int), s->stream, V);
-      DBG("k_cc_lds");
     } else {
       hipLaunchKernelGGL(k_cc_init, pg, pb, 0, s->stream, V);
-      DBG("k_cc_init");
       hipLaunchKernelGGL(k_cc_merge, pg, pb, 0, s->stream, V);
-      DBG("k_cc_merge");
       hipLaunchKernelGGL(k_cc_flatten, pg, pb, 0, s->stream, V);
-      DBG("k_cc_flatten");
       hipLaunchKernelGGL(k_cc_flatten2, pg, pb, 0, s->stream, V);
-      DBG("k_cc_flatten2");
     }
     if (nb > 256) hipLaunchKernelGGL(k_regions<256>, dim3(nb), dim3(256), 0, s->stream, V);
     else hipLaunchKernelGGL(k_regions<1024>, dim3(nb), dim3(1024), 0, s->stream, V);
-    DBG("k_regions");
     hipLaunchKernelGGL(k_relabel, pg, pb, 0, s->stream, V);
-    DBG("k_relabel");
     bool tiles_ok = true;   // k_refine_lds: every thread's tile must fit its 32-bit candidate mask
     for (auto& b : s->boxes) tiles_ok = tiles_ok && ((b.w + kRefTX - 1) / kRefTX) * ((b.h + kRefTY - 1) / kRefTY) <= 32;
     if (maxpix <= kCcLdsMax && tiles_ok && !getenv("SSLAM_SEG_WAVEFRONT_REFINE")) {
       // 16-bit labels + 16-bit masks: 4 bytes per pixel (three 12k-pixel boxes per CU)
       hipLaunchKernelGGL(k_refine_lds, dim3(nb), dim3(kRefTX * kRefTY), (size_t)maxpix * 4 + 8, s->stream, V);
-      DBG("k_refine_lds");
-      if (V.dbg & 8) {
-        int dc[6];
-        (void)hipStreamSynchronize(s->stream);
-        (void)hipMemcpy(dc, V.overflow + 2, sizeof dc, hipMemcpyDeviceToHost);
-        fprintf(stderr, "[seg] refine passes: sweep 1 max %d mean %.1f, sweep 2 max %d mean %.1f over %d boxes\n", dc[1], dc[3] / (double)std::max(dc[5], 1), dc[2],
-                dc[4] / (double)std::max(dc[5], 1), dc[5]);
-      }
     } else {
       hipLaunchKernelGGL(k_refine, dim3(nb), dim3(256), rband_bytes, s->stream, V);
-      DBG("k_refine");
-    }
-    if (dbg) {
-      std::vector<Region> rr((size_t)nb * kMaxRegions); std::vector<int> nn(nb);
-      (void)hipMemcpy(rr.data(), V.reg, rr.size() * sizeof(Region), hipMemcpyDeviceToHost);
-      (void)hipMemcpy(nn.data(), V.nreg, nb * sizeof(int), hipMemcpyDeviceToHost);
-      for (int bi = 0; bi < nb; ++bi) for (int k = 0; k < nn[bi]; ++k) {
-        const Region& R = rr[(size_t)bi * kMaxRegions + k];
-        fprintf(stderr, "[seg] box %d reg %d: inl %d first %d label %d key %llx\n", bi, k, R.inliers, R.first_inlier, R.label, R.last_key);
-      }
     }
     size_t cimg_bytes = 0;
     for (auto& b : s->boxes) cimg_bytes = std::max(cimg_bytes, (size_t)(b.w + 2) * (b.h + 2));
-    if (cimg_bytes <= 150 * 1024 && !getenv("SSLAM_SEG_NOSTAGE")) {
+    if (cimg_bytes <= 150 * 1024) {
       hipLaunchKernelGGL(k_contour<true>, dim3(nb), dim3(256), cimg_bytes, s->stream, V);
-    DBG("k_contour");
     } else {
       hipLaunchKernelGGL(k_contour<false>, dim3(nb), dim3(256), 0, s->stream, V);
-    DBG("k_contour");
     }
     hipLaunchKernelGGL(k_area, dim3(nb, kMaxRegions), dim3(64), 0, s->stream, V);
-    DBG("k_area");
     SSLAM_HIP_TRY(hipEventRecord(e1, s->stream));
     SSLAM_HIP_TRY(hipMemcpyAsync(regs, V.reg, (size_t)nb * kMaxRegions * sizeof(Region), hipMemcpyDeviceToHost, s->stream));
     SSLAM_HIP_TRY(hipMemcpyAsync(nreg, V.nreg, nb * sizeof(int), hipMemcpyDeviceToHost, s->stream));
@@ -2332,7 +2286,6 @@ static int seg_finish(sslam_seg* s, sslam_plane* out, int max_out, int32_t* out_
     if (le != hipSuccess) return set_error(SSLAM_ERR_HIP, "frontend kernels: %s", hipGetErrorString(le));
     SSLAM_HIP_TRY(hipEventElapsedTime(&kernel_ms, s->q_e0, s->q_e1));
   }
-  if (getenv("SSLAM_SEG_DEBUG")) for (int bi = 0; bi < nb; ++bi) for (int k = 0; k < nreg[bi]; ++k) { const Region& R = regs[(size_t)bi * kMaxRegions + k]; fprintf(stderr, "[seg] post box %d reg %d: inl %d contour %d off %d area %g\n", bi, k, R.inliers, R.contour_n, R.contour_off, R.area); }
   int nout = 0, dropped = 0;
   for (int bi = 0; bi < nb; ++bi) {
     const sslam_seg::FrameMeta& fr = s->q_frames[s->box_frame[bi]];

@@ -28,7 +28,8 @@ def _internal_order(gp):
 def _plan_and_system(hip_lib, g, interleave, env=None):
     from semantic_slam_amd import GraphSLAM
     old = {}
-    for k, v in (env or {}).items():
+    env = {"SSLAM_CHOL_OPTS": ",".join(f"{k}={v}" for k, v in env.items())} if env else {}   # plan options by field name (chol_plan.hpp CholOpts)
+    for k, v in env.items():
         old[k] = os.environ.get(k); os.environ[k] = str(v)
     try:
         gp = GraphProblem.from_synth(g, interleave=interleave)
@@ -146,25 +147,25 @@ def test_plan_small_graph_matches_dense_cholesky(hip_lib, interleave):
 def test_plan_with_tiny_pieces_exercises_every_phase(hip_lib):
     """Caps far below the defaults force many pieces, external phases, split lists (partial tiles) and a multi-piece tail."""
     g = make_graph(150, 30, seed=5)
-    env = {"SSLAM_CHOL_SMALL_COLS": 0, "SSLAM_CHOL_CAP_LEAF": 400, "SSLAM_CHOL_CAP_TAIL": 700, "SSLAM_CHOL_TAIL_WIDTH": 2, "SSLAM_CHOL_MIN_CHUNK": 1, "SSLAM_CHOL_PCAP_LEAF": 16, "SSLAM_CHOL_NT_LEAF": 256}
+    env = {"cap_leaf": 400, "cap_tail": 700, "tail_width": 2, "min_chunk": 1, "pcap_leaf": 16, "nt_leaf": 256}
     plan, H, b = _plan_and_system(hip_lib, g, False, env)
     assert plan.npiece > 20 and len(plan.tail_pieces) >= 2 and len(plan.plv_ptr) > 2
     assert len(plan.mb) > 0 and len(plan.umb) > 0 and np.any(plan.piece["nas"] > 0) and np.any(plan.piece["nus"] > 0)
     _structure_invariants(plan)
     _check(plan, H, b, 1e-3)
     # pieces of equal depth packed into execution groups (one workgroup factors several subtrees side by side)
-    plan3, H3, b3 = _plan_and_system(hip_lib, g, False, dict(env, SSLAM_CHOL_GROUP_CAP=1500, SSLAM_CHOL_NT_LEAF=512))
+    plan3, H3, b3 = _plan_and_system(hip_lib, g, False, dict(env, group_cap=1500, nt_leaf=512))
     assert plan3.npiece < plan.npiece
     _structure_invariants(plan3)
     _check(plan3, H3, b3, 1e-3)
     # same system, no tail: every piece goes through the per-depth launches
-    plan2, H2, b2 = _plan_and_system(hip_lib, g, False, dict(env, SSLAM_CHOL_TAIL_WIDTH=0))
+    plan2, H2, b2 = _plan_and_system(hip_lib, g, False, dict(env, tail_width=0))
     assert len(plan2.tail_pieces) == 0
     _check(plan2, H2, b2, 1e-3)
     # a depth with many pieces is launched in parts, by LDS need (sorted inside the depth; cuts where a CU holds 32 / 24 / 16 workgroups)
     g5 = make_graph(400, 80, seed=2)
-    plan5, H5, b5 = _plan_and_system(hip_lib, g5, False, {"SSLAM_CHOL_SMALL_COLS": 0, "SSLAM_CHOL_TAIL_WIDTH": 2})
-    plan4, H4, b4 = _plan_and_system(hip_lib, g5, False, {"SSLAM_CHOL_SMALL_COLS": 0, "SSLAM_CHOL_TAIL_WIDTH": 2, "SSLAM_CHOL_SPLIT_MIN": 4})
+    plan5, H5, b5 = _plan_and_system(hip_lib, g5, False, {"tail_width": 2})
+    plan4, H4, b4 = _plan_and_system(hip_lib, g5, False, {"tail_width": 2, "split_min": 4})
     assert len(plan4.plv_ptr) > len(plan5.plv_ptr) and plan4.npiece == plan5.npiece
     assert int(plan4.plv_lds_b[0]) < int(plan5.plv_lds_b[0])   # the small pieces of the first depth no longer reserve what its largest needs
     _structure_invariants(plan4)
@@ -176,10 +177,10 @@ def test_mid_class_pieces_between_the_bottom_and_the_tail(hip_lib):
     per depth next to the leaf pieces of that depth); their internal updates come as right-looking lists like the tail's.  Fewer, larger
     pieces there, less update-matrix storage, same factor."""
     g = make_graph(600, 120, seed=3)
-    base = {"SSLAM_CHOL_SMALL_COLS": 0, "SSLAM_CHOL_TAIL_WIDTH": 2, "SSLAM_CHOL_CAP_LEAF": 500, "SSLAM_CHOL_MID_WIDTH": 0}
+    base = {"tail_width": 2, "cap_leaf": 500, "mid_width": 0}
     p0, H0, b0 = _plan_and_system(hip_lib, g, False, base)
     assert not np.any(p0.piece["pad5"] == 1) and not np.any(p0.plv_cls == 1)
-    p1, H1, b1 = _plan_and_system(hip_lib, g, False, dict(base, SSLAM_CHOL_MID_WIDTH=12, SSLAM_CHOL_CAP_MID=1600))
+    p1, H1, b1 = _plan_and_system(hip_lib, g, False, dict(base, mid_width=12, cap_mid=1600))
     mid = p1.piece["pad5"] == 1
     assert mid.sum() >= 3 and np.any(p1.plv_cls == 1) and np.any(p1.plv_cls == 0) and len(p1.tail_pieces) >= 1
     assert p1.npiece < p0.npiece and p1.unz < p0.unz and p1.lnz == p0.lnz
@@ -191,34 +192,30 @@ def test_mid_class_pieces_between_the_bottom_and_the_tail(hip_lib):
     _structure_invariants(p1)
     _check(p1, H1, b1, 1e-3)
     # no tail at all: the mid class runs up to the root
-    p2, H2, b2 = _plan_and_system(hip_lib, g, False, dict(base, SSLAM_CHOL_MID_WIDTH=12, SSLAM_CHOL_CAP_MID=1600, SSLAM_CHOL_TAIL_WIDTH=0))
+    p2, H2, b2 = _plan_and_system(hip_lib, g, False, dict(base, mid_width=12, cap_mid=1600, tail_width=0))
     assert len(p2.tail_pieces) == 0 and np.any(p2.piece["pad5"] == 1)
     _structure_invariants(p2)
     _check(p2, H2, b2, 1e-3)
 
 
-def test_small_graph_plan_is_all_tail_and_both_orderings_factor(hip_lib):
-    """SSLAM_CHOL_SMALL_COLS: a graph of <= small_cols block columns is walked by one workgroup from the leaves to the root (no per-depth
-    launches: what the fused LM kernel k_lm_trial_small needs; off by default); both elimination orders (multiple minimum degree over independent sets, round 4; lowest-index minimum degree) give a
-    valid plan, and the new one a shallower tree."""
+def test_parent_links_and_both_orderings_factor(hip_lib):
+    """Every piece names the piece its update matrix goes to (what the dependency-driven launch k_chol_flow waits on); both elimination
+    orders (multiple minimum degree over independent sets, round 4; lowest-index minimum degree) give a valid plan, and the new one a
+    shallower tree."""
     g = make_graph(150, 30, seed=5)
-    plan, H, b = _plan_and_system(hip_lib, g, False, {"SSLAM_CHOL_SMALL_COLS": 1200})
-    assert len(plan.plv_pieces) == 0 and len(plan.tail_pieces) == plan.npiece and plan.npiece >= 2
+    plan, H, b = _plan_and_system(hip_lib, g, False, {"cap_leaf": 400, "tail_width": 2})
     _structure_invariants(plan)
     _check(plan, H, b, 1e-3)
-    g2 = make_graph(600, 120, seed=3)
-    # every piece names the piece its update matrix goes to (PieceMeta.pad4): later in launch order, -1 only for roots -- what the
-    # dependency-driven launch (k_chol_flow) waits on
     order_of = {int(p): k for k, p in enumerate(list(plan.plv_pieces) + list(plan.tail_pieces))}
     par = plan.piece["pad4"]
     assert (par >= -1).all() and (par == -1).sum() >= 1
     for p, q in enumerate(par):
         if q >= 0:
             assert order_of[int(q)] > order_of[p]
-            assert plan.piece["nus"][p] + plan.piece["nuit"][p] >= 0
+    g2 = make_graph(600, 120, seed=3)
     lv = {}
     for order in ("mmd", "mindeg"):
-        p2, H2, b2 = _plan_and_system(hip_lib, g2, False, {"SSLAM_CHOL_ORDER": order, "SSLAM_CHOL_SMALL_COLS": 0})
+        p2, H2, b2 = _plan_and_system(hip_lib, g2, False, {"order": order})
         _structure_invariants(p2)
         _check(p2, H2, b2, 1e-3)
         lv[order] = p2.nlevels
@@ -234,13 +231,13 @@ def test_plan_plane_landmarks_and_S_config(hip_lib):
 
 def test_bitset_ordering_gives_the_plan_of_the_list_ordering(hip_lib):
     """Graphs of <= 2048 nodes (what the orchestrator re-plans at every tick) are ordered on adjacency bitsets (chol_plan.hpp
-    multi_min_degree_bits); SSLAM_CHOL_ORDER_BITS=0 keeps the sorted-list form that large graphs use.  Same candidates, same tie breaks:
+    multi_min_degree_bits); SSLAM_CHOL_OPTS order_bits_max=0 keeps the sorted-list form that large graphs use.  Same candidates, same tie breaks:
     every array of the plan is identical."""
     names = ("col", "blk", "upd", "item", "mb", "ilv", "piece", "asrc", "usrc", "fwd", "uitem", "umb", "rcol", "rupd")
     for (n, m, seed, kind) in [(110, 39, 4, "point"), (436, 149, 9, "point"), (300, 60, 2, "plane"), (37, 5, 1, "point")]:
         g = make_graph(n, m, seed=seed, landmark_kind=kind)
         a, _, _ = _plan_and_system(hip_lib, g, False)
-        b, _, _ = _plan_and_system(hip_lib, g, False, {"SSLAM_CHOL_ORDER_BITS": 0})
+        b, _, _ = _plan_and_system(hip_lib, g, False, {"order_bits_max": 0})
         assert a.ncol == b.ncol and a.lnz == b.lnz and a.unz == b.unz and a.nlevels == b.nlevels
         for name in names:
             x, y = getattr(a, name), getattr(b, name)

@@ -146,23 +146,22 @@ def test_cholesky_solve_matches_oracle_cholesky(gpu_lib, lam):
 
 
 @pytest.mark.parametrize("env", [
-    {"SSLAM_CHOL_CAP_LEAF": "400", "SSLAM_CHOL_CAP_TAIL": "700", "SSLAM_CHOL_TAIL_WIDTH": "2", "SSLAM_CHOL_MIN_CHUNK": "1", "SSLAM_CHOL_PCAP_LEAF": "16", "SSLAM_CHOL_NT_LEAF": "256"},   # many pieces, split lists, a multi-piece tail
-    {"SSLAM_CHOL_CAP_LEAF": "400", "SSLAM_CHOL_CAP_TAIL": "700", "SSLAM_CHOL_TAIL_WIDTH": "0"},     # no tail: one launch per depth
-    {"SSLAM_CHOL_CAP_LEAF": "900", "SSLAM_CHOL_CAP_TAIL": "2000", "SSLAM_CHOL_NT_TAIL": "1024"},    # 1024-thread tail workgroups
-    {"SSLAM_CHOL_CAP_LEAF": "400", "SSLAM_CHOL_GROUP_CAP": "1500", "SSLAM_CHOL_NT_LEAF": "512", "SSLAM_CHOL_USTAGE": "0"},   # groups of subtrees per workgroup
-    {"SSLAM_CHOL_CAP_LEAF": "400", "SSLAM_CHOL_GROUP_CAP": "1200", "SSLAM_CHOL_NT_LEAF": "64", "SSLAM_CHOL_MIN_CHUNK": "1"},
-    {"SSLAM_CHOL_SPLIT_MIN": "4", "SSLAM_CHOL_TAIL_WIDTH": "2"},      # depths launched in parts, by LDS need
+    {"cap_leaf": "400", "cap_tail": "700", "tail_width": "2", "min_chunk": "1", "pcap_leaf": "16", "nt_leaf": "256"},   # many pieces, split lists, a multi-piece tail
+    {"cap_leaf": "400", "cap_tail": "700", "tail_width": "0"},     # no tail: one launch per depth
+    {"cap_leaf": "900", "cap_tail": "2000", "nt_tail": "1024"},    # 1024-thread tail workgroups
+    {"cap_leaf": "400", "group_cap": "1500", "nt_leaf": "512", "ustage": "0"},   # groups of subtrees per workgroup
+    {"cap_leaf": "400", "group_cap": "1200", "nt_leaf": "64", "min_chunk": "1"},
+    {"split_min": "4", "tail_width": "2"},      # depths launched in parts, by LDS need
     # round 5, mid class: the depths between the bottom and the tail as larger pieces on 256-thread workgroups (per-depth launches: no k_chol_flow)
-    {"SSLAM_CHOL_FLOW": "0", "SSLAM_CHOL_CAP_LEAF": "400", "SSLAM_CHOL_TAIL_WIDTH": "2", "SSLAM_CHOL_MID_WIDTH": "12", "SSLAM_CHOL_CAP_MID": "1200"},
-    {"SSLAM_CHOL_FLOW": "0", "SSLAM_CHOL_CAP_LEAF": "400", "SSLAM_CHOL_TAIL_WIDTH": "0", "SSLAM_CHOL_MID_WIDTH": "8", "SSLAM_CHOL_CAP_MID": "1500", "SSLAM_CHOL_NT_MID": "512"},
+    {"flow": "0", "cap_leaf": "400", "tail_width": "2", "mid_width": "12", "cap_mid": "1200"},
+    {"flow": "0", "cap_leaf": "400", "tail_width": "0", "mid_width": "8", "cap_mid": "1500", "nt_mid": "512"},
 ])
 def test_cholesky_pieces_of_every_shape(gpu_lib, monkeypatch, env):
     """The piece plan is cut by LDS capacity; caps far below the defaults force what the 5000-pose graph has (pieces with
     external updates, split update lists summed through partial tiles, a tail of several pieces) onto a 150-pose graph
     whose solution is checked against the oracle's Cholesky.  The same plans are pinned on the CPU by tests/test_chol_plan_cpu.py."""
     from semantic_slam_amd import GraphSLAM
-    for k, v in env.items():
-        monkeypatch.setenv(k, v)
+    monkeypatch.setenv("SSLAM_CHOL_OPTS", ",".join(f"{k}={v}" for k, v in env.items()))   # plan options by field name (chol_plan.hpp CholOpts)
     g = make_graph(150, 30, seed=5)
     gp = GraphProblem.from_synth(g)
     G = GraphSLAM.from_problem(gp)
@@ -595,6 +594,7 @@ def test_path_marginals_equal_the_multi_rhs_solves(gpu_lib):
 def _optimize_variant(gp, iters, env, fused, spec=1):
     import os
     from semantic_slam_amd import GraphSLAM
+    env = {"SSLAM_CHOL_OPTS": ",".join(f"{k}={v}" for k, v in env.items())} if env else {}   # plan options by field name (chol_plan.hpp CholOpts)
     old = {k: os.environ.get(k) for k in env}
     os.environ.update({k: str(v) for k, v in env.items()})
     try:
@@ -615,8 +615,7 @@ def test_single_launch_solve_and_fused_steps_equal_the_stand_alone_kernels(gpu_l
         launch, then the accept / reject replay (k_lm_control_spec) -> bitwise (a), same iteration AND trial counts;
     (a) Jacobian kernels + k_lm_begin_small + k_chol_flow (factor and both solves in one dependency-driven launch) + k_lm_end_small;
     (b) the same plan with the stand-alone LM kernels round the single-launch solve -> bitwise (a);
-    (c) SSLAM_CHOL_FLOW=0: a launch per depth of the tree (other work-item cuts: same result up to rounding);
-    (d) SSLAM_CHOL_SMALL_COLS: the all-tail plan with k_lm_trial_small (every retry inside one launch) -> bitwise its own stand-alone run;
+    (c) SSLAM_CHOL_OPTS flow=0: a launch per depth of the tree (other work-item cuts: same result up to rounding);
     and all of them equal the oracle."""
     for (n, m, kind, iters) in [(120, 24, "point", 40), (80, 16, "plane", 12), (300, 60, "point", 10)]:
         g = make_graph(n, m, seed=11, landmark_kind=kind)
@@ -627,13 +626,10 @@ def test_single_launch_solve_and_fused_steps_equal_the_stand_alone_kernels(gpu_l
         assert sp[:3] == a[:3] and np.array_equal(sp[3], a[3]), (sp[:3], a[:3])
         assert sp2[:3] == a[:3] and np.array_equal(sp2[3], a[3]), (sp2[:3], a[:3])
         b = _optimize_variant(gp, iters, {}, 0)
-        c = _optimize_variant(gp, iters, {"SSLAM_CHOL_FLOW": 0}, 0)
-        d1 = _optimize_variant(gp, iters, {"SSLAM_CHOL_SMALL_COLS": 1200, "SSLAM_CHOL_FLOW": 0}, 1)
-        d0 = _optimize_variant(gp, iters, {"SSLAM_CHOL_SMALL_COLS": 1200, "SSLAM_CHOL_FLOW": 0}, 0)
+        c = _optimize_variant(gp, iters, {"flow": 0}, 0)
         assert a[:3] == b[:3] and np.array_equal(a[3], b[3]), (a[:3], b[:3])
-        assert d1[:3] == d0[:3] and np.array_equal(d1[3], d0[3]), (d1[:3], d0[:3])
         st = gp.optimize(iters)
-        for r in (a, c, d1):
+        for r in (a, c):
             assert abs(r[2] - st.chi2_after) <= 1e-8 * st.chi2_after
             assert np.abs(r[3] - gp.est).max() <= 1e-5 * np.abs(gp.est).max()
         gp = GraphProblem.from_synth(g, interleave=True)   # gp.optimize moved the estimates: fresh problem for the next size
@@ -646,20 +642,20 @@ def test_single_launch_solve_on_the_L_graph_and_a_small_batch(gpu_lib):
     from semantic_slam_amd import GraphSLAM, GraphBatch
     g = make_graph(5000, 1000, seed=2)
     gp = GraphProblem.from_synth(g)
-    a = _optimize_variant(gp, 4, {"SSLAM_CHOL_FLOW": 2}, 1)     # 2: the single launch on a wide tree too (by default such a graph keeps its per-depth launches: measured faster)
-    c = _optimize_variant(gp, 4, {"SSLAM_CHOL_FLOW": 0}, 0)
+    a = _optimize_variant(gp, 4, {"flow": 2}, 1)     # 2: the single launch on a wide tree too (by default such a graph keeps its per-depth launches: measured faster)
+    c = _optimize_variant(gp, 4, {"flow": 0}, 0)
     assert a[0] == c[0] and abs(a[2] - c[2]) <= 1e-9 * c[2]
     assert np.abs(a[3] - c[3]).max() <= 1e-7 * np.abs(c[3]).max()
     out = []
     for flow in (1, 0):
-        os.environ["SSLAM_CHOL_FLOW"] = str(flow)
+        os.environ["SSLAM_CHOL_OPTS"] = f"flow={flow}"
         try:
             graphs = [GraphSLAM.from_synth(make_graph(90 + 7 * k, 18 + k, seed=20 + k)) for k in range(4)]
             bt = GraphBatch(graphs); bt.upload()
             st = bt.optimize(15)
             bt.download()
         finally:
-            os.environ.pop("SSLAM_CHOL_FLOW")
+            os.environ.pop("SSLAM_CHOL_OPTS")
         out.append(([(int(s.iterations), float(s.chi2_after)) for s in st], [G.estimates().copy() for G in graphs]))
     for (ia, ca), (ib, cb) in zip(out[0][0], out[1][0]):
         assert abs(ca - cb) <= 1e-9 * cb
@@ -792,29 +788,3 @@ def test_seg_golden_patch(gpu_lib):
                                  point_step=32, row_step=32 * w)
     assert np.array_equal(seg.normals(0).reshape(-1, 4), g["normals"], equal_nan=True)
     assert np.array_equal(seg.labels(0).reshape(-1), g["labels"])
-
-
-def test_handover_jacobian_kernel_matches_oracle(gpu_lib):
-    """The hand-over form of the pose-row kernel (SSLAM_LIN_HANDOVER=1: a chain EdgeSE3 evaluated once, J_j^T Omega J_j handed to the
-    neighbouring row through LDS, operands prefetched a slot ahead) builds the same normal equations: H, b vs the oracle to 1e-11.
-    The switch is read once per process, hence the child process."""
-    import os, subprocess, sys
-    code = r'''
-import sys, numpy as np, scipy.sparse as sp
-sys.path.insert(0, %r)
-from semantic_slam_amd import GraphSLAM
-from semantic_slam_amd.synth import make_graph
-from oracle.oracle import GraphProblem
-for kind, tol in (("point", 1e-11), ("plane", 2e-5)):
-    gp = GraphProblem.from_synth(make_graph(200, 40, seed=4, landmark_kind=kind))
-    G = GraphSLAM.from_problem(gp)
-    U, b = G.linearize(); Uo, bo = gp.linearize()
-    f = lambda M: (M + sp.triu(M, 1).T).tocsc()
-    assert abs(f(U) - f(Uo)).max() <= tol * abs(Uo).max() and np.abs(b - bo).max() <= tol * max(1.0, np.abs(bo).max())
-    assert G.optimize(6)
-    st = gp.optimize(6)
-    assert G.last_stats.iterations == st.iterations and abs(G.last_stats.chi2_after - st.chi2_after) <= 1e-6 * st.chi2_after
-print("handover ok")
-''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, SSLAM_LIN_HANDOVER="1"), capture_output=True, text=True)
-    assert out.returncode == 0 and "handover ok" in out.stdout, out.stdout + out.stderr
