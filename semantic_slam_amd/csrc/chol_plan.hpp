@@ -69,11 +69,30 @@ inline int blk_irank(int info) { return ((info >> 11) & 31) | (((info >> 24) & 2
 struct AsmSrc { int uoff, uyoff; };      // an update-matrix block of a child piece (Uval offset); uyoff >= 0: its rhs part too (diagonal blocks)
 struct FwdMeta { int off, yoff; };       // block L(j,k) of row j: Lval offset | (dim k == 6) << 31, y offset of column k
 
-struct UpdMeta { int ua, ub, ux, pk; };  // Lval offsets of L_ik, L_jk; y offset (elimination order) of y_k; flags below
-constexpr int kUpdDi6 = 1 << 20;         // target block has 6 rows (else 3)
-constexpr int kUpdDk6 = 1 << 21;         // source column k is 6 wide (else 3)
-constexpr int kUpdDiag = 1 << 22;        // target is a diagonal block (carries the forward-substitution rhs too)
-constexpr int kUpdDj6 = 1 << 23;         // target column is 6 wide (else 3)
+// One update  S(i,j) -= L(i,k) L(j,k)^T  in 8 bytes (round 5; rounds 1-4: four ints, and the update records were a third of a plan's table
+// bytes and as large in a piece's LDS as its part of L).  Both operands are blocks of the piece that owns the source column k, so their
+// offsets are piece-local and fit 16 bits:
+//   ab = local Lval offset of L_ik | local offset of L_jk << 16
+//   xk = local y offset of column k (13 bits) | flags << 28                                       target-major lists (upd[])
+//      = local offset of the target block (16 bits) | local y offset of its column << 16 (12 bits) | flags << 28     right-looking lists (rupd[])
+struct UpdMeta { unsigned ab, xk; };
+constexpr unsigned kUpdDi6 = 1u << 28;    // target block has 6 rows (else 3)
+constexpr unsigned kUpdDk6 = 1u << 29;    // source column k is 6 wide (else 3)
+constexpr unsigned kUpdDiag = 1u << 30;   // target is a diagonal block (carries the forward-substitution rhs too)
+constexpr unsigned kUpdDj6 = 1u << 31;    // target column is 6 wide (else 3)
+constexpr int kUpdLocalMax = 1 << 16, kUpdYMax = 1 << 13, kUpdRightYMax = 1 << 12;
+#if defined(__HIPCC__)
+#define SSLAM_HD_INLINE __host__ __device__ inline
+#else
+#define SSLAM_HD_INLINE inline
+#endif
+SSLAM_HD_INLINE int upd_ua(const UpdMeta& r) { return (int)(r.ab & 0xFFFFu); }
+SSLAM_HD_INLINE int upd_ub(const UpdMeta& r) { return (int)(r.ab >> 16); }
+SSLAM_HD_INLINE int upd_yk(const UpdMeta& r) { return (int)(r.xk & 0x1FFFu); }            // target-major records
+SSLAM_HD_INLINE int upd_rt(const UpdMeta& r) { return (int)(r.xk & 0xFFFFu); }            // right-looking records: target block
+SSLAM_HD_INLINE int upd_ry(const UpdMeta& r) { return (int)((r.xk >> 16) & 0xFFFu); }     // ... and the local y offset of its column
+inline UpdMeta upd_make(int ua_local, int ub_local, int yk_local, unsigned flags) { return UpdMeta{(unsigned)ua_local | ((unsigned)ub_local << 16), (unsigned)yk_local | flags}; }
+inline UpdMeta upd_make_right(int ua_local, int ub_local, int tl, int yl, unsigned flags) { return UpdMeta{(unsigned)ua_local | ((unsigned)ub_local << 16), (unsigned)tl | ((unsigned)yl << 16) | flags}; }
 
 struct ItemMeta { int u0, n, tloff, flags; };   // updates [u0, u0 + n) (index into the piece's update records, LDS copy) of one target
                                                 // block at piece-local offset tloff
@@ -81,8 +100,8 @@ constexpr int kItemSole = 1;                     // flags: bit 0 sole (subtract 
 constexpr int kItemSlotShift = 1, kItemSlotMask = 0x7FF, kItemYShift = 12;
 struct MbMeta { int tloff, ps0, n, info; };      // a target block with n > 1 items: partial slots [ps0, ps0 + n); info = di | dj << 4 | diag << 9 | ylocal << 12
 struct RCol { int u0, n; };             // tail pieces: the internal updates a finished column applies to later columns of its piece (right-looking form),
-                                         // records [u0, u0 + n) of rupd[] counted from the piece's first record (PieceMeta.pad3); UpdMeta with
-                                         // ux = target offset in the piece | local y offset of the target's column << 16
+                                         // records [u0, u0 + n) of rupd[] counted from the piece's first record (PieceMeta.pad3), in UpdMeta's
+                                         // right-looking form
 struct ILevel { int c0, c1, b0, b1, it0, it1, mb0, mb1; };   // one level inside a piece: columns, blocks (global ids), items and multi-blocks (piece-local)
 
 // update-matrix side: a block U(a,b) of the piece = sum of its own updates [u0, u0 + n) (upd[], sources in the piece) + the
@@ -121,7 +140,7 @@ struct SymIn {
   int64_t hll_base = 0, hpp_off_base = 0, hpl_base = 0, hll_off_base = 0;
 };
 struct CholOpts {
-  int cap_leaf = 900;      // doubles of L per piece (pieces that share launches): small pieces, many resident per CU
+  int cap_leaf = -1;       // doubles of L per piece (pieces that share launches): small pieces, many resident per CU.  -1: 700 for batches >= 32, else 900
   int cap_tail = 4608;     // doubles of L per piece of a tail (two tail workgroups per CU must fit the LDS)
   int max_blocks = 224;    // blocks per piece
   int tail_width = -1;     // a graph's tail starts where it has <= tail_width pieces per depth; -1: 6 for batches >= 32, else 2; 0: no tail
@@ -131,16 +150,22 @@ struct CholOpts {
   // bytes).  The depths between the bottom and the tail -- where a graph has <= mid_width pieces per depth -- are cut again with a larger
   // cap and run by wider workgroups, one launch per depth next to the leaf pieces of that depth: several columns of a chain share a
   // piece, their updates stay in LDS (right-looking lists like the tail's), and four waves share the tiles of what is still handed up.
-  int mid_width = -1;      // -1: 100 for batches >= 32, else 0 (small batches run k_chol_flow with one workgroup size); 0: no mid class
+  int mid_width = -1;      // -1: 60 for batches >= 32, else 0 (small batches run k_chol_flow with one workgroup size); 0: no mid class
   int cap_mid = 1800;      // doubles of L per mid piece (512 L graphs: 1800 / 2400 / 3600 -> 9.14 / 9.47 / 10.2 ms per factorisation, 9.55 without the class)
   int nt_mid = 256;        // its workgroup
   int pcap_mid = 16;
-  int nt_leaf = 64, nt_tail = 512;    // workgroup sizes the items are cut for
+  int nt_leaf = -1, nt_tail = 512;    // workgroup sizes the items are cut for; nt_leaf -1: 128 for batches >= 32 (groups of pieces, below), else 64
   int min_chunk = 4;       // a list of <= min_chunk updates is never split
   int split_min = 4096;    // a depth with at least this many pieces is launched in up to four parts, by LDS need
   int pcap_leaf = 4, pcap_tail = 32;   // partial tiles per phase (split lists): LDS budget of a piece
-  int group_cap = 0;       // > 0: pieces of equal depth are packed into groups of <= group_cap doubles of L (and <= group_blocks blocks) that one
-  int group_blocks = 1024; //      workgroup factors side by side: the per-level latencies and barriers are shared by all members
+  // Groups (round 5 default for large batches): the leaf pieces of equal depth of a graph are packed, neighbours in elimination order, into
+  // groups of <= group_cap doubles of L (and <= group_blocks blocks) that ONE workgroup factors side by side -- the levels inside the
+  // members run together, so every dependent step (a round trip to HBM, a 6 x 6 factor by one lane, a barrier) serves several pieces, and a
+  // wave's lanes are filled (a lone leaf piece keeps ~40 % of 64 lanes busy in its parallel phases and one or two in its diagonal blocks).
+  // 512 L graphs, factor / backward solve per batch: no groups 8.87 / 3.35 ms; 64-thread groups of 1000 (cap_leaf 500) 8.24 / 2.69;
+  // 128-thread groups of 2800 (cap_leaf 700) 8.35 / 2.29 (the default); 256-thread groups of 4000-5000 8.5-9.3 / 2.3-2.4.
+  int group_cap = -1;      // -1: 2800 for batches >= 32, else 0 (no groups: small batches run the dependency-driven launch, one piece per workgroup)
+  int group_blocks = 1024;
   int ustage = -1;         // 1: the per-depth kernels stage the update-matrix records in LDS too (one round trip for all tables: shorter
                            //    piece latency, fewer pieces per CU); -1: 1 for batches < 32 (latency-bound), else 0 (residency-bound)
   int order = 1;           // 0: minimum degree, lowest index first (rounds 1-3: eliminates a pose chain from one end -> a tree as deep as the chain);
@@ -436,7 +461,10 @@ inline int chol_symbolic(const SymIn& in, CholOpts opt, CholHost& out) {
   const int nPr = in.nPr, nLr = in.nLr, nrow = nPr + nLr, B = in.B;
   if (opt.tail_width < 0) opt.tail_width = B >= 32 ? 6 : 2;
   if (opt.ustage < 0) opt.ustage = B >= 32 ? 0 : 1;
-  if (opt.mid_width < 0) opt.mid_width = B >= 32 ? 100 : 0;
+  if (opt.mid_width < 0) opt.mid_width = B >= 32 ? 60 : 0;
+  if (opt.cap_leaf < 0) opt.cap_leaf = B >= 32 ? 700 : 900;
+  if (opt.group_cap < 0) opt.group_cap = B >= 32 ? 2800 : 0;
+  if (opt.nt_leaf < 0) opt.nt_leaf = B >= 32 ? 128 : 64;
   if (opt.order < 0) opt.order = 1;
   if (opt.order_mul < 0 || opt.order_add < 0) { opt.order_mul = B >= 32 ? 1.5 : 2.0; opt.order_add = B >= 32 ? 2 : 4; }
   out = CholHost();
@@ -880,9 +908,9 @@ inline int chol_symbolic(const SymIn& in, CholOpts opt, CholHost& out) {
           for (int q = pp; q < k1; ++q) {
             const int t = find_blk(j, brow[q]);     // present: checked when the internal updates were listed
             const int tl = out.blk[t].off - pm.lbase, yl = col_yoff[j] - pm.y0;
-            if (tl < 0 || tl >= (1 << 16) || yl < 0 || yl >= (1 << 15)) right_ok = false;   // (an oversized SSLAM_CHOL_CAP_TAIL) the packed records do not fit: target-major lists everywhere
-            const int tpk = (col_dim[brow[t]] == 6 ? kUpdDi6 : 0) | (t == bp[j] ? kUpdDiag : 0) | (col_dim[j] == 6 ? kUpdDj6 : 0) | (col_dim[k] == 6 ? kUpdDk6 : 0);
-            out.rupd.push_back(UpdMeta{boff[q], boff[pp], tl | (yl << 16), tpk});
+            if (tl < 0 || tl >= kUpdLocalMax || yl < 0 || yl >= kUpdRightYMax) right_ok = false;   // (an oversized cap_tail) the packed records do not fit: target-major lists everywhere
+            const unsigned tpk = (col_dim[brow[t]] == 6 ? kUpdDi6 : 0u) | (t == bp[j] ? kUpdDiag : 0u) | (col_dim[j] == 6 ? kUpdDj6 : 0u) | (col_dim[k] == 6 ? kUpdDk6 : 0u);
+            out.rupd.push_back(upd_make_right(boff[q] - pm.lbase, boff[pp] - pm.lbase, tl, yl, tpk));
           }
         }
         out.rcol[k].n = (int)out.rupd.size() - pm.pad3 - out.rcol[k].u0;
@@ -936,11 +964,11 @@ inline int chol_symbolic(const SymIn& in, CholOpts opt, CholHost& out) {
     bi0.assign(pm.nb, 0); bi1.assign(pm.nb, 0);
     for (int t = pm.b0; t < pm.b0 + pm.nb; ++t) {
       const int j = block_col[t];
-      const int tpk = (col_dim[brow[t]] == 6 ? kUpdDi6 : 0) | (t == bp[j] ? kUpdDiag : 0) | (col_dim[j] == 6 ? kUpdDj6 : 0);
+      const unsigned tpk = (col_dim[brow[t]] == 6 ? kUpdDi6 : 0u) | (t == bp[j] ? kUpdDiag : 0u) | (col_dim[j] == 6 ? kUpdDj6 : 0u);
       bi0[t - pm.b0] = (int)out.upd.size() - pm.iu0;
       for (int q = iu_ptr[t - pm.b0]; q < iu_ptr[t - pm.b0 + 1]; ++q) {
         const IU& u = iu_s[q];
-        out.upd.push_back(UpdMeta{u.ua, u.ub2, col_yoff[u.k], tpk | (col_dim[u.k] == 6 ? kUpdDk6 : 0)});
+        out.upd.push_back(upd_make(u.ua - pm.lbase, u.ub2 - pm.lbase, col_yoff[u.k] - pm.y0, tpk | (col_dim[u.k] == 6 ? kUpdDk6 : 0u)));
       }
       bi1[t - pm.b0] = (int)out.upd.size() - pm.iu0;
     }
@@ -991,6 +1019,7 @@ inline int chol_symbolic(const SymIn& in, CholOpts opt, CholHost& out) {
     pm.nimb = (int)out.mb.size() - pm.imb0;
     if (pm.nilv > kMaxILevels) { out.error = "a piece has too many internal levels"; return -1; }
     if (pm.ysize >= (1 << (32 - kItemYShift - 1))) { out.error = "a piece has too many unknowns"; return -1; }
+    if (pm.lsize >= kUpdLocalMax || pm.ysize >= kUpdYMax) { out.error = "a piece is too large for the packed update records (65535 doubles of L, 8191 unknowns)"; return -1; }
     // update matrix of the piece: blocks in (a, b) order, own update records, child sources, U items
     order.clear();   // (component, a, b) ascending = the order of the dense tables (components and boundary rows ascend)
     for (int slot : ctab) if (slot >= 0) order.push_back(slot);
@@ -1022,9 +1051,9 @@ inline int chol_symbolic(const SymIn& in, CholOpts opt, CholHost& out) {
           const std::vector<int>& R = comp_R[x.comp];
           uy = comp_uy[std::lower_bound(comps.begin(), comps.end(), x.comp) - comps.begin()] + 6 * (int)(std::lower_bound(R.begin(), R.end(), x.a) - R.begin());
         }
-        const int tpk = (di == 6 ? kUpdDi6 : 0) | (diag ? kUpdDiag : 0) | (dj == 6 ? kUpdDj6 : 0);
+        const unsigned tpk = (di == 6 ? kUpdDi6 : 0u) | (diag ? kUpdDiag : 0u) | (dj == 6 ? kUpdDj6 : 0u);
         const int u0 = (int)out.upd.size() - pm.uu0;
-        for (int w = own_ptr[q]; w < own_ptr[q + 1]; ++w) { const OwnRec& u = own_s[w]; out.upd.push_back(UpdMeta{u.ua, u.ubo, col_yoff[u.k], tpk | (col_dim[u.k] == 6 ? kUpdDk6 : 0)}); }
+        for (int w = own_ptr[q]; w < own_ptr[q + 1]; ++w) { const OwnRec& u = own_s[w]; out.upd.push_back(upd_make(u.ua - pm.lbase, u.ubo - pm.lbase, col_yoff[u.k] - pm.y0, tpk | (col_dim[u.k] == 6 ? kUpdDk6 : 0u))); }
         const int n = own_ptr[q + 1] - own_ptr[q];
         const int s0 = (int)out.usrc.size() - pm.us0;
         for (int w = src_ptr[q]; w < src_ptr[q + 1]; ++w) out.usrc.push_back(src_s[w]);
@@ -1067,8 +1096,8 @@ inline int chol_symbolic(const SymIn& in, CholOpts opt, CholHost& out) {
   // ---- LDS needs (doubles) ---------------------------------------------------------------------------------------------------
   auto lds_f = [&](int p) {
     const PieceMeta& pm = out.piece[p];
-    const int ustage = (piece_cls[p] >= 1 || !opt.ustage) ? 0 : 4 * pm.nuit + 4 * pm.numb + 2 * pm.nuu + pm.nus + 2;
-    return 4 * pm.nilv + ((pm.lsize + 1) & ~1) + 2 * ((pm.ysize + 1) & ~1) + 4 * pm.nb + 3 * pm.nc + 2 * pm.nit_i + 2 * pm.nu_i + 2 * pm.nimb + pm.nas + ustage +
+    const int ustage = (piece_cls[p] >= 1 || !opt.ustage) ? 0 : 4 * pm.nuit + 4 * pm.numb + ((pm.nuu + 1) & ~1) + pm.nus + 2;
+    return 4 * pm.nilv + ((pm.lsize + 1) & ~1) + 2 * ((pm.ysize + 1) & ~1) + 4 * pm.nb + 3 * pm.nc + 2 * pm.nit_i + ((pm.nu_i + 1) & ~1) + 2 * pm.nimb + pm.nas + ustage +
            kItemDoubles * piece_pmax[p] + 8 + (piece_cls[p] >= 1 ? pm.nc + 2 : 0);   // (right-looking form: one RCol per column where the items were)
   };
   auto lds_b = [&](int p) {

@@ -41,7 +41,7 @@ struct CholView {
   const UItem* uitem;
   const UMb* umb;
   const RCol* rcol;         // tail pieces, right-looking form: per column, its internal updates of later blocks of the piece ...
-  const UpdMeta* rupd;      // ... (ux = target offset in the piece | local y offset of the target's column << 16); nullptr: target-major items
+  const UpdMeta* rupd;      // ... (UpdMeta's right-looking form); nullptr: target-major items
   const FwdMeta* fwd;       // blocks of every row (multi right-hand-side forward substitution)
   const int* lvl_cols;      // columns grouped by level of the elimination tree
   const int* plv_pieces;    // pieces grouped by depth
@@ -189,7 +189,7 @@ __device__ __forceinline__ void tile_update_k(const double* __restrict__ Ls, con
     accy[rr] = w;
   }
 }
-__device__ __forceinline__ void tile_update(const double* __restrict__ Ls, const double* __restrict__ Ys, int ua, int ub, int ux, int pk,
+__device__ __forceinline__ void tile_update(const double* __restrict__ Ls, const double* __restrict__ Ys, int ua, int ub, int ux, unsigned pk,
                                             int tre, int tce, double (&acc)[9], double (&accy)[3]) {
   if (pk & kUpdDk6) tile_update_k<6>(Ls, Ys, ua, ub, ux, tre, tce, acc, accy);
   else tile_update_k<3>(Ls, Ys, ua, ub, ux, tre, tce, acc, accy);
@@ -218,14 +218,15 @@ __device__ __forceinline__ void run_items(const ItemMeta* items, int it_begin, i
       const UpdMeta r0 = upd[im.u0 + min(k0 + lq, n - 1)];
       const UpdMeta r1 = upd[im.u0 + min(k0 + 4 + lq, n - 1)];
       if (k0 == 0) {
-        const int pk0 = quad_bcast<0>(r0.pk);
+        const unsigned pk0 = (unsigned)quad_bcast<0>((int)r0.xk);
         di = (pk0 & kUpdDi6) ? 6 : 3; dj = (pk0 & kUpdDj6) ? 6 : 3; diag = pk0 & kUpdDiag;
         tre = 3 * tr < di ? tr : 0; tce = 3 * tc < dj ? tc : 0;   // idle lanes shadow tile (0, 0): valid addresses
       }
 #define SSLAM_STEP(KK, R)                                                                                        \
-  if (k0 + KK < n)                                                                                               \
-    tile_update(Ls, Ys, quad_bcast<(KK) & 3>(R.ua) - lofs, quad_bcast<(KK) & 3>(R.ub) - lofs,                    \
-                quad_bcast<(KK) & 3>(R.ux) - yofs, quad_bcast<(KK) & 3>(R.pk), tre, tce, acc, accy);
+  if (k0 + KK < n) {                                                                                             \
+    const UpdMeta q_{(unsigned)quad_bcast<(KK) & 3>((int)R.ab), (unsigned)quad_bcast<(KK) & 3>((int)R.xk)};        \
+    tile_update(Ls, Ys, upd_ua(q_), upd_ub(q_), upd_yk(q_), q_.xk, tre, tce, acc, accy);                          \
+  }
       SSLAM_STEP(0, r0) SSLAM_STEP(1, r0) SSLAM_STEP(2, r0) SSLAM_STEP(3, r0)
       SSLAM_STEP(4, r1) SSLAM_STEP(5, r1) SSLAM_STEP(6, r1) SSLAM_STEP(7, r1)
 #undef SSLAM_STEP
@@ -319,9 +320,10 @@ __device__ __forceinline__ void run_uitems(const UItem* __restrict__ items, int 
       const UpdMeta r0 = upd[im.u0 + min(k0 + lq, n - 1)];
       const UpdMeta r1 = upd[im.u0 + min(k0 + 4 + lq, n - 1)];
 #define SSLAM_STEP(KK, R)                                                                                        \
-  if (k0 + KK < n)                                                                                               \
-    tile_update(smL, smY, quad_bcast<(KK) & 3>(R.ua) - lofs, quad_bcast<(KK) & 3>(R.ub) - lofs,                  \
-                quad_bcast<(KK) & 3>(R.ux) - yofs, quad_bcast<(KK) & 3>(R.pk), tre, tce, acc, accy);
+  if (k0 + KK < n) {                                                                                             \
+    const UpdMeta q_{(unsigned)quad_bcast<(KK) & 3>((int)R.ab), (unsigned)quad_bcast<(KK) & 3>((int)R.xk)};        \
+    tile_update(smL, smY, upd_ua(q_), upd_ub(q_), upd_yk(q_), q_.xk, tre, tce, acc, accy);                        \
+  }
       SSLAM_STEP(0, r0) SSLAM_STEP(1, r0) SSLAM_STEP(2, r0) SSLAM_STEP(3, r0)
       SSLAM_STEP(4, r1) SSLAM_STEP(5, r1) SSLAM_STEP(6, r1) SSLAM_STEP(7, r1)
 #undef SSLAM_STEP
@@ -408,8 +410,8 @@ __device__ __forceinline__ void run_utiles(const UItem* __restrict__ items, cons
     nsrc = nxt.ns > 0 ? usrc[nxt.s0] : AsmSrc{0, -1};
     for (int k0 = 0; k0 < n; k0 += 2) {   // the item's own updates out of LDS, records two at a time
       const UpdMeta r0 = upd[im.u0 + k0], r1 = upd[im.u0 + min(k0 + 1, n - 1)];
-      tile_update(smL, smY, r0.ua - lofs, r0.ub - lofs, r0.ux - yofs, r0.pk, tr, tc, acc, accy);
-      if (k0 + 1 < n) tile_update(smL, smY, r1.ua - lofs, r1.ub - lofs, r1.ux - yofs, r1.pk, tr, tc, acc, accy);
+      tile_update(smL, smY, upd_ua(r0), upd_ub(r0), upd_yk(r0), r0.xk, tr, tc, acc, accy);
+      if (k0 + 1 < n) tile_update(smL, smY, upd_ua(r1), upd_ub(r1), upd_yk(r1), r1.xk, tr, tc, acc, accy);
     }
     for (int s2 = 1; s2 < im.ns; ++s2) {
       const AsmSrc src = usrc[im.s0 + s2];
@@ -546,14 +548,14 @@ __device__ __forceinline__ void chol_piece(const BatchView& V, const CholView& C
   // internal updates: target-major items + records + multi-blocks, or (RIGHT) one {first record, count} per column + source-major records
   ItemMeta* sItem = reinterpret_cast<ItemMeta*>(sCol + pm.nc);
   UpdMeta* sUpd = reinterpret_cast<UpdMeta*>(sItem + (RIGHT ? (pm.nc + 1) / 2 : pm.nit_i));
-  MbMeta* sMb = reinterpret_cast<MbMeta*>(sUpd + pm.nu_i);
+  MbMeta* sMb = reinterpret_cast<MbMeta*>(sUpd + ((pm.nu_i + 1) & ~1));   // (8-byte records: an even count keeps what follows 16-byte aligned)
   AsmSrc* sAsm = reinterpret_cast<AsmSrc*>(sMb + (RIGHT ? 0 : pm.nimb));   // child update-matrix blocks to absorb
   RCol* sRcol = reinterpret_cast<RCol*>(sItem);
   // update-matrix records: staged in LDS by the per-depth kernels (USTAGE), read from HBM by the tail
   UItem* sUItem = reinterpret_cast<UItem*>(sAsm + pm.nas + (pm.nas & 1));
   UMb* sUMb = reinterpret_cast<UMb*>(sUItem + (USTAGE ? pm.nuit : 0));
   UpdMeta* sUUpd = reinterpret_cast<UpdMeta*>(sUMb + (USTAGE ? pm.numb : 0));
-  AsmSrc* sUSrc = reinterpret_cast<AsmSrc*>(sUUpd + (USTAGE ? pm.nuu : 0));
+  AsmSrc* sUSrc = reinterpret_cast<AsmSrc*>(sUUpd + (USTAGE ? ((pm.nuu + 1) & ~1) : 0));
   double* part = reinterpret_cast<double*>(sUSrc + (USTAGE ? pm.nus + (pm.nus & 1) : 0));
   const double* __restrict__ H = V.Hpp_diag;
   const double* __restrict__ U = C.Uval;
@@ -741,22 +743,22 @@ __device__ __forceinline__ void chol_piece(const BatchView& V, const CholView& C
         const int yk = sCol[c].z;
         for (int it = tid >> 2; it < rc.n; it += NT / 4) {
           const UpdMeta r = sUpd[rc.u0 + it];
-          const int di = (r.pk & kUpdDi6) ? 6 : 3, dj = (r.pk & kUpdDj6) ? 6 : 3;
+          const int di = (r.xk & kUpdDi6) ? 6 : 3, dj = (r.xk & kUpdDj6) ? 6 : 3;
           const int tre = 3 * tr < di ? tr : 0, tce = 3 * tc < dj ? tc : 0;   // idle lanes shadow tile (0, 0): valid addresses
           double acc[9], accy[3];
 #pragma unroll
           for (int q = 0; q < 9; ++q) acc[q] = 0;
 #pragma unroll
           for (int q = 0; q < 3; ++q) accy[q] = 0;
-          tile_update(smL, smY, r.ua - pm.lbase, r.ub - pm.lbase, yk, r.pk, tre, tce, acc, accy);
+          tile_update(smL, smY, upd_ua(r), upd_ub(r), yk, r.xk, tre, tce, acc, accy);
           if (3 * tr < di && 3 * tc < dj) {
-            double* o = smL + (r.ux & 0xFFFF);
+            double* o = smL + upd_rt(r);
 #pragma unroll
             for (int rr = 0; rr < 3; ++rr)
 #pragma unroll
               for (int cc = 0; cc < 3; ++cc) o[(3 * tr + rr) * dj + 3 * tc + cc] -= acc[rr * 3 + cc];
-            if ((r.pk & kUpdDiag) && tc == 0) {
-              double* oy = smY + (r.ux >> 16);
+            if ((r.xk & kUpdDiag) && tc == 0) {
+              double* oy = smY + upd_ry(r);
 #pragma unroll
               for (int rr = 0; rr < 3; ++rr) oy[3 * tr + rr] -= accy[rr];
             }
@@ -1672,13 +1674,13 @@ int chol_plan_build(Batch& b) {
   CholOpts opt;
   opt.from_env();
   if (opt.nt_tail != 1024) opt.nt_tail = 512;
-  if (opt.nt_leaf != 128 && opt.nt_leaf != 256 && opt.nt_leaf != 512 && opt.nt_leaf != 1024) opt.nt_leaf = 64;
+  if (opt.nt_leaf != -1 && opt.nt_leaf != 128 && opt.nt_leaf != 256 && opt.nt_leaf != 512 && opt.nt_leaf != 1024) opt.nt_leaf = 64;   // -1: by batch size (chol_symbolic)
   if (opt.nt_mid != 128 && opt.nt_mid != 512) opt.nt_mid = 256;
   // small batches (latency-bound: the orchestrator's graph, a single large graph): the dependency-driven single launch (k_chol_flow) runs
   // every piece with the tail's workgroup size
   const int flow_mode = opt.flow;   // 0 off, 1 auto, 2 also on wide trees (SSLAM_CHOL_OPTS flow=...; read per plan: tests toggle it)
   const bool flow_on = flow_mode != 0;
-  const bool want_flow = flow_on && b.V.B < 8 && opt.nt_tail == 512 && opt.group_cap == 0 && !opt.nt_leaf_set;
+  const bool want_flow = flow_on && b.V.B < 8 && opt.nt_tail == 512 && opt.group_cap <= 0 && !opt.nt_leaf_set;
   if (want_flow) { opt.nt_leaf = opt.nt_tail; opt.mid_width = 0; }
   CholHost H;
   if (chol_symbolic(in, opt, H)) return set_error(SSLAM_ERR_NUMERIC, "Cholesky plan: %s", H.error.c_str());

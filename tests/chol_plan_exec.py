@@ -14,7 +14,7 @@ ASRC = np.dtype([("uoff", "<i4"), ("uyoff", "<i4")])
 FWD = np.dtype([("off", "<i4"), ("yoff", "<i4")])
 UITEM = np.dtype([(n, "<i4") for n in ("u0", "n", "uoff", "flags", "s0", "ns", "uyoff", "pad")])
 UMB = np.dtype([(n, "<i4") for n in ("uoff", "ps0", "n", "info", "s0", "ns", "uyoff", "pad")])
-UPD = np.dtype([(n, "<i4") for n in ("ua", "ub", "ux", "pk")])
+UPD = np.dtype([("ab", "<u4"), ("xk", "<u4")])     # 8-byte update record: piece-local operand offsets | local y offset / target + flags (chol_plan.hpp UpdMeta)
 ITEM = np.dtype([(n, "<i4") for n in ("u0", "n", "tloff", "flags")])
 MB = np.dtype([(n, "<i4") for n in ("tloff", "ps0", "n", "info")])
 RCOL = np.dtype([("u0", "<i4"), ("n", "<i4")])
@@ -22,7 +22,19 @@ ILV = np.dtype([(n, "<i4") for n in ("c0", "c1", "b0", "b1", "it0", "it1", "mb0"
 PIECE = np.dtype([(n, "<i4") for n in ("graph", "c0", "nc", "b0", "nb", "lbase", "lsize", "y0", "ysize", "ilv0", "nilv", "iit0", "nit_i",
                                        "iu0", "nu_i", "imb0", "nimb", "as0", "nas", "uit0", "nuit", "umb0", "numb",
                                        "uu0", "nuu", "us0", "nus", "n36", "n18", "nint", "pad3", "pad4", "nu4", "nu2", "nu1", "pad5")])
-K_DI6, K_DK6, K_DIAG, K_DJ6 = 1 << 20, 1 << 21, 1 << 22, 1 << 23
+K_DI6, K_DK6, K_DIAG, K_DJ6 = 1 << 28, 1 << 29, 1 << 30, 1 << 31
+
+
+def upd_fields(r):
+    """(local offset of L_ik, of L_jk, local y offset of column k, flags) of a target-major update record"""
+    ab, xk = int(r["ab"]), int(r["xk"])
+    return ab & 0xFFFF, ab >> 16, xk & 0x1FFF, xk
+
+
+def upd_fields_right(r):
+    """(local offset of L_ik, of L_jk, local offset of the target block, local y offset of its column, flags) of a right-looking record"""
+    ab, xk = int(r["ab"]), int(r["xk"])
+    return ab & 0xFFFF, ab >> 16, xk & 0xFFFF, (xk >> 16) & 0xFFF, xk
 B_FMT, B_DIAG, B_ROWIN = 1 << 8, 1 << 9, 1 << 10
 
 
@@ -94,21 +106,22 @@ class Plan:
 
     def _tile_sum(self, upd, Ls, Ys, lofs, yofs, di, dj, diag):
         acc = np.zeros((di, dj)); accy = np.zeros(di)
-        for r in upd:
-            dk = 6 if r["pk"] & K_DK6 else 3
-            assert bool(r["pk"] & K_DI6) == (di == 6) and bool(r["pk"] & K_DJ6) == (dj == 6) and bool(r["pk"] & K_DIAG) == diag
-            A = Ls[r["ua"] - lofs:r["ua"] - lofs + di * dk].reshape(di, dk)
-            Bm = Ls[r["ub"] - lofs:r["ub"] - lofs + dj * dk].reshape(dj, dk)
+        for r in upd:   # offsets are piece-local (lofs / yofs: the piece's base, kept for the callers' signatures)
+            ua, ub, yk, pk = upd_fields(r)
+            dk = 6 if pk & K_DK6 else 3
+            assert bool(pk & K_DI6) == (di == 6) and bool(pk & K_DJ6) == (dj == 6) and bool(pk & K_DIAG) == diag
+            A = Ls[ua:ua + di * dk].reshape(di, dk)
+            Bm = Ls[ub:ub + dj * dk].reshape(dj, dk)
             acc += A @ Bm.T
             if diag:
-                accy += A @ Ys[r["ux"] - yofs:r["ux"] - yofs + dk]
+                accy += A @ Ys[yk:yk + dk]
         return acc, accy
 
     def _run_items(self, items, upd, Ls, Ys, lofs, yofs, smL, smY, part):
         for im in items:
             u = upd[im["u0"]:im["u0"] + im["n"]]
             assert len(u) == im["n"] and im["n"] > 0
-            pk0 = int(u[0]["pk"])
+            pk0 = int(u[0]["xk"])
             di = 6 if pk0 & K_DI6 else 3
             dj = 6 if pk0 & K_DJ6 else 3
             diag = bool(pk0 & K_DIAG)
@@ -199,16 +212,15 @@ class Plan:
                     recs = self.rupd[int(pm["pad3"]) + int(rc["u0"]):int(pm["pad3"]) + int(rc["u0"]) + int(rc["n"])]
                     assert len(recs) == rc["n"]
                     for r in recs:
-                        pk = int(r["pk"])
+                        ua, ub, tl, yl, pk = upd_fields_right(r)
                         di = 6 if pk & K_DI6 else 3
                         dj = 6 if pk & K_DJ6 else 3
                         assert (6 if pk & K_DK6 else 3) == dk
-                        A = smL[r["ua"] - lbase:r["ua"] - lbase + di * dk].reshape(di, dk)
-                        Bm = smL[r["ub"] - lbase:r["ub"] - lbase + dj * dk].reshape(dj, dk)
-                        tl, yl = int(r["ux"]) & 0xFFFF, int(r["ux"]) >> 16
+                        A = smL[ua:ua + di * dk].reshape(di, dk)
+                        Bm = smL[ub:ub + dj * dk].reshape(dj, dk)
                         smL[tl:tl + di * dj] -= (A @ Bm.T).ravel()
                         if pk & K_DIAG:
-                            assert r["ua"] == r["ub"]
+                            assert ua == ub
                             smY[yl:yl + dj] -= A @ smY[yk:yk + dk]
         # update matrix of the piece: own updates (sources in the piece) + the children's blocks
         part = {}
@@ -222,7 +234,7 @@ class Plan:
             u = uupd[im["u0"]:im["u0"] + im["n"]]
             assert len(u) == im["n"]
             for r in u:
-                assert lbase <= r["ua"] < lbase + pm["lsize"] and lbase <= r["ub"] < lbase + pm["lsize"]
+                assert upd_fields(r)[0] < pm["lsize"] and upd_fields(r)[1] < pm["lsize"] and upd_fields(r)[2] < pm["ysize"]
             acc, accy = self._tile_sum(u, smL, smY, lbase, y0, di, dj, diag)
             if fl & 1:
                 assert im["s0"] + im["ns"] <= pm["nus"]

@@ -9,7 +9,7 @@ import pytest
 
 from semantic_slam_amd.synth import make_graph
 from oracle.oracle import GraphProblem
-from chol_plan_exec import Plan
+from chol_plan_exec import Plan, upd_fields
 
 
 def _internal_order(gp):
@@ -101,8 +101,9 @@ def _structure_invariants(plan):
         pm = P[p]
         for im in plan.item[pm["iit0"]:pm["iit0"] + pm["nit_i"]]:
             assert 0 <= im["u0"] and im["u0"] + im["n"] <= pm["nu_i"]
-            for r in plan.upd[pm["iu0"] + im["u0"]:pm["iu0"] + im["u0"] + im["n"]]:
-                assert pm["lbase"] <= r["ua"] < pm["lbase"] + pm["lsize"] and pm["lbase"] <= r["ub"] < pm["lbase"] + pm["lsize"]
+            for r in plan.upd[pm["iu0"] + im["u0"]:pm["iu0"] + im["u0"] + im["n"]]:   # 8-byte records: piece-local offsets
+                ua, ub, yk, _ = upd_fields(r)
+                assert ua < pm["lsize"] and ub < pm["lsize"] and yk < pm["ysize"]
         srcs = list(plan.asrc[pm["as0"]:pm["as0"] + pm["nas"]])
         srcs += list(plan.usrc[pm["us0"]:pm["us0"] + pm["nus"]])
         for a in srcs:

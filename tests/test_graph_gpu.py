@@ -213,7 +213,7 @@ def test_optimize_small_graph_matches_oracle(gpu_lib, kind, solver):
     assert np.abs(E - Eo).max() <= 1e-4 * np.abs(Eo).max()
 
 
-@pytest.mark.parametrize("solver", [1, 0, 3])
+@pytest.mark.parametrize("solver", [1, 0])
 def test_optimize_S_config_10_iterations(gpu_lib, solver):
     """BASELINE.json configs[1]: 500 poses / 100 landmarks, exactly 10 LM iterations."""
     from semantic_slam_amd import GraphSLAM
@@ -329,7 +329,7 @@ def test_dcs_robust_kernel_matches_oracle(gpu_lib):
         assert G.chi2() == pytest.approx(gp.chi2(), rel=1e-9)          # kernel off again: the plain chi2 of the optimised state
 
 
-@pytest.mark.parametrize("solver", [1, 3, 0])
+@pytest.mark.parametrize("solver", [1, 0])
 def test_point_point_edges_match_oracle(gpu_lib, solver, tmp_path):
     """add_point_xyz_point_xyz_edge (g2o::EdgePointXYZ, reference graph_slam.cpp:168-180): landmark-landmark blocks in H (the landmark
     block is no longer block diagonal), two edges on one vertex pair; chi2, the normal equations, the optimised estimates and the g2o
