@@ -78,7 +78,11 @@ __device__ __forceinline__ Pose load_pose16(const double* a, int idx) {   // fou
 // spilled registers: 2.46 / 4.26 vs 2.12 ms); staged, coalesced block stores, also with the next round's operands requested before the
 // stores (2.06 vs 2.02, 2.09 vs 2.07 ms).  What they established: the build is bound by the life time of ONE wave per SIMD (304 VGPRs: both
 // Jacobians 45, Omega 27, J^T Omega 36, an off-diagonal block 36 doubles) -- instruction issue of a single FP64 wave plus the round trips it
-// cannot overlap -- not by bytes, occupancy alone, or the shape of its stores.
+// cannot overlap -- not by bytes, occupancy alone, or the shape of its stores.  Round 5 closed the occupancy question: the SAME arithmetic
+// with shorter live ranges (J_j built where the off-diagonal block is formed, that block two rows at a time, the own pose re-fetched per
+// slot) compiles to 231 VGPRs -- two waves per SIMD, no spill -- and ran 2.33 vs 2.10 ms per 512-graph build.  By the raw counters the build
+// moves ~13 MB per graph (both endpoint rows read an EdgeSE3, the landmark rows read every landmark edge again) at ~3.2 TB/s of mixed reads
+// and scattered 16-byte writes: it sits at what HBM gives such a mix, and only fewer bytes would make it faster.
 template <bool PL, bool SHARD>
 __global__ __launch_bounds__(kRowThreads, 1) void k_linearize_rowthread(BatchView V) {
   __shared__ double accD[27][kRowThreads];   // this row's diagonal block (upper triangle) and rhs: a thread-private LDS column, conflict free
@@ -90,13 +94,9 @@ __global__ __launch_bounds__(kRowThreads, 1) void k_linearize_rowthread(BatchVie
   const int s0 = V.pslot_ptr[row], s1 = V.pslot_ptr[row + 1];
   const int own = V.prow_pose[row];
   const int sh_lo = SHARD ? V.shard_lo[V.prow_graph[row]] : 0, sh_hi = SHARD ? V.shard_hi[V.prow_graph[row]] : 0;
+  const Pose Xown = load_pose16(V.pose, own);   // this row's vertex: loaded once, reused by every slot
   for (int s = s0; s < s1; ++s) {
     const int4 rec = V.pslot_rec[s];
-    // this row's vertex: fetched again for every slot (an L2 hit) instead of held across the loop -- its seven doubles would be alive through
-    // the whole EdgeSE3 body, which sits at the register budget of two waves per SIMD (the opaque copy keeps the load inside the loop)
-    int own_s = own;
-    asm volatile("" : "+v"(own_s));
-    const Pose Xown = load_pose16(V.pose, own_s);
     const int e = rec.x, kind = rec.y & 15, ia = rec.z, ib = rec.w;
     if (kind != 2) {
       // EdgeSE3: both Jacobians are 2 x 2 block upper triangular in 3 x 3 blocks,
@@ -140,20 +140,17 @@ __global__ __launch_bounds__(kRowThreads, 1) void k_linearize_rowthread(BatchVie
           Cc[0 * 3 + k] = -L.s * t.x; Cc[1 * 3 + k] = -L.s * t.y; Cc[2 * 3 + k] = -L.s * t.z;
         }
       }
-      // J_j = [[E, 0], [0, F]]:  E = R(qe),  F = s (w I + [qe_xyz]x).  On the j side it IS the own Jacobian (A = E, B = 0, Cc = F); on the i
-      // side only the owner of the off-diagonal block needs it, after J_i^T Omega has been formed -- it is built there, so that its 18
-      // values are not alive while Omega (27) and J_i^T Omega (36) are
-      auto jj_blocks = [&](double (&E)[9], double (&F)[9]) {
+      double E[9], F[9];          // J_j = [[E, 0], [0, F]]
+      {
         const Mat3 Re = qmat(L.qe);
         const double w = L.s * L.qe.w, x = L.s * L.qe.x, y = L.s * L.qe.y, z = L.s * L.qe.z;
 #pragma unroll
         for (int q = 0; q < 9; ++q) E[q] = Re.m[q];
         F[0] = w; F[1] = -z; F[2] = y; F[3] = z; F[4] = w; F[5] = -x; F[6] = -y; F[7] = x; F[8] = w;
-      };
+      }
       if (!iside) {
-        jj_blocks(A, Cc);
 #pragma unroll
-        for (int q = 0; q < 9; ++q) B[q] = 0.0;
+        for (int q = 0; q < 9; ++q) { A[q] = E[q]; B[q] = 0.0; Cc[q] = F[q]; }
       }
       // M = J_self^T Omega = [[A^T P, A^T Q], [B^T P + C^T Q^T, B^T Q + C^T R]]
       double M11[9], M12[9], M21[9], M22[9];
@@ -176,34 +173,30 @@ __global__ __launch_bounds__(kRowThreads, 1) void k_linearize_rowthread(BatchVie
           M11[a * 3 + c] = m11; M12[a * 3 + c] = m12; M21[a * 3 + c] = m21; M22[a * 3 + c] = m22;
         }
       const int blk = iside ? V.eo_blk[e] : -1;
-      if (blk >= 0) {   // owner of the off-diagonal block: J_i^T Omega J_j = [[M11 E, M12 F], [M21 E, M22 F]], formed and stored two rows at a time
+      if (blk >= 0) {   // owner of the off-diagonal block: J_i^T Omega J_j = [[M11 E, M12 F], [M21 E, M22 F]]
         double* O = V.Hpp_off + (size_t)(blk >> 1) * 36;
         const bool swapped = blk & 1;
-        double E[9], F[9];
-        jj_blocks(E, F);
+        double o[36];
 #pragma unroll
-        for (int a = 0; a < 6; a += 2) {
-          double o0[6], o1[6];
+        for (int a = 0; a < 3; ++a)
 #pragma unroll
           for (int c = 0; c < 3; ++c) {
-            double e0 = 0, f0 = 0, e1 = 0, f1 = 0;
+            double o11 = 0, o12 = 0, o21 = 0, o22 = 0;
 #pragma unroll
             for (int r = 0; r < 3; ++r) {
-              // rows a, a + 1 of [[M11, M12], [M21, M22]] (a < 3: the upper block row)
-              const double ma0 = a < 3 ? M11[a * 3 + r] : M21[(a - 3) * 3 + r], mb0 = a < 3 ? M12[a * 3 + r] : M22[(a - 3) * 3 + r];
-              const double ma1 = a + 1 < 3 ? M11[(a + 1) * 3 + r] : M21[(a + 1 - 3) * 3 + r], mb1 = a + 1 < 3 ? M12[(a + 1) * 3 + r] : M22[(a + 1 - 3) * 3 + r];
-              e0 += ma0 * E[r * 3 + c]; f0 += mb0 * F[r * 3 + c];
-              e1 += ma1 * E[r * 3 + c]; f1 += mb1 * F[r * 3 + c];
+              o11 += M11[a * 3 + r] * E[r * 3 + c]; o12 += M12[a * 3 + r] * F[r * 3 + c];
+              o21 += M21[a * 3 + r] * E[r * 3 + c]; o22 += M22[a * 3 + r] * F[r * 3 + c];
             }
-            o0[c] = e0; o0[3 + c] = f0; o1[c] = e1; o1[3 + c] = f1;
+            o[a * 6 + c] = o11; o[a * 6 + 3 + c] = o12; o[(3 + a) * 6 + c] = o21; o[(3 + a) * 6 + 3 + c] = o22;
           }
-          if (!swapped) {   // stored [row_i][row_j]
+        if (!swapped) {   // stored [row_i][row_j]
 #pragma unroll
-            for (int c = 0; c < 6; c += 2) { store2(O + a * 6 + c, o0[c], o0[c + 1]); store2(O + (a + 1) * 6 + c, o1[c], o1[c + 1]); }
-          } else {          // stored transposed: element (c, a), (c, a + 1) are neighbours
+          for (int k = 0; k < 36; k += 2) store2(O + k, o[k], o[k + 1]);
+        } else {          // stored transposed
 #pragma unroll
-            for (int c = 0; c < 6; ++c) store2(O + c * 6 + a, o0[c], o1[c]);
-          }
+          for (int c = 0; c < 6; ++c)
+#pragma unroll
+            for (int a = 0; a < 6; a += 2) store2(O + c * 6 + a, o[a * 6 + c], o[(a + 1) * 6 + c]);
         }
       }
       // diagonal block J^T Omega J (upper triangle) and b -= J^T Omega e
