@@ -1,6 +1,6 @@
 #!/bin/bash
 # SQ instruction / occupancy counters per kernel (separate rocprofv3 --pmc passes; no trace domains combined with them).
-# usage (GPU box): bash tools/pmc_run.sh <tag> <batch> ; environment SSLAM_CHOL_* selects the factorisation configuration
+# usage (GPU box): bash tools/pmc_run.sh <tag> <batch> ; SSLAM_CHOL_OPTS selects the factorisation configuration
 R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out; T=${1:-pmc}; B=${2:-512}
 cd /tmp && export TMPDIR=/tmp
 for set in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES" "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVE_CYCLES SQ_BUSY_CYCLES" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_ANY SQ_INST_CYCLES_VMEM" "FETCH_SIZE" "WRITE_SIZE"; do

@@ -1,53 +1,49 @@
 #!/bin/bash
 # Re-measure what the round's profiles/ hold.  Run on the GPU box: gpurun -- 'bash tools/refresh_profiles.sh [sections]'
-# sections (default "tests bench stats pmc frontend"): tests bench stats pmc mfma frontend
-# Writes gpurun_out/refresh/r4_*; copy the ones to be judged into profiles/.
+# sections (default "tests bench stats pmc frontend trace"): tests bench stats pmc frontend trace
+# Writes gpurun_out/refresh/r5_*; copy the ones to be judged into profiles/.
 set -u
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/refresh; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-SECTIONS="${*:-tests bench stats pmc frontend}"
+SECTIONS="${*:-tests bench stats pmc frontend trace}"
 has() { [[ " $SECTIONS " == *" $1 "* ]]; }
 DRV="--gpus 1 --steps 20 --warmup 5"
 if has tests; then
-  python -m pytest $R/tests -m gpu -q > $O/r4_pytest_gpu.txt 2>&1; tail -3 $O/r4_pytest_gpu.txt
+  python -m pytest $R/tests -m gpu -q > $O/r5_pytest_gpu.txt 2>&1; tail -3 $O/r5_pytest_gpu.txt
 fi
 if has bench; then
-  python $R/bench.py $DRV > $O/bench_stdout.txt 2> $O/bench_stderr.txt; tail -1 $O/bench_stdout.txt > $O/r4_bench.json; cut -c1-400 $O/r4_bench.json
+  python $R/bench.py $DRV > $O/bench_stdout.txt 2> $O/bench_stderr.txt; tail -1 $O/bench_stdout.txt > $O/r5_bench.json; cut -c1-400 $O/r5_bench.json
 fi
 if has stats; then
   # kernel stats of the pass the rooflines come from: one batch-synchronous batch on one stream (--streams 1); in the stream-group
   # region the launches of four parts overlap on the chip and a per-launch duration says nothing about a kernel
   rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python $R/bench.py $DRV --streams 1 --no-cpu-baseline --no-frontend --no-single --plane-batch 0 > /dev/null 2>&1
-  cp $(ls $O/stats/*/*kernel_stats.csv | head -1) $O/r4_bench_kernel_stats.csv; head -12 $O/r4_bench_kernel_stats.csv | cut -c1-160
+  cp $(ls $O/stats/*/*kernel_stats.csv | head -1) $O/r5_bench_kernel_stats.csv; head -12 $O/r5_bench_kernel_stats.csv | cut -c1-160
   rm -rf $O/stats
 fi
 if has pmc; then
-  FB=$(python -c "import json;print(json.load(open('$O/r4_bench.json'))['roofline_factor']['bytes_per_launch'])")
-  JB=$(python -c "import json;print(json.load(open('$O/r4_bench.json'))['roofline_jacobian_build']['bytes_per_launch'])")
+  FB=$(python -c "import json;print(json.load(open('$O/r5_bench.json'))['roofline_factor']['bytes_per_launch'])")
+  JB=$(python -c "import json;print(json.load(open('$O/r5_bench.json'))['roofline_jacobian_build']['bytes_per_launch'])")
   # PMC traffic: one full-batch factorisation / Jacobian build of the SAME 512 distinct graphs (tools/pmc_workload.py), separate passes
   for c in FETCH_SIZE WRITE_SIZE; do
     rocprofv3 --pmc $c --output-format csv -d $O/pmc_factor_$c -- python $R/tools/pmc_workload.py 512 factor > /dev/null 2>&1
     rocprofv3 --pmc $c --output-format csv -d $O/pmc_jac_$c -- python $R/tools/pmc_workload.py 512 jacobian > /dev/null 2>&1
   done
-  python $R/tools/pmc_traffic.py $O/pmc_factor_FETCH_SIZE $O/pmc_factor_WRITE_SIZE $O/r4_pmc_factor.json $FB 0 k_chol_tail k_chol_pieces k_chol_begin k_chol_end
-  python $R/tools/pmc_traffic.py $O/pmc_jac_FETCH_SIZE $O/pmc_jac_WRITE_SIZE $O/r4_pmc_jacobian_build.json $JB 0 k_linearize_rowthread k_linearize_lm_rows k_linearize_dups
+  python $R/tools/pmc_traffic.py $O/pmc_factor_FETCH_SIZE $O/pmc_factor_WRITE_SIZE $O/r5_pmc_factor.json $FB 0 k_chol_tail k_chol_pieces k_chol_begin k_chol_end
+  python $R/tools/pmc_traffic.py $O/pmc_jac_FETCH_SIZE $O/pmc_jac_WRITE_SIZE $O/r5_pmc_jacobian_build.json $JB 0 k_linearize_rowthread k_linearize_lm_rows k_linearize_dups
   rm -rf $O/pmc_*
-fi
-if has mfma; then
-  # matrix-core counters of the window plan's MFMA form (north_star: "MFMA only if ... evidenced by rocprof MFMA utilisation")
-  rm -f $O/r4_pmc_mfma_window.txt
-  for set in "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES" "SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT"; do
-    rm -rf $O/_pmc
-    SSLAM_WCHOL=1 timeout 300 rocprofv3 --pmc $set --output-format csv -d $O/_pmc -- python $R/tools/prof_opt.py 128 1 > $O/_pmc.log 2>&1 || tail -3 $O/_pmc.log
-    python $R/tools/pmc_summary.py $O/_pmc 2>/dev/null | grep -E "k_wchol" >> $O/r4_pmc_mfma_window.txt
-    rm -rf $O/_pmc
-  done
-  sort $O/r4_pmc_mfma_window.txt | cut -c1-250
 fi
 if has frontend; then
   # per-kernel times of one batched frontend call (32 frames x 32 boxes)
   rocprofv3 --kernel-trace --stats --output-format csv -d $O/fstats -- python $R/tools/frontend_kernels.py > /dev/null 2>&1
-  cp $(ls $O/fstats/*/*kernel_stats.csv | head -1) $O/r4_frontend_kernel_stats.csv; head -14 $O/r4_frontend_kernel_stats.csv | cut -c1-140
+  cp $(ls $O/fstats/*/*kernel_stats.csv | head -1) $O/r5_frontend_kernel_stats.csv; head -14 $O/r5_frontend_kernel_stats.csv | cut -c1-140
   rm -rf $O/fstats
+fi
+if has trace; then
+  # per-launch trace of one LM step of the 512-graph batch (which launches the factorisation is made of and what each takes)
+  rm -rf $O/_p512
+  rocprofv3 --kernel-trace --output-format csv -d $O/_p512 -- python $R/tools/prof_opt.py 512 2 > /dev/null 2>&1
+  python $R/tools/level_profile.py $O/_p512 > $O/r5_factor_launch_trace_512.txt; rm -rf $O/_p512
+  head -20 $O/r5_factor_launch_trace_512.txt | cut -c1-120
 fi
