@@ -39,6 +39,7 @@ struct DevArena {
   std::vector<void*> spill;
   char* mirror = nullptr;
   size_t mirror_cap = 0, flushed = 0;
+  bool mirror_off = false;   // the pinned mirror could not be allocated during this rebuild: every table array is written directly until reset()
   static constexpr size_t kMirrorMax = 256 << 10;   // arrays above this size live in the large region
   // direct: the caller writes the array itself (memset / copy on its stream, issued before the flush): never from the table region,
   // whose bytes all come from the mirror
@@ -58,19 +59,20 @@ struct DevArena {
   bool in_block(const void* p) const { return base && (const char*)p >= base && (const char*)p < base + cap; }
   // host address that shadows device address p (table region only), or nullptr
   char* shadow(void* p, size_t bytes) {
-    if (!base || (const char*)p < base || (const char*)p + bytes > base + small_cap) return nullptr;
+    if (mirror_off || !base || (const char*)p < base || (const char*)p + bytes > base + small_cap) return nullptr;
     if (mirror_cap < small_cap) {
       if (mirror) (void)hipHostFree(mirror);
       mirror = nullptr; mirror_cap = 0;
       void* q = nullptr;
-      if (hipHostMalloc(&q, small_cap, hipHostMallocDefault) != hipSuccess) return nullptr;
+      // (round-4 ADVICE: once an array of this rebuild has been written directly, a mirror allocated later would flush uninitialised bytes over it)
+      if (hipHostMalloc(&q, small_cap, hipHostMallocDefault) != hipSuccess) { mirror_off = true; return nullptr; }
       mirror = (char*)q; mirror_cap = small_cap; flushed = 0;
     }
     return mirror + ((char*)p - base);
   }
   // everything written to the mirror since the last flush -> device, one copy (every byte of the table region is shadowed: no holes)
   int flush(hipStream_t st) {
-    if (mirror && small_used > flushed && hipMemcpyAsync(base + flushed, mirror + flushed, small_used - flushed, hipMemcpyHostToDevice, st) != hipSuccess) return -3;
+    if (mirror && !mirror_off && small_used > flushed && hipMemcpyAsync(base + flushed, mirror + flushed, small_used - flushed, hipMemcpyHostToDevice, st) != hipSuccess) return -3;
     flushed = small_used;
     return 0;
   }
@@ -89,7 +91,7 @@ struct DevArena {
       if (hipMalloc(&p, want) == hipSuccess) { base = (char*)p; cap = want; }
     }
     small_cap = base ? new_small : 0;
-    used = small_cap; small_used = 0; need = 0; small_need = 0; flushed = 0;
+    used = small_cap; small_used = 0; need = 0; small_need = 0; flushed = 0; mirror_off = false;
   }
   ~DevArena() {
     for (void* p : spill) (void)hipFree(p);

@@ -788,3 +788,30 @@ def test_seg_golden_patch(gpu_lib):
                                  point_step=32, row_step=32 * w)
     assert np.array_equal(seg.normals(0).reshape(-1, 4), g["normals"], equal_nan=True)
     assert np.array_equal(seg.labels(0).reshape(-1), g["labels"])
+
+
+def test_concurrent_handles_with_persistent_launches_equal_their_sequential_runs(gpu_lib):
+    """Round-4 ADVICE: k_chol_flow / k_chol_spec_round are persistent grids sized for an otherwise free device; several graph handles (each
+    with its own stream) driven from several host threads used to be able to leave each launch partly resident.  Persistent launches are now
+    chained per device (PersistScope in sslam_chol.hip): four handles optimised concurrently give, bit for bit, what each gives alone."""
+    import threading
+    from semantic_slam_amd import GraphSLAM
+    gps = [GraphProblem.from_synth(make_graph(100 + 15 * k, 20 + 3 * k, seed=40 + k), interleave=True) for k in range(4)]
+    alone = []
+    for gp in gps:
+        G = GraphSLAM.from_problem(gp)
+        assert G.optimize(30)
+        alone.append((G.last_stats.iterations, G.last_stats.trials, G.last_stats.chi2_after, G.estimates().copy()))
+    for rep in range(2):
+        Gs = [GraphSLAM.from_problem(gp) for gp in gps]
+        ok = [False] * len(Gs)
+
+        def run(k):
+            ok[k] = bool(Gs[k].optimize(30))
+        th = [threading.Thread(target=run, args=(k,)) for k in range(len(Gs))]
+        for t in th: t.start()
+        for t in th: t.join()
+        assert all(ok)
+        for G, ref in zip(Gs, alone):
+            assert (G.last_stats.iterations, G.last_stats.trials, G.last_stats.chi2_after) == ref[:3]
+            assert np.array_equal(G.estimates(), ref[3])
