@@ -166,7 +166,7 @@ struct CholOpts {
   // 128-thread groups of 2800 (cap_leaf 700) 8.35 / 2.29 (the default); 256-thread groups of 4000-5000 8.5-9.3 / 2.3-2.4.
   int group_cap = -1;      // -1: 2800 for batches >= 32, else 0 (no groups: small batches run the dependency-driven launch, one piece per workgroup)
   int group_blocks = 1024;
-  int ustage = -1;         // 2: only the 8-byte update records and child sources of the update matrix are staged (round 5 experiment); 1: the per-depth kernels stage the update-matrix records in LDS too (one round trip for all tables: shorter
+  int ustage = -1;         // 1: the per-depth kernels stage the update-matrix records in LDS too (one round trip for all tables: shorter
                            //    piece latency, fewer pieces per CU); -1: 1 for batches < 32 (latency-bound), else 0 (residency-bound)
   int order = 1;           // 0: minimum degree, lowest index first (rounds 1-3: eliminates a pose chain from one end -> a tree as deep as the chain);
                            // 1: multiple minimum degree over independent sets (below): a chain halves per round -> O(log n) levels.  Small
@@ -1096,7 +1096,7 @@ inline int chol_symbolic(const SymIn& in, CholOpts opt, CholHost& out) {
   // ---- LDS needs (doubles) ---------------------------------------------------------------------------------------------------
   auto lds_f = [&](int p) {
     const PieceMeta& pm = out.piece[p];
-    const int ustage = (piece_cls[p] >= 1 || !opt.ustage) ? 0 : (opt.ustage == 1 ? 4 * pm.nuit + 4 * pm.numb : 0) + ((pm.nuu + 1) & ~1) + pm.nus + 2;
+    const int ustage = (piece_cls[p] >= 1 || !opt.ustage) ? 0 : 4 * pm.nuit + 4 * pm.numb + ((pm.nuu + 1) & ~1) + pm.nus + 2;
     return 4 * pm.nilv + ((pm.lsize + 1) & ~1) + 2 * ((pm.ysize + 1) & ~1) + 4 * pm.nb + 3 * pm.nc + 2 * pm.nit_i + ((pm.nu_i + 1) & ~1) + 2 * pm.nimb + pm.nas + ustage +
            kItemDoubles * piece_pmax[p] + 8 + (piece_cls[p] >= 1 ? pm.nc + 2 : 0);   // (right-looking form: one RCol per column where the items were)
   };

@@ -529,10 +529,7 @@ __device__ __forceinline__ void row_solve(double* v, const double* Ljj, const do
 // them); only the children's update-matrix blocks are read after it -- two dependent round trips less on the critical path of a piece.
 // The sums are those of the one-pass gather, in its order: (H + lambda I) first, then the sources one after the other.
 __device__ __forceinline__ bool flow_wait(const int* p, int target, int* err, int* fail = nullptr);
-// USTAGE: 0 the update-matrix records are read from HBM in the update-matrix phase; 1 all of them are staged in LDS with the other tables
-// (one round trip for everything: shorter piece latency, fewer pieces per CU); 2 only the 8-byte update records and the child sources
-// (what a tile waits for inside its pass), the 32-byte item records stay in HBM and are fetched one pass ahead
-template <int NT, int USTAGE, bool RIGHT, bool DEFER = false>
+template <int NT, bool USTAGE, bool RIGHT, bool DEFER = false>
 __device__ __forceinline__ void chol_piece(const BatchView& V, const CholView& C, const PieceMeta pm, double* sm, long long* dbg,
                                            const int* wait_p = nullptr, int wait_target = 0, int* wait_err = nullptr) {
   constexpr int NW = NT / 64;
@@ -556,11 +553,10 @@ __device__ __forceinline__ void chol_piece(const BatchView& V, const CholView& C
   RCol* sRcol = reinterpret_cast<RCol*>(sItem);
   // update-matrix records: staged in LDS by the per-depth kernels (USTAGE), read from HBM by the tail
   UItem* sUItem = reinterpret_cast<UItem*>(sAsm + pm.nas + (pm.nas & 1));
-  constexpr bool ST_IT = USTAGE == 1, ST_UP = USTAGE >= 1;
-  UMb* sUMb = reinterpret_cast<UMb*>(sUItem + (ST_IT ? pm.nuit : 0));
-  UpdMeta* sUUpd = reinterpret_cast<UpdMeta*>(sUMb + (ST_IT ? pm.numb : 0));
-  AsmSrc* sUSrc = reinterpret_cast<AsmSrc*>(sUUpd + (ST_UP ? ((pm.nuu + 1) & ~1) : 0));
-  double* part = reinterpret_cast<double*>(sUSrc + (ST_UP ? pm.nus + (pm.nus & 1) : 0));
+  UMb* sUMb = reinterpret_cast<UMb*>(sUItem + (USTAGE ? pm.nuit : 0));
+  UpdMeta* sUUpd = reinterpret_cast<UpdMeta*>(sUMb + (USTAGE ? pm.numb : 0));
+  AsmSrc* sUSrc = reinterpret_cast<AsmSrc*>(sUUpd + (USTAGE ? ((pm.nuu + 1) & ~1) : 0));
+  double* part = reinterpret_cast<double*>(sUSrc + (USTAGE ? pm.nus + (pm.nus & 1) : 0));
   const double* __restrict__ H = V.Hpp_diag;
   const double* __restrict__ U = C.Uval;
   const int ry = lane - 40;
@@ -581,10 +577,10 @@ __device__ __forceinline__ void chol_piece(const BatchView& V, const CholView& C
     SSLAM_LD(RCol, t_rcol, C.rcol + pm.c0, RIGHT ? pm.nc : 0, 1)
     SSLAM_LD(AsmSrc, t_asm, C.asrc + pm.as0, pm.nas, 2)
     SSLAM_LD(ColMeta, t_col, C.col + pm.c0, pm.nc, 1)
-    SSLAM_LD(UItem, t_uit, C.uitem + pm.uit0, ST_IT ? pm.nuit : 0, 2)
-    SSLAM_LD(UMb, t_umb, C.umb + pm.umb0, ST_IT ? pm.numb : 0, 1)
-    SSLAM_LD(UpdMeta, t_uupd, C.upd + pm.uu0, ST_UP ? pm.nuu : 0, 2)
-    SSLAM_LD(AsmSrc, t_usrc, C.usrc + pm.us0, ST_UP ? pm.nus : 0, 2)
+    SSLAM_LD(UItem, t_uit, C.uitem + pm.uit0, USTAGE ? pm.nuit : 0, 2)
+    SSLAM_LD(UMb, t_umb, C.umb + pm.umb0, USTAGE ? pm.numb : 0, 1)
+    SSLAM_LD(UpdMeta, t_uupd, C.upd + pm.uu0, USTAGE ? pm.nuu : 0, 2)
+    SSLAM_LD(AsmSrc, t_usrc, C.usrc + pm.us0, USTAGE ? pm.nus : 0, 2)
     SSLAM_ST(t_lv, s_lv, C.ilv + pm.ilv0, pm.nilv, 1)
     SSLAM_ST(t_blk, sBlk, C.blk + pm.b0, pm.nb, 2)
     SSLAM_ST(t_item, sItem, C.item + pm.iit0, RIGHT ? 0 : pm.nit_i, 2)
@@ -597,11 +593,9 @@ __device__ __forceinline__ void chol_piece(const BatchView& V, const CholView& C
       const ColMeta cm = C.col[pm.c0 + c];
       sCol[c] = make_int4(cm.base - pm.lbase, cm.dim, cm.yoff - pm.y0, 0);
     }
-    if (ST_IT) {
+    if (USTAGE) {
       SSLAM_ST(t_uit, sUItem, C.uitem + pm.uit0, pm.nuit, 2)
       SSLAM_ST(t_umb, sUMb, C.umb + pm.umb0, pm.numb, 1)
-    }
-    if (ST_UP) {
       SSLAM_ST(t_uupd, sUUpd, C.upd + pm.uu0, pm.nuu, 2)
       SSLAM_ST(t_usrc, sUSrc, C.usrc + pm.us0, pm.nus, 2)
     }
@@ -779,20 +773,16 @@ __device__ __forceinline__ void chol_piece(const BatchView& V, const CholView& C
   if (pm.nuit > 0) {
     // sole items by tiles (run_utiles), the items of split lists by quads into their partial slots (run_uitems)
     const int nsole = pm.nu4 + pm.nu2 + pm.nu1;
-    if (ST_IT) {
+    if (USTAGE) {
       if (nsole > 0) run_utiles<NT>(sUItem, pm.nu4, pm.nu2, pm.nu1, sUUpd, sUSrc, smL, smY, pm.lbase, pm.y0, C.Uval, tid);
       if (pm.nuit > nsole) run_uitems<NT>(sUItem, nsole, pm.nuit, sUUpd, sUSrc, smL, smY, pm.lbase, pm.y0, C.Uval, part, tid);
-    } else if (ST_UP) {
-      if (nsole > 0) run_utiles<NT>(C.uitem + pm.uit0, pm.nu4, pm.nu2, pm.nu1, sUUpd, sUSrc, smL, smY, pm.lbase, pm.y0, C.Uval, tid);
-      if (pm.nuit > nsole) run_uitems<NT>(C.uitem + pm.uit0, nsole, pm.nuit, sUUpd, sUSrc, smL, smY, pm.lbase, pm.y0, C.Uval, part, tid);
     } else {
       if (nsole > 0) run_utiles<NT>(C.uitem + pm.uit0, pm.nu4, pm.nu2, pm.nu1, C.upd + pm.uu0, C.usrc + pm.us0, smL, smY, pm.lbase, pm.y0, C.Uval, tid);
       if (pm.nuit > nsole) run_uitems<NT>(C.uitem + pm.uit0, nsole, pm.nuit, C.upd + pm.uu0, C.usrc + pm.us0, smL, smY, pm.lbase, pm.y0, C.Uval, part, tid);
     }
     if (pm.numb > 0) {
       __syncthreads();
-      if (ST_IT) reduce_umulti(sUMb, 0, pm.numb, sUSrc, C.Uval, part, wave, lane, NW);
-      else if (ST_UP) reduce_umulti(C.umb + pm.umb0, 0, pm.numb, sUSrc, C.Uval, part, wave, lane, NW);
+      if (USTAGE) reduce_umulti(sUMb, 0, pm.numb, sUSrc, C.Uval, part, wave, lane, NW);
       else reduce_umulti(C.umb + pm.umb0, 0, pm.numb, C.usrc + pm.us0, C.Uval, part, wave, lane, NW);
     }
   }
@@ -818,7 +808,7 @@ __device__ __forceinline__ void chol_piece(const BatchView& V, const CholView& C
 }
 #undef SSLAM_STAMP
 
-template <int NT, int USTAGE, bool RIGHT = false>   // RIGHT: mid pieces (several columns of a chain per piece), internal updates by source column
+template <int NT, bool USTAGE, bool RIGHT = false>   // RIGHT: mid pieces (several columns of a chain per piece), internal updates by source column
 __global__ __launch_bounds__(NT, 4) void k_chol_pieces(BatchView V, CholView C, int begin, const int* __restrict__ idx) {   // <= 128 VGPRs: four waves per SIMD
   extern __shared__ double sm[];
   const PieceMeta pm = C.lpiece[idx ? idx[blockIdx.x] : begin + blockIdx.x];   // idx: the pieces of the graphs that are still active
@@ -1691,7 +1681,7 @@ int chol_plan_build(Batch& b) {
   const int flow_mode = opt.flow;   // 0 off, 1 auto, 2 also on wide trees (SSLAM_CHOL_OPTS flow=...; read per plan: tests toggle it)
   const bool flow_on = flow_mode != 0;
   const bool want_flow = flow_on && b.V.B < 8 && opt.nt_tail == 512 && opt.group_cap <= 0 && !opt.nt_leaf_set;
-  if (want_flow) { opt.nt_leaf = opt.nt_tail; opt.mid_width = 0; if (opt.ustage == 2) opt.ustage = 1; }   // (the single-launch kernels know 0 / 1)
+  if (want_flow) { opt.nt_leaf = opt.nt_tail; opt.mid_width = 0; }
   CholHost H;
   if (chol_symbolic(in, opt, H)) return set_error(SSLAM_ERR_NUMERIC, "Cholesky plan: %s", H.error.c_str());
   CholPlan* P = new CholPlan();
@@ -1807,13 +1797,11 @@ int chol_plan_build(Batch& b) {
     std::lock_guard<std::mutex> lk(mu);
     if (std::find(done.begin(), done.end(), b.device) == done.end()) {
       const int v = lds_lim;
-      const void* fns[] = {(const void*)k_chol_pieces<64, 1>, (const void*)k_chol_pieces<128, 1>, (const void*)k_chol_pieces<256, 1>,
-                           (const void*)k_chol_pieces<512, 1>, (const void*)k_chol_pieces<1024, 1>,
-                           (const void*)k_chol_pieces<64, 2>, (const void*)k_chol_pieces<128, 2>, (const void*)k_chol_pieces<256, 2>,
-                           (const void*)k_chol_pieces<512, 2>, (const void*)k_chol_pieces<1024, 2>,
-                           (const void*)k_chol_pieces<64, 0>, (const void*)k_chol_pieces<128, 0>, (const void*)k_chol_pieces<256, 0>,
-                           (const void*)k_chol_pieces<512, 0>, (const void*)k_chol_pieces<1024, 0>,
-                           (const void*)k_chol_pieces<128, 0, true>, (const void*)k_chol_pieces<256, 0, true>, (const void*)k_chol_pieces<512, 0, true>,
+      const void* fns[] = {(const void*)k_chol_pieces<64, true>, (const void*)k_chol_pieces<128, true>, (const void*)k_chol_pieces<256, true>,
+                           (const void*)k_chol_pieces<512, true>, (const void*)k_chol_pieces<1024, true>,
+                           (const void*)k_chol_pieces<64, false>, (const void*)k_chol_pieces<128, false>, (const void*)k_chol_pieces<256, false>,
+                           (const void*)k_chol_pieces<512, false>, (const void*)k_chol_pieces<1024, false>,
+                           (const void*)k_chol_pieces<128, false, true>, (const void*)k_chol_pieces<256, false, true>, (const void*)k_chol_pieces<512, false, true>,
                            (const void*)k_chol_tail<512>, (const void*)k_chol_tail<1024>,
                            (const void*)k_chol_back_pieces<64>, (const void*)k_chol_back_pieces<128>, (const void*)k_chol_back_pieces<256>,
                            (const void*)k_chol_back_pieces<512>, (const void*)k_chol_back_pieces<1024>, (const void*)k_chol_back_tail<512>,
@@ -1945,8 +1933,8 @@ static void flow_launches(Batch& b, bool spec = false, bool backward = true, boo
   const int np = (int)P.lp_graph.size();
   for (int l = 0; l < P.flow_launch0; ++l) {
     const int n = P.plv_ptr[l + 1] - P.plv_ptr[l];
-    if (P.ustage) hipLaunchKernelGGL((k_chol_pieces<512, 1>), dim3(n), dim3(512), (size_t)P.plv_lds_f[l] * sizeof(double), b.stream, b.V, C, P.plv_ptr[l], (const int*)nullptr);
-    else hipLaunchKernelGGL((k_chol_pieces<512, 0>), dim3(n), dim3(512), (size_t)P.plv_lds_f[l] * sizeof(double), b.stream, b.V, C, P.plv_ptr[l], (const int*)nullptr);
+    if (P.ustage) hipLaunchKernelGGL((k_chol_pieces<512, true>), dim3(n), dim3(512), (size_t)P.plv_lds_f[l] * sizeof(double), b.stream, b.V, C, P.plv_ptr[l], (const int*)nullptr);
+    else hipLaunchKernelGGL((k_chol_pieces<512, false>), dim3(n), dim3(512), (size_t)P.plv_lds_f[l] * sizeof(double), b.stream, b.V, C, P.plv_ptr[l], (const int*)nullptr);
   }
   const int epoch = spec ? ++P.spec_epoch : ++P.flow_epoch;   // the lanes count on their own counters
   const SpecLanes SL = spec ? P.spec : SpecLanes{};
@@ -2101,12 +2089,11 @@ int chol_factor_and_forward(Batch& b, bool flat) {
     const int* idx = P.compact ? P.d_idx + P.c_ptr[l] : nullptr;
     const size_t lds = (size_t)P.plv_lds_f[l] * sizeof(double);
 #define SSLAM_LAUNCH_PIECES(NTV)                                                                                                   \
-  if (P.ustage == 1) hipLaunchKernelGGL((k_chol_pieces<NTV, 1>), dim3(n), dim3(NTV), lds, b.stream, b.V, C, P.plv_ptr[l], idx);     \
-  else if (P.ustage == 2) hipLaunchKernelGGL((k_chol_pieces<NTV, 2>), dim3(n), dim3(NTV), lds, b.stream, b.V, C, P.plv_ptr[l], idx); \
-  else hipLaunchKernelGGL((k_chol_pieces<NTV, 0>), dim3(n), dim3(NTV), lds, b.stream, b.V, C, P.plv_ptr[l], idx);
+  if (P.ustage) hipLaunchKernelGGL((k_chol_pieces<NTV, true>), dim3(n), dim3(NTV), lds, b.stream, b.V, C, P.plv_ptr[l], idx);       \
+  else hipLaunchKernelGGL((k_chol_pieces<NTV, false>), dim3(n), dim3(NTV), lds, b.stream, b.V, C, P.plv_ptr[l], idx);
 #define SSLAM_LAUNCH_MID(NTV)                                                                                                      \
-  if (C.rupd) hipLaunchKernelGGL((k_chol_pieces<NTV, 0, true>), dim3(n), dim3(NTV), lds, b.stream, b.V, C, P.plv_ptr[l], idx);      \
-  else hipLaunchKernelGGL((k_chol_pieces<NTV, 0, false>), dim3(n), dim3(NTV), lds, b.stream, b.V, C, P.plv_ptr[l], idx);
+  if (C.rupd) hipLaunchKernelGGL((k_chol_pieces<NTV, false, true>), dim3(n), dim3(NTV), lds, b.stream, b.V, C, P.plv_ptr[l], idx);  \
+  else hipLaunchKernelGGL((k_chol_pieces<NTV, false, false>), dim3(n), dim3(NTV), lds, b.stream, b.V, C, P.plv_ptr[l], idx);
     if (P.plv_cls[l] == 1) {   // mid pieces: wider workgroups, right-looking internal updates, update-matrix records from HBM
       switch (P.plv_nt[l]) {
         case 128: SSLAM_LAUNCH_MID(128) break;
