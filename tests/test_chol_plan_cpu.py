@@ -199,6 +199,46 @@ def test_mid_class_pieces_between_the_bottom_and_the_tail(hip_lib):
     _check(p2, H2, b2, 1e-3)
 
 
+def test_multi_graph_batch_plan_with_groups_mid_and_tail(hip_lib):
+    """The throughput plan of round 5 on a BATCH (groups of leaf pieces on 128-thread workgroups, mid pieces, a tail per graph; the
+    defaults of batches >= 32, forced here onto six small graphs): the executor factors the block-diagonal system of all graphs; a group
+    never mixes graphs, a launch never mixes classes."""
+    from semantic_slam_amd import GraphSLAM
+    gs = [make_graph(40 + 5 * k, 8 + k, seed=70 + k) for k in range(6)]
+    gps = [GraphProblem.from_synth(g, interleave=bool(k & 1)) for k, g in enumerate(gs)]
+    os.environ["SSLAM_CHOL_OPTS"] = "nt_leaf=128,group_cap=600,cap_leaf=150,mid_width=3,cap_mid=400,tail_width=1"
+    try:
+        plan = Plan(hip_lib, [GraphSLAM.from_problem(gp) for gp in gps])
+    finally:
+        os.environ.pop("SSLAM_CHOL_OPTS")
+    cls = plan.piece["pad5"]
+    assert (cls == 0).sum() >= 6 and (cls == 1).sum() >= 6 and (cls == 2).sum() >= 6 and set(plan.plv_nt) == {128, 256}
+    for p in range(plan.npiece):     # every column of a piece (group) belongs to the piece's graph
+        pm = plan.piece[p]
+        assert np.all(plan.col["graph"][pm["c0"]:pm["c0"] + pm["nc"]] == pm["graph"])
+    _structure_invariants(plan)
+    # block-diagonal system in the batch's internal row order: the pose rows of all graphs, then the landmark rows of all graphs
+    Hs, bs, npose = [], [], []
+    for gp in gps:
+        U, b = gp.linearize()
+        Hg = (U + U.T).toarray() - np.diag(U.diagonal())
+        idx, n = _internal_order(gp)
+        Hs.append(Hg[np.ix_(idx, idx)]); bs.append(b[idx])
+        h, _ = gp.hessian_index()
+        npose.append(6 * sum(1 for v in range(gp.nv) if gp.vtype[v] == 0 and h[v] >= 0))
+    dim = sum(len(b) for b in bs)
+    assert dim == plan.dim
+    P0 = sum(npose)
+    pos_p, pos_l, where = 0, P0, []
+    for b, npz in zip(bs, npose):
+        where.append(np.concatenate([np.arange(pos_p, pos_p + npz), np.arange(pos_l, pos_l + len(b) - npz)]))
+        pos_p += npz; pos_l += len(b) - npz
+    H = np.zeros((dim, dim)); bb = np.zeros(dim)
+    for Hg, b, w in zip(Hs, bs, where):
+        H[np.ix_(w, w)] = Hg; bb[w] = b
+    _check(plan, H, bb, 1e-3)
+
+
 def test_parent_links_and_both_orderings_factor(hip_lib):
     """Every piece names the piece its update matrix goes to (what the dependency-driven launch k_chol_flow waits on); both elimination
     orders (multiple minimum degree over independent sets, round 4; lowest-index minimum degree) give a valid plan, and the new one a

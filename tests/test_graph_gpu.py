@@ -426,6 +426,30 @@ def test_large_batch_of_unequal_graphs_matches_individual(gpu_lib):
         assert np.abs(G1.estimates() - G2.estimates()).max() < 1e-9
 
 
+def test_batch_regime_plan_with_all_three_piece_classes_matches_the_oracle(gpu_lib):
+    """Round 5: a batch of >= 32 graphs takes the throughput plan -- groups of leaf pieces on 128-thread workgroups, mid pieces on 256, a tail
+    per graph.  32 distinct graphs of ~600 poses (all three classes present: the plan is also walked on the CPU by
+    tests/test_chol_plan_cpu.py) against the oracle on a sample and against their own single-handle runs (the latency plan) on all."""
+    from semantic_slam_amd import GraphSLAM, GraphBatch
+    gps = [GraphProblem.from_synth(make_graph(600 + 7 * k, 120 + k, seed=500 + k), interleave=bool(k & 1)) for k in range(32)]
+    graphs = [GraphSLAM.from_problem(gp) for gp in gps]
+    B = GraphBatch(graphs); B.upload()
+    stats = B.optimize(6)
+    B.download()
+    for k in (0, 13, 31):
+        st = gps[k].optimize(6)
+        assert stats[k].iterations == st.iterations and stats[k].trials == st.trials
+        assert stats[k].chi2_after == pytest.approx(st.chi2_after, rel=1e-9)
+        assert np.abs(graphs[k].estimates() - gps[k].est).max() <= 1e-6 * np.abs(gps[k].est).max()
+    gps2 = [GraphProblem.from_synth(make_graph(600 + 7 * k, 120 + k, seed=500 + k), interleave=bool(k & 1)) for k in range(32)]
+    for k in range(0, 32, 5):
+        G = GraphSLAM.from_problem(gps2[k])
+        assert G.optimize(6)
+        assert G.last_stats.iterations == stats[k].iterations
+        assert G.last_stats.chi2_after == pytest.approx(stats[k].chi2_after, rel=1e-9)
+        assert np.abs(G.estimates() - graphs[k].estimates()).max() <= 1e-8 * np.abs(G.estimates()).max()
+
+
 def test_stream_group_matches_the_single_stream_batch(gpu_lib):
     """sslam_batch_create_streams: the graphs split over several batches, each on its own stream + host thread.  Every graph runs its own
     LM, so the parts only change what overlaps on the chip: with parts of >= 32 graphs (same plan parameters as the whole batch) the
