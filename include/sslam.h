@@ -292,7 +292,9 @@ int sslam_seg_segment_batch(sslam_seg* s, const sslam_frame* frames, int n_frame
  * the read-back of the result tables on one of two pipelines of the handle (own HIP stream, own device buffers, used in turn) and
  * returns; collect waits for the OLDEST submitted batch and runs the scalar post-processing.  At most two batches are in flight:
  *     submit(0);  for (k = 0; ...; ++k) { submit(k + 1); collect(k); }
- * so that the copy of batch k+1 (9.8 MB per 640x480 frame) runs under the kernels of batch k.  The cloud buffers of a batch must stay
+ * so that the copy of batch k+1 (9.8 MB per 640x480 frame of 32-byte points; 3.7 MB with point_step = 12: the frontend reads x, y, z only)
+ * runs under the kernels of batch k -- the kernels of a batch wait for the other pipeline's kernels, so copies and kernels of successive
+ * batches overlap whatever the host's timing.  The cloud buffers of a batch must stay
  * valid until it is collected (boxes and poses are copied at submit); pinned clouds (hipHostMalloc / hipHostRegister) make submit
  * itself asynchronous.  Results are those of sslam_seg_segment_batch.  The blocking calls refuse to run while a batch is in flight. */
 int sslam_seg_submit_batch(sslam_seg* s, const sslam_frame* frames, int n_frames, int width, int height, int point_step, int row_step,
@@ -355,8 +357,9 @@ typedef struct sslam_box_plane {
 int sslam_seg_ransac_boxes(sslam_seg* s, float threshold, int max_iterations, double probability, uint64_t seed, sslam_box_plane* out, int max_out,
                            double* kernel_ms);
 int sslam_seg_ransac_box_inliers(sslam_seg* s, int slot, int32_t* out, int max_out);
-/* sslam_seg_icp_boxes: sslam_seg_icp_point_to_plane per FRAME of the resident batch, all frames and all Gauss-Newton rounds in one launch
- * (one workgroup per frame; the 6 x 6 solve on the device): the points of a frame are the RANSAC inliers of its boxes, the points of box
+/* sslam_seg_icp_boxes: sslam_seg_icp_point_to_plane per FRAME of the resident batch; a Gauss-Newton round is two launches over ALL frames
+ * (one workgroup per box for the 29 sums over its inliers, one wave per frame for the reduction in slot order, the 6 x 6 solve and the
+ * update of T -- no host round trip per iteration): the points of a frame are the RANSAC inliers of its boxes, the points of box
  * slot q measure plane box_plane[q] of `planes` (n_planes x 4 floats, e.g. the previous keyframe's planes in the camera frame of this
  * one; -1: the box takes no part).  T0: NULL (identity) or 12 doubles per frame.  out[f].status is 0 or SSLAM_ERR_NUMERIC (planes that
  * leave a degree of freedom unconstrained).  Returns the number of frames. */
