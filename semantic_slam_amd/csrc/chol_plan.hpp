@@ -163,7 +163,7 @@ struct CholOpts {
   // members run together, so every dependent step (a round trip to HBM, a 6 x 6 factor by one lane, a barrier) serves several pieces, and a
   // wave's lanes are filled (a lone leaf piece keeps ~40 % of 64 lanes busy in its parallel phases and one or two in its diagonal blocks).
   // 512 L graphs, factor / backward solve per batch: no groups 8.87 / 3.35 ms; 64-thread groups of 1000 (cap_leaf 500) 8.24 / 2.69;
-  // 128-thread groups of 2800 (cap_leaf 700) 8.35 / 2.29 (the default); 256-thread groups of 4000-5000 8.5-9.3 / 2.3-2.4.
+  // 128-thread groups of 2800 (cap_leaf 700) 7.9-8.3 / 2.3 (the default); 256-thread groups of 4000-5000 8.5-9.3 / 2.3-2.4.
   int group_cap = -1;      // -1: 2800 for batches >= 32, else 0 (no groups: small batches run the dependency-driven launch, one piece per workgroup)
   int group_blocks = 1024;
   int ustage = -1;         // 1: the per-depth kernels stage the update-matrix records in LDS too (one round trip for all tables: shorter

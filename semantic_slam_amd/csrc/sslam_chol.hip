@@ -17,6 +17,7 @@
 #include <cstdio>
 #include <cstring>
 #include <mutex>
+#include <type_traits>
 #include <vector>
 
 #include "../../include/sslam.h"
@@ -609,63 +610,75 @@ __device__ __forceinline__ void chol_piece(const BatchView& V, const CholView& C
   //         not by bytes).  kG rows per thread are in flight together, H row and first child row side by side; a row's sources
   //         are summed by its own thread -> no conflicts, fixed order.
   {
-    constexpr int kG = 2;
-    const int nrow = pm.nb * 6;
-    for (int t0 = tid; t0 < nrow; t0 += NT * kG) {
-      double v[kG][6], w[kG][6], rhsv[kG], uyv[kG];
+    // KG rows per thread in flight together; SRC: the rows' first child block rides along with the H row.  A piece without child blocks (every
+    // group of the bottom launch: a quarter of all groups; and the first pass of DEFER) loads the H rows only and keeps five per thread in
+    // flight: the 600 rows of a 100-block group are one round trip for 128 threads instead of three (round 5; the 64-thread pieces of
+    // rounds 2-4 had 96 rows and were one trip at two per thread).
+    auto gather = [&](auto KGc, auto SRCc) {
+      constexpr int KG = decltype(KGc)::value;
+      constexpr bool SRC = decltype(SRCc)::value;
+      const int nrow = pm.nb * 6;
+      for (int t0 = tid; t0 < nrow; t0 += NT * KG) {
+        double v[KG][6], w[SRC ? KG : 1][6], rhsv[KG], uyv[SRC ? KG : 1];
 #pragma unroll
-      for (int g2 = 0; g2 < kG; ++g2) {
-        const int t = min(t0 + g2 * NT, nrow - 1);
-        const int b = t / 6, row = t - 6 * b;
-        const BlkMeta bm = sBlk[b];
-        const int di = bm.info & 15, dj = (bm.info >> 4) & 15, nas = DEFER ? 0 : (bm.info >> kBlkNasShift) & 255;
-        const int rw = min(row, di - 1);                                   // idle threads shadow the last row: valid addresses
-        const double* ph = H + max(bm.src, 0) + ((bm.info & kBlkFmt) ? rw : rw * dj);
-        const int st = (bm.info & kBlkFmt) ? di : 1;
-        const AsmSrc as = nas > 0 ? sAsm[bm.as0] : AsmSrc{0, -1};
-        const double* pu = U + as.uoff + rw * dj;
-        if (dj == 6 && !(bm.info & kBlkFmt)) {   // 48 contiguous, 16-byte aligned bytes: three wide loads each
-          const D2* ph2 = reinterpret_cast<const D2*>(ph);
-          const D2* pu2 = reinterpret_cast<const D2*>(pu);
+        for (int g2 = 0; g2 < KG; ++g2) {
+          const int t = min(t0 + g2 * NT, nrow - 1);
+          const int b = t / 6, row = t - 6 * b;
+          const BlkMeta bm = sBlk[b];
+          const int di = bm.info & 15, dj = (bm.info >> 4) & 15, nas = SRC ? (bm.info >> kBlkNasShift) & 255 : 0;
+          const int rw = min(row, di - 1);                                   // idle threads shadow the last row: valid addresses
+          const double* ph = H + max(bm.src, 0) + ((bm.info & kBlkFmt) ? rw : rw * dj);
+          const int st = (bm.info & kBlkFmt) ? di : 1;
+          const AsmSrc as = nas > 0 ? sAsm[bm.as0] : AsmSrc{0, -1};
+          const double* pu = U + as.uoff + rw * dj;
+          if (dj == 6 && !(bm.info & kBlkFmt)) {   // 48 contiguous, 16-byte aligned bytes: three wide loads each
+            const D2* ph2 = reinterpret_cast<const D2*>(ph);
+            const D2* pu2 = reinterpret_cast<const D2*>(pu);
 #pragma unroll
-          for (int c = 0; c < 3; ++c) { const D2 a2 = ph2[c], b2 = pu2[c]; v[g2][2 * c] = a2.a; v[g2][2 * c + 1] = a2.b; w[g2][2 * c] = b2.a; w[g2][2 * c + 1] = b2.b; }
-        } else {
+            for (int c = 0; c < 3; ++c) {
+              const D2 a2 = ph2[c]; v[g2][2 * c] = a2.a; v[g2][2 * c + 1] = a2.b;
+              if (SRC) { const D2 b2 = pu2[c]; w[g2][2 * c] = b2.a; w[g2][2 * c + 1] = b2.b; }
+            }
+          } else {
 #pragma unroll
-          for (int c = 0; c < 6; ++c) { const int cc = min(c, dj - 1); v[g2][c] = ph[cc * st]; w[g2][c] = pu[cc]; }
-        }
-        const bool dg = bm.info & kBlkDiag;                                 // non-diagonal rows all read element 0: one request per wave
-        rhsv[g2] = V.bvec[dg ? bm.xoff_row + rw : 0];
-        uyv[g2] = U[(dg && as.uyoff >= 0) ? as.uyoff + rw : 0];
-      }
-#pragma unroll
-      for (int g2 = 0; g2 < kG; ++g2) {
-        const int t = t0 + g2 * NT;
-        if (t >= nrow) continue;
-        const int b = t / 6, row = t - 6 * b;
-        const BlkMeta bm = sBlk[b];
-        const int di = bm.info & 15, dj = (bm.info >> 4) & 15, nas = DEFER ? 0 : (bm.info >> kBlkNasShift) & 255;
-        if (row >= di) continue;
-        const bool diag = bm.info & kBlkDiag;
-        double vy = diag ? rhsv[g2] : 0.0;
-#pragma unroll
-        for (int c = 0; c < 6; ++c) v[g2][c] = (bm.src >= 0 ? v[g2][c] : 0.0) + ((diag && c == row) ? lambda : 0.0) - (nas > 0 ? w[g2][c] : 0.0);
-        if (nas > 0) {
-          const AsmSrc as0 = sAsm[bm.as0];
-          if (diag && as0.uyoff >= 0) vy -= uyv[g2];
-          for (int s2 = 1; s2 < nas; ++s2) {
-            const AsmSrc as = sAsm[bm.as0 + s2];
-            const double* pu = U + as.uoff + row * dj;
-#pragma unroll
-            for (int c = 0; c < 6; ++c) if (c < dj) v[g2][c] -= pu[c];
-            if (diag && as.uyoff >= 0) vy -= U[as.uyoff + row];
+            for (int c = 0; c < 6; ++c) { const int cc = min(c, dj - 1); v[g2][c] = ph[cc * st]; if (SRC) w[g2][c] = pu[cc]; }
           }
+          const bool dg = bm.info & kBlkDiag;                                 // non-diagonal rows all read element 0: one request per wave
+          rhsv[g2] = V.bvec[dg ? bm.xoff_row + rw : 0];
+          if (SRC) uyv[g2] = U[(dg && as.uyoff >= 0) ? as.uyoff + rw : 0];
         }
-        double* o = smL + (bm.off - pm.lbase) + row * dj;
 #pragma unroll
-        for (int c = 0; c < 6; ++c) if (c < dj) o[c] = v[g2][c];
-        if (diag) smY[bm.colyoff - pm.y0 + row] = vy;
+        for (int g2 = 0; g2 < KG; ++g2) {
+          const int t = t0 + g2 * NT;
+          if (t >= nrow) continue;
+          const int b = t / 6, row = t - 6 * b;
+          const BlkMeta bm = sBlk[b];
+          const int di = bm.info & 15, dj = (bm.info >> 4) & 15, nas = SRC ? (bm.info >> kBlkNasShift) & 255 : 0;
+          if (row >= di) continue;
+          const bool diag = bm.info & kBlkDiag;
+          double vy = diag ? rhsv[g2] : 0.0;
+#pragma unroll
+          for (int c = 0; c < 6; ++c) v[g2][c] = (bm.src >= 0 ? v[g2][c] : 0.0) + ((diag && c == row) ? lambda : 0.0) - ((SRC && nas > 0) ? w[SRC ? g2 : 0][c] : 0.0);
+          if (SRC && nas > 0) {
+            const AsmSrc as0 = sAsm[bm.as0];
+            if (diag && as0.uyoff >= 0) vy -= uyv[SRC ? g2 : 0];
+            for (int s2 = 1; s2 < nas; ++s2) {
+              const AsmSrc as = sAsm[bm.as0 + s2];
+              const double* pu = U + as.uoff + row * dj;
+#pragma unroll
+              for (int c = 0; c < 6; ++c) if (c < dj) v[g2][c] -= pu[c];
+              if (diag && as.uyoff >= 0) vy -= U[as.uyoff + row];
+            }
+          }
+          double* o = smL + (bm.off - pm.lbase) + row * dj;
+#pragma unroll
+          for (int c = 0; c < 6; ++c) if (c < dj) o[c] = v[g2][c];
+          if (diag) smY[bm.colyoff - pm.y0 + row] = vy;
+        }
       }
-    }
+    };
+    if (DEFER || pm.nas == 0) gather(std::integral_constant<int, 5>{}, std::false_type{});
+    else gather(std::integral_constant<int, 3>{}, std::true_type{});
   }
   if (DEFER) {
     // ---- 1b. the children's update-matrix blocks, once they are there
