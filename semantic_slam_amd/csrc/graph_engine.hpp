@@ -100,6 +100,8 @@ struct DevArena {
   }
 };
 
+void persist_forget_stream(int device, hipStream_t stream);   // sslam_chol.hip: the per-device chain of persistent launches forgets a stream that is going away
+
 struct Batch {
   int device = 0;
   hipStream_t stream = nullptr;
@@ -152,7 +154,7 @@ struct Batch {
     event_pool.clear();
     for (void* p : allocs) hipFree(p);
     allocs.clear();
-    if (stream && own_stream) hipStreamDestroy(stream);
+    if (stream && own_stream) { hipStreamSynchronize(stream); persist_forget_stream(device, stream); hipStreamDestroy(stream); }
     stream = nullptr;
   }
   hipEvent_t get_event() {

@@ -1482,7 +1482,7 @@ struct sslam_graph {
   bool linearized = false;
   ~sslam_graph() {
     batch.reset();               // synchronises the stream
-    if (stream) { (void)hipSetDevice(g.device); (void)hipStreamDestroy(stream); }
+    if (stream) { (void)hipSetDevice(g.device); (void)hipStreamSynchronize(stream); persist_forget_stream(g.device, stream); (void)hipStreamDestroy(stream); }
   }
 };
 struct sslam_batch {
