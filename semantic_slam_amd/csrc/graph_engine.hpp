@@ -111,6 +111,8 @@ struct Batch {
   BatchView V{};
   std::vector<void*> allocs;
   DevArena* arena = nullptr;   // set for the batch of one behind a graph handle: device arrays come out of the handle's arena
+  PinnedScratch own_pin;       // staging of the small copies ...
+  PinnedScratch* pin = &own_pin;   // ... or the graph handle's (kept across the per-tick rebuilds of its batch of one)
   // host-side metadata
   std::vector<GraphSeg> seg;
   std::vector<std::vector<int>> v2pose, v2lm;     // per graph: vertex id -> pose / landmark index (global), -1

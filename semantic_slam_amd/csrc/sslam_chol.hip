@@ -67,6 +67,7 @@ struct SpecLanes {
   LmState* lm = nullptr;      // [K][B] per-lane copy of the graph's state (lambda of the lane, in_trial)
   double *Lval = nullptr, *Uval = nullptr, *y = nullptr, *x = nullptr, *pose_trial = nullptr, *lmk_trial = nullptr, *part_e = nullptr, *part_a = nullptr;
   int *fail = nullptr, *flow = nullptr;
+  int* err = nullptr;         // ONE timeout flag for all lanes (the plan's own: d_flow + 3 * npiece) -- chol_flow_check reads a single word
   const double *pose_cur = nullptr, *lmk_cur = nullptr;   // the current estimates (V.pose / V.lmk)
   long long sL = 0, sU = 0, sy = 0, sx = 0, spose = 0, slmk = 0, spe = 0, spa = 0, sflow = 0;   // lane strides (elements)
   int g0 = 0, g1 = 0;         // workgroups of lane 0 / of every other lane in the (one-dimensional) grid of k_chol_flow
@@ -1462,7 +1463,7 @@ __global__ __launch_bounds__(NT) void k_chol_flow(BatchView V, CholView C, int q
   int* child_done = flow;
   int* back_done = flow + np;
   int* fwd_done = flow + 2 * np;
-  int* err = flow + 3 * np;
+  int* err = SL.K > 0 ? SL.err : flow + 3 * np;
   int* begin_done = flow + 3 * np + 1;
   int* end_ticket = flow + 3 * np + 2;
   if (lmstep) {
@@ -1563,7 +1564,7 @@ __global__ __launch_bounds__(NT) void k_chol_spec_round(BatchView V, CholView C,
       __hip_atomic_fetch_add(ctl, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
-  if (tid == 0) flow_wait(ctl, round, SL.flow + 3 * np);
+  if (tid == 0) flow_wait(ctl, round, SL.err);
   __syncthreads();
   int wg = blockIdx.x, nwg = SL.g0;
   long long k = 0;
@@ -1575,7 +1576,7 @@ __global__ __launch_bounds__(NT) void k_chol_spec_round(BatchView V, CholView C,
   int* child_done = flow;
   int* back_done = flow + np;
   int* fwd_done = flow + 2 * np;
-  int* err = flow + 3 * np;
+  int* err = SL.err;
   const int epoch = ctl[8 + SL.K + k] + 1;
   for (int q = wg; q < np; q += nwg) {
     const PieceMeta pm = C.lpiece[q];
@@ -1896,6 +1897,7 @@ int chol_plan_build(Batch& b) {
           if ((rc = plan_alloc(&p, (size_t)(2 * K + 16) * sizeof(int)))) return rc;
           SSLAM_HIP_TRY(hipMemsetAsync(p, 0, (size_t)(2 * K + 16) * sizeof(int), b.stream));
           SL.ctl = (int*)p;
+          SL.err = P->d_flow + 3 * dep.size();
           SL.K = K;
         }
       }
@@ -2045,17 +2047,14 @@ int chol_lm_step_spec(Batch& b, int max_iters) {
 // the error flag of k_chol_flow (a dependency wait that gave up); call after a stream synchronisation point
 int chol_flow_check(Batch& b) {
   if (!b.chol || !b.chol->flow || !b.chol->d_flow) return 0;
-  int err = 0;
-  SSLAM_HIP_TRY(hipMemcpyAsync(&err, b.chol->d_flow + 3 * b.chol->lp_graph.size(), sizeof err, hipMemcpyDeviceToHost, b.stream));
-  std::vector<int> lane_err(b.chol->spec.K > 0 && b.chol->spec_epoch > 0 ? b.chol->spec.K : 0, 0);
-  for (size_t k = 0; k < lane_err.size(); ++k)
-    SSLAM_HIP_TRY(hipMemcpyAsync(&lane_err[k], b.chol->spec.flow + k * b.chol->spec.sflow + 3 * b.chol->lp_graph.size(), sizeof(int), hipMemcpyDeviceToHost, b.stream));
+  int* d_err = b.chol->d_flow + 3 * b.chol->lp_graph.size();   // the speculative lanes report into the same word (SpecLanes::err)
+  int local = 0;
+  int* stage = reinterpret_cast<int*>(b.pin->get(sizeof(int)));
+  if (!stage) stage = &local;
+  SSLAM_HIP_TRY(hipMemcpyAsync(stage, d_err, sizeof(int), hipMemcpyDeviceToHost, b.stream));
   SSLAM_HIP_TRY(hipStreamSynchronize(b.stream));
-  for (int e2 : lane_err) err |= e2;
-  if (err) {   // reported once: cleared, so that the next solve of the handle is judged on its own
-    SSLAM_HIP_TRY(hipMemsetAsync(b.chol->d_flow + 3 * b.chol->lp_graph.size(), 0, sizeof(int), b.stream));
-    for (size_t k = 0; k < lane_err.size(); ++k)
-      SSLAM_HIP_TRY(hipMemsetAsync(b.chol->spec.flow + k * b.chol->spec.sflow + 3 * b.chol->lp_graph.size(), 0, sizeof(int), b.stream));
+  if (*stage) {   // reported once: cleared, so that the next solve of the handle is judged on its own
+    SSLAM_HIP_TRY(hipMemsetAsync(d_err, 0, sizeof(int), b.stream));
     SSLAM_HIP_TRY(hipStreamSynchronize(b.stream));
     return set_error(SSLAM_ERR_HIP, "sparse Cholesky: a dependency wait of the single-launch factorisation timed out (the graphs concerned carry a failed trial)");
   }
@@ -2248,11 +2247,18 @@ int chol_marginal_diag(Batch& b, const std::vector<int>& xoff, const std::vector
     P.mout_cap = (size_t)n * 36 + 1024;
   }
   hdr.insert(hdr.end(), cols.begin(), cols.end());
-  SSLAM_HIP_TRY(hipMemcpyAsync(P.d_mpath, hdr.data(), hdr.size() * sizeof(int), hipMemcpyHostToDevice, b.stream));
+  // both copies through the page-locked staging buffer: [paths | results]
+  const size_t in_bytes = (hdr.size() * sizeof(int) + 7) & ~(size_t)7, out_bytes = (size_t)n * 36 * sizeof(double);
+  char* stage = b.pin->get(in_bytes + out_bytes);
+  const void* src = hdr.data();
+  void* dst = out;
+  if (stage) { memcpy(stage, hdr.data(), hdr.size() * sizeof(int)); src = stage; dst = stage + in_bytes; }
+  SSLAM_HIP_TRY(hipMemcpyAsync(P.d_mpath, src, hdr.size() * sizeof(int), hipMemcpyHostToDevice, b.stream));
   hipLaunchKernelGGL(k_chol_marginal_paths, dim3(n), dim3(64), lds, b.stream, C, (const int*)P.d_mpath, (const int*)(P.d_mpath + n + 1),
                      (const int*)(P.d_mpath + 2 * (size_t)n + 1), P.d_mout, maxlen);
-  SSLAM_HIP_TRY(hipMemcpyAsync(out, P.d_mout, (size_t)n * 36 * sizeof(double), hipMemcpyDeviceToHost, b.stream));
+  SSLAM_HIP_TRY(hipMemcpyAsync(dst, P.d_mout, out_bytes, hipMemcpyDeviceToHost, b.stream));
   SSLAM_HIP_TRY(hipStreamSynchronize(b.stream));   // hdr is a local
+  if (stage) memcpy(out, stage + in_bytes, out_bytes);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return set_error(SSLAM_ERR_HIP, "path marginals launch: %s", hipGetErrorString(e));
   return 0;

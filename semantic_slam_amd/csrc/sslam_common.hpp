@@ -28,6 +28,27 @@ inline int lds_optin_limit(int device, int want, int reserve) {
   if (v <= 64 * 1024) return want;   // attribute not reported (or only the 64 KiB no-opt-in figure): keep the gfx950 constant, hipFuncSetAttribute fails loudly if it is too much
   return v - reserve < want ? v - reserve : want;
 }
+// Page-locked staging for the small host <-> device copies of an optimise call (estimates up / down, the looks at the LM state, error
+// flags).  From pageable memory every such copy is a staged blit with its own host round trip: ~38 of them per tick of the orchestrator,
+// 13 us apart -- 0.6 ms of a 5.6 ms tick (rocprofv3 trace, round 5).  One buffer, used by one copy sequence at a time: every user
+// synchronises its stream before the host touches the bytes and before the next user fills them.  Lives in the graph handle (a batch of
+// one is rebuilt every tick) or in the batch itself.
+struct PinnedScratch {
+  char* p = nullptr;
+  size_t cap = 0;
+  char* get(size_t bytes) {
+    if (bytes <= cap) return p;
+    if (p) (void)hipHostFree(p);
+    p = nullptr; cap = 0;
+    void* q = nullptr;
+    const size_t want = bytes + bytes / 2 + 4096;
+    if (hipHostMalloc(&q, want, hipHostMallocDefault) != hipSuccess) return nullptr;
+    p = (char*)q; cap = want;
+    return p;
+  }
+  ~PinnedScratch() { if (p) (void)hipHostFree(p); }
+};
+
 }  // namespace sslam
 
 #define SSLAM_HIP_TRY(expr)                                                                          \

@@ -1211,7 +1211,12 @@ static int batch_build(Batch& b, bool host_only = false) {
 
 static int batch_upload_estimates(Batch& b) {
   SSLAM_HIP_TRY(hipSetDevice(b.device));
-  std::vector<double> pose((size_t)b.V.nPose * 8, 0.0), lmk((size_t)b.V.nLm * 4, 0.0);
+  const size_t np = (size_t)b.V.nPose * 8, nl = (size_t)b.V.nLm * 4;
+  std::vector<double> fallback;
+  double* stage = reinterpret_cast<double*>(b.pin->get((np + nl) * sizeof(double)));   // page-locked: four asynchronous copies, no staged blits
+  if (!stage) { fallback.assign(np + nl, 0.0); stage = fallback.data(); }
+  std::fill(stage, stage + np + nl, 0.0);
+  double* pose = stage; double* lmk = stage + np;
   for (size_t g = 0; g < b.graphs.size(); ++g) {
     const HostGraph& G = *b.graphs[g];
     for (int v = 0; v < G.nv(); ++v) {
@@ -1220,13 +1225,13 @@ static int batch_upload_estimates(Batch& b) {
       else { double* o = &lmk[(size_t)b.v2lm[g][v] * 4]; for (int k = 0; k < (G.vtype[v] == VT_POINT ? 3 : 4); ++k) o[k] = e[k]; }
     }
   }
-  if (!pose.empty()) {
-    SSLAM_HIP_TRY(hipMemcpyAsync(b.V.pose, pose.data(), pose.size() * 8, hipMemcpyHostToDevice, b.stream));
-    SSLAM_HIP_TRY(hipMemcpyAsync(b.V.pose_trial, pose.data(), pose.size() * 8, hipMemcpyHostToDevice, b.stream));
+  if (np) {
+    SSLAM_HIP_TRY(hipMemcpyAsync(b.V.pose, pose, np * 8, hipMemcpyHostToDevice, b.stream));
+    SSLAM_HIP_TRY(hipMemcpyAsync(b.V.pose_trial, pose, np * 8, hipMemcpyHostToDevice, b.stream));
   }
-  if (!lmk.empty()) {
-    SSLAM_HIP_TRY(hipMemcpyAsync(b.V.lmk, lmk.data(), lmk.size() * 8, hipMemcpyHostToDevice, b.stream));
-    SSLAM_HIP_TRY(hipMemcpyAsync(b.V.lmk_trial, lmk.data(), lmk.size() * 8, hipMemcpyHostToDevice, b.stream));
+  if (nl) {
+    SSLAM_HIP_TRY(hipMemcpyAsync(b.V.lmk, lmk, nl * 8, hipMemcpyHostToDevice, b.stream));
+    SSLAM_HIP_TRY(hipMemcpyAsync(b.V.lmk_trial, lmk, nl * 8, hipMemcpyHostToDevice, b.stream));
   }
   SSLAM_HIP_TRY(hipStreamSynchronize(b.stream));
   b.uploaded = true;
@@ -1235,9 +1240,13 @@ static int batch_upload_estimates(Batch& b) {
 
 static int batch_download_estimates(Batch& b) {
   SSLAM_HIP_TRY(hipSetDevice(b.device));
-  std::vector<double> pose((size_t)b.V.nPose * 8), lmk((size_t)b.V.nLm * 4);
-  if (!pose.empty()) SSLAM_HIP_TRY(hipMemcpyAsync(pose.data(), b.V.pose, pose.size() * 8, hipMemcpyDeviceToHost, b.stream));
-  if (!lmk.empty()) SSLAM_HIP_TRY(hipMemcpyAsync(lmk.data(), b.V.lmk, lmk.size() * 8, hipMemcpyDeviceToHost, b.stream));
+  const size_t np = (size_t)b.V.nPose * 8, nl = (size_t)b.V.nLm * 4;
+  std::vector<double> fallback;
+  double* stage = reinterpret_cast<double*>(b.pin->get((np + nl) * sizeof(double)));
+  if (!stage) { fallback.assign(np + nl, 0.0); stage = fallback.data(); }
+  double* pose = stage; double* lmk = stage + np;
+  if (np) SSLAM_HIP_TRY(hipMemcpyAsync(pose, b.V.pose, np * 8, hipMemcpyDeviceToHost, b.stream));
+  if (nl) SSLAM_HIP_TRY(hipMemcpyAsync(lmk, b.V.lmk, nl * 8, hipMemcpyDeviceToHost, b.stream));
   SSLAM_HIP_TRY(hipStreamSynchronize(b.stream));
   for (size_t g = 0; g < b.graphs.size(); ++g) {
     HostGraph& G = *b.graphs[g];
@@ -1247,6 +1256,15 @@ static int batch_download_estimates(Batch& b) {
       else { const double* o = &lmk[(size_t)b.v2lm[g][v] * 4]; for (int k = 0; k < (G.vtype[v] == VT_POINT ? 3 : 4); ++k) e[k] = o[k]; }
     }
   }
+  return 0;
+}
+
+// a few device bytes -> host through the batch's page-locked staging buffer; synchronises the stream
+static int read_device(Batch& b, void* host, const void* dev, size_t bytes) {
+  char* stage = b.pin->get(bytes);
+  SSLAM_HIP_TRY(hipMemcpyAsync(stage ? (void*)stage : host, dev, bytes, hipMemcpyDeviceToHost, b.stream));
+  SSLAM_HIP_TRY(hipStreamSynchronize(b.stream));
+  if (stage) memcpy(host, stage, bytes);
   return 0;
 }
 
@@ -1335,8 +1353,7 @@ static int pcg_solve(Batch& b) {
     }
     hipLaunchKernelGGL(k_pcg_alldone, dim3(1), dim3(256), 0, b.stream, V, it & 1);
     int flag = 0;
-    SSLAM_HIP_TRY(hipMemcpyAsync(&flag, V.flags + 1, sizeof(int), hipMemcpyDeviceToHost, b.stream));
-    SSLAM_HIP_TRY(hipStreamSynchronize(b.stream));
+    if (int rc2 = read_device(b, &flag, V.flags + 1, sizeof(int))) return rc2;
     b.harvest();
     if (flag) break;
   }
@@ -1367,6 +1384,9 @@ static int batch_chi2(Batch& b, const double* pose, const double* lmk, int mask_
 }
 
 constexpr int kStepChunk = 8;   // LM steps enqueued between two looks at the per-graph state
+// the per-graph LM states -> host, through the page-locked staging buffer (synchronises the stream)
+static int read_lm_state(Batch& b, std::vector<LmState>& st) { return read_device(b, st.data(), b.V.lm, sizeof(LmState) * (size_t)b.V.B); }
+
 static int batch_optimize(Batch& b, int max_iters, sslam_opt_stats* out) {
   SSLAM_HIP_TRY(hipSetDevice(b.device));
   const auto t0 = std::chrono::steady_clock::now();
@@ -1415,8 +1435,7 @@ static int batch_optimize(Batch& b, int max_iters, sslam_opt_stats* out) {
     }
     budget -= chunk;
     const auto tq1 = std::chrono::steady_clock::now();
-    SSLAM_HIP_TRY(hipMemcpyAsync(st.data(), V.lm, sizeof(LmState) * V.B, hipMemcpyDeviceToHost, b.stream));
-    SSLAM_HIP_TRY(hipStreamSynchronize(b.stream));
+    if ((rc = read_lm_state(b, st))) return rc;
     if (chunk_timing && V.B == 1)
       fprintf(stderr, "[timing] LM chunk: %d steps enqueued in %.3f ms, waited %.3f ms more; iteration %d trials %d active %d\n", chunk,
               std::chrono::duration<double, std::milli>(tq1 - tq0).count(), std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tq1).count(),
@@ -1447,8 +1466,7 @@ static int batch_optimize(Batch& b, int max_iters, sslam_opt_stats* out) {
     }
   }
   if ((rc = chol_set_active(b, nullptr))) return rc;
-  SSLAM_HIP_TRY(hipMemcpyAsync(st.data(), V.lm, sizeof(LmState) * V.B, hipMemcpyDeviceToHost, b.stream));
-  SSLAM_HIP_TRY(hipStreamSynchronize(b.stream));
+  if ((rc = read_lm_state(b, st))) return rc;
   b.harvest();
   if ((rc = launch_check("optimize"))) return rc;
   if ((rc = chol_flow_check(b))) return rc;
@@ -1476,6 +1494,7 @@ using namespace sslam;
 struct sslam_graph {
   HostGraph g;
   DevArena arena;                // device memory of the batch below, kept across structure rebuilds (declared first: destroyed last)
+  PinnedScratch pin;             // page-locked staging of the batch's small copies, kept across rebuilds as well
   hipStream_t stream = nullptr;  // the handle's stream, handed to every batch it builds (a stream create / destroy pair per tick costs more
                                  // than optimising a small graph)
   std::unique_ptr<Batch> batch;  // batch of one, rebuilt when the structure changes
@@ -1529,6 +1548,7 @@ static int ensure_batch(sslam_graph* h) {
     if (timing) fprintf(stderr, "[timing] rebuild: release of the old batch + arena reset %.3f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tr0).count());
     h->batch.reset(new Batch());
     h->batch->arena = &h->arena;
+    h->batch->pin = &h->pin;
     h->batch->device = h->g.device;
     if (!h->stream) SSLAM_HIP_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
     h->batch->stream = h->stream; h->batch->own_stream = false;
@@ -1706,8 +1726,7 @@ int sslam_graph_chi2(sslam_graph* h, double* chi2) {
   if ((rc = batch_chi2(b, b.V.pose, b.V.lmk, 0))) return rc;
   hipLaunchKernelGGL(k_lm_init, dim3(b.V.B), dim3(64), 0, b.stream, b.V, b.d_part_e, 0);
   LmState s;
-  SSLAM_HIP_TRY(hipMemcpyAsync(&s, b.V.lm, sizeof s, hipMemcpyDeviceToHost, b.stream));
-  SSLAM_HIP_TRY(hipStreamSynchronize(b.stream));
+  if ((rc = read_device(b, &s, b.V.lm, sizeof s))) return rc;
   *chi2 = s.cur_chi;
   return 0;
 }

@@ -323,6 +323,7 @@ struct sslam_slam {
   DevBuf<int> d_kind, d_count;
   DevBuf<DetIn> d_det;
   DevBuf<sslam_landmark> d_out;
+  sslam::PinnedScratch pin;               // page-locked staging of the table / detection / result copies
   bool table_dirty = true;                // host landmarks changed outside the kernel -> re-upload before the next association
   ~sslam_slam() {
     if (graph) sslam_graph_destroy(graph);
@@ -350,8 +351,15 @@ int upload_table(sslam_slam* s) {
   if ((rc = s->d_cov.reserve(9 * (n + 64), s->stream, 0))) return rc;
   if ((rc = s->d_kind.reserve(n + 64, s->stream, 0))) return rc;
   if ((rc = s->d_count.reserve(1, s->stream, 0))) return rc;
-  std::vector<float> est(3 * n), cov(9 * n);
-  std::vector<int> kind(n);
+  // staged page-locked: [est 3n | cov 9n | kind n | count]
+  const size_t bytes = (13 * n + 1) * 4;
+  std::vector<char> fallback;
+  char* stage = s->pin.get(bytes);
+  if (!stage) { fallback.resize(bytes); stage = fallback.data(); }
+  float* est = reinterpret_cast<float*>(stage);
+  float* cov = est + 3 * n;
+  int* kind = reinterpret_cast<int*>(cov + 9 * n);
+  int* cnt = kind + n;
   for (size_t i = 0; i < n; ++i) {
     const sslam_landmark& l = s->landmarks[i];
     if (l.vertex >= 0) {   // landmarkMeasurementModel: h = l.node->estimate().cast<float>()
@@ -364,13 +372,13 @@ int upload_table(sslam_slam* s) {
     for (int k = 0; k < 9; ++k) cov[9 * i + k] = l.covariance[k];
     kind[i] = l.class_id | (l.plane_type << 16);
   }
-  const int cnt = (int)n;
+  *cnt = (int)n;
   if (n) {
-    SSLAM_HIP_TRY(hipMemcpyAsync(s->d_est.p, est.data(), est.size() * sizeof(float), hipMemcpyHostToDevice, s->stream));
-    SSLAM_HIP_TRY(hipMemcpyAsync(s->d_cov.p, cov.data(), cov.size() * sizeof(float), hipMemcpyHostToDevice, s->stream));
-    SSLAM_HIP_TRY(hipMemcpyAsync(s->d_kind.p, kind.data(), kind.size() * sizeof(int), hipMemcpyHostToDevice, s->stream));
+    SSLAM_HIP_TRY(hipMemcpyAsync(s->d_est.p, est, 3 * n * sizeof(float), hipMemcpyHostToDevice, s->stream));
+    SSLAM_HIP_TRY(hipMemcpyAsync(s->d_cov.p, cov, 9 * n * sizeof(float), hipMemcpyHostToDevice, s->stream));
+    SSLAM_HIP_TRY(hipMemcpyAsync(s->d_kind.p, kind, n * sizeof(int), hipMemcpyHostToDevice, s->stream));
   }
-  SSLAM_HIP_TRY(hipMemcpyAsync(s->d_count.p, &cnt, sizeof(int), hipMemcpyHostToDevice, s->stream));
+  SSLAM_HIP_TRY(hipMemcpyAsync(s->d_count.p, cnt, sizeof(int), hipMemcpyHostToDevice, s->stream));
   SSLAM_HIP_TRY(hipStreamSynchronize(s->stream));
   s->table_dirty = false;
   return 0;
@@ -390,7 +398,12 @@ int find_matches(sslam_slam* s, const sslam_plane* objs, int n, const float robo
   if ((rc = s->d_kind.reserve(nl + n, s->stream, nl))) return rc;
   if ((rc = s->d_det.reserve(n, s->stream, 0))) return rc;
   if ((rc = s->d_out.reserve(n, s->stream, 0))) return rc;
-  std::vector<DetIn> det(n);
+  // detections in, landmark records out: both through the page-locked staging buffer
+  const size_t det_bytes = ((size_t)n * sizeof(DetIn) + 7) & ~(size_t)7, out_bytes = (size_t)n * sizeof(sslam_landmark);
+  std::vector<char> fallback;
+  char* stage = s->pin.get(det_bytes + out_bytes);
+  if (!stage) { fallback.resize(det_bytes + out_bytes); stage = fallback.data(); }
+  DetIn* det = reinterpret_cast<DetIn*>(stage);
   for (int j = 0; j < n; ++j) {
     for (int k = 0; k < 3; ++k) det[j].pose[k] = objs[j].centroid_cam[k];
     for (int k = 0; k < 4; ++k) det[j].normal[k] = objs[j].normal_d[k];
@@ -410,12 +423,13 @@ int find_matches(sslam_slam* s, const sslam_plane* objs, int n, const float robo
   A.keep_distance_min = s->P.reference_quirks & 1;
   A.n_det = n;
   LmTable L{s->d_est.p, s->d_cov.p, s->d_kind.p, s->d_count.p};
-  SSLAM_HIP_TRY(hipMemcpyAsync(s->d_det.p, det.data(), n * sizeof(DetIn), hipMemcpyHostToDevice, s->stream));
+  SSLAM_HIP_TRY(hipMemcpyAsync(s->d_det.p, det, n * sizeof(DetIn), hipMemcpyHostToDevice, s->stream));
   hipLaunchKernelGGL(k_associate, dim3(1), dim3(kAssocThreads), 0, s->stream, A, s->d_det.p, L, s->d_out.p);
   SSLAM_HIP_TRY(hipGetLastError());
-  out.resize(n);
-  SSLAM_HIP_TRY(hipMemcpyAsync(out.data(), s->d_out.p, n * sizeof(sslam_landmark), hipMemcpyDeviceToHost, s->stream));
+  SSLAM_HIP_TRY(hipMemcpyAsync(stage + det_bytes, s->d_out.p, out_bytes, hipMemcpyDeviceToHost, s->stream));
   SSLAM_HIP_TRY(hipStreamSynchronize(s->stream));
+  out.resize(n);
+  memcpy(out.data(), stage + det_bytes, out_bytes);
   for (sslam_landmark& r : out) {
     if (r.is_new) {
       s->landmarks.push_back(r);                       // landmarks_.push_back(new_landmark) (:269)
