@@ -286,7 +286,7 @@ def bench_frontend(device, frames=8, cpu_baseline=True, batch_frames=32, dist=No
             pinned.append(g)
         pbf = [pinned[k % len(pinned)] for k in range(batch_frames)]
         list(seg.segment_stream([pbf, pbf]))                                 # warm-up (allocates the second pipeline)
-        preps, ppl = 6, 0
+        preps, ppl = 24, 0                                                    # a stream: the unhidden first copy and last kernels are 2 of 24 batches, not 2 of 6
         if dist is not None:
             import torch
             torch.cuda.synchronize(); dist.barrier()

@@ -36,6 +36,9 @@ inline int lds_optin_limit(int device, int want, int reserve) {
 struct PinnedScratch {
   char* p = nullptr;
   size_t cap = 0;
+  PinnedScratch() = default;
+  PinnedScratch(const PinnedScratch&) = delete;
+  PinnedScratch& operator=(const PinnedScratch&) = delete;
   char* get(size_t bytes) {
     if (bytes <= cap) return p;
     if (p) (void)hipHostFree(p);
