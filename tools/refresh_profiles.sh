@@ -1,6 +1,6 @@
 #!/bin/bash
 # Re-measure what the round's profiles/ hold.  Run on the GPU box: gpurun -- 'bash tools/refresh_profiles.sh [sections]'
-# sections (default "tests bench stats pmc frontend trace"): tests bench stats pmc frontend trace
+# sections (default "tests bench stats pmc frontend trace"): tests bench stats pmc frontend trace tick smoke
 # Writes gpurun_out/refresh/r5_*; copy the ones to be judged into profiles/.
 set -u
 R=${GRAFT_REPO_ROOT:-/root/repo}
@@ -46,4 +46,21 @@ if has trace; then
   rocprofv3 --kernel-trace --output-format csv -d $O/_p512 -- python $R/tools/prof_opt.py 512 2 > /dev/null 2>&1
   python $R/tools/level_profile.py $O/_p512 > $O/r5_factor_launch_trace_512.txt; rm -rf $O/_p512
   head -20 $O/r5_factor_launch_trace_512.txt | cut -c1-120
+fi
+if has tick; then
+  # kernel stats of the 110-keyframe tick replay (no CPU baseline inside the profiled process)
+  cat > /tmp/tick110.py <<PY
+import sys, json
+sys.path.insert(0, "$R")
+import bench
+t = bench.bench_tick(0, cpu_baseline=False)
+print(json.dumps({k: t[k] for k in ("keyframes", "ms_per_tick", "ms_per_tick_optimize", "ms_per_tick_marginals", "lm_iterations_per_tick")}))
+PY
+  rm -rf $O/_tk
+  rocprofv3 --kernel-trace --stats --output-format csv -d $O/_tk -- python /tmp/tick110.py > $O/tick_stdout.txt 2>&1
+  cp $(ls $O/_tk/*/*kernel_stats.csv | head -1) $O/r5_tick_kernel_stats.csv; rm -rf $O/_tk
+  tail -1 $O/tick_stdout.txt | cut -c1-200; head -6 $O/r5_tick_kernel_stats.csv | cut -c1-150
+fi
+if has smoke; then
+  (cd $R && python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')") 2>&1 | tail -2
 fi
