@@ -284,3 +284,36 @@ def test_bitset_ordering_gives_the_plan_of_the_list_ordering(hip_lib):
             x, y = getattr(a, name), getattr(b, name)
             assert x.shape == y.shape and x.tobytes() == y.tobytes(), name
         assert list(a.plv_pieces) == list(b.plv_pieces) and list(a.tail_pieces) == list(b.tail_pieces)
+
+
+def test_plans_of_the_growing_orchestrator_graph_factor(hip_lib):
+    """The structures a tick of the orchestrator really hands to the symbolic phase: the keyframe chain with its landmark edges as it
+    grows over a replay (oracle/oracle_slam.c drives the growth: semantic_graph_slam.cpp:104-150), planned in the small-batch regime the
+    tick runs in (one graph: per-piece workgroups, no groups) -- tiny graphs with a handful of columns included."""
+    from oracle.oracle import SlamTickC
+    from semantic_slam_amd import GraphSLAM
+    from semantic_slam_amd.synth import make_replay
+    events, _ = make_replay(7, n_samples=260, n_landmarks=24)
+    o = SlamTickC(const_stddev_x=0.00667, const_stddev_q=0.00001)
+    ticks, checked = 0, 0
+    for ev in events:
+        if ev.objects is not None:
+            o.set_segmented_objects(ev.objects)
+        o.vio(ev.stamp[0], ev.stamp[1], ev.odom)
+        if not (ev.run_after and o.run()):
+            continue
+        ticks += 1
+        if ticks not in (1, 2, 5, 12, 25, 40):
+            continue
+        g = o.graph()
+        vfixed = np.zeros(len(g["vtype"]), np.int32); vfixed[0] = 1          # graph_slam.cpp:109-111
+        gp = GraphProblem(g["vtype"], vfixed, g["est"], g["etype"], g["evi"], g["evj"], g["meas"], g["info"])
+        plan = Plan(hip_lib, [GraphSLAM.from_problem(gp)])
+        _structure_invariants(plan)
+        U, b = gp.linearize()
+        Hg = (U + U.T).toarray() - np.diag(U.diagonal())
+        idx, n = _internal_order(gp)
+        assert n == plan.dim
+        _check(plan, Hg[np.ix_(idx, idx)], b[idx], 1e-4 * np.abs(Hg).max())
+        checked += 1
+    assert checked >= 4
