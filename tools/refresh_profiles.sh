@@ -23,15 +23,21 @@ if has stats; then
   rm -rf $O/stats
 fi
 if has pmc; then
-  FB=$(python -c "import json;print(json.load(open('$O/r5_bench.json'))['roofline_factor']['bytes_per_launch'])")
-  JB=$(python -c "import json;print(json.load(open('$O/r5_bench.json'))['roofline_jacobian_build']['bytes_per_launch'])")
+  BJ=$O/r5_bench.json; [ -f $BJ ] || BJ=$R/profiles/r5_bench.json     # (a run without the bench section: the committed line)
+  FB=$(python -c "import json;print(json.load(open('$BJ'))['roofline_factor']['bytes_per_launch'])")
+  JB=$(python -c "import json;print(json.load(open('$BJ'))['roofline_jacobian_build']['bytes_per_launch'])")
   # PMC traffic: one full-batch factorisation / Jacobian build of the SAME 512 distinct graphs (tools/pmc_workload.py), separate passes
-  for c in FETCH_SIZE WRITE_SIZE; do
-    rocprofv3 --pmc $c --output-format csv -d $O/pmc_factor_$c -- python $R/tools/pmc_workload.py 512 factor > /dev/null 2>&1
-    rocprofv3 --pmc $c --output-format csv -d $O/pmc_jac_$c -- python $R/tools/pmc_workload.py 512 jacobian > /dev/null 2>&1
+  # PMC_WHAT="factor" or "jacobian" restricts the passes to one of the two
+  for w in ${PMC_WHAT:-factor jacobian}; do
+    for c in FETCH_SIZE WRITE_SIZE; do
+      rocprofv3 --pmc $c --output-format csv -d $O/pmc_${w}_$c -- python $R/tools/pmc_workload.py 512 $w > /dev/null 2>&1
+    done
+    if [ $w = factor ]; then
+      python $R/tools/pmc_traffic.py $O/pmc_factor_FETCH_SIZE $O/pmc_factor_WRITE_SIZE $O/r5_pmc_factor.json $FB 0 k_chol_tail k_chol_pieces k_chol_begin k_chol_end
+    else
+      python $R/tools/pmc_traffic.py $O/pmc_jacobian_FETCH_SIZE $O/pmc_jacobian_WRITE_SIZE $O/r5_pmc_jacobian_build.json $JB 0 k_linearize_rowthread k_linearize_lm_rows k_linearize_dups
+    fi
   done
-  python $R/tools/pmc_traffic.py $O/pmc_factor_FETCH_SIZE $O/pmc_factor_WRITE_SIZE $O/r5_pmc_factor.json $FB 0 k_chol_tail k_chol_pieces k_chol_begin k_chol_end
-  python $R/tools/pmc_traffic.py $O/pmc_jac_FETCH_SIZE $O/pmc_jac_WRITE_SIZE $O/r5_pmc_jacobian_build.json $JB 0 k_linearize_rowthread k_linearize_lm_rows k_linearize_dups
   rm -rf $O/pmc_*
 fi
 if has frontend; then
