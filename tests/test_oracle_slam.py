@@ -151,3 +151,39 @@ def test_c_tick_driver_equals_the_numpy_tick():
                 assert len(cov) == 0 or np.abs(lm["covariance"] - cov).max() <= 1e-5 * np.abs(cov).max()
                 assert np.abs(c.robot_pose() - o.robot_pose).max() <= 1e-7
         assert ticks >= 20 and c.counts()[2] == len(o.keyframes) and c.counts()[3] == len(o.assoc.landmarks)
+
+
+def test_tick_drivers_reproduce_the_committed_replay():
+    """tests/golden/tick400.npz (made by tests/golden/make_golden.py from oracle/oracle_slam.c): both CPU tick drivers replay the run to
+    the same graph -- structure exactly, estimates / landmark covariances / robot pose to tolerances that survive another libm."""
+    import os
+    from oracle.oracle import SlamTickC
+    from tests.slam_replay import ODOM_STDDEV_X, ODOM_STDDEV_Q
+    G = np.load(os.path.join(os.path.dirname(__file__), "golden", "tick400.npz"))
+    events, _ = make_replay(int(G["seed"]), n_samples=int(G["n_samples"]), n_landmarks=int(G["n_landmarks"]))
+    o = oracle_instance()
+    c = SlamTickC(const_stddev_x=ODOM_STDDEV_X, const_stddev_q=ODOM_STDDEV_Q)
+    per_tick = []
+    for ev in events:
+        if ev.objects is not None:
+            o.set_segmented_objects(ev.objects); c.set_segmented_objects(ev.objects)
+        o.vio(ev.stamp[0], ev.stamp[1], ev.odom); c.vio(ev.stamp[0], ev.stamp[1], ev.odom)
+        if ev.run_after:
+            ran = c.run()
+            assert o.run() == ran
+            if ran:
+                st = c.last_stats
+                per_tick.append((st.keyframes_added, st.landmarks_added, st.landmarks_matched, st.landmark_edges_added) + tuple(c.counts()))
+    assert np.array_equal(np.array(per_tick, np.int32), G["per_tick"])
+    g, lm = c.graph(), c.landmarks()
+    for k in ("vtype", "etype", "evi", "evj"):
+        assert np.array_equal(g[k], G[k])
+    assert list(o.vtype) == list(G["vtype"]) and list(o.evi) == list(G["evi"]) and list(o.evj) == list(G["evj"])
+    assert np.abs(g["meas"] - G["meas"]).max() <= 1e-9
+    assert np.array_equal(lm["vertex"], G["landmark_vertex"]) and np.array_equal(lm["class_id"], G["landmark_class"])
+    for est in (g["est"], np.array(o.est)):
+        assert np.abs(est - G["est"]).max() <= 1e-6
+    cov_np = np.array([l["covariance"] for l in o.assoc.landmarks]).reshape(-1, 3, 3)
+    for cov in (lm["covariance"], cov_np):
+        assert np.abs(cov - G["landmark_cov"]).max() <= 1e-4 * np.abs(G["landmark_cov"]).max()
+    assert np.abs(c.robot_pose() - G["robot_pose"]).max() <= 1e-6 and np.abs(o.robot_pose - G["robot_pose"]).max() <= 1e-6
