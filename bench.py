@@ -137,7 +137,7 @@ def bench_tick(device, n_samples=600, cpu_baseline=True, n_landmarks=40):
             q.class_id, q.plane_type = int(o["class_id"]), int(o["plane_type"])
             out.append(q)
         return out
-    ticks, t_tick, parts, lm_iters = 0, 0.0, [0.0, 0.0, 0.0], 0
+    ticks, t_tick, parts, lm_iters, plan_us = 0, 0.0, [0.0, 0.0, 0.0], 0, []
     for ev in events:
         if ev.objects is not None:
             S.setSegmentedObjects(planes_of(ev.objects))
@@ -150,6 +150,8 @@ def bench_tick(device, n_samples=600, cpu_baseline=True, n_landmarks=40):
                 st = S.last_stats
                 ticks += 1; t_tick += dt; lm_iters += int(st.opt.iterations) if st.optimized else 0
                 parts[0] += st.seconds_association; parts[1] += st.seconds_optimize; parts[2] += st.seconds_marginals
+                if st.optimized:
+                    plan_us.append(int(st.opt.host_plan_us))
     ids, _ = S.getKeyframes()
     cpu = None
     if cpu_baseline:
@@ -170,6 +172,11 @@ def bench_tick(device, n_samples=600, cpu_baseline=True, n_landmarks=40):
             "ms_per_tick_association": round(1e3 * parts[0] / max(ticks, 1), 3),
             "ms_per_tick_optimize": round(1e3 * parts[1] / max(ticks, 1), 3),
             "ms_per_tick_marginals": round(1e3 * parts[2] / max(ticks, 1), 3),
+            # host work a tick's structure change costs before the first launch: batch tables + symbolic factorisation, re-done from
+            # scratch at every tick (no incremental symbolic phase; part of ms_per_tick_optimize): median over the replay (the first tick
+            # also allocates the handle's arena) and mean of the last ten ticks, where the graph is largest
+            "ms_per_tick_host_plan_median": round(1e-3 * sorted(plan_us)[len(plan_us) // 2], 3) if plan_us else None,
+            "ms_per_tick_host_plan_last10": round(1e-3 * sum(plan_us[-10:]) / max(len(plan_us[-10:]), 1), 3) if plan_us else None,
             "lm_iterations_per_tick": round(lm_iters / max(ticks, 1), 1)}
 
 

@@ -52,7 +52,8 @@ typedef struct sslam_opt_stats {
   int trials;            /* linear solves (accepted + rejected LM trials) */
   int status;            /* 0 = iteration cap reached, 1 = LM terminated (10 failed trials or rho == 0),
                             <0 = SSLAM_ERR_* */
-  int reserved;
+  int host_plan_us;      /* sslam_graph_optimize: microseconds of host work before the first launch of this call that a structure change
+                            cost -- batch tables + symbolic factorisation (0 when the structure of the last call was reused); 0 in batches */
   double chi2_before;    /* graph->chi2() before (graph_slam.cpp:202) */
   double chi2_after;     /* graph->chi2() after  (graph_slam.cpp:211) */
   double lambda;         /* final LM damping */

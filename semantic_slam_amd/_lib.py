@@ -27,7 +27,7 @@ def build_library(force: bool = False) -> str:
 
 
 class OptStats(C.Structure):
-    _fields_ = [("iterations", C.c_int), ("trials", C.c_int), ("status", C.c_int), ("reserved", C.c_int),
+    _fields_ = [("iterations", C.c_int), ("trials", C.c_int), ("status", C.c_int), ("host_plan_us", C.c_int),
                 ("chi2_before", C.c_double), ("chi2_after", C.c_double), ("lambda_", C.c_double),
                 ("seconds", C.c_double), ("solver_iterations", C.c_int64)]
 

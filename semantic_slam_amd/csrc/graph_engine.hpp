@@ -111,6 +111,7 @@ struct Batch {
   BatchView V{};
   std::vector<void*> allocs;
   DevArena* arena = nullptr;   // set for the batch of one behind a graph handle: device arrays come out of the handle's arena
+  double plan_build_ms = 0;    // host time of chol_plan_build since the last sslam_graph_optimize read it (sslam_opt_stats::host_plan_us)
   PinnedScratch own_pin;       // staging of the small copies ...
   PinnedScratch* pin = &own_pin;   // ... or the graph handle's (kept across the per-tick rebuilds of its batch of one)
   // host-side metadata

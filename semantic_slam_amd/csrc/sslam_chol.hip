@@ -1681,6 +1681,8 @@ int chol_spec_mode(const Batch& b) {
   return env >= 0 ? env : b.graphs[0]->opt.speculative;
 }
 int chol_plan_build(Batch& b) {
+  struct HostTimer { Batch& b; std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+                     ~HostTimer() { b.plan_build_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); } } host_timer{b};
   if (b.chol) { chol_plan_free(b.chol); b.chol = nullptr; }
   SSLAM_HIP_TRY(hipSetDevice(b.device));
   SymIn in;

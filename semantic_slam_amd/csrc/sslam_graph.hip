@@ -1728,6 +1728,8 @@ int sslam_graph_optimize(sslam_graph* h, int max_iters, sslam_opt_stats* out) {
   const double t2 = now();
   if ((rc = batch_optimize(*h->batch, max_iters, out))) return rc;
   const double t3 = now();
+  out->host_plan_us = (int)std::lround(1e3 * ((t1 - t0) + h->batch->plan_build_ms));   // what the structure change cost the host (0.0x ms when nothing changed)
+  h->batch->plan_build_ms = 0;
   h->linearized = false;
   rc = batch_download_estimates(*h->batch);
   if (timing) fprintf(stderr, "[timing] optimize: vertices %d edges %d | structure %.3f upload %.3f LM %.3f (iterations %d trials %d) download %.3f ms\n",
