@@ -94,6 +94,10 @@ SSLAM_HD_INLINE int upd_ry(const UpdMeta& r) { return (int)((r.xk >> 16) & 0xFFF
 inline UpdMeta upd_make(int ua_local, int ub_local, int yk_local, unsigned flags) { return UpdMeta{(unsigned)ua_local | ((unsigned)ub_local << 16), (unsigned)yk_local | flags}; }
 inline UpdMeta upd_make_right(int ua_local, int ub_local, int tl, int yl, unsigned flags) { return UpdMeta{(unsigned)ua_local | ((unsigned)ub_local << 16), (unsigned)tl | ((unsigned)yl << 16) | flags}; }
 
+}  // namespace sslam
+#include "front_plan.hpp"
+namespace sslam {
+
 struct ItemMeta { int u0, n, tloff, flags; };   // updates [u0, u0 + n) (index into the piece's update records, LDS copy) of one target
                                                 // block at piece-local offset tloff
 constexpr int kItemSole = 1;                     // flags: bit 0 sole (subtract in place); bits 1..11 partial slot; bits 12.. local y offset
@@ -179,6 +183,9 @@ struct CholOpts {
                            // matrices, five levels more: throughput -- measured 9.30 vs 9.48 ms per 512 factorisations)
   int order_bits_max = 2048;   // graphs up to this many nodes are ordered on adjacency bitsets (same order, a fraction of the time); 0: never
   bool dump = false;
+  int front = -1;          // front tables (front_plan.hpp: one blob of relative indices per workgroup, kernels k_front_*): -1: for batches >= 32
+                           // (the per-depth launches), 0: never, 1: build them for every plan (the dependency-driven launches of small batches
+                           // still run the record plan)
   int flow = 1;            // small batches: 0 a launch per depth; 1 the dependency-driven single launch (k_chol_flow) when the tree is narrower than its
                            // grid; 2 also on wide trees (per-depth launches for the bottom, measured slower: tests only)
   // SSLAM_CHOL_OPTS="key=value,key=value,...": every plan option above by its field name (tests force the piece shapes of a 5000-pose graph
@@ -203,7 +210,7 @@ struct CholOpts {
       else if (k == "min_chunk") min_chunk = std::max(1, iv); else if (k == "split_min") split_min = std::max(2, iv);
       else if (k == "pcap_leaf") pcap_leaf = iv; else if (k == "pcap_mid") pcap_mid = iv; else if (k == "pcap_tail") pcap_tail = iv;
       else if (k == "group_cap") group_cap = iv; else if (k == "group_blocks") group_blocks = iv; else if (k == "ustage") ustage = iv;
-      else if (k == "order_bits_max") order_bits_max = iv; else if (k == "flow") flow = iv; else if (k == "dump") dump = iv != 0;
+      else if (k == "order_bits_max") order_bits_max = iv; else if (k == "flow") flow = iv; else if (k == "front") front = iv; else if (k == "dump") dump = iv != 0;
       else if (k == "order") order = (v == "mindeg" || v == "0") ? 0 : 1;
       else if (k == "order_mul") order_mul = atof(v.c_str()); else if (k == "order_add") order_add = iv;
       else fprintf(stderr, "[sslam] SSLAM_CHOL_OPTS: unknown key '%s'\n", k.c_str());
@@ -211,6 +218,20 @@ struct CholOpts {
   }
   bool nt_leaf_set = false;   // nt_leaf came from SSLAM_CHOL_OPTS (the single-launch solve leaves it alone then)
 };
+
+// The options a plan is really built with: the workgroup sizes the kernels exist for, and the small-batch regime -- batches < 8
+// (latency-bound: the orchestrator's graph, a single large graph) run the dependency-driven single launch (k_chol_flow) with every piece
+// cut for the tail's workgroup size and no mid class.  ONE place for chol_plan_build and the plan introspection of the CPU tests (round-5
+// ADVICE: the tests pinned plans cut for 64-thread pieces while the tick factored 512-thread ones).  Returns whether the plan is meant
+// for the single launch.
+inline bool chol_opts_normalise(CholOpts& opt, int B) {
+  if (opt.nt_tail != 1024) opt.nt_tail = 512;
+  if (opt.nt_leaf != -1 && opt.nt_leaf != 128 && opt.nt_leaf != 256 && opt.nt_leaf != 512 && opt.nt_leaf != 1024) opt.nt_leaf = 64;   // -1: by batch size (chol_symbolic)
+  if (opt.nt_mid != 128 && opt.nt_mid != 512) opt.nt_mid = 256;
+  const bool want_flow = opt.flow != 0 && B < 8 && opt.nt_tail == 512 && opt.group_cap <= 0 && !opt.nt_leaf_set;
+  if (want_flow) { opt.nt_leaf = opt.nt_tail; opt.mid_width = 0; }
+  return want_flow;
+}
 
 struct CholHost {
   int ncol = 0, nlevels = 0, dim = 0, B = 0, npiece = 0;
@@ -228,6 +249,14 @@ struct CholHost {
   std::vector<int> plv_nt, plv_cls;         // workgroup size (nt_leaf | nt_mid) and class (0 leaf | 1 mid) per launch
   int tail_lds_f = 0, tail_lds_b = 0;
   int nt_leaf = 64, nt_mid = 256, nt_tail = 512, ustage = 0;
+  // front tables (front_plan.hpp); empty when the plan has none (front_why says why)
+  bool front = false;
+  std::string front_why;
+  std::vector<uint32_t> fblob;
+  std::vector<FrontGrp> fgrp, lfgrp;        // by piece id / in launch order (like lpiece)
+  std::vector<int> plv_lds_ff;              // LDS doubles of the front factor kernel per launch
+  int tail_lds_ff = 0;
+  int64_t funz = 0;                         // doubles of update matrices in the front layout
   std::string error;
 };
 
@@ -467,6 +496,7 @@ inline int chol_symbolic(const SymIn& in, CholOpts opt, CholHost& out) {
   if (opt.nt_leaf < 0) opt.nt_leaf = B >= 32 ? 128 : 64;
   if (opt.order < 0) opt.order = 1;
   if (opt.order_mul < 0 || opt.order_add < 0) { opt.order_mul = B >= 32 ? 1.5 : 2.0; opt.order_add = B >= 32 ? 2 : 4; }
+  if (opt.front < 0) opt.front = B >= 32 ? 1 : 0;
   out = CholHost();
   out.B = B; out.nt_leaf = opt.nt_leaf; out.nt_mid = opt.nt_mid; out.nt_tail = opt.nt_tail; out.ustage = opt.ustage;
   auto row_dim = [&](int r) { return r < nPr ? 6 : 3; };
@@ -1148,6 +1178,31 @@ inline int chol_symbolic(const SymIn& in, CholOpts opt, CholHost& out) {
       out.plv_lds_b[l] = std::max(out.plv_lds_b[l], lds_b(out.plv_pieces[q]));
     }
   for (int p : out.tail_pieces) { out.tail_lds_f = std::max(out.tail_lds_f, lds_f(p)); out.tail_lds_b = std::max(out.tail_lds_b, lds_b(p)); }
+  // ---- front tables (front_plan.hpp): the same pieces as one blob of relative indices per workgroup -------------------------------
+  if (opt.front > 0) {
+    FrontHost F;
+    front_build(FrontIn{ncol, npiece, ncomp, bp, brow, boff, bsrc, bfmt, col_comp, col_piece, col_dim, col_xoff, col_yoff, col_il, comp_parent, comp_R}, out.piece, out.ilv, F);
+    // the kernels keep the diagonal blocks of a level in registers of 8-lane teams, up to two columns per team (front_kernels.hpp)
+    for (int p = 0; p < npiece && F.ok; ++p) {
+      const int nt = piece_tail[p] ? opt.nt_tail : (piece_cls[p] == 1 ? opt.nt_mid : opt.nt_leaf);
+      for (int l = 0; l < out.piece[p].nilv; ++l) {
+        const ILevel& lv = out.ilv[out.piece[p].ilv0 + l];
+        if (lv.c1 - lv.c0 > 2 * (nt / 8)) { F.ok = false; F.why = "a level of a piece has more columns than the workgroup's teams hold"; break; }
+      }
+    }
+    out.front = F.ok; out.front_why = F.why;
+    if (F.ok) {
+      out.fblob.swap(F.blob); out.fgrp.swap(F.grp); out.funz = F.unz;
+      out.lfgrp.reserve(npiece);
+      for (int p : out.plv_pieces) out.lfgrp.push_back(out.fgrp[p]);
+      for (int p : out.tail_pieces) out.lfgrp.push_back(out.fgrp[p]);
+      out.plv_lds_ff.assign(nlaunch, 0);
+      for (int l = 0; l < nlaunch; ++l)
+        for (int q = out.plv_ptr[l]; q < out.plv_ptr[l + 1]; ++q) out.plv_lds_ff[l] = std::max(out.plv_lds_ff[l], F.lds[out.plv_pieces[q]]);
+      for (int p : out.tail_pieces) out.tail_lds_ff = std::max(out.tail_lds_ff, F.lds[p]);
+    }
+    SSLAM_PT("front tables")
+  }
   if (opt.dump) {
     fprintf(stderr, "[chol-dump] B %d cols %d blocks %d lnz %lld unz %lld updates %zu (internal items %zu, U items %zu) column-levels %d pieces %d piece-levels %d tail pieces %zu\n",
             B, ncol, nblk, (long long)lnz, (long long)out.unz, out.upd.size(), out.item.size(), out.uitem.size(), nlev, npiece, nplv, out.tail_pieces.size());

@@ -52,6 +52,8 @@ struct CholView {
   double* Uval;             // update matrices handed from child pieces to their parents
   double* y;                // forward-substituted rhs, elimination order [dim]
   int* fail;                // [B]
+  const unsigned* fblob;    // front tables (front_plan.hpp): the blobs, and per launch-order piece where its blob is; nullptr: record plan only
+  const FrontGrp* lfgrp;
   int flat_L;               // 1: the factor is written in flat form (multi right-hand-side kernels); 0: class-interleaved (LM loop)
   long long* dbg;           // SSLAM_CHOL_STAMPS: shader-clock totals per phase of workgroup 0 ([16] tail kernel, [16] per-depth kernels)
 };
@@ -80,6 +82,9 @@ struct CholPlan {
   CholView C{};
   SpecLanes spec{};
   std::vector<int> lvl_ptr, plv_ptr, plv_lds_f, plv_lds_b, plv_nt, plv_cls;
+  std::vector<int> plv_lds_ff;  // front kernels (front_kernels.hpp): LDS doubles per launch; front: the per-depth launches run them
+  int tail_lds_ff = 0;
+  bool front = false;
   int tail_lds_f = 0, tail_lds_b = 0, tail_total = 0, nt_tail = 512, nt_leaf = 64, ustage = 0;
   std::vector<void*> allocs;
   DevArena* arena = nullptr;    // the owning batch's arena (single-graph handles), else hipMalloc
@@ -115,14 +120,19 @@ struct CholPlan {
 void chol_plan_free(CholPlan* p) {
   if (!p) return;
   if (p->C.dbg) {   // SSLAM_CHOL_STAMPS: where workgroup 0 of the factor kernels spent its shader clocks
-    long long h[48];
+    long long h[64];
     if (hipMemcpy(h, p->C.dbg, sizeof h, hipMemcpyDeviceToHost) == hipSuccess) {
       for (int k = 0; k < 2; ++k) {
         const long long* d = h + 32 + 8 * k;
         fprintf(stderr, "[chol-stamps] backward %s: pieces %lld levels %lld blocks %lld | clocks: blocks pass %lld column sums %lld levels %lld store %lld\n",
                 k ? "depth kernels (wg 0)" : "tail (graph 0)", d[4], d[5], d[6], d[0], d[1], d[2], d[3]);
       }
-      for (int k = 0; k < 2; ++k) {
+      if (p->front) for (int k = 0; k < 3; ++k) {
+        const long long* d = h + (k == 2 ? 48 : 16 * k);
+        fprintf(stderr, "[front-stamps] %s: pieces %lld levels %lld U-tiles %lld target tiles %lld | clocks: blob %lld derive %lld gather %lld tiles %lld factor+rows %lld U %lld out %lld\n",
+                k == 2 ? "mid pieces (wg 0)" : k ? "leaf groups (wg 0)" : "tail (graph 0)", d[8], d[9], d[10], d[11], d[0], d[1], d[2], d[3], d[4], d[5], d[6]);
+      }
+      else for (int k = 0; k < 2; ++k) {
         const long long* d = h + 16 * k;
         fprintf(stderr, "[chol-stamps] %s: pieces %lld levels %lld U-items %lld int-items %lld | clocks: tables %lld gather %lld items %lld reduce %lld diag %lld rows %lld U %lld out %lld\n",
                 k ? "depth kernels (wg 0)" : "tail (graph 0)", d[8], d[9], d[10], d[11], d[0], d[1], d[2], d[3], d[4], d[5], d[6], d[7]);
@@ -1641,6 +1651,10 @@ __global__ void k_chol_end(BatchView V, CholView C) {  // publish failures throu
   if (g < V.B && V.lm[g].in_trial) V.pcg_fail[g] = C.fail[g];
 }
 
+}  // namespace sslam
+#include "front_kernels.hpp"
+namespace sslam {
+
 // ------------------------------------------------------------------------------------------------
 // host
 // ------------------------------------------------------------------------------------------------
@@ -1689,15 +1703,10 @@ int chol_plan_build(Batch& b) {
   chol_sym_input(b, in);
   CholOpts opt;
   opt.from_env();
-  if (opt.nt_tail != 1024) opt.nt_tail = 512;
-  if (opt.nt_leaf != -1 && opt.nt_leaf != 128 && opt.nt_leaf != 256 && opt.nt_leaf != 512 && opt.nt_leaf != 1024) opt.nt_leaf = 64;   // -1: by batch size (chol_symbolic)
-  if (opt.nt_mid != 128 && opt.nt_mid != 512) opt.nt_mid = 256;
   // small batches (latency-bound: the orchestrator's graph, a single large graph): the dependency-driven single launch (k_chol_flow) runs
-  // every piece with the tail's workgroup size
+  // every piece with the tail's workgroup size (chol_opts_normalise, shared with the plan introspection of the CPU tests)
   const int flow_mode = opt.flow;   // 0 off, 1 auto, 2 also on wide trees (SSLAM_CHOL_OPTS flow=...; read per plan: tests toggle it)
-  const bool flow_on = flow_mode != 0;
-  const bool want_flow = flow_on && b.V.B < 8 && opt.nt_tail == 512 && opt.group_cap <= 0 && !opt.nt_leaf_set;
-  if (want_flow) { opt.nt_leaf = opt.nt_tail; opt.mid_width = 0; }
+  const bool want_flow = chol_opts_normalise(opt, b.V.B);
   CholHost H;
   if (chol_symbolic(in, opt, H)) return set_error(SSLAM_ERR_NUMERIC, "Cholesky plan: %s", H.error.c_str());
   CholPlan* P = new CholPlan();
@@ -1762,6 +1771,14 @@ int chol_plan_build(Batch& b) {
   if ((rc = up_to_dev(*P, b.stream, H.plv_pieces, &C.plv_pieces))) return rc;
   if ((rc = up_to_dev(*P, b.stream, H.tail_ptr, &C.tail_ptr))) return rc;
   if ((rc = up_to_dev(*P, b.stream, H.tail_pieces, &C.tail_pieces))) return rc;
+  C.fblob = nullptr; C.lfgrp = nullptr;
+  if (H.front) {
+    if ((rc = up_to_dev(*P, b.stream, H.fblob, (const uint32_t**)&C.fblob))) return rc;
+    if ((rc = up_to_dev(*P, b.stream, H.lfgrp, &C.lfgrp))) return rc;
+    P->front = true; P->plv_lds_ff = H.plv_lds_ff; P->tail_lds_ff = H.tail_lds_ff;
+  } else if (opt.front != 0 && b.V.B >= 32) {
+    fprintf(stderr, "[sslam] Cholesky plan without front tables (%s): the record kernels run\n", H.front_why.c_str());
+  }
   void* p = nullptr;
   auto plan_alloc = [&](void** q, size_t bytes) -> int {
     if (P->arena) {
@@ -1775,10 +1792,11 @@ int chol_plan_build(Batch& b) {
   if ((rc = plan_alloc(&p, (H.lnz + 64) * sizeof(double)))) return rc;
   C.Lval = (double*)p;
   SSLAM_HIP_TRY(hipMemsetAsync(p, 0, (H.lnz + 64) * sizeof(double), b.stream));
-  if ((rc = plan_alloc(&p, (H.unz + 64) * sizeof(double)))) return rc;
+  const int64_t unz_all = std::max(H.unz, H.funz);   // (the front layout of the update matrices takes the same space: dense triangles either way)
+  if ((rc = plan_alloc(&p, (unz_all + 64) * sizeof(double)))) return rc;
   C.Uval = (double*)p;
-  SSLAM_HIP_TRY(hipMemsetAsync(p, 0, (H.unz + 64) * sizeof(double), b.stream));
-  P->unz = H.unz;
+  SSLAM_HIP_TRY(hipMemsetAsync(p, 0, (unz_all + 64) * sizeof(double), b.stream));
+  P->unz = unz_all;
   if ((rc = plan_alloc(&p, (C.dim + 8) * sizeof(double)))) return rc;
   C.y = (double*)p;
   SSLAM_HIP_TRY(hipMemsetAsync(p, 0, (C.dim + 8) * sizeof(double), b.stream));
@@ -1788,9 +1806,9 @@ int chol_plan_build(Batch& b) {
   C.dbg = nullptr;
   C.flat_L = 0;
   if (getenv("SSLAM_CHOL_STAMPS")) {
-    if ((rc = plan_alloc(&p, 48 * sizeof(long long)))) return rc;
+    if ((rc = plan_alloc(&p, 64 * sizeof(long long)))) return rc;
     C.dbg = (long long*)p;
-    SSLAM_HIP_TRY(hipMemsetAsync(p, 0, 48 * sizeof(long long), b.stream));
+    SSLAM_HIP_TRY(hipMemsetAsync(p, 0, 64 * sizeof(long long), b.stream));
   }
   // index lists of the LM endgame (chol_set_active), sized once: no allocation inside an optimize call (a stream group runs several of
   // them side by side)
@@ -1800,8 +1818,9 @@ int chol_plan_build(Batch& b) {
     P->idx_cap = cap;
   }
   // LDS opt-in above 64 KiB
-  size_t lds_max = (size_t)std::max(P->tail_lds_f, P->tail_lds_b);
+  size_t lds_max = (size_t)std::max(std::max(P->tail_lds_f, P->tail_lds_b), P->tail_lds_ff);
   for (size_t l = 0; l < P->plv_lds_f.size(); ++l) lds_max = std::max(lds_max, (size_t)std::max(P->plv_lds_f[l], P->plv_lds_b[l]));
+  for (int v : P->plv_lds_ff) lds_max = std::max(lds_max, (size_t)v);
   lds_max *= sizeof(double);
   const int lds_lim = lds_optin_limit(b.device, 160 * 1024 - 2048, 2048);
   if (lds_max > (size_t)lds_lim) return set_error(SSLAM_ERR_UNSUPPORTED, "a piece of the factor needs %zu B of LDS (device limit %d B)", lds_max, lds_lim);
@@ -1822,7 +1841,12 @@ int chol_plan_build(Batch& b) {
                            (const void*)k_chol_back_pieces<64>, (const void*)k_chol_back_pieces<128>, (const void*)k_chol_back_pieces<256>,
                            (const void*)k_chol_back_pieces<512>, (const void*)k_chol_back_pieces<1024>, (const void*)k_chol_back_tail<512>,
                            (const void*)k_chol_flow<512, true>, (const void*)k_chol_flow<512, false>,
-                           (const void*)k_chol_spec_round<512, true>, (const void*)k_chol_spec_round<512, false>};
+                           (const void*)k_chol_spec_round<512, true>, (const void*)k_chol_spec_round<512, false>,
+                           (const void*)k_front_pieces<64, false>, (const void*)k_front_pieces<128, false>, (const void*)k_front_pieces<256, false>,
+                           (const void*)k_front_pieces<512, false>, (const void*)k_front_pieces<1024, false>,
+                           (const void*)k_front_pieces<64, true>, (const void*)k_front_pieces<128, true>, (const void*)k_front_pieces<256, true>,
+                           (const void*)k_front_pieces<512, true>, (const void*)k_front_pieces<1024, true>,
+                           (const void*)k_front_tail<512>, (const void*)k_front_tail<1024>};
       for (const void* f : fns) SSLAM_HIP_TRY(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, v));
       done.push_back(b.device);
     }
@@ -2113,6 +2137,21 @@ int chol_factor_and_forward(Batch& b, bool flat) {
     const int n = P.compact ? P.c_ptr[l + 1] - P.c_ptr[l] : P.plv_ptr[l + 1] - P.plv_ptr[l];
     if (n <= 0) continue;
     const int* idx = P.compact ? P.d_idx + P.c_ptr[l] : nullptr;
+    if (P.front) {   // front tables: one kernel for every class, the workgroup size the launch was cut for
+      const size_t ldf = (size_t)P.plv_lds_ff[l] * sizeof(double);
+#define SSLAM_LAUNCH_FRONT(NTV)                                                                                                     \
+  if (P.plv_cls[l] == 1) hipLaunchKernelGGL((k_front_pieces<NTV, true>), dim3(n), dim3(NTV), ldf, b.stream, b.V, C, P.plv_ptr[l], idx);   \
+  else hipLaunchKernelGGL((k_front_pieces<NTV, false>), dim3(n), dim3(NTV), ldf, b.stream, b.V, C, P.plv_ptr[l], idx);
+      switch (P.plv_nt[l]) {
+        case 128: SSLAM_LAUNCH_FRONT(128) break;
+        case 256: SSLAM_LAUNCH_FRONT(256) break;
+        case 512: SSLAM_LAUNCH_FRONT(512) break;
+        case 1024: SSLAM_LAUNCH_FRONT(1024) break;
+        default: SSLAM_LAUNCH_FRONT(64) break;
+      }
+#undef SSLAM_LAUNCH_FRONT
+      continue;
+    }
     const size_t lds = (size_t)P.plv_lds_f[l] * sizeof(double);
 #define SSLAM_LAUNCH_PIECES(NTV)                                                                                                   \
   if (P.ustage) hipLaunchKernelGGL((k_chol_pieces<NTV, true>), dim3(n), dim3(NTV), lds, b.stream, b.V, C, P.plv_ptr[l], idx);       \
@@ -2139,7 +2178,10 @@ int chol_factor_and_forward(Batch& b, bool flat) {
   if (P.tail_total > 0) {
     const int n = P.compact ? P.c_ptr[nplv + 1] - P.c_ptr[nplv] : b.V.B;
     const int* idx = P.compact ? P.d_idx + P.c_ptr[nplv] : nullptr;
-    if (n > 0) {
+    if (n > 0 && P.front) {
+      if (P.nt_tail == 1024) hipLaunchKernelGGL(k_front_tail<1024>, dim3(n), dim3(1024), (size_t)P.tail_lds_ff * sizeof(double), b.stream, b.V, C, idx);
+      else hipLaunchKernelGGL(k_front_tail<512>, dim3(n), dim3(512), (size_t)P.tail_lds_ff * sizeof(double), b.stream, b.V, C, idx);
+    } else if (n > 0) {
       if (P.nt_tail == 1024) hipLaunchKernelGGL(k_chol_tail<1024>, dim3(n), dim3(1024), (size_t)P.tail_lds_f * sizeof(double), b.stream, b.V, C, idx);
       else hipLaunchKernelGGL(k_chol_tail<512>, dim3(n), dim3(512), (size_t)P.tail_lds_f * sizeof(double), b.stream, b.V, C, idx);
     }

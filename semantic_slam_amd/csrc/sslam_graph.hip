@@ -2390,9 +2390,7 @@ void* sslam_debug_plan_create(sslam_graph* const* graphs, int n) {
   chol_sym_input(b, in);
   CholOpts opt;
   opt.from_env();
-  if (opt.nt_tail != 1024) opt.nt_tail = 512;
-  if (opt.nt_leaf != -1 && opt.nt_leaf != 128 && opt.nt_leaf != 256 && opt.nt_leaf != 512 && opt.nt_leaf != 1024) opt.nt_leaf = 64;   // -1: by batch size (chol_symbolic)
-  if (opt.nt_mid != 128 && opt.nt_mid != 512) opt.nt_mid = 256;
+  chol_opts_normalise(opt, b.V.B);   // the plan chol_plan_build would execute, small-batch regime included
   sslam_debug_plan* P = new sslam_debug_plan();
   P->h_total = b.V.h_total;
   for (auto& q : b.ppoff) { P->ppoff.push_back(q.first); P->ppoff.push_back(q.second); }
@@ -2418,10 +2416,14 @@ int64_t sslam_debug_plan_array(void* p, const char* name, void* out, int64_t cap
   ARR("ppoff", DP.ppoff) ARR("plblk", DP.plblk) ARR("tail_ptr", H.tail_ptr)
   ARR("asrc", H.asrc) ARR("usrc", H.usrc) ARR("fwd", H.fwd) ARR("uitem", H.uitem) ARR("umb", H.umb) ARR("tail_pieces", H.tail_pieces) ARR("plv_lds_f", H.plv_lds_f) ARR("plv_lds_b", H.plv_lds_b)
   ARR("rcol", H.rcol) ARR("rupd", H.rupd) ARR("plv_nt", H.plv_nt) ARR("plv_cls", H.plv_cls)
+  ARR("fblob", H.fblob) ARR("fgrp", H.fgrp) ARR("plv_lds_ff", H.plv_lds_ff)
 #undef ARR
+  int fscal[4] = {H.front ? 1 : 0, (int)H.funz, H.tail_lds_ff, 0};   // front tables (front_plan.hpp): present, doubles of update matrices, LDS of the tail
+  if (k == "fscalars") { src = fscal; bytes = sizeof fscal; }
   if (k == "scalars") { src = scal; bytes = sizeof scal; }
   static const char* known[] = {"col", "blk", "upd", "item", "mb", "ilv", "piece", "lvl_ptr", "lvl_cols", "plv_ptr", "plv_pieces", "ppoff", "plblk",
-                                "tail_ptr", "tail_pieces", "plv_lds_f", "plv_lds_b", "scalars", "asrc", "usrc", "fwd", "uitem", "umb", "rcol", "rupd", "plv_nt", "plv_cls"};
+                                "tail_ptr", "tail_pieces", "plv_lds_f", "plv_lds_b", "scalars", "asrc", "usrc", "fwd", "uitem", "umb", "rcol", "rupd", "plv_nt", "plv_cls",
+                                "fblob", "fgrp", "plv_lds_ff", "fscalars"};
   bool ok = false;
   for (const char* q : known) ok |= (k == q);
   if (!ok) return set_error(SSLAM_ERR_INVALID, "unknown plan array '%s'", name);

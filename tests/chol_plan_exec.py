@@ -55,6 +55,12 @@ class Plan:
         s = self.scalars
         (self.ncol, self.nlevels, self.dim, self.B, self.npiece, self.lnz, self.tail_lds_f, self.tail_lds_b, self.nt_leaf, self.nt_tail,
          self.h_total, self.nPr, self.nLr, self.hll_base, self.hpp_off_base, self.hpl_base, self.unz) = [int(v) for v in s[:17]]
+        # front tables (semantic_slam_amd/csrc/front_plan.hpp): one blob of relative indices per workgroup
+        fs = g("fscalars", np.int32)
+        self.front, self.funz, self.tail_lds_ff = bool(fs[0]), int(fs[1]), int(fs[2])
+        self.fblob = g("fblob", np.uint32) if self.front else np.zeros(0, np.uint32)
+        self.fgrp = g("fgrp", np.dtype([(n, "<i4") for n in ("blob", "words", "dbytes", "graph")])) if self.front else None
+        self.plv_lds_ff = g("plv_lds_ff", np.int32) if self.front else None
         lib.sslam_debug_plan_destroy(self._h)
         self._h = None
 
@@ -263,6 +269,262 @@ class Plan:
             Uval[mm["uoff"]:mm["uoff"] + di * dj] = acc.ravel()
             if diag:
                 Uval[mm["uyoff"]:mm["uyoff"] + dj] = accy
+        Lval[lbase:lbase + pm["lsize"]] = smL
+        y[y0:y0 + pm["ysize"]] = smY
+        return ok
+
+    # ---- the same factorisation through the FRONT tables (front_plan.hpp), the way k_front_pieces / k_front_tail walk them: the blob of a
+    #      workgroup -> row masks, (column, row) -> offset maps, child row maps; gather through relative indices; target tiles with their
+    #      sources from the AND of two row masks; dense lower-triangular update matrices
+    def front_group(self, p):
+        """decode the blob of piece p"""
+        fg = self.fgrp[p]
+        W = self.fblob[fg["blob"]:fg["blob"] + fg["words"]]
+        G = {"ncomp": int(W[0] & 255), "nlv": int((W[0] >> 8) & 255), "nchild": int(W[0] >> 16), "nc": int(W[1] & 0xFFFF), "nb": int(W[1] >> 16),
+             "ntile": int(W[2] & 0xFFFFF), "n1": int(W[9] & 0xFFFF), "n2": int(W[9] >> 16), "nmore": int(W[2] >> 20)}
+        G["multi"] = [(int(e[0] & 0xFFFF), int(e[0] >> 16), int(e[1] & 255), int((e[1] >> 8) & 255), int(e[1] >> 16))
+                      for e in W[int(W[8]):int(W[8]) + 2 * (G["n1"] + G["n2"] + G["nmore"])].reshape(-1, 2)]      # (block, child, row index, column index, rank)
+        iw = W[int(W[10]):int(W[10]) + (int(W[11]) + 1) // 2]
+        G["items"] = [int(v) for v in np.stack([iw & 0xFFFF, iw >> 16], 1).ravel()[:int(W[11])]]        # gather items: block << 1 | half
+        w_cols, w_blk, w_lv, w_tile, w_child = [int(v) for v in W[3:8]]
+        comps = []
+        for q in range(G["ncomp"]):
+            c = W[12 + 8 * q:20 + 8 * q]
+            nc, nR, T, nch = int(c[0] & 255), int((c[0] >> 8) & 255), int((c[0] >> 16) & 255), int(c[0] >> 24)
+            p6 = int(c[5]) | (int(c[6]) << 32)
+            bt = W[int(c[3]):int(c[3]) + 2 * nR].reshape(nR, 2)
+            comps.append({"nc": nc, "nR": nR, "T": T, "nch": nch, "ubase": int(c[1]), "usize": int(c[2]), "child0": int(c[4] & 0xFFFF), "tcum": int(c[4] >> 16),
+                          "p6": p6, "dbase": int(c[7]), "tags": [int(e[0] >> 25) | (int(e[1] >> 24) << 7) for e in bt],
+                          "bt": [(int(e[0] & 255), int((e[0] >> 8) & 255), int((e[0] >> 16) & 255), int((e[0] >> 24) & 1), int(e[1] & 0xFFFFFF)) for e in bt]})
+        cols = [(int(c[0] & 0xFFFF), int(c[0] >> 16), int(c[1] & 255), int((c[1] >> 8) & 255), int((c[1] >> 16) & 1), int(c[1] >> 24), int(c[2]))
+                for c in W[w_cols:w_cols + 4 * G["nc"]].reshape(-1, 4)]      # (diag offset, y offset, component, local column, dim6, level, xoff)
+        G["colblk"] = [(int(c[3] & 0x3FFF), int((c[3] >> 14) & 255), int(c[3] >> 22)) for c in W[w_cols:w_cols + 4 * G["nc"]].reshape(-1, 4)]   # (first block, blocks, internal off-diagonal blocks)
+        braw = W[w_blk:w_blk + 4 * G["nb"]].reshape(-1, 4)
+        blks = [(int(np.int32(b[0])), int(b[1] & 0xFFFF), int((b[1] >> 16) & 63), int((b[1] >> 22) & 255), int((b[1] >> 30) & 1), int(b[1] >> 31))
+                for b in braw]                                                # (src, L offset, local row, column, fmt, diag)
+        G["bsrc"] = [(int(b[2] & 255), int((b[2] >> 8) & 63), int((b[2] >> 14) & 63), int(b[2] >> 20)) for b in braw]   # first child source (child, row, column index), sources
+        G["binfo"] = [(int(b[3] & 255), int((b[3] >> 8) & 255), int((b[3] >> 16) & 1), int((b[3] >> 17) & 1)) for b in braw]   # (component, local column, rows == 6, columns == 6)
+        lvs = [(int(l[0] & 0xFFFF), int(l[0] >> 16), int(l[1]), int(l[2]), int(l[3] & 0xFFFF), int(l[3] >> 16)) for l in W[w_lv:w_lv + 4 * G["nlv"]].reshape(-1, 4)]
+        tw = W[w_tile:w_tile + (G["ntile"] + 1) // 2]
+        tiles = np.stack([tw & 0xFFFF, tw >> 16], 1).ravel()[:G["ntile"]] if G["ntile"] else np.zeros(0, np.uint32)
+        children = []
+        for ch in range(G["nchild"]):
+            h = W[w_child + 4 * ch:w_child + 4 * ch + 4]
+            nRd = int(h[2] & 255)
+            bt = W[int(h[3]):int(h[3]) + 2 * nRd].reshape(nRd, 2)
+            children.append({"ubase": int(h[0]), "usize": int(h[1]), "nR": nRd, "comp": int((h[2] >> 8) & 255), "idx": int(h[2] >> 16),
+                             "tags": [int(e[0] >> 25) | (int(e[1] >> 24) << 7) for e in bt],
+                             "bt": [(int(e[0] & 255), int((e[0] >> 8) & 255), int((e[0] >> 16) & 255), int((e[0] >> 24) & 1), int(e[1] & 0xFFFFFF)) for e in bt]})
+        G.update(comps=comps, cols=cols, blks=blks, lvs=lvs, tiles=tiles, children=children)
+        return G
+
+    @staticmethod
+    def _u_off(bt, a, b2, di):
+        """offset of block (a, b2) of an update matrix with boundary table bt (front_u_offset)"""
+        return bt[a][4] + bt[b2][1] * 6 * di + bt[b2][2] * (18 if di == 6 else 10)
+
+    def factor_front(self, Hdev, bvec, lam, right=True):
+        """right: mid and tail pieces apply their internal updates by source column, the pairs of a column's blocks enumerated the way
+        front_piece<NT, true> does (what the kernels run); False: target tiles everywhere"""
+        assert self.front
+        Lval = np.zeros(self.lnz + 64)
+        Uval = np.full(self.funz + 64, np.nan)
+        y = np.zeros(self.dim + 8)
+        ok = True
+        for p in self.piece_order():
+            ok &= self._factor_front_piece(p, Hdev, bvec, lam, Lval, Uval, y, right and int(self.piece[p]["pad5"]) >= 1)
+        self.Uval_front = Uval
+        return Lval, y, ok
+
+    def _factor_front_piece(self, p, Hdev, bvec, lam, Lval, Uval, y, right=False):
+        pm = self.piece[p]
+        G = self.front_group(p)
+        lbase, y0 = int(pm["lbase"]), int(pm["y0"])
+        assert G["nc"] == pm["nc"] and G["nb"] == pm["nb"] and G["nlv"] == pm["nilv"]
+        smL = np.zeros(pm["lsize"]); smY = np.zeros(pm["ysize"])
+        comps, cols, blks = G["comps"], G["cols"], G["blks"]
+        dim = lambda cp, r: 6 if (cp["p6"] >> r) & 1 else 3
+        # derived tables
+        tc_ = 0
+        for q, cp in enumerate(comps):
+            assert cp["tcum"] == tc_ and all(t == q for t in cp["tags"])
+            tc_ += cp["T"] * (cp["T"] + 1) // 2
+        for ci, ch in enumerate(G["children"]):
+            assert all(t == ci for t in ch["tags"]) and comps[ch["comp"]]["child0"] + ch["idx"] == ci
+        for cp in comps:
+            NR = cp["nc"] + cp["nR"]
+            assert NR <= 64
+            cp["rw"] = [0] * NR; cp["map"] = {}; cp["ycol"] = [None] * cp["nc"]; cp["inv"] = []
+            cp["trow"] = []
+            for a, e in enumerate(cp["bt"]):
+                assert len(cp["trow"]) == 2 * e[1] + e[2]
+                cp["trow"] += [(a, 0), (a, 1)] if e[3] else [(a, 0)]
+            assert len(cp["trow"]) == cp["T"]
+        for ch in G["children"]:
+            cp = comps[ch["comp"]]
+            assert ch["idx"] == len(cp["inv"])
+            inv = {}
+            for q, e in enumerate(ch["bt"]):
+                inv[e[0]] = q
+            cp["inv"].append((inv, ch))
+        for gc, c in enumerate(cols):
+            comps[c[2]]["ycol"][c[3]] = c[1]
+        for (src, off, lr, gc, fmt, diag) in blks:
+            cp = comps[cols[gc][2]]; kc = cols[gc][3]
+            cp["map"][(kc, lr)] = off
+            if not diag:
+                cp["rw"][lr] |= 1 << kc
+            else:
+                assert lr == kc and off == cols[gc][0]
+        # gather
+        multi_seen = []
+        for bi, (src, off, lr, gc, fmt, diag) in enumerate(blks):
+            c = cols[gc]; cp = comps[c[2]]; kc = c[3]
+            di, dj = dim(cp, lr), 6 if c[4] else 3
+            assert dj == dim(cp, kc)
+            assert G["binfo"][bi] == (c[2], kc, int(di == 6), int(dj == 6))
+            hits = [(k, inv[lr], inv[kc]) for k, (inv, ch) in enumerate(cp["inv"]) if lr in inv and kc in inv]     # the plan names the first child source
+            f, qa, qb, ns = G["bsrc"][bi]
+            assert ns == min(len(hits), 255) and (not hits or (f, qa, qb) == hits[0])
+            multi_seen += [(bi, k, a_, b_, r + 1) for r, (k, a_, b_) in enumerate(hits)]
+            v = np.zeros((di, dj))
+            if src >= 0:
+                raw = Hdev[src:src + di * dj]
+                v = raw.reshape(dj, di).T.copy() if fmt else raw.reshape(di, dj).copy()
+            rhs = None
+            if diag:
+                v += lam * np.eye(dj)
+                rhs = bvec[c[6]:c[6] + dj].copy()
+            for inv, ch in cp["inv"]:
+                if lr in inv and kc in inv:
+                    qa, qb = inv[lr], inv[kc]
+                    assert qa >= qb
+                    o = ch["ubase"] + self._u_off(ch["bt"], qa, qb, di)
+                    blk = Uval[o:o + di * dj].reshape(di, dj).copy()
+                    if diag and di == 6:
+                        blk[0:3, 3:6] = 0.0        # the upper right tile of a diagonal block is never written (nor used: the factor reads the lower triangle)
+                    assert not np.isnan(blk).any()
+                    v -= blk
+                    if diag:
+                        uy = Uval[ch["ubase"] + ch["usize"] + 6 * qa:ch["ubase"] + ch["usize"] + 6 * qa + dj]
+                        assert not np.isnan(uy).any()
+                        rhs -= uy
+            if diag:
+                smY[c[1]:c[1] + dj] = rhs
+            smL[off:off + di * dj] = v.ravel()
+        assert sorted(G["multi"], key=lambda e: (e[4], e[0])) == G["multi"] and sorted(G["multi"]) == sorted(multi_seen)      # the listed further sources: exactly these
+        assert G["n1"] == sum(1 for e in G["multi"] if e[4] == 1) and G["n2"] == sum(1 for e in G["multi"] if e[4] == 2) and pm["graph"] == self.fgrp[p]["graph"]
+        assert G["items"] == [(bi << 1) | h for bi, (src, off, lr, gc, fmt, diag) in enumerate(blks) for h in range(dim(comps[cols[gc][2]], lr) // 3)]
+        for gc, (cb0, nblk, mi) in enumerate(G["colblk"]):
+            assert blks[cb0][5] and blks[cb0][3] == gc and all(blks[cb0 + k][3] == gc for k in range(nblk))
+            ncq = comps[cols[gc][2]]["nc"]
+            assert mi == sum(1 for k in range(1, nblk) if blks[cb0 + k][2] < ncq) and all(blks[cb0 + k][2] < ncq for k in range(1, mi + 1))
+
+        def tile_sum(cp, li, lj, di, dj, tr, tc, want_y):
+            m = cp["rw"][lj] if li == lj else cp["rw"][li] & cp["rw"][lj]
+            acc = np.zeros((3, 3)); accy = np.zeros(3)
+            k = 0
+            while m >> k:
+                if (m >> k) & 1:
+                    dk = dim(cp, k)
+                    ua, ub, yk = cp["map"][(k, li)], cp["map"][(k, lj)], cp["ycol"][k]
+                    A = smL[ua:ua + di * dk].reshape(di, dk)[3 * tr:3 * tr + 3]
+                    Bm = smL[ub:ub + dj * dk].reshape(dj, dk)[3 * tc:3 * tc + 3]
+                    acc += A @ Bm.T
+                    if want_y:
+                        accy += A @ smY[yk:yk + dk]
+                k += 1
+            return acc, accy, m
+
+        ok = True
+        for (b0, b1, t0, t1, c0, c1) in G["lvs"]:
+            for e in (G["tiles"][t0:t1] if not right else []):
+                b, tr, tc = int(e) >> 2, (int(e) >> 1) & 1, int(e) & 1
+                (src, off, lr, gc, fmt, diag) = blks[b]
+                assert b0 <= b < b1 and c0 <= gc < c1
+                c = cols[gc]; cp = comps[c[2]]; kc = c[3]
+                di, dj = dim(cp, lr), dim(cp, kc)
+                assert 3 * tr < di and 3 * tc < dj and not (diag and tc > tr)
+                acc, accy, m = tile_sum(cp, lr, kc, di, dj, tr, tc, bool(diag) and tc == 0)
+                assert m
+                T = smL[off:off + di * dj].reshape(di, dj)
+                T[3 * tr:3 * tr + 3, 3 * tc:3 * tc + 3] -= acc
+                if diag and tc == 0:
+                    smY[c[1] + 3 * tr:c[1] + 3 * tr + 3] -= accy
+            # every tile of the level that has sources must be in the list
+            for b in range(b0, b1):
+                (src, off, lr, gc, fmt, diag) = blks[b]
+                cp = comps[cols[gc][2]]; kc = cols[gc][3]
+                m = cp["rw"][kc] if diag else cp["rw"][lr] & cp["rw"][kc]
+                listed = any((int(e) >> 2) == b for e in G["tiles"][t0:t1])
+                assert bool(m) == listed
+            for gc in range(c0, c1):
+                c = cols[gc]; d = 6 if c[4] else 3; o = c[0]
+                S = smL[o:o + d * d].reshape(d, d)
+                S = np.tril(S) + np.tril(S, -1).T
+                try:
+                    Lj = np.linalg.cholesky(S)
+                except np.linalg.LinAlgError:
+                    ok = False
+                    Lj = np.eye(d)
+                smL[o:o + d * d] = Lj.ravel()
+                smY[c[1]:c[1] + d] = np.linalg.solve(Lj, smY[c[1]:c[1] + d])
+            for b in range(b0, b1):
+                (src, off, lr, gc, fmt, diag) = blks[b]
+                if diag:
+                    continue
+                c = cols[gc]; cp = comps[c[2]]
+                di, dj = dim(cp, lr), 6 if c[4] else 3
+                Lj = smL[c[0]:c[0] + dj * dj].reshape(dj, dj)
+                Vb = smL[off:off + di * dj].reshape(di, dj)
+                smL[off:off + di * dj] = np.linalg.solve(Lj, Vb.T).T.ravel()
+            if right:   # a finished column updates every later block of its piece: pairs (p >= q) of its off-diagonal blocks, block q's row inside the component
+                for gc in range(c0, c1):
+                    cb0, nblk, mi = G["colblk"][gc]
+                    c = cols[gc]; cp = comps[c[2]]; dk = 6 if c[4] else 3; m = nblk - 1
+                    npair = mi * m - mi * (mi - 1) // 2
+                    seen = 0
+                    for q in range(mi):
+                        for pp in range(q, m):
+                            assert seen == q * m - q * (q - 1) // 2 + (pp - q)     # the numbering the kernel inverts
+                            seen += 1
+                            (_, offa, li, _, _, _), (_, offb, lj, _, _, _) = blks[cb0 + 1 + pp], blks[cb0 + 1 + q]
+                            di, dj = dim(cp, li), dim(cp, lj)
+                            A = smL[offa:offa + di * dk].reshape(di, dk); Bm = smL[offb:offb + dj * dk].reshape(dj, dk)
+                            to = cp["map"][(lj, li)]
+                            T = smL[to:to + di * dj].reshape(di, dj)
+                            upd = A @ Bm.T
+                            if pp == q and di == 6:
+                                upd[0:3, 3:6] = 0.0     # the upper right tile of a diagonal target is never touched
+                            T -= upd
+                            if pp == q:
+                                yo = cp["ycol"][lj]
+                                smY[yo:yo + dj] -= A @ smY[c[1]:c[1] + dk]
+                    assert seen == npair
+        # update matrices: dense lower triangle over the boundary rows, tile by tile
+        for cp in comps:
+            nc = cp["nc"]
+            for pi in range(cp["T"]):
+                for qi in range(pi + 1):
+                    (ia, tra), (ib, trb) = cp["trow"][pi], cp["trow"][qi]
+                    li, lj = nc + ia, nc + ib
+                    di, dj = dim(cp, li), dim(cp, lj)
+                    diag = ia == ib
+                    acc, accy, _ = tile_sum(cp, li, lj, di, dj, tra, trb, diag and trb == 0)
+                    for inv, ch in cp["inv"]:
+                        if li in inv and lj in inv:
+                            qa, qb = inv[li], inv[lj]
+                            o = ch["ubase"] + self._u_off(ch["bt"], qa, qb, di)
+                            blk = Uval[o:o + di * dj].reshape(di, dj)[3 * tra:3 * tra + 3, 3 * trb:3 * trb + 3]
+                            assert not np.isnan(blk).any()
+                            acc += blk
+                            if diag and trb == 0:
+                                accy += Uval[ch["ubase"] + ch["usize"] + 6 * qa + 3 * tra:ch["ubase"] + ch["usize"] + 6 * qa + 3 * tra + 3]
+                    o = cp["ubase"] + self._u_off(cp["bt"], ia, ib, di)
+                    blk = Uval[o:o + di * dj].reshape(di, dj)       # a view: writes go through
+                    blk[3 * tra:3 * tra + 3, 3 * trb:3 * trb + 3] = acc
+                    if diag and trb == 0:
+                        Uval[cp["ubase"] + cp["usize"] + 6 * ia + 3 * tra:cp["ubase"] + cp["usize"] + 6 * ia + 3 * tra + 3] = accy
         Lval[lbase:lbase + pm["lsize"]] = smL
         y[y0:y0 + pm["ysize"]] = smY
         return ok
