@@ -183,9 +183,11 @@ struct CholOpts {
                            // matrices, five levels more: throughput -- measured 9.30 vs 9.48 ms per 512 factorisations)
   int order_bits_max = 2048;   // graphs up to this many nodes are ordered on adjacency bitsets (same order, a fraction of the time); 0: never
   bool dump = false;
-  int front = -1;          // front tables (front_plan.hpp: one blob of relative indices per workgroup, kernels k_front_*): -1: for batches >= 32
-                           // (the per-depth launches), 0: never, 1: build them for every plan (the dependency-driven launches of small batches
-                           // still run the record plan)
+  int front = -1;          // front tables (front_plan.hpp: one blob of relative indices per workgroup; front_kernels.hpp): 1: built, and every
+                           // factorisation -- per-depth launches and the dependency-driven launches alike -- runs through them; 0: the record
+                           // kernels (chol_piece); -1: 1 for batches >= 32, else 0.  Measured (round 6): 512 L graphs 7.85 vs 8.0 ms per
+                           // factorisation with a fifth of the table bytes; the orchestrator's tick (latency-bound: the LDS digest of the blob
+                           // sits on the chain of pieces) 5.53-5.70 vs 5.27-5.30 ms at 110 keyframes, 8.0 vs 7.64 at 436 -> record kernels there
   int flow = 1;            // small batches: 0 a launch per depth; 1 the dependency-driven single launch (k_chol_flow) when the tree is narrower than its
                            // grid; 2 also on wide trees (per-depth launches for the bottom, measured slower: tests only)
   // SSLAM_CHOL_OPTS="key=value,key=value,...": every plan option above by its field name (tests force the piece shapes of a 5000-pose graph

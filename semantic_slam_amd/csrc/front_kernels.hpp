@@ -92,7 +92,8 @@ __device__ __forceinline__ bool front_factor6(double (&a)[36], double (&tv)[6], 
 
 #define SSLAM_FSTAMP(k) if (dbg) { const long long now_ = clock64(); if (threadIdx.x == 0) dbg[k] += now_ - tprev; tprev = now_; }
 template <int NT, bool RIGHT>
-__device__ __forceinline__ void front_piece(const BatchView& V, const CholView& C, const PieceMeta pm, const FrontGrp fg, double* sm, long long* dbg = nullptr) {
+__device__ __forceinline__ void front_piece(const BatchView& V, const CholView& C, const PieceMeta pm, const FrontGrp fg, double* sm, long long* dbg = nullptr,
+                                            const int* wait_p = nullptr, int wait_target = 0, int* wait_err = nullptr) {
   long long tprev = dbg ? clock64() : 0;
   const int tid = threadIdx.x;
   const int g = fg.graph;
@@ -172,6 +173,15 @@ __device__ __forceinline__ void front_piece(const BatchView& V, const CholView& 
   double m2[6], m2y = 0;
   {
     bool derived = false;
+    if (wait_p) {
+      // dependency-driven launches (k_chol_flow, k_chol_spec_round): the tables are in LDS and digested BEFORE the wait for the child pieces -- only
+      // the gather itself (the children's update-matrix blocks) follows it
+      derive();
+      derived = true;
+      __syncthreads();
+      if (tid == 0) flow_wait(wait_p, wait_target, wait_err, C.fail + g);
+      __syncthreads();
+    }
     auto gather = [&](auto KGc, auto SRCc) {
       constexpr int KG = decltype(KGc)::value;
       constexpr bool SRC = decltype(SRCc)::value;
@@ -216,7 +226,7 @@ __device__ __forceinline__ void front_piece(const BatchView& V, const CholView& 
             uyv[g2] = U[(on && dg) ? cc.ubase + cc.usize + 6 * qa + rw : 0];
           }
         }
-        if (!derived) {
+        if (t0 == tid) {
           // second child sources of the piece's blocks (a few per group; one (block, row) per thread): their loads travel with the main ones
           if (SRC && n2 > 0) {
             const int t = min(tid, min(n2, NT / 6) * 6 - 1);
@@ -230,8 +240,7 @@ __device__ __forceinline__ void front_piece(const BatchView& V, const CholView& 
             for (int c = 0; c < 6; ++c) m2[c] = pu[min(c, dj - 1)];
             m2y = U[cc.ubase + cc.usize + 6 * (int)(me.y & 255) + rw];
           }
-          derive();
-          derived = true;
+          if (!derived) { derive(); derived = true; }
         }
 #pragma unroll
         for (int g2 = 0; g2 < KG; ++g2) {

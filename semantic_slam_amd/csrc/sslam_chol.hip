@@ -1448,6 +1448,10 @@ __device__ __forceinline__ bool flow_wait(const int* p, int target, int* err, in
   }
   return true;
 }
+}  // namespace sslam
+#include "front_kernels.hpp"
+namespace sslam {
+
 template <int NT, bool USTAGE>
 __global__ __launch_bounds__(NT) void k_chol_flow(BatchView V, CholView C, int q_first, int np, int epoch, const int2* __restrict__ dep, int* flow, SpecLanes SL,
                                                   int do_backward, double* __restrict__ part_e, int max_iters, int lm_epoch) {
@@ -1496,7 +1500,11 @@ __global__ __launch_bounds__(NT) void k_chol_flow(BatchView V, CholView C, int q
       if (tid == 0) flow_wait(child_done + q, d.y * epoch, err, C.fail + pm.graph);
       __syncthreads();
     }
-    if (run) {
+    if (run && C.fblob) {   // front tables (front_kernels.hpp): tables before the wait whenever the piece waits
+      const int* wp = (d.y > 0 && defer) ? child_done + q : nullptr;
+      if (q >= C.ltail0) front_piece<NT, true>(V, C, pm, C.lfgrp[q], sm, nullptr, wp, d.y * epoch, err);
+      else front_piece<NT, false>(V, C, pm, C.lfgrp[q], sm, nullptr, wp, d.y * epoch, err);
+    } else if (run) {
       const int* wp = d.y > 0 ? child_done + q : nullptr;
       if (defer) {
         if (q >= C.ltail0) {
@@ -1592,7 +1600,10 @@ __global__ __launch_bounds__(NT) void k_chol_spec_round(BatchView V, CholView C,
     const PieceMeta pm = C.lpiece[q];
     const int2 d = dep[q];
     const int* wp = d.y > 0 ? child_done + q : nullptr;
-    if (q >= C.ltail0) {
+    if (C.fblob) {
+      if (q >= C.ltail0) front_piece<NT, true>(V, C, pm, C.lfgrp[q], sm, nullptr, wp, d.y * epoch, err);
+      else front_piece<NT, false>(V, C, pm, C.lfgrp[q], sm, nullptr, wp, d.y * epoch, err);
+    } else if (q >= C.ltail0) {
       if (C.rupd) chol_piece<NT, false, true, true>(V, C, pm, sm, nullptr, wp, d.y * epoch, err);
       else chol_piece<NT, false, false, true>(V, C, pm, sm, nullptr, wp, d.y * epoch, err);
     } else chol_piece<NT, USTAGE, false, true>(V, C, pm, sm, nullptr, wp, d.y * epoch, err);
@@ -1650,10 +1661,6 @@ __global__ void k_chol_end(BatchView V, CholView C) {  // publish failures throu
   const int g = blockIdx.x * blockDim.x + threadIdx.x;
   if (g < V.B && V.lm[g].in_trial) V.pcg_fail[g] = C.fail[g];
 }
-
-}  // namespace sslam
-#include "front_kernels.hpp"
-namespace sslam {
 
 // ------------------------------------------------------------------------------------------------
 // host

@@ -28,6 +28,7 @@ def _internal_order(gp):
 def _plan_and_system(hip_lib, g, interleave, env=None):
     from semantic_slam_amd import GraphSLAM
     old = {}
+    env = dict({"front": 1}, **(env or {}))   # the front tables (front_plan.hpp) ride along with every plan of these tests: _check walks them too
     env = {"SSLAM_CHOL_OPTS": ",".join(f"{k}={v}" for k, v in env.items())} if env else {}   # plan options by field name (chol_plan.hpp CholOpts)
     for k, v in env.items():
         old[k] = os.environ.get(k); os.environ[k] = str(v)
@@ -71,6 +72,13 @@ def _check(plan, H, b, lam):
         assert okr
         assert np.abs(Lr - Lval).max() <= 1e-10 * max(np.abs(Lval).max(), 1e-30)
         assert np.abs(yr[:plan.dim] - y[:plan.dim]).max() <= 1e-9 * max(np.abs(yref).max(), 1e-30)
+    if plan.front:   # the same pieces through the front tables (one blob of relative indices per workgroup): the walk of k_front_pieces / k_front_tail
+        assert plan.funz == plan.unz                     # dense lower triangles over the boundary rows: what the record plan allocates block by block
+        for right in (True, False):                      # right-looking mid / tail pieces (what the kernels run) and target tiles everywhere
+            Lf, yf, okf = plan.factor_front(Hdev, b, lam, right=right)
+            assert okf
+            assert np.abs(Lf - Lval).max() <= 1e-10 * max(np.abs(Lval).max(), 1e-30)
+            assert np.abs(yf[:plan.dim] - y[:plan.dim]).max() <= 1e-9 * max(np.abs(yref).max(), 1e-30)
     return Lval
 
 
@@ -178,7 +186,7 @@ def test_mid_class_pieces_between_the_bottom_and_the_tail(hip_lib):
     per depth next to the leaf pieces of that depth); their internal updates come as right-looking lists like the tail's.  Fewer, larger
     pieces there, less update-matrix storage, same factor."""
     g = make_graph(600, 120, seed=3)
-    base = {"tail_width": 2, "cap_leaf": 500, "mid_width": 0}
+    base = {"tail_width": 2, "cap_leaf": 500, "mid_width": 0, "flow": 0}   # (flow = 0: not the single-launch regime, which has no mid class and one workgroup size)
     p0, H0, b0 = _plan_and_system(hip_lib, g, False, base)
     assert not np.any(p0.piece["pad5"] == 1) and not np.any(p0.plv_cls == 1)
     p1, H1, b1 = _plan_and_system(hip_lib, g, False, dict(base, mid_width=12, cap_mid=1600))
@@ -206,7 +214,7 @@ def test_multi_graph_batch_plan_with_groups_mid_and_tail(hip_lib):
     from semantic_slam_amd import GraphSLAM
     gs = [make_graph(40 + 5 * k, 8 + k, seed=70 + k) for k in range(6)]
     gps = [GraphProblem.from_synth(g, interleave=bool(k & 1)) for k, g in enumerate(gs)]
-    os.environ["SSLAM_CHOL_OPTS"] = "nt_leaf=128,group_cap=600,cap_leaf=150,mid_width=3,cap_mid=400,tail_width=1"
+    os.environ["SSLAM_CHOL_OPTS"] = "nt_leaf=128,group_cap=600,cap_leaf=150,mid_width=3,cap_mid=400,tail_width=1,front=1"
     try:
         plan = Plan(hip_lib, [GraphSLAM.from_problem(gp) for gp in gps])
     finally:
@@ -237,6 +245,27 @@ def test_multi_graph_batch_plan_with_groups_mid_and_tail(hip_lib):
     for Hg, b, w in zip(Hs, bs, where):
         H[np.ix_(w, w)] = Hg; bb[w] = b
     _check(plan, H, bb, 1e-3)
+
+
+def test_front_tables_are_a_fraction_of_the_record_tables(hip_lib):
+    """Round 6: the front tables of the throughput plan (batch regime forced onto one 600-pose graph): every piece has its blob, the blobs tile
+    fblob in 16-byte pieces, the tables are a fraction of the record plan's, the LDS a workgroup needs does not grow, and a plan whose
+    pieces the packed tables cannot hold (more than two columns per 8-lane team of a level) reports why and keeps the record kernels."""
+    g = make_graph(600, 120, seed=11)
+    env = {"nt_leaf": 128, "group_cap": 2800, "cap_leaf": 700, "mid_width": 60, "tail_width": 6, "order_mul": 1.5, "order_add": 2, "ustage": 0, "flow": 0}
+    plan, H, b = _plan_and_system(hip_lib, g, True, env)
+    assert plan.front and len(plan.fgrp) == plan.npiece
+    fg = plan.fgrp
+    order = np.argsort(fg["blob"])
+    assert fg["blob"][order[0]] == 0 and np.all(fg["blob"][order][1:] == (fg["blob"] + fg["words"])[order][:-1]) and np.all(fg["words"] % 4 == 0)
+    assert int((fg["blob"] + fg["words"]).max()) == len(plan.fblob) and np.all(fg["graph"] == plan.piece["graph"])
+    record_bytes = sum(a.nbytes for a in (plan.blk, plan.col, plan.upd, plan.item, plan.uitem, plan.asrc, plan.usrc, plan.ilv, plan.mb, plan.umb, plan.rupd, plan.piece))
+    assert 4 * len(plan.fblob) < 0.35 * record_bytes
+    assert np.all(plan.plv_lds_ff <= plan.plv_lds_f + 128)      # LDS doubles per launch: residency is LDS-bound
+    _check(plan, H, b, 1e-3)
+    G = plan.front_group(int(plan.plv_pieces[0]))
+    assert G["ncomp"] >= 2 and G["nchild"] == 0                  # a group of leaf pieces of the bottom depth: several components, no children
+    assert any(plan.front_group(p)["n2"] > 0 for p in range(plan.npiece))     # blocks with a second child source exist (the rank lists are exercised)
 
 
 def test_parent_links_and_both_orderings_factor(hip_lib):

@@ -659,6 +659,28 @@ def test_single_launch_solve_and_fused_steps_equal_the_stand_alone_kernels(gpu_l
         gp = GraphProblem.from_synth(g, interleave=True)   # gp.optimize moved the estimates: fresh problem for the next size
 
 
+def test_front_tables_through_every_launch_form(gpu_lib):
+    """Round 6: the front tables (csrc/front_plan.hpp, front_kernels.hpp -- one blob of relative indices per workgroup, dense update matrices,
+    team-factored diagonal blocks) are the default of batches >= 32 (covered by the batch tests against the oracle); forced onto a single small
+    graph (front=1) they also run inside the dependency-driven launches: k_chol_flow, the speculative lanes, and a launch per depth.  Same
+    iteration and trial counts as the record kernels, chi2 / estimates equal to the oracle's; bitwise repeatable."""
+    for (n, m, kind, iters) in [(120, 24, "point", 30), (80, 16, "plane", 12), (300, 60, "point", 10)]:
+        g = make_graph(n, m, seed=13, landmark_kind=kind)
+        gp = GraphProblem.from_synth(g, interleave=True)
+        rec = _optimize_variant(gp, iters, {"front": 0}, 1, spec=0)
+        fs = _optimize_variant(gp, iters, {"front": 1}, 1, spec=1)       # speculative lanes (k_chol_spec_round)
+        fa = _optimize_variant(gp, iters, {"front": 1}, 1, spec=0)       # k_chol_flow with the LM halves
+        fa2 = _optimize_variant(gp, iters, {"front": 1}, 1, spec=0)
+        fc = _optimize_variant(gp, iters, {"front": 1, "flow": 0}, 0)    # a launch per depth (k_front_pieces / k_front_tail)
+        assert fa[:3] == fa2[:3] and np.array_equal(fa[3], fa2[3])
+        assert fs[:3] == fa[:3] and np.array_equal(fs[3], fa[3]), (fs[:3], fa[:3])
+        st = gp.optimize(iters)
+        for r in (rec, fa, fc):
+            assert r[0] == st.iterations
+            assert abs(r[2] - st.chi2_after) <= 1e-8 * st.chi2_after
+            assert np.abs(r[3] - gp.est).max() <= 1e-5 * np.abs(gp.est).max()
+
+
 def test_single_launch_solve_on_the_L_graph_and_a_small_batch(gpu_lib):
     """k_chol_flow with more pieces than workgroups (one 5000-pose graph: ~1500 pieces over a persistent grid) and on a batch of four
     distinct graphs: same chi2 / estimates as the launch-per-depth path up to rounding."""
