@@ -31,13 +31,14 @@ PEAK_HBM_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E ~8 TB/s
 def pmc_traffic(name, algorithmic_bytes):
     """HBM bytes per launch from the committed PMC passes (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs,
     FETCH x2 on gfx950 per MI355X_MICROARCH.md); only quoted when the profiled workload had the same algorithmic bytes."""
-    for rnd in ("r5", "r4", "r3", "r2", "r1"):
+    for rnd in ("r6", "r5", "r4", "r3", "r2", "r1"):
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", f"{rnd}_pmc_{name}.json")))
         except (OSError, ValueError):
             continue
         if int(pmc.get("algorithmic_bytes", -1)) == int(algorithmic_bytes):
-            return int(pmc["hbm_bytes_fetch_x2"]), int(pmc["hbm_bytes_raw"]), f"profiles/{rnd}_pmc_{name}.json"
+            at = pmc.get("collected_at_commit")     # stamped when the summary was committed (the GPU box has no .git)
+            return int(pmc["hbm_bytes_fetch_x2"]), int(pmc["hbm_bytes_raw"]), f"profiles/{rnd}_pmc_{name}.json" + (f" (collected at commit {at})" if at else "")
     return None, None, None
 
 
@@ -582,6 +583,12 @@ def main():
     }
     if roof_factor is not None:
         out["roofline_factor"] = roof_factor
+    if sharded:
+        # evidence that RCCL saw `world` ranks: the all-reduce calls this rank issued inside the LM loop and what each of them summed
+        out["collective"] = {"backend": "rccl (ncclAllReduce, ncclDouble, sum, out of place)", "world": world,
+                             "allreduce_calls": int(batch.info("allreduce_calls")),
+                             "bytes_per_call": int(8 * (batch.info("h_doubles") + batch.info("dim"))),
+                             "note": "one call per Jacobian build of the batch: [H || b] of every graph, rank-partial buffer -> full system"}
     del batch
 
     frontend = None

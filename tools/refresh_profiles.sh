@@ -1,7 +1,7 @@
 #!/bin/bash
 # Re-measure what the round's profiles/ hold.  Run on the GPU box: gpurun -- 'bash tools/refresh_profiles.sh [sections]'
 # sections (default "tests bench stats pmc frontend trace"): tests bench stats pmc frontend trace tick smoke
-# Writes gpurun_out/refresh/r5_*; copy the ones to be judged into profiles/.
+# Writes gpurun_out/refresh/r6_*; copy the ones to be judged into profiles/.
 set -u
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/refresh; mkdir -p $O
@@ -10,20 +10,20 @@ SECTIONS="${*:-tests bench stats pmc frontend trace}"
 has() { [[ " $SECTIONS " == *" $1 "* ]]; }
 DRV="--gpus 1 --steps 20 --warmup 5"
 if has tests; then
-  python -m pytest $R/tests -m gpu -q > $O/r5_pytest_gpu.txt 2>&1; tail -3 $O/r5_pytest_gpu.txt
+  python -m pytest $R/tests -m gpu -q > $O/r6_pytest_gpu.txt 2>&1; tail -3 $O/r6_pytest_gpu.txt
 fi
 if has bench; then
-  python $R/bench.py $DRV > $O/bench_stdout.txt 2> $O/bench_stderr.txt; tail -1 $O/bench_stdout.txt > $O/r5_bench.json; cut -c1-400 $O/r5_bench.json
+  python $R/bench.py $DRV > $O/bench_stdout.txt 2> $O/bench_stderr.txt; tail -1 $O/bench_stdout.txt > $O/r6_bench.json; cut -c1-400 $O/r6_bench.json
 fi
 if has stats; then
   # kernel stats of the pass the rooflines come from: one batch-synchronous batch on one stream (--streams 1); in the stream-group
   # region the launches of four parts overlap on the chip and a per-launch duration says nothing about a kernel
   rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python $R/bench.py $DRV --streams 1 --no-cpu-baseline --no-frontend --no-single --plane-batch 0 > /dev/null 2>&1
-  cp $(ls $O/stats/*/*kernel_stats.csv | head -1) $O/r5_bench_kernel_stats.csv; head -12 $O/r5_bench_kernel_stats.csv | cut -c1-160
+  cp $(ls $O/stats/*/*kernel_stats.csv | head -1) $O/r6_bench_kernel_stats.csv; head -12 $O/r6_bench_kernel_stats.csv | cut -c1-160
   rm -rf $O/stats
 fi
 if has pmc; then
-  BJ=$O/r5_bench.json; [ -f $BJ ] || BJ=$R/profiles/r5_bench.json     # (a run without the bench section: the committed line)
+  BJ=$O/r6_bench.json; [ -f $BJ ] || BJ=$R/profiles/r6_bench.json     # (a run without the bench section: the committed line)
   FB=$(python -c "import json;print(json.load(open('$BJ'))['roofline_factor']['bytes_per_launch'])")
   JB=$(python -c "import json;print(json.load(open('$BJ'))['roofline_jacobian_build']['bytes_per_launch'])")
   # PMC traffic: one full-batch factorisation / Jacobian build of the SAME 512 distinct graphs (tools/pmc_workload.py), separate passes
@@ -33,9 +33,9 @@ if has pmc; then
       rocprofv3 --pmc $c --output-format csv -d $O/pmc_${w}_$c -- python $R/tools/pmc_workload.py 512 $w > /dev/null 2>&1
     done
     if [ $w = factor ]; then
-      python $R/tools/pmc_traffic.py $O/pmc_factor_FETCH_SIZE $O/pmc_factor_WRITE_SIZE $O/r5_pmc_factor.json $FB 0 k_chol_tail k_chol_pieces k_chol_begin k_chol_end
+      python $R/tools/pmc_traffic.py $O/pmc_factor_FETCH_SIZE $O/pmc_factor_WRITE_SIZE $O/r6_pmc_factor.json $FB 0 k_front_tail k_front_pieces k_chol_tail k_chol_pieces k_chol_begin k_chol_end
     else
-      python $R/tools/pmc_traffic.py $O/pmc_jacobian_FETCH_SIZE $O/pmc_jacobian_WRITE_SIZE $O/r5_pmc_jacobian_build.json $JB 0 k_linearize_rowthread k_linearize_lm_rows k_linearize_dups
+      python $R/tools/pmc_traffic.py $O/pmc_jacobian_FETCH_SIZE $O/pmc_jacobian_WRITE_SIZE $O/r6_pmc_jacobian_build.json $JB 0 k_linearize_rowthread k_linearize_lm_rows k_linearize_dups
     fi
   done
   rm -rf $O/pmc_*
@@ -43,15 +43,15 @@ fi
 if has frontend; then
   # per-kernel times of one batched frontend call (32 frames x 32 boxes)
   rocprofv3 --kernel-trace --stats --output-format csv -d $O/fstats -- python $R/tools/frontend_kernels.py > /dev/null 2>&1
-  cp $(ls $O/fstats/*/*kernel_stats.csv | head -1) $O/r5_frontend_kernel_stats.csv; head -14 $O/r5_frontend_kernel_stats.csv | cut -c1-140
+  cp $(ls $O/fstats/*/*kernel_stats.csv | head -1) $O/r6_frontend_kernel_stats.csv; head -14 $O/r6_frontend_kernel_stats.csv | cut -c1-140
   rm -rf $O/fstats
 fi
 if has trace; then
   # per-launch trace of one LM step of the 512-graph batch (which launches the factorisation is made of and what each takes)
   rm -rf $O/_p512
   rocprofv3 --kernel-trace --output-format csv -d $O/_p512 -- python $R/tools/prof_opt.py 512 2 > /dev/null 2>&1
-  python $R/tools/level_profile.py $O/_p512 > $O/r5_factor_launch_trace_512.txt; rm -rf $O/_p512
-  head -20 $O/r5_factor_launch_trace_512.txt | cut -c1-120
+  python $R/tools/level_profile.py $O/_p512 > $O/r6_factor_launch_trace_512.txt; rm -rf $O/_p512
+  head -20 $O/r6_factor_launch_trace_512.txt | cut -c1-120
 fi
 if has tick; then
   # kernel stats of the 110-keyframe tick replay (no CPU baseline inside the profiled process)
@@ -64,8 +64,8 @@ print(json.dumps({k: t[k] for k in ("keyframes", "ms_per_tick", "ms_per_tick_opt
 PY
   rm -rf $O/_tk
   rocprofv3 --kernel-trace --stats --output-format csv -d $O/_tk -- python /tmp/tick110.py > $O/tick_stdout.txt 2>&1
-  cp $(ls $O/_tk/*/*kernel_stats.csv | head -1) $O/r5_tick_kernel_stats.csv; rm -rf $O/_tk
-  tail -1 $O/tick_stdout.txt | cut -c1-200; head -6 $O/r5_tick_kernel_stats.csv | cut -c1-150
+  cp $(ls $O/_tk/*/*kernel_stats.csv | head -1) $O/r6_tick_kernel_stats.csv; rm -rf $O/_tk
+  tail -1 $O/tick_stdout.txt | cut -c1-200; head -6 $O/r6_tick_kernel_stats.csv | cut -c1-150
 fi
 if has smoke; then
   (cd $R && python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')") 2>&1 | tail -2
