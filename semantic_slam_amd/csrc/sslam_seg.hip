@@ -1502,36 +1502,56 @@ __global__ __launch_bounds__(256) void k_icp_accumulate(const float* __restrict_
 // float sums over the inliers IN INDEX ORDER: the points are walked 1024 at a time, every inlier gets its rank from wave ballots and
 // parks its nine products in LDS, nine lanes add them in rank order -- the arithmetic of oracle_seg.c's serial loop, bit for bit.
 struct RansacBox { float coeff[4]; int inliers, best_count, best_iter, hyps; };
+// Round 6: two kernels.  (PMC, profiles/r6_pmc_frontend.json: the one-kernel form spent 85 % of its wave cycles parked -- nine lanes added
+// the inliers' products one LDS round trip at a time while fifteen waves and a 147 KB crop waited, one box per CU.)
+//   k_ransac_hyp      one 1024-thread workgroup per box, the crop staged in LDS once.  A round draws up to sixteen samples (one wave each, lane
+//                     0, the counter hash of the single-cloud entry point), then ONE pass over the points scores all of them: a thread keeps the
+//                     round's models in registers and tests each of its points against every model -- three LDS reads per point instead of
+//                     three per point and hypothesis.  Thread 0 replays pcl::RandomSampleConsensus' adaptive loop over the counts in order and
+//                     stops where the sequential algorithm stops (rounds after the first draw eight samples: the scene's boxes stop at 17).
+//   k_ransac_refine   one 256-thread workgroup per box, eight per CU: optimizeModelCoefficients' float sums over the inliers IN INDEX ORDER
+//                     (ranks from wave ballots, nine products parked in LDS, nine lanes add them in rank order, sixteen loads in flight ahead of
+//                     the dependent adds) -- the arithmetic of oracle_seg.c's serial loop, bit for bit --, eigen33, then the inlier flags of the
+//                     refined model.  The chains of eight boxes overlap on a CU; the points come through L2.
 constexpr int kRsProd = 256;   // inlier products parked per round of the ordered sums
-__global__ __launch_bounds__(1024) void k_ransac_boxes(View V, float thr, int max_iterations, double probability, unsigned long long seed0,
-                                                       int lds_points, RansacBox* __restrict__ out, unsigned char* __restrict__ flag) {
+constexpr int kRsHyp = 16;     // hypotheses of the first round of a box (later rounds: kRsHyp / 2)
+__global__ __launch_bounds__(1024) void k_ransac_hyp(View V, float thr, int max_iterations, double probability, unsigned long long seed0,
+                                                     int lds_points, RansacBox* __restrict__ out) {
   extern __shared__ float sp[];
-  __shared__ float s_models[16][4];
-  __shared__ int s_cnt[16];
-  __shared__ float s_best[4], s_acc[9];
-  __shared__ int s_woff[17];
-  __shared__ int s_stop, s_best_n, s_best_it, s_it, s_total;
+  __shared__ float s_models[kRsHyp][4];
+  __shared__ int s_cnt[kRsHyp], s_ok[kRsHyp];
+  __shared__ float s_best[4];
+  __shared__ int s_stop, s_best_n, s_best_it, s_it;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const BoxMeta b = V.box[blockIdx.x];
   const int n = b.w * b.h;
   const float* gp = V.pts + (size_t)b.pix0 * 3;
   const bool staged = n <= lds_points;
-  if (staged) for (int e = tid; e < 3 * n; e += 1024) sp[e] = gp[e];
+  if (staged) {
+    if ((((size_t)b.pix0 * 3) & 3) == 0) {   // 16-byte pieces where the crop starts on one
+      const float4* g4 = reinterpret_cast<const float4*>(gp);
+      float4* s4 = reinterpret_cast<float4*>(sp);
+      const int n4 = (3 * n) >> 2;
+      for (int e = tid; e < n4; e += 1024) s4[e] = g4[e];
+      for (int e = 4 * n4 + tid; e < 3 * n; e += 1024) sp[e] = gp[e];
+    } else {
+      for (int e = tid; e < 3 * n; e += 1024) sp[e] = gp[e];
+    }
+  }
   const float* P = staged ? (const float*)sp : gp;
-  float* prod = sp + (staged ? 3 * n : 0);
   const unsigned long long seed = seed0 + (unsigned long long)blockIdx.x * 0x9E3779B97F4A7C15ull;
   if (tid == 0) { s_stop = n < 3 ? 1 : 0; s_best_n = -1; s_best_it = -1; s_it = 0; s_best[0] = s_best[1] = s_best[2] = s_best[3] = 0; }
   __syncthreads();
-  // ---- hypotheses, sixteen at a time; the adaptive loop's state lives in thread 0
+  // the adaptive loop's state lives in thread 0
   double k = 1.0;
   int iterations = 0, skipped = 0;
   const int max_skip = max_iterations * 10;
   const double log_probability = log(1.0 - probability), one_over = 1.0 / (double)n, eps = 2.220446049250313e-16;
+  int nh = kRsHyp;
   while (!s_stop) {
-    const int iter = s_it + wave;
-    float m0 = 0, m1 = 0, m2 = 0, m3 = 0;
-    int ok = 0;
-    if (lane == 0) {
+    if (wave < nh && lane == 0) {
+      const int iter = s_it + wave;
+      float m0 = 0, m1 = 0, m2 = 0, m3 = 0;
       int good = 0;
       for (int attempt = 0; attempt < 1000 && !good; ++attempt) {
         int id[3];
@@ -1549,23 +1569,49 @@ __global__ __launch_bounds__(1024) void k_ransac_boxes(View V, float thr, int ma
         m3 = -1 * (m0 * p0[0] + m1 * p0[1] + m2 * p0[2]);
         good = 2;
       }
-      ok = (good == 2) && isfinite(m0) && isfinite(m3);
+      s_ok[wave] = (good == 2) && isfinite(m0) && isfinite(m3);
+      s_models[wave][0] = m0; s_models[wave][1] = m1; s_models[wave][2] = m2; s_models[wave][3] = m3;
+      s_cnt[wave] = 0;
     }
-    m0 = __shfl(m0, 0, 64); m1 = __shfl(m1, 0, 64); m2 = __shfl(m2, 0, 64); m3 = __shfl(m3, 0, 64); ok = __shfl(ok, 0, 64);
-    int cnt = 0;
-    if (ok) {
-      const float m[4] = {m0, m1, m2, m3};
-      for (int i = lane; i < n; i += 64) cnt += plane_inlier(m, P + (size_t)i * 3, thr) ? 1 : 0;
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_down(cnt, o, 64);
-    if (lane == 0) { s_cnt[wave] = ok ? cnt : -1; s_models[wave][0] = m0; s_models[wave][1] = m1; s_models[wave][2] = m2; s_models[wave][3] = m3; }
     __syncthreads();
-    if (tid == 0) {   // pcl::RandomSampleConsensus::computeModel over these sixteen hypotheses, in order
+    {   // one pass over the points for all hypotheses of the round
+      float m[kRsHyp][4];
+      int cnt[kRsHyp];
+#pragma unroll
+      for (int h = 0; h < kRsHyp; ++h) {
+        const int hh = h < nh ? h : 0;
+        m[h][0] = s_models[hh][0]; m[h][1] = s_models[hh][1]; m[h][2] = s_models[hh][2]; m[h][3] = s_models[hh][3];
+        cnt[h] = 0;
+      }
+      if (nh == kRsHyp) {
+        for (int i = tid; i < n; i += 1024) {
+          const float p[3] = {P[(size_t)i * 3], P[(size_t)i * 3 + 1], P[(size_t)i * 3 + 2]};
+#pragma unroll
+          for (int h = 0; h < kRsHyp; ++h) cnt[h] += plane_inlier(m[h], p, thr) ? 1 : 0;
+        }
+      } else {
+        for (int i = tid; i < n; i += 1024) {
+          const float p[3] = {P[(size_t)i * 3], P[(size_t)i * 3 + 1], P[(size_t)i * 3 + 2]};
+#pragma unroll
+          for (int h = 0; h < kRsHyp / 2; ++h) cnt[h] += plane_inlier(m[h], p, thr) ? 1 : 0;
+        }
+      }
+#pragma unroll
+      for (int h = 0; h < kRsHyp; ++h) {
+        if (h < nh) {
+          int c = cnt[h];
+#pragma unroll
+          for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o, 64);
+          if (lane == 0) atomicAdd(&s_cnt[h], c);     // integer counts: the order of the waves does not matter
+        }
+      }
+    }
+    __syncthreads();
+    if (tid == 0) {   // pcl::RandomSampleConsensus::computeModel over these hypotheses, in order
       int stop = 0;
-      for (int j = 0; j < 16; ++j) {
+      for (int j = 0; j < nh; ++j) {
         if (!((double)iterations < k && skipped < max_skip)) { stop = 1; break; }
-        const int c = s_cnt[j];
+        const int c = s_ok[j] ? s_cnt[j] : -1;
         ++s_it;
         if (c < 0) { ++skipped; continue; }
         if (c > s_best_n) {
@@ -1582,40 +1628,61 @@ __global__ __launch_bounds__(1024) void k_ransac_boxes(View V, float thr, int ma
       }
       s_stop = stop;
     }
+    nh = kRsHyp / 2;
     __syncthreads();
   }
-  const int best = s_best_n;
-  float model[4] = {s_best[0], s_best[1], s_best[2], s_best[3]};
+  if (tid == 0) out[blockIdx.x] = RansacBox{{s_best[0], s_best[1], s_best[2], s_best[3]}, 0, s_best_n, s_best_it, s_it};
+}
+
+__global__ __launch_bounds__(256) void k_ransac_refine(View V, float thr, RansacBox* __restrict__ out, unsigned char* __restrict__ flag) {
+  __shared__ float prod[kRsProd * 9];
+  __shared__ int s_woff[5];
+  __shared__ float s_best[4], s_acc[9];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const BoxMeta b = V.box[blockIdx.x];
+  const int n = b.w * b.h;
+  const float* P = V.pts + (size_t)b.pix0 * 3;
+  const RansacBox rb = out[blockIdx.x];
+  const int best = rb.best_count;
+  float model[4] = {rb.coeff[0], rb.coeff[1], rb.coeff[2], rb.coeff[3]};
   if (best <= 0) {
-    for (int i = tid; i < n; i += 1024) flag[(size_t)b.pix0 + i] = 0;
-    if (tid == 0) out[blockIdx.x] = RansacBox{{0, 0, 0, 0}, 0, best, s_best_it, s_it};
+    for (int i = tid; i < n; i += 256) flag[(size_t)b.pix0 + i] = 0;
+    if (tid == 0) out[blockIdx.x] = RansacBox{{0, 0, 0, 0}, 0, best, rb.best_iter, rb.hyps};
     return;
   }
   // ---- optimizeModelCoefficients: float mean / covariance of the inliers of the sampled model, summed in index order
   if (best > 3) {
     float acc = 0;
     int total = 0;
-    for (int c0 = 0; c0 < n; c0 += 1024) {
+    for (int c0 = 0; c0 < n; c0 += kRsProd) {
       const int i = c0 + tid;
-      const bool in = i < n && plane_inlier(model, P + (size_t)i * 3, thr);
+      float p[3] = {0, 0, 0};
+      if (i < n) { p[0] = P[(size_t)i * 3]; p[1] = P[(size_t)i * 3 + 1]; p[2] = P[(size_t)i * 3 + 2]; }
+      const bool in = i < n && plane_inlier(model, p, thr);
       const unsigned long long mask = __ballot(in);
       if (lane == 0) s_woff[wave] = __popcll(mask);
       __syncthreads();
-      if (tid == 0) { int a = 0; for (int w = 0; w < 16; ++w) { const int c = s_woff[w]; s_woff[w] = a; a += c; } s_woff[16] = a; }
-      __syncthreads();
-      const int rank = s_woff[wave] + __popcll(mask & ((1ull << lane) - 1ull));
-      const int cn = s_woff[16];
-      for (int r0 = 0; r0 < cn; r0 += kRsProd) {
-        if (in && rank >= r0 && rank < r0 + kRsProd) {
-          const float* p = P + (size_t)i * 3;
-          float* q = prod + (rank - r0) * 9;
-          q[0] = p[0] * p[0]; q[1] = p[0] * p[1]; q[2] = p[0] * p[2]; q[3] = p[1] * p[1]; q[4] = p[1] * p[2]; q[5] = p[2] * p[2];
-          q[6] = p[0]; q[7] = p[1]; q[8] = p[2];
-        }
-        __syncthreads();
-        if (tid < 9) { const int mcount = min(kRsProd, cn - r0); for (int q = 0; q < mcount; ++q) acc += prod[q * 9 + tid]; }
-        __syncthreads();
+      const int w0 = s_woff[0], w1 = s_woff[1], w2 = s_woff[2], w3 = s_woff[3];
+      const int cn = w0 + w1 + w2 + w3;
+      const int rank = (wave > 0 ? w0 : 0) + (wave > 1 ? w1 : 0) + (wave > 2 ? w2 : 0) + __popcll(mask & ((1ull << lane) - 1ull));
+      if (in) {
+        float* q = prod + rank * 9;
+        q[0] = p[0] * p[0]; q[1] = p[0] * p[1]; q[2] = p[0] * p[2]; q[3] = p[1] * p[1]; q[4] = p[1] * p[2]; q[5] = p[2] * p[2];
+        q[6] = p[0]; q[7] = p[1]; q[8] = p[2];
       }
+      __syncthreads();
+      if (tid < 9) {   // sixteen loads ahead of sixteen dependent adds: the chain is the adds, not LDS round trips
+        int q = 0;
+        for (; q + 16 <= cn; q += 16) {
+          float v[16];
+#pragma unroll
+          for (int u = 0; u < 16; ++u) v[u] = prod[(q + u) * 9 + tid];
+#pragma unroll
+          for (int u = 0; u < 16; ++u) acc += v[u];
+        }
+        for (; q < cn; ++q) acc += prod[q * 9 + tid];
+      }
+      __syncthreads();
       total += cn;
     }
     if (tid < 9) s_acc[tid] = acc;
@@ -1639,20 +1706,17 @@ __global__ __launch_bounds__(1024) void k_ransac_boxes(View V, float thr, int ma
   }
   // ---- inliers of the refined model: flags for the box's pixels + their count
   int cnt = 0;
-  for (int i = tid; i < n; i += 1024) {
+  for (int i = tid; i < n; i += 256) {
     const bool in = plane_inlier(model, P + (size_t)i * 3, thr);
     flag[(size_t)b.pix0 + i] = in ? 1 : 0;
     cnt += in ? 1 : 0;
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) cnt += __shfl_down(cnt, o, 64);
+  __syncthreads();
   if (lane == 0) s_woff[wave] = cnt;
   __syncthreads();
-  if (tid == 0) {
-    int a = 0;
-    for (int w = 0; w < 16; ++w) a += s_woff[w];
-    out[blockIdx.x] = RansacBox{{model[0], model[1], model[2], model[3]}, a, best, s_best_it, s_it};
-  }
+  if (tid == 0) out[blockIdx.x] = RansacBox{{model[0], model[1], model[2], model[3]}, s_woff[0] + s_woff[1] + s_woff[2] + s_woff[3], best, rb.best_iter, rb.hyps};
 }
 
 // Point-to-plane ICP of every frame of the resident batch against a plane list (e.g. the previous keyframe's planes): the points are the
@@ -2490,7 +2554,7 @@ static int seg_ransac_lds_opt_in(int device, int* limit) {
   std::lock_guard<std::mutex> lk(mu);
   for (auto& d : done) if (d.first == device) { *limit = d.second; return 0; }
   const int v = lds_optin_limit(device, 156 * 1024, 4096);
-  SSLAM_HIP_TRY(hipFuncSetAttribute((const void*)k_ransac_boxes, hipFuncAttributeMaxDynamicSharedMemorySize, v));
+  SSLAM_HIP_TRY(hipFuncSetAttribute((const void*)k_ransac_hyp, hipFuncAttributeMaxDynamicSharedMemorySize, v));
   done.push_back({device, v});
   *limit = v;
   return 0;
@@ -2520,16 +2584,16 @@ int sslam_seg_ransac_boxes(sslam_seg* s, float threshold, int max_iterations, do
   }
   int lds_limit = 0;
   if ((rc = seg_ransac_lds_opt_in(s->P.device, &lds_limit))) return rc;
-  // a box whose points fit next to the product table is scored out of LDS; larger boxes read their points through L2
-  const int prod_bytes = kRsProd * 9 * (int)sizeof(float);
-  const int lds_points = std::max(0, (lds_limit - prod_bytes - 1024) / 12);
+  // a box whose points fit the LDS is scored out of it; larger boxes read their points through L2
+  const int lds_points = std::max(0, (lds_limit - 1024) / 12);
   int max_staged = 0;
   for (auto& b : s->boxes) { const int n = b.w * b.h; if (n <= lds_points) max_staged = std::max(max_staged, n); }
-  const size_t lds = (size_t)max_staged * 12 + prod_bytes;
+  const size_t lds = (size_t)max_staged * 12 + 16;
   if (!s->q_e0) { SSLAM_HIP_TRY(hipEventCreate(&s->q_e0)); SSLAM_HIP_TRY(hipEventCreate(&s->q_e1)); }
   SSLAM_HIP_TRY(hipEventRecord(s->q_e0, s->stream));
-  hipLaunchKernelGGL(k_ransac_boxes, dim3(nb), dim3(1024), lds, s->stream, s->V, threshold, max_iterations, probability, (unsigned long long)seed, lds_points,
-                     (RansacBox*)s->d_rbox, s->d_rflag);
+  hipLaunchKernelGGL(k_ransac_hyp, dim3(nb), dim3(1024), lds, s->stream, s->V, threshold, max_iterations, probability, (unsigned long long)seed, lds_points,
+                     (RansacBox*)s->d_rbox);
+  hipLaunchKernelGGL(k_ransac_refine, dim3(nb), dim3(256), 0, s->stream, s->V, threshold, (RansacBox*)s->d_rbox, s->d_rflag);
   SSLAM_HIP_TRY(hipGetLastError());
   SSLAM_HIP_TRY(hipEventRecord(s->q_e1, s->stream));
   std::vector<RansacBox> rb(nb);
