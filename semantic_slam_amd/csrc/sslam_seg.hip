@@ -536,40 +536,50 @@ __global__ __launch_bounds__(NT) void k_regions(View V) {
     const int label = cand[k];
     float acc = 0;            // lanes 0..8: component `lane`
     int first = -1, last = -1;
-    // the next chunk's label and point travel while this chunk's serial additions run (the loop is otherwise one HBM / L2 round trip
-    // per 64 pixels long)
-    int ln = lane < n ? L[lane] : -2;
-    float xn = 0, yn = 0, zn = 0;
-    if (lane < n) { xn = pts[(size_t)lane * 3]; yn = pts[(size_t)lane * 3 + 1]; zn = pts[(size_t)lane * 3 + 2]; }
-    for (int i0 = 0; i0 < n; i0 += 64) {
-      const int i = i0 + lane;
-      const bool m = i < n && ln == label;
-      const float x = xn, y = yn, z = zn;
-      {
-        const int j = i + 64;
-        ln = j < n ? L[j] : -2;
-        if (j < n) { xn = pts[(size_t)j * 3]; yn = pts[(size_t)j * 3 + 1]; zn = pts[(size_t)j * 3 + 2]; }
-      }
-      if (m) {
-        float* p = prod[wave][lane];
-        p[0] = x * x; p[1] = x * y; p[2] = x * z; p[3] = y * y; p[4] = y * z; p[5] = z * z; p[6] = x; p[7] = y; p[8] = z;
-      }
-      const unsigned long long mask = __ballot(m);
-      if (mask) {
-        if (first < 0) first = i0 + __ffsll((long long)mask) - 1;
-        last = i0 + 63 - __clzll((long long)mask);
-        // the additions are a serial chain in pixel order (PCL's), the LDS reads are not: eight products are fetched together,
-        // then added under the (wave-uniform) inlier bits
-        if (lane < 9) {
+    // the labels and points of the next FOUR chunks travel while a chunk's serial additions run: with one chunk ahead (round 3) the loop was one
+    // L2 round trip per 64 pixels long -- 90 % of the kernel's wave cycles parked (profiles/r6_pmc_frontend.json)
+    constexpr int PF = 4;
+    int lq[PF];
+    float xq[PF], yq[PF], zq[PF];
 #pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            const unsigned bits = (unsigned)(mask >> (8 * j)) & 0xffu;
-            if (bits) {
-              float v[8];
+    for (int c = 0; c < PF; ++c) {
+      const int j = 64 * c + lane;
+      lq[c] = j < n ? L[j] : -2; xq[c] = yq[c] = zq[c] = 0;
+      if (j < n) { xq[c] = pts[(size_t)j * 3]; yq[c] = pts[(size_t)j * 3 + 1]; zq[c] = pts[(size_t)j * 3 + 2]; }
+    }
+    for (int i00 = 0; i00 < n; i00 += 64 * PF) {
 #pragma unroll
-              for (int q = 0; q < 8; ++q) v[q] = prod[wave][8 * j + q][lane];
+      for (int c = 0; c < PF; ++c) {
+        const int i0 = i00 + 64 * c;
+        const int i = i0 + lane;
+        const bool m = i < n && lq[c] == label;
+        const float x = xq[c], y = yq[c], z = zq[c];
+        {
+          const int j = i + 64 * PF;
+          lq[c] = j < n ? L[j] : -2;
+          if (j < n) { xq[c] = pts[(size_t)j * 3]; yq[c] = pts[(size_t)j * 3 + 1]; zq[c] = pts[(size_t)j * 3 + 2]; }
+        }
+        if (m) {
+          float* p = prod[wave][lane];
+          p[0] = x * x; p[1] = x * y; p[2] = x * z; p[3] = y * y; p[4] = y * z; p[5] = z * z; p[6] = x; p[7] = y; p[8] = z;
+        }
+        const unsigned long long mask = __ballot(m);
+        if (mask) {
+          if (first < 0) first = i0 + __ffsll((long long)mask) - 1;
+          last = i0 + 63 - __clzll((long long)mask);
+          // the additions are a serial chain in pixel order (PCL's), the LDS reads are not: eight products are fetched together,
+          // then added under the (wave-uniform) inlier bits
+          if (lane < 9) {
 #pragma unroll
-              for (int q = 0; q < 8; ++q) if (bits & (1u << q)) acc += v[q];
+            for (int j = 0; j < 8; ++j) {
+              const unsigned bits = (unsigned)(mask >> (8 * j)) & 0xffu;
+              if (bits) {
+                float v[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) v[q] = prod[wave][8 * j + q][lane];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) if (bits & (1u << q)) acc += v[q];
+              }
             }
           }
         }
