@@ -102,6 +102,7 @@ struct CholPlan {
   bool flow = false;            // the plan can run it (every piece has one parent piece; nt_leaf == nt_tail)
   int flow_grid = 0;            // persistent workgroups
   int spec_grid = 0;            // workgroups of a speculative round (all lanes)
+  double flow_need = 1.0, spec_need = 1.0;   // the share of the device those grids occupy when resident (workgroups / what the device holds of them)
   int flow_first = 0;           // first launch-order piece of the single launch; the per-depth launches [0, flow_launch0) come before it
   int flow_launch0 = 0;
   int flow_epoch = 0;           // launches so far: the counters are never reset, a launch waits for epoch * (children)
@@ -1879,6 +1880,7 @@ int chol_plan_build(Batch& b) {
       if (l0 > 0 && flow_mode != 2) P->flow = false;
       P->flow_first = l0 < (int)P->plv_ptr.size() ? P->plv_ptr[l0] : 0;
       P->flow_grid = std::max(1, std::min((int)dep.size() - P->flow_first, cap));
+      P->flow_need = std::min(1.0, (double)P->flow_grid / (double)(per_cu * cus));
       if (!P->flow) { /* launch-per-depth path */ }
       else if (P->flow_first > 0) {   // children that the launches finish are not waited for
         for (auto& d2 : dep) d2.y = 0;
@@ -1910,6 +1912,7 @@ int chol_plan_build(Batch& b) {
         if (spec_mode == 2 || lanes_fit) {
           SL.after = spec_mode == 2 ? 0 : 1;
           P->spec_grid = SL.g0 + (K - 1) * SL.g1;
+          P->spec_need = std::min(1.0, (double)P->spec_grid / (double)(per_cu_s * cus));
           SL.sL = (H.lnz + 64 + 1) & ~1LL; SL.sU = (H.unz + 64 + 1) & ~1LL; SL.sy = (C.dim + 8 + 1) & ~1LL; SL.sx = (C.dim + 8 + 1) & ~1LL;
           SL.spose = (long long)b.V.nPose * 8; SL.slmk = (long long)b.V.nLm * 4; SL.spe = (long long)b.V.B * b.V.maxEdgeChunks; SL.spa = (long long)b.V.B * b.V.maxRowChunks;
           SL.sflow = (long long)nints;
@@ -1942,14 +1945,18 @@ int chol_plan_build(Batch& b) {
 }
 
 // Persistent launches (k_chol_flow, k_chol_spec_round) spin on counters that only workgroups of the SAME launch advance: a launch whose
-// grid is not wholly on the chip can wait for a workgroup that has not started.  Every such grid is sized for an otherwise free device
-// (flow: half of it, a speculative round: all of it) -- so launches of different handles / streams / host threads must not overlap
-// (round-4 ADVICE).  They are chained per device: a launch waits for the event its predecessor recorded, whatever stream that was on.  On
-// one stream (a single graph handle: the orchestrator) the wait is already implied and costs an event record per launch.
+// grid is not wholly on the chip can wait for a workgroup that has not started (round-4 ADVICE).  Round 5 chained all of them per device,
+// one at a time -- correct, but eight robots on one GPU queued behind each other while each used a tenth of the chip.  Round 6: a BUDGET.
+// Every plan knows the share of the device its grid occupies when resident (`need`: workgroups / what the device holds of them); the
+// ledger keeps, per stream, the need of that stream's latest persistent launch (a stream runs its own launches one after the other).  A new
+// launch may overlap the launches of the OTHER streams as long as the shares add up to <= 1; otherwise it waits (an event behind everything
+// such a stream holds) for as many of them as it takes, largest first.  Launches enqueued later make the same check against this one, so at
+// any time the launches that are not ordered behind one another fit the device.  One stream (the orchestrator) never waits and records no
+// event.  A stream whose event has completed is idle and leaves the ledger.
+struct PersistEntry { hipStream_t stream; double need; hipEvent_t ev; bool fresh; };   // fresh: ev was recorded behind the stream's latest launch
 struct PersistGate {
   std::mutex mu;
-  hipEvent_t ev = nullptr;
-  hipStream_t last = nullptr;   // stream of the device's latest persistent launch (nullptr: none, or that stream is gone)
+  std::vector<PersistEntry> entries;
 };
 static PersistGate& persist_gate(int device) {
   static std::mutex mu;
@@ -1959,25 +1966,56 @@ static PersistGate& persist_gate(int device) {
   if (!gates[device]) gates[device] = new PersistGate();
   return *gates[device];
 }
-// Construct before the launch, destroy after it.  A launch on the stream of the previous persistent launch is ordered behind it by the
-// stream itself and costs nothing here (the orchestrator's case: ~25 such launches per tick; an event record + wait per launch added
-// ~0.1 ms per tick when round 5 first chained them).  A launch on ANOTHER stream records an event behind everything the previous stream
-// holds (its last persistent launch included) and waits for it.
+// Construct before the launch, destroy after it (the lock orders the bookkeeping of concurrent host threads, not the launches).
 struct PersistScope {
-  PersistGate& g; hipStream_t s; std::unique_lock<std::mutex> lk;
-  PersistScope(int device, hipStream_t stream) : g(persist_gate(device)), s(stream), lk(g.mu) {
-    if (g.last && g.last != s) {
-      if (!g.ev && hipEventCreateWithFlags(&g.ev, hipEventDisableTiming) != hipSuccess) g.ev = nullptr;
-      if (g.ev && hipEventRecord(g.ev, g.last) == hipSuccess) (void)hipStreamWaitEvent(s, g.ev, 0);
+  PersistGate& g; hipStream_t s; double need; std::unique_lock<std::mutex> lk;
+  PersistScope(int device, hipStream_t stream, double need_) : g(persist_gate(device)), s(stream), need(std::min(1.0, std::max(0.0, need_))), lk(g.mu) {
+    // idle streams leave the ledger
+    for (size_t i = 0; i < g.entries.size();) {
+      PersistEntry& e = g.entries[i];
+      if (e.stream != s && e.fresh && e.ev && hipEventQuery(e.ev) == hipSuccess) { (void)hipEventDestroy(e.ev); g.entries.erase(g.entries.begin() + i); }
+      else ++i;
+    }
+    double others = 0;
+    for (const PersistEntry& e : g.entries) if (e.stream != s) others += e.need;
+    std::vector<char> waited(g.entries.size(), 0);
+    while (others + need > 1.0 + 1e-9) {
+      int pick = -1;
+      for (size_t i = 0; i < g.entries.size(); ++i)
+        if (g.entries[i].stream != s && !waited[i] && (pick < 0 || g.entries[i].need > g.entries[pick].need)) pick = (int)i;
+      if (pick < 0) break;
+      PersistEntry& e = g.entries[pick];
+      bool chained = false;
+      if (!e.ev && hipEventCreateWithFlags(&e.ev, hipEventDisableTiming) != hipSuccess) e.ev = nullptr;
+      if (e.ev) {
+        if (!e.fresh && hipEventRecord(e.ev, e.stream) == hipSuccess) e.fresh = true;
+        if (e.fresh && hipStreamWaitEvent(s, e.ev, 0) == hipSuccess) chained = true;
+      }
+      if (!chained) (void)hipStreamSynchronize(e.stream);   // (round-5 ADVICE: never let the launch go out unchained)
+      waited[pick] = 1;
+      others -= e.need;
     }
   }
-  ~PersistScope() { g.last = s; }
+  ~PersistScope() {
+    for (PersistEntry& e : g.entries)
+      if (e.stream == s) { e.need = need; e.fresh = false; return; }
+    g.entries.push_back(PersistEntry{s, need, nullptr, false});
+  }
 };
 // a stream is about to be destroyed (its owner synchronises it first): no later launch may record an event on it
 void persist_forget_stream(int device, hipStream_t stream) {
   PersistGate& g = persist_gate(device);
   std::lock_guard<std::mutex> lk(g.mu);
-  if (g.last == stream) g.last = nullptr;
+  for (size_t i = 0; i < g.entries.size(); ++i)
+    if (g.entries[i].stream == stream) { if (g.entries[i].ev) (void)hipEventDestroy(g.entries[i].ev); g.entries.erase(g.entries.begin() + i); return; }
+}
+
+// LDS bytes the dependency-driven launches reserve: the largest piece of the plan, whichever kernels run it
+static size_t plan_flow_lds(const CholPlan& P) {
+  size_t lds = (size_t)std::max(std::max(P.tail_lds_f, P.tail_lds_b), P.tail_lds_ff);
+  for (size_t l = 0; l < P.plv_lds_f.size(); ++l) lds = std::max(lds, (size_t)std::max(P.plv_lds_f[l], P.plv_lds_b[l]));
+  for (int v : P.plv_lds_ff) lds = std::max(lds, (size_t)v);
+  return lds * sizeof(double);
 }
 
 // (H + lambda I) dx = b in ONE launch (k_chol_flow) for plans that allow it; false: the caller takes the launch-per-depth path
@@ -1987,9 +2025,7 @@ bool chol_plan_flow(const Batch& b) { return b.chol && b.chol->flow && !b.chol->
 static void flow_launches(Batch& b, bool spec = false, bool backward = true, bool lmstep = false, int max_iters = 0) {
   CholPlan& P = *b.chol;
   const CholView& C = P.C;
-  size_t lds = (size_t)std::max(P.tail_lds_f, P.tail_lds_b);
-  for (size_t l = 0; l < P.plv_lds_f.size(); ++l) lds = std::max(lds, (size_t)std::max(P.plv_lds_f[l], P.plv_lds_b[l]));
-  lds *= sizeof(double);
+  const size_t lds = plan_flow_lds(P);
   const int np = (int)P.lp_graph.size();
   for (int l = 0; l < P.flow_launch0; ++l) {
     const int n = P.plv_ptr[l + 1] - P.plv_ptr[l];
@@ -2002,7 +2038,7 @@ static void flow_launches(Batch& b, bool spec = false, bool backward = true, boo
   const dim3 grid(spec ? P.spec_grid : P.flow_grid);
   const int defer = 2;   // tables + H before the wait for the children (round 4: -0.43 ms per tick)
   {
-    PersistScope gate(b.device, b.stream);
+    PersistScope gate(b.device, b.stream, spec ? P.spec_need : P.flow_need);
     if (P.ustage) hipLaunchKernelGGL((k_chol_flow<512, true>), grid, dim3(512), lds, b.stream, b.V, C, P.flow_first, np, epoch, (const int2*)P.d_dep, P.d_flow, SL, (backward ? 1 : 0) | defer | (lmstep ? 4 : 0), b.d_part_e, max_iters, lm_epoch);
     else hipLaunchKernelGGL((k_chol_flow<512, false>), grid, dim3(512), lds, b.stream, b.V, C, P.flow_first, np, epoch, (const int2*)P.d_dep, P.d_flow, SL, (backward ? 1 : 0) | defer | (lmstep ? 4 : 0), b.d_part_e, max_iters, lm_epoch);
   }
@@ -2016,9 +2052,7 @@ int chol_solve_flow(Batch& b) {
   P.C.flat_L = 0;
   const CholView& C = P.C;
   ScopedTimer t(b, "factor");
-  size_t lds = (size_t)std::max(P.tail_lds_f, P.tail_lds_b);
-  for (size_t l = 0; l < P.plv_lds_f.size(); ++l) lds = std::max(lds, (size_t)std::max(P.plv_lds_f[l], P.plv_lds_b[l]));
-  lds *= sizeof(double);
+  const size_t lds = plan_flow_lds(P);
   const int np = (int)P.lp_graph.size();
   hipLaunchKernelGGL(k_chol_begin, dim3((b.V.B + 63) / 64), dim3(64), 0, b.stream, b.V, C);
   flow_launches(b);
@@ -2043,9 +2077,7 @@ int chol_lm_step_flow(Batch& b, int max_iters) {
   CholPlan& P = *b.chol;
   P.C.flat_L = 0;
   const CholView& C = P.C;
-  size_t lds = (size_t)std::max(P.tail_lds_f, P.tail_lds_b);
-  for (size_t l = 0; l < P.plv_lds_f.size(); ++l) lds = std::max(lds, (size_t)std::max(P.plv_lds_f[l], P.plv_lds_b[l]));
-  lds *= sizeof(double);
+  const size_t lds = plan_flow_lds(P);
   const int np = (int)P.lp_graph.size();
   // the begin / end halves of the trial inside the launch when it covers the whole tree and has a workgroup per graph
   if (P.flow_launch0 == 0 && P.flow_grid >= b.V.B) { flow_launches(b, false, true, true, max_iters); }
@@ -2063,13 +2095,11 @@ bool chol_plan_spec(const Batch& b) { return chol_plan_flow(b) && b.chol->spec.K
 int chol_lm_step_spec(Batch& b, int max_iters) {
   CholPlan& P = *b.chol;
   P.C.flat_L = 0;
-  size_t lds = (size_t)std::max(P.tail_lds_f, P.tail_lds_b);
-  for (size_t l = 0; l < P.plv_lds_f.size(); ++l) lds = std::max(lds, (size_t)std::max(P.plv_lds_f[l], P.plv_lds_b[l]));
-  lds *= sizeof(double);
+  const size_t lds = plan_flow_lds(P);
   const int np = (int)P.lp_graph.size();
   const int round = ++P.spec_epoch;
   {
-    PersistScope gate(b.device, b.stream);
+    PersistScope gate(b.device, b.stream, P.spec_need);
     if (P.ustage) hipLaunchKernelGGL((k_chol_spec_round<512, true>), dim3(P.spec_grid), dim3(512), lds, b.stream, b.V, P.C, np, (const int2*)P.d_dep, P.spec, round, max_iters);
     else hipLaunchKernelGGL((k_chol_spec_round<512, false>), dim3(P.spec_grid), dim3(512), lds, b.stream, b.V, P.C, np, (const int2*)P.d_dep, P.spec, round, max_iters);
   }

@@ -155,6 +155,10 @@ def test_cholesky_solve_matches_oracle_cholesky(gpu_lib, lam):
     # round 5, mid class: the depths between the bottom and the tail as larger pieces on 256-thread workgroups (per-depth launches: no k_chol_flow)
     {"flow": "0", "cap_leaf": "400", "tail_width": "2", "mid_width": "12", "cap_mid": "1200"},
     {"flow": "0", "cap_leaf": "400", "tail_width": "0", "mid_width": "8", "cap_mid": "1500", "nt_mid": "512"},
+    # round 6, front tables (one blob of relative indices per workgroup; k_front_pieces / k_front_tail): all three classes, groups, no tail, the single launch
+    {"front": "1", "flow": "0", "cap_leaf": "400", "tail_width": "2", "mid_width": "12", "cap_mid": "1200"},
+    {"front": "1", "flow": "0", "cap_leaf": "300", "group_cap": "1200", "nt_leaf": "128", "tail_width": "0", "mid_width": "8", "cap_mid": "1500"},
+    {"front": "1", "cap_leaf": "400", "cap_tail": "700", "tail_width": "2"},
 ])
 def test_cholesky_pieces_of_every_shape(gpu_lib, monkeypatch, env):
     """The piece plan is cut by LDS capacity; caps far below the defaults force what the 5000-pose graph has (pieces with
@@ -838,8 +842,10 @@ def test_seg_golden_patch(gpu_lib):
 def test_concurrent_handles_with_persistent_launches_equal_their_sequential_runs(gpu_lib):
     """Round-4 ADVICE: k_chol_flow / k_chol_spec_round are persistent grids sized for an otherwise free device; several graph handles (each
     with its own stream) driven from several host threads used to be able to leave each launch partly resident.  Persistent launches are now
-    chained per device (PersistScope in sslam_chol.hip): four handles optimised concurrently give, bit for bit, what each gives alone."""
-    import threading
+    chained per device (PersistScope in sslam_chol.hip): four handles optimised concurrently give, bit for bit, what each gives alone.
+    Round 6: the chain is a BUDGET -- launches whose grids together fit the device overlap, the others wait -- so four concurrent 100-pose
+    optimisations must take less than twice one of them (round 5 ran them one at a time: four times)."""
+    import threading, time
     from semantic_slam_amd import GraphSLAM
     gps = [GraphProblem.from_synth(make_graph(100 + 15 * k, 20 + 3 * k, seed=40 + k), interleave=True) for k in range(4)]
     alone = []
@@ -860,3 +866,21 @@ def test_concurrent_handles_with_persistent_launches_equal_their_sequential_runs
         for G, ref in zip(Gs, alone):
             assert (G.last_stats.iterations, G.last_stats.trials, G.last_stats.chi2_after) == ref[:3]
             assert np.array_equal(G.estimates(), ref[3])
+    # timing: the same 100-pose graph in four handles, warm (plans built, clocks up), best of three
+    gp = GraphProblem.from_synth(make_graph(100, 20, seed=44), interleave=True)
+
+    def timed(n_handles):
+        best = 1e9
+        for rep in range(3):
+            Gs = [GraphSLAM.from_problem(gp) for _ in range(n_handles)]
+            for G in Gs:
+                G.set_option("speculative_trials", 0)     # the plain single-launch solve: a tenth of the device per handle (ten lanes would fill it)
+                assert G.optimize(2)                       # plan + first launches outside the timed part
+            th = [threading.Thread(target=lambda G=G: G.optimize(40)) for G in Gs]
+            t0 = time.perf_counter()
+            for t in th: t.start()
+            for t in th: t.join()
+            best = min(best, time.perf_counter() - t0)
+        return best
+    one, four = timed(1), timed(4)
+    assert four < 2.0 * one, (one, four)
