@@ -114,8 +114,7 @@ int sslam_graph_hessian_index(sslam_graph* g, int id);
  * "fused_small_graph" 1 (default) / 0: a batch of fewer than eight graphs whose elimination tree is narrower than the chip runs the
  * factorisation, both triangular solves and the begin / end halves of a damping trial in ONE dependency-driven launch (k_chol_flow; the
  * reference's per-tick call pattern, semantic_graph_slam.cpp:58-102); 0: the stand-alone kernels -- same results, bitwise.  (The
- * one-workgroup-per-graph kernel k_lm_trial_small of round 4 is only reachable with SSLAM_CHOL_SMALL_COLS in the environment: measured
- * slower)
+ * one-workgroup-per-graph kernel k_lm_trial_small of round 4 -- measured slower, DESIGN.md section 5 -- left the library in round 5.)
  * "speculative_trials" 0 / 1 (default since round 5) / 2: a single small graph runs the damping trials of an LM iteration side by side -- g2o's retry
  * lambdas are known when the iteration starts -- in the lanes of ONE launch (k_chol_spec_round) that also replays the accept / reject
  * sequence over their results: bitwise the sequential result, trial counts included.  1: the lanes join once a trial of the iteration

@@ -193,6 +193,17 @@ struct CholOpts {
   // SSLAM_CHOL_OPTS="key=value,key=value,...": every plan option above by its field name (tests force the piece shapes of a 5000-pose graph
   // onto small graphs with it; tuning sweeps), plus order=mmd|mindeg and dump=1.  The ONE environment switch of the plan.
   void from_env() {
+    {   // legacy per-knob variables (rounds 2-4) are ignored: say so once
+      static bool warned = false;
+      if (!warned) {
+        warned = true;
+        static const char* legacy[] = {"SSLAM_CHOL_CAP_LEAF", "SSLAM_CHOL_CAP_TAIL", "SSLAM_CHOL_TAIL_WIDTH", "SSLAM_CHOL_NT_TAIL", "SSLAM_CHOL_NT_LEAF", "SSLAM_CHOL_MAX_BLOCKS",
+                                       "SSLAM_CHOL_DUMP", "SSLAM_CHOL_FLOW", "SSLAM_CHOL_ORDER", "SSLAM_CHOL_USTAGE", "SSLAM_CHOL_RIGHT", "SSLAM_CHOL_SMALL_COLS",
+                                       "SSLAM_CHOL_GROUP_CAP", "SSLAM_CHOL_MID_WIDTH", "SSLAM_FLOW_DEFER", "SSLAM_FLOW_LMSTEP"};
+        for (const char* v : legacy)
+          if (getenv(v)) fprintf(stderr, "[sslam] %s is no longer read: plan options go through SSLAM_CHOL_OPTS=\"key=value,...\" (chol_plan.hpp CholOpts)\n", v);
+      }
+    }
     const char* e = getenv("SSLAM_CHOL_OPTS");
     if (!e) return;
     std::string str(e);

@@ -115,6 +115,8 @@ __device__ __forceinline__ void front_piece(const BatchView& V, const CholView& 
   __syncthreads();
   if (!in_trial) return;
   SSLAM_FSTAMP(0)
+  const int skip = C.skip;
+  if (skip & 64) return;
   const unsigned h0 = sB[0], h1 = sB[1], h2 = sB[2];
   const int ncomp = h0 & 255, nlv = (h0 >> 8) & 255, nchild = h0 >> 16, nc = h1 & 0xFFFF, nb = h1 >> 16;
   const uint2* sMulti = reinterpret_cast<const uint2*>(sB + sB[8]);
@@ -269,6 +271,7 @@ __device__ __forceinline__ void front_piece(const BatchView& V, const CholView& 
   }
   __syncthreads();
   SSLAM_FSTAMP(1)
+  if (skip & 128) return;
   if (n2 + nmore > 0) {
     // further child sources, in list order: the second ones (loaded above) now that the first are in LDS, one (block, row) per thread; what does
     // not fit a pass, and third and later sources (rare), one source after the other by the first lanes of the workgroup
@@ -308,7 +311,7 @@ __device__ __forceinline__ void front_piece(const BatchView& V, const CholView& 
     const unsigned* lv = sLv + kFrontLv * il;
     const int t0 = (int)lv[1], t1 = (int)lv[2];
     // 2a. target tiles: one lane per 3 x 3 tile, its sources from the row masks (left-looking: the groups of leaf pieces)
-    if (!RIGHT && t1 > t0) {
+    if (!RIGHT && t1 > t0 && !(skip & 2)) {
       for (int t = t0 + tid; t < t1; t += NT) {
         const unsigned e = sTile[t];
         const int tr = (e >> 1) & 1, tc = e & 1;
@@ -351,7 +354,7 @@ __device__ __forceinline__ void front_piece(const BatchView& V, const CholView& 
 #pragma unroll
     for (int r2 = 0; r2 < kKeep; ++r2) {
       const int cc = team + r2 * teams;
-      if (cc < ncl) {
+      if (cc < ncl && !(skip & 4)) {
         const uint4 col = sCol[c0 + cc];
         const int dj = ((col.y >> 16) & 1) ? 6 : 3;
         const double* Sd = smL + (col.x & 0xFFFF);
@@ -410,7 +413,7 @@ __device__ __forceinline__ void front_piece(const BatchView& V, const CholView& 
     // 2c. right-looking (mid and tail pieces: chains of columns): a finished column updates every later block of its piece at once, all tile
     //     pairs in parallel, one tile update deep; one column per round (two columns of a level may meet in a target).  The pairs (p >= q) of the
     //     column's off-diagonal blocks with block q's row inside the piece are enumerated by arithmetic: 4 lanes per pair, one per 3 x 3 tile.
-    if (RIGHT) {
+    if (RIGHT && !(skip & 8)) {
       for (int c = c0; c < c0 + ncl; ++c) {
         const uint4 col = sCol[c];
         const int cb0 = col.w & 0x3FFF, m = (int)((col.w >> 14) & 255) - 1, mi = (int)(col.w >> 22);
@@ -457,7 +460,7 @@ __device__ __forceinline__ void front_piece(const BatchView& V, const CholView& 
   __syncthreads();   // (the last level's diagonal blocks are in LDS before the final store)
   // ---- 3. the update matrices: dense lower triangles over the boundary rows, one lane per 3 x 3 tile: own updates out of LDS + the
   //         children's blocks through their relative indices -> HBM
-  {
+  if (!(skip & 16)) {
     const unsigned cwl = sB[kFrontHdr + kFrontComp * (ncomp - 1) + 4], Tl = (sB[kFrontHdr + kFrontComp * (ncomp - 1)] >> 16) & 255;
     const int ntile = (int)(cwl >> 16) + (int)(Tl * (Tl + 1) / 2);
     for (int t = tid; t < ntile; t += NT) {
@@ -536,6 +539,7 @@ __device__ __forceinline__ void front_piece(const BatchView& V, const CholView& 
   }
   SSLAM_FSTAMP(5)
   // ---- 4. one coalesced stream out (the layouts of chol_piece)
+  if (skip & 32) return;
   if (C.flat_L) {
     D2* dst = reinterpret_cast<D2*>(C.Lval + pm.lbase);
     const D2* src = reinterpret_cast<const D2*>(smL);

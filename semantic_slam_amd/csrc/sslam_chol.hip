@@ -10,8 +10,10 @@
 //   k_chol_forward_level / k_chol_backward_level<Q>   level-scheduled multi right-hand-side solves (marginals)
 // Everything is gather-form: every L entry is written by exactly one thread, sums run in a fixed order -> bitwise
 // repeatable.  Forward substitution is fused into the factorisation (b rides along as an extra row of the diagonal block).
-// Tuning knobs (environment, read when a plan is built): SSLAM_CHOL_CAP_LEAF / _CAP_TAIL (doubles of L per piece),
-// SSLAM_CHOL_TAIL_WIDTH, SSLAM_CHOL_NT_TAIL (512 or 1024), SSLAM_CHOL_MAX_BLOCKS, SSLAM_CHOL_DUMP.
+//   k_front_pieces / k_front_tail (front_kernels.hpp, round 6)   the same pieces through the front tables of front_plan.hpp: the default of batches >= 32
+// Tuning: ONE environment variable, read when a plan is built -- SSLAM_CHOL_OPTS="key=value,..." with the field names of CholOpts
+// (chol_plan.hpp).  The per-knob variables of rounds 2-4 (SSLAM_CHOL_CAP_LEAF, SSLAM_CHOL_FLOW, SSLAM_FLOW_DEFER, ...) are gone; setting one
+// earns a warning on stderr, once, instead of a sweep that silently measures the default plan.
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <cstdio>
@@ -55,6 +57,7 @@ struct CholView {
   const unsigned* fblob;    // front tables (front_plan.hpp): the blobs, and per launch-order piece where its blob is; nullptr: record plan only
   const FrontGrp* lfgrp;
   int flat_L;               // 1: the factor is written in flat form (multi right-hand-side kernels); 0: class-interleaved (LM loop)
+  int skip;                 // EXPERIMENT (SSLAM_CHOL_SKIP): phases left out, timing only
   long long* dbg;           // SSLAM_CHOL_STAMPS: shader-clock totals per phase of workgroup 0 ([16] tail kernel, [16] per-depth kernels)
 };
 
@@ -1812,6 +1815,7 @@ int chol_plan_build(Batch& b) {
   C.fail = (int*)p;
   SSLAM_HIP_TRY(hipMemsetAsync(C.fail, 0, std::max(b.V.B, 1) * sizeof(int), b.stream));
   C.dbg = nullptr;
+  C.skip = getenv("SSLAM_CHOL_SKIP") ? atoi(getenv("SSLAM_CHOL_SKIP")) : 0;
   C.flat_L = 0;
   if (getenv("SSLAM_CHOL_STAMPS")) {
     if ((rc = plan_alloc(&p, 64 * sizeof(long long)))) return rc;

@@ -1721,6 +1721,8 @@ int sslam_graph_optimize(sslam_graph* h, int max_iters, sslam_opt_stats* out) {
   static const bool timing = getenv("SSLAM_TIMING") != nullptr;
   auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   const double t0 = now();
+  const bool reuse = h->batch && !h->batch->versions.empty() && h->batch->versions[0] == h->g.structure_version;   // ensure_batch rebuilds otherwise
+  if (h->batch) h->batch->plan_build_ms = 0;   // (a call that failed after a rebuild must not leak its plan time into this one: round-5 ADVICE)
   int rc = ensure_batch(h);
   if (rc) { out->status = rc; return rc; }
   const double t1 = now();
@@ -1728,7 +1730,8 @@ int sslam_graph_optimize(sslam_graph* h, int max_iters, sslam_opt_stats* out) {
   const double t2 = now();
   if ((rc = batch_optimize(*h->batch, max_iters, out))) return rc;
   const double t3 = now();
-  out->host_plan_us = (int)std::lround(1e3 * ((t1 - t0) + h->batch->plan_build_ms));   // what the structure change cost the host (0.0x ms when nothing changed)
+  // what a structure change cost the host: batch tables (ensure_batch) + symbolic factorisation; exactly 0 when the structure was reused
+  out->host_plan_us = (reuse && h->batch->plan_build_ms == 0) ? 0 : (int)std::lround(1e3 * ((reuse ? 0.0 : t1 - t0) + h->batch->plan_build_ms));
   h->batch->plan_build_ms = 0;
   h->linearized = false;
   rc = batch_download_estimates(*h->batch);

@@ -14,6 +14,7 @@ from typing import List, Sequence
 import numpy as np
 
 from ._lib import load_library
+from . import synth
 
 CLASS_NAMES = ["other", "chair", "tvmonitor", "book", "keyboard", "laptop", "bucket", "car"]  # point_cloud_segmentation.h:126-130
 
@@ -167,8 +168,9 @@ class PointCloudSegmentation:
     def _boxes(object_info):
         # a structured array in the C layout (synth.BOX_DTYPE: four int32, class id, float probability) is copied as it stands -- per-box
         # Python conversions cost 3 ms per batch of 32 x 32 boxes, more than the GPU needs for the batch
-        if isinstance(object_info, np.ndarray) and object_info.dtype.fields is not None and object_info.dtype.itemsize == C.sizeof(Box) \
-                and object_info.dtype.names == ("tl_x", "tl_y", "width", "height", "class_id", "prob"):
+        # (the dtype itself must match -- names, field types AND offsets: an array with class_id as float32 has the same item size and would be
+        # reinterpreted silently; it takes the converting path below instead)
+        if isinstance(object_info, np.ndarray) and object_info.dtype == synth.BOX_DTYPE and object_info.dtype.itemsize == C.sizeof(Box):
             return (Box * len(object_info)).from_buffer_copy(np.ascontiguousarray(object_info).tobytes()) if len(object_info) else (Box * 0)()
         boxes = (Box * len(object_info))()
         for k, o in enumerate(object_info):
