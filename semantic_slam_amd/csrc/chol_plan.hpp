@@ -156,7 +156,9 @@ struct CholOpts {
   // piece, their updates stay in LDS (right-looking lists like the tail's), and four waves share the tiles of what is still handed up.
   int mid_width = -1;      // -1: 60 for batches >= 32, else 0 (small batches run k_chol_flow with one workgroup size); 0: no mid class
   int cap_mid = 1800;      // doubles of L per mid piece (512 L graphs: 1800 / 2400 / 3600 -> 9.14 / 9.47 / 10.2 ms per factorisation, 9.55 without the class)
-  int nt_mid = 256;        // its workgroup
+  int nt_mid = 128;        // its workgroup.  Round 6, front kernels, 512 L graphs, mid launches per factorisation: 512 threads 3.87 ms, 256 1.91, 128 1.54, 64 1.89
+                           // (a piece's phases hold a few hundred lanes of work at most; every further wave adds its share of the barriers and idle passes)
+  int nt_ftail = 256;      // workgroup of k_front_tail (the front tables do not depend on it): 128 | 256 | 512 | 1024; tail launch 1.12 / 0.84 / 1.13 ms at 128 / 256 / 512
   int pcap_mid = 16;
   int nt_leaf = -1, nt_tail = 512;    // workgroup sizes the items are cut for; nt_leaf -1: 128 for batches >= 32 (groups of pieces, below), else 64
   int min_chunk = 4;       // a list of <= min_chunk updates is never split
@@ -219,7 +221,7 @@ struct CholOpts {
       const int iv = atoi(v.c_str());
       if (k == "cap_leaf") cap_leaf = iv; else if (k == "cap_mid") cap_mid = iv; else if (k == "cap_tail") cap_tail = iv;
       else if (k == "max_blocks") max_blocks = iv; else if (k == "tail_width") tail_width = iv; else if (k == "mid_width") mid_width = iv;
-      else if (k == "nt_leaf") { nt_leaf = iv; nt_leaf_set = true; } else if (k == "nt_mid") nt_mid = iv; else if (k == "nt_tail") nt_tail = iv;
+      else if (k == "nt_leaf") { nt_leaf = iv; nt_leaf_set = true; } else if (k == "nt_mid") nt_mid = iv; else if (k == "nt_ftail") nt_ftail = iv; else if (k == "nt_tail") nt_tail = iv;
       else if (k == "min_chunk") min_chunk = std::max(1, iv); else if (k == "split_min") split_min = std::max(2, iv);
       else if (k == "pcap_leaf") pcap_leaf = iv; else if (k == "pcap_mid") pcap_mid = iv; else if (k == "pcap_tail") pcap_tail = iv;
       else if (k == "group_cap") group_cap = iv; else if (k == "group_blocks") group_blocks = iv; else if (k == "ustage") ustage = iv;
@@ -240,7 +242,7 @@ struct CholOpts {
 inline bool chol_opts_normalise(CholOpts& opt, int B) {
   if (opt.nt_tail != 1024) opt.nt_tail = 512;
   if (opt.nt_leaf != -1 && opt.nt_leaf != 128 && opt.nt_leaf != 256 && opt.nt_leaf != 512 && opt.nt_leaf != 1024) opt.nt_leaf = 64;   // -1: by batch size (chol_symbolic)
-  if (opt.nt_mid != 128 && opt.nt_mid != 512) opt.nt_mid = 256;
+  if (opt.nt_mid != 256 && opt.nt_mid != 512) opt.nt_mid = 128;
   const bool want_flow = opt.flow != 0 && B < 8 && opt.nt_tail == 512 && opt.group_cap <= 0 && !opt.nt_leaf_set;
   if (want_flow) { opt.nt_leaf = opt.nt_tail; opt.mid_width = 0; }
   return want_flow;
@@ -261,7 +263,7 @@ struct CholHost {
   std::vector<int> plv_lds_f, plv_lds_b;    // LDS doubles per launch (factor / backward)
   std::vector<int> plv_nt, plv_cls;         // workgroup size (nt_leaf | nt_mid) and class (0 leaf | 1 mid) per launch
   int tail_lds_f = 0, tail_lds_b = 0;
-  int nt_leaf = 64, nt_mid = 256, nt_tail = 512, ustage = 0;
+  int nt_leaf = 64, nt_mid = 128, nt_tail = 512, nt_ftail = 256, ustage = 0;
   // front tables (front_plan.hpp); empty when the plan has none (front_why says why)
   bool front = false;
   std::string front_why;
@@ -511,7 +513,7 @@ inline int chol_symbolic(const SymIn& in, CholOpts opt, CholHost& out) {
   if (opt.order_mul < 0 || opt.order_add < 0) { opt.order_mul = B >= 32 ? 1.5 : 2.0; opt.order_add = B >= 32 ? 2 : 4; }
   if (opt.front < 0) opt.front = B >= 32 ? 1 : 0;
   out = CholHost();
-  out.B = B; out.nt_leaf = opt.nt_leaf; out.nt_mid = opt.nt_mid; out.nt_tail = opt.nt_tail; out.ustage = opt.ustage;
+  out.B = B; out.nt_leaf = opt.nt_leaf; out.nt_mid = opt.nt_mid; out.nt_tail = opt.nt_tail; out.nt_ftail = opt.nt_ftail; out.ustage = opt.ustage;
   auto row_dim = [&](int r) { return r < nPr ? 6 : 3; };
   auto row_xoff = [&](int r) { return r < nPr ? 6 * r : 6 * nPr + 3 * (r - nPr); };
   // adjacency of the block graph in CSR form (rows: pose rows, then landmark rows), every edge with the offset of its block in H: three
@@ -1197,7 +1199,7 @@ inline int chol_symbolic(const SymIn& in, CholOpts opt, CholHost& out) {
     front_build(FrontIn{ncol, npiece, ncomp, bp, brow, boff, bsrc, bfmt, col_comp, col_piece, col_dim, col_xoff, col_yoff, col_il, comp_parent, comp_R}, out.piece, out.ilv, F);
     // the kernels keep the diagonal blocks of a level in registers of 8-lane teams, up to two columns per team (front_kernels.hpp)
     for (int p = 0; p < npiece && F.ok; ++p) {
-      const int nt = piece_tail[p] ? opt.nt_tail : (piece_cls[p] == 1 ? opt.nt_mid : opt.nt_leaf);
+      const int nt = piece_tail[p] ? (opt.nt_tail == 1024 ? 1024 : opt.nt_ftail) : (piece_cls[p] == 1 ? opt.nt_mid : opt.nt_leaf);   // the workgroup k_front_* runs the piece with
       for (int l = 0; l < out.piece[p].nilv; ++l) {
         const ILevel& lv = out.ilv[out.piece[p].ilv0 + l];
         if (lv.c1 - lv.c0 > 2 * (nt / 8)) { F.ok = false; F.why = "a level of a piece has more columns than the workgroup's teams hold"; break; }

@@ -288,21 +288,30 @@ __device__ __forceinline__ void front_piece(const BatchView& V, const CholView& 
     if (tid < npar * 6) apply(sMulti[n1 + tid / 6], tid % 6, m2, m2y);
     __syncthreads();
     if (n2 > npar || nmore > 0) {
-      if (tid < 6)
-        for (int e = n1 + npar; e < n1 + n2 + nmore; ++e) {
-          const uint2 me = sMulti[e];
-          const uint4 bm = sBlk[me.x & 0xFFFF];
-          const int di = ((bm.w >> 16) & 1) ? 6 : 3, dj = ((bm.w >> 17) & 1) ? 6 : 3;
-          const int rw = min(tid, di - 1);
-          const FrontChild cc = front_child(sB, sChild, (int)(sB[kFrontHdr + kFrontComp * (bm.w & 255) + 4] & 0xFFFF) + (int)(me.x >> 16));
-          const double* pu = U + front_child_block(cc, me.y & 255, (me.y >> 8) & 255, di) + rw * dj;
-          double u[6];
+      // what is left, a chunk of NT / 6 sources at a time, one (source, row) per thread: the loads of a chunk travel together (ONE trip to HBM per
+      // chunk -- the lists of the upper leaf depths and of the mid pieces ran to dozens of dependent trips by six lanes); a block has at most one
+      // source of every rank and the list is sorted by rank, so the ranks of a chunk are applied one after the other: list order per block
+      constexpr int CH = NT / 6;
+      const int eend = n1 + n2 + nmore;
+      for (int e0 = n1 + npar; e0 < eend; e0 += CH) {
+        const int e = e0 + tid / 6, row = tid % 6;
+        const bool have = tid < CH * 6 && e < eend;
+        const uint2 me = sMulti[have ? e : e0];
+        const uint4 bm = sBlk[me.x & 0xFFFF];
+        const int di = ((bm.w >> 16) & 1) ? 6 : 3, dj = ((bm.w >> 17) & 1) ? 6 : 3;
+        const int rw = min(row, di - 1);
+        const FrontChild cc = front_child(sB, sChild, (int)(sB[kFrontHdr + kFrontComp * (bm.w & 255) + 4] & 0xFFFF) + (int)(me.x >> 16));
+        const double* pu = U + front_child_block(cc, me.y & 255, (me.y >> 8) & 255, di) + rw * dj;
+        double u[6];
 #pragma unroll
-          for (int c = 0; c < 6; ++c) u[c] = pu[min(c, dj - 1)];
-          const double uy = U[cc.ubase + cc.usize + 6 * (int)(me.y & 255) + rw];
-          apply(me, tid, u, uy);
+        for (int c = 0; c < 6; ++c) u[c] = pu[min(c, dj - 1)];
+        const double uy = U[cc.ubase + cc.usize + 6 * (int)(me.y & 255) + rw];
+        const int r0 = (int)(sMulti[e0].y >> 16), r1 = (int)(sMulti[min(e0 + CH, eend) - 1].y >> 16), myr = (int)(me.y >> 16);
+        for (int r = r0; r <= r1; ++r) {
+          if (have && myr == r) apply(me, row, u, uy);
+          __syncthreads();
         }
-      __syncthreads();
+      }
     }
   }
   SSLAM_FSTAMP(2)

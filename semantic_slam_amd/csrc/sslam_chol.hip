@@ -88,7 +88,7 @@ struct CholPlan {
   std::vector<int> plv_lds_ff;  // front kernels (front_kernels.hpp): LDS doubles per launch; front: the per-depth launches run them
   int tail_lds_ff = 0;
   bool front = false;
-  int tail_lds_f = 0, tail_lds_b = 0, tail_total = 0, nt_tail = 512, nt_leaf = 64, ustage = 0;
+  int tail_lds_f = 0, tail_lds_b = 0, tail_total = 0, nt_tail = 512, nt_ftail = 256, nt_leaf = 64, ustage = 0;
   std::vector<void*> allocs;
   DevArena* arena = nullptr;    // the owning batch's arena (single-graph handles), else hipMalloc
   int64_t lnz = 0, unz = 0;
@@ -1726,7 +1726,7 @@ int chol_plan_build(Batch& b) {
   CholView& C = P->C;
   C.ncol = H.ncol; C.nlevels = H.nlevels; C.dim = H.dim; C.npiece = H.npiece;
   P->lvl_ptr = H.lvl_ptr; P->plv_ptr = H.plv_ptr; P->plv_lds_f = H.plv_lds_f; P->plv_lds_b = H.plv_lds_b; P->plv_nt = H.plv_nt; P->plv_cls = H.plv_cls;
-  P->tail_lds_f = H.tail_lds_f; P->tail_lds_b = H.tail_lds_b; P->tail_total = (int)H.tail_pieces.size(); P->nt_tail = H.nt_tail; P->nt_leaf = H.nt_leaf; P->ustage = H.ustage;
+  P->tail_lds_f = H.tail_lds_f; P->tail_lds_b = H.tail_lds_b; P->tail_total = (int)H.tail_pieces.size(); P->nt_tail = H.nt_tail; P->nt_ftail = H.nt_ftail; P->nt_leaf = H.nt_leaf; P->ustage = H.ustage;
   P->lnz = H.lnz;
   {   // elimination-tree parents (first block below the diagonal) and the vertex -> column map, for the path marginals
     std::vector<int> yoff_col(H.dim + 1, -1);
@@ -1858,7 +1858,7 @@ int chol_plan_build(Batch& b) {
                            (const void*)k_front_pieces<512, false>, (const void*)k_front_pieces<1024, false>,
                            (const void*)k_front_pieces<64, true>, (const void*)k_front_pieces<128, true>, (const void*)k_front_pieces<256, true>,
                            (const void*)k_front_pieces<512, true>, (const void*)k_front_pieces<1024, true>,
-                           (const void*)k_front_tail<512>, (const void*)k_front_tail<1024>};
+                           (const void*)k_front_tail<128>, (const void*)k_front_tail<256>, (const void*)k_front_tail<512>, (const void*)k_front_tail<1024>};
       for (const void* f : fns) SSLAM_HIP_TRY(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, v));
       done.push_back(b.device);
     }
@@ -2220,7 +2220,10 @@ int chol_factor_and_forward(Batch& b, bool flat) {
     const int n = P.compact ? P.c_ptr[nplv + 1] - P.c_ptr[nplv] : b.V.B;
     const int* idx = P.compact ? P.d_idx + P.c_ptr[nplv] : nullptr;
     if (n > 0 && P.front) {
-      if (P.nt_tail == 1024) hipLaunchKernelGGL(k_front_tail<1024>, dim3(n), dim3(1024), (size_t)P.tail_lds_ff * sizeof(double), b.stream, b.V, C, idx);
+      const int ntf = P.nt_tail == 1024 ? 1024 : P.nt_ftail;
+      if (ntf == 1024) hipLaunchKernelGGL(k_front_tail<1024>, dim3(n), dim3(1024), (size_t)P.tail_lds_ff * sizeof(double), b.stream, b.V, C, idx);
+      else if (ntf == 128) hipLaunchKernelGGL(k_front_tail<128>, dim3(n), dim3(128), (size_t)P.tail_lds_ff * sizeof(double), b.stream, b.V, C, idx);
+      else if (ntf == 256) hipLaunchKernelGGL(k_front_tail<256>, dim3(n), dim3(256), (size_t)P.tail_lds_ff * sizeof(double), b.stream, b.V, C, idx);
       else hipLaunchKernelGGL(k_front_tail<512>, dim3(n), dim3(512), (size_t)P.tail_lds_ff * sizeof(double), b.stream, b.V, C, idx);
     } else if (n > 0) {
       if (P.nt_tail == 1024) hipLaunchKernelGGL(k_chol_tail<1024>, dim3(n), dim3(1024), (size_t)P.tail_lds_f * sizeof(double), b.stream, b.V, C, idx);
