@@ -160,6 +160,7 @@ struct CholOpts {
                            // (a piece's phases hold a few hundred lanes of work at most; every further wave adds its share of the barriers and idle passes)
   int nt_ftail = 256;      // workgroup of k_front_tail (the front tables do not depend on it): 128 | 256 | 512 | 1024; tail launch 1.12 / 0.84 / 1.13 ms at 128 / 256 / 512
   int pcap_mid = 16;
+  int nt_bleaf = 0, nt_bmid = 0, nt_btail = 0;   // workgroups of the backward-substitution launches (0: those of the factorisation; the kernels do not depend on the cut)
   int nt_leaf = -1, nt_tail = 512;    // workgroup sizes the items are cut for; nt_leaf -1: 128 for batches >= 32 (groups of pieces, below), else 64
   int min_chunk = 4;       // a list of <= min_chunk updates is never split
   int split_min = 4096;    // a depth with at least this many pieces is launched in up to four parts, by LDS need
@@ -221,7 +222,7 @@ struct CholOpts {
       const int iv = atoi(v.c_str());
       if (k == "cap_leaf") cap_leaf = iv; else if (k == "cap_mid") cap_mid = iv; else if (k == "cap_tail") cap_tail = iv;
       else if (k == "max_blocks") max_blocks = iv; else if (k == "tail_width") tail_width = iv; else if (k == "mid_width") mid_width = iv;
-      else if (k == "nt_leaf") { nt_leaf = iv; nt_leaf_set = true; } else if (k == "nt_mid") nt_mid = iv; else if (k == "nt_ftail") nt_ftail = iv; else if (k == "nt_tail") nt_tail = iv;
+      else if (k == "nt_leaf") { nt_leaf = iv; nt_leaf_set = true; } else if (k == "nt_mid") nt_mid = iv; else if (k == "nt_ftail") nt_ftail = iv; else if (k == "nt_bleaf") nt_bleaf = iv; else if (k == "nt_bmid") nt_bmid = iv; else if (k == "nt_btail") nt_btail = iv; else if (k == "nt_tail") nt_tail = iv;
       else if (k == "min_chunk") min_chunk = std::max(1, iv); else if (k == "split_min") split_min = std::max(2, iv);
       else if (k == "pcap_leaf") pcap_leaf = iv; else if (k == "pcap_mid") pcap_mid = iv; else if (k == "pcap_tail") pcap_tail = iv;
       else if (k == "group_cap") group_cap = iv; else if (k == "group_blocks") group_blocks = iv; else if (k == "ustage") ustage = iv;
@@ -263,7 +264,7 @@ struct CholHost {
   std::vector<int> plv_lds_f, plv_lds_b;    // LDS doubles per launch (factor / backward)
   std::vector<int> plv_nt, plv_cls;         // workgroup size (nt_leaf | nt_mid) and class (0 leaf | 1 mid) per launch
   int tail_lds_f = 0, tail_lds_b = 0;
-  int nt_leaf = 64, nt_mid = 128, nt_tail = 512, nt_ftail = 256, ustage = 0;
+  int nt_leaf = 64, nt_mid = 128, nt_tail = 512, nt_ftail = 256, nt_bleaf = 0, nt_bmid = 0, nt_btail = 0, ustage = 0;
   // front tables (front_plan.hpp); empty when the plan has none (front_why says why)
   bool front = false;
   std::string front_why;
@@ -513,7 +514,7 @@ inline int chol_symbolic(const SymIn& in, CholOpts opt, CholHost& out) {
   if (opt.order_mul < 0 || opt.order_add < 0) { opt.order_mul = B >= 32 ? 1.5 : 2.0; opt.order_add = B >= 32 ? 2 : 4; }
   if (opt.front < 0) opt.front = B >= 32 ? 1 : 0;
   out = CholHost();
-  out.B = B; out.nt_leaf = opt.nt_leaf; out.nt_mid = opt.nt_mid; out.nt_tail = opt.nt_tail; out.nt_ftail = opt.nt_ftail; out.ustage = opt.ustage;
+  out.B = B; out.nt_leaf = opt.nt_leaf; out.nt_mid = opt.nt_mid; out.nt_tail = opt.nt_tail; out.nt_ftail = opt.nt_ftail; out.nt_bleaf = opt.nt_bleaf; out.nt_bmid = opt.nt_bmid; out.nt_btail = opt.nt_btail; out.ustage = opt.ustage;
   auto row_dim = [&](int r) { return r < nPr ? 6 : 3; };
   auto row_xoff = [&](int r) { return r < nPr ? 6 * r : 6 * nPr + 3 * (r - nPr); };
   // adjacency of the block graph in CSR form (rows: pose rows, then landmark rows), every edge with the offset of its block in H: three

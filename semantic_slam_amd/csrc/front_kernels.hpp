@@ -23,6 +23,7 @@ struct FrontComp {
   unsigned long long p6;
   const uint2* bt;                 // own boundary table
   unsigned long long* rw;          // [NR] columns that hold local row r
+  unsigned long long* cmask;       // [NR] children (the first 64) whose boundary holds local row r
   unsigned short* map;             // [nc][NR] local L offset of block (row r, column k)
   unsigned short* ycol;            // [nc] local y offset of column k
   unsigned char* trow;             // [T] boundary row << 1 | tile row
@@ -37,6 +38,7 @@ __device__ __forceinline__ FrontComp front_comp(const unsigned* sB, unsigned cha
   c.bt = reinterpret_cast<const uint2*>(sB + W0.w);
   unsigned char* d = sD + W1.w;
   c.rw = reinterpret_cast<unsigned long long*>(d); d += 8 * c.NR;
+  c.cmask = reinterpret_cast<unsigned long long*>(d); d += 8 * c.NR;
   c.map = reinterpret_cast<unsigned short*>(d); d += front_pad8(2 * c.nc * c.NR);
   c.ycol = reinterpret_cast<unsigned short*>(d); d += front_pad8(2 * c.nc);
   c.trow = d; d += front_pad8(c.T);
@@ -115,8 +117,6 @@ __device__ __forceinline__ void front_piece(const BatchView& V, const CholView& 
   __syncthreads();
   if (!in_trial) return;
   SSLAM_FSTAMP(0)
-  const int skip = C.skip;
-  if (skip & 64) return;
   const unsigned h0 = sB[0], h1 = sB[1], h2 = sB[2];
   const int ncomp = h0 & 255, nlv = (h0 >> 8) & 255, nchild = h0 >> 16, nc = h1 & 0xFFFF, nb = h1 >> 16;
   const uint2* sMulti = reinterpret_cast<const uint2*>(sB + sB[8]);
@@ -167,6 +167,7 @@ __device__ __forceinline__ void front_piece(const BatchView& V, const CholView& 
           if (q < 0 || q >= (int)(h[2] & 255)) continue;
           const FrontComp cp = front_comp(sB, sD, (h[2] >> 8) & 255);
           cp.inv[(h[2] >> 16) * cp.NR + (w.x & 255)] = (unsigned char)(q + 1);
+          if ((h[2] >> 16) < 64) atomicOr(&cp.cmask[w.x & 255], 1ull << (h[2] >> 16));
         }
       }
     }
@@ -271,7 +272,6 @@ __device__ __forceinline__ void front_piece(const BatchView& V, const CholView& 
   }
   __syncthreads();
   SSLAM_FSTAMP(1)
-  if (skip & 128) return;
   if (n2 + nmore > 0) {
     // further child sources, in list order: the second ones (loaded above) now that the first are in LDS, one (block, row) per thread; what does
     // not fit a pass, and third and later sources (rare), one source after the other by the first lanes of the workgroup
@@ -320,7 +320,7 @@ __device__ __forceinline__ void front_piece(const BatchView& V, const CholView& 
     const unsigned* lv = sLv + kFrontLv * il;
     const int t0 = (int)lv[1], t1 = (int)lv[2];
     // 2a. target tiles: one lane per 3 x 3 tile, its sources from the row masks (left-looking: the groups of leaf pieces)
-    if (!RIGHT && t1 > t0 && !(skip & 2)) {
+    if (!RIGHT && t1 > t0) {
       for (int t = t0 + tid; t < t1; t += NT) {
         const unsigned e = sTile[t];
         const int tr = (e >> 1) & 1, tc = e & 1;
@@ -363,7 +363,7 @@ __device__ __forceinline__ void front_piece(const BatchView& V, const CholView& 
 #pragma unroll
     for (int r2 = 0; r2 < kKeep; ++r2) {
       const int cc = team + r2 * teams;
-      if (cc < ncl && !(skip & 4)) {
+      if (cc < ncl) {
         const uint4 col = sCol[c0 + cc];
         const int dj = ((col.y >> 16) & 1) ? 6 : 3;
         const double* Sd = smL + (col.x & 0xFFFF);
@@ -422,7 +422,7 @@ __device__ __forceinline__ void front_piece(const BatchView& V, const CholView& 
     // 2c. right-looking (mid and tail pieces: chains of columns): a finished column updates every later block of its piece at once, all tile
     //     pairs in parallel, one tile update deep; one column per round (two columns of a level may meet in a target).  The pairs (p >= q) of the
     //     column's off-diagonal blocks with block q's row inside the piece are enumerated by arithmetic: 4 lanes per pair, one per 3 x 3 tile.
-    if (RIGHT && !(skip & 8)) {
+    if (RIGHT) {
       for (int c = c0; c < c0 + ncl; ++c) {
         const uint4 col = sCol[c];
         const int cb0 = col.w & 0x3FFF, m = (int)((col.w >> 14) & 255) - 1, mi = (int)(col.w >> 22);
@@ -469,7 +469,7 @@ __device__ __forceinline__ void front_piece(const BatchView& V, const CholView& 
   __syncthreads();   // (the last level's diagonal blocks are in LDS before the final store)
   // ---- 3. the update matrices: dense lower triangles over the boundary rows, one lane per 3 x 3 tile: own updates out of LDS + the
   //         children's blocks through their relative indices -> HBM
-  if (!(skip & 16)) {
+  {
     const unsigned cwl = sB[kFrontHdr + kFrontComp * (ncomp - 1) + 4], Tl = (sB[kFrontHdr + kFrontComp * (ncomp - 1)] >> 16) & 255;
     const int ntile = (int)(cwl >> 16) + (int)(Tl * (Tl + 1) / 2);
     for (int t = tid; t < ntile; t += NT) {
@@ -491,10 +491,14 @@ __device__ __forceinline__ void front_piece(const BatchView& V, const CholView& 
       int f = -1;
       {
         int qa = 0, qb = 0;
-        for (int ch = 0; ch < cp.nch; ++ch) {
-          const int a = cp.inv[ch * cp.NR + li], c2 = cp.inv[ch * cp.NR + lj];
-          if (a && c2) { f = ch; qa = a - 1; qb = c2 - 1; break; }
-        }
+        // the children that hold both rows: the AND of two masks (a component with more than 64 children scans the rest)
+        unsigned long long cm = cp.cmask[li] & cp.cmask[lj];
+        if (cm) { f = __builtin_ctzll(cm); qa = cp.inv[f * cp.NR + li] - 1; qb = cp.inv[f * cp.NR + lj] - 1; }
+        else
+          for (int ch = 64; ch < cp.nch; ++ch) {
+            const int a = cp.inv[ch * cp.NR + li], c2 = cp.inv[ch * cp.NR + lj];
+            if (a && c2) { f = ch; qa = a - 1; qb = c2 - 1; break; }
+          }
         const FrontChild cc = front_child(sB, sChild, min(cp.child0 + max(f, 0), max(nchild - 1, 0)));
         const double* o = U + (f >= 0 ? front_child_block(cc, qa, qb, di) : 0);
 #pragma unroll
@@ -518,7 +522,13 @@ __device__ __forceinline__ void front_piece(const BatchView& V, const CholView& 
 #pragma unroll
           for (int k = 0; k < 3; ++k) accy[k] += c0y[k];
         }
+        unsigned long long cm = f < 63 ? (cp.cmask[li] & cp.cmask[lj]) >> (f + 1) << (f + 1) : 0ull;   // the children after f that hold both rows
         for (int ch = f + 1; ch < cp.nch; ++ch) {
+          if (ch < 64) {
+            if (!cm) { ch = 63; continue; }
+            ch = __builtin_ctzll(cm);
+            cm &= cm - 1;
+          }
           const int a = cp.inv[ch * cp.NR + li], c2 = cp.inv[ch * cp.NR + lj];
           if (!(a && c2)) continue;
           const FrontChild cc = front_child(sB, sChild, cp.child0 + ch);
@@ -548,7 +558,6 @@ __device__ __forceinline__ void front_piece(const BatchView& V, const CholView& 
   }
   SSLAM_FSTAMP(5)
   // ---- 4. one coalesced stream out (the layouts of chol_piece)
-  if (skip & 32) return;
   if (C.flat_L) {
     D2* dst = reinterpret_cast<D2*>(C.Lval + pm.lbase);
     const D2* src = reinterpret_cast<const D2*>(smL);

@@ -65,10 +65,11 @@ constexpr int kFrontMaxRows = 64, kFrontMaxCols = 256, kFrontMaxComps = 255, kFr
 SSLAM_HD_INLINE int front_blk_doubles(int di, int dj) { return (di * dj + 1) & ~1; }
 // offset of block (a, b), b <= a, inside an update matrix: rowbase[a] + what the blocks (a, 0 .. b-1) take
 SSLAM_HD_INLINE int front_u_offset(int rowbase_a, int di, int n6_b, int n3_b) { return rowbase_a + n6_b * 6 * di + n3_b * (di == 6 ? 18 : 10); }
-// derived tables of a component in LDS (bytes): [row masks 8 NR | (column, row) -> L offset map 2 nc NR | y offsets 2 nc | tile rows T | child row maps nchild NR]
+// derived tables of a component in LDS (bytes): [row masks 8 NR | child masks 8 NR (the children whose boundary holds local row r; the first 64 children) |
+//   (column, row) -> L offset map 2 nc NR | y offsets 2 nc | tile rows T | child row maps nchild NR]
 SSLAM_HD_INLINE int front_pad8(int x) { return (x + 7) & ~7; }
 SSLAM_HD_INLINE int front_derived_bytes(int nc, int NR, int T, int nchild) {
-  return 8 * NR + front_pad8(2 * nc * NR) + front_pad8(2 * nc) + front_pad8(T) + front_pad8(nchild * NR);
+  return 16 * NR + front_pad8(2 * nc * NR) + front_pad8(2 * nc) + front_pad8(T) + front_pad8(nchild * NR);
 }
 
 struct FrontIn {

@@ -57,7 +57,6 @@ struct CholView {
   const unsigned* fblob;    // front tables (front_plan.hpp): the blobs, and per launch-order piece where its blob is; nullptr: record plan only
   const FrontGrp* lfgrp;
   int flat_L;               // 1: the factor is written in flat form (multi right-hand-side kernels); 0: class-interleaved (LM loop)
-  int skip;                 // EXPERIMENT (SSLAM_CHOL_SKIP): phases left out, timing only
   long long* dbg;           // SSLAM_CHOL_STAMPS: shader-clock totals per phase of workgroup 0 ([16] tail kernel, [16] per-depth kernels)
 };
 
@@ -88,7 +87,7 @@ struct CholPlan {
   std::vector<int> plv_lds_ff;  // front kernels (front_kernels.hpp): LDS doubles per launch; front: the per-depth launches run them
   int tail_lds_ff = 0;
   bool front = false;
-  int tail_lds_f = 0, tail_lds_b = 0, tail_total = 0, nt_tail = 512, nt_ftail = 256, nt_leaf = 64, ustage = 0;
+  int tail_lds_f = 0, tail_lds_b = 0, tail_total = 0, nt_tail = 512, nt_ftail = 256, nt_bleaf = 0, nt_bmid = 0, nt_btail = 0, nt_leaf = 64, ustage = 0;
   std::vector<void*> allocs;
   DevArena* arena = nullptr;    // the owning batch's arena (single-graph handles), else hipMalloc
   int64_t lnz = 0, unz = 0;
@@ -1726,7 +1725,7 @@ int chol_plan_build(Batch& b) {
   CholView& C = P->C;
   C.ncol = H.ncol; C.nlevels = H.nlevels; C.dim = H.dim; C.npiece = H.npiece;
   P->lvl_ptr = H.lvl_ptr; P->plv_ptr = H.plv_ptr; P->plv_lds_f = H.plv_lds_f; P->plv_lds_b = H.plv_lds_b; P->plv_nt = H.plv_nt; P->plv_cls = H.plv_cls;
-  P->tail_lds_f = H.tail_lds_f; P->tail_lds_b = H.tail_lds_b; P->tail_total = (int)H.tail_pieces.size(); P->nt_tail = H.nt_tail; P->nt_ftail = H.nt_ftail; P->nt_leaf = H.nt_leaf; P->ustage = H.ustage;
+  P->tail_lds_f = H.tail_lds_f; P->tail_lds_b = H.tail_lds_b; P->tail_total = (int)H.tail_pieces.size(); P->nt_tail = H.nt_tail; P->nt_ftail = H.nt_ftail; P->nt_bleaf = H.nt_bleaf; P->nt_bmid = H.nt_bmid; P->nt_btail = H.nt_btail; P->nt_leaf = H.nt_leaf; P->ustage = H.ustage;
   P->lnz = H.lnz;
   {   // elimination-tree parents (first block below the diagonal) and the vertex -> column map, for the path marginals
     std::vector<int> yoff_col(H.dim + 1, -1);
@@ -1815,7 +1814,6 @@ int chol_plan_build(Batch& b) {
   C.fail = (int*)p;
   SSLAM_HIP_TRY(hipMemsetAsync(C.fail, 0, std::max(b.V.B, 1) * sizeof(int), b.stream));
   C.dbg = nullptr;
-  C.skip = getenv("SSLAM_CHOL_SKIP") ? atoi(getenv("SSLAM_CHOL_SKIP")) : 0;
   C.flat_L = 0;
   if (getenv("SSLAM_CHOL_STAMPS")) {
     if ((rc = plan_alloc(&p, 64 * sizeof(long long)))) return rc;
@@ -1851,7 +1849,7 @@ int chol_plan_build(Batch& b) {
                            (const void*)k_chol_pieces<128, false, true>, (const void*)k_chol_pieces<256, false, true>, (const void*)k_chol_pieces<512, false, true>,
                            (const void*)k_chol_tail<512>, (const void*)k_chol_tail<1024>,
                            (const void*)k_chol_back_pieces<64>, (const void*)k_chol_back_pieces<128>, (const void*)k_chol_back_pieces<256>,
-                           (const void*)k_chol_back_pieces<512>, (const void*)k_chol_back_pieces<1024>, (const void*)k_chol_back_tail<512>,
+                           (const void*)k_chol_back_pieces<512>, (const void*)k_chol_back_pieces<1024>, (const void*)k_chol_back_tail<128>, (const void*)k_chol_back_tail<256>, (const void*)k_chol_back_tail<512>,
                            (const void*)k_chol_flow<512, true>, (const void*)k_chol_flow<512, false>,
                            (const void*)k_chol_spec_round<512, true>, (const void*)k_chol_spec_round<512, false>,
                            (const void*)k_front_pieces<64, false>, (const void*)k_front_pieces<128, false>, (const void*)k_front_pieces<256, false>,
@@ -2245,7 +2243,10 @@ int chol_backward(Batch& b) {
   if (P.tail_total > 0) {
     const int n = P.compact ? P.c_ptr[nplv + 1] - P.c_ptr[nplv] : b.V.B;
     const int* idx = P.compact ? P.d_idx + P.c_ptr[nplv] : nullptr;
-    if (n > 0) hipLaunchKernelGGL(k_chol_back_tail<512>, dim3(n), dim3(512), (size_t)P.tail_lds_b * sizeof(double), b.stream, C, (const double*)C.y, b.V.x, (const LmState*)b.V.lm, idx);
+    const int ntb = P.nt_btail == 128 || P.nt_btail == 256 ? P.nt_btail : 512;
+    if (n > 0 && ntb == 128) hipLaunchKernelGGL(k_chol_back_tail<128>, dim3(n), dim3(128), (size_t)P.tail_lds_b * sizeof(double), b.stream, C, (const double*)C.y, b.V.x, (const LmState*)b.V.lm, idx);
+    else if (n > 0 && ntb == 256) hipLaunchKernelGGL(k_chol_back_tail<256>, dim3(n), dim3(256), (size_t)P.tail_lds_b * sizeof(double), b.stream, C, (const double*)C.y, b.V.x, (const LmState*)b.V.lm, idx);
+    else if (n > 0) hipLaunchKernelGGL(k_chol_back_tail<512>, dim3(n), dim3(512), (size_t)P.tail_lds_b * sizeof(double), b.stream, C, (const double*)C.y, b.V.x, (const LmState*)b.V.lm, idx);
   }
   for (int l = nplv - 1; l >= 0; --l) {
     const int n = P.compact ? P.c_ptr[l + 1] - P.c_ptr[l] : P.plv_ptr[l + 1] - P.plv_ptr[l];
@@ -2253,7 +2254,8 @@ int chol_backward(Batch& b) {
     const int* idx = P.compact ? P.d_idx + P.c_ptr[l] : nullptr;
     const size_t lds = (size_t)P.plv_lds_b[l] * sizeof(double);
 #define SSLAM_LAUNCH_BACK(NTV) hipLaunchKernelGGL(k_chol_back_pieces<NTV>, dim3(n), dim3(NTV), lds, b.stream, C, P.plv_ptr[l], (const double*)C.y, b.V.x, (const LmState*)b.V.lm, idx);
-    switch (P.plv_nt[l]) {
+    const int ovr = P.plv_cls[l] == 1 ? P.nt_bmid : P.nt_bleaf;
+    switch (ovr > 0 ? ovr : P.plv_nt[l]) {
       case 128: SSLAM_LAUNCH_BACK(128) break;
       case 512: SSLAM_LAUNCH_BACK(512) break;
       case 1024: SSLAM_LAUNCH_BACK(1024) break;

@@ -196,7 +196,7 @@ def test_mid_class_pieces_between_the_bottom_and_the_tail(hip_lib):
     # a launch holds pieces of one class, and its workgroup size is that class's
     for l in range(len(p1.plv_ptr) - 1):
         cls = p1.piece["pad5"][p1.plv_pieces[p1.plv_ptr[l]:p1.plv_ptr[l + 1]]]
-        assert np.all(cls == p1.plv_cls[l]) and p1.plv_nt[l] == (256 if p1.plv_cls[l] else 64)
+        assert np.all(cls == p1.plv_cls[l]) and p1.plv_nt[l] == (128 if p1.plv_cls[l] else 64)   # (mid pieces: 128 threads since round 6)
     assert p1.piece["nc"][mid].mean() > p0.piece["nc"][p0.piece["pad5"] == 0].mean()
     _structure_invariants(p1)
     _check(p1, H1, b1, 1e-3)
@@ -220,7 +220,7 @@ def test_multi_graph_batch_plan_with_groups_mid_and_tail(hip_lib):
     finally:
         os.environ.pop("SSLAM_CHOL_OPTS")
     cls = plan.piece["pad5"]
-    assert (cls == 0).sum() >= 6 and (cls == 1).sum() >= 6 and (cls == 2).sum() >= 6 and set(plan.plv_nt) == {128, 256}
+    assert (cls == 0).sum() >= 6 and (cls == 1).sum() >= 6 and (cls == 2).sum() >= 6 and set(plan.plv_nt) == {128}   # (leaf groups and, since round 6, mid pieces: 128 threads)
     for p in range(plan.npiece):     # every column of a piece (group) belongs to the piece's graph
         pm = plan.piece[p]
         assert np.all(plan.col["graph"][pm["c0"]:pm["c0"] + pm["nc"]] == pm["graph"])
