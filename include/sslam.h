@@ -106,7 +106,12 @@ int sslam_graph_hessian_index(sslam_graph* g, int id);
  * BASELINE.json north_star).  SOLVER 2 IS S-SCALE ONLY: its preconditioner is block-Jacobi, and on a long pose chain with the reference's
  * odometry information (1 / 0.00001 on the rotation block against 2.5 on a landmark, config/bucket_detector.yaml:22-27) the reduced
  * system needs ~1,050 CG iterations per damping trial at 5000 poses (157 ms, against 1.5 ms for the direct solver) -- it converges to the
- * same optimum (tests: S config) but is not a solver for the L configuration; use 1.  (3, the window-plan Cholesky of round 3 -- register-resident sliding
+ * same optimum (tests: S config, and since round 6 three LM iterations of the L config against the oracle) but is not a solver for the
+ * L configuration; use 1.  Round 6 measured what the missing preconditioner would buy (tools/pcg_preconditioner_experiment.py, the L graph's
+ * reduced system at g2o's first lambda, relative residual 1e-10): block-Jacobi 801 CG iterations, the EXACT block-tridiagonal factor of
+ * the odometry chain 111, wider bands (2-16 blocks) 111-112 -- what is left is the coupling of poses on different laps through shared
+ * landmarks.  A tridiagonal solve is two sequential sweeps over 5000 blocks per CG iteration: ~110 x 1.5 ms per trial on one wave per
+ * graph, slower than the 157 ms it would replace, and still above the 100 iterations asked for -> not built; decision closed.  (3, the window-plan Cholesky of round 3 -- register-resident sliding
  * fronts, VALU and FP64-MFMA updates; correct, leaner in traffic, 2-2.7x slower -- was removed from the library in round 5; DESIGN.md
  * section 5 keeps its measurements.)  "pcg_tol" relative residual; "pcg_max_iters";
  * "robust_kernel_dcs" = phi > 0: g2o::RobustKernelDCS(delta = phi) on every landmark edge (EdgeSE3PointXYZ / EdgeSE3Plane), as
