@@ -66,6 +66,9 @@ struct BatchView {
   double* Hll_off;                     // [nLL][9], block (row a < row b) = sum over its edges of -Omega
   // H
   double* Hpp_diag; double* Hll_diag; double* Hpp_off; double* Hpl; double* bvec;
+  // plane landmarks (round 6): error and central-difference Jacobians of every EdgeSE3Plane, evaluated ONCE per linearisation by
+  // k_plane_jacobians (a thread per (edge, perturbation)) -- [nEl][30] = {e 3 | J_l 3x3 | J_i 3x6}; nullptr when the batch has no plane
+  double* pj;
   int64_t h_total;  // doubles in the H allocation
   // row adjacency for SpMV (rows = pose rows then landmark rows)
   const int* adj_ptr; const int* adj_blk; const int* adj_x; const unsigned char* adj_fmt;

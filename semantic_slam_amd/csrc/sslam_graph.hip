@@ -69,6 +69,64 @@ __device__ __forceinline__ Pose load_pose16(const double* a, int idx) {   // fou
   return Pose{{v0.a, v0.b, v1.a}, {v1.b, v2.a, v2.b, v3.a}};
 }
 
+// EdgeSE3Plane (reference include/g2o/edge_se3_plane.hpp:8-48; g2o's BaseBinaryEdge numeric Jacobian: central differences, delta 1e-9): 19
+// evaluations of the error per edge -- the error itself, +/- delta on the six components of the pose and on the three of the plane -- each ~900
+// FP64 instructions (four atan2, two sincos pairs).  Until round 6 the pose row's thread did all 19 for every plane slot (at one wave per SIMD:
+// the kernel holds 304 VGPRs) and the landmark row's lanes the 7 of the plane side again: 15.6 ms per 512-graph build against 2.1 ms with
+// point landmarks.  Now a thread per (edge, evaluation): twenty lanes per edge (lane 0 the error, lane 1 idle, lanes 2 + 2 d / 3 + 2 d the
+// + / - evaluations of component d; a pair sits in neighbouring lanes and meets through one shuffle), full occupancy, every evaluation done
+// once; the row kernels read the 30 doubles.  Same functions on the same inputs: the values the row kernels used to compute themselves.
+constexpr int kPjDoubles = 30;   // {e 3 | J_l 3 x 3 row-major | J_i 3 x 6 row-major}
+__global__ __launch_bounds__(256) void k_plane_jacobians(BatchView V) {
+  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+  const long long e64 = t / 20;
+  const int j = (int)(t - e64 * 20);
+  const bool in = e64 < V.nEl;
+  const int e = in ? (int)e64 : 0;
+  const int pi = V.el_p[e], li = V.el_l[e];
+  bool live = in && V.lm_kind[li] == VT_PLANE && j != 1;
+  if (live) {
+    const int pr = V.pose_row[pi], lr = V.lm_row[li];
+    const int g = pr >= 0 ? V.prow_graph[pr] : (lr >= 0 ? V.lrow_graph[lr] : -1);
+    live = g >= 0 && V.lm[g].lin;
+  }
+  double err[3] = {0, 0, 0};
+  if (live) {
+    const size_t n = (size_t)V.nEl;
+    Pose Xi = load_pose(V.pose, pi);
+    const double* lp = V.lmk + (size_t)li * 4;
+    Plane pw{{lp[0], lp[1], lp[2]}, lp[3]};
+    const Plane z{{V.el_z[0 * n + e], V.el_z[1 * n + e], V.el_z[2 * n + e]}, V.el_z[3 * n + e]};
+    const double delta = 1e-9;
+    if (j >= 2) {
+      const int d = (j - 2) >> 1;
+      const double sd = (j & 1) ? -delta : delta;
+      if (d < 6) {
+        double dv[6] = {0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int q = 0; q < 6; ++q) dv[q] = q == d ? sd : 0.0;
+        Xi = se3_oplus(Xi, dv);
+      } else {
+        double d3[3];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) d3[q] = q == d - 6 ? sd : 0.0;
+        pw = pl_oplus(pw, d3);
+      }
+    }
+    plane_error(Xi, pw, z, err);
+  }
+  // the - evaluation of a pair sits one lane up (t even <-> t + 1: twenty lanes per edge, an even number of lanes per wave)
+  const double m0 = __shfl_down(err[0], 1, 64), m1 = __shfl_down(err[1], 1, 64), m2 = __shfl_down(err[2], 1, 64);
+  if (!live || (j & 1)) return;
+  double* o = V.pj + (size_t)e * kPjDoubles;
+  if (j == 0) { o[0] = err[0]; o[1] = err[1]; o[2] = err[2]; return; }
+  const double scalar = 1.0 / (2 * 1e-9);
+  const int d = (j - 2) >> 1;
+  const double c0 = scalar * (err[0] - m0), c1 = scalar * (err[1] - m1), c2 = scalar * (err[2] - m2);
+  if (d < 6) { o[12 + d] = c0; o[18 + d] = c1; o[24 + d] = c2; }
+  else { o[3 + d - 6] = c0; o[6 + d - 6] = c1; o[9 + d - 6] = c2; }
+}
+
 // Pose-row kernel: every slot (incident edge) of a row evaluated by the row's own thread, contributions summed in slot order.
 // What rounds 2-4 built and measured against it -- all correct, none faster, all removed from the library in round 5 (DESIGN.md section 5
 // keeps the numbers): a hand-over form that evaluates a chain edge once (1.97 vs 2.00 ms per 512-graph build, but it adds the handed block
@@ -235,10 +293,17 @@ __global__ __launch_bounds__(kRowThreads, 1) void k_linearize_rowthread(BatchVie
         point_jacobians(L, Ji, Jl);
         err[0] = L.e[0]; err[1] = L.e[1]; err[2] = L.e[2];
       } else {
-        const Plane pw{{lp[0], lp[1], lp[2]}, lp[3]};
-        const Plane z{{zl(0), zl(1), zl(2)}, zl(3)};
-        plane_error(Xi, pw, z, err);
-        plane_jacobians(Xi, pw, z, Ji, Jl);
+        // error and both Jacobians from k_plane_jacobians (fifteen 16-byte loads instead of nineteen evaluations)
+        const D2* pj = reinterpret_cast<const D2*>(V.pj + (size_t)e * kPjDoubles);
+        double v[kPjDoubles];
+#pragma unroll
+        for (int q = 0; q < kPjDoubles / 2; ++q) { const D2 w = pj[q]; v[2 * q] = w.a; v[2 * q + 1] = w.b; }
+#pragma unroll
+        for (int q = 0; q < 3; ++q) err[q] = v[q];
+#pragma unroll
+        for (int q = 0; q < 9; ++q) Jl[q] = v[3 + q];
+#pragma unroll
+        for (int q = 0; q < 18; ++q) Ji[q] = v[12 + q];
       }
       double W[9];
       load_sym3(V.el_w, n, e, W);
@@ -324,21 +389,11 @@ __global__ __launch_bounds__(256) void k_linearize_lm_rows(BatchView V) {
 #pragma unroll
           for (int c = 0; c < 3; ++c) Jl[a * 3 + c] = L.R.m[c * 3 + a];
       } else {
-        const Plane pw{{lp[0], lp[1], lp[2]}, lp[3]};
-        const Plane z{{V.el_z[0 * (size_t)n + e], V.el_z[1 * (size_t)n + e], V.el_z[2 * (size_t)n + e]}, V.el_z[3 * (size_t)n + e]};
-        plane_error(Xi, pw, z, err);
-        const double delta = 1e-9, scalar = 1.0 / (2 * delta);
+        const double* pj = V.pj + (size_t)e * kPjDoubles;   // from k_plane_jacobians: {e | J_l | ...}
 #pragma unroll
-        for (int d = 0; d < 3; ++d) {
-          double d3[3], ep[3], em[3];
+        for (int q = 0; q < 3; ++q) err[q] = pj[q];
 #pragma unroll
-          for (int q = 0; q < 3; ++q) d3[q] = q == d ? delta : 0.0;
-          plane_error(Xi, pl_oplus(pw, d3), z, ep);
-#pragma unroll
-          for (int q = 0; q < 3; ++q) d3[q] = q == d ? -delta : 0.0;
-          plane_error(Xi, pl_oplus(pw, d3), z, em);
-          Jl[0 * 3 + d] = scalar * (ep[0] - em[0]); Jl[1 * 3 + d] = scalar * (ep[1] - em[1]); Jl[2 * 3 + d] = scalar * (ep[2] - em[2]);
-        }
+        for (int q = 0; q < 9; ++q) Jl[q] = pj[3 + q];
       }
       double W[9];
       load_sym3(V.el_w, n, e, W);
@@ -1196,6 +1251,8 @@ static int batch_build(Batch& b, bool host_only = false) {
   V.Hpp_diag = H; V.Hll_diag = H + b.hll_base; V.Hpp_off = H + b.hpp_off_base; V.Hpl = H + b.hpl_base; V.Hll_off = H + b.hll_off_base;
   V.bvec = H + h_even;
   b.hb_doubles = (int64_t)(h_even + dim);
+  V.pj = nullptr;
+  if (b.has_planes && (rc = dev_alloc(b, (size_t)std::max(nEl, 1) * kPjDoubles, &V.pj))) return rc;
   if ((rc = dev_alloc(b, (size_t)V.nPose * 8, &V.pose))) return rc;
   if ((rc = dev_alloc(b, (size_t)V.nPose * 8, &V.pose_trial))) return rc;
   if ((rc = dev_alloc(b, (size_t)V.nLm * 4, &V.lmk))) return rc;
@@ -1302,6 +1359,7 @@ static int batch_linearize(Batch& b) {
   const int nblk = (V.nPr + kRowThreads - 1) / kRowThreads;
 #define SSLAM_LAUNCH_LIN(PLV, SHV)                                                                                                    \
   {                                                                                                                                   \
+    if (PLV && V.nEl > 0) hipLaunchKernelGGL(k_plane_jacobians, dim3((unsigned)(((long long)V.nEl * 20 + 255) / 256)), dim3(256), 0, b.stream, V);   \
     if (V.nPr > 0) hipLaunchKernelGGL((k_linearize_rowthread<PLV, SHV>), dim3(nblk), dim3(kRowThreads), 0, b.stream, V);               \
     if (V.nLr > 0) hipLaunchKernelGGL((k_linearize_lm_rows<PLV, SHV>), dim3((V.nLr + 15) / 16), dim3(256), 0, b.stream, V);            \
     if (V.nLL > 0) hipLaunchKernelGGL((k_linearize_ll<SHV>), dim3((V.nLL + 63) / 64), dim3(64), 0, b.stream, V);                       \
