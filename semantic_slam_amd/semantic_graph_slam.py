@@ -157,6 +157,16 @@ class SemanticGraphSLAM:
         if rc < 0:
             raise SslamError(rc, self._lib.sslam_last_error().decode())
 
+    def set_graph_option(self, key: str, value: float) -> None:
+        """an option of the orchestrator's graph handle (sslam_graph_set_option through sslam_slam_graph): e.g. "speculative_trials" 0 for
+        several robots sharing one GPU (ten speculative lanes fill the device; the plain single-launch solve takes a tenth of it)"""
+        lib = self._lib
+        lib.sslam_graph_set_option.restype = C.c_int
+        lib.sslam_graph_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_double]
+        rc = lib.sslam_graph_set_option(lib.sslam_slam_graph(self._h), key.encode(), float(value))
+        if rc < 0:
+            raise SslamError(rc, lib.sslam_last_error().decode())
+
     def num_edges(self) -> int:
         return int(self._lib.sslam_graph_num_edges(self._lib.sslam_slam_graph(self._h)))
 
