@@ -433,8 +433,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=int(os.environ.get("SSLAM_BENCH_BATCH", "512")),
-                    help="independent graphs resident per GPU (512 x ~10 MB of H + 7.5 MB of L each: far beyond the 256 MiB MALL)")
+    ap.add_argument("--batch", type=int, default=int(os.environ.get("SSLAM_BENCH_BATCH", "1024")),
+                    help="independent graphs resident per GPU (~30 MB each: H, L, update matrices, tables -- 30 GB of the 288, far beyond the 256 MiB MALL).  "
+                         "Round 6: 1024 (rounds 1-5: 512) -- the top of the elimination tree is latency-bound with one workgroup per graph, and twice the graphs "
+                         "hide it better: 45.6 k vs 43.4 k it/s on one box; 2048: 37.0 k")
     ap.add_argument("--poses", type=int, default=5000)
     ap.add_argument("--landmarks", type=int, default=1000)
     ap.add_argument("--distinct", type=int, default=-1, help="distinct seeds generated per rank (tiled to --batch); -1 = one per graph of the batch")
@@ -444,7 +446,7 @@ def main():
     ap.add_argument("--streams", type=int, default=4,
                     help="stream group of the timed region (sslam_batch_create_streams): the batch split into this many parts, each on its own "
                          "HIP stream + host thread; <= 1: one batch-synchronous batch.  The kernel rooflines always come from a single-stream pass")
-    ap.add_argument("--plane-batch", type=int, default=512, help="graphs in the plane-landmark leg (0 = skip)")
+    ap.add_argument("--plane-batch", type=int, default=1024, help="graphs in the plane-landmark leg (0 = skip)")
     ap.add_argument("--edge-sharded", action="store_true",
                     help="N > 1: every rank holds the SAME batch, builds the partial normal equations of its edge shard and the ranks "
                          "all-reduce [H || b] over RCCL each LM step (SURVEY 8e mode E / BASELINE.json configs[4]); strong scaling")
@@ -574,11 +576,11 @@ def main():
                 "frac": round(jac_gbs / PEAK_HBM_GBS, 4), "traffic": None, "measured_in": "single-stream pass of the same steps (hipEvents per kernel group)",
                 "bytes_per_launch": jac_bytes, "graph_builds_in_region": int(iters_total), "ms_in_region": round(lin_ms, 3), "launches": lin_n,
                 "full_batch": {"ms_per_launch": round(full_lin_ms, 5), "achieved": round(jac_bytes / (full_lin_ms * 1e-3) / 1e9, 2),
-                               "frac": round(jac_bytes / (full_lin_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)}}
+                               "frac": round(jac_bytes / (full_lin_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4), "ms_per_512_graphs": round(full_lin_ms * 512 / args.batch, 5)}}
     t, raw, src = pmc_traffic("jacobian_build", jac_bytes)
     if t is not None:
         roof_jac.update({"traffic": t, "traffic_raw_counters": raw, "traffic_source": src,
-                         "traffic_kind": "static: the committed rocprofv3 PMC passes over one launch of the same 512-graph workload, not collected in this run"})
+                         "traffic_kind": f"static: the committed rocprofv3 PMC passes over one launch of the same {args.batch}-graph workload, not collected in this run"})
     roofline = roof_jac
     roof_factor = None
     if ktimes["factor"][1] > 0:
@@ -591,13 +593,14 @@ def main():
                        "measured_in": "single-stream pass of the same steps (hipEvents per kernel group)", "bytes_per_launch": fbytes, "graph_factorisations_in_region": trials_total, "ms_in_region": round(ktimes["factor"][0], 3),
                        "launches": ktimes["factor"][1],
                        "full_batch": {"ms_per_launch": round(full_f_ms, 4), "achieved": round(fbytes / (full_f_ms * 1e-3) / 1e9, 2),
-                                      "frac": round(fbytes / (full_f_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4), "backward_solve_ms": round(full_s_ms, 4)},
+                                      "frac": round(fbytes / (full_f_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4), "backward_solve_ms": round(full_s_ms, 4),
+                                      "ms_per_512_graphs": round(full_f_ms * 512 / args.batch, 4), "backward_solve_ms_per_512_graphs": round(full_s_ms * 512 / args.batch, 4)},
                        "levels": int(batch.info("factor_levels")), "factor_doubles": int(batch.info("factor_lnz")),
                        "note": "algorithmic bytes = read H, b once + write L, y once per graph factorisation"}
         t, raw, src = pmc_traffic("factor", fbytes)
         if t is not None:
             roof_factor.update({"traffic": t, "traffic_raw_counters": raw, "traffic_source": src,
-                                "traffic_kind": "static: the committed rocprofv3 PMC passes over one launch of the same 512-graph workload, not collected in this run"})
+                                "traffic_kind": f"static: the committed rocprofv3 PMC passes over one launch of the same {args.batch}-graph workload, not collected in this run"})
         if dominant == "factor":
             roofline = roof_factor
     if dominant == "spmv" and ktimes["spmv"][1] > 0:

@@ -9,6 +9,7 @@ cd /tmp && export TMPDIR=/tmp
 SECTIONS="${*:-tests bench stats pmc frontend trace}"
 has() { [[ " $SECTIONS " == *" $1 "* ]]; }
 DRV="--gpus 1 --steps 20 --warmup 5"
+NB=${NB:-1024}   # graphs of the bench batch (bench.py --batch default): the PMC passes and the launch trace run the same batch
 if has tests; then
   python -m pytest $R/tests -m gpu -q > $O/r6_pytest_gpu.txt 2>&1; tail -3 $O/r6_pytest_gpu.txt
 fi
@@ -26,11 +27,11 @@ if has pmc; then
   BJ=$O/r6_bench.json; [ -f $BJ ] || BJ=$R/profiles/r6_bench.json     # (a run without the bench section: the committed line)
   FB=$(python -c "import json;print(json.load(open('$BJ'))['roofline_factor']['bytes_per_launch'])")
   JB=$(python -c "import json;print(json.load(open('$BJ'))['roofline_jacobian_build']['bytes_per_launch'])")
-  # PMC traffic: one full-batch factorisation / Jacobian build of the SAME 512 distinct graphs (tools/pmc_workload.py), separate passes
+  # PMC traffic: one full-batch factorisation / Jacobian build of the SAME $NB distinct graphs (tools/pmc_workload.py), separate passes
   # PMC_WHAT="factor" or "jacobian" restricts the passes to one of the two
   for w in ${PMC_WHAT:-factor jacobian}; do
     for c in FETCH_SIZE WRITE_SIZE; do
-      rocprofv3 --pmc $c --output-format csv -d $O/pmc_${w}_$c -- python $R/tools/pmc_workload.py 512 $w > /dev/null 2>&1
+      rocprofv3 --pmc $c --output-format csv -d $O/pmc_${w}_$c -- python $R/tools/pmc_workload.py $NB $w > /dev/null 2>&1
     done
     if [ $w = factor ]; then
       python $R/tools/pmc_traffic.py $O/pmc_factor_FETCH_SIZE $O/pmc_factor_WRITE_SIZE $O/r6_pmc_factor.json $FB 0 k_front_tail k_front_pieces k_chol_tail k_chol_pieces k_chol_begin k_chol_end
@@ -47,11 +48,11 @@ if has frontend; then
   rm -rf $O/fstats
 fi
 if has trace; then
-  # per-launch trace of one LM step of the 512-graph batch (which launches the factorisation is made of and what each takes)
-  rm -rf $O/_p512
-  rocprofv3 --kernel-trace --output-format csv -d $O/_p512 -- python $R/tools/prof_opt.py 512 2 > /dev/null 2>&1
-  python $R/tools/level_profile.py $O/_p512 > $O/r6_factor_launch_trace_512.txt; rm -rf $O/_p512
-  head -20 $O/r6_factor_launch_trace_512.txt | cut -c1-120
+  # per-launch trace of one LM step of the batch (which launches the factorisation is made of and what each takes)
+  rm -rf $O/_ptr
+  rocprofv3 --kernel-trace --output-format csv -d $O/_ptr -- python $R/tools/prof_opt.py $NB 2 > /dev/null 2>&1
+  python $R/tools/level_profile.py $O/_ptr > $O/r6_factor_launch_trace_$NB.txt; rm -rf $O/_ptr
+  head -20 $O/r6_factor_launch_trace_$NB.txt | cut -c1-120
 fi
 if has tick; then
   # kernel stats of the 110-keyframe tick replay (no CPU baseline inside the profiled process)
