@@ -73,23 +73,29 @@ __device__ __forceinline__ Pose load_pose16(const double* a, int idx) {   // fou
 // evaluations of the error per edge -- the error itself, +/- delta on the six components of the pose and on the three of the plane -- each ~900
 // FP64 instructions (four atan2, two sincos pairs).  Until round 6 the pose row's thread did all 19 for every plane slot (at one wave per SIMD:
 // the kernel holds 304 VGPRs) and the landmark row's lanes the 7 of the plane side again: 15.6 ms per 512-graph build against 2.1 ms with
-// point landmarks.  Now a thread per (edge, evaluation): twenty lanes per edge (lane 0 the error, lane 1 idle, lanes 2 + 2 d / 3 + 2 d the
-// + / - evaluations of component d; a pair sits in neighbouring lanes and meets through one shuffle), full occupancy, every evaluation done
-// once; the row kernels read the 30 doubles.  Same functions on the same inputs: the values the row kernels used to compute themselves.
+// point landmarks.  Now a thread per (edge, evaluation) -- a pair of + / - evaluations sits in neighbouring lanes and meets through one shuffle --,
+// full occupancy, every evaluation done once; the row kernels read the 30 doubles.  Same functions on the same inputs: the values the row kernels used to compute themselves.
 constexpr int kPjDoubles = 30;   // {e 3 | J_l 3 x 3 row-major | J_i 3 x 6 row-major}
-__global__ __launch_bounds__(256) void k_plane_jacobians(BatchView V) {
-  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
-  const long long e64 = t / 20;
-  const int j = (int)(t - e64 * 20);
+// Two regions of workgroups so that a wave runs ONE of the two perturbation paths (se3_oplus / pl_oplus: ~150 / ~300 instructions next to the
+// ~400 of the error itself; mixed in one wave both were paid by every lane: 4.84 -> 3.5 ms per 512 graphs): blocks [0, blocksA) hold fourteen
+// lanes per edge -- lane 0 the error, lane 1 idle, lanes 2 + 2 d / 3 + 2 d the + / - evaluations of pose component d --, the blocks behind them
+// six lanes per edge, the + / - evaluations of the three plane components.  A pair sits in neighbouring lanes (even lane counts per edge).
+__global__ __launch_bounds__(256) void k_plane_jacobians(BatchView V, int blocksA) {
+  const bool regA = (int)blockIdx.x < blocksA;
+  const int per = regA ? 14 : 6;
+  const long long t = (long long)(regA ? blockIdx.x : blockIdx.x - blocksA) * 256 + threadIdx.x;
+  const long long e64 = t / per;
+  const int j = (int)(t - e64 * per);
   const bool in = e64 < V.nEl;
   const int e = in ? (int)e64 : 0;
   const int pi = V.el_p[e], li = V.el_l[e];
-  bool live = in && V.lm_kind[li] == VT_PLANE && j != 1;
+  bool live = in && V.lm_kind[li] == VT_PLANE && !(regA && j == 1);
   if (live) {
     const int pr = V.pose_row[pi], lr = V.lm_row[li];
     const int g = pr >= 0 ? V.prow_graph[pr] : (lr >= 0 ? V.lrow_graph[lr] : -1);
     live = g >= 0 && V.lm[g].lin;
   }
+  const double delta = 1e-9;
   double err[3] = {0, 0, 0};
   if (live) {
     const size_t n = (size_t)V.nEl;
@@ -97,34 +103,33 @@ __global__ __launch_bounds__(256) void k_plane_jacobians(BatchView V) {
     const double* lp = V.lmk + (size_t)li * 4;
     Plane pw{{lp[0], lp[1], lp[2]}, lp[3]};
     const Plane z{{V.el_z[0 * n + e], V.el_z[1 * n + e], V.el_z[2 * n + e]}, V.el_z[3 * n + e]};
-    const double delta = 1e-9;
-    if (j >= 2) {
-      const int d = (j - 2) >> 1;
-      const double sd = (j & 1) ? -delta : delta;
-      if (d < 6) {
-        double dv[6] = {0, 0, 0, 0, 0, 0};
+    const double sd = (j & 1) ? -delta : delta;
+    if (regA) {
+      if (j >= 2) {
+        const int d = (j - 2) >> 1;
+        double dv[6];
 #pragma unroll
         for (int q = 0; q < 6; ++q) dv[q] = q == d ? sd : 0.0;
         Xi = se3_oplus(Xi, dv);
-      } else {
-        double d3[3];
-#pragma unroll
-        for (int q = 0; q < 3; ++q) d3[q] = q == d - 6 ? sd : 0.0;
-        pw = pl_oplus(pw, d3);
       }
+    } else {
+      const int d = j >> 1;
+      double d3[3];
+#pragma unroll
+      for (int q = 0; q < 3; ++q) d3[q] = q == d ? sd : 0.0;
+      pw = pl_oplus(pw, d3);
     }
     plane_error(Xi, pw, z, err);
   }
-  // the - evaluation of a pair sits one lane up (t even <-> t + 1: twenty lanes per edge, an even number of lanes per wave)
+  // the - evaluation of a pair sits one lane up
   const double m0 = __shfl_down(err[0], 1, 64), m1 = __shfl_down(err[1], 1, 64), m2 = __shfl_down(err[2], 1, 64);
   if (!live || (j & 1)) return;
   double* o = V.pj + (size_t)e * kPjDoubles;
-  if (j == 0) { o[0] = err[0]; o[1] = err[1]; o[2] = err[2]; return; }
-  const double scalar = 1.0 / (2 * 1e-9);
-  const int d = (j - 2) >> 1;
+  if (regA && j == 0) { o[0] = err[0]; o[1] = err[1]; o[2] = err[2]; return; }
+  const double scalar = 1.0 / (2 * delta);
   const double c0 = scalar * (err[0] - m0), c1 = scalar * (err[1] - m1), c2 = scalar * (err[2] - m2);
-  if (d < 6) { o[12 + d] = c0; o[18 + d] = c1; o[24 + d] = c2; }
-  else { o[3 + d - 6] = c0; o[6 + d - 6] = c1; o[9 + d - 6] = c2; }
+  if (regA) { const int d = (j - 2) >> 1; o[12 + d] = c0; o[18 + d] = c1; o[24 + d] = c2; }
+  else { const int d = j >> 1; o[3 + d] = c0; o[6 + d] = c1; o[9 + d] = c2; }
 }
 
 // Pose-row kernel: every slot (incident edge) of a row evaluated by the row's own thread, contributions summed in slot order.
@@ -1359,7 +1364,10 @@ static int batch_linearize(Batch& b) {
   const int nblk = (V.nPr + kRowThreads - 1) / kRowThreads;
 #define SSLAM_LAUNCH_LIN(PLV, SHV)                                                                                                    \
   {                                                                                                                                   \
-    if (PLV && V.nEl > 0) hipLaunchKernelGGL(k_plane_jacobians, dim3((unsigned)(((long long)V.nEl * 20 + 255) / 256)), dim3(256), 0, b.stream, V);   \
+    if (PLV && V.nEl > 0) {                                                                                                           \
+      const long long bA = ((long long)V.nEl * 14 + 255) / 256, bB = ((long long)V.nEl * 6 + 255) / 256;                                \
+      hipLaunchKernelGGL(k_plane_jacobians, dim3((unsigned)(bA + bB)), dim3(256), 0, b.stream, V, (int)bA);                              \
+    }                                                                                                                                 \
     if (V.nPr > 0) hipLaunchKernelGGL((k_linearize_rowthread<PLV, SHV>), dim3(nblk), dim3(kRowThreads), 0, b.stream, V);               \
     if (V.nLr > 0) hipLaunchKernelGGL((k_linearize_lm_rows<PLV, SHV>), dim3((V.nLr + 15) / 16), dim3(256), 0, b.stream, V);            \
     if (V.nLL > 0) hipLaunchKernelGGL((k_linearize_ll<SHV>), dim3((V.nLL + 63) / 64), dim3(64), 0, b.stream, V);                       \
