@@ -13,7 +13,7 @@
 //     column's rows against it, lanes 0..5 keep row r of L_jj and write it after the barrier;
 //   * mid and tail pieces (chains of columns) apply their internal updates right-looking, by source column, the pairs of a column's
 //     blocks enumerated by arithmetic.
-// Sums run in a fixed order (sources ascending, then the children in list order): bitwise repeatable.
+// Sums run in a fixed order (sources of dimension 6 ascending, then those of dimension 3, then the children in list order): bitwise repeatable.
 #pragma once
 
 namespace sslam {
@@ -56,15 +56,22 @@ __device__ __forceinline__ int front_child_block(const FrontChild& c, int qa, in
   return c.ubase + front_u_offset((int)(c.bt[qa].y & 0xFFFFFF), di, (wb >> 8) & 255, (wb >> 16) & 255);
 }
 
-// sum over the sources k of a target tile: the set bits of m, ascending
+// sum over the sources k of a target tile: the set bits of m -- first the columns of dimension 6, ascending, then those of dimension 3,
+// ascending.  (One loop over all bits with the dimension tested per source made every wave that met both kinds in one iteration pay for
+// both tile updates: the lanes of a wave walk different masks.  Two loops, each uniform in its arithmetic; the order of the sum is fixed
+// either way.)
 __device__ __forceinline__ void front_tile_sources(const FrontComp& cp, unsigned long long m, int li, int lj, int tr, int tc,
                                                    const double* __restrict__ smL, const double* __restrict__ smY, double (&acc)[9], double (&accy)[3]) {
-  while (m) {
-    const int k = __builtin_ctzll(m);
-    m &= m - 1;
-    const int ua = cp.map[k * cp.NR + li], ub = cp.map[k * cp.NR + lj], yk = cp.ycol[k];
-    if ((cp.p6 >> k) & 1) tile_update_k<6>(smL, smY, ua, ub, yk, tr, tc, acc, accy);
-    else tile_update_k<3>(smL, smY, ua, ub, yk, tr, tc, acc, accy);
+  unsigned long long m6 = m & cp.p6, m3 = m & ~cp.p6;
+  while (m6) {
+    const int k = __builtin_ctzll(m6);
+    m6 &= m6 - 1;
+    tile_update_k<6>(smL, smY, cp.map[k * cp.NR + li], cp.map[k * cp.NR + lj], cp.ycol[k], tr, tc, acc, accy);
+  }
+  while (m3) {
+    const int k = __builtin_ctzll(m3);
+    m3 &= m3 - 1;
+    tile_update_k<3>(smL, smY, cp.map[k * cp.NR + li], cp.map[k * cp.NR + lj], cp.ycol[k], tr, tc, acc, accy);
   }
 }
 

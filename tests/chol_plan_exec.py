@@ -423,17 +423,18 @@ class Plan:
         def tile_sum(cp, li, lj, di, dj, tr, tc, want_y):
             m = cp["rw"][lj] if li == lj else cp["rw"][li] & cp["rw"][lj]
             acc = np.zeros((3, 3)); accy = np.zeros(3)
-            k = 0
-            while m >> k:
-                if (m >> k) & 1:
-                    dk = dim(cp, k)
-                    ua, ub, yk = cp["map"][(k, li)], cp["map"][(k, lj)], cp["ycol"][k]
-                    A = smL[ua:ua + di * dk].reshape(di, dk)[3 * tr:3 * tr + 3]
-                    Bm = smL[ub:ub + dj * dk].reshape(dj, dk)[3 * tc:3 * tc + 3]
-                    acc += A @ Bm.T
-                    if want_y:
-                        accy += A @ smY[yk:yk + dk]
-                k += 1
+            for want in (6, 3):     # the kernel's order: the sources of dimension 6 ascending, then those of dimension 3 (front_tile_sources)
+                k = 0
+                while m >> k:
+                    if (m >> k) & 1 and dim(cp, k) == want:
+                        dk = want
+                        ua, ub, yk = cp["map"][(k, li)], cp["map"][(k, lj)], cp["ycol"][k]
+                        A = smL[ua:ua + di * dk].reshape(di, dk)[3 * tr:3 * tr + 3]
+                        Bm = smL[ub:ub + dj * dk].reshape(dj, dk)[3 * tc:3 * tc + 3]
+                        acc += A @ Bm.T
+                        if want_y:
+                            accy += A @ smY[yk:yk + dk]
+                    k += 1
             return acc, accy, m
 
         ok = True
