@@ -363,7 +363,7 @@ __device__ __forceinline__ void front_piece(const BatchView& V, const CholView& 
     //     target tiles need not wait for them.
     const int c0 = lv[3] & 0xFFFF, ncl = (int)(lv[3] >> 16) - c0;
     int W = 8;
-    while (W < 64 && ncl * (2 * W) <= NT) W *= 2;
+    while (W < NT && ncl * (2 * W) <= NT) W *= 2;   // (a lone column's team is the whole workgroup: its rows are solved in one round)
     const int teams = NT / W, team = tid / W, lt = tid % W;
     constexpr int kKeep = 2;   // (the plan refuses levels of more than kKeep * NT / 8 columns)
     double keep[kKeep][6];
@@ -381,7 +381,7 @@ __device__ __forceinline__ void front_piece(const BatchView& V, const CholView& 
 #pragma unroll
           for (int c = 0; c <= r; ++c) a[r * 6 + c] = (r < dj) ? Sd[r * dj + c] : (r == c ? 1.0 : 0.0);
 #pragma unroll
-        for (int c = 0; c < 6; ++c) tv[c] = c < dj ? py[c] : 0.0;
+        for (int c = 0; c < 6; ++c) tv[c] = (c < dj && lt < 64) ? py[c] : 0.0;   // (a team may span waves: only its first wave -- the one that writes y -- reads it)
         const bool ok = front_factor6(a, tv, inv);
         if (!ok && lt == 0) C.fail[g] = 1;
 #pragma unroll
