@@ -83,7 +83,9 @@ int sslam_graph_add_edge_se3(sslam_graph* g, int i, int j, const double z_tq[7],
  * "robust_kernel_dcs" asks for the one it names (g2o::RobustKernelDCS). */
 int sslam_graph_add_edge_se3_point(sslam_graph* g, int i, int l, const double z[3], const double info[9]);
 /* add_se3_plane_edge (commented out, graph_slam.hpp:73-75) -> g2o::EdgeSE3Plane
- * (reference include/g2o/edge_se3_plane.hpp:8-48; numeric Jacobian). */
+ * (reference include/g2o/edge_se3_plane.hpp:8-48; numeric Jacobian: g2o's central differences, delta 1e-9 -- evaluated on the device once per
+ * edge and linearisation by k_plane_jacobians, a thread per evaluation (round 6); the plane rotation is formed from the normal's components
+ * instead of through its two angles: the same matrix to an ulp). */
 int sslam_graph_add_edge_se3_plane(sslam_graph* g, int i, int l, const double z[4], const double info[9]);
 
 /* add_point_xyz_point_xyz_edge (graph_slam.cpp:168-180): g2o::EdgePointXYZ between two VertexPointXYZ, e = (p2 - p1) - z.  Declared and
