@@ -188,3 +188,35 @@ def test_tick_parity_through_the_frontend(gpu_lib):
         _compare_state(P, Or)
     assert ticks >= 20 and kfs >= 20 and with_planes >= 40 and len(Or.assoc.landmarks) >= 3
     assert seg.last_overflow() == (0, 0, 0)
+
+
+def test_three_robots_on_one_gpu_equal_their_solo_replays(gpu_lib):
+    """Round 6: several orchestrator handles on one GPU (persistent launches share the device by a budget; the handles' graphs run the
+    plain single-launch solve, `speculative_trials` 0, so that their launches overlap).  Three robots replaying different runs concurrently,
+    one host thread each, end with the keyframes, landmarks and estimates -- bit for bit -- that each reaches alone."""
+    import threading
+    from semantic_slam_amd.synth import make_replay
+    runs = [make_replay(seed, n_samples=220, n_landmarks=24)[0] for seed in (3, 5, 8)]
+
+    def replay(events, out, k):
+        S = product_instance()
+        S.set_graph_option("speculative_trials", 0)
+        ticks = 0
+        for ev in events:
+            _, ran = feed(S, ev, True)
+            ticks += int(ran)
+        ids, est = S.getKeyframes()
+        out[k] = (ticks, ids.copy(), est.copy(), [(l.id, l.vertex, tuple(l.pose)) for l in S.getMappedLandmarks()])
+
+    solo = [None] * len(runs)
+    for k, ev in enumerate(runs):
+        replay(ev, solo, k)
+    assert all(s[0] >= 5 and len(s[1]) >= 10 for s in solo)
+    for rep in range(2):
+        conc = [None] * len(runs)
+        th = [threading.Thread(target=replay, args=(ev, conc, k)) for k, ev in enumerate(runs)]
+        for t in th: t.start()
+        for t in th: t.join()
+        for a, b in zip(solo, conc):
+            assert b is not None and a[0] == b[0] and a[3] == b[3]
+            assert np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
