@@ -355,9 +355,9 @@ __device__ __forceinline__ void front_piece(const BatchView& V, const CholView& 
       __syncthreads();
       SSLAM_FSTAMP(3)
     }
-    // 2b. a team of W lanes per column of the level (W: 8 .. 64, the widest that still gives every column its team).  Every lane reads the
+    // 2b. a team of W lanes per column of the level (W: 8 .. NT, the widest that still gives every column its team; a lone column: the whole workgroup).  Every lane reads the
     //     diagonal block S_jj (lower triangle) and the rhs out of LDS and factors the block ITSELF in registers; lane r < 6 of the team owns
-    //     row r of L_jj and y_r (y goes to LDS at once: the team sits in one wave, its reads precede its writes); then the lanes solve the
+    //     row r of L_jj and y_r (y goes to LDS at once: only the team's first wave reads y, and its reads precede its writes); then the lanes solve the
     //     column's off-diagonal rows against the factor, x L_jj^T = v, W rows at a time.  Nothing but the rows of L_jj is written that another
     //     thread of this phase reads, and those are written AFTER the barrier; nobody but the final store reads them, so the next level's
     //     target tiles need not wait for them.
