@@ -994,6 +994,14 @@ inline int chol_symbolic(const SymIn& in, CholOpts opt, CholHost& out) {
       for (auto& r : own_flat) own_s[c3[r.blk]++] = r;
       for (auto& r : src_flat) src_s[c4[r.blk]++] = r.s;
     }
+    // the sources of a target: those of dimension 6 first, then those of dimension 3 (each ascending, as listed) -- the lanes of a wave walk
+    // different lists, and a step that meets both kinds pays for both tile updates (tile_update: one branch per kind); with the lists
+    // ordered alike the steps of a wave agree on the kind for all but the short 3-wide ends (round 6; the front kernels do the same with
+    // their masks).  Any fixed order gives a bitwise repeatable factor.
+    for (int t = 0; t < pm.nb; ++t)
+      std::stable_partition(iu_s.begin() + iu_ptr[t], iu_s.begin() + iu_ptr[t + 1], [&](const IU& u) { return col_dim[u.k] == 6; });
+    for (size_t q = 0; q < ub.size(); ++q)
+      std::stable_partition(own_s.begin() + own_ptr[q], own_s.begin() + own_ptr[q + 1], [&](const OwnRec& u) { return col_dim[u.k] == 6; });
     // assembly records, block order
     pm.as0 = (int)out.asrc.size();
     for (int t = pm.b0; t < pm.b0 + pm.nb; ++t) {
