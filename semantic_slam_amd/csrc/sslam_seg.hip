@@ -2305,8 +2305,8 @@ static int seg_enqueue(sslam_seg* s, const sslam_frame* frames, int n_frames, in
     {
       // band rows: as many as fit next to the (w+1) x 10 double carry row in ~150 KiB of LDS (<= 64 lanes)
       const size_t carry = (size_t)(maxw + 1) * 10 * sizeof(double);
-      // (a call with more boxes than CUs takes 24-row bands: three boxes per CU instead of one)
-      const size_t row_cap = nb > 512 ? 24 : 64;
+      // (a call with more boxes than CUs takes 16-row bands: four boxes per CU instead of one)
+      const size_t row_cap = nb > 512 ? 16 : 64;   // (1024 boxes of 128 x 96, per call: 12 / 16 / 24 / 32 / 48 / 64 rows 0.599 / 0.551 / 0.604 / 0.606 / 0.680 / 0.706 ms)
       const int ib_rows = (int)std::max<size_t>(1, std::min<size_t>(row_cap, (150 * 1024 - carry) / ((size_t)maxw * 12)));
       const size_t ilds = carry + (size_t)ib_rows * maxw * 12;
       hipLaunchKernelGGL(k_integral, dim3(nb), dim3(256), ilds, s->stream, V, ib_rows);
