@@ -147,7 +147,9 @@ struct CholOpts {
   int cap_leaf = -1;       // doubles of L per piece (pieces that share launches): small pieces, many resident per CU.  -1: 700 for batches >= 32, else 900
   int cap_tail = 4608;     // doubles of L per piece of a tail (two tail workgroups per CU must fit the LDS)
   int max_blocks = 224;    // blocks per piece
-  int tail_width = -1;     // a graph's tail starts where it has <= tail_width pieces per depth; -1: 6 for batches >= 32, else 2; 0: no tail
+  int tail_width = -1;     // a graph's tail starts where it has <= tail_width pieces per depth; -1: 2; 0: no tail.  (Rounds 3-5 took 6 for batches >= 32;
+                           // since the mid pieces run on 128 threads the depths below a short tail are cheaper in the mid class: 1024 L graphs, factor /
+                           // backward solve 12.32 / 4.40 ms at 6, 12.15 / 4.33 at 4, 12.14 / 4.29 at 3, 12.05 / 4.25 at 2, 12.13 / 4.27 at 1, 12.38 / 4.36 without a tail)
   // Mid class (round 5).  Above the bushy bottom a column has 15-25 blocks and a leaf-sized piece holds two of them: its update matrix
   // (boundary^2: 160-190 blocks) is 4-5 x its part of L, every such piece reads its children's and writes its own, and ONE wave walks
   // those ~600 tiles in ten passes of dependent HBM trips (~100 us per piece against ~20 us for a leaf piece; 53 % of all update-matrix
@@ -504,7 +506,7 @@ inline int chol_symbolic(const SymIn& in, CholOpts opt, CholHost& out) {
   using namespace chol_detail;
   SSLAM_PT_INIT
   const int nPr = in.nPr, nLr = in.nLr, nrow = nPr + nLr, B = in.B;
-  if (opt.tail_width < 0) opt.tail_width = B >= 32 ? 6 : 2;
+  if (opt.tail_width < 0) opt.tail_width = 2;
   if (opt.ustage < 0) opt.ustage = B >= 32 ? 0 : 1;
   if (opt.mid_width < 0) opt.mid_width = B >= 32 ? 60 : 0;
   if (opt.cap_leaf < 0) opt.cap_leaf = B >= 32 ? 700 : 900;
