@@ -51,6 +51,8 @@ struct BatchView {
   const int* prow_pose;  // [nPr] -> pose index
   const int* lrow_lm;    // [nLr] -> landmark index
   const int* prow_graph; // [nPr]
+  const int* prow_perm;  // [nPr] thread -> pose row of k_linearize_rowthread: the rows of a graph ordered by their slot counts (EdgeSE3 slots, then
+                         //       landmark slots), so that the lanes of a wave walk slot lists of the same shape (round 6)
   const int* lrow_graph; // [nLr]
   const unsigned char* lm_kind;  // [nLm] VT_POINT / VT_PLANE
   // edges
