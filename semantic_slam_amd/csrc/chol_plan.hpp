@@ -242,11 +242,15 @@ struct CholOpts {
 // cut for the tail's workgroup size and no mid class.  ONE place for chol_plan_build and the plan introspection of the CPU tests (round-5
 // ADVICE: the tests pinned plans cut for 64-thread pieces while the tick factored 512-thread ones).  Returns whether the plan is meant
 // for the single launch.
-inline bool chol_opts_normalise(CholOpts& opt, int B) {
+// The throughput regime (groups of leaf pieces on 128 threads, mid class, front tables) is for batches that fill the chip with independent
+// pieces: 32 graphs of any size, or four and more LARGE ones (>= 8000 block rows in the batch; round 6: four / sixteen 5000-pose graphs
+// 3.39 k -> 3.80 k / 7.75 k -> 9.62 k LM iterations/s against the plans small batches took before; one such graph keeps its 512-thread pieces).
+inline bool chol_throughput_regime(int B, int block_rows) { return B >= 32 || (B >= 4 && block_rows >= 8000); }
+inline bool chol_opts_normalise(CholOpts& opt, int B, int block_rows) {
   if (opt.nt_tail != 1024) opt.nt_tail = 512;
   if (opt.nt_leaf != -1 && opt.nt_leaf != 128 && opt.nt_leaf != 256 && opt.nt_leaf != 512 && opt.nt_leaf != 1024) opt.nt_leaf = 64;   // -1: by batch size (chol_symbolic)
   if (opt.nt_mid != 256 && opt.nt_mid != 512) opt.nt_mid = 128;
-  const bool want_flow = opt.flow != 0 && B < 8 && opt.nt_tail == 512 && opt.group_cap <= 0 && !opt.nt_leaf_set;
+  const bool want_flow = opt.flow != 0 && B < 8 && !chol_throughput_regime(B, block_rows) && opt.nt_tail == 512 && opt.group_cap <= 0 && !opt.nt_leaf_set;
   if (want_flow) { opt.nt_leaf = opt.nt_tail; opt.mid_width = 0; }
   return want_flow;
 }
@@ -507,14 +511,15 @@ inline int chol_symbolic(const SymIn& in, CholOpts opt, CholHost& out) {
   SSLAM_PT_INIT
   const int nPr = in.nPr, nLr = in.nLr, nrow = nPr + nLr, B = in.B;
   if (opt.tail_width < 0) opt.tail_width = 2;
-  if (opt.ustage < 0) opt.ustage = B >= 32 ? 0 : 1;
-  if (opt.mid_width < 0) opt.mid_width = B >= 32 ? 60 : 0;
-  if (opt.cap_leaf < 0) opt.cap_leaf = B >= 32 ? 700 : 900;
-  if (opt.group_cap < 0) opt.group_cap = B >= 32 ? 2800 : 0;
-  if (opt.nt_leaf < 0) opt.nt_leaf = B >= 32 ? 128 : 64;
+  const bool thr = chol_throughput_regime(B, nrow);
+  if (opt.ustage < 0) opt.ustage = thr ? 0 : 1;
+  if (opt.mid_width < 0) opt.mid_width = thr ? 60 : 0;
+  if (opt.cap_leaf < 0) opt.cap_leaf = thr ? 700 : 900;
+  if (opt.group_cap < 0) opt.group_cap = thr ? (B >= 32 ? 2800 : 1400) : 0;   // (a few large graphs: smaller groups, more of them)
+  if (opt.nt_leaf < 0) opt.nt_leaf = thr ? 128 : 64;
   if (opt.order < 0) opt.order = 1;
-  if (opt.order_mul < 0 || opt.order_add < 0) { opt.order_mul = B >= 32 ? 1.5 : 2.0; opt.order_add = B >= 32 ? 2 : 4; }
-  if (opt.front < 0) opt.front = B >= 32 ? 1 : 0;
+  if (opt.order_mul < 0 || opt.order_add < 0) { opt.order_mul = B >= 32 ? 1.5 : 2.0; opt.order_add = B >= 32 ? 2 : 4; }   // (a few large graphs keep the shallowest tree)
+  if (opt.front < 0) opt.front = thr ? 1 : 0;
   out = CholHost();
   out.B = B; out.nt_leaf = opt.nt_leaf; out.nt_mid = opt.nt_mid; out.nt_tail = opt.nt_tail; out.nt_ftail = opt.nt_ftail; out.nt_bleaf = opt.nt_bleaf; out.nt_bmid = opt.nt_bmid; out.nt_btail = opt.nt_btail; out.ustage = opt.ustage;
   auto row_dim = [&](int r) { return r < nPr ? 6 : 3; };

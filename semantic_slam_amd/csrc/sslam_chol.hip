@@ -1716,7 +1716,7 @@ int chol_plan_build(Batch& b) {
   // small batches (latency-bound: the orchestrator's graph, a single large graph): the dependency-driven single launch (k_chol_flow) runs
   // every piece with the tail's workgroup size (chol_opts_normalise, shared with the plan introspection of the CPU tests)
   const int flow_mode = opt.flow;   // 0 off, 1 auto, 2 also on wide trees (SSLAM_CHOL_OPTS flow=...; read per plan: tests toggle it)
-  const bool want_flow = chol_opts_normalise(opt, b.V.B);
+  const bool want_flow = chol_opts_normalise(opt, b.V.B, b.V.nPr + b.V.nLr);
   CholHost H;
   if (chol_symbolic(in, opt, H)) return set_error(SSLAM_ERR_NUMERIC, "Cholesky plan: %s", H.error.c_str());
   CholPlan* P = new CholPlan();
@@ -1786,7 +1786,7 @@ int chol_plan_build(Batch& b) {
     if ((rc = up_to_dev(*P, b.stream, H.fblob, (const uint32_t**)&C.fblob))) return rc;
     if ((rc = up_to_dev(*P, b.stream, H.lfgrp, &C.lfgrp))) return rc;
     P->front = true; P->plv_lds_ff = H.plv_lds_ff; P->tail_lds_ff = H.tail_lds_ff;
-  } else if (opt.front != 0 && b.V.B >= 32) {
+  } else if (opt.front != 0 && chol_throughput_regime(b.V.B, b.V.nPr + b.V.nLr)) {
     fprintf(stderr, "[sslam] Cholesky plan without front tables (%s): the record kernels run\n", H.front_why.c_str());
   }
   void* p = nullptr;

@@ -2478,7 +2478,7 @@ void* sslam_debug_plan_create(sslam_graph* const* graphs, int n) {
   chol_sym_input(b, in);
   CholOpts opt;
   opt.from_env();
-  chol_opts_normalise(opt, b.V.B);   // the plan chol_plan_build would execute, small-batch regime included
+  chol_opts_normalise(opt, b.V.B, b.V.nPr + b.V.nLr);   // the plan chol_plan_build would execute, small-batch regime included
   sslam_debug_plan* P = new sslam_debug_plan();
   P->h_total = b.V.h_total;
   for (auto& q : b.ppoff) { P->ppoff.push_back(q.first); P->ppoff.push_back(q.second); }
