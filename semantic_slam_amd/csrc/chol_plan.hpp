@@ -243,9 +243,10 @@ struct CholOpts {
 // ADVICE: the tests pinned plans cut for 64-thread pieces while the tick factored 512-thread ones).  Returns whether the plan is meant
 // for the single launch.
 // The throughput regime (groups of leaf pieces on 128 threads, mid class, front tables) is for batches that fill the chip with independent
-// pieces: 32 graphs of any size, or four and more LARGE ones (>= 8000 block rows in the batch; round 6: four / sixteen 5000-pose graphs
-// 3.39 k -> 3.80 k / 7.75 k -> 9.62 k LM iterations/s against the plans small batches took before; one such graph keeps its 512-thread pieces).
-inline bool chol_throughput_regime(int B, int block_rows) { return B >= 32 || (B >= 4 && block_rows >= 8000); }
+// pieces: 32 graphs of any size, or two and more LARGE ones (>= 8000 block rows in the batch; round 6: 2 / 3 / 4 / 16 5000-pose graphs
+// 1.96 k -> 2.04 k / 2.71 k -> 2.93 k / 3.39 k -> 3.81 k / 7.75 k -> 9.60 k LM iterations/s against the plans small batches took before; one such
+// graph is as fast either way and keeps its 512-thread pieces).
+inline bool chol_throughput_regime(int B, int block_rows) { return B >= 32 || (B >= 2 && block_rows >= 8000); }
 inline bool chol_opts_normalise(CholOpts& opt, int B, int block_rows) {
   if (opt.nt_tail != 1024) opt.nt_tail = 512;
   if (opt.nt_leaf != -1 && opt.nt_leaf != 128 && opt.nt_leaf != 256 && opt.nt_leaf != 512 && opt.nt_leaf != 1024) opt.nt_leaf = 64;   // -1: by batch size (chol_symbolic)
